@@ -1,0 +1,121 @@
+// Shared host/device helpers for libfv2p_ops (gfx950 only).
+//
+// Conventions used by every translation unit in csrc/:
+//  * every extern "C" entry point returns 0 on success or a negative FV2P_E* code and
+//    records a message retrievable through fv2p_last_error();
+//  * no hipMalloc/hipFree inside an op: scratch comes from the caller-provided workspace;
+//  * kernels are launched on the caller's stream, never on the legacy default stream;
+//  * wave64 everywhere (ballot masks are 64 bit).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/fv2p_ops.h"
+
+namespace fv2p {
+
+constexpr int kWave = 64;
+
+int set_error(int code, const char* fmt, ...);
+
+#define FV2P_REQUIRE(cond, code, ...)                      \
+  do {                                                     \
+    if (!(cond)) return ::fv2p::set_error((code), __VA_ARGS__); \
+  } while (0)
+
+#define FV2P_HIP(expr)                                                              \
+  do {                                                                              \
+    hipError_t e__ = (expr);                                                        \
+    if (e__ != hipSuccess)                                                          \
+      return ::fv2p::set_error(FV2P_EHIP, "%s failed: %s (%s:%d)", #expr,           \
+                               hipGetErrorString(e__), __FILE__, __LINE__);         \
+  } while (0)
+
+#define FV2P_LAUNCH_CHECK() FV2P_HIP(hipGetLastError())
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// Carves typed, 256-byte aligned regions out of the caller's workspace.
+struct Carver {
+  char* base;
+  size_t off;
+  size_t cap;
+  Carver(void* p, size_t bytes) : base(static_cast<char*>(p)), off(0), cap(bytes) {}
+  template <typename T>
+  T* take(size_t n) {
+    size_t o = align_up(off);
+    off = o + n * sizeof(T);
+    return reinterpret_cast<T*>(base + o);
+  }
+  bool ok() const { return off <= cap; }
+};
+// Same arithmetic without a buffer, for *_ws_bytes queries.
+struct Sizer {
+  size_t off = 0;
+  template <typename T>
+  void take(size_t n) { off = align_up(off) + n * sizeof(T); }
+  size_t bytes() const { return align_up(off); }
+};
+
+// ---- device-side helpers -------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ uint64_t lanemask_lt() {
+  return (1ull << (threadIdx.x & 63)) - 1ull;
+}
+
+// 64-bit mix (splitmix64 finaliser) used by every open-addressing table in the library.
+__device__ __forceinline__ uint32_t hash_u64(uint64_t k, uint32_t mask) {
+  k ^= k >> 30; k *= 0xbf58476d1ce4e5b9ull;
+  k ^= k >> 27; k *= 0x94d049bb133111ebull;
+  k ^= k >> 31;
+  return static_cast<uint32_t>(k) & mask;
+}
+
+// Packed hash slot: high 40 bits = key (flat voxel index), low 24 bits = payload (row / point id).
+constexpr int kValBits = 24;
+constexpr uint64_t kValMask = (1ull << kValBits) - 1ull;
+constexpr uint64_t kEmptySlot = ~0ull;
+constexpr int64_t kMaxRows = (1ll << kValBits) - 2;      // payload 0xFFFFFF is reserved
+constexpr int64_t kMaxKey = (1ll << 40) - 2;
+
+__device__ __forceinline__ uint64_t slot_pack(uint64_t key, uint32_t val) {
+  return (key << kValBits) | static_cast<uint64_t>(val);
+}
+__device__ __forceinline__ uint64_t slot_key(uint64_t s) { return s >> kValBits; }
+__device__ __forceinline__ uint32_t slot_val(uint64_t s) { return static_cast<uint32_t>(s & kValMask); }
+
+// Lookup in a packed table; returns payload or -1.
+__device__ __forceinline__ int table_find(const uint64_t* __restrict__ table, uint32_t mask, uint64_t key) {
+  uint32_t h = hash_u64(key, mask);
+  while (true) {
+    uint64_t s = table[h];
+    if (s == kEmptySlot) return -1;
+    if (slot_key(s) == key) return static_cast<int>(slot_val(s));
+    h = (h + 1) & mask;
+  }
+}
+
+// ---- internal primitives (sort_scan.hip) ---------------------------------------------
+size_t scan_ws_bytes(int64_t n);
+// Exclusive prefix sum of int32; in == out allowed. total (device int*, may be null) gets the sum.
+int exclusive_scan_i32(const int* in, int* out, int64_t n, int* total, void* ws, size_t ws_bytes,
+                       hipStream_t stream);
+size_t radix_sort_ws_bytes(int64_t n);
+// Stable LSD radix sort of 64-bit words on bits [bit_lo, bit_hi). Result ends in `keys`;
+// `tmp` is an n-word ping-pong buffer.
+int radix_sort_u64(uint64_t* keys, uint64_t* tmp, int64_t n, int bit_lo, int bit_hi, void* ws,
+                   size_t ws_bytes, hipStream_t stream);
+
+static inline uint32_t next_pow2(uint64_t x) {
+  uint64_t p = 1;
+  while (p < x) p <<= 1;
+  return static_cast<uint32_t>(p);
+}
+static inline int bits_for(uint64_t max_value) {  // number of bits needed to hold max_value
+  int b = 0;
+  while (max_value) { ++b; max_value >>= 1; }
+  return b < 1 ? 1 : b;
+}
+
+}  // namespace fv2p

@@ -1,0 +1,234 @@
+// Prefix-scan and LSD radix-sort primitives used by the voxeliser and the rulebook builder.
+//
+// Both are launch-structured (no inter-workgroup hand-offs inside a launch), so they carry no
+// dispatch-order assumption.  Radix passes stage their digit histograms in LDS and rank keys
+// with wavefront ballots (wave64 match-any over the 8 digit bits).
+#include "common.hpp"
+#include <stdarg.h>
+#include <stdio.h>
+
+namespace fv2p {
+
+static thread_local char g_err[512] = "";
+
+int set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+// ------------------------------------------------------------------ scan ---------------
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kScanThreads * kScanItems;  // 2048
+
+// Block-wide exclusive scan of one value per thread (256 threads); returns exclusive prefix,
+// *block_total receives the sum (valid in all threads).
+__device__ __forceinline__ int block_excl_scan_256(int v, int* lds_wave /*[4]*/, int* block_total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int t = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) lds_wave[w] = incl;
+  __syncthreads();
+  int w0 = lds_wave[0], w1 = lds_wave[1], w2 = lds_wave[2], w3 = lds_wave[3];
+  int base = (w > 0 ? w0 : 0) + (w > 1 ? w1 : 0) + (w > 2 ? w2 : 0);
+  *block_total = w0 + w1 + w2 + w3;
+  __syncthreads();
+  return base + incl - v;
+}
+
+__global__ __launch_bounds__(kScanThreads) void scan_block_sums(const int* __restrict__ in, int64_t n,
+                                                                int* __restrict__ sums) {
+  __shared__ int lds_wave[4];
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kScanTile + threadIdx.x * kScanItems;
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j) {
+    int64_t i = base + j;
+    if (i < n) s += in[i];
+  }
+  int tot;
+  block_excl_scan_256(s, lds_wave, &tot);
+  if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+// Single workgroup: exclusive scan of `m` block sums in place, total -> *total.
+__global__ __launch_bounds__(kScanThreads) void scan_sums_inplace(int* __restrict__ sums, int64_t m,
+                                                                  int* __restrict__ total) {
+  __shared__ int lds_wave[4];
+  int carry = 0;
+  for (int64_t c = 0; c < m; c += kScanThreads) {
+    int64_t i = c + threadIdx.x;
+    int v = (i < m) ? sums[i] : 0;
+    int tot;
+    int ex = block_excl_scan_256(v, lds_wave, &tot);
+    if (i < m) sums[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0 && total) *total = carry;
+}
+
+__global__ __launch_bounds__(kScanThreads) void scan_apply(const int* __restrict__ in, int* __restrict__ out,
+                                                           int64_t n, const int* __restrict__ block_off) {
+  __shared__ int lds_wave[4];
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kScanTile + threadIdx.x * kScanItems;
+  int v[kScanItems];
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j) {
+    int64_t i = base + j;
+    v[j] = (i < n) ? in[i] : 0;
+    s += v[j];
+  }
+  int tot;
+  int ex = block_excl_scan_256(s, lds_wave, &tot) + block_off[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j) {
+    int64_t i = base + j;
+    if (i < n) out[i] = ex;
+    ex += v[j];
+  }
+}
+
+size_t scan_ws_bytes(int64_t n) {
+  Sizer s;
+  s.take<int>(static_cast<size_t>(ceil_div(n > 0 ? n : 1, kScanTile)) + 1);
+  return s.bytes();
+}
+
+int exclusive_scan_i32(const int* in, int* out, int64_t n, int* total, void* ws, size_t ws_bytes,
+                       hipStream_t stream) {
+  if (n <= 0) {
+    if (total) FV2P_HIP(hipMemsetAsync(total, 0, sizeof(int), stream));
+    return 0;
+  }
+  FV2P_REQUIRE(ws_bytes >= scan_ws_bytes(n), FV2P_EWORKSPACE, "scan workspace too small");
+  Carver c(ws, ws_bytes);
+  const int64_t nb = ceil_div(n, kScanTile);
+  int* sums = c.take<int>(static_cast<size_t>(nb) + 1);
+  hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(kScanThreads), 0, stream, in, n, sums);
+  hipLaunchKernelGGL(scan_sums_inplace, dim3(1), dim3(kScanThreads), 0, stream, sums, nb, total);
+  hipLaunchKernelGGL(scan_apply, dim3(nb), dim3(kScanThreads), 0, stream, in, out, n, sums);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ radix sort ---------
+constexpr int kSortThreads = 256;
+constexpr int kSortRounds = 16;                          // keys per thread per tile
+constexpr int kSortTile = kSortThreads * kSortRounds;    // 4096 keys per workgroup
+constexpr int kRadix = 256;
+
+__global__ __launch_bounds__(kSortThreads) void radix_hist(const uint64_t* __restrict__ keys, int64_t n,
+                                                           int shift, uint32_t digit_mask, int nblk,
+                                                           int* __restrict__ hist /*[256][nblk]*/) {
+  __shared__ int lh[kRadix];
+  lh[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kSortTile;
+#pragma unroll 4
+  for (int r = 0; r < kSortRounds; ++r) {
+    int64_t i = base + r * kSortThreads + threadIdx.x;
+    if (i < n) {
+      uint32_t d = static_cast<uint32_t>(keys[i] >> shift) & digit_mask;
+      atomicAdd(&lh[d], 1);
+    }
+  }
+  __syncthreads();
+  hist[static_cast<int64_t>(threadIdx.x) * nblk + blockIdx.x] = lh[threadIdx.x];
+}
+
+__global__ __launch_bounds__(kSortThreads) void radix_scatter(const uint64_t* __restrict__ keys,
+                                                              uint64_t* __restrict__ out, int64_t n, int shift,
+                                                              uint32_t digit_mask, int nblk,
+                                                              const int* __restrict__ offs /*[256][nblk] scanned*/) {
+  __shared__ int base[kRadix];           // running output position per digit for this tile
+  __shared__ int wave_cnt[4][kRadix];    // per-round, per-wave digit counts
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  base[tid] = offs[static_cast<int64_t>(tid) * nblk + blockIdx.x];
+  const int64_t tile0 = static_cast<int64_t>(blockIdx.x) * kSortTile;
+  for (int r = 0; r < kSortRounds; ++r) {
+    const int64_t i = tile0 + r * kSortThreads + tid;
+    if (tile0 + r * kSortThreads >= n) break;  // uniform
+    // zero the per-wave counters of this round
+    wave_cnt[0][tid] = 0; wave_cnt[1][tid] = 0; wave_cnt[2][tid] = 0; wave_cnt[3][tid] = 0;
+    __syncthreads();
+    const bool valid = i < n;
+    uint64_t key = valid ? keys[i] : 0;
+    uint32_t d = static_cast<uint32_t>(key >> shift) & digit_mask;
+    // wave64 match-any on the 8 digit bits
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      uint64_t vote = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? vote : ~vote;
+    }
+    const int rank_in_wave = __popcll(peers & lanemask_lt());
+    if (valid && rank_in_wave == 0) wave_cnt[w][d] = __popcll(peers);
+    __syncthreads();
+    if (valid) {
+      int pos = base[d] + rank_in_wave;
+      for (int ww = 0; ww < w; ++ww) pos += wave_cnt[ww][d];
+      out[pos] = key;
+    }
+    __syncthreads();
+    base[tid] += wave_cnt[0][tid] + wave_cnt[1][tid] + wave_cnt[2][tid] + wave_cnt[3][tid];
+    __syncthreads();
+  }
+}
+
+size_t radix_sort_ws_bytes(int64_t n) {
+  const int64_t nblk = ceil_div(n > 0 ? n : 1, kSortTile);
+  Sizer s;
+  s.take<int>(static_cast<size_t>(kRadix * nblk));
+  s.take<char>(scan_ws_bytes(kRadix * nblk));
+  return s.bytes();
+}
+
+int radix_sort_u64(uint64_t* keys, uint64_t* tmp, int64_t n, int bit_lo, int bit_hi, void* ws,
+                   size_t ws_bytes, hipStream_t stream) {
+  if (n <= 1 || bit_hi <= bit_lo) return 0;
+  FV2P_REQUIRE(ws_bytes >= radix_sort_ws_bytes(n), FV2P_EWORKSPACE, "radix sort workspace too small");
+  const int nblk = static_cast<int>(ceil_div(n, kSortTile));
+  Carver c(ws, ws_bytes);
+  int* hist = c.take<int>(static_cast<size_t>(kRadix) * nblk);
+  size_t sws_bytes = scan_ws_bytes(static_cast<int64_t>(kRadix) * nblk);
+  char* sws = c.take<char>(sws_bytes);
+  uint64_t* src = keys;
+  uint64_t* dst = tmp;
+  for (int lo = bit_lo; lo < bit_hi; lo += 8) {
+    const int nb = (bit_hi - lo) < 8 ? (bit_hi - lo) : 8;
+    const uint32_t dm = (1u << nb) - 1u;
+    hipLaunchKernelGGL(radix_hist, dim3(nblk), dim3(kSortThreads), 0, stream, src, n, lo, dm, nblk, hist);
+    int rc = exclusive_scan_i32(hist, hist, static_cast<int64_t>(kRadix) * nblk, nullptr, sws, sws_bytes, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(radix_scatter, dim3(nblk), dim3(kSortThreads), 0, stream, src, dst, n, lo, dm, nblk, hist);
+    uint64_t* t = src; src = dst; dst = t;
+  }
+  FV2P_LAUNCH_CHECK();
+  if (src != keys) FV2P_HIP(hipMemcpyAsync(keys, src, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream));
+  return 0;
+}
+
+}  // namespace fv2p
+
+extern "C" const char* fv2p_last_error(void) { return fv2p::g_err; }
+extern "C" int fv2p_abi_version(void) { return FV2P_ABI_VERSION; }
+
+// Test hooks for the primitives (exercised by tests/test_primitives.py through the C ABI).
+extern "C" size_t fv2p_scan_ws_bytes(int64_t n) { return fv2p::scan_ws_bytes(n); }
+extern "C" int fv2p_exclusive_scan_i32(const int* in, int* out, int64_t n, int* total, void* ws,
+                                       size_t ws_bytes, void* stream) {
+  return fv2p::exclusive_scan_i32(in, out, n, total, ws, ws_bytes, static_cast<hipStream_t>(stream));
+}
+extern "C" size_t fv2p_radix_sort_ws_bytes(int64_t n) { return fv2p::radix_sort_ws_bytes(n); }
+extern "C" int fv2p_radix_sort_u64(uint64_t* keys, uint64_t* tmp, int64_t n, int bit_lo, int bit_hi,
+                                   void* ws, size_t ws_bytes, void* stream) {
+  return fv2p::radix_sort_u64(keys, tmp, n, bit_lo, bit_hi, ws, ws_bytes, static_cast<hipStream_t>(stream));
+}

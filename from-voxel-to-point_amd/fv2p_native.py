@@ -1,0 +1,158 @@
+"""ctypes binding of libfv2p_ops.so (the C ABI declared in include/fv2p_ops.h).
+
+The prototypes are parsed from the header itself so the header stays the single source of
+truth; `declared_symbols()` is what the CPU test-suite checks against the built library.
+There is no fallback of any kind: if the shared object is missing, `lib()` raises.
+PyTorch is used only as the owner of device memory and streams.
+"""
+import ctypes
+import os
+import re
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "fv2p_ops.h")
+LIB_PATH = os.path.join(_HERE, "lib", "libfv2p_ops.so")
+
+_SCALARS = {
+    "int": ctypes.c_int, "int64_t": ctypes.c_int64, "size_t": ctypes.c_size_t, "float": ctypes.c_float,
+    "double": ctypes.c_double, "uint32_t": ctypes.c_uint32, "uint64_t": ctypes.c_uint64,
+    "fv2p_stream_t": ctypes.c_void_p,
+}
+_ELEM = {"float": ctypes.c_float, "int": ctypes.c_int, "int64_t": ctypes.c_int64, "double": ctypes.c_double}
+
+
+class Proto:
+    def __init__(self, name, restype, params):
+        self.name, self.restype, self.params = name, restype, params  # params: list of (kind, ctype, n)
+
+
+def _parse_header(path=HEADER):
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", " ", src)
+    src = re.sub(r"^\s*#.*$", " ", src, flags=re.M)
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(fv2p_\w+)\s*\(([^;{}]*?)\)\s*;", src, flags=re.S):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if "typedef" in ret:
+            continue
+        if ret.endswith("*"):
+            restype = ctypes.c_char_p if "char" in ret else ctypes.c_void_p
+        else:
+            restype = _SCALARS[ret.split()[-1]]
+        params = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                arr = re.match(r"(?:const )?(\w+) \w+\[(\d+)\]$", a)
+                if arr:  # small host-side array, e.g. `const float voxel_size[3]`
+                    params.append(("hostarr", _ELEM[arr.group(1)], int(arr.group(2))))
+                elif "*" in a:
+                    params.append(("ptr", ctypes.c_void_p, 0))
+                else:
+                    t = a.split()[-2] if len(a.split()) > 1 else a
+                    params.append(("scalar", _SCALARS[t], 0))
+        protos[name] = Proto(name, restype, params)
+    return protos
+
+
+_PROTOS = None
+_LIB = None
+_LOCK = threading.Lock()
+
+
+def declared_symbols():
+    global _PROTOS
+    if _PROTOS is None:
+        _PROTOS = _parse_header()
+    return _PROTOS
+
+
+class Fv2pError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads the HIP library (after torch, so both share torch's libamdhip64) — no fallback."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    with _LOCK:
+        if _LIB is not None:
+            return _LIB
+        if not os.path.exists(LIB_PATH):
+            raise Fv2pError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for the pcdet.ops hot path.")
+        import torch  # noqa: F401  (loads libamdhip64.so.7 first so our DT_NEEDED resolves to the same runtime)
+        handle = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        for name, p in declared_symbols().items():
+            fn = getattr(handle, name)  # AttributeError here == header/library mismatch
+            fn.restype = p.restype
+            fn.argtypes = [ctypes.POINTER(c) if k == "hostarr" else c for k, c, _ in p.params]
+        if handle.fv2p_abi_version() != 1:
+            raise Fv2pError("libfv2p_ops ABI version mismatch")
+        _LIB = handle
+    return _LIB
+
+
+def last_error():
+    return lib().fv2p_last_error().decode()
+
+
+def call(name, *args):
+    """Calls an int-returning entry point, converting tensors to device pointers; raises on error."""
+    l = lib()
+    p = declared_symbols()[name]
+    if len(args) != len(p.params):
+        raise TypeError(f"{name} expects {len(p.params)} arguments, got {len(args)}")
+    conv = []
+    for (kind, ctype, n), a in zip(p.params, args):
+        if kind == "ptr":
+            conv.append(ptr(a))
+        elif kind == "hostarr":
+            vals = [a[i] for i in range(n)]
+            conv.append((ctype * n)(*vals))
+        else:
+            conv.append(a)
+    rc = getattr(l, name)(*conv)
+    if p.restype is ctypes.c_int and rc < 0:
+        raise Fv2pError(f"{name} failed ({rc}): {last_error()}")
+    return rc
+
+
+def ptr(t):
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return t
+    return t.data_ptr()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+_WS = {}
+
+
+def workspace(nbytes, device):
+    """Grow-only per-device scratch buffer (torch caching allocator owns the memory).
+
+    All library calls are issued on the caller's current stream, so reuse across consecutive
+    calls is ordered by the stream itself."""
+    import torch
+    key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise Fv2pError("fv2p ops run on the GPU only: got a CPU tensor (no CPU fallback exists)")

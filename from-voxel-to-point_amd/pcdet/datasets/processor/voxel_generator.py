@@ -1,0 +1,105 @@
+"""GPU voxeliser behind the reference's `VoxelGenerator` / `points_to_voxel` API.
+
+Mirrors pcdet/datasets/processor/voxel_generator.py:5-133 of the reference (class
+`VoxelGenerator`, function `points_to_voxel`): same constructor arguments, properties,
+return triple `(voxels [M,max_points,ndim] f32, coordinates [M,3] i32 (z,y,x), num_points [M] i32)`
+and the same first-come / max_voxels-break semantics — but the work is done by the hashed HIP
+voxeliser `fv2p_points_to_voxel` (csrc/voxelize.hip).  numpy in → numpy out (H2D/D2H around the
+kernel); CUDA tensor in → CUDA tensors out.  There is no CPU implementation here.
+
+Note for DataLoader workers: HIP cannot be initialised in a forked child of a process that
+already initialised it; voxelise in the main process (e.g. on the collated batch) or use
+`multiprocessing_context="spawn"`.
+"""
+import numpy as np
+
+from pcdet import ops as _ops  # noqa: F401  (puts fv2p_native on sys.path)
+import fv2p_native as _nat
+
+
+def _grid_size(voxel_size, coors_range):
+    # float32 arithmetic + np.round, as voxel_generator.py:22-27,104-105
+    g = (coors_range[3:] - coors_range[:3]) / voxel_size
+    return np.round(g).astype(np.int64)
+
+
+def points_to_voxel_gpu(points, voxel_size, coors_range, max_points=35, reverse_index=True, max_voxels=20000):
+    """points: CUDA float32 tensor [N, ndim>=3]. Returns CUDA tensors sliced to the voxel count."""
+    import torch
+    _nat.require_cuda(points)
+    if points.dtype != torch.float32:
+        raise TypeError("points must be float32")
+    points = points.contiguous()
+    voxel_size = np.asarray(voxel_size, dtype=np.float32)
+    coors_range = np.asarray(coors_range, dtype=np.float32)
+    grid = _grid_size(voxel_size, coors_range)
+    n, ndim = points.shape
+    dev = points.device
+    voxels = torch.empty((max_voxels, max_points, ndim), dtype=torch.float32, device=dev)
+    coors = torch.empty((max_voxels, 3), dtype=torch.int32, device=dev)
+    num = torch.empty((max_voxels,), dtype=torch.int32, device=dev)
+    count = torch.empty((1,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        ws_bytes = _nat.lib().fv2p_points_to_voxel_ws_bytes(n, max_voxels)
+        ws = _nat.workspace(ws_bytes, dev)
+        _nat.call("fv2p_points_to_voxel", points, n, ndim, voxel_size.tolist(), coors_range[:3].tolist(),
+                  [int(g) for g in grid], int(max_points), int(max_voxels), voxels, coors, num, count,
+                  ws, ws.numel(), _nat.stream())
+    m = int(count.item())
+    voxels, coors, num = voxels[:m], coors[:m], num[:m]
+    if not reverse_index:
+        coors = coors.flip(1).contiguous()
+    return voxels, coors, num
+
+
+def points_to_voxel(points, voxel_size, coors_range, max_points=35, reverse_index=True, max_voxels=20000):
+    """Drop-in for the reference function of the same name (voxel_generator.py:75-133)."""
+    import torch
+    if isinstance(points, torch.Tensor):
+        return points_to_voxel_gpu(points, voxel_size, coors_range, max_points, reverse_index, max_voxels)
+    pts = np.ascontiguousarray(points)
+    if not isinstance(voxel_size, np.ndarray):
+        voxel_size = np.array(voxel_size, dtype=pts.dtype)
+    if not isinstance(coors_range, np.ndarray):
+        coors_range = np.array(coors_range, dtype=pts.dtype)
+    dpts = torch.from_numpy(pts.astype(np.float32, copy=False)).cuda()
+    v, c, n = points_to_voxel_gpu(dpts, voxel_size, coors_range, max_points, reverse_index, max_voxels)
+    return v.cpu().numpy().astype(pts.dtype, copy=False), c.cpu().numpy(), n.cpu().numpy()
+
+
+class VoxelGenerator(object):
+    """Same surface as the reference class (voxel_generator.py:5-72)."""
+
+    def __init__(self, voxel_size, point_cloud_range, max_num_points, max_voxels=20000):
+        point_cloud_range = np.array(point_cloud_range, dtype=np.float32)
+        voxel_size = np.array(voxel_size, dtype=np.float32)
+        self._voxel_size = voxel_size
+        self._point_cloud_range = point_cloud_range
+        self._max_num_points = max_num_points
+        self._max_voxels = max_voxels
+        self._grid_size = _grid_size(voxel_size, point_cloud_range)
+
+    def generate(self, points):
+        return points_to_voxel(points, self._voxel_size, self._point_cloud_range, self._max_num_points, True,
+                               self._max_voxels)
+
+    @property
+    def voxel_size(self):
+        return self._voxel_size
+
+    @property
+    def max_num_points_per_voxel(self):
+        return self._max_num_points
+
+    @property
+    def point_cloud_range(self):
+        return self._point_cloud_range
+
+    @property
+    def grid_size(self):
+        return self._grid_size
+
+    def __repr__(self):
+        return (f"{self.__class__.__name__}(voxel_size={self._voxel_size}, "
+                f"point_cloud_range={self._point_cloud_range.tolist()}, max_num_points={self._max_num_points}, "
+                f"max_voxels={self._max_voxels}, grid_size={self._grid_size.tolist()})")
