@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the pcdet.ops hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+A "step" is one training step of the sparse 3-D backbone over one batch of synthetic KITTI-shaped clouds
+whose points are already resident in HBM:  HIP voxelisation (points_to_voxel) -> MeanVFE -> backbone
+forward (8-9 hashed rulebook builds + 12-21 fused MFMA sparse convs + BN/ReLU) -> loss -> backward ->
+AdamW step.  Workload at N=1 = BASELINE.json configs[1] (VoxelBackBone8x, batch 4, KITTI grid 0.05 m,
+16384-point clouds) extended with the backward pass the metric asks for.  Weak scaling: every rank keeps
+batch 4 (DistributedDataParallel over RCCL); value = clouds processed by all ranks / max-over-ranks time.
+
+Rank 0 prints ONE JSON line with `roofline` (dominant kernel, timed live with events on the launch stream)
+and, at N=1, `cpu_baseline` (the oracle port of the reference algorithm on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for p in (REPO, os.path.join(REPO, "from-voxel-to-point_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
+METRIC = "point clouds/sec fwd+bwd (FV2P, KITTI shape) at 1/2/4/8 MI355X"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4, help="clouds per GPU per step")
+    ap.add_argument("--points", type=int, default=16384)
+    ap.add_argument("--backbone", choices=["8x", "res8x"], default="8x")
+    ap.add_argument("--cpu-clouds", type=int, default=8, help="clouds in the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def build_step(args, device, rank, world):
+    from fv2p_harness import synth
+    from fv2p_harness.backbone import VoxelBackBone8x, VoxelResBackBone8x, mean_vfe
+    from pcdet.datasets.processor.voxel_generator import points_to_voxel_gpu
+
+    torch.manual_seed(0)
+    cls = VoxelBackBone8x if args.backbone == "8x" else VoxelResBackBone8x
+    model = cls(4, [1408, 1600, 40]).to(device)
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], find_unused_parameters=True)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.01)
+    # a small pool of distinct batches, points resident in HBM; seeds differ per rank
+    n_pool = 4
+    pool = [[torch.from_numpy(synth.lidar_cloud(1000 * rank + 10 * j + b, args.points)).to(device) for b in range(args.batch)]
+            for j in range(n_pool)]
+
+    def voxelize(clouds):
+        feats, coords = [], []
+        for b, pts in enumerate(clouds):
+            v, c, n = points_to_voxel_gpu(pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, True, 16000)
+            feats.append(mean_vfe(v, n))
+            coords.append(torch.nn.functional.pad(c, (1, 0), value=b))
+        return torch.cat(feats), torch.cat(coords)
+
+    def step(i):
+        feats, coords = voxelize(pool[i % n_pool])
+        out, _ = net(feats, coords, args.batch)
+        loss = out.features.square().mean()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return loss
+
+    return model, step, voxelize, pool
+
+
+def roofline_probe(model, voxelize, pool, args, device):
+    """Times the dominant kernel (fused sparse-conv rows kernel of the widest-work layer) with events on the
+    stream it is launched on, and prices it with SURVEY §8(d)'s algorithmic flops / bytes."""
+    from pcdet.ops import spconv
+    from pcdet.ops.spconv import ops
+    from pcdet.ops.spconv.conv import SparseConvolution
+
+    records = []
+
+    def hook(mod, inp, out):
+        x = inp[0]
+        if mod.conv1x1 or mod.indice_key is None:
+            return
+        rb = x.indice_dict[mod.indice_key]
+        p = int(rb.indice_pair_num.sum().item())
+        cin, cout = mod.in_channels, mod.out_channels
+        records.append(dict(mod=mod, feats=x.features.detach(), rb=rb, n_in=x.features.shape[0], n_out=out.features.shape[0],
+                            pairs=p, flops=2.0 * p * cin * cout))
+
+    hs = [m.register_forward_hook(hook) for m in model.modules() if isinstance(m, SparseConvolution)]
+    with torch.no_grad():
+        feats, coords = voxelize(pool[0])
+        model(feats, coords, args.batch)
+    for h in hs:
+        h.remove()
+    rec = max(records, key=lambda r: r["flops"])
+    mod, rb = rec["mod"], rec["rb"]
+    w = mod.weight.detach()
+    reps = 50
+    for _ in range(5):
+        ops.indice_conv(rec["feats"], w, rb, rb.indice_pair_num, rec["n_out"], False, mod.subm)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.indice_conv(rec["feats"], w, rb, rb.indice_pair_num, rec["n_out"], False, mod.subm)
+    e1.record()
+    torch.cuda.synchronize()
+    dur_s = e0.elapsed_time(e1) / reps / 1e3
+    cin, cout, kvol = mod.in_channels, mod.out_channels, rb.kvol
+    flops = rec["flops"]
+    bytes_alg = 4.0 * (rec["n_in"] * cin + rec["n_out"] * cout) + 8.0 * rec["pairs"] + 4.0 * kvol * cin * cout
+    t_mfma, t_hbm = flops / (PEAK_MFMA_F32_TFLOPS * 1e12), bytes_alg / (PEAK_HBM_GBS * 1e9)
+    if t_mfma >= t_hbm:
+        ach, peak, unit, bound = flops / dur_s / 1e12, PEAK_MFMA_F32_TFLOPS, "TFLOP/s", "mfma"
+    else:
+        ach, peak, unit, bound = bytes_alg / dur_s / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
+    return {"bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "traffic": None,
+            "kernel": "conv_rows_vec (fv2p_sparse_conv_rows)",
+            "layer": f"{'subm' if mod.subm else 'conv'} {cin}->{cout} key={mod.indice_key} n_in={rec['n_in']} n_out={rec['n_out']} pairs={rec['pairs']}",
+            "avg_kernel_us": round(dur_s * 1e6, 2), "alg_flops": flops, "alg_bytes": bytes_alg}
+
+
+def cpu_baseline(model, args):
+    """The reference algorithm restated in oracle/ (dense-map voxeliser, geometry.h rulebook, per-offset
+    gather -> mm -> scatter-add) on the host cores, forward + backward, on a bounded sample of the same clouds."""
+    import oracle
+    from fv2p_harness import synth
+    from fv2p_harness.backbone import mean_vfe
+    from oracle.spconv_cpu import cpu_mirror
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ref = cpu_mirror(model)
+    n = max(1, args.cpu_clouds)
+    clouds = [synth.lidar_cloud(10 * j, args.points) for j in range(n)]
+    t0 = time.perf_counter()
+    done = 0
+    for b0 in range(0, n, args.batch):
+        feats, coords = [], []
+        chunk = clouds[b0:b0 + args.batch]
+        for b, pts in enumerate(chunk):
+            v, c, k = oracle.points_to_voxel(pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 16000)
+            feats.append(mean_vfe(torch.from_numpy(v), torch.from_numpy(k)))
+            coords.append(torch.from_numpy(np.concatenate([np.full((c.shape[0], 1), b, np.int32), c], 1)))
+        out, _ = ref(torch.cat(feats), torch.cat(coords), len(chunk))
+        ref.zero_grad(set_to_none=True)
+        out.features.square().mean().backward()
+        done += len(chunk)
+        if time.perf_counter() - t0 > 40.0:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(done / dt, 3), "unit": "point clouds/s", "cores": cores, "kind": "port",
+            "sample": f"{done} synthetic KITTI-shaped clouds ({args.points} pts), batches of <= {args.batch}: oracle voxeliser + "
+                      f"dense-grid-equivalent rulebook + per-offset gather/mm/scatter backbone fwd+bwd (torch CPU, {cores} threads), {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+    import fv2p_native
+    fv2p_native.lib()
+
+    model, step, voxelize, pool = build_step(args, device, rank, world)
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    result = None
+    if rank == 0:
+        clouds = args.batch * world * args.steps
+        result = {
+            "metric": METRIC, "value": round(clouds / dt, 2), "unit": "point clouds/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("VoxelBackBone8x" if args.backbone == "8x" else "VoxelResBackBone8x") +
+                       " train step (HIP voxelise + MeanVFE + sparse backbone fwd + bwd + AdamW), KITTI grid 0.05 m "
+                       "[41,1600,1408], LiDAR-like synthetic clouds", "batch_per_gpu": args.batch, "points_per_cloud": args.points,
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+        }
+        if not args.no_roofline:
+            result["roofline"] = roofline_probe(model, voxelize, pool, args, device)
+        if world == 1 and args.cpu_clouds > 0:
+            result["cpu_baseline"] = cpu_baseline(model, args)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

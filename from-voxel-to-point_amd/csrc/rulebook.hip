@@ -1,0 +1,382 @@
+// A3/A4 — hashed rulebook builder for submanifold / strided / transposed sparse conv.
+//
+// Replaces the reference's dense-grid builders (pcdet/ops/spconv/include/spconv/spconv_ops.h:27-140,
+// src/indice_cuda.cu:29-135, include/spconv/indice.cu.h:22-203): instead of a B*Z*Y*X int grid
+// (1.48 GB per call at KITTI level 1) the active set lives in an open-addressing table of packed
+// {flat index : 40, row : 24} words, and the rulebook is produced as two dense neighbour tables
+//     tab_in [K][n_in ] : output row reached from input row i through kernel offset k (or -1)
+//     tab_out[K][n_out] : input row that feeds output row o through kernel offset k   (or -1)
+// which is what the fused output-stationary conv kernels consume (every (k, o) has at most one
+// input, every (k, i) at most one output).  The reference's pair lists [K,2,n_in] are derived
+// from tab_in by an ordered stream compaction (canonical order: ascending input row).
+//
+// Output rows of a strided/transposed conv are the sorted distinct flat output indices
+// (b*V + (z*Y + y)*X + x), exactly the order torch::_unique gives the GPU reference
+// (spconv_ops.h:130-131): candidates are de-duplicated in a hash set, radix sorted, ranked.
+// Neighbour enumeration and the kernel-offset formula follow geometry.h:24-142 literally
+// (C integer division, the `m * (...) / dilation` precedence included).
+#include "common.hpp"
+
+namespace fv2p {
+
+struct RbGeom {
+  int in_shape[3], out_shape[3], k[3], s[3], p[3], d[3], E[3];
+  int kvol, emax, transpose;
+  long long out_vol;
+};
+
+// Enumerated candidate e of input position `in` -> output position + kernel offset (geometry.h:24-142).
+__device__ __forceinline__ bool enum_out(const RbGeom& g, const int in[3], int e, int out[3], int* offset) {
+  int lower[3], upper[3], cs[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    if (g.transpose) {
+      lower[j] = in[j] * g.s[j] - g.p[j];
+      upper[j] = lower[j] + (g.k[j] - 1) * g.d[j];
+    } else {
+      lower[j] = (in[j] - (g.k[j] - 1) * g.d[j] - 1 + g.s[j] + g.p[j]) / g.s[j];
+      upper[j] = (in[j] + g.p[j]) / g.s[j];
+    }
+    cs[j] = (upper[j] - lower[j]) / g.d[j] + 1;
+    if (cs[j] <= 0) return false;
+  }
+  if (e >= cs[0] * cs[1] * cs[2]) return false;
+  int c[3];
+  c[2] = e % cs[2]; e /= cs[2];
+  c[1] = e % cs[1];
+  c[0] = e / cs[1];
+  bool valid = true;
+  int m = 1, off = 0;
+#pragma unroll
+  for (int j = 2; j >= 0; --j) {
+    const int val = upper[j] - c[j] * g.d[j];
+    out[j] = val;
+    if (val < 0 || val > g.out_shape[j] - 1) valid = false;
+    if (g.transpose) off += m * (val - lower[j]) / g.d[j];
+    else off += m * (in[j] - val * g.s[j] + g.p[j]) / g.d[j];
+    m *= g.k[j];
+  }
+  *offset = off;
+  return valid;
+}
+
+__device__ __forceinline__ uint64_t flat_key(int b, const int pos[3], const int shape[3], long long vol) {
+  return static_cast<uint64_t>(b) * vol + (static_cast<uint64_t>(pos[0]) * shape[1] + pos[1]) * shape[2] + pos[2];
+}
+
+// subM: table key(position of row i) -> i ; duplicates: highest row wins (geometry.h:275-280).
+__global__ void rb_insert_rows(const int* __restrict__ ind, int n, RbGeom g, uint64_t* __restrict__ table, uint32_t mask) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int4 c = reinterpret_cast<const int4*>(ind)[i];
+  const int pos[3] = {c.y, c.z, c.w};
+  const uint64_t key = flat_key(c.x, pos, g.out_shape, g.out_vol);
+  const uint64_t word = slot_pack(key, static_cast<uint32_t>(i));
+  uint32_t h = hash_u64(key, mask);
+  while (true) {
+    unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&table[h]), (unsigned long long)kEmptySlot,
+                                       (unsigned long long)word);
+    if (old == kEmptySlot) break;
+    if (slot_key(old) == key) { atomicMax(reinterpret_cast<unsigned long long*>(&table[h]), (unsigned long long)word); break; }
+    h = (h + 1) & mask;
+  }
+}
+
+// strided / transposed: hash-set of candidate output keys; the inserting thread appends the key to uniq[].
+__global__ void rb_insert_outputs(const int* __restrict__ ind, int n, RbGeom g, uint64_t* __restrict__ table, uint32_t mask,
+                                  uint64_t* __restrict__ uniq, int* __restrict__ n_uniq) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = blockIdx.y;
+  if (i >= n) return;
+  const int4 c = reinterpret_cast<const int4*>(ind)[i];
+  const int in[3] = {c.y, c.z, c.w};
+  int out[3], off;
+  if (!enum_out(g, in, e, out, &off)) return;
+  const uint64_t key = flat_key(c.x, out, g.out_shape, g.out_vol);
+  const uint64_t word = slot_pack(key, static_cast<uint32_t>(kValMask));
+  uint32_t h = hash_u64(key, mask);
+  while (true) {
+    unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&table[h]), (unsigned long long)kEmptySlot,
+                                       (unsigned long long)word);
+    if (old == kEmptySlot) { uniq[atomicAdd(n_uniq, 1)] = key; break; }
+    if (slot_key(old) == key) break;
+    h = (h + 1) & mask;
+  }
+}
+
+// rank r -> table payload, decoded output coordinates
+__global__ void rb_assign_outputs(const uint64_t* __restrict__ uniq, int n_out, RbGeom g, uint64_t* __restrict__ table,
+                                  uint32_t mask, int* __restrict__ out_ind) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_out) return;
+  const uint64_t key = uniq[r];
+  uint32_t h = hash_u64(key, mask);
+  while (slot_key(table[h]) != key) h = (h + 1) & mask;
+  table[h] = slot_pack(key, static_cast<uint32_t>(r));
+  uint64_t rem = key % static_cast<uint64_t>(g.out_vol);
+  int4 o;
+  o.x = static_cast<int>(key / static_cast<uint64_t>(g.out_vol));
+  o.w = static_cast<int>(rem % g.out_shape[2]); rem /= g.out_shape[2];
+  o.z = static_cast<int>(rem % g.out_shape[1]);
+  o.y = static_cast<int>(rem / g.out_shape[1]);
+  reinterpret_cast<int4*>(out_ind)[r] = o;
+}
+
+// one thread per (input row, candidate): probe and fill the neighbour tables
+__global__ void rb_fill_tables(const int* __restrict__ ind, int n_in, int n_out, RbGeom g, const uint64_t* __restrict__ table,
+                               uint32_t mask, int* __restrict__ tab_in, int* __restrict__ tab_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = blockIdx.y;
+  if (i >= n_in) return;
+  const int4 c = reinterpret_cast<const int4*>(ind)[i];
+  const int in[3] = {c.y, c.z, c.w};
+  int out[3], off;
+  if (!enum_out(g, in, e, out, &off)) return;
+  const int o = table_find(table, mask, flat_key(c.x, out, g.out_shape, g.out_vol));
+  if (o < 0) return;
+  tab_in[static_cast<int64_t>(off) * n_in + i] = o;
+  if (tab_out) tab_out[static_cast<int64_t>(off) * n_out + o] = i;
+}
+
+// indice_num[k] = #valid entries of tab[k][:]
+__global__ void rb_count_rows(const int* __restrict__ tab, int n, int* __restrict__ num) {
+  const int k = blockIdx.y;
+  int cnt = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    cnt += tab[static_cast<int64_t>(k) * n + i] >= 0;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) cnt += __shfl_down(cnt, d, 64);
+  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&num[k], cnt);
+}
+
+// ---- reference-format pair lists: ordered compaction of tab_in[k][:] -----------------------------
+constexpr int kPairTile = 1024;  // rows per workgroup (256 threads x 4)
+__global__ __launch_bounds__(256) void rb_pair_counts(const int* __restrict__ tab, int n, int nblk, int* __restrict__ cnt) {
+  const int k = blockIdx.y;
+  const int base = blockIdx.x * kPairTile;
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = base + j * 256 + threadIdx.x;
+    c += (i < n) && tab[static_cast<int64_t>(k) * n + i] >= 0;
+  }
+  __shared__ int ws[4];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) cnt[k * nblk + blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+// offs = exclusive scan of cnt over the flattened [K][nblk] array; row start of k = offs[k*nblk]
+__global__ __launch_bounds__(256) void rb_pair_write(const int* __restrict__ tab, int n, int nblk, const int* __restrict__ offs,
+                                                     int* __restrict__ pairs, int64_t ld /* row length of pairs */) {
+  const int k = blockIdx.y;
+  const int base = blockIdx.x * kPairTile;
+  __shared__ int wave_cnt[4];
+  __shared__ int run;
+  if (threadIdx.x == 0) run = offs[k * nblk + blockIdx.x] - offs[k * nblk];
+  __syncthreads();
+  const int w = threadIdx.x >> 6;
+  for (int j = 0; j < 4; ++j) {
+    const int i = base + j * 256 + threadIdx.x;
+    const int o = (i < n) ? tab[static_cast<int64_t>(k) * n + i] : -1;
+    const uint64_t vote = __ballot(o >= 0);
+    if ((threadIdx.x & 63) == 0) wave_cnt[w] = __popcll(vote);
+    __syncthreads();
+    int pos = run + __popcll(vote & lanemask_lt());
+    for (int ww = 0; ww < w; ++ww) pos += wave_cnt[ww];
+    if (o >= 0) {
+      pairs[(static_cast<int64_t>(k) * 2 + 0) * ld + pos] = i;
+      pairs[(static_cast<int64_t>(k) * 2 + 1) * ld + pos] = o;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) run += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+}
+
+// pair lists -> tables (for rulebooks supplied in the reference format)
+__global__ void rb_pairs_to_tables(const int* __restrict__ pairs, const int* __restrict__ num, int64_t ld, int n_in, int n_out,
+                                   int* __restrict__ tab_in, int* __restrict__ tab_out) {
+  const int k = blockIdx.y;
+  const int cnt = num[k];
+  for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < cnt; s += gridDim.x * blockDim.x) {
+    const int i = pairs[(static_cast<int64_t>(k) * 2 + 0) * ld + s];
+    const int o = pairs[(static_cast<int64_t>(k) * 2 + 1) * ld + s];
+    if (i < 0 || o < 0 || i >= n_in || o >= n_out) continue;
+    if (tab_in) tab_in[static_cast<int64_t>(k) * n_in + i] = o;
+    if (tab_out) tab_out[static_cast<int64_t>(k) * n_out + o] = i;
+  }
+}
+
+struct RbWs {
+  uint64_t* table; uint32_t cap;
+  uint64_t* uniq; uint64_t* tmp; int* n_uniq;
+  char* aux; size_t aux_bytes;
+};
+
+static int rb_geom(RbGeom* g, const int in_shape[3], const int out_shape[3], const int ksize[3], const int stride[3],
+                   const int padding[3], const int dilation[3], int subm, int transpose) {
+  g->kvol = 1; g->emax = 1; g->out_vol = 1; g->transpose = transpose && !subm;
+  for (int j = 0; j < 3; ++j) {
+    FV2P_REQUIRE(ksize[j] >= 1 && stride[j] >= 1 && dilation[j] >= 1 && in_shape[j] >= 1 && out_shape[j] >= 1, FV2P_EINVAL,
+                 "rulebook: bad geometry in dim %d", j);
+    g->in_shape[j] = in_shape[j]; g->out_shape[j] = out_shape[j]; g->k[j] = ksize[j]; g->d[j] = dilation[j];
+    if (subm) { g->s[j] = 1; g->p[j] = ksize[j] / 2; }   // spconv_ops.h:76-80
+    else { g->s[j] = stride[j]; g->p[j] = padding[j]; }
+    g->E[j] = g->transpose ? ksize[j] : ((ksize[j] - 1) * dilation[j] / g->s[j]) / dilation[j] + 1;
+    g->kvol *= ksize[j]; g->emax *= g->E[j]; g->out_vol *= out_shape[j];
+  }
+  FV2P_REQUIRE(g->kvol <= 4096, FV2P_ELIMIT, "rulebook: kernel volume > 4096 (spconv_ops.h:52)");
+  return 0;
+}
+
+template <typename C>
+static void rb_carve(C& c, int64_t n_in, int emax, int subm, RbWs* w) {
+  const uint64_t items = subm ? static_cast<uint64_t>(n_in) : static_cast<uint64_t>(n_in) * emax;
+  const uint32_t cap = next_pow2((items > 512 ? items : 512) * 2);
+  const int64_t nu = subm ? 1 : static_cast<int64_t>(items);
+  const size_t aux = radix_sort_ws_bytes(nu);
+  uint64_t* table = c.template take<uint64_t>(cap);
+  int* n_uniq = c.template take<int>(4);
+  uint64_t* uniq = c.template take<uint64_t>(nu);
+  uint64_t* tmp = c.template take<uint64_t>(nu);
+  char* auxp = c.template take<char>(aux);
+  if (w) { w->table = table; w->cap = cap; w->n_uniq = n_uniq; w->uniq = uniq; w->tmp = tmp; w->aux = auxp; w->aux_bytes = aux; }
+}
+struct SizerC : Sizer { template <typename T> T* take(size_t n) { Sizer::take<T>(n); return nullptr; } };
+
+}  // namespace fv2p
+
+using namespace fv2p;
+
+extern "C" size_t fv2p_rulebook_ws_bytes(int64_t n_in, const int ksize[3], const int stride[3], const int dilation[3], int subm,
+                                         int transpose) {
+  RbGeom g;
+  const int one[3] = {1, 1, 1}, zero[3] = {0, 0, 0};
+  if (rb_geom(&g, one, one, ksize, stride, zero, dilation, subm, transpose)) return 0;
+  SizerC s;
+  rb_carve(s, n_in > 0 ? n_in : 1, g.emax, subm, static_cast<RbWs*>(nullptr));
+  return s.bytes();
+}
+
+extern "C" int fv2p_rulebook_begin(const int* indices, int64_t n_in, int batch, const int in_shape[3], const int out_shape[3],
+                                   const int ksize[3], const int stride[3], const int padding[3], const int dilation[3], int subm,
+                                   int transpose, int64_t* n_out_host, void* ws, size_t ws_bytes, fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  RbGeom g;
+  if (int rc = rb_geom(&g, in_shape, out_shape, ksize, stride, padding, dilation, subm, transpose)) return rc;
+  FV2P_REQUIRE(n_out_host, FV2P_EINVAL, "rulebook_begin: n_out_host is null");
+  FV2P_REQUIRE(n_in >= 0 && n_in <= kMaxRows, FV2P_ELIMIT, "rulebook: n_in=%lld outside [0, 2^24)", (long long)n_in);
+  FV2P_REQUIRE(batch >= 1 && static_cast<double>(batch) * g.out_vol <= static_cast<double>(kMaxKey), FV2P_ELIMIT,
+               "rulebook: batch*volume exceeds 2^40");
+  if (subm)
+    for (int j = 0; j < 3; ++j)
+      FV2P_REQUIRE(in_shape[j] == out_shape[j], FV2P_EINVAL, "rulebook: subm needs out_shape == in_shape");
+  if (n_in == 0) { *n_out_host = 0; return 0; }
+  FV2P_REQUIRE(indices && ws && ws_bytes >= fv2p_rulebook_ws_bytes(n_in, ksize, stride, dilation, subm, transpose), FV2P_EWORKSPACE,
+               "rulebook: workspace too small");
+  Carver c(ws, ws_bytes);
+  RbWs w;
+  rb_carve(c, n_in, g.emax, subm, &w);
+  FV2P_HIP(hipMemsetAsync(w.table, 0xFF, sizeof(uint64_t) * w.cap, stream));
+  const int T = 256;
+  const unsigned nb = static_cast<unsigned>(ceil_div(n_in, T));
+  if (subm) {
+    hipLaunchKernelGGL(rb_insert_rows, dim3(nb), dim3(T), 0, stream, indices, (int)n_in, g, w.table, w.cap - 1);
+    FV2P_LAUNCH_CHECK();
+    *n_out_host = n_in;
+    return 0;
+  }
+  FV2P_REQUIRE(static_cast<int64_t>(n_in) * g.emax <= kMaxRows, FV2P_ELIMIT, "rulebook: too many candidate outputs");
+  FV2P_HIP(hipMemsetAsync(w.n_uniq, 0, sizeof(int) * 4, stream));
+  hipLaunchKernelGGL(rb_insert_outputs, dim3(nb, g.emax), dim3(T), 0, stream, indices, (int)n_in, g, w.table, w.cap - 1, w.uniq,
+                     w.n_uniq);
+  FV2P_LAUNCH_CHECK();
+  int n_out = 0;
+  FV2P_HIP(hipMemcpyAsync(&n_out, w.n_uniq, sizeof(int), hipMemcpyDeviceToHost, stream));
+  FV2P_HIP(hipStreamSynchronize(stream));  // output row count is a host-side shape (as in spconv_ops.h:131-139)
+  *n_out_host = n_out;
+  return 0;
+}
+
+extern "C" int fv2p_rulebook_finish(const int* indices, int64_t n_in, int batch, const int in_shape[3], const int out_shape[3],
+                                    const int ksize[3], const int stride[3], const int padding[3], const int dilation[3], int subm,
+                                    int transpose, int64_t n_out, int* out_indices, int* tab_in, int* tab_out, int* indice_num,
+                                    void* ws, size_t ws_bytes, fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  RbGeom g;
+  if (int rc = rb_geom(&g, in_shape, out_shape, ksize, stride, padding, dilation, subm, transpose)) return rc;
+  FV2P_REQUIRE(indice_num, FV2P_EINVAL, "rulebook_finish: null indice_num");
+  FV2P_HIP(hipMemsetAsync(indice_num, 0, sizeof(int) * g.kvol, stream));
+  if (n_in == 0) return 0;
+  FV2P_REQUIRE(tab_in, FV2P_EINVAL, "rulebook_finish: null tab_in");
+  FV2P_REQUIRE(ws && ws_bytes >= fv2p_rulebook_ws_bytes(n_in, ksize, stride, dilation, subm, transpose), FV2P_EWORKSPACE,
+               "rulebook: workspace too small");
+  Carver c(ws, ws_bytes);
+  RbWs w;
+  rb_carve(c, n_in, g.emax, subm, &w);
+  const int T = 256;
+  const unsigned nb = static_cast<unsigned>(ceil_div(n_in, T));
+  FV2P_HIP(hipMemsetAsync(tab_in, 0xFF, sizeof(int) * (size_t)g.kvol * n_in, stream));
+  if (tab_out && n_out > 0) FV2P_HIP(hipMemsetAsync(tab_out, 0xFF, sizeof(int) * (size_t)g.kvol * n_out, stream));
+  if (!subm) {
+    FV2P_REQUIRE(out_indices || n_out == 0, FV2P_EINVAL, "rulebook_finish: out_indices is null");
+    if (n_out > 0) {
+      const int bits = bits_for(static_cast<uint64_t>(batch) * g.out_vol);
+      if (int rc = radix_sort_u64(w.uniq, w.tmp, n_out, 0, bits, w.aux, w.aux_bytes, stream)) return rc;
+      hipLaunchKernelGGL(rb_assign_outputs, dim3((unsigned)ceil_div(n_out, T)), dim3(T), 0, stream, w.uniq, (int)n_out, g, w.table,
+                         w.cap - 1, out_indices);
+    }
+  } else {
+    FV2P_REQUIRE(n_out == n_in, FV2P_EINVAL, "rulebook_finish: subm needs n_out == n_in");
+  }
+  hipLaunchKernelGGL(rb_fill_tables, dim3(nb, g.emax), dim3(T), 0, stream, indices, (int)n_in, (int)n_out, g, w.table, w.cap - 1,
+                     tab_in, tab_out);
+  const unsigned cb = static_cast<unsigned>(ceil_div(n_in, 1024) < 64 ? ceil_div(n_in, 1024) : 64);
+  hipLaunchKernelGGL(rb_count_rows, dim3(cb, g.kvol), dim3(T), 0, stream, tab_in, (int)n_in, indice_num);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t fv2p_rulebook_pairs_ws_bytes(int64_t n_in, int kvol) {
+  const int64_t nblk = ceil_div(n_in > 0 ? n_in : 1, kPairTile);
+  Sizer s;
+  s.take<int>(static_cast<size_t>(kvol) * nblk + 1);
+  s.take<char>(scan_ws_bytes(static_cast<int64_t>(kvol) * nblk + 1));
+  return s.bytes();
+}
+
+extern "C" int fv2p_rulebook_pairs(const int* tab_in, int64_t n_in, int kvol, int* pairs, void* ws, size_t ws_bytes,
+                                   fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FV2P_REQUIRE(kvol >= 1 && n_in >= 0, FV2P_EINVAL, "rulebook_pairs: bad sizes");
+  if (n_in == 0) return 0;
+  FV2P_REQUIRE(tab_in && pairs, FV2P_EINVAL, "rulebook_pairs: null pointer");
+  FV2P_REQUIRE(ws && ws_bytes >= fv2p_rulebook_pairs_ws_bytes(n_in, kvol), FV2P_EWORKSPACE, "rulebook_pairs: workspace too small");
+  const int nblk = static_cast<int>(ceil_div(n_in, kPairTile));
+  Carver c(ws, ws_bytes);
+  int* cnt = c.take<int>(static_cast<size_t>(kvol) * nblk + 1);
+  const size_t sb = scan_ws_bytes(static_cast<int64_t>(kvol) * nblk + 1);
+  char* sws = c.take<char>(sb);
+  FV2P_HIP(hipMemsetAsync(pairs, 0xFF, sizeof(int) * 2 * (size_t)kvol * n_in, stream));  // -1 padding, spconv_ops.h:55-57
+  hipLaunchKernelGGL(rb_pair_counts, dim3(nblk, kvol), dim3(256), 0, stream, tab_in, (int)n_in, nblk, cnt);
+  if (int rc = exclusive_scan_i32(cnt, cnt, static_cast<int64_t>(kvol) * nblk, nullptr, sws, sb, stream)) return rc;
+  hipLaunchKernelGGL(rb_pair_write, dim3(nblk, kvol), dim3(256), 0, stream, tab_in, (int)n_in, nblk, cnt, pairs, n_in);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fv2p_pairs_to_tables(const int* pairs, const int* indice_num, int kvol, int64_t pair_len, int64_t n_in, int64_t n_out,
+                                    int* tab_in, int* tab_out, fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FV2P_REQUIRE(pairs && indice_num && kvol >= 1 && pair_len >= 0, FV2P_EINVAL, "pairs_to_tables: bad arguments");
+  if (tab_in && n_in > 0) FV2P_HIP(hipMemsetAsync(tab_in, 0xFF, sizeof(int) * (size_t)kvol * n_in, stream));
+  if (tab_out && n_out > 0) FV2P_HIP(hipMemsetAsync(tab_out, 0xFF, sizeof(int) * (size_t)kvol * n_out, stream));
+  if (pair_len == 0) return 0;
+  const unsigned nb = static_cast<unsigned>(ceil_div(pair_len, 256) < 256 ? ceil_div(pair_len, 256) : 256);
+  hipLaunchKernelGGL(rb_pairs_to_tables, dim3(nb, kvol), dim3(256), 0, stream, pairs, indice_num, pair_len, (int)n_in, (int)n_out,
+                     tab_in, tab_out);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}

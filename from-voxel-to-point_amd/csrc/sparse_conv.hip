@@ -1,0 +1,387 @@
+// A5/A6 — fused sparse convolution (gather + per-offset GEMM + accumulate) on fp32 MFMA.
+//
+// Replaces the reference's per-offset gather -> torch::mm -> scatterAdd loop
+// (pcdet/ops/spconv/include/spconv/spconv_ops.h:260-457, reordering.cu.h:21-157: ~78 launches,
+// two staging buffers and a D2H sync per layer) with ONE output-stationary kernel per direction:
+//
+//   dst[r, :] = sum_k  src[tab[k][r], :] * W_k        (rows with tab == -1 contribute nothing)
+//
+// Forward uses tab_out, backward-data uses tab_in with W_k transposed, inverse conv uses tab_in
+// (see rulebook.hip).  Every destination row is owned by exactly one wavefront, so there are no
+// atomics and the k = 0..K-1 summation order is fixed (deterministic).  The per-offset GEMM runs on
+// v_mfma_f32_16x16x4_f32 (exact fp32, bitwise an fmaf chain): a wave owns 16 destination rows x all
+// output columns; the A fragment is gathered straight from HBM/L2 as one 16-byte load per lane
+// (lane (r, g) reads channels 16j+4g..+3 of row r, a K-permutation that both operands share), the
+// B fragment (W_k) is staged once per workgroup in LDS in fragment order so every lane does a
+// conflict-free ds_read_b128.
+//
+// Weight gradient: dW_k = sum_r src[tab[k][r], :]^T * grad[r, :], one wave per (row chunk, k,
+// cin-block group); valid rows are compacted with a wave64 ballot so only real pairs reach the MFMA.
+#include "common.hpp"
+
+namespace fv2p {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgs {
+  const float* src; int ld_src; int c_src;          // c_src: valid source channels in this launch
+  const float* w; long long w_kstride; int w_ld;     // W_k = w + k*w_kstride, row stride w_ld
+  const int* tab; int n_dst; int kvol; int flip;
+  const float* bias;
+  float* dst; int ld_dst; int c_dst;                 // c_dst: valid destination channels in this launch
+  int accumulate;                                    // dst += result (used when the host splits c_src)
+};
+
+// ---- B staging --------------------------------------------------------------------------------
+// VEC layout: element B[c][col] at (((c>>4)*NB + (col>>4))*64 + ((c>>2)&3)*16 + (col&15))*4 + (c&3)
+template <int CINP, int NB, bool WT>
+__device__ __forceinline__ void stage_w_vec(const ConvArgs& a, const float* __restrict__ wk, float* __restrict__ lds) {
+  constexpr int COLS = NB * 16;
+  if (!WT) {
+    // W_k[c][col], row-major: float4 along col
+    for (int e = threadIdx.x; e < CINP * (COLS / 4); e += 256) {
+      const int c = e / (COLS / 4), col = (e % (COLS / 4)) * 4;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (c < a.c_src) {
+        const float* p = wk + static_cast<long long>(c) * a.w_ld + col;
+        if (col + 3 < a.c_dst && (a.w_ld & 3) == 0) {
+          const float4 q = *reinterpret_cast<const float4*>(p);
+          v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) if (col + u < a.c_dst) v[u] = p[u];
+        }
+      }
+      const int j = c >> 4, g = (c >> 2) & 3, t = c & 3;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int cc = col + u;
+        lds[(((j * NB + (cc >> 4)) * 64) + g * 16 + (cc & 15)) * 4 + t] = v[u];
+      }
+    }
+  } else {
+    // B[c][col] = W_k[col][c]: float4 along c -> one 16-byte LDS store
+    for (int e = threadIdx.x; e < COLS * (CINP / 4); e += 256) {
+      const int col = e / (CINP / 4), c = (e % (CINP / 4)) * 4;
+      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (col < a.c_dst) {
+        const float* p = wk + static_cast<long long>(col) * a.w_ld + c;
+        if (c + 3 < a.c_src && (a.w_ld & 3) == 0) q = *reinterpret_cast<const float4*>(p);
+        else {
+          if (c + 0 < a.c_src) q.x = p[0];
+          if (c + 1 < a.c_src) q.y = p[1];
+          if (c + 2 < a.c_src) q.z = p[2];
+          if (c + 3 < a.c_src) q.w = p[3];
+        }
+      }
+      const int j = c >> 4, g = (c >> 2) & 3;
+      *reinterpret_cast<float4*>(&lds[(((j * NB + (col >> 4)) * 64) + g * 16 + (col & 15)) * 4]) = q;
+    }
+  }
+}
+
+// SCALAR layout: element B[c][col] at ((c>>2)*NB + (col>>4))*64 + (c&3)*16 + (col&15)
+template <int STEPS, int NB, bool WT>
+__device__ __forceinline__ void stage_w_scalar(const ConvArgs& a, const float* __restrict__ wk, float* __restrict__ lds) {
+  constexpr int COLS = NB * 16;
+  for (int e = threadIdx.x; e < STEPS * 4 * COLS; e += 256) {
+    const int c = e / COLS, col = e % COLS;
+    float v = 0.f;
+    if (c < a.c_src && col < a.c_dst)
+      v = WT ? wk[static_cast<long long>(col) * a.w_ld + c] : wk[static_cast<long long>(c) * a.w_ld + col];
+    lds[((c >> 2) * NB + (col >> 4)) * 64 + (c & 3) * 16 + (col & 15)] = v;
+  }
+}
+
+template <int NB>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x4 (&acc)[NB], int row0) {
+  const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int col = nb * 16 + n;
+    if (col >= a.c_dst) continue;
+    const float b = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int row = row0 + q * 4 + reg;
+      if (row < a.n_dst) {
+        float* p = a.dst + static_cast<long long>(row) * a.ld_dst + col;
+        const float v = acc[nb][reg] + b;
+        *p = a.accumulate ? (*p + v) : v;
+      }
+    }
+  }
+}
+
+// CINP: source channels padded to a multiple of 16 (c_src % 4 == 0 required, 16-byte row loads)
+template <int CINP, int NB, bool WT>
+__global__ __launch_bounds__(256) void conv_rows_vec(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int J = CINP / 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+  const int row0 = blockIdx.x * 64 + wave * 16;
+  const int my_row = row0 + r;
+  f32x4 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < a.kvol; ++k) {
+    const int trow = a.flip ? (a.kvol - 1 - k) : k;
+    const int idx = (my_row < a.n_dst) ? a.tab[static_cast<long long>(trow) * a.n_dst + my_row] : -1;
+    float4 av[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      av[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx >= 0 && (16 * j + 4 * g) < a.c_src)
+        av[j] = *reinterpret_cast<const float4*>(a.src + static_cast<long long>(idx) * a.ld_src + 16 * j + 4 * g);
+    }
+    const bool any = __ballot(idx >= 0) != 0ull;
+    __syncthreads();
+    stage_w_vec<CINP, NB, WT>(a, a.w + static_cast<long long>(k) * a.w_kstride, lds);
+    __syncthreads();
+    if (any) {
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        float4 bv[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) bv[nb] = *reinterpret_cast<const float4*>(&lds[((j * NB + nb) * 64 + lane) * 4]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].x, bv[nb].x, acc[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].y, bv[nb].y, acc[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].z, bv[nb].z, acc[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].w, bv[nb].w, acc[nb], 0, 0, 0);
+      }
+    }
+  }
+  conv_epilogue<NB>(a, acc, row0);
+}
+
+// any c_src <= 4*STEPS (scalar row loads): first layer (4 or 5 point features) and odd channel counts
+template <int STEPS, int NB, bool WT>
+__global__ __launch_bounds__(256) void conv_rows_scalar(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+  const int row0 = blockIdx.x * 64 + wave * 16;
+  const int my_row = row0 + r;
+  f32x4 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < a.kvol; ++k) {
+    const int trow = a.flip ? (a.kvol - 1 - k) : k;
+    const int idx = (my_row < a.n_dst) ? a.tab[static_cast<long long>(trow) * a.n_dst + my_row] : -1;
+    float av[STEPS];
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      av[s] = 0.f;
+      if (idx >= 0 && (4 * s + g) < a.c_src) av[s] = a.src[static_cast<long long>(idx) * a.ld_src + 4 * s + g];
+    }
+    const bool any = __ballot(idx >= 0) != 0ull;
+    __syncthreads();
+    stage_w_scalar<STEPS, NB, WT>(a, a.w + static_cast<long long>(k) * a.w_kstride, lds);
+    __syncthreads();
+    if (any) {
+#pragma unroll
+      for (int s = 0; s < STEPS; ++s)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], lds[(s * NB + nb) * 64 + lane], acc[nb], 0, 0, 0);
+    }
+  }
+  conv_epilogue<NB>(a, acc, row0);
+}
+
+// ---- weight gradient ----------------------------------------------------------------------------
+struct WgradArgs {
+  const float* src; int ld_src; int c_src;     // gathered operand (features), rows = tab values
+  const float* grad; int ld_grad; int c_grad;  // row-aligned operand (gradient wrt dst rows)
+  const int* tab; int n_dst; int kvol; int flip;
+  float* dw; long long dw_kstride; int dw_ld;   // dW_k[c_src][c_grad]
+  int rows_per_chunk;
+};
+
+// One wave per (row chunk, k, cin-block group).  MBW cin blocks x NB cout blocks of 16x16 accumulators.
+template <int MBW, int NB>
+__global__ __launch_bounds__(64) void conv_wgrad(WgradArgs a) {
+  __shared__ int s_src[64];
+  __shared__ int s_row[64];
+  const int lane = threadIdx.x, m = lane & 15, g = lane >> 4;
+  const int k = blockIdx.y;
+  const int trow = a.flip ? (a.kvol - 1 - k) : k;
+  const int mb0 = blockIdx.z * MBW;
+  f32x4 acc[MBW][NB];
+#pragma unroll
+  for (int i = 0; i < MBW; ++i)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[i][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int r_begin = blockIdx.x * a.rows_per_chunk;
+  const int r_end = min(r_begin + a.rows_per_chunk, a.n_dst);
+  bool touched = false;
+  for (int base = r_begin; base < r_end; base += 64) {
+    const int row = base + lane;
+    const int idx = (row < r_end) ? a.tab[static_cast<long long>(trow) * a.n_dst + row] : -1;
+    const uint64_t vote = __ballot(idx >= 0);
+    if (vote == 0ull) continue;
+    touched = true;
+    const int cnt = __popcll(vote);
+    if (idx >= 0) {
+      const int pos = __popcll(vote & lanemask_lt());
+      s_src[pos] = idx;
+      s_row[pos] = row;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes of this wave are visible to its own reads
+    __builtin_amdgcn_wave_barrier();
+    for (int p0 = 0; p0 < cnt; p0 += 4) {
+      const int p = p0 + g;
+      const int sr = (p < cnt) ? s_src[p] : -1;
+      const int rr = (p < cnt) ? s_row[p] : -1;
+      float av[MBW], bv[NB];
+#pragma unroll
+      for (int i = 0; i < MBW; ++i) {
+        const int c = (mb0 + i) * 16 + m;
+        av[i] = (sr >= 0 && c < a.c_src) ? a.src[static_cast<long long>(sr) * a.ld_src + c] : 0.f;
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int c = nb * 16 + m;
+        bv[nb] = (rr >= 0 && c < a.c_grad) ? a.grad[static_cast<long long>(rr) * a.ld_grad + c] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < MBW; ++i)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[nb], acc[i][nb], 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (!touched) return;
+  float* dwk = a.dw + static_cast<long long>(k) * a.dw_kstride;
+#pragma unroll
+  for (int i = 0; i < MBW; ++i)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int cr = (mb0 + i) * 16 + g * 4 + reg, cc = nb * 16 + m;
+        if (cr < a.c_src && cc < a.c_grad) atomicAdd(&dwk[static_cast<long long>(cr) * a.dw_ld + cc], acc[i][nb][reg]);
+      }
+}
+
+// ---- dispatch -----------------------------------------------------------------------------------
+template <int CINP, int NB, bool WT>
+static void launch_vec(const ConvArgs& a, hipStream_t s) {
+  const unsigned blocks = static_cast<unsigned>(ceil_div(a.n_dst, 64));
+  hipLaunchKernelGGL((conv_rows_vec<CINP, NB, WT>), dim3(blocks), dim3(256), CINP * NB * 16 * sizeof(float), s, a);
+}
+template <int STEPS, int NB, bool WT>
+static void launch_scalar(const ConvArgs& a, hipStream_t s) {
+  const unsigned blocks = static_cast<unsigned>(ceil_div(a.n_dst, 64));
+  hipLaunchKernelGGL((conv_rows_scalar<STEPS, NB, WT>), dim3(blocks), dim3(256), STEPS * 4 * NB * 16 * sizeof(float), s, a);
+}
+
+template <bool WT>
+static int dispatch_conv(const ConvArgs& a, hipStream_t s) {
+  const int nb = static_cast<int>(ceil_div(a.c_dst, 16));
+  const int nbp = nb <= 1 ? 1 : nb <= 2 ? 2 : nb <= 4 ? 4 : 8;
+  const bool vec = (a.c_src % 4 == 0) && (a.ld_src % 4 == 0) && a.c_src >= 16 &&
+                   (reinterpret_cast<uintptr_t>(a.src) % 16 == 0);
+#define FV2P_VEC_CASE(CINP)                                            \
+  switch (nbp) {                                                       \
+    case 1: launch_vec<CINP, 1, WT>(a, s); break;                      \
+    case 2: launch_vec<CINP, 2, WT>(a, s); break;                      \
+    case 4: launch_vec<CINP, 4, WT>(a, s); break;                      \
+    default: launch_vec<CINP, 8, WT>(a, s); break;                     \
+  }
+#define FV2P_SCALAR_CASE(STEPS)                                        \
+  switch (nbp) {                                                       \
+    case 1: launch_scalar<STEPS, 1, WT>(a, s); break;                  \
+    case 2: launch_scalar<STEPS, 2, WT>(a, s); break;                  \
+    case 4: launch_scalar<STEPS, 4, WT>(a, s); break;                  \
+    default: launch_scalar<STEPS, 8, WT>(a, s); break;                 \
+  }
+  if (vec) {
+    if (a.c_src <= 16) { FV2P_VEC_CASE(16) }
+    else if (a.c_src <= 32) { FV2P_VEC_CASE(32) }
+    else if (a.c_src <= 64) { FV2P_VEC_CASE(64) }
+    else { FV2P_VEC_CASE(128) }
+  } else {
+    if (a.c_src <= 4) { FV2P_SCALAR_CASE(1) }
+    else if (a.c_src <= 8) { FV2P_SCALAR_CASE(2) }
+    else if (a.c_src <= 16) { FV2P_SCALAR_CASE(4) }
+    else if (a.c_src <= 32) { FV2P_SCALAR_CASE(8) }
+    else return set_error(FV2P_ELIMIT, "sparse conv: %d source channels (not a multiple of 4) unsupported above 32", a.c_src);
+  }
+#undef FV2P_VEC_CASE
+#undef FV2P_SCALAR_CASE
+  return 0;
+}
+
+}  // namespace fv2p
+
+using namespace fv2p;
+
+extern "C" int fv2p_sparse_conv_rows(const float* src, int64_t n_src, int c_src, const float* weight, int kvol, const int* tab,
+                                     int64_t n_dst, int c_dst, int flip_k, int transpose_w, const float* bias, float* dst,
+                                     fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FV2P_REQUIRE(c_src >= 1 && c_dst >= 1 && kvol >= 1 && n_dst >= 0 && n_src >= 0, FV2P_EINVAL, "sparse_conv_rows: bad sizes");
+  if (n_dst == 0) return 0;
+  FV2P_REQUIRE(weight && tab && dst && (src || n_src == 0), FV2P_EINVAL, "sparse_conv_rows: null pointer");
+  FV2P_REQUIRE(n_dst < (1ll << 31) - 64, FV2P_ELIMIT, "sparse_conv_rows: too many rows");
+  // weight is [K][Cin][Cout] in the reference layout (spconv/conv.py:98-99); with transpose_w the roles of the
+  // two channel axes are swapped: W_k^T is used, i.e. weight is [K][c_dst][c_src].
+  const int w_rows = transpose_w ? c_dst : c_src, w_cols = transpose_w ? c_src : c_dst;
+  for (int d0 = 0; d0 < c_dst; d0 += 128) {
+    const int cd = (c_dst - d0) < 128 ? (c_dst - d0) : 128;
+    for (int s0 = 0; s0 < c_src; s0 += 128) {
+      const int cs = (c_src - s0) < 128 ? (c_src - s0) : 128;
+      ConvArgs a;
+      a.src = src + s0; a.ld_src = c_src; a.c_src = cs;
+      a.w = transpose_w ? weight + static_cast<long long>(d0) * w_cols + s0 : weight + static_cast<long long>(s0) * w_cols + d0;
+      a.w_kstride = static_cast<long long>(w_rows) * w_cols; a.w_ld = w_cols;
+      a.tab = tab; a.n_dst = static_cast<int>(n_dst); a.kvol = kvol; a.flip = flip_k;
+      a.bias = (bias && s0 == 0) ? bias + d0 : nullptr;
+      a.dst = dst + d0; a.ld_dst = c_dst; a.c_dst = cd; a.accumulate = s0 > 0;
+      int rc = transpose_w ? dispatch_conv<true>(a, stream) : dispatch_conv<false>(a, stream);
+      if (rc) return rc;
+    }
+  }
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fv2p_sparse_conv_wgrad(const float* src, int64_t n_src, int c_src, const float* grad, const int* tab, int64_t n_dst,
+                                      int c_dst, int kvol, int flip_k, float* dweight, fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FV2P_REQUIRE(c_src >= 1 && c_dst >= 1 && kvol >= 1 && n_dst >= 0, FV2P_EINVAL, "sparse_conv_wgrad: bad sizes");
+  FV2P_REQUIRE(dweight, FV2P_EINVAL, "sparse_conv_wgrad: null dweight");
+  FV2P_HIP(hipMemsetAsync(dweight, 0, sizeof(float) * (size_t)kvol * c_src * c_dst, stream));
+  if (n_dst == 0 || n_src == 0) return 0;
+  FV2P_REQUIRE(src && grad && tab, FV2P_EINVAL, "sparse_conv_wgrad: null pointer");
+  const int rows_per_chunk = 2048;
+  const unsigned chunks = static_cast<unsigned>(ceil_div(n_dst, rows_per_chunk));
+  for (int d0 = 0; d0 < c_dst; d0 += 128) {
+    const int cd = (c_dst - d0) < 128 ? (c_dst - d0) : 128;
+    WgradArgs a;
+    a.src = src; a.ld_src = c_src; a.c_src = c_src;
+    a.grad = grad + d0; a.ld_grad = c_dst; a.c_grad = cd;
+    a.tab = tab; a.n_dst = static_cast<int>(n_dst); a.kvol = kvol; a.flip = flip_k;
+    a.dw = dweight + d0; a.dw_kstride = static_cast<long long>(c_src) * c_dst; a.dw_ld = c_dst;
+    a.rows_per_chunk = rows_per_chunk;
+    const int mb = static_cast<int>(ceil_div(c_src, 16));
+    const int nb = static_cast<int>(ceil_div(cd, 16));
+    const int nbp = nb <= 1 ? 1 : nb <= 2 ? 2 : nb <= 4 ? 4 : 8;
+    // accumulators per wave: MBW*NB <= 16
+    const int mbw = nbp == 8 ? 2 : (mb >= 4 ? 4 : mb >= 2 ? 2 : 1);
+    const unsigned gz = static_cast<unsigned>(ceil_div(mb, mbw));
+    const dim3 grid(chunks, kvol, gz), block(64);
+#define FV2P_WG(MBW, NB) hipLaunchKernelGGL((conv_wgrad<MBW, NB>), grid, block, 0, stream, a)
+    if (nbp == 8) { FV2P_WG(2, 8); }
+    else if (nbp == 4) { if (mbw == 4) FV2P_WG(4, 4); else if (mbw == 2) FV2P_WG(2, 4); else FV2P_WG(1, 4); }
+    else if (nbp == 2) { if (mbw == 4) FV2P_WG(4, 2); else if (mbw == 2) FV2P_WG(2, 2); else FV2P_WG(1, 2); }
+    else { if (mbw == 4) FV2P_WG(4, 1); else if (mbw == 2) FV2P_WG(2, 1); else FV2P_WG(1, 1); }
+#undef FV2P_WG
+  }
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,159 @@
+"""Sparse convolution modules — class names, constructor arguments, parameter layout
+(`weight [*kernel_size, Cin, Cout]`, optional `bias [Cout]`) and forward contract of the reference's
+spconv/conv.py:48-480, running on the hashed rulebook + fused MFMA conv of libfv2p_ops.
+
+mmcv is not required: if it is importable the classes are registered in its CONV_LAYERS registry as the
+reference does (conv.py:17,233), otherwise registration is skipped."""
+import math
+
+import numpy as np
+import torch
+from torch.nn import init
+from torch.nn.parameter import Parameter
+
+from . import functional as Fsp
+from . import ops
+from .modules import SparseModule
+from .structure import SparseConvTensor
+
+try:  # optional, registry only (no arithmetic lives in mmcv)
+    from mmcv.cnn import CONV_LAYERS as _REG
+    _register = _REG.register_module()
+except Exception:  # noqa: BLE001
+    def _register(cls):
+        return cls
+
+
+def _calculate_fan_in_and_fan_out_hwio(tensor):
+    if tensor.ndimension() < 2:
+        raise ValueError('fan in and fan out can not be computed for tensor with fewer than 2 dimensions')
+    if tensor.ndimension() == 2:
+        return tensor.size(-2), tensor.size(-1)
+    rf = tensor[..., 0, 0].numel()
+    return tensor.size(-2) * rf, tensor.size(-1) * rf
+
+
+class SparseConvolution(SparseModule):
+
+    def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1, groups=1,
+                 bias=True, subm=False, output_padding=0, transposed=False, inverse=False, indice_key=None,
+                 fused_bn=False):
+        super(SparseConvolution, self).__init__()
+        assert groups == 1
+        as_list = lambda v: list(v) if isinstance(v, (list, tuple)) else [v] * ndim
+        kernel_size, stride, padding = as_list(kernel_size), as_list(stride), as_list(padding)
+        dilation, output_padding = as_list(dilation), as_list(output_padding)
+        for d, s in zip(dilation, stride):
+            assert any([s == 1, d == 1]), "don't support this."
+        self.ndim = ndim
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = kernel_size
+        self.conv1x1 = np.prod(kernel_size) == 1
+        self.stride = stride
+        self.padding = padding
+        self.dilation = dilation
+        self.transposed = transposed
+        self.inverse = inverse
+        self.output_padding = output_padding
+        self.groups = groups
+        self.subm = subm
+        self.indice_key = indice_key
+        self.fused_bn = fused_bn
+        self.weight = Parameter(torch.Tensor(*kernel_size, in_channels, out_channels))
+        if bias:
+            self.bias = Parameter(torch.Tensor(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in, _ = _calculate_fan_in_and_fan_out_hwio(self.weight)
+            bound = 1 / math.sqrt(fan_in)
+            init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, input):
+        assert isinstance(input, SparseConvTensor)
+        features = input.features
+        indices = input.indices
+        spatial_shape = input.spatial_shape
+        batch_size = input.batch_size
+        if self.subm:
+            out_spatial_shape = spatial_shape
+        elif self.transposed:
+            out_spatial_shape = ops.get_deconv_output_size(spatial_shape, self.kernel_size, self.stride, self.padding,
+                                                           self.dilation, self.output_padding)
+        else:
+            out_spatial_shape = ops.get_conv_output_size(spatial_shape, self.kernel_size, self.stride, self.padding,
+                                                         self.dilation)
+        if self.conv1x1:  # reference conv.py:137-148: plain GEMM on the feature matrix
+            features = torch.mm(input.features, self.weight.view(self.in_channels, self.out_channels))
+            if self.bias is not None:
+                features += self.bias
+            out_tensor = SparseConvTensor(features, input.indices, input.spatial_shape, input.batch_size)
+            out_tensor.indice_dict = input.indice_dict
+            out_tensor.grid = input.grid
+            return out_tensor
+        datas = input.find_indice_pair(self.indice_key)
+        if self.inverse:
+            assert datas is not None and self.indice_key is not None
+            rb = datas
+            outids, out_spatial_shape = rb.indices, rb.spatial_shape
+            assert rb.kvol == np.prod(self.kernel_size), 'inverse conv must have same kernel size as its couple conv'
+        else:
+            if self.indice_key is not None and datas is not None:
+                rb = datas
+            else:
+                rb = ops.build_rulebook(indices, batch_size, spatial_shape, self.kernel_size, self.stride, self.padding,
+                                        self.dilation, self.output_padding, self.subm, self.transposed)
+                input.indice_dict[self.indice_key] = rb
+            outids = rb.outids
+        n_out = outids.shape[0]
+        if self.fused_bn:
+            assert self.bias is not None
+            out_features = ops.fused_indice_conv(features, self.weight, self.bias, rb, rb.indice_pair_num, n_out,
+                                                 self.inverse, self.subm)
+        else:
+            if self.subm:
+                out_features = Fsp.indice_subm_conv(features, self.weight, rb, rb.indice_pair_num, n_out)
+            elif self.inverse:
+                out_features = Fsp.indice_inverse_conv(features, self.weight, rb, rb.indice_pair_num, n_out)
+            else:
+                out_features = Fsp.indice_conv(features, self.weight, rb, rb.indice_pair_num, n_out)
+            if self.bias is not None:
+                out_features += self.bias
+        out_tensor = SparseConvTensor(out_features, outids, out_spatial_shape, batch_size)
+        out_tensor.indice_dict = input.indice_dict
+        out_tensor.grid = input.grid
+        return out_tensor
+
+
+def _make(name, ndim, **fixed):
+    """Builds the thin reference subclasses (conv.py:233-480)."""
+    takes_geometry = not fixed.get("inverse", False)
+
+    if takes_geometry:
+        def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                     indice_key=None):
+            SparseConvolution.__init__(self, ndim, in_channels, out_channels, kernel_size, stride, padding, dilation,
+                                       groups, bias, indice_key=indice_key, **fixed)
+    else:
+        def __init__(self, in_channels, out_channels, kernel_size, indice_key, bias=True):
+            SparseConvolution.__init__(self, ndim, in_channels, out_channels, kernel_size, bias=bias,
+                                       indice_key=indice_key, **fixed)
+    cls = type(name, (SparseConvolution,), {"__init__": __init__, "__module__": __name__})
+    return _register(cls)
+
+
+SparseConv2d = _make("SparseConv2d", 2)
+SparseConv3d = _make("SparseConv3d", 3)
+SparseConv4d = _make("SparseConv4d", 4)
+SparseConvTranspose2d = _make("SparseConvTranspose2d", 2, transposed=True)
+SparseConvTranspose3d = _make("SparseConvTranspose3d", 3, transposed=True)
+SparseInverseConv2d = _make("SparseInverseConv2d", 2, inverse=True)
+SparseInverseConv3d = _make("SparseInverseConv3d", 3, inverse=True)
+SubMConv2d = _make("SubMConv2d", 2, subm=True)
+SubMConv3d = _make("SubMConv3d", 3, subm=True)
+SubMConv4d = _make("SubMConv4d", 4, subm=True)

@@ -1,0 +1,121 @@
+"""SparseModule / SparseSequential / ToDense / RemoveGrid — surface of reference spconv/modules.py:46-202."""
+import sys
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from .structure import SparseConvTensor
+
+
+def is_spconv_module(module):
+    return isinstance(module, (SparseModule,))
+
+
+def is_sparse_conv(module):
+    from .conv import SparseConvolution
+    return isinstance(module, SparseConvolution)
+
+
+class SparseModule(nn.Module):
+    """Marker base class: subclasses receive the SparseConvTensor itself inside SparseSequential."""
+    pass
+
+
+class SparseSequential(SparseModule):
+    """Sequential container: sparse modules get the tensor, plain nn.Modules are applied to `.features`
+    in place (reference modules.py:125-136 — models rely on that in-place mutation)."""
+
+    def __init__(self, *args, **kwargs):
+        super(SparseSequential, self).__init__()
+        if len(args) == 1 and isinstance(args[0], OrderedDict):
+            for key, module in args[0].items():
+                self.add_module(key, module)
+        else:
+            for idx, module in enumerate(args):
+                self.add_module(str(idx), module)
+        for name, module in kwargs.items():
+            if sys.version_info < (3, 6):
+                raise ValueError('kwargs only supported in py36+')
+            if name in self._modules:
+                raise ValueError('name exists.')
+            self.add_module(name, module)
+        self._sparity_dict = {}
+
+    def __getitem__(self, idx):
+        if not (-len(self) <= idx < len(self)):
+            raise IndexError('index {} is out of range'.format(idx))
+        if idx < 0:
+            idx += len(self)
+        return list(self._modules.values())[idx]
+
+    def __len__(self):
+        return len(self._modules)
+
+    @property
+    def sparity_dict(self):
+        return self._sparity_dict
+
+    def add(self, module, name=None):
+        if name is None:
+            name = str(len(self._modules))
+            if name in self._modules:
+                raise KeyError('name exists')
+        self.add_module(name, module)
+
+    def forward(self, input):
+        for k, module in self._modules.items():
+            if is_spconv_module(module):
+                assert isinstance(input, SparseConvTensor)
+                self._sparity_dict[k] = input.sparity
+                input = module(input)
+            elif isinstance(input, SparseConvTensor):
+                if input.indices.shape[0] != 0:
+                    input.features = module(input.features)
+            else:
+                input = module(input)
+        return input
+
+    def fused(self):
+        """Folds every (SparseConvolution, BatchNorm1d) pair into one biased conv for inference
+        (the reference's `fused()` is documented "don't use this", modules.py:138-185; the folding here
+        uses the standard sqrt(var + eps) so the fused net equals conv -> eval-mode BN)."""
+        from .conv import SparseConvolution
+        mods = list(self._modules.values())
+        out, i = [], 0
+        while i < len(mods):
+            m = mods[i]
+            if is_sparse_conv(m) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm1d):
+                bn = mods[i + 1]
+                conv = SparseConvolution(ndim=m.ndim, in_channels=m.in_channels, out_channels=m.out_channels,
+                                         kernel_size=m.kernel_size, stride=m.stride, padding=m.padding,
+                                         dilation=m.dilation, groups=m.groups, bias=True, subm=m.subm,
+                                         output_padding=m.output_padding, transposed=m.transposed, inverse=m.inverse,
+                                         indice_key=m.indice_key, fused_bn=True)
+                conv.to(m.weight.device)
+                with torch.no_grad():
+                    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+                    conv.weight.copy_(m.weight * scale)
+                    b0 = m.bias if m.bias is not None else torch.zeros_like(bn.running_mean)
+                    conv.bias.copy_((b0 - bn.running_mean) * scale + bn.bias)
+                out.append(conv)
+                i += 2
+            else:
+                out.append(m)
+                i += 1
+        return SparseSequential(*out)
+
+
+class ToDense(SparseModule):
+    """SparseConvTensor -> dense N C (D) H W tensor."""
+
+    def forward(self, x: SparseConvTensor):
+        return x.dense()
+
+
+class RemoveGrid(SparseModule):
+    """Drops the (unused) pre-allocated grid buffer."""
+
+    def forward(self, x: SparseConvTensor):
+        x.grid = None
+        return x

@@ -1,0 +1,289 @@
+"""Host side of the sparse-conv hot path: same function names / argument meaning as the reference's
+spconv/ops.py:20-260, implemented on the C ABI of libfv2p_ops (include/fv2p_ops.h).
+
+A rulebook is held as a `Rulebook`: two dense neighbour tables (tab_in [K,n_in], tab_out [K,n_out])
+that the fused HIP conv kernels consume directly, plus — only when somebody asks — the reference's
+pair-list format (`indice_pairs [K,2,n_in]`, -1 padded; canonical order = ascending input row).
+"""
+import numpy as np
+import torch
+
+import fv2p_native as _nat
+
+
+def get_conv_output_size(input_size, kernel_size, stride, padding, dilation):
+    out = []
+    for i in range(len(input_size)):
+        size = (input_size[i] + 2 * padding[i] - dilation[i] * (kernel_size[i] - 1) - 1) // stride[i] + 1
+        out.append(1 if kernel_size[i] == -1 else size)
+    return out
+
+
+def get_deconv_output_size(input_size, kernel_size, stride, padding, dilation, output_padding):
+    out = []
+    for i in range(len(input_size)):
+        if kernel_size[i] == -1:
+            raise ValueError("deconv don't support kernel_size < 0")
+        out.append((input_size[i] - 1) * stride[i] - 2 * padding[i] + kernel_size[i] + output_padding[i])
+    return out
+
+
+def _as_list(v, ndim):
+    return list(v) if isinstance(v, (list, tuple)) else [v] * ndim
+
+
+def _pad3(v, fill):
+    v = [int(x) for x in v]
+    return [fill] * (3 - len(v)) + v
+
+
+class Rulebook(object):
+    """Neighbour tables of one (indice_key) rulebook.
+
+    Behaves like the reference's cached 5-tuple `(outids, indices, indice_pairs, indice_pair_num,
+    spatial_shape)` (conv.py:180-183) for unpacking / indexing; `indice_pairs` is materialised lazily."""
+
+    def __init__(self, outids, indices, tab_in, tab_out, indice_num, spatial_shape, kvol, subm):
+        self.outids, self.indices = outids, indices
+        self.tab_in, self.tab_out = tab_in, tab_out  # tab_out None => symmetric subm: tab_out[k] == tab_in[K-1-k]
+        self.indice_pair_num = indice_num
+        self.spatial_shape = spatial_shape
+        self.kvol, self.subm = kvol, subm
+        self.n_in, self.n_out = int(indices.shape[0]), int(outids.shape[0])
+        self._pairs = None
+
+    # -- tables as the kernels want them: (table, flip_k)
+    def out_table(self):
+        return (self.tab_in, 1) if self.tab_out is None else (self.tab_out, 0)
+
+    def in_table(self):
+        return (self.tab_in, 0)
+
+    @property
+    def indice_pairs(self):
+        if self._pairs is None:
+            pairs = torch.empty((self.kvol, 2, self.n_in), dtype=torch.int32, device=self.tab_in.device)
+            if self.n_in > 0:
+                with torch.cuda.device(pairs.device):
+                    nb = _nat.lib().fv2p_rulebook_pairs_ws_bytes(self.n_in, self.kvol)
+                    ws = _nat.workspace(nb, pairs.device)
+                    _nat.call("fv2p_rulebook_pairs", self.tab_in, self.n_in, self.kvol, pairs, ws, ws.numel(), _nat.stream())
+            pairs._fv2p_rulebook = self
+            self._pairs = pairs
+        return self._pairs
+
+    def _tuple(self):
+        return (self.outids, self.indices, self.indice_pairs, self.indice_pair_num, self.spatial_shape)
+
+    def __iter__(self):
+        return iter(self._tuple())
+
+    def __getitem__(self, i):
+        return self._tuple()[i]
+
+    def __len__(self):
+        return 5
+
+
+def build_rulebook(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1, out_padding=0,
+                   subm=False, transpose=False):
+    """Hashed rulebook build (fv2p_rulebook_begin/finish). Returns a `Rulebook`."""
+    _nat.require_cuda(indices)
+    ndim = indices.shape[1] - 1
+    if ndim not in (2, 3):
+        raise NotImplementedError("fv2p rulebook supports 2-D and 3-D sparse tensors")
+    ksize, stride, padding = _as_list(ksize, ndim), _as_list(stride, ndim), _as_list(padding, ndim)
+    dilation, out_padding = _as_list(dilation, ndim), _as_list(out_padding, ndim)
+    for d, s in zip(dilation, stride):
+        assert any([s == 1, d == 1]), "don't support this."
+    spatial_shape = [int(s) for s in spatial_shape]
+    if subm:
+        out_shape = spatial_shape
+    elif transpose:
+        out_shape = get_deconv_output_size(spatial_shape, ksize, stride, padding, dilation, out_padding)
+    else:
+        out_shape = get_conv_output_size(spatial_shape, ksize, stride, padding, dilation)
+    if indices.dtype != torch.int32:
+        indices = indices.int()
+    indices = indices.contiguous()
+    ind4 = indices
+    if ndim == 2:  # embed (b, y, x) as (b, 0, y, x)
+        ind4 = torch.cat([indices[:, :1], torch.zeros_like(indices[:, :1]), indices[:, 1:]], dim=1).contiguous()
+    g = dict(in_shape=_pad3(spatial_shape, 1), out_shape=_pad3(out_shape, 1), ksize=_pad3(ksize, 1),
+             stride=_pad3(stride, 1), padding=_pad3(padding, 0), dilation=_pad3(dilation, 1))
+    kvol = int(np.prod(ksize))
+    n_in = int(indices.shape[0])
+    dev = indices.device
+    symmetric = bool(subm) and all(k % 2 == 1 for k in ksize) and all(d == 1 for d in dilation)
+    with torch.cuda.device(dev):
+        lib = _nat.lib()
+        import ctypes
+        arr = lambda v: (ctypes.c_int * 3)(*v)
+        ws_bytes = lib.fv2p_rulebook_ws_bytes(n_in, arr(g["ksize"]), arr(g["stride"]), arr(g["dilation"]), int(subm), int(transpose))
+        ws = _nat.workspace(ws_bytes, dev)
+        n_out_host = ctypes.c_int64(0)
+        geom = (g["in_shape"], g["out_shape"], g["ksize"], g["stride"], g["padding"], g["dilation"], int(subm), int(transpose))
+        _nat.call("fv2p_rulebook_begin", ind4, n_in, int(batch_size), *geom, ctypes.addressof(n_out_host), ws, ws.numel(), _nat.stream())
+        n_out = int(n_out_host.value)
+        tab_in = torch.empty((kvol, n_in), dtype=torch.int32, device=dev)
+        num = torch.empty((kvol,), dtype=torch.int32, device=dev)
+        if subm:
+            outids4, tab_out = None, (None if symmetric else torch.empty((kvol, n_out), dtype=torch.int32, device=dev))
+        else:
+            outids4 = torch.empty((n_out, 4), dtype=torch.int32, device=dev)
+            tab_out = torch.empty((kvol, n_out), dtype=torch.int32, device=dev)
+        _nat.call("fv2p_rulebook_finish", ind4, n_in, int(batch_size), *geom, n_out, outids4, tab_in, tab_out, num, ws, ws.numel(),
+                  _nat.stream())
+    if subm:
+        outids = indices
+    elif ndim == 2:
+        outids = outids4[:, [0, 2, 3]].contiguous()
+    else:
+        outids = outids4
+    rb = Rulebook(outids, indices, tab_in, tab_out, num, spatial_shape, kvol, bool(subm))
+    rb.out_spatial_shape = out_shape
+    return rb
+
+
+def get_indice_pairs(indices, batch_size, spatial_shape, ksize=3, stride=1, padding=0, dilation=1, out_padding=0,
+                     subm=False, transpose=False, grid=None):
+    """Reference signature (ops.py:46-105): returns (outids, indice_pairs [K,2,N], indice_pair_num [K]).
+    `grid` (pre-allocated dense grid of the reference) is accepted and ignored."""
+    rb = build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, out_padding, subm, transpose)
+    return rb.outids, rb.indice_pairs, rb.indice_pair_num
+
+
+def _rulebook_of(indice_pairs, indice_pair_num, n_src_rows, num_activate_out, inverse):
+    """Accepts a Rulebook, a pair tensor produced by this package, or a foreign pair tensor."""
+    if isinstance(indice_pairs, Rulebook):
+        return indice_pairs
+    rb = getattr(indice_pairs, "_fv2p_rulebook", None)
+    if rb is not None:
+        return rb
+    # foreign rulebook in the reference format: rebuild the tables on the device
+    _nat.require_cuda(indice_pairs)
+    pairs = indice_pairs.int().contiguous()
+    num = indice_pair_num.to(device=pairs.device, dtype=torch.int32).contiguous()
+    kvol, _, plen = pairs.shape
+    n_in = n_src_rows if not inverse else num_activate_out
+    n_out = num_activate_out if not inverse else n_src_rows
+    tab_in = torch.empty((kvol, n_in), dtype=torch.int32, device=pairs.device)
+    tab_out = torch.empty((kvol, n_out), dtype=torch.int32, device=pairs.device)
+    with torch.cuda.device(pairs.device):
+        _nat.call("fv2p_pairs_to_tables", pairs, num, kvol, plen, n_in, n_out, tab_in, tab_out, _nat.stream())
+    rb = Rulebook.__new__(Rulebook)
+    rb.outids = rb.indices = None
+    rb.tab_in, rb.tab_out, rb.indice_pair_num = tab_in, tab_out, num
+    rb.spatial_shape, rb.kvol, rb.subm, rb.n_in, rb.n_out, rb._pairs = None, kvol, False, n_in, n_out, pairs
+    indice_pairs._fv2p_rulebook = rb
+    return rb
+
+
+def _conv_rows(src, weight, table, flip, n_dst, c_dst, transpose_w, bias=None):
+    _nat.require_cuda(src, weight, table)
+    half = src.dtype == torch.half
+    if half:  # the reference binds *_half entry points (all.cc:36-51); computed here in fp32
+        src, weight = src.float(), weight.float()
+        bias = None if bias is None else bias.float()
+    if src.dtype != torch.float32 or weight.dtype != torch.float32:
+        raise NotImplementedError("sparse conv: float32 / float16 only")
+    src = src.contiguous()
+    w = weight.contiguous()
+    kvol = table.shape[0]
+    dst = torch.empty((n_dst, c_dst), dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        _nat.call("fv2p_sparse_conv_rows", src, src.shape[0], src.shape[1], w, kvol, table, n_dst, c_dst, int(flip),
+                  int(transpose_w), bias.contiguous() if bias is not None else None, dst, _nat.stream())
+    return dst.half() if half else dst
+
+
+def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_out, inverse=False, subm=False, bias=None):
+    """out[o] = sum_k feat[i] W_k over the rulebook (reference ops.py:108-126 -> spconv_ops.h:260-362)."""
+    rb = _rulebook_of(indice_pairs, indice_pair_num, features.shape[0], num_activate_out, inverse)
+    cin, cout = filters.shape[-2], filters.shape[-1]
+    w = filters.reshape(-1, cin, cout)
+    table, flip = rb.in_table() if inverse else rb.out_table()
+    return _conv_rows(features, w, table, flip, num_activate_out, cout, False, bias)
+
+
+def fused_indice_conv(features, filters, bias, indice_pairs, indice_pair_num, num_activate_out, inverse, subm):
+    """conv + bias in the kernel epilogue (reference ops.py:129-139 -> fused_spconv_ops.h:28-131)."""
+    return indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_out, inverse, subm, bias=bias)
+
+
+def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_num, inverse=False, subm=False):
+    """Returns [d_features, d_filters] (reference ops.py:142-157 -> spconv_ops.h:364-457)."""
+    rb = _rulebook_of(indice_pairs, indice_pair_num, features.shape[0], out_bp.shape[0], inverse)
+    cin, cout = filters.shape[-2], filters.shape[-1]
+    half = features.dtype == torch.half
+    f32 = lambda t: t.float() if half else t
+    feats, w, g = f32(features).contiguous(), f32(filters).reshape(-1, cin, cout).contiguous(), f32(out_bp).contiguous()
+    kvol = w.shape[0]
+    # forward used table F (dst rows = outputs); its transpose-direction table B has dst rows = inputs
+    (tab_f, flip_f), (tab_b, flip_b) = (rb.in_table(), rb.out_table()) if inverse else (rb.out_table(), rb.in_table())
+    din = _conv_rows(g, w, tab_b, flip_b, features.shape[0], cin, True)
+    dw = torch.empty_like(w)
+    with torch.cuda.device(feats.device):
+        _nat.call("fv2p_sparse_conv_wgrad", feats, feats.shape[0], cin, g, tab_f, g.shape[0], cout, kvol, int(flip_f), dw, _nat.stream())
+    dw = dw.reshape(filters.shape)
+    if half:
+        din, dw = din.half(), dw.half()
+    return [din, dw]
+
+
+# ---- max-pool / group over the same tables (A7; reference pool_ops.h:25-94, group_ops.h:29-291) ----
+def indice_maxpool(features, indice_pairs, indice_pair_num, num_activate_out):
+    rb = _rulebook_of(indice_pairs, indice_pair_num, features.shape[0], num_activate_out, False)
+    table, flip = rb.out_table()
+    return _table_maxpool(features, table, flip, num_activate_out)
+
+
+def indice_maxpool_backward(features, out_features, out_bp, indice_pairs, indice_pair_num):
+    rb = _rulebook_of(indice_pairs, indice_pair_num, features.shape[0], out_features.shape[0], False)
+    table, flip = rb.in_table()
+    return _table_maxpool_backward(features, out_features, out_bp, table)
+
+
+def _table_maxpool(features, table, flip, n_out):
+    _nat.require_cuda(features)
+    half = features.dtype == torch.half
+    f = features.float().contiguous()
+    out = torch.empty((n_out, f.shape[1]), dtype=torch.float32, device=f.device)
+    with torch.cuda.device(f.device):
+        _nat.call("fv2p_sparse_maxpool_fwd", f, f.shape[0], f.shape[1], table, table.shape[0], n_out, int(flip), out, _nat.stream())
+    return out.half() if half else out
+
+
+def _table_maxpool_backward(features, out_features, out_bp, tab_in):
+    half = features.dtype == torch.half
+    f, o, g = features.float().contiguous(), out_features.float().contiguous(), out_bp.float().contiguous()
+    din = torch.empty_like(f)
+    with torch.cuda.device(f.device):
+        _nat.call("fv2p_sparse_maxpool_bwd", f, o, g, f.shape[0], f.shape[1], tab_in, tab_in.shape[0], din, _nat.stream())
+    return din.half() if half else din
+
+
+def indice_group(features, indice_pairs, indice_pair_num, num_activate_out, inverse=False, subm=False):
+    """[K, n_out, C] gather of neighbour features, zeros where no neighbour (reference ops.py:196-211)."""
+    if features.dtype != torch.float32:
+        raise NotImplementedError
+    rb = _rulebook_of(indice_pairs, indice_pair_num, features.shape[0], num_activate_out, inverse)
+    table, flip = rb.in_table() if inverse else rb.out_table()
+    f = features.contiguous()
+    out = torch.empty((table.shape[0], num_activate_out, f.shape[1]), dtype=torch.float32, device=f.device)
+    with torch.cuda.device(f.device):
+        _nat.call("fv2p_sparse_group_fwd", f, f.shape[0], f.shape[1], table, table.shape[0], num_activate_out, int(flip), out, _nat.stream())
+    return out
+
+
+def indice_group_backward(features, out_bp, indice_pairs, indice_pair_num, inverse=False, subm=False):
+    """d_features[i] = sum_k out_bp[k, tab_in[k][i]] (reference ops.py:214-230)."""
+    if features.dtype != torch.float32:
+        raise NotImplementedError
+    rb = _rulebook_of(indice_pairs, indice_pair_num, features.shape[0], out_bp.shape[1], inverse)
+    table, flip = rb.out_table() if inverse else rb.in_table()
+    g = out_bp.contiguous()
+    din = torch.empty((features.shape[0], features.shape[1]), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        _nat.call("fv2p_sparse_group_bwd", g, g.shape[1], g.shape[2], table, table.shape[0], features.shape[0], int(flip), din, _nat.stream())
+    return din

@@ -1,0 +1,53 @@
+"""SparseConvTensor container — same surface as the reference's spconv/structure.py:5-71."""
+import numpy as np
+import torch
+
+
+def scatter_nd(indices, updates, shape):
+    """Dense tensor of `shape` with `updates` written at `indices` (no duplicate handling),
+    cf. reference structure.py:5-18."""
+    ret = torch.zeros(*shape, dtype=updates.dtype, device=updates.device)
+    ndim = indices.shape[-1]
+    flat = indices.reshape(-1, ndim)
+    out_shape = list(indices.shape[:-1]) + list(shape[ndim:])
+    ret[tuple(flat[:, i] for i in range(ndim)) + (Ellipsis,)] = updates.reshape(*out_shape)
+    return ret
+
+
+class SparseConvTensor(object):
+    """features [N,C] f32, indices [N,1+ndim] i32 (batch, z, y, x), spatial_shape, batch_size.
+
+    `indice_dict` caches rulebooks per indice_key and is shared by reference between the tensors
+    of one network pass (reference conv.py:227); `grid` is kept for API compatibility only — the
+    hashed rulebook builder never needs a pre-allocated dense grid."""
+
+    def __init__(self, features, indices, spatial_shape, batch_size, grid=None):
+        self.features = features
+        self.indices = indices if indices.dtype == torch.int32 else indices.int()
+        self.spatial_shape = spatial_shape
+        self.batch_size = batch_size
+        self.indice_dict = {}
+        self.grid = grid
+
+    @property
+    def spatial_size(self):
+        return np.prod(self.spatial_shape)
+
+    def find_indice_pair(self, key):
+        if key is None:
+            return None
+        return self.indice_dict.get(key, None)
+
+    def dense(self, channels_first=True):
+        out_shape = [self.batch_size] + list(self.spatial_shape) + [self.features.shape[1]]
+        res = scatter_nd(self.indices.long(), self.features, out_shape)
+        if not channels_first:
+            return res
+        ndim = len(self.spatial_shape)
+        perm = list(range(0, ndim + 1))
+        perm.insert(1, ndim + 1)
+        return res.permute(*perm).contiguous()
+
+    @property
+    def sparity(self):
+        return self.indices.shape[0] / np.prod(self.spatial_shape) / self.batch_size

@@ -54,3 +54,138 @@ def points_to_voxel(points, voxel_size, coors_range, max_points, max_voxels, scr
     if m < 0:
         raise MemoryError("oracle_points_to_voxel")
     return voxels[:m], coors[:m], num[:m]
+
+
+# ---------------------------------------------------------------- spconv rulebook -----------
+def _conv_out_shape(shape, k, s, p, d):
+    return [(shape[i] + 2 * p[i] - d[i] * (k[i] - 1) - 1) // s[i] + 1 for i in range(len(shape))]
+
+
+def _deconv_out_shape(shape, k, s, p, d, op):
+    return [(shape[i] - 1) * s[i] - 2 * p[i] + k[i] + op[i] for i in range(len(shape))]
+
+
+def indice_pairs(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, out_padding=(0, 0, 0),
+                 subm=False, transpose=False, canonical=True, force_sparse=False):
+    """spconv_ops.h:27-140 (getIndicePair<3>) on the CPU functors of geometry.h, restated in rulebook_oracle.c.
+    canonical=True returns the GPU reference's output order (sorted flat index, spconv_ops.h:130) for conv;
+    canonical=False keeps the CPU reference's first-touch order.  Returns (outids [M,4], pairs [K,2,N], num [K])."""
+    ind = np.ascontiguousarray(indices, dtype=np.int32)
+    n = ind.shape[0]
+    i3 = lambda v: np.ascontiguousarray(v, dtype=np.int32)
+    k, d = i3(ksize), i3(dilation)
+    kvol = int(np.prod(k))
+    pairs = np.full((kvol, 2, max(n, 1)), -1, np.int32)[:, :, :n].copy() if n else np.full((kvol, 2, 0), -1, np.int32)
+    pairs = np.ascontiguousarray(pairs)
+    num = np.zeros((kvol,), np.int32)
+    L = lib()
+    pi = ctypes.POINTER(_i32)
+    if subm:
+        s, p = i3([1, 1, 1]), i3([kk // 2 for kk in ksize])  # spconv_ops.h:76-80
+        out_shape = i3(spatial_shape)
+        f = L.oracle_indice_pairs_subm
+        f.restype = ctypes.c_int
+        f.argtypes = [pi, _i32, _i32, pi, pi, pi, pi, pi, pi, pi, ctypes.c_int]
+        r = f(_p(ind, _i32), n, batch_size, _p(k, _i32), _p(s, _i32), _p(p, _i32), _p(d, _i32), _p(out_shape, _i32),
+              _p(pairs, _i32), _p(num, _i32), int(force_sparse))
+        assert r >= 0
+        return ind.copy(), pairs, num
+    s, p = i3(stride), i3(padding)
+    if transpose:
+        out_shape = i3(_deconv_out_shape(list(spatial_shape), list(ksize), list(stride), list(padding), list(dilation), list(out_padding)))
+    else:
+        out_shape = i3(_conv_out_shape(list(spatial_shape), list(ksize), list(stride), list(padding), list(dilation)))
+    out_ids = np.zeros((max(n * kvol, 1), 4), np.int32)
+    f = L.oracle_indice_pairs_conv
+    f.restype = ctypes.c_int
+    f.argtypes = [pi, _i32, _i32, pi, pi, pi, pi, pi, ctypes.c_int, pi, pi, pi, ctypes.c_int]
+    m = f(_p(ind, _i32), n, batch_size, _p(k, _i32), _p(s, _i32), _p(p, _i32), _p(d, _i32), _p(out_shape, _i32),
+          int(transpose), _p(out_ids, _i32), _p(pairs, _i32), _p(num, _i32), int(force_sparse))
+    assert m >= 0
+    if canonical:
+        g = L.oracle_canonicalize_conv
+        g.restype = ctypes.c_int
+        g.argtypes = [pi, _i32, pi, pi, pi, _i32, _i32]
+        assert g(_p(out_ids, _i32), m, _p(out_shape, _i32), _p(pairs, _i32), _p(num, _i32), kvol, n) == 0
+    return out_ids[:m].copy(), pairs, num
+
+
+def indice_conv(features, filters, pairs, num, n_out, inverse=False, subm=False):
+    """spconv_ops.h:260-362 (indiceConv<float>) restated with torch CPU ops: zeros output, subM centre GEMM
+    first (:300-304), then k = 0..K-1 gather -> mm -> scatter-add (:308-357).  fp32."""
+    import torch
+    feats = torch.as_tensor(features, dtype=torch.float32)
+    w = torch.as_tensor(filters, dtype=torch.float32)
+    cin, cout = w.shape[-2], w.shape[-1]
+    w = w.reshape(-1, cin, cout)
+    pairs_t = torch.as_tensor(np.asarray(pairs)).long()
+    num = np.asarray(num)
+    kvol = w.shape[0]
+    out = torch.zeros((n_out, cout), dtype=torch.float32)
+    centre = int(np.argmax(num)) if subm else -1  # spconv_ops.h:272-277
+    if subm:
+        out = torch.mm(feats, w[centre])
+    a, b = (1, 0) if inverse else (0, 1)
+    for k in range(kvol):
+        nh = int(num[k])
+        if nh <= 0 or (subm and k == centre):
+            continue
+        out.index_add_(0, pairs_t[k, b, :nh], torch.mm(feats[pairs_t[k, a, :nh]], w[k]))
+    return out
+
+
+def indice_conv_backward(features, filters, out_bp, pairs, num, inverse=False, subm=False):
+    """spconv_ops.h:364-457 restated: dW_k = gather(feat)^T gather(dout); dX[in] += dout[out] W_k^T."""
+    import torch
+    feats = torch.as_tensor(features, dtype=torch.float32)
+    w = torch.as_tensor(filters, dtype=torch.float32)
+    g = torch.as_tensor(out_bp, dtype=torch.float32)
+    cin, cout = w.shape[-2], w.shape[-1]
+    w3 = w.reshape(-1, cin, cout)
+    pairs_t = torch.as_tensor(np.asarray(pairs)).long()
+    num = np.asarray(num)
+    din = torch.zeros_like(feats)
+    dw = torch.zeros_like(w3)
+    a, b = (1, 0) if inverse else (0, 1)
+    for k in range(w3.shape[0]):
+        nh = int(num[k])
+        if nh <= 0:
+            continue
+        fi, go = feats[pairs_t[k, a, :nh]], g[pairs_t[k, b, :nh]]
+        dw[k] = fi.t() @ go
+        din.index_add_(0, pairs_t[k, a, :nh], go @ w3[k].t())
+    return din, dw.reshape(w.shape)
+
+
+def indice_maxpool(features, pairs, num, n_out):
+    """pool_ops.h:25-57 + maxpool.cc: zero-initialised output, out = max(out, in) per pair."""
+    f = np.asarray(features, dtype=np.float32)
+    out = np.zeros((n_out, f.shape[1]), np.float32)
+    for k in range(pairs.shape[0]):
+        nh = int(num[k])
+        if nh:
+            np.maximum.at(out, pairs[k, 1, :nh], f[pairs[k, 0, :nh]])
+    return out
+
+
+def indice_maxpool_backward(features, out_features, out_bp, pairs, num):
+    """pool_ops.h:59-94: din[i] += dout[o] where in[i] == out[o]."""
+    f, o, g = (np.asarray(x, dtype=np.float32) for x in (features, out_features, out_bp))
+    din = np.zeros_like(f)
+    for k in range(pairs.shape[0]):
+        nh = int(num[k])
+        if nh:
+            i, oo = pairs[k, 0, :nh], pairs[k, 1, :nh]
+            np.add.at(din, i, np.where(f[i] == o[oo], g[oo], 0).astype(np.float32))
+    return din
+
+
+def indice_group(features, pairs, num, n_out):
+    """group_ops.h:29-140: out[k, o, :] = feat[i, :] for every pair (i, o) of offset k, zeros elsewhere."""
+    f = np.asarray(features, dtype=np.float32)
+    out = np.zeros((pairs.shape[0], n_out, f.shape[1]), np.float32)
+    for k in range(pairs.shape[0]):
+        nh = int(num[k])
+        if nh:
+            out[k, pairs[k, 1, :nh]] = f[pairs[k, 0, :nh]]
+    return out
