@@ -54,14 +54,26 @@ def build_step(args, device, rank, world):
     torch.manual_seed(0)
     cls = VoxelBackBone8x if args.backbone == "8x" else VoxelResBackBone8x
     model = cls(4, [1408, 1600, 40]).to(device)
-    net = model
-    if world > 1:
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index], find_unused_parameters=True)
+    from fv2p_harness import dist_utils
+
+    class TrainStep(torch.nn.Module):
+        """What DistributedDataParallel wraps: returns the loss tensor (DDP traces used parameters from tensors in the
+        forward output, as with the reference's detectors, tools/train_utils/train_utils.py:27)."""
+
+        def __init__(self, body):
+            super().__init__()
+            self.body = body
+
+        def forward(self, feats, coords, batch):
+            out, _ = self.body(feats, coords, batch)
+            return out.features.square().mean()
+
+    net = dist_utils.wrap_ddp(TrainStep(model), device)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.01)
     # a small pool of distinct batches, points resident in HBM; seeds differ per rank
     n_pool = 4
-    pool = [[torch.from_numpy(synth.lidar_cloud(1000 * rank + 10 * j + b, args.points)).to(device) for b in range(args.batch)]
-            for j in range(n_pool)]
+    pool = [[torch.from_numpy(synth.lidar_cloud(seed, args.points)).to(device) for seed in seeds]
+            for seeds in dist_utils.rank_seeds(rank, n_pool, args.batch)]
 
     def voxelize(clouds):
         feats, coords = [], []
@@ -73,8 +85,7 @@ def build_step(args, device, rank, world):
 
     def step(i):
         feats, coords = voxelize(pool[i % n_pool])
-        out, _ = net(feats, coords, args.batch)
-        loss = out.features.square().mean()
+        loss = net(feats, coords, args.batch)
         opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()
@@ -144,7 +155,13 @@ def cpu_baseline(model, args):
     from fv2p_harness.backbone import mean_vfe
     from oracle.spconv_cpu import cpu_mirror
 
-    cores = os.cpu_count() or 1
+    # threads actually used: the cores this process may run on, capped (torch's small per-offset mm / index_add
+    # calls stop scaling long before that, and oversubscribing a cgroup-limited box is pathological)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
     torch.set_num_threads(cores)
     ref = cpu_mirror(model)
     n = max(1, args.cpu_clouds)
@@ -162,7 +179,7 @@ def cpu_baseline(model, args):
         ref.zero_grad(set_to_none=True)
         out.features.square().mean().backward()
         done += len(chunk)
-        if time.perf_counter() - t0 > 40.0:
+        if time.perf_counter() - t0 > 25.0:
             break
     dt = time.perf_counter() - t0
     return {"value": round(done / dt, 3), "unit": "point clouds/s", "cores": cores, "kind": "port",
@@ -172,35 +189,26 @@ def cpu_baseline(model, args):
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from fv2p_harness import dist_utils
+    rank, world, local = dist_utils.env_world()
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+    dist_utils.init_distributed("nccl", device)
     import fv2p_native
     fv2p_native.lib()
 
     model, step, voxelize, pool = build_step(args, device, rank, world)
     for i in range(args.warmup):
         step(i)
-    if world > 1:
-        dist.barrier()
+    dist_utils.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
-    if world > 1:
-        dist.barrier()
+    dist_utils.barrier()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = dist_utils.max_over_ranks(time.perf_counter() - t0, device)
     result = None
     if rank == 0:
         clouds = args.batch * world * args.steps

@@ -1,0 +1,285 @@
+// A16 — rotated BEV overlap / IoU and rotated / axis-aligned NMS.
+//
+// Replaces iou3d_nms_cuda.{boxes_overlap_bev_gpu, boxes_iou_bev_gpu, nms_gpu, nms_normal_gpu, boxes_iou_bev_cpu}
+// (pcdet/ops/iou3d_nms/src/iou3d_nms_api.cpp:11-17, iou3d_nms.cpp:49-187, iou3d_nms_kernel.cu:104-372,
+// iou3d_cpu.cpp:232-252).  The polygon-clipping arithmetic follows box_overlap() of the reference step by
+// step in fp32 (rotate corners, 16 edge intersections, corner containment with MARGIN 1e-2, bubble sort by
+// atan2 around the centroid, shoelace); sin/cos/atan2 come from include/fv2p_math.h so that host and device
+// agree bit for bit.
+//
+// NMS: the 64x64 tile of the suppression bit-matrix is exactly one wave64 (one box row per lane); only the
+// upper-triangular tiles are computed (the greedy pass never reads the others, iou3d_nms.cpp:121-135).
+// The greedy pass itself runs on the device (single workgroup: in-register scan of each 64-box diagonal
+// tile + parallel OR of the kept rows), which removes the reference's N*N/8-byte mask D2H copy
+// (10.2 MB at N=9000) and its host loop.
+#include "common.hpp"
+#include "../../include/fv2p_math.h"
+
+namespace fv2p {
+
+struct P2 { float x, y; };
+
+FV2P_HD float cross2(const P2& a, const P2& b) { return a.x * b.y - a.y * b.x; }
+FV2P_HD float cross3(const P2& p1, const P2& p2, const P2& p0) {
+  return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y);
+}
+FV2P_HD float fmin2(float a, float b) { return a < b ? a : b; }
+FV2P_HD float fmax2(float a, float b) { return a > b ? a : b; }
+
+FV2P_HD int rect_cross(const P2& p1, const P2& p2, const P2& q1, const P2& q2) {
+  return fmin2(p1.x, p2.x) <= fmax2(q1.x, q2.x) && fmin2(q1.x, q2.x) <= fmax2(p1.x, p2.x) &&
+         fmin2(p1.y, p2.y) <= fmax2(q1.y, q2.y) && fmin2(q1.y, q2.y) <= fmax2(p1.y, p2.y);
+}
+
+FV2P_HD int in_box2d(const float* box, const P2& p) {  // iou3d_nms_kernel.cu:51-62
+  const float MARGIN = 1e-2f;
+  const float cx = box[0], cy = box[1];
+  const float ac = fv2p_cosf(-box[6]), as = fv2p_sinf(-box[6]);
+  const float rx = (p.x - cx) * ac + (p.y - cy) * (-as);
+  const float ry = (p.x - cx) * as + (p.y - cy) * ac;
+  return (fabsf(rx) < box[3] / 2 + MARGIN && fabsf(ry) < box[4] / 2 + MARGIN);
+}
+
+FV2P_HD int seg_intersection(const P2& p1, const P2& p0, const P2& q1, const P2& q0, P2* ans) {  // :64-95
+  const float EPS = 1e-8f;
+  if (rect_cross(p0, p1, q0, q1) == 0) return 0;
+  const float s1 = cross3(q0, p1, p0);
+  const float s2 = cross3(p1, q1, p0);
+  const float s3 = cross3(p0, q1, q0);
+  const float s4 = cross3(q1, p1, q0);
+  if (!(s1 * s2 > 0 && s3 * s4 > 0)) return 0;
+  const float s5 = cross3(q1, p1, p0);
+  if (fabsf(s5 - s1) > EPS) {
+    ans->x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
+    ans->y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
+  } else {
+    const float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
+    const float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
+    const float D = a0 * b1 - a1 * b0;
+    ans->x = (b0 * c1 - b1 * c0) / D;
+    ans->y = (a1 * c0 - a0 * c1) / D;
+  }
+  return 1;
+}
+
+FV2P_HD void rot_center(const P2& c, float ac, float as, P2* p) {
+  const float nx = (p->x - c.x) * ac + (p->y - c.y) * (-as) + c.x;
+  const float ny = (p->x - c.x) * as + (p->y - c.y) * ac + c.y;
+  p->x = nx; p->y = ny;
+}
+
+FV2P_HD float box_overlap(const float* a, const float* b) {  // :104-225
+  const float a_angle = a[6], b_angle = b[6];
+  const float a_dx = a[3] / 2, b_dx = b[3] / 2, a_dy = a[4] / 2, b_dy = b[4] / 2;
+  const float ax1 = a[0] - a_dx, ay1 = a[1] - a_dy, ax2 = a[0] + a_dx, ay2 = a[1] + a_dy;
+  const float bx1 = b[0] - b_dx, by1 = b[1] - b_dy, bx2 = b[0] + b_dx, by2 = b[1] + b_dy;
+  const P2 ca = {a[0], a[1]}, cb = {b[0], b[1]};
+  P2 A[5] = {{ax1, ay1}, {ax2, ay1}, {ax2, ay2}, {ax1, ay2}, {0, 0}};
+  P2 B[5] = {{bx1, by1}, {bx2, by1}, {bx2, by2}, {bx1, by2}, {0, 0}};
+  const float acs = fv2p_cosf(a_angle), asn = fv2p_sinf(a_angle);
+  const float bcs = fv2p_cosf(b_angle), bsn = fv2p_sinf(b_angle);
+  for (int k = 0; k < 4; ++k) {
+    rot_center(ca, acs, asn, &A[k]);
+    rot_center(cb, bcs, bsn, &B[k]);
+  }
+  A[4] = A[0];
+  B[4] = B[0];
+  P2 pts[16];
+  P2 center = {0.f, 0.f};
+  int cnt = 0;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j)
+      if (seg_intersection(A[i + 1], A[i], B[j + 1], B[j], &pts[cnt])) {
+        center.x = center.x + pts[cnt].x;
+        center.y = center.y + pts[cnt].y;
+        ++cnt;
+      }
+  for (int k = 0; k < 4; ++k) {
+    if (in_box2d(a, B[k])) {
+      center.x = center.x + B[k].x; center.y = center.y + B[k].y;
+      pts[cnt++] = B[k];
+    }
+    if (in_box2d(b, A[k])) {
+      center.x = center.x + A[k].x; center.y = center.y + A[k].y;
+      pts[cnt++] = A[k];
+    }
+  }
+  if (cnt == 0) return 0.f;  // reference divides by zero here and then sums an empty polygon: 0
+  center.x /= cnt;
+  center.y /= cnt;
+  float ang[16];
+  for (int i = 0; i < cnt; ++i) ang[i] = fv2p_atan2f(pts[i].y - center.y, pts[i].x - center.x);
+  for (int j = 0; j < cnt - 1; ++j)
+    for (int i = 0; i < cnt - j - 1; ++i)
+      if (ang[i] > ang[i + 1]) {
+        const P2 t = pts[i]; pts[i] = pts[i + 1]; pts[i + 1] = t;
+        const float ta = ang[i]; ang[i] = ang[i + 1]; ang[i + 1] = ta;
+      }
+  float area = 0.f;
+  for (int k = 0; k < cnt - 1; ++k) {
+    const P2 u = {pts[k].x - pts[0].x, pts[k].y - pts[0].y};
+    const P2 v = {pts[k + 1].x - pts[0].x, pts[k + 1].y - pts[0].y};
+    area += cross2(u, v);
+  }
+  return fabsf(area) / 2.0f;
+}
+
+FV2P_HD float iou_bev(const float* a, const float* b) {  // :227-234
+  const float sa = a[3] * a[4], sb = b[3] * b[4];
+  const float s = box_overlap(a, b);
+  return s / fmax2(sa + sb - s, 1e-8f);
+}
+
+FV2P_HD float iou_normal(const float* a, const float* b) {  // :314-325
+  const float left = fmax2(a[0] - a[3] / 2, b[0] - b[3] / 2), right = fmin2(a[0] + a[3] / 2, b[0] + b[3] / 2);
+  const float top = fmax2(a[1] - a[4] / 2, b[1] - b[4] / 2), bottom = fmin2(a[1] + a[4] / 2, b[1] + b[4] / 2);
+  const float width = fmax2(right - left, 0.f), height = fmax2(bottom - top, 0.f);
+  const float inter = width * height;
+  return inter / fmax2(a[3] * a[4] + b[3] * b[4] - inter, 1e-8f);
+}
+
+template <int MODE>  // 0 overlap, 1 iou
+__global__ void pairwise_bev(int na, const float* __restrict__ A, int nb, const float* __restrict__ B, float* __restrict__ out) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= static_cast<int64_t>(na) * nb) return;
+  const int ia = static_cast<int>(t / nb), ib = static_cast<int>(t % nb);
+  float a[7], b[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) { a[j] = A[ia * 7 + j]; b[j] = B[ib * 7 + j]; }
+  out[t] = MODE == 0 ? box_overlap(a, b) : iou_bev(a, b);
+}
+
+// one wave per upper-triangular 64x64 tile; lane = row box, loop over the 64 column boxes staged in LDS
+template <int NORMAL>
+__global__ __launch_bounds__(64) void nms_mask(int n, float thresh, const float* __restrict__ boxes, int col_blocks,
+                                               unsigned long long* __restrict__ mask) {
+  // linear tile id -> (row_blk, col_blk) with col_blk >= row_blk
+  int t = blockIdx.x, rb = 0, rem = col_blocks;
+  while (t >= rem) { t -= rem; --rem; ++rb; }
+  const int cb = rb + t;
+  __shared__ float cbox[64 * 7];
+  const int lane = threadIdx.x;
+  const int col_size = min(n - cb * 64, 64), row_size = min(n - rb * 64, 64);
+  if (lane < col_size)
+    for (int j = 0; j < 7; ++j) cbox[lane * 7 + j] = boxes[(cb * 64 + lane) * 7 + j];
+  __syncthreads();
+  if (lane < row_size) {
+    const int row = rb * 64 + lane;
+    float a[7];
+    for (int j = 0; j < 7; ++j) a[j] = boxes[row * 7 + j];
+    unsigned long long bits = 0ull;
+    const int start = (rb == cb) ? lane + 1 : 0;
+    for (int i = start; i < col_size; ++i) {
+      const float v = NORMAL ? iou_normal(a, cbox + i * 7) : iou_bev(a, cbox + i * 7);
+      if (v > thresh) bits |= 1ull << i;
+    }
+    mask[static_cast<int64_t>(row) * col_blocks + cb] = bits;
+  }
+}
+
+// Greedy pass of iou3d_nms.cpp:121-135 on the device: one workgroup, remv[] in LDS.
+__global__ __launch_bounds__(256) void nms_greedy(int n, int col_blocks, const unsigned long long* __restrict__ mask,
+                                                  long long* __restrict__ keep, int* __restrict__ num_keep) {
+  extern __shared__ unsigned long long remv[];  // [col_blocks]
+  __shared__ unsigned long long s_kept;
+  __shared__ int s_count;
+  for (int j = threadIdx.x; j < col_blocks; j += 256) remv[j] = 0ull;
+  if (threadIdx.x == 0) s_count = 0;
+  __syncthreads();
+  for (int b = 0; b < col_blocks; ++b) {
+    if (threadIdx.x < 64) {  // wave 0: sequential scan of the 64 candidates of this block, all in registers
+      const int lane = threadIdx.x;
+      const int row = b * 64 + lane;
+      const unsigned long long diag = (row < n) ? mask[static_cast<int64_t>(row) * col_blocks + b] : 0ull;
+      unsigned long long cur = remv[b];
+      unsigned long long kept = 0ull;
+      const int lim = min(64, n - b * 64);
+      for (int t = 0; t < lim; ++t) {
+        const unsigned long long d = __shfl(diag, t, 64);
+        if (!((cur >> t) & 1ull)) { kept |= 1ull << t; cur |= d; }
+      }
+      if (lane == 0) s_kept = kept;
+      // emit survivor indices in order
+      const int base = s_count;
+      if ((kept >> lane) & 1ull) keep[base + __popcll(kept & ((1ull << lane) - 1ull))] = row;
+    }
+    __syncthreads();
+    const unsigned long long kept = s_kept;
+    if (threadIdx.x == 0) s_count += __popcll(kept);
+    if (kept) {
+      for (int j = b + 1 + threadIdx.x; j < col_blocks; j += 256) {
+        unsigned long long acc = remv[j];
+        unsigned long long k = kept;
+        while (k) {
+          const int t = __ffsll(static_cast<long long>(k)) - 1;
+          k &= k - 1;
+          acc |= mask[static_cast<int64_t>(b * 64 + t) * col_blocks + j];
+        }
+        remv[j] = acc;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *num_keep = s_count;
+}
+
+}  // namespace fv2p
+using namespace fv2p;
+
+static int pairwise(int mode, const float* a, int na, const float* b, int nb, float* out, fv2p_stream_t s) {
+  FV2P_REQUIRE(na >= 0 && nb >= 0, FV2P_EINVAL, "boxes_bev: negative box count");
+  if (na == 0 || nb == 0) return 0;
+  FV2P_REQUIRE(a && b && out, FV2P_EINVAL, "boxes_bev: null pointer");
+  const int64_t total = static_cast<int64_t>(na) * nb;
+  const dim3 grid(static_cast<unsigned>(ceil_div(total, 256))), block(256);
+  if (mode == 0) hipLaunchKernelGGL(pairwise_bev<0>, grid, block, 0, static_cast<hipStream_t>(s), na, a, nb, b, out);
+  else hipLaunchKernelGGL(pairwise_bev<1>, grid, block, 0, static_cast<hipStream_t>(s), na, a, nb, b, out);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fv2p_boxes_overlap_bev(const float* boxes_a, int num_a, const float* boxes_b, int num_b, float* ans_overlap,
+                                      fv2p_stream_t stream) {
+  return pairwise(0, boxes_a, num_a, boxes_b, num_b, ans_overlap, stream);
+}
+extern "C" int fv2p_boxes_iou_bev(const float* boxes_a, int num_a, const float* boxes_b, int num_b, float* ans_iou,
+                                  fv2p_stream_t stream) {
+  return pairwise(1, boxes_a, num_a, boxes_b, num_b, ans_iou, stream);
+}
+
+extern "C" size_t fv2p_nms_ws_bytes(int n) {
+  const int64_t cb = ceil_div(n > 0 ? n : 1, 64);
+  Sizer s;
+  s.take<unsigned long long>(static_cast<size_t>(n > 0 ? n : 1) * cb);
+  return s.bytes();
+}
+
+extern "C" int fv2p_nms(const float* boxes, int n, float thresh, int normal, int64_t* keep, int* num_keep, void* ws,
+                        size_t ws_bytes, fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FV2P_REQUIRE(n >= 0 && num_keep, FV2P_EINVAL, "nms: bad arguments");
+  FV2P_HIP(hipMemsetAsync(num_keep, 0, sizeof(int), stream));
+  if (n == 0) return 0;
+  FV2P_REQUIRE(boxes && keep, FV2P_EINVAL, "nms: null pointer");
+  FV2P_REQUIRE(ws && ws_bytes >= fv2p_nms_ws_bytes(n), FV2P_EWORKSPACE, "nms: workspace too small");
+  const int cb = static_cast<int>(ceil_div(n, 64));
+  FV2P_REQUIRE(static_cast<size_t>(cb) * 8 <= 60000, FV2P_ELIMIT, "nms: more than 480000 boxes");
+  Carver c(ws, ws_bytes);
+  unsigned long long* mask = c.take<unsigned long long>(static_cast<size_t>(n) * cb);
+  const unsigned tiles = static_cast<unsigned>(static_cast<int64_t>(cb) * (cb + 1) / 2);
+  if (normal) hipLaunchKernelGGL(nms_mask<1>, dim3(tiles), dim3(64), 0, stream, n, thresh, boxes, cb, mask);
+  else hipLaunchKernelGGL(nms_mask<0>, dim3(tiles), dim3(64), 0, stream, n, thresh, boxes, cb, mask);
+  hipLaunchKernelGGL(nms_greedy, dim3(1), dim3(256), cb * sizeof(unsigned long long), stream, n, cb, mask,
+                     reinterpret_cast<long long*>(keep), num_keep);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
+// Host entry point of the reference extension (boxes_iou_bev_cpu, iou3d_cpu.cpp:232-252): plain host pointers.
+extern "C" int fv2p_boxes_iou_bev_cpu(const float* boxes_a, int num_a, const float* boxes_b, int num_b, float* ans_iou) {
+  FV2P_REQUIRE(num_a >= 0 && num_b >= 0 && (boxes_a || !num_a) && (boxes_b || !num_b) && (ans_iou || !num_a || !num_b), FV2P_EINVAL,
+               "boxes_iou_bev_cpu: bad arguments");
+  for (int i = 0; i < num_a; ++i)
+    for (int j = 0; j < num_b; ++j) ans_iou[static_cast<int64_t>(i) * num_b + j] = iou_bev(boxes_a + i * 7, boxes_b + j * 7);
+  return 0;
+}

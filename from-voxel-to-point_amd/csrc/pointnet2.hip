@@ -1,0 +1,596 @@
+// A8-A12 — pointnet2 stack: furthest point sampling, ball / voxel query, grouping, gather, 3-NN, interpolation.
+//
+// Replaces pointnet2_batch_cuda.* (pcdet/ops/pointnet2/pointnet2_batch/src/{ball_query,group_points,sampling,
+// interpolate}_gpu.cu) and pointnet2_stack_cuda.* (pcdet/ops/pointnet2/pointnet2_stack/src/{ball_query,group_points,
+// sampling,interpolate,voxel_query}_gpu.cu).  Index outputs reproduce the reference's sequential scan order and
+// tie-breaks; distances are fp32 sums in the reference's operand order without fused multiply-add.
+//
+// Where the reference lets every thread stream the whole point set from global memory, the kernels here stage the
+// scanned set through LDS once per workgroup (all queries of a workgroup belong to one sample), and FPS keeps each
+// thread's points and running distances in registers for the whole 16 k-round loop (the reference re-reads and
+// re-writes `temp` in global memory every round).
+#include "common.hpp"
+
+namespace fv2p {
+
+__device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, float by, float bz) {
+  // (a-b)^2 summed x, y, z left to right (ball_query_gpu.cu:39, interpolate_gpu.cu:42, sampling_gpu.cu:140)
+  const float dx = ax - bx, dy = ay - by, dz = az - bz;
+  return dx * dx + dy * dy + dz * dz;
+}
+
+// sample of a stacked row given per-sample counts (the reference's per-thread linear search, ball_query_gpu.cu:27-35)
+__device__ __forceinline__ void stack_locate(int row, int B, const int* __restrict__ cnt, int* bs, int* start) {
+  int b = 0, acc = cnt[0], st = 0;
+  for (int k = 1; k < B; ++k) {
+    if (row < acc) break;
+    st = acc;
+    acc += cnt[k];
+    b = k;
+  }
+  *bs = b;
+  *start = st;
+}
+__device__ __forceinline__ int stack_start(int bs, const int* __restrict__ cnt) {
+  int s = 0;
+  for (int k = 0; k < bs; ++k) s += cnt[k];
+  return s;
+}
+
+// ------------------------------------------------------------------ ball query (batch) ------------
+constexpr int kTile = 1024;  // points staged per LDS tile (12 KB)
+
+// grid (ceil(M/256), B); idx (B,M,nsample) pre-zeroed by the caller (pointnet2_utils.py:218)
+__global__ __launch_bounds__(256) void ball_query_batch_k(int n, int m, float radius, int nsample, const float* __restrict__ new_xyz,
+                                                          const float* __restrict__ xyz, int* __restrict__ idx) {
+  __shared__ float tile[kTile * 3];
+  const int b = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
+  const bool live = q < m;
+  float qx = 0, qy = 0, qz = 0;
+  if (live) {
+    const float* p = new_xyz + (static_cast<int64_t>(b) * m + q) * 3;
+    qx = p[0]; qy = p[1]; qz = p[2];
+  }
+  int* out = idx + (static_cast<int64_t>(b) * m + (live ? q : 0)) * nsample;
+  const float r2 = radius * radius;
+  int cnt = 0;
+  bool done = !live;
+  for (int base = 0; base < n; base += kTile) {
+    const int len = min(kTile, n - base);
+    __syncthreads();
+    for (int e = threadIdx.x; e < len * 3; e += 256) tile[e] = xyz[(static_cast<int64_t>(b) * n + base) * 3 + e];
+    __syncthreads();
+    if (__syncthreads_and(done)) break;
+    if (!done)
+      for (int k = 0; k < len; ++k) {
+        const float d2 = sqdist(qx, qy, qz, tile[k * 3], tile[k * 3 + 1], tile[k * 3 + 2]);
+        if (d2 < r2) {
+          if (cnt == 0)
+            for (int l = 0; l < nsample; ++l) out[l] = base + k;
+          out[cnt] = base + k;
+          if (++cnt >= nsample) { done = true; break; }
+        }
+      }
+  }
+}
+
+// stacked variant: one workgroup handles 256 consecutive queries; queries of different samples in one workgroup are
+// handled by staging, per query group, the sample of the workgroup's first query and looping over samples.
+__global__ __launch_bounds__(256) void ball_query_stack_k(int B, int M, float radius, int nsample, const float* __restrict__ new_xyz,
+                                                          const int* __restrict__ new_cnt, const float* __restrict__ xyz,
+                                                          const int* __restrict__ xyz_cnt, int* __restrict__ idx) {
+  __shared__ float tile[kTile * 3];
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  const bool live = q < M;
+  int my_bs = -1, tmp;
+  float qx = 0, qy = 0, qz = 0;
+  if (live) {
+    stack_locate(q, B, new_cnt, &my_bs, &tmp);
+    qx = new_xyz[q * 3]; qy = new_xyz[q * 3 + 1]; qz = new_xyz[q * 3 + 2];
+  }
+  int first_bs, last_bs;
+  stack_locate(blockIdx.x * 256, B, new_cnt, &first_bs, &tmp);
+  stack_locate(min(blockIdx.x * 256 + 255, M - 1), B, new_cnt, &last_bs, &tmp);
+  int* out = idx + static_cast<int64_t>(live ? q : 0) * nsample;
+  const float r2 = radius * radius;
+  int cnt = 0;
+  for (int bs = first_bs; bs <= last_bs; ++bs) {
+    const int start = stack_start(bs, xyz_cnt), n = xyz_cnt[bs];
+    const bool mine = live && my_bs == bs;
+    bool done = !mine;
+    for (int base = 0; base < n; base += kTile) {
+      const int len = min(kTile, n - base);
+      __syncthreads();
+      for (int e = threadIdx.x; e < len * 3; e += 256) tile[e] = xyz[(static_cast<int64_t>(start) + base) * 3 + e];
+      __syncthreads();
+      if (__syncthreads_and(done)) break;
+      if (!done)
+        for (int k = 0; k < len; ++k) {
+          const float d2 = sqdist(qx, qy, qz, tile[k * 3], tile[k * 3 + 1], tile[k * 3 + 2]);
+          if (d2 < r2) {
+            if (cnt == 0)
+              for (int l = 0; l < nsample; ++l) out[l] = base + k;
+            out[cnt] = base + k;
+            if (++cnt >= nsample) { done = true; break; }
+          }
+        }
+    }
+  }
+  if (live && cnt == 0) out[0] = -1;  // ball_query_gpu.cu:65
+}
+
+// voxel_query_gpu.cu:10-89: scan the (2r+1)^3 neighbourhood of the query's voxel in a dense (B,Z,Y,X) index volume
+__global__ void voxel_query_stack_k(int M, int R1, int R2, int R3, int nsample, float radius, int z_range, int y_range, int x_range,
+                                    const float* __restrict__ new_xyz, const float* __restrict__ xyz, const int* __restrict__ new_coords,
+                                    const int* __restrict__ point_indices, int* __restrict__ idx) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= M) return;
+  const float qx = new_xyz[q * 3], qy = new_xyz[q * 3 + 1], qz = new_xyz[q * 3 + 2];
+  const int bi = new_coords[q * 4], cz = new_coords[q * 4 + 1], cy = new_coords[q * 4 + 2], cx = new_coords[q * 4 + 3];
+  int* out = idx + static_cast<int64_t>(q) * nsample;
+  const float r2 = radius * radius;
+  int cnt = 0;
+  for (int dz = -z_range; dz <= z_range; ++dz) {
+    const int z = cz + dz;
+    if (z < 0 || z >= R1) continue;
+    for (int dy = -y_range; dy <= y_range; ++dy) {
+      const int y = cy + dy;
+      if (y < 0 || y >= R2) continue;
+      for (int dx = -x_range; dx <= x_range; ++dx) {
+        const int x = cx + dx;
+        if (x < 0 || x >= R3) continue;
+        const int nb = point_indices[((static_cast<int64_t>(bi) * R1 + z) * R2 + y) * R3 + x];
+        if (nb < 0) continue;
+        const float d2 = sqdist(xyz[nb * 3], xyz[nb * 3 + 1], xyz[nb * 3 + 2], qx, qy, qz);
+        if (d2 > r2) continue;  // accepts equality, unlike ball query (voxel_query_gpu.cu:65)
+        if (cnt < nsample) {
+          if (cnt == 0)
+            for (int l = 0; l < nsample; ++l) out[l] = nb;
+          out[cnt++] = nb;
+        }
+      }
+    }
+  }
+  if (cnt == 0) out[0] = -1;
+}
+
+// ------------------------------------------------------------------ grouping / gather -------------
+// batch: points (B,C,N), idx (B,npoints,nsample) -> out (B,C,npoints,nsample)
+__global__ void group_points_batch_k(int64_t total, int c, int n, int npoints, int nsample, const float* __restrict__ points,
+                                     const int* __restrict__ idx, float* __restrict__ out) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int64_t per = static_cast<int64_t>(npoints) * nsample;
+  const int64_t bc = t / per, rem = t % per;
+  const int b = static_cast<int>(bc / c);
+  out[t] = points[bc * n + idx[b * per + rem]];
+}
+__global__ void group_points_batch_grad_k(int64_t total, int c, int n, int npoints, int nsample, const float* __restrict__ grad_out,
+                                          const int* __restrict__ idx, float* __restrict__ grad_points) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int64_t per = static_cast<int64_t>(npoints) * nsample;
+  const int64_t bc = t / per, rem = t % per;
+  const int b = static_cast<int>(bc / c);
+  atomicAdd(&grad_points[bc * n + idx[b * per + rem]], grad_out[t]);
+}
+// gather: points (B,C,N), idx (B,M) -> out (B,C,M)
+__global__ void gather_points_k(int64_t total, int c, int n, int m, const float* __restrict__ points, const int* __restrict__ idx,
+                                float* __restrict__ out) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int64_t bc = t / m;
+  const int b = static_cast<int>(bc / c);
+  out[t] = points[bc * n + idx[static_cast<int64_t>(b) * m + t % m]];
+}
+__global__ void gather_points_grad_k(int64_t total, int c, int n, int m, const float* __restrict__ grad_out, const int* __restrict__ idx,
+                                     float* __restrict__ grad_points) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int64_t bc = t / m;
+  const int b = static_cast<int>(bc / c);
+  atomicAdd(&grad_points[bc * n + idx[static_cast<int64_t>(b) * m + t % m]], grad_out[t]);
+}
+// stack: features (N,C), idx (M,nsample) local to the sample -> out (M,C,nsample)
+__global__ void group_points_stack_k(int B, int M, int C, int nsample, const float* __restrict__ features, const int* __restrict__ feat_cnt,
+                                     const int* __restrict__ idx, const int* __restrict__ idx_cnt, float* __restrict__ out) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= static_cast<int64_t>(M) * C * nsample) return;
+  const int s = static_cast<int>(t % nsample), ch = static_cast<int>((t / nsample) % C), pt = static_cast<int>(t / nsample / C);
+  int bs, tmp;
+  stack_locate(pt, B, idx_cnt, &bs, &tmp);
+  const int start = stack_start(bs, feat_cnt);
+  out[t] = features[(static_cast<int64_t>(start) + idx[static_cast<int64_t>(pt) * nsample + s]) * C + ch];
+}
+__global__ void group_points_stack_grad_k(int B, int M, int C, int nsample, const float* __restrict__ grad_out, const int* __restrict__ idx,
+                                          const int* __restrict__ idx_cnt, const int* __restrict__ feat_cnt, float* __restrict__ grad_features) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= static_cast<int64_t>(M) * C * nsample) return;
+  const int s = static_cast<int>(t % nsample), ch = static_cast<int>((t / nsample) % C), pt = static_cast<int>(t / nsample / C);
+  int bs, tmp;
+  stack_locate(pt, B, idx_cnt, &bs, &tmp);
+  const int start = stack_start(bs, feat_cnt);
+  atomicAdd(&grad_features[(static_cast<int64_t>(start) + idx[static_cast<int64_t>(pt) * nsample + s]) * C + ch], grad_out[t]);
+}
+
+// ------------------------------------------------------------------ furthest point sampling -------
+// One workgroup per sample.  Ownership and tie-break follow sampling_gpu.cu:100-216 exactly: with
+// bs = 2^floor(log2 n) (<= 1024) reference threads, thread t owns points t, t+bs, ...; a thread keeps its FIRST
+// maximum (strict >), the tree reduction keeps the LOWER thread on equal values -> winner = max distance, then
+// smallest t, then smallest k.  REG: points + running distances live in registers (n <= THREADS*PPT).
+template <int THREADS, int PPT, bool REG>
+__global__ __launch_bounds__(THREADS) void fps_k(int n, int m, int bs, const float* __restrict__ dataset, float* __restrict__ temp,
+                                                 int* __restrict__ idxs) {
+  if (m <= 0) return;
+  constexpr int NW = THREADS / 64;
+  __shared__ float s_val[2][NW];
+  __shared__ int s_idx[2][NW];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  dataset += static_cast<int64_t>(b) * n * 3;
+  temp += static_cast<int64_t>(b) * n;
+  idxs += static_cast<int64_t>(b) * m;
+  float px[PPT], py[PPT], pz[PPT], pt[PPT];
+  if (REG) {
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      const int k = tid + j * bs;
+      const bool ok = tid < bs && k < n;
+      px[j] = ok ? dataset[k * 3] : 0.f;
+      py[j] = ok ? dataset[k * 3 + 1] : 0.f;
+      pz[j] = ok ? dataset[k * 3 + 2] : 0.f;
+      pt[j] = ok ? temp[k] : -2.f;  // never selected: min(d, -2) = -2 < best init -1
+    }
+  }
+  int old = 0;
+  if (tid == 0) idxs[0] = 0;
+  for (int j = 1; j < m; ++j) {
+    const float x1 = dataset[old * 3], y1 = dataset[old * 3 + 1], z1 = dataset[old * 3 + 2];
+    float best = -1.f;
+    int besti = 0;
+    if (REG) {
+#pragma unroll
+      for (int q = 0; q < PPT; ++q) {
+        const float d = sqdist(px[q], py[q], pz[q], x1, y1, z1);
+        const float d2 = fminf(d, pt[q]);
+        pt[q] = d2;
+        if (d2 > best) { best = d2; besti = tid + q * bs; }
+      }
+    } else if (tid < bs) {
+      for (int k = tid; k < n; k += bs) {
+        const float d = sqdist(dataset[k * 3], dataset[k * 3 + 1], dataset[k * 3 + 2], x1, y1, z1);
+        const float d2 = fminf(d, temp[k]);
+        temp[k] = d2;
+        if (d2 > best) { best = d2; besti = k; }
+      }
+    }
+    // wave argmax: max value, lowest lane on ties
+    float wmax = best;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, d, 64));
+    const uint64_t who = __ballot(best == wmax);
+    const int leader = __ffsll(static_cast<long long>(who)) - 1;
+    const int widx = __shfl(besti, leader, 64);
+    const int buf = j & 1;
+    if (lane == 0) { s_val[buf][w] = wmax; s_idx[buf][w] = widx; }
+    __syncthreads();
+    float gmax = s_val[buf][0];
+    int gidx = s_idx[buf][0];
+#pragma unroll
+    for (int ww = 1; ww < NW; ++ww) {
+      const float v = s_val[buf][ww];
+      if (v > gmax) { gmax = v; gidx = s_idx[buf][ww]; }
+    }
+    old = gidx;
+    if (tid == 0) idxs[j] = old;
+  }
+  if (REG) {  // the reference leaves the final running distances in `temp` (caller-visible buffer)
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      const int k = tid + j * bs;
+      if (tid < bs && k < n) temp[k] = pt[j];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ three_nn / interpolate --------
+// one query per thread, known points staged through LDS; strict '<' keeps the lowest index on ties
+// (interpolate_gpu.cu:37-55; the reference's double best* hold float values: float compares are identical).
+struct Best3 {
+  float d1, d2, d3;
+  int i1, i2, i3;
+};
+__device__ __forceinline__ void best3_init(Best3* b) {
+  b->d1 = b->d2 = b->d3 = INFINITY;  // 1e40 in the reference (:37) == +inf once cast to float (:56)
+  b->i1 = b->i2 = b->i3 = 0;
+}
+__device__ __forceinline__ void best3_push(Best3* b, float d, int k) {
+  if (d < b->d1) { b->d3 = b->d2; b->i3 = b->i2; b->d2 = b->d1; b->i2 = b->i1; b->d1 = d; b->i1 = k; }
+  else if (d < b->d2) { b->d3 = b->d2; b->i3 = b->i2; b->d2 = d; b->i2 = k; }
+  else if (d < b->d3) { b->d3 = d; b->i3 = k; }
+}
+
+__global__ __launch_bounds__(256) void three_nn_batch_k(int n, int m, const float* __restrict__ unknown, const float* __restrict__ known,
+                                                        float* __restrict__ dist2, int* __restrict__ idx) {
+  __shared__ float tile[kTile * 3];
+  const int b = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
+  const bool live = q < n;
+  float ux = 0, uy = 0, uz = 0;
+  if (live) {
+    const float* p = unknown + (static_cast<int64_t>(b) * n + q) * 3;
+    ux = p[0]; uy = p[1]; uz = p[2];
+  }
+  Best3 bst;
+  best3_init(&bst);
+  for (int base = 0; base < m; base += kTile) {
+    const int len = min(kTile, m - base);
+    __syncthreads();
+    for (int e = threadIdx.x; e < len * 3; e += 256) tile[e] = known[(static_cast<int64_t>(b) * m + base) * 3 + e];
+    __syncthreads();
+    if (live)
+      for (int k = 0; k < len; ++k) best3_push(&bst, sqdist(ux, uy, uz, tile[k * 3], tile[k * 3 + 1], tile[k * 3 + 2]), base + k);
+  }
+  if (live) {
+    const int64_t o = (static_cast<int64_t>(b) * n + q) * 3;
+    dist2[o] = bst.d1; dist2[o + 1] = bst.d2; dist2[o + 2] = bst.d3;
+    idx[o] = bst.i1; idx[o + 1] = bst.i2; idx[o + 2] = bst.i3;
+  }
+}
+
+__global__ __launch_bounds__(256) void three_nn_stack_k(int B, int N, const float* __restrict__ unknown, const int* __restrict__ unk_cnt,
+                                                        const float* __restrict__ known, const int* __restrict__ known_cnt,
+                                                        float* __restrict__ dist2, int* __restrict__ idx) {
+  __shared__ float tile[kTile * 3];
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  const bool live = q < N;
+  int my_bs = -1, tmp;
+  float ux = 0, uy = 0, uz = 0;
+  if (live) {
+    stack_locate(q, B, unk_cnt, &my_bs, &tmp);
+    ux = unknown[q * 3]; uy = unknown[q * 3 + 1]; uz = unknown[q * 3 + 2];
+  }
+  int first_bs, last_bs;
+  stack_locate(blockIdx.x * 256, B, unk_cnt, &first_bs, &tmp);
+  stack_locate(min(blockIdx.x * 256 + 255, N - 1), B, unk_cnt, &last_bs, &tmp);
+  Best3 bst;
+  best3_init(&bst);
+  int my_start = 0;
+  for (int bs = first_bs; bs <= last_bs; ++bs) {
+    const int start = stack_start(bs, known_cnt), m = known_cnt[bs];
+    const bool mine = live && my_bs == bs;
+    if (mine) my_start = start;
+    for (int base = 0; base < m; base += kTile) {
+      const int len = min(kTile, m - base);
+      __syncthreads();
+      for (int e = threadIdx.x; e < len * 3; e += 256) tile[e] = known[(static_cast<int64_t>(start) + base) * 3 + e];
+      __syncthreads();
+      if (mine)
+        for (int k = 0; k < len; ++k) best3_push(&bst, sqdist(ux, uy, uz, tile[k * 3], tile[k * 3 + 1], tile[k * 3 + 2]), base + k);
+    }
+  }
+  if (live) {
+    dist2[q * 3] = bst.d1; dist2[q * 3 + 1] = bst.d2; dist2[q * 3 + 2] = bst.d3;
+    idx[q * 3] = bst.i1 + my_start; idx[q * 3 + 1] = bst.i2 + my_start; idx[q * 3 + 2] = bst.i3 + my_start;  // global rows (:72-74)
+  }
+}
+
+// batch interpolate: points (B,C,M) channel-major, idx/weight (B,N,3) -> out (B,C,N)
+__global__ void three_interp_batch_k(int64_t total, int c, int m, int n, const float* __restrict__ points, const int* __restrict__ idx,
+                                     const float* __restrict__ weight, float* __restrict__ out) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int64_t bc = t / n;
+  const int pt = static_cast<int>(t % n), b = static_cast<int>(bc / c);
+  const int64_t o = (static_cast<int64_t>(b) * n + pt) * 3;
+  const float* p = points + bc * m;
+  out[t] = weight[o] * p[idx[o]] + weight[o + 1] * p[idx[o + 1]] + weight[o + 2] * p[idx[o + 2]];
+}
+__global__ void three_interp_batch_grad_k(int64_t total, int c, int m, int n, const float* __restrict__ grad_out, const int* __restrict__ idx,
+                                          const float* __restrict__ weight, float* __restrict__ grad_points) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int64_t bc = t / n;
+  const int pt = static_cast<int>(t % n), b = static_cast<int>(bc / c);
+  const int64_t o = (static_cast<int64_t>(b) * n + pt) * 3;
+  float* g = grad_points + bc * m;
+  const float go = grad_out[t];
+  atomicAdd(&g[idx[o]], go * weight[o]);
+  atomicAdd(&g[idx[o + 1]], go * weight[o + 1]);
+  atomicAdd(&g[idx[o + 2]], go * weight[o + 2]);
+}
+// stack interpolate: features (M,C) row-major, idx/weight (N,3) -> out (N,C)
+__global__ void three_interp_stack_k(int64_t total, int c, const float* __restrict__ features, const int* __restrict__ idx,
+                                     const float* __restrict__ weight, float* __restrict__ out) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int64_t pt = t / c;
+  const int ch = static_cast<int>(t % c);
+  out[t] = weight[pt * 3] * features[static_cast<int64_t>(idx[pt * 3]) * c + ch] +
+           weight[pt * 3 + 1] * features[static_cast<int64_t>(idx[pt * 3 + 1]) * c + ch] +
+           weight[pt * 3 + 2] * features[static_cast<int64_t>(idx[pt * 3 + 2]) * c + ch];
+}
+__global__ void three_interp_stack_grad_k(int64_t total, int c, const float* __restrict__ grad_out, const int* __restrict__ idx,
+                                          const float* __restrict__ weight, float* __restrict__ grad_features) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int64_t pt = t / c;
+  const int ch = static_cast<int>(t % c);
+  const float go = grad_out[t];
+  atomicAdd(&grad_features[static_cast<int64_t>(idx[pt * 3]) * c + ch], go * weight[pt * 3]);
+  atomicAdd(&grad_features[static_cast<int64_t>(idx[pt * 3 + 1]) * c + ch], go * weight[pt * 3 + 1]);
+  atomicAdd(&grad_features[static_cast<int64_t>(idx[pt * 3 + 2]) * c + ch], go * weight[pt * 3 + 2]);
+}
+
+static int fps_ref_block(int n) {  // opt_n_threads (cuda_utils.h:10-14): 2^floor(log2 n) clamped to [1, 1024]
+  int p = 1;
+  while (p * 2 <= n && p < 1024) p *= 2;
+  return p;
+}
+
+}  // namespace fv2p
+using namespace fv2p;
+
+#define G1D(total) dim3(static_cast<unsigned>(ceil_div((total), 256))), dim3(256)
+#define STREAM(s) static_cast<hipStream_t>(s)
+
+extern "C" int fv2p_ball_query_batch(int b, int n, int m, float radius, int nsample, const float* new_xyz, const float* xyz, int* idx,
+                                     fv2p_stream_t s) {
+  FV2P_REQUIRE(b >= 0 && n >= 0 && m >= 0 && nsample >= 1, FV2P_EINVAL, "ball_query: bad sizes");
+  if (b == 0 || m == 0) return 0;
+  FV2P_REQUIRE(new_xyz && idx && (xyz || n == 0), FV2P_EINVAL, "ball_query: null pointer");
+  hipLaunchKernelGGL(ball_query_batch_k, dim3((unsigned)ceil_div(m, 256), b), dim3(256), 0, STREAM(s), n, m, radius, nsample, new_xyz, xyz, idx);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int fv2p_ball_query_stack(int b, int m, float radius, int nsample, const float* new_xyz, const int* new_xyz_batch_cnt,
+                                     const float* xyz, const int* xyz_batch_cnt, int* idx, fv2p_stream_t s) {
+  FV2P_REQUIRE(b >= 1 && m >= 0 && nsample >= 1, FV2P_EINVAL, "ball_query_stack: bad sizes");
+  if (m == 0) return 0;
+  FV2P_REQUIRE(new_xyz && new_xyz_batch_cnt && xyz_batch_cnt && idx, FV2P_EINVAL, "ball_query_stack: null pointer");
+  hipLaunchKernelGGL(ball_query_stack_k, dim3((unsigned)ceil_div(m, 256)), dim3(256), 0, STREAM(s), b, m, radius, nsample, new_xyz,
+                     new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int fv2p_voxel_query_stack(int m, int r1, int r2, int r3, int nsample, float radius, int z_range, int y_range, int x_range,
+                                      const float* new_xyz, const float* xyz, const int* new_coords, const int* point_indices, int* idx,
+                                      fv2p_stream_t s) {
+  FV2P_REQUIRE(m >= 0 && nsample >= 1 && r1 >= 1 && r2 >= 1 && r3 >= 1, FV2P_EINVAL, "voxel_query: bad sizes");
+  if (m == 0) return 0;
+  FV2P_REQUIRE(new_xyz && xyz && new_coords && point_indices && idx, FV2P_EINVAL, "voxel_query: null pointer");
+  hipLaunchKernelGGL(voxel_query_stack_k, G1D(m), 0, STREAM(s), m, r1, r2, r3, nsample, radius, z_range, y_range, x_range, new_xyz, xyz,
+                     new_coords, point_indices, idx);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fv2p_group_points_batch(int b, int c, int n, int npoints, int nsample, const float* points, const int* idx, float* out,
+                                       fv2p_stream_t s) {
+  const int64_t total = static_cast<int64_t>(b) * c * npoints * nsample;
+  FV2P_REQUIRE(total >= 0, FV2P_EINVAL, "group_points: bad sizes");
+  if (total == 0) return 0;
+  FV2P_REQUIRE(points && idx && out, FV2P_EINVAL, "group_points: null pointer");
+  hipLaunchKernelGGL(group_points_batch_k, G1D(total), 0, STREAM(s), total, c, n, npoints, nsample, points, idx, out);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int fv2p_group_points_batch_grad(int b, int c, int n, int npoints, int nsample, const float* grad_out, const int* idx,
+                                            float* grad_points, fv2p_stream_t s) {
+  const int64_t total = static_cast<int64_t>(b) * c * npoints * nsample;
+  if (total <= 0) return 0;
+  FV2P_REQUIRE(grad_out && idx && grad_points, FV2P_EINVAL, "group_points_grad: null pointer");
+  hipLaunchKernelGGL(group_points_batch_grad_k, G1D(total), 0, STREAM(s), total, c, n, npoints, nsample, grad_out, idx, grad_points);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int fv2p_gather_points(int b, int c, int n, int npoints, const float* points, const int* idx, float* out, fv2p_stream_t s) {
+  const int64_t total = static_cast<int64_t>(b) * c * npoints;
+  if (total <= 0) return 0;
+  FV2P_REQUIRE(points && idx && out, FV2P_EINVAL, "gather_points: null pointer");
+  hipLaunchKernelGGL(gather_points_k, G1D(total), 0, STREAM(s), total, c, n, npoints, points, idx, out);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int fv2p_gather_points_grad(int b, int c, int n, int npoints, const float* grad_out, const int* idx, float* grad_points,
+                                       fv2p_stream_t s) {
+  const int64_t total = static_cast<int64_t>(b) * c * npoints;
+  if (total <= 0) return 0;
+  FV2P_REQUIRE(grad_out && idx && grad_points, FV2P_EINVAL, "gather_points_grad: null pointer");
+  hipLaunchKernelGGL(gather_points_grad_k, G1D(total), 0, STREAM(s), total, c, n, npoints, grad_out, idx, grad_points);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int fv2p_group_points_stack(int b, int m, int c, int nsample, const float* features, const int* features_batch_cnt,
+                                       const int* idx, const int* idx_batch_cnt, float* out, fv2p_stream_t s) {
+  const int64_t total = static_cast<int64_t>(m) * c * nsample;
+  if (total <= 0) return 0;
+  FV2P_REQUIRE(b >= 1 && features && features_batch_cnt && idx && idx_batch_cnt && out, FV2P_EINVAL, "group_points_stack: bad arguments");
+  hipLaunchKernelGGL(group_points_stack_k, G1D(total), 0, STREAM(s), b, m, c, nsample, features, features_batch_cnt, idx, idx_batch_cnt, out);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int fv2p_group_points_stack_grad(int b, int m, int c, int n, int nsample, const float* grad_out, const int* idx,
+                                            const int* idx_batch_cnt, const int* features_batch_cnt, float* grad_features, fv2p_stream_t s) {
+  const int64_t total = static_cast<int64_t>(m) * c * nsample;
+  if (total <= 0) return 0;
+  FV2P_REQUIRE(b >= 1 && grad_out && idx && idx_batch_cnt && features_batch_cnt && grad_features, FV2P_EINVAL, "group_points_stack_grad: bad arguments");
+  hipLaunchKernelGGL(group_points_stack_grad_k, G1D(total), 0, STREAM(s), b, m, c, nsample, grad_out, idx, idx_batch_cnt, features_batch_cnt,
+                     grad_features);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fv2p_furthest_point_sampling(int b, int n, int m, const float* dataset, float* temp, int* idxs, fv2p_stream_t s) {
+  FV2P_REQUIRE(b >= 0 && n >= 1 && m >= 0, FV2P_EINVAL, "furthest_point_sampling: bad sizes");
+  if (b == 0 || m == 0) return 0;
+  FV2P_REQUIRE(dataset && temp && idxs, FV2P_EINVAL, "furthest_point_sampling: null pointer");
+  const int bs = fps_ref_block(n);
+  hipStream_t st = STREAM(s);
+  if (bs == 1024) {
+    const int ppt = static_cast<int>(ceil_div(n, 1024));
+    if (ppt <= 4) hipLaunchKernelGGL((fps_k<1024, 4, true>), dim3(b), dim3(1024), 0, st, n, m, bs, dataset, temp, idxs);
+    else if (ppt <= 8) hipLaunchKernelGGL((fps_k<1024, 8, true>), dim3(b), dim3(1024), 0, st, n, m, bs, dataset, temp, idxs);
+    else if (ppt <= 16) hipLaunchKernelGGL((fps_k<1024, 16, true>), dim3(b), dim3(1024), 0, st, n, m, bs, dataset, temp, idxs);
+    else hipLaunchKernelGGL((fps_k<1024, 1, false>), dim3(b), dim3(1024), 0, st, n, m, bs, dataset, temp, idxs);
+  } else if (bs >= 256) {
+    hipLaunchKernelGGL((fps_k<512, 2, true>), dim3(b), dim3(512), 0, st, n, m, bs, dataset, temp, idxs);  // n < 1024: <= 2 points per owner
+  } else {
+    hipLaunchKernelGGL((fps_k<128, 2, true>), dim3(b), dim3(128), 0, st, n, m, bs, dataset, temp, idxs);
+  }
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fv2p_three_nn_batch(int b, int n, int m, const float* unknown, const float* known, float* dist2, int* idx, fv2p_stream_t s) {
+  FV2P_REQUIRE(b >= 0 && n >= 0 && m >= 0, FV2P_EINVAL, "three_nn: bad sizes");
+  if (b == 0 || n == 0) return 0;
+  FV2P_REQUIRE(unknown && dist2 && idx && (known || m == 0), FV2P_EINVAL, "three_nn: null pointer");
+  hipLaunchKernelGGL(three_nn_batch_k, dim3((unsigned)ceil_div(n, 256), b), dim3(256), 0, STREAM(s), n, m, unknown, known, dist2, idx);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int fv2p_three_nn_stack(int b, int n, int m, const float* unknown, const int* unknown_batch_cnt, const float* known,
+                                   const int* known_batch_cnt, float* dist2, int* idx, fv2p_stream_t s) {
+  FV2P_REQUIRE(b >= 1 && n >= 0, FV2P_EINVAL, "three_nn_stack: bad sizes");
+  if (n == 0) return 0;
+  FV2P_REQUIRE(unknown && unknown_batch_cnt && known_batch_cnt && dist2 && idx, FV2P_EINVAL, "three_nn_stack: null pointer");
+  hipLaunchKernelGGL(three_nn_stack_k, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, STREAM(s), b, n, unknown, unknown_batch_cnt, known,
+                     known_batch_cnt, dist2, idx);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int fv2p_three_interpolate_batch(int b, int c, int m, int n, const float* points, const int* idx, const float* weight, float* out,
+                                            fv2p_stream_t s) {
+  const int64_t total = static_cast<int64_t>(b) * c * n;
+  if (total <= 0) return 0;
+  FV2P_REQUIRE(points && idx && weight && out, FV2P_EINVAL, "three_interpolate: null pointer");
+  hipLaunchKernelGGL(three_interp_batch_k, G1D(total), 0, STREAM(s), total, c, m, n, points, idx, weight, out);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int fv2p_three_interpolate_batch_grad(int b, int c, int n, int m, const float* grad_out, const int* idx, const float* weight,
+                                                 float* grad_points, fv2p_stream_t s) {
+  const int64_t total = static_cast<int64_t>(b) * c * n;
+  if (total <= 0) return 0;
+  FV2P_REQUIRE(grad_out && idx && weight && grad_points, FV2P_EINVAL, "three_interpolate_grad: null pointer");
+  hipLaunchKernelGGL(three_interp_batch_grad_k, G1D(total), 0, STREAM(s), total, c, m, n, grad_out, idx, weight, grad_points);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int fv2p_three_interpolate_stack(int n, int c, const float* features, const int* idx, const float* weight, float* out,
+                                            fv2p_stream_t s) {
+  const int64_t total = static_cast<int64_t>(n) * c;
+  if (total <= 0) return 0;
+  FV2P_REQUIRE(features && idx && weight && out, FV2P_EINVAL, "three_interpolate_stack: null pointer");
+  hipLaunchKernelGGL(three_interp_stack_k, G1D(total), 0, STREAM(s), total, c, features, idx, weight, out);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int fv2p_three_interpolate_stack_grad(int n, int c, const float* grad_out, const int* idx, const float* weight,
+                                                 float* grad_features, fv2p_stream_t s) {
+  const int64_t total = static_cast<int64_t>(n) * c;
+  if (total <= 0) return 0;
+  FV2P_REQUIRE(grad_out && idx && weight && grad_features, FV2P_EINVAL, "three_interpolate_stack_grad: null pointer");
+  hipLaunchKernelGGL(three_interp_stack_grad_k, G1D(total), 0, STREAM(s), total, c, grad_out, idx, weight, grad_features);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,53 @@
+"""One-process-per-GPU data parallel plumbing shared by bench.py and the gloo CPU tests.
+
+The hot path shards by sample: every rank owns its own clouds, rulebooks and features; the only
+collective is DistributedDataParallel's bucketed gradient all-reduce (RCCL over xGMI when backend == "nccl")."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init_distributed(backend, device=None):
+    rank, world, _ = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+        dist.init_process_group(backend, **kw)
+    return rank, world
+
+
+def rank_seeds(rank, n_pool, batch):
+    """Distinct synthetic-cloud seeds per (rank, pool slot, sample): ranks never see the same cloud."""
+    return [[100000 * rank + 10 * j + b for b in range(batch)] for j in range(n_pool)]
+
+
+def wrap_ddp(model, device=None):
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return model
+    ids = [device.index] if (device is not None and device.type == "cuda") else None
+    # find_unused_parameters=True as the reference trainer (tools/train.py:166)
+    return torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, find_unused_parameters=True)
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(seconds, device="cpu"):
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(seconds)
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def aggregate_throughput(units_per_rank_per_step, steps, seconds_max):
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    return units_per_rank_per_step * world * steps / seconds_max

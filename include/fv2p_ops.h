@@ -136,6 +136,105 @@ int fv2p_sparse_group_fwd(const float* in, int64_t n_in, int c, const int* tab, 
 int fv2p_sparse_group_bwd(const float* grad, int64_t n_out, int c, const int* tab, int kvol, int64_t n_in,
                           int flip_k, float* din, fv2p_stream_t stream);
 
+/* ---- A16: rotated BEV overlap / IoU, rotated and axis-aligned NMS ----------------------------
+ * Replace iou3d_nms_cuda.* (pcdet/ops/iou3d_nms/src/iou3d_nms_api.cpp:11-17):
+ *   boxes_overlap_bev_gpu (iou3d_nms.cpp:49-68,  kernel iou3d_nms_kernel.cu:236-249)
+ *   boxes_iou_bev_gpu     (iou3d_nms.cpp:70-88,  kernel :251-265)
+ *   nms_gpu / nms_normal_gpu (iou3d_nms.cpp:90-187, kernels :267-372, host greedy loop :121-135)
+ *   boxes_iou_bev_cpu     (iou3d_cpu.cpp:232-252) — host pointers, runs on the calling thread.
+ * boxes are [n,7] f32 (x, y, z, dx, dy, dz, heading).  fv2p_nms expects boxes already sorted by descending
+ * score; keep [n] i64 and num_keep [1] i32 are DEVICE buffers (the greedy pass runs on the GPU); survivors
+ * are written in ascending index order, exactly the reference's keep list.  normal!=0 ignores headings.
+ */
+int fv2p_boxes_overlap_bev(const float* boxes_a, int num_a, const float* boxes_b, int num_b,
+                           float* ans_overlap, fv2p_stream_t stream);
+int fv2p_boxes_iou_bev(const float* boxes_a, int num_a, const float* boxes_b, int num_b, float* ans_iou,
+                       fv2p_stream_t stream);
+size_t fv2p_nms_ws_bytes(int n);
+int fv2p_nms(const float* boxes, int n, float thresh, int normal, int64_t* keep, int* num_keep, void* ws,
+             size_t ws_bytes, fv2p_stream_t stream);
+int fv2p_boxes_iou_bev_cpu(const float* boxes_a, int num_a, const float* boxes_b, int num_b, float* ans_iou);
+
+/* ---- A15 / A18: point-in-box, RoI-aware voxel pooling, RoI point pooling ------------------------
+ * Replace roiaware_pool3d_cuda.{points_in_boxes_gpu, points_in_boxes_cpu, forward, backward}
+ * (pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:29-177, kernels roiaware_pool3d_kernel.cu:16-359) and
+ * roipoint_pool3d_cuda.forward (pcdet/ops/roipoint_pool3d/src/roipoint_pool3d.cpp:22-56, kernels
+ * roipoint_pool3d_kernel.cu:16-165).  boxes: [x,y,z,dx,dy,dz,heading]; MARGIN 1e-5 on the GPU paths, 1e-2 in the
+ * host path, as in the reference.
+ *   points_in_boxes      boxes (B,T,7), pts (B,M,3) -> box_idx_of_points (B,M): first containing box or -1
+ *   points_in_boxes_cpu  host pointers; boxes (N,7), pts (M,3) -> pts_indices (N,M) 0/1
+ *   roipoint_pool3d      xyz (B,N,3), boxes3d (B,M,7), pts_feature (B,N,C) -> pooled (B,M,S,3+C) = the first S
+ *                        inside points in index order, wrapped when fewer; pooled_empty_flag (B,M)
+ *   roiaware_pool3d_fwd  rois (R,7), pts (P,3), pts_feature (P,C) -> pts_idx_of_voxels (R,ox,oy,oz,max_pts)
+ *                        [slot 0 = count], argmax (R,ox,oy,oz,C), pooled (R,ox,oy,oz,C); pool_method 0 max / 1 avg
+ *   roiaware_pool3d_bwd  grad_in (P,C) must be zeroed by the caller (roiaware_pool3d_utils.py:104), accumulated.
+ */
+int fv2p_points_in_boxes(const float* boxes, const float* pts, int batch, int boxes_num, int pts_num,
+                         int* box_idx_of_points, fv2p_stream_t stream);
+int fv2p_points_in_boxes_cpu(const float* boxes, const float* pts, int boxes_num, int pts_num, int* pts_indices);
+int fv2p_roipoint_pool3d(const float* xyz, const float* boxes3d, const float* pts_feature, int batch, int pts_num,
+                         int boxes_num, int feature_len, int sampled_pts_num, float* pooled_features,
+                         int* pooled_empty_flag, fv2p_stream_t stream);
+int fv2p_roiaware_pool3d_fwd(const float* rois, const float* pts, const float* pts_feature, int boxes_num,
+                             int pts_num, int channels, int max_pts_each_voxel, int out_x, int out_y, int out_z,
+                             int pool_method, int* argmax, int* pts_idx_of_voxels, float* pooled_features,
+                             fv2p_stream_t stream);
+int fv2p_roiaware_pool3d_bwd(const int* pts_idx_of_voxels, const int* argmax, const float* grad_out, int boxes_num,
+                             int out_x, int out_y, int out_z, int channels, int max_pts_each_voxel, int pool_method,
+                             float* grad_in, fv2p_stream_t stream);
+
+/* ---- A8-A12: pointnet2 (batch and stacked layouts) ------------------------------------------------
+ * Replace pointnet2_batch_cuda.* (pcdet/ops/pointnet2/pointnet2_batch/src/pointnet2_api.cpp:10-24) and
+ * pointnet2_stack_cuda.* (pcdet/ops/pointnet2/pointnet2_stack/src/pointnet2_api.cpp:11-23).  Argument order and
+ * meaning follow the reference wrappers (ints first, then tensors); outputs are caller-allocated.
+ *  batch layouts : xyz (B,N,3), features channel-major (B,C,N), idx (B,M,nsample) / (B,M) / (B,N,3)
+ *  stack layouts : rows of all samples concatenated, per-sample row counts in *_batch_cnt (int32 [B], device)
+ * ball_query      first `nsample` points with d2 <  r^2 in index order, padded with the first hit
+ *                 (ball_query_gpu.cu:15-51; stack: idx[0] = -1 when the ball is empty, :16-66); idx pre-zeroed by caller
+ * voxel_query     (2r+1)^3 neighbourhood of a dense (B,Z,Y,X) int volume, d2 <= r^2 (voxel_query_gpu.cu:10-89)
+ * furthest_point_sampling  temp (B,N) must hold 1e10 (pointnet2_utils.py:26); first index 0; ties as the reference's
+ *                 strided tree reduction (sampling_gpu.cu:93-216); temp holds the final distances on return
+ * three_nn        3 smallest squared distances (strict <, lowest index wins) + indices (stack: global rows)
+ * *_grad          accumulate into grad buffers the caller zeroed (atomic adds, as the reference)
+ */
+int fv2p_ball_query_batch(int b, int n, int m, float radius, int nsample, const float* new_xyz, const float* xyz,
+                          int* idx, fv2p_stream_t stream);
+int fv2p_ball_query_stack(int b, int m, float radius, int nsample, const float* new_xyz,
+                          const int* new_xyz_batch_cnt, const float* xyz, const int* xyz_batch_cnt, int* idx,
+                          fv2p_stream_t stream);
+int fv2p_voxel_query_stack(int m, int r1, int r2, int r3, int nsample, float radius, int z_range, int y_range,
+                           int x_range, const float* new_xyz, const float* xyz, const int* new_coords,
+                           const int* point_indices, int* idx, fv2p_stream_t stream);
+int fv2p_group_points_batch(int b, int c, int n, int npoints, int nsample, const float* points, const int* idx,
+                            float* out, fv2p_stream_t stream);
+int fv2p_group_points_batch_grad(int b, int c, int n, int npoints, int nsample, const float* grad_out,
+                                 const int* idx, float* grad_points, fv2p_stream_t stream);
+int fv2p_gather_points(int b, int c, int n, int npoints, const float* points, const int* idx, float* out,
+                       fv2p_stream_t stream);
+int fv2p_gather_points_grad(int b, int c, int n, int npoints, const float* grad_out, const int* idx,
+                            float* grad_points, fv2p_stream_t stream);
+int fv2p_group_points_stack(int b, int m, int c, int nsample, const float* features,
+                            const int* features_batch_cnt, const int* idx, const int* idx_batch_cnt, float* out,
+                            fv2p_stream_t stream);
+int fv2p_group_points_stack_grad(int b, int m, int c, int n, int nsample, const float* grad_out, const int* idx,
+                                 const int* idx_batch_cnt, const int* features_batch_cnt, float* grad_features,
+                                 fv2p_stream_t stream);
+int fv2p_furthest_point_sampling(int b, int n, int m, const float* dataset, float* temp, int* idxs,
+                                 fv2p_stream_t stream);
+int fv2p_three_nn_batch(int b, int n, int m, const float* unknown, const float* known, float* dist2, int* idx,
+                        fv2p_stream_t stream);
+int fv2p_three_nn_stack(int b, int n, int m, const float* unknown, const int* unknown_batch_cnt,
+                        const float* known, const int* known_batch_cnt, float* dist2, int* idx,
+                        fv2p_stream_t stream);
+int fv2p_three_interpolate_batch(int b, int c, int m, int n, const float* points, const int* idx,
+                                 const float* weight, float* out, fv2p_stream_t stream);
+int fv2p_three_interpolate_batch_grad(int b, int c, int n, int m, const float* grad_out, const int* idx,
+                                      const float* weight, float* grad_points, fv2p_stream_t stream);
+int fv2p_three_interpolate_stack(int n, int c, const float* features, const int* idx, const float* weight,
+                                 float* out, fv2p_stream_t stream);
+int fv2p_three_interpolate_stack_grad(int n, int c, const float* grad_out, const int* idx, const float* weight,
+                                      float* grad_features, fv2p_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

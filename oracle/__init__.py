@@ -189,3 +189,206 @@ def indice_group(features, pairs, num, n_out):
         if nh:
             out[k, pairs[k, 1, :nh]] = f[pairs[k, 0, :nh]]
     return out
+
+
+# ---------------------------------------------------------------- iou3d / NMS ---------------
+def boxes_bev(boxes_a, boxes_b, mode="iou"):
+    """iou3d_nms_kernel.cu:236-265 restated: pairwise BEV overlap area (mode='overlap') or IoU (mode='iou')."""
+    a = np.ascontiguousarray(boxes_a, dtype=np.float32)
+    b = np.ascontiguousarray(boxes_b, dtype=np.float32)
+    out = np.zeros((a.shape[0], b.shape[0]), np.float32)
+    f = lib().oracle_boxes_bev
+    f.restype = None
+    f.argtypes = [ctypes.POINTER(_f32), ctypes.c_int, ctypes.POINTER(_f32), ctypes.c_int, ctypes.c_int, ctypes.POINTER(_f32)]
+    f(_p(a, _f32), a.shape[0], _p(b, _f32), b.shape[0], 1 if mode == "iou" else 0, _p(out, _f32))
+    return out
+
+
+def boxes_iou3d(boxes_a, boxes_b):
+    """iou3d_nms_utils.py:454-491 restated in numpy float32."""
+    a = np.asarray(boxes_a, np.float32)
+    b = np.asarray(boxes_b, np.float32)
+    ov = boxes_bev(a, b, "overlap")
+    a_max, a_min = (a[:, 2] + a[:, 5] / 2)[:, None], (a[:, 2] - a[:, 5] / 2)[:, None]
+    b_max, b_min = (b[:, 2] + b[:, 5] / 2)[None, :], (b[:, 2] - b[:, 5] / 2)[None, :]
+    oh = np.clip(np.minimum(a_max, b_max) - np.maximum(a_min, b_min), 0, None)
+    o3 = ov * oh
+    va, vb = (a[:, 3] * a[:, 4] * a[:, 5])[:, None], (b[:, 3] * b[:, 4] * b[:, 5])[None, :]
+    return np.clip(o3 / np.clip(va + vb - o3, 1e-6, None), 0, 1).astype(np.float32)
+
+
+def nms(boxes, scores, thresh, pre_maxsize=None, normal=False):
+    """iou3d_nms_utils.py:494-526 restated: stable descending score sort, optional cut, greedy suppression.
+    Returns indices into `boxes`."""
+    boxes = np.ascontiguousarray(boxes, dtype=np.float32)
+    order = np.argsort(-np.asarray(scores, np.float32), kind="stable")
+    if pre_maxsize is not None:
+        order = order[:pre_maxsize]
+    sb = np.ascontiguousarray(boxes[order])
+    keep = np.zeros((max(sb.shape[0], 1),), np.int64)
+    f = lib().oracle_nms
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.POINTER(_f32), ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.POINTER(_i64)]
+    num = f(_p(sb, _f32), sb.shape[0], float(thresh), int(normal), _p(keep, _i64))
+    return order[keep[:num]]
+
+
+# ---------------------------------------------------------------- roiaware / roipoint ---------
+def points_in_boxes_gpu(points, boxes):
+    """roiaware_pool3d_kernel.cu:313-336 restated: points (B,M,3), boxes (B,T,7) -> (B,M) first box index or -1."""
+    p = np.ascontiguousarray(points, np.float32)
+    b = np.ascontiguousarray(boxes, np.float32)
+    out = np.full((p.shape[0], p.shape[1]), -1, np.int32)
+    f = lib().oracle_points_in_boxes_gpu
+    f.restype = None
+    f.argtypes = [ctypes.POINTER(_f32), ctypes.POINTER(_f32), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_i32)]
+    f(_p(b, _f32), _p(p, _f32), p.shape[0], b.shape[1], p.shape[1], _p(out, _i32))
+    return out
+
+
+def points_in_boxes_cpu(points, boxes):
+    """roiaware_pool3d.cpp:143-168 restated: points (M,3), boxes (N,7) -> (N,M) 0/1 with MARGIN 1e-2."""
+    p = np.ascontiguousarray(points, np.float32)
+    b = np.ascontiguousarray(boxes, np.float32)
+    out = np.zeros((b.shape[0], p.shape[0]), np.int32)
+    f = lib().oracle_points_in_boxes_cpu
+    f.restype = None
+    f.argtypes = [ctypes.POINTER(_f32), ctypes.POINTER(_f32), ctypes.c_int, ctypes.c_int, ctypes.POINTER(_i32)]
+    f(_p(b, _f32), _p(p, _f32), b.shape[0], p.shape[0], _p(out, _i32))
+    return out
+
+
+def roipoint_pool3d(points, point_features, pooled_boxes3d, num_sampled_points=512):
+    """roipoint_pool3d_kernel.cu:38-130 restated on already-enlarged boxes."""
+    xyz = np.ascontiguousarray(points, np.float32)
+    ft = np.ascontiguousarray(point_features, np.float32)
+    bx = np.ascontiguousarray(pooled_boxes3d, np.float32)
+    B, N, _ = xyz.shape
+    M, C = bx.shape[1], ft.shape[2]
+    pooled = np.zeros((B, M, num_sampled_points, 3 + C), np.float32)
+    flag = np.zeros((B, M), np.int32)
+    f = lib().oracle_roipoint_pool3d
+    f.restype = None
+    f.argtypes = [ctypes.POINTER(_f32)] * 3 + [ctypes.c_int] * 5 + [ctypes.POINTER(_f32), ctypes.POINTER(_i32)]
+    f(_p(xyz, _f32), _p(bx, _f32), _p(ft, _f32), B, N, M, C, num_sampled_points, _p(pooled, _f32), _p(flag, _i32))
+    return pooled, flag
+
+
+def roiaware_pool3d(rois, pts, pts_feature, out_size, max_pts_each_voxel, pool_method):
+    """roiaware_pool3d_kernel.cu:39-232 restated. Returns (pooled, argmax, pts_idx_of_voxels)."""
+    r = np.ascontiguousarray(rois, np.float32)
+    p = np.ascontiguousarray(pts, np.float32)
+    ft = np.ascontiguousarray(pts_feature, np.float32)
+    ox, oy, oz = (out_size,) * 3 if isinstance(out_size, int) else out_size
+    R, C = r.shape[0], ft.shape[1]
+    pooled = np.zeros((R, ox, oy, oz, C), np.float32)
+    argmax = np.zeros((R, ox, oy, oz, C), np.int32)
+    vox = np.zeros((R, ox, oy, oz, max_pts_each_voxel), np.int32)
+    f = lib().oracle_roiaware_pool3d
+    f.restype = None
+    f.argtypes = [ctypes.POINTER(_f32)] * 3 + [ctypes.c_int] * 8 + [ctypes.POINTER(_i32), ctypes.POINTER(_i32), ctypes.POINTER(_f32)]
+    f(_p(r, _f32), _p(p, _f32), _p(ft, _f32), R, p.shape[0], C, max_pts_each_voxel, ox, oy, oz, {"max": 0, "avg": 1}[pool_method],
+      _p(argmax, _i32), _p(vox, _i32), _p(pooled, _f32))
+    return pooled, argmax, vox
+
+
+# ---------------------------------------------------------------- pointnet2 -------------------
+def _pf(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def _pi(a):
+    return np.ascontiguousarray(a, np.int32)
+
+
+_PF, _PI = ctypes.POINTER(_f32), ctypes.POINTER(_i32)
+
+
+def ball_query_batch(radius, nsample, xyz, new_xyz):
+    xyz, new_xyz = _pf(xyz), _pf(new_xyz)
+    B, N, _ = xyz.shape
+    M = new_xyz.shape[1]
+    idx = np.zeros((B, M, nsample), np.int32)
+    f = lib().oracle_ball_query_batch
+    f.restype = None
+    f.argtypes = [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_int, _PF, _PF, _PI]
+    f(B, N, M, radius, nsample, _p(new_xyz, _f32), _p(xyz, _f32), _p(idx, _i32))
+    return idx
+
+
+def ball_query_stack(radius, nsample, xyz, xyz_cnt, new_xyz, new_cnt):
+    """Raw kernel output (idx[:,0] == -1 marks an empty ball), before pointnet2_utils.py:35-38 zeroes it."""
+    xyz, new_xyz, xyz_cnt, new_cnt = _pf(xyz), _pf(new_xyz), _pi(xyz_cnt), _pi(new_cnt)
+    M = new_xyz.shape[0]
+    idx = np.zeros((M, nsample), np.int32)
+    f = lib().oracle_ball_query_stack
+    f.restype = None
+    f.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, _PF, _PI, _PF, _PI, _PI]
+    f(len(xyz_cnt), M, radius, nsample, _p(new_xyz, _f32), _p(new_cnt, _i32), _p(xyz, _f32), _p(xyz_cnt, _i32), _p(idx, _i32))
+    return idx
+
+
+def voxel_query_stack(max_range, radius, nsample, xyz, new_xyz, new_coords, point_indices):
+    xyz, new_xyz, new_coords, point_indices = _pf(xyz), _pf(new_xyz), _pi(new_coords), _pi(point_indices)
+    M = new_coords.shape[0]
+    B, Z, Y, X = point_indices.shape
+    idx = np.zeros((M, nsample), np.int32)
+    f = lib().oracle_voxel_query_stack
+    f.restype = None
+    f.argtypes = [ctypes.c_int] * 5 + [ctypes.c_float] + [ctypes.c_int] * 3 + [_PF, _PF, _PI, _PI, _PI]
+    f(M, Z, Y, X, nsample, radius, max_range[0], max_range[1], max_range[2], _p(new_xyz, _f32), _p(xyz, _f32), _p(new_coords, _i32),
+      _p(point_indices, _i32), _p(idx, _i32))
+    return idx
+
+
+def furthest_point_sample(xyz, npoint):
+    xyz = _pf(xyz)
+    B, N, _ = xyz.shape
+    temp = np.full((B, N), 1e10, np.float32)
+    out = np.zeros((B, npoint), np.int32)
+    f = lib().oracle_furthest_point_sampling
+    f.restype = None
+    f.argtypes = [ctypes.c_int] * 3 + [_PF, _PF, _PI]
+    f(B, N, npoint, _p(xyz, _f32), _p(temp, _f32), _p(out, _i32))
+    return out, temp
+
+
+def three_nn_batch(unknown, known):
+    """Returns (dist2, idx) — squared distances as the kernel writes them (the python layer takes sqrt)."""
+    unknown, known = _pf(unknown), _pf(known)
+    B, N, _ = unknown.shape
+    d2 = np.zeros((B, N, 3), np.float32)
+    idx = np.zeros((B, N, 3), np.int32)
+    f = lib().oracle_three_nn_batch
+    f.restype = None
+    f.argtypes = [ctypes.c_int] * 3 + [_PF, _PF, _PF, _PI]
+    f(B, N, known.shape[1], _p(unknown, _f32), _p(known, _f32), _p(d2, _f32), _p(idx, _i32))
+    return d2, idx
+
+
+def three_nn_stack(unknown, unk_cnt, known, known_cnt):
+    unknown, known, unk_cnt, known_cnt = _pf(unknown), _pf(known), _pi(unk_cnt), _pi(known_cnt)
+    N = unknown.shape[0]
+    d2 = np.zeros((N, 3), np.float32)
+    idx = np.zeros((N, 3), np.int32)
+    f = lib().oracle_three_nn_stack
+    f.restype = None
+    f.argtypes = [ctypes.c_int, ctypes.c_int, _PF, _PI, _PF, _PI, _PF, _PI]
+    f(len(unk_cnt), N, _p(unknown, _f32), _p(unk_cnt, _i32), _p(known, _f32), _p(known_cnt, _i32), _p(d2, _f32), _p(idx, _i32))
+    return d2, idx
+
+
+def three_interpolate_batch(features, idx, weight):
+    """interpolate_gpu.cu:84-104: features (B,C,M), idx/weight (B,N,3) -> (B,C,N), fp32 left-to-right sum."""
+    f, w = np.asarray(features, np.float32), np.asarray(weight, np.float32)
+    idx = np.asarray(idx)
+    g = np.take_along_axis(f[:, :, None, :], idx[:, None, :, :].astype(np.int64), axis=3)  # (B,C,N,3)
+    return ((w[:, None, :, 0] * g[..., 0] + w[:, None, :, 1] * g[..., 1]) + w[:, None, :, 2] * g[..., 2]).astype(np.float32)
+
+
+def group_points_batch(features, idx):
+    """group_points_gpu.cu:53-72: features (B,C,N), idx (B,npoint,nsample) -> (B,C,npoint,nsample)."""
+    f = np.asarray(features, np.float32)
+    idx = np.asarray(idx).astype(np.int64)
+    B, C, N = f.shape
+    return np.stack([f[b][:, idx[b]] for b in range(B)], 0)

@@ -1,0 +1,79 @@
+"""CPU, world_size 2, gloo: the N>1 plumbing of bench.py (per-rank data, barrier, max-over-ranks timing, aggregate
+throughput) and DistributedDataParallel over a network built from pcdet.ops.spconv modules (run here through the
+CPU oracle mirror, since the HIP path needs a GPU): after backward every rank holds the mean of the per-rank gradients."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, out):
+    for p in (REPO, os.path.join(REPO, "from-voxel-to-point_amd"), os.path.join(REPO, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    import numpy as np
+    from fv2p_harness import dist_utils
+    from oracle.spconv_cpu import cpu_mirror
+    from pcdet.ops import spconv
+    from sparse_util import random_active
+    r, w = dist_utils.init_distributed("gloo")
+    assert (r, w) == (rank, world)
+    seeds = dist_utils.rank_seeds(rank, 2, 3)
+    torch.manual_seed(0)  # identical initial weights on every rank (DDP also broadcasts rank 0's)
+    net = spconv.SparseSequential(
+        spconv.SubMConv3d(4, 8, 3, padding=1, bias=False, indice_key="s1"), torch.nn.BatchNorm1d(8), torch.nn.ReLU(),
+        spconv.SparseConv3d(8, 16, 3, stride=2, padding=1, bias=True, indice_key="d1"))
+    ref = cpu_mirror(net)
+
+    class Step(torch.nn.Module):
+        """DDP needs tensors (not SparseConvTensor objects) in the forward output to trace used parameters; the
+        reference's DDP-wrapped detectors likewise return loss tensors (tools/train_utils/train_utils.py:27)."""
+
+        def __init__(self, body):
+            super().__init__()
+            self.body = body
+
+        def forward(self, feats, coords, shape, batch):
+            return self.body(spconv.SparseConvTensor(feats, coords, shape, batch)).features.square().mean()
+
+    ddp = dist_utils.wrap_ddp(Step(ref))
+    assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel)
+    ind = random_active(seeds[0][0], 2, [6, 10, 10], 150)
+    feats = torch.from_numpy(np.random.default_rng(seeds[0][1]).standard_normal((ind.shape[0], 4)).astype(np.float32))
+    ddp(feats, torch.from_numpy(ind), [6, 10, 10], 2).backward()
+    grads = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+    gathered = [torch.zeros_like(grads) for _ in range(world)]
+    dist.all_gather(gathered, grads)
+    dist_utils.barrier()
+    dt = dist_utils.max_over_ranks(1.0 + rank)
+    thr = dist_utils.aggregate_throughput(4, 10, dt)
+    if rank == 0:
+        torch.save({"seeds": seeds, "same": bool(torch.equal(gathered[0], gathered[1])), "dt": dt, "thr": thr,
+                    "gnorm": float(grads.norm())}, out)
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_data_parallel(tmp_path):
+    out = str(tmp_path / "r0.pt")
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    res = torch.load(out)
+    assert res["same"] and res["gnorm"] > 0            # all-reduced gradients are identical on both ranks
+    assert res["dt"] == 2.0                              # MAX over ranks (rank 1 reported 2.0 s)
+    assert res["thr"] == pytest.approx(4 * 2 * 10 / 2.0)  # whole-job units / max time
+    assert res["seeds"][0][0] == 0                       # rank 0's first seed; rank 1 starts at 100000
+
+
+def test_rank_seeds_are_disjoint():
+    sys.path.insert(0, os.path.join(REPO, "from-voxel-to-point_amd"))
+    from fv2p_harness import dist_utils
+    a = {s for row in dist_utils.rank_seeds(0, 4, 4) for s in row}
+    b = {s for row in dist_utils.rank_seeds(1, 4, 4) for s in row}
+    assert not (a & b) and len(a) == 16

@@ -1,0 +1,173 @@
+"""GPU parity of the pointnet2 ops (A8-A12) through the pcdet API against the oracle restatement.
+
+Bar: index outputs (FPS order, ball/voxel query members, 3-NN indices) bit-exact; squared distances bit-exact
+(same fp32 op order, no fused multiply-add); interpolated / grouped features <= 1e-6 (copies and 3-term sums);
+backward passes against torch autograd on an index-based re-expression, <= 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from fv2p_harness import synth
+from pcdet.ops.pointnet2.pointnet2_batch import pointnet2_modules as bmod
+from pcdet.ops.pointnet2.pointnet2_batch import pointnet2_utils as bu
+from pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as su
+from pcdet.ops.pointnet2.pointnet2_stack import voxel_query_utils as vq
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, gpu):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(gpu)
+
+
+@pytest.mark.parametrize("n,m", [(16384, 16384), (16384, 4096), (5000, 1024), (700, 256), (100, 50), (20000, 512), (3, 3)])
+def test_fps_order_bit_exact(gpu, n, m):
+    pts = np.stack([synth.lidar_cloud(n + b, max(n, 64))[:n, :3] for b in range(2)])
+    out = bu.furthest_point_sample(T(pts, gpu), m)
+    ref, _ = oracle.furthest_point_sample(pts, m)
+    assert out.dtype == torch.int32 and np.array_equal(out.cpu().numpy(), ref)
+    assert (ref[:, 0] == 0).all()
+    out2 = su.furthest_point_sample(T(pts[:1], gpu), m)  # the stack module binds the same kernel
+    assert np.array_equal(out2.cpu().numpy(), ref[:1])
+
+
+def test_fps_ties_follow_reference_reduction(gpu):
+    """Lattice points give many exactly-equal distances: winner = lowest owning thread, then lowest index."""
+    g = np.stack(np.meshgrid(np.arange(16), np.arange(16), np.arange(8), indexing="ij"), -1).reshape(1, -1, 3).astype(np.float32)
+    out = bu.furthest_point_sample(T(g, gpu), 300)
+    ref, _ = oracle.furthest_point_sample(g, 300)
+    assert np.array_equal(out.cpu().numpy(), ref)
+
+
+def test_ball_query_group_gather_batch(gpu):
+    """RoI-head shapes (iouguided_roi_head.py:276): many small samples, 512 points, 216 centres, radii 0.8 / 1.6."""
+    rng = np.random.default_rng(0)
+    B, N, M, C = 48, 512, 216, 128
+    xyz = rng.uniform(-2, 2, (B, N, 3)).astype(np.float32)
+    new = rng.uniform(-2, 2, (B, M, 3)).astype(np.float32)
+    feats = rng.standard_normal((B, C, N)).astype(np.float32)
+    for r, ns in [(0.8, 16), (1.6, 32), (0.05, 8)]:
+        idx = bu.ball_query(r, ns, T(xyz, gpu), T(new, gpu))
+        ref = oracle.ball_query_batch(r, ns, xyz, new)
+        assert np.array_equal(idx.cpu().numpy(), ref)
+    ft = T(feats, gpu).requires_grad_(True)
+    g = bu.grouping_operation(ft, idx)
+    assert np.array_equal(g.detach().cpu().numpy(), oracle.group_points_batch(feats, ref))
+    go = torch.randn(g.shape, device=gpu)
+    g.backward(go)
+    ref_grad = torch.zeros((B, C, N), device=gpu)
+    ref_grad.scatter_add_(2, idx.long().view(B, 1, -1).expand(B, C, -1), go.view(B, C, -1))
+    assert (ft.grad - ref_grad).abs().max().item() < 1e-4
+    # gather
+    sel = T(rng.integers(0, N, (B, 64)).astype(np.int32), gpu)
+    ft2 = T(feats, gpu).requires_grad_(True)
+    ga = bu.gather_operation(ft2, sel)
+    assert torch.equal(ga, torch.gather(ft2, 2, sel.long().unsqueeze(1).expand(B, C, 64)))
+    ga.sum().backward()
+    cnt = torch.zeros((B, N), device=gpu).scatter_add_(1, sel.long(), torch.ones((B, 64), device=gpu))
+    assert torch.equal(ft2.grad, cnt.unsqueeze(1).expand(B, C, N))
+    # QueryAndGroup + SA module run end to end on the ops
+    sa = bmod.PointnetSAModuleMSG(npoint=M, radii=[0.8, 1.6], nsamples=[16, 32], mlps=[[C, 32], [C, 32]], use_xyz=True).to(gpu)
+    nx, nf = sa(T(xyz, gpu), T(feats, gpu), new_xyz=T(new, gpu))
+    assert nf.shape == (B, 64, M)
+    nx2, nf2 = sa(T(xyz[:2], gpu), T(feats[:2], gpu))  # FPS-chosen centres
+    assert nx2.shape == (2, M, 3)
+
+
+def test_three_nn_and_interpolate_batch(gpu):
+    """V2P decoder shape: 16384 keypoints against the voxel centres of one level (top3_interpolate)."""
+    rng = np.random.default_rng(1)
+    kp = synth.lidar_cloud(7, 16384)[:, :3]
+    centres = (np.floor(synth.lidar_cloud(8, 12000)[:, :3] / 0.4) * 0.4 + 0.2).astype(np.float32)  # lattice: many exact ties
+    feats = rng.standard_normal((centres.shape[0], 64)).astype(np.float32)
+    dist, idx = bu.three_nn(T(kp[None], gpu), T(centres[None], gpu))
+    d2, ridx = oracle.three_nn_batch(kp[None], centres[None])
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    assert np.array_equal(dist.cpu().numpy(), np.sqrt(d2))
+    ft = T(feats, gpu).requires_grad_(True)
+    out = bu.top3_interpolate(T(centres, gpu), T(kp, gpu), ft)
+    w = 1.0 / (np.sqrt(d2) + 1e-8)
+    w = (w / w.sum(2, keepdims=True)).astype(np.float32)
+    ref = oracle.three_interpolate_batch(feats.T[None], ridx, w)[0].T
+    assert out.shape == (16384, 64) and np.abs(out.detach().cpu().numpy() - ref).max() < 1e-5
+    go = torch.randn(out.shape, device=gpu)
+    out.backward(go)
+    wt, it = T(w[0], gpu), T(ridx[0], gpu).long()
+    rg = torch.zeros_like(ft)
+    for j in range(3):
+        rg.index_add_(0, it[:, j], go * wt[:, j:j + 1])
+    assert (ft.grad - rg).abs().max().item() < 1e-4
+    # fewer than 3 known points: untouched slots keep index 0 and distance inf (interpolate_gpu.cu:37-57)
+    dist, idx = bu.three_nn(T(kp[None, :100], gpu), T(centres[None, :2], gpu))
+    assert torch.isinf(dist[0, :, 2]).all() and (idx[0, :, 2] == 0).all()
+    xg = bu.top3_interpolate_with_grad(T(centres, gpu), T(kp[:2000], gpu), T(feats, gpu))
+    assert xg.shape == (2000, 64)
+
+
+def test_stack_ops(gpu):
+    rng = np.random.default_rng(2)
+    cnt_xyz, cnt_new = np.array([3000, 1, 2500], np.int32), np.array([300, 200, 290], np.int32)
+    xyz = rng.uniform(-3, 3, (int(cnt_xyz.sum()), 3)).astype(np.float32)
+    new = rng.uniform(-3, 3, (int(cnt_new.sum()), 3)).astype(np.float32)
+    feats = rng.standard_normal((xyz.shape[0], 16)).astype(np.float32)
+    idx, empty = su.ball_query(0.5, 16, T(xyz, gpu), T(cnt_xyz, gpu), T(new, gpu), T(cnt_new, gpu))
+    raw = oracle.ball_query_stack(0.5, 16, xyz, cnt_xyz, new, cnt_new)
+    rempty = raw[:, 0] == -1
+    raw[rempty] = 0
+    assert np.array_equal(idx.cpu().numpy(), raw) and np.array_equal(empty.cpu().numpy(), rempty)
+    assert rempty.any() and not rempty.all()
+    ft = T(feats, gpu).requires_grad_(True)
+    g = su.grouping_operation(ft, T(cnt_xyz, gpu), idx, T(cnt_new, gpu))
+    starts = np.concatenate([[0], np.cumsum(cnt_xyz)[:-1]])
+    bs_of = np.repeat(np.arange(3), cnt_new)
+    gidx = raw + starts[bs_of][:, None]
+    assert np.array_equal(g.detach().cpu().numpy(), feats[gidx].transpose(0, 2, 1))
+    go = torch.randn(g.shape, device=gpu)
+    g.backward(go)
+    rg = torch.zeros_like(ft).index_add_(0, T(gidx.reshape(-1), gpu).long(), go.permute(0, 2, 1).reshape(-1, 16))
+    assert (ft.grad - rg).abs().max().item() < 1e-4
+    nf, _ = su.QueryAndGroup(0.5, 16)(T(xyz, gpu), T(cnt_xyz, gpu), T(new, gpu), T(cnt_new, gpu), T(feats, gpu))
+    assert nf.shape == (new.shape[0], 19, 16) and (nf[T(rempty, gpu)] == 0).all()
+    # three_nn / interpolate (unknown = new, known = xyz)
+    dist, i3 = su.three_nn(T(new, gpu), T(cnt_new, gpu), T(xyz, gpu), T(cnt_xyz, gpu))
+    d2, r3 = oracle.three_nn_stack(new, cnt_new, xyz, cnt_xyz)
+    assert np.array_equal(i3.cpu().numpy(), r3) and np.array_equal(dist.cpu().numpy(), np.sqrt(d2))
+    w = torch.softmax(torch.randn((new.shape[0], 3), device=gpu), 1)
+    ft2 = T(feats, gpu).requires_grad_(True)
+    out = su.three_interpolate(ft2, i3, w)
+    ref = sum(ft2.detach()[i3[:, j].long()] * w[:, j:j + 1] for j in range(3))
+    assert (out - ref).abs().max().item() < 1e-5
+    out.sum().backward()
+    rg = torch.zeros_like(ft2)
+    for j in range(3):
+        rg.index_add_(0, i3[:, j].long(), w[:, j:j + 1].expand(-1, 16))
+    assert (ft2.grad - rg).abs().max().item() < 1e-4
+
+
+def test_voxel_query(gpu):
+    rng = np.random.default_rng(3)
+    Z, Y, X = 8, 40, 40
+    n = 2000
+    flat = rng.choice(Z * Y * X, n, replace=False)
+    coords = np.stack([np.zeros(n, np.int64), flat // (Y * X), (flat // X) % Y, flat % X], 1).astype(np.int32)
+    vs = np.array([0.2, 0.1, 0.1], np.float32)  # z, y, x voxel size
+    xyz = (coords[:, [3, 2, 1]] * vs[[2, 1, 0]] + rng.uniform(0, 1, (n, 3)) * vs[[2, 1, 0]]).astype(np.float32)
+    vol = -np.ones((1, Z, Y, X), np.int32)
+    vol[0, coords[:, 1], coords[:, 2], coords[:, 3]] = np.arange(n)
+    q = rng.integers(0, n, 500)
+    new_coords, new_xyz = np.ascontiguousarray(coords[q]), np.ascontiguousarray(xyz[q] + 0.01)
+    idx, empty = vq.voxel_query([1, 2, 2], 0.25, 16, T(xyz, gpu), T(new_xyz, gpu), T(new_coords, gpu), T(vol, gpu))
+    raw = oracle.voxel_query_stack([1, 2, 2], 0.25, 16, xyz, new_xyz, new_coords, vol)
+    re = raw[:, 0] == -1
+    raw[re] = 0
+    assert np.array_equal(idx.cpu().numpy(), raw) and np.array_equal(empty.cpu().numpy(), re)
+    grp = vq.VoxelQueryAndGrouping([1, 2, 2], 0.25, 16)
+    gf, gx, em = grp(T(new_coords, gpu), T(xyz, gpu), T(np.array([n], np.int32), gpu), T(new_xyz, gpu),
+                     T(np.array([500], np.int32), gpu), T(rng.standard_normal((n, 8)).astype(np.float32), gpu), T(vol, gpu))
+    assert gf.shape == (500, 8, 16) and gx.shape == (500, 3, 16)
+
+
+def test_errors_are_exceptions_not_exit(gpu):
+    with pytest.raises(Exception):
+        bu.ball_query(1.0, 8, torch.zeros(1, 10, 3), torch.zeros(1, 4, 3))  # CPU tensors: the reference would exit(-1)
