@@ -216,15 +216,18 @@ __global__ void group_points_stack_grad_k(int B, int M, int C, int nsample, cons
 // ------------------------------------------------------------------ furthest point sampling -------
 // One workgroup per sample.  Ownership and tie-break follow sampling_gpu.cu:100-216 exactly: with
 // bs = 2^floor(log2 n) (<= 1024) reference threads, thread t owns points t, t+bs, ...; a thread keeps its FIRST
-// maximum (strict >), the tree reduction keeps the LOWER thread on equal values -> winner = max distance, then
-// smallest t, then smallest k.  REG: points + running distances live in registers (n <= THREADS*PPT).
+// maximum (strict >); the block reduction's tie-break is reproduced below.  REG: points + running distances live
+// in registers (n <= THREADS*PPT).
 template <int THREADS, int PPT, bool REG>
 __global__ __launch_bounds__(THREADS) void fps_k(int n, int m, int bs, const float* __restrict__ dataset, float* __restrict__ temp,
                                                  int* __restrict__ idxs) {
   if (m <= 0) return;
   constexpr int NW = THREADS / 64;
-  __shared__ float s_val[2][NW];
+  __shared__ uint64_t s_key[2][NW];
   __shared__ int s_idx[2][NW];
+  int log2bs = 0;
+  while ((1 << (log2bs + 1)) <= bs) ++log2bs;
+  if (log2bs == 0) log2bs = 1;  // bs == 1: a single owner, priority irrelevant (shift by 31 stays defined)
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   dataset += static_cast<int64_t>(b) * n * 3;
   temp += static_cast<int64_t>(b) * n;
@@ -263,22 +266,31 @@ __global__ __launch_bounds__(THREADS) void fps_k(int n, int m, int bs, const flo
         if (d2 > best) { best = d2; besti = k; }
       }
     }
-    // wave argmax: max value, lowest lane on ties
-    float wmax = best;
+    // Block argmax with the reference's tie-break.  Its shared-memory tree (sampling_gpu.cu:93-98,150-207) merges slot
+    // t+s into slot t and keeps slot t unless the other value is strictly larger, so among equal maxima the survivor
+    // is the thread whose index is smallest in BIT-REVERSED order (the s = 1 step prefers even slots, s = 2 then
+    // prefers slots = 0 mod 4, ...).  Encode (value, ~bitrev(tid)) in one 64-bit key and take the maximum.
+    const uint32_t prio = (tid < bs) ? (__brev(static_cast<uint32_t>(tid)) >> (32 - log2bs)) : 0x7fffffffu;
+    const uint32_t vbits = best >= 0.f ? __float_as_uint(best) : 0u;
+    uint64_t key = (static_cast<uint64_t>(vbits) << 32) | static_cast<uint64_t>(0xffffffffu - prio);
+    uint64_t wkey = key;
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, d, 64));
-    const uint64_t who = __ballot(best == wmax);
+    for (int d = 32; d > 0; d >>= 1) {
+      const uint64_t o = __shfl_xor(wkey, d, 64);
+      wkey = o > wkey ? o : wkey;
+    }
+    const uint64_t who = __ballot(key == wkey);
     const int leader = __ffsll(static_cast<long long>(who)) - 1;
     const int widx = __shfl(besti, leader, 64);
     const int buf = j & 1;
-    if (lane == 0) { s_val[buf][w] = wmax; s_idx[buf][w] = widx; }
+    if (lane == 0) { s_key[buf][w] = wkey; s_idx[buf][w] = widx; }
     __syncthreads();
-    float gmax = s_val[buf][0];
+    uint64_t gkey = s_key[buf][0];
     int gidx = s_idx[buf][0];
 #pragma unroll
     for (int ww = 1; ww < NW; ++ww) {
-      const float v = s_val[buf][ww];
-      if (v > gmax) { gmax = v; gidx = s_idx[buf][ww]; }
+      const uint64_t v = s_key[buf][ww];
+      if (v > gkey) { gkey = v; gidx = s_idx[buf][ww]; }
     }
     old = gidx;
     if (tid == 0) idxs[j] = old;

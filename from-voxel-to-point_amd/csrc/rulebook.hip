@@ -87,20 +87,35 @@ __global__ void rb_insert_outputs(const int* __restrict__ ind, int n, RbGeom g, 
                                   uint64_t* __restrict__ uniq, int* __restrict__ n_uniq) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int e = blockIdx.y;
-  if (i >= n) return;
-  const int4 c = reinterpret_cast<const int4*>(ind)[i];
-  const int in[3] = {c.y, c.z, c.w};
-  int out[3], off;
-  if (!enum_out(g, in, e, out, &off)) return;
-  const uint64_t key = flat_key(c.x, out, g.out_shape, g.out_vol);
-  const uint64_t word = slot_pack(key, static_cast<uint32_t>(kValMask));
-  uint32_t h = hash_u64(key, mask);
-  while (true) {
-    unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&table[h]), (unsigned long long)kEmptySlot,
-                                       (unsigned long long)word);
-    if (old == kEmptySlot) { uniq[atomicAdd(n_uniq, 1)] = key; break; }
-    if (slot_key(old) == key) break;
-    h = (h + 1) & mask;
+  bool fresh = false;
+  uint64_t key = 0;
+  if (i < n) {
+    const int4 c = reinterpret_cast<const int4*>(ind)[i];
+    const int in[3] = {c.y, c.z, c.w};
+    int out[3], off;
+    if (enum_out(g, in, e, out, &off)) {
+      key = flat_key(c.x, out, g.out_shape, g.out_vol);
+      const uint64_t word = slot_pack(key, static_cast<uint32_t>(kValMask));
+      uint32_t h = hash_u64(key, mask);
+      while (true) {
+        // plain (L2-coherent) read first: most candidates are duplicates of a key that is already present
+        unsigned long long old = __hip_atomic_load(reinterpret_cast<unsigned long long*>(&table[h]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == kEmptySlot)
+          old = atomicCAS(reinterpret_cast<unsigned long long*>(&table[h]), (unsigned long long)kEmptySlot, (unsigned long long)word);
+        if (old == kEmptySlot) { fresh = true; break; }
+        if (slot_key(old) == key) break;
+        h = (h + 1) & mask;
+      }
+    }
+  }
+  // one atomic per wave: the lanes that inserted a new key take consecutive slots of uniq[]
+  const uint64_t vote = __ballot(fresh);
+  if (vote) {
+    int base = 0;
+    const int leader = __ffsll(static_cast<long long>(vote)) - 1;
+    if ((threadIdx.x & 63) == leader) base = atomicAdd(n_uniq, __popcll(vote));
+    base = __shfl(base, leader, 64);
+    if (fresh) uniq[base + __popcll(vote & lanemask_lt())] = key;
   }
 }
 
@@ -307,8 +322,7 @@ extern "C" int fv2p_rulebook_finish(const int* indices, int64_t n_in, int batch,
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   RbGeom g;
   if (int rc = rb_geom(&g, in_shape, out_shape, ksize, stride, padding, dilation, subm, transpose)) return rc;
-  FV2P_REQUIRE(indice_num, FV2P_EINVAL, "rulebook_finish: null indice_num");
-  FV2P_HIP(hipMemsetAsync(indice_num, 0, sizeof(int) * g.kvol, stream));
+  if (indice_num) FV2P_HIP(hipMemsetAsync(indice_num, 0, sizeof(int) * g.kvol, stream));
   if (n_in == 0) return 0;
   FV2P_REQUIRE(tab_in, FV2P_EINVAL, "rulebook_finish: null tab_in");
   FV2P_REQUIRE(ws && ws_bytes >= fv2p_rulebook_ws_bytes(n_in, ksize, stride, dilation, subm, transpose), FV2P_EWORKSPACE,
@@ -333,8 +347,22 @@ extern "C" int fv2p_rulebook_finish(const int* indices, int64_t n_in, int batch,
   }
   hipLaunchKernelGGL(rb_fill_tables, dim3(nb, g.emax), dim3(T), 0, stream, indices, (int)n_in, (int)n_out, g, w.table, w.cap - 1,
                      tab_in, tab_out);
+  if (indice_num) {
+    const unsigned cb = static_cast<unsigned>(ceil_div(n_in, 1024) < 64 ? ceil_div(n_in, 1024) : 64);
+    hipLaunchKernelGGL(rb_count_rows, dim3(cb, g.kvol), dim3(T), 0, stream, tab_in, (int)n_in, indice_num);
+  }
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fv2p_rulebook_count(const int* tab_in, int64_t n_in, int kvol, int* indice_num, fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FV2P_REQUIRE(indice_num && kvol >= 1 && n_in >= 0, FV2P_EINVAL, "rulebook_count: bad arguments");
+  FV2P_HIP(hipMemsetAsync(indice_num, 0, sizeof(int) * kvol, stream));
+  if (n_in == 0) return 0;
+  FV2P_REQUIRE(tab_in, FV2P_EINVAL, "rulebook_count: null table");
   const unsigned cb = static_cast<unsigned>(ceil_div(n_in, 1024) < 64 ? ceil_div(n_in, 1024) : 64);
-  hipLaunchKernelGGL(rb_count_rows, dim3(cb, g.kvol), dim3(T), 0, stream, tab_in, (int)n_in, indice_num);
+  hipLaunchKernelGGL(rb_count_rows, dim3(cb, kvol), dim3(256), 0, stream, tab_in, (int)n_in, indice_num);
   FV2P_LAUNCH_CHECK();
   return 0;
 }

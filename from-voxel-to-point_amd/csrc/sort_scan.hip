@@ -74,6 +74,35 @@ __global__ __launch_bounds__(kScanThreads) void scan_sums_inplace(int* __restric
   if (threadIdx.x == 0 && total) *total = carry;
 }
 
+// Whole array in one workgroup (n <= kSmallScan): one launch instead of three.
+constexpr int kSmallScan = 16 * kScanTile;
+__global__ __launch_bounds__(kScanThreads) void scan_small(const int* __restrict__ in, int* __restrict__ out, int64_t n,
+                                                           int* __restrict__ total) {
+  __shared__ int lds_wave[4];
+  int carry = 0;
+  for (int64_t c = 0; c < n; c += kScanTile) {
+    const int64_t base = c + threadIdx.x * kScanItems;
+    int v[kScanItems];
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) {
+      const int64_t i = base + j;
+      v[j] = (i < n) ? in[i] : 0;
+      s += v[j];
+    }
+    int tot;
+    int ex = block_excl_scan_256(s, lds_wave, &tot) + carry;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) {
+      const int64_t i = base + j;
+      if (i < n) out[i] = ex;
+      ex += v[j];
+    }
+    carry += tot;
+  }
+  if (threadIdx.x == 0 && total) *total = carry;
+}
+
 __global__ __launch_bounds__(kScanThreads) void scan_apply(const int* __restrict__ in, int* __restrict__ out,
                                                            int64_t n, const int* __restrict__ block_off) {
   __shared__ int lds_wave[4];
@@ -108,6 +137,11 @@ int exclusive_scan_i32(const int* in, int* out, int64_t n, int* total, void* ws,
     if (total) FV2P_HIP(hipMemsetAsync(total, 0, sizeof(int), stream));
     return 0;
   }
+  if (n <= kSmallScan) {
+    hipLaunchKernelGGL(scan_small, dim3(1), dim3(kScanThreads), 0, stream, in, out, n, total);
+    FV2P_LAUNCH_CHECK();
+    return 0;
+  }
   FV2P_REQUIRE(ws_bytes >= scan_ws_bytes(n), FV2P_EWORKSPACE, "scan workspace too small");
   Carver c(ws, ws_bytes);
   const int64_t nb = ceil_div(n, kScanTile);
@@ -121,13 +155,14 @@ int exclusive_scan_i32(const int* in, int* out, int64_t n, int* total, void* ws,
 
 // ------------------------------------------------------------------ radix sort ---------
 constexpr int kSortThreads = 256;
-constexpr int kSortRounds = 16;                          // keys per thread per tile
-constexpr int kSortTile = kSortThreads * kSortRounds;    // 4096 keys per workgroup
+constexpr int kSortRounds = 4;                           // keys per thread per tile
+constexpr int kSortTile = kSortThreads * kSortRounds;    // 1024 keys per workgroup
 constexpr int kRadix = 256;
 
+// hist layout [nblk][256]: hist[b][d] = number of keys of tile b whose digit is d
 __global__ __launch_bounds__(kSortThreads) void radix_hist(const uint64_t* __restrict__ keys, int64_t n,
                                                            int shift, uint32_t digit_mask, int nblk,
-                                                           int* __restrict__ hist /*[256][nblk]*/) {
+                                                           int* __restrict__ hist) {
   __shared__ int lh[kRadix];
   lh[threadIdx.x] = 0;
   __syncthreads();
@@ -141,17 +176,30 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist(const uint64_t* __res
     }
   }
   __syncthreads();
-  hist[static_cast<int64_t>(threadIdx.x) * nblk + blockIdx.x] = lh[threadIdx.x];
+  hist[static_cast<int64_t>(blockIdx.x) * kRadix + threadIdx.x] = lh[threadIdx.x];
 }
 
+// The global offset of (digit d, tile b) = sum_{d' < d} total[d'] + sum_{b' < b} hist[b'][d] is computed by every
+// workgroup for itself (thread d walks column d of hist: nblk coalesced loads), which removes the separate scan launch.
 __global__ __launch_bounds__(kSortThreads) void radix_scatter(const uint64_t* __restrict__ keys,
                                                               uint64_t* __restrict__ out, int64_t n, int shift,
                                                               uint32_t digit_mask, int nblk,
-                                                              const int* __restrict__ offs /*[256][nblk] scanned*/) {
+                                                              const int* __restrict__ hist /*[nblk][256]*/) {
   __shared__ int base[kRadix];           // running output position per digit for this tile
   __shared__ int wave_cnt[4][kRadix];    // per-round, per-wave digit counts
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  base[tid] = offs[static_cast<int64_t>(tid) * nblk + blockIdx.x];
+  __shared__ int lds_wave[4];
+  const int tid = threadIdx.x, w = tid >> 6;
+  {
+    int before = 0, total = 0;
+    for (int b = 0; b < nblk; ++b) {
+      const int v = hist[static_cast<int64_t>(b) * kRadix + tid];
+      total += v;
+      if (b < static_cast<int>(blockIdx.x)) before += v;
+    }
+    int tot;
+    const int ex = block_excl_scan_256(total, lds_wave, &tot);  // exclusive over digits
+    base[tid] = ex + before;
+  }
   const int64_t tile0 = static_cast<int64_t>(blockIdx.x) * kSortTile;
   for (int r = 0; r < kSortRounds; ++r) {
     const int64_t i = tile0 + r * kSortThreads + tid;
@@ -187,7 +235,6 @@ size_t radix_sort_ws_bytes(int64_t n) {
   const int64_t nblk = ceil_div(n > 0 ? n : 1, kSortTile);
   Sizer s;
   s.take<int>(static_cast<size_t>(kRadix * nblk));
-  s.take<char>(scan_ws_bytes(kRadix * nblk));
   return s.bytes();
 }
 
@@ -198,16 +245,12 @@ int radix_sort_u64(uint64_t* keys, uint64_t* tmp, int64_t n, int bit_lo, int bit
   const int nblk = static_cast<int>(ceil_div(n, kSortTile));
   Carver c(ws, ws_bytes);
   int* hist = c.take<int>(static_cast<size_t>(kRadix) * nblk);
-  size_t sws_bytes = scan_ws_bytes(static_cast<int64_t>(kRadix) * nblk);
-  char* sws = c.take<char>(sws_bytes);
   uint64_t* src = keys;
   uint64_t* dst = tmp;
   for (int lo = bit_lo; lo < bit_hi; lo += 8) {
     const int nb = (bit_hi - lo) < 8 ? (bit_hi - lo) : 8;
     const uint32_t dm = (1u << nb) - 1u;
     hipLaunchKernelGGL(radix_hist, dim3(nblk), dim3(kSortThreads), 0, stream, src, n, lo, dm, nblk, hist);
-    int rc = exclusive_scan_i32(hist, hist, static_cast<int64_t>(kRadix) * nblk, nullptr, sws, sws_bytes, stream);
-    if (rc) return rc;
     hipLaunchKernelGGL(radix_scatter, dim3(nblk), dim3(kSortThreads), 0, stream, src, dst, n, lo, dm, nblk, hist);
     uint64_t* t = src; src = dst; dst = t;
   }

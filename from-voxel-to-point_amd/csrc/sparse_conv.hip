@@ -18,6 +18,7 @@
 // Weight gradient: dW_k = sum_r src[tab[k][r], :]^T * grad[r, :], one wave per (row chunk, k,
 // cin-block group); valid rows are compacted with a wave64 ballot so only real pairs reach the MFMA.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace fv2p {
 
@@ -158,6 +159,105 @@ __global__ __launch_bounds__(256) void conv_rows_vec(ConvArgs a) {
   conv_epilogue<NB>(a, acc, row0);
 }
 
+// Compacted variant: the workgroup owns TM destination rows whose accumulators live in LDS.  For every kernel
+// offset the rows that actually have a neighbour are compacted (wave64 ballot + prefix) into a list, and only
+// ceil(n_k / 16) MFMA row groups are issued (round-robin over the 4 waves) instead of TM/16 — the MFMA work follows
+// the real pair count P instead of K*N.  A group loads its 16 accumulator rows from LDS as the MFMA C operand,
+// gathers its A fragment from global memory, and writes the rows back; a row occurs at most once per offset, so
+// groups of one offset never collide, and the barrier between offsets orders the LDS traffic.
+template <int CINP, int NB, bool WT, int TM>
+__global__ __launch_bounds__(256) void conv_rows_cmp(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int J = CINP / 16;
+  constexpr int COLS = NB * 16;
+  constexpr int LDA = COLS + 16;               // accumulator row stride (floats)
+  float* wl = lds;                             // W_k fragments: CINP*COLS floats
+  float* accl = lds + CINP * COLS;             // [TM][LDA]
+  int* lsrc = reinterpret_cast<int*>(accl + TM * LDA);  // [TM]
+  int* lrow = lsrc + TM;                       // [TM]
+  __shared__ int wave_cnt[4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
+  const int row0 = blockIdx.x * TM;
+  for (int e = tid; e < TM * LDA; e += 256) accl[e] = 0.f;
+  for (int k = 0; k < a.kvol; ++k) {
+    const int trow = a.flip ? (a.kvol - 1 - k) : k;
+    int idx[TM / 256 > 0 ? TM / 256 : 1];
+    int total = 0;
+    // ---- compaction of this offset's valid rows (TM may exceed 256: process in slabs of 256 rows)
+#pragma unroll
+    for (int slab = 0; slab < (TM + 255) / 256; ++slab) {
+      const int t = slab * 256 + tid;
+      const int row = row0 + t;
+      const int v = (t < TM && row < a.n_dst) ? a.tab[static_cast<long long>(trow) * a.n_dst + row] : -1;
+      idx[slab] = v;
+      const uint64_t vote = __ballot(v >= 0);
+      if (lane == 0) wave_cnt[w] = __popcll(vote);
+      __syncthreads();  // (first slab: also closes the previous offset's group phase)
+      int pos = total + __popcll(vote & lanemask_lt());
+      for (int ww = 0; ww < w; ++ww) pos += wave_cnt[ww];
+      if (v >= 0) { lsrc[pos] = v; lrow[pos] = t; }
+      total += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+      if (slab + 1 < (TM + 255) / 256) __syncthreads();
+    }
+    if (total == 0) { __syncthreads(); continue; }
+    stage_w_vec<CINP, NB, WT>(a, a.w + static_cast<long long>(k) * a.w_kstride, wl);
+    __syncthreads();
+    const int ngroups = (total + 15) >> 4;
+    for (int gi = w; gi < ngroups; gi += 4) {
+      const int e = gi * 16 + r;
+      const int src = e < total ? lsrc[e] : -1;
+      float4 av[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        av[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (src >= 0 && (16 * j + 4 * g) < a.c_src)
+          av[j] = *reinterpret_cast<const float4*>(a.src + static_cast<long long>(src) * a.ld_src + 16 * j + 4 * g);
+      }
+      int rr[4];
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int ee = gi * 16 + g * 4 + reg;
+        rr[reg] = ee < total ? lrow[ee] : -1;
+      }
+      f32x4 acc[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) acc[nb][reg] = rr[reg] >= 0 ? accl[rr[reg] * LDA + nb * 16 + r] : 0.f;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        float4 bv[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) bv[nb] = *reinterpret_cast<const float4*>(&wl[((j * NB + nb) * 64 + lane) * 4]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].x, bv[nb].x, acc[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].y, bv[nb].y, acc[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].z, bv[nb].z, acc[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].w, bv[nb].w, acc[nb], 0, 0, 0);
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+          if (rr[reg] >= 0) accl[rr[reg] * LDA + nb * 16 + r] = acc[nb][reg];
+    }
+  }
+  __syncthreads();
+  // epilogue: whole rows, coalesced
+  for (int e = tid; e < TM * COLS; e += 256) {
+    const int t = e / COLS, col = e % COLS;
+    const int row = row0 + t;
+    if (row < a.n_dst && col < a.c_dst) {
+      float v = accl[t * LDA + col] + (a.bias ? a.bias[col] : 0.f);
+      float* p = a.dst + static_cast<long long>(row) * a.ld_dst + col;
+      *p = a.accumulate ? (*p + v) : v;
+    }
+  }
+}
+
 // any c_src <= 4*STEPS (scalar row loads): first layer (4 or 5 point features) and odd channel counts
 template <int STEPS, int NB, bool WT>
 __global__ __launch_bounds__(256) void conv_rows_scalar(ConvArgs a) {
@@ -201,22 +301,29 @@ struct WgradArgs {
   int rows_per_chunk;
 };
 
-// One wave per (row chunk, k, cin-block group).  MBW cin blocks x NB cout blocks of 16x16 accumulators.
+// One workgroup per (row chunk, k, cin-block group): its 4 waves split the chunk's rows, each compacts the valid
+// rows of its slice with a wave64 ballot so only real pairs reach the MFMA, the four partial [16*MBW, 16*NB]
+// tiles are summed in LDS and written to partial[chunk][k] (no global atomics; a second kernel adds the chunks,
+// so the result is deterministic).
 template <int MBW, int NB>
-__global__ __launch_bounds__(64) void conv_wgrad(WgradArgs a) {
-  __shared__ int s_src[64];
-  __shared__ int s_row[64];
-  const int lane = threadIdx.x, m = lane & 15, g = lane >> 4;
+__global__ __launch_bounds__(256) void conv_wgrad(WgradArgs a, float* __restrict__ partial) {
+  __shared__ int s_src[4][64];
+  __shared__ int s_row[4][64];
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [MBW*16][NB*16]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, m = lane & 15, g = lane >> 4;
   const int k = blockIdx.y;
   const int trow = a.flip ? (a.kvol - 1 - k) : k;
   const int mb0 = blockIdx.z * MBW;
+  constexpr int TILE = MBW * 16 * NB * 16;
+  for (int e = threadIdx.x; e < TILE; e += 256) red[e] = 0.f;
   f32x4 acc[MBW][NB];
 #pragma unroll
   for (int i = 0; i < MBW; ++i)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[i][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int r_begin = blockIdx.x * a.rows_per_chunk;
-  const int r_end = min(r_begin + a.rows_per_chunk, a.n_dst);
+  const int per_wave = a.rows_per_chunk / 4;
+  const int r_begin = blockIdx.x * a.rows_per_chunk + w * per_wave;
+  const int r_end = min(r_begin + per_wave, a.n_dst);
   bool touched = false;
   for (int base = r_begin; base < r_end; base += 64) {
     const int row = base + lane;
@@ -227,15 +334,14 @@ __global__ __launch_bounds__(64) void conv_wgrad(WgradArgs a) {
     const int cnt = __popcll(vote);
     if (idx >= 0) {
       const int pos = __popcll(vote & lanemask_lt());
-      s_src[pos] = idx;
-      s_row[pos] = row;
+      s_src[w][pos] = idx;
+      s_row[w][pos] = row;
     }
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes of this wave are visible to its own reads
     __builtin_amdgcn_wave_barrier();
     for (int p0 = 0; p0 < cnt; p0 += 4) {
       const int p = p0 + g;
-      const int sr = (p < cnt) ? s_src[p] : -1;
-      const int rr = (p < cnt) ? s_row[p] : -1;
+      const int sr = (p < cnt) ? s_src[w][p] : -1;
+      const int rr = (p < cnt) ? s_row[w][p] : -1;
       float av[MBW], bv[NB];
 #pragma unroll
       for (int i = 0; i < MBW; ++i) {
@@ -254,22 +360,57 @@ __global__ __launch_bounds__(64) void conv_wgrad(WgradArgs a) {
     }
     __builtin_amdgcn_wave_barrier();
   }
-  if (!touched) return;
-  float* dwk = a.dw + static_cast<long long>(k) * a.dw_kstride;
+  __syncthreads();  // red[] zeroed
+  if (touched) {
 #pragma unroll
-  for (int i = 0; i < MBW; ++i)
+    for (int i = 0; i < MBW; ++i)
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+      for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int cr = (mb0 + i) * 16 + g * 4 + reg, cc = nb * 16 + m;
-        if (cr < a.c_src && cc < a.c_grad) atomicAdd(&dwk[static_cast<long long>(cr) * a.dw_ld + cc], acc[i][nb][reg]);
-      }
+        for (int reg = 0; reg < 4; ++reg) atomicAdd(&red[(i * 16 + g * 4 + reg) * (NB * 16) + nb * 16 + m], acc[i][nb][reg]);
+  }
+  __syncthreads();
+  // partial[chunk][k][c_src][c_grad]
+  float* out = partial + (static_cast<long long>(blockIdx.x) * a.kvol + k) * a.c_src * a.c_grad;
+  for (int e = threadIdx.x; e < TILE; e += 256) {
+    const int cr = mb0 * 16 + e / (NB * 16), cc = e % (NB * 16);
+    if (cr < a.c_src && cc < a.c_grad) out[static_cast<long long>(cr) * a.c_grad + cc] = red[e];
+  }
+}
+
+// dW[k][cr][d0 + cc] = sum over chunks of partial[chunk][k][cr][cc]
+__global__ void wgrad_reduce(const float* __restrict__ partial, int chunks, int kvol, int c_src, int c_grad, float* __restrict__ dw,
+                             long long dw_kstride, int dw_ld) {
+  const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const long long per_chunk = static_cast<long long>(kvol) * c_src * c_grad;
+  if (t >= per_chunk) return;
+  float s = 0.f;
+  for (int c = 0; c < chunks; ++c) s += partial[c * per_chunk + t];
+  const int cc = static_cast<int>(t % c_grad), cr = static_cast<int>((t / c_grad) % c_src), k = static_cast<int>(t / (static_cast<long long>(c_grad) * c_src));
+  dw[k * dw_kstride + static_cast<long long>(cr) * dw_ld + cc] = s;
 }
 
 // ---- dispatch -----------------------------------------------------------------------------------
+static int conv_impl() {  // FV2P_CONV_IMPL=dense|cmp overrides the heuristic (used by the parity tests)
+  static int impl = -1;
+  if (impl < 0) {
+    const char* e = getenv("FV2P_CONV_IMPL");
+    impl = (e && e[0] == 'd') ? 1 : (e && e[0] == 'c') ? 2 : 0;
+  }
+  return impl;
+}
+
 template <int CINP, int NB, bool WT>
 static void launch_vec(const ConvArgs& a, hipStream_t s) {
+  constexpr int TM = 128;
+  constexpr size_t cmp_lds = (static_cast<size_t>(CINP) * NB * 16 + static_cast<size_t>(TM) * (NB * 16 + 16)) * sizeof(float) + 2 * TM * sizeof(int);
+  const int impl = conv_impl();
+  const bool use_cmp = (impl == 2 || (impl == 0 && a.kvol > 1)) && cmp_lds <= 64 * 1024;
+  if (use_cmp) {
+    const unsigned blocks = static_cast<unsigned>(ceil_div(a.n_dst, TM));
+    hipLaunchKernelGGL((conv_rows_cmp<CINP, NB, WT, TM>), dim3(blocks), dim3(256), cmp_lds, s, a);
+    return;
+  }
   const unsigned blocks = static_cast<unsigned>(ceil_div(a.n_dst, 64));
   hipLaunchKernelGGL((conv_rows_vec<CINP, NB, WT>), dim3(blocks), dim3(256), CINP * NB * 16 * sizeof(float), s, a);
 }
@@ -350,16 +491,32 @@ extern "C" int fv2p_sparse_conv_rows(const float* src, int64_t n_src, int c_src,
   return 0;
 }
 
+static int wgrad_rows_per_chunk(int64_t n_dst) { return n_dst > 200000 ? 2048 : (n_dst > 50000 ? 1024 : 512); }
+
+extern "C" size_t fv2p_sparse_conv_wgrad_ws_bytes(int64_t n_dst, int c_src, int c_dst, int kvol) {
+  const int64_t chunks = ceil_div(n_dst > 0 ? n_dst : 1, wgrad_rows_per_chunk(n_dst));
+  const int cd = c_dst < 128 ? c_dst : 128;
+  Sizer s;
+  s.take<float>(static_cast<size_t>(chunks) * kvol * c_src * cd);
+  return s.bytes();
+}
+
 extern "C" int fv2p_sparse_conv_wgrad(const float* src, int64_t n_src, int c_src, const float* grad, const int* tab, int64_t n_dst,
-                                      int c_dst, int kvol, int flip_k, float* dweight, fv2p_stream_t stream_) {
+                                      int c_dst, int kvol, int flip_k, float* dweight, void* ws, size_t ws_bytes,
+                                      fv2p_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   FV2P_REQUIRE(c_src >= 1 && c_dst >= 1 && kvol >= 1 && n_dst >= 0, FV2P_EINVAL, "sparse_conv_wgrad: bad sizes");
   FV2P_REQUIRE(dweight, FV2P_EINVAL, "sparse_conv_wgrad: null dweight");
-  FV2P_HIP(hipMemsetAsync(dweight, 0, sizeof(float) * (size_t)kvol * c_src * c_dst, stream));
-  if (n_dst == 0 || n_src == 0) return 0;
+  if (n_dst == 0 || n_src == 0) {
+    FV2P_HIP(hipMemsetAsync(dweight, 0, sizeof(float) * (size_t)kvol * c_src * c_dst, stream));
+    return 0;
+  }
   FV2P_REQUIRE(src && grad && tab, FV2P_EINVAL, "sparse_conv_wgrad: null pointer");
-  const int rows_per_chunk = 2048;
+  FV2P_REQUIRE(ws && ws_bytes >= fv2p_sparse_conv_wgrad_ws_bytes(n_dst, c_src, c_dst, kvol), FV2P_EWORKSPACE,
+               "sparse_conv_wgrad: workspace too small");
+  const int rows_per_chunk = wgrad_rows_per_chunk(n_dst);
   const unsigned chunks = static_cast<unsigned>(ceil_div(n_dst, rows_per_chunk));
+  float* partial = static_cast<float*>(ws);
   for (int d0 = 0; d0 < c_dst; d0 += 128) {
     const int cd = (c_dst - d0) < 128 ? (c_dst - d0) : 128;
     WgradArgs a;
@@ -374,13 +531,17 @@ extern "C" int fv2p_sparse_conv_wgrad(const float* src, int64_t n_src, int c_src
     // accumulators per wave: MBW*NB <= 16
     const int mbw = nbp == 8 ? 2 : (mb >= 4 ? 4 : mb >= 2 ? 2 : 1);
     const unsigned gz = static_cast<unsigned>(ceil_div(mb, mbw));
-    const dim3 grid(chunks, kvol, gz), block(64);
-#define FV2P_WG(MBW, NB) hipLaunchKernelGGL((conv_wgrad<MBW, NB>), grid, block, 0, stream, a)
+    const dim3 grid(chunks, kvol, gz), block(256);
+    const size_t lds = static_cast<size_t>(mbw) * 16 * nbp * 16 * sizeof(float);
+#define FV2P_WG(MBW, NB) hipLaunchKernelGGL((conv_wgrad<MBW, NB>), grid, block, lds, stream, a, partial)
     if (nbp == 8) { FV2P_WG(2, 8); }
     else if (nbp == 4) { if (mbw == 4) FV2P_WG(4, 4); else if (mbw == 2) FV2P_WG(2, 4); else FV2P_WG(1, 4); }
     else if (nbp == 2) { if (mbw == 4) FV2P_WG(4, 2); else if (mbw == 2) FV2P_WG(2, 2); else FV2P_WG(1, 2); }
     else { if (mbw == 4) FV2P_WG(4, 1); else if (mbw == 2) FV2P_WG(2, 1); else FV2P_WG(1, 1); }
 #undef FV2P_WG
+    const long long per_chunk = static_cast<long long>(kvol) * c_src * cd;
+    hipLaunchKernelGGL(wgrad_reduce, dim3(static_cast<unsigned>(ceil_div(per_chunk, 256))), dim3(256), 0, stream, partial, (int)chunks, kvol,
+                       c_src, cd, a.dw, a.dw_kstride, a.dw_ld);
   }
   FV2P_LAUNCH_CHECK();
   return 0;

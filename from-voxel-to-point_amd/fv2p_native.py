@@ -101,23 +101,38 @@ def last_error():
     return lib().fv2p_last_error().decode()
 
 
-def call(name, *args):
-    """Calls an int-returning entry point, converting tensors to device pointers; raises on error."""
+_BOUND = {}
+
+
+def _bind(name):
     l = lib()
     p = declared_symbols()[name]
-    if len(args) != len(p.params):
-        raise TypeError(f"{name} expects {len(p.params)} arguments, got {len(args)}")
-    conv = []
-    for (kind, ctype, n), a in zip(p.params, args):
-        if kind == "ptr":
-            conv.append(ptr(a))
-        elif kind == "hostarr":
-            vals = [a[i] for i in range(n)]
-            conv.append((ctype * n)(*vals))
+    fn = getattr(l, name)
+    kinds = tuple(k for k, _, _ in p.params)
+    arrs = tuple((c * n) if k == "hostarr" else None for k, c, n in p.params)
+    ent = (fn, kinds, arrs, p.restype is ctypes.c_int)
+    _BOUND[name] = ent
+    return ent
+
+
+def call(name, *args):
+    """Calls an entry point, converting tensors to device pointers; raises Fv2pError on a negative return code.
+    (Hot: kept allocation-light — one tuple build and one foreign call.)"""
+    ent = _BOUND.get(name) or _bind(name)
+    fn, kinds, arrs, is_int = ent
+    if len(args) != len(kinds):
+        raise TypeError(f"{name} expects {len(kinds)} arguments, got {len(args)}")
+    conv = [None] * len(args)
+    for i, a in enumerate(args):
+        k = kinds[i]
+        if k == "scalar":
+            conv[i] = a
+        elif k == "ptr":
+            conv[i] = a if (a is None or isinstance(a, int)) else a.data_ptr()
         else:
-            conv.append(a)
-    rc = getattr(l, name)(*conv)
-    if p.restype is ctypes.c_int and rc < 0:
+            conv[i] = arrs[i](*a)
+    rc = fn(*conv)
+    if is_int and rc < 0:
         raise Fv2pError(f"{name} failed ({rc}): {last_error()}")
     return rc
 
@@ -131,8 +146,38 @@ def ptr(t):
 
 
 def stream():
-    import torch
-    return torch.cuda.current_stream().cuda_stream
+    return _torch().cuda.current_stream().cuda_stream
+
+
+_TORCH = None
+
+
+def _torch():
+    global _TORCH
+    if _TORCH is None:
+        import torch
+        _TORCH = torch
+    return _TORCH
+
+
+class _NoGuard(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NOGUARD = _NoGuard()
+
+
+def device_guard(device):
+    """`torch.cuda.device(device)` only when `device` is not already current (the context manager costs ~10 us)."""
+    t = _torch()
+    idx = device.index
+    if idx is None or idx == t.cuda.current_device():
+        return _NOGUARD
+    return t.cuda.device(device)
 
 
 _WS = {}
@@ -143,11 +188,11 @@ def workspace(nbytes, device):
 
     All library calls are issued on the caller's current stream, so reuse across consecutive
     calls is ordered by the stream itself."""
-    import torch
-    key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
+    torch = _torch()
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        buf = torch.empty(max(int(nbytes) * 2, 1 << 22), dtype=torch.uint8, device=device)
         _WS[key] = buf
     return buf
 

@@ -39,7 +39,7 @@ def points_to_voxel_gpu(points, voxel_size, coors_range, max_points=35, reverse_
     coors = torch.empty((max_voxels, 3), dtype=torch.int32, device=dev)
     num = torch.empty((max_voxels,), dtype=torch.int32, device=dev)
     count = torch.empty((1,), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _nat.device_guard(dev):
         ws_bytes = _nat.lib().fv2p_points_to_voxel_ws_bytes(n, max_voxels)
         ws = _nat.workspace(ws_bytes, dev)
         _nat.call("fv2p_points_to_voxel", points, n, ndim, voxel_size.tolist(), coors_range[:3].tolist(),

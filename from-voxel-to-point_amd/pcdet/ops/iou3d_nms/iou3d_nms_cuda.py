@@ -15,7 +15,7 @@ def _check(t, name, cuda=True):
 def boxes_overlap_bev_gpu(boxes_a, boxes_b, ans_overlap):
     for t, n in ((boxes_a, "boxes_a"), (boxes_b, "boxes_b"), (ans_overlap, "ans_overlap")):
         _check(t, n)
-    with torch.cuda.device(boxes_a.device):
+    with _nat.device_guard(boxes_a.device):
         _nat.call("fv2p_boxes_overlap_bev", boxes_a, boxes_a.shape[0], boxes_b, boxes_b.shape[0], ans_overlap, _nat.stream())
     return 1
 
@@ -23,7 +23,7 @@ def boxes_overlap_bev_gpu(boxes_a, boxes_b, ans_overlap):
 def boxes_iou_bev_gpu(boxes_a, boxes_b, ans_iou):
     for t, n in ((boxes_a, "boxes_a"), (boxes_b, "boxes_b"), (ans_iou, "ans_iou")):
         _check(t, n)
-    with torch.cuda.device(boxes_a.device):
+    with _nat.device_guard(boxes_a.device):
         _nat.call("fv2p_boxes_iou_bev", boxes_a, boxes_a.shape[0], boxes_b, boxes_b.shape[0], ans_iou, _nat.stream())
     return 1
 
@@ -45,7 +45,7 @@ def nms_device(boxes, thresh, normal=False):
     n = boxes.shape[0]
     keep = torch.empty((max(n, 1),), dtype=torch.int64, device=boxes.device)
     cnt = torch.zeros((1,), dtype=torch.int32, device=boxes.device)
-    with torch.cuda.device(boxes.device):
+    with _nat.device_guard(boxes.device):
         nb = _nat.lib().fv2p_nms_ws_bytes(n)
         ws = _nat.workspace(nb, boxes.device)
         _nat.call("fv2p_nms", boxes, n, float(thresh), int(bool(normal)), keep, cnt, ws, ws.numel(), _nat.stream())

@@ -11,7 +11,7 @@ def _go(name, dev_tensor, *args):
     for a in ts:
         if not a.is_contiguous():
             raise _nat.Fv2pError(f"{name}: tensors must be contiguous")
-    with torch.cuda.device(dev_tensor.device):
+    with _nat.device_guard(dev_tensor.device):
         _nat.call(name, *args, _nat.stream())
     return 1
 

@@ -9,7 +9,7 @@ def forward(rois, pts, pts_feature, argmax, pts_idx_of_voxels, pooled_features, 
     _nat.require_cuda(rois, pts, pts_feature, argmax, pts_idx_of_voxels, pooled_features)
     boxes_num, out_x, out_y, out_z, channels = pooled_features.shape
     max_pts = pts_idx_of_voxels.shape[4]
-    with torch.cuda.device(rois.device):
+    with _nat.device_guard(rois.device):
         _nat.call("fv2p_roiaware_pool3d_fwd", rois.contiguous(), pts.contiguous(), pts_feature.contiguous(), boxes_num, pts.shape[0],
                   channels, max_pts, out_x, out_y, out_z, int(pool_method), argmax, pts_idx_of_voxels, pooled_features, _nat.stream())
     return 1
@@ -19,7 +19,7 @@ def backward(pts_idx_of_voxels, argmax, grad_out, grad_in, pool_method):
     _nat.require_cuda(pts_idx_of_voxels, argmax, grad_out, grad_in)
     boxes_num, out_x, out_y, out_z, max_pts = pts_idx_of_voxels.shape
     channels = grad_out.shape[4]
-    with torch.cuda.device(grad_out.device):
+    with _nat.device_guard(grad_out.device):
         _nat.call("fv2p_roiaware_pool3d_bwd", pts_idx_of_voxels, argmax, grad_out.contiguous(), boxes_num, out_x, out_y, out_z, channels,
                   max_pts, int(pool_method), grad_in, _nat.stream())
     return 1
@@ -28,7 +28,7 @@ def backward(pts_idx_of_voxels, argmax, grad_out, grad_in, pool_method):
 def points_in_boxes_gpu(boxes_tensor, pts_tensor, box_idx_of_points_tensor):
     _nat.require_cuda(boxes_tensor, pts_tensor, box_idx_of_points_tensor)
     b, t, _ = boxes_tensor.shape
-    with torch.cuda.device(boxes_tensor.device):
+    with _nat.device_guard(boxes_tensor.device):
         _nat.call("fv2p_points_in_boxes", boxes_tensor.contiguous(), pts_tensor.contiguous(), b, t, pts_tensor.shape[1],
                   box_idx_of_points_tensor, _nat.stream())
     return 1

@@ -12,6 +12,6 @@ def forward(xyz, boxes3d, pts_feature, pooled_features, pooled_empty_flag):
             raise _nat.Fv2pError("roipoint_pool3d: tensors must be contiguous")
     b, n, _ = xyz.shape
     m, c, s = boxes3d.shape[1], pts_feature.shape[2], pooled_features.shape[2]
-    with torch.cuda.device(xyz.device):
+    with _nat.device_guard(xyz.device):
         _nat.call("fv2p_roipoint_pool3d", xyz, boxes3d, pts_feature, b, n, m, c, s, pooled_features, pooled_empty_flag, _nat.stream())
     return 1

@@ -113,15 +113,15 @@ class SparseConvolution(SparseModule):
         n_out = outids.shape[0]
         if self.fused_bn:
             assert self.bias is not None
-            out_features = ops.fused_indice_conv(features, self.weight, self.bias, rb, rb.indice_pair_num, n_out,
+            out_features = ops.fused_indice_conv(features, self.weight, self.bias, rb, None, n_out,
                                                  self.inverse, self.subm)
         else:
             if self.subm:
-                out_features = Fsp.indice_subm_conv(features, self.weight, rb, rb.indice_pair_num, n_out)
+                out_features = Fsp.indice_subm_conv(features, self.weight, rb, None, n_out)
             elif self.inverse:
-                out_features = Fsp.indice_inverse_conv(features, self.weight, rb, rb.indice_pair_num, n_out)
+                out_features = Fsp.indice_inverse_conv(features, self.weight, rb, None, n_out)
             else:
-                out_features = Fsp.indice_conv(features, self.weight, rb, rb.indice_pair_num, n_out)
+                out_features = Fsp.indice_conv(features, self.weight, rb, None, n_out)
             if self.bias is not None:
                 out_features += self.bias
         out_tensor = SparseConvTensor(out_features, outids, out_spatial_shape, batch_size)

@@ -45,7 +45,7 @@ class SparseGroup(SparseModule):
                                     self.padding, self.dilation, self.output_padding, self.subm, False)
             input.indice_dict[self.indice_key] = rb
         fn = Fsp.indice_subm_group if self.subm else Fsp.indice_group
-        out_features = fn(features, rb, rb.indice_pair_num, rb.outids.shape[0]).permute(1, 0, 2)
+        out_features = fn(features, rb, None, rb.outids.shape[0]).permute(1, 0, 2)
         out_shape = input.spatial_shape if self.subm else rb.out_spatial_shape
         out_tensor = SparseConvTensor(out_features, rb.outids, out_shape, input.batch_size)
         out_tensor.indice_dict = input.indice_dict

@@ -46,7 +46,7 @@ class Rulebook(object):
     def __init__(self, outids, indices, tab_in, tab_out, indice_num, spatial_shape, kvol, subm):
         self.outids, self.indices = outids, indices
         self.tab_in, self.tab_out = tab_in, tab_out  # tab_out None => symmetric subm: tab_out[k] == tab_in[K-1-k]
-        self.indice_pair_num = indice_num
+        self._num = indice_num
         self.spatial_shape = spatial_shape
         self.kvol, self.subm = kvol, subm
         self.n_in, self.n_out = int(indices.shape[0]), int(outids.shape[0])
@@ -60,11 +60,21 @@ class Rulebook(object):
         return (self.tab_in, 0)
 
     @property
+    def indice_pair_num(self):
+        """indiceNum [K] of the reference, counted on first use (the fused kernels never need it)."""
+        if self._num is None:
+            num = torch.empty((self.kvol,), dtype=torch.int32, device=self.tab_in.device)
+            with _nat.device_guard(num.device):
+                _nat.call("fv2p_rulebook_count", self.tab_in, self.n_in, self.kvol, num, _nat.stream())
+            self._num = num
+        return self._num
+
+    @property
     def indice_pairs(self):
         if self._pairs is None:
             pairs = torch.empty((self.kvol, 2, self.n_in), dtype=torch.int32, device=self.tab_in.device)
             if self.n_in > 0:
-                with torch.cuda.device(pairs.device):
+                with _nat.device_guard(pairs.device):
                     nb = _nat.lib().fv2p_rulebook_pairs_ws_bytes(self.n_in, self.kvol)
                     ws = _nat.workspace(nb, pairs.device)
                     _nat.call("fv2p_rulebook_pairs", self.tab_in, self.n_in, self.kvol, pairs, ws, ws.numel(), _nat.stream())
@@ -115,7 +125,7 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize=3, stride=1, paddin
     n_in = int(indices.shape[0])
     dev = indices.device
     symmetric = bool(subm) and all(k % 2 == 1 for k in ksize) and all(d == 1 for d in dilation)
-    with torch.cuda.device(dev):
+    with _nat.device_guard(dev):
         lib = _nat.lib()
         import ctypes
         arr = lambda v: (ctypes.c_int * 3)(*v)
@@ -126,7 +136,7 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize=3, stride=1, paddin
         _nat.call("fv2p_rulebook_begin", ind4, n_in, int(batch_size), *geom, ctypes.addressof(n_out_host), ws, ws.numel(), _nat.stream())
         n_out = int(n_out_host.value)
         tab_in = torch.empty((kvol, n_in), dtype=torch.int32, device=dev)
-        num = torch.empty((kvol,), dtype=torch.int32, device=dev)
+        num = None
         if subm:
             outids4, tab_out = None, (None if symmetric else torch.empty((kvol, n_out), dtype=torch.int32, device=dev))
         else:
@@ -169,11 +179,11 @@ def _rulebook_of(indice_pairs, indice_pair_num, n_src_rows, num_activate_out, in
     n_out = num_activate_out if not inverse else n_src_rows
     tab_in = torch.empty((kvol, n_in), dtype=torch.int32, device=pairs.device)
     tab_out = torch.empty((kvol, n_out), dtype=torch.int32, device=pairs.device)
-    with torch.cuda.device(pairs.device):
+    with _nat.device_guard(pairs.device):
         _nat.call("fv2p_pairs_to_tables", pairs, num, kvol, plen, n_in, n_out, tab_in, tab_out, _nat.stream())
     rb = Rulebook.__new__(Rulebook)
     rb.outids = rb.indices = None
-    rb.tab_in, rb.tab_out, rb.indice_pair_num = tab_in, tab_out, num
+    rb.tab_in, rb.tab_out, rb._num = tab_in, tab_out, num
     rb.spatial_shape, rb.kvol, rb.subm, rb.n_in, rb.n_out, rb._pairs = None, kvol, False, n_in, n_out, pairs
     indice_pairs._fv2p_rulebook = rb
     return rb
@@ -191,7 +201,7 @@ def _conv_rows(src, weight, table, flip, n_dst, c_dst, transpose_w, bias=None):
     w = weight.contiguous()
     kvol = table.shape[0]
     dst = torch.empty((n_dst, c_dst), dtype=torch.float32, device=src.device)
-    with torch.cuda.device(src.device):
+    with _nat.device_guard(src.device):
         _nat.call("fv2p_sparse_conv_rows", src, src.shape[0], src.shape[1], w, kvol, table, n_dst, c_dst, int(flip),
                   int(transpose_w), bias.contiguous() if bias is not None else None, dst, _nat.stream())
     return dst.half() if half else dst
@@ -223,8 +233,11 @@ def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_nu
     (tab_f, flip_f), (tab_b, flip_b) = (rb.in_table(), rb.out_table()) if inverse else (rb.out_table(), rb.in_table())
     din = _conv_rows(g, w, tab_b, flip_b, features.shape[0], cin, True)
     dw = torch.empty_like(w)
-    with torch.cuda.device(feats.device):
-        _nat.call("fv2p_sparse_conv_wgrad", feats, feats.shape[0], cin, g, tab_f, g.shape[0], cout, kvol, int(flip_f), dw, _nat.stream())
+    with _nat.device_guard(feats.device):
+        wsb = _nat.lib().fv2p_sparse_conv_wgrad_ws_bytes(g.shape[0], cin, cout, kvol)
+        ws = _nat.workspace(wsb, feats.device)
+        _nat.call("fv2p_sparse_conv_wgrad", feats, feats.shape[0], cin, g, tab_f, g.shape[0], cout, kvol, int(flip_f), dw, ws, ws.numel(),
+                  _nat.stream())
     dw = dw.reshape(filters.shape)
     if half:
         din, dw = din.half(), dw.half()
@@ -249,7 +262,7 @@ def _table_maxpool(features, table, flip, n_out):
     half = features.dtype == torch.half
     f = features.float().contiguous()
     out = torch.empty((n_out, f.shape[1]), dtype=torch.float32, device=f.device)
-    with torch.cuda.device(f.device):
+    with _nat.device_guard(f.device):
         _nat.call("fv2p_sparse_maxpool_fwd", f, f.shape[0], f.shape[1], table, table.shape[0], n_out, int(flip), out, _nat.stream())
     return out.half() if half else out
 
@@ -258,7 +271,7 @@ def _table_maxpool_backward(features, out_features, out_bp, tab_in):
     half = features.dtype == torch.half
     f, o, g = features.float().contiguous(), out_features.float().contiguous(), out_bp.float().contiguous()
     din = torch.empty_like(f)
-    with torch.cuda.device(f.device):
+    with _nat.device_guard(f.device):
         _nat.call("fv2p_sparse_maxpool_bwd", f, o, g, f.shape[0], f.shape[1], tab_in, tab_in.shape[0], din, _nat.stream())
     return din.half() if half else din
 
@@ -271,7 +284,7 @@ def indice_group(features, indice_pairs, indice_pair_num, num_activate_out, inve
     table, flip = rb.in_table() if inverse else rb.out_table()
     f = features.contiguous()
     out = torch.empty((table.shape[0], num_activate_out, f.shape[1]), dtype=torch.float32, device=f.device)
-    with torch.cuda.device(f.device):
+    with _nat.device_guard(f.device):
         _nat.call("fv2p_sparse_group_fwd", f, f.shape[0], f.shape[1], table, table.shape[0], num_activate_out, int(flip), out, _nat.stream())
     return out
 
@@ -284,6 +297,6 @@ def indice_group_backward(features, out_bp, indice_pairs, indice_pair_num, inver
     table, flip = rb.out_table() if inverse else rb.in_table()
     g = out_bp.contiguous()
     din = torch.empty((features.shape[0], features.shape[1]), dtype=torch.float32, device=g.device)
-    with torch.cuda.device(g.device):
+    with _nat.device_guard(g.device):
         _nat.call("fv2p_sparse_group_bwd", g, g.shape[1], g.shape[2], table, table.shape[0], features.shape[0], int(flip), din, _nat.stream())
     return din

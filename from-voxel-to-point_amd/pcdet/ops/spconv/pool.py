@@ -21,7 +21,7 @@ class SparseMaxPool(SparseModule):
         assert isinstance(input, SparseConvTensor)
         rb = ops.build_rulebook(input.indices, input.batch_size, input.spatial_shape, self.kernel_size, self.stride,
                                 self.padding, self.dilation, 0, self.subm)
-        out_features = Fsp.indice_maxpool(input.features, rb, rb.indice_pair_num, rb.outids.shape[0])
+        out_features = Fsp.indice_maxpool(input.features, rb, None, rb.outids.shape[0])
         out_tensor = SparseConvTensor(out_features, rb.outids, rb.out_spatial_shape, input.batch_size)
         out_tensor.indice_dict = input.indice_dict
         out_tensor.grid = input.grid

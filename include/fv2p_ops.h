@@ -73,7 +73,8 @@ int fv2p_points_to_voxel(const float* points, int64_t n_points, int ndim, const 
  *                   tab_out [K, n_out]  input row feeding output row o through offset k, or -1
  *                                       (may be null: for subm with odd ksize and dilation 1
  *                                        tab_out[k] == tab_in[K-1-k]),
- *                   indice_num [K]      pairs per offset (the reference's indiceNum).
+ *                   indice_num [K]      pairs per offset (the reference's indiceNum); may be null and obtained
+ *                                       later with fv2p_rulebook_count (the fused conv kernels never read it).
  * begin and finish must be given the same workspace (>= fv2p_rulebook_ws_bytes) and arguments.
  * Kernel offset index k = (kz*Ky + ky)*Kx + kx with k_j = in_j - out_j*s_j + p_j (geometry.h:62-73).
  */
@@ -88,6 +89,7 @@ int fv2p_rulebook_finish(const int* indices, int64_t n_in, int batch, const int 
                          const int dilation[3], int subm, int transpose, int64_t n_out, int* out_indices,
                          int* tab_in, int* tab_out, int* indice_num, void* ws, size_t ws_bytes,
                          fv2p_stream_t stream);
+int fv2p_rulebook_count(const int* tab_in, int64_t n_in, int kvol, int* indice_num, fv2p_stream_t stream);
 /* Reference-format pair lists indicePairs [K,2,n_in] (-1 padded, spconv_ops.h:55-57) from tab_in;
  * within one offset pairs are ordered by ascending input row (the CPU reference's order,
  * geometry.h:281-295; the GPU reference's slot order is atomic-order). */
@@ -113,11 +115,13 @@ int fv2p_pairs_to_tables(const int* pairs, const int* indice_num, int kvol, int6
 int fv2p_sparse_conv_rows(const float* src, int64_t n_src, int c_src, const float* weight, int kvol,
                           const int* tab, int64_t n_dst, int c_dst, int flip_k, int transpose_w,
                           const float* bias, float* dst, fv2p_stream_t stream);
-/* dW_k[c_src][c_dst] = sum_r src[tab[k][r],:]^T grad[r,:]   (dweight [K][c_src][c_dst], zeroed here).
- *   forward conv's dW : src=features, grad=dOut [n_out,Cout], tab=tab_out, n_dst=n_out. */
+/* dW_k[c_src][c_dst] = sum_r src[tab[k][r],:]^T grad[r,:]   (dweight [K][c_src][c_dst], fully written here).
+ *   forward conv's dW : src=features, grad=dOut [n_out,Cout], tab=tab_out, n_dst=n_out.
+ * Per-chunk partial tiles go through the workspace and are summed in a fixed order (deterministic, no atomics). */
+size_t fv2p_sparse_conv_wgrad_ws_bytes(int64_t n_dst, int c_src, int c_dst, int kvol);
 int fv2p_sparse_conv_wgrad(const float* src, int64_t n_src, int c_src, const float* grad, const int* tab,
-                           int64_t n_dst, int c_dst, int kvol, int flip_k, float* dweight,
-                           fv2p_stream_t stream);
+                           int64_t n_dst, int c_dst, int kvol, int flip_k, float* dweight, void* ws,
+                           size_t ws_bytes, fv2p_stream_t stream);
 
 /* ---- A7: sparse max-pool / neighbour group over the same tables ------------------------------
  * Replace sparse_conv_ext.indice_maxpool_fp32(+backward) (all.cc:52-63 -> pool_ops.h:25-94; output starts

@@ -33,7 +33,8 @@ def test_fps_order_bit_exact(gpu, n, m):
 
 
 def test_fps_ties_follow_reference_reduction(gpu):
-    """Lattice points give many exactly-equal distances: winner = lowest owning thread, then lowest index."""
+    """Lattice points give many exactly-equal distances: the winner must follow the reference's shared-memory tree
+    (lower slot kept on ties at every halving step => smallest bit-reversed thread index wins)."""
     g = np.stack(np.meshgrid(np.arange(16), np.arange(16), np.arange(8), indexing="ij"), -1).reshape(1, -1, 3).astype(np.float32)
     out = bu.furthest_point_sample(T(g, gpu), 300)
     ref, _ = oracle.furthest_point_sample(g, 300)
@@ -58,7 +59,7 @@ def test_ball_query_group_gather_batch(gpu):
     g.backward(go)
     ref_grad = torch.zeros((B, C, N), device=gpu)
     ref_grad.scatter_add_(2, idx.long().view(B, 1, -1).expand(B, C, -1), go.view(B, C, -1))
-    assert (ft.grad - ref_grad).abs().max().item() < 1e-4
+    assert (ft.grad - ref_grad).abs().max().item() < 1e-5 * ref_grad.abs().max().item()  # atomic-add order only
     # gather
     sel = T(rng.integers(0, N, (B, 64)).astype(np.int32), gpu)
     ft2 = T(feats, gpu).requires_grad_(True)
@@ -97,7 +98,7 @@ def test_three_nn_and_interpolate_batch(gpu):
     rg = torch.zeros_like(ft)
     for j in range(3):
         rg.index_add_(0, it[:, j], go * wt[:, j:j + 1])
-    assert (ft.grad - rg).abs().max().item() < 1e-4
+    assert (ft.grad - rg).abs().max().item() < 1e-5 * rg.abs().max().item()
     # fewer than 3 known points: untouched slots keep index 0 and distance inf (interpolate_gpu.cu:37-57)
     dist, idx = bu.three_nn(T(kp[None, :100], gpu), T(centres[None, :2], gpu))
     assert torch.isinf(dist[0, :, 2]).all() and (idx[0, :, 2] == 0).all()
@@ -126,7 +127,7 @@ def test_stack_ops(gpu):
     go = torch.randn(g.shape, device=gpu)
     g.backward(go)
     rg = torch.zeros_like(ft).index_add_(0, T(gidx.reshape(-1), gpu).long(), go.permute(0, 2, 1).reshape(-1, 16))
-    assert (ft.grad - rg).abs().max().item() < 1e-4
+    assert (ft.grad - rg).abs().max().item() < 1e-5 * rg.abs().max().item()
     nf, _ = su.QueryAndGroup(0.5, 16)(T(xyz, gpu), T(cnt_xyz, gpu), T(new, gpu), T(cnt_new, gpu), T(feats, gpu))
     assert nf.shape == (new.shape[0], 19, 16) and (nf[T(rempty, gpu)] == 0).all()
     # three_nn / interpolate (unknown = new, known = xyz)
@@ -142,7 +143,7 @@ def test_stack_ops(gpu):
     rg = torch.zeros_like(ft2)
     for j in range(3):
         rg.index_add_(0, i3[:, j].long(), w[:, j:j + 1].expand(-1, 16))
-    assert (ft2.grad - rg).abs().max().item() < 1e-4
+    assert (ft2.grad - rg).abs().max().item() < 1e-5 * rg.abs().max().item()
 
 
 def test_voxel_query(gpu):

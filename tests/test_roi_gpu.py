@@ -54,15 +54,15 @@ def test_roipoint_pool3d(gpu, width):
     B, N, C, M = 2, 16384, 130, 128
     pts, gt = scene(5, N, B)
     rng = np.random.default_rng(1)
-    rois = np.concatenate([gt, gt + rng.normal(0, 0.3, gt.shape).astype(np.float32)] * 4, 1)[:, :M]
+    rois = np.ascontiguousarray(np.concatenate([gt, gt + rng.normal(0, 0.3, gt.shape).astype(np.float32)] * 4, 1)[:, :M])
     rois[:, -3:] = random_boxes(3, 3, spread=60)[None]  # a few RoIs in empty space
     feats = rng.standard_normal((B, N, C)).astype(np.float32)
     pool = RoIPointPool3d(512, width)
     with torch.no_grad():
         pooled, flag = pool(torch.from_numpy(pts).to(gpu), torch.from_numpy(feats).to(gpu), torch.from_numpy(rois).to(gpu))
     from pcdet.utils import box_utils
-    big = (box_utils.enlarge_box3d(torch.from_numpy(rois).view(-1, 7), width) if isinstance(width, list)
-           else box_utils.expand_box3d(torch.from_numpy(rois).view(-1, 7), width)).view(B, M, 7).numpy()
+    big = (box_utils.enlarge_box3d(torch.from_numpy(rois).reshape(-1, 7), width) if isinstance(width, list)
+           else box_utils.expand_box3d(torch.from_numpy(rois).reshape(-1, 7), width)).view(B, M, 7).numpy()
     rp, rf = oracle.roipoint_pool3d(pts, feats, big, 512)
     assert pooled.shape == (B, M, 512, 3 + C) and flag.dtype == torch.int32
     assert np.array_equal(flag.cpu().numpy(), rf) and np.array_equal(pooled.cpu().numpy(), rp)
