@@ -1,0 +1,426 @@
+// A13 — modulated deformable convolution (DCNv2) as fused implicit GEMMs on fp32 MFMA.
+//
+// Replaces DCN.modulated_deform_conv_{forward,backward} (pcdet/ops/DeformableConvolutionV2PyTorch/src/vision.cpp:6-12,
+// src/cuda/modulated_deform_conv_cuda.cu:19-280, kernels modulated_deform_im2col_cuda.cuh:24-328).  The reference
+// writes a [Cin*kh*kw, B*Ho*Wo] `columns` buffer (1.3 GB for the MGAF head) and runs cuBLAS on it, and its backward
+// scatters with atomics from three element-wise kernels.  Here the bilinear samples are produced inside the GEMM
+// operand fetch, so no columns buffer exists in either direction:
+//
+//   forward   y[p, co]        = b[co] + sum_{k,ci} m[p,k] * bilin(x, p, k)[ci] * W[k][ci][co]
+//   backward  dcol[p, k, ci]  = sum_co dy[p, co] * W[k][ci][co]           (MFMA, A = dy rows, B = W_k^T)
+//             dx    += scatter(dcol * m * tap weights)                     (epilogue, atomics on the 4 taps)
+//             dm[p,k], doff[p,k] = reductions of dcol * bilin / d bilin    (epilogue, wave shuffles over ci)
+//             dW[k][ci][co] = sum_p m*bilin(x,p,k)[ci] * dy[p, co]         (MFMA over pixel chunks, deterministic reduce)
+//
+// Activations are NHWC here (16-byte channel vectors per tap); the Python layer permutes once on entry/exit, as the
+// reference itself computes NHWC and permutes (modulated_deform_conv_cuda.cu:78,118).  Sampling follows
+// mdmcn_im2col_bilinear (:24-54) and the validity test of :176 exactly; offsets/masks keep the reference layout
+// [B, dg*2*K, Ho, Wo] / [B, dg*K, Ho, Wo] with (2*(i*kw+j), +1) = (dh, dw).
+#include "common.hpp"
+
+namespace fv2p {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct DcnGeom {
+  int B, H, W, Cin, Cout, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw, dg;
+};
+
+struct Taps {
+  int o[4];     // element offsets (pixel index in [0, H*W)) of the 4 taps, -1 if outside
+  float w[4];   // bilinear weights hh*hw, hh*lw, lh*hw, lh*lw
+  float lh, lw; // fractional parts
+  int valid;    // the reference's whole-sample validity (h_im > -1 && w_im > -1 && h_im < H && w_im < W)
+};
+
+__device__ __forceinline__ Taps make_taps(const DcnGeom& g, float h_im, float w_im) {
+  Taps t;
+  t.valid = (h_im > -1.f && w_im > -1.f && h_im < static_cast<float>(g.H) && w_im < static_cast<float>(g.W));
+  const int h_low = static_cast<int>(floorf(h_im)), w_low = static_cast<int>(floorf(w_im));
+  const int h_high = h_low + 1, w_high = w_low + 1;
+  const float lh = h_im - h_low, lw = w_im - w_low, hh = 1.f - lh, hw = 1.f - lw;
+  t.lh = lh; t.lw = lw;
+  t.w[0] = hh * hw; t.w[1] = hh * lw; t.w[2] = lh * hw; t.w[3] = lh * lw;
+  const bool hl = h_low >= 0, hhi = h_high <= g.H - 1, wl = w_low >= 0, whi = w_high <= g.W - 1;
+  t.o[0] = (t.valid && hl && wl) ? h_low * g.W + w_low : -1;
+  t.o[1] = (t.valid && hl && whi) ? h_low * g.W + w_high : -1;
+  t.o[2] = (t.valid && hhi && wl) ? h_high * g.W + w_low : -1;
+  t.o[3] = (t.valid && hhi && whi) ? h_high * g.W + w_high : -1;
+  return t;
+}
+
+// sample position of output pixel (b, ho, wo), kernel tap k = i*kw + j, deformable group dgi
+__device__ __forceinline__ Taps pixel_taps(const DcnGeom& g, const float* __restrict__ offset, const float* __restrict__ mask, int b, int ho,
+                                           int wo, int k, int dgi, float* m) {
+  const int K = g.kh * g.kw, i = k / g.kw, j = k % g.kw;
+  const long long plane = static_cast<long long>(g.Ho) * g.Wo, pos = static_cast<long long>(ho) * g.Wo + wo;
+  const float* ob = offset + (static_cast<long long>(b) * g.dg + dgi) * 2 * K * plane;
+  const float off_h = ob[(2 * k) * plane + pos], off_w = ob[(2 * k + 1) * plane + pos];
+  *m = mask[((static_cast<long long>(b) * g.dg + dgi) * K + k) * plane + pos];
+  const float h_im = static_cast<float>(ho * g.sh - g.ph + i * g.dh) + off_h;
+  const float w_im = static_cast<float>(wo * g.sw - g.pw + j * g.dw) + off_w;
+  return make_taps(g, h_im, w_im);
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// B fragment staging: 16 source rows x COLS columns of a row-major [rows][ld] matrix -> fragment order (see sparse_conv.hip)
+template <int NB>
+__device__ __forceinline__ void stage16(const float* __restrict__ src, int ld, int rows_valid, int cols_valid, float* __restrict__ lds) {
+  constexpr int COLS = NB * 16;
+  for (int e = threadIdx.x; e < 16 * (COLS / 4); e += 256) {
+    const int c = e / (COLS / 4), col = (e % (COLS / 4)) * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < rows_valid) {
+      const float* p = src + static_cast<long long>(c) * ld + col;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (col + u < cols_valid) v[u] = p[u];
+    }
+    const int gq = (c >> 2) & 3, t = c & 3;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int cc = col + u;
+      lds[(((cc >> 4) * 64) + gq * 16 + (cc & 15)) * 4 + t] = v[u];
+    }
+  }
+}
+
+// ---------------------------------------------------------------- forward ----------------------------
+// x NHWC [B,H,W,Cin], wt [K][Cin][Cout], y NHWC [B*Ho*Wo, Cout]; block = 64 output pixels, wave = 16 pixels x all Cout
+template <int NB>
+__global__ __launch_bounds__(256) void dcn_fwd_k(DcnGeom g, const float* __restrict__ x, const float* __restrict__ wt,
+                                                 const float* __restrict__ bias, const float* __restrict__ offset,
+                                                 const float* __restrict__ mask, float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // 16 x NB*16 fragment
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, gq = lane >> 4;
+  const long long npix = static_cast<long long>(g.B) * g.Ho * g.Wo;
+  const long long pix = static_cast<long long>(blockIdx.x) * 64 + wave * 16 + r;
+  const bool live = pix < npix;
+  const int b = live ? static_cast<int>(pix / (g.Ho * g.Wo)) : 0;
+  const int rem = live ? static_cast<int>(pix % (g.Ho * g.Wo)) : 0;
+  const int ho = rem / g.Wo, wo = rem % g.Wo;
+  const int K = g.kh * g.kw, cpg = g.Cin / g.dg;
+  const float* xb = x + static_cast<long long>(b) * g.H * g.W * g.Cin;
+  f32x4 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < K; ++k) {
+    for (int dgi = 0; dgi < g.dg; ++dgi) {
+      float m = 0.f;
+      Taps t;
+      t.valid = 0;
+      t.o[0] = t.o[1] = t.o[2] = t.o[3] = -1;
+      t.w[0] = t.w[1] = t.w[2] = t.w[3] = 0.f;
+      if (live) t = pixel_taps(g, offset, mask, b, ho, wo, k, dgi, &m);
+      for (int c0 = dgi * cpg; c0 < (dgi + 1) * cpg; c0 += 16) {
+        // A fragment: channels c0 + 4*gq .. +3 of the modulated bilinear sample of this lane's pixel
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c = c0 + 4 * gq;
+        if (c < (dgi + 1) * cpg) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (t.o[q] >= 0) {
+              const float4 v = ld4(xb + static_cast<long long>(t.o[q]) * g.Cin + c);
+              a.x += t.w[q] * v.x; a.y += t.w[q] * v.y; a.z += t.w[q] * v.z; a.w += t.w[q] * v.w;
+            }
+          a.x *= m; a.y *= m; a.z *= m; a.w *= m;
+        }
+        __syncthreads();
+        stage16<NB>(wt + (static_cast<long long>(k) * g.Cin + c0) * g.Cout, g.Cout, min(16, (dgi + 1) * cpg - c0), g.Cout, lds);
+        __syncthreads();
+        float4 bv[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) bv[nb] = *reinterpret_cast<const float4*>(&lds[(nb * 64 + lane) * 4]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bv[nb].x, acc[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bv[nb].y, acc[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bv[nb].z, acc[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bv[nb].w, acc[nb], 0, 0, 0);
+      }
+    }
+  }
+  const int n = lane & 15, q = lane >> 4;
+  const long long row0 = static_cast<long long>(blockIdx.x) * 64 + wave * 16;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int col = nb * 16 + n;
+    if (col >= g.Cout) continue;
+    const float bb = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const long long row = row0 + q * 4 + reg;
+      if (row < npix) y[row * g.Cout + col] = acc[nb][reg] + bb;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- backward: data / offset / mask -----
+// One wave = 16 output pixels.  dy fragment (A operand, Cout values per pixel) stays in registers; for every tap k and
+// 16-channel chunk the wave forms dcol[16 pixels][16 ci] with Cout/4 MFMAs against W_k^T (LDS), then turns it into
+// grad_x (atomics on the 4 taps), grad_mask and grad_offset (reduced over ci with shuffles, accumulated over chunks).
+template <int JO>  // Cout padded to 16*JO
+__global__ __launch_bounds__(256) void dcn_bwd_data_k(DcnGeom g, const float* __restrict__ x, const float* __restrict__ wt,
+                                                      const float* __restrict__ offset, const float* __restrict__ mask,
+                                                      const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ doff,
+                                                      float* __restrict__ dmask) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // B fragment: [JO][64 lanes][4]: B[co][ci]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, gq = lane >> 4;
+  const long long npix = static_cast<long long>(g.B) * g.Ho * g.Wo;
+  const long long row0 = static_cast<long long>(blockIdx.x) * 64 + wave * 16;
+  const long long pix = row0 + r;
+  const bool live = pix < npix;
+  const int K = g.kh * g.kw, cpg = g.Cin / g.dg;
+  const long long plane = static_cast<long long>(g.Ho) * g.Wo;
+  // A fragment: lane (r, gq) holds dy[pix_r][16j + 4gq .. +3]
+  float4 av[JO];
+#pragma unroll
+  for (int j = 0; j < JO; ++j) {
+    av[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int c = 16 * j + 4 * gq;
+    if (live && c < g.Cout) av[j] = ld4(dy + pix * g.Cout + c);
+  }
+  // epilogue view: lane (n = ci within chunk, q) owns pixels row0 + 4q + reg
+  const int n = lane & 15, q = lane >> 4;
+  for (int k = 0; k < K; ++k) {
+    for (int dgi = 0; dgi < g.dg; ++dgi) {
+      // taps of the 4 pixels this lane post-processes
+      Taps tp[4];
+      float mk[4];
+      int pb[4];
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const long long p = row0 + q * 4 + reg;
+        mk[reg] = 0.f;
+        pb[reg] = 0;
+        tp[reg].valid = 0;
+        tp[reg].o[0] = tp[reg].o[1] = tp[reg].o[2] = tp[reg].o[3] = -1;
+        tp[reg].w[0] = tp[reg].w[1] = tp[reg].w[2] = tp[reg].w[3] = 0.f;
+        tp[reg].lh = tp[reg].lw = 0.f;
+        if (p < npix) {
+          const int b = static_cast<int>(p / plane), rem = static_cast<int>(p % plane);
+          pb[reg] = b;
+          tp[reg] = pixel_taps(g, offset, mask, b, rem / g.Wo, rem % g.Wo, k, dgi, &mk[reg]);
+        }
+      }
+      float gm[4] = {0.f, 0.f, 0.f, 0.f}, gh[4] = {0.f, 0.f, 0.f, 0.f}, gw[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int c0 = dgi * cpg; c0 < (dgi + 1) * cpg; c0 += 16) {
+        __syncthreads();
+        // B[co][ci] = wt[k][c0 + ci][co]  -> fragment order with source index co: element at ((co>>4)*64 + ((co>>2)&3)*16 + ci)*4 + (co&3)
+        for (int e = threadIdx.x; e < 16 * (JO * 4); e += 256) {
+          const int ci = e / (JO * 4), co = (e % (JO * 4)) * 4;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (c0 + ci < (dgi + 1) * cpg) {
+            const float* p = wt + (static_cast<long long>(k) * g.Cin + c0 + ci) * g.Cout + co;
+            if (co + 3 < g.Cout) v = ld4(p);
+            else {
+              if (co < g.Cout) v.x = p[0];
+              if (co + 1 < g.Cout) v.y = p[1];
+              if (co + 2 < g.Cout) v.z = p[2];
+            }
+          }
+          *reinterpret_cast<float4*>(&lds[(((co >> 4) * 64) + ((co >> 2) & 3) * 16 + ci) * 4]) = v;
+        }
+        __syncthreads();
+        f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < JO; ++j) {
+          const float4 bv = *reinterpret_cast<const float4*>(&lds[(j * 64 + lane) * 4]);
+          d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].x, bv.x, d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].y, bv.y, d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].z, bv.z, d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].w, bv.w, d, 0, 0, 0);
+        }
+        // d[reg] = dcol[pixel row0+4q+reg][ci = c0 + n]
+        const int ci = c0 + n;
+        const bool cok = ci < (dgi + 1) * cpg;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const Taps& t = tp[reg];
+          if (!t.valid || !cok) continue;
+          const float gcol = d[reg];
+          const float* xb = x + static_cast<long long>(pb[reg]) * g.H * g.W * g.Cin + ci;
+          float* dxb = dx + static_cast<long long>(pb[reg]) * g.H * g.W * g.Cin + ci;
+          float v[4];
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {
+            v[qq] = t.o[qq] >= 0 ? xb[static_cast<long long>(t.o[qq]) * g.Cin] : 0.f;
+            if (t.o[qq] >= 0) atomicAdd(&dxb[static_cast<long long>(t.o[qq]) * g.Cin], gcol * mk[reg] * t.w[qq]);
+          }
+          const float val = t.w[0] * v[0] + t.w[1] * v[1] + t.w[2] * v[2] + t.w[3] * v[3];
+          gm[reg] += gcol * val;
+          // d val / d h = -hw*v1 - lw*v2 + hw*v3 + lw*v4 ; d val / d w = -hh*v1 + hh*v2 - lh*v3 + lh*v4 (mdmcn_get_coordinate_weight)
+          const float hw = 1.f - t.lw, hh = 1.f - t.lh;
+          gh[reg] += gcol * mk[reg] * (-hw * v[0] - t.lw * v[1] + hw * v[2] + t.lw * v[3]);
+          gw[reg] += gcol * mk[reg] * (-hh * v[0] + hh * v[1] - t.lh * v[2] + t.lh * v[3]);
+        }
+      }
+      // reduce over the 16 ci lanes (n) and store: (pixel, k, dgi) is owned by exactly one wave
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        float a = gm[reg], bh = gh[reg], bw = gw[reg];
+#pragma unroll
+        for (int s = 1; s < 16; s <<= 1) {
+          a += __shfl_xor(a, s, 64); bh += __shfl_xor(bh, s, 64); bw += __shfl_xor(bw, s, 64);
+        }
+        const long long p = row0 + q * 4 + reg;
+        if (n == 0 && p < npix) {
+          const int b = static_cast<int>(p / plane);
+          const long long pos = p % plane;
+          dmask[((static_cast<long long>(b) * g.dg + dgi) * K + k) * plane + pos] = a;
+          float* ob = doff + (static_cast<long long>(b) * g.dg + dgi) * 2 * K * plane;
+          ob[(2 * k) * plane + pos] = bh;
+          ob[(2 * k + 1) * plane + pos] = bw;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- backward: weight ---------------------
+// grid (pixel chunks, K, Cin/16); block 256 = 4 waves splitting the chunk's pixels; A_mfma[m = ci][kk = pixel] =
+// modulated sample, B_mfma[kk = pixel][n = co] = dy; partial [chunk][k][ci][co] tiles, reduced by wgrad-style sum.
+template <int NB>
+__global__ __launch_bounds__(256) void dcn_bwd_weight_k(DcnGeom g, const float* __restrict__ x, const float* __restrict__ offset,
+                                                        const float* __restrict__ mask, const float* __restrict__ dy, int pix_per_chunk,
+                                                        float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [16][NB*16]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, m = lane & 15, gq = lane >> 4;
+  const int k = blockIdx.y, c0 = blockIdx.z * 16, K = g.kh * g.kw, cpg = g.Cin / g.dg;
+  const int dgi = c0 / cpg;
+  const long long npix = static_cast<long long>(g.B) * g.Ho * g.Wo, plane = static_cast<long long>(g.Ho) * g.Wo;
+  constexpr int TILE = 16 * NB * 16;
+  for (int e = threadIdx.x; e < TILE; e += 256) red[e] = 0.f;
+  f32x4 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const long long p_begin = static_cast<long long>(blockIdx.x) * pix_per_chunk + static_cast<long long>(w) * (pix_per_chunk / 4);
+  const long long p_end = min(p_begin + pix_per_chunk / 4, npix);
+  const int ci = c0 + m;
+  for (long long p0 = p_begin; p0 < p_end; p0 += 4) {
+    const long long p = p0 + gq;
+    float a = 0.f;
+    float bv[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) bv[nb] = 0.f;
+    if (p < p_end) {
+      const int b = static_cast<int>(p / plane), rem = static_cast<int>(p % plane);
+      float mk;
+      const Taps t = pixel_taps(g, offset, mask, b, rem / g.Wo, rem % g.Wo, k, dgi, &mk);
+      if (ci < g.Cin) {
+        const float* xb = x + static_cast<long long>(b) * g.H * g.W * g.Cin + ci;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+          if (t.o[qq] >= 0) a += t.w[qq] * xb[static_cast<long long>(t.o[qq]) * g.Cin];
+        a *= mk;
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int co = nb * 16 + m;
+        if (co < g.Cout) bv[nb] = dy[p * g.Cout + co];
+      }
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[nb], acc[nb], 0, 0, 0);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) atomicAdd(&red[(gq * 4 + reg) * (NB * 16) + nb * 16 + m], acc[nb][reg]);
+  __syncthreads();
+  float* out = partial + ((static_cast<long long>(blockIdx.x) * K + k) * g.Cin + c0) * g.Cout;
+  for (int e = threadIdx.x; e < TILE; e += 256) {
+    const int cr = e / (NB * 16), cc = e % (NB * 16);
+    if (c0 + cr < g.Cin && cc < g.Cout) out[static_cast<long long>(cr) * g.Cout + cc] = red[e];
+  }
+}
+
+__global__ void dcn_reduce_k(const float* __restrict__ partial, int chunks, long long per_chunk, float* __restrict__ out) {
+  const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= per_chunk) return;
+  float s = 0.f;
+  for (int c = 0; c < chunks; ++c) s += partial[c * per_chunk + t];
+  out[t] = s;
+}
+
+static int dcn_check(const DcnGeom& g) {
+  FV2P_REQUIRE(g.B >= 0 && g.H >= 1 && g.W >= 1 && g.Cin >= 1 && g.Cout >= 1 && g.kh >= 1 && g.kw >= 1 && g.sh >= 1 && g.sw >= 1 &&
+                   g.dh >= 1 && g.dw >= 1 && g.dg >= 1 && g.Ho >= 1 && g.Wo >= 1,
+               FV2P_EINVAL, "dcn: bad geometry");
+  FV2P_REQUIRE(g.Cin % g.dg == 0 && (g.Cin / g.dg) % 16 == 0, FV2P_ELIMIT,
+               "dcn: channels per deformable group (%d/%d) must be a multiple of 16", g.Cin, g.dg);
+  FV2P_REQUIRE(g.Cout <= 256, FV2P_ELIMIT, "dcn: more than 256 output channels per launch (split on the host)");
+  return 0;
+}
+
+static const int kDcnPixChunk = 2048;
+
+}  // namespace fv2p
+using namespace fv2p;
+
+#define DCN_GEOM_ARGS int batch, int height, int width, int c_in, int c_out, int h_out, int w_out, int kh, int kw, int sh, int sw, \
+                      int ph, int pw, int dh, int dw, int deformable_group
+#define DCN_GEOM_INIT DcnGeom g = {batch, height, width, c_in, c_out, h_out, w_out, kh, kw, sh, sw, ph, pw, dh, dw, deformable_group}
+
+extern "C" int fv2p_dcn_forward(const float* x_nhwc, const float* wt, const float* bias, const float* offset, const float* mask,
+                                DCN_GEOM_ARGS, float* y_nhwc, fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DCN_GEOM_INIT;
+  if (int rc = dcn_check(g)) return rc;
+  const long long npix = static_cast<long long>(g.B) * g.Ho * g.Wo;
+  if (npix == 0) return 0;
+  FV2P_REQUIRE(x_nhwc && wt && offset && mask && y_nhwc, FV2P_EINVAL, "dcn_forward: null pointer");
+  const unsigned blocks = static_cast<unsigned>(ceil_div(npix, 64));
+  const int nb = static_cast<int>(ceil_div(g.Cout, 16));
+#define DCN_FWD(NB) hipLaunchKernelGGL((dcn_fwd_k<NB>), dim3(blocks), dim3(256), 16 * NB * 16 * sizeof(float), stream, g, x_nhwc, wt, bias, offset, mask, y_nhwc)
+  if (nb <= 1) DCN_FWD(1); else if (nb <= 2) DCN_FWD(2); else if (nb <= 4) DCN_FWD(4); else if (nb <= 8) DCN_FWD(8); else DCN_FWD(16);
+#undef DCN_FWD
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t fv2p_dcn_backward_ws_bytes(int batch, int h_out, int w_out, int c_in, int c_out, int kh, int kw) {
+  const long long npix = static_cast<long long>(batch) * h_out * w_out;
+  const long long chunks = ceil_div(npix > 0 ? npix : 1, kDcnPixChunk);
+  Sizer s;
+  s.take<float>(static_cast<size_t>(chunks) * kh * kw * c_in * c_out);
+  return s.bytes();
+}
+
+// dx_nhwc must be zeroed by the caller (atomically accumulated); doff / dmask / dwt are fully written.
+extern "C" int fv2p_dcn_backward(const float* x_nhwc, const float* wt, const float* offset, const float* mask, const float* dy_nhwc,
+                                 DCN_GEOM_ARGS, float* dx_nhwc, float* doffset, float* dmask, float* dwt, void* ws, size_t ws_bytes,
+                                 fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DCN_GEOM_INIT;
+  if (int rc = dcn_check(g)) return rc;
+  const long long npix = static_cast<long long>(g.B) * g.Ho * g.Wo;
+  const int K = g.kh * g.kw;
+  FV2P_REQUIRE(dwt, FV2P_EINVAL, "dcn_backward: null dwt");
+  if (npix == 0) {
+    FV2P_HIP(hipMemsetAsync(dwt, 0, sizeof(float) * (size_t)K * g.Cin * g.Cout, stream));
+    return 0;
+  }
+  FV2P_REQUIRE(x_nhwc && wt && offset && mask && dy_nhwc && dx_nhwc && doffset && dmask, FV2P_EINVAL, "dcn_backward: null pointer");
+  FV2P_REQUIRE(ws && ws_bytes >= fv2p_dcn_backward_ws_bytes(g.B, g.Ho, g.Wo, g.Cin, g.Cout, g.kh, g.kw), FV2P_EWORKSPACE,
+               "dcn_backward: workspace too small");
+  const unsigned blocks = static_cast<unsigned>(ceil_div(npix, 64));
+  const int jo = static_cast<int>(ceil_div(g.Cout, 16));
+#define DCN_BD(JO) hipLaunchKernelGGL((dcn_bwd_data_k<JO>), dim3(blocks), dim3(256), JO * 64 * 4 * sizeof(float), stream, g, x_nhwc, wt, offset, mask, dy_nhwc, dx_nhwc, doffset, dmask)
+  if (jo <= 1) DCN_BD(1); else if (jo <= 2) DCN_BD(2); else if (jo <= 4) DCN_BD(4); else if (jo <= 8) DCN_BD(8); else DCN_BD(16);
+#undef DCN_BD
+  const unsigned chunks = static_cast<unsigned>(ceil_div(npix, kDcnPixChunk));
+  float* partial = static_cast<float*>(ws);
+  const dim3 grid(chunks, K, static_cast<unsigned>(ceil_div(g.Cin, 16)));
+#define DCN_BW(NB) hipLaunchKernelGGL((dcn_bwd_weight_k<NB>), grid, dim3(256), 16 * NB * 16 * sizeof(float), stream, g, x_nhwc, offset, mask, dy_nhwc, kDcnPixChunk, partial)
+  if (jo <= 1) DCN_BW(1); else if (jo <= 2) DCN_BW(2); else if (jo <= 4) DCN_BW(4); else if (jo <= 8) DCN_BW(8); else DCN_BW(16);
+#undef DCN_BW
+  const long long per_chunk = static_cast<long long>(K) * g.Cin * g.Cout;
+  hipLaunchKernelGGL(dcn_reduce_k, dim3(static_cast<unsigned>(ceil_div(per_chunk, 256))), dim3(256), 0, stream, partial, (int)chunks, per_chunk, dwt);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,89 @@
+"""`DCN` — the extension module of the reference's DeformableConvolutionV2PyTorch (src/vision.cpp:6-12) as a Python
+shim over libfv2p_ops: same six function names and positional arguments.  The deformable PSROI pooling pair is bound
+by the reference but used by no model and is not implemented here."""
+import torch
+
+import fv2p_native as _nat
+
+
+def _geom(input, weight, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, group, deformable_group):
+    if not input.is_cuda:
+        raise _nat.Fv2pError("Not implemented on the CPU")  # as the reference dispatcher (modulated_deform_conv.h:43)
+    if group != 1:
+        raise NotImplementedError("fv2p DCN: groups > 1 is not supported (no reference config uses it)")
+    B, C, H, W = input.shape
+    Cout = weight.shape[0]
+    assert weight.shape[1] == C and weight.shape[2] == kernel_h and weight.shape[3] == kernel_w, "input / kernel shape mismatch"
+    Ho = (H + 2 * pad_h - (dilation_h * (kernel_h - 1) + 1)) // stride_h + 1
+    Wo = (W + 2 * pad_w - (dilation_w * (kernel_w - 1) + 1)) // stride_w + 1
+    return (B, H, W, C, Cout, Ho, Wo, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, deformable_group)
+
+
+def _wt(weight):
+    cout, cin, kh, kw = weight.shape
+    return weight.permute(2, 3, 1, 0).reshape(kh * kw, cin, cout).contiguous()
+
+
+def modulated_deform_conv_forward(input, weight, bias, offset, mask, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w,
+                                  dilation_h, dilation_w, group, deformable_group, im2col_step):
+    """-> output [B, Cout, Ho, Wo] (contiguous NCHW, as modulated_deform_conv_cuda.cu:118). im2col_step is accepted and
+    irrelevant: there is no columns buffer to chunk."""
+    g = _geom(input, weight, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, group, deformable_group)
+    B, H, W, C, Cout, Ho, Wo = g[:7]
+    x = input.float().permute(0, 2, 3, 1).contiguous()
+    y = torch.empty((B * Ho * Wo, Cout), dtype=torch.float32, device=input.device)
+    with _nat.device_guard(input.device):
+        _nat.call("fv2p_dcn_forward", x, _wt(weight.float()), bias.float().contiguous() if bias is not None else None,
+                  offset.float().contiguous(), mask.float().contiguous(), *g, y, _nat.stream())
+    return y.view(B, Ho, Wo, Cout).permute(0, 3, 1, 2).contiguous().to(input.dtype)
+
+
+def modulated_deform_conv_backward(input, weight, bias, offset, mask, grad_output, kernel_h, kernel_w, stride_h, stride_w, pad_h,
+                                   pad_w, dilation_h, dilation_w, group, deformable_group, im2col_step):
+    """-> [grad_input, grad_offset, grad_mask, grad_weight, grad_bias] (modulated_deform_conv_cuda.cu:127-280)."""
+    g = _geom(input, weight, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, group, deformable_group)
+    B, H, W, C, Cout, Ho, Wo = g[:7]
+    dev = input.device
+    x = input.float().permute(0, 2, 3, 1).contiguous()
+    dy = grad_output.float().permute(0, 2, 3, 1).contiguous().view(B * Ho * Wo, Cout)
+    dx = torch.zeros_like(x)
+    doff = torch.empty_like(offset, dtype=torch.float32).contiguous()
+    dmask = torch.empty_like(mask, dtype=torch.float32).contiguous()
+    dwt = torch.empty((kernel_h * kernel_w, C, Cout), dtype=torch.float32, device=dev)
+    with _nat.device_guard(dev):
+        nb = _nat.lib().fv2p_dcn_backward_ws_bytes(B, Ho, Wo, C, Cout, kernel_h, kernel_w)
+        ws = _nat.workspace(nb, dev)
+        _nat.call("fv2p_dcn_backward", x, _wt(weight.float()), offset.float().contiguous(), mask.float().contiguous(), dy, *g, dx, doff,
+                  dmask, dwt, ws, ws.numel(), _nat.stream())
+    grad_input = dx.permute(0, 3, 1, 2).contiguous()
+    grad_weight = dwt.view(kernel_h, kernel_w, C, Cout).permute(3, 2, 0, 1).contiguous()
+    grad_bias = dy.sum(dim=0)
+    return [grad_input, doff, dmask, grad_weight, grad_bias]
+
+
+def deform_conv_forward(input, weight, bias, offset, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w,
+                        group, deformable_group, im2col_step):
+    """DCNv1 = DCNv2 with an all-ones modulation mask (deform_im2col_cuda.cuh:127-190 vs modulated_*:127-194)."""
+    B, _, Ho, Wo = offset.shape
+    mask = torch.ones((B, deformable_group * kernel_h * kernel_w, Ho, Wo), dtype=torch.float32, device=input.device)
+    return modulated_deform_conv_forward(input, weight, bias, offset, mask, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w,
+                                         dilation_h, dilation_w, group, deformable_group, im2col_step)
+
+
+def deform_conv_backward(input, weight, bias, offset, grad_output, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h,
+                         dilation_w, group, deformable_group, im2col_step):
+    """-> [grad_input, grad_offset, grad_weight, grad_bias]."""
+    B, _, Ho, Wo = offset.shape
+    mask = torch.ones((B, deformable_group * kernel_h * kernel_w, Ho, Wo), dtype=torch.float32, device=input.device)
+    gi, go, _, gw, gb = modulated_deform_conv_backward(input, weight, bias, offset, mask, grad_output, kernel_h, kernel_w, stride_h,
+                                                       stride_w, pad_h, pad_w, dilation_h, dilation_w, group, deformable_group,
+                                                       im2col_step)
+    return [gi, go, gw, gb]
+
+
+def deform_psroi_pooling_forward(*args, **kwargs):
+    raise NotImplementedError("deformable PSROI pooling is bound by the reference but used by no model; not provided")
+
+
+def deform_psroi_pooling_backward(*args, **kwargs):
+    raise NotImplementedError("deformable PSROI pooling is bound by the reference but used by no model; not provided")

@@ -1,0 +1,93 @@
+"""GPU parity of DCNv2 / DCNv1 (A13/A14) — the reference's own self-checks (DeformableConvolutionV2PyTorch/test.py)
+restated, plus random-offset parity against the torch-CPU restatement (oracle/dcn_oracle.py).
+
+Tolerances: forward 1e-4 relative (north_star; the reference's own check uses 1e-5 absolute on tiny tensors);
+gradients 1e-3 relative to the largest entry (the reference's gradcheck uses atol 1e-3, rtol 1e-2, test.py:351-435)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import dcn_oracle
+from pcdet.ops.DeformableConvolutionV2PyTorch.modules.deform_conv import DeformConv
+from pcdet.ops.DeformableConvolutionV2PyTorch.modules.mdeformable_conv_block import MdeformConvBlock
+from pcdet.ops.DeformableConvolutionV2PyTorch.modules.modulated_deform_conv import ModulatedDeformConv, ModulatedDeformConvPack
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+@pytest.mark.parametrize("cin,cout,dg,hw", [(16, 16, 1, (9, 11)), (64, 32, 4, (12, 10)), (128, 128, 1, (20, 16)), (32, 200, 2, (7, 7))])
+def test_zero_offset_equals_conv2d(gpu, cin, cout, dg, hw):
+    """test.py:69-110 (check_mdconv_zero_offset): zero offsets, mask = 1 -> plain convolution."""
+    torch.manual_seed(3)
+    B, (H, W) = 2, hw
+    x = torch.randn(B, cin, H, W, device=gpu)
+    m = ModulatedDeformConv(cin, cout, 3, stride=1, padding=1, deformable_groups=dg, bias=True).to(gpu)
+    offset = torch.zeros(B, dg * 18, H, W, device=gpu)
+    mask = torch.ones(B, dg * 9, H, W, device=gpu)
+    y = m(x, offset, mask)
+    ref = F.conv2d(x.cpu(), m.weight.detach().cpu(), m.bias.detach().cpu(), padding=1)
+    assert y.shape == ref.shape and y.is_contiguous()
+    assert rel(y, ref) < 1e-4
+    # DCNv1 with zero offsets as well (test.py:36-67)
+    d = DeformConv(cin, cout, 3, stride=1, padding=1, deformable_groups=dg, bias=False).to(gpu)
+    assert rel(d(x, offset), F.conv2d(x.cpu(), d.weight.detach().cpu(), d.bias.detach().cpu(), padding=1)) < 1e-4
+
+
+def test_identity_kernel_returns_input(gpu):
+    """test.py:142-181: centre-tap identity weights, zero offset, unit mask -> output == input."""
+    x = torch.randn(2, 32, 10, 12, device=gpu)
+    m = ModulatedDeformConv(32, 32, 3, stride=1, padding=1, bias=False).to(gpu)
+    with torch.no_grad():
+        m.weight.zero_()
+        m.weight[torch.arange(32), torch.arange(32), 1, 1] = 1.0
+        m.bias.zero_()
+    y = m(x, torch.zeros(2, 18, 10, 12, device=gpu), torch.ones(2, 9, 10, 12, device=gpu))
+    assert rel(y, x) < 1e-6
+
+
+@pytest.mark.parametrize("cin,cout,dg,stride,dil", [(32, 48, 2, 1, 1), (16, 16, 1, 2, 1), (64, 64, 4, 1, 2)])
+def test_random_offsets_forward_backward_vs_oracle(gpu, cin, cout, dg, stride, dil):
+    torch.manual_seed(0)
+    B, H, W = 2, 11, 13
+    pad = dil
+    Ho, Wo = (H + 2 * pad - (dil * 2 + 1)) // stride + 1, (W + 2 * pad - (dil * 2 + 1)) // stride + 1
+    x = torch.randn(B, cin, H, W)
+    offset = torch.randn(B, dg * 18, Ho, Wo) * 1.5     # frequently leaves the image: exercises the border rule
+    mask = torch.sigmoid(torch.randn(B, dg * 9, Ho, Wo))
+    m = ModulatedDeformConv(cin, cout, 3, stride=stride, padding=pad, dilation=dil, deformable_groups=dg, bias=True).to(gpu)
+    gx, go, gm = (t.clone().to(gpu).requires_grad_(True) for t in (x, offset, mask))
+    y = m(gx, go, gm)
+    cx, co, cm = (t.clone().double().requires_grad_(True) for t in (x, offset, mask))
+    w, b = m.weight.detach().cpu().double().requires_grad_(True), m.bias.detach().cpu().double().requires_grad_(True)
+    ref = dcn_oracle.modulated_deform_conv(cx, co, cm, w, b, (stride, stride), (pad, pad), (dil, dil), dg)
+    assert rel(y, ref) < 1e-4
+    g = torch.randn(ref.shape)
+    y.backward(g.to(gpu))
+    ref.backward(g.double())
+    assert rel(gx.grad, cx.grad) < 1e-3
+    assert rel(go.grad, co.grad) < 1e-3
+    assert rel(gm.grad, cm.grad) < 1e-3
+    assert rel(m.weight.grad, w.grad) < 1e-3
+    assert rel(m.bias.grad, b.grad) < 1e-3
+
+
+def test_mgaf_block_shapes_and_pack(gpu):
+    """MdeformConvBlock as DCNBEVBackbone builds it (dcn_bev_backbone.py:56-62), small spatial size."""
+    blk = MdeformConvBlock(128, 128, deformable_groups=1).to(gpu)
+    x = torch.randn(2, 128, 25, 22, device=gpu, requires_grad=True)
+    y = blk(x)
+    # offsets are zero-initialised and mask = sigmoid(0) = 0.5 -> 0.5 * conv2d (bias is frozen but still added)
+    ref = 0.5 * F.conv2d(x.detach().cpu(), blk.conv_adaption.weight.detach().cpu(), None, padding=1) \
+        + blk.conv_adaption.bias.detach().cpu().view(1, -1, 1, 1)
+    assert rel(y, ref) < 1e-4
+    y.sum().backward()
+    assert x.grad is not None and blk.conv_offset_mask.weight.grad is not None and blk.conv_adaption.bias.grad is None
+    pack = ModulatedDeformConvPack(16, 16, 3, stride=1, padding=1, deformable_groups=1).to(gpu)
+    assert pack(torch.randn(1, 16, 8, 8, device=gpu)).shape == (1, 16, 8, 8)
+    with pytest.raises(Exception):
+        blk.cpu()(torch.randn(1, 128, 8, 8))  # "Not implemented on the CPU", as the reference dispatcher
