@@ -69,6 +69,14 @@ FV2P_HD void rot_center(const P2& c, float ac, float as, P2* p) {
 }
 
 FV2P_HD float box_overlap(const float* a, const float* b) {  // :104-225
+  // Early out, result-preserving: if the centres are farther apart than the two half-diagonals plus the 1e-2 corner
+  // margin, the reference code finds no edge crossing and no contained corner and returns exactly 0.
+  // (ra + rb + m)^2 <= 3 (ra^2 + rb^2 + m^2), m = 0.1, keeps the test sqrt-free and conservative.
+  {
+    const float ddx = a[0] - b[0], ddy = a[1] - b[1];
+    const float ra2 = 0.25f * (a[3] * a[3] + a[4] * a[4]), rb2 = 0.25f * (b[3] * b[3] + b[4] * b[4]);
+    if (ddx * ddx + ddy * ddy > 3.0f * (ra2 + rb2 + 0.01f)) return 0.f;
+  }
   const float a_angle = a[6], b_angle = b[6];
   const float a_dx = a[3] / 2, b_dx = b[3] / 2, a_dy = a[4] / 2, b_dy = b[4] / 2;
   const float ax1 = a[0] - a_dx, ay1 = a[1] - a_dy, ax2 = a[0] + a_dx, ay2 = a[1] + a_dy;

@@ -311,20 +311,73 @@ struct Best3 {
   float d1, d2, d3;
   int i1, i2, i3;
 };
-__device__ __forceinline__ void best3_init(Best3* b) {
-  b->d1 = b->d2 = b->d3 = INFINITY;  // 1e40 in the reference (:37) == +inf once cast to float (:56)
-  b->i1 = b->i2 = b->i3 = 0;
+__device__ __forceinline__ void best3_init(Best3& b) {
+  b.d1 = b.d2 = b.d3 = INFINITY;  // 1e40 in the reference (:37) == +inf once cast to float (:56)
+  b.i1 = b.i2 = b.i3 = 0;
 }
-__device__ __forceinline__ void best3_push(Best3* b, float d, int k) {
-  if (d < b->d1) { b->d3 = b->d2; b->i3 = b->i2; b->d2 = b->d1; b->i2 = b->i1; b->d1 = d; b->i1 = k; }
-  else if (d < b->d2) { b->d3 = b->d2; b->i3 = b->i2; b->d2 = d; b->i2 = k; }
-  else if (d < b->d3) { b->d3 = d; b->i3 = k; }
+// branch-free form of the reference's if / else-if chain (interpolate_gpu.cu:43-54): strict '<' everywhere
+__device__ __forceinline__ void best3_push(Best3& b, float d, int k) {
+  const bool c1 = d < b.d1, c2 = d < b.d2, c3 = d < b.d3;
+  b.d3 = c2 ? b.d2 : (c3 ? d : b.d3);
+  b.i3 = c2 ? b.i2 : (c3 ? k : b.i3);
+  b.d2 = c1 ? b.d1 : (c2 ? d : b.d2);
+  b.i2 = c1 ? b.i1 : (c2 ? k : b.i2);
+  b.d1 = c1 ? d : b.d1;
+  b.i1 = c1 ? k : b.i1;
+}
+
+// A workgroup = 64 queries x 4 waves; wave w scans the w-th quarter of every LDS tile of known points and the four
+// partial top-3 lists are merged on (distance, index), which is exactly "strict < in ascending index order".
+// 4x the wave-level parallelism of one-thread-per-query at these sizes (16384 queries = 256 workgroups).
+__device__ __forceinline__ void three_nn_scan(const float* __restrict__ known, int64_t start, int m, float ux, float uy, float uz,
+                                              bool live, float* tile, Best3& bst) {
+  const int w = threadIdx.x >> 6;
+  for (int base = 0; base < m; base += kTile) {
+    const int len = min(kTile, m - base);
+    __syncthreads();
+    for (int e = threadIdx.x; e < len * 3; e += 256) tile[e] = known[(start + base) * 3 + e];
+    __syncthreads();
+    const int q = (len + 3) >> 2;
+    const int k0 = w * q, k1 = min(k0 + q, len);
+    if (live)
+      for (int k = k0; k < k1; ++k) best3_push(bst, sqdist(ux, uy, uz, tile[k * 3], tile[k * 3 + 1], tile[k * 3 + 2]), base + k);
+  }
+}
+
+__device__ __forceinline__ void best3_merge_one(Best3& b, float d, int k) {
+  const bool c1 = d < b.d1 || (d == b.d1 && k < b.i1);
+  const bool c2 = d < b.d2 || (d == b.d2 && k < b.i2);
+  const bool c3 = d < b.d3 || (d == b.d3 && k < b.i3);
+  b.d3 = c2 ? b.d2 : (c3 ? d : b.d3);
+  b.i3 = c2 ? b.i2 : (c3 ? k : b.i3);
+  b.d2 = c1 ? b.d1 : (c2 ? d : b.d2);
+  b.i2 = c1 ? b.i1 : (c2 ? k : b.i2);
+  b.d1 = c1 ? d : b.d1;
+  b.i1 = c1 ? k : b.i1;
+}
+
+__device__ __forceinline__ bool three_nn_merge(Best3& bst, float* sd /*[4][64][3]*/, int* si) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  sd[(w * 64 + lane) * 3] = bst.d1; sd[(w * 64 + lane) * 3 + 1] = bst.d2; sd[(w * 64 + lane) * 3 + 2] = bst.d3;
+  si[(w * 64 + lane) * 3] = bst.i1; si[(w * 64 + lane) * 3 + 1] = bst.i2; si[(w * 64 + lane) * 3 + 2] = bst.i3;
+  __syncthreads();
+  if (w == 0) {
+    for (int ww = 1; ww < 4; ++ww)
+      for (int j = 0; j < 3; ++j) {
+        const float d = sd[(ww * 64 + lane) * 3 + j];
+        if (d < INFINITY) best3_merge_one(bst, d, si[(ww * 64 + lane) * 3 + j]);
+      }
+  }
+  return w == 0;
 }
 
 __global__ __launch_bounds__(256) void three_nn_batch_k(int n, int m, const float* __restrict__ unknown, const float* __restrict__ known,
                                                         float* __restrict__ dist2, int* __restrict__ idx) {
   __shared__ float tile[kTile * 3];
-  const int b = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
+  __shared__ float sd[4 * 64 * 3];
+  __shared__ int si[4 * 64 * 3];
+  const int b = blockIdx.y, q = blockIdx.x * 64 + (threadIdx.x & 63);
   const bool live = q < n;
   float ux = 0, uy = 0, uz = 0;
   if (live) {
@@ -332,16 +385,9 @@ __global__ __launch_bounds__(256) void three_nn_batch_k(int n, int m, const floa
     ux = p[0]; uy = p[1]; uz = p[2];
   }
   Best3 bst;
-  best3_init(&bst);
-  for (int base = 0; base < m; base += kTile) {
-    const int len = min(kTile, m - base);
-    __syncthreads();
-    for (int e = threadIdx.x; e < len * 3; e += 256) tile[e] = known[(static_cast<int64_t>(b) * m + base) * 3 + e];
-    __syncthreads();
-    if (live)
-      for (int k = 0; k < len; ++k) best3_push(&bst, sqdist(ux, uy, uz, tile[k * 3], tile[k * 3 + 1], tile[k * 3 + 2]), base + k);
-  }
-  if (live) {
+  best3_init(bst);
+  three_nn_scan(known, static_cast<int64_t>(b) * m, m, ux, uy, uz, live, tile, bst);
+  if (three_nn_merge(bst, sd, si) && live) {
     const int64_t o = (static_cast<int64_t>(b) * n + q) * 3;
     dist2[o] = bst.d1; dist2[o + 1] = bst.d2; dist2[o + 2] = bst.d3;
     idx[o] = bst.i1; idx[o + 1] = bst.i2; idx[o + 2] = bst.i3;
@@ -352,7 +398,9 @@ __global__ __launch_bounds__(256) void three_nn_stack_k(int B, int N, const floa
                                                         const float* __restrict__ known, const int* __restrict__ known_cnt,
                                                         float* __restrict__ dist2, int* __restrict__ idx) {
   __shared__ float tile[kTile * 3];
-  const int q = blockIdx.x * 256 + threadIdx.x;
+  __shared__ float sd[4 * 64 * 3];
+  __shared__ int si[4 * 64 * 3];
+  const int q = blockIdx.x * 64 + (threadIdx.x & 63);
   const bool live = q < N;
   int my_bs = -1, tmp;
   float ux = 0, uy = 0, uz = 0;
@@ -361,25 +409,18 @@ __global__ __launch_bounds__(256) void three_nn_stack_k(int B, int N, const floa
     ux = unknown[q * 3]; uy = unknown[q * 3 + 1]; uz = unknown[q * 3 + 2];
   }
   int first_bs, last_bs;
-  stack_locate(blockIdx.x * 256, B, unk_cnt, &first_bs, &tmp);
-  stack_locate(min(blockIdx.x * 256 + 255, N - 1), B, unk_cnt, &last_bs, &tmp);
+  stack_locate(blockIdx.x * 64, B, unk_cnt, &first_bs, &tmp);
+  stack_locate(min(blockIdx.x * 64 + 63, N - 1), B, unk_cnt, &last_bs, &tmp);
   Best3 bst;
-  best3_init(&bst);
+  best3_init(bst);
   int my_start = 0;
   for (int bs = first_bs; bs <= last_bs; ++bs) {
     const int start = stack_start(bs, known_cnt), m = known_cnt[bs];
     const bool mine = live && my_bs == bs;
     if (mine) my_start = start;
-    for (int base = 0; base < m; base += kTile) {
-      const int len = min(kTile, m - base);
-      __syncthreads();
-      for (int e = threadIdx.x; e < len * 3; e += 256) tile[e] = known[(static_cast<int64_t>(start) + base) * 3 + e];
-      __syncthreads();
-      if (mine)
-        for (int k = 0; k < len; ++k) best3_push(&bst, sqdist(ux, uy, uz, tile[k * 3], tile[k * 3 + 1], tile[k * 3 + 2]), base + k);
-    }
+    three_nn_scan(known, start, m, ux, uy, uz, mine, tile, bst);
   }
-  if (live) {
+  if (three_nn_merge(bst, sd, si) && live) {
     dist2[q * 3] = bst.d1; dist2[q * 3 + 1] = bst.d2; dist2[q * 3 + 2] = bst.d3;
     idx[q * 3] = bst.i1 + my_start; idx[q * 3 + 1] = bst.i2 + my_start; idx[q * 3 + 2] = bst.i3 + my_start;  // global rows (:72-74)
   }
@@ -556,7 +597,7 @@ extern "C" int fv2p_three_nn_batch(int b, int n, int m, const float* unknown, co
   FV2P_REQUIRE(b >= 0 && n >= 0 && m >= 0, FV2P_EINVAL, "three_nn: bad sizes");
   if (b == 0 || n == 0) return 0;
   FV2P_REQUIRE(unknown && dist2 && idx && (known || m == 0), FV2P_EINVAL, "three_nn: null pointer");
-  hipLaunchKernelGGL(three_nn_batch_k, dim3((unsigned)ceil_div(n, 256), b), dim3(256), 0, STREAM(s), n, m, unknown, known, dist2, idx);
+  hipLaunchKernelGGL(three_nn_batch_k, dim3((unsigned)ceil_div(n, 64), b), dim3(256), 0, STREAM(s), n, m, unknown, known, dist2, idx);
   FV2P_LAUNCH_CHECK();
   return 0;
 }
@@ -565,7 +606,7 @@ extern "C" int fv2p_three_nn_stack(int b, int n, int m, const float* unknown, co
   FV2P_REQUIRE(b >= 1 && n >= 0, FV2P_EINVAL, "three_nn_stack: bad sizes");
   if (n == 0) return 0;
   FV2P_REQUIRE(unknown && unknown_batch_cnt && known_batch_cnt && dist2 && idx, FV2P_EINVAL, "three_nn_stack: null pointer");
-  hipLaunchKernelGGL(three_nn_stack_k, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, STREAM(s), b, n, unknown, unknown_batch_cnt, known,
+  hipLaunchKernelGGL(three_nn_stack_k, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, STREAM(s), b, n, unknown, unknown_batch_cnt, known,
                      known_batch_cnt, dist2, idx);
   FV2P_LAUNCH_CHECK();
   return 0;

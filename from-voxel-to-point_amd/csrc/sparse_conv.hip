@@ -405,7 +405,7 @@ static void launch_vec(const ConvArgs& a, hipStream_t s) {
   constexpr int TM = 128;
   constexpr size_t cmp_lds = (static_cast<size_t>(CINP) * NB * 16 + static_cast<size_t>(TM) * (NB * 16 + 16)) * sizeof(float) + 2 * TM * sizeof(int);
   const int impl = conv_impl();
-  const bool use_cmp = (impl == 2 || (impl == 0 && a.kvol > 1)) && cmp_lds <= 64 * 1024;
+  const bool use_cmp = impl == 2 && cmp_lds <= 64 * 1024;  // measured slower than the dense tile at KITTI sizes (profiles/r01_*): opt-in
   if (use_cmp) {
     const unsigned blocks = static_cast<unsigned>(ceil_div(a.n_dst, TM));
     hipLaunchKernelGGL((conv_rows_cmp<CINP, NB, WT, TM>), dim3(blocks), dim3(256), cmp_lds, s, a);
@@ -491,7 +491,12 @@ extern "C" int fv2p_sparse_conv_rows(const float* src, int64_t n_src, int c_src,
   return 0;
 }
 
-static int wgrad_rows_per_chunk(int64_t n_dst) { return n_dst > 200000 ? 2048 : (n_dst > 50000 ? 1024 : 512); }
+static int wgrad_rows_per_chunk(int64_t n_dst) {
+  static int forced = -1;  // FV2P_WGRAD_RPC: tuning override (multiple of 256)
+  if (forced < 0) { const char* e = getenv("FV2P_WGRAD_RPC"); forced = e ? atoi(e) : 0; }
+  if (forced >= 256) return forced;
+  return n_dst > 200000 ? 2048 : (n_dst > 50000 ? 1024 : 512);
+}
 
 extern "C" size_t fv2p_sparse_conv_wgrad_ws_bytes(int64_t n_dst, int c_src, int c_dst, int kvol) {
   const int64_t chunks = ceil_div(n_dst > 0 ? n_dst : 1, wgrad_rows_per_chunk(n_dst));

@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""Per-kernel timings on one GPU (events on the launch stream). Not part of the product or of bench.py; used to
+iterate on kernel variants:  python tools/microbench.py [conv|dcn|fps|nms|all]"""
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (REPO, os.path.join(REPO, "from-voxel-to-point_amd")):
+    sys.path.insert(0, p)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def timeit(fn, reps=30, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3  # us
+
+
+def conv():
+    from fv2p_harness import synth
+    from fv2p_harness.backbone import VoxelBackBone8x, mean_vfe
+    from pcdet.datasets.processor.voxel_generator import points_to_voxel_gpu
+    from pcdet.ops.spconv import ops
+    from pcdet.ops.spconv.conv import SparseConvolution
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = VoxelBackBone8x(4, [1408, 1600, 40]).to(dev)
+    feats, coords = [], []
+    for b in range(4):
+        v, c, n = points_to_voxel_gpu(torch.from_numpy(synth.lidar_cloud(b, 16384)).to(dev), synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, True, 16000)
+        feats.append(mean_vfe(v, n))
+        coords.append(torch.nn.functional.pad(c, (1, 0), value=b))
+    recs = []
+
+    def hook(mod, inp, out):
+        x = inp[0]
+        rb = x.indice_dict[mod.indice_key]
+        recs.append((mod, x.features.detach(), rb, out.features.shape[0]))
+    hs = [m.register_forward_hook(hook) for m in model.modules() if isinstance(m, SparseConvolution)]
+    with torch.no_grad():
+        model(torch.cat(feats), torch.cat(coords), 4)
+    for h in hs:
+        h.remove()
+    print(f"{'layer':34s} {'n_in':>6s} {'n_out':>6s} {'pairs':>8s} {'fwd us':>8s} {'TF/s':>6s} {'dX us':>8s} {'dW us':>8s} {'TF/s':>6s}")
+    for mod, f, rb, n_out in recs:
+        w = mod.weight.detach()
+        p = int(rb.indice_pair_num.sum().item())
+        g = torch.randn((n_out, mod.out_channels), device=dev)
+        t_f = timeit(lambda: ops.indice_conv(f, w, rb, None, n_out, False, mod.subm))
+        cin, cout = mod.in_channels, mod.out_channels
+        w3 = w.reshape(-1, cin, cout)
+        tab_b, flip_b = rb.in_table()
+        t_dx = timeit(lambda: ops._conv_rows(g, w3, tab_b, flip_b, f.shape[0], cin, True))
+        t_all = timeit(lambda: ops.indice_conv_backward(f, w, g, rb, None, False, mod.subm))
+        fl = 2.0 * p * cin * cout
+        name = f"{'subm' if mod.subm else 'conv'} {cin}->{cout} {mod.indice_key}"
+        print(f"{name:34s} {f.shape[0]:6d} {n_out:6d} {p:8d} {t_f:8.1f} {fl / t_f / 1e6:6.1f} {t_dx:8.1f} {t_all - t_dx:8.1f} {fl / max(t_all - t_dx, 1e-3) / 1e6:6.1f}")
+    # rulebook build timings
+    x = torch.cat(coords)
+    for subm, k, s, p in [(True, 3, 1, 1), (False, 3, 2, 1)]:
+        t = timeit(lambda: ops.build_rulebook(x, 4, [41, 1600, 1408], k, s, p, 1, 0, subm), reps=20)
+        print(f"rulebook {'subm' if subm else 'conv s2'} n={x.shape[0]}: {t:.1f} us")
+    pts = torch.from_numpy(synth.lidar_cloud(0, 16384)).to(dev)
+    t = timeit(lambda: points_to_voxel_gpu(pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, True, 16000), reps=20)
+    print(f"points_to_voxel 16384 pts: {t:.1f} us")
+
+
+def dcn():
+    from pcdet.ops.DeformableConvolutionV2PyTorch.modules.mdeformable_conv_block import MdeformConvBlock
+    dev = torch.device("cuda:0")
+    for (b, c, h, w, dg) in [(4, 128, 200, 176, 1), (4, 256, 100, 88, 1), (4, 256, 50, 44, 1), (4, 256, 200, 176, 4)]:
+        blk = MdeformConvBlock(c, c, deformable_groups=dg).to(dev)
+        with torch.no_grad():
+            blk.conv_offset_mask.weight.normal_(0, 0.01)
+        x = torch.randn(b, c, h, w, device=dev, requires_grad=True)
+        off = torch.randn(b, dg * 18, h, w, device=dev) * 0.5
+        msk = torch.sigmoid(torch.randn(b, dg * 9, h, w, device=dev))
+        t_f = timeit(lambda: blk.conv_adaption(x.detach(), off, msk), reps=10, warm=2)
+        y = blk.conv_adaption(x, off, msk)
+        g = torch.randn_like(y)
+        t_fb = timeit(lambda: torch.autograd.grad(blk.conv_adaption(x, off, msk), [x, blk.conv_adaption.weight], g), reps=5, warm=1)
+        fl = 2.0 * b * h * w * c * c * 9
+        print(f"DCNv2 [{b},{c},{h},{w}] dg={dg}: fwd {t_f:9.1f} us ({fl / t_f / 1e6:6.1f} TF/s)   fwd+bwd {t_fb:9.1f} us")
+
+
+def fps():
+    from fv2p_harness import synth
+    from pcdet.ops.pointnet2.pointnet2_batch import pointnet2_utils as bu
+    dev = torch.device("cuda:0")
+    for n, m, b in [(16384, 16384, 1), (16384, 16384, 4), (16384, 4096, 4), (20000, 16384, 1)]:
+        pts = torch.from_numpy(np.stack([synth.lidar_cloud(i, n)[:, :3] for i in range(b)])).to(dev)
+        t = timeit(lambda: bu.furthest_point_sample(pts, m), reps=3, warm=1)
+        print(f"FPS B={b} N={n} M={m}: {t / 1e3:8.2f} ms  ({t / m:6.3f} us/round)")
+    kp = torch.from_numpy(synth.lidar_cloud(1, 16384)[None, :, :3]).to(dev)
+    for v in (60000, 15000, 4000):
+        known = torch.rand(1, v, 3, device=dev) * 70
+        t = timeit(lambda: bu.three_nn(kp, known), reps=5, warm=1)
+        print(f"three_nn 16384 x {v}: {t:8.1f} us ({8.0 * 16384 * v / t / 1e6:6.2f} TFLOP/s)")
+
+
+def nms():
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from boxes_util import random_boxes
+    from pcdet.ops.iou3d_nms import iou3d_nms_utils
+    dev = torch.device("cuda:0")
+    for n, th in [(9000, 0.8), (4096, 0.1)]:
+        boxes = torch.from_numpy(random_boxes(n, n)).to(dev)
+        scores = torch.rand(n, device=dev)
+        t = timeit(lambda: iou3d_nms_utils.nms_gpu(boxes, scores, th), reps=5, warm=1)
+        print(f"nms_gpu N={n} thr={th}: {t:8.1f} us")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    for name, fn in (("conv", conv), ("dcn", dcn), ("fps", fps), ("nms", nms)):
+        if which in (name, "all"):
+            print(f"==== {name}")
+            fn()
