@@ -43,13 +43,14 @@ def parse():
     ap.add_argument("--backbone", choices=["8x", "res8x"], default="8x")
     ap.add_argument("--cpu-clouds", type=int, default=8, help="clouds in the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--pyprofile", action="store_true", help="cProfile the timed steps (host-overhead hunting; prints to stderr)")
     return ap.parse_args()
 
 
 def build_step(args, device, rank, world):
     from fv2p_harness import synth
     from fv2p_harness.backbone import VoxelBackBone8x, VoxelResBackBone8x, mean_vfe
-    from pcdet.datasets.processor.voxel_generator import points_to_voxel_gpu
+    from pcdet.datasets.processor.voxel_generator import points_to_voxel_batch
 
     torch.manual_seed(0)
     cls = VoxelBackBone8x if args.backbone == "8x" else VoxelResBackBone8x
@@ -76,12 +77,8 @@ def build_step(args, device, rank, world):
             for seeds in dist_utils.rank_seeds(rank, n_pool, args.batch)]
 
     def voxelize(clouds):
-        feats, coords = [], []
-        for b, pts in enumerate(clouds):
-            v, c, n = points_to_voxel_gpu(pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, True, 16000)
-            feats.append(mean_vfe(v, n))
-            coords.append(torch.nn.functional.pad(c, (1, 0), value=b))
-        return torch.cat(feats), torch.cat(coords)
+        v, coords, n = points_to_voxel_batch(clouds, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 16000)
+        return mean_vfe(v, n), coords
 
     def step(i):
         feats, coords = voxelize(pool[i % n_pool])
@@ -203,9 +200,18 @@ def main():
         step(i)
     dist_utils.barrier()
     torch.cuda.synchronize()
+    prof = None
+    if args.pyprofile:
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    if prof is not None:
+        prof.disable()
+        import pstats
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(28)
     dist_utils.barrier()
     torch.cuda.synchronize()
     dt = dist_utils.max_over_ranks(time.perf_counter() - t0, device)

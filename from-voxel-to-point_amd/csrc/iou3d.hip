@@ -186,44 +186,59 @@ __global__ __launch_bounds__(64) void nms_mask(int n, float thresh, const float*
 }
 
 // Greedy pass of iou3d_nms.cpp:121-135 on the device: one workgroup, remv[] in LDS.
+// Per 64-box block: (1) wave 0 resolves the block's own 64 candidates on the scalar unit — the diagonal mask words are
+// pulled out of the lanes with v_readlane (compile-time lane index, fully unrolled), so the inherently serial
+// "keep t unless an earlier kept box suppresses it" chain costs a few SALU ops per box and no LDS round trips;
+// (2) all 256 threads OR the kept rows' mask words into remv[] with independent loads + LDS atomic OR.
+__device__ __forceinline__ unsigned long long lane_word(unsigned long long v, int t) {
+  const unsigned lo = __builtin_amdgcn_readlane(static_cast<int>(v & 0xffffffffull), t);
+  const unsigned hi = __builtin_amdgcn_readlane(static_cast<int>(v >> 32), t);
+  return (static_cast<unsigned long long>(hi) << 32) | lo;
+}
+
 __global__ __launch_bounds__(256) void nms_greedy(int n, int col_blocks, const unsigned long long* __restrict__ mask,
                                                   long long* __restrict__ keep, int* __restrict__ num_keep) {
   extern __shared__ unsigned long long remv[];  // [col_blocks]
   __shared__ unsigned long long s_kept;
   __shared__ int s_count;
+  __shared__ int s_list[64];  // lanes (rows of this block) that survived, in order
   for (int j = threadIdx.x; j < col_blocks; j += 256) remv[j] = 0ull;
   if (threadIdx.x == 0) s_count = 0;
   __syncthreads();
   for (int b = 0; b < col_blocks; ++b) {
-    if (threadIdx.x < 64) {  // wave 0: sequential scan of the 64 candidates of this block, all in registers
+    if (threadIdx.x < 64) {
       const int lane = threadIdx.x;
       const int row = b * 64 + lane;
       const unsigned long long diag = (row < n) ? mask[static_cast<int64_t>(row) * col_blocks + b] : 0ull;
-      unsigned long long cur = remv[b];
-      unsigned long long kept = 0ull;
       const int lim = min(64, n - b * 64);
-      for (int t = 0; t < lim; ++t) {
-        const unsigned long long d = __shfl(diag, t, 64);
+      unsigned long long cur = remv[b];
+      if (lim < 64) cur |= ~0ull << lim;  // rows past the end are never kept
+      unsigned long long kept = 0ull;
+#pragma unroll
+      for (int t = 0; t < 64; ++t) {
+        const unsigned long long d = lane_word(diag, t);
         if (!((cur >> t) & 1ull)) { kept |= 1ull << t; cur |= d; }
       }
       if (lane == 0) s_kept = kept;
-      // emit survivor indices in order
       const int base = s_count;
-      if ((kept >> lane) & 1ull) keep[base + __popcll(kept & ((1ull << lane) - 1ull))] = row;
+      if ((kept >> lane) & 1ull) {
+        const int rank = __popcll(kept & ((1ull << lane) - 1ull));
+        keep[base + rank] = row;
+        s_list[rank] = lane;
+      }
     }
     __syncthreads();
     const unsigned long long kept = s_kept;
     if (threadIdx.x == 0) s_count += __popcll(kept);
-    if (kept) {
-      for (int j = b + 1 + threadIdx.x; j < col_blocks; j += 256) {
-        unsigned long long acc = remv[j];
-        unsigned long long k = kept;
-        while (k) {
-          const int t = __ffsll(static_cast<long long>(k)) - 1;
-          k &= k - 1;
-          acc |= mask[static_cast<int64_t>(b * 64 + t) * col_blocks + j];
-        }
-        remv[j] = acc;
+    const int ncols = col_blocks - (b + 1);
+    if (kept && ncols > 0) {
+      // flatten (kept row, column) pairs over the workgroup: every load is independent of the others
+      const int nk = __popcll(kept);
+      for (int e = threadIdx.x; e < nk * ncols; e += 256) {
+        const int ki = e / ncols, j = b + 1 + e % ncols;
+        const int t = s_list[ki];
+        const unsigned long long v = mask[static_cast<int64_t>(b * 64 + t) * col_blocks + j];
+        if (v) atomicOr(&remv[j], v);
       }
     }
     __syncthreads();

@@ -159,6 +159,142 @@ __global__ __launch_bounds__(256) void conv_rows_vec(ConvArgs a) {
   conv_epilogue<NB>(a, acc, row0);
 }
 
+// ---- software-pipelined variant (CINP*NB <= 256) ---------------------------------------------------
+// Same tile as conv_rows_vec, but W_k is double-buffered in LDS and staged through registers (global loads issued
+// before the MFMA block, LDS stores after it), the A fragment of offset k+1 and the table row of offset k+2 are
+// fetched while offset k is on the matrix pipe, and a single barrier per offset remains.
+template <int CINP, int NB, bool WT>
+struct WStage {
+  static constexpr int COLS = NB * 16;
+  static constexpr int UNITS = CINP * COLS / 4;             // float4 units of one W_k
+  static constexpr int R = (UNITS + 255) / 256;             // units per thread
+  float4 v[R];
+  __device__ __forceinline__ void load(const ConvArgs& a, const float* __restrict__ wk) {
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      const int e = threadIdx.x + u * 256;
+      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < UNITS) {
+        if (!WT) {
+          const int c = e / (COLS / 4), col = (e % (COLS / 4)) * 4;
+          if (c < a.c_src) {
+            const float* p = wk + static_cast<long long>(c) * a.w_ld + col;
+            if (col + 3 < a.c_dst && (a.w_ld & 3) == 0) q = *reinterpret_cast<const float4*>(p);
+            else {
+              if (col + 0 < a.c_dst) q.x = p[0];
+              if (col + 1 < a.c_dst) q.y = p[1];
+              if (col + 2 < a.c_dst) q.z = p[2];
+              if (col + 3 < a.c_dst) q.w = p[3];
+            }
+          }
+        } else {
+          // unit e in LDS fragment order: n fastest, then g, nb, j  ->  the LDS store below is perfectly linear
+          const int n = e & 15, gq = (e >> 4) & 3, rest = e >> 6;
+          const int col = (rest % NB) * 16 + n, c = (rest / NB) * 16 + gq * 4;
+          if (col < a.c_dst) {
+            const float* p = wk + static_cast<long long>(col) * a.w_ld + c;
+            if (c + 3 < a.c_src && (a.w_ld & 3) == 0) q = *reinterpret_cast<const float4*>(p);
+            else {
+              if (c + 0 < a.c_src) q.x = p[0];
+              if (c + 1 < a.c_src) q.y = p[1];
+              if (c + 2 < a.c_src) q.z = p[2];
+              if (c + 3 < a.c_src) q.w = p[3];
+            }
+          }
+        }
+      }
+      v[u] = q;
+    }
+  }
+  __device__ __forceinline__ void store(float* __restrict__ lds) const {
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      const int e = threadIdx.x + u * 256;
+      if (e >= UNITS) continue;
+      if (!WT) {
+        const int c = e / (COLS / 4), col = (e % (COLS / 4)) * 4;
+        const int j = c >> 4, g = (c >> 2) & 3, t = c & 3;
+        const float q[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const int cc = col + x;
+          lds[(((j * NB + (cc >> 4)) * 64) + g * 16 + (cc & 15)) * 4 + t] = q[x];
+        }
+      } else {
+        *reinterpret_cast<float4*>(&lds[e * 4]) = v[u];
+      }
+    }
+  }
+};
+
+template <int CINP, int NB, bool WT>
+__global__ __launch_bounds__(256) void conv_rows_pipe(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // 2 x W_k
+  constexpr int J = CINP / 16;
+  constexpr int WSZ = CINP * NB * 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+  const int row0 = blockIdx.x * 64 + wave * 16;
+  const int my_row = row0 + r;
+  const bool row_ok = my_row < a.n_dst;
+  f32x4 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto tab_at = [&](int k) -> int {
+    const int trow = a.flip ? (a.kvol - 1 - k) : k;
+    return row_ok ? a.tab[static_cast<long long>(trow) * a.n_dst + my_row] : -1;
+  };
+  auto gather = [&](int idx, float4 (&av)[J]) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      av[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx >= 0 && (16 * j + 4 * g) < a.c_src)
+        av[j] = *reinterpret_cast<const float4*>(a.src + static_cast<long long>(idx) * a.ld_src + 16 * j + 4 * g);
+    }
+  };
+  WStage<CINP, NB, WT> ws;
+  float4 a_cur[J], a_nxt[J];
+  int idx_cur = tab_at(0);
+  int idx_nxt = a.kvol > 1 ? tab_at(1) : -1;
+  ws.load(a, a.w);
+  gather(idx_cur, a_cur);
+  ws.store(lds);
+  __syncthreads();
+  for (int k = 0; k < a.kvol; ++k) {
+    float* wcur = lds + (k & 1) * WSZ;
+    float* wnxt = lds + ((k + 1) & 1) * WSZ;
+    const bool more = k + 1 < a.kvol;
+    int idx_nn = -1;
+    if (more) {
+      ws.load(a, a.w + static_cast<long long>(k + 1) * a.w_kstride);
+      gather(idx_nxt, a_nxt);
+      if (k + 2 < a.kvol) idx_nn = tab_at(k + 2);
+    }
+    if (__ballot(idx_cur >= 0) != 0ull) {
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        float4 bv[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) bv[nb] = *reinterpret_cast<const float4*>(&wcur[((j * NB + nb) * 64 + lane) * 4]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j].x, bv[nb].x, acc[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j].y, bv[nb].y, acc[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j].z, bv[nb].z, acc[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j].w, bv[nb].w, acc[nb], 0, 0, 0);
+      }
+    }
+    if (more) ws.store(wnxt);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < J; ++j) a_cur[j] = a_nxt[j];
+    idx_cur = idx_nxt;
+    idx_nxt = idx_nn;
+  }
+  conv_epilogue<NB>(a, acc, row0);
+}
+
 // Compacted variant: the workgroup owns TM destination rows whose accumulators live in LDS.  For every kernel
 // offset the rows that actually have a neighbour are compacted (wave64 ballot + prefix) into a list, and only
 // ceil(n_k / 16) MFMA row groups are issued (round-robin over the 4 waves) instead of TM/16 — the MFMA work follows
@@ -299,94 +435,105 @@ struct WgradArgs {
   const int* tab; int n_dst; int kvol; int flip;
   float* dw; long long dw_kstride; int dw_ld;   // dW_k[c_src][c_grad]
   int rows_per_chunk;
+  int skip_k;                                    // offset computed elsewhere (dense identity GEMM), or -1
 };
 
-// One workgroup per (row chunk, k, cin-block group): its 4 waves split the chunk's rows, each compacts the valid
-// rows of its slice with a wave64 ballot so only real pairs reach the MFMA, the four partial [16*MBW, 16*NB]
-// tiles are summed in LDS and written to partial[chunk][k] (no global atomics; a second kernel adds the chunks,
-// so the result is deterministic).
+// One WAVE per (row chunk, kernel offset k, cin-block group); the 4 waves of a workgroup take 4 consecutive k of the
+// same chunk.  The wave first compacts the valid rows of its whole chunk (wave64 ballots) into an LDS pair list, then
+// walks the list in macro-steps of 16 pairs (4 MFMA k-slices): the 4*(MBW+NB) operand loads of the NEXT macro-step are
+// in flight while the 4*MBW*NB MFMAs of the current one run — the gathers are L2/HBM-latency bound, so the depth of
+// this prefetch is what sets the speed.  The [16*MBW, 16*NB] tile goes to partial[chunk][k] straight from the
+// accumulators (no LDS reduction, no atomics); a second kernel adds the chunks in a fixed order (deterministic).
+constexpr int kWgradMaxChunk = 1024;
 template <int MBW, int NB>
 __global__ __launch_bounds__(256) void conv_wgrad(WgradArgs a, float* __restrict__ partial) {
-  __shared__ int s_src[4][64];
-  __shared__ int s_row[4][64];
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [MBW*16][NB*16]
+  extern __shared__ int s_pairs[];  // [4 waves][2][rows_per_chunk]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, m = lane & 15, g = lane >> 4;
-  const int k = blockIdx.y;
+  const int k = blockIdx.y * 4 + w;
+  if (k >= a.kvol || k == a.skip_k) return;  // whole wave; no workgroup barrier is used below
+  int* s_src = s_pairs + (w * 2) * a.rows_per_chunk;
+  int* s_row = s_src + a.rows_per_chunk;
   const int trow = a.flip ? (a.kvol - 1 - k) : k;
   const int mb0 = blockIdx.z * MBW;
-  constexpr int TILE = MBW * 16 * NB * 16;
-  for (int e = threadIdx.x; e < TILE; e += 256) red[e] = 0.f;
+  const int r_begin = blockIdx.x * a.rows_per_chunk;
+  const int r_end = min(r_begin + a.rows_per_chunk, a.n_dst);
+  int cnt = 0;
+  for (int base = r_begin; base < r_end; base += 64) {
+    const int row = base + lane;
+    const int idx = (row < r_end) ? a.tab[static_cast<long long>(trow) * a.n_dst + row] : -1;
+    const uint64_t vote = __ballot(idx >= 0);
+    if (idx >= 0) {
+      const int pos = cnt + __popcll(vote & lanemask_lt());
+      s_src[pos] = idx;
+      s_row[pos] = row;
+    }
+    cnt += __popcll(vote);
+  }
+  __builtin_amdgcn_wave_barrier();
   f32x4 acc[MBW][NB];
 #pragma unroll
   for (int i = 0; i < MBW; ++i)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[i][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int per_wave = a.rows_per_chunk / 4;
-  const int r_begin = blockIdx.x * a.rows_per_chunk + w * per_wave;
-  const int r_end = min(r_begin + per_wave, a.n_dst);
-  bool touched = false;
-  for (int base = r_begin; base < r_end; base += 64) {
-    const int row = base + lane;
-    const int idx = (row < r_end) ? a.tab[static_cast<long long>(trow) * a.n_dst + row] : -1;
-    const uint64_t vote = __ballot(idx >= 0);
-    if (vote == 0ull) continue;
-    touched = true;
-    const int cnt = __popcll(vote);
-    if (idx >= 0) {
-      const int pos = __popcll(vote & lanemask_lt());
-      s_src[w][pos] = idx;
-      s_row[w][pos] = row;
-    }
-    __builtin_amdgcn_wave_barrier();
-    for (int p0 = 0; p0 < cnt; p0 += 4) {
-      const int p = p0 + g;
-      const int sr = (p < cnt) ? s_src[w][p] : -1;
-      const int rr = (p < cnt) ? s_row[w][p] : -1;
-      float av[MBW], bv[NB];
+  float av[4][MBW], bv[4][NB], av2[4][MBW], bv2[4][NB];
+  auto fetch = [&](int p0, float (&xa)[4][MBW], float (&xb)[4][NB]) {
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int p = p0 + s4 * 4 + g;
+      const int sr = (p < cnt) ? s_src[p] : -1;
+      const int rr = (p < cnt) ? s_row[p] : -1;
 #pragma unroll
       for (int i = 0; i < MBW; ++i) {
         const int c = (mb0 + i) * 16 + m;
-        av[i] = (sr >= 0 && c < a.c_src) ? a.src[static_cast<long long>(sr) * a.ld_src + c] : 0.f;
+        xa[s4][i] = (sr >= 0 && c < a.c_src) ? a.src[static_cast<long long>(sr) * a.ld_src + c] : 0.f;
       }
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         const int c = nb * 16 + m;
-        bv[nb] = (rr >= 0 && c < a.c_grad) ? a.grad[static_cast<long long>(rr) * a.ld_grad + c] : 0.f;
+        xb[s4][nb] = (rr >= 0 && c < a.c_grad) ? a.grad[static_cast<long long>(rr) * a.ld_grad + c] : 0.f;
       }
+    }
+  };
+  if (cnt > 0) fetch(0, av, bv);
+  for (int p0 = 0; p0 < cnt; p0 += 16) {
+    if (p0 + 16 < cnt) fetch(p0 + 16, av2, bv2);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
       for (int i = 0; i < MBW; ++i)
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[nb], acc[i][nb], 0, 0, 0);
+        for (int nb = 0; nb < NB; ++nb) acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4][i], bv[s4][nb], acc[i][nb], 0, 0, 0);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+#pragma unroll
+      for (int i = 0; i < MBW; ++i) av[s4][i] = av2[s4][i];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) bv[s4][nb] = bv2[s4][nb];
     }
-    __builtin_amdgcn_wave_barrier();
   }
-  __syncthreads();  // red[] zeroed
-  if (touched) {
-#pragma unroll
-    for (int i = 0; i < MBW; ++i)
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) atomicAdd(&red[(i * 16 + g * 4 + reg) * (NB * 16) + nb * 16 + m], acc[i][nb][reg]);
-  }
-  __syncthreads();
-  // partial[chunk][k][c_src][c_grad]
+  // partial[chunk][k][c_src][c_grad]: C layout row = 4g + reg (cin), col = m (cout)
   float* out = partial + (static_cast<long long>(blockIdx.x) * a.kvol + k) * a.c_src * a.c_grad;
-  for (int e = threadIdx.x; e < TILE; e += 256) {
-    const int cr = mb0 * 16 + e / (NB * 16), cc = e % (NB * 16);
-    if (cr < a.c_src && cc < a.c_grad) out[static_cast<long long>(cr) * a.c_grad + cc] = red[e];
-  }
+#pragma unroll
+  for (int i = 0; i < MBW; ++i)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int cr = (mb0 + i) * 16 + g * 4 + reg, cc = nb * 16 + m;
+        if (cr < a.c_src && cc < a.c_grad) out[static_cast<long long>(cr) * a.c_grad + cc] = acc[i][nb][reg];
+      }
 }
 
 // dW[k][cr][d0 + cc] = sum over chunks of partial[chunk][k][cr][cc]
 __global__ void wgrad_reduce(const float* __restrict__ partial, int chunks, int kvol, int c_src, int c_grad, float* __restrict__ dw,
-                             long long dw_kstride, int dw_ld) {
+                             long long dw_kstride, int dw_ld, int skip_k) {
   const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   const long long per_chunk = static_cast<long long>(kvol) * c_src * c_grad;
   if (t >= per_chunk) return;
+  const int cc = static_cast<int>(t % c_grad), cr = static_cast<int>((t / c_grad) % c_src), k = static_cast<int>(t / (static_cast<long long>(c_grad) * c_src));
+  if (k == skip_k) return;
   float s = 0.f;
   for (int c = 0; c < chunks; ++c) s += partial[c * per_chunk + t];
-  const int cc = static_cast<int>(t % c_grad), cr = static_cast<int>((t / c_grad) % c_src), k = static_cast<int>(t / (static_cast<long long>(c_grad) * c_src));
   dw[k * dw_kstride + static_cast<long long>(cr) * dw_ld + cc] = s;
 }
 
@@ -412,6 +559,12 @@ static void launch_vec(const ConvArgs& a, hipStream_t s) {
     return;
   }
   const unsigned blocks = static_cast<unsigned>(ceil_div(a.n_dst, 64));
+  if constexpr (CINP * NB <= 256) {
+    if (impl != 1 && a.kvol > 1) {  // FV2P_CONV_IMPL=dense keeps the unpipelined tile (parity tests run both)
+      hipLaunchKernelGGL((conv_rows_pipe<CINP, NB, WT>), dim3(blocks), dim3(256), 2 * CINP * NB * 16 * sizeof(float), s, a);
+      return;
+    }
+  }
   hipLaunchKernelGGL((conv_rows_vec<CINP, NB, WT>), dim3(blocks), dim3(256), CINP * NB * 16 * sizeof(float), s, a);
 }
 template <int STEPS, int NB, bool WT>
@@ -494,8 +647,8 @@ extern "C" int fv2p_sparse_conv_rows(const float* src, int64_t n_src, int c_src,
 static int wgrad_rows_per_chunk(int64_t n_dst) {
   static int forced = -1;  // FV2P_WGRAD_RPC: tuning override (multiple of 256)
   if (forced < 0) { const char* e = getenv("FV2P_WGRAD_RPC"); forced = e ? atoi(e) : 0; }
-  if (forced >= 256) return forced;
-  return n_dst > 200000 ? 2048 : (n_dst > 50000 ? 1024 : 512);
+  if (forced >= 256 && forced <= kWgradMaxChunk) return forced;
+  return n_dst > 200000 ? 1024 : (n_dst > 60000 ? 512 : 256);
 }
 
 extern "C" size_t fv2p_sparse_conv_wgrad_ws_bytes(int64_t n_dst, int c_src, int c_dst, int kvol) {
@@ -507,7 +660,7 @@ extern "C" size_t fv2p_sparse_conv_wgrad_ws_bytes(int64_t n_dst, int c_src, int 
 }
 
 extern "C" int fv2p_sparse_conv_wgrad(const float* src, int64_t n_src, int c_src, const float* grad, const int* tab, int64_t n_dst,
-                                      int c_dst, int kvol, int flip_k, float* dweight, void* ws, size_t ws_bytes,
+                                      int c_dst, int kvol, int flip_k, int skip_k, float* dweight, void* ws, size_t ws_bytes,
                                       fv2p_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   FV2P_REQUIRE(c_src >= 1 && c_dst >= 1 && kvol >= 1 && n_dst >= 0, FV2P_EINVAL, "sparse_conv_wgrad: bad sizes");
@@ -530,14 +683,15 @@ extern "C" int fv2p_sparse_conv_wgrad(const float* src, int64_t n_src, int c_src
     a.tab = tab; a.n_dst = static_cast<int>(n_dst); a.kvol = kvol; a.flip = flip_k;
     a.dw = dweight + d0; a.dw_kstride = static_cast<long long>(c_src) * c_dst; a.dw_ld = c_dst;
     a.rows_per_chunk = rows_per_chunk;
+    a.skip_k = skip_k;
     const int mb = static_cast<int>(ceil_div(c_src, 16));
     const int nb = static_cast<int>(ceil_div(cd, 16));
     const int nbp = nb <= 1 ? 1 : nb <= 2 ? 2 : nb <= 4 ? 4 : 8;
     // accumulators per wave: MBW*NB <= 16
     const int mbw = nbp == 8 ? 2 : (mb >= 4 ? 4 : mb >= 2 ? 2 : 1);
     const unsigned gz = static_cast<unsigned>(ceil_div(mb, mbw));
-    const dim3 grid(chunks, kvol, gz), block(256);
-    const size_t lds = static_cast<size_t>(mbw) * 16 * nbp * 16 * sizeof(float);
+    const dim3 grid(chunks, static_cast<unsigned>(ceil_div(kvol, 4)), gz), block(256);
+    const size_t lds = static_cast<size_t>(8) * rows_per_chunk * sizeof(int);
 #define FV2P_WG(MBW, NB) hipLaunchKernelGGL((conv_wgrad<MBW, NB>), grid, block, lds, stream, a, partial)
     if (nbp == 8) { FV2P_WG(2, 8); }
     else if (nbp == 4) { if (mbw == 4) FV2P_WG(4, 4); else if (mbw == 2) FV2P_WG(2, 4); else FV2P_WG(1, 4); }
@@ -546,7 +700,7 @@ extern "C" int fv2p_sparse_conv_wgrad(const float* src, int64_t n_src, int c_src
 #undef FV2P_WG
     const long long per_chunk = static_cast<long long>(kvol) * c_src * cd;
     hipLaunchKernelGGL(wgrad_reduce, dim3(static_cast<unsigned>(ceil_div(per_chunk, 256))), dim3(256), 0, stream, partial, (int)chunks, kvol,
-                       c_src, cd, a.dw, a.dw_kstride, a.dw_ld);
+                       c_src, cd, a.dw, a.dw_kstride, a.dw_ld, skip_k);
   }
   FV2P_LAUNCH_CHECK();
   return 0;

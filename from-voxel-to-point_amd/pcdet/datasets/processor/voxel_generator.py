@@ -12,6 +12,7 @@ already initialised it; voxelise in the main process (e.g. on the collated batch
 `multiprocessing_context="spawn"`.
 """
 import numpy as np
+import torch
 
 from pcdet import ops as _ops  # noqa: F401  (puts fv2p_native on sys.path)
 import fv2p_native as _nat
@@ -50,6 +51,54 @@ def points_to_voxel_gpu(points, voxel_size, coors_range, max_points=35, reverse_
     if not reverse_index:
         coors = coors.flip(1).contiguous()
     return voxels, coors, num
+
+
+_STREAMS = {}
+
+
+def _launch(points, voxel_size, coors_range, grid, max_points, max_voxels):
+    """Enqueues one cloud's voxelisation on the current stream; no host synchronisation."""
+    n, ndim = points.shape
+    dev = points.device
+    voxels = torch.empty((max_voxels, max_points, ndim), dtype=torch.float32, device=dev)
+    coors = torch.empty((max_voxels, 3), dtype=torch.int32, device=dev)
+    num = torch.empty((max_voxels,), dtype=torch.int32, device=dev)
+    count = torch.empty((1,), dtype=torch.int32, device=dev)
+    ws_bytes = _nat.lib().fv2p_points_to_voxel_ws_bytes(n, max_voxels)
+    ws = _nat.workspace(ws_bytes, dev)
+    _nat.call("fv2p_points_to_voxel", points, n, ndim, voxel_size.tolist(), coors_range[:3].tolist(), [int(g) for g in grid],
+              int(max_points), int(max_voxels), voxels, coors, num, count, ws, ws.numel(), _nat.stream())
+    return voxels, coors, num, count
+
+
+def points_to_voxel_batch(points_list, voxel_size, coors_range, max_points=35, max_voxels=20000):
+    """Voxelises the clouds of one batch concurrently — one HIP stream per cloud, a single host sync for all voxel
+    counts — and returns the collated batch the models consume (dataset.collate_batch, pcdet/datasets/dataset.py:152-183):
+    voxels [sum M, max_points, ndim], coords [sum M, 4] (batch, z, y, x) int32, num_points [sum M] int32."""
+    voxel_size = np.asarray(voxel_size, dtype=np.float32)
+    coors_range = np.asarray(coors_range, dtype=np.float32)
+    grid = _grid_size(voxel_size, coors_range)
+    dev = points_list[0].device
+    main = torch.cuda.current_stream(dev)
+    pool = _STREAMS.setdefault(dev.index, [])
+    while len(pool) < len(points_list):
+        pool.append(torch.cuda.Stream(device=dev))
+    outs = []
+    with _nat.device_guard(dev):
+        for pts, st in zip(points_list, pool):
+            _nat.require_cuda(pts)
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                outs.append(_launch(pts.contiguous(), voxel_size, coors_range, grid, max_points, max_voxels))
+        for st, o in zip(pool, outs):
+            main.wait_stream(st)
+            for t in o:
+                t.record_stream(main)
+    counts = torch.cat([o[3] for o in outs]).cpu().tolist()  # the one synchronisation of the batch
+    v = torch.cat([o[0][:m] for o, m in zip(outs, counts)])
+    c = torch.cat([torch.nn.functional.pad(o[1][:m], (1, 0), value=b) for b, (o, m) in enumerate(zip(outs, counts))])
+    k = torch.cat([o[2][:m] for o, m in zip(outs, counts)])
+    return v, c, k
 
 
 def points_to_voxel(points, voxel_size, coors_range, max_points=35, reverse_index=True, max_voxels=20000):

@@ -73,3 +73,14 @@ def test_voxeliser_edge_cases(gpu):
 def test_cpu_tensor_is_rejected_loudly(gpu):
     with pytest.raises(Exception):
         points_to_voxel(torch.zeros(10, 4), synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, True, 100)
+
+
+def test_batched_multistream_voxeliser_equals_per_cloud(gpu):
+    from pcdet.datasets.processor.voxel_generator import points_to_voxel_batch
+    clouds = [synth.lidar_cloud(20 + b, 16384 if b % 2 == 0 else 9000) for b in range(4)]
+    v, c, k = points_to_voxel_batch([torch.from_numpy(p).to(gpu) for p in clouds], synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 16000)
+    ref = [oracle.points_to_voxel(p, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 16000) for p in clouds]
+    assert np.array_equal(v.cpu().numpy(), np.concatenate([r[0] for r in ref]))
+    assert np.array_equal(k.cpu().numpy(), np.concatenate([r[2] for r in ref]))
+    rc = np.concatenate([np.concatenate([np.full((r[1].shape[0], 1), b, np.int32), r[1]], 1) for b, r in enumerate(ref)])
+    assert c.dtype == torch.int32 and np.array_equal(c.cpu().numpy(), rc)
