@@ -161,8 +161,8 @@ __global__ __launch_bounds__(256) void conv_rows_vec(ConvArgs a) {
 
 // ---- software-pipelined variant (CINP*NB <= 256) ---------------------------------------------------
 // Same tile as conv_rows_vec, but W_k is double-buffered in LDS and staged through registers (global loads issued
-// before the MFMA block, LDS stores after it), the A fragment of offset k+1 and the table row of offset k+2 are
-// fetched while offset k is on the matrix pipe, and a single barrier per offset remains.
+// before the MFMA block, LDS stores after it), the A fragments of the next offsets and the table rows of the ones
+// after are fetched while the current offsets are on the matrix pipe, and a single barrier per iteration remains.
 template <int CINP, int NB, bool WT>
 struct WStage {
   static constexpr int COLS = NB * 16;
@@ -227,9 +227,11 @@ struct WStage {
   }
 };
 
-template <int CINP, int NB, bool WT>
+// KU kernel offsets are processed per loop iteration (KU = 2 for the usual 27-offset kernels): the gathers are
+// latency bound, so issuing the loads of KU offsets at once halves the number of exposed round trips.
+template <int CINP, int NB, bool WT, int KU>
 __global__ __launch_bounds__(256) void conv_rows_pipe(ConvArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // 2 x W_k
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // 2 (double buffer) x KU x W_k
   constexpr int J = CINP / 16;
   constexpr int WSZ = CINP * NB * 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
@@ -240,8 +242,9 @@ __global__ __launch_bounds__(256) void conv_rows_pipe(ConvArgs a) {
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto tab_at = [&](int k) -> int {
+    if (k >= a.kvol || !row_ok) return -1;
     const int trow = a.flip ? (a.kvol - 1 - k) : k;
-    return row_ok ? a.tab[static_cast<long long>(trow) * a.n_dst + my_row] : -1;
+    return a.tab[static_cast<long long>(trow) * a.n_dst + my_row];
   };
   auto gather = [&](int idx, float4 (&av)[J]) {
 #pragma unroll
@@ -251,46 +254,64 @@ __global__ __launch_bounds__(256) void conv_rows_pipe(ConvArgs a) {
         av[j] = *reinterpret_cast<const float4*>(a.src + static_cast<long long>(idx) * a.ld_src + 16 * j + 4 * g);
     }
   };
-  WStage<CINP, NB, WT> ws;
-  float4 a_cur[J], a_nxt[J];
-  int idx_cur = tab_at(0);
-  int idx_nxt = a.kvol > 1 ? tab_at(1) : -1;
-  ws.load(a, a.w);
-  gather(idx_cur, a_cur);
-  ws.store(lds);
+  WStage<CINP, NB, WT> ws[KU];
+  float4 a_cur[KU][J], a_nxt[KU][J];
+  int idx_cur[KU], idx_nxt[KU], idx_nn[KU];
+#pragma unroll
+  for (int u = 0; u < KU; ++u) { idx_cur[u] = tab_at(u); idx_nxt[u] = tab_at(KU + u); }
+#pragma unroll
+  for (int u = 0; u < KU; ++u) {
+    if (u < a.kvol) ws[u].load(a, a.w + static_cast<long long>(u) * a.w_kstride);
+    gather(idx_cur[u], a_cur[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < KU; ++u)
+    if (u < a.kvol) ws[u].store(lds + u * WSZ);
   __syncthreads();
-  for (int k = 0; k < a.kvol; ++k) {
-    float* wcur = lds + (k & 1) * WSZ;
-    float* wnxt = lds + ((k + 1) & 1) * WSZ;
-    const bool more = k + 1 < a.kvol;
-    int idx_nn = -1;
-    if (more) {
-      ws.load(a, a.w + static_cast<long long>(k + 1) * a.w_kstride);
-      gather(idx_nxt, a_nxt);
-      if (k + 2 < a.kvol) idx_nn = tab_at(k + 2);
-    }
-    if (__ballot(idx_cur >= 0) != 0ull) {
+  int it = 0;
+  for (int k0 = 0; k0 < a.kvol; k0 += KU, ++it) {
+    float* wcur = lds + (it & 1) * KU * WSZ;
+    float* wnxt = lds + ((it + 1) & 1) * KU * WSZ;
 #pragma unroll
-      for (int j = 0; j < J; ++j) {
-        float4 bv[NB];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) bv[nb] = *reinterpret_cast<const float4*>(&wcur[((j * NB + nb) * 64 + lane) * 4]);
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j].x, bv[nb].x, acc[nb], 0, 0, 0);
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j].y, bv[nb].y, acc[nb], 0, 0, 0);
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j].z, bv[nb].z, acc[nb], 0, 0, 0);
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j].w, bv[nb].w, acc[nb], 0, 0, 0);
+    for (int u = 0; u < KU; ++u) {
+      const int kn = k0 + KU + u;
+      idx_nn[u] = tab_at(kn + KU);
+      if (kn < a.kvol) {
+        ws[u].load(a, a.w + static_cast<long long>(kn) * a.w_kstride);
+        gather(idx_nxt[u], a_nxt[u]);
       }
     }
-    if (more) ws.store(wnxt);
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      if (k0 + u < a.kvol && __ballot(idx_cur[u] >= 0) != 0ull) {
+        const float* wk = wcur + u * WSZ;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          float4 bv[NB];
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) bv[nb] = *reinterpret_cast<const float4*>(&wk[((j * NB + nb) * 64 + lane) * 4]);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u][j].x, bv[nb].x, acc[nb], 0, 0, 0);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u][j].y, bv[nb].y, acc[nb], 0, 0, 0);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u][j].z, bv[nb].z, acc[nb], 0, 0, 0);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[u][j].w, bv[nb].w, acc[nb], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < KU; ++u)
+      if (k0 + KU + u < a.kvol) ws[u].store(wnxt + u * WSZ);
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < J; ++j) a_cur[j] = a_nxt[j];
-    idx_cur = idx_nxt;
-    idx_nxt = idx_nn;
+    for (int u = 0; u < KU; ++u) {
+#pragma unroll
+      for (int j = 0; j < J; ++j) a_cur[u][j] = a_nxt[u][j];
+      idx_cur[u] = idx_nxt[u];
+      idx_nxt[u] = idx_nn[u];
+    }
   }
   conv_epilogue<NB>(a, acc, row0);
 }
@@ -435,106 +456,155 @@ struct WgradArgs {
   const int* tab; int n_dst; int kvol; int flip;
   float* dw; long long dw_kstride; int dw_ld;   // dW_k[c_src][c_grad]
   int rows_per_chunk;
-  int skip_k;                                    // offset computed elsewhere (dense identity GEMM), or -1
+  int skip_k;                                    // offset handled by another launch, or -1
+  int k_base, k_count;                           // this launch covers offsets [k_base, k_base + k_count)
 };
 
-// One WAVE per (row chunk, kernel offset k, cin-block group); the 4 waves of a workgroup take 4 consecutive k of the
-// same chunk.  The wave first compacts the valid rows of its whole chunk (wave64 ballots) into an LDS pair list, then
-// walks the list in macro-steps of 16 pairs (4 MFMA k-slices): the 4*(MBW+NB) operand loads of the NEXT macro-step are
-// in flight while the 4*MBW*NB MFMAs of the current one run — the gathers are L2/HBM-latency bound, so the depth of
-// this prefetch is what sets the speed.  The [16*MBW, 16*NB] tile goes to partial[chunk][k] straight from the
-// accumulators (no LDS reduction, no atomics); a second kernel adds the chunks in a fixed order (deterministic).
+// One WORKGROUP per (row chunk, kernel offset k).  The gathers are latency bound (a dependent table read, then rows
+// scattered over L2/HBM), so the kernel is organised around memory-level parallelism:
+//   1. the 256 threads compact the chunk's valid rows into an LDS pair list (ordered: ballot + wave prefix);
+//   2. per stage of 64 pairs they fetch both operands COOPERATIVELY — every thread issues (CIN+COUT)/16 independent
+//      16-byte loads (whole 256-byte rows, coalesced) for the next stage into registers while the current stage is on
+//      the matrix pipe, then parks them in LDS (F[64][CIN], G[64][COUT], padded rows);
+//   3. wave w owns cin block(s) w*MBW.. and all cout blocks: A_mfma[m = cin][kk = pair] and B_mfma[kk = pair][n = cout]
+//      are 4-byte LDS reads, 16 k-slices per stage.
+// The [Cin, Cout] tile goes to partial[chunk][k] straight from the accumulators (no atomics); a second kernel adds
+// the chunks in a fixed order, so the gradient is deterministic.
 constexpr int kWgradMaxChunk = 1024;
-template <int MBW, int NB>
+template <int MB, int NB>     // CINP = 16*MB, COUTP = 16*NB ; MBW = max(MB/4, 1) cin blocks per wave
 __global__ __launch_bounds__(256) void conv_wgrad(WgradArgs a, float* __restrict__ partial) {
-  extern __shared__ int s_pairs[];  // [4 waves][2][rows_per_chunk]
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, m = lane & 15, g = lane >> 4;
-  const int k = blockIdx.y * 4 + w;
-  if (k >= a.kvol || k == a.skip_k) return;  // whole wave; no workgroup barrier is used below
-  int* s_src = s_pairs + (w * 2) * a.rows_per_chunk;
+  constexpr int CINP = MB * 16, COUTP = NB * 16;
+  constexpr int kWgStage = (MB * NB >= 64) ? 32 : 64;  // pairs per stage (keeps the LDS footprint under 64 KB)
+  constexpr int MBW = MB >= 4 ? MB / 4 : 1;
+  constexpr int LDF = CINP + 4, LDG = COUTP + 4;
+  constexpr int RF = (kWgStage * CINP / 4 + 255) / 256, RG = (kWgStage * COUTP / 4 + 255) / 256;  // float4 units per thread per stage
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* F = lds;                                   // [64][LDF]
+  float* G = F + kWgStage * LDF;                    // [64][LDG]
+  int* s_src = reinterpret_cast<int*>(G + kWgStage * LDG);  // [rows_per_chunk]
   int* s_row = s_src + a.rows_per_chunk;
+  __shared__ int wave_cnt[4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, m = lane & 15, g = lane >> 4;
+  const int kl = blockIdx.y, k = a.k_base + kl;
+  if (k == a.skip_k) return;  // whole workgroup
   const int trow = a.flip ? (a.kvol - 1 - k) : k;
-  const int mb0 = blockIdx.z * MBW;
   const int r_begin = blockIdx.x * a.rows_per_chunk;
   const int r_end = min(r_begin + a.rows_per_chunk, a.n_dst);
+  // ---- 1. ordered compaction
   int cnt = 0;
-  for (int base = r_begin; base < r_end; base += 64) {
-    const int row = base + lane;
+  for (int base = r_begin; base < r_end; base += 256) {
+    const int row = base + tid;
     const int idx = (row < r_end) ? a.tab[static_cast<long long>(trow) * a.n_dst + row] : -1;
     const uint64_t vote = __ballot(idx >= 0);
-    if (idx >= 0) {
-      const int pos = cnt + __popcll(vote & lanemask_lt());
-      s_src[pos] = idx;
-      s_row[pos] = row;
-    }
-    cnt += __popcll(vote);
+    if (lane == 0) wave_cnt[w] = __popcll(vote);
+    __syncthreads();
+    int pos = cnt + __popcll(vote & lanemask_lt());
+    for (int ww = 0; ww < w; ++ww) pos += wave_cnt[ww];
+    if (idx >= 0) { s_src[pos] = idx; s_row[pos] = row; }
+    cnt += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
   }
-  __builtin_amdgcn_wave_barrier();
   f32x4 acc[MBW][NB];
 #pragma unroll
   for (int i = 0; i < MBW; ++i)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[i][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float av[4][MBW], bv[4][NB], av2[4][MBW], bv2[4][NB];
-  auto fetch = [&](int p0, float (&xa)[4][MBW], float (&xb)[4][NB]) {
+  // ---- 2./3. staged gather + MFMA
+  float4 rf[RF], rg[RG];
+  auto fetch = [&](int p0) {
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      const int p = p0 + s4 * 4 + g;
-      const int sr = (p < cnt) ? s_src[p] : -1;
-      const int rr = (p < cnt) ? s_row[p] : -1;
-#pragma unroll
-      for (int i = 0; i < MBW; ++i) {
-        const int c = (mb0 + i) * 16 + m;
-        xa[s4][i] = (sr >= 0 && c < a.c_src) ? a.src[static_cast<long long>(sr) * a.ld_src + c] : 0.f;
+    for (int u = 0; u < RF; ++u) {
+      const int e = tid + u * 256, pr = e / (CINP / 4), c = (e % (CINP / 4)) * 4;
+      const int sr = (pr < kWgStage && p0 + pr < cnt) ? s_src[p0 + pr] : -1;
+      rf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (sr >= 0 && c < a.c_src) {
+        const float* q = a.src + static_cast<long long>(sr) * a.ld_src + c;
+        if (c + 3 < a.c_src && (a.ld_src & 3) == 0) rf[u] = *reinterpret_cast<const float4*>(q);
+        else { rf[u].x = q[0]; if (c + 1 < a.c_src) rf[u].y = q[1]; if (c + 2 < a.c_src) rf[u].z = q[2]; if (c + 3 < a.c_src) rf[u].w = q[3]; }
       }
+    }
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const int c = nb * 16 + m;
-        xb[s4][nb] = (rr >= 0 && c < a.c_grad) ? a.grad[static_cast<long long>(rr) * a.ld_grad + c] : 0.f;
+    for (int u = 0; u < RG; ++u) {
+      const int e = tid + u * 256, pr = e / (COUTP / 4), c = (e % (COUTP / 4)) * 4;
+      const int rr = (pr < kWgStage && p0 + pr < cnt) ? s_row[p0 + pr] : -1;
+      rg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rr >= 0 && c < a.c_grad) {
+        const float* q = a.grad + static_cast<long long>(rr) * a.ld_grad + c;
+        if (c + 3 < a.c_grad && (a.ld_grad & 3) == 0) rg[u] = *reinterpret_cast<const float4*>(q);
+        else { rg[u].x = q[0]; if (c + 1 < a.c_grad) rg[u].y = q[1]; if (c + 2 < a.c_grad) rg[u].z = q[2]; if (c + 3 < a.c_grad) rg[u].w = q[3]; }
       }
     }
   };
-  if (cnt > 0) fetch(0, av, bv);
-  for (int p0 = 0; p0 < cnt; p0 += 16) {
-    if (p0 + 16 < cnt) fetch(p0 + 16, av2, bv2);
+  auto park = [&]() {
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4)
+    for (int u = 0; u < RF; ++u) {
+      const int e = tid + u * 256, pr = e / (CINP / 4), c = (e % (CINP / 4)) * 4;
+      if (pr < kWgStage) *reinterpret_cast<float4*>(&F[pr * LDF + c]) = rf[u];
+    }
 #pragma unroll
-      for (int i = 0; i < MBW; ++i)
+    for (int u = 0; u < RG; ++u) {
+      const int e = tid + u * 256, pr = e / (COUTP / 4), c = (e % (COUTP / 4)) * 4;
+      if (pr < kWgStage) *reinterpret_cast<float4*>(&G[pr * LDG + c]) = rg[u];
+    }
+  };
+  if (cnt > 0) fetch(0);
+  for (int p0 = 0; p0 < cnt; p0 += kWgStage) {
+    __syncthreads();  // previous stage's LDS reads are done
+    park();
+    __syncthreads();
+    if (p0 + kWgStage < cnt) fetch(p0 + kWgStage);
+    const int npair = min(kWgStage, cnt - p0);
+    if (w * MBW < MB) {
+      for (int sl = 0; sl * 4 < npair; ++sl) {
+        const int pr = sl * 4 + g;  // rows beyond npair were parked as zeros
+        float av[MBW], bv[NB];
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4][i], bv[s4][nb], acc[i][nb], 0, 0, 0);
+        for (int i = 0; i < MBW; ++i) av[i] = F[pr * LDF + (w * MBW + i) * 16 + m];
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
+        for (int nb = 0; nb < NB; ++nb) bv[nb] = G[pr * LDG + nb * 16 + m];
 #pragma unroll
-      for (int i = 0; i < MBW; ++i) av[s4][i] = av2[s4][i];
+        for (int i = 0; i < MBW; ++i)
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) bv[s4][nb] = bv2[s4][nb];
+          for (int nb = 0; nb < NB; ++nb) acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[nb], acc[i][nb], 0, 0, 0);
+      }
     }
   }
   // partial[chunk][k][c_src][c_grad]: C layout row = 4g + reg (cin), col = m (cout)
-  float* out = partial + (static_cast<long long>(blockIdx.x) * a.kvol + k) * a.c_src * a.c_grad;
+  if (w * MBW < MB) {
+    float* out = partial + (static_cast<long long>(blockIdx.x) * a.k_count + kl) * a.c_src * a.c_grad;
 #pragma unroll
-  for (int i = 0; i < MBW; ++i)
+    for (int i = 0; i < MBW; ++i)
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+      for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int cr = (mb0 + i) * 16 + g * 4 + reg, cc = nb * 16 + m;
-        if (cr < a.c_src && cc < a.c_grad) out[static_cast<long long>(cr) * a.c_grad + cc] = acc[i][nb][reg];
-      }
+        for (int reg = 0; reg < 4; ++reg) {
+          const int cr = (w * MBW + i) * 16 + g * 4 + reg, cc = nb * 16 + m;
+          if (cr < a.c_src && cc < a.c_grad) out[static_cast<long long>(cr) * a.c_grad + cc] = acc[i][nb][reg];
+        }
+  }
 }
 
-// dW[k][cr][d0 + cc] = sum over chunks of partial[chunk][k][cr][cc]
-__global__ void wgrad_reduce(const float* __restrict__ partial, int chunks, int kvol, int c_src, int c_grad, float* __restrict__ dw,
-                             long long dw_kstride, int dw_ld, int skip_k) {
-  const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
-  const long long per_chunk = static_cast<long long>(kvol) * c_src * c_grad;
-  if (t >= per_chunk) return;
-  const int cc = static_cast<int>(t % c_grad), cr = static_cast<int>((t / c_grad) % c_src), k = static_cast<int>(t / (static_cast<long long>(c_grad) * c_src));
-  if (k == skip_k) return;
+// Sums the per-chunk tiles in a fixed order.  A workgroup covers 16 consecutive elements x 16 chunk groups (64-byte
+// coalesced reads, chunks/16 independent loads per thread), then folds the 16 partial sums through LDS.
+__global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ partial, int chunks, int k_base, int k_count, int c_src,
+                                                    int c_grad, float* __restrict__ dw, long long dw_kstride, int dw_ld, int skip_k) {
+  __shared__ float part[16][17];
+  const int e = threadIdx.x & 15, cg = threadIdx.x >> 4;
+  const long long per_chunk = static_cast<long long>(k_count) * c_src * c_grad;
+  const long long t = static_cast<long long>(blockIdx.x) * 16 + e;
   float s = 0.f;
-  for (int c = 0; c < chunks; ++c) s += partial[c * per_chunk + t];
-  dw[k * dw_kstride + static_cast<long long>(cr) * dw_ld + cc] = s;
+  if (t < per_chunk)
+    for (int c = cg; c < chunks; c += 16) s += partial[c * per_chunk + t];
+  part[cg][e] = s;
+  __syncthreads();
+  if (cg == 0 && t < per_chunk) {
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tot += part[q][e];
+    const int cc = static_cast<int>(t % c_grad), cr = static_cast<int>((t / c_grad) % c_src);
+    const int k = k_base + static_cast<int>(t / (static_cast<long long>(c_grad) * c_src));
+    if (k != skip_k) dw[k * dw_kstride + static_cast<long long>(cr) * dw_ld + cc] = tot;
+  }
 }
 
 // ---- dispatch -----------------------------------------------------------------------------------
@@ -561,7 +631,8 @@ static void launch_vec(const ConvArgs& a, hipStream_t s) {
   const unsigned blocks = static_cast<unsigned>(ceil_div(a.n_dst, 64));
   if constexpr (CINP * NB <= 256) {
     if (impl != 1 && a.kvol > 1) {  // FV2P_CONV_IMPL=dense keeps the unpipelined tile (parity tests run both)
-      hipLaunchKernelGGL((conv_rows_pipe<CINP, NB, WT>), dim3(blocks), dim3(256), 2 * CINP * NB * 16 * sizeof(float), s, a);
+      constexpr int KU = 2;
+      hipLaunchKernelGGL((conv_rows_pipe<CINP, NB, WT, KU>), dim3(blocks), dim3(256), 2 * KU * CINP * NB * 16 * sizeof(float), s, a);
       return;
     }
   }
@@ -645,25 +716,35 @@ extern "C" int fv2p_sparse_conv_rows(const float* src, int64_t n_src, int c_src,
 }
 
 static int wgrad_rows_per_chunk(int64_t n_dst) {
-  static int forced = -1;  // FV2P_WGRAD_RPC: tuning override (multiple of 256)
+  static int forced = -1;  // FV2P_WGRAD_RPC: tuning override (multiple of 64)
   if (forced < 0) { const char* e = getenv("FV2P_WGRAD_RPC"); forced = e ? atoi(e) : 0; }
-  if (forced >= 256 && forced <= kWgradMaxChunk) return forced;
-  return n_dst > 200000 ? 1024 : (n_dst > 60000 ? 512 : 256);
+  if (forced >= 64 && forced <= kWgradMaxChunk) return forced;
+  return n_dst > 200000 ? 1024 : 512;
 }
+static const int kDenseRpc = 256;  // rows per wave for an identity (every row valid) offset
 
 extern "C" size_t fv2p_sparse_conv_wgrad_ws_bytes(int64_t n_dst, int c_src, int c_dst, int kvol) {
-  const int64_t chunks = ceil_div(n_dst > 0 ? n_dst : 1, wgrad_rows_per_chunk(n_dst));
-  const int cd = c_dst < 128 ? c_dst : 128;
+  const int64_t n = n_dst > 0 ? n_dst : 1;
+  const int cd = c_dst < 128 ? c_dst : 128, cs = c_src < 128 ? c_src : 128;
   Sizer s;
-  s.take<float>(static_cast<size_t>(chunks) * kvol * c_src * cd);
+  s.take<float>(static_cast<size_t>(ceil_div(n, wgrad_rows_per_chunk(n_dst))) * kvol * cs * cd);
+  s.take<float>(static_cast<size_t>(ceil_div(n, kDenseRpc)) * cs * cd);
   return s.bytes();
 }
 
+template <int MB, int NB>
+static void wgrad_launch(const WgradArgs& a, float* partial, unsigned chunks, hipStream_t stream) {
+  const dim3 grid(chunks, static_cast<unsigned>(a.k_count), 1), block(256);
+  constexpr int stage = (MB * NB >= 64) ? 32 : 64;
+  const size_t lds = static_cast<size_t>(stage) * (MB * 16 + 4 + NB * 16 + 4) * sizeof(float) + 2 * a.rows_per_chunk * sizeof(int);
+  hipLaunchKernelGGL((conv_wgrad<MB, NB>), grid, block, lds, stream, a, partial);
+}
+
 extern "C" int fv2p_sparse_conv_wgrad(const float* src, int64_t n_src, int c_src, const float* grad, const int* tab, int64_t n_dst,
-                                      int c_dst, int kvol, int flip_k, int skip_k, float* dweight, void* ws, size_t ws_bytes,
+                                      int c_dst, int kvol, int flip_k, int dense_k, float* dweight, void* ws, size_t ws_bytes,
                                       fv2p_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  FV2P_REQUIRE(c_src >= 1 && c_dst >= 1 && kvol >= 1 && n_dst >= 0, FV2P_EINVAL, "sparse_conv_wgrad: bad sizes");
+  FV2P_REQUIRE(c_src >= 1 && c_dst >= 1 && kvol >= 1 && n_dst >= 0 && dense_k < kvol, FV2P_EINVAL, "sparse_conv_wgrad: bad sizes");
   FV2P_REQUIRE(dweight, FV2P_EINVAL, "sparse_conv_wgrad: null dweight");
   if (n_dst == 0 || n_src == 0) {
     FV2P_HIP(hipMemsetAsync(dweight, 0, sizeof(float) * (size_t)kvol * c_src * c_dst, stream));
@@ -672,35 +753,47 @@ extern "C" int fv2p_sparse_conv_wgrad(const float* src, int64_t n_src, int c_src
   FV2P_REQUIRE(src && grad && tab, FV2P_EINVAL, "sparse_conv_wgrad: null pointer");
   FV2P_REQUIRE(ws && ws_bytes >= fv2p_sparse_conv_wgrad_ws_bytes(n_dst, c_src, c_dst, kvol), FV2P_EWORKSPACE,
                "sparse_conv_wgrad: workspace too small");
-  const int rows_per_chunk = wgrad_rows_per_chunk(n_dst);
-  const unsigned chunks = static_cast<unsigned>(ceil_div(n_dst, rows_per_chunk));
-  float* partial = static_cast<float*>(ws);
+  const int rpc = wgrad_rows_per_chunk(n_dst);
+  const unsigned chunks = static_cast<unsigned>(ceil_div(n_dst, rpc));
+  const unsigned dchunks = static_cast<unsigned>(ceil_div(n_dst, kDenseRpc));
   for (int d0 = 0; d0 < c_dst; d0 += 128) {
     const int cd = (c_dst - d0) < 128 ? (c_dst - d0) : 128;
+   for (int s0 = 0; s0 < c_src; s0 += 128) {
+    const int cs = (c_src - s0) < 128 ? (c_src - s0) : 128;
+    Carver c(ws, ws_bytes);
+    float* partial = c.take<float>(static_cast<size_t>(chunks) * kvol * cs * cd);
+    float* dpartial = c.take<float>(static_cast<size_t>(dchunks) * cs * cd);
     WgradArgs a;
-    a.src = src; a.ld_src = c_src; a.c_src = c_src;
+    a.src = src + s0; a.ld_src = c_src; a.c_src = cs;
     a.grad = grad + d0; a.ld_grad = c_dst; a.c_grad = cd;
     a.tab = tab; a.n_dst = static_cast<int>(n_dst); a.kvol = kvol; a.flip = flip_k;
-    a.dw = dweight + d0; a.dw_kstride = static_cast<long long>(c_src) * c_dst; a.dw_ld = c_dst;
-    a.rows_per_chunk = rows_per_chunk;
-    a.skip_k = skip_k;
-    const int mb = static_cast<int>(ceil_div(c_src, 16));
+    a.dw = dweight + static_cast<long long>(s0) * c_dst + d0; a.dw_kstride = static_cast<long long>(c_src) * c_dst; a.dw_ld = c_dst;
+    const int mb = static_cast<int>(ceil_div(cs, 16));
     const int nb = static_cast<int>(ceil_div(cd, 16));
     const int nbp = nb <= 1 ? 1 : nb <= 2 ? 2 : nb <= 4 ? 4 : 8;
-    // accumulators per wave: MBW*NB <= 16
-    const int mbw = nbp == 8 ? 2 : (mb >= 4 ? 4 : mb >= 2 ? 2 : 1);
-    const unsigned gz = static_cast<unsigned>(ceil_div(mb, mbw));
-    const dim3 grid(chunks, static_cast<unsigned>(ceil_div(kvol, 4)), gz), block(256);
-    const size_t lds = static_cast<size_t>(8) * rows_per_chunk * sizeof(int);
-#define FV2P_WG(MBW, NB) hipLaunchKernelGGL((conv_wgrad<MBW, NB>), grid, block, lds, stream, a, partial)
-    if (nbp == 8) { FV2P_WG(2, 8); }
-    else if (nbp == 4) { if (mbw == 4) FV2P_WG(4, 4); else if (mbw == 2) FV2P_WG(2, 4); else FV2P_WG(1, 4); }
-    else if (nbp == 2) { if (mbw == 4) FV2P_WG(4, 2); else if (mbw == 2) FV2P_WG(2, 2); else FV2P_WG(1, 2); }
-    else { if (mbw == 4) FV2P_WG(4, 1); else if (mbw == 2) FV2P_WG(2, 1); else FV2P_WG(1, 1); }
+    const int mbp = mb <= 1 ? 1 : mb <= 2 ? 2 : mb <= 4 ? 4 : 8;
+    FV2P_REQUIRE(mb <= 8, FV2P_ELIMIT, "sparse_conv_wgrad: more than 128 source channels per launch (split on the host)");
+    // pass 0: every offset except the dense one, rpc rows per workgroup; pass 1: the dense (identity) offset, whose pair
+    // count equals the row count, in shorter chunks so that it is not the straggler of the launch
+    for (int pass = 0; pass < (dense_k >= 0 ? 2 : 1); ++pass) {
+      a.k_base = pass ? dense_k : 0;
+      a.k_count = pass ? 1 : kvol;
+      a.skip_k = pass ? -1 : dense_k;
+      a.rows_per_chunk = pass ? kDenseRpc : rpc;
+      float* pp = pass ? dpartial : partial;
+      const unsigned nch = pass ? dchunks : chunks;
+#define FV2P_WG(MB, NB) wgrad_launch<MB, NB>(a, pp, nch, stream)
+#define FV2P_WG_NB(MB)                                                                   \
+      switch (nbp) { case 1: FV2P_WG(MB, 1); break; case 2: FV2P_WG(MB, 2); break;      \
+                     case 4: FV2P_WG(MB, 4); break; default: FV2P_WG(MB, 8); break; }
+      switch (mbp) { case 1: FV2P_WG_NB(1) break; case 2: FV2P_WG_NB(2) break; case 4: FV2P_WG_NB(4) break; default: FV2P_WG_NB(8) break; }
+#undef FV2P_WG_NB
 #undef FV2P_WG
-    const long long per_chunk = static_cast<long long>(kvol) * c_src * cd;
-    hipLaunchKernelGGL(wgrad_reduce, dim3(static_cast<unsigned>(ceil_div(per_chunk, 256))), dim3(256), 0, stream, partial, (int)chunks, kvol,
-                       c_src, cd, a.dw, a.dw_kstride, a.dw_ld, skip_k);
+      const long long per_chunk = static_cast<long long>(a.k_count) * cs * cd;
+      hipLaunchKernelGGL(wgrad_reduce, dim3(static_cast<unsigned>(ceil_div(per_chunk, 16))), dim3(256), 0, stream, pp, (int)nch, a.k_base,
+                         a.k_count, cs, cd, a.dw, a.dw_kstride, a.dw_ld, a.skip_k);
+    }
+   }
   }
   FV2P_LAUNCH_CHECK();
   return 0;

@@ -236,13 +236,11 @@ def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_nu
     with _nat.device_guard(feats.device):
         wsb = _nat.lib().fv2p_sparse_conv_wgrad_ws_bytes(g.shape[0], cin, cout, kvol)
         ws = _nat.workspace(wsb, feats.device)
-        # submanifold conv: the centre offset is the identity pairing (spconv_ops.h:398-402 treats it un-gathered too),
-        # i.e. a plain dense [Cin, N] x [N, Cout] product — left to the library GEMM; the kernel skips that offset.
+        # submanifold conv: the centre offset pairs every row with itself (spconv_ops.h:398-402 treats it un-gathered too);
+        # the kernel gives that dense offset its own finely chunked pass
         centre = (kvol // 2) if (rb.subm and rb.tab_out is None and not inverse) else -1
         _nat.call("fv2p_sparse_conv_wgrad", feats, feats.shape[0], cin, g, tab_f, g.shape[0], cout, kvol, int(flip_f), centre, dw, ws,
                   ws.numel(), _nat.stream())
-        if centre >= 0:
-            torch.mm(feats.t(), g, out=dw[centre])
     dw = dw.reshape(filters.shape)
     if half:
         din, dw = din.half(), dw.half()

@@ -118,11 +118,11 @@ int fv2p_sparse_conv_rows(const float* src, int64_t n_src, int c_src, const floa
 /* dW_k[c_src][c_dst] = sum_r src[tab[k][r],:]^T grad[r,:]   (dweight [K][c_src][c_dst], fully written here).
  *   forward conv's dW : src=features, grad=dOut [n_out,Cout], tab=tab_out, n_dst=n_out.
  * Per-chunk partial tiles go through the workspace and are summed in a fixed order (deterministic, no atomics).
- * skip_k >= 0 leaves dweight[skip_k] untouched: for a submanifold conv the centre offset pairs every row with itself,
- * so its slice is the plain dense product src^T . grad, which the caller computes with a library GEMM. */
+ * dense_k >= 0 names an offset known to pair (almost) every row — the centre of a submanifold conv — which is then split
+ * into many short row chunks of its own so that it does not become the straggler of the launch (-1: none). */
 size_t fv2p_sparse_conv_wgrad_ws_bytes(int64_t n_dst, int c_src, int c_dst, int kvol);
 int fv2p_sparse_conv_wgrad(const float* src, int64_t n_src, int c_src, const float* grad, const int* tab,
-                           int64_t n_dst, int c_dst, int kvol, int flip_k, int skip_k, float* dweight, void* ws,
+                           int64_t n_dst, int c_dst, int kvol, int flip_k, int dense_k, float* dweight, void* ws,
                            size_t ws_bytes, fv2p_stream_t stream);
 
 /* ---- A7: sparse max-pool / neighbour group over the same tables ------------------------------
