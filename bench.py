@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=4, help="clouds per GPU per step")
     ap.add_argument("--points", type=int, default=16384)
     ap.add_argument("--backbone", choices=["8x", "res8x"], default="8x")
-    ap.add_argument("--cpu-clouds", type=int, default=8, help="clouds in the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--cpu-clouds", type=int, default=64, help="clouds in the cpu_baseline sample, ~0.2 s each, capped at 25 s (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--pyprofile", action="store_true", help="cProfile the timed steps (host-overhead hunting; prints to stderr)")
     return ap.parse_args()

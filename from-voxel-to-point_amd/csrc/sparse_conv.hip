@@ -31,6 +31,7 @@ struct ConvArgs {
   const float* bias;
   float* dst; int ld_dst; int c_dst;                 // c_dst: valid destination channels in this launch
   int accumulate;                                    // dst += result (used when the host splits c_src)
+  int dbg;
 };
 
 // ---- B staging --------------------------------------------------------------------------------
@@ -277,13 +278,13 @@ __global__ __launch_bounds__(256) void conv_rows_pipe(ConvArgs a) {
       const int kn = k0 + KU + u;
       idx_nn[u] = tab_at(kn + KU);
       if (kn < a.kvol) {
-        ws[u].load(a, a.w + static_cast<long long>(kn) * a.w_kstride);
-        gather(idx_nxt[u], a_nxt[u]);
+        if (!(a.dbg & 1)) ws[u].load(a, a.w + static_cast<long long>(kn) * a.w_kstride);
+        if (!(a.dbg & 2)) gather(idx_nxt[u], a_nxt[u]);
       }
     }
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
-      if (k0 + u < a.kvol && __ballot(idx_cur[u] >= 0) != 0ull) {
+      if (k0 + u < a.kvol && __ballot(idx_cur[u] >= 0) != 0ull && !(a.dbg & 4)) {
         const float* wk = wcur + u * WSZ;
 #pragma unroll
         for (int j = 0; j < J; ++j) {
@@ -303,8 +304,8 @@ __global__ __launch_bounds__(256) void conv_rows_pipe(ConvArgs a) {
     }
 #pragma unroll
     for (int u = 0; u < KU; ++u)
-      if (k0 + KU + u < a.kvol) ws[u].store(wnxt + u * WSZ);
-    __syncthreads();
+      if (k0 + KU + u < a.kvol && !(a.dbg & 1)) ws[u].store(wnxt + u * WSZ);
+    if (!(a.dbg & 8)) __syncthreads();
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
 #pragma unroll
@@ -314,6 +315,189 @@ __global__ __launch_bounds__(256) void conv_rows_pipe(ConvArgs a) {
     }
   }
   conv_epilogue<NB>(a, acc, row0);
+}
+
+// ---- LDS-DMA variant (the default for full 16-channel multiples) --------------------------------------
+// W_k goes global -> LDS with `global_load_lds_dwordx4` (no staging VGPRs, no ds_write pass): the LDS image of one
+// wave-instruction is lane-linear, so the fragment order is produced on the SOURCE side — every lane fetches the 16
+// contiguous bytes of W that its own later `ds_read_b128` expects:
+//   forward  (W_k[c][col], contiguous in col): lane (g, n), K-step (j, t), column block cb reads
+//            W_k[16j+4g+t][64cb+4n .. +3]; the four components feed four MFMAs whose accumulators are the output
+//            columns 64cb+4n+{0,1,2,3}  (needs c_dst % 64 == 0);
+//   backward (B[c][col] = W_k[col][c], contiguous in c): lane (g, n), block (j, nb) reads W_k[NB*n+nb][16j+4g .. +3];
+//            the components are the four K-steps of one MFMA column, accumulator nb is output column NB*n+nb.
+// Either way a lane ends up owning runs of 4 adjacent output columns, so the epilogue writes float4s (256 B per row
+// per 16 lanes).  Tiles are handed to workgroups XCD-major (blockIdx % 8 = XCD): each XCD's L2 sees one contiguous
+// slab of destination rows and therefore one spatial slab of gathered source rows.
+#define FV2P_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define FV2P_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// One LDS-DMA piece: 64 lanes x 16 B, lane l lands at lds_dst + 16*l.  Issued as asm so that hipcc does not drain
+// vmcnt before the MFMA phase's ds_reads of the OTHER buffer (with the builtin it waits vmcnt(0) at the next LDS
+// read); the kernel waits vmcnt(0) itself right before the barrier that publishes the buffer.  hipcc's own vmcnt
+// bookkeeping for ordinary loads stays safe: unknown extra loads only make its counted waits conservative.
+__device__ __forceinline__ void glds16(const float* gsrc, float* lds_dst) {
+  const unsigned dst = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<uintptr_t>(lds_dst)));
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+
+__device__ __forceinline__ int xcd_major_tile(int b, int nblk) {
+  const int x = b & 7, slot = b >> 3;
+  return x * (nblk >> 3) + min(x, nblk & 7) + slot;
+}
+
+// Loads whose completion the kernel tracks itself (hipcc keeps no vmcnt score for asm): they are issued before the
+// MFMA phase and awaited by wait_loads() right before the barrier, so nothing in the MFMA phase stalls on them.
+template <int OFF>
+__device__ __forceinline__ void load16_at(f32x4& d, const float* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(d) : "v"(p), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void load4_async(int& d, const int* p) {
+  asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p) : "memory");
+}
+// s_waitcnt vmcnt(0) that every asynchronously loaded register passes through ("+v"): uses are ordered after it
+template <int J>
+__device__ __forceinline__ void wait_loads(f32x4 (&v)[J], int& idx) {
+  if constexpr (J == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(idx) : : "memory");
+  else if constexpr (J == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(idx) : : "memory");
+  else if constexpr (J == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(idx) : : "memory");
+  else {
+    static_assert(J == 8, "J in {1,2,4,8}");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(idx) : : "memory");
+  }
+}
+template <int J, int JJ = 0>
+__device__ __forceinline__ void gather_async(f32x4 (&v)[J], const float* p) {
+  if constexpr (JJ < J) {
+    load16_at<64 * JJ>(v[JJ], p);
+    gather_async<J, JJ + 1>(v, p);
+  }
+}
+
+__device__ __attribute__((aligned(256))) float g_zero_row[256];  // stands in for "no neighbour": A fragment = 0
+
+template <int CINP, int NB, bool WT>
+__global__ __launch_bounds__(256) void conv_rows_dma(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // 2 x W_k
+  constexpr int J = CINP / 16;
+  constexpr int WSZ = CINP * NB * 16;
+  constexpr int UNITS = WSZ / 4;
+  constexpr int R = (UNITS + 255) / 256;
+  constexpr int NCB = NB / 4;  // forward only
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 15, g = lane >> 4;
+  const int row0 = xcd_major_tile(blockIdx.x, gridDim.x) * 64 + wave * 16;
+  // rows past the end compute on the last row's neighbours and are never stored (no masks in the loop)
+  const int my_row = min(row0 + r, a.n_dst - 1);
+  f32x4 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // per-lane source offset (floats, relative to W_k) of every unit this lane fetches
+  long long woff[R];
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    const int rest = u * 4 + wave;
+    if constexpr (!WT) {
+      const int cb = rest % NCB, jt = rest / NCB;
+      woff[u] = static_cast<long long>(16 * (jt >> 2) + 4 * g + (jt & 3)) * a.w_ld + 64 * cb + 4 * r;
+    } else {
+      const int nb = rest % NB, j = rest / NB;
+      woff[u] = static_cast<long long>(NB * r + nb) * a.w_ld + 16 * j + 4 * g;
+    }
+  }
+  auto issue_w = [&](int k, float* buf) {
+    const float* wk = a.w + static_cast<long long>(k) * a.w_kstride;
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      const int e0 = (u * 4 + wave) * 64;
+      if (UNITS % 256 == 0 || e0 < UNITS) glds16(wk + woff[u], buf + e0 * 4);
+    }
+  };
+  const int* tab_me = a.tab + my_row;
+  auto tab_ptr = [&](int k) -> const int* {
+    const int kk = min(k, a.kvol - 1);  // past-the-end offsets re-read the last one; the value is never used
+    return tab_me + static_cast<long long>(a.flip ? (a.kvol - 1 - kk) : kk) * a.n_dst;
+  };
+  auto row_ptr = [&](int idx) -> const float* {
+    return idx >= 0 ? a.src + static_cast<long long>(idx) * a.ld_src + 4 * g : g_zero_row + 4 * g;
+  };
+  f32x4 a_cur[J], a_nxt[J];
+  int idx_cur = *tab_ptr(0), idx_nxt = *tab_ptr(1), idx_nn;
+  issue_w(0, lds);
+  gather_async<J>(a_cur, row_ptr(idx_cur));
+  wait_loads<J>(a_cur, idx_nxt);
+  __syncthreads();
+  for (int k = 0; k < a.kvol; ++k) {
+    const float* wcur = lds + (k & 1) * WSZ;
+    if (k + 1 < a.kvol) issue_w(k + 1, lds + ((k + 1) & 1) * WSZ);
+    gather_async<J>(a_nxt, row_ptr(idx_nxt));
+    load4_async(idx_nn, tab_ptr(k + 2));
+    if (__ballot(idx_cur >= 0) != 0ull) {
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        if constexpr (!WT) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            float4 bv[NCB > 0 ? NCB : 1];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) bv[cb] = *reinterpret_cast<const float4*>(&wcur[(((j * 4 + t) * NCB + cb) * 64 + lane) * 4]);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+              acc[cb * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j][t], bv[cb].x, acc[cb * 4 + 0], 0, 0, 0);
+              acc[cb * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j][t], bv[cb].y, acc[cb * 4 + 1], 0, 0, 0);
+              acc[cb * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j][t], bv[cb].z, acc[cb * 4 + 2], 0, 0, 0);
+              acc[cb * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j][t], bv[cb].w, acc[cb * 4 + 3], 0, 0, 0);
+            }
+          }
+        } else {
+          float4 bv[NB];
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) bv[nb] = *reinterpret_cast<const float4*>(&wcur[((j * NB + nb) * 64 + lane) * 4]);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j][0], bv[nb].x, acc[nb], 0, 0, 0);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j][1], bv[nb].y, acc[nb], 0, 0, 0);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j][2], bv[nb].z, acc[nb], 0, 0, 0);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j][3], bv[nb].w, acc[nb], 0, 0, 0);
+        }
+      }
+    }
+    wait_loads<J>(a_nxt, idx_nn);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < J; ++j) a_cur[j] = a_nxt[j];
+    idx_cur = idx_nxt;
+    idx_nxt = idx_nn;
+  }
+  // epilogue: accumulator i of lane (q, n) is output column  WT ? NB*n + i : 64*(i/4) + 4*n + i%4
+  const int q = lane >> 4, n = lane & 15;
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int row = row0 + q * 4 + reg;
+    if (row >= a.n_dst) continue;
+    float* prow = a.dst + static_cast<long long>(row) * a.ld_dst;
+    if constexpr (NB % 4 == 0) {
+#pragma unroll
+      for (int v = 0; v < NB / 4; ++v) {
+        const int col = WT ? (NB * n + 4 * v) : (64 * v + 4 * n);
+        float4 o = make_float4(acc[4 * v][reg], acc[4 * v + 1][reg], acc[4 * v + 2][reg], acc[4 * v + 3][reg]);
+        if (a.bias) { const float4 b = *reinterpret_cast<const float4*>(a.bias + col); o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w; }
+        float4* p = reinterpret_cast<float4*>(prow + col);
+        if (a.accumulate) { const float4 old = *p; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+        *p = o;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int col = NB * n + i;  // WT only (forward requires NB % 4 == 0)
+        const float v = acc[i][reg] + (a.bias ? a.bias[col] : 0.f);
+        prow[col] = a.accumulate ? (prow[col] + v) : v;
+      }
+    }
+  }
 }
 
 // Compacted variant: the workgroup owns TM destination rows whose accumulators live in LDS.  For every kernel
@@ -608,13 +792,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ pa
 }
 
 // ---- dispatch -----------------------------------------------------------------------------------
-static int conv_impl() {  // FV2P_CONV_IMPL=dense|cmp overrides the heuristic (used by the parity tests)
-  static int impl = -1;
-  if (impl < 0) {
+// kernel variant: 0 = heuristic (LDS-DMA tile when the shapes allow, else the register-staged pipeline), 1 = plain
+// dense tile, 2 = compacted tile, 3 = register-staged pipeline.  FV2P_CONV_IMPL=dense|cmp|pipe presets it;
+// fv2p_sparse_conv_set_impl() lets the parity tests run every variant in one process.
+static int g_conv_impl = -1;
+static int conv_impl() {
+  if (g_conv_impl < 0) {
     const char* e = getenv("FV2P_CONV_IMPL");
-    impl = (e && e[0] == 'd') ? 1 : (e && e[0] == 'c') ? 2 : 0;
+    g_conv_impl = (e && e[0] == 'd') ? 1 : (e && e[0] == 'c') ? 2 : (e && e[0] == 'p') ? 3 : 0;
   }
-  return impl;
+  return g_conv_impl;
 }
 
 template <int CINP, int NB, bool WT>
@@ -629,10 +816,23 @@ static void launch_vec(const ConvArgs& a, hipStream_t s) {
     return;
   }
   const unsigned blocks = static_cast<unsigned>(ceil_div(a.n_dst, 64));
+  if constexpr (CINP * NB <= 512 && (WT || NB % 4 == 0)) {
+    // LDS-DMA kernel: whole fragments only (every lane's 16-byte source must exist and be aligned)
+    const bool whole = a.c_src == CINP && a.c_dst == NB * 16 && (a.w_ld & 3) == 0 && (a.w_kstride & 3) == 0 &&
+                       (reinterpret_cast<uintptr_t>(a.w) & 15) == 0 && (a.ld_dst & 3) == 0 &&
+                       (reinterpret_cast<uintptr_t>(a.dst) & 15) == 0 && (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0);
+    if (impl == 0 && whole && a.kvol > 1) {
+      hipLaunchKernelGGL((conv_rows_dma<CINP, NB, WT>), dim3(blocks), dim3(256), 2 * CINP * NB * 16 * sizeof(float), s, a);
+      return;
+    }
+  }
   if constexpr (CINP * NB <= 256) {
-    if (impl != 1 && a.kvol > 1) {  // FV2P_CONV_IMPL=dense keeps the unpipelined tile (parity tests run both)
-      constexpr int KU = 2;
-      hipLaunchKernelGGL((conv_rows_pipe<CINP, NB, WT, KU>), dim3(blocks), dim3(256), 2 * KU * CINP * NB * 16 * sizeof(float), s, a);
+    if (impl != 1 && a.kvol > 1) {  // FV2P_CONV_IMPL=dense keeps the unpipelined tile, =pipe the register-staged pipeline (parity tests run all)
+      static int ku = -1, dbg = 0;
+      if (ku < 0) { const char* e = getenv("FV2P_CONV_KU"); ku = e ? atoi(e) : 1; e = getenv("FV2P_CONV_DBG"); dbg = e ? atoi(e) : 0; }
+      ConvArgs b = a; b.dbg = dbg;
+      if (ku == 2) hipLaunchKernelGGL((conv_rows_pipe<CINP, NB, WT, 2>), dim3(blocks), dim3(256), 2 * 2 * CINP * NB * 16 * sizeof(float), s, b);
+      else hipLaunchKernelGGL((conv_rows_pipe<CINP, NB, WT, 1>), dim3(blocks), dim3(256), 2 * 1 * CINP * NB * 16 * sizeof(float), s, b);
       return;
     }
   }
@@ -684,6 +884,12 @@ static int dispatch_conv(const ConvArgs& a, hipStream_t s) {
 }  // namespace fv2p
 
 using namespace fv2p;
+
+extern "C" int fv2p_sparse_conv_set_impl(int impl) {
+  FV2P_REQUIRE(impl >= 0 && impl <= 3, FV2P_EINVAL, "impl must be 0 (auto), 1 (dense), 2 (compacted) or 3 (pipelined)");
+  fv2p::g_conv_impl = impl;
+  return 0;
+}
 
 extern "C" int fv2p_sparse_conv_rows(const float* src, int64_t n_src, int c_src, const float* weight, int kvol, const int* tab,
                                      int64_t n_dst, int c_dst, int flip_k, int transpose_w, const float* bias, float* dst,

@@ -112,6 +112,11 @@ int fv2p_pairs_to_tables(const int* pairs, const int* indice_num, int kvol, int6
  * flip_k!=0 reads table row K-1-k for offset k (subm symmetry, lets subm reuse tab_in as tab_out).
  * fp32 in / fp32 accumulate on v_mfma_f32_16x16x4_f32; deterministic (fixed k order, no atomics).
  */
+/* Test / tuning hook: force one kernel variant of fv2p_sparse_conv_rows for the calls that follow
+ * (0 = heuristic, 1 = plain dense tile, 2 = compacted tile, 3 = register-staged pipeline).  All variants compute
+ * the same sum in the same k order. */
+int fv2p_sparse_conv_set_impl(int impl);
+
 int fv2p_sparse_conv_rows(const float* src, int64_t n_src, int c_src, const float* weight, int kvol,
                           const int* tab, int64_t n_dst, int c_dst, int flip_k, int transpose_w,
                           const float* bias, float* dst, fv2p_stream_t stream);

@@ -52,6 +52,31 @@ def test_subm_conv_forward_backward_vs_oracle(gpu, cin, cout):
     assert rel_err(x.features.grad.cpu().numpy(), din.numpy()) < RTOL
     assert rel_err(conv.weight.grad.cpu().numpy(), dw.numpy()) < RTOL
 
+@pytest.mark.parametrize("impl", [1, 2, 3])
+def test_conv_kernel_variants_agree_with_oracle(gpu, impl):
+    """Every kernel variant behind fv2p_sparse_conv_rows (plain dense tile / compacted / register-staged pipeline;
+    the default heuristic = LDS-DMA tile is what all other tests run) gives the oracle's features and input gradient,
+    with a bias, with n_dst not a multiple of the 64-row tile and with a strided (non-symmetric) rulebook."""
+    import fv2p_native
+    try:
+        fv2p_native.call("fv2p_sparse_conv_set_impl", impl)
+        for cin, cout in [(16, 16), (32, 64), (64, 64), (64, 128), (128, 64), (24, 40)]:
+            batch, shape = 2, [9, 20, 18]
+            ind, feats, x = make_input(cin * 7 + cout, batch, shape, 1100, cin, gpu)
+            conv = spconv.SparseConv3d(cin, cout, 3, stride=2, padding=1, bias=True).to(gpu)
+            x.features.requires_grad_(True)
+            y = conv(x)
+            w, b = conv.weight.detach().cpu().numpy(), conv.bias.detach().cpu().numpy()
+            outids, pairs, num = oracle.indice_pairs(ind, batch, shape, [3, 3, 3], [2, 2, 2], [1, 1, 1], [1, 1, 1])
+            ref = oracle.indice_conv(feats, w, pairs, num, outids.shape[0]).numpy() + b
+            assert rel_err(y.features.detach().cpu().numpy(), ref) < RTOL, (impl, cin, cout)
+            g = np.random.default_rng(3).standard_normal(ref.shape).astype(np.float32)
+            y.features.backward(torch.from_numpy(g).to(gpu))
+            din, _ = oracle.indice_conv_backward(feats, w, g, pairs, num)
+            assert rel_err(x.features.grad.cpu().numpy(), din.numpy()) < RTOL, (impl, cin, cout)
+    finally:
+        fv2p_native.call("fv2p_sparse_conv_set_impl", 0)
+
 
 @pytest.mark.parametrize("k,s,p", [([3, 3, 3], [2, 2, 2], [1, 1, 1]), ([3, 3, 3], [2, 2, 2], [0, 1, 1]), ([3, 1, 1], [2, 1, 1], [0, 0, 0]),
                                    ([2, 2, 2], [2, 2, 2], [0, 0, 0]), ([3, 3, 3], [1, 1, 1], [1, 1, 1])])

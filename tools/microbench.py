@@ -25,7 +25,7 @@ def timeit(fn, reps=30, warm=5):
     return e0.elapsed_time(e1) / reps * 1e3  # us
 
 
-def conv():
+def conv(only=None):
     from fv2p_harness import synth
     from fv2p_harness.backbone import VoxelBackBone8x, mean_vfe
     from pcdet.datasets.processor.voxel_generator import points_to_voxel_gpu
@@ -50,6 +50,13 @@ def conv():
         model(torch.cat(feats), torch.cat(coords), 4)
     for h in hs:
         h.remove()
+    if only is not None:  # just the roofline kernel (bench.py's probe): forward conv of the layer with most flops
+        mod, f, rb, n_out = max(recs, key=lambda r: int(r[2].indice_pair_num.sum().item()) * r[0].in_channels * r[0].out_channels)
+        w = mod.weight.detach()
+        t = timeit(lambda: ops.indice_conv(f, w, rb, None, n_out, False, mod.subm), reps=only, warm=3)
+        print(f"roofline kernel: {'subm' if mod.subm else 'conv'} {mod.in_channels}->{mod.out_channels} key={mod.indice_key} "
+              f"n={f.shape[0]} pairs={int(rb.indice_pair_num.sum().item())}: {t:.1f} us")
+        return
     print(f"{'layer':34s} {'n_in':>6s} {'n_out':>6s} {'pairs':>8s} {'fwd us':>8s} {'TF/s':>6s} {'dX us':>8s} {'dW us':>8s} {'TF/s':>6s}")
     for mod, f, rb, n_out in recs:
         w = mod.weight.detach()
@@ -121,6 +128,9 @@ def nms():
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which == "convone":
+        conv(only=20)
+        sys.exit(0)
     for name, fn in (("conv", conv), ("dcn", dcn), ("fps", fps), ("nms", nms)):
         if which in (name, "all"):
             print(f"==== {name}")
