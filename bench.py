@@ -132,15 +132,26 @@ def roofline_probe(model, voxelize, pool, args, device):
     dur_s = e0.elapsed_time(e1) / reps / 1e3
     cin, cout, kvol = mod.in_channels, mod.out_channels, rb.kvol
     flops = rec["flops"]
-    bytes_alg = 4.0 * (rec["n_in"] * cin + rec["n_out"] * cout) + 8.0 * rec["pairs"] + 4.0 * kvol * cin * cout
+    bytes_alg = 4.0 * (rec["n_in"] * cin + rec["n_out"] * cout) + 4.0 * kvol * rec["n_out"] + 4.0 * kvol * cin * cout  # features in/out + neighbour table + W
     t_mfma, t_hbm = flops / (PEAK_MFMA_F32_TFLOPS * 1e12), bytes_alg / (PEAK_HBM_GBS * 1e9)
     if t_mfma >= t_hbm:
         ach, peak, unit, bound = flops / dur_s / 1e12, PEAK_MFMA_F32_TFLOPS, "TFLOP/s", "mfma"
     else:
         ach, peak, unit, bound = bytes_alg / dur_s / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
-    return {"bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "traffic": None,
-            "kernel": "conv_rows_vec (fv2p_sparse_conv_rows)",
-            "layer": f"{'subm' if mod.subm else 'conv'} {cin}->{cout} key={mod.indice_key} n_in={rec['n_in']} n_out={rec['n_out']} pairs={rec['pairs']}",
+    # HBM traffic per launch cannot be read from inside the process: it comes from the separate rocprofv3 --pmc passes
+    # (tools/pmc_roofline.sh) whose summary is committed under profiles/; reported only for the very layer they measured.
+    traffic = None
+    layer = f"{'subm' if mod.subm else 'conv'} {cin}->{cout} key={mod.indice_key} n_in={rec['n_in']} n_out={rec['n_out']} pairs={rec['pairs']}"
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_roofline.json")) as f:
+            pmc = json.load(f)
+        if pmc["layer"] == layer:
+            traffic = pmc["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return {"bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "traffic": traffic,
+            "kernel": "conv_rows_dma<64,4,false> (fv2p_sparse_conv_rows)",
+            "layer": layer,
             "avg_kernel_us": round(dur_s * 1e6, 2), "alg_flops": flops, "alg_bytes": bytes_alg}
 
 

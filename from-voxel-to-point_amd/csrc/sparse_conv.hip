@@ -31,7 +31,7 @@ struct ConvArgs {
   const float* bias;
   float* dst; int ld_dst; int c_dst;                 // c_dst: valid destination channels in this launch
   int accumulate;                                    // dst += result (used when the host splits c_src)
-  int dbg;
+  unsigned long long* trace;                         // optional per-workgroup placement/timing trace (test hook)
 };
 
 // ---- B staging --------------------------------------------------------------------------------
@@ -278,13 +278,13 @@ __global__ __launch_bounds__(256) void conv_rows_pipe(ConvArgs a) {
       const int kn = k0 + KU + u;
       idx_nn[u] = tab_at(kn + KU);
       if (kn < a.kvol) {
-        if (!(a.dbg & 1)) ws[u].load(a, a.w + static_cast<long long>(kn) * a.w_kstride);
-        if (!(a.dbg & 2)) gather(idx_nxt[u], a_nxt[u]);
+        ws[u].load(a, a.w + static_cast<long long>(kn) * a.w_kstride);
+        gather(idx_nxt[u], a_nxt[u]);
       }
     }
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
-      if (k0 + u < a.kvol && __ballot(idx_cur[u] >= 0) != 0ull && !(a.dbg & 4)) {
+      if (k0 + u < a.kvol && __ballot(idx_cur[u] >= 0) != 0ull) {
         const float* wk = wcur + u * WSZ;
 #pragma unroll
         for (int j = 0; j < J; ++j) {
@@ -304,8 +304,8 @@ __global__ __launch_bounds__(256) void conv_rows_pipe(ConvArgs a) {
     }
 #pragma unroll
     for (int u = 0; u < KU; ++u)
-      if (k0 + KU + u < a.kvol && !(a.dbg & 1)) ws[u].store(wnxt + u * WSZ);
-    if (!(a.dbg & 8)) __syncthreads();
+      if (k0 + KU + u < a.kvol) ws[u].store(wnxt + u * WSZ);
+    __syncthreads();
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
 #pragma unroll
@@ -388,6 +388,8 @@ __global__ __launch_bounds__(256) void conv_rows_dma(ConvArgs a) {
   constexpr int NCB = NB / 4;  // forward only
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 15, g = lane >> 4;
   const int row0 = xcd_major_tile(blockIdx.x, gridDim.x) * 64 + wave * 16;
+  unsigned long long t_begin = 0;
+  if (a.trace) t_begin = __builtin_readcyclecounter();
   // rows past the end compute on the last row's neighbours and are never stored (no masks in the loop)
   const int my_row = min(row0 + r, a.n_dst - 1);
   f32x4 acc[NB];
@@ -471,6 +473,15 @@ __global__ __launch_bounds__(256) void conv_rows_dma(ConvArgs a) {
     for (int j = 0; j < J; ++j) a_cur[j] = a_nxt[j];
     idx_cur = idx_nxt;
     idx_nxt = idx_nn;
+  }
+  if (a.trace && threadIdx.x == 0) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    a.trace[blockIdx.x * 4 + 0] = hw;
+    a.trace[blockIdx.x * 4 + 1] = xcc;
+    a.trace[blockIdx.x * 4 + 2] = t_begin;
+    a.trace[blockIdx.x * 4 + 3] = __builtin_readcyclecounter();
   }
   // epilogue: accumulator i of lane (q, n) is output column  WT ? NB*n + i : 64*(i/4) + 4*n + i%4
   const int q = lane >> 4, n = lane & 15;
@@ -796,6 +807,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ pa
 // dense tile, 2 = compacted tile, 3 = register-staged pipeline.  FV2P_CONV_IMPL=dense|cmp|pipe presets it;
 // fv2p_sparse_conv_set_impl() lets the parity tests run every variant in one process.
 static int g_conv_impl = -1;
+static unsigned long long* g_conv_trace = nullptr;
 static int conv_impl() {
   if (g_conv_impl < 0) {
     const char* e = getenv("FV2P_CONV_IMPL");
@@ -822,17 +834,15 @@ static void launch_vec(const ConvArgs& a, hipStream_t s) {
                        (reinterpret_cast<uintptr_t>(a.w) & 15) == 0 && (a.ld_dst & 3) == 0 &&
                        (reinterpret_cast<uintptr_t>(a.dst) & 15) == 0 && (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0);
     if (impl == 0 && whole && a.kvol > 1) {
-      hipLaunchKernelGGL((conv_rows_dma<CINP, NB, WT>), dim3(blocks), dim3(256), 2 * CINP * NB * 16 * sizeof(float), s, a);
+      ConvArgs b = a; b.trace = g_conv_trace;
+      hipLaunchKernelGGL((conv_rows_dma<CINP, NB, WT>), dim3(blocks), dim3(256), 2 * CINP * NB * 16 * sizeof(float), s, b);
       return;
     }
   }
   if constexpr (CINP * NB <= 256) {
     if (impl != 1 && a.kvol > 1) {  // FV2P_CONV_IMPL=dense keeps the unpipelined tile, =pipe the register-staged pipeline (parity tests run all)
-      static int ku = -1, dbg = 0;
-      if (ku < 0) { const char* e = getenv("FV2P_CONV_KU"); ku = e ? atoi(e) : 1; e = getenv("FV2P_CONV_DBG"); dbg = e ? atoi(e) : 0; }
-      ConvArgs b = a; b.dbg = dbg;
-      if (ku == 2) hipLaunchKernelGGL((conv_rows_pipe<CINP, NB, WT, 2>), dim3(blocks), dim3(256), 2 * 2 * CINP * NB * 16 * sizeof(float), s, b);
-      else hipLaunchKernelGGL((conv_rows_pipe<CINP, NB, WT, 1>), dim3(blocks), dim3(256), 2 * 1 * CINP * NB * 16 * sizeof(float), s, b);
+      // KU = 2 (two offsets per barrier) measured slower than KU = 1 on MI355X (93.9 vs 89.6 us, 64->64 N=29k)
+      hipLaunchKernelGGL((conv_rows_pipe<CINP, NB, WT, 1>), dim3(blocks), dim3(256), 2 * CINP * NB * 16 * sizeof(float), s, a);
       return;
     }
   }
@@ -885,6 +895,11 @@ static int dispatch_conv(const ConvArgs& a, hipStream_t s) {
 
 using namespace fv2p;
 
+extern "C" int fv2p_sparse_conv_set_trace(unsigned long long* trace) {
+  fv2p::g_conv_trace = trace;
+  return 0;
+}
+
 extern "C" int fv2p_sparse_conv_set_impl(int impl) {
   FV2P_REQUIRE(impl >= 0 && impl <= 3, FV2P_EINVAL, "impl must be 0 (auto), 1 (dense), 2 (compacted) or 3 (pipelined)");
   fv2p::g_conv_impl = impl;
@@ -907,6 +922,7 @@ extern "C" int fv2p_sparse_conv_rows(const float* src, int64_t n_src, int c_src,
     for (int s0 = 0; s0 < c_src; s0 += 128) {
       const int cs = (c_src - s0) < 128 ? (c_src - s0) : 128;
       ConvArgs a;
+      a.trace = nullptr;
       a.src = src + s0; a.ld_src = c_src; a.c_src = cs;
       a.w = transpose_w ? weight + static_cast<long long>(d0) * w_cols + s0 : weight + static_cast<long long>(s0) * w_cols + d0;
       a.w_kstride = static_cast<long long>(w_rows) * w_cols; a.w_ld = w_cols;

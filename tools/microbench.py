@@ -56,6 +56,42 @@ def conv(only=None):
         t = timeit(lambda: ops.indice_conv(f, w, rb, None, n_out, False, mod.subm), reps=only, warm=3)
         print(f"roofline kernel: {'subm' if mod.subm else 'conv'} {mod.in_channels}->{mod.out_channels} key={mod.indice_key} "
               f"n={f.shape[0]} pairs={int(rb.indice_pair_num.sum().item())}: {t:.1f} us")
+        if os.environ.get("FV2P_TRACE"):
+            import collections
+            import fv2p_native
+            nblk = (n_out + 63) // 64
+            tr = torch.zeros(nblk * 4, dtype=torch.int64, device="cuda")
+            fv2p_native.call("fv2p_sparse_conv_set_trace", tr)
+            ops.indice_conv(f, w, rb, None, n_out, False, mod.subm)
+            torch.cuda.synchronize()
+            fv2p_native.call("fv2p_sparse_conv_set_trace", None)
+            tr = tr.cpu().numpy().reshape(nblk, 4)
+            hw, xcc, t0, t1 = tr[:, 0], tr[:, 1] & 0xF, tr[:, 2], tr[:, 3]
+            cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
+            place = collections.Counter(zip(xcc.tolist(), se.tolist(), sh.tolist(), cu.tolist()))
+            print("distinct CUs used:", len(place), "blocks/CU histogram:", sorted(collections.Counter(place.values()).items()))
+            dur = (t1 - t0).astype(float)
+            # per-block activity from the rulebook: U = offsets with any active row in the 64-row tile, A = per-wave max
+            tab = (rb.tab_in if getattr(rb, "tab_out", None) is None else rb.tab_out).cpu().numpy() >= 0   # [K, n]
+            K = tab.shape[0]
+            padn = nblk * 64 - tab.shape[1]
+            act = np.concatenate([tab, np.zeros((K, padn), bool)], 1).reshape(K, nblk, 4, 16).any(3)      # [K, tile, wave]
+            U_t = act.any(2).sum(0); A_t = act.sum(0).max(1)
+            b = np.arange(nblk); x = b & 7; tile = x * (nblk >> 3) + np.minimum(x, nblk & 7) + (b >> 3)
+            U, A = U_t[tile], A_t[tile]
+            keys = list(zip(xcc.tolist(), se.tolist(), sh.tolist(), cu.tolist()))
+            share = np.array([place[k] for k in keys])
+            for sh_n in (1, 2):
+                m = share == sh_n
+                if m.any():
+                    Xm = np.stack([U[m], np.ones(m.sum())], 1)
+                    coef = np.linalg.lstsq(Xm, dur[m], rcond=None)[0]
+                    print(f"blocks/CU={sh_n}: n={m.sum()} mean dur {dur[m].mean():.0f} mean U {U[m].mean():.1f} mean maxA {A[m].mean():.1f}; fit dur = {coef[0]:.0f}*U + {coef[1]:.0f}")
+            order = np.argsort(dur)
+            for i in list(order[:3]) + list(order[-3:]):
+                print(f"  block {i} share={share[i]} U={U[i]} maxA={A[i]} dur={dur[i]:.0f} start={t0[i]-t0.min()}")
+            print(f"block duration (shader clocks): min {dur.min():.0f} median {np.median(dur):.0f} max {dur.max():.0f}; "
+                  f"span first start -> last end {t1.max() - t0.min()} clocks; starts spread {t0.max() - t0.min()}")
         return
     print(f"{'layer':34s} {'n_in':>6s} {'n_out':>6s} {'pairs':>8s} {'fwd us':>8s} {'TF/s':>6s} {'dX us':>8s} {'dW us':>8s} {'TF/s':>6s}")
     for mod, f, rb, n_out in recs:

@@ -9,9 +9,10 @@ python3 - <<'PY'
 import csv, glob
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob(f"gpurun_out/pmc_{c}/*counter_collection.csv"):
-        rows = [r for r in csv.DictReader(open(f)) if "conv_rows" in r["Kernel_Name"] and r["Counter_Name"] == c]
+        rows = [r for r in csv.DictReader(open(f)) if "conv_rows_dma" in r["Kernel_Name"] and r["Counter_Name"] == c]
         big = max(int(r["Grid_Size"]) for r in rows) if rows else 0
-        vals = [float(r["Counter_Value"]) for r in rows if int(r["Grid_Size"]) == big]
+        rows = [r for r in rows if int(r["Grid_Size"]) == big]
+        vals = [float(r["Counter_Value"]) for r in rows]
         if vals:
-            print(c, "kernel", rows[0]["Kernel_Name"][:60], "dispatches", len(vals), "avg counter", sum(vals) / len(vals))
+            print(c, "kernel", rows[0]["Kernel_Name"][:60], "dispatches", len(vals), "avg counter (KiB)", sum(vals) / len(vals))
 PY
