@@ -1,0 +1,298 @@
+// BatchNorm1d (+ ReLU) over sparse-tensor features [N, C] — SURVEY §8(f).3.
+//
+// Every conv of the reference's sparse backbones is followed by BatchNorm1d(eps=1e-3, momentum=0.01) + ReLU
+// (pcdet/models/backbones_3d/spconv_backbone.py:8-27 post_act_block, :75 conv_input).  On [N, C] with C = 16..128
+// torch's channels-last BN kernels run 25-30 us per call at N ~ 5e4 (profiles/r01_bench_kernel_stats.csv), i.e.
+// ~0.25 TB/s; here the layer is two launches forward and two backward, each a plain coalesced float4 stream:
+//   forward : bn_reduce_k<FWD>  per-channel sum / sum of squares in fp64, last workgroup folds the partials in a fixed
+//                               order (deterministic), writes mean / invstd and updates the running statistics;
+//             bn_apply_fwd_k    y = relu((x - mean) * invstd * gamma + beta)
+//   backward: bn_reduce_k<BWD>  dz = dy * [y > 0];  sum dz, sum dz * xhat  ->  dbeta, dgamma, c1, c2
+//             bn_apply_bwd_k    dx = gamma * invstd * (dz - c1 - xhat * c2)
+// The ReLU mask is recomputed from x, so y is not needed by the backward pass.
+#include "common.hpp"
+
+namespace fv2p {
+
+struct BnGeom {
+  long long n;
+  int c, tcols, rpp, nblk;
+  long long rows_per_block;
+};
+
+struct BnFwdFin {   // outputs of the forward finalisation
+  float* mean; float* invstd;
+  float* running_mean; float* running_var; long long* num_batches_tracked;
+  float momentum;   // < 0: cumulative moving average (momentum=None)
+  float eps;
+};
+struct BnBwdFin {
+  float* dgamma; float* dbeta; float* coef;  // coef[0][c] = mean(dz), coef[1][c] = mean(dz * xhat) (0 when running stats were used)
+  int batch_stats;
+};
+
+template <int V>
+struct Vec;
+template <>
+struct Vec<4> {
+  float v[4];
+  __device__ __forceinline__ void load(const float* p, int, int) { const float4 q = *reinterpret_cast<const float4*>(p); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+  __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <>
+struct Vec<1> {
+  float v[1];
+  __device__ __forceinline__ void load(const float* p, int, int) { v[0] = *p; }
+  __device__ __forceinline__ void store(float* p) const { *p = v[0]; }
+};
+
+// Block-level reduction of per-thread (a, b) channel sums + "last workgroup finalises".
+// partial: [nblk][2][c] doubles.  sync: one zero-initialised counter, left at zero.
+template <int V, bool BWD>
+__global__ __launch_bounds__(256) void bn_reduce_k(const float* __restrict__ x, const float* __restrict__ dy, BnGeom g,
+                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
+                                                   double* __restrict__ partial, unsigned* __restrict__ sync, BnFwdFin ff, BnBwdFin bf) {
+  __shared__ double red[2][256 * V];
+  __shared__ int is_last;
+  const int tid = threadIdx.x;
+  const int rl = tid / g.tcols, cq = tid % g.tcols;
+  const int col = cq * V;
+  const bool live = rl < g.rpp && col < g.c;
+  double s1[V], s2[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) s1[i] = s2[i] = 0.0;
+  if (live) {
+    float m[V], is[V], ga[V], be[V];
+    if (BWD) {
+#pragma unroll
+      for (int i = 0; i < V; ++i) { m[i] = mean[col + i]; is[i] = invstd[col + i]; ga[i] = gamma ? gamma[col + i] : 1.f; be[i] = beta ? beta[col + i] : 0.f; }
+    }
+    const long long r0 = static_cast<long long>(blockIdx.x) * g.rows_per_block;
+    const long long r1 = min(r0 + g.rows_per_block, g.n);
+    for (long long r = r0 + rl; r < r1; r += g.rpp) {
+      Vec<V> xv;
+      xv.load(x + r * g.c + col, 0, 0);
+      if (!BWD) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) { const double d = xv.v[i]; s1[i] += d; s2[i] += d * d; }
+      } else {
+        Vec<V> gv;
+        gv.load(dy + r * g.c + col, 0, 0);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          const float xhat = (xv.v[i] - m[i]) * is[i];
+          const float y = xhat * ga[i] + be[i];
+          const float dz = (relu && !(y > 0.f)) ? 0.f : gv.v[i];
+          s1[i] += dz; s2[i] += static_cast<double>(dz) * xhat;
+        }
+      }
+    }
+  }
+  // fold the row lanes: red[.][rl * c + col]
+  if (rl < g.rpp) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) { red[0][(rl * g.tcols + cq) * V + i] = s1[i]; red[1][(rl * g.tcols + cq) * V + i] = s2[i]; }
+  }
+  __syncthreads();
+  const int cpad = g.tcols * V;
+  for (int e = tid; e < cpad; e += 256) {
+    double a = 0.0, b = 0.0;
+    for (int q = 0; q < g.rpp; ++q) { a += red[0][q * cpad + e]; b += red[1][q * cpad + e]; }
+    if (e < g.c) {
+      partial[(static_cast<long long>(blockIdx.x) * 2 + 0) * g.c + e] = a;
+      partial[(static_cast<long long>(blockIdx.x) * 2 + 1) * g.c + e] = b;
+    }
+  }
+  // release the partials, count this workgroup in, the last one acquires and finalises
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned prev = __hip_atomic_fetch_add(sync, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = prev == static_cast<unsigned>(g.nblk - 1);
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  // fold the workgroup partials: L = 256 / c lanes per channel take interleaved slices, then a fixed-order LDS fold
+  const int cfold = g.c < 256 ? g.c : 256;
+  const int L = 256 / cfold;
+  for (int e0 = 0; e0 < g.c; e0 += cfold) {
+    const int e = e0 + tid % cfold, lane_q = tid / cfold;
+    double a = 0.0, b = 0.0;
+    if (lane_q < L && e < g.c) {
+      for (int q = lane_q; q < g.nblk; q += L) {
+        a += partial[(static_cast<long long>(q) * 2 + 0) * g.c + e];
+        b += partial[(static_cast<long long>(q) * 2 + 1) * g.c + e];
+      }
+    }
+    __syncthreads();
+    red[0][tid] = a; red[1][tid] = b;
+    __syncthreads();
+    if (tid >= cfold || e >= g.c) continue;
+    a = 0.0; b = 0.0;
+    for (int q = 0; q < L; ++q) { a += red[0][q * cfold + tid]; b += red[1][q * cfold + tid]; }
+    const double n = static_cast<double>(g.n);
+    if (!BWD) {
+      const double mu = a / n;
+      double var = b / n - mu * mu;
+      if (var < 0.0) var = 0.0;
+      ff.mean[e] = static_cast<float>(mu);
+      ff.invstd[e] = static_cast<float>(1.0 / sqrt(var + static_cast<double>(ff.eps)));
+      if (ff.running_mean) {
+        double f = ff.momentum;
+        if (ff.momentum < 0.f) f = 1.0 / static_cast<double>(ff.num_batches_tracked ? (*ff.num_batches_tracked + 1) : 1);
+        const double unbiased = g.n > 1 ? var * n / (n - 1.0) : var;
+        ff.running_mean[e] = static_cast<float>((1.0 - f) * ff.running_mean[e] + f * mu);
+        ff.running_var[e] = static_cast<float>((1.0 - f) * ff.running_var[e] + f * unbiased);
+      }
+    } else {
+      bf.dbeta[e] = static_cast<float>(a);
+      bf.dgamma[e] = static_cast<float>(b);
+      bf.coef[e] = bf.batch_stats ? static_cast<float>(a / n) : 0.f;
+      bf.coef[g.c + e] = bf.batch_stats ? static_cast<float>(b / n) : 0.f;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    if (!BWD && ff.running_mean && ff.num_batches_tracked) *ff.num_batches_tracked += 1;
+    __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void bn_apply_fwd_k(const float* __restrict__ x, long long units, int c, const float* __restrict__ mean,
+                                                      const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, int relu, float* __restrict__ y) {
+  const int cv = c / V;
+  for (long long u = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; u < units; u += static_cast<long long>(gridDim.x) * 256) {
+    const int col = static_cast<int>(u % cv) * V;
+    Vec<V> xv, o;
+    xv.load(x + u * V, 0, 0);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const float xhat = (xv.v[i] - mean[col + i]) * invstd[col + i];
+      const float t = xhat * (gamma ? gamma[col + i] : 1.f) + (beta ? beta[col + i] : 0.f);
+      o.v[i] = (relu && t <= 0.f) ? 0.f : t;  // NaN passes through, like torch.relu
+    }
+    o.store(y + u * V);
+  }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void bn_apply_bwd_k(const float* __restrict__ x, const float* __restrict__ dy, long long units, int c,
+                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
+                                                      const float* __restrict__ coef, float* __restrict__ dx) {
+  const int cv = c / V;
+  for (long long u = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; u < units; u += static_cast<long long>(gridDim.x) * 256) {
+    const int col = static_cast<int>(u % cv) * V;
+    Vec<V> xv, gv, o;
+    xv.load(x + u * V, 0, 0);
+    gv.load(dy + u * V, 0, 0);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const float is = invstd[col + i], ga = gamma ? gamma[col + i] : 1.f;
+      const float xhat = (xv.v[i] - mean[col + i]) * is;
+      const float t = xhat * ga + (beta ? beta[col + i] : 0.f);
+      const float dz = (relu && !(t > 0.f)) ? 0.f : gv.v[i];
+      o.v[i] = ga * is * (dz - coef[col + i] - xhat * coef[c + col + i]);
+    }
+    o.store(dx + u * V);
+  }
+}
+
+static int bn_geom(int64_t n, int c, bool vec, BnGeom* g) {
+  const int v = vec ? 4 : 1;
+  g->n = n; g->c = c;
+  g->tcols = static_cast<int>(ceil_div(c, v));
+  if (g->tcols > 256) return -1;
+  g->rpp = 256 / g->tcols;
+  // ~8 rows per row lane per workgroup, at most 1024 workgroups
+  int64_t nblk = ceil_div(n, static_cast<int64_t>(g->rpp) * 8);
+  if (nblk > 256) nblk = 256;
+  if (nblk < 1) nblk = 1;
+  g->rows_per_block = ceil_div(n, nblk);
+  g->nblk = static_cast<int>(ceil_div(n, g->rows_per_block));
+  return 0;
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace fv2p
+
+using namespace fv2p;
+
+extern "C" size_t fv2p_batchnorm_ws_bytes(int64_t n, int c) {
+  (void)n;
+  Sizer s;
+  s.take<double>(static_cast<size_t>(1024) * 2 * (c > 0 ? c : 1));
+  s.take<float>(2 * static_cast<size_t>(c > 0 ? c : 1));
+  return s.bytes();
+}
+
+extern "C" int fv2p_batchnorm_stats(const float* x, int64_t n, int c, float eps, float momentum, float* mean, float* invstd,
+                                    float* running_mean, float* running_var, int64_t* num_batches_tracked, void* ws, size_t ws_bytes,
+                                    unsigned* sync, fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FV2P_REQUIRE(n >= 1 && c >= 1, FV2P_EINVAL, "batchnorm_stats: n=%lld c=%d", static_cast<long long>(n), c);
+  FV2P_REQUIRE(x && mean && invstd && ws && sync, FV2P_EINVAL, "batchnorm_stats: null pointer");
+  FV2P_REQUIRE((running_mean == nullptr) == (running_var == nullptr), FV2P_EINVAL, "batchnorm_stats: running_mean and running_var come together");
+  FV2P_REQUIRE(ws_bytes >= fv2p_batchnorm_ws_bytes(n, c), FV2P_EWORKSPACE, "batchnorm_stats: workspace %lld < %lld", static_cast<long long>(ws_bytes),
+               static_cast<long long>(fv2p_batchnorm_ws_bytes(n, c)));
+  const bool vec = (c % 4 == 0) && aligned16(x);
+  BnGeom g;
+  FV2P_REQUIRE(bn_geom(n, c, vec, &g) == 0, FV2P_ELIMIT, "batchnorm: c=%d exceeds %d", c, vec ? 1024 : 256);
+  Carver cv(ws, static_cast<size_t>(ws_bytes));
+  double* partial = cv.take<double>(static_cast<size_t>(1024) * 2 * c);
+  BnFwdFin ff{mean, invstd, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), momentum, eps};
+  BnBwdFin bf{nullptr, nullptr, nullptr, 0};
+  if (vec) hipLaunchKernelGGL((bn_reduce_k<4, false>), dim3(g.nblk), dim3(256), 0, stream, x, nullptr, g, nullptr, nullptr, nullptr, nullptr, 0, partial, sync, ff, bf);
+  else hipLaunchKernelGGL((bn_reduce_k<1, false>), dim3(g.nblk), dim3(256), 0, stream, x, nullptr, g, nullptr, nullptr, nullptr, nullptr, 0, partial, sync, ff, bf);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fv2p_batchnorm_apply(const float* x, int64_t n, int c, const float* mean, const float* invstd, const float* gamma,
+                                    const float* beta, int relu, float* y, fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FV2P_REQUIRE(n >= 0 && c >= 1, FV2P_EINVAL, "batchnorm_apply: n=%lld c=%d", static_cast<long long>(n), c);
+  if (n == 0) return 0;
+  FV2P_REQUIRE(x && y && mean && invstd, FV2P_EINVAL, "batchnorm_apply: null pointer");
+  const bool vec = (c % 4 == 0) && aligned16(x) && aligned16(y);
+  const long long units = n * c / (vec ? 4 : 1);
+  const unsigned blocks = static_cast<unsigned>(ceil_div(units, 256 * 4) > 8192 ? 8192 : ceil_div(units, 256 * 4));
+  if (vec) hipLaunchKernelGGL((bn_apply_fwd_k<4>), dim3(blocks ? blocks : 1), dim3(256), 0, stream, x, units, c, mean, invstd, gamma, beta, relu, y);
+  else hipLaunchKernelGGL((bn_apply_fwd_k<1>), dim3(blocks ? blocks : 1), dim3(256), 0, stream, x, units, c, mean, invstd, gamma, beta, relu, y);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fv2p_batchnorm_backward(const float* x, const float* dy, int64_t n, int c, const float* mean, const float* invstd,
+                                       const float* gamma, const float* beta, int relu, int batch_stats, float* dx, float* dgamma,
+                                       float* dbeta, void* ws, size_t ws_bytes, unsigned* sync, fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FV2P_REQUIRE(n >= 1 && c >= 1, FV2P_EINVAL, "batchnorm_backward: n=%lld c=%d", static_cast<long long>(n), c);
+  FV2P_REQUIRE(x && dy && mean && invstd && dx && dgamma && dbeta && ws && sync, FV2P_EINVAL, "batchnorm_backward: null pointer");
+  FV2P_REQUIRE(ws_bytes >= fv2p_batchnorm_ws_bytes(n, c), FV2P_EWORKSPACE, "batchnorm_backward: workspace %lld < %lld",
+               static_cast<long long>(ws_bytes), static_cast<long long>(fv2p_batchnorm_ws_bytes(n, c)));
+  const bool vec = (c % 4 == 0) && aligned16(x) && aligned16(dy) && aligned16(dx);
+  BnGeom g;
+  FV2P_REQUIRE(bn_geom(n, c, vec, &g) == 0, FV2P_ELIMIT, "batchnorm: c=%d exceeds %d", c, vec ? 1024 : 256);
+  Carver cv(ws, static_cast<size_t>(ws_bytes));
+  double* partial = cv.take<double>(static_cast<size_t>(1024) * 2 * c);
+  float* coef = cv.take<float>(2 * static_cast<size_t>(c));
+  BnFwdFin ff{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f};
+  BnBwdFin bf{dgamma, dbeta, coef, batch_stats};
+  const long long units = n * c / (vec ? 4 : 1);
+  const unsigned blocks = static_cast<unsigned>(ceil_div(units, 256 * 4) > 8192 ? 8192 : ceil_div(units, 256 * 4));
+  if (vec) {
+    hipLaunchKernelGGL((bn_reduce_k<4, true>), dim3(g.nblk), dim3(256), 0, stream, x, dy, g, mean, invstd, gamma, beta, relu, partial, sync, ff, bf);
+    hipLaunchKernelGGL((bn_apply_bwd_k<4>), dim3(blocks ? blocks : 1), dim3(256), 0, stream, x, dy, units, c, mean, invstd, gamma, beta, relu, coef, dx);
+  } else {
+    hipLaunchKernelGGL((bn_reduce_k<1, true>), dim3(g.nblk), dim3(256), 0, stream, x, dy, g, mean, invstd, gamma, beta, relu, partial, sync, ff, bf);
+    hipLaunchKernelGGL((bn_apply_bwd_k<1>), dim3(blocks ? blocks : 1), dim3(256), 0, stream, x, dy, units, c, mean, invstd, gamma, beta, relu, coef, dx);
+  }
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}

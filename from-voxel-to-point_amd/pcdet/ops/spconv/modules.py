@@ -5,6 +5,7 @@ from collections import OrderedDict
 import torch
 from torch import nn
 
+from .norm import batch_norm_relu
 from .structure import SparseConvTensor
 
 
@@ -64,13 +65,25 @@ class SparseSequential(SparseModule):
         self.add_module(name, module)
 
     def forward(self, input):
-        for k, module in self._modules.items():
+        items = list(self._modules.items())
+        i = 0
+        while i < len(items):
+            k, module = items[i]
+            i += 1
             if is_spconv_module(module):
                 assert isinstance(input, SparseConvTensor)
                 self._sparity_dict[k] = input.sparity
                 input = module(input)
             elif isinstance(input, SparseConvTensor):
                 if input.indices.shape[0] != 0:
+                    if isinstance(module, nn.BatchNorm1d):
+                        # BatchNorm1d (+ReLU) pair of the reference's post_act_block: one fused HIP op (norm.py)
+                        nxt = items[i][1] if i < len(items) and isinstance(items[i][1], nn.ReLU) else None
+                        fused = batch_norm_relu(module, input.features, nxt)
+                        if fused is not None:
+                            input.features = fused
+                            i += nxt is not None
+                            continue
                     input.features = module(input.features)
             else:
                 input = module(input)

@@ -1,0 +1,94 @@
+"""BatchNorm1d (+ReLU) on sparse-tensor features as two HIP launches forward and two backward.
+
+The reference builds every backbone block as ``SparseSequential(conv, nn.BatchNorm1d(eps=1e-3, momentum=0.01),
+nn.ReLU())`` (pcdet/models/backbones_3d/spconv_backbone.py:8-27, :75) and ``SparseSequential.forward`` applies the two
+torch modules to ``.features`` (pcdet/ops/spconv/modules.py:86-100).  ``batch_norm_relu`` is what this package's
+``SparseSequential`` calls for that pair instead: same parameters, same running-statistics update, same result within
+fp32 rounding, kernels in csrc/batchnorm.hip.  It returns None whenever the situation is not the plain one (hooks on
+the modules, autocast, non-fp32, CPU tensors, a single row in training mode ...) and the caller then runs the torch
+modules one by one, so error behaviour stays torch's.
+"""
+import os
+
+import torch
+from torch import nn
+from torch.autograd import Function
+
+import fv2p_native as _nat
+
+_SYNC = {}
+_ENABLED = os.environ.get("FV2P_FUSED_BN", "1") != "0"
+
+
+def _sync_word(device):
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    t = _SYNC.get(key)
+    if t is None:
+        t = torch.zeros(64, dtype=torch.int32, device=device)
+        _SYNC[key] = t
+    return t
+
+
+class _BatchNormReLU(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn, relu):
+        n, c = x.shape
+        dev = x.device
+        batch_stats = bn.training or bn.running_mean is None
+        with _nat.device_guard(dev):
+            if batch_stats:
+                mean = torch.empty(c, dtype=torch.float32, device=dev)
+                invstd = torch.empty(c, dtype=torch.float32, device=dev)
+                track = bn.training and bn.running_mean is not None
+                nbytes = _nat.call("fv2p_batchnorm_ws_bytes", n, c)
+                ws = _nat.workspace(nbytes, dev)
+                _nat.call("fv2p_batchnorm_stats", x, n, c, float(bn.eps), -1.0 if bn.momentum is None else float(bn.momentum),
+                          mean, invstd, bn.running_mean if track else None, bn.running_var if track else None,
+                          bn.num_batches_tracked if track else None, ws, ws.numel(), _sync_word(dev), _nat.stream())
+            else:
+                mean = bn.running_mean
+                invstd = torch.rsqrt(bn.running_var + bn.eps)
+            y = torch.empty_like(x)
+            _nat.call("fv2p_batchnorm_apply", x, n, c, mean, invstd, weight, bias, int(relu), y, _nat.stream())
+        ctx.save_for_backward(x, mean, invstd, weight, bias)
+        ctx.relu, ctx.batch_stats = bool(relu), bool(batch_stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, invstd, weight, bias = ctx.saved_tensors
+        n, c = x.shape
+        dev = x.device
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+        with _nat.device_guard(dev):
+            nbytes = _nat.call("fv2p_batchnorm_ws_bytes", n, c)
+            ws = _nat.workspace(nbytes, dev)
+            _nat.call("fv2p_batchnorm_backward", x, dy, n, c, mean, invstd, weight, bias, int(ctx.relu), int(ctx.batch_stats),
+                      dx, dgamma, dbeta, ws, ws.numel(), _sync_word(dev), _nat.stream())
+        return (dx if ctx.needs_input_grad[0] else None, dgamma if (weight is not None and ctx.needs_input_grad[1]) else None,
+                dbeta if (bias is not None and ctx.needs_input_grad[2]) else None, None, None)
+
+
+def _plain(module):
+    return not (module._forward_hooks or module._forward_pre_hooks or module._backward_hooks)
+
+
+def batch_norm_relu(bn, x, relu_module=None):
+    """y = relu?(bn(x)) for x [N, C] fp32 on the GPU, or None when the fused path does not apply."""
+    if not _ENABLED or type(bn) is not nn.BatchNorm1d or not _plain(bn):
+        return None
+    if relu_module is not None and (type(relu_module) is not nn.ReLU or not _plain(relu_module)):
+        return None
+    if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()):
+        return None
+    if torch.is_autocast_enabled() or x.shape[1] != bn.num_features:
+        return None
+    n, c = x.shape
+    if n < 2 or c > 256 and c % 4 != 0 or c > 1024:
+        return None
+    if bn.weight is not None and (bn.weight.dtype != torch.float32 or not bn.weight.is_cuda):
+        return None
+    return _BatchNormReLU.apply(x, bn.weight, bn.bias, bn, relu_module is not None)

@@ -271,6 +271,32 @@ int fv2p_dcn_backward(const float* x_nhwc, const float* wt, const float* offset,
                       int deformable_group, float* dx_nhwc, float* doffset, float* dmask, float* dwt, void* ws,
                       size_t ws_bytes, fv2p_stream_t stream);
 
+/* ---- (f).3: BatchNorm1d (+ReLU) over sparse-tensor features [N, C] --------------------------------
+ * The pair every conv of the reference backbones is followed by: nn.BatchNorm1d(eps=1e-3, momentum=0.01) + nn.ReLU
+ * (pcdet/models/backbones_3d/spconv_backbone.py:8-27, :75), applied to SparseConvTensor.features by
+ * SparseSequential (pcdet/ops/spconv/modules.py:86-100).  torch semantics: biased batch variance for the
+ * normalisation, unbiased for running_var; running = (1 - momentum) * running + momentum * batch; momentum < 0
+ * means momentum=None (cumulative average over num_batches_tracked).  Sums are accumulated in fp64 and folded in a
+ * fixed order (deterministic).
+ *   fv2p_batchnorm_stats    : mean[c], invstd[c] of x[n,c]; updates running_mean / running_var /
+ *                             num_batches_tracked in place when running_mean != NULL.
+ *   fv2p_batchnorm_apply    : y = relu?((x - mean) * invstd * gamma + beta)   (gamma / beta may be NULL; y may alias x)
+ *   fv2p_batchnorm_backward : dz = dy * [y > 0] (mask recomputed from x); dgamma = sum dz * xhat, dbeta = sum dz,
+ *                             dx = gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat))  when batch_stats != 0,
+ *                             dx = gamma * invstd * dz                                          otherwise (eval mode).
+ * sync: one unsigned in device memory, zero before the first call; the kernels leave it zero (one per stream).
+ */
+size_t fv2p_batchnorm_ws_bytes(int64_t n, int c);
+int fv2p_batchnorm_stats(const float* x, int64_t n, int c, float eps, float momentum, float* mean, float* invstd,
+                         float* running_mean, float* running_var, int64_t* num_batches_tracked, void* ws,
+                         size_t ws_bytes, unsigned* sync, fv2p_stream_t stream);
+int fv2p_batchnorm_apply(const float* x, int64_t n, int c, const float* mean, const float* invstd,
+                         const float* gamma, const float* beta, int relu, float* y, fv2p_stream_t stream);
+int fv2p_batchnorm_backward(const float* x, const float* dy, int64_t n, int c, const float* mean,
+                            const float* invstd, const float* gamma, const float* beta, int relu, int batch_stats,
+                            float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, unsigned* sync,
+                            fv2p_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

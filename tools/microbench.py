@@ -162,12 +162,33 @@ def nms():
         print(f"nms_gpu N={n} thr={th}: {t:8.1f} us")
 
 
+def bn():
+    import copy
+    from torch import nn
+    from pcdet.ops.spconv import norm
+    dev = torch.device("cuda:0")
+    for n, c in [(45868, 16), (50783, 32), (29446, 64), (13425, 64), (11446, 128)]:
+        x = torch.randn(n, c, device=dev, requires_grad=True)
+        g = torch.randn(n, c, device=dev)
+        m = nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(dev)
+        act = nn.ReLU()
+        tf = timeit(lambda: norm.batch_norm_relu(m, x, act))
+        y = norm.batch_norm_relu(m, x, act)
+        tb = timeit(lambda: y.backward(g, retain_graph=True))
+        m2 = copy.deepcopy(m)
+        rf = timeit(lambda: act(m2(x)))
+        y2 = act(m2(x))
+        rb = timeit(lambda: y2.backward(g, retain_graph=True))
+        print(f"bn+relu n={n} c={c}: fused fwd {tf:6.1f} us bwd {tb:6.1f} us | torch fwd {rf:6.1f} us bwd {rb:6.1f} us | "
+              f"fwd {3 * 4 * n * c / tf / 1e6:5.2f} TB/s")
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which == "convone":
         conv(only=20)
         sys.exit(0)
-    for name, fn in (("conv", conv), ("dcn", dcn), ("fps", fps), ("nms", nms)):
+    for name, fn in (("conv", conv), ("dcn", dcn), ("fps", fps), ("nms", nms), ("bn", bn)):
         if which in (name, "all"):
             print(f"==== {name}")
             fn()
