@@ -3,9 +3,10 @@
 // Every conv of the reference's sparse backbones is followed by BatchNorm1d(eps=1e-3, momentum=0.01) + ReLU
 // (pcdet/models/backbones_3d/spconv_backbone.py:8-27 post_act_block, :75 conv_input).  On [N, C] with C = 16..128
 // torch's channels-last BN kernels run 25-30 us per call at N ~ 5e4 (profiles/r01_bench_kernel_stats.csv), i.e.
-// ~0.25 TB/s; here the layer is two launches forward and two backward, each a plain coalesced float4 stream:
-//   forward : bn_reduce_k<FWD>  per-channel sum / sum of squares in fp64, last workgroup folds the partials in a fixed
-//                               order (deterministic), writes mean / invstd and updates the running statistics;
+// ~0.25 TB/s; here the layer is three small launches forward and three backward, plain coalesced float4 streams:
+//   forward : bn_reduce_k<FWD>  per-channel sum / sum of squares in fp64, one partial per workgroup;
+//             bn_finalize_k     folds the partials in a fixed order (deterministic), writes mean / invstd and updates
+//                               the running statistics;
 //             bn_apply_fwd_k    y = relu((x - mean) * invstd * gamma + beta)
 //   backward: bn_reduce_k<BWD>  dz = dy * [y > 0];  sum dz, sum dz * xhat  ->  dbeta, dgamma, c1, c2
 //             bn_apply_bwd_k    dx = gamma * invstd * (dz - c1 - xhat * c2)
@@ -46,15 +47,13 @@ struct Vec<1> {
   __device__ __forceinline__ void store(float* p) const { *p = v[0]; }
 };
 
-// Block-level reduction of per-thread (a, b) channel sums + "last workgroup finalises".
-// partial: [nblk][2][c] doubles.  sync: one zero-initialised counter, left at zero.
+// Workgroup-level reduction of per-thread (a, b) channel sums.  partial: [nblk][2][c] doubles.
 template <int V, bool BWD>
 __global__ __launch_bounds__(256) void bn_reduce_k(const float* __restrict__ x, const float* __restrict__ dy, BnGeom g,
                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
-                                                   double* __restrict__ partial, unsigned* __restrict__ sync, BnFwdFin ff, BnBwdFin bf) {
+                                                   double* __restrict__ partial) {
   __shared__ double red[2][256 * V];
-  __shared__ int is_last;
   const int tid = threadIdx.x;
   const int rl = tid / g.tcols, cq = tid % g.tcols;
   const int col = cq * V;
@@ -63,22 +62,21 @@ __global__ __launch_bounds__(256) void bn_reduce_k(const float* __restrict__ x, 
 #pragma unroll
   for (int i = 0; i < V; ++i) s1[i] = s2[i] = 0.0;
   if (live) {
-    float m[V], is[V], ga[V], be[V];
+    float m[V] = {}, is[V] = {}, ga[V] = {}, be[V] = {};
     if (BWD) {
 #pragma unroll
       for (int i = 0; i < V; ++i) { m[i] = mean[col + i]; is[i] = invstd[col + i]; ga[i] = gamma ? gamma[col + i] : 1.f; be[i] = beta ? beta[col + i] : 0.f; }
     }
     const long long r0 = static_cast<long long>(blockIdx.x) * g.rows_per_block;
     const long long r1 = min(r0 + g.rows_per_block, g.n);
-    for (long long r = r0 + rl; r < r1; r += g.rpp) {
-      Vec<V> xv;
-      xv.load(x + r * g.c + col, 0, 0);
+    // U rows in flight per thread: the pass is latency bound (a few MB spread over the whole chip), so the loads of
+    // a group are all issued before the first fp64 add
+    constexpr int U = 8;
+    auto accumulate = [&](const Vec<V>& xv, const Vec<V>& gv) {
       if (!BWD) {
 #pragma unroll
         for (int i = 0; i < V; ++i) { const double d = xv.v[i]; s1[i] += d; s2[i] += d * d; }
       } else {
-        Vec<V> gv;
-        gv.load(dy + r * g.c + col, 0, 0);
 #pragma unroll
         for (int i = 0; i < V; ++i) {
           const float xhat = (xv.v[i] - m[i]) * is[i];
@@ -87,6 +85,23 @@ __global__ __launch_bounds__(256) void bn_reduce_k(const float* __restrict__ x, 
           s1[i] += dz; s2[i] += static_cast<double>(dz) * xhat;
         }
       }
+    };
+    long long r = r0 + rl;
+    for (; r + static_cast<long long>(U - 1) * g.rpp < r1; r += static_cast<long long>(U) * g.rpp) {
+      Vec<V> xv[U], gv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        xv[u].load(x + (r + static_cast<long long>(u) * g.rpp) * g.c + col, 0, 0);
+        if (BWD) gv[u].load(dy + (r + static_cast<long long>(u) * g.rpp) * g.c + col, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) accumulate(xv[u], gv[u]);
+    }
+    for (; r < r1; r += g.rpp) {
+      Vec<V> xv, gv;
+      xv.load(x + r * g.c + col, 0, 0);
+      if (BWD) gv.load(dy + r * g.c + col, 0, 0);
+      accumulate(xv, gv);
     }
   }
   // fold the row lanes: red[.][rl * c + col]
@@ -104,16 +119,14 @@ __global__ __launch_bounds__(256) void bn_reduce_k(const float* __restrict__ x, 
       partial[(static_cast<long long>(blockIdx.x) * 2 + 1) * g.c + e] = b;
     }
   }
-  // release the partials, count this workgroup in, the last one acquires and finalises
-  __threadfence();
-  __syncthreads();
-  if (tid == 0) {
-    const unsigned prev = __hip_atomic_fetch_add(sync, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = prev == static_cast<unsigned>(g.nblk - 1);
-  }
-  __syncthreads();
-  if (!is_last) return;
-  __threadfence();
+}
+
+// One workgroup folds the [nblk][2][c] partials in a fixed order (a kernel boundary instead of an agent-scope fence per
+// producer workgroup: on gfx950 that fence writes the whole L2 back, measured 20 us per reduce launch).
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_finalize_k(BnGeom g, const double* __restrict__ partial, BnFwdFin ff, BnBwdFin bf) {
+  __shared__ double red[2][256];
+  const int tid = threadIdx.x;
   // fold the workgroup partials: L = 256 / c lanes per channel take interleaved slices, then a fixed-order LDS fold
   const int cfold = g.c < 256 ? g.c : 256;
   const int L = 256 / cfold;
@@ -121,6 +134,7 @@ __global__ __launch_bounds__(256) void bn_reduce_k(const float* __restrict__ x, 
     const int e = e0 + tid % cfold, lane_q = tid / cfold;
     double a = 0.0, b = 0.0;
     if (lane_q < L && e < g.c) {
+#pragma unroll 8
       for (int q = lane_q; q < g.nblk; q += L) {
         a += partial[(static_cast<long long>(q) * 2 + 0) * g.c + e];
         b += partial[(static_cast<long long>(q) * 2 + 1) * g.c + e];
@@ -154,10 +168,7 @@ __global__ __launch_bounds__(256) void bn_reduce_k(const float* __restrict__ x, 
     }
   }
   __syncthreads();
-  if (tid == 0) {
-    if (!BWD && ff.running_mean && ff.num_batches_tracked) *ff.num_batches_tracked += 1;
-    __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  if (tid == 0 && !BWD && ff.running_mean && ff.num_batches_tracked) *ff.num_batches_tracked += 1;
 }
 
 template <int V>
@@ -210,7 +221,7 @@ static int bn_geom(int64_t n, int c, bool vec, BnGeom* g) {
   g->rpp = 256 / g->tcols;
   // ~8 rows per row lane per workgroup, at most 1024 workgroups
   int64_t nblk = ceil_div(n, static_cast<int64_t>(g->rpp) * 8);
-  if (nblk > 256) nblk = 256;
+  if (nblk > 128) nblk = 128;
   if (nblk < 1) nblk = 1;
   g->rows_per_block = ceil_div(n, nblk);
   g->nblk = static_cast<int>(ceil_div(n, g->rows_per_block));
@@ -226,17 +237,17 @@ using namespace fv2p;
 extern "C" size_t fv2p_batchnorm_ws_bytes(int64_t n, int c) {
   (void)n;
   Sizer s;
-  s.take<double>(static_cast<size_t>(1024) * 2 * (c > 0 ? c : 1));
+  s.take<double>(static_cast<size_t>(128) * 2 * (c > 0 ? c : 1));
   s.take<float>(2 * static_cast<size_t>(c > 0 ? c : 1));
   return s.bytes();
 }
 
 extern "C" int fv2p_batchnorm_stats(const float* x, int64_t n, int c, float eps, float momentum, float* mean, float* invstd,
                                     float* running_mean, float* running_var, int64_t* num_batches_tracked, void* ws, size_t ws_bytes,
-                                    unsigned* sync, fv2p_stream_t stream_) {
+                                    fv2p_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   FV2P_REQUIRE(n >= 1 && c >= 1, FV2P_EINVAL, "batchnorm_stats: n=%lld c=%d", static_cast<long long>(n), c);
-  FV2P_REQUIRE(x && mean && invstd && ws && sync, FV2P_EINVAL, "batchnorm_stats: null pointer");
+  FV2P_REQUIRE(x && mean && invstd && ws, FV2P_EINVAL, "batchnorm_stats: null pointer");
   FV2P_REQUIRE((running_mean == nullptr) == (running_var == nullptr), FV2P_EINVAL, "batchnorm_stats: running_mean and running_var come together");
   FV2P_REQUIRE(ws_bytes >= fv2p_batchnorm_ws_bytes(n, c), FV2P_EWORKSPACE, "batchnorm_stats: workspace %lld < %lld", static_cast<long long>(ws_bytes),
                static_cast<long long>(fv2p_batchnorm_ws_bytes(n, c)));
@@ -244,11 +255,12 @@ extern "C" int fv2p_batchnorm_stats(const float* x, int64_t n, int c, float eps,
   BnGeom g;
   FV2P_REQUIRE(bn_geom(n, c, vec, &g) == 0, FV2P_ELIMIT, "batchnorm: c=%d exceeds %d", c, vec ? 1024 : 256);
   Carver cv(ws, static_cast<size_t>(ws_bytes));
-  double* partial = cv.take<double>(static_cast<size_t>(1024) * 2 * c);
+  double* partial = cv.take<double>(static_cast<size_t>(128) * 2 * c);
   BnFwdFin ff{mean, invstd, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), momentum, eps};
   BnBwdFin bf{nullptr, nullptr, nullptr, 0};
-  if (vec) hipLaunchKernelGGL((bn_reduce_k<4, false>), dim3(g.nblk), dim3(256), 0, stream, x, nullptr, g, nullptr, nullptr, nullptr, nullptr, 0, partial, sync, ff, bf);
-  else hipLaunchKernelGGL((bn_reduce_k<1, false>), dim3(g.nblk), dim3(256), 0, stream, x, nullptr, g, nullptr, nullptr, nullptr, nullptr, 0, partial, sync, ff, bf);
+  if (vec) hipLaunchKernelGGL((bn_reduce_k<4, false>), dim3(g.nblk), dim3(256), 0, stream, x, nullptr, g, nullptr, nullptr, nullptr, nullptr, 0, partial);
+  else hipLaunchKernelGGL((bn_reduce_k<1, false>), dim3(g.nblk), dim3(256), 0, stream, x, nullptr, g, nullptr, nullptr, nullptr, nullptr, 0, partial);
+  hipLaunchKernelGGL((bn_finalize_k<false>), dim3(1), dim3(256), 0, stream, g, partial, ff, bf);
   FV2P_LAUNCH_CHECK();
   return 0;
 }
@@ -261,7 +273,7 @@ extern "C" int fv2p_batchnorm_apply(const float* x, int64_t n, int c, const floa
   FV2P_REQUIRE(x && y && mean && invstd, FV2P_EINVAL, "batchnorm_apply: null pointer");
   const bool vec = (c % 4 == 0) && aligned16(x) && aligned16(y);
   const long long units = n * c / (vec ? 4 : 1);
-  const unsigned blocks = static_cast<unsigned>(ceil_div(units, 256 * 4) > 8192 ? 8192 : ceil_div(units, 256 * 4));
+  const unsigned blocks = static_cast<unsigned>(ceil_div(units, 256) > 16384 ? 16384 : ceil_div(units, 256));
   if (vec) hipLaunchKernelGGL((bn_apply_fwd_k<4>), dim3(blocks ? blocks : 1), dim3(256), 0, stream, x, units, c, mean, invstd, gamma, beta, relu, y);
   else hipLaunchKernelGGL((bn_apply_fwd_k<1>), dim3(blocks ? blocks : 1), dim3(256), 0, stream, x, units, c, mean, invstd, gamma, beta, relu, y);
   FV2P_LAUNCH_CHECK();
@@ -270,27 +282,29 @@ extern "C" int fv2p_batchnorm_apply(const float* x, int64_t n, int c, const floa
 
 extern "C" int fv2p_batchnorm_backward(const float* x, const float* dy, int64_t n, int c, const float* mean, const float* invstd,
                                        const float* gamma, const float* beta, int relu, int batch_stats, float* dx, float* dgamma,
-                                       float* dbeta, void* ws, size_t ws_bytes, unsigned* sync, fv2p_stream_t stream_) {
+                                       float* dbeta, void* ws, size_t ws_bytes, fv2p_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   FV2P_REQUIRE(n >= 1 && c >= 1, FV2P_EINVAL, "batchnorm_backward: n=%lld c=%d", static_cast<long long>(n), c);
-  FV2P_REQUIRE(x && dy && mean && invstd && dx && dgamma && dbeta && ws && sync, FV2P_EINVAL, "batchnorm_backward: null pointer");
+  FV2P_REQUIRE(x && dy && mean && invstd && dx && dgamma && dbeta && ws, FV2P_EINVAL, "batchnorm_backward: null pointer");
   FV2P_REQUIRE(ws_bytes >= fv2p_batchnorm_ws_bytes(n, c), FV2P_EWORKSPACE, "batchnorm_backward: workspace %lld < %lld",
                static_cast<long long>(ws_bytes), static_cast<long long>(fv2p_batchnorm_ws_bytes(n, c)));
   const bool vec = (c % 4 == 0) && aligned16(x) && aligned16(dy) && aligned16(dx);
   BnGeom g;
   FV2P_REQUIRE(bn_geom(n, c, vec, &g) == 0, FV2P_ELIMIT, "batchnorm: c=%d exceeds %d", c, vec ? 1024 : 256);
   Carver cv(ws, static_cast<size_t>(ws_bytes));
-  double* partial = cv.take<double>(static_cast<size_t>(1024) * 2 * c);
+  double* partial = cv.take<double>(static_cast<size_t>(128) * 2 * c);
   float* coef = cv.take<float>(2 * static_cast<size_t>(c));
   BnFwdFin ff{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f};
   BnBwdFin bf{dgamma, dbeta, coef, batch_stats};
   const long long units = n * c / (vec ? 4 : 1);
-  const unsigned blocks = static_cast<unsigned>(ceil_div(units, 256 * 4) > 8192 ? 8192 : ceil_div(units, 256 * 4));
+  const unsigned blocks = static_cast<unsigned>(ceil_div(units, 256) > 16384 ? 16384 : ceil_div(units, 256));
   if (vec) {
-    hipLaunchKernelGGL((bn_reduce_k<4, true>), dim3(g.nblk), dim3(256), 0, stream, x, dy, g, mean, invstd, gamma, beta, relu, partial, sync, ff, bf);
+    hipLaunchKernelGGL((bn_reduce_k<4, true>), dim3(g.nblk), dim3(256), 0, stream, x, dy, g, mean, invstd, gamma, beta, relu, partial);
+    hipLaunchKernelGGL((bn_finalize_k<true>), dim3(1), dim3(256), 0, stream, g, partial, ff, bf);
     hipLaunchKernelGGL((bn_apply_bwd_k<4>), dim3(blocks ? blocks : 1), dim3(256), 0, stream, x, dy, units, c, mean, invstd, gamma, beta, relu, coef, dx);
   } else {
-    hipLaunchKernelGGL((bn_reduce_k<1, true>), dim3(g.nblk), dim3(256), 0, stream, x, dy, g, mean, invstd, gamma, beta, relu, partial, sync, ff, bf);
+    hipLaunchKernelGGL((bn_reduce_k<1, true>), dim3(g.nblk), dim3(256), 0, stream, x, dy, g, mean, invstd, gamma, beta, relu, partial);
+    hipLaunchKernelGGL((bn_finalize_k<true>), dim3(1), dim3(256), 0, stream, g, partial, ff, bf);
     hipLaunchKernelGGL((bn_apply_bwd_k<1>), dim3(blocks ? blocks : 1), dim3(256), 0, stream, x, dy, units, c, mean, invstd, gamma, beta, relu, coef, dx);
   }
   FV2P_LAUNCH_CHECK();

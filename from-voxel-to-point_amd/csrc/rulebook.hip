@@ -294,7 +294,10 @@ extern "C" int fv2p_rulebook_begin(const int* indices, int64_t n_in, int batch, 
   Carver c(ws, ws_bytes);
   RbWs w;
   rb_carve(c, n_in, g.emax, subm, &w);
-  FV2P_HIP(hipMemsetAsync(w.table, 0xFF, sizeof(uint64_t) * w.cap, stream));
+  FillJobs fill;
+  fill.add(w.table, sizeof(uint64_t) * w.cap, 0xFFFFFFFFu);
+  if (!subm) fill.add(w.n_uniq, sizeof(int) * 4, 0u);
+  if (int rc = multi_fill(fill, stream)) return rc;
   const int T = 256;
   const unsigned nb = static_cast<unsigned>(ceil_div(n_in, T));
   if (subm) {
@@ -304,7 +307,6 @@ extern "C" int fv2p_rulebook_begin(const int* indices, int64_t n_in, int batch, 
     return 0;
   }
   FV2P_REQUIRE(static_cast<int64_t>(n_in) * g.emax <= kMaxRows, FV2P_ELIMIT, "rulebook: too many candidate outputs");
-  FV2P_HIP(hipMemsetAsync(w.n_uniq, 0, sizeof(int) * 4, stream));
   hipLaunchKernelGGL(rb_insert_outputs, dim3(nb, g.emax), dim3(T), 0, stream, indices, (int)n_in, g, w.table, w.cap - 1, w.uniq,
                      w.n_uniq);
   FV2P_LAUNCH_CHECK();
@@ -322,8 +324,9 @@ extern "C" int fv2p_rulebook_finish(const int* indices, int64_t n_in, int batch,
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   RbGeom g;
   if (int rc = rb_geom(&g, in_shape, out_shape, ksize, stride, padding, dilation, subm, transpose)) return rc;
-  if (indice_num) FV2P_HIP(hipMemsetAsync(indice_num, 0, sizeof(int) * g.kvol, stream));
-  if (n_in == 0) return 0;
+  FillJobs fill;
+  if (indice_num) fill.add(indice_num, sizeof(int) * g.kvol, 0u);
+  if (n_in == 0) return multi_fill(fill, stream);
   FV2P_REQUIRE(tab_in, FV2P_EINVAL, "rulebook_finish: null tab_in");
   FV2P_REQUIRE(ws && ws_bytes >= fv2p_rulebook_ws_bytes(n_in, ksize, stride, dilation, subm, transpose), FV2P_EWORKSPACE,
                "rulebook: workspace too small");
@@ -332,8 +335,9 @@ extern "C" int fv2p_rulebook_finish(const int* indices, int64_t n_in, int batch,
   rb_carve(c, n_in, g.emax, subm, &w);
   const int T = 256;
   const unsigned nb = static_cast<unsigned>(ceil_div(n_in, T));
-  FV2P_HIP(hipMemsetAsync(tab_in, 0xFF, sizeof(int) * (size_t)g.kvol * n_in, stream));
-  if (tab_out && n_out > 0) FV2P_HIP(hipMemsetAsync(tab_out, 0xFF, sizeof(int) * (size_t)g.kvol * n_out, stream));
+  fill.add(tab_in, sizeof(int) * (size_t)g.kvol * n_in, 0xFFFFFFFFu);
+  if (tab_out && n_out > 0) fill.add(tab_out, sizeof(int) * (size_t)g.kvol * n_out, 0xFFFFFFFFu);
+  if (int rc = multi_fill(fill, stream)) return rc;
   if (!subm) {
     FV2P_REQUIRE(out_indices || n_out == 0, FV2P_EINVAL, "rulebook_finish: out_indices is null");
     if (n_out > 0) {

@@ -194,11 +194,12 @@ extern "C" int fv2p_points_to_voxel(const float* points, int64_t n, int ndim, co
   FV2P_REQUIRE(static_cast<int64_t>(grid[0]) * grid[1] * grid[2] <= kMaxKey, FV2P_ELIMIT,
                "points_to_voxel: grid volume exceeds 2^40");
   FV2P_REQUIRE(max_voxels <= kMaxRows, FV2P_ELIMIT, "points_to_voxel: max_voxels too large");
-  FV2P_HIP(hipMemsetAsync(voxels, 0, sizeof(float) * max_voxels * (size_t)max_points * ndim, stream));
-  FV2P_HIP(hipMemsetAsync(coors, 0, sizeof(int) * 3 * (size_t)max_voxels, stream));
-  FV2P_HIP(hipMemsetAsync(num_points_per_voxel, 0, sizeof(int) * (size_t)max_voxels, stream));
-  FV2P_HIP(hipMemsetAsync(num_voxels, 0, sizeof(int), stream));
-  if (n == 0) return 0;
+  FillJobs fill;
+  fill.add(voxels, sizeof(float) * max_voxels * (size_t)max_points * ndim, 0u);
+  fill.add(coors, sizeof(int) * 3 * (size_t)max_voxels, 0u);
+  fill.add(num_points_per_voxel, sizeof(int) * (size_t)max_voxels, 0u);
+  fill.add(num_voxels, sizeof(int), 0u);
+  if (n == 0) return multi_fill(fill, stream);
   FV2P_REQUIRE(ws && ws_bytes >= fv2p_points_to_voxel_ws_bytes(n, max_voxels), FV2P_EWORKSPACE,
                "points_to_voxel: workspace too small");
   Carver c(ws, ws_bytes);
@@ -207,9 +208,10 @@ extern "C" int fv2p_points_to_voxel(const float* points, int64_t n, int ndim, co
   VoxGeom g;
   for (int j = 0; j < 3; ++j) { g.vs[j] = voxel_size[j]; g.lo[j] = range_lo[j]; g.grid[j] = grid[j]; }
 
-  FV2P_HIP(hipMemsetAsync(w.table, 0xFF, sizeof(uint64_t) * w.cap, stream));
-  FV2P_HIP(hipMemsetAsync(w.count, 0, sizeof(int) * (max_voxels + 2), stream));
-  FV2P_HIP(hipMemsetAsync(w.scalars, 0, sizeof(int) * 8, stream));
+  fill.add(w.table, sizeof(uint64_t) * w.cap, 0xFFFFFFFFu);
+  fill.add(w.count, sizeof(int) * (max_voxels + 2), 0u);
+  fill.add(w.scalars, sizeof(int) * 8, 0u);
+  if (int rc = multi_fill(fill, stream)) return rc;
   const int T = 256;
   const dim3 gridN(static_cast<unsigned>(ceil_div(n, T)));
   hipLaunchKernelGGL(vox_insert, gridN, dim3(T), 0, stream, points, n, ndim, g, w.table, w.cap - 1, w.slot, w.scalars);

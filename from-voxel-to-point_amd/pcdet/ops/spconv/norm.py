@@ -1,4 +1,4 @@
-"""BatchNorm1d (+ReLU) on sparse-tensor features as two HIP launches forward and two backward.
+"""BatchNorm1d (+ReLU) on sparse-tensor features as three small HIP launches forward and three backward.
 
 The reference builds every backbone block as ``SparseSequential(conv, nn.BatchNorm1d(eps=1e-3, momentum=0.01),
 nn.ReLU())`` (pcdet/models/backbones_3d/spconv_backbone.py:8-27, :75) and ``SparseSequential.forward`` applies the two
@@ -16,17 +16,7 @@ from torch.autograd import Function
 
 import fv2p_native as _nat
 
-_SYNC = {}
 _ENABLED = os.environ.get("FV2P_FUSED_BN", "1") != "0"
-
-
-def _sync_word(device):
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-    t = _SYNC.get(key)
-    if t is None:
-        t = torch.zeros(64, dtype=torch.int32, device=device)
-        _SYNC[key] = t
-    return t
 
 
 class _BatchNormReLU(Function):
@@ -44,7 +34,7 @@ class _BatchNormReLU(Function):
                 ws = _nat.workspace(nbytes, dev)
                 _nat.call("fv2p_batchnorm_stats", x, n, c, float(bn.eps), -1.0 if bn.momentum is None else float(bn.momentum),
                           mean, invstd, bn.running_mean if track else None, bn.running_var if track else None,
-                          bn.num_batches_tracked if track else None, ws, ws.numel(), _sync_word(dev), _nat.stream())
+                          bn.num_batches_tracked if track else None, ws, ws.numel(), _nat.stream())
             else:
                 mean = bn.running_mean
                 invstd = torch.rsqrt(bn.running_var + bn.eps)
@@ -67,7 +57,7 @@ class _BatchNormReLU(Function):
             nbytes = _nat.call("fv2p_batchnorm_ws_bytes", n, c)
             ws = _nat.workspace(nbytes, dev)
             _nat.call("fv2p_batchnorm_backward", x, dy, n, c, mean, invstd, weight, bias, int(ctx.relu), int(ctx.batch_stats),
-                      dx, dgamma, dbeta, ws, ws.numel(), _sync_word(dev), _nat.stream())
+                      dx, dgamma, dbeta, ws, ws.numel(), _nat.stream())
         return (dx if ctx.needs_input_grad[0] else None, dgamma if (weight is not None and ctx.needs_input_grad[1]) else None,
                 dbeta if (bias is not None and ctx.needs_input_grad[2]) else None, None, None)
 

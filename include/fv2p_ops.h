@@ -284,17 +284,16 @@ int fv2p_dcn_backward(const float* x_nhwc, const float* wt, const float* offset,
  *   fv2p_batchnorm_backward : dz = dy * [y > 0] (mask recomputed from x); dgamma = sum dz * xhat, dbeta = sum dz,
  *                             dx = gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat))  when batch_stats != 0,
  *                             dx = gamma * invstd * dz                                          otherwise (eval mode).
- * sync: one unsigned in device memory, zero before the first call; the kernels leave it zero (one per stream).
  */
 size_t fv2p_batchnorm_ws_bytes(int64_t n, int c);
 int fv2p_batchnorm_stats(const float* x, int64_t n, int c, float eps, float momentum, float* mean, float* invstd,
                          float* running_mean, float* running_var, int64_t* num_batches_tracked, void* ws,
-                         size_t ws_bytes, unsigned* sync, fv2p_stream_t stream);
+                         size_t ws_bytes, fv2p_stream_t stream);
 int fv2p_batchnorm_apply(const float* x, int64_t n, int c, const float* mean, const float* invstd,
                          const float* gamma, const float* beta, int relu, float* y, fv2p_stream_t stream);
 int fv2p_batchnorm_backward(const float* x, const float* dy, int64_t n, int c, const float* mean,
                             const float* invstd, const float* gamma, const float* beta, int relu, int batch_stats,
-                            float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, unsigned* sync,
+                            float* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
                             fv2p_stream_t stream);
 
 #ifdef __cplusplus
