@@ -36,13 +36,14 @@ METRIC = "point clouds/sec fwd+bwd (FV2P, KITTI shape) at 1/2/4/8 MI355X"
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4, help="clouds per GPU per step")
     ap.add_argument("--points", type=int, default=16384)
     ap.add_argument("--backbone", choices=["8x", "res8x"], default="8x")
     ap.add_argument("--cpu-clouds", type=int, default=64, help="clouds in the cpu_baseline sample, ~0.2 s each, capped at 25 s (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--phases", action="store_true", help="diagnostic: host issue time and synchronised wall time per phase (stderr)")
     ap.add_argument("--pyprofile", action="store_true", help="cProfile the timed steps (host-overhead hunting; prints to stderr)")
     return ap.parse_args()
 
@@ -88,6 +89,26 @@ def build_step(args, device, rank, world):
         opt.step()
         return loss
 
+    def step_phases(i, acc):
+        """Same step with a device sync after every phase: (host time until the calls returned, time until the GPU drained)."""
+        def phase(name, fn):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = fn()
+            t1 = time.perf_counter()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            a = acc.setdefault(name, [0.0, 0.0])
+            a[0] += t1 - t0
+            a[1] += t2 - t0
+            return r
+        feats, coords = phase("voxelise+vfe", lambda: voxelize(pool[i % n_pool]))
+        loss = phase("forward", lambda: net(feats, coords, args.batch))
+        opt.zero_grad(set_to_none=True)
+        phase("backward", lambda: loss.backward())
+        phase("optimizer", lambda: opt.step())
+
+    step.phases = step_phases
     return model, step, voxelize, pool
 
 
@@ -211,6 +232,12 @@ def main():
         step(i)
     dist_utils.barrier()
     torch.cuda.synchronize()
+    if args.phases and rank == 0:
+        acc = {}
+        for i in range(20):
+            step.phases(args.warmup + i, acc)
+        for k, (h, w) in acc.items():
+            print(f"[phases] {k:14s} host issue {h / 20 * 1e3:7.3f} ms   synchronised wall {w / 20 * 1e3:7.3f} ms", file=sys.stderr)
     prof = None
     if args.pyprofile:
         import cProfile

@@ -3,13 +3,14 @@
 // Every conv of the reference's sparse backbones is followed by BatchNorm1d(eps=1e-3, momentum=0.01) + ReLU
 // (pcdet/models/backbones_3d/spconv_backbone.py:8-27 post_act_block, :75 conv_input).  On [N, C] with C = 16..128
 // torch's channels-last BN kernels run 25-30 us per call at N ~ 5e4 (profiles/r01_bench_kernel_stats.csv), i.e.
-// ~0.25 TB/s; here the layer is three small launches forward and three backward, plain coalesced float4 streams:
-//   forward : bn_reduce_k<FWD>  per-channel sum / sum of squares in fp64, one partial per workgroup;
-//             bn_finalize_k     folds the partials in a fixed order (deterministic), writes mean / invstd and updates
-//                               the running statistics;
-//             bn_apply_fwd_k    y = relu((x - mean) * invstd * gamma + beta)
-//   backward: bn_reduce_k<BWD>  dz = dy * [y > 0];  sum dz, sum dz * xhat  ->  dbeta, dgamma, c1, c2
-//             bn_apply_bwd_k    dx = gamma * invstd * (dz - c1 - xhat * c2)
+// ~0.25 TB/s; here the layer is two launches forward and two backward, plain coalesced float4 streams:
+//   forward : bn_reduce_k<FWD>  per-channel sum / sum of squares in fp64, one partial per workgroup (<= 64 of them);
+//             bn_apply_fwd_k    every workgroup folds the partials in the same fixed order (deterministic; the kernel
+//                               boundary replaces an agent-scope fence per producer, which on gfx950 writes the whole
+//                               L2 back: measured 20 us per launch), workgroup 0 also stores mean / invstd and updates
+//                               the running statistics; then y = relu((x - mean) * invstd * gamma + beta)
+//   backward: bn_reduce_k<BWD>  dz = dy * [y > 0];  sum dz, sum dz * xhat
+//             bn_apply_bwd_k    folds to dbeta, dgamma, c1, c2;  dx = gamma * invstd * (dz - c1 - xhat * c2)
 // The ReLU mask is recomputed from x, so y is not needed by the backward pass.
 #include "common.hpp"
 
@@ -121,69 +122,86 @@ __global__ __launch_bounds__(256) void bn_reduce_k(const float* __restrict__ x, 
   }
 }
 
-// One workgroup folds the [nblk][2][c] partials in a fixed order (a kernel boundary instead of an agent-scope fence per
-// producer workgroup: on gfx950 that fence writes the whole L2 back, measured 20 us per reduce launch).
-template <bool BWD>
-__global__ __launch_bounds__(256) void bn_finalize_k(BnGeom g, const double* __restrict__ partial, BnFwdFin ff, BnBwdFin bf) {
-  __shared__ double red[2][256];
-  const int tid = threadIdx.x;
-  // fold the workgroup partials: L = 256 / c lanes per channel take interleaved slices, then a fixed-order LDS fold
-  const int cfold = g.c < 256 ? g.c : 256;
-  const int L = 256 / cfold;
-  for (int e0 = 0; e0 < g.c; e0 += cfold) {
-    const int e = e0 + tid % cfold, lane_q = tid / cfold;
-    double a = 0.0, b = 0.0;
-    if (lane_q < L && e < g.c) {
+// Folds the [nblk][2][c] partials of channels [e0, e0 + cfold) in a fixed order: L = 256 / cfold lanes per channel take
+// interleaved slices, then an ordered LDS fold.  Returns the two sums of channel e0 + tid (valid for tid < cfold).
+__device__ __forceinline__ void fold_chunk(const BnGeom& g, const double* __restrict__ partial, int e0, int cfold, double (*red)[256],
+                                           double* a_out, double* b_out) {
+  const int tid = threadIdx.x, L = 256 / cfold;
+  const int e = e0 + tid % cfold, lane_q = tid / cfold;
+  double a = 0.0, b = 0.0;
+  if (lane_q < L && e < g.c) {
 #pragma unroll 8
-      for (int q = lane_q; q < g.nblk; q += L) {
-        a += partial[(static_cast<long long>(q) * 2 + 0) * g.c + e];
-        b += partial[(static_cast<long long>(q) * 2 + 1) * g.c + e];
-      }
-    }
-    __syncthreads();
-    red[0][tid] = a; red[1][tid] = b;
-    __syncthreads();
-    if (tid >= cfold || e >= g.c) continue;
-    a = 0.0; b = 0.0;
-    for (int q = 0; q < L; ++q) { a += red[0][q * cfold + tid]; b += red[1][q * cfold + tid]; }
-    const double n = static_cast<double>(g.n);
-    if (!BWD) {
-      const double mu = a / n;
-      double var = b / n - mu * mu;
-      if (var < 0.0) var = 0.0;
-      ff.mean[e] = static_cast<float>(mu);
-      ff.invstd[e] = static_cast<float>(1.0 / sqrt(var + static_cast<double>(ff.eps)));
-      if (ff.running_mean) {
-        double f = ff.momentum;
-        if (ff.momentum < 0.f) f = 1.0 / static_cast<double>(ff.num_batches_tracked ? (*ff.num_batches_tracked + 1) : 1);
-        const double unbiased = g.n > 1 ? var * n / (n - 1.0) : var;
-        ff.running_mean[e] = static_cast<float>((1.0 - f) * ff.running_mean[e] + f * mu);
-        ff.running_var[e] = static_cast<float>((1.0 - f) * ff.running_var[e] + f * unbiased);
-      }
-    } else {
-      bf.dbeta[e] = static_cast<float>(a);
-      bf.dgamma[e] = static_cast<float>(b);
-      bf.coef[e] = bf.batch_stats ? static_cast<float>(a / n) : 0.f;
-      bf.coef[g.c + e] = bf.batch_stats ? static_cast<float>(b / n) : 0.f;
+    for (int q = lane_q; q < g.nblk; q += L) {
+      a += partial[(static_cast<long long>(q) * 2 + 0) * g.c + e];
+      b += partial[(static_cast<long long>(q) * 2 + 1) * g.c + e];
     }
   }
   __syncthreads();
-  if (tid == 0 && !BWD && ff.running_mean && ff.num_batches_tracked) *ff.num_batches_tracked += 1;
+  red[0][tid] = a; red[1][tid] = b;
+  __syncthreads();
+  a = 0.0; b = 0.0;
+  if (tid < cfold)
+    for (int q = 0; q < L; ++q) { a += red[0][q * cfold + tid]; b += red[1][q * cfold + tid]; }
+  *a_out = a; *b_out = b;
 }
 
-template <int V>
-__global__ __launch_bounds__(256) void bn_apply_fwd_k(const float* __restrict__ x, long long units, int c, const float* __restrict__ mean,
-                                                      const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, int relu, float* __restrict__ y) {
+constexpr int kBnMaxC = 1024;
+
+// FOLD: batch statistics come from the partials (training); otherwise mean / invstd are read from memory (eval).
+template <int V, bool FOLD>
+__global__ __launch_bounds__(256) void bn_apply_fwd_k(const float* __restrict__ x, long long units, BnGeom g, const double* __restrict__ partial,
+                                                      BnFwdFin ff, const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
+                                                      float* __restrict__ y) {
+  __shared__ double red[2][256];
+  __shared__ float sh_scale[kBnMaxC], sh_shift[kBnMaxC];   // y = x * scale + shift would change rounding: keep (x-mean)*invstd*gamma+beta
+  __shared__ float sh_mean[kBnMaxC], sh_gamma[kBnMaxC];
+  const int tid = threadIdx.x, c = g.c;
+  const int cfold = c < 256 ? c : 256;
+  for (int e0 = 0; e0 < c; e0 += cfold) {
+    const int e = e0 + tid;
+    float mu_f, is_f;
+    if (FOLD) {
+      double a, b;
+      fold_chunk(g, partial, e0, cfold, red, &a, &b);
+      const double n = static_cast<double>(g.n);
+      const double mu = a / n;
+      double var = b / n - mu * mu;
+      if (var < 0.0) var = 0.0;
+      mu_f = static_cast<float>(mu);
+      is_f = static_cast<float>(1.0 / sqrt(var + static_cast<double>(ff.eps)));
+      if (blockIdx.x == 0 && tid < cfold && e < c) {
+        ff.mean[e] = mu_f;
+        ff.invstd[e] = is_f;
+        if (ff.running_mean) {
+          double f = ff.momentum;
+          if (ff.momentum < 0.f) f = 1.0 / static_cast<double>(ff.num_batches_tracked ? (*ff.num_batches_tracked + 1) : 1);
+          const double unbiased = g.n > 1 ? var * n / (n - 1.0) : var;
+          ff.running_mean[e] = static_cast<float>((1.0 - f) * ff.running_mean[e] + f * mu);
+          ff.running_var[e] = static_cast<float>((1.0 - f) * ff.running_var[e] + f * unbiased);
+        }
+      }
+    } else {
+      mu_f = (tid < cfold && e < c) ? ff.mean[e] : 0.f;
+      is_f = (tid < cfold && e < c) ? ff.invstd[e] : 0.f;
+    }
+    if (tid < cfold && e < c) {
+      sh_mean[e] = mu_f;
+      sh_scale[e] = is_f;
+      sh_gamma[e] = gamma ? gamma[e] : 1.f;
+      sh_shift[e] = beta ? beta[e] : 0.f;
+    }
+  }
+  __syncthreads();
+  if (FOLD && blockIdx.x == 0 && tid == 0 && ff.running_mean && ff.num_batches_tracked) *ff.num_batches_tracked += 1;
   const int cv = c / V;
-  for (long long u = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; u < units; u += static_cast<long long>(gridDim.x) * 256) {
+  for (long long u = static_cast<long long>(blockIdx.x) * 256 + tid; u < units; u += static_cast<long long>(gridDim.x) * 256) {
     const int col = static_cast<int>(u % cv) * V;
     Vec<V> xv, o;
     xv.load(x + u * V, 0, 0);
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-      const float xhat = (xv.v[i] - mean[col + i]) * invstd[col + i];
-      const float t = xhat * (gamma ? gamma[col + i] : 1.f) + (beta ? beta[col + i] : 0.f);
+      const float xhat = (xv.v[i] - sh_mean[col + i]) * sh_scale[col + i];
+      const float t = xhat * sh_gamma[col + i] + sh_shift[col + i];
       o.v[i] = (relu && t <= 0.f) ? 0.f : t;  // NaN passes through, like torch.relu
     }
     o.store(y + u * V);
@@ -191,37 +209,62 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_k(const float* __restrict__ 
 }
 
 template <int V>
-__global__ __launch_bounds__(256) void bn_apply_bwd_k(const float* __restrict__ x, const float* __restrict__ dy, long long units, int c,
-                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                      const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
-                                                      const float* __restrict__ coef, float* __restrict__ dx) {
+__global__ __launch_bounds__(256) void bn_apply_bwd_k(const float* __restrict__ x, const float* __restrict__ dy, long long units, BnGeom g,
+                                                      const double* __restrict__ partial, const float* __restrict__ mean,
+                                                      const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, int relu, BnBwdFin bf, float* __restrict__ dx) {
+  __shared__ double red[2][256];
+  __shared__ float sh_mean[kBnMaxC], sh_is[kBnMaxC], sh_gamma[kBnMaxC], sh_beta[kBnMaxC], sh_c1[kBnMaxC], sh_c2[kBnMaxC];
+  const int tid = threadIdx.x, c = g.c;
+  const int cfold = c < 256 ? c : 256;
+  for (int e0 = 0; e0 < c; e0 += cfold) {
+    const int e = e0 + tid;
+    double a, b;
+    fold_chunk(g, partial, e0, cfold, red, &a, &b);
+    if (tid < cfold && e < c) {
+      const double n = static_cast<double>(g.n);
+      if (blockIdx.x == 0) {
+        bf.dbeta[e] = static_cast<float>(a);
+        bf.dgamma[e] = static_cast<float>(b);
+      }
+      sh_c1[e] = bf.batch_stats ? static_cast<float>(a / n) : 0.f;
+      sh_c2[e] = bf.batch_stats ? static_cast<float>(b / n) : 0.f;
+      sh_mean[e] = mean[e];
+      sh_is[e] = invstd[e];
+      sh_gamma[e] = gamma ? gamma[e] : 1.f;
+      sh_beta[e] = beta ? beta[e] : 0.f;
+    }
+  }
+  __syncthreads();
   const int cv = c / V;
-  for (long long u = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; u < units; u += static_cast<long long>(gridDim.x) * 256) {
+  for (long long u = static_cast<long long>(blockIdx.x) * 256 + tid; u < units; u += static_cast<long long>(gridDim.x) * 256) {
     const int col = static_cast<int>(u % cv) * V;
     Vec<V> xv, gv, o;
     xv.load(x + u * V, 0, 0);
     gv.load(dy + u * V, 0, 0);
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-      const float is = invstd[col + i], ga = gamma ? gamma[col + i] : 1.f;
-      const float xhat = (xv.v[i] - mean[col + i]) * is;
-      const float t = xhat * ga + (beta ? beta[col + i] : 0.f);
+      const float is = sh_is[col + i], ga = sh_gamma[col + i];
+      const float xhat = (xv.v[i] - sh_mean[col + i]) * is;
+      const float t = xhat * ga + sh_beta[col + i];
       const float dz = (relu && !(t > 0.f)) ? 0.f : gv.v[i];
-      o.v[i] = ga * is * (dz - coef[col + i] - xhat * coef[c + col + i]);
+      o.v[i] = ga * is * (dz - sh_c1[col + i] - xhat * sh_c2[col + i]);
     }
     o.store(dx + u * V);
   }
 }
 
+constexpr int kBnPartials = 64;
+
 static int bn_geom(int64_t n, int c, bool vec, BnGeom* g) {
   const int v = vec ? 4 : 1;
   g->n = n; g->c = c;
   g->tcols = static_cast<int>(ceil_div(c, v));
-  if (g->tcols > 256) return -1;
+  if (g->tcols > 256 || c > kBnMaxC) return -1;
   g->rpp = 256 / g->tcols;
-  // ~8 rows per row lane per workgroup, at most 1024 workgroups
+  // >= 8 rows per row lane per workgroup, at most kBnPartials workgroups (every apply workgroup re-folds the partials)
   int64_t nblk = ceil_div(n, static_cast<int64_t>(g->rpp) * 8);
-  if (nblk > 128) nblk = 128;
+  if (nblk > kBnPartials) nblk = kBnPartials;
   if (nblk < 1) nblk = 1;
   g->rows_per_block = ceil_div(n, nblk);
   g->nblk = static_cast<int>(ceil_div(n, g->rows_per_block));
@@ -230,6 +273,12 @@ static int bn_geom(int64_t n, int c, bool vec, BnGeom* g) {
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+static unsigned apply_blocks(long long units) {
+  // grid-stride, ~4 units per thread, at most 2 workgroups per CU worth of fold prologues
+  const int64_t b = ceil_div(units, 256 * 4);
+  return static_cast<unsigned>(b > 512 ? 512 : (b < 1 ? 1 : b));
+}
+
 }  // namespace fv2p
 
 using namespace fv2p;
@@ -237,30 +286,34 @@ using namespace fv2p;
 extern "C" size_t fv2p_batchnorm_ws_bytes(int64_t n, int c) {
   (void)n;
   Sizer s;
-  s.take<double>(static_cast<size_t>(128) * 2 * (c > 0 ? c : 1));
-  s.take<float>(2 * static_cast<size_t>(c > 0 ? c : 1));
+  s.take<double>(static_cast<size_t>(kBnPartials) * 2 * (c > 0 ? c : 1));
   return s.bytes();
 }
 
-extern "C" int fv2p_batchnorm_stats(const float* x, int64_t n, int c, float eps, float momentum, float* mean, float* invstd,
-                                    float* running_mean, float* running_var, int64_t* num_batches_tracked, void* ws, size_t ws_bytes,
-                                    fv2p_stream_t stream_) {
+extern "C" int fv2p_batchnorm_forward(const float* x, int64_t n, int c, float eps, float momentum, const float* gamma, const float* beta,
+                                      int relu, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean,
+                                      float* invstd, float* y, void* ws, size_t ws_bytes, fv2p_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  FV2P_REQUIRE(n >= 1 && c >= 1, FV2P_EINVAL, "batchnorm_stats: n=%lld c=%d", static_cast<long long>(n), c);
-  FV2P_REQUIRE(x && mean && invstd && ws, FV2P_EINVAL, "batchnorm_stats: null pointer");
-  FV2P_REQUIRE((running_mean == nullptr) == (running_var == nullptr), FV2P_EINVAL, "batchnorm_stats: running_mean and running_var come together");
-  FV2P_REQUIRE(ws_bytes >= fv2p_batchnorm_ws_bytes(n, c), FV2P_EWORKSPACE, "batchnorm_stats: workspace %lld < %lld", static_cast<long long>(ws_bytes),
-               static_cast<long long>(fv2p_batchnorm_ws_bytes(n, c)));
-  const bool vec = (c % 4 == 0) && aligned16(x);
+  FV2P_REQUIRE(n >= 1 && c >= 1, FV2P_EINVAL, "batchnorm_forward: n=%lld c=%d", static_cast<long long>(n), c);
+  FV2P_REQUIRE(x && y && mean && invstd && ws, FV2P_EINVAL, "batchnorm_forward: null pointer");
+  FV2P_REQUIRE((running_mean == nullptr) == (running_var == nullptr), FV2P_EINVAL, "batchnorm_forward: running_mean and running_var come together");
+  FV2P_REQUIRE(ws_bytes >= fv2p_batchnorm_ws_bytes(n, c), FV2P_EWORKSPACE, "batchnorm_forward: workspace %lld < %lld",
+               static_cast<long long>(ws_bytes), static_cast<long long>(fv2p_batchnorm_ws_bytes(n, c)));
+  const bool vec = (c % 4 == 0) && aligned16(x) && aligned16(y);
   BnGeom g;
-  FV2P_REQUIRE(bn_geom(n, c, vec, &g) == 0, FV2P_ELIMIT, "batchnorm: c=%d exceeds %d", c, vec ? 1024 : 256);
-  Carver cv(ws, static_cast<size_t>(ws_bytes));
-  double* partial = cv.take<double>(static_cast<size_t>(128) * 2 * c);
+  FV2P_REQUIRE(bn_geom(n, c, vec, &g) == 0, FV2P_ELIMIT, "batchnorm: c=%d exceeds %d", c, vec ? kBnMaxC : 256);
+  Carver cv(ws, ws_bytes);
+  double* partial = cv.take<double>(static_cast<size_t>(kBnPartials) * 2 * c);
   BnFwdFin ff{mean, invstd, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), momentum, eps};
-  BnBwdFin bf{nullptr, nullptr, nullptr, 0};
-  if (vec) hipLaunchKernelGGL((bn_reduce_k<4, false>), dim3(g.nblk), dim3(256), 0, stream, x, nullptr, g, nullptr, nullptr, nullptr, nullptr, 0, partial);
-  else hipLaunchKernelGGL((bn_reduce_k<1, false>), dim3(g.nblk), dim3(256), 0, stream, x, nullptr, g, nullptr, nullptr, nullptr, nullptr, 0, partial);
-  hipLaunchKernelGGL((bn_finalize_k<false>), dim3(1), dim3(256), 0, stream, g, partial, ff, bf);
+  const long long units = n * c / (vec ? 4 : 1);
+  const unsigned blocks = apply_blocks(units);
+  if (vec) {
+    hipLaunchKernelGGL((bn_reduce_k<4, false>), dim3(g.nblk), dim3(256), 0, stream, x, nullptr, g, nullptr, nullptr, nullptr, nullptr, 0, partial);
+    hipLaunchKernelGGL((bn_apply_fwd_k<4, true>), dim3(blocks), dim3(256), 0, stream, x, units, g, partial, ff, gamma, beta, relu, y);
+  } else {
+    hipLaunchKernelGGL((bn_reduce_k<1, false>), dim3(g.nblk), dim3(256), 0, stream, x, nullptr, g, nullptr, nullptr, nullptr, nullptr, 0, partial);
+    hipLaunchKernelGGL((bn_apply_fwd_k<1, true>), dim3(blocks), dim3(256), 0, stream, x, units, g, partial, ff, gamma, beta, relu, y);
+  }
   FV2P_LAUNCH_CHECK();
   return 0;
 }
@@ -272,10 +325,13 @@ extern "C" int fv2p_batchnorm_apply(const float* x, int64_t n, int c, const floa
   if (n == 0) return 0;
   FV2P_REQUIRE(x && y && mean && invstd, FV2P_EINVAL, "batchnorm_apply: null pointer");
   const bool vec = (c % 4 == 0) && aligned16(x) && aligned16(y);
+  BnGeom g;
+  FV2P_REQUIRE(bn_geom(n, c, vec, &g) == 0, FV2P_ELIMIT, "batchnorm: c=%d exceeds %d", c, vec ? kBnMaxC : 256);
+  BnFwdFin ff{const_cast<float*>(mean), const_cast<float*>(invstd), nullptr, nullptr, nullptr, 0.f, 0.f};
   const long long units = n * c / (vec ? 4 : 1);
-  const unsigned blocks = static_cast<unsigned>(ceil_div(units, 256) > 16384 ? 16384 : ceil_div(units, 256));
-  if (vec) hipLaunchKernelGGL((bn_apply_fwd_k<4>), dim3(blocks ? blocks : 1), dim3(256), 0, stream, x, units, c, mean, invstd, gamma, beta, relu, y);
-  else hipLaunchKernelGGL((bn_apply_fwd_k<1>), dim3(blocks ? blocks : 1), dim3(256), 0, stream, x, units, c, mean, invstd, gamma, beta, relu, y);
+  const unsigned blocks = apply_blocks(units);
+  if (vec) hipLaunchKernelGGL((bn_apply_fwd_k<4, false>), dim3(blocks), dim3(256), 0, stream, x, units, g, nullptr, ff, gamma, beta, relu, y);
+  else hipLaunchKernelGGL((bn_apply_fwd_k<1, false>), dim3(blocks), dim3(256), 0, stream, x, units, g, nullptr, ff, gamma, beta, relu, y);
   FV2P_LAUNCH_CHECK();
   return 0;
 }
@@ -290,22 +346,18 @@ extern "C" int fv2p_batchnorm_backward(const float* x, const float* dy, int64_t 
                static_cast<long long>(ws_bytes), static_cast<long long>(fv2p_batchnorm_ws_bytes(n, c)));
   const bool vec = (c % 4 == 0) && aligned16(x) && aligned16(dy) && aligned16(dx);
   BnGeom g;
-  FV2P_REQUIRE(bn_geom(n, c, vec, &g) == 0, FV2P_ELIMIT, "batchnorm: c=%d exceeds %d", c, vec ? 1024 : 256);
-  Carver cv(ws, static_cast<size_t>(ws_bytes));
-  double* partial = cv.take<double>(static_cast<size_t>(128) * 2 * c);
-  float* coef = cv.take<float>(2 * static_cast<size_t>(c));
-  BnFwdFin ff{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f};
-  BnBwdFin bf{dgamma, dbeta, coef, batch_stats};
+  FV2P_REQUIRE(bn_geom(n, c, vec, &g) == 0, FV2P_ELIMIT, "batchnorm: c=%d exceeds %d", c, vec ? kBnMaxC : 256);
+  Carver cv(ws, ws_bytes);
+  double* partial = cv.take<double>(static_cast<size_t>(kBnPartials) * 2 * c);
+  BnBwdFin bf{dgamma, dbeta, nullptr, batch_stats};
   const long long units = n * c / (vec ? 4 : 1);
-  const unsigned blocks = static_cast<unsigned>(ceil_div(units, 256) > 16384 ? 16384 : ceil_div(units, 256));
+  const unsigned blocks = apply_blocks(units);
   if (vec) {
     hipLaunchKernelGGL((bn_reduce_k<4, true>), dim3(g.nblk), dim3(256), 0, stream, x, dy, g, mean, invstd, gamma, beta, relu, partial);
-    hipLaunchKernelGGL((bn_finalize_k<true>), dim3(1), dim3(256), 0, stream, g, partial, ff, bf);
-    hipLaunchKernelGGL((bn_apply_bwd_k<4>), dim3(blocks ? blocks : 1), dim3(256), 0, stream, x, dy, units, c, mean, invstd, gamma, beta, relu, coef, dx);
+    hipLaunchKernelGGL((bn_apply_bwd_k<4>), dim3(blocks), dim3(256), 0, stream, x, dy, units, g, partial, mean, invstd, gamma, beta, relu, bf, dx);
   } else {
     hipLaunchKernelGGL((bn_reduce_k<1, true>), dim3(g.nblk), dim3(256), 0, stream, x, dy, g, mean, invstd, gamma, beta, relu, partial);
-    hipLaunchKernelGGL((bn_finalize_k<true>), dim3(1), dim3(256), 0, stream, g, partial, ff, bf);
-    hipLaunchKernelGGL((bn_apply_bwd_k<1>), dim3(blocks ? blocks : 1), dim3(256), 0, stream, x, dy, units, c, mean, invstd, gamma, beta, relu, coef, dx);
+    hipLaunchKernelGGL((bn_apply_bwd_k<1>), dim3(blocks), dim3(256), 0, stream, x, dy, units, g, partial, mean, invstd, gamma, beta, relu, bf, dx);
   }
   FV2P_LAUNCH_CHECK();
   return 0;

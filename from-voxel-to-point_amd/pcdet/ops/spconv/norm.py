@@ -1,4 +1,4 @@
-"""BatchNorm1d (+ReLU) on sparse-tensor features as three small HIP launches forward and three backward.
+"""BatchNorm1d (+ReLU) on sparse-tensor features as two HIP launches forward and two backward.
 
 The reference builds every backbone block as ``SparseSequential(conv, nn.BatchNorm1d(eps=1e-3, momentum=0.01),
 nn.ReLU())`` (pcdet/models/backbones_3d/spconv_backbone.py:8-27, :75) and ``SparseSequential.forward`` applies the two
@@ -19,27 +19,36 @@ import fv2p_native as _nat
 _ENABLED = os.environ.get("FV2P_FUSED_BN", "1") != "0"
 
 
+_WS_BYTES = {}
+
+
+def _ws_bytes(c):
+    b = _WS_BYTES.get(c)
+    if b is None:
+        b = _WS_BYTES[c] = _nat.call("fv2p_batchnorm_ws_bytes", 0, c)
+    return b
+
+
 class _BatchNormReLU(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, bn, relu):
         n, c = x.shape
         dev = x.device
         batch_stats = bn.training or bn.running_mean is None
+        y = torch.empty_like(x)
         with _nat.device_guard(dev):
             if batch_stats:
-                mean = torch.empty(c, dtype=torch.float32, device=dev)
-                invstd = torch.empty(c, dtype=torch.float32, device=dev)
+                stats = torch.empty((2, c), dtype=torch.float32, device=dev)
+                mean, invstd = stats[0], stats[1]
                 track = bn.training and bn.running_mean is not None
-                nbytes = _nat.call("fv2p_batchnorm_ws_bytes", n, c)
-                ws = _nat.workspace(nbytes, dev)
-                _nat.call("fv2p_batchnorm_stats", x, n, c, float(bn.eps), -1.0 if bn.momentum is None else float(bn.momentum),
-                          mean, invstd, bn.running_mean if track else None, bn.running_var if track else None,
-                          bn.num_batches_tracked if track else None, ws, ws.numel(), _nat.stream())
+                ws = _nat.workspace(_ws_bytes(c), dev)
+                _nat.call("fv2p_batchnorm_forward", x, n, c, float(bn.eps), -1.0 if bn.momentum is None else float(bn.momentum),
+                          weight, bias, int(relu), bn.running_mean if track else None, bn.running_var if track else None,
+                          bn.num_batches_tracked if track else None, mean, invstd, y, ws, ws.numel(), _nat.stream())
             else:
                 mean = bn.running_mean
                 invstd = torch.rsqrt(bn.running_var + bn.eps)
-            y = torch.empty_like(x)
-            _nat.call("fv2p_batchnorm_apply", x, n, c, mean, invstd, weight, bias, int(relu), y, _nat.stream())
+                _nat.call("fv2p_batchnorm_apply", x, n, c, mean, invstd, weight, bias, int(relu), y, _nat.stream())
         ctx.save_for_backward(x, mean, invstd, weight, bias)
         ctx.relu, ctx.batch_stats = bool(relu), bool(batch_stats)
         return y
@@ -51,11 +60,10 @@ class _BatchNormReLU(Function):
         dev = x.device
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        dgamma = torch.empty(c, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+        dpar = torch.empty((2, c), dtype=torch.float32, device=dev)
+        dgamma, dbeta = dpar[0], dpar[1]
         with _nat.device_guard(dev):
-            nbytes = _nat.call("fv2p_batchnorm_ws_bytes", n, c)
-            ws = _nat.workspace(nbytes, dev)
+            ws = _nat.workspace(_ws_bytes(c), dev)
             _nat.call("fv2p_batchnorm_backward", x, dy, n, c, mean, invstd, weight, bias, int(ctx.relu), int(ctx.batch_stats),
                       dx, dgamma, dbeta, ws, ws.numel(), _nat.stream())
         return (dx if ctx.needs_input_grad[0] else None, dgamma if (weight is not None and ctx.needs_input_grad[1]) else None,

@@ -278,17 +278,21 @@ int fv2p_dcn_backward(const float* x_nhwc, const float* wt, const float* offset,
  * normalisation, unbiased for running_var; running = (1 - momentum) * running + momentum * batch; momentum < 0
  * means momentum=None (cumulative average over num_batches_tracked).  Sums are accumulated in fp64 and folded in a
  * fixed order (deterministic).
- *   fv2p_batchnorm_stats    : mean[c], invstd[c] of x[n,c]; updates running_mean / running_var /
- *                             num_batches_tracked in place when running_mean != NULL.
- *   fv2p_batchnorm_apply    : y = relu?((x - mean) * invstd * gamma + beta)   (gamma / beta may be NULL; y may alias x)
+ *   fv2p_batchnorm_forward  : training-mode layer: batch mean / invstd of x[n,c] (also returned for the backward
+ *                             pass), running_mean / running_var / num_batches_tracked updated in place when
+ *                             running_mean != NULL, y = relu?((x - mean) * invstd * gamma + beta).
+ *   fv2p_batchnorm_apply    : the same normalisation with given mean / invstd (eval mode: running statistics).
+ *                             gamma / beta may be NULL; y may alias x.
  *   fv2p_batchnorm_backward : dz = dy * [y > 0] (mask recomputed from x); dgamma = sum dz * xhat, dbeta = sum dz,
  *                             dx = gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat))  when batch_stats != 0,
  *                             dx = gamma * invstd * dz                                          otherwise (eval mode).
+ * c <= 1024 (c % 4 == 0) or c <= 256.
  */
 size_t fv2p_batchnorm_ws_bytes(int64_t n, int c);
-int fv2p_batchnorm_stats(const float* x, int64_t n, int c, float eps, float momentum, float* mean, float* invstd,
-                         float* running_mean, float* running_var, int64_t* num_batches_tracked, void* ws,
-                         size_t ws_bytes, fv2p_stream_t stream);
+int fv2p_batchnorm_forward(const float* x, int64_t n, int c, float eps, float momentum, const float* gamma,
+                           const float* beta, int relu, float* running_mean, float* running_var,
+                           int64_t* num_batches_tracked, float* mean, float* invstd, float* y, void* ws,
+                           size_t ws_bytes, fv2p_stream_t stream);
 int fv2p_batchnorm_apply(const float* x, int64_t n, int c, const float* mean, const float* invstd,
                          const float* gamma, const float* beta, int relu, float* y, fv2p_stream_t stream);
 int fv2p_batchnorm_backward(const float* x, const float* dy, int64_t n, int c, const float* mean,
