@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--backbone", choices=["8x", "res8x"], default="8x")
     ap.add_argument("--cpu-clouds", type=int, default=64, help="clouds in the cpu_baseline sample, ~0.2 s each, capped at 25 s (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--prefetch", type=int, default=2,
+                    help="input-pipeline thread prepares batch t+1 while batch t trains: 2 = voxelisation + rulebooks, 1 = voxelisation, 0 = all in line")
     ap.add_argument("--phases", action="store_true", help="diagnostic: host issue time and synchronised wall time per phase (stderr)")
     ap.add_argument("--pyprofile", action="store_true", help="cProfile the timed steps (host-overhead hunting; prints to stderr)")
     return ap.parse_args()
@@ -81,8 +83,31 @@ def build_step(args, device, rank, world):
         v, coords, n = points_to_voxel_batch(clouds, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 16000)
         return mean_vfe(v, n), coords
 
+    from fv2p_harness.prefetch import BatchPrefetcher
+    from pcdet.ops import spconv
+    pre = None
+    if args.prefetch:
+        # the input pipeline also builds the batch's rulebooks (they depend on coordinates only): recipe from one pass
+        with torch.no_grad():
+            f0, c0 = voxelize(pool[0])
+            recipe = spconv.rulebook_recipe(model(f0, c0, args.batch)[0].indice_dict, c0)
+
+        def produce(i):
+            feats, coords = voxelize(pool[i % n_pool])
+            if args.prefetch > 1:
+                spconv.attach_rulebooks(coords, spconv.build_rulebooks(recipe, coords, args.batch))
+            return feats, coords
+
+        pre = BatchPrefetcher(produce, device)
+
     def step(i):
-        feats, coords = voxelize(pool[i % n_pool])
+        if pre is None:
+            feats, coords = voxelize(pool[i % n_pool])
+        else:  # input pipeline thread: batch i was submitted during step i-1, batch i+1 is prepared during this step
+            if pre.pending == 0:
+                pre.submit(i)
+            pre.submit(i + 1)
+            feats, coords = pre.get()
         loss = net(feats, coords, args.batch)
         opt.zero_grad(set_to_none=True)
         loss.backward()

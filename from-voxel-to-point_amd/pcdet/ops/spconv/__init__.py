@@ -5,10 +5,12 @@ from .conv import (SparseConv2d, SparseConv3d, SparseConv4d, SparseConvolution, 
 from .group import SparseGroup3d, SubMGroup3d
 from .modules import RemoveGrid, SparseModule, SparseSequential, ToDense
 from .pool import SparseMaxPool2d, SparseMaxPool3d
+from .prefetch import attach_rulebooks, build_rulebooks, rulebook_recipe
 from .structure import SparseConvTensor, scatter_nd
 
 __all__ = [
     'SparseConv2d', 'SparseConv3d', 'SubMConv2d', 'SubMConv3d', 'SparseConvTranspose2d', 'SparseConvTranspose3d',
     'SparseInverseConv2d', 'SparseInverseConv3d', 'SparseModule', 'SparseSequential', 'SparseMaxPool2d',
     'SparseMaxPool3d', 'SparseConvTensor', 'scatter_nd', 'SparseGroup3d', 'SubMGroup3d',
+    'rulebook_recipe', 'build_rulebooks', 'attach_rulebooks',
 ]

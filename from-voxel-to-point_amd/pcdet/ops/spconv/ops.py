@@ -152,6 +152,8 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize=3, stride=1, paddin
         outids = outids4
     rb = Rulebook(outids, indices, tab_in, tab_out, num, spatial_shape, kvol, bool(subm))
     rb.out_spatial_shape = out_shape
+    rb.geom = (tuple(ksize), tuple(stride), tuple(padding), tuple(dilation), tuple(out_padding), bool(subm), bool(transpose))
+    rb.batch_size = int(batch_size)
     return rb
 
 

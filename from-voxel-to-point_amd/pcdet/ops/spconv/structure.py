@@ -26,7 +26,9 @@ class SparseConvTensor(object):
         self.indices = indices if indices.dtype == torch.int32 else indices.int()
         self.spatial_shape = spatial_shape
         self.batch_size = batch_size
-        self.indice_dict = {}
+        # rulebooks prefetched for exactly this coordinate tensor (prefetch.attach_rulebooks), else empty
+        pre = getattr(indices, "_fv2p_indice_dict", None)
+        self.indice_dict = dict(pre) if pre else {}
         self.grid = grid
 
     @property

@@ -61,3 +61,47 @@ def test_backbone_forward_backward_matches_cpu_oracle(gpu, cls):
             continue
         a, b = gp[name].grad.cpu().double(), p.grad.double()
         assert float((a - b).norm() / b.norm().clamp_min(1e-12)) < 5e-3, name  # relative L2 over the tensor
+
+
+def test_input_pipeline_thread_produces_the_inline_batches(gpu):
+    """fv2p_harness.prefetch.BatchPrefetcher: batches voxelised (and their rulebooks built) on the pipeline thread's
+    stream equal the ones produced in line, and a training step consumes them with identical loss."""
+    from fv2p_harness import synth
+    from fv2p_harness.backbone import VoxelBackBone8x, mean_vfe
+    from fv2p_harness.prefetch import BatchPrefetcher
+    from pcdet.datasets.processor.voxel_generator import points_to_voxel_batch
+    from pcdet.ops import spconv
+
+    clouds = [[torch.from_numpy(synth.lidar_cloud(10 * b + s, 4096)).to(gpu) for s in range(2)] for b in range(3)]
+    torch.manual_seed(0)
+    model = VoxelBackBone8x(4, [1408, 1600, 40]).to(gpu)
+
+    def voxelize(i):
+        v, c, n = points_to_voxel_batch(clouds[i % 3], synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 16000)
+        return mean_vfe(v, n), c
+
+    with torch.no_grad():
+        f0, c0 = voxelize(0)
+        recipe = spconv.rulebook_recipe(model(f0, c0, 2)[0].indice_dict, c0)
+        inline = []
+        for i in range(3):
+            f, c = voxelize(i)
+            inline.append((f, c, model(f, c, 2)[0].features.square().mean().item()))
+
+    def produce(i):
+        f, c = voxelize(i)
+        spconv.attach_rulebooks(c, spconv.build_rulebooks(recipe, c, 2))
+        return f, c
+
+    pre = BatchPrefetcher(produce, gpu)
+    try:
+        for i in range(3):
+            pre.submit(i)
+        with torch.no_grad():
+            for i in range(3):
+                f, c = pre.get()
+                assert torch.equal(f, inline[i][0]) and torch.equal(c, inline[i][1])
+                assert hasattr(c, "_fv2p_indice_dict")
+                assert model(f, c, 2)[0].features.square().mean().item() == inline[i][2]
+    finally:
+        pre.close()

@@ -270,3 +270,49 @@ def test_empty_and_tiny_inputs(gpu):
     assert rel_err(y.features.detach().cpu().numpy(), conv.weight[1, 1, 1].sum(0, keepdim=True).detach().cpu().numpy()) < RTOL
     with pytest.raises(Exception):  # CPU tensors fail loudly: there is no CPU path
         conv.cpu()(spconv.SparseConvTensor(torch.ones((1, 16)), torch.zeros((1, 4), dtype=torch.int32), [4, 4, 4], 1))
+
+
+def test_rulebook_prefetch_recipe_matches_inline_build_and_ignores_stale_geometry(gpu):
+    """spconv.rulebook_recipe / build_rulebooks / attach_rulebooks (input-pipeline prefetch): a pass that finds every
+    indice_key prefetched gives bit-identical features and indices to the pass that builds its rulebooks in line, on
+    new coordinates; an attached rulebook with another geometry is ignored (rebuilt), not used."""
+    batch, shape = 2, [17, 40, 36]
+
+    def net(pad=1):
+        torch.manual_seed(1)
+        return spconv.SparseSequential(
+            spconv.SubMConv3d(8, 16, 3, padding=1, bias=False, indice_key="subm1"),
+            spconv.SparseConv3d(16, 32, 3, stride=2, padding=pad, bias=False, indice_key="spconv2"),
+            spconv.SubMConv3d(32, 32, 3, padding=1, bias=False, indice_key="subm2"),
+            spconv.SparseConv3d(32, 32, (3, 1, 1), stride=(2, 1, 1), padding=0, bias=False, indice_key="down"),
+            spconv.SparseInverseConv3d(32, 16, (3, 1, 1), indice_key="down", bias=False)).to(gpu)
+
+    model = net()
+    ind0, f0, x0 = make_input(11, batch, shape, 1500, 8, gpu)
+    y0 = model(x0)
+    recipe = spconv.rulebook_recipe(y0.indice_dict, x0.indices)
+    assert [r[0] for r in recipe] == ["subm1", "spconv2", "subm2", "down"] and [r[1] for r in recipe] == [None, None, "spconv2", "spconv2"]
+    ind1, f1, x1 = make_input(12, batch, shape, 1700, 8, gpu)
+    ref = model(x1)
+    coords = torch.from_numpy(ind1).to(gpu)
+    built = spconv.build_rulebooks(recipe, coords, batch)
+    spconv.attach_rulebooks(coords, built)
+    x2 = spconv.SparseConvTensor(torch.from_numpy(f1).to(gpu), coords, shape, batch)
+    assert set(x2.indice_dict) == {"subm1", "spconv2", "subm2", "down"}
+    calls = []
+    orig = ops.build_rulebook
+    ops.build_rulebook = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        out = model(x2)
+        assert calls == []                                        # every key was a cache hit
+        assert torch.equal(out.features, ref.features) and torch.equal(out.indices, ref.indices)
+        # stale geometry: same keys, but the model's strided conv now has another padding -> rebuilt, result = inline
+        model2 = net(pad=0)
+        x3 = spconv.SparseConvTensor(torch.from_numpy(f1).to(gpu), coords, shape, batch)
+        out3 = model2(x3)
+        assert len(calls) >= 1
+    finally:
+        ops.build_rulebook = orig
+    x4 = spconv.SparseConvTensor(torch.from_numpy(f1).to(gpu), torch.from_numpy(ind1).to(gpu), shape, batch)
+    ref3 = model2(x4)
+    assert torch.equal(out3.indices, ref3.indices) and torch.equal(out3.features, ref3.features)
