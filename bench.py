@@ -73,7 +73,7 @@ def build_step(args, device, rank, world):
             return out.features.square().mean()
 
     net = dist_utils.wrap_ddp(TrainStep(model), device)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.01)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.01, fused=True)  # one multi-tensor kernel per step
     # a small pool of distinct batches, points resident in HBM; seeds differ per rank
     n_pool = 4
     pool = [[torch.from_numpy(synth.lidar_cloud(seed, args.points)).to(device) for seed in seeds]

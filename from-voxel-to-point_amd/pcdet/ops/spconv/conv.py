@@ -104,7 +104,7 @@ class SparseConvolution(SparseModule):
             outids, out_spatial_shape = rb.indices, rb.spatial_shape
             assert rb.kvol == np.prod(self.kernel_size), 'inverse conv must have same kernel size as its couple conv'
         else:
-            if self.indice_key is not None and datas is not None and geometry_matches(datas, self):
+            if self.indice_key is not None and datas is not None and geometry_matches(datas, self, indices):
                 rb = datas
             else:
                 rb = ops.build_rulebook(indices, batch_size, spatial_shape, self.kernel_size, self.stride, self.padding,

@@ -11,8 +11,8 @@ knows the next batch's coordinates can do the whole chain earlier, on its own st
     model(next_feats, next_coords)      # SparseConvTensor adopts the attached dict: every indice_key hits the cache
 
 The cache lookup in SparseConvolution.forward stays what it is in the reference (conv.py:178-196): a hit on
-`indice_key` reuses the rulebook.  A prefetched entry whose geometry differs from the module asking for it is ignored
-and rebuilt, so a stale recipe costs time, never correctness.
+`indice_key` reuses the rulebook.  A prefetched entry whose geometry differs from the module asking for it, or whose
+input rows are not the tensor's, is ignored and rebuilt, so a stale recipe costs time, never correctness.
 """
 import torch
 
@@ -51,6 +51,7 @@ def build_rulebooks(recipe, indices, batch_size):
         ind = indices if src is None else out[src].outids
         out[key] = ops.build_rulebook(ind, batch_size, shape, list(ksize), list(stride), list(padding), list(dilation),
                                       list(out_padding), subm, transpose)
+        out[key].prefetched = True
     return out
 
 
@@ -60,11 +61,14 @@ def attach_rulebooks(indices, rulebooks):
     return indices
 
 
-def geometry_matches(rb, module):
+def geometry_matches(rb, module, indices):
+    """False for a prefetched rulebook that was built for another conv geometry or for other input rows (a rebuilt
+    upstream conv invalidates everything prefetched downstream of it).  Rulebooks cached by a pass itself keep the
+    reference semantics: the key is trusted."""
     g = getattr(rb, "geom", None)
-    if g is None:
-        return True  # foreign / hand-made rulebook: the reference semantics (trust the key)
-    if module.inverse:
+    if g is None or module.inverse or not getattr(rb, "prefetched", False):
         return True
+    if rb.indices is not indices and (rb.indices.data_ptr() != indices.data_ptr() or rb.indices.shape != indices.shape):
+        return False
     return (g[0] == tuple(module.kernel_size) and g[1] == tuple(module.stride) and g[2] == tuple(module.padding) and
             g[3] == tuple(module.dilation) and g[5] == bool(module.subm) and g[6] == bool(module.transposed))
