@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--prefetch", type=int, default=2,
                     help="input-pipeline thread prepares batch t+1 while batch t trains: 2 = voxelisation + rulebooks, 1 = voxelisation, 0 = all in line")
+    ap.add_argument("--prefetch-depth", type=int, default=2, help="batches the input-pipeline thread keeps in flight")
     ap.add_argument("--phases", action="store_true", help="diagnostic: host issue time and synchronised wall time per phase (stderr)")
     ap.add_argument("--pyprofile", action="store_true", help="cProfile the timed steps (host-overhead hunting; prints to stderr)")
     return ap.parse_args()
@@ -103,10 +104,12 @@ def build_step(args, device, rank, world):
     def step(i):
         if pre is None:
             feats, coords = voxelize(pool[i % n_pool])
-        else:  # input pipeline thread: batch i was submitted during step i-1, batch i+1 is prepared during this step
+        else:  # input pipeline thread: keeps `depth` batches in flight; each step consumes one and submits one
             if pre.pending == 0:
-                pre.submit(i)
-            pre.submit(i + 1)
+                step.next_submit = i
+            while pre.pending < args.prefetch_depth:
+                pre.submit(step.next_submit)
+                step.next_submit += 1
             feats, coords = pre.get()
         loss = net(feats, coords, args.batch)
         opt.zero_grad(set_to_none=True)
