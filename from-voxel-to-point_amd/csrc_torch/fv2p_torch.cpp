@@ -1,0 +1,183 @@
+// fv2p_torch — compiled torch binding of the hot autograd ops on top of the C ABI (include/fv2p_ops.h).
+//
+// The reference binds its ops with pybind torch extensions too (pcdet/ops/spconv/src/all.cc:18-62) and keeps the
+// autograd Functions in Python (spconv/functional.py:20-175).  At BASELINE's batch size the training step is bound
+// by host work, not kernels, and the Python autograd Functions + ctypes crossings are most of it; here
+// the two Functions every backbone block runs — sparse conv and BatchNorm1d(+ReLU) — are torch::autograd::Functions:
+// their backward runs on the autograd engine's thread without the GIL.  No kernels live here: every call goes
+// through libfv2p_ops.so.  Optional: without this module the same ops run through fv2p_native.py (ctypes).
+#include <torch/extension.h>
+#include <c10/hip/HIPStream.h>
+#include <c10/core/DeviceGuard.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+
+#include "../../include/fv2p_ops.h"
+
+namespace {
+
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+void* cur_stream(const at::Tensor& t) { return static_cast<void*>(c10::hip::getCurrentHIPStream(t.device().index()).stream()); }
+
+void check(int rc, const char* what) {
+  TORCH_CHECK(rc >= 0, what, " failed (", rc, "): ", fv2p_last_error());
+}
+
+// grow-only scratch per (device, stream): library calls on one stream are ordered by the stream itself
+at::Tensor workspace(size_t bytes, const at::Tensor& like, void* stream) {
+  static std::mutex mu;
+  static std::map<std::pair<int, void*>, at::Tensor> pool;
+  std::lock_guard<std::mutex> lock(mu);
+  auto key = std::make_pair(static_cast<int>(like.device().index()), stream);
+  auto it = pool.find(key);
+  if (it == pool.end() || static_cast<size_t>(it->second.numel()) < bytes) {
+    const int64_t cap = static_cast<int64_t>(std::max<size_t>(bytes * 2, size_t(1) << 22));
+    pool[key] = at::empty({cap}, like.options().dtype(at::kByte));
+    it = pool.find(key);
+  }
+  return it->second;
+}
+
+void require_f32_cuda(const at::Tensor& t, const char* name) {
+  TORCH_CHECK(t.is_cuda(), name, ": fv2p ops run on the GPU only (no CPU fallback exists)");
+  TORCH_CHECK(t.scalar_type() == at::kFloat, name, ": float32 expected");
+}
+
+// ---- sparse convolution: out[r] = sum_k feat[tab_f[k][r]] . W_k ------------------------------------------------------
+struct SparseConvFn : public torch::autograd::Function<SparseConvFn> {
+  static at::Tensor forward(AutogradContext* ctx, const at::Tensor& features_, const at::Tensor& weight_, const at::Tensor& tab_f,
+                            int64_t flip_f, const at::Tensor& tab_b, int64_t flip_b, int64_t n_out, int64_t centre) {
+    require_f32_cuda(features_, "features");
+    require_f32_cuda(weight_, "weight");
+    const at::Tensor features = features_.contiguous(), weight = weight_.contiguous();
+    const int64_t cin = weight.size(-2), cout = weight.size(-1);
+    const int64_t kvol = weight.numel() / (cin * cout);
+    TORCH_CHECK(features.dim() == 2 && features.size(1) == cin, "features [N, Cin] expected");
+    c10::DeviceGuard guard(features.device());
+    void* stream = cur_stream(features);
+    at::Tensor out = at::empty({n_out, cout}, features.options());
+    check(fv2p_sparse_conv_rows(features.data_ptr<float>(), features.size(0), static_cast<int>(cin), weight.data_ptr<float>(),
+                                static_cast<int>(kvol), tab_f.data_ptr<int>(), n_out, static_cast<int>(cout), static_cast<int>(flip_f), 0,
+                                nullptr, out.data_ptr<float>(), stream),
+          "fv2p_sparse_conv_rows");
+    ctx->save_for_backward({features, weight, tab_f, tab_b});
+    ctx->saved_data["flip_f"] = flip_f;
+    ctx->saved_data["flip_b"] = flip_b;
+    ctx->saved_data["centre"] = centre;
+    return out;
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    const auto saved = ctx->get_saved_variables();
+    const at::Tensor &features = saved[0], &weight = saved[1], &tab_f = saved[2], &tab_b = saved[3];
+    const at::Tensor g = grads[0].contiguous();
+    const int64_t cin = weight.size(-2), cout = weight.size(-1);
+    const int64_t kvol = weight.numel() / (cin * cout);
+    const int flip_f = static_cast<int>(ctx->saved_data["flip_f"].toInt()), flip_b = static_cast<int>(ctx->saved_data["flip_b"].toInt());
+    const int centre = static_cast<int>(ctx->saved_data["centre"].toInt());
+    c10::DeviceGuard guard(features.device());
+    void* stream = cur_stream(features);
+    at::Tensor din, dw;
+    if (ctx->needs_input_grad(0)) {
+      din = at::empty_like(features);
+      check(fv2p_sparse_conv_rows(g.data_ptr<float>(), g.size(0), static_cast<int>(cout), weight.data_ptr<float>(), static_cast<int>(kvol),
+                                  tab_b.data_ptr<int>(), features.size(0), static_cast<int>(cin), flip_b, 1, nullptr, din.data_ptr<float>(), stream),
+            "fv2p_sparse_conv_rows (backward data)");
+    }
+    if (ctx->needs_input_grad(1)) {
+      dw = at::empty_like(weight);
+      const size_t wsb = fv2p_sparse_conv_wgrad_ws_bytes(g.size(0), static_cast<int>(cin), static_cast<int>(cout), static_cast<int>(kvol));
+      at::Tensor ws = workspace(wsb, features, stream);
+      check(fv2p_sparse_conv_wgrad(features.data_ptr<float>(), features.size(0), static_cast<int>(cin), g.data_ptr<float>(), tab_f.data_ptr<int>(),
+                                   g.size(0), static_cast<int>(cout), static_cast<int>(kvol), flip_f, centre, dw.data_ptr<float>(), ws.data_ptr(),
+                                   static_cast<size_t>(ws.numel()), stream),
+            "fv2p_sparse_conv_wgrad");
+    }
+    return {din, dw, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+  }
+};
+
+at::Tensor sparse_conv(const at::Tensor& features, const at::Tensor& weight, const at::Tensor& tab_f, int64_t flip_f, const at::Tensor& tab_b,
+                       int64_t flip_b, int64_t n_out, int64_t centre) {
+  return SparseConvFn::apply(features, weight, tab_f, flip_f, tab_b, flip_b, n_out, centre);
+}
+
+// ---- BatchNorm1d (+ReLU) on [N, C] ---------------------------------------------------------------------------------------
+struct BnReluFn : public torch::autograd::Function<BnReluFn> {
+  static at::Tensor forward(AutogradContext* ctx, const at::Tensor& x_, const c10::optional<at::Tensor>& weight, const c10::optional<at::Tensor>& bias,
+                            const c10::optional<at::Tensor>& running_mean, const c10::optional<at::Tensor>& running_var,
+                            const c10::optional<at::Tensor>& num_batches_tracked, bool training, double momentum, double eps, bool relu) {
+    require_f32_cuda(x_, "input");
+    const at::Tensor x = x_.contiguous();
+    const int64_t n = x.size(0), c = x.size(1);
+    const bool has_running = running_mean.has_value() && running_mean->defined();
+    const bool batch_stats = training || !has_running;
+    c10::DeviceGuard guard(x.device());
+    void* stream = cur_stream(x);
+    at::Tensor y = at::empty_like(x);
+    at::Tensor mean, invstd;
+    const float* gamma = (weight.has_value() && weight->defined()) ? weight->data_ptr<float>() : nullptr;
+    const float* beta = (bias.has_value() && bias->defined()) ? bias->data_ptr<float>() : nullptr;
+    if (batch_stats) {
+      at::Tensor stats = at::empty({2, c}, x.options());
+      mean = stats[0];
+      invstd = stats[1];
+      const bool track = training && has_running;
+      at::Tensor ws = workspace(fv2p_batchnorm_ws_bytes(n, static_cast<int>(c)), x, stream);
+      int64_t* nbt = (track && num_batches_tracked.has_value() && num_batches_tracked->defined()) ? num_batches_tracked->data_ptr<int64_t>() : nullptr;
+      check(fv2p_batchnorm_forward(x.data_ptr<float>(), n, static_cast<int>(c), static_cast<float>(eps), static_cast<float>(momentum), gamma, beta,
+                                   relu ? 1 : 0, track ? running_mean->data_ptr<float>() : nullptr, track ? running_var->data_ptr<float>() : nullptr,
+                                   nbt, mean.data_ptr<float>(), invstd.data_ptr<float>(), y.data_ptr<float>(), ws.data_ptr(),
+                                   static_cast<size_t>(ws.numel()), stream),
+            "fv2p_batchnorm_forward");
+    } else {
+      mean = *running_mean;
+      invstd = at::rsqrt(*running_var + eps);
+      check(fv2p_batchnorm_apply(x.data_ptr<float>(), n, static_cast<int>(c), mean.data_ptr<float>(), invstd.data_ptr<float>(), gamma, beta,
+                                 relu ? 1 : 0, y.data_ptr<float>(), stream),
+            "fv2p_batchnorm_apply");
+    }
+    ctx->save_for_backward({x, mean, invstd, weight.has_value() ? *weight : at::Tensor(), bias.has_value() ? *bias : at::Tensor()});
+    ctx->saved_data["relu"] = relu;
+    ctx->saved_data["batch_stats"] = batch_stats;
+    return y;
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    const auto saved = ctx->get_saved_variables();
+    const at::Tensor &x = saved[0], &mean = saved[1], &invstd = saved[2], &weight = saved[3], &bias = saved[4];
+    const at::Tensor dy = grads[0].contiguous();
+    const int64_t n = x.size(0), c = x.size(1);
+    c10::DeviceGuard guard(x.device());
+    void* stream = cur_stream(x);
+    at::Tensor dx = at::empty_like(x);
+    at::Tensor dpar = at::empty({2, c}, x.options());
+    at::Tensor ws = workspace(fv2p_batchnorm_ws_bytes(n, static_cast<int>(c)), x, stream);
+    check(fv2p_batchnorm_backward(x.data_ptr<float>(), dy.data_ptr<float>(), n, static_cast<int>(c), mean.data_ptr<float>(), invstd.data_ptr<float>(),
+                                  weight.defined() ? weight.data_ptr<float>() : nullptr, bias.defined() ? bias.data_ptr<float>() : nullptr,
+                                  ctx->saved_data["relu"].toBool() ? 1 : 0, ctx->saved_data["batch_stats"].toBool() ? 1 : 0, dx.data_ptr<float>(),
+                                  dpar[0].data_ptr<float>(), dpar[1].data_ptr<float>(), ws.data_ptr(), static_cast<size_t>(ws.numel()), stream),
+          "fv2p_batchnorm_backward");
+    return {dx, weight.defined() ? dpar[0] : at::Tensor(), bias.defined() ? dpar[1] : at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
+            at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+  }
+};
+
+at::Tensor batch_norm_relu(const at::Tensor& x, const c10::optional<at::Tensor>& weight, const c10::optional<at::Tensor>& bias,
+                           const c10::optional<at::Tensor>& running_mean, const c10::optional<at::Tensor>& running_var,
+                           const c10::optional<at::Tensor>& num_batches_tracked, bool training, double momentum, double eps, bool relu) {
+  return BnReluFn::apply(x, weight, bias, running_mean, running_var, num_batches_tracked, training, momentum, eps, relu);
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  m.doc() = "compiled autograd binding of libfv2p_ops (sparse conv, BatchNorm1d+ReLU)";
+  m.def("abi_version", []() { return fv2p_abi_version(); });
+  m.def("sparse_conv", &sparse_conv, "fused sparse convolution with autograd (tables from a Rulebook)");
+  m.def("batch_norm_relu", &batch_norm_relu, "BatchNorm1d (+ReLU) on [N, C] with autograd");
+}

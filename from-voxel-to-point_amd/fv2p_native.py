@@ -97,6 +97,30 @@ def lib():
     return _LIB
 
 
+_EXT = False
+
+
+def torch_ext():
+    """The compiled autograd binding lib/fv2p_torch.so (csrc_torch/fv2p_torch.cpp), or None.
+
+    It is an optional second front end of the same library: sparse conv and BatchNorm1d(+ReLU) as C++
+    torch::autograd::Functions (no Python in their backward).  FV2P_TORCH_EXT=0 keeps everything on ctypes."""
+    global _EXT
+    if _EXT is False:
+        _EXT = None
+        path = os.path.join(_HERE, "lib", "fv2p_torch.so")
+        if os.environ.get("FV2P_TORCH_EXT", "1") != "0" and os.path.exists(path):
+            lib()  # libfv2p_ops.so first (RTLD_GLOBAL), the extension links against it
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("fv2p_torch", path)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            if mod.abi_version() != 1:
+                raise Fv2pError("fv2p_torch.so / libfv2p_ops.so ABI version mismatch")
+            _EXT = mod
+    return _EXT
+
+
 def last_error():
     return lib().fv2p_last_error().decode()
 

@@ -111,9 +111,28 @@ class SubMGroupFunction(Function):
         return ops.indice_group_backward(features, grad_output.contiguous(), ctx.rulebook, None, False, True), None, None, None
 
 
-indice_conv = SparseConvFunction.apply
-indice_inverse_conv = SparseInverseConvFunction.apply
-indice_subm_conv = SubMConvFunction.apply
+def _dispatch(fn_cls):
+    """reference functional.py:169-171 binds `X.apply`; here the call first tries the compiled autograd Function
+    (lib/fv2p_torch.so: same kernels, backward without Python) and otherwise runs the Python Function above."""
+    import fv2p_native as _nat
+
+    def call(features, filters, indice_pairs, indice_pair_num, num_activate_out):
+        ext = _nat.torch_ext()
+        if (ext is not None and features.is_cuda and features.dtype == torch.float32 and filters.dtype == torch.float32
+                and features.dim() == 2 and not torch.is_autocast_enabled()):
+            rb = ops._rulebook_of(indice_pairs, indice_pair_num, features.shape[0], num_activate_out, fn_cls.INVERSE)
+            (tab_f, flip_f), (tab_b, flip_b) = (rb.in_table(), rb.out_table()) if fn_cls.INVERSE else (rb.out_table(), rb.in_table())
+            centre = (rb.kvol // 2) if (rb.subm and rb.tab_out is None and not fn_cls.INVERSE) else -1
+            return ext.sparse_conv(features, filters, tab_f, flip_f, tab_b, flip_b, num_activate_out, centre)
+        return fn_cls.apply(features, filters, indice_pairs, indice_pair_num, num_activate_out)
+
+    call.__name__ = fn_cls.__name__ + "_apply"
+    return call
+
+
+indice_conv = _dispatch(SparseConvFunction)
+indice_inverse_conv = _dispatch(SparseInverseConvFunction)
+indice_subm_conv = _dispatch(SubMConvFunction)
 indice_maxpool = SparseMaxPoolFunction.apply
 indice_group = SparseGroupFunction.apply
 indice_subm_group = SubMGroupFunction.apply

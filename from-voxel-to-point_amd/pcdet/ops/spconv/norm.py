@@ -89,4 +89,8 @@ def batch_norm_relu(bn, x, relu_module=None):
         return None
     if bn.weight is not None and (bn.weight.dtype != torch.float32 or not bn.weight.is_cuda):
         return None
+    ext = _nat.torch_ext()
+    if ext is not None:
+        return ext.batch_norm_relu(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.training,
+                                   -1.0 if bn.momentum is None else float(bn.momentum), float(bn.eps), relu_module is not None)
     return _BatchNormReLU.apply(x, bn.weight, bn.bias, bn, relu_module is not None)

@@ -33,3 +33,18 @@ def gpu():
     import fv2p_native
     fv2p_native.lib()  # raises if libfv2p_ops.so is missing: no fallback
     return torch.device("cuda:0")
+
+
+@pytest.fixture(params=["compiled", "ctypes"])
+def front_end(request):
+    """Runs a test once per Python front end of the library: the compiled autograd binding (lib/fv2p_torch.so) and the
+    ctypes binding with Python autograd Functions.  Both reach the same kernels through the C ABI."""
+    import fv2p_native
+    ext = fv2p_native.torch_ext()
+    assert ext is not None, "lib/fv2p_torch.so is missing: build with __graft_entry__.build()"
+    if request.param == "ctypes":
+        fv2p_native._EXT = None
+    try:
+        yield request.param
+    finally:
+        fv2p_native._EXT = ext

@@ -33,3 +33,13 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 src = open(os.path.join(d, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "liboracle" not in src, f
+
+
+def test_compiled_torch_binding_loads_and_matches_the_abi():
+    """lib/fv2p_torch.so (csrc_torch/fv2p_torch.cpp) imports without a GPU, links the same libfv2p_ops.so and exposes the
+    two autograd ops the Python API dispatches to."""
+    import fv2p_native
+    ext = fv2p_native.torch_ext()
+    assert ext is not None, "lib/fv2p_torch.so is missing: build with __graft_entry__.build()"
+    assert ext.abi_version() == fv2p_native.lib().fv2p_abi_version() == 1
+    assert callable(ext.sparse_conv) and callable(ext.batch_norm_relu)

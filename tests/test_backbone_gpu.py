@@ -32,7 +32,7 @@ def make_batch(gpu, seeds, n_points):
 
 
 @pytest.mark.parametrize("cls", [VoxelBackBone8x, VoxelResBackBone8x], ids=["VoxelBackBone8x", "VoxelResBackBone8x"])
-def test_backbone_forward_backward_matches_cpu_oracle(gpu, cls):
+def test_backbone_forward_backward_matches_cpu_oracle(gpu, front_end, cls):
     torch.manual_seed(0)
     model = cls(4, [1408, 1600, 40]).to(gpu)
     ref = cpu_mirror(model)

@@ -35,7 +35,7 @@ CHANNELS = [(4, 16), (5, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64), 
 
 
 @pytest.mark.parametrize("cin,cout", CHANNELS)
-def test_subm_conv_forward_backward_vs_oracle(gpu, cin, cout):
+def test_subm_conv_forward_backward_vs_oracle(gpu, front_end, cin, cout):
     batch, shape = 2, [9, 20, 18]
     ind, feats, x = make_input(cin * 100 + cout, batch, shape, 900, cin, gpu)
     conv = spconv.SubMConv3d(cin, cout, 3, padding=1, bias=False, indice_key="k").to(gpu)
@@ -80,7 +80,7 @@ def test_conv_kernel_variants_agree_with_oracle(gpu, impl):
 
 @pytest.mark.parametrize("k,s,p", [([3, 3, 3], [2, 2, 2], [1, 1, 1]), ([3, 3, 3], [2, 2, 2], [0, 1, 1]), ([3, 1, 1], [2, 1, 1], [0, 0, 0]),
                                    ([2, 2, 2], [2, 2, 2], [0, 0, 0]), ([3, 3, 3], [1, 1, 1], [1, 1, 1])])
-def test_strided_conv_vs_oracle_and_dense(gpu, k, s, p):
+def test_strided_conv_vs_oracle_and_dense(gpu, front_end, k, s, p):
     batch, shape, cin, cout = 2, [9, 16, 14], 16, 32
     ind, feats, x = make_input(11, batch, shape, 500, cin, gpu)
     conv = spconv.SparseConv3d(cin, cout, k, stride=s, padding=p, bias=True).to(gpu)
@@ -133,7 +133,7 @@ def test_subm_conv_equals_masked_dense_conv_and_autograd(gpu):
     assert rel_err(conv.weight.grad.cpu().numpy(), w.grad.numpy()) < RTOL
 
 
-def test_inverse_and_transposed_conv(gpu):
+def test_inverse_and_transposed_conv(gpu, front_end):
     batch, shape, c = 2, [8, 12, 12], 16
     ind, feats, x = make_input(21, batch, shape, 350, c, gpu)
     down = spconv.SparseConv3d(c, 32, 3, stride=2, padding=1, bias=False, indice_key="d").to(gpu)
