@@ -291,7 +291,9 @@ def main():
             "config": {"workload": ("VoxelBackBone8x" if args.backbone == "8x" else "VoxelResBackBone8x") +
                        " train step (HIP voxelise + MeanVFE + sparse backbone fwd + bwd + AdamW), KITTI grid 0.05 m "
                        "[41,1600,1408], LiDAR-like synthetic clouds", "batch_per_gpu": args.batch, "points_per_cloud": args.points,
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "input_pipeline": {0: "in line", 1: "thread voxelises batch t+1 during step t",
+                                          2: "thread voxelises batch t+1 and builds its rulebooks during step t"}[min(args.prefetch, 2)]},
         }
         if not args.no_roofline:
             result["roofline"] = roofline_probe(model, voxelize, pool, args, device)
