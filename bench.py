@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--prefetch", type=int, default=2,
                     help="input-pipeline thread prepares batch t+1 while batch t trains: 2 = voxelisation + rulebooks, 1 = voxelisation, 0 = all in line")
+    ap.add_argument("--pair-lists", type=int, default=1, help="prefetch also materialises the reference-format pair lists (pair-split weight gradient)")
+    ap.add_argument("--switch-interval", type=float, default=0.0, help="sys.setswitchinterval (s); 0 keeps Python's default 5 ms")
     ap.add_argument("--prefetch-depth", type=int, default=2, help="batches the input-pipeline thread keeps in flight")
     ap.add_argument("--phases", action="store_true", help="diagnostic: host issue time and synchronised wall time per phase (stderr)")
     ap.add_argument("--pyprofile", action="store_true", help="cProfile the timed steps (host-overhead hunting; prints to stderr)")
@@ -96,7 +98,7 @@ def build_step(args, device, rank, world):
         def produce(i):
             feats, coords = voxelize(pool[i % n_pool])
             if args.prefetch > 1:
-                spconv.attach_rulebooks(coords, spconv.build_rulebooks(recipe, coords, args.batch))
+                spconv.attach_rulebooks(coords, spconv.build_rulebooks(recipe, coords, args.batch, pair_lists=bool(args.pair_lists)))
             return feats, coords
 
         pre = BatchPrefetcher(produce, device)
@@ -255,6 +257,8 @@ def main():
     import fv2p_native
     fv2p_native.lib()
 
+    if args.switch_interval > 0:
+        sys.setswitchinterval(args.switch_interval)
     model, step, voxelize, pool = build_step(args, device, rank, world)
     for i in range(args.warmup):
         step(i)

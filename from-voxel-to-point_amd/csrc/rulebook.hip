@@ -184,12 +184,16 @@ __global__ __launch_bounds__(256) void rb_pair_counts(const int* __restrict__ ta
 }
 // offs = exclusive scan of cnt over the flattened [K][nblk] array; row start of k = offs[k*nblk]
 __global__ __launch_bounds__(256) void rb_pair_write(const int* __restrict__ tab, int n, int nblk, const int* __restrict__ offs,
-                                                     int* __restrict__ pairs, int64_t ld /* row length of pairs */) {
+                                                     int* __restrict__ pairs, int64_t ld /* row length of pairs */,
+                                                     int* __restrict__ pair_num /* [K] or null */) {
   const int k = blockIdx.y;
   const int base = blockIdx.x * kPairTile;
   __shared__ int wave_cnt[4];
   __shared__ int run;
-  if (threadIdx.x == 0) run = offs[k * nblk + blockIdx.x] - offs[k * nblk];
+  if (threadIdx.x == 0) {
+    run = offs[k * nblk + blockIdx.x] - offs[k * nblk];
+    if (pair_num && blockIdx.x == 0) pair_num[k] = offs[(k + 1) * nblk] - offs[k * nblk];  // offs has K*nblk + 1 entries
+  }
   __syncthreads();
   const int w = threadIdx.x >> 6;
   for (int j = 0; j < 4; ++j) {
@@ -379,11 +383,14 @@ extern "C" size_t fv2p_rulebook_pairs_ws_bytes(int64_t n_in, int kvol) {
   return s.bytes();
 }
 
-extern "C" int fv2p_rulebook_pairs(const int* tab_in, int64_t n_in, int kvol, int* pairs, void* ws, size_t ws_bytes,
-                                   fv2p_stream_t stream_) {
+extern "C" int fv2p_rulebook_pairs(const int* tab_in, int64_t n_in, int kvol, int pad, int* pairs, int* pair_num, void* ws,
+                                   size_t ws_bytes, fv2p_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   FV2P_REQUIRE(kvol >= 1 && n_in >= 0, FV2P_EINVAL, "rulebook_pairs: bad sizes");
-  if (n_in == 0) return 0;
+  if (n_in == 0) {
+    if (pair_num) FV2P_HIP(hipMemsetAsync(pair_num, 0, sizeof(int) * kvol, stream));
+    return 0;
+  }
   FV2P_REQUIRE(tab_in && pairs, FV2P_EINVAL, "rulebook_pairs: null pointer");
   FV2P_REQUIRE(ws && ws_bytes >= fv2p_rulebook_pairs_ws_bytes(n_in, kvol), FV2P_EWORKSPACE, "rulebook_pairs: workspace too small");
   const int nblk = static_cast<int>(ceil_div(n_in, kPairTile));
@@ -391,10 +398,13 @@ extern "C" int fv2p_rulebook_pairs(const int* tab_in, int64_t n_in, int kvol, in
   int* cnt = c.take<int>(static_cast<size_t>(kvol) * nblk + 1);
   const size_t sb = scan_ws_bytes(static_cast<int64_t>(kvol) * nblk + 1);
   char* sws = c.take<char>(sb);
-  FV2P_HIP(hipMemsetAsync(pairs, 0xFF, sizeof(int) * 2 * (size_t)kvol * n_in, stream));  // -1 padding, spconv_ops.h:55-57
+  FillJobs fill;
+  if (pad) fill.add(pairs, sizeof(int) * 2 * (size_t)kvol * n_in, 0xFFFFFFFFu);  // -1 padding, spconv_ops.h:55-57
+  fill.add(cnt + static_cast<size_t>(kvol) * nblk, sizeof(int), 0u);            // the scan's extra entry = total
+  if (int rc = multi_fill(fill, stream)) return rc;
   hipLaunchKernelGGL(rb_pair_counts, dim3(nblk, kvol), dim3(256), 0, stream, tab_in, (int)n_in, nblk, cnt);
-  if (int rc = exclusive_scan_i32(cnt, cnt, static_cast<int64_t>(kvol) * nblk, nullptr, sws, sb, stream)) return rc;
-  hipLaunchKernelGGL(rb_pair_write, dim3(nblk, kvol), dim3(256), 0, stream, tab_in, (int)n_in, nblk, cnt, pairs, n_in);
+  if (int rc = exclusive_scan_i32(cnt, cnt, static_cast<int64_t>(kvol) * nblk + 1, nullptr, sws, sb, stream)) return rc;
+  hipLaunchKernelGGL(rb_pair_write, dim3(nblk, kvol), dim3(256), 0, stream, tab_in, (int)n_in, nblk, cnt, pairs, n_in, pair_num);
   FV2P_LAUNCH_CHECK();
   return 0;
 }

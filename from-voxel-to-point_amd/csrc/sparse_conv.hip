@@ -779,6 +779,150 @@ __global__ __launch_bounds__(256) void conv_wgrad(WgradArgs a, float* __restrict
   }
 }
 
+// ---- weight gradient from pair lists ---------------------------------------------------------------------------
+// Same staged gather + MFMA as conv_wgrad, but the valid (source row, gradient row) pairs come from the rulebook's
+// compacted pair lists (the reference's indice_pairs [K][2][n] + indice_pair_num [K], spconv_ops.h:403-455 walks the
+// same lists): no per-launch compaction prologue, every workgroup gets kPairsPerChunk real pairs whatever the offset's
+// density (the dense centre offset of a submanifold conv needs no launch of its own), and workgroups past an offset's
+// pair count exit at once.  The pair lists are built once per rulebook, off the training stream when prefetched.
+constexpr int kPairsPerChunk = 512;
+
+struct WgradPairArgs {
+  const float* src; int ld_src; int c_src;     // operand indexed by pairs[k][side_src]
+  const float* grad; int ld_grad; int c_grad;  // operand indexed by pairs[k][1 - side_src]
+  const int* pairs; long long pair_len;         // [kvol][2][pair_len]
+  const int* pair_num;                          // [kvol]
+  int side_src;                                 // 0: src rows are pairs[k][0] (forward conv), 1: pairs[k][1] (inverse conv)
+  int kvol;
+};
+
+template <int MB, int NB>
+__global__ __launch_bounds__(256) void conv_wgrad_pairs(WgradPairArgs a, float* __restrict__ partial) {
+  constexpr int CINP = MB * 16, COUTP = NB * 16;
+  constexpr int kWgStage = (MB * NB >= 64) ? 32 : 64;
+  constexpr int MBW = MB >= 4 ? MB / 4 : 1;
+  constexpr int LDF = CINP + 4, LDG = COUTP + 4;
+  constexpr int RF = (kWgStage * CINP / 4 + 255) / 256, RG = (kWgStage * COUTP / 4 + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* F = lds;
+  float* G = F + kWgStage * LDF;
+  int* s_src = reinterpret_cast<int*>(G + kWgStage * LDG);  // [kPairsPerChunk]
+  int* s_row = s_src + kPairsPerChunk;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, m = lane & 15, g = lane >> 4;
+  const int k = blockIdx.y;
+  const int total = a.pair_num[k];
+  const int p_begin = blockIdx.x * kPairsPerChunk;
+  if (p_begin >= total) return;  // whole workgroup
+  const int cnt = min(kPairsPerChunk, total - p_begin);
+  {
+    const int* pa = a.pairs + (static_cast<long long>(k) * 2 + a.side_src) * a.pair_len + p_begin;
+    const int* pb = a.pairs + (static_cast<long long>(k) * 2 + 1 - a.side_src) * a.pair_len + p_begin;
+    for (int e = tid; e < cnt; e += 256) { s_src[e] = pa[e]; s_row[e] = pb[e]; }
+  }
+  __syncthreads();
+  f32x4 acc[MBW][NB];
+#pragma unroll
+  for (int i = 0; i < MBW; ++i)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[i][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float4 rf[RF], rg[RG];
+  auto fetch = [&](int p0) {
+#pragma unroll
+    for (int u = 0; u < RF; ++u) {
+      const int e = tid + u * 256, pr = e / (CINP / 4), c = (e % (CINP / 4)) * 4;
+      const int sr = (pr < kWgStage && p0 + pr < cnt) ? s_src[p0 + pr] : -1;
+      rf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (sr >= 0 && c < a.c_src) {
+        const float* q = a.src + static_cast<long long>(sr) * a.ld_src + c;
+        if (c + 3 < a.c_src && (a.ld_src & 3) == 0) rf[u] = *reinterpret_cast<const float4*>(q);
+        else { rf[u].x = q[0]; if (c + 1 < a.c_src) rf[u].y = q[1]; if (c + 2 < a.c_src) rf[u].z = q[2]; if (c + 3 < a.c_src) rf[u].w = q[3]; }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RG; ++u) {
+      const int e = tid + u * 256, pr = e / (COUTP / 4), c = (e % (COUTP / 4)) * 4;
+      const int rr = (pr < kWgStage && p0 + pr < cnt) ? s_row[p0 + pr] : -1;
+      rg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rr >= 0 && c < a.c_grad) {
+        const float* q = a.grad + static_cast<long long>(rr) * a.ld_grad + c;
+        if (c + 3 < a.c_grad && (a.ld_grad & 3) == 0) rg[u] = *reinterpret_cast<const float4*>(q);
+        else { rg[u].x = q[0]; if (c + 1 < a.c_grad) rg[u].y = q[1]; if (c + 2 < a.c_grad) rg[u].z = q[2]; if (c + 3 < a.c_grad) rg[u].w = q[3]; }
+      }
+    }
+  };
+  auto park = [&]() {
+#pragma unroll
+    for (int u = 0; u < RF; ++u) {
+      const int e = tid + u * 256, pr = e / (CINP / 4), c = (e % (CINP / 4)) * 4;
+      if (pr < kWgStage) *reinterpret_cast<float4*>(&F[pr * LDF + c]) = rf[u];
+    }
+#pragma unroll
+    for (int u = 0; u < RG; ++u) {
+      const int e = tid + u * 256, pr = e / (COUTP / 4), c = (e % (COUTP / 4)) * 4;
+      if (pr < kWgStage) *reinterpret_cast<float4*>(&G[pr * LDG + c]) = rg[u];
+    }
+  };
+  fetch(0);
+  for (int p0 = 0; p0 < cnt; p0 += kWgStage) {
+    __syncthreads();
+    park();
+    __syncthreads();
+    if (p0 + kWgStage < cnt) fetch(p0 + kWgStage);
+    const int npair = min(kWgStage, cnt - p0);
+    if (w * MBW < MB) {
+      for (int sl = 0; sl * 4 < npair; ++sl) {
+        const int pr = sl * 4 + g;
+        float av[MBW], bv[NB];
+#pragma unroll
+        for (int i = 0; i < MBW; ++i) av[i] = F[pr * LDF + (w * MBW + i) * 16 + m];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) bv[nb] = G[pr * LDG + nb * 16 + m];
+#pragma unroll
+        for (int i = 0; i < MBW; ++i)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[nb], acc[i][nb], 0, 0, 0);
+      }
+    }
+  }
+  if (w * MBW < MB) {
+    float* out = partial + (static_cast<long long>(blockIdx.x) * a.kvol + k) * a.c_src * a.c_grad;
+#pragma unroll
+    for (int i = 0; i < MBW; ++i)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int cr = (w * MBW + i) * 16 + g * 4 + reg, cc = nb * 16 + m;
+          if (cr < a.c_src && cc < a.c_grad) out[static_cast<long long>(cr) * a.c_grad + cc] = acc[i][nb][reg];
+        }
+  }
+}
+
+// Fixed-order sum of the tiles of the chunks that exist for each offset: ceil(pair_num[k] / kPairsPerChunk).
+__global__ __launch_bounds__(256) void wgrad_reduce_pairs(const float* __restrict__ partial, const int* __restrict__ pair_num, int kvol,
+                                                          int c_src, int c_grad, float* __restrict__ dw, long long dw_kstride, int dw_ld) {
+  __shared__ float part[16][17];
+  const int e = threadIdx.x & 15, cg = threadIdx.x >> 4;
+  const long long per_chunk = static_cast<long long>(kvol) * c_src * c_grad;
+  const long long t = static_cast<long long>(blockIdx.x) * 16 + e;
+  float s = 0.f;
+  int k = 0;
+  if (t < per_chunk) {
+    k = static_cast<int>(t / (static_cast<long long>(c_grad) * c_src));
+    const int chunks = (pair_num[k] + kPairsPerChunk - 1) / kPairsPerChunk;
+    for (int c = cg; c < chunks; c += 16) s += partial[c * per_chunk + t];
+  }
+  part[cg][e] = s;
+  __syncthreads();
+  if (cg == 0 && t < per_chunk) {
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tot += part[q][e];
+    const int cc = static_cast<int>(t % c_grad), cr = static_cast<int>((t / c_grad) % c_src);
+    dw[k * dw_kstride + static_cast<long long>(cr) * dw_ld + cc] = tot;
+  }
+}
+
 // Sums the per-chunk tiles in a fixed order.  A workgroup covers 16 consecutive elements x 16 chunk groups (64-byte
 // coalesced reads, chunks/16 independent loads per thread), then folds the 16 partial sums through LDS.
 __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ partial, int chunks, int k_base, int k_count, int c_src,
@@ -1016,6 +1160,65 @@ extern "C" int fv2p_sparse_conv_wgrad(const float* src, int64_t n_src, int c_src
                          a.k_count, cs, cd, a.dw, a.dw_kstride, a.dw_ld, a.skip_k);
     }
    }
+  }
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int MB, int NB>
+static void wgrad_pairs_launch(const WgradPairArgs& a, float* partial, unsigned chunks, hipStream_t stream) {
+  const dim3 grid(chunks, static_cast<unsigned>(a.kvol), 1), block(256);
+  constexpr int stage = (MB * NB >= 64) ? 32 : 64;
+  const size_t lds = static_cast<size_t>(stage) * (MB * 16 + 4 + NB * 16 + 4) * sizeof(float) + 2 * kPairsPerChunk * sizeof(int);
+  hipLaunchKernelGGL((conv_wgrad_pairs<MB, NB>), grid, block, lds, stream, a, partial);
+}
+
+extern "C" size_t fv2p_sparse_conv_wgrad_pairs_ws_bytes(int64_t pair_len, int c_src, int c_dst, int kvol) {
+  const int cs = c_src < 128 ? c_src : 128, cd = c_dst < 128 ? c_dst : 128;
+  Sizer s;
+  s.take<float>(static_cast<size_t>(ceil_div(pair_len > 0 ? pair_len : 1, kPairsPerChunk)) * kvol * cs * cd);
+  return s.bytes();
+}
+
+extern "C" int fv2p_sparse_conv_wgrad_pairs(const float* src, int64_t n_src, int c_src, const float* grad, int64_t n_grad, int c_dst,
+                                            const int* pairs, const int* pair_num, int kvol, int64_t pair_len, int side_src,
+                                            float* dweight, void* ws, size_t ws_bytes, fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FV2P_REQUIRE(c_src >= 1 && c_dst >= 1 && kvol >= 1 && pair_len >= 0 && (side_src == 0 || side_src == 1), FV2P_EINVAL,
+               "sparse_conv_wgrad_pairs: bad sizes");
+  FV2P_REQUIRE(dweight, FV2P_EINVAL, "sparse_conv_wgrad_pairs: null dweight");
+  if (pair_len == 0 || n_src == 0 || n_grad == 0) {
+    FV2P_HIP(hipMemsetAsync(dweight, 0, sizeof(float) * (size_t)kvol * c_src * c_dst, stream));
+    return 0;
+  }
+  FV2P_REQUIRE(src && grad && pairs && pair_num, FV2P_EINVAL, "sparse_conv_wgrad_pairs: null pointer");
+  FV2P_REQUIRE(ws && ws_bytes >= fv2p_sparse_conv_wgrad_pairs_ws_bytes(pair_len, c_src, c_dst, kvol), FV2P_EWORKSPACE,
+               "sparse_conv_wgrad_pairs: workspace too small");
+  const unsigned chunks = static_cast<unsigned>(ceil_div(pair_len, kPairsPerChunk));
+  for (int d0 = 0; d0 < c_dst; d0 += 128) {
+    const int cd = (c_dst - d0) < 128 ? (c_dst - d0) : 128;
+    for (int s0 = 0; s0 < c_src; s0 += 128) {
+      const int cs = (c_src - s0) < 128 ? (c_src - s0) : 128;
+      Carver c(ws, ws_bytes);
+      float* partial = c.take<float>(static_cast<size_t>(chunks) * kvol * cs * cd);
+      WgradPairArgs a;
+      a.src = src + s0; a.ld_src = c_src; a.c_src = cs;
+      a.grad = grad + d0; a.ld_grad = c_dst; a.c_grad = cd;
+      a.pairs = pairs; a.pair_len = pair_len; a.pair_num = pair_num; a.side_src = side_src; a.kvol = kvol;
+      const int mb = static_cast<int>(ceil_div(cs, 16)), nb = static_cast<int>(ceil_div(cd, 16));
+      const int nbp = nb <= 1 ? 1 : nb <= 2 ? 2 : nb <= 4 ? 4 : 8;
+      const int mbp = mb <= 1 ? 1 : mb <= 2 ? 2 : mb <= 4 ? 4 : 8;
+#define FV2P_WGP(MB, NB) wgrad_pairs_launch<MB, NB>(a, partial, chunks, stream)
+#define FV2P_WGP_NB(MB)                                                                    \
+      switch (nbp) { case 1: FV2P_WGP(MB, 1); break; case 2: FV2P_WGP(MB, 2); break;      \
+                     case 4: FV2P_WGP(MB, 4); break; default: FV2P_WGP(MB, 8); break; }
+      switch (mbp) { case 1: FV2P_WGP_NB(1) break; case 2: FV2P_WGP_NB(2) break; case 4: FV2P_WGP_NB(4) break; default: FV2P_WGP_NB(8) break; }
+#undef FV2P_WGP_NB
+#undef FV2P_WGP
+      const long long per_chunk = static_cast<long long>(kvol) * cs * cd;
+      hipLaunchKernelGGL(wgrad_reduce_pairs, dim3(static_cast<unsigned>(ceil_div(per_chunk, 16))), dim3(256), 0, stream, partial, pair_num, kvol,
+                         cs, cd, dweight + static_cast<long long>(s0) * c_dst + d0, static_cast<long long>(c_src) * c_dst, c_dst);
+    }
   }
   FV2P_LAUNCH_CHECK();
   return 0;

@@ -50,7 +50,8 @@ void require_f32_cuda(const at::Tensor& t, const char* name) {
 // ---- sparse convolution: out[r] = sum_k feat[tab_f[k][r]] . W_k ------------------------------------------------------
 struct SparseConvFn : public torch::autograd::Function<SparseConvFn> {
   static at::Tensor forward(AutogradContext* ctx, const at::Tensor& features_, const at::Tensor& weight_, const at::Tensor& tab_f,
-                            int64_t flip_f, const at::Tensor& tab_b, int64_t flip_b, int64_t n_out, int64_t centre) {
+                            int64_t flip_f, const at::Tensor& tab_b, int64_t flip_b, int64_t n_out, int64_t centre,
+                            const c10::optional<at::Tensor>& pairs, const c10::optional<at::Tensor>& pair_num, int64_t side_src) {
     require_f32_cuda(features_, "features");
     require_f32_cuda(weight_, "weight");
     const at::Tensor features = features_.contiguous(), weight = weight_.contiguous();
@@ -64,7 +65,9 @@ struct SparseConvFn : public torch::autograd::Function<SparseConvFn> {
                                 static_cast<int>(kvol), tab_f.data_ptr<int>(), n_out, static_cast<int>(cout), static_cast<int>(flip_f), 0,
                                 nullptr, out.data_ptr<float>(), stream),
           "fv2p_sparse_conv_rows");
-    ctx->save_for_backward({features, weight, tab_f, tab_b});
+    const bool have_pairs = pairs.has_value() && pairs->defined() && pair_num.has_value() && pair_num->defined();
+    ctx->save_for_backward({features, weight, tab_f, tab_b, have_pairs ? *pairs : at::Tensor(), have_pairs ? *pair_num : at::Tensor()});
+    ctx->saved_data["side_src"] = side_src;
     ctx->saved_data["flip_f"] = flip_f;
     ctx->saved_data["flip_b"] = flip_b;
     ctx->saved_data["centre"] = centre;
@@ -73,7 +76,7 @@ struct SparseConvFn : public torch::autograd::Function<SparseConvFn> {
 
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
     const auto saved = ctx->get_saved_variables();
-    const at::Tensor &features = saved[0], &weight = saved[1], &tab_f = saved[2], &tab_b = saved[3];
+    const at::Tensor &features = saved[0], &weight = saved[1], &tab_f = saved[2], &tab_b = saved[3], &pairs = saved[4], &pair_num = saved[5];
     const at::Tensor g = grads[0].contiguous();
     const int64_t cin = weight.size(-2), cout = weight.size(-1);
     const int64_t kvol = weight.numel() / (cin * cout);
@@ -90,20 +93,32 @@ struct SparseConvFn : public torch::autograd::Function<SparseConvFn> {
     }
     if (ctx->needs_input_grad(1)) {
       dw = at::empty_like(weight);
-      const size_t wsb = fv2p_sparse_conv_wgrad_ws_bytes(g.size(0), static_cast<int>(cin), static_cast<int>(cout), static_cast<int>(kvol));
-      at::Tensor ws = workspace(wsb, features, stream);
-      check(fv2p_sparse_conv_wgrad(features.data_ptr<float>(), features.size(0), static_cast<int>(cin), g.data_ptr<float>(), tab_f.data_ptr<int>(),
-                                   g.size(0), static_cast<int>(cout), static_cast<int>(kvol), flip_f, centre, dw.data_ptr<float>(), ws.data_ptr(),
-                                   static_cast<size_t>(ws.numel()), stream),
-            "fv2p_sparse_conv_wgrad");
+      if (pairs.defined()) {  // compacted pair lists of the rulebook: balanced by pairs, no compaction prologue
+        const int64_t plen = pairs.size(2);
+        const size_t wsb = fv2p_sparse_conv_wgrad_pairs_ws_bytes(plen, static_cast<int>(cin), static_cast<int>(cout), static_cast<int>(kvol));
+        at::Tensor ws = workspace(wsb, features, stream);
+        check(fv2p_sparse_conv_wgrad_pairs(features.data_ptr<float>(), features.size(0), static_cast<int>(cin), g.data_ptr<float>(), g.size(0),
+                                           static_cast<int>(cout), pairs.data_ptr<int>(), pair_num.data_ptr<int>(), static_cast<int>(kvol), plen,
+                                           static_cast<int>(ctx->saved_data["side_src"].toInt()), dw.data_ptr<float>(), ws.data_ptr(),
+                                           static_cast<size_t>(ws.numel()), stream),
+              "fv2p_sparse_conv_wgrad_pairs");
+      } else {
+        const size_t wsb = fv2p_sparse_conv_wgrad_ws_bytes(g.size(0), static_cast<int>(cin), static_cast<int>(cout), static_cast<int>(kvol));
+        at::Tensor ws = workspace(wsb, features, stream);
+        check(fv2p_sparse_conv_wgrad(features.data_ptr<float>(), features.size(0), static_cast<int>(cin), g.data_ptr<float>(), tab_f.data_ptr<int>(),
+                                     g.size(0), static_cast<int>(cout), static_cast<int>(kvol), flip_f, centre, dw.data_ptr<float>(), ws.data_ptr(),
+                                     static_cast<size_t>(ws.numel()), stream),
+              "fv2p_sparse_conv_wgrad");
+      }
     }
-    return {din, dw, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+    return {din, dw, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
   }
 };
 
 at::Tensor sparse_conv(const at::Tensor& features, const at::Tensor& weight, const at::Tensor& tab_f, int64_t flip_f, const at::Tensor& tab_b,
-                       int64_t flip_b, int64_t n_out, int64_t centre) {
-  return SparseConvFn::apply(features, weight, tab_f, flip_f, tab_b, flip_b, n_out, centre);
+                       int64_t flip_b, int64_t n_out, int64_t centre, const c10::optional<at::Tensor>& pairs,
+                       const c10::optional<at::Tensor>& pair_num, int64_t side_src) {
+  return SparseConvFn::apply(features, weight, tab_f, flip_f, tab_b, flip_b, n_out, centre, pairs, pair_num, side_src);
 }
 
 // ---- BatchNorm1d (+ReLU) on [N, C] ---------------------------------------------------------------------------------------

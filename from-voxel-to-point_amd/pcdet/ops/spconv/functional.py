@@ -123,7 +123,9 @@ def _dispatch(fn_cls):
             rb = ops._rulebook_of(indice_pairs, indice_pair_num, features.shape[0], num_activate_out, fn_cls.INVERSE)
             (tab_f, flip_f), (tab_b, flip_b) = (rb.in_table(), rb.out_table()) if fn_cls.INVERSE else (rb.out_table(), rb.in_table())
             centre = (rb.kvol // 2) if (rb.subm and rb.tab_out is None and not fn_cls.INVERSE) else -1
-            return ext.sparse_conv(features, filters, tab_f, flip_f, tab_b, flip_b, num_activate_out, centre)
+            have = rb._wpairs is not None and rb._num is not None   # pair lists already materialised (prefetch): pair-split wgrad
+            return ext.sparse_conv(features, filters, tab_f, flip_f, tab_b, flip_b, num_activate_out, centre,
+                                   rb._wpairs if have else None, rb._num if have else None, 1 if fn_cls.INVERSE else 0)
         return fn_cls.apply(features, filters, indice_pairs, indice_pair_num, num_activate_out)
 
     call.__name__ = fn_cls.__name__ + "_apply"

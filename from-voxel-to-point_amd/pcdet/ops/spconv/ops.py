@@ -51,6 +51,7 @@ class Rulebook(object):
         self.kvol, self.subm = kvol, subm
         self.n_in, self.n_out = int(indices.shape[0]), int(outids.shape[0])
         self._pairs = None
+        self._wpairs = None   # compacted pair lists for the weight gradient (== _pairs once that exists)
 
     # -- tables as the kernels want them: (table, flip_k)
     def out_table(self):
@@ -77,10 +78,28 @@ class Rulebook(object):
                 with _nat.device_guard(pairs.device):
                     nb = _nat.lib().fv2p_rulebook_pairs_ws_bytes(self.n_in, self.kvol)
                     ws = _nat.workspace(nb, pairs.device)
-                    _nat.call("fv2p_rulebook_pairs", self.tab_in, self.n_in, self.kvol, pairs, ws, ws.numel(), _nat.stream())
+                    num = self._num
+                    if num is None:
+                        num = torch.empty((self.kvol,), dtype=torch.int32, device=pairs.device)
+                    _nat.call("fv2p_rulebook_pairs", self.tab_in, self.n_in, self.kvol, 1, pairs, num, ws, ws.numel(), _nat.stream())
+                    self._num = num
             pairs._fv2p_rulebook = self
             self._pairs = pairs
+            self._wpairs = pairs
         return self._pairs
+
+    def wgrad_pairs(self):
+        """(pairs [K,2,n_in], pair_num [K]) for the pair-split weight gradient: the compacted lists without the -1
+        padding pass (not handed out as `indice_pairs`).  None for empty rulebooks."""
+        if self._wpairs is None and self.n_in > 0:
+            dev = self.tab_in.device
+            pairs = torch.empty((self.kvol, 2, self.n_in), dtype=torch.int32, device=dev)
+            num = self._num if self._num is not None else torch.empty((self.kvol,), dtype=torch.int32, device=dev)
+            with _nat.device_guard(dev):
+                ws = _nat.workspace(_nat.lib().fv2p_rulebook_pairs_ws_bytes(self.n_in, self.kvol), dev)
+                _nat.call("fv2p_rulebook_pairs", self.tab_in, self.n_in, self.kvol, 0, pairs, num, ws, ws.numel(), _nat.stream())
+            self._num, self._wpairs = num, pairs
+        return self._wpairs
 
     def _tuple(self):
         return (self.outids, self.indices, self.indice_pairs, self.indice_pair_num, self.spatial_shape)
@@ -186,7 +205,7 @@ def _rulebook_of(indice_pairs, indice_pair_num, n_src_rows, num_activate_out, in
     rb = Rulebook.__new__(Rulebook)
     rb.outids = rb.indices = None
     rb.tab_in, rb.tab_out, rb._num = tab_in, tab_out, num
-    rb.spatial_shape, rb.kvol, rb.subm, rb.n_in, rb.n_out, rb._pairs = None, kvol, False, n_in, n_out, pairs
+    rb.spatial_shape, rb.kvol, rb.subm, rb.n_in, rb.n_out, rb._pairs, rb._wpairs = None, kvol, False, n_in, n_out, pairs, pairs
     indice_pairs._fv2p_rulebook = rb
     return rb
 
@@ -236,13 +255,21 @@ def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_nu
     din = _conv_rows(g, w, tab_b, flip_b, features.shape[0], cin, True)
     dw = torch.empty_like(w)
     with _nat.device_guard(feats.device):
-        wsb = _nat.lib().fv2p_sparse_conv_wgrad_ws_bytes(g.shape[0], cin, cout, kvol)
-        ws = _nat.workspace(wsb, feats.device)
-        # submanifold conv: the centre offset pairs every row with itself (spconv_ops.h:398-402 treats it un-gathered too);
-        # the kernel gives that dense offset its own finely chunked pass
-        centre = (kvol // 2) if (rb.subm and rb.tab_out is None and not inverse) else -1
-        _nat.call("fv2p_sparse_conv_wgrad", feats, feats.shape[0], cin, g, tab_f, g.shape[0], cout, kvol, int(flip_f), centre, dw, ws,
-                  ws.numel(), _nat.stream())
+        if rb._wpairs is not None and rb._num is not None:
+            # pair lists already materialised: work split by pairs, no compaction prologue
+            pairs, num = rb._wpairs, rb._num
+            wsb = _nat.lib().fv2p_sparse_conv_wgrad_pairs_ws_bytes(pairs.shape[2], cin, cout, kvol)
+            ws = _nat.workspace(wsb, feats.device)
+            _nat.call("fv2p_sparse_conv_wgrad_pairs", feats, feats.shape[0], cin, g, g.shape[0], cout, pairs, num, kvol, pairs.shape[2],
+                      1 if inverse else 0, dw, ws, ws.numel(), _nat.stream())
+        else:
+            wsb = _nat.lib().fv2p_sparse_conv_wgrad_ws_bytes(g.shape[0], cin, cout, kvol)
+            ws = _nat.workspace(wsb, feats.device)
+            # submanifold conv: the centre offset pairs every row with itself (spconv_ops.h:398-402 treats it un-gathered
+            # too); the kernel gives that dense offset its own finely chunked pass
+            centre = (kvol // 2) if (rb.subm and rb.tab_out is None and not inverse) else -1
+            _nat.call("fv2p_sparse_conv_wgrad", feats, feats.shape[0], cin, g, tab_f, g.shape[0], cout, kvol, int(flip_f), centre, dw, ws,
+                      ws.numel(), _nat.stream())
     dw = dw.reshape(filters.shape)
     if half:
         din, dw = din.half(), dw.half()

@@ -40,7 +40,7 @@ def rulebook_recipe(indice_dict, root_indices):
     return recipe
 
 
-def build_rulebooks(recipe, indices, batch_size):
+def build_rulebooks(recipe, indices, batch_size, pair_lists=True):
     """Replays a recipe on new root indices; returns {indice_key: Rulebook}."""
     if indices.dtype != torch.int32:
         indices = indices.int()
@@ -52,6 +52,8 @@ def build_rulebooks(recipe, indices, batch_size):
         out[key] = ops.build_rulebook(ind, batch_size, shape, list(ksize), list(stride), list(padding), list(dilation),
                                       list(out_padding), subm, transpose)
         out[key].prefetched = True
+        if pair_lists and subm:  # compacted pair lists: the weight gradient of submanifold convs splits its work by them
+            out[key].wgrad_pairs()   # (measured: a win for subm rulebooks, a loss for the sparser strided ones)
     return out
 
 

@@ -90,12 +90,13 @@ int fv2p_rulebook_finish(const int* indices, int64_t n_in, int batch, const int 
                          int* tab_in, int* tab_out, int* indice_num, void* ws, size_t ws_bytes,
                          fv2p_stream_t stream);
 int fv2p_rulebook_count(const int* tab_in, int64_t n_in, int kvol, int* indice_num, fv2p_stream_t stream);
-/* Reference-format pair lists indicePairs [K,2,n_in] (-1 padded, spconv_ops.h:55-57) from tab_in;
- * within one offset pairs are ordered by ascending input row (the CPU reference's order,
- * geometry.h:281-295; the GPU reference's slot order is atomic-order). */
+/* Reference-format pair lists indicePairs [K,2,n_in] from tab_in; within one offset pairs are ordered by ascending
+ * input row (the CPU reference's order, geometry.h:281-295; the GPU reference's slot order is atomic-order).
+ * pad != 0 fills the unused tail with -1 (spconv_ops.h:55-57); pad == 0 leaves it unwritten (enough for
+ * fv2p_sparse_conv_wgrad_pairs, which reads pair_num[k] entries).  pair_num [K] (optional) receives indiceNum. */
 size_t fv2p_rulebook_pairs_ws_bytes(int64_t n_in, int kvol);
-int fv2p_rulebook_pairs(const int* tab_in, int64_t n_in, int kvol, int* pairs, void* ws, size_t ws_bytes,
-                        fv2p_stream_t stream);
+int fv2p_rulebook_pairs(const int* tab_in, int64_t n_in, int kvol, int pad, int* pairs, int* pair_num, void* ws,
+                        size_t ws_bytes, fv2p_stream_t stream);
 /* Tables from caller-supplied pair lists [K,2,pair_len] + indice_num [K] (device). */
 int fv2p_pairs_to_tables(const int* pairs, const int* indice_num, int kvol, int64_t pair_len, int64_t n_in,
                          int64_t n_out, int* tab_in, int* tab_out, fv2p_stream_t stream);
@@ -132,6 +133,15 @@ size_t fv2p_sparse_conv_wgrad_ws_bytes(int64_t n_dst, int c_src, int c_dst, int 
 int fv2p_sparse_conv_wgrad(const float* src, int64_t n_src, int c_src, const float* grad, const int* tab,
                            int64_t n_dst, int c_dst, int kvol, int flip_k, int dense_k, float* dweight, void* ws,
                            size_t ws_bytes, fv2p_stream_t stream);
+/* The same weight gradient from the rulebook's compacted pair lists — the reference's indice_pairs [K][2][pair_len]
+ * (-1 padded) and indice_pair_num [K] (spconv_ops.h:403-455 walks the same lists; fv2p_rulebook_pairs / _count build
+ * them): dW_k = sum_{p < pair_num[k]} src[pairs[k][side_src][p], :]^T grad[pairs[k][1 - side_src][p], :].
+ * side_src = 0 for a forward / submanifold conv (src = features indexed by the input side), 1 for an inverse conv.
+ * Work is split by pairs, not rows, so dense and sparse offsets cost what their pair counts say. */
+size_t fv2p_sparse_conv_wgrad_pairs_ws_bytes(int64_t pair_len, int c_src, int c_dst, int kvol);
+int fv2p_sparse_conv_wgrad_pairs(const float* src, int64_t n_src, int c_src, const float* grad, int64_t n_grad,
+                                 int c_dst, const int* pairs, const int* pair_num, int kvol, int64_t pair_len,
+                                 int side_src, float* dweight, void* ws, size_t ws_bytes, fv2p_stream_t stream);
 
 /* ---- A7: sparse max-pool / neighbour group over the same tables ------------------------------
  * Replace sparse_conv_ext.indice_maxpool_fp32(+backward) (all.cc:52-63 -> pool_ops.h:25-94; output starts

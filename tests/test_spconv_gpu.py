@@ -316,3 +316,41 @@ def test_rulebook_prefetch_recipe_matches_inline_build_and_ignores_stale_geometr
     x4 = spconv.SparseConvTensor(torch.from_numpy(f1).to(gpu), torch.from_numpy(ind1).to(gpu), shape, batch)
     ref3 = model2(x4)
     assert torch.equal(out3.indices, ref3.indices) and torch.equal(out3.features, ref3.features)
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 64), (64, 64), (5, 16), (128, 64), (160, 144)])
+def test_weight_gradient_from_pair_lists_vs_oracle(gpu, front_end, cin, cout):
+    """fv2p_sparse_conv_wgrad_pairs (work split by the rulebook's reference-format pair lists, used once
+    indice_pairs / indice_pair_num are materialised, e.g. by the rulebook prefetch): dW of a submanifold conv, a strided
+    conv and its inverse conv against the oracle's gather -> mm loop (spconv_ops.h:403-455 restated)."""
+    batch, shape = 2, [9, 20, 18]
+    ind, feats, x = make_input(cin * 3 + cout, batch, shape, 1300, cin, gpu)
+    torch.manual_seed(0)
+    net = spconv.SparseSequential(
+        spconv.SubMConv3d(cin, cout, 3, padding=1, bias=False, indice_key="s"),
+        spconv.SparseConv3d(cout, cout, 3, stride=2, padding=1, bias=False, indice_key="d"),
+        spconv.SparseInverseConv3d(cout, cin, 3, indice_key="d", bias=False)).to(gpu)
+    with torch.no_grad():
+        net(x)                                       # fills x.indice_dict
+    for i, rb in enumerate(x.indice_dict.values()):
+        if i == 0:
+            rb.wgrad_pairs()                         # compacted lists without the -1 padding pass
+        else:
+            rb.indice_pairs, rb.indice_pair_num      # reference-format lists; either way the backward takes the pair-list kernel
+        assert rb._wpairs is not None and rb._num is not None
+    x.features.requires_grad_(True)
+    y = net(x)
+    g = np.random.default_rng(5).standard_normal(tuple(y.features.shape)).astype(np.float32)
+    y.features.backward(torch.from_numpy(g).to(gpu))
+    # oracle chain
+    w = [m.weight.detach().cpu().numpy() for m in net]
+    _, p_s, n_s = oracle.indice_pairs(ind, batch, shape, [3, 3, 3], [1, 1, 1], [1, 1, 1], [1, 1, 1], subm=True)
+    out_d, p_d, n_d = oracle.indice_pairs(ind, batch, shape, [3, 3, 3], [2, 2, 2], [1, 1, 1], [1, 1, 1])
+    f1 = oracle.indice_conv(feats, w[0], p_s, n_s, ind.shape[0], subm=True).numpy()
+    f2 = oracle.indice_conv(f1, w[1], p_d, n_d, out_d.shape[0]).numpy()
+    d2, dw2 = oracle.indice_conv_backward(f2, w[2], g, p_d, n_d, inverse=True)
+    d1, dw1 = oracle.indice_conv_backward(f1, w[1], d2.numpy(), p_d, n_d)
+    d0, dw0 = oracle.indice_conv_backward(feats, w[0], d1.numpy(), p_s, n_s, subm=True)
+    for m, ref in zip(net, (dw0, dw1, dw2)):
+        assert rel_err(m.weight.grad.cpu().numpy(), ref.numpy()) < RTOL
+    assert rel_err(x.features.grad.cpu().numpy(), d0.numpy()) < RTOL

@@ -93,7 +93,7 @@ def conv(only=None):
             print(f"block duration (shader clocks): min {dur.min():.0f} median {np.median(dur):.0f} max {dur.max():.0f}; "
                   f"span first start -> last end {t1.max() - t0.min()} clocks; starts spread {t0.max() - t0.min()}")
         return
-    print(f"{'layer':34s} {'n_in':>6s} {'n_out':>6s} {'pairs':>8s} {'fwd us':>8s} {'TF/s':>6s} {'dX us':>8s} {'dW us':>8s} {'TF/s':>6s}")
+    print(f"{'layer':34s} {'n_in':>6s} {'n_out':>6s} {'pairs':>8s} {'fwd us':>8s} {'TF/s':>6s} {'dX us':>8s} {'dW us':>8s} {'TF/s':>6s} {'dWpair':>8s} {'TF/s':>6s}")
     for mod, f, rb, n_out in recs:
         w = mod.weight.detach()
         p = int(rb.indice_pair_num.sum().item())
@@ -103,10 +103,14 @@ def conv(only=None):
         w3 = w.reshape(-1, cin, cout)
         tab_b, flip_b = rb.in_table()
         t_dx = timeit(lambda: ops._conv_rows(g, w3, tab_b, flip_b, f.shape[0], cin, True))
+        pairs_saved, rb._wpairs = rb._wpairs, None     # table-based weight gradient
         t_all = timeit(lambda: ops.indice_conv_backward(f, w, g, rb, None, False, mod.subm))
+        rb._wpairs = pairs_saved
+        rb.wgrad_pairs()                                 # pair-list weight gradient
+        t_allp = timeit(lambda: ops.indice_conv_backward(f, w, g, rb, None, False, mod.subm))
         fl = 2.0 * p * cin * cout
         name = f"{'subm' if mod.subm else 'conv'} {cin}->{cout} {mod.indice_key}"
-        print(f"{name:34s} {f.shape[0]:6d} {n_out:6d} {p:8d} {t_f:8.1f} {fl / t_f / 1e6:6.1f} {t_dx:8.1f} {t_all - t_dx:8.1f} {fl / max(t_all - t_dx, 1e-3) / 1e6:6.1f}")
+        print(f"{name:34s} {f.shape[0]:6d} {n_out:6d} {p:8d} {t_f:8.1f} {fl / t_f / 1e6:6.1f} {t_dx:8.1f} {t_all - t_dx:8.1f} {fl / max(t_all - t_dx, 1e-3) / 1e6:6.1f} {t_allp - t_dx:8.1f} {fl / max(t_allp - t_dx, 1e-3) / 1e6:6.1f}")
     # rulebook build timings
     x = torch.cat(coords)
     for subm, k, s, p in [(True, 3, 1, 1), (False, 3, 2, 1)]:
