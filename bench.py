@@ -132,7 +132,11 @@ def build_step(args, device, rank, world):
             a[0] += t1 - t0
             a[1] += t2 - t0
             return r
-        feats, coords = phase("voxelise+vfe", lambda: voxelize(pool[i % n_pool]))
+        if pre is None:
+            feats, coords = phase("voxelise+vfe", lambda: voxelize(pool[i % n_pool]))
+        else:  # input pipeline off the clock here: this mode times the training thread's phases
+            pre.submit(i)
+            feats, coords = pre.get()
         loss = phase("forward", lambda: net(feats, coords, args.batch))
         opt.zero_grad(set_to_none=True)
         phase("backward", lambda: loss.backward())

@@ -898,6 +898,104 @@ __global__ __launch_bounds__(256) void conv_wgrad_pairs(WgradPairArgs a, float* 
   }
 }
 
+// LDS-DMA variant for 64 / 128 channels on both sides (AS = c_src / 64, BS = c_grad / 64).  The pair rows of a stage are
+// gathered straight into LDS by `global_load_lds_dwordx4` (lane l of a piece covers 16 bytes of row l / 16: whole 256-byte
+// rows, no staging registers, no ds_write pass), double buffered, one barrier per stage.  MFMA operands come from LDS as
+// the 16 bytes a lane owns: lane (m, g) reads unit m of pair row 4*sl + g — for the gradient side all four components
+// (four MFMAs, output columns 4m + {0..3}), for the feature side component w of wave w (output rows 4m + w): one
+// ds_read_b128 + one ds_read_b32 per four MFMAs instead of five ds_read_b32.  A lane therefore owns runs of four
+// adjacent dW columns and the partial tile is written with float4 stores.
+template <int AS, int BS, int ST>
+__global__ __launch_bounds__(256) void conv_wgrad_pairs_dma(WgradPairArgs a, float* __restrict__ partial) {
+  constexpr int CS = AS * 64, CG = BS * 64;             // ST = pairs per stage
+  constexpr int ROWF = CS, ROWG = CG;                   // floats per staged row
+  constexpr int STAGE = ST * (ROWF + ROWG);             // floats per stage buffer
+  constexpr int PF = ST * (CS / 4) / 64, PG = ST * (CG / 4) / 64;  // DMA pieces (64 lanes x 16 B) per stage
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int* s_src = reinterpret_cast<int*>(lds + 2 * STAGE);
+  int* s_row = s_src + kPairsPerChunk;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), m = lane & 15, g = lane >> 4;
+  const int k = blockIdx.y;
+  const int total = a.pair_num[k];
+  const int p_begin = blockIdx.x * kPairsPerChunk;
+  if (p_begin >= total) return;  // whole workgroup
+  const int cnt = min(kPairsPerChunk, total - p_begin);
+  {
+    const int* pa = a.pairs + (static_cast<long long>(k) * 2 + a.side_src) * a.pair_len + p_begin;
+    const int* pb = a.pairs + (static_cast<long long>(k) * 2 + 1 - a.side_src) * a.pair_len + p_begin;
+    for (int e = tid; e < kPairsPerChunk; e += 256) { s_src[e] = e < cnt ? pa[e] : -1; s_row[e] = e < cnt ? pb[e] : -1; }
+  }
+  __syncthreads();
+  // piece q of a stage: rows [q * 64 / U, ...) of F (q < PF) or G; lane l -> row q*64/U + l/U, unit l%U  (U = units per row)
+  auto issue = [&](int p0, float* buf) {
+#pragma unroll
+    for (int q = 0; q < (PF + PG + 3) / 4; ++q) {
+      const int piece = q * 4 + w;
+      if (piece < PF) {
+        constexpr int U = CS / 4;
+        const int row = piece * (64 / U) + lane / U, unit = lane % U;
+        const int sr = s_src[p0 + row];
+        const float* src = sr >= 0 ? a.src + static_cast<long long>(sr) * a.ld_src + unit * 4 : g_zero_row + unit * 4;
+        glds16(src, buf + piece * 256);
+      } else if (piece < PF + PG) {
+        constexpr int U = CG / 4;
+        const int pg = piece - PF;
+        const int row = pg * (64 / U) + lane / U, unit = lane % U;
+        const int rr = s_row[p0 + row];
+        const float* src = rr >= 0 ? a.grad + static_cast<long long>(rr) * a.ld_grad + unit * 4 : g_zero_row + unit * 4;
+        glds16(src, buf + ST * ROWF + pg * 256);
+      }
+    }
+  };
+  f32x4 acc[AS][BS * 4];
+#pragma unroll
+  for (int i = 0; i < AS; ++i)
+#pragma unroll
+    for (int j = 0; j < BS * 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  issue(0, lds);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int it = 0;
+  for (int p0 = 0; p0 < cnt; p0 += ST, ++it) {
+    const float* F = lds + (it & 1) * STAGE;
+    const float* G = F + ST * ROWF;
+    if (p0 + ST < cnt) issue(p0 + ST, lds + ((it + 1) & 1) * STAGE);
+    const int npair = min(ST, cnt - p0);
+    for (int sl = 0; sl * 4 < npair; ++sl) {
+      const int pr = sl * 4 + g;  // rows beyond npair were staged from the zero row
+      float av[AS];
+      float4 bv[BS];
+#pragma unroll
+      for (int i = 0; i < AS; ++i) av[i] = F[pr * ROWF + (m + 16 * i) * 4 + w];
+#pragma unroll
+      for (int j = 0; j < BS; ++j) bv[j] = *reinterpret_cast<const float4*>(&G[pr * ROWG + (m + 16 * j) * 4]);
+#pragma unroll
+      for (int i = 0; i < AS; ++i)
+#pragma unroll
+        for (int j = 0; j < BS; ++j) {
+          acc[i][j * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j].x, acc[i][j * 4 + 0], 0, 0, 0);
+          acc[i][j * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j].y, acc[i][j * 4 + 1], 0, 0, 0);
+          acc[i][j * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j].z, acc[i][j * 4 + 2], 0, 0, 0);
+          acc[i][j * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j].w, acc[i][j * 4 + 3], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  // C layout: row = 4 * (lane >> 4) + reg is the A lane index m' -> cin = 4 * (m' + 16 i) + w; col n = lane & 15 -> cout = 4 * (n + 16 j) + t
+  float* out = partial + (static_cast<long long>(blockIdx.x) * a.kvol + k) * CS * CG;
+#pragma unroll
+  for (int i = 0; i < AS; ++i)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int cin = 4 * (4 * g + reg + 16 * i) + w;
+#pragma unroll
+      for (int j = 0; j < BS; ++j)
+        *reinterpret_cast<float4*>(&out[static_cast<long long>(cin) * CG + 4 * (m + 16 * j)]) =
+            make_float4(acc[i][j * 4 + 0][reg], acc[i][j * 4 + 1][reg], acc[i][j * 4 + 2][reg], acc[i][j * 4 + 3][reg]);
+    }
+}
+
 // Fixed-order sum of the tiles of the chunks that exist for each offset: ceil(pair_num[k] / kPairsPerChunk).
 __global__ __launch_bounds__(256) void wgrad_reduce_pairs(const float* __restrict__ partial, const int* __restrict__ pair_num, int kvol,
                                                           int c_src, int c_grad, float* __restrict__ dw, long long dw_kstride, int dw_ld) {
@@ -951,6 +1049,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ pa
 // dense tile, 2 = compacted tile, 3 = register-staged pipeline.  FV2P_CONV_IMPL=dense|cmp|pipe presets it;
 // fv2p_sparse_conv_set_impl() lets the parity tests run every variant in one process.
 static int g_conv_impl = -1;
+static int g_wgrad_dma = 1;   // pair-split weight gradient: 1 = LDS-DMA kernel where the shapes allow, 0 = register-staged kernel
 static unsigned long long* g_conv_trace = nullptr;
 static int conv_impl() {
   if (g_conv_impl < 0) {
@@ -1047,6 +1146,7 @@ extern "C" int fv2p_sparse_conv_set_trace(unsigned long long* trace) {
 extern "C" int fv2p_sparse_conv_set_impl(int impl) {
   FV2P_REQUIRE(impl >= 0 && impl <= 3, FV2P_EINVAL, "impl must be 0 (auto), 1 (dense), 2 (compacted) or 3 (pipelined)");
   fv2p::g_conv_impl = impl;
+  fv2p::g_wgrad_dma = impl == 0;   // forcing any variant also selects the register-staged pair-split weight gradient
   return 0;
 }
 
@@ -1208,6 +1308,24 @@ extern "C" int fv2p_sparse_conv_wgrad_pairs(const float* src, int64_t n_src, int
       const int mb = static_cast<int>(ceil_div(cs, 16)), nb = static_cast<int>(ceil_div(cd, 16));
       const int nbp = nb <= 1 ? 1 : nb <= 2 ? 2 : nb <= 4 ? 4 : 8;
       const int mbp = mb <= 1 ? 1 : mb <= 2 ? 2 : mb <= 4 ? 4 : 8;
+      const bool dma_ok = (cs == 64 || cs == 128) && (cd == 64 || cd == 128) && (c_src & 3) == 0 && (c_dst & 3) == 0 &&
+                          (reinterpret_cast<uintptr_t>(a.src) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.grad) & 15) == 0 && g_wgrad_dma;
+      if (dma_ok) {
+        const dim3 grid(chunks, static_cast<unsigned>(kvol), 1), block(256);
+        const int as = cs / 64, bs = cd / 64;
+        // 64 x 64: 64-pair stages (64 KB LDS, 2 workgroups per CU) when the launch has about one live workgroup per CU,
+        // 32-pair stages (4 per CU) when it has several (measured: 35 vs 43 us at N = 13k, 54 vs 61 us at N = 29k)
+        static int st_env = -1;
+        if (st_env < 0) { const char* e = getenv("FV2P_WGRAD_ST"); st_env = e ? atoi(e) : 0; }
+        const int st64 = st_env ? st_env : (static_cast<long long>(chunks) * kvol > 1200 ? 32 : 64);
+        const int st = (as + bs <= 2) ? st64 : 32;
+        const size_t lds = static_cast<size_t>(2) * st * (cs + cd) * sizeof(float) + 2 * kPairsPerChunk * sizeof(int);
+        if (as == 1 && bs == 1 && st == 64) hipLaunchKernelGGL((conv_wgrad_pairs_dma<1, 1, 64>), grid, block, lds, stream, a, partial);
+        else if (as == 1 && bs == 1) hipLaunchKernelGGL((conv_wgrad_pairs_dma<1, 1, 32>), grid, block, lds, stream, a, partial);
+        else if (as == 2 && bs == 1) hipLaunchKernelGGL((conv_wgrad_pairs_dma<2, 1, 32>), grid, block, lds, stream, a, partial);
+        else if (as == 1 && bs == 2) hipLaunchKernelGGL((conv_wgrad_pairs_dma<1, 2, 32>), grid, block, lds, stream, a, partial);
+        else hipLaunchKernelGGL((conv_wgrad_pairs_dma<2, 2, 32>), grid, block, lds, stream, a, partial);
+      } else {
 #define FV2P_WGP(MB, NB) wgrad_pairs_launch<MB, NB>(a, partial, chunks, stream)
 #define FV2P_WGP_NB(MB)                                                                    \
       switch (nbp) { case 1: FV2P_WGP(MB, 1); break; case 2: FV2P_WGP(MB, 2); break;      \
@@ -1215,6 +1333,7 @@ extern "C" int fv2p_sparse_conv_wgrad_pairs(const float* src, int64_t n_src, int
       switch (mbp) { case 1: FV2P_WGP_NB(1) break; case 2: FV2P_WGP_NB(2) break; case 4: FV2P_WGP_NB(4) break; default: FV2P_WGP_NB(8) break; }
 #undef FV2P_WGP_NB
 #undef FV2P_WGP
+      }
       const long long per_chunk = static_cast<long long>(kvol) * cs * cd;
       hipLaunchKernelGGL(wgrad_reduce_pairs, dim3(static_cast<unsigned>(ceil_div(per_chunk, 16))), dim3(256), 0, stream, partial, pair_num, kvol,
                          cs, cd, dweight + static_cast<long long>(s0) * c_dst + d0, static_cast<long long>(c_src) * c_dst, c_dst);

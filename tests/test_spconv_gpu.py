@@ -318,8 +318,9 @@ def test_rulebook_prefetch_recipe_matches_inline_build_and_ignores_stale_geometr
     assert torch.equal(out3.indices, ref3.indices) and torch.equal(out3.features, ref3.features)
 
 
-@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 64), (64, 64), (5, 16), (128, 64), (160, 144)])
-def test_weight_gradient_from_pair_lists_vs_oracle(gpu, front_end, cin, cout):
+@pytest.mark.parametrize("staged", [False, True], ids=["lds-dma", "register-staged"])
+@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 64), (64, 64), (5, 16), (128, 64), (64, 128), (128, 128), (160, 144)])
+def test_weight_gradient_from_pair_lists_vs_oracle(gpu, front_end, cin, cout, staged):
     """fv2p_sparse_conv_wgrad_pairs (work split by the rulebook's reference-format pair lists, used once
     indice_pairs / indice_pair_num are materialised, e.g. by the rulebook prefetch): dW of a submanifold conv, a strided
     conv and its inverse conv against the oracle's gather -> mm loop (spconv_ops.h:403-455 restated)."""
@@ -338,10 +339,16 @@ def test_weight_gradient_from_pair_lists_vs_oracle(gpu, front_end, cin, cout):
         else:
             rb.indice_pairs, rb.indice_pair_num      # reference-format lists; either way the backward takes the pair-list kernel
         assert rb._wpairs is not None and rb._num is not None
+    import fv2p_native
     x.features.requires_grad_(True)
-    y = net(x)
-    g = np.random.default_rng(5).standard_normal(tuple(y.features.shape)).astype(np.float32)
-    y.features.backward(torch.from_numpy(g).to(gpu))
+    try:
+        if staged:   # forcing a conv variant also selects the register-staged pair-split kernel (64/128 channels: LDS-DMA otherwise)
+            fv2p_native.call("fv2p_sparse_conv_set_impl", 3)
+        y = net(x)
+        g = np.random.default_rng(5).standard_normal(tuple(y.features.shape)).astype(np.float32)
+        y.features.backward(torch.from_numpy(g).to(gpu))
+    finally:
+        fv2p_native.call("fv2p_sparse_conv_set_impl", 0)
     # oracle chain
     w = [m.weight.detach().cpu().numpy() for m in net]
     _, p_s, n_s = oracle.indice_pairs(ind, batch, shape, [3, 3, 3], [1, 1, 1], [1, 1, 1], [1, 1, 1], subm=True)
