@@ -430,6 +430,8 @@ __global__ __launch_bounds__(256) void conv_rows_dma(ConvArgs a) {
   gather_async<J>(a_cur, row_ptr(idx_cur));
   wait_loads<J>(a_cur, idx_nxt);
   __syncthreads();
+  unsigned long long t_pro = 0, t_wait = 0, t_mark = 0;
+  if (a.trace) t_pro = __builtin_readcyclecounter();
   for (int k = 0; k < a.kvol; ++k) {
     const float* wcur = lds + (k & 1) * WSZ;
     if (k + 1 < a.kvol) issue_w(k + 1, lds + ((k + 1) & 1) * WSZ);
@@ -467,8 +469,10 @@ __global__ __launch_bounds__(256) void conv_rows_dma(ConvArgs a) {
         }
       }
     }
+    if (a.trace) t_mark = __builtin_readcyclecounter();
     wait_loads<J>(a_nxt, idx_nn);
     __syncthreads();
+    if (a.trace) t_wait += __builtin_readcyclecounter() - t_mark;
 #pragma unroll
     for (int j = 0; j < J; ++j) a_cur[j] = a_nxt[j];
     idx_cur = idx_nxt;
@@ -478,10 +482,12 @@ __global__ __launch_bounds__(256) void conv_rows_dma(ConvArgs a) {
     unsigned hw, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    a.trace[blockIdx.x * 4 + 0] = hw;
-    a.trace[blockIdx.x * 4 + 1] = xcc;
-    a.trace[blockIdx.x * 4 + 2] = t_begin;
-    a.trace[blockIdx.x * 4 + 3] = __builtin_readcyclecounter();
+    a.trace[blockIdx.x * 8 + 0] = hw;
+    a.trace[blockIdx.x * 8 + 1] = xcc;
+    a.trace[blockIdx.x * 8 + 2] = t_begin;
+    a.trace[blockIdx.x * 8 + 3] = __builtin_readcyclecounter();
+    a.trace[blockIdx.x * 8 + 4] = t_pro;
+    a.trace[blockIdx.x * 8 + 5] = t_wait;   // clocks wave 0 spent between the end of its MFMA block and the barrier's release
   }
   // epilogue: accumulator i of lane (q, n) is output column  WT ? NB*n + i : 64*(i/4) + 4*n + i%4
   const int q = lane >> 4, n = lane & 15;

@@ -117,8 +117,9 @@ int fv2p_pairs_to_tables(const int* pairs, const int* indice_num, int kvol, int6
  * (0 = heuristic, 1 = plain dense tile, 2 = compacted tile, 3 = register-staged pipeline).  All variants compute
  * the same sum in the same k order. */
 int fv2p_sparse_conv_set_impl(int impl);
-/* Profiling hook: when non-NULL, every workgroup of the LDS-DMA conv kernel writes {HW_ID, XCC_ID, start, end
- * (shader clock)} to trace[4*blockIdx .. +3] (device memory, >= 4*ceil(n_dst/64) entries).  NULL switches it off. */
+/* Profiling hook: when non-NULL, every workgroup of the LDS-DMA conv kernel writes {HW_ID, XCC_ID, start, end of the
+ * offset loop, end of the prologue, clocks spent waiting at the per-offset barrier (wave 0), 0, 0} (shader clock) to
+ * trace[8*blockIdx .. +7] (device memory, >= 8*ceil(n_dst/64) entries).  NULL switches it off. */
 int fv2p_sparse_conv_set_trace(unsigned long long* trace);
 
 int fv2p_sparse_conv_rows(const float* src, int64_t n_src, int c_src, const float* weight, int kvol,

@@ -56,21 +56,85 @@ def conv(only=None):
         t = timeit(lambda: ops.indice_conv(f, w, rb, None, n_out, False, mod.subm), reps=only, warm=3)
         print(f"roofline kernel: {'subm' if mod.subm else 'conv'} {mod.in_channels}->{mod.out_channels} key={mod.indice_key} "
               f"n={f.shape[0]} pairs={int(rb.indice_pair_num.sum().item())}: {t:.1f} us")
-        if os.environ.get("FV2P_TRACE"):
-            import collections
+        if os.environ.get("FV2P_SORT_EXPERIMENT"):
+            # what would tiles sorted by neighbour pattern buy?  Renumber the rows (sorted by the 27-bit offset mask, by its
+            # 9-bit (dz,dy)-line summary, or shuffled) and rebuild the rulebook: tiles then follow that order.
+            tabn = rb.tab_in.cpu().numpy() >= 0
+            K = tabn.shape[0]
+            mask = np.zeros(tabn.shape[1], np.int64)
+            for k in range(K):
+                mask |= tabn[k].astype(np.int64) << k
+            line = np.zeros_like(mask)
+            for q in range(K // 3):
+                line |= tabn[3 * q:3 * q + 3].any(0).astype(np.int64) << q
+            pc = np.array([bin(v).count("1") for v in mask])
+            orders = {"as is": np.arange(mask.size), "mask sort": np.argsort(mask, kind="stable"), "line9 sort": np.argsort(line, kind="stable"),
+                      "popcount sort": np.argsort(pc, kind="stable"), "shuffle": np.random.default_rng(0).permutation(mask.size)}
+            ind = rb.indices
+            # balanced variant: rows sorted by (popcount, mask); 64-row tiles handed out so that the two workgroups a CU
+            # receives (taken from a placement trace of this very launch shape) are one heavy and one light tile
             import fv2p_native
             nblk = (n_out + 63) // 64
-            tr = torch.zeros(nblk * 4, dtype=torch.int64, device="cuda")
+            tr = torch.zeros(nblk * 8, dtype=torch.int64, device="cuda")
             fv2p_native.call("fv2p_sparse_conv_set_trace", tr)
             ops.indice_conv(f, w, rb, None, n_out, False, mod.subm)
             torch.cuda.synchronize()
             fv2p_native.call("fv2p_sparse_conv_set_trace", None)
-            tr = tr.cpu().numpy().reshape(nblk, 4)
+            trn = tr.cpu().numpy().reshape(nblk, 8)
+            cu_key = (trn[:, 1] & 0xF) * 4096 + ((trn[:, 0] >> 8) & 0xFFF)
+            order_w = np.argsort(pc * (1 << 27) + mask, kind="stable")           # light -> heavy rows
+            tiles_sorted = [order_w[i * 64:(i + 1) * 64] for i in range(nblk)]   # tile i: i-th lightest
+            by_cu = {}
+            for b in range(nblk):
+                by_cu.setdefault(int(cu_key[b]), []).append(b)
+            singles = [v[0] for v in by_cu.values() if len(v) == 1]
+            pairs_b = [v for v in by_cu.values() if len(v) >= 2]
+            assign = {}
+            lo, hi = 0, nblk - 1
+            for v in pairs_b:                      # heavy + light on the same CU
+                assign[v[0]] = hi; hi -= 1
+                assign[v[1]] = lo; lo += 1
+                for extra in v[2:]:
+                    assign[extra] = lo; lo += 1
+            for b in singles:                      # CUs with one workgroup take the middle
+                assign[b] = lo; lo += 1
+            bb = np.arange(nblk); xx = bb & 7
+            tile_of_block = xx * (nblk >> 3) + np.minimum(xx, nblk & 7) + (bb >> 3)
+            row_order = np.zeros(nblk * 64, np.int64) - 1
+            for b in range(nblk):
+                rows = tiles_sorted[assign[b]]
+                row_order[tile_of_block[b] * 64: tile_of_block[b] * 64 + len(rows)] = rows
+            row_order = row_order[row_order >= 0]
+            if row_order.size == mask.size and len(set(row_order.tolist())) == mask.size:
+                orders["(popcount,mask) sort + heavy/light per CU"] = row_order
+            orders["(popcount,mask) sort"] = order_w
+            for name, perm in orders.items():
+                pt = torch.from_numpy(perm).to(ind.device)
+                ind_p, f_p = ind[pt].contiguous(), f[pt].contiguous()
+                rb_p = ops.build_rulebook(ind_p, 4, rb.spatial_shape, mod.kernel_size, mod.stride, mod.padding, mod.dilation, 0, True)
+                act = (rb_p.tab_in.cpu().numpy() >= 0)
+                padn = (-act.shape[1]) % 16
+                tiles = np.concatenate([act, np.zeros((K, padn), bool)], 1).reshape(K, -1, 16).any(2).sum(0)
+                tt = timeit(lambda: ops.indice_conv(f_p, w, rb_p, None, n_out, False, True), reps=only, warm=3)
+                print(f"  rows {name:44s}: {tt:6.1f} us   active offsets per 16-row tile {tiles.mean():5.2f}")
+        if os.environ.get("FV2P_TRACE"):
+            import collections
+            import fv2p_native
+            nblk = (n_out + 63) // 64
+            tr = torch.zeros(nblk * 8, dtype=torch.int64, device="cuda")
+            fv2p_native.call("fv2p_sparse_conv_set_trace", tr)
+            ops.indice_conv(f, w, rb, None, n_out, False, mod.subm)
+            torch.cuda.synchronize()
+            fv2p_native.call("fv2p_sparse_conv_set_trace", None)
+            tr = tr.cpu().numpy().reshape(nblk, 8)
             hw, xcc, t0, t1 = tr[:, 0], tr[:, 1] & 0xF, tr[:, 2], tr[:, 3]
             cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
             place = collections.Counter(zip(xcc.tolist(), se.tolist(), sh.tolist(), cu.tolist()))
             print("distinct CUs used:", len(place), "blocks/CU histogram:", sorted(collections.Counter(place.values()).items()))
             dur = (t1 - t0).astype(float)
+            pro, wait = (tr[:, 4] - t0).astype(float), tr[:, 5].astype(float)
+            print(f"prologue clocks: median {np.median(pro):.0f} max {pro.max():.0f}; barrier-wait clocks per block: median {np.median(wait):.0f} "
+                  f"({100 * np.median(wait / dur):.0f}% of the loop+prologue time)")
             # per-block activity from the rulebook: U = offsets with any active row in the 64-row tile, A = per-wave max
             tab = (rb.tab_in if getattr(rb, "tab_out", None) is None else rb.tab_out).cpu().numpy() >= 0   # [K, n]
             K = tab.shape[0]
