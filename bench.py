@@ -83,8 +83,8 @@ def build_step(args, device, rank, world):
             for seeds in dist_utils.rank_seeds(rank, n_pool, args.batch)]
 
     def voxelize(clouds):
-        v, coords, n = points_to_voxel_batch(clouds, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 16000)
-        return mean_vfe(v, n), coords
+        # voxelise + MeanVFE + collate: (features [sum M, 4], coords [sum M, 4]) straight from the voxeliser's outputs
+        return points_to_voxel_batch(clouds, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 16000, mean_vfe=True)
 
     from fv2p_harness.prefetch import BatchPrefetcher
     from pcdet.ops import spconv

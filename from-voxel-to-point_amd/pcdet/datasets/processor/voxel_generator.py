@@ -71,10 +71,12 @@ def _launch(points, voxel_size, coors_range, grid, max_points, max_voxels):
     return voxels, coors, num, count
 
 
-def points_to_voxel_batch(points_list, voxel_size, coors_range, max_points=35, max_voxels=20000):
+def points_to_voxel_batch(points_list, voxel_size, coors_range, max_points=35, max_voxels=20000, mean_vfe=False):
     """Voxelises the clouds of one batch concurrently — one HIP stream per cloud, a single host sync for all voxel
     counts — and returns the collated batch the models consume (dataset.collate_batch, pcdet/datasets/dataset.py:152-183):
-    voxels [sum M, max_points, ndim], coords [sum M, 4] (batch, z, y, x) int32, num_points [sum M] int32."""
+    voxels [sum M, max_points, ndim], coords [sum M, 4] (batch, z, y, x) int32, num_points [sum M] int32.
+    mean_vfe=True returns (features [sum M, ndim], coords) instead: MeanVFE (vfe/mean_vfe.py:14-31) and the collation
+    in one launch per cloud, without the padded [M, max_points, ndim] batch tensor."""
     voxel_size = np.asarray(voxel_size, dtype=np.float32)
     coors_range = np.asarray(coors_range, dtype=np.float32)
     grid = _grid_size(voxel_size, coors_range)
@@ -95,6 +97,19 @@ def points_to_voxel_batch(points_list, voxel_size, coors_range, max_points=35, m
             for t in o:
                 t.record_stream(main)
     counts = torch.cat([o[3] for o in outs]).cpu().tolist()  # the one synchronisation of the batch
+    if mean_vfe:
+        counts = [min(int(m), int(max_voxels)) for m in counts]
+        total, ndim = sum(counts), points_list[0].shape[1]
+        feats = torch.empty((total, ndim), dtype=torch.float32, device=dev)
+        coords = torch.empty((total, 4), dtype=torch.int32, device=dev)
+        off = 0
+        with _nat.device_guard(dev):
+            for b, (o, m) in enumerate(zip(outs, counts)):
+                if m > 0:
+                    _nat.call("fv2p_voxel_mean_collate", o[0], o[1], o[2], o[3], m, int(max_points), ndim, b,
+                              feats[off:], coords[off:], _nat.stream())
+                off += m
+        return feats, coords
     v = torch.cat([o[0][:m] for o, m in zip(outs, counts)])
     c = torch.cat([torch.nn.functional.pad(o[1][:m], (1, 0), value=b) for b, (o, m) in enumerate(zip(outs, counts))])
     k = torch.cat([o[2][:m] for o, m in zip(outs, counts)])

@@ -14,6 +14,35 @@ def scatter_nd(indices, updates, shape):
     return ret
 
 
+class _Dense(torch.autograd.Function):
+    """features [N, C] -> dense [B, C, *spatial] (or [B, *spatial, C]); gradient = gather at the active cells."""
+
+    @staticmethod
+    def forward(ctx, features, indices, spatial, batch, channels_first):
+        import fv2p_native as _nat
+        n, c = features.shape
+        ndim = len(spatial)
+        shape = [batch, c] + list(spatial) if channels_first else [batch] + list(spatial) + [c]
+        out = torch.empty(shape, dtype=torch.float32, device=features.device)
+        sp3 = list(spatial) + [1] * (3 - ndim)
+        ind = indices.contiguous()
+        with _nat.device_guard(features.device):
+            _nat.call("fv2p_sparse_to_dense", features.contiguous(), ind, n, c, ndim, batch, sp3, int(channels_first), out, _nat.stream())
+        ctx.save_for_backward(ind)
+        ctx.meta = (n, c, ndim, batch, sp3, channels_first)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        import fv2p_native as _nat
+        (ind,) = ctx.saved_tensors
+        n, c, ndim, batch, sp3, channels_first = ctx.meta
+        rows = torch.empty((n, c), dtype=torch.float32, device=grad.device)
+        with _nat.device_guard(grad.device):
+            _nat.call("fv2p_dense_to_sparse", grad.contiguous(), ind, n, c, ndim, batch, sp3, int(channels_first), rows, _nat.stream())
+        return rows, None, None, None, None
+
+
 class SparseConvTensor(object):
     """features [N,C] f32, indices [N,1+ndim] i32 (batch, z, y, x), spatial_shape, batch_size.
 
@@ -41,6 +70,12 @@ class SparseConvTensor(object):
         return self.indice_dict.get(key, None)
 
     def dense(self, channels_first=True):
+        ndim = len(self.spatial_shape)
+        f = self.features
+        if f.is_cuda and f.dtype == torch.float32 and f.dim() == 2 and ndim in (2, 3) and not torch.is_autocast_enabled():
+            # one fill + one scatter straight into the requested layout (csrc/sparse_aux.hip), instead of
+            # zeros -> index scatter -> permute -> contiguous over the whole dense volume
+            return _Dense.apply(f, self.indices, tuple(int(v) for v in self.spatial_shape), int(self.batch_size), bool(channels_first))
         out_shape = [self.batch_size] + list(self.spatial_shape) + [self.features.shape[1]]
         res = scatter_nd(self.indices.long(), self.features, out_shape)
         if not channels_first:

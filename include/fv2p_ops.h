@@ -161,6 +161,25 @@ int fv2p_sparse_group_fwd(const float* in, int64_t n_in, int c, const int* tab, 
 int fv2p_sparse_group_bwd(const float* grad, int64_t n_out, int c, const int* tab, int kvol, int64_t n_in,
                           int flip_k, float* din, fv2p_stream_t stream);
 
+/* ---- (f).2: SparseConvTensor.dense() and its gradient ---------------------------------------------------------
+ * Replaces scatter_nd + permute + contiguous (pcdet/ops/spconv/structure.py:5-18, 57-66; consumer HeightCompression,
+ * pcdet/models/backbones_2d/map_to_bev/height_compression.py:10-26).  indices [n, 1+ndim] (batch, z, y, x) or
+ * (batch, y, x); dense is [B, C, *spatial] (channels_first) or [B, *spatial, C]; it is zero-filled here.
+ * Duplicate coordinates: last writer in thread order wins (the reference's index_put is equally unordered). */
+int fv2p_sparse_to_dense(const float* features, const int* indices, int64_t n, int c, int ndim, int batch,
+                         const int spatial[3], int channels_first, float* dense, fv2p_stream_t stream);
+int fv2p_dense_to_sparse(const float* dense, const int* indices, int64_t n, int c, int ndim, int batch,
+                         const int spatial[3], int channels_first, float* rows, fv2p_stream_t stream);
+
+/* ---- (f).1: MeanVFE + collate of one voxelised cloud -------------------------------------------------------------
+ * feats[v, :] = sum of the zero-padded point slots of voxel v / max(num_points[v], 1)   (vfe/mean_vfe.py:14-31),
+ * coords[v, :] = (batch_idx, z, y, x)   (dataset.collate_batch, pcdet/datasets/dataset.py:165-171), for the
+ * v < min(*num_voxels, max_voxels) voxels of fv2p_points_to_voxel's output; feats / coords point at this cloud's
+ * offset inside the batch tensors.  *num_voxels is read on the device. */
+int fv2p_voxel_mean_collate(const float* voxels, const int* coors, const int* num_points, const int* num_voxels,
+                            int max_voxels, int max_points, int ndim, int batch_idx, float* feats, int* coords,
+                            fv2p_stream_t stream);
+
 /* ---- A16: rotated BEV overlap / IoU, rotated and axis-aligned NMS ----------------------------
  * Replace iou3d_nms_cuda.* (pcdet/ops/iou3d_nms/src/iou3d_nms_api.cpp:11-17):
  *   boxes_overlap_bev_gpu (iou3d_nms.cpp:49-68,  kernel iou3d_nms_kernel.cu:236-249)

@@ -361,3 +361,31 @@ def test_weight_gradient_from_pair_lists_vs_oracle(gpu, front_end, cin, cout, st
     for m, ref in zip(net, (dw0, dw1, dw2)):
         assert rel_err(m.weight.grad.cpu().numpy(), ref.numpy()) < RTOL
     assert rel_err(x.features.grad.cpu().numpy(), d0.numpy()) < RTOL
+
+
+@pytest.mark.parametrize("ndim", [3, 2])
+def test_dense_scatter_equals_reference_expression_and_gradient(gpu, ndim):
+    """SparseConvTensor.dense() on the GPU (fv2p_sparse_to_dense / fv2p_dense_to_sparse) against the reference's
+    expression zeros -> scatter_nd -> permute (structure.py:5-18, 57-66), both layouts, values bit-exact, gradient
+    = the rows of the dense gradient."""
+    batch, c = 3, 24
+    shape = [5, 12, 10] if ndim == 3 else [12, 10]
+    rng = np.random.default_rng(0)
+    cells = rng.permutation(batch * int(np.prod(shape)))[:300]
+    ind = np.stack(np.unravel_index(cells, [batch] + shape), 1).astype(np.int32)
+    feats = rng.standard_normal((300, c)).astype(np.float32)
+    for channels_first in (True, False):
+        f = torch.from_numpy(feats).to(gpu).requires_grad_(True)
+        x = spconv.SparseConvTensor(f, torch.from_numpy(ind).to(gpu), shape, batch)
+        d = x.dense(channels_first)
+        ref = spconv.scatter_nd(torch.from_numpy(ind).long(), torch.from_numpy(feats), [batch] + shape + [c])
+        if channels_first:
+            perm = list(range(0, ndim + 1))
+            perm.insert(1, ndim + 1)
+            ref = ref.permute(*perm).contiguous()
+        assert d.shape == ref.shape and torch.equal(d.cpu(), ref)
+        g = torch.from_numpy(rng.standard_normal(tuple(ref.shape)).astype(np.float32))
+        d.backward(g.to(gpu))
+        gl = g if not channels_first else g.permute(*([0] + list(range(2, ndim + 2)) + [1]))
+        want = gl[tuple(torch.from_numpy(ind[:, i]).long() for i in range(ndim + 1))]
+        assert torch.equal(f.grad.cpu(), want)

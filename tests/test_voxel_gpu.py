@@ -84,3 +84,21 @@ def test_batched_multistream_voxeliser_equals_per_cloud(gpu):
     assert np.array_equal(k.cpu().numpy(), np.concatenate([r[2] for r in ref]))
     rc = np.concatenate([np.concatenate([np.full((r[1].shape[0], 1), b, np.int32), r[1]], 1) for b, r in enumerate(ref)])
     assert c.dtype == torch.int32 and np.array_equal(c.cpu().numpy(), rc)
+
+
+def test_mean_vfe_collate_matches_padded_batch_expression(gpu):
+    """points_to_voxel_batch(mean_vfe=True) (fv2p_voxel_mean_collate) equals MeanVFE over the padded batch it replaces:
+    features = sum over the point slots / clamp_min(num_points, 1) (vfe/mean_vfe.py:14-31), coords = (b, z, y, x)."""
+    import torch
+    from fv2p_harness import synth
+    from pcdet.datasets.processor.voxel_generator import points_to_voxel_batch
+    clouds = [torch.from_numpy(synth.lidar_cloud(7 + b, 6000 + 500 * b)).to(gpu) for b in range(3)]
+    v, c, k = points_to_voxel_batch(clouds, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 16000)
+    want = v.sum(dim=1) / torch.clamp_min(k.view(-1, 1), 1.0).type_as(v)
+    feats, coords = points_to_voxel_batch(clouds, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 16000, mean_vfe=True)
+    assert torch.equal(coords, c) and coords.dtype == torch.int32
+    assert feats.shape == want.shape and torch.allclose(feats, want, rtol=1e-6, atol=0)
+    # max_voxels overflow: only the kept voxels are collated
+    f2, c2 = points_to_voxel_batch(clouds, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 1000, mean_vfe=True)
+    v2, cc2, k2 = points_to_voxel_batch(clouds, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 1000)
+    assert f2.shape[0] == v2.shape[0] == 3000 and torch.equal(c2, cc2)
