@@ -75,7 +75,7 @@ def build_step(args, device, rank, world):
             out, _ = self.body(feats, coords, batch)
             return out.features.square().mean()
 
-    net = dist_utils.wrap_ddp(TrainStep(model), device)
+    net = dist_utils.wrap_ddp(TrainStep(model), device, find_unused_parameters=False)   # every parameter is used every step
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.01, fused=True)  # one multi-tensor kernel per step
     # a small pool of distinct batches, points resident in HBM; seeds differ per rank
     n_pool = 4
@@ -255,9 +255,13 @@ def main():
     from fv2p_harness import dist_utils
     rank, world, local = dist_utils.env_world()
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    # FV2P_FORCE_DEVICE / FV2P_DIST_BACKEND: test hooks to exercise the multi-rank path on a one-GPU box (all ranks on one
+    # device, gloo instead of RCCL); the driver's runs set neither
+    if os.environ.get("FV2P_FORCE_DEVICE"):
+        local = int(os.environ["FV2P_FORCE_DEVICE"])
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
-    dist_utils.init_distributed("nccl", device)
+    dist_utils.init_distributed(os.environ.get("FV2P_DIST_BACKEND", "nccl"), device)
     import fv2p_native
     fv2p_native.lib()
 

@@ -27,12 +27,15 @@ def rank_seeds(rank, n_pool, batch):
     return [[100000 * rank + 10 * j + b for b in range(batch)] for j in range(n_pool)]
 
 
-def wrap_ddp(model, device=None):
+def wrap_ddp(model, device=None, find_unused_parameters=True):
+    """find_unused_parameters=True is the reference trainer's setting (tools/train.py:166: its detectors have heads that
+    sit out some iterations); a module that uses every parameter each step (the backbone train step of bench.py) passes
+    False and saves DDP's extra autograd-graph traversal per iteration."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return model
     ids = [device.index] if (device is not None and device.type == "cuda") else None
-    # find_unused_parameters=True as the reference trainer (tools/train.py:166)
-    return torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, find_unused_parameters=True)
+    return torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, find_unused_parameters=find_unused_parameters,
+                                                     gradient_as_bucket_view=True)
 
 
 def barrier():
