@@ -36,7 +36,9 @@ def gather_points_grad_wrapper(b, c, n, npoints, grad_out_tensor, idx_tensor, gr
 
 
 def furthest_point_sampling_wrapper(b, n, m, points_tensor, temp_tensor, idx_tensor):
-    return _go("fv2p_furthest_point_sampling", idx_tensor, b, n, m, points_tensor, temp_tensor, idx_tensor)
+    with _nat.device_guard(idx_tensor.device):   # scratch of the bucketed (lazy, bit-identical) kernel
+        ws = _nat.workspace(_nat.lib().fv2p_furthest_point_sampling_ws_bytes(b, n), idx_tensor.device)
+    return _go("fv2p_furthest_point_sampling", idx_tensor, b, n, m, points_tensor, temp_tensor, idx_tensor, ws, ws.numel())
 
 
 def three_nn_wrapper(b, n, m, unknown_tensor, known_tensor, dist2_tensor, idx_tensor):

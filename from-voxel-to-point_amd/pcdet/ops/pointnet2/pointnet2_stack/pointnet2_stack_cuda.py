@@ -30,7 +30,9 @@ def voxel_query_wrapper(M, R1, R2, R3, nsample, radius, z_range, y_range, x_rang
 
 
 def furthest_point_sampling_wrapper(b, n, m, points_tensor, temp_tensor, idx_tensor):
-    return _go("fv2p_furthest_point_sampling", idx_tensor, b, n, m, points_tensor, temp_tensor, idx_tensor)
+    with _nat.device_guard(idx_tensor.device):   # scratch of the bucketed (lazy, bit-identical) kernel
+        ws = _nat.workspace(_nat.lib().fv2p_furthest_point_sampling_ws_bytes(b, n), idx_tensor.device)
+    return _go("fv2p_furthest_point_sampling", idx_tensor, b, n, m, points_tensor, temp_tensor, idx_tensor, ws, ws.numel())
 
 
 def group_points_wrapper(B, M, C, nsample, features, features_batch_cnt, idx, idx_batch_cnt, out):

@@ -263,8 +263,12 @@ int fv2p_group_points_stack(int b, int m, int c, int nsample, const float* featu
 int fv2p_group_points_stack_grad(int b, int m, int c, int n, int nsample, const float* grad_out, const int* idx,
                                  const int* idx_batch_cnt, const int* features_batch_cnt, float* grad_features,
                                  fv2p_stream_t stream);
-int fv2p_furthest_point_sampling(int b, int n, int m, const float* dataset, float* temp, int* idxs,
-                                 fv2p_stream_t stream);
+/* ws / ws_bytes (fv2p_furthest_point_sampling_ws_bytes, may be NULL): scratch of the bucketed kernel — Morton-sorted
+ * point order, per-bucket boxes; with it 2048 <= n <= 16384, m >= 1024 run the lazy variant, whose indices and final
+ * `temp` are bit-identical to the plain kernel's (and the reference's, sampling_gpu.cu:100-216). */
+size_t fv2p_furthest_point_sampling_ws_bytes(int b, int n);
+int fv2p_furthest_point_sampling(int b, int n, int m, const float* dataset, float* temp, int* idxs, void* ws,
+                                 size_t ws_bytes, fv2p_stream_t stream);
 int fv2p_three_nn_batch(int b, int n, int m, const float* unknown, const float* known, float* dist2, int* idx,
                         fv2p_stream_t stream);
 int fv2p_three_nn_stack(int b, int n, int m, const float* unknown, const int* unknown_batch_cnt,

@@ -172,3 +172,20 @@ def test_voxel_query(gpu):
 def test_errors_are_exceptions_not_exit(gpu):
     with pytest.raises(Exception):
         bu.ball_query(1.0, 8, torch.zeros(1, 10, 3), torch.zeros(1, 4, 3))  # CPU tensors: the reference would exit(-1)
+
+
+@pytest.mark.parametrize("n,m,b", [(16384, 2048, 2), (4099, 1500, 3), (2048, 2048, 1), (9000, 1024, 2), (9000, 64, 2)])
+def test_fps_bucketed_kernel_indices_and_running_distances(gpu, n, m, b):
+    """The bucketed (lazy) FPS kernel — Morton-sorted buckets skipped when the new point cannot lower any of their
+    running distances — must be indistinguishable from the reference loop: same indices AND same final `temp`
+    (sampling_gpu.cu:100-216), also with duplicated points (exact ties) and n not a multiple of the bucket size."""
+    from pcdet.ops.pointnet2.pointnet2_batch import pointnet2_batch_cuda as ext
+    pts = np.stack([synth.lidar_cloud(3 * n + s, n)[:, :3] for s in range(b)])
+    pts[:, n // 2: n // 2 + 200] = pts[:, :200]          # duplicates: zero distances and exact ties
+    ref_idx, ref_temp = oracle.furthest_point_sample(pts, m)
+    xyz = T(pts, gpu)
+    temp = torch.full((b, n), 1e10, dtype=torch.float32, device=gpu)
+    idx = torch.zeros((b, m), dtype=torch.int32, device=gpu)
+    ext.furthest_point_sampling_wrapper(b, n, m, xyz, temp, idx)
+    assert np.array_equal(idx.cpu().numpy(), ref_idx)
+    assert np.array_equal(temp.cpu().numpy(), ref_temp)
