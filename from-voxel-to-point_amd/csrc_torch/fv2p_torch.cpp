@@ -8,7 +8,11 @@
 // through libfv2p_ops.so.  Optional: without this module the same ops run through fv2p_native.py (ctypes).
 #include <torch/extension.h>
 #include <c10/hip/HIPStream.h>
+#include <c10/hip/HIPGuard.h>
 #include <c10/core/DeviceGuard.h>
+#include <hip/hip_runtime_api.h>
+
+#include <cstdlib>
 
 #include <map>
 #include <mutex>
@@ -40,6 +44,32 @@ at::Tensor workspace(size_t bytes, const at::Tensor& like, void* stream) {
     it = pool.find(key);
   }
   return it->second;
+}
+
+// Second stream per device for the weight gradient: it depends only on what the backward-data conv depends on, so the
+// two run side by side and fill each other's tails (both are tile kernels whose launches end on a few heavy CUs).
+// The training stream waits for the side stream before the backward function returns, so nothing downstream (gradient
+// accumulation, DDP bucket copies, the optimiser) sees a half-written dW.  FV2P_WGRAD_OVERLAP=0 keeps one stream.
+struct SideStream {
+  c10::hip::HIPStream stream;
+  hipEvent_t fork, join;
+};
+SideStream& side_stream(int device) {
+  static std::mutex mu;
+  static std::map<int, SideStream> pool;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = pool.find(device);
+  if (it == pool.end()) {
+    SideStream s{c10::hip::getStreamFromPool(false, static_cast<c10::DeviceIndex>(device)), nullptr, nullptr};
+    TORCH_CHECK(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
+    it = pool.emplace(device, s).first;
+  }
+  return it->second;
+}
+bool wgrad_overlap() {
+  static const bool on = [] { const char* e = std::getenv("FV2P_WGRAD_OVERLAP"); return !(e && e[0] == '0'); }();
+  return on;
 }
 
 void require_f32_cuda(const at::Tensor& t, const char* name) {
@@ -85,6 +115,17 @@ struct SparseConvFn : public torch::autograd::Function<SparseConvFn> {
     c10::DeviceGuard guard(features.device());
     void* stream = cur_stream(features);
     at::Tensor din, dw;
+    const bool both = ctx->needs_input_grad(0) && ctx->needs_input_grad(1);
+    const bool overlap = both && wgrad_overlap();
+    void* wstream = stream;   // stream of the weight gradient
+    SideStream* side = nullptr;
+    if (ctx->needs_input_grad(1)) dw = at::empty_like(weight);
+    if (overlap) {
+      side = &side_stream(features.device().index());
+      TORCH_CHECK(hipEventRecord(side->fork, static_cast<hipStream_t>(stream)) == hipSuccess, "hipEventRecord failed");
+      TORCH_CHECK(hipStreamWaitEvent(side->stream.stream(), side->fork, 0) == hipSuccess, "hipStreamWaitEvent failed");
+      wstream = static_cast<void*>(side->stream.stream());
+    }
     if (ctx->needs_input_grad(0)) {
       din = at::empty_like(features);
       check(fv2p_sparse_conv_rows(g.data_ptr<float>(), g.size(0), static_cast<int>(cout), weight.data_ptr<float>(), static_cast<int>(kvol),
@@ -92,24 +133,30 @@ struct SparseConvFn : public torch::autograd::Function<SparseConvFn> {
             "fv2p_sparse_conv_rows (backward data)");
     }
     if (ctx->needs_input_grad(1)) {
-      dw = at::empty_like(weight);
+      // scratch of the side stream is allocated under that stream, so the caching allocator recycles it in its order
+      c10::optional<c10::hip::HIPStreamGuard> sg;
+      if (overlap) sg.emplace(side->stream);
       if (pairs.defined()) {  // compacted pair lists of the rulebook: balanced by pairs, no compaction prologue
         const int64_t plen = pairs.size(2);
         const size_t wsb = fv2p_sparse_conv_wgrad_pairs_ws_bytes(plen, static_cast<int>(cin), static_cast<int>(cout), static_cast<int>(kvol));
-        at::Tensor ws = workspace(wsb, features, stream);
+        at::Tensor ws = workspace(wsb, features, wstream);
         check(fv2p_sparse_conv_wgrad_pairs(features.data_ptr<float>(), features.size(0), static_cast<int>(cin), g.data_ptr<float>(), g.size(0),
                                            static_cast<int>(cout), pairs.data_ptr<int>(), pair_num.data_ptr<int>(), static_cast<int>(kvol), plen,
                                            static_cast<int>(ctx->saved_data["side_src"].toInt()), dw.data_ptr<float>(), ws.data_ptr(),
-                                           static_cast<size_t>(ws.numel()), stream),
+                                           static_cast<size_t>(ws.numel()), wstream),
               "fv2p_sparse_conv_wgrad_pairs");
       } else {
         const size_t wsb = fv2p_sparse_conv_wgrad_ws_bytes(g.size(0), static_cast<int>(cin), static_cast<int>(cout), static_cast<int>(kvol));
-        at::Tensor ws = workspace(wsb, features, stream);
+        at::Tensor ws = workspace(wsb, features, wstream);
         check(fv2p_sparse_conv_wgrad(features.data_ptr<float>(), features.size(0), static_cast<int>(cin), g.data_ptr<float>(), tab_f.data_ptr<int>(),
                                      g.size(0), static_cast<int>(cout), static_cast<int>(kvol), flip_f, centre, dw.data_ptr<float>(), ws.data_ptr(),
-                                     static_cast<size_t>(ws.numel()), stream),
+                                     static_cast<size_t>(ws.numel()), wstream),
               "fv2p_sparse_conv_wgrad");
       }
+    }
+    if (overlap) {
+      TORCH_CHECK(hipEventRecord(side->join, side->stream.stream()) == hipSuccess, "hipEventRecord failed");
+      TORCH_CHECK(hipStreamWaitEvent(static_cast<hipStream_t>(stream), side->join, 0) == hipSuccess, "hipStreamWaitEvent failed");
     }
     return {din, dw, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
   }
