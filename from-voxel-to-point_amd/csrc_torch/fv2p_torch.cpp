@@ -235,6 +235,19 @@ at::Tensor batch_norm_relu(const at::Tensor& x, const c10::optional<at::Tensor>&
   return BnReluFn::apply(x, weight, bias, running_mean, running_var, num_batches_tracked, training, momentum, eps, relu);
 }
 
+// conv -> BatchNorm1d (-> ReLU) of one backbone block in one crossing from Python (post_act_block, spconv_backbone.py:8-27)
+at::Tensor sparse_conv_bn_relu(const at::Tensor& features, const at::Tensor& weight, const at::Tensor& tab_f, int64_t flip_f, const at::Tensor& tab_b,
+                               int64_t flip_b, int64_t n_out, int64_t centre, const c10::optional<at::Tensor>& pairs,
+                               const c10::optional<at::Tensor>& pair_num, int64_t side_src, const c10::optional<at::Tensor>& conv_bias,
+                               const c10::optional<at::Tensor>& bn_weight, const c10::optional<at::Tensor>& bn_bias,
+                               const c10::optional<at::Tensor>& running_mean, const c10::optional<at::Tensor>& running_var,
+                               const c10::optional<at::Tensor>& num_batches_tracked, bool training, double momentum, double eps, bool relu) {
+  at::Tensor y = SparseConvFn::apply(features, weight, tab_f, flip_f, tab_b, flip_b, n_out, centre, pairs, pair_num, side_src);
+  if (conv_bias.has_value() && conv_bias->defined()) y = y + *conv_bias;
+  if (n_out < 2 && training) return at::Tensor();   // torch raises for one value per channel: let the caller run the module
+  return BnReluFn::apply(y, bn_weight, bn_bias, running_mean, running_var, num_batches_tracked, training, momentum, eps, relu);
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -242,4 +255,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("abi_version", []() { return fv2p_abi_version(); });
   m.def("sparse_conv", &sparse_conv, "fused sparse convolution with autograd (tables from a Rulebook)");
   m.def("batch_norm_relu", &batch_norm_relu, "BatchNorm1d (+ReLU) on [N, C] with autograd");
+  m.def("sparse_conv_bn_relu", &sparse_conv_bn_relu, "sparse conv -> BatchNorm1d (-> ReLU) with autograd, one call per backbone block");
 }

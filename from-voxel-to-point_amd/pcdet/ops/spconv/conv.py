@@ -75,7 +75,9 @@ class SparseConvolution(SparseModule):
             bound = 1 / math.sqrt(fan_in)
             init.uniform_(self.bias, -bound, bound)
 
-    def forward(self, input):
+    def forward(self, input, _post=None):
+        """`_post` (internal, set by SparseSequential): the (BatchNorm1d, ReLU-or-None) pair that follows this conv; when
+        the compiled binding can run conv -> BN -> ReLU in one call the returned tensor carries `_fv2p_post_done`."""
         assert isinstance(input, SparseConvTensor)
         features = input.features
         indices = input.indices
@@ -112,6 +114,14 @@ class SparseConvolution(SparseModule):
                 input.indice_dict[self.indice_key] = rb
             outids = rb.outids
         n_out = outids.shape[0]
+        if _post is not None and not self.fused_bn:
+            fused = self._conv_bn_relu(features, rb, n_out, _post)
+            if fused is not None:
+                out_tensor = SparseConvTensor(fused, outids, out_spatial_shape, batch_size)
+                out_tensor.indice_dict = input.indice_dict
+                out_tensor.grid = input.grid
+                out_tensor._fv2p_post_done = True
+                return out_tensor
         if self.fused_bn:
             assert self.bias is not None
             out_features = ops.fused_indice_conv(features, self.weight, self.bias, rb, None, n_out,
@@ -129,6 +139,30 @@ class SparseConvolution(SparseModule):
         out_tensor.indice_dict = input.indice_dict
         out_tensor.grid = input.grid
         return out_tensor
+
+
+def _conv_bn_relu(self, features, rb, n_out, post):
+    """conv -> BatchNorm1d (-> ReLU) through the compiled binding in one call, or None when any of the three is not the
+    plain case (then the modules run one by one, with torch's own error behaviour)."""
+    import fv2p_native as _nat
+    from .norm import fusable
+    ext = _nat.torch_ext()
+    bn, relu = post
+    if ext is None or n_out < 2 or not fusable(bn, relu, features, self.out_channels):
+        return None
+    if not (features.is_cuda and features.dtype == torch.float32 and self.weight.dtype == torch.float32 and features.dim() == 2):
+        return None
+    (tab_f, flip_f), (tab_b, flip_b) = (rb.in_table(), rb.out_table()) if self.inverse else (rb.out_table(), rb.in_table())
+    centre = (rb.kvol // 2) if (rb.subm and rb.tab_out is None and not self.inverse) else -1
+    have = rb._wpairs is not None and rb._num is not None
+    out = ext.sparse_conv_bn_relu(features, self.weight, tab_f, flip_f, tab_b, flip_b, n_out, centre, rb._wpairs if have else None,
+                                  rb._num if have else None, 1 if self.inverse else 0, self.bias, bn.weight, bn.bias, bn.running_mean,
+                                  bn.running_var, bn.num_batches_tracked, bn.training,
+                                  -1.0 if bn.momentum is None else float(bn.momentum), float(bn.eps), relu is not None)
+    return out
+
+
+SparseConvolution._conv_bn_relu = _conv_bn_relu
 
 
 def _make(name, ndim, **fixed):

@@ -73,7 +73,15 @@ class SparseSequential(SparseModule):
             if is_spconv_module(module):
                 assert isinstance(input, SparseConvTensor)
                 self._sparity_dict[k] = input.sparity
-                input = module(input)
+                if is_sparse_conv(module) and i < len(items) and isinstance(items[i][1], nn.BatchNorm1d) and input.indices.shape[0] != 0:
+                    # conv -> BatchNorm1d (-> ReLU), the reference's post_act_block: offered to the conv as one fused call
+                    relu = items[i + 1][1] if i + 1 < len(items) and isinstance(items[i + 1][1], nn.ReLU) else None
+                    input = module(input, _post=(items[i][1], relu))
+                    if getattr(input, "_fv2p_post_done", False):
+                        input._fv2p_post_done = False
+                        i += 1 + (relu is not None)
+                else:
+                    input = module(input)
             elif isinstance(input, SparseConvTensor):
                 if input.indices.shape[0] != 0:
                     if isinstance(module, nn.BatchNorm1d):

@@ -74,20 +74,29 @@ def _plain(module):
     return not (module._forward_hooks or module._forward_pre_hooks or module._backward_hooks)
 
 
+def fusable(bn, relu_module, x, channels):
+    """The plain case of the (BatchNorm1d, ReLU) pair on features x [N, channels] the fused op covers."""
+    if not _ENABLED or type(bn) is not nn.BatchNorm1d or not _plain(bn):
+        return False
+    if relu_module is not None and (type(relu_module) is not nn.ReLU or not _plain(relu_module)):
+        return False
+    if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2):
+        return False
+    if torch.is_autocast_enabled() or channels != bn.num_features:
+        return False
+    c = channels
+    if c > 256 and c % 4 != 0 or c > 1024:
+        return False
+    if bn.weight is not None and (bn.weight.dtype != torch.float32 or not bn.weight.is_cuda):
+        return False
+    return True
+
+
 def batch_norm_relu(bn, x, relu_module=None):
     """y = relu?(bn(x)) for x [N, C] fp32 on the GPU, or None when the fused path does not apply."""
-    if not _ENABLED or type(bn) is not nn.BatchNorm1d or not _plain(bn):
+    if not (torch.is_tensor(x) and x.dim() == 2 and x.is_contiguous() and fusable(bn, relu_module, x, x.shape[1])):
         return None
-    if relu_module is not None and (type(relu_module) is not nn.ReLU or not _plain(relu_module)):
-        return None
-    if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()):
-        return None
-    if torch.is_autocast_enabled() or x.shape[1] != bn.num_features:
-        return None
-    n, c = x.shape
-    if n < 2 or c > 256 and c % 4 != 0 or c > 1024:
-        return None
-    if bn.weight is not None and (bn.weight.dtype != torch.float32 or not bn.weight.is_cuda):
+    if x.shape[0] < 2:
         return None
     ext = _nat.torch_ext()
     if ext is not None:

@@ -120,14 +120,23 @@ def test_sparse_sequential_uses_fused_pair_and_falls_back(gpu, front_end, monkey
 
     calls = []
     from pcdet.ops.spconv import modules
+    from pcdet.ops.spconv.conv import SparseConvolution
     orig = modules.batch_norm_relu
+    orig_block = SparseConvolution._conv_bn_relu
 
-    def counting(bn, x, relu_module=None):
+    def counting(bn, x, relu_module=None):          # BN(+ReLU) fused on its own (ctypes front end)
         out = orig(bn, x, relu_module)
         calls.append(out is not None and relu_module is not None)
         return out
 
+    def counting_block(self, features, rb, n_out, post):   # conv -> BN -> ReLU in one call (compiled front end)
+        out = orig_block(self, features, rb, n_out, post)
+        if out is not None:
+            calls.append(post[1] is not None)
+        return out
+
     monkeypatch.setattr(modules, "batch_norm_relu", counting)
+    monkeypatch.setattr(SparseConvolution, "_conv_bn_relu", counting_block)
     y1, g1, rv1 = run(build())
     assert calls == [True]                       # the BN+ReLU pair went through the fused op
     net = build()
