@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--pair-lists", type=int, default=1, help="prefetch also materialises the reference-format pair lists (pair-split weight gradient)")
     ap.add_argument("--switch-interval", type=float, default=0.0, help="sys.setswitchinterval (s); 0 keeps Python's default 5 ms")
     ap.add_argument("--prefetch-depth", type=int, default=2, help="batches the input-pipeline thread keeps in flight")
+    ap.add_argument("--step-times", action="store_true", help="diagnostic: percentiles of the host-side interval between steps (stderr)")
     ap.add_argument("--phases", action="store_true", help="diagnostic: host issue time and synchronised wall time per phase (stderr)")
     ap.add_argument("--pyprofile", action="store_true", help="cProfile the timed steps (host-overhead hunting; prints to stderr)")
     return ap.parse_args()
@@ -284,8 +285,11 @@ def main():
         prof = cProfile.Profile()
         prof.enable()
     t0 = time.perf_counter()
+    stamps = []
     for i in range(args.steps):
         step(args.warmup + i)
+        if args.step_times:
+            stamps.append(time.perf_counter())
     if prof is not None:
         prof.disable()
         import pstats
@@ -293,6 +297,12 @@ def main():
     dist_utils.barrier()
     torch.cuda.synchronize()
     dt = dist_utils.max_over_ranks(time.perf_counter() - t0, device)
+    if args.step_times and rank == 0 and len(stamps) > 2:
+        d = np.diff(np.array(stamps)) * 1e3
+        print("[step-times] host interval between steps, ms: p10 %.3f p50 %.3f p90 %.3f p99 %.3f max %.3f" %
+              tuple(np.percentile(d, [10, 50, 90, 99, 100])), file=sys.stderr)
+        top = np.argsort(d)[-4:][::-1]
+        print("[step-times] slowest steps (index: ms):", ", ".join("%d: %.2f" % (int(i) + 1, d[i]) for i in top), file=sys.stderr)
     result = None
     if rank == 0:
         clouds = args.batch * world * args.steps

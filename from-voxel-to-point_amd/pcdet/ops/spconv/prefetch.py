@@ -45,10 +45,14 @@ def build_rulebooks(recipe, indices, batch_size, pair_lists=True):
     if indices.dtype != torch.int32:
         indices = indices.int()
     indices = indices.contiguous()
+    # the rulebooks keep an alias of the root coordinates, not the tensor object they get attached to: attaching would
+    # otherwise close a reference cycle (tensor -> dict -> Rulebook.indices -> tensor) and every batch's device memory
+    # would wait for Python's cyclic collector (seen as one 90 ms step every ~300 steps)
+    root = indices.detach()
     out = {}
     for key, src, shape, geom in recipe:
         ksize, stride, padding, dilation, out_padding, subm, transpose = geom
-        ind = indices if src is None else out[src].outids
+        ind = root if src is None else out[src].outids
         out[key] = ops.build_rulebook(ind, batch_size, shape, list(ksize), list(stride), list(padding), list(dilation),
                                       list(out_padding), subm, transpose)
         out[key].prefetched = True
