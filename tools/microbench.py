@@ -33,10 +33,14 @@ def conv(only=None):
     from pcdet.ops.spconv.conv import SparseConvolution
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    model = VoxelBackBone8x(4, [1408, 1600, 40]).to(dev)
+    waymo = bool(os.environ.get("FV2P_WAYMO"))   # BASELINE configs[4]: ~180 k points per cloud, 0.1 m voxels, [41, 1504, 1504] grid
+    model = VoxelBackBone8x(4, [1504, 1504, 40] if waymo else [1408, 1600, 40]).to(dev)
     feats, coords = [], []
     for b in range(4):
-        v, c, n = points_to_voxel_gpu(torch.from_numpy(synth.lidar_cloud(b, 16384)).to(dev), synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, True, 16000)
+        if waymo:
+            v, c, n = points_to_voxel_gpu(torch.from_numpy(synth.waymo_like_cloud(b, 180000)).to(dev), synth.WAYMO_VOXEL, synth.WAYMO_RANGE, 5, True, 150000)
+        else:
+            v, c, n = points_to_voxel_gpu(torch.from_numpy(synth.lidar_cloud(b, 16384)).to(dev), synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, True, 16000)
         feats.append(mean_vfe(v, n))
         coords.append(torch.nn.functional.pad(c, (1, 0), value=b))
     recs = []
