@@ -143,7 +143,14 @@ def build_step(args, device, rank, world):
         phase("backward", lambda: loss.backward())
         phase("optimizer", lambda: opt.step())
 
+    def close():   # drain the input pipeline before the interpreter shuts down
+        if pre is not None:
+            while pre.pending:
+                pre.get()
+            pre.close()
+
     step.phases = step_phases
+    step.close = close
     return model, step, voxelize, pool
 
 
@@ -303,6 +310,7 @@ def main():
               tuple(np.percentile(d, [10, 50, 90, 99, 100])), file=sys.stderr)
         top = np.argsort(d)[-4:][::-1]
         print("[step-times] slowest steps (index: ms):", ", ".join("%d: %.2f" % (int(i) + 1, d[i]) for i in top), file=sys.stderr)
+    step.close()
     result = None
     if rank == 0:
         clouds = args.batch * world * args.steps
