@@ -27,8 +27,9 @@ FV2P_HD int pt_in_box3d(const float* pt, const float* box, float margin, float* 
   const float ly = sx * sina + sy * cosa;
   *local_x = lx;
   *local_y = ly;
-  return (static_cast<double>(fabsf(lx)) < static_cast<double>(dx) / 2.0 + static_cast<double>(margin)) &
-         (static_cast<double>(fabsf(ly)) < static_cast<double>(dy) / 2.0 + static_cast<double>(margin));
+  const bool in_x = static_cast<double>(fabsf(lx)) < static_cast<double>(dx) / 2.0 + static_cast<double>(margin);
+  const bool in_y = static_cast<double>(fabsf(ly)) < static_cast<double>(dy) / 2.0 + static_cast<double>(margin);
+  return in_x && in_y;
 }
 
 constexpr float kMarginGpu = 1e-5f;  // roiaware_pool3d_kernel.cu:27, roipoint_pool3d_kernel.cu:26
@@ -58,7 +59,6 @@ __global__ __launch_bounds__(256) void roipoint_pool_k(int pts_num, int boxes_nu
                                                        float* __restrict__ pooled, int* __restrict__ empty_flag) {
   extern __shared__ int sidx[];  // [sampled]
   __shared__ int wave_cnt[4];
-  __shared__ int s_total;
   const int m = blockIdx.x, b = blockIdx.y;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float box[7];
