@@ -10,15 +10,11 @@ import threading
 import torch
 
 
-class BatchPrefetcher(object):
-    def __init__(self, produce, device, depth=1):
-        """produce(i) -> tuple of tensors (any nesting of tuples/lists/dicts of tensors is walked for record_stream)."""
-        self.produce, self.device = produce, device
+class _Worker(object):
+    def __init__(self, owner, device):
+        self.owner, self.device = owner, device
         self.stream = torch.cuda.Stream(device=device)
-        self.jobs, self.done = queue.Queue(), queue.Queue()
-        self.depth, self.pending = depth, 0
-        self.retire = queue.Queue()   # (batch, event on the training stream after its last use)
-        self.last = None
+        self.jobs, self.done, self.retire = queue.Queue(), queue.Queue(), queue.Queue()
         self.thread = threading.Thread(target=self._run, daemon=True)
         self.thread.start()
 
@@ -40,21 +36,37 @@ class BatchPrefetcher(object):
                 del old
             try:
                 with torch.cuda.stream(self.stream):
-                    out = self.produce(i)
+                    out = self.owner.produce(i)
                     ev = torch.cuda.Event()
                     ev.record(self.stream)
                 self.done.put((out, ev, None))
             except BaseException as e:  # surfaced by get()
                 self.done.put((None, None, e))
 
+
+class BatchPrefetcher(object):
+    def __init__(self, produce, device, workers=1):
+        """produce(i) -> the batch (tensors, possibly nested / with rulebooks attached).  `workers` pipeline threads, each
+        with its own HIP stream, prepare consecutive batches concurrently (a batch's preparation is a chain of small
+        kernels and host synchronisations — latency, not throughput — so two in flight nearly double the rate);
+        batches are handed out in submission order."""
+        self.produce, self.device = produce, device
+        self.workers = [_Worker(self, device) for _ in range(max(1, int(workers)))]
+        self.pending = 0
+        self.n_in = self.n_out = 0
+        self.last = None   # (batch, worker) handed out by the previous get()
+
     def submit(self, i):
-        self.jobs.put(i)
+        self.workers[self.n_in % len(self.workers)].jobs.put(i)
+        self.n_in += 1
         self.pending += 1
 
     def get(self):
         """Next prepared batch.  Contract: a batch (and the rulebooks attached to it) is used only until the next get()
-        — its memory belongs to the pipeline stream and is recycled once the training stream passes that point."""
-        out, ev, err = self.done.get()
+        — its memory belongs to its pipeline stream and is recycled once the training stream passes that point."""
+        w = self.workers[self.n_out % len(self.workers)]
+        out, ev, err = w.done.get()
+        self.n_out += 1
         self.pending -= 1
         if err is not None:
             raise err
@@ -63,14 +75,16 @@ class BatchPrefetcher(object):
             # the previous batch must not be touched after this call: everything that used it is already on `main`
             done_ev = torch.cuda.Event()
             done_ev.record(main)
-            self.retire.put((self.last, done_ev))
+            self.last[1].retire.put((self.last[0], done_ev))
         main.wait_event(ev)
-        self.last = out
+        self.last = (out, w)
         return out
 
     def close(self):
-        self.jobs.put(None)
-        self.thread.join(timeout=5)
+        for w in self.workers:
+            w.jobs.put(None)
+        for w in self.workers:
+            w.thread.join(timeout=5)
 
 
 def _walk(obj, fn, seen=None):

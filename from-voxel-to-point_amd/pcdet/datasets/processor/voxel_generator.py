@@ -82,7 +82,7 @@ def points_to_voxel_batch(points_list, voxel_size, coors_range, max_points=35, m
     grid = _grid_size(voxel_size, coors_range)
     dev = points_list[0].device
     main = torch.cuda.current_stream(dev)
-    pool = _STREAMS.setdefault(dev.index, [])
+    pool = _STREAMS.setdefault((dev.index, main.cuda_stream), [])   # per calling stream: concurrent pipeline threads never share
     while len(pool) < len(points_list):
         pool.append(torch.cuda.Stream(device=dev))
     outs = []

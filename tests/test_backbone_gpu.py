@@ -93,7 +93,7 @@ def test_input_pipeline_thread_produces_the_inline_batches(gpu):
         spconv.attach_rulebooks(c, spconv.build_rulebooks(recipe, c, 2))
         return f, c
 
-    pre = BatchPrefetcher(produce, gpu)
+    pre = BatchPrefetcher(produce, gpu, workers=2)
     try:
         for i in range(3):
             pre.submit(i)
