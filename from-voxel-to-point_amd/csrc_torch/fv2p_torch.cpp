@@ -15,6 +15,8 @@
 #include <cstdlib>
 
 #include <map>
+#include <tuple>
+#include <vector>
 #include <mutex>
 #include <string>
 
@@ -248,6 +250,152 @@ at::Tensor sparse_conv_bn_relu(const at::Tensor& features, const at::Tensor& wei
   return BnReluFn::apply(y, bn_weight, bn_bias, running_mean, running_var, num_batches_tracked, training, momentum, eps, relu);
 }
 
+
+// ---- input-pipeline entry points: one GIL-free call each ----------------------------------------------------------------
+// A pipeline thread that prepares the next batch shares the interpreter lock with the training thread.  Issued from
+// Python, a batch's voxelisation and rulebook chain is ~120 small calls, i.e. ~120 lock hand-offs per step with the
+// training thread; these two functions do the same work (same library calls, same order) inside C++ with the lock
+// released, allocating their outputs with at::empty.
+
+// points_to_voxel_batch(mean_vfe=True): one stream per cloud, one host synchronisation for the voxel counts, then
+// MeanVFE + collate (voxel_mean_collate) -> (features [sum M, ndim], coords [sum M, 4] int32)
+std::vector<at::Tensor> voxelize_batch_mean(const std::vector<at::Tensor>& clouds, std::vector<double> voxel_size, std::vector<double> range_lo,
+                                            std::vector<int64_t> grid, int64_t max_points, int64_t max_voxels) {
+  TORCH_CHECK(!clouds.empty() && voxel_size.size() == 3 && range_lo.size() == 3 && grid.size() == 3, "voxelize_batch_mean: bad arguments");
+  const at::Tensor& first = clouds[0];
+  c10::DeviceGuard guard(first.device());
+  const int dev = first.device().index();
+  const c10::hip::HIPStream main = c10::hip::getCurrentHIPStream(dev);
+  const float vs[3] = {static_cast<float>(voxel_size[0]), static_cast<float>(voxel_size[1]), static_cast<float>(voxel_size[2])};
+  const float lo[3] = {static_cast<float>(range_lo[0]), static_cast<float>(range_lo[1]), static_cast<float>(range_lo[2])};
+  const int gr[3] = {static_cast<int>(grid[0]), static_cast<int>(grid[1]), static_cast<int>(grid[2])};
+  const size_t nb = clouds.size();
+  static std::mutex mu;
+  static std::map<std::pair<int, void*>, std::vector<c10::hip::HIPStream>> pools;   // cloud streams per calling stream
+  static std::map<std::pair<int, void*>, std::pair<hipEvent_t, std::vector<hipEvent_t>>> events;
+  std::vector<c10::hip::HIPStream>* pool;
+  std::pair<hipEvent_t, std::vector<hipEvent_t>>* evs;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    auto key = std::make_pair(dev, static_cast<void*>(main.stream()));
+    pool = &pools[key];
+    evs = &events[key];
+    while (pool->size() < nb) pool->push_back(c10::hip::getStreamFromPool(false, static_cast<c10::DeviceIndex>(dev)));
+    if (!evs->first) TORCH_CHECK(hipEventCreateWithFlags(&evs->first, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
+    while (evs->second.size() < nb) {
+      hipEvent_t e;
+      TORCH_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess, "hipEventCreate failed");
+      evs->second.push_back(e);
+    }
+  }
+  TORCH_CHECK(hipEventRecord(evs->first, main.stream()) == hipSuccess, "hipEventRecord failed");
+  std::vector<at::Tensor> vox(nb), coors(nb), num(nb);
+  at::Tensor counts = at::empty({static_cast<int64_t>(nb)}, first.options().dtype(at::kInt));
+  for (size_t b = 0; b < nb; ++b) {
+    const at::Tensor pts = clouds[b].contiguous();
+    require_f32_cuda(pts, "points");
+    const int64_t n = pts.size(0), ndim = pts.size(1);
+    // per-cloud outputs are allocated on the calling stream and handed to the cloud's stream behind the fork event
+    vox[b] = at::empty({max_voxels, max_points, ndim}, pts.options());
+    coors[b] = at::empty({max_voxels, 3}, pts.options().dtype(at::kInt));
+    num[b] = at::empty({max_voxels}, pts.options().dtype(at::kInt));
+    hipStream_t st = (*pool)[b].stream();
+    TORCH_CHECK(hipStreamWaitEvent(st, evs->first, 0) == hipSuccess, "hipStreamWaitEvent failed");
+    at::Tensor ws;
+    {
+      c10::hip::HIPStreamGuard sg((*pool)[b]);
+      ws = workspace(fv2p_points_to_voxel_ws_bytes(n, static_cast<int>(max_voxels)), pts, static_cast<void*>(st));
+    }
+    check(fv2p_points_to_voxel(pts.data_ptr<float>(), n, static_cast<int>(ndim), vs, lo, gr, static_cast<int>(max_points),
+                               static_cast<int>(max_voxels), vox[b].data_ptr<float>(), coors[b].data_ptr<int>(), num[b].data_ptr<int>(),
+                               counts.data_ptr<int>() + b, ws.data_ptr(), static_cast<size_t>(ws.numel()), static_cast<void*>(st)),
+          "fv2p_points_to_voxel");
+    TORCH_CHECK(hipEventRecord(evs->second[b], st) == hipSuccess, "hipEventRecord failed");
+    TORCH_CHECK(hipStreamWaitEvent(main.stream(), evs->second[b], 0) == hipSuccess, "hipStreamWaitEvent failed");
+  }
+  const at::Tensor counts_host = counts.cpu();   // the one synchronisation of the batch
+  const int* ch = counts_host.data_ptr<int>();
+  int64_t total = 0;
+  std::vector<int64_t> m(nb);
+  for (size_t b = 0; b < nb; ++b) { m[b] = std::min<int64_t>(ch[b], max_voxels); total += m[b]; }
+  const int64_t ndim = clouds[0].size(1);
+  at::Tensor feats = at::empty({total, ndim}, first.options());
+  at::Tensor coords = at::empty({total, 4}, first.options().dtype(at::kInt));
+  int64_t off = 0;
+  for (size_t b = 0; b < nb; ++b) {
+    if (m[b] > 0)
+      check(fv2p_voxel_mean_collate(vox[b].data_ptr<float>(), coors[b].data_ptr<int>(), num[b].data_ptr<int>(), counts.data_ptr<int>() + b,
+                                    static_cast<int>(m[b]), static_cast<int>(max_points), static_cast<int>(ndim), static_cast<int>(b),
+                                    feats.data_ptr<float>() + off * ndim, coords.data_ptr<int>() + off * 4, static_cast<void*>(main.stream())),
+            "fv2p_voxel_mean_collate");
+    off += m[b];
+  }
+  return {feats, coords};
+}
+
+// One rulebook of a chain: geometry as the Python layer computes it (3-D, (z, y, x) order).
+struct RulebookSpec {
+  int64_t src;   // index of the entry whose output rows are this entry's input rows, -1 = the root coordinates
+  std::vector<int64_t> in_shape, out_shape, ksize, stride, padding, dilation;
+  bool subm, transpose, symmetric, want_pairs;
+};
+// -> per entry [outids (or empty for subm), tab_in, tab_out (empty when symmetric), pairs (or empty), pair_num (or empty)]
+std::vector<std::vector<at::Tensor>> build_rulebook_chain(const at::Tensor& root, int64_t batch,
+                                                          const std::vector<std::tuple<int64_t, std::vector<int64_t>, std::vector<int64_t>, std::vector<int64_t>,
+                                                                                       std::vector<int64_t>, std::vector<int64_t>, std::vector<int64_t>, bool, bool, bool, bool>>& specs) {
+  TORCH_CHECK(root.is_cuda() && root.scalar_type() == at::kInt && root.dim() == 2 && root.size(1) == 4 && root.is_contiguous(),
+              "build_rulebook_chain: root indices must be a contiguous CUDA int32 [N, 4] tensor");
+  c10::DeviceGuard guard(root.device());
+  void* stream = cur_stream(root);
+  std::vector<std::vector<at::Tensor>> out;
+  out.reserve(specs.size());
+  auto arr3 = [](const std::vector<int64_t>& v, int (&a)[3]) {
+    TORCH_CHECK(v.size() == 3, "build_rulebook_chain: 3-D geometry expected");
+    for (int i = 0; i < 3; ++i) a[i] = static_cast<int>(v[i]);
+  };
+  for (const auto& sp : specs) {
+    const int64_t src = std::get<0>(sp);
+    int in_shape[3], out_shape[3], ksize[3], stride[3], padding[3], dilation[3];
+    arr3(std::get<1>(sp), in_shape); arr3(std::get<2>(sp), out_shape); arr3(std::get<3>(sp), ksize);
+    arr3(std::get<4>(sp), stride); arr3(std::get<5>(sp), padding); arr3(std::get<6>(sp), dilation);
+    const bool subm = std::get<7>(sp), transpose = std::get<8>(sp), symmetric = std::get<9>(sp), want_pairs = std::get<10>(sp);
+    TORCH_CHECK(src < static_cast<int64_t>(out.size()), "build_rulebook_chain: source entry comes later in the chain");
+    const at::Tensor ind = src < 0 ? root : out[src][0];
+    TORCH_CHECK(ind.defined(), "build_rulebook_chain: source entry has no output rows of its own (submanifold)");
+    const int64_t n_in = ind.size(0);
+    const int kvol = ksize[0] * ksize[1] * ksize[2];
+    at::Tensor ws = workspace(fv2p_rulebook_ws_bytes(n_in, ksize, stride, dilation, subm, transpose), root, stream);
+    int64_t n_out = 0;
+    check(fv2p_rulebook_begin(ind.data_ptr<int>(), n_in, static_cast<int>(batch), in_shape, out_shape, ksize, stride, padding, dilation, subm,
+                              transpose, &n_out, ws.data_ptr(), static_cast<size_t>(ws.numel()), stream),
+          "fv2p_rulebook_begin");
+    const auto iopt = root.options();
+    at::Tensor tab_in = at::empty({kvol, n_in}, iopt), tab_out, outids;
+    if (subm) {
+      if (!symmetric) tab_out = at::empty({kvol, n_out}, iopt);
+    } else {
+      outids = at::empty({n_out, 4}, iopt);
+      tab_out = at::empty({kvol, n_out}, iopt);
+    }
+    check(fv2p_rulebook_finish(ind.data_ptr<int>(), n_in, static_cast<int>(batch), in_shape, out_shape, ksize, stride, padding, dilation, subm,
+                               transpose, n_out, outids.defined() ? outids.data_ptr<int>() : nullptr, tab_in.data_ptr<int>(),
+                               tab_out.defined() ? tab_out.data_ptr<int>() : nullptr, nullptr, ws.data_ptr(), static_cast<size_t>(ws.numel()), stream),
+          "fv2p_rulebook_finish");
+    at::Tensor pairs, pnum;
+    if (want_pairs && n_in > 0) {
+      pairs = at::empty({kvol, 2, n_in}, iopt);
+      pnum = at::empty({kvol}, iopt);
+      at::Tensor pws = workspace(fv2p_rulebook_pairs_ws_bytes(n_in, kvol), root, stream);
+      check(fv2p_rulebook_pairs(tab_in.data_ptr<int>(), n_in, kvol, 0, pairs.data_ptr<int>(), pnum.data_ptr<int>(), pws.data_ptr(),
+                                static_cast<size_t>(pws.numel()), stream),
+            "fv2p_rulebook_pairs");
+    }
+    out.push_back({subm ? at::Tensor() : outids, tab_in, tab_out, pairs, pnum});
+    if (subm) out.back()[0] = at::Tensor();
+  }
+  return out;
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -255,5 +403,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("abi_version", []() { return fv2p_abi_version(); });
   m.def("sparse_conv", &sparse_conv, "fused sparse convolution with autograd (tables from a Rulebook)");
   m.def("batch_norm_relu", &batch_norm_relu, "BatchNorm1d (+ReLU) on [N, C] with autograd");
+  m.def("voxelize_batch_mean", &voxelize_batch_mean, py::call_guard<py::gil_scoped_release>(),
+        "voxelise a batch of clouds + MeanVFE + collate, without the GIL");
+  m.def("build_rulebook_chain", &build_rulebook_chain, py::call_guard<py::gil_scoped_release>(),
+        "build a chain of rulebooks (and pair lists) from root coordinates, without the GIL");
   m.def("sparse_conv_bn_relu", &sparse_conv_bn_relu, "sparse conv -> BatchNorm1d (-> ReLU) with autograd, one call per backbone block");
 }

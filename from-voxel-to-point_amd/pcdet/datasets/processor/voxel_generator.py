@@ -81,6 +81,14 @@ def points_to_voxel_batch(points_list, voxel_size, coors_range, max_points=35, m
     coors_range = np.asarray(coors_range, dtype=np.float32)
     grid = _grid_size(voxel_size, coors_range)
     dev = points_list[0].device
+    ext = _nat.torch_ext() if mean_vfe else None
+    if ext is not None and all(p.is_cuda and p.dtype == torch.float32 and p.dim() == 2 for p in points_list):
+        # the whole batch (per-cloud streams, the one synchronisation, MeanVFE + collate) inside the compiled binding,
+        # without the interpreter lock: an input-pipeline thread then barely competes with the training thread for it
+        with _nat.device_guard(dev):
+            feats, coords = ext.voxelize_batch_mean(list(points_list), [float(v) for v in voxel_size], [float(v) for v in coors_range[:3]],
+                                                    [int(g) for g in grid], int(max_points), int(max_voxels))
+        return feats, coords
     main = torch.cuda.current_stream(dev)
     pool = _STREAMS.setdefault((dev.index, main.cuda_stream), [])   # per calling stream: concurrent pipeline threads never share
     while len(pool) < len(points_list):

@@ -16,6 +16,8 @@ input rows are not the tensor's, is ignored and rebuilt, so a stale recipe costs
 """
 import torch
 
+import fv2p_native as _nat
+
 from . import ops
 
 
@@ -49,6 +51,9 @@ def build_rulebooks(recipe, indices, batch_size, pair_lists=True):
     # otherwise close a reference cycle (tensor -> dict -> Rulebook.indices -> tensor) and every batch's device memory
     # would wait for Python's cyclic collector (seen as one 90 ms step every ~300 steps)
     root = indices.detach()
+    ext = _nat.torch_ext()
+    if ext is not None and root.is_cuda and root.dim() == 2 and root.shape[1] == 4 and all(len(r[2]) == 3 for r in recipe):
+        return _build_chain(ext, recipe, root, batch_size, pair_lists)
     out = {}
     for key, src, shape, geom in recipe:
         ksize, stride, padding, dilation, out_padding, subm, transpose = geom
@@ -58,6 +63,37 @@ def build_rulebooks(recipe, indices, batch_size, pair_lists=True):
         out[key].prefetched = True
         if pair_lists and subm:  # compacted pair lists: the weight gradient of submanifold convs splits its work by them
             out[key].wgrad_pairs()   # (measured: a win for subm rulebooks, a loss for the sparser strided ones)
+    return out
+
+
+def _build_chain(ext, recipe, root, batch_size, pair_lists):
+    """The same chain through one call of the compiled binding, which runs it without the interpreter lock (a pipeline
+    thread issuing ~60 small calls from Python trades the lock with the training thread ~60 times per batch)."""
+    keys = [r[0] for r in recipe]
+    specs, shapes = [], []
+    for key, src, shape, geom in recipe:
+        ksize, stride, padding, dilation, out_padding, subm, transpose = (list(g) if isinstance(g, tuple) else g for g in geom)
+        if subm:
+            out_shape = list(shape)
+        elif transpose:
+            out_shape = ops.get_deconv_output_size(shape, ksize, stride, padding, dilation, out_padding)
+        else:
+            out_shape = ops.get_conv_output_size(shape, ksize, stride, padding, dilation)
+        symmetric = bool(subm) and all(k % 2 == 1 for k in ksize) and all(d == 1 for d in dilation)
+        specs.append((-1 if src is None else keys.index(src), [int(v) for v in shape], [int(v) for v in out_shape], ksize, stride, padding,
+                      dilation, bool(subm), bool(transpose), symmetric, bool(pair_lists and subm)))
+        shapes.append(out_shape)
+    with _nat.device_guard(root.device):
+        res = ext.build_rulebook_chain(root, int(batch_size), specs)
+    out = {}
+    for (key, src, shape, geom), (outids, tab_in, tab_out, pairs, num), out_shape in zip(recipe, res, shapes):
+        ind = root if src is None else out[src].outids
+        subm = geom[5]
+        rb = ops.Rulebook(ind if subm else outids, ind, tab_in, tab_out, num, shape, int(tab_in.shape[0]), bool(subm))
+        rb.out_spatial_shape = out_shape
+        rb.geom, rb.batch_size, rb.prefetched = geom, int(batch_size), True
+        rb._wpairs = pairs
+        out[key] = rb
     return out
 
 
