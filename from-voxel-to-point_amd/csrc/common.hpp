@@ -109,6 +109,25 @@ __device__ __forceinline__ int table_find(const uint64_t* __restrict__ table, ui
   }
 }
 
+// Block-wide exclusive scan of one value per thread (256 threads); returns exclusive prefix,
+// *block_total receives the sum (valid in all threads).
+__device__ __forceinline__ int block_excl_scan_256(int v, int* lds_wave /*[4]*/, int* block_total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int t = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) lds_wave[w] = incl;
+  __syncthreads();
+  int w0 = lds_wave[0], w1 = lds_wave[1], w2 = lds_wave[2], w3 = lds_wave[3];
+  int base = (w > 0 ? w0 : 0) + (w > 1 ? w1 : 0) + (w > 2 ? w2 : 0);
+  *block_total = w0 + w1 + w2 + w3;
+  __syncthreads();
+  return base + incl - v;
+}
+
 // ---- internal primitives (sort_scan.hip) ---------------------------------------------
 size_t scan_ws_bytes(int64_t n);
 // Exclusive prefix sum of int32; in == out allowed. total (device int*, may be null) gets the sum.

@@ -153,6 +153,88 @@ __global__ void rb_fill_tables(const int* __restrict__ ind, int n_in, int n_out,
   if (tab_out) tab_out[static_cast<int64_t>(off) * n_out + o] = i;
 }
 
+// ---- strided / transposed rulebook through a bitmap of the output grid -----------------------------------------------------
+// When the output grid is small enough to afford one bit per cell (batch * volume <= 2^28: 32 MB; every KITTI / Waymo level
+// is below 2^26) the distinct output cells need neither a hash set nor a sort: candidates set their bit, an exclusive
+// popcount scan over the words ranks the cells in ascending flat index — the order torch::_unique gives the GPU reference
+// (spconv_ops.h:130-131) — and a neighbour's output row is prefix[word] + popc(bits below): two loads instead of a probe.
+// Replaces {hash-set insert, 4 radix passes, rank write-back} = 11 launches by {mark, tile sums, scan of sums, emit} = 4.
+constexpr int kBmTile = 2048;            // words per workgroup in the popcount passes (256 threads x 8)
+constexpr long long kBmMaxCells = 1ll << 28;
+
+__global__ void rb_mark_outputs(const int* __restrict__ ind, int n, RbGeom g, uint32_t* __restrict__ bitmap) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = blockIdx.y;
+  if (i >= n) return;
+  const int4 c = reinterpret_cast<const int4*>(ind)[i];
+  const int in[3] = {c.y, c.z, c.w};
+  int out[3], off;
+  if (!enum_out(g, in, e, out, &off)) return;
+  const uint64_t key = flat_key(c.x, out, g.out_shape, g.out_vol);
+  const uint32_t bit = 1u << (key & 31);
+  uint32_t* wp = bitmap + (key >> 5);
+  if (!(__hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(wp, bit);   // most candidates are repeats
+}
+// sums[b] = number of set bits in tile b
+__global__ __launch_bounds__(256) void rb_tile_popc(const uint32_t* __restrict__ bitmap, int64_t words, int* __restrict__ sums) {
+  __shared__ int ws[4];
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kBmTile + threadIdx.x * 8;
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) c += (base + j < words) ? __popc(bitmap[base + j]) : 0;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) sums[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+// prefix[w] = set bits before word w (tile offset from the scanned sums + local scan); out_ind[row] = decoded cell
+__global__ __launch_bounds__(256) void rb_emit_outputs(const uint32_t* __restrict__ bitmap, int64_t words, const int* __restrict__ tile_off,
+                                                       RbGeom g, int* __restrict__ prefix, int* __restrict__ out_ind) {
+  __shared__ int lds_wave[4];
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kBmTile + threadIdx.x * 8;
+  uint32_t w[8];
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { w[j] = (base + j < words) ? bitmap[base + j] : 0u; c += __popc(w[j]); }
+  int tot;
+  int run = block_excl_scan_256(c, lds_wave, &tot) + tile_off[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (base + j >= words) break;
+    prefix[base + j] = run;
+    uint32_t bits = w[j];
+    while (bits) {
+      const int b = __ffs(static_cast<int>(bits)) - 1;
+      bits &= bits - 1;
+      const uint64_t key = (static_cast<uint64_t>(base + j) << 5) + b;
+      uint64_t rem = key % static_cast<uint64_t>(g.out_vol);
+      int4 o;
+      o.x = static_cast<int>(key / static_cast<uint64_t>(g.out_vol));
+      o.w = static_cast<int>(rem % g.out_shape[2]); rem /= g.out_shape[2];
+      o.z = static_cast<int>(rem % g.out_shape[1]);
+      o.y = static_cast<int>(rem / g.out_shape[1]);
+      reinterpret_cast<int4*>(out_ind)[run++] = o;
+    }
+  }
+}
+__global__ void rb_fill_tables_bm(const int* __restrict__ ind, int n_in, int n_out, RbGeom g, const uint32_t* __restrict__ bitmap,
+                                  const int* __restrict__ prefix, int* __restrict__ tab_in, int* __restrict__ tab_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int e = blockIdx.y;
+  if (i >= n_in) return;
+  const int4 c = reinterpret_cast<const int4*>(ind)[i];
+  const int in[3] = {c.y, c.z, c.w};
+  int out[3], off;
+  if (!enum_out(g, in, e, out, &off)) return;
+  const uint64_t key = flat_key(c.x, out, g.out_shape, g.out_vol);
+  const uint32_t word = bitmap[key >> 5], bit = 1u << (key & 31);
+  if (!(word & bit)) return;
+  const int o = prefix[key >> 5] + __popc(word & (bit - 1u));
+  tab_in[static_cast<int64_t>(off) * n_in + i] = o;
+  if (tab_out) tab_out[static_cast<int64_t>(off) * n_out + o] = i;
+}
+
 // indice_num[k] = #valid entries of tab[k][:]
 __global__ void rb_count_rows(const int* __restrict__ tab, int n, int* __restrict__ num) {
   const int k = blockIdx.y;
@@ -265,6 +347,23 @@ static void rb_carve(C& c, int64_t n_in, int emax, int subm, RbWs* w) {
 }
 struct SizerC : Sizer { template <typename T> T* take(size_t n) { Sizer::take<T>(n); return nullptr; } };
 
+struct BmWs {
+  uint32_t* bitmap; int* prefix; int* sums; int64_t words; int tiles;
+  char* aux; size_t aux_bytes;
+};
+static bool bm_applies(long long cells, int subm) { return !subm && cells > 0 && cells <= kBmMaxCells; }
+template <typename C>
+static void bm_carve(C& c, long long cells, BmWs* w) {
+  const int64_t words = (cells + 31) / 32;
+  const int tiles = static_cast<int>(ceil_div(words, kBmTile));
+  const size_t aux = scan_ws_bytes(tiles + 1);
+  uint32_t* bitmap = c.template take<uint32_t>(static_cast<size_t>(words));
+  int* prefix = c.template take<int>(static_cast<size_t>(words));
+  int* sums = c.template take<int>(static_cast<size_t>(tiles) + 1);
+  char* auxp = c.template take<char>(aux);
+  if (w) { w->bitmap = bitmap; w->prefix = prefix; w->sums = sums; w->words = words; w->tiles = tiles; w->aux = auxp; w->aux_bytes = aux; }
+}
+
 }  // namespace fv2p
 
 using namespace fv2p;
@@ -277,6 +376,30 @@ extern "C" size_t fv2p_rulebook_ws_bytes(int64_t n_in, const int ksize[3], const
   SizerC s;
   rb_carve(s, n_in > 0 ? n_in : 1, g.emax, subm, static_cast<RbWs*>(nullptr));
   return s.bytes();
+}
+
+extern "C" size_t fv2p_rulebook_ws_bytes_grid(int64_t n_in, int batch, const int out_shape[3], const int ksize[3], const int stride[3],
+                                              const int dilation[3], int subm, int transpose) {
+  const size_t hashed = fv2p_rulebook_ws_bytes(n_in, ksize, stride, dilation, subm, transpose);
+  const long long cells = static_cast<long long>(batch > 0 ? batch : 1) * out_shape[0] * out_shape[1] * out_shape[2];
+  if (!bm_applies(cells, subm)) return hashed;
+  SizerC s;
+  s.take<int>(4);
+  bm_carve(s, cells, static_cast<BmWs*>(nullptr));
+  return s.bytes() > hashed ? s.bytes() : hashed;
+}
+
+// the bitmap path is taken when it applies and the caller's workspace was sized for it (fv2p_rulebook_ws_bytes_grid)
+static int g_rb_path = 0;   // 0 = bitmap when it applies, 1 = always the hash set + sort (tests compare the two)
+extern "C" int fv2p_rulebook_set_path(int path) { g_rb_path = path; return 0; }
+static bool use_bitmap(const RbGeom& g, int batch, int subm, size_t ws_bytes) {
+  if (g_rb_path == 1) return false;
+  const long long cells = static_cast<long long>(batch) * g.out_vol;
+  if (!bm_applies(cells, subm)) return false;
+  SizerC s;
+  s.take<int>(4);
+  bm_carve(s, cells, static_cast<BmWs*>(nullptr));
+  return ws_bytes >= s.bytes();
 }
 
 extern "C" int fv2p_rulebook_begin(const int* indices, int64_t n_in, int batch, const int in_shape[3], const int out_shape[3],
@@ -295,6 +418,26 @@ extern "C" int fv2p_rulebook_begin(const int* indices, int64_t n_in, int batch, 
   if (n_in == 0) { *n_out_host = 0; return 0; }
   FV2P_REQUIRE(indices && ws && ws_bytes >= fv2p_rulebook_ws_bytes(n_in, ksize, stride, dilation, subm, transpose), FV2P_EWORKSPACE,
                "rulebook: workspace too small");
+  if (use_bitmap(g, batch, subm, ws_bytes)) {
+    FV2P_REQUIRE(static_cast<int64_t>(n_in) * g.emax <= kMaxRows, FV2P_ELIMIT, "rulebook: too many candidate outputs");
+    Carver cb(ws, ws_bytes);
+    int* total = cb.take<int>(4);
+    BmWs b;
+    bm_carve(cb, static_cast<long long>(batch) * g.out_vol, &b);
+    FillJobs fill;
+    fill.add(b.bitmap, sizeof(uint32_t) * static_cast<size_t>(b.words), 0u);
+    fill.add(total, sizeof(int) * 4, 0u);
+    if (int rc = multi_fill(fill, stream)) return rc;
+    hipLaunchKernelGGL(rb_mark_outputs, dim3(static_cast<unsigned>(ceil_div(n_in, 256)), g.emax), dim3(256), 0, stream, indices, (int)n_in, g,
+                       b.bitmap);
+    hipLaunchKernelGGL(rb_tile_popc, dim3(b.tiles), dim3(256), 0, stream, b.bitmap, b.words, b.sums);
+    if (int rc = exclusive_scan_i32(b.sums, b.sums, b.tiles, total, b.aux, b.aux_bytes, stream)) return rc;
+    int n_out = 0;
+    FV2P_HIP(hipMemcpyAsync(&n_out, total, sizeof(int), hipMemcpyDeviceToHost, stream));
+    FV2P_HIP(hipStreamSynchronize(stream));  // output row count = host-side shape (spconv_ops.h:131-139), see below
+    *n_out_host = n_out;
+    return 0;
+  }
   Carver c(ws, ws_bytes);
   RbWs w;
   rb_carve(c, n_in, g.emax, subm, &w);
@@ -337,6 +480,27 @@ extern "C" int fv2p_rulebook_finish(const int* indices, int64_t n_in, int batch,
   FV2P_REQUIRE(tab_in, FV2P_EINVAL, "rulebook_finish: null tab_in");
   FV2P_REQUIRE(ws && ws_bytes >= fv2p_rulebook_ws_bytes(n_in, ksize, stride, dilation, subm, transpose), FV2P_EWORKSPACE,
                "rulebook: workspace too small");
+  if (use_bitmap(g, batch, subm, ws_bytes)) {
+    Carver cb(ws, ws_bytes);
+    cb.take<int>(4);
+    BmWs b;
+    bm_carve(cb, static_cast<long long>(batch) * g.out_vol, &b);
+    fill.add(tab_in, sizeof(int) * (size_t)g.kvol * n_in, 0xFFFFFFFFu);
+    if (tab_out && n_out > 0) fill.add(tab_out, sizeof(int) * (size_t)g.kvol * n_out, 0xFFFFFFFFu);
+    if (int rc = multi_fill(fill, stream)) return rc;
+    FV2P_REQUIRE(out_indices || n_out == 0, FV2P_EINVAL, "rulebook_finish: out_indices is null");
+    if (n_out > 0) {
+      hipLaunchKernelGGL(rb_emit_outputs, dim3(b.tiles), dim3(256), 0, stream, b.bitmap, b.words, b.sums, g, b.prefix, out_indices);
+      hipLaunchKernelGGL(rb_fill_tables_bm, dim3(static_cast<unsigned>(ceil_div(n_in, 256)), g.emax), dim3(256), 0, stream, indices, (int)n_in,
+                         (int)n_out, g, b.bitmap, b.prefix, tab_in, tab_out);
+    }
+    if (indice_num) {
+      const unsigned cbk = static_cast<unsigned>(ceil_div(n_in, 1024) < 64 ? ceil_div(n_in, 1024) : 64);
+      hipLaunchKernelGGL(rb_count_rows, dim3(cbk, g.kvol), dim3(256), 0, stream, tab_in, (int)n_in, indice_num);
+    }
+    FV2P_LAUNCH_CHECK();
+    return 0;
+  }
   Carver c(ws, ws_bytes);
   RbWs w;
   rb_carve(c, n_in, g.emax, subm, &w);

@@ -364,7 +364,7 @@ std::vector<std::vector<at::Tensor>> build_rulebook_chain(const at::Tensor& root
     TORCH_CHECK(ind.defined(), "build_rulebook_chain: source entry has no output rows of its own (submanifold)");
     const int64_t n_in = ind.size(0);
     const int kvol = ksize[0] * ksize[1] * ksize[2];
-    at::Tensor ws = workspace(fv2p_rulebook_ws_bytes(n_in, ksize, stride, dilation, subm, transpose), root, stream);
+    at::Tensor ws = workspace(fv2p_rulebook_ws_bytes_grid(n_in, static_cast<int>(batch), out_shape, ksize, stride, dilation, subm, transpose), root, stream);
     int64_t n_out = 0;
     check(fv2p_rulebook_begin(ind.data_ptr<int>(), n_in, static_cast<int>(batch), in_shape, out_shape, ksize, stride, padding, dilation, subm,
                               transpose, &n_out, ws.data_ptr(), static_cast<size_t>(ws.numel()), stream),

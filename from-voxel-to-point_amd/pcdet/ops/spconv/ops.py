@@ -148,7 +148,8 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize=3, stride=1, paddin
         lib = _nat.lib()
         import ctypes
         arr = lambda v: (ctypes.c_int * 3)(*v)
-        ws_bytes = lib.fv2p_rulebook_ws_bytes(n_in, arr(g["ksize"]), arr(g["stride"]), arr(g["dilation"]), int(subm), int(transpose))
+        ws_bytes = lib.fv2p_rulebook_ws_bytes_grid(n_in, int(batch_size), arr(g["out_shape"]), arr(g["ksize"]), arr(g["stride"]),
+                                                   arr(g["dilation"]), int(subm), int(transpose))
         ws = _nat.workspace(ws_bytes, dev)
         n_out_host = ctypes.c_int64(0)
         geom = (g["in_shape"], g["out_shape"], g["ksize"], g["stride"], g["padding"], g["dilation"], int(subm), int(transpose))

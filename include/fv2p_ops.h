@@ -80,6 +80,13 @@ int fv2p_points_to_voxel(const float* points, int64_t n_points, int ndim, const 
  */
 size_t fv2p_rulebook_ws_bytes(int64_t n_in, const int ksize[3], const int stride[3], const int dilation[3],
                               int subm, int transpose);
+/* Same, plus room for the bitmap path of strided / transposed rulebooks: when batch * output volume <= 2^28 cells and the
+ * workspace has this size, begin/finish rank the output cells with one bit per cell and a popcount scan (ascending
+ * flat index = the reference's sorted-unique order) instead of the hash set + radix sort; results are identical. */
+size_t fv2p_rulebook_ws_bytes_grid(int64_t n_in, int batch, const int out_shape[3], const int ksize[3],
+                                   const int stride[3], const int dilation[3], int subm, int transpose);
+/* 0 (default): bitmap path whenever it applies; 1: always the hash set + radix sort. Process-wide; for tests / A-B runs. */
+int fv2p_rulebook_set_path(int path);
 int fv2p_rulebook_begin(const int* indices, int64_t n_in, int batch, const int in_shape[3],
                         const int out_shape[3], const int ksize[3], const int stride[3], const int padding[3],
                         const int dilation[3], int subm, int transpose, int64_t* n_out_host, void* ws,

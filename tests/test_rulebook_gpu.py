@@ -50,8 +50,18 @@ def _check(gpu, ind, batch, shape, k, s, p, d, subm, transpose):
     return outids, num
 
 
+@pytest.fixture(params=["bitmap", "hashed"])
+def rb_path(request):
+    """Strided / transposed rulebooks rank their output cells through a bitmap of the grid (default) or through the hash
+    set + radix sort (grids above 2^28 cells): both must equal the oracle."""
+    import fv2p_native
+    fv2p_native.lib().fv2p_rulebook_set_path(1 if request.param == "hashed" else 0)
+    yield request.param
+    fv2p_native.lib().fv2p_rulebook_set_path(0)
+
+
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-def test_rulebook_matches_oracle(gpu, case):
+def test_rulebook_matches_oracle(gpu, case, rb_path):
     _, batch, shape, n, k, s, p, d, subm, transpose = case
     ind = random_active(sum(map(ord, case[0])), batch, shape, n)
     _check(gpu, ind, batch, shape, k, s, p, d, subm, transpose)
@@ -70,7 +80,7 @@ def test_rulebook_2d(gpu):
             assert np.array_equal(a, b)
 
 
-def test_rulebook_kitti_backbone_chain(gpu):
+def test_rulebook_kitti_backbone_chain(gpu, rb_path):
     """Full-size KITTI grid, batch 2: the eight rulebooks of VoxelBackBone8x chained level to level."""
     ind = voxel_indices_from_clouds([0, 1])
     shape = [41, 1600, 1408]
@@ -90,7 +100,7 @@ def test_rulebook_kitti_backbone_chain(gpu):
     assert shape == [2, 200, 176]
 
 
-def test_rulebook_edge_cases(gpu):
+def test_rulebook_edge_cases(gpu, rb_path):
     # empty active set
     e = torch.zeros((0, 4), dtype=torch.int32, device=gpu)
     outids, pairs, num = ops.get_indice_pairs(e, 1, [4, 4, 4], 3, 1, 1, 1, 0, True)
