@@ -188,33 +188,39 @@ __global__ __launch_bounds__(256) void rb_tile_popc(const uint32_t* __restrict__
   __syncthreads();
   if (threadIdx.x == 0) sums[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
-// prefix[w] = set bits before word w (tile offset from the scanned sums + local scan); out_ind[row] = decoded cell
+// prefix[w] = set bits before word w (tile offset from the scanned sums + local scan); out_ind[row] = decoded cell.
+// One word per lane and round (8 rounds of 256 words): the serial part is the <= 32 bits of one word, neighbouring lanes
+// hold neighbouring words of similar density, and a cell is decoded with three 32-bit divisions per non-empty word plus
+// carries per bit (the first version — 8 words per thread, two 64-bit divisions per bit — took 100 us on any grid).
 __global__ __launch_bounds__(256) void rb_emit_outputs(const uint32_t* __restrict__ bitmap, int64_t words, const int* __restrict__ tile_off,
                                                        RbGeom g, int* __restrict__ prefix, int* __restrict__ out_ind) {
   __shared__ int lds_wave[4];
-  const int64_t base = static_cast<int64_t>(blockIdx.x) * kBmTile + threadIdx.x * 8;
-  uint32_t w[8];
-  int c = 0;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { w[j] = (base + j < words) ? bitmap[base + j] : 0u; c += __popc(w[j]); }
-  int tot;
-  int run = block_excl_scan_256(c, lds_wave, &tot) + tile_off[blockIdx.x];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    if (base + j >= words) break;
-    prefix[base + j] = run;
-    uint32_t bits = w[j];
-    while (bits) {
-      const int b = __ffs(static_cast<int>(bits)) - 1;
-      bits &= bits - 1;
-      const uint64_t key = (static_cast<uint64_t>(base + j) << 5) + b;
-      uint64_t rem = key % static_cast<uint64_t>(g.out_vol);
-      int4 o;
-      o.x = static_cast<int>(key / static_cast<uint64_t>(g.out_vol));
-      o.w = static_cast<int>(rem % g.out_shape[2]); rem /= g.out_shape[2];
-      o.z = static_cast<int>(rem % g.out_shape[1]);
-      o.y = static_cast<int>(rem / g.out_shape[1]);
-      reinterpret_cast<int4*>(out_ind)[run++] = o;
+  const uint32_t W = g.out_shape[2], H = g.out_shape[1], D = g.out_shape[0];
+  const uint32_t HW = H * W, vol = static_cast<uint32_t>(g.out_vol);   // cells <= 2^28: everything fits 32 bits
+  int run0 = tile_off[blockIdx.x];
+#pragma unroll 1
+  for (int r = 0; r < kBmTile / 256; ++r) {
+    const int64_t wi = static_cast<int64_t>(blockIdx.x) * kBmTile + r * 256 + threadIdx.x;
+    uint32_t bits = wi < words ? bitmap[wi] : 0u;
+    int tot;
+    int run = run0 + block_excl_scan_256(__popc(bits), lds_wave, &tot);
+    run0 += tot;
+    if (wi < words) prefix[wi] = run;
+    if (bits) {
+      const uint32_t key = static_cast<uint32_t>(wi) << 5;
+      const uint32_t b0 = key / vol, r1 = key - b0 * vol;
+      const uint32_t z0 = r1 / HW, r2 = r1 - z0 * HW;
+      const uint32_t y0 = r2 / W, x0 = r2 - y0 * W;
+      do {
+        const int bit = __ffs(static_cast<int>(bits)) - 1;
+        bits &= bits - 1;
+        uint32_t x = x0 + bit, y = y0, z = z0, b = b0;
+        while (x >= W) {
+          x -= W;
+          if (++y == H) { y = 0; if (++z == D) { z = 0; ++b; } }
+        }
+        reinterpret_cast<int4*>(out_ind)[run++] = make_int4((int)b, (int)z, (int)y, (int)x);
+      } while (bits);
     }
   }
 }
