@@ -63,6 +63,7 @@ class VoxelBackBone8x(nn.Module):
         self.num_point_features = 128
 
     def forward(self, voxel_features, voxel_coords, batch_size):
+        spconv.defer_weight_gradients(self)   # dW of every conv joined once, at the end of backward
         x = spconv.SparseConvTensor(voxel_features, voxel_coords.int(), self.sparse_shape, batch_size)
         x = self.conv_input(x)
         c1 = self.conv1(x)

@@ -79,6 +79,10 @@ class SparseConvolution(SparseModule):
         """`_post` (internal, set by SparseSequential): the (BatchNorm1d, ReLU-or-None) pair that follows this conv; when
         the compiled binding can run conv -> BN -> ReLU in one call the returned tensor carries `_fv2p_post_done`."""
         assert isinstance(input, SparseConvTensor)
+        # alias of self.weight made by defer_weight_gradients() for this pass (its dW is joined at the end of backward)
+        weight = self.__dict__.pop("_fv2p_gated_weight", None)
+        if weight is None or not torch.is_grad_enabled():
+            weight = self.weight
         features = input.features
         indices = input.indices
         spatial_shape = input.spatial_shape
@@ -92,7 +96,7 @@ class SparseConvolution(SparseModule):
             out_spatial_shape = ops.get_conv_output_size(spatial_shape, self.kernel_size, self.stride, self.padding,
                                                          self.dilation)
         if self.conv1x1:  # reference conv.py:137-148: plain GEMM on the feature matrix
-            features = torch.mm(input.features, self.weight.view(self.in_channels, self.out_channels))
+            features = torch.mm(input.features, weight.view(self.in_channels, self.out_channels))
             if self.bias is not None:
                 features += self.bias
             out_tensor = SparseConvTensor(features, input.indices, input.spatial_shape, input.batch_size)
@@ -115,7 +119,7 @@ class SparseConvolution(SparseModule):
             outids = rb.outids
         n_out = outids.shape[0]
         if _post is not None and not self.fused_bn:
-            fused = self._conv_bn_relu(features, rb, n_out, _post)
+            fused = self._conv_bn_relu(features, rb, n_out, _post, weight)
             if fused is not None:
                 out_tensor = SparseConvTensor(fused, outids, out_spatial_shape, batch_size)
                 out_tensor.indice_dict = input.indice_dict
@@ -124,15 +128,15 @@ class SparseConvolution(SparseModule):
                 return out_tensor
         if self.fused_bn:
             assert self.bias is not None
-            out_features = ops.fused_indice_conv(features, self.weight, self.bias, rb, None, n_out,
+            out_features = ops.fused_indice_conv(features, weight, self.bias, rb, None, n_out,
                                                  self.inverse, self.subm)
         else:
             if self.subm:
-                out_features = Fsp.indice_subm_conv(features, self.weight, rb, None, n_out)
+                out_features = Fsp.indice_subm_conv(features, weight, rb, None, n_out)
             elif self.inverse:
-                out_features = Fsp.indice_inverse_conv(features, self.weight, rb, None, n_out)
+                out_features = Fsp.indice_inverse_conv(features, weight, rb, None, n_out)
             else:
-                out_features = Fsp.indice_conv(features, self.weight, rb, None, n_out)
+                out_features = Fsp.indice_conv(features, weight, rb, None, n_out)
             if self.bias is not None:
                 out_features += self.bias
         out_tensor = SparseConvTensor(out_features, outids, out_spatial_shape, batch_size)
@@ -141,13 +145,14 @@ class SparseConvolution(SparseModule):
         return out_tensor
 
 
-def _conv_bn_relu(self, features, rb, n_out, post):
+def _conv_bn_relu(self, features, rb, n_out, post, weight=None):
     """conv -> BatchNorm1d (-> ReLU) through the compiled binding in one call, or None when any of the three is not the
     plain case (then the modules run one by one, with torch's own error behaviour)."""
     import fv2p_native as _nat
     from .norm import fusable
     ext = _nat.torch_ext()
     bn, relu = post
+    weight = self.weight if weight is None else weight
     if ext is None or n_out < 2 or not fusable(bn, relu, features, self.out_channels):
         return None
     if not (features.is_cuda and features.dtype == torch.float32 and self.weight.dtype == torch.float32 and features.dim() == 2):
@@ -155,7 +160,7 @@ def _conv_bn_relu(self, features, rb, n_out, post):
     (tab_f, flip_f), (tab_b, flip_b) = (rb.in_table(), rb.out_table()) if self.inverse else (rb.out_table(), rb.in_table())
     centre = (rb.kvol // 2) if (rb.subm and rb.tab_out is None and not self.inverse) else -1
     have = rb._wpairs is not None and rb._num is not None
-    out = ext.sparse_conv_bn_relu(features, self.weight, tab_f, flip_f, tab_b, flip_b, n_out, centre, rb._wpairs if have else None,
+    out = ext.sparse_conv_bn_relu(features, weight, tab_f, flip_f, tab_b, flip_b, n_out, centre, rb._wpairs if have else None,
                                   rb._num if have else None, 1 if self.inverse else 0, self.bias, bn.weight, bn.bias, bn.running_mean,
                                   bn.running_var, bn.num_batches_tracked, bn.training,
                                   -1.0 if bn.momentum is None else float(bn.momentum), float(bn.eps), relu is not None)
@@ -163,6 +168,25 @@ def _conv_bn_relu(self, features, rb, n_out, post):
 
 
 SparseConvolution._conv_bn_relu = _conv_bn_relu
+
+
+def defer_weight_gradients(module):
+    """Call at the top of a model's forward pass (training): the weight gradients of all sparse convolutions under
+    `module` are then joined from their side stream once, at the end of the backward pass, instead of at the end of every
+    conv's backward (csrc_torch/fv2p_torch.cpp, WeightGateFn) — the training stream no longer idles behind each dW.
+    Gradients, hooks and DistributedDataParallel see the same values; conv weights just become ready last.  No-op
+    without the compiled binding, under no_grad, or for CPU / frozen weights."""
+    import fv2p_native as _nat
+    ext = _nat.torch_ext()
+    if ext is None or not torch.is_grad_enabled():
+        return
+    convs = module.__dict__.get("_fv2p_convs")
+    if convs is None:
+        convs = module.__dict__["_fv2p_convs"] = [m for m in module.modules() if isinstance(m, SparseConvolution)]
+    live = [m for m in convs if m.weight.requires_grad and m.weight.is_cuda and m.weight.dtype == torch.float32]
+    if live:
+        for m, w in zip(live, ext.gate_weights([m.weight for m in live])):
+            m.__dict__["_fv2p_gated_weight"] = w
 
 
 def _make(name, ndim, **fixed):

@@ -129,8 +129,8 @@ def test_sparse_sequential_uses_fused_pair_and_falls_back(gpu, front_end, monkey
         calls.append(out is not None and relu_module is not None)
         return out
 
-    def counting_block(self, features, rb, n_out, post):   # conv -> BN -> ReLU in one call (compiled front end)
-        out = orig_block(self, features, rb, n_out, post)
+    def counting_block(self, features, rb, n_out, post, weight=None):   # conv -> BN -> ReLU in one call (compiled front end)
+        out = orig_block(self, features, rb, n_out, post, weight)
         if out is not None:
             calls.append(post[1] is not None)
         return out

@@ -389,3 +389,55 @@ def test_dense_scatter_equals_reference_expression_and_gradient(gpu, ndim):
         gl = g if not channels_first else g.permute(*([0] + list(range(2, ndim + 2)) + [1]))
         want = gl[tuple(torch.from_numpy(ind[:, i]).long() for i in range(ndim + 1))]
         assert torch.equal(f.grad.cpu(), want)
+
+
+def test_deferred_weight_gradient_join_gives_the_same_gradients(gpu):
+    """spconv.defer_weight_gradients (compiled binding): every conv's dW runs on the side stream and is joined once at
+    the end of backward.  Gradients are bit-identical to the per-layer join, over several iterations with the training
+    stream's allocator recycling blocks in between; a conv applied twice (second use: plain weight, immediate join) and a
+    conv left out of the pass are handled."""
+    import fv2p_native
+    if fv2p_native.torch_ext() is None:
+        pytest.skip("compiled binding not built")
+    batch, shape = 2, [9, 40, 36]
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            bn = lambda c: torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01)
+            self.a = spconv.SparseSequential(spconv.SubMConv3d(16, 32, 3, padding=1, bias=False, indice_key="s1"), bn(32), torch.nn.ReLU())
+            self.b = spconv.SparseSequential(spconv.SubMConv3d(32, 32, 3, padding=1, bias=False, indice_key="s1"), bn(32), torch.nn.ReLU())
+            self.c = spconv.SparseSequential(spconv.SparseConv3d(32, 64, 3, stride=2, padding=1, bias=False, indice_key="d"), bn(64), torch.nn.ReLU())
+            self.unused = spconv.SubMConv3d(64, 64, 3, padding=1, bias=False, indice_key="s2")
+            self.defer = False
+
+        def forward(self, x):
+            if self.defer:
+                spconv.defer_weight_gradients(self)
+            return self.c(self.b(self.b(self.a(x))))      # self.b twice: shared weight
+
+    torch.manual_seed(0)
+    net = Net().to(gpu)
+    results = {}
+    for defer in (False, True):
+        net.defer = defer
+        grads = []
+        for it in range(4):
+            ind, feats, x = make_input(100 + it, batch, shape, 3000, 16, gpu)
+            x.features.requires_grad_(True)
+            net.zero_grad(set_to_none=True)
+            y = net(x)
+            junk = [torch.empty(int(n), device=gpu) for n in (1e6, 3e5, 2e6)]   # churn the allocator around backward
+            y.features.square().sum().backward()
+            del junk
+            junk = [torch.zeros(int(n), device=gpu) for n in (2e6, 1e6)]
+            grads.append([p.grad.clone() if p.grad is not None else None for p in net.parameters()] + [x.features.grad.clone()])
+            del junk
+        torch.cuda.synchronize()
+        results[defer] = grads
+    assert net.unused.weight.grad is None
+    for ga, gb in zip(results[False], results[True]):
+        for a, b in zip(ga, gb):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert torch.equal(a, b)
