@@ -159,7 +159,7 @@ __global__ void rb_fill_tables(const int* __restrict__ ind, int n_in, int n_out,
 // popcount scan over the words ranks the cells in ascending flat index — the order torch::_unique gives the GPU reference
 // (spconv_ops.h:130-131) — and a neighbour's output row is prefix[word] + popc(bits below): two loads instead of a probe.
 // Replaces {hash-set insert, 4 radix passes, rank write-back} = 11 launches by {mark, tile sums, scan of sums, emit} = 4.
-constexpr int kBmTile = 2048;            // words per workgroup in the popcount passes (256 threads x 8)
+constexpr int kBmTile = 256;             // words per workgroup in the popcount passes: one per thread (a dense word is 32 serial steps)
 constexpr long long kBmMaxCells = 1ll << 28;
 
 __global__ void rb_mark_outputs(const int* __restrict__ ind, int n, RbGeom g, uint32_t* __restrict__ bitmap) {
@@ -178,50 +178,43 @@ __global__ void rb_mark_outputs(const int* __restrict__ ind, int n, RbGeom g, ui
 // sums[b] = number of set bits in tile b
 __global__ __launch_bounds__(256) void rb_tile_popc(const uint32_t* __restrict__ bitmap, int64_t words, int* __restrict__ sums) {
   __shared__ int ws[4];
-  const int64_t base = static_cast<int64_t>(blockIdx.x) * kBmTile + threadIdx.x * 8;
-  int c = 0;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) c += (base + j < words) ? __popc(bitmap[base + j]) : 0;
+  const int64_t wi = static_cast<int64_t>(blockIdx.x) * kBmTile + threadIdx.x;
+  int c = wi < words ? __popc(bitmap[wi]) : 0;
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
   if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
   __syncthreads();
   if (threadIdx.x == 0) sums[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
-// prefix[w] = set bits before word w (tile offset from the scanned sums + local scan); out_ind[row] = decoded cell.
-// One word per lane and round (8 rounds of 256 words): the serial part is the <= 32 bits of one word, neighbouring lanes
-// hold neighbouring words of similar density, and a cell is decoded with three 32-bit divisions per non-empty word plus
-// carries per bit (the first version — 8 words per thread, two 64-bit divisions per bit — took 100 us on any grid).
+// prefix[w] = set bits before word w (tile offset from the scanned sums + scan inside the tile); out_ind[row] = decoded
+// cell.  One word per lane: the serial part is the <= 32 bits of a word, neighbouring lanes hold neighbouring words of
+// similar density, a cell is decoded with three 32-bit divisions per non-empty word plus carries per bit.  (Per-thread
+// runs of 8 words with two 64-bit divisions per bit took 100 us on any grid; 2048-word tiles in 8 rounds still 25 us.)
 __global__ __launch_bounds__(256) void rb_emit_outputs(const uint32_t* __restrict__ bitmap, int64_t words, const int* __restrict__ tile_off,
                                                        RbGeom g, int* __restrict__ prefix, int* __restrict__ out_ind) {
   __shared__ int lds_wave[4];
   const uint32_t W = g.out_shape[2], H = g.out_shape[1], D = g.out_shape[0];
   const uint32_t HW = H * W, vol = static_cast<uint32_t>(g.out_vol);   // cells <= 2^28: everything fits 32 bits
-  int run0 = tile_off[blockIdx.x];
-#pragma unroll 1
-  for (int r = 0; r < kBmTile / 256; ++r) {
-    const int64_t wi = static_cast<int64_t>(blockIdx.x) * kBmTile + r * 256 + threadIdx.x;
-    uint32_t bits = wi < words ? bitmap[wi] : 0u;
-    int tot;
-    int run = run0 + block_excl_scan_256(__popc(bits), lds_wave, &tot);
-    run0 += tot;
-    if (wi < words) prefix[wi] = run;
-    if (bits) {
-      const uint32_t key = static_cast<uint32_t>(wi) << 5;
-      const uint32_t b0 = key / vol, r1 = key - b0 * vol;
-      const uint32_t z0 = r1 / HW, r2 = r1 - z0 * HW;
-      const uint32_t y0 = r2 / W, x0 = r2 - y0 * W;
-      do {
-        const int bit = __ffs(static_cast<int>(bits)) - 1;
-        bits &= bits - 1;
-        uint32_t x = x0 + bit, y = y0, z = z0, b = b0;
-        while (x >= W) {
-          x -= W;
-          if (++y == H) { y = 0; if (++z == D) { z = 0; ++b; } }
-        }
-        reinterpret_cast<int4*>(out_ind)[run++] = make_int4((int)b, (int)z, (int)y, (int)x);
-      } while (bits);
-    }
+  const int64_t wi = static_cast<int64_t>(blockIdx.x) * kBmTile + threadIdx.x;
+  uint32_t bits = wi < words ? bitmap[wi] : 0u;
+  int tot;
+  int run = tile_off[blockIdx.x] + block_excl_scan_256(__popc(bits), lds_wave, &tot);
+  if (wi < words) prefix[wi] = run;
+  if (bits) {
+    const uint32_t key = static_cast<uint32_t>(wi) << 5;
+    const uint32_t b0 = key / vol, r1 = key - b0 * vol;
+    const uint32_t z0 = r1 / HW, r2 = r1 - z0 * HW;
+    const uint32_t y0 = r2 / W, x0 = r2 - y0 * W;
+    do {
+      const int bit = __ffs(static_cast<int>(bits)) - 1;
+      bits &= bits - 1;
+      uint32_t x = x0 + bit, y = y0, z = z0, b = b0;
+      while (x >= W) {
+        x -= W;
+        if (++y == H) { y = 0; if (++z == D) { z = 0; ++b; } }
+      }
+      reinterpret_cast<int4*>(out_ind)[run++] = make_int4((int)b, (int)z, (int)y, (int)x);
+    } while (bits);
   }
 }
 __global__ void rb_fill_tables_bm(const int* __restrict__ ind, int n_in, int n_out, RbGeom g, const uint32_t* __restrict__ bitmap,

@@ -5,6 +5,7 @@ spconv/conv.py:48-480, running on the hashed rulebook + fused MFMA conv of libfv
 mmcv is not required: if it is importable the classes are registered in its CONV_LAYERS registry as the
 reference does (conv.py:17,233), otherwise registration is skipped."""
 import math
+import os
 
 import numpy as np
 import torch
@@ -178,7 +179,7 @@ def defer_weight_gradients(module):
     without the compiled binding, under no_grad, or for CPU / frozen weights."""
     import fv2p_native as _nat
     ext = _nat.torch_ext()
-    if ext is None or not torch.is_grad_enabled():
+    if ext is None or not torch.is_grad_enabled() or os.environ.get("FV2P_DEFER_WGRAD", "1") == "0":
         return
     convs = module.__dict__.get("_fv2p_convs")
     if convs is None:
