@@ -151,8 +151,12 @@ constexpr int kBnMaxC = 1024;
 template <int V, bool FOLD>
 __global__ __launch_bounds__(256) void bn_apply_fwd_k(const float* __restrict__ x, long long units, BnGeom g, const double* __restrict__ partial,
                                                       BnFwdFin ff, const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
-                                                      float* __restrict__ y) {
+                                                      float* __restrict__ y, double* __restrict__ zero_next, long long zero_count) {
   __shared__ double red[2][256];
+  // conv-epilogue statistics alternate between two slot buffers: this launch reads one and clears the other for the
+  // next fused conv, which runs after it on the stream
+  if (zero_next && blockIdx.x == 0)
+    for (long long e = threadIdx.x; e < zero_count; e += 256) zero_next[e] = 0.0;
   __shared__ float sh_scale[kBnMaxC], sh_shift[kBnMaxC];   // y = x * scale + shift would change rounding: keep (x-mean)*invstd*gamma+beta
   __shared__ float sh_mean[kBnMaxC], sh_gamma[kBnMaxC];
   const int tid = threadIdx.x, c = g.c;
@@ -254,7 +258,7 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_k(const float* __restrict__ 
   }
 }
 
-constexpr int kBnPartials = 64;
+constexpr int kBnPartials = kStatSlots;
 
 static int bn_geom(int64_t n, int c, bool vec, BnGeom* g) {
   const int v = vec ? 4 : 1;
@@ -309,11 +313,43 @@ extern "C" int fv2p_batchnorm_forward(const float* x, int64_t n, int c, float ep
   const unsigned blocks = apply_blocks(units);
   if (vec) {
     hipLaunchKernelGGL((bn_reduce_k<4, false>), dim3(g.nblk), dim3(256), 0, stream, x, nullptr, g, nullptr, nullptr, nullptr, nullptr, 0, partial);
-    hipLaunchKernelGGL((bn_apply_fwd_k<4, true>), dim3(blocks), dim3(256), 0, stream, x, units, g, partial, ff, gamma, beta, relu, y);
+    hipLaunchKernelGGL((bn_apply_fwd_k<4, true>), dim3(blocks), dim3(256), 0, stream, x, units, g, partial, ff, gamma, beta, relu, y, nullptr, 0);
   } else {
     hipLaunchKernelGGL((bn_reduce_k<1, false>), dim3(g.nblk), dim3(256), 0, stream, x, nullptr, g, nullptr, nullptr, nullptr, nullptr, 0, partial);
-    hipLaunchKernelGGL((bn_apply_fwd_k<1, true>), dim3(blocks), dim3(256), 0, stream, x, units, g, partial, ff, gamma, beta, relu, y);
+    hipLaunchKernelGGL((bn_apply_fwd_k<1, true>), dim3(blocks), dim3(256), 0, stream, x, units, g, partial, ff, gamma, beta, relu, y, nullptr, 0);
   }
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
+// column sums of x into the slot layout of the conv-epilogue statistics (slots beyond the reduce grid stay as they are: zero)
+int fv2p::bn_column_sums(const float* x, int64_t n, int c, double* stats, hipStream_t stream) {
+  const bool vec = (c % 4 == 0) && aligned16(x);
+  BnGeom g;
+  FV2P_REQUIRE(bn_geom(n, c, vec, &g) == 0, FV2P_ELIMIT, "batchnorm: c=%d exceeds %d", c, vec ? kBnMaxC : 256);
+  if (vec) hipLaunchKernelGGL((bn_reduce_k<4, false>), dim3(g.nblk), dim3(256), 0, stream, x, nullptr, g, nullptr, nullptr, nullptr, nullptr, 0, stats);
+  else hipLaunchKernelGGL((bn_reduce_k<1, false>), dim3(g.nblk), dim3(256), 0, stream, x, nullptr, g, nullptr, nullptr, nullptr, nullptr, 0, stats);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fv2p_batchnorm_forward_stats(const float* x, int64_t n, int c, float eps, float momentum, const float* gamma, const float* beta,
+                                            int relu, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean,
+                                            float* invstd, float* y, const double* stats, double* zero_next, int64_t zero_count,
+                                            fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FV2P_REQUIRE(n >= 1 && c >= 1, FV2P_EINVAL, "batchnorm_forward_stats: n=%lld c=%d", static_cast<long long>(n), c);
+  FV2P_REQUIRE(x && y && mean && invstd && stats, FV2P_EINVAL, "batchnorm_forward_stats: null pointer");
+  FV2P_REQUIRE((running_mean == nullptr) == (running_var == nullptr), FV2P_EINVAL, "batchnorm_forward_stats: running_mean and running_var come together");
+  const bool vec = (c % 4 == 0) && aligned16(x) && aligned16(y);
+  BnGeom g;
+  FV2P_REQUIRE(bn_geom(n, c, vec, &g) == 0, FV2P_ELIMIT, "batchnorm: c=%d exceeds %d", c, vec ? kBnMaxC : 256);
+  g.nblk = kStatSlots;   // every slot is folded (untouched ones hold zeros)
+  BnFwdFin ff{mean, invstd, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), momentum, eps};
+  const long long units = n * c / (vec ? 4 : 1);
+  const unsigned blocks = apply_blocks(units);
+  if (vec) hipLaunchKernelGGL((bn_apply_fwd_k<4, true>), dim3(blocks), dim3(256), 0, stream, x, units, g, stats, ff, gamma, beta, relu, y, zero_next, static_cast<long long>(zero_count));
+  else hipLaunchKernelGGL((bn_apply_fwd_k<1, true>), dim3(blocks), dim3(256), 0, stream, x, units, g, stats, ff, gamma, beta, relu, y, zero_next, static_cast<long long>(zero_count));
   FV2P_LAUNCH_CHECK();
   return 0;
 }
@@ -330,8 +366,8 @@ extern "C" int fv2p_batchnorm_apply(const float* x, int64_t n, int c, const floa
   BnFwdFin ff{const_cast<float*>(mean), const_cast<float*>(invstd), nullptr, nullptr, nullptr, 0.f, 0.f};
   const long long units = n * c / (vec ? 4 : 1);
   const unsigned blocks = apply_blocks(units);
-  if (vec) hipLaunchKernelGGL((bn_apply_fwd_k<4, false>), dim3(blocks), dim3(256), 0, stream, x, units, g, nullptr, ff, gamma, beta, relu, y);
-  else hipLaunchKernelGGL((bn_apply_fwd_k<1, false>), dim3(blocks), dim3(256), 0, stream, x, units, g, nullptr, ff, gamma, beta, relu, y);
+  if (vec) hipLaunchKernelGGL((bn_apply_fwd_k<4, false>), dim3(blocks), dim3(256), 0, stream, x, units, g, nullptr, ff, gamma, beta, relu, y, nullptr, 0);
+  else hipLaunchKernelGGL((bn_apply_fwd_k<1, false>), dim3(blocks), dim3(256), 0, stream, x, units, g, nullptr, ff, gamma, beta, relu, y, nullptr, 0);
   FV2P_LAUNCH_CHECK();
   return 0;
 }

@@ -128,6 +128,10 @@ __device__ __forceinline__ int block_excl_scan_256(int v, int* lds_wave /*[4]*/,
   return base + incl - v;
 }
 
+constexpr int kStatSlots = 64;   // accumulator rows of the conv-epilogue BatchNorm statistics = partials the BatchNorm apply kernels fold
+
+int bn_column_sums(const float* x, int64_t n, int c, double* stats, hipStream_t stream);   // batchnorm.hip
+
 // ---- internal primitives (sort_scan.hip) ---------------------------------------------
 size_t scan_ws_bytes(int64_t n);
 // Exclusive prefix sum of int32; in == out allowed. total (device int*, may be null) gets the sum.

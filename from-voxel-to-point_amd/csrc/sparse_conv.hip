@@ -32,7 +32,36 @@ struct ConvArgs {
   float* dst; int ld_dst; int c_dst;                 // c_dst: valid destination channels in this launch
   int accumulate;                                    // dst += result (used when the host splits c_src)
   unsigned long long* trace;                         // optional per-workgroup placement/timing trace (test hook)
+  double* stats;                                     // optional [kStatSlots][2][stats_ld]: per-column sum / sum of squares of dst
+  int stats_ld;
 };
+
+// ---- BatchNorm statistics in the epilogue --------------------------------------------------------
+// Every conv of the reference's backbones feeds BatchNorm1d (spconv_backbone.py:8-27); its per-channel sum and sum of
+// squares are taken here from the accumulators instead of by a separate pass over dst.  A wave reduces its 16 rows
+// (fp64 from the first add on: E[x^2] - E[x]^2 cancels), then adds to one of kStatSlots accumulator rows with fp64
+// atomics — fire and forget, the kernel boundary orders them before the consumer (bn_apply_fwd_k folds the slots like
+// the partials of bn_reduce_k).  vals[i][reg]: value stored to row row0 + 4 * (lane / 16) + reg, column col[i].
+template <int NV>
+__device__ __forceinline__ void tile_stats(const ConvArgs& a, const float (&vals)[NV][4], const int (&col)[NV], int row0) {
+  const int lane = threadIdx.x & 63, q = lane >> 4;
+  const int slot = (blockIdx.x * 4 + (threadIdx.x >> 6)) % kStatSlots;
+  double* base = a.stats + static_cast<long long>(slot) * 2 * a.stats_ld;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      if (row0 + q * 4 + reg < a.n_dst) { const double v = vals[i][reg]; s1 += v; s2 += v * v; }
+    }
+    s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+    s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+    if (q == 0 && col[i] < a.c_dst) {
+      __hip_atomic_fetch_add(base + col[i], s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(base + a.stats_ld + col[i], s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
 
 // ---- B staging --------------------------------------------------------------------------------
 // VEC layout: element B[c][col] at (((c>>4)*NB + (col>>4))*64 + ((c>>2)&3)*16 + (col&15))*4 + (c&3)
@@ -112,6 +141,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x4 (&a
         *p = a.accumulate ? (*p + v) : v;
       }
     }
+  }
+  if (a.stats) {   // uniform; never together with accumulate (host)
+    float vals[NB][4];
+    int cols[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      cols[nb] = nb * 16 + n;
+      const float b = (a.bias && cols[nb] < a.c_dst) ? a.bias[cols[nb]] : 0.f;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) vals[nb][reg] = acc[nb][reg] + b;
+    }
+    tile_stats<NB>(a, vals, cols, row0);
   }
 }
 
@@ -514,6 +555,18 @@ __global__ __launch_bounds__(256) void conv_rows_dma(ConvArgs a) {
         prow[col] = a.accumulate ? (prow[col] + v) : v;
       }
     }
+  }
+  if (a.stats) {
+    float vals[NB][4];
+    int cols[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      cols[i] = (NB % 4 == 0) ? (WT ? (NB * n + i) : (64 * (i / 4) + 4 * n + (i % 4))) : (NB * n + i);
+      const float b = a.bias ? a.bias[cols[i]] : 0.f;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) vals[i][reg] = acc[i][reg] + b;
+    }
+    tile_stats<NB>(a, vals, cols, row0);
   }
 }
 
@@ -1156,10 +1209,8 @@ extern "C" int fv2p_sparse_conv_set_impl(int impl) {
   return 0;
 }
 
-extern "C" int fv2p_sparse_conv_rows(const float* src, int64_t n_src, int c_src, const float* weight, int kvol, const int* tab,
-                                     int64_t n_dst, int c_dst, int flip_k, int transpose_w, const float* bias, float* dst,
-                                     fv2p_stream_t stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
+static int conv_rows_impl(const float* src, int64_t n_src, int c_src, const float* weight, int kvol, const int* tab, int64_t n_dst, int c_dst,
+                          int flip_k, int transpose_w, const float* bias, float* dst, double* stats, hipStream_t stream) {
   FV2P_REQUIRE(c_src >= 1 && c_dst >= 1 && kvol >= 1 && n_dst >= 0 && n_src >= 0, FV2P_EINVAL, "sparse_conv_rows: bad sizes");
   if (n_dst == 0) return 0;
   FV2P_REQUIRE(weight && tab && dst && (src || n_src == 0), FV2P_EINVAL, "sparse_conv_rows: null pointer");
@@ -1173,6 +1224,7 @@ extern "C" int fv2p_sparse_conv_rows(const float* src, int64_t n_src, int c_src,
       const int cs = (c_src - s0) < 128 ? (c_src - s0) : 128;
       ConvArgs a;
       a.trace = nullptr;
+      a.stats = stats ? stats + d0 : nullptr; a.stats_ld = c_dst;
       a.src = src + s0; a.ld_src = c_src; a.c_src = cs;
       a.w = transpose_w ? weight + static_cast<long long>(d0) * w_cols + s0 : weight + static_cast<long long>(s0) * w_cols + d0;
       a.w_kstride = static_cast<long long>(w_rows) * w_cols; a.w_ld = w_cols;
@@ -1184,6 +1236,29 @@ extern "C" int fv2p_sparse_conv_rows(const float* src, int64_t n_src, int c_src,
     }
   }
   FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fv2p_sparse_conv_rows(const float* src, int64_t n_src, int c_src, const float* weight, int kvol, const int* tab,
+                                     int64_t n_dst, int c_dst, int flip_k, int transpose_w, const float* bias, float* dst,
+                                     fv2p_stream_t stream_) {
+  return conv_rows_impl(src, n_src, c_src, weight, kvol, tab, n_dst, c_dst, flip_k, transpose_w, bias, dst, nullptr,
+                        static_cast<hipStream_t>(stream_));
+}
+
+extern "C" int fv2p_sparse_conv_stat_slots(void) { return kStatSlots; }
+
+extern "C" int fv2p_sparse_conv_rows_stats(const float* src, int64_t n_src, int c_src, const float* weight, int kvol, const int* tab,
+                                           int64_t n_dst, int c_dst, int flip_k, int transpose_w, const float* bias, float* dst,
+                                           double* stats, fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FV2P_REQUIRE(stats, FV2P_EINVAL, "sparse_conv_rows_stats: null stats");
+  // epilogue statistics need the whole sum in one launch per column block and a kernel with the shared epilogue;
+  // otherwise the columns are summed by the BatchNorm reduce pass right after the conv (same slots, same meaning)
+  const bool fused = c_src <= 128 && conv_impl() != 2 && n_dst > 0;
+  if (int rc = conv_rows_impl(src, n_src, c_src, weight, kvol, tab, n_dst, c_dst, flip_k, transpose_w, bias, dst, fused ? stats : nullptr, stream))
+    return rc;
+  if (!fused && n_dst > 0) return bn_column_sums(dst, n_dst, c_dst, stats, stream);
   return 0;
 }
 

@@ -125,7 +125,8 @@ static bool is_gated(const at::Tensor& w) {
 struct SparseConvFn : public torch::autograd::Function<SparseConvFn> {
   static at::Tensor forward(AutogradContext* ctx, const at::Tensor& features_, const at::Tensor& weight_, const at::Tensor& tab_f,
                             int64_t flip_f, const at::Tensor& tab_b, int64_t flip_b, int64_t n_out, int64_t centre,
-                            const c10::optional<at::Tensor>& pairs, const c10::optional<at::Tensor>& pair_num, int64_t side_src) {
+                            const c10::optional<at::Tensor>& pairs, const c10::optional<at::Tensor>& pair_num, int64_t side_src,
+                            const c10::optional<at::Tensor>& stats) {
     require_f32_cuda(features_, "features");
     require_f32_cuda(weight_, "weight");
     const at::Tensor features = features_.contiguous(), weight = weight_.contiguous();
@@ -135,10 +136,16 @@ struct SparseConvFn : public torch::autograd::Function<SparseConvFn> {
     c10::DeviceGuard guard(features.device());
     void* stream = cur_stream(features);
     at::Tensor out = at::empty({n_out, cout}, features.options());
-    check(fv2p_sparse_conv_rows(features.data_ptr<float>(), features.size(0), static_cast<int>(cin), weight.data_ptr<float>(),
-                                static_cast<int>(kvol), tab_f.data_ptr<int>(), n_out, static_cast<int>(cout), static_cast<int>(flip_f), 0,
-                                nullptr, out.data_ptr<float>(), stream),
-          "fv2p_sparse_conv_rows");
+    if (stats.has_value() && stats->defined())   // BatchNorm follows: its column sums come out of the conv epilogue
+      check(fv2p_sparse_conv_rows_stats(features.data_ptr<float>(), features.size(0), static_cast<int>(cin), weight.data_ptr<float>(),
+                                        static_cast<int>(kvol), tab_f.data_ptr<int>(), n_out, static_cast<int>(cout), static_cast<int>(flip_f), 0,
+                                        nullptr, out.data_ptr<float>(), stats->data_ptr<double>(), stream),
+            "fv2p_sparse_conv_rows_stats");
+    else
+      check(fv2p_sparse_conv_rows(features.data_ptr<float>(), features.size(0), static_cast<int>(cin), weight.data_ptr<float>(),
+                                  static_cast<int>(kvol), tab_f.data_ptr<int>(), n_out, static_cast<int>(cout), static_cast<int>(flip_f), 0,
+                                  nullptr, out.data_ptr<float>(), stream),
+            "fv2p_sparse_conv_rows");
     const bool have_pairs = pairs.has_value() && pairs->defined() && pair_num.has_value() && pair_num->defined();
     ctx->save_for_backward({features, weight, tab_f, tab_b, have_pairs ? *pairs : at::Tensor(), have_pairs ? *pair_num : at::Tensor()});
     ctx->saved_data["side_src"] = side_src;
@@ -209,21 +216,23 @@ struct SparseConvFn : public torch::autograd::Function<SparseConvFn> {
       TORCH_CHECK(hipEventRecord(side->join, side->stream.stream()) == hipSuccess, "hipEventRecord failed");
       TORCH_CHECK(hipStreamWaitEvent(static_cast<hipStream_t>(stream), side->join, 0) == hipSuccess, "hipStreamWaitEvent failed");
     }
-    return {din, dw, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+    return {din, dw, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
+            at::Tensor()};
   }
 };
 
 at::Tensor sparse_conv(const at::Tensor& features, const at::Tensor& weight, const at::Tensor& tab_f, int64_t flip_f, const at::Tensor& tab_b,
                        int64_t flip_b, int64_t n_out, int64_t centre, const c10::optional<at::Tensor>& pairs,
                        const c10::optional<at::Tensor>& pair_num, int64_t side_src) {
-  return SparseConvFn::apply(features, weight, tab_f, flip_f, tab_b, flip_b, n_out, centre, pairs, pair_num, side_src);
+  return SparseConvFn::apply(features, weight, tab_f, flip_f, tab_b, flip_b, n_out, centre, pairs, pair_num, side_src, c10::optional<at::Tensor>());
 }
 
 // ---- BatchNorm1d (+ReLU) on [N, C] ---------------------------------------------------------------------------------------
 struct BnReluFn : public torch::autograd::Function<BnReluFn> {
   static at::Tensor forward(AutogradContext* ctx, const at::Tensor& x_, const c10::optional<at::Tensor>& weight, const c10::optional<at::Tensor>& bias,
                             const c10::optional<at::Tensor>& running_mean, const c10::optional<at::Tensor>& running_var,
-                            const c10::optional<at::Tensor>& num_batches_tracked, bool training, double momentum, double eps, bool relu) {
+                            const c10::optional<at::Tensor>& num_batches_tracked, bool training, double momentum, double eps, bool relu,
+                            const c10::optional<at::Tensor>& stats, const c10::optional<at::Tensor>& zero_next, int64_t zero_count) {
     require_f32_cuda(x_, "input");
     const at::Tensor x = x_.contiguous();
     const int64_t n = x.size(0), c = x.size(1);
@@ -236,17 +245,26 @@ struct BnReluFn : public torch::autograd::Function<BnReluFn> {
     const float* gamma = (weight.has_value() && weight->defined()) ? weight->data_ptr<float>() : nullptr;
     const float* beta = (bias.has_value() && bias->defined()) ? bias->data_ptr<float>() : nullptr;
     if (batch_stats) {
-      at::Tensor stats = at::empty({2, c}, x.options());
-      mean = stats[0];
-      invstd = stats[1];
+      at::Tensor saved = at::empty({2, c}, x.options());
+      mean = saved[0];
+      invstd = saved[1];
       const bool track = training && has_running;
-      at::Tensor ws = workspace(fv2p_batchnorm_ws_bytes(n, static_cast<int>(c)), x, stream);
       int64_t* nbt = (track && num_batches_tracked.has_value() && num_batches_tracked->defined()) ? num_batches_tracked->data_ptr<int64_t>() : nullptr;
+      if (stats.has_value() && stats->defined()) {   // sums taken by the producing conv's epilogue: one launch
+        check(fv2p_batchnorm_forward_stats(x.data_ptr<float>(), n, static_cast<int>(c), static_cast<float>(eps), static_cast<float>(momentum), gamma,
+                                           beta, relu ? 1 : 0, track ? running_mean->data_ptr<float>() : nullptr,
+                                           track ? running_var->data_ptr<float>() : nullptr, nbt, mean.data_ptr<float>(), invstd.data_ptr<float>(),
+                                           y.data_ptr<float>(), stats->data_ptr<double>(),
+                                           (zero_next.has_value() && zero_next->defined()) ? zero_next->data_ptr<double>() : nullptr, zero_count, stream),
+              "fv2p_batchnorm_forward_stats");
+      } else {
+      at::Tensor ws = workspace(fv2p_batchnorm_ws_bytes(n, static_cast<int>(c)), x, stream);
       check(fv2p_batchnorm_forward(x.data_ptr<float>(), n, static_cast<int>(c), static_cast<float>(eps), static_cast<float>(momentum), gamma, beta,
                                    relu ? 1 : 0, track ? running_mean->data_ptr<float>() : nullptr, track ? running_var->data_ptr<float>() : nullptr,
                                    nbt, mean.data_ptr<float>(), invstd.data_ptr<float>(), y.data_ptr<float>(), ws.data_ptr(),
                                    static_cast<size_t>(ws.numel()), stream),
             "fv2p_batchnorm_forward");
+      }
     } else {
       mean = *running_mean;
       invstd = at::rsqrt(*running_var + eps);
@@ -276,27 +294,72 @@ struct BnReluFn : public torch::autograd::Function<BnReluFn> {
                                   dpar[0].data_ptr<float>(), dpar[1].data_ptr<float>(), ws.data_ptr(), static_cast<size_t>(ws.numel()), stream),
           "fv2p_batchnorm_backward");
     return {dx, weight.defined() ? dpar[0] : at::Tensor(), bias.defined() ? dpar[1] : at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
-            at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+            at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
   }
 };
 
 at::Tensor batch_norm_relu(const at::Tensor& x, const c10::optional<at::Tensor>& weight, const c10::optional<at::Tensor>& bias,
                            const c10::optional<at::Tensor>& running_mean, const c10::optional<at::Tensor>& running_var,
                            const c10::optional<at::Tensor>& num_batches_tracked, bool training, double momentum, double eps, bool relu) {
-  return BnReluFn::apply(x, weight, bias, running_mean, running_var, num_batches_tracked, training, momentum, eps, relu);
+  return BnReluFn::apply(x, weight, bias, running_mean, running_var, num_batches_tracked, training, momentum, eps, relu, c10::optional<at::Tensor>(),
+                         c10::optional<at::Tensor>(), 0);
 }
 
 // conv -> BatchNorm1d (-> ReLU) of one backbone block in one crossing from Python (post_act_block, spconv_backbone.py:8-27)
+// Column statistics of a conv that feeds BatchNorm come out of its epilogue (fv2p_sparse_conv_rows_stats).  Two slot
+// buffers per (device, stream) alternate: the BatchNorm launch that reads one clears what the previous user left in the
+// other, so the next fused conv — later on the same stream — finds it zeroed without a fill launch of its own.
+struct StatRing {
+  at::Tensor buf[2];
+  int64_t dirty[2] = {0, 0};   // doubles the last user of each buffer wrote
+  int cur = 0;
+};
+StatRing& stat_ring(const at::Tensor& like, void* stream) {
+  static std::mutex mu;
+  static std::map<std::pair<int, void*>, StatRing> pool;
+  std::lock_guard<std::mutex> lock(mu);
+  auto key = std::make_pair(static_cast<int>(like.device().index()), stream);
+  auto it = pool.find(key);
+  if (it == pool.end()) {
+    StatRing r;
+    const int64_t cap = static_cast<int64_t>(fv2p_sparse_conv_stat_slots()) * 2 * 1024;
+    for (auto& b : r.buf) b = at::zeros({cap}, like.options().dtype(at::kDouble));
+    it = pool.emplace(key, std::move(r)).first;
+  }
+  return it->second;
+}
+static bool fuse_bn_stats() {
+  static const bool on = [] { const char* e = std::getenv("FV2P_BN_EPILOGUE"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 at::Tensor sparse_conv_bn_relu(const at::Tensor& features, const at::Tensor& weight, const at::Tensor& tab_f, int64_t flip_f, const at::Tensor& tab_b,
                                int64_t flip_b, int64_t n_out, int64_t centre, const c10::optional<at::Tensor>& pairs,
                                const c10::optional<at::Tensor>& pair_num, int64_t side_src, const c10::optional<at::Tensor>& conv_bias,
                                const c10::optional<at::Tensor>& bn_weight, const c10::optional<at::Tensor>& bn_bias,
                                const c10::optional<at::Tensor>& running_mean, const c10::optional<at::Tensor>& running_var,
                                const c10::optional<at::Tensor>& num_batches_tracked, bool training, double momentum, double eps, bool relu) {
-  at::Tensor y = SparseConvFn::apply(features, weight, tab_f, flip_f, tab_b, flip_b, n_out, centre, pairs, pair_num, side_src);
-  if (conv_bias.has_value() && conv_bias->defined()) y = y + *conv_bias;
   if (n_out < 2 && training) return at::Tensor();   // torch raises for one value per channel: let the caller run the module
-  return BnReluFn::apply(y, bn_weight, bn_bias, running_mean, running_var, num_batches_tracked, training, momentum, eps, relu);
+  const bool has_bias = conv_bias.has_value() && conv_bias->defined();
+  const bool batch_stats = training || !(running_mean.has_value() && running_mean->defined());
+  const int64_t cout = weight.size(-1);
+  if (fuse_bn_stats() && batch_stats && !has_bias && cout <= 1024 && features.is_cuda()) {
+    c10::DeviceGuard guard(features.device());
+    StatRing& ring = stat_ring(features, cur_stream(features));
+    const int cur = ring.cur, other = 1 - cur;
+    at::Tensor y = SparseConvFn::apply(features, weight, tab_f, flip_f, tab_b, flip_b, n_out, centre, pairs, pair_num, side_src,
+                                       c10::optional<at::Tensor>(ring.buf[cur]));
+    ring.dirty[cur] = static_cast<int64_t>(fv2p_sparse_conv_stat_slots()) * 2 * cout;
+    at::Tensor out = BnReluFn::apply(y, bn_weight, bn_bias, running_mean, running_var, num_batches_tracked, training, momentum, eps, relu,
+                                     c10::optional<at::Tensor>(ring.buf[cur]), c10::optional<at::Tensor>(ring.buf[other]), ring.dirty[other]);
+    ring.dirty[other] = 0;
+    ring.cur = other;
+    return out;
+  }
+  at::Tensor y = SparseConvFn::apply(features, weight, tab_f, flip_f, tab_b, flip_b, n_out, centre, pairs, pair_num, side_src, c10::optional<at::Tensor>());
+  if (has_bias) y = y + *conv_bias;
+  return BnReluFn::apply(y, bn_weight, bn_bias, running_mean, running_var, num_batches_tracked, training, momentum, eps, relu,
+                         c10::optional<at::Tensor>(), c10::optional<at::Tensor>(), 0);
 }
 
 

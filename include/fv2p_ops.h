@@ -129,9 +129,17 @@ int fv2p_sparse_conv_set_impl(int impl);
  * trace[8*blockIdx .. +7] (device memory, >= 8*ceil(n_dst/64) entries).  NULL switches it off. */
 int fv2p_sparse_conv_set_trace(unsigned long long* trace);
 
+/* fv2p_sparse_conv_rows that also leaves the per-column sum and sum of squares of dst (fp64) in `stats`
+ * [fv2p_sparse_conv_stat_slots()][2][c_dst]: the caller passes it zero-filled, the conv epilogue (or, for shapes
+ * whose sum takes several launches, a reduce pass after the conv) adds into it; the total over the slots is what
+ * BatchNorm1d needs (fv2p_batchnorm_forward_stats).  Declared after fv2p_sparse_conv_rows below. */
+int fv2p_sparse_conv_stat_slots(void);
 int fv2p_sparse_conv_rows(const float* src, int64_t n_src, int c_src, const float* weight, int kvol,
                           const int* tab, int64_t n_dst, int c_dst, int flip_k, int transpose_w,
                           const float* bias, float* dst, fv2p_stream_t stream);
+int fv2p_sparse_conv_rows_stats(const float* src, int64_t n_src, int c_src, const float* weight, int kvol,
+                                const int* tab, int64_t n_dst, int c_dst, int flip_k, int transpose_w,
+                                const float* bias, float* dst, double* stats, fv2p_stream_t stream);
 /* dW_k[c_src][c_dst] = sum_r src[tab[k][r],:]^T grad[r,:]   (dweight [K][c_src][c_dst], fully written here).
  *   forward conv's dW : src=features, grad=dOut [n_out,Cout], tab=tab_out, n_dst=n_out.
  * Per-chunk partial tiles go through the workspace and are summed in a fixed order (deterministic, no atomics).
@@ -334,6 +342,13 @@ int fv2p_batchnorm_forward(const float* x, int64_t n, int c, float eps, float mo
                            const float* beta, int relu, float* running_mean, float* running_var,
                            int64_t* num_batches_tracked, float* mean, float* invstd, float* y, void* ws,
                            size_t ws_bytes, fv2p_stream_t stream);
+/* fv2p_batchnorm_forward with the sums already taken (stats as left by fv2p_sparse_conv_rows_stats): one launch.
+ * zero_next: NULL, or a second stats buffer whose first zero_count doubles are cleared for the next fused conv on this
+ * stream (two buffers alternate: a launch reads one and clears what the other's last user left). */
+int fv2p_batchnorm_forward_stats(const float* x, int64_t n, int c, float eps, float momentum, const float* gamma,
+                                 const float* beta, int relu, float* running_mean, float* running_var,
+                                 int64_t* num_batches_tracked, float* mean, float* invstd, float* y,
+                                 const double* stats, double* zero_next, int64_t zero_count, fv2p_stream_t stream);
 int fv2p_batchnorm_apply(const float* x, int64_t n, int c, const float* mean, const float* invstd,
                          const float* gamma, const float* beta, int relu, float* y, fv2p_stream_t stream);
 int fv2p_batchnorm_backward(const float* x, const float* dy, int64_t n, int c, const float* mean,

@@ -441,3 +441,40 @@ def test_deferred_weight_gradient_join_gives_the_same_gradients(gpu):
             assert (a is None) == (b is None)
             if a is not None:
                 assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("impl", [0, 1, 2, 3])
+def test_conv_epilogue_statistics_equal_the_column_sums(gpu, impl):
+    """fv2p_sparse_conv_rows_stats (C ABI): dst is bit-identical to fv2p_sparse_conv_rows and the slots of `stats` add up to
+    the fp64 column sums / sums of squares of dst — for every kernel variant, with and without a bias, rows not a multiple
+    of the 64-row tile, scalar (cin 4, 24) and split (cin 160) shapes; a second call keeps adding (caller zero-fills)."""
+    import fv2p_native
+    slots = int(fv2p_native.lib().fv2p_sparse_conv_stat_slots())
+    batch, shape = 2, [9, 20, 18]
+    try:
+        fv2p_native.call("fv2p_sparse_conv_set_impl", impl)
+        for cin, cout, subm in [(4, 16, True), (16, 16, True), (32, 64, False), (64, 64, True), (64, 128, True), (24, 40, False), (160, 144, True)]:
+            ind, feats, x = make_input(cin + cout, batch, shape, 1100, cin, gpu)
+            rb = ops.build_rulebook(x.indices, batch, shape, 3, 1 if subm else 2, 1, 1, 0, subm)
+            n_out = rb.outids.shape[0]
+            tab, flip = rb.out_table()
+            rng = np.random.default_rng(cin)
+            w = torch.from_numpy(rng.standard_normal((27, cin, cout)).astype(np.float32) * 0.1).to(gpu)
+            for bias in (None, torch.from_numpy(rng.standard_normal(cout).astype(np.float32)).to(gpu)):
+                ref = torch.empty((n_out, cout), device=gpu)
+                fv2p_native.call("fv2p_sparse_conv_rows", x.features, x.features.shape[0], cin, w, 27, tab, n_out, cout, int(flip), 0, bias, ref,
+                                 fv2p_native.stream())
+                dst = torch.empty_like(ref)
+                stats = torch.zeros((slots, 2, cout), dtype=torch.float64, device=gpu)
+                for rep in (1, 2):
+                    fv2p_native.call("fv2p_sparse_conv_rows_stats", x.features, x.features.shape[0], cin, w, 27, tab, n_out, cout, int(flip), 0, bias,
+                                     dst, stats, fv2p_native.stream())
+                    assert torch.equal(dst, ref), (impl, cin, cout)
+                    if rep == 2 and not (cin <= 128 and impl != 2):
+                        break    # the reduce-pass fallback stores its partials instead of adding: one call per zero-fill
+                    tot = stats.sum(0).cpu().numpy()
+                    d64 = ref.double().cpu().numpy()
+                    want = np.stack([d64.sum(0), (d64 * d64).sum(0)]) * rep
+                    assert np.allclose(tot, want, rtol=1e-11, atol=1e-9), (impl, cin, cout, rep)
+    finally:
+        fv2p_native.call("fv2p_sparse_conv_set_impl", 0)
