@@ -216,8 +216,11 @@ template <int V>
 __global__ __launch_bounds__(256) void bn_apply_bwd_k(const float* __restrict__ x, const float* __restrict__ dy, long long units, BnGeom g,
                                                       const double* __restrict__ partial, const float* __restrict__ mean,
                                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, int relu, BnBwdFin bf, float* __restrict__ dx) {
+                                                      const float* __restrict__ beta, int relu, BnBwdFin bf, float* __restrict__ dx,
+                                                      double* __restrict__ zero_next, long long zero_count) {
   __shared__ double red[2][256];
+  if (zero_next && blockIdx.x == 0)   // see bn_apply_fwd_k
+    for (long long e = threadIdx.x; e < zero_count; e += 256) zero_next[e] = 0.0;
   __shared__ float sh_mean[kBnMaxC], sh_is[kBnMaxC], sh_gamma[kBnMaxC], sh_beta[kBnMaxC], sh_c1[kBnMaxC], sh_c2[kBnMaxC];
   const int tid = threadIdx.x, c = g.c;
   const int cfold = c < 256 ? c : 256;
@@ -333,6 +336,18 @@ int fv2p::bn_column_sums(const float* x, int64_t n, int c, double* stats, hipStr
   return 0;
 }
 
+// (sum dz, sum dz * xhat) into the same slot layout, for a backward-data conv that could not take them in its epilogue
+int fv2p::bn_backward_sums(const float* x, const float* dy, int64_t n, int c, const float* mean, const float* invstd, const float* gamma,
+                           const float* beta, int relu, double* stats, hipStream_t stream) {
+  const bool vec = (c % 4 == 0) && aligned16(x) && aligned16(dy);
+  BnGeom g;
+  FV2P_REQUIRE(bn_geom(n, c, vec, &g) == 0, FV2P_ELIMIT, "batchnorm: c=%d exceeds %d", c, vec ? kBnMaxC : 256);
+  if (vec) hipLaunchKernelGGL((bn_reduce_k<4, true>), dim3(g.nblk), dim3(256), 0, stream, x, dy, g, mean, invstd, gamma, beta, relu, stats);
+  else hipLaunchKernelGGL((bn_reduce_k<1, true>), dim3(g.nblk), dim3(256), 0, stream, x, dy, g, mean, invstd, gamma, beta, relu, stats);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int fv2p_batchnorm_forward_stats(const float* x, int64_t n, int c, float eps, float momentum, const float* gamma, const float* beta,
                                             int relu, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean,
                                             float* invstd, float* y, const double* stats, double* zero_next, int64_t zero_count,
@@ -350,6 +365,27 @@ extern "C" int fv2p_batchnorm_forward_stats(const float* x, int64_t n, int c, fl
   const unsigned blocks = apply_blocks(units);
   if (vec) hipLaunchKernelGGL((bn_apply_fwd_k<4, true>), dim3(blocks), dim3(256), 0, stream, x, units, g, stats, ff, gamma, beta, relu, y, zero_next, static_cast<long long>(zero_count));
   else hipLaunchKernelGGL((bn_apply_fwd_k<1, true>), dim3(blocks), dim3(256), 0, stream, x, units, g, stats, ff, gamma, beta, relu, y, zero_next, static_cast<long long>(zero_count));
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fv2p_batchnorm_backward_stats(const float* x, const float* dy, int64_t n, int c, const float* mean, const float* invstd,
+                                             const float* gamma, const float* beta, int relu, int batch_stats, float* dx, float* dgamma,
+                                             float* dbeta, const double* stats, double* zero_next, int64_t zero_count, fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FV2P_REQUIRE(n >= 1 && c >= 1, FV2P_EINVAL, "batchnorm_backward_stats: n=%lld c=%d", static_cast<long long>(n), c);
+  FV2P_REQUIRE(x && dy && mean && invstd && dx && dgamma && dbeta && stats, FV2P_EINVAL, "batchnorm_backward_stats: null pointer");
+  const bool vec = (c % 4 == 0) && aligned16(x) && aligned16(dy) && aligned16(dx);
+  BnGeom g;
+  FV2P_REQUIRE(bn_geom(n, c, vec, &g) == 0, FV2P_ELIMIT, "batchnorm: c=%d exceeds %d", c, vec ? kBnMaxC : 256);
+  g.nblk = kStatSlots;
+  BnBwdFin bf{dgamma, dbeta, nullptr, batch_stats};
+  const long long units = n * c / (vec ? 4 : 1);
+  const unsigned blocks = apply_blocks(units);
+  if (vec) hipLaunchKernelGGL((bn_apply_bwd_k<4>), dim3(blocks), dim3(256), 0, stream, x, dy, units, g, stats, mean, invstd, gamma, beta, relu, bf, dx,
+                              zero_next, static_cast<long long>(zero_count));
+  else hipLaunchKernelGGL((bn_apply_bwd_k<1>), dim3(blocks), dim3(256), 0, stream, x, dy, units, g, stats, mean, invstd, gamma, beta, relu, bf, dx,
+                          zero_next, static_cast<long long>(zero_count));
   FV2P_LAUNCH_CHECK();
   return 0;
 }
@@ -390,10 +426,10 @@ extern "C" int fv2p_batchnorm_backward(const float* x, const float* dy, int64_t 
   const unsigned blocks = apply_blocks(units);
   if (vec) {
     hipLaunchKernelGGL((bn_reduce_k<4, true>), dim3(g.nblk), dim3(256), 0, stream, x, dy, g, mean, invstd, gamma, beta, relu, partial);
-    hipLaunchKernelGGL((bn_apply_bwd_k<4>), dim3(blocks), dim3(256), 0, stream, x, dy, units, g, partial, mean, invstd, gamma, beta, relu, bf, dx);
+    hipLaunchKernelGGL((bn_apply_bwd_k<4>), dim3(blocks), dim3(256), 0, stream, x, dy, units, g, partial, mean, invstd, gamma, beta, relu, bf, dx, nullptr, 0);
   } else {
     hipLaunchKernelGGL((bn_reduce_k<1, true>), dim3(g.nblk), dim3(256), 0, stream, x, dy, g, mean, invstd, gamma, beta, relu, partial);
-    hipLaunchKernelGGL((bn_apply_bwd_k<1>), dim3(blocks), dim3(256), 0, stream, x, dy, units, g, partial, mean, invstd, gamma, beta, relu, bf, dx);
+    hipLaunchKernelGGL((bn_apply_bwd_k<1>), dim3(blocks), dim3(256), 0, stream, x, dy, units, g, partial, mean, invstd, gamma, beta, relu, bf, dx, nullptr, 0);
   }
   FV2P_LAUNCH_CHECK();
   return 0;

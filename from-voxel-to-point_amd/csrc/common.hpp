@@ -131,6 +131,8 @@ __device__ __forceinline__ int block_excl_scan_256(int v, int* lds_wave /*[4]*/,
 constexpr int kStatSlots = 64;   // accumulator rows of the conv-epilogue BatchNorm statistics = partials the BatchNorm apply kernels fold
 
 int bn_column_sums(const float* x, int64_t n, int c, double* stats, hipStream_t stream);   // batchnorm.hip
+int bn_backward_sums(const float* x, const float* dy, int64_t n, int c, const float* mean, const float* invstd, const float* gamma,
+                     const float* beta, int relu, double* stats, hipStream_t stream);
 
 // ---- internal primitives (sort_scan.hip) ---------------------------------------------
 size_t scan_ws_bytes(int64_t n);

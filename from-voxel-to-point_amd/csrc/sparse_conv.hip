@@ -34,6 +34,9 @@ struct ConvArgs {
   unsigned long long* trace;                         // optional per-workgroup placement/timing trace (test hook)
   double* stats;                                     // optional [kStatSlots][2][stats_ld]: per-column sum / sum of squares of dst
   int stats_ld;
+  // backward-data conv whose result is the gradient of a BatchNorm(+ReLU) output: stats then receive that layer's
+  // backward sums  (sum dz, sum dz * xhat), dz = dst * [y > 0], from the BatchNorm input bn_x (same shape as dst)
+  const float* bn_x; const float* bn_mean; const float* bn_invstd; const float* bn_gamma; const float* bn_beta; int bn_relu;
 };
 
 // ---- BatchNorm statistics in the epilogue --------------------------------------------------------
@@ -50,13 +53,29 @@ __device__ __forceinline__ void tile_stats(const ConvArgs& a, const float (&vals
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     double s1 = 0.0, s2 = 0.0;
+    const bool live = col[i] < a.c_dst;
+    if (a.bn_x == nullptr) {
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      if (row0 + q * 4 + reg < a.n_dst) { const double v = vals[i][reg]; s1 += v; s2 += v * v; }
+      for (int reg = 0; reg < 4; ++reg) {
+        if (row0 + q * 4 + reg < a.n_dst) { const double v = vals[i][reg]; s1 += v; s2 += v * v; }
+      }
+    } else if (live) {   // same arithmetic as bn_reduce_k<BWD> (batchnorm.hip)
+      const float m = a.bn_mean[col[i]], is = a.bn_invstd[col[i]];
+      const float ga = a.bn_gamma ? a.bn_gamma[col[i]] : 1.f, be = a.bn_beta ? a.bn_beta[col[i]] : 0.f;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = row0 + q * 4 + reg;
+        if (row < a.n_dst) {
+          const float xhat = (a.bn_x[static_cast<long long>(row) * a.ld_dst + col[i]] - m) * is;
+          const float y = xhat * ga + be;
+          const float dz = (a.bn_relu && !(y > 0.f)) ? 0.f : vals[i][reg];
+          s1 += dz; s2 += static_cast<double>(dz) * xhat;
+        }
+      }
     }
     s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
     s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-    if (q == 0 && col[i] < a.c_dst) {
+    if (q == 0 && live) {
       __hip_atomic_fetch_add(base + col[i], s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_fetch_add(base + a.stats_ld + col[i], s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1210,7 +1229,8 @@ extern "C" int fv2p_sparse_conv_set_impl(int impl) {
 }
 
 static int conv_rows_impl(const float* src, int64_t n_src, int c_src, const float* weight, int kvol, const int* tab, int64_t n_dst, int c_dst,
-                          int flip_k, int transpose_w, const float* bias, float* dst, double* stats, hipStream_t stream) {
+                          int flip_k, int transpose_w, const float* bias, float* dst, double* stats, hipStream_t stream,
+                          const ConvArgs* bn = nullptr) {
   FV2P_REQUIRE(c_src >= 1 && c_dst >= 1 && kvol >= 1 && n_dst >= 0 && n_src >= 0, FV2P_EINVAL, "sparse_conv_rows: bad sizes");
   if (n_dst == 0) return 0;
   FV2P_REQUIRE(weight && tab && dst && (src || n_src == 0), FV2P_EINVAL, "sparse_conv_rows: null pointer");
@@ -1225,6 +1245,11 @@ static int conv_rows_impl(const float* src, int64_t n_src, int c_src, const floa
       ConvArgs a;
       a.trace = nullptr;
       a.stats = stats ? stats + d0 : nullptr; a.stats_ld = c_dst;
+      a.bn_x = nullptr; a.bn_mean = a.bn_invstd = a.bn_gamma = a.bn_beta = nullptr; a.bn_relu = 0;
+      if (bn && stats) {   // per-column pointers move with the column block, bn_x is addressed like dst (row * ld_dst + col)
+        a.bn_x = bn->bn_x + d0; a.bn_mean = bn->bn_mean + d0; a.bn_invstd = bn->bn_invstd + d0;
+        a.bn_gamma = bn->bn_gamma ? bn->bn_gamma + d0 : nullptr; a.bn_beta = bn->bn_beta ? bn->bn_beta + d0 : nullptr; a.bn_relu = bn->bn_relu;
+      }
       a.src = src + s0; a.ld_src = c_src; a.c_src = cs;
       a.w = transpose_w ? weight + static_cast<long long>(d0) * w_cols + s0 : weight + static_cast<long long>(s0) * w_cols + d0;
       a.w_kstride = static_cast<long long>(w_rows) * w_cols; a.w_ld = w_cols;
@@ -1259,6 +1284,22 @@ extern "C" int fv2p_sparse_conv_rows_stats(const float* src, int64_t n_src, int 
   if (int rc = conv_rows_impl(src, n_src, c_src, weight, kvol, tab, n_dst, c_dst, flip_k, transpose_w, bias, dst, fused ? stats : nullptr, stream))
     return rc;
   if (!fused && n_dst > 0) return bn_column_sums(dst, n_dst, c_dst, stats, stream);
+  return 0;
+}
+
+extern "C" int fv2p_sparse_conv_rows_bnbwd(const float* src, int64_t n_src, int c_src, const float* weight, int kvol, const int* tab,
+                                           int64_t n_dst, int c_dst, int flip_k, int transpose_w, float* dst, const float* bn_x,
+                                           const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_beta, int relu,
+                                           double* stats, fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FV2P_REQUIRE(stats && bn_x && bn_mean && bn_invstd, FV2P_EINVAL, "sparse_conv_rows_bnbwd: null pointer");
+  const bool fused = c_src <= 128 && conv_impl() != 2 && n_dst > 0;   // as in fv2p_sparse_conv_rows_stats
+  ConvArgs bn;
+  bn.bn_x = bn_x; bn.bn_mean = bn_mean; bn.bn_invstd = bn_invstd; bn.bn_gamma = bn_gamma; bn.bn_beta = bn_beta; bn.bn_relu = relu;
+  if (int rc = conv_rows_impl(src, n_src, c_src, weight, kvol, tab, n_dst, c_dst, flip_k, transpose_w, nullptr, dst, fused ? stats : nullptr, stream,
+                              fused ? &bn : nullptr))
+    return rc;
+  if (!fused && n_dst > 0) return bn_backward_sums(bn_x, dst, n_dst, c_dst, bn_mean, bn_invstd, bn_gamma, bn_beta, relu, stats, stream);
   return 0;
 }
 

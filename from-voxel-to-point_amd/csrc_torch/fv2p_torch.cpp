@@ -79,6 +79,137 @@ void require_f32_cuda(const at::Tensor& t, const char* name) {
   TORCH_CHECK(t.scalar_type() == at::kFloat, name, ": float32 expected");
 }
 
+// Column statistics of a conv that feeds BatchNorm come out of its epilogue (fv2p_sparse_conv_rows_stats).  Two slot
+// buffers per (device, stream) alternate: the BatchNorm launch that reads one clears what the previous user left in the
+// other, so the next fused conv — later on the same stream — finds it zeroed without a fill launch of its own.
+// The backward pass has its own pair: a backward-data conv leaves (sum dz, sum dz * xhat) of the BatchNorm that produced its
+// input, the BatchNorm's backward node consumes them a few autograd nodes later (`unread` guards a buffer until then).
+struct StatRing {
+  at::Tensor buf[2];
+  int64_t dirty[2] = {0, 0};   // doubles the last user of each buffer wrote
+  bool unread[2] = {false, false};
+  int cur = 0;
+};
+StatRing& stat_ring(const at::Tensor& like, void* stream, int which = 0) {
+  static std::mutex mu;
+  static std::map<std::tuple<int, void*, int>, StatRing> pool;
+  std::lock_guard<std::mutex> lock(mu);
+  auto key = std::make_tuple(static_cast<int>(like.device().index()), stream, which);
+  auto it = pool.find(key);
+  if (it == pool.end()) {
+    StatRing r;
+    const int64_t cap = static_cast<int64_t>(fv2p_sparse_conv_stat_slots()) * 2 * 1024;
+    for (auto& b : r.buf) b = at::zeros({cap}, like.options().dtype(at::kDouble));
+    it = pool.emplace(key, std::move(r)).first;
+  }
+  return it->second;
+}
+static int g_bn_epilogue = -1;   // FV2P_BN_EPILOGUE=0 or set_bn_epilogue(false): BatchNorm takes its own sums (tests compare the two)
+static bool fuse_bn_stats() {
+  if (g_bn_epilogue < 0) { const char* e = std::getenv("FV2P_BN_EPILOGUE"); g_bn_epilogue = !(e && e[0] == '0'); }
+  return g_bn_epilogue != 0;
+}
+void set_bn_epilogue(bool on) { g_bn_epilogue = on ? 1 : 0; }
+
+
+// ---- BatchNorm1d (+ReLU) on [N, C] ---------------------------------------------------------------------------------------
+struct BnReluFn : public torch::autograd::Function<BnReluFn> {
+  static at::Tensor forward(AutogradContext* ctx, const at::Tensor& x_, const c10::optional<at::Tensor>& weight, const c10::optional<at::Tensor>& bias,
+                            const c10::optional<at::Tensor>& running_mean, const c10::optional<at::Tensor>& running_var,
+                            const c10::optional<at::Tensor>& num_batches_tracked, bool training, double momentum, double eps, bool relu,
+                            const c10::optional<at::Tensor>& stats, const c10::optional<at::Tensor>& zero_next, int64_t zero_count) {
+    require_f32_cuda(x_, "input");
+    const at::Tensor x = x_.contiguous();
+    const int64_t n = x.size(0), c = x.size(1);
+    const bool has_running = running_mean.has_value() && running_mean->defined();
+    const bool batch_stats = training || !has_running;
+    c10::DeviceGuard guard(x.device());
+    void* stream = cur_stream(x);
+    at::Tensor y = at::empty_like(x);
+    at::Tensor mean, invstd;
+    const float* gamma = (weight.has_value() && weight->defined()) ? weight->data_ptr<float>() : nullptr;
+    const float* beta = (bias.has_value() && bias->defined()) ? bias->data_ptr<float>() : nullptr;
+    if (batch_stats) {
+      at::Tensor saved = at::empty({2, c}, x.options());
+      mean = saved[0];
+      invstd = saved[1];
+      const bool track = training && has_running;
+      int64_t* nbt = (track && num_batches_tracked.has_value() && num_batches_tracked->defined()) ? num_batches_tracked->data_ptr<int64_t>() : nullptr;
+      if (stats.has_value() && stats->defined()) {   // sums taken by the producing conv's epilogue: one launch
+        check(fv2p_batchnorm_forward_stats(x.data_ptr<float>(), n, static_cast<int>(c), static_cast<float>(eps), static_cast<float>(momentum), gamma,
+                                           beta, relu ? 1 : 0, track ? running_mean->data_ptr<float>() : nullptr,
+                                           track ? running_var->data_ptr<float>() : nullptr, nbt, mean.data_ptr<float>(), invstd.data_ptr<float>(),
+                                           y.data_ptr<float>(), stats->data_ptr<double>(),
+                                           (zero_next.has_value() && zero_next->defined()) ? zero_next->data_ptr<double>() : nullptr, zero_count, stream),
+              "fv2p_batchnorm_forward_stats");
+      } else {
+      at::Tensor ws = workspace(fv2p_batchnorm_ws_bytes(n, static_cast<int>(c)), x, stream);
+      check(fv2p_batchnorm_forward(x.data_ptr<float>(), n, static_cast<int>(c), static_cast<float>(eps), static_cast<float>(momentum), gamma, beta,
+                                   relu ? 1 : 0, track ? running_mean->data_ptr<float>() : nullptr, track ? running_var->data_ptr<float>() : nullptr,
+                                   nbt, mean.data_ptr<float>(), invstd.data_ptr<float>(), y.data_ptr<float>(), ws.data_ptr(),
+                                   static_cast<size_t>(ws.numel()), stream),
+            "fv2p_batchnorm_forward");
+      }
+    } else {
+      mean = *running_mean;
+      invstd = at::rsqrt(*running_var + eps);
+      check(fv2p_batchnorm_apply(x.data_ptr<float>(), n, static_cast<int>(c), mean.data_ptr<float>(), invstd.data_ptr<float>(), gamma, beta,
+                                 relu ? 1 : 0, y.data_ptr<float>(), stream),
+            "fv2p_batchnorm_apply");
+    }
+    ctx->save_for_backward({x, mean, invstd, weight.has_value() ? *weight : at::Tensor(), bias.has_value() ? *bias : at::Tensor()});
+    ctx->saved_data["relu"] = relu;
+    ctx->saved_data["batch_stats"] = batch_stats;
+    return y;
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    const auto saved = ctx->get_saved_variables();
+    const at::Tensor &x = saved[0], &mean = saved[1], &invstd = saved[2], &weight = saved[3], &bias = saved[4];
+    const at::Tensor dy = grads[0].contiguous();
+    const int64_t n = x.size(0), c = x.size(1);
+    c10::DeviceGuard guard(x.device());
+    void* stream = cur_stream(x);
+    at::Tensor dx = at::empty_like(x);
+    at::Tensor dpar = at::empty({2, c}, x.options());
+    // sums left by the backward-data conv that produced exactly this dy (SparseConvFn::backward): one launch
+    auto it = ctx->saved_data.find("stats_buf");
+    if (it != ctx->saved_data.end()) {
+      const int b = static_cast<int>(it->second.toInt());
+      // exactly the tensor that conv wrote, untouched: the engine sums several gradients into a new tensor or in place
+      // into the first one (which bumps its version counter)
+      const bool mine = ctx->saved_data["stats_dy"].toInt() == reinterpret_cast<int64_t>(dy.data_ptr()) &&
+                        ctx->saved_data["stats_ver"].toInt() == static_cast<int64_t>(dy._version());
+      ctx->saved_data.erase("stats_buf");
+      StatRing& ring = stat_ring(x, stream, 1);
+      ring.unread[b] = false;   // read below, or abandoned (dy is a sum of several gradients): the next producer clears it
+      if (mine) {
+        const int other = 1 - b;
+        const int64_t zc = ring.unread[other] ? 0 : ring.dirty[other];
+        check(fv2p_batchnorm_backward_stats(x.data_ptr<float>(), dy.data_ptr<float>(), n, static_cast<int>(c), mean.data_ptr<float>(),
+                                            invstd.data_ptr<float>(), weight.defined() ? weight.data_ptr<float>() : nullptr,
+                                            bias.defined() ? bias.data_ptr<float>() : nullptr, ctx->saved_data["relu"].toBool() ? 1 : 0,
+                                            ctx->saved_data["batch_stats"].toBool() ? 1 : 0, dx.data_ptr<float>(), dpar[0].data_ptr<float>(),
+                                            dpar[1].data_ptr<float>(), ring.buf[b].data_ptr<double>(), zc ? ring.buf[other].data_ptr<double>() : nullptr,
+                                            zc, stream),
+              "fv2p_batchnorm_backward_stats");
+        if (zc) ring.dirty[other] = 0;
+        return {dx, weight.defined() ? dpar[0] : at::Tensor(), bias.defined() ? dpar[1] : at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
+                at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+      }
+    }
+    at::Tensor ws = workspace(fv2p_batchnorm_ws_bytes(n, static_cast<int>(c)), x, stream);
+    check(fv2p_batchnorm_backward(x.data_ptr<float>(), dy.data_ptr<float>(), n, static_cast<int>(c), mean.data_ptr<float>(), invstd.data_ptr<float>(),
+                                  weight.defined() ? weight.data_ptr<float>() : nullptr, bias.defined() ? bias.data_ptr<float>() : nullptr,
+                                  ctx->saved_data["relu"].toBool() ? 1 : 0, ctx->saved_data["batch_stats"].toBool() ? 1 : 0, dx.data_ptr<float>(),
+                                  dpar[0].data_ptr<float>(), dpar[1].data_ptr<float>(), ws.data_ptr(), static_cast<size_t>(ws.numel()), stream),
+          "fv2p_batchnorm_backward");
+    return {dx, weight.defined() ? dpar[0] : at::Tensor(), bias.defined() ? dpar[1] : at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
+            at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+  }
+};
+
+
 // ---- deferred join of the weight-gradient stream ------------------------------------------------------------------------
 // Joining the side stream before a conv's backward returns leaves the training stream idle for the tail of every weight
 // gradient (measured: 2.14 -> 1.93 ms per step without the joins).  gate_weights() is applied to all conv weights at the
@@ -153,6 +284,9 @@ struct SparseConvFn : public torch::autograd::Function<SparseConvFn> {
     ctx->saved_data["flip_b"] = flip_b;
     ctx->saved_data["centre"] = centre;
     ctx->saved_data["gated"] = is_gated(weight_);
+    // features straight out of a fused BatchNorm(+ReLU): the backward-data conv can take that layer's backward sums
+    auto* bn_node = features_.grad_fn() ? dynamic_cast<torch::autograd::CppNode<BnReluFn>*>(features_.grad_fn().get()) : nullptr;
+    ctx->saved_data["bn_node"] = reinterpret_cast<int64_t>(bn_node);   // kept alive by this node's edge to it
     return out;
   }
 
@@ -180,9 +314,37 @@ struct SparseConvFn : public torch::autograd::Function<SparseConvFn> {
     }
     if (ctx->needs_input_grad(0)) {
       din = at::empty_like(features);
-      check(fv2p_sparse_conv_rows(g.data_ptr<float>(), g.size(0), static_cast<int>(cout), weight.data_ptr<float>(), static_cast<int>(kvol),
-                                  tab_b.data_ptr<int>(), features.size(0), static_cast<int>(cin), flip_b, 1, nullptr, din.data_ptr<float>(), stream),
-            "fv2p_sparse_conv_rows (backward data)");
+      auto* bn_node = reinterpret_cast<torch::autograd::CppNode<BnReluFn>*>(ctx->saved_data["bn_node"].toInt());
+      bool fused = false;
+      if (bn_node && fuse_bn_stats() && cout <= 128 && cin <= 1024) {
+        StatRing& ring = stat_ring(features, stream, 1);
+        const int b = ring.cur;
+        if (!ring.unread[b]) {
+          if (ring.dirty[b]) { ring.buf[b].zero_(); ring.dirty[b] = 0; }   // left by sums nobody read: rare, costs a fill
+          AutogradContext& bctx = bn_node->ctx_;
+          const auto bsaved = bctx.get_saved_variables();   // x, mean, invstd, weight, bias of the BatchNorm
+          const at::Tensor &bx = bsaved[0], &bmean = bsaved[1], &binv = bsaved[2], &bw = bsaved[3], &bb = bsaved[4];
+          if (bx.defined() && bx.sizes() == din.sizes() && bx.is_contiguous()) {
+            check(fv2p_sparse_conv_rows_bnbwd(g.data_ptr<float>(), g.size(0), static_cast<int>(cout), weight.data_ptr<float>(), static_cast<int>(kvol),
+                                              tab_b.data_ptr<int>(), features.size(0), static_cast<int>(cin), flip_b, 1, din.data_ptr<float>(),
+                                              bx.data_ptr<float>(), bmean.data_ptr<float>(), binv.data_ptr<float>(),
+                                              bw.defined() ? bw.data_ptr<float>() : nullptr, bb.defined() ? bb.data_ptr<float>() : nullptr,
+                                              bctx.saved_data["relu"].toBool() ? 1 : 0, ring.buf[b].data_ptr<double>(), stream),
+                  "fv2p_sparse_conv_rows_bnbwd");
+            ring.dirty[b] = static_cast<int64_t>(fv2p_sparse_conv_stat_slots()) * 2 * cin;
+            ring.unread[b] = true;
+            ring.cur = 1 - b;
+            bctx.saved_data["stats_buf"] = static_cast<int64_t>(b);
+            bctx.saved_data["stats_dy"] = reinterpret_cast<int64_t>(din.data_ptr());
+            bctx.saved_data["stats_ver"] = static_cast<int64_t>(din._version());
+            fused = true;
+          }
+        }
+      }
+      if (!fused)
+        check(fv2p_sparse_conv_rows(g.data_ptr<float>(), g.size(0), static_cast<int>(cout), weight.data_ptr<float>(), static_cast<int>(kvol),
+                                    tab_b.data_ptr<int>(), features.size(0), static_cast<int>(cin), flip_b, 1, nullptr, din.data_ptr<float>(), stream),
+              "fv2p_sparse_conv_rows (backward data)");
     }
     if (ctx->needs_input_grad(1)) {
       // scratch of the side stream is allocated under that stream, so the caching allocator recycles it in its order
@@ -227,77 +389,6 @@ at::Tensor sparse_conv(const at::Tensor& features, const at::Tensor& weight, con
   return SparseConvFn::apply(features, weight, tab_f, flip_f, tab_b, flip_b, n_out, centre, pairs, pair_num, side_src, c10::optional<at::Tensor>());
 }
 
-// ---- BatchNorm1d (+ReLU) on [N, C] ---------------------------------------------------------------------------------------
-struct BnReluFn : public torch::autograd::Function<BnReluFn> {
-  static at::Tensor forward(AutogradContext* ctx, const at::Tensor& x_, const c10::optional<at::Tensor>& weight, const c10::optional<at::Tensor>& bias,
-                            const c10::optional<at::Tensor>& running_mean, const c10::optional<at::Tensor>& running_var,
-                            const c10::optional<at::Tensor>& num_batches_tracked, bool training, double momentum, double eps, bool relu,
-                            const c10::optional<at::Tensor>& stats, const c10::optional<at::Tensor>& zero_next, int64_t zero_count) {
-    require_f32_cuda(x_, "input");
-    const at::Tensor x = x_.contiguous();
-    const int64_t n = x.size(0), c = x.size(1);
-    const bool has_running = running_mean.has_value() && running_mean->defined();
-    const bool batch_stats = training || !has_running;
-    c10::DeviceGuard guard(x.device());
-    void* stream = cur_stream(x);
-    at::Tensor y = at::empty_like(x);
-    at::Tensor mean, invstd;
-    const float* gamma = (weight.has_value() && weight->defined()) ? weight->data_ptr<float>() : nullptr;
-    const float* beta = (bias.has_value() && bias->defined()) ? bias->data_ptr<float>() : nullptr;
-    if (batch_stats) {
-      at::Tensor saved = at::empty({2, c}, x.options());
-      mean = saved[0];
-      invstd = saved[1];
-      const bool track = training && has_running;
-      int64_t* nbt = (track && num_batches_tracked.has_value() && num_batches_tracked->defined()) ? num_batches_tracked->data_ptr<int64_t>() : nullptr;
-      if (stats.has_value() && stats->defined()) {   // sums taken by the producing conv's epilogue: one launch
-        check(fv2p_batchnorm_forward_stats(x.data_ptr<float>(), n, static_cast<int>(c), static_cast<float>(eps), static_cast<float>(momentum), gamma,
-                                           beta, relu ? 1 : 0, track ? running_mean->data_ptr<float>() : nullptr,
-                                           track ? running_var->data_ptr<float>() : nullptr, nbt, mean.data_ptr<float>(), invstd.data_ptr<float>(),
-                                           y.data_ptr<float>(), stats->data_ptr<double>(),
-                                           (zero_next.has_value() && zero_next->defined()) ? zero_next->data_ptr<double>() : nullptr, zero_count, stream),
-              "fv2p_batchnorm_forward_stats");
-      } else {
-      at::Tensor ws = workspace(fv2p_batchnorm_ws_bytes(n, static_cast<int>(c)), x, stream);
-      check(fv2p_batchnorm_forward(x.data_ptr<float>(), n, static_cast<int>(c), static_cast<float>(eps), static_cast<float>(momentum), gamma, beta,
-                                   relu ? 1 : 0, track ? running_mean->data_ptr<float>() : nullptr, track ? running_var->data_ptr<float>() : nullptr,
-                                   nbt, mean.data_ptr<float>(), invstd.data_ptr<float>(), y.data_ptr<float>(), ws.data_ptr(),
-                                   static_cast<size_t>(ws.numel()), stream),
-            "fv2p_batchnorm_forward");
-      }
-    } else {
-      mean = *running_mean;
-      invstd = at::rsqrt(*running_var + eps);
-      check(fv2p_batchnorm_apply(x.data_ptr<float>(), n, static_cast<int>(c), mean.data_ptr<float>(), invstd.data_ptr<float>(), gamma, beta,
-                                 relu ? 1 : 0, y.data_ptr<float>(), stream),
-            "fv2p_batchnorm_apply");
-    }
-    ctx->save_for_backward({x, mean, invstd, weight.has_value() ? *weight : at::Tensor(), bias.has_value() ? *bias : at::Tensor()});
-    ctx->saved_data["relu"] = relu;
-    ctx->saved_data["batch_stats"] = batch_stats;
-    return y;
-  }
-
-  static variable_list backward(AutogradContext* ctx, variable_list grads) {
-    const auto saved = ctx->get_saved_variables();
-    const at::Tensor &x = saved[0], &mean = saved[1], &invstd = saved[2], &weight = saved[3], &bias = saved[4];
-    const at::Tensor dy = grads[0].contiguous();
-    const int64_t n = x.size(0), c = x.size(1);
-    c10::DeviceGuard guard(x.device());
-    void* stream = cur_stream(x);
-    at::Tensor dx = at::empty_like(x);
-    at::Tensor dpar = at::empty({2, c}, x.options());
-    at::Tensor ws = workspace(fv2p_batchnorm_ws_bytes(n, static_cast<int>(c)), x, stream);
-    check(fv2p_batchnorm_backward(x.data_ptr<float>(), dy.data_ptr<float>(), n, static_cast<int>(c), mean.data_ptr<float>(), invstd.data_ptr<float>(),
-                                  weight.defined() ? weight.data_ptr<float>() : nullptr, bias.defined() ? bias.data_ptr<float>() : nullptr,
-                                  ctx->saved_data["relu"].toBool() ? 1 : 0, ctx->saved_data["batch_stats"].toBool() ? 1 : 0, dx.data_ptr<float>(),
-                                  dpar[0].data_ptr<float>(), dpar[1].data_ptr<float>(), ws.data_ptr(), static_cast<size_t>(ws.numel()), stream),
-          "fv2p_batchnorm_backward");
-    return {dx, weight.defined() ? dpar[0] : at::Tensor(), bias.defined() ? dpar[1] : at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
-            at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
-  }
-};
-
 at::Tensor batch_norm_relu(const at::Tensor& x, const c10::optional<at::Tensor>& weight, const c10::optional<at::Tensor>& bias,
                            const c10::optional<at::Tensor>& running_mean, const c10::optional<at::Tensor>& running_var,
                            const c10::optional<at::Tensor>& num_batches_tracked, bool training, double momentum, double eps, bool relu) {
@@ -306,33 +397,6 @@ at::Tensor batch_norm_relu(const at::Tensor& x, const c10::optional<at::Tensor>&
 }
 
 // conv -> BatchNorm1d (-> ReLU) of one backbone block in one crossing from Python (post_act_block, spconv_backbone.py:8-27)
-// Column statistics of a conv that feeds BatchNorm come out of its epilogue (fv2p_sparse_conv_rows_stats).  Two slot
-// buffers per (device, stream) alternate: the BatchNorm launch that reads one clears what the previous user left in the
-// other, so the next fused conv — later on the same stream — finds it zeroed without a fill launch of its own.
-struct StatRing {
-  at::Tensor buf[2];
-  int64_t dirty[2] = {0, 0};   // doubles the last user of each buffer wrote
-  int cur = 0;
-};
-StatRing& stat_ring(const at::Tensor& like, void* stream) {
-  static std::mutex mu;
-  static std::map<std::pair<int, void*>, StatRing> pool;
-  std::lock_guard<std::mutex> lock(mu);
-  auto key = std::make_pair(static_cast<int>(like.device().index()), stream);
-  auto it = pool.find(key);
-  if (it == pool.end()) {
-    StatRing r;
-    const int64_t cap = static_cast<int64_t>(fv2p_sparse_conv_stat_slots()) * 2 * 1024;
-    for (auto& b : r.buf) b = at::zeros({cap}, like.options().dtype(at::kDouble));
-    it = pool.emplace(key, std::move(r)).first;
-  }
-  return it->second;
-}
-static bool fuse_bn_stats() {
-  static const bool on = [] { const char* e = std::getenv("FV2P_BN_EPILOGUE"); return !(e && e[0] == '0'); }();
-  return on;
-}
-
 at::Tensor sparse_conv_bn_relu(const at::Tensor& features, const at::Tensor& weight, const at::Tensor& tab_f, int64_t flip_f, const at::Tensor& tab_b,
                                int64_t flip_b, int64_t n_out, int64_t centre, const c10::optional<at::Tensor>& pairs,
                                const c10::optional<at::Tensor>& pair_num, int64_t side_src, const c10::optional<at::Tensor>& conv_bias,
@@ -513,6 +577,7 @@ std::vector<std::vector<at::Tensor>> build_rulebook_chain(const at::Tensor& root
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "compiled autograd binding of libfv2p_ops (sparse conv, BatchNorm1d+ReLU)";
   m.def("abi_version", []() { return fv2p_abi_version(); });
+  m.def("set_bn_epilogue", &set_bn_epilogue, "BatchNorm sums from the conv epilogues (default) or from BatchNorm's own reduce pass");
   m.def("gate_weights", &gate_weights, "aliases of the conv weights whose gradients are joined from the side stream at the end of backward");
   m.def("sparse_conv", &sparse_conv, "fused sparse convolution with autograd (tables from a Rulebook)");
   m.def("batch_norm_relu", &batch_norm_relu, "BatchNorm1d (+ReLU) on [N, C] with autograd");

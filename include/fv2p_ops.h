@@ -140,6 +140,14 @@ int fv2p_sparse_conv_rows(const float* src, int64_t n_src, int c_src, const floa
 int fv2p_sparse_conv_rows_stats(const float* src, int64_t n_src, int c_src, const float* weight, int kvol,
                                 const int* tab, int64_t n_dst, int c_dst, int flip_k, int transpose_w,
                                 const float* bias, float* dst, double* stats, fv2p_stream_t stream);
+/* Backward-data conv (no bias) whose result dst is the gradient of a BatchNorm1d(+ReLU) output: `stats` (zero-filled,
+ * same slot layout) additionally receives that layer's backward sums, sum dz and sum dz * xhat with
+ * dz = dst * [y > 0] and xhat, y recomputed from the BatchNorm input bn_x [n_dst, c_dst] — what
+ * fv2p_batchnorm_backward_stats needs (c_src > 128: summed by a pass after the conv instead of in its epilogue). */
+int fv2p_sparse_conv_rows_bnbwd(const float* src, int64_t n_src, int c_src, const float* weight, int kvol,
+                                const int* tab, int64_t n_dst, int c_dst, int flip_k, int transpose_w, float* dst,
+                                const float* bn_x, const float* bn_mean, const float* bn_invstd, const float* bn_gamma,
+                                const float* bn_beta, int relu, double* stats, fv2p_stream_t stream);
 /* dW_k[c_src][c_dst] = sum_r src[tab[k][r],:]^T grad[r,:]   (dweight [K][c_src][c_dst], fully written here).
  *   forward conv's dW : src=features, grad=dOut [n_out,Cout], tab=tab_out, n_dst=n_out.
  * Per-chunk partial tiles go through the workspace and are summed in a fixed order (deterministic, no atomics).
@@ -349,6 +357,11 @@ int fv2p_batchnorm_forward_stats(const float* x, int64_t n, int c, float eps, fl
                                  const float* beta, int relu, float* running_mean, float* running_var,
                                  int64_t* num_batches_tracked, float* mean, float* invstd, float* y,
                                  const double* stats, double* zero_next, int64_t zero_count, fv2p_stream_t stream);
+/* fv2p_batchnorm_backward with (sum dz, sum dz * xhat) already in `stats` (fv2p_sparse_conv_rows_bnbwd): one launch. */
+int fv2p_batchnorm_backward_stats(const float* x, const float* dy, int64_t n, int c, const float* mean,
+                                  const float* invstd, const float* gamma, const float* beta, int relu,
+                                  int batch_stats, float* dx, float* dgamma, float* dbeta, const double* stats,
+                                  double* zero_next, int64_t zero_count, fv2p_stream_t stream);
 int fv2p_batchnorm_apply(const float* x, int64_t n, int c, const float* mean, const float* invstd,
                          const float* gamma, const float* beta, int relu, float* y, fv2p_stream_t stream);
 int fv2p_batchnorm_backward(const float* x, const float* dy, int64_t n, int c, const float* mean,

@@ -478,3 +478,94 @@ def test_conv_epilogue_statistics_equal_the_column_sums(gpu, impl):
                     assert np.allclose(tot, want, rtol=1e-11, atol=1e-9), (impl, cin, cout, rep)
     finally:
         fv2p_native.call("fv2p_sparse_conv_set_impl", 0)
+
+
+def test_batchnorm_sums_from_conv_epilogues_match_the_separate_passes(gpu):
+    """Compiled binding: in a conv -> BN -> ReLU chain the forward column sums come from the conv's epilogue and the
+    BatchNorm backward sums from the epilogue of the next layer's backward-data conv (two alternating slot buffers per
+    stream and direction).  Features, running statistics and all gradients equal the path where BatchNorm reduces by
+    itself (fp64 sums in another order: 1e-5), over several iterations; a BatchNorm whose output feeds two consumers
+    (its dy is a sum) falls back by itself."""
+    import fv2p_native
+    ext = fv2p_native.torch_ext()
+    if ext is None:
+        pytest.skip("compiled binding not built")
+    batch, shape = 2, [9, 40, 36]
+
+    def block(cin, cout, key, **kw):
+        conv = spconv.SubMConv3d(cin, cout, 3, padding=1, bias=False, indice_key=key) if not kw else \
+            spconv.SparseConv3d(cin, cout, 3, bias=False, indice_key=key, **kw)
+        return spconv.SparseSequential(conv, torch.nn.BatchNorm1d(cout, eps=1e-3, momentum=0.01), torch.nn.ReLU())
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b = block(16, 32, "s1"), block(32, 32, "s1")
+            self.c = block(32, 64, "d", stride=2, padding=1)
+            self.d, self.e = block(64, 64, "s2"), block(64, 160, "s2")      # 160 output channels: dX sums by the fallback pass
+            self.f = block(160, 64, "s2")
+            self.side = block(32, 32, "s1")
+
+        def forward(self, x):
+            xb = self.b(self.a(x))
+            y = self.f(self.e(self.d(self.c(xb))))
+            z = self.side(xb)                                              # xb feeds two convs: BatchNorm b's dy is a sum
+            return y.features.square().sum() + z.features.square().sum()
+
+    results = {}
+    try:
+        for mode in (True, False):
+            ext.set_bn_epilogue(mode)
+            torch.manual_seed(0)
+            net = Net().to(gpu)
+            outs = []
+            for it in range(3):
+                ind, feats, x = make_input(200 + it, batch, shape, 3000, 16, gpu)
+                x.features.requires_grad_(True)
+                net.zero_grad(set_to_none=True)
+                loss = net(x)
+                loss.backward()
+                outs.append([loss.detach().clone(), x.features.grad.clone()] + [p.grad.clone() for p in net.parameters()]
+                            + [b.clone() for b in net.buffers() if b.dtype == torch.float32])
+            results[mode] = outs
+    finally:
+        ext.set_bn_epilogue(True)
+    for it, (oa, ob) in enumerate(zip(results[True], results[False])):
+        for j, (a, b) in enumerate(zip(oa, ob)):
+            err = float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+            assert err < 1e-5, (it, j, tuple(a.shape), err)
+
+
+def test_backward_data_conv_leaves_the_batchnorm_backward_sums(gpu):
+    """fv2p_sparse_conv_rows_bnbwd (C ABI): dst equals the plain backward-data conv bit for bit; the slots add up to
+    sum dz and sum dz * xhat (dz = dst * [y > 0]) computed in float64 from the same fp32 xhat — in the epilogue
+    (c_src <= 128) and by the pass after the conv (c_src = 160)."""
+    import fv2p_native
+    slots = int(fv2p_native.lib().fv2p_sparse_conv_stat_slots())
+    batch, shape = 2, [9, 20, 18]
+    for cin, cout in [(16, 32), (64, 64), (32, 160), (160, 64), (24, 40)]:     # conv cin -> cout; its dX has c_src = cout, c_dst = cin
+        ind, feats, x = make_input(cin * 3 + cout, batch, shape, 1100, cin, gpu)
+        rb = ops.build_rulebook(x.indices, batch, shape, 3, 1, 1, 1, 0, True)
+        n = x.features.shape[0]
+        tab, flip = rb.in_table()
+        rng = np.random.default_rng(cout)
+        w = torch.from_numpy(rng.standard_normal((27, cin, cout)).astype(np.float32) * 0.1).to(gpu)
+        g = torch.from_numpy(rng.standard_normal((n, cout)).astype(np.float32)).to(gpu)
+        bn_x = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32) * 2 + 1).to(gpu)
+        mean = torch.from_numpy(rng.uniform(0.5, 1.5, cin).astype(np.float32)).to(gpu)
+        invstd = torch.from_numpy(rng.uniform(0.3, 0.8, cin).astype(np.float32)).to(gpu)
+        gamma = torch.from_numpy(rng.uniform(0.5, 1.5, cin).astype(np.float32)).to(gpu)
+        beta = torch.from_numpy(rng.uniform(-0.5, 0.5, cin).astype(np.float32)).to(gpu)
+        ref = torch.empty((n, cin), device=gpu)
+        fv2p_native.call("fv2p_sparse_conv_rows", g, n, cout, w, 27, tab, n, cin, int(flip), 1, None, ref, fv2p_native.stream())
+        for relu in (1, 0):
+            dst = torch.empty_like(ref)
+            stats = torch.zeros((slots, 2, cin), dtype=torch.float64, device=gpu)
+            fv2p_native.call("fv2p_sparse_conv_rows_bnbwd", g, n, cout, w, 27, tab, n, cin, int(flip), 1, dst, bn_x, mean, invstd, gamma, beta, relu,
+                             stats, fv2p_native.stream())
+            assert torch.equal(dst, ref), (cin, cout)
+            xhat = (bn_x - mean) * invstd                       # fp32, as the kernel
+            y = xhat * gamma + beta
+            dz = torch.where(y > 0, ref, torch.zeros_like(ref)) if relu else ref
+            want = torch.stack([dz.double().sum(0), (dz.double() * xhat.double()).sum(0)]).cpu().numpy()
+            assert np.allclose(stats.sum(0).cpu().numpy(), want, rtol=1e-9, atol=1e-7), (cin, cout, relu)
