@@ -9,7 +9,7 @@ python3 - <<'PY'
 import csv, glob
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob(f"gpurun_out/pmc_{c}/*counter_collection.csv"):
-        rows = [r for r in csv.DictReader(open(f)) if "conv_rows_dma" in r["Kernel_Name"] and r["Counter_Name"] == c]
+        rows = [r for r in csv.DictReader(open(f)) if "conv_rows_dma<64, 4, false>" in r["Kernel_Name"] and r["Counter_Name"] == c]
         big = max(int(r["Grid_Size"]) for r in rows) if rows else 0
         rows = [r for r in rows if int(r["Grid_Size"]) == big]
         vals = [float(r["Counter_Value"]) for r in rows]
