@@ -1,4 +1,6 @@
 """SparseConvTensor container — same surface as the reference's spconv/structure.py:5-71."""
+import math
+
 import numpy as np
 import torch
 
@@ -87,4 +89,4 @@ class SparseConvTensor(object):
 
     @property
     def sparity(self):
-        return self.indices.shape[0] / np.prod(self.spatial_shape) / self.batch_size
+        return self.indices.shape[0] / math.prod(int(v) for v in self.spatial_shape) / self.batch_size   # python ints: called per layer
