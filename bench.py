@@ -52,6 +52,7 @@ def parse():
                     help="input-pipeline threads, each with its own HIP stream (measured: a second one adds nothing — launches from "
                          "several threads serialise in the runtime)")
     ap.add_argument("--step-times", action="store_true", help="diagnostic: percentiles of the host-side interval between steps (stderr)")
+    ap.add_argument("--lean-adamw", type=int, default=1, help="1: torch's fused AdamW kernels called on cached tensor lists (fv2p_harness/optim.py); 0: torch.optim.AdamW(fused=True)")
     ap.add_argument("--phases", action="store_true", help="diagnostic: host issue time and synchronised wall time per phase (stderr)")
     ap.add_argument("--pyprofile", action="store_true", help="cProfile the timed steps (host-overhead hunting; prints to stderr)")
     return ap.parse_args()
@@ -80,7 +81,9 @@ def build_step(args, device, rank, world):
             return out.features.square().mean()
 
     net = dist_utils.wrap_ddp(TrainStep(model), device, find_unused_parameters=False)   # every parameter is used every step
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.01, fused=True)  # one multi-tensor kernel per step
+    from fv2p_harness.optim import LeanAdamW
+    opt = LeanAdamW(model.parameters(), lr=1e-3, weight_decay=0.01) if device.type == "cuda" and args.lean_adamw else \
+        torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.01, fused=True)  # one multi-tensor kernel per step
     # a small pool of distinct batches, points resident in HBM; seeds differ per rank
     n_pool = 4
     pool = [[torch.from_numpy(synth.lidar_cloud(seed, args.points)).to(device) for seed in seeds]

@@ -105,3 +105,24 @@ def test_input_pipeline_thread_produces_the_inline_batches(gpu):
                 assert model(f, c, 2)[0].features.square().mean().item() == inline[i][2]
     finally:
         pre.close()
+
+
+def test_lean_adamw_equals_torch_fused_adamw(gpu):
+    """fv2p_harness.optim.LeanAdamW (the benchmark's optimiser): bit-identical parameters and state to
+    torch.optim.AdamW(fused=True) over several steps, including a step where one parameter has no gradient."""
+    from fv2p_harness.optim import LeanAdamW
+    torch.manual_seed(0)
+    ps_a = [torch.nn.Parameter(torch.randn(s, device=gpu)) for s in [(27, 16, 32), (32,), (64, 64), (5,)]]
+    ps_b = [torch.nn.Parameter(p.detach().clone()) for p in ps_a]
+    a, b = LeanAdamW(ps_a, lr=1e-2, weight_decay=0.05), torch.optim.AdamW(ps_b, lr=1e-2, weight_decay=0.05, fused=True)
+    for it in range(6):
+        for pa, pb in zip(ps_a, ps_b):
+            g = torch.randn_like(pa)
+            pa.grad, pb.grad = g.clone(), g.clone()
+        if it == 3:
+            ps_a[-1].grad = ps_b[-1].grad = None
+        a.step(), b.step()
+        a.zero_grad(set_to_none=True), b.zero_grad(set_to_none=True)
+    for pa, pb in zip(ps_a, ps_b):
+        assert torch.equal(pa, pb)
+        assert torch.equal(a.state[pa]["exp_avg_sq"], b.state[pb]["exp_avg_sq"]) and torch.equal(a.state[pa]["step"], b.state[pb]["step"])
