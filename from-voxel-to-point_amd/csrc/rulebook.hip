@@ -162,11 +162,12 @@ __global__ void rb_fill_tables(const int* __restrict__ ind, int n_in, int n_out,
 constexpr int kBmTile = 256;             // words per workgroup in the popcount passes: one per thread (a dense word is 32 serial steps)
 constexpr long long kBmMaxCells = 1ll << 28;
 
-__global__ void rb_mark_outputs(const int* __restrict__ ind, int n, RbGeom g, uint32_t* __restrict__ bitmap) {
+__global__ void rb_mark_outputs(const int* __restrict__ ind, int n, int batch, RbGeom g, uint32_t* __restrict__ bitmap) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int e = blockIdx.y;
   if (i >= n) return;
   const int4 c = reinterpret_cast<const int4*>(ind)[i];
+  if (static_cast<unsigned>(c.x) >= static_cast<unsigned>(batch)) return;   // a batch index outside the bitmap: the row takes no part
   const int in[3] = {c.y, c.z, c.w};
   int out[3], off;
   if (!enum_out(g, in, e, out, &off)) return;
@@ -217,12 +218,13 @@ __global__ __launch_bounds__(256) void rb_emit_outputs(const uint32_t* __restric
     } while (bits);
   }
 }
-__global__ void rb_fill_tables_bm(const int* __restrict__ ind, int n_in, int n_out, RbGeom g, const uint32_t* __restrict__ bitmap,
+__global__ void rb_fill_tables_bm(const int* __restrict__ ind, int n_in, int n_out, int batch, RbGeom g, const uint32_t* __restrict__ bitmap,
                                   const int* __restrict__ prefix, int* __restrict__ tab_in, int* __restrict__ tab_out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int e = blockIdx.y;
   if (i >= n_in) return;
   const int4 c = reinterpret_cast<const int4*>(ind)[i];
+  if (static_cast<unsigned>(c.x) >= static_cast<unsigned>(batch)) return;
   const int in[3] = {c.y, c.z, c.w};
   int out[3], off;
   if (!enum_out(g, in, e, out, &off)) return;
@@ -427,7 +429,7 @@ extern "C" int fv2p_rulebook_begin(const int* indices, int64_t n_in, int batch, 
     fill.add(b.bitmap, sizeof(uint32_t) * static_cast<size_t>(b.words), 0u);
     fill.add(total, sizeof(int) * 4, 0u);
     if (int rc = multi_fill(fill, stream)) return rc;
-    hipLaunchKernelGGL(rb_mark_outputs, dim3(static_cast<unsigned>(ceil_div(n_in, 256)), g.emax), dim3(256), 0, stream, indices, (int)n_in, g,
+    hipLaunchKernelGGL(rb_mark_outputs, dim3(static_cast<unsigned>(ceil_div(n_in, 256)), g.emax), dim3(256), 0, stream, indices, (int)n_in, batch, g,
                        b.bitmap);
     hipLaunchKernelGGL(rb_tile_popc, dim3(b.tiles), dim3(256), 0, stream, b.bitmap, b.words, b.sums);
     if (int rc = exclusive_scan_i32(b.sums, b.sums, b.tiles, total, b.aux, b.aux_bytes, stream)) return rc;
@@ -491,7 +493,7 @@ extern "C" int fv2p_rulebook_finish(const int* indices, int64_t n_in, int batch,
     if (n_out > 0) {
       hipLaunchKernelGGL(rb_emit_outputs, dim3(b.tiles), dim3(256), 0, stream, b.bitmap, b.words, b.sums, g, b.prefix, out_indices);
       hipLaunchKernelGGL(rb_fill_tables_bm, dim3(static_cast<unsigned>(ceil_div(n_in, 256)), g.emax), dim3(256), 0, stream, indices, (int)n_in,
-                         (int)n_out, g, b.bitmap, b.prefix, tab_in, tab_out);
+                         (int)n_out, batch, g, b.bitmap, b.prefix, tab_in, tab_out);
     }
     if (indice_num) {
       const unsigned cbk = static_cast<unsigned>(ceil_div(n_in, 1024) < 64 ? ceil_div(n_in, 1024) : 64);
