@@ -261,9 +261,10 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_k(const float* __restrict__ 
   }
 }
 
-constexpr int kBnPartials = kStatSlots;
+constexpr int kBnPartials = 64;
+static_assert(kStatSlots <= kBnPartials, "the fallback passes write their partials into the statistics slots");
 
-static int bn_geom(int64_t n, int c, bool vec, BnGeom* g) {
+static int bn_geom(int64_t n, int c, bool vec, BnGeom* g, int max_blocks = kBnPartials) {
   const int v = vec ? 4 : 1;
   g->n = n; g->c = c;
   g->tcols = static_cast<int>(ceil_div(c, v));
@@ -271,7 +272,7 @@ static int bn_geom(int64_t n, int c, bool vec, BnGeom* g) {
   g->rpp = 256 / g->tcols;
   // >= 8 rows per row lane per workgroup, at most kBnPartials workgroups (every apply workgroup re-folds the partials)
   int64_t nblk = ceil_div(n, static_cast<int64_t>(g->rpp) * 8);
-  if (nblk > kBnPartials) nblk = kBnPartials;
+  if (nblk > max_blocks) nblk = max_blocks;
   if (nblk < 1) nblk = 1;
   g->rows_per_block = ceil_div(n, nblk);
   g->nblk = static_cast<int>(ceil_div(n, g->rows_per_block));
@@ -329,7 +330,7 @@ extern "C" int fv2p_batchnorm_forward(const float* x, int64_t n, int c, float ep
 int fv2p::bn_column_sums(const float* x, int64_t n, int c, double* stats, hipStream_t stream) {
   const bool vec = (c % 4 == 0) && aligned16(x);
   BnGeom g;
-  FV2P_REQUIRE(bn_geom(n, c, vec, &g) == 0, FV2P_ELIMIT, "batchnorm: c=%d exceeds %d", c, vec ? kBnMaxC : 256);
+  FV2P_REQUIRE(bn_geom(n, c, vec, &g, kStatSlots) == 0, FV2P_ELIMIT, "batchnorm: c=%d exceeds %d", c, vec ? kBnMaxC : 256);
   if (vec) hipLaunchKernelGGL((bn_reduce_k<4, false>), dim3(g.nblk), dim3(256), 0, stream, x, nullptr, g, nullptr, nullptr, nullptr, nullptr, 0, stats);
   else hipLaunchKernelGGL((bn_reduce_k<1, false>), dim3(g.nblk), dim3(256), 0, stream, x, nullptr, g, nullptr, nullptr, nullptr, nullptr, 0, stats);
   FV2P_LAUNCH_CHECK();
@@ -341,7 +342,7 @@ int fv2p::bn_backward_sums(const float* x, const float* dy, int64_t n, int c, co
                            const float* beta, int relu, double* stats, hipStream_t stream) {
   const bool vec = (c % 4 == 0) && aligned16(x) && aligned16(dy);
   BnGeom g;
-  FV2P_REQUIRE(bn_geom(n, c, vec, &g) == 0, FV2P_ELIMIT, "batchnorm: c=%d exceeds %d", c, vec ? kBnMaxC : 256);
+  FV2P_REQUIRE(bn_geom(n, c, vec, &g, kStatSlots) == 0, FV2P_ELIMIT, "batchnorm: c=%d exceeds %d", c, vec ? kBnMaxC : 256);
   if (vec) hipLaunchKernelGGL((bn_reduce_k<4, true>), dim3(g.nblk), dim3(256), 0, stream, x, dy, g, mean, invstd, gamma, beta, relu, stats);
   else hipLaunchKernelGGL((bn_reduce_k<1, true>), dim3(g.nblk), dim3(256), 0, stream, x, dy, g, mean, invstd, gamma, beta, relu, stats);
   FV2P_LAUNCH_CHECK();
