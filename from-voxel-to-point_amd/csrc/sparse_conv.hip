@@ -37,6 +37,7 @@ struct ConvArgs {
   // backward-data conv whose result is the gradient of a BatchNorm(+ReLU) output: stats then receive that layer's
   // backward sums  (sum dz, sum dz * xhat), dz = dst * [y > 0], from the BatchNorm input bn_x (same shape as dst)
   const float* bn_x; const float* bn_mean; const float* bn_invstd; const float* bn_gamma; const float* bn_beta; int bn_relu;
+  const int* perm;                                   // optional row order: tile t owns destination rows perm[64t .. 64t+63]
 };
 
 // ---- BatchNorm statistics in the epilogue --------------------------------------------------------
@@ -46,8 +47,8 @@ struct ConvArgs {
 // atomics — fire and forget, the kernel boundary orders them before the consumer (bn_apply_fwd_k folds the slots like
 // the partials of bn_reduce_k).  vals[i][reg]: value stored to row row0 + 4 * (lane / 16) + reg, column col[i].
 template <int NV>
-__device__ __forceinline__ void tile_stats(const ConvArgs& a, const float (&vals)[NV][4], const int (&col)[NV], int row0) {
-  const int lane = threadIdx.x & 63, q = lane >> 4;
+__device__ __forceinline__ void tile_stats_rows(const ConvArgs& a, const float (&vals)[NV][4], const int (&col)[NV], const int (&rows)[4]) {
+  const int lane = threadIdx.x & 63, q = lane >> 4;   // rows[reg]: destination row of value reg, -1 past the end
   const int slot = (blockIdx.x * 4 + (threadIdx.x >> 6)) % kStatSlots;
   double* base = a.stats + static_cast<long long>(slot) * 2 * a.stats_ld;
 #pragma unroll
@@ -57,15 +58,15 @@ __device__ __forceinline__ void tile_stats(const ConvArgs& a, const float (&vals
     if (a.bn_x == nullptr) {
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        if (row0 + q * 4 + reg < a.n_dst) { const double v = vals[i][reg]; s1 += v; s2 += v * v; }
+        if (rows[reg] >= 0) { const double v = vals[i][reg]; s1 += v; s2 += v * v; }
       }
     } else if (live) {   // same arithmetic as bn_reduce_k<BWD> (batchnorm.hip)
       const float m = a.bn_mean[col[i]], is = a.bn_invstd[col[i]];
       const float ga = a.bn_gamma ? a.bn_gamma[col[i]] : 1.f, be = a.bn_beta ? a.bn_beta[col[i]] : 0.f;
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        const int row = row0 + q * 4 + reg;
-        if (row < a.n_dst) {
+        const int row = rows[reg];
+        if (row >= 0) {
           const float xhat = (a.bn_x[static_cast<long long>(row) * a.ld_dst + col[i]] - m) * is;
           const float y = xhat * ga + be;
           const float dz = (a.bn_relu && !(y > 0.f)) ? 0.f : vals[i][reg];
@@ -80,6 +81,14 @@ __device__ __forceinline__ void tile_stats(const ConvArgs& a, const float (&vals
       __hip_atomic_fetch_add(base + a.stats_ld + col[i], s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+}
+template <int NV>
+__device__ __forceinline__ void tile_stats(const ConvArgs& a, const float (&vals)[NV][4], const int (&col)[NV], int row0) {
+  const int q = (threadIdx.x & 63) >> 4;
+  int rows[4];
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) rows[reg] = (row0 + q * 4 + reg < a.n_dst) ? row0 + q * 4 + reg : -1;
+  tile_stats_rows<NV>(a, vals, col, rows);
 }
 
 // ---- B staging --------------------------------------------------------------------------------
@@ -586,6 +595,174 @@ __global__ __launch_bounds__(256) void conv_rows_dma(ConvArgs a) {
       for (int reg = 0; reg < 4; ++reg) vals[i][reg] = acc[i][reg] + b;
     }
     tile_stats<NB>(a, vals, cols, row0);
+  }
+}
+
+// ---- LDS-DMA variant for permuted rows: visits only the offsets its tile uses ----------------------------------------
+// Same data flow as conv_rows_dma, for launches that come with a row permutation (a.perm: tile t owns destination rows
+// perm[64t .. 64t+63]).  The backward-data conv of a strided layer is the case: an input voxel of a k=3, s=2 conv can
+// only reach the offsets the parity of its coordinates allows (1, 2, 4 or 8 of 27), so with the rows grouped by parity
+// class a tile uses a few offsets and the rest cost neither the weight DMA nor the barrier nor MFMAs on zero rows (in
+// flat-index order neighbouring rows alternate parity and every tile visits all 27 at 10 % row density).  The prologue
+// loads the tile's slice of the table into LDS ([kvol <= 32][64] ints) and ORs the mask of used offsets.  Every row's
+// sum still runs over ascending k: results are bit-identical to the unpermuted launch.
+template <int CINP, int NB, bool WT>
+__global__ __launch_bounds__(256) void conv_rows_act(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // 2 x W_k | table slice [32][64] | mask
+  constexpr int J = CINP / 16;
+  constexpr int WSZ = CINP * NB * 16;
+  constexpr int UNITS = WSZ / 4;
+  constexpr int R = (UNITS + 255) / 256;
+  constexpr int NCB = NB / 4;  // forward only
+  int* idx_lds = reinterpret_cast<int*>(lds + 2 * WSZ);
+  unsigned* mask_lds = reinterpret_cast<unsigned*>(idx_lds + 32 * 64);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 15, g = lane >> 4;
+  const int slot0 = xcd_major_tile(blockIdx.x, gridDim.x) * 64 + wave * 16;
+  const int my_slot = min(slot0 + r, a.n_dst - 1);
+  const int my_row = a.perm ? a.perm[my_slot] : my_slot;
+  if (threadIdx.x == 0) *mask_lds = 0u;
+  unsigned m = 0u;
+  {
+    const int* tab_me = a.tab + my_row;
+    for (int k = g; k < a.kvol; k += 4) {
+      const int v = tab_me[static_cast<long long>(a.flip ? (a.kvol - 1 - k) : k) * a.n_dst];
+      idx_lds[k * 64 + wave * 16 + r] = v;
+      if (v >= 0 && slot0 + r < a.n_dst) m |= 1u << k;
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) m |= __shfl_xor(m, d, 64);
+  }
+  __syncthreads();
+  if (lane == 0 && m) atomicOr(mask_lds, m);
+  f32x4 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  long long woff[R];
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    const int rest = u * 4 + wave;
+    if constexpr (!WT) {
+      const int cb = rest % (NCB > 0 ? NCB : 1), jt = rest / (NCB > 0 ? NCB : 1);
+      woff[u] = static_cast<long long>(16 * (jt >> 2) + 4 * g + (jt & 3)) * a.w_ld + 64 * cb + 4 * r;
+    } else {
+      const int nb = rest % NB, j = rest / NB;
+      woff[u] = static_cast<long long>(NB * r + nb) * a.w_ld + 16 * j + 4 * g;
+    }
+  }
+  auto issue_w = [&](int k, float* buf) {
+    const float* wk = a.w + static_cast<long long>(k) * a.w_kstride;
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      const int e0 = (u * 4 + wave) * 64;
+      if (UNITS % 256 == 0 || e0 < UNITS) glds16(wk + woff[u], buf + e0 * 4);
+    }
+  };
+  auto row_ptr = [&](int idx) -> const float* {
+    return idx >= 0 ? a.src + static_cast<long long>(idx) * a.ld_src + 4 * g : g_zero_row + 4 * g;
+  };
+  __syncthreads();
+  unsigned todo = __builtin_amdgcn_readfirstlane(*mask_lds);
+  if (todo) {
+    f32x4 a_cur[J], a_nxt[J];
+    int k = __ffs(static_cast<int>(todo)) - 1;
+    todo &= todo - 1;
+    int idx_cur = idx_lds[k * 64 + wave * 16 + r], idx_nxt = -1;
+    issue_w(k, lds);
+    gather_async<J>(a_cur, row_ptr(idx_cur));
+    wait_loads<J>(a_cur, idx_nxt);
+    __syncthreads();
+    for (int it = 0;; ++it) {
+      const float* wcur = lds + (it & 1) * WSZ;
+      const bool more = todo != 0u;   // uniform
+      if (more) {
+        k = __ffs(static_cast<int>(todo)) - 1;
+        todo &= todo - 1;
+        issue_w(k, lds + ((it + 1) & 1) * WSZ);
+        idx_nxt = idx_lds[k * 64 + wave * 16 + r];
+        gather_async<J>(a_nxt, row_ptr(idx_nxt));
+      }
+      if (__ballot(idx_cur >= 0) != 0ull) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          if constexpr (!WT) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              float4 bv[NCB > 0 ? NCB : 1];
+#pragma unroll
+              for (int cb = 0; cb < NCB; ++cb) bv[cb] = *reinterpret_cast<const float4*>(&wcur[(((j * 4 + t) * NCB + cb) * 64 + lane) * 4]);
+#pragma unroll
+              for (int cb = 0; cb < NCB; ++cb) {
+                acc[cb * 4 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j][t], bv[cb].x, acc[cb * 4 + 0], 0, 0, 0);
+                acc[cb * 4 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j][t], bv[cb].y, acc[cb * 4 + 1], 0, 0, 0);
+                acc[cb * 4 + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j][t], bv[cb].z, acc[cb * 4 + 2], 0, 0, 0);
+                acc[cb * 4 + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j][t], bv[cb].w, acc[cb * 4 + 3], 0, 0, 0);
+              }
+            }
+          } else {
+            float4 bv[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) bv[nb] = *reinterpret_cast<const float4*>(&wcur[((j * NB + nb) * 64 + lane) * 4]);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j][0], bv[nb].x, acc[nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j][1], bv[nb].y, acc[nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j][2], bv[nb].z, acc[nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[j][3], bv[nb].w, acc[nb], 0, 0, 0);
+          }
+        }
+      }
+      if (!more) break;
+      wait_loads<J>(a_nxt, idx_nxt);
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < J; ++j) a_cur[j] = a_nxt[j];
+      idx_cur = idx_nxt;
+    }
+  }
+  // epilogue: accumulator i of lane (q, n) is output column  WT ? NB*n + i : 64*(i/4) + 4*n + i%4; rows through perm
+  const int q = lane >> 4, n = lane & 15;
+  int rows[4];
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int slot = slot0 + q * 4 + reg;
+    rows[reg] = slot < a.n_dst ? (a.perm ? a.perm[slot] : slot) : -1;
+  }
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    if (rows[reg] < 0) continue;
+    float* prow = a.dst + static_cast<long long>(rows[reg]) * a.ld_dst;
+    if constexpr (NB % 4 == 0) {
+#pragma unroll
+      for (int v = 0; v < NB / 4; ++v) {
+        const int col = WT ? (NB * n + 4 * v) : (64 * v + 4 * n);
+        float4 o = make_float4(acc[4 * v][reg], acc[4 * v + 1][reg], acc[4 * v + 2][reg], acc[4 * v + 3][reg]);
+        if (a.bias) { const float4 b = *reinterpret_cast<const float4*>(a.bias + col); o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w; }
+        float4* p = reinterpret_cast<float4*>(prow + col);
+        if (a.accumulate) { const float4 old = *p; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+        *p = o;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int col = NB * n + i;  // WT only (forward requires NB % 4 == 0)
+        const float v = acc[i][reg] + (a.bias ? a.bias[col] : 0.f);
+        prow[col] = a.accumulate ? (prow[col] + v) : v;
+      }
+    }
+  }
+  if (a.stats) {
+    float vals[NB][4];
+    int cols[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      cols[i] = (NB % 4 == 0) ? (WT ? (NB * n + i) : (64 * (i / 4) + 4 * n + (i % 4))) : (NB * n + i);
+      const float b = a.bias ? a.bias[cols[i]] : 0.f;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) vals[i][reg] = acc[i][reg] + b;
+    }
+    tile_stats_rows<NB>(a, vals, cols, rows);
   }
 }
 
@@ -1154,6 +1331,11 @@ static void launch_vec(const ConvArgs& a, hipStream_t s) {
     const bool whole = a.c_src == CINP && a.c_dst == NB * 16 && (a.w_ld & 3) == 0 && (a.w_kstride & 3) == 0 &&
                        (reinterpret_cast<uintptr_t>(a.w) & 15) == 0 && (a.ld_dst & 3) == 0 &&
                        (reinterpret_cast<uintptr_t>(a.dst) & 15) == 0 && (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0);
+    constexpr size_t act_lds = 2 * CINP * NB * 16 * sizeof(float) + 32 * 64 * sizeof(int) + 16;
+    if (a.perm && impl == 0 && whole && a.kvol > 1 && a.kvol <= 32 && act_lds <= 64 * 1024) {
+      hipLaunchKernelGGL((conv_rows_act<CINP, NB, WT>), dim3(blocks), dim3(256), act_lds, s, a);
+      return;
+    }
     if (impl == 0 && whole && a.kvol > 1) {
       ConvArgs b = a; b.trace = g_conv_trace;
       hipLaunchKernelGGL((conv_rows_dma<CINP, NB, WT>), dim3(blocks), dim3(256), 2 * CINP * NB * 16 * sizeof(float), s, b);
@@ -1230,7 +1412,7 @@ extern "C" int fv2p_sparse_conv_set_impl(int impl) {
 
 static int conv_rows_impl(const float* src, int64_t n_src, int c_src, const float* weight, int kvol, const int* tab, int64_t n_dst, int c_dst,
                           int flip_k, int transpose_w, const float* bias, float* dst, double* stats, hipStream_t stream,
-                          const ConvArgs* bn = nullptr) {
+                          const ConvArgs* bn = nullptr, const int* perm = nullptr) {
   FV2P_REQUIRE(c_src >= 1 && c_dst >= 1 && kvol >= 1 && n_dst >= 0 && n_src >= 0, FV2P_EINVAL, "sparse_conv_rows: bad sizes");
   if (n_dst == 0) return 0;
   FV2P_REQUIRE(weight && tab && dst && (src || n_src == 0), FV2P_EINVAL, "sparse_conv_rows: null pointer");
@@ -1246,6 +1428,7 @@ static int conv_rows_impl(const float* src, int64_t n_src, int c_src, const floa
       a.trace = nullptr;
       a.stats = stats ? stats + d0 : nullptr; a.stats_ld = c_dst;
       a.bn_x = nullptr; a.bn_mean = a.bn_invstd = a.bn_gamma = a.bn_beta = nullptr; a.bn_relu = 0;
+      a.perm = perm;   // honoured by the LDS-DMA tile for permuted rows, ignored (plain row order, same result) by the others
       if (bn && stats) {   // per-column pointers move with the column block, bn_x is addressed like dst (row * ld_dst + col)
         a.bn_x = bn->bn_x + d0; a.bn_mean = bn->bn_mean + d0; a.bn_invstd = bn->bn_invstd + d0;
         a.bn_gamma = bn->bn_gamma ? bn->bn_gamma + d0 : nullptr; a.bn_beta = bn->bn_beta ? bn->bn_beta + d0 : nullptr; a.bn_relu = bn->bn_relu;
@@ -1271,6 +1454,13 @@ extern "C" int fv2p_sparse_conv_rows(const float* src, int64_t n_src, int c_src,
                         static_cast<hipStream_t>(stream_));
 }
 
+extern "C" int fv2p_sparse_conv_rows_perm(const float* src, int64_t n_src, int c_src, const float* weight, int kvol, const int* tab,
+                                          int64_t n_dst, int c_dst, int flip_k, int transpose_w, const float* bias, float* dst, const int* perm,
+                                          fv2p_stream_t stream_) {
+  return conv_rows_impl(src, n_src, c_src, weight, kvol, tab, n_dst, c_dst, flip_k, transpose_w, bias, dst, nullptr,
+                        static_cast<hipStream_t>(stream_), nullptr, perm);
+}
+
 extern "C" int fv2p_sparse_conv_stat_slots(void) { return kStatSlots; }
 
 extern "C" int fv2p_sparse_conv_rows_stats(const float* src, int64_t n_src, int c_src, const float* weight, int kvol, const int* tab,
@@ -1290,14 +1480,14 @@ extern "C" int fv2p_sparse_conv_rows_stats(const float* src, int64_t n_src, int 
 extern "C" int fv2p_sparse_conv_rows_bnbwd(const float* src, int64_t n_src, int c_src, const float* weight, int kvol, const int* tab,
                                            int64_t n_dst, int c_dst, int flip_k, int transpose_w, float* dst, const float* bn_x,
                                            const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_beta, int relu,
-                                           double* stats, fv2p_stream_t stream_) {
+                                           double* stats, const int* perm, fv2p_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   FV2P_REQUIRE(stats && bn_x && bn_mean && bn_invstd, FV2P_EINVAL, "sparse_conv_rows_bnbwd: null pointer");
   const bool fused = c_src <= 128 && conv_impl() != 2 && n_dst > 0;   // as in fv2p_sparse_conv_rows_stats
   ConvArgs bn;
   bn.bn_x = bn_x; bn.bn_mean = bn_mean; bn.bn_invstd = bn_invstd; bn.bn_gamma = bn_gamma; bn.bn_beta = bn_beta; bn.bn_relu = relu;
   if (int rc = conv_rows_impl(src, n_src, c_src, weight, kvol, tab, n_dst, c_dst, flip_k, transpose_w, nullptr, dst, fused ? stats : nullptr, stream,
-                              fused ? &bn : nullptr))
+                              fused ? &bn : nullptr, perm))
     return rc;
   if (!fused && n_dst > 0) return bn_backward_sums(bn_x, dst, n_dst, c_dst, bn_mean, bn_invstd, bn_gamma, bn_beta, relu, stats, stream);
   return 0;

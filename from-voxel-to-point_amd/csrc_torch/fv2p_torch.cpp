@@ -257,7 +257,7 @@ struct SparseConvFn : public torch::autograd::Function<SparseConvFn> {
   static at::Tensor forward(AutogradContext* ctx, const at::Tensor& features_, const at::Tensor& weight_, const at::Tensor& tab_f,
                             int64_t flip_f, const at::Tensor& tab_b, int64_t flip_b, int64_t n_out, int64_t centre,
                             const c10::optional<at::Tensor>& pairs, const c10::optional<at::Tensor>& pair_num, int64_t side_src,
-                            const c10::optional<at::Tensor>& stats) {
+                            const c10::optional<at::Tensor>& stats, const c10::optional<at::Tensor>& perm_b) {
     require_f32_cuda(features_, "features");
     require_f32_cuda(weight_, "weight");
     const at::Tensor features = features_.contiguous(), weight = weight_.contiguous();
@@ -278,7 +278,8 @@ struct SparseConvFn : public torch::autograd::Function<SparseConvFn> {
                                   nullptr, out.data_ptr<float>(), stream),
             "fv2p_sparse_conv_rows");
     const bool have_pairs = pairs.has_value() && pairs->defined() && pair_num.has_value() && pair_num->defined();
-    ctx->save_for_backward({features, weight, tab_f, tab_b, have_pairs ? *pairs : at::Tensor(), have_pairs ? *pair_num : at::Tensor()});
+    ctx->save_for_backward({features, weight, tab_f, tab_b, have_pairs ? *pairs : at::Tensor(), have_pairs ? *pair_num : at::Tensor(),
+                            (perm_b.has_value() && perm_b->defined()) ? *perm_b : at::Tensor()});
     ctx->saved_data["side_src"] = side_src;
     ctx->saved_data["flip_f"] = flip_f;
     ctx->saved_data["flip_b"] = flip_b;
@@ -293,6 +294,7 @@ struct SparseConvFn : public torch::autograd::Function<SparseConvFn> {
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
     const auto saved = ctx->get_saved_variables();
     const at::Tensor &features = saved[0], &weight = saved[1], &tab_f = saved[2], &tab_b = saved[3], &pairs = saved[4], &pair_num = saved[5];
+    const int* perm_b = (saved[6].defined() && saved[6].numel() == features.size(0)) ? saved[6].data_ptr<int>() : nullptr;
     const at::Tensor g = grads[0].contiguous();
     const int64_t cin = weight.size(-2), cout = weight.size(-1);
     const int64_t kvol = weight.numel() / (cin * cout);
@@ -329,7 +331,7 @@ struct SparseConvFn : public torch::autograd::Function<SparseConvFn> {
                                               tab_b.data_ptr<int>(), features.size(0), static_cast<int>(cin), flip_b, 1, din.data_ptr<float>(),
                                               bx.data_ptr<float>(), bmean.data_ptr<float>(), binv.data_ptr<float>(),
                                               bw.defined() ? bw.data_ptr<float>() : nullptr, bb.defined() ? bb.data_ptr<float>() : nullptr,
-                                              bctx.saved_data["relu"].toBool() ? 1 : 0, ring.buf[b].data_ptr<double>(), stream),
+                                              bctx.saved_data["relu"].toBool() ? 1 : 0, ring.buf[b].data_ptr<double>(), perm_b, stream),
                   "fv2p_sparse_conv_rows_bnbwd");
             ring.dirty[b] = static_cast<int64_t>(fv2p_sparse_conv_stat_slots()) * 2 * cin;
             ring.unread[b] = true;
@@ -342,8 +344,9 @@ struct SparseConvFn : public torch::autograd::Function<SparseConvFn> {
         }
       }
       if (!fused)
-        check(fv2p_sparse_conv_rows(g.data_ptr<float>(), g.size(0), static_cast<int>(cout), weight.data_ptr<float>(), static_cast<int>(kvol),
-                                    tab_b.data_ptr<int>(), features.size(0), static_cast<int>(cin), flip_b, 1, nullptr, din.data_ptr<float>(), stream),
+        check(fv2p_sparse_conv_rows_perm(g.data_ptr<float>(), g.size(0), static_cast<int>(cout), weight.data_ptr<float>(), static_cast<int>(kvol),
+                                         tab_b.data_ptr<int>(), features.size(0), static_cast<int>(cin), flip_b, 1, nullptr, din.data_ptr<float>(),
+                                         perm_b, stream),
               "fv2p_sparse_conv_rows (backward data)");
     }
     if (ctx->needs_input_grad(1)) {
@@ -379,14 +382,15 @@ struct SparseConvFn : public torch::autograd::Function<SparseConvFn> {
       TORCH_CHECK(hipStreamWaitEvent(static_cast<hipStream_t>(stream), side->join, 0) == hipSuccess, "hipStreamWaitEvent failed");
     }
     return {din, dw, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
-            at::Tensor()};
+            at::Tensor(), at::Tensor()};
   }
 };
 
 at::Tensor sparse_conv(const at::Tensor& features, const at::Tensor& weight, const at::Tensor& tab_f, int64_t flip_f, const at::Tensor& tab_b,
                        int64_t flip_b, int64_t n_out, int64_t centre, const c10::optional<at::Tensor>& pairs,
-                       const c10::optional<at::Tensor>& pair_num, int64_t side_src) {
-  return SparseConvFn::apply(features, weight, tab_f, flip_f, tab_b, flip_b, n_out, centre, pairs, pair_num, side_src, c10::optional<at::Tensor>());
+                       const c10::optional<at::Tensor>& pair_num, int64_t side_src, const c10::optional<at::Tensor>& perm_b) {
+  return SparseConvFn::apply(features, weight, tab_f, flip_f, tab_b, flip_b, n_out, centre, pairs, pair_num, side_src, c10::optional<at::Tensor>(),
+                             perm_b);
 }
 
 at::Tensor batch_norm_relu(const at::Tensor& x, const c10::optional<at::Tensor>& weight, const c10::optional<at::Tensor>& bias,
@@ -402,7 +406,8 @@ at::Tensor sparse_conv_bn_relu(const at::Tensor& features, const at::Tensor& wei
                                const c10::optional<at::Tensor>& pair_num, int64_t side_src, const c10::optional<at::Tensor>& conv_bias,
                                const c10::optional<at::Tensor>& bn_weight, const c10::optional<at::Tensor>& bn_bias,
                                const c10::optional<at::Tensor>& running_mean, const c10::optional<at::Tensor>& running_var,
-                               const c10::optional<at::Tensor>& num_batches_tracked, bool training, double momentum, double eps, bool relu) {
+                               const c10::optional<at::Tensor>& num_batches_tracked, bool training, double momentum, double eps, bool relu,
+                               const c10::optional<at::Tensor>& perm_b) {
   if (n_out < 2 && training) return at::Tensor();   // torch raises for one value per channel: let the caller run the module
   const bool has_bias = conv_bias.has_value() && conv_bias->defined();
   const bool batch_stats = training || !(running_mean.has_value() && running_mean->defined());
@@ -412,7 +417,7 @@ at::Tensor sparse_conv_bn_relu(const at::Tensor& features, const at::Tensor& wei
     StatRing& ring = stat_ring(features, cur_stream(features));
     const int cur = ring.cur, other = 1 - cur;
     at::Tensor y = SparseConvFn::apply(features, weight, tab_f, flip_f, tab_b, flip_b, n_out, centre, pairs, pair_num, side_src,
-                                       c10::optional<at::Tensor>(ring.buf[cur]));
+                                       c10::optional<at::Tensor>(ring.buf[cur]), perm_b);
     ring.dirty[cur] = static_cast<int64_t>(fv2p_sparse_conv_stat_slots()) * 2 * cout;
     at::Tensor out = BnReluFn::apply(y, bn_weight, bn_bias, running_mean, running_var, num_batches_tracked, training, momentum, eps, relu,
                                      c10::optional<at::Tensor>(ring.buf[cur]), c10::optional<at::Tensor>(ring.buf[other]), ring.dirty[other]);
@@ -420,7 +425,8 @@ at::Tensor sparse_conv_bn_relu(const at::Tensor& features, const at::Tensor& wei
     ring.cur = other;
     return out;
   }
-  at::Tensor y = SparseConvFn::apply(features, weight, tab_f, flip_f, tab_b, flip_b, n_out, centre, pairs, pair_num, side_src, c10::optional<at::Tensor>());
+  at::Tensor y = SparseConvFn::apply(features, weight, tab_f, flip_f, tab_b, flip_b, n_out, centre, pairs, pair_num, side_src, c10::optional<at::Tensor>(),
+                                     perm_b);
   if (has_bias) y = y + *conv_bias;
   return BnReluFn::apply(y, bn_weight, bn_bias, running_mean, running_var, num_batches_tracked, training, momentum, eps, relu,
                          c10::optional<at::Tensor>(), c10::optional<at::Tensor>(), 0);
@@ -566,7 +572,17 @@ std::vector<std::vector<at::Tensor>> build_rulebook_chain(const at::Tensor& root
                                 static_cast<size_t>(pws.numel()), stream),
             "fv2p_rulebook_pairs");
     }
-    out.push_back({subm ? at::Tensor() : outids, tab_in, tab_out, pairs, pnum});
+    // strided conv: input rows grouped by parity class, the tile order of its backward-data conv (fv2p_rulebook_class_perm)
+    at::Tensor perm;
+    if (!subm && !transpose && n_in > 0 && stride[0] * stride[1] * stride[2] > 1 && stride[0] <= 2 && stride[1] <= 2 && stride[2] <= 2 &&
+        dilation[0] == 1 && dilation[1] == 1 && dilation[2] == 1) {
+      perm = at::empty({n_in}, iopt);
+      at::Tensor cws = workspace(fv2p_rulebook_class_perm_ws_bytes(n_in), root, stream);
+      check(fv2p_rulebook_class_perm(ind.data_ptr<int>(), n_in, stride, padding, perm.data_ptr<int>(), cws.data_ptr(), static_cast<size_t>(cws.numel()),
+                                     stream),
+            "fv2p_rulebook_class_perm");
+    }
+    out.push_back({subm ? at::Tensor() : outids, tab_in, tab_out, pairs, pnum, perm});
     if (subm) out.back()[0] = at::Tensor();
   }
   return out;

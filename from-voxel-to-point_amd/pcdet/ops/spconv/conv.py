@@ -164,7 +164,8 @@ def _conv_bn_relu(self, features, rb, n_out, post, weight=None):
     out = ext.sparse_conv_bn_relu(features, weight, tab_f, flip_f, tab_b, flip_b, n_out, centre, rb._wpairs if have else None,
                                   rb._num if have else None, 1 if self.inverse else 0, self.bias, bn.weight, bn.bias, bn.running_mean,
                                   bn.running_var, bn.num_batches_tracked, bn.training,
-                                  -1.0 if bn.momentum is None else float(bn.momentum), float(bn.eps), relu is not None)
+                                  -1.0 if bn.momentum is None else float(bn.momentum), float(bn.eps), relu is not None,
+                                  None if self.inverse else getattr(rb, "_perm_in", None))
     return out
 
 

@@ -52,6 +52,7 @@ class Rulebook(object):
         self.n_in, self.n_out = int(indices.shape[0]), int(outids.shape[0])
         self._pairs = None
         self._wpairs = None   # compacted pair lists for the weight gradient (== _pairs once that exists)
+        self._perm_in = None  # strided conv: input rows grouped by parity class (tile order of the backward-data conv)
 
     # -- tables as the kernels want them: (table, flip_k)
     def out_table(self):

@@ -14,6 +14,8 @@ The cache lookup in SparseConvolution.forward stays what it is in the reference 
 `indice_key` reuses the rulebook.  A prefetched entry whose geometry differs from the module asking for it, or whose
 input rows are not the tensor's, is ignored and rebuilt, so a stale recipe costs time, never correctness.
 """
+import os
+
 import torch
 
 import fv2p_native as _nat
@@ -86,13 +88,14 @@ def _build_chain(ext, recipe, root, batch_size, pair_lists):
     with _nat.device_guard(root.device):
         res = ext.build_rulebook_chain(root, int(batch_size), specs)
     out = {}
-    for (key, src, shape, geom), (outids, tab_in, tab_out, pairs, num), out_shape in zip(recipe, res, shapes):
+    for (key, src, shape, geom), (outids, tab_in, tab_out, pairs, num, perm), out_shape in zip(recipe, res, shapes):
         ind = root if src is None else out[src].outids
         subm = geom[5]
         rb = ops.Rulebook(ind if subm else outids, ind, tab_in, tab_out, num, shape, int(tab_in.shape[0]), bool(subm))
         rb.out_spatial_shape = out_shape
         rb.geom, rb.batch_size, rb.prefetched = geom, int(batch_size), True
         rb._wpairs = pairs
+        rb._perm_in = perm if os.environ.get("FV2P_DX_PERM", "1") != "0" else None   # strided conv: input rows by parity class = tile order of its backward-data conv
         out[key] = rb
     return out
 

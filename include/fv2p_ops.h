@@ -96,6 +96,11 @@ int fv2p_rulebook_finish(const int* indices, int64_t n_in, int batch, const int 
                          const int dilation[3], int subm, int transpose, int64_t n_out, int* out_indices,
                          int* tab_in, int* tab_out, int* indice_num, void* ws, size_t ws_bytes,
                          fv2p_stream_t stream);
+/* Rows [n,4] (b,z,y,x) ordered by the residue class of (coordinate + padding) mod stride, stable inside a class:
+ * input rows of one class of a strided conv reach the same few kernel offsets.  Strides 1 or 2. */
+size_t fv2p_rulebook_class_perm_ws_bytes(int64_t n);
+int fv2p_rulebook_class_perm(const int* indices, int64_t n, const int stride[3], const int padding[3], int* perm,
+                             void* ws, size_t ws_bytes, fv2p_stream_t stream);
 int fv2p_rulebook_count(const int* tab_in, int64_t n_in, int kvol, int* indice_num, fv2p_stream_t stream);
 /* Reference-format pair lists indicePairs [K,2,n_in] from tab_in; within one offset pairs are ordered by ascending
  * input row (the CPU reference's order, geometry.h:281-295; the GPU reference's slot order is atomic-order).
@@ -147,7 +152,14 @@ int fv2p_sparse_conv_rows_stats(const float* src, int64_t n_src, int c_src, cons
 int fv2p_sparse_conv_rows_bnbwd(const float* src, int64_t n_src, int c_src, const float* weight, int kvol,
                                 const int* tab, int64_t n_dst, int c_dst, int flip_k, int transpose_w, float* dst,
                                 const float* bn_x, const float* bn_mean, const float* bn_invstd, const float* bn_gamma,
-                                const float* bn_beta, int relu, double* stats, fv2p_stream_t stream);
+                                const float* bn_beta, int relu, double* stats, const int* perm, fv2p_stream_t stream);
+/* fv2p_sparse_conv_rows with a row order: perm [n_dst] (NULL = identity) says which destination rows share a 64-row
+ * tile; every row's sum is unchanged (bit-identical results), only the work per tile changes — a tile visits just the
+ * kernel offsets its rows use.  Meant for the backward-data conv of strided layers with fv2p_rulebook_class_perm's
+ * order (also accepted by fv2p_sparse_conv_rows_bnbwd). */
+int fv2p_sparse_conv_rows_perm(const float* src, int64_t n_src, int c_src, const float* weight, int kvol,
+                               const int* tab, int64_t n_dst, int c_dst, int flip_k, int transpose_w,
+                               const float* bias, float* dst, const int* perm, fv2p_stream_t stream);
 /* dW_k[c_src][c_dst] = sum_r src[tab[k][r],:]^T grad[r,:]   (dweight [K][c_src][c_dst], fully written here).
  *   forward conv's dW : src=features, grad=dOut [n_out,Cout], tab=tab_out, n_dst=n_out.
  * Per-chunk partial tiles go through the workspace and are summed in a fixed order (deterministic, no atomics).

@@ -4,6 +4,8 @@ Oracles: (1) oracle.indice_conv / indice_conv_backward — the reference's gathe
 torch CPU ops on the oracle rulebook; (2) torch.nn.functional.conv3d on the densified tensor (the upstream
 spconv test idea that spconv/test_utils.py:144-193 was written for) — independent of any rulebook code.
 Tolerance (north_star): 1e-4 relative for float features, stated per assert below."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -562,10 +564,52 @@ def test_backward_data_conv_leaves_the_batchnorm_backward_sums(gpu):
             dst = torch.empty_like(ref)
             stats = torch.zeros((slots, 2, cin), dtype=torch.float64, device=gpu)
             fv2p_native.call("fv2p_sparse_conv_rows_bnbwd", g, n, cout, w, 27, tab, n, cin, int(flip), 1, dst, bn_x, mean, invstd, gamma, beta, relu,
-                             stats, fv2p_native.stream())
+                             stats, None, fv2p_native.stream())
             assert torch.equal(dst, ref), (cin, cout)
             xhat = (bn_x - mean) * invstd                       # fp32, as the kernel
             y = xhat * gamma + beta
             dz = torch.where(y > 0, ref, torch.zeros_like(ref)) if relu else ref
             want = torch.stack([dz.double().sum(0), (dz.double() * xhat.double()).sum(0)]).cpu().numpy()
             assert np.allclose(stats.sum(0).cpu().numpy(), want, rtol=1e-9, atol=1e-7), (cin, cout, relu)
+
+
+def test_backward_data_of_strided_conv_with_parity_ordered_tiles(gpu):
+    """fv2p_rulebook_class_perm + fv2p_sparse_conv_rows_perm / _bnbwd(perm): the permutation is a stable grouping of
+    the input rows by (coordinate + padding) mod stride, and the backward-data conv that takes it (tiles visit only the
+    offsets their rows use) returns bit-identical rows and the same BatchNorm sums as the launch in plain row order."""
+    import fv2p_native
+    slots = int(fv2p_native.lib().fv2p_sparse_conv_stat_slots())
+    batch, shape = 2, [11, 40, 36]
+    for cin, cout, stride, pad in [(32, 64, (2, 2, 2), (1, 1, 1)), (16, 32, (2, 2, 2), (0, 1, 1)), (64, 64, (2, 1, 1), (0, 0, 0)), (64, 128, (2, 2, 2), (1, 1, 1))]:
+        ksize = (3, 1, 1) if stride == (2, 1, 1) else (3, 3, 3)
+        kvol = int(np.prod(ksize))
+        ind, feats, x = make_input(cin + cout, batch, shape, 5000, cin, gpu)
+        rb = ops.build_rulebook(x.indices, batch, shape, ksize, stride, pad, 1, 0, False)
+        n, n_out = x.features.shape[0], rb.outids.shape[0]
+        perm = torch.empty(n, dtype=torch.int32, device=gpu)
+        arr = lambda v: (ctypes.c_int * 3)(*v)
+        ws = fv2p_native.workspace(int(fv2p_native.lib().fv2p_rulebook_class_perm_ws_bytes(n)), x.indices.device)
+        fv2p_native.call("fv2p_rulebook_class_perm", x.indices, n, arr(stride), arr(pad), perm, ws, ws.numel(), fv2p_native.stream())
+        cls = ((x.indices[:, 1:].cpu().numpy() + np.array(pad)) % np.array(stride)) @ np.array([stride[1] * stride[2], stride[2], 1])
+        want = np.argsort(cls, kind="stable")
+        assert np.array_equal(perm.cpu().numpy(), want)
+        tab, flip = rb.in_table()
+        rng = np.random.default_rng(cout)
+        w = torch.from_numpy(rng.standard_normal((kvol, cin, cout)).astype(np.float32) * 0.1).to(gpu)
+        g = torch.from_numpy(rng.standard_normal((n_out, cout)).astype(np.float32)).to(gpu)
+        ref = torch.empty((n, cin), device=gpu)
+        fv2p_native.call("fv2p_sparse_conv_rows", g, n_out, cout, w, kvol, tab, n, cin, int(flip), 1, None, ref, fv2p_native.stream())
+        dst = torch.empty_like(ref)
+        fv2p_native.call("fv2p_sparse_conv_rows_perm", g, n_out, cout, w, kvol, tab, n, cin, int(flip), 1, None, dst, perm, fv2p_native.stream())
+        assert torch.equal(dst, ref), (cin, cout, stride)
+        bn_x = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32) * 2 + 1).to(gpu)
+        par = [torch.from_numpy(rng.uniform(0.3, 1.5, cin).astype(np.float32)).to(gpu) for _ in range(4)]
+        outs = []
+        for p in (None, perm):
+            dst = torch.empty_like(ref)
+            stats = torch.zeros((slots, 2, cin), dtype=torch.float64, device=gpu)
+            fv2p_native.call("fv2p_sparse_conv_rows_bnbwd", g, n_out, cout, w, kvol, tab, n, cin, int(flip), 1, dst, bn_x, par[0], par[1], par[2], par[3], 1,
+                             stats, p, fv2p_native.stream())
+            assert torch.equal(dst, ref)
+            outs.append(stats.sum(0).cpu().numpy())
+        assert np.allclose(outs[0], outs[1], rtol=1e-11, atol=1e-9)

@@ -171,6 +171,21 @@ def conv(only=None):
         w3 = w.reshape(-1, cin, cout)
         tab_b, flip_b = rb.in_table()
         t_dx = timeit(lambda: ops._conv_rows(g, w3, tab_b, flip_b, f.shape[0], cin, True))
+        extra = ""
+        if not mod.subm and not mod.transposed:   # strided conv: backward-data with the rows grouped by parity class
+            import ctypes
+            import fv2p_native
+            arr = lambda v: (ctypes.c_int * 3)(*v)
+            perm = torch.empty(f.shape[0], dtype=torch.int32, device=dev)
+            ind = rb.indices
+            pws = fv2p_native.workspace(int(fv2p_native.lib().fv2p_rulebook_class_perm_ws_bytes(ind.shape[0])), ind.device)
+            fv2p_native.call("fv2p_rulebook_class_perm", ind, ind.shape[0], arr(mod.stride), arr(mod.padding), perm, pws, pws.numel(), fv2p_native.stream())
+            din = torch.empty((f.shape[0], cin), device=dev)
+            t_dxp = timeit(lambda: fv2p_native.call("fv2p_sparse_conv_rows_perm", g, g.shape[0], cout, w3, w3.shape[0], tab_b, f.shape[0], cin,
+                                                    int(flip_b), 1, None, din, perm, fv2p_native.stream()))
+            t_perm = timeit(lambda: fv2p_native.call("fv2p_rulebook_class_perm", ind, ind.shape[0], arr(mod.stride), arr(mod.padding), perm, pws,
+                                                     pws.numel(), fv2p_native.stream()))
+            extra = f"   dX parity-ordered {t_dxp:6.1f} us (perm build {t_perm:5.1f} us)"
         pairs_saved, rb._wpairs = rb._wpairs, None     # table-based weight gradient
         t_all = timeit(lambda: ops.indice_conv_backward(f, w, g, rb, None, False, mod.subm))
         rb._wpairs = pairs_saved
@@ -178,7 +193,7 @@ def conv(only=None):
         t_allp = timeit(lambda: ops.indice_conv_backward(f, w, g, rb, None, False, mod.subm))
         fl = 2.0 * p * cin * cout
         name = f"{'subm' if mod.subm else 'conv'} {cin}->{cout} {mod.indice_key}"
-        print(f"{name:34s} {f.shape[0]:6d} {n_out:6d} {p:8d} {t_f:8.1f} {fl / t_f / 1e6:6.1f} {t_dx:8.1f} {t_all - t_dx:8.1f} {fl / max(t_all - t_dx, 1e-3) / 1e6:6.1f} {t_allp - t_dx:8.1f} {fl / max(t_allp - t_dx, 1e-3) / 1e6:6.1f}")
+        print(f"{name:34s} {f.shape[0]:6d} {n_out:6d} {p:8d} {t_f:8.1f} {fl / t_f / 1e6:6.1f} {t_dx:8.1f} {t_all - t_dx:8.1f} {fl / max(t_all - t_dx, 1e-3) / 1e6:6.1f} {t_allp - t_dx:8.1f} {fl / max(t_allp - t_dx, 1e-3) / 1e6:6.1f}{extra}")
     # rulebook build timings
     x = torch.cat(coords)
     for subm, k, s, p in [(True, 3, 1, 1), (False, 3, 2, 1)]:
