@@ -558,7 +558,7 @@ __global__ __launch_bounds__(256) void rb_class_hist(const int* __restrict__ ind
 __global__ __launch_bounds__(256) void rb_class_scatter(const int* __restrict__ ind, int n, int sy, int sx, int mz, int my, int mx, int pz, int py,
                                                         int px, const int* __restrict__ hist, int nblk, int* __restrict__ perm) {
   __shared__ int part[256][2];          // per thread: rows of class q in all / in earlier workgroups
-  __shared__ int base[kPermClasses], wcount[4][kPermClasses];
+  __shared__ int base[kPermClasses], wcount[4][kPermClasses], tot[2][kPermClasses];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   // thread (q = t % 8, s = t / 8) sums hist[b][q] over b = s, s + 32, ...
   const int q = t & 7, s = t >> 3;
@@ -570,13 +570,17 @@ __global__ __launch_bounds__(256) void rb_class_scatter(const int* __restrict__ 
   }
   part[t][0] = all; part[t][1] = before;
   __syncthreads();
+  if (t < 2 * kPermClasses) {   // 16 threads fold the 32 slices of (class, all | before), then 8 take the prefix over the classes
+    const int q2 = t & 7, which = t >> 3;
+    int v = 0;
+    for (int s2 = 0; s2 < 32; ++s2) v += part[s2 * 8 + q2][which];
+    tot[which][q2] = v;
+  }
+  __syncthreads();
   if (t < kPermClasses) {
-    int lower = 0, mine_before = 0;
-    for (int s2 = 0; s2 < 32; ++s2) {
-      mine_before += part[s2 * 8 + t][1];
-      for (int q2 = 0; q2 < t; ++q2) lower += part[s2 * 8 + q2][0];
-    }
-    base[t] = lower + mine_before;
+    int lower = 0;
+    for (int q2 = 0; q2 < t; ++q2) lower += tot[0][q2];
+    base[t] = lower + tot[1][t];
   }
   const int i = blockIdx.x * 256 + t;
   const int c = i < n ? perm_class(ind, i, sy, sx, mz, my, mx, pz, py, px) : -1;
