@@ -47,7 +47,7 @@ def parse():
                     help="input-pipeline thread prepares batch t+1 while batch t trains: 2 = voxelisation + rulebooks, 1 = voxelisation, 0 = all in line")
     ap.add_argument("--pair-lists", type=int, default=1, help="prefetch also materialises the reference-format pair lists (pair-split weight gradient)")
     ap.add_argument("--switch-interval", type=float, default=0.0, help="sys.setswitchinterval (s); 0 keeps Python's default 5 ms")
-    ap.add_argument("--prefetch-depth", type=int, default=2, help="batches the input pipeline keeps in flight")
+    ap.add_argument("--prefetch-depth", type=int, default=3, help="batches the input pipeline keeps in flight")
     ap.add_argument("--prefetch-workers", type=int, default=1,
                     help="input-pipeline threads, each with its own HIP stream (measured: a second one adds nothing — launches from "
                          "several threads serialise in the runtime)")
