@@ -77,3 +77,24 @@ def test_rank_seeds_are_disjoint():
     a = {s for row in dist_utils.rank_seeds(0, 4, 4) for s in row}
     b = {s for row in dist_utils.rank_seeds(1, 4, 4) for s in row}
     assert not (a & b) and len(a) == 16
+
+
+def test_core_blocks_are_disjoint_per_local_rank(monkeypatch):
+    """bench.pin_cores: every local rank takes its own compact block out of the affinity mask it inherited; small masks and
+    platforms without sched_setaffinity are left alone."""
+    sys.path.insert(0, REPO)
+    import bench
+    mask = set(range(256))
+    got = {}
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(mask), raising=False)
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cores: got.__setitem__("cores", list(cores)), raising=False)
+    blocks = [bench.pin_cores(r, 8, 16) for r in range(8)]
+    assert all(len(b) == 16 for b in blocks) and len(set().union(*map(set, blocks))) == 128
+    assert blocks[0] == list(range(16)) and blocks[4] == list(range(64, 80))      # ranks 0-3 / 4-7 on the two sockets' first cores
+    assert got["cores"] == blocks[7]
+    assert bench.pin_cores(0, 1, 0) is None                                        # switched off
+    mask = set(range(8))
+    assert bench.pin_cores(0, 1, 16) is None                                       # launcher already restricted us to 8 cores
+    mask = set(range(256))
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cores: (_ for _ in ()).throw(OSError("not permitted")), raising=False)
+    assert bench.pin_cores(0, 1, 16) is None
