@@ -196,6 +196,19 @@ int fv2p_sparse_group_fwd(const float* in, int64_t n_in, int c, const int* tab, 
 int fv2p_sparse_group_bwd(const float* grad, int64_t n_out, int c, const int* tab, int kvol, int64_t n_in,
                           int flip_k, float* din, fv2p_stream_t stream);
 
+/* ---- (f).2: bilinear gather of BEV features at key points --------------------------------------------------------
+ * Replaces bilinear_interpolate_torch and BEVGridPooling.interpolate_from_bev_features
+ * (pcdet/models/backbones_3d/pfe/bev_grid_pooling.py:11-45, 68-83).  bev: [B, C, H, W] (channels_first, the layout the
+ * detector holds; transposed once into the workspace) or [B, H, W, C]; x, y [B, n]: pixel coordinates (already divided
+ * by voxel size and stride); out [B, n, C].  Corners floor / floor + 1 clamped to the map, weights from the clamped
+ * corners, sum order a, b, c, d — the reference's arithmetic, no contraction.  bwd: gradient of the map (zero-filled
+ * here, float atomics: unordered like torch's index backward); x, y get no gradient. */
+size_t fv2p_bev_interp_ws_bytes(int batch, int c, int h, int w, int channels_first);
+int fv2p_bev_interp_fwd(const float* bev, int batch, int c, int h, int w, int channels_first, const float* x,
+                        const float* y, int64_t n, float* out, void* ws, size_t ws_bytes, fv2p_stream_t stream);
+int fv2p_bev_interp_bwd(const float* grad_out, int batch, int c, int h, int w, int channels_first, const float* x,
+                        const float* y, int64_t n, float* grad_bev, void* ws, size_t ws_bytes, fv2p_stream_t stream);
+
 /* ---- (f).2: SparseConvTensor.dense() and its gradient ---------------------------------------------------------
  * Replaces scatter_nd + permute + contiguous (pcdet/ops/spconv/structure.py:5-18, 57-66; consumer HeightCompression,
  * pcdet/models/backbones_2d/map_to_bev/height_compression.py:10-26).  indices [n, 1+ndim] (batch, z, y, x) or

@@ -30,3 +30,13 @@ def test_voxel_oracle_scratch_map_equals_dense_map():
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
     assert (scratch == -1).all()
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "bev_interp_*.npz"))),
+                         ids=lambda p: os.path.basename(p)[:-4])
+def test_bev_interp_oracle_matches_reference_golden(path):
+    """oracle/bev_oracle.py against the outputs of the reference's own bilinear_interpolate_torch (fixtures made by
+    oracle/gen_golden_bev.py in the build container): bit-exact, including points on and beyond the map border."""
+    from oracle import bev_oracle
+    d = np.load(path)
+    assert np.array_equal(bev_oracle.bilinear_interpolate(d["im"], d["x"], d["y"]), d["out"])

@@ -270,12 +270,47 @@ def bn():
               f"fwd {3 * 4 * n * c / tf / 1e6:5.2f} TB/s")
 
 
+def bev():
+    """Bilinear BEV gather at the FV2P size vs the reference's torch composition (permute + 4 index gathers + weights)."""
+    from pcdet.models.backbones_3d.pfe import bev_grid_pooling as bgp
+    dev = torch.device("cuda:0")
+    b, c, h, w, n = 4, 128, 200, 176, 27648
+    bev_f = torch.randn(b, c, h, w, device=dev, requires_grad=True)
+    kp = torch.rand(b, n, 3, device=dev) * torch.tensor([70.4, 80.0, 4.0], device=dev) + torch.tensor([0.0, -40.0, -3.0], device=dev)
+    rng, vox = [0.0, -40.0, -3.0, 70.4, 40.0, 1.0], [0.05, 0.05, 0.1]
+
+    def torch_ref():
+        xs = ((kp[:, :, 0] - rng[0]) / vox[0]) / 8
+        ys = ((kp[:, :, 1] - rng[1]) / vox[1]) / 8
+        outs = []
+        for k in range(b):
+            im = bev_f[k].permute(1, 2, 0).contiguous()
+            x, y = xs[k], ys[k]
+            x0, y0 = torch.floor(x).long(), torch.floor(y).long()
+            x1, y1 = x0 + 1, y0 + 1
+            x0, x1 = x0.clamp(0, w - 1), x1.clamp(0, w - 1)
+            y0, y1 = y0.clamp(0, h - 1), y1.clamp(0, h - 1)
+            wa, wb = (x1.float() - x) * (y1.float() - y), (x1.float() - x) * (y - y0.float())
+            wc, wd = (x - x0.float()) * (y1.float() - y), (x - x0.float()) * (y - y0.float())
+            outs.append((im[y0, x0] * wa[:, None] + im[y1, x0] * wb[:, None] + im[y0, x1] * wc[:, None] + im[y1, x1] * wd[:, None]).unsqueeze(0))
+        return torch.cat(outs)
+
+    ours = lambda: bgp.interpolate_from_bev_features(kp, bev_f, b, 8, rng, vox)
+    g = torch.randn(b, n, c, device=dev)
+    t_f, t_rf = timeit(lambda: ours().detach(), reps=20), timeit(lambda: torch_ref().detach(), reps=20)
+    o, r = ours(), torch_ref()
+    t_b = timeit(lambda: o.backward(g, retain_graph=True), reps=20)
+    t_rb = timeit(lambda: r.backward(g, retain_graph=True), reps=20)
+    byt = 4.0 * b * (c * h * w * 2 + n * c * 5)
+    print(f"bev gather [{b},{c},{h},{w}] x {n} pts: fwd {t_f:7.1f} us ({byt / t_f / 1e6:5.2f} TB/s)  bwd {t_b:7.1f} us | torch composition fwd {t_rf:7.1f} us bwd {t_rb:7.1f} us")
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which == "convone":
         conv(only=20)
         sys.exit(0)
-    for name, fn in (("conv", conv), ("dcn", dcn), ("fps", fps), ("nms", nms), ("bn", bn)):
+    for name, fn in (("conv", conv), ("dcn", dcn), ("fps", fps), ("nms", nms), ("bn", bn), ("bev", bev)):
         if which in (name, "all"):
             print(f"==== {name}")
             fn()
