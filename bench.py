@@ -339,6 +339,9 @@ def main():
     dist_utils.barrier()
     torch.cuda.synchronize()
     dt = dist_utils.max_over_ranks(time.perf_counter() - t0, device)
+    if rank == 0:   # leak check at a glance: what the caching allocator holds after the timed steps
+        print("[memory] allocated %.1f MB, peak %.1f MB, reserved %.1f MB" % (torch.cuda.memory_allocated(device) / 2**20,
+              torch.cuda.max_memory_allocated(device) / 2**20, torch.cuda.memory_reserved(device) / 2**20), file=sys.stderr)
     if args.step_times and rank == 0 and len(stamps) > 2:
         d = np.diff(np.array(stamps)) * 1e3
         print("[step-times] host interval between steps, ms: p10 %.3f p50 %.3f p90 %.3f p99 %.3f max %.3f" %
