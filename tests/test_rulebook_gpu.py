@@ -163,3 +163,21 @@ def test_waymo_scale_rulebooks_and_conv_against_oracle(gpu):
     ref = oracle.indice_conv(feats, conv.weight.detach().cpu().numpy(), p_d, n_d, o_d.shape[0]).numpy()
     got = y.features.detach().cpu().numpy()
     assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-4
+    # backward-data of the strided conv at this size on parity-ordered tiles (fv2p_rulebook_class_perm): the permutation is
+    # the stable grouping by (coordinate + padding) mod stride and the rows equal the plain launch bit for bit
+    import ctypes
+    import fv2p_native
+    n_in, n_out = ind.shape[0], o_d.shape[0]
+    arr = lambda v: (ctypes.c_int * 3)(*v)
+    perm = torch.empty(n_in, dtype=torch.int32, device=gpu)
+    ws = fv2p_native.workspace(int(fv2p_native.lib().fv2p_rulebook_class_perm_ws_bytes(n_in)), ind.device)
+    fv2p_native.call("fv2p_rulebook_class_perm", ind, n_in, arr((2, 2, 2)), arr((1, 1, 1)), perm, ws, ws.numel(), fv2p_native.stream())
+    cls = ((ind_np[:, 1:] + 1) % 2) @ np.array([4, 2, 1])
+    assert np.array_equal(perm.cpu().numpy(), np.argsort(cls, kind="stable"))
+    g = torch.randn((n_out, 32), device=gpu)
+    w3 = conv.weight.detach().reshape(27, 16, 32).contiguous()
+    tab, flip = rb_d.in_table()
+    plain, ordered = torch.empty((n_in, 16), device=gpu), torch.empty((n_in, 16), device=gpu)
+    fv2p_native.call("fv2p_sparse_conv_rows", g, n_out, 32, w3, 27, tab, n_in, 16, int(flip), 1, None, plain, fv2p_native.stream())
+    fv2p_native.call("fv2p_sparse_conv_rows_perm", g, n_out, 32, w3, 27, tab, n_in, 16, int(flip), 1, None, ordered, perm, fv2p_native.stream())
+    assert torch.equal(plain, ordered)
