@@ -59,8 +59,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_sums_inplace(int* __restric
 // issued before the first add (the 16-tile loop this replaces was a chain of 16 dependent round trips, 19.5 us at
 // n = 16384-32768), then one wave-shuffle scan per wave and a 16-entry LDS scan across the waves.
 constexpr int kSmallThreads = 1024;
-constexpr int kSmallItems = 32;
-constexpr int kSmallScan = kSmallThreads * kSmallItems;
+constexpr int kSmallScan = kSmallThreads * 32;
+// kSmallItems = 32 for up to 32768 entries, 4 for up to 4096 (tile sums, digit histograms, per-offset counts: most calls)
+template <int kSmallItems>
 __global__ __launch_bounds__(kSmallThreads) void scan_small(const int* __restrict__ in, int* __restrict__ out, int64_t n,
                                                             int* __restrict__ total) {
   __shared__ int lds_wave[kSmallThreads / 64];
@@ -153,7 +154,8 @@ int exclusive_scan_i32(const int* in, int* out, int64_t n, int* total, void* ws,
     return 0;
   }
   if (n <= kSmallScan) {
-    hipLaunchKernelGGL(scan_small, dim3(1), dim3(kSmallThreads), 0, stream, in, out, n, total);
+    if (n <= kSmallThreads * 4) hipLaunchKernelGGL(scan_small<4>, dim3(1), dim3(kSmallThreads), 0, stream, in, out, n, total);
+    else hipLaunchKernelGGL(scan_small<32>, dim3(1), dim3(kSmallThreads), 0, stream, in, out, n, total);
     FV2P_LAUNCH_CHECK();
     return 0;
   }
