@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(256) void conv_wgrad(WgradArgs a, float* __restrict
 // same lists): no per-launch compaction prologue, every workgroup gets kPairsPerChunk real pairs whatever the offset's
 // density (the dense centre offset of a submanifold conv needs no launch of its own), and workgroups past an offset's
 // pair count exit at once.  The pair lists are built once per rulebook, off the training stream when prefetched.
-constexpr int kPairsPerChunk = 512;
+constexpr int kPairsPerChunk = 256;
 
 struct WgradPairArgs {
   const float* src; int ld_src; int c_src;     // operand indexed by pairs[k][side_src]

@@ -63,9 +63,18 @@ def build_rulebooks(recipe, indices, batch_size, pair_lists=True):
         out[key] = ops.build_rulebook(ind, batch_size, shape, list(ksize), list(stride), list(padding), list(dilation),
                                       list(out_padding), subm, transpose)
         out[key].prefetched = True
-        if pair_lists and subm:  # compacted pair lists: the weight gradient of submanifold convs splits its work by them
-            out[key].wgrad_pairs()   # (measured: a win for subm rulebooks, a loss for the sparser strided ones)
+        if pair_lists and (subm or _few_offsets(ksize)):  # compacted pair lists: the weight gradient splits its work by them
+            out[key].wgrad_pairs()   # (measured: a win for subm rulebooks and for kernels of < 8 offsets, a loss for other strided ones)
     return out
+
+
+def _few_offsets(ksize):
+    """Kernels like (3, 1, 1): the table-driven weight gradient launches chunks x offsets workgroups and starves with 3
+    offsets (45 us for 15 k pairs at 64 -> 128); split by pair lists it takes 21 us."""
+    k = 1
+    for v in ksize:
+        k *= int(v)
+    return k < 8
 
 
 def _build_chain(ext, recipe, root, batch_size, pair_lists):
@@ -83,7 +92,7 @@ def _build_chain(ext, recipe, root, batch_size, pair_lists):
             out_shape = ops.get_conv_output_size(shape, ksize, stride, padding, dilation)
         symmetric = bool(subm) and all(k % 2 == 1 for k in ksize) and all(d == 1 for d in dilation)
         specs.append((-1 if src is None else keys.index(src), [int(v) for v in shape], [int(v) for v in out_shape], ksize, stride, padding,
-                      dilation, bool(subm), bool(transpose), symmetric, bool(pair_lists and subm)))
+                      dilation, bool(subm), bool(transpose), symmetric, bool(pair_lists and (subm or _few_offsets(ksize)))))
         shapes.append(out_shape)
     with _nat.device_guard(root.device):
         res = ext.build_rulebook_chain(root, int(batch_size), specs)
