@@ -1037,10 +1037,12 @@ __global__ __launch_bounds__(256) void conv_wgrad(WgradArgs a, float* __restrict
 // ---- weight gradient from pair lists ---------------------------------------------------------------------------
 // Same staged gather + MFMA as conv_wgrad, but the valid (source row, gradient row) pairs come from the rulebook's
 // compacted pair lists (the reference's indice_pairs [K][2][n] + indice_pair_num [K], spconv_ops.h:403-455 walks the
-// same lists): no per-launch compaction prologue, every workgroup gets kPairsPerChunk real pairs whatever the offset's
+// same lists): no per-launch compaction prologue, every workgroup gets pairs_per_chunk() real pairs whatever the offset's
 // density (the dense centre offset of a submanifold conv needs no launch of its own), and workgroups past an offset's
 // pair count exit at once.  The pair lists are built once per rulebook, off the training stream when prefetched.
-constexpr int kPairsPerChunk = 256;
+constexpr int kPairsMax = 512;     // LDS room for a workgroup's pair indices
+// pairs per workgroup: 256 up to ~1e5 rows (512 leaves a 2.3-round tail at KITTI size), 512 above (fewer partial tiles to fold)
+static int pairs_per_chunk(long long pair_len) { return pair_len > 100000 ? 512 : 256; }
 
 struct WgradPairArgs {
   const float* src; int ld_src; int c_src;     // operand indexed by pairs[k][side_src]
@@ -1049,6 +1051,7 @@ struct WgradPairArgs {
   const int* pair_num;                          // [kvol]
   int side_src;                                 // 0: src rows are pairs[k][0] (forward conv), 1: pairs[k][1] (inverse conv)
   int kvol;
+  int chunk;                                    // pairs per workgroup (<= kPairsMax)
 };
 
 template <int MB, int NB>
@@ -1061,14 +1064,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_pairs(WgradPairArgs a, float* 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* F = lds;
   float* G = F + kWgStage * LDF;
-  int* s_src = reinterpret_cast<int*>(G + kWgStage * LDG);  // [kPairsPerChunk]
-  int* s_row = s_src + kPairsPerChunk;
+  int* s_src = reinterpret_cast<int*>(G + kWgStage * LDG);  // [kPairsMax]
+  int* s_row = s_src + kPairsMax;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, m = lane & 15, g = lane >> 4;
   const int k = blockIdx.y;
   const int total = a.pair_num[k];
-  const int p_begin = blockIdx.x * kPairsPerChunk;
+  const int p_begin = blockIdx.x * a.chunk;
   if (p_begin >= total) return;  // whole workgroup
-  const int cnt = min(kPairsPerChunk, total - p_begin);
+  const int cnt = min(a.chunk, total - p_begin);
   {
     const int* pa = a.pairs + (static_cast<long long>(k) * 2 + a.side_src) * a.pair_len + p_begin;
     const int* pb = a.pairs + (static_cast<long long>(k) * 2 + 1 - a.side_src) * a.pair_len + p_begin;
@@ -1168,17 +1171,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_pairs_dma(WgradPairArgs a, flo
   constexpr int PF = ST * (CS / 4) / 64, PG = ST * (CG / 4) / 64;  // DMA pieces (64 lanes x 16 B) per stage
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int* s_src = reinterpret_cast<int*>(lds + 2 * STAGE);
-  int* s_row = s_src + kPairsPerChunk;
+  int* s_row = s_src + kPairsMax;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), m = lane & 15, g = lane >> 4;
   const int k = blockIdx.y;
   const int total = a.pair_num[k];
-  const int p_begin = blockIdx.x * kPairsPerChunk;
+  const int p_begin = blockIdx.x * a.chunk;
   if (p_begin >= total) return;  // whole workgroup
-  const int cnt = min(kPairsPerChunk, total - p_begin);
+  const int cnt = min(a.chunk, total - p_begin);
   {
     const int* pa = a.pairs + (static_cast<long long>(k) * 2 + a.side_src) * a.pair_len + p_begin;
     const int* pb = a.pairs + (static_cast<long long>(k) * 2 + 1 - a.side_src) * a.pair_len + p_begin;
-    for (int e = tid; e < kPairsPerChunk; e += 256) { s_src[e] = e < cnt ? pa[e] : -1; s_row[e] = e < cnt ? pb[e] : -1; }
+    for (int e = tid; e < a.chunk; e += 256) { s_src[e] = e < cnt ? pa[e] : -1; s_row[e] = e < cnt ? pb[e] : -1; }
   }
   __syncthreads();
   // piece q of a stage: rows [q * 64 / U, ...) of F (q < PF) or G; lane l -> row q*64/U + l/U, unit l%U  (U = units per row)
@@ -1251,8 +1254,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_pairs_dma(WgradPairArgs a, flo
     }
 }
 
-// Fixed-order sum of the tiles of the chunks that exist for each offset: ceil(pair_num[k] / kPairsPerChunk).
-__global__ __launch_bounds__(256) void wgrad_reduce_pairs(const float* __restrict__ partial, const int* __restrict__ pair_num, int kvol,
+// Fixed-order sum of the tiles of the chunks that exist for each offset: ceil(pair_num[k] / chunk).
+__global__ __launch_bounds__(256) void wgrad_reduce_pairs(const float* __restrict__ partial, const int* __restrict__ pair_num, int kvol, int chunk,
                                                           int c_src, int c_grad, float* __restrict__ dw, long long dw_kstride, int dw_ld) {
   __shared__ float part[16][17];
   const int e = threadIdx.x & 15, cg = threadIdx.x >> 4;
@@ -1262,7 +1265,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_pairs(const float* __restric
   int k = 0;
   if (t < per_chunk) {
     k = static_cast<int>(t / (static_cast<long long>(c_grad) * c_src));
-    const int chunks = (pair_num[k] + kPairsPerChunk - 1) / kPairsPerChunk;
+    const int chunks = (pair_num[k] + chunk - 1) / chunk;
     for (int c = cg; c < chunks; c += 16) s += partial[c * per_chunk + t];
   }
   part[cg][e] = s;
@@ -1581,14 +1584,14 @@ template <int MB, int NB>
 static void wgrad_pairs_launch(const WgradPairArgs& a, float* partial, unsigned chunks, hipStream_t stream) {
   const dim3 grid(chunks, static_cast<unsigned>(a.kvol), 1), block(256);
   constexpr int stage = (MB * NB >= 64) ? 32 : 64;
-  const size_t lds = static_cast<size_t>(stage) * (MB * 16 + 4 + NB * 16 + 4) * sizeof(float) + 2 * kPairsPerChunk * sizeof(int);
+  const size_t lds = static_cast<size_t>(stage) * (MB * 16 + 4 + NB * 16 + 4) * sizeof(float) + 2 * kPairsMax * sizeof(int);
   hipLaunchKernelGGL((conv_wgrad_pairs<MB, NB>), grid, block, lds, stream, a, partial);
 }
 
 extern "C" size_t fv2p_sparse_conv_wgrad_pairs_ws_bytes(int64_t pair_len, int c_src, int c_dst, int kvol) {
   const int cs = c_src < 128 ? c_src : 128, cd = c_dst < 128 ? c_dst : 128;
   Sizer s;
-  s.take<float>(static_cast<size_t>(ceil_div(pair_len > 0 ? pair_len : 1, kPairsPerChunk)) * kvol * cs * cd);
+  s.take<float>(static_cast<size_t>(ceil_div(pair_len > 0 ? pair_len : 1, pairs_per_chunk(pair_len))) * kvol * cs * cd);
   return s.bytes();
 }
 
@@ -1606,7 +1609,8 @@ extern "C" int fv2p_sparse_conv_wgrad_pairs(const float* src, int64_t n_src, int
   FV2P_REQUIRE(src && grad && pairs && pair_num, FV2P_EINVAL, "sparse_conv_wgrad_pairs: null pointer");
   FV2P_REQUIRE(ws && ws_bytes >= fv2p_sparse_conv_wgrad_pairs_ws_bytes(pair_len, c_src, c_dst, kvol), FV2P_EWORKSPACE,
                "sparse_conv_wgrad_pairs: workspace too small");
-  const unsigned chunks = static_cast<unsigned>(ceil_div(pair_len, kPairsPerChunk));
+  const int chunk = pairs_per_chunk(pair_len);
+  const unsigned chunks = static_cast<unsigned>(ceil_div(pair_len, chunk));
   for (int d0 = 0; d0 < c_dst; d0 += 128) {
     const int cd = (c_dst - d0) < 128 ? (c_dst - d0) : 128;
     for (int s0 = 0; s0 < c_src; s0 += 128) {
@@ -1616,7 +1620,7 @@ extern "C" int fv2p_sparse_conv_wgrad_pairs(const float* src, int64_t n_src, int
       WgradPairArgs a;
       a.src = src + s0; a.ld_src = c_src; a.c_src = cs;
       a.grad = grad + d0; a.ld_grad = c_dst; a.c_grad = cd;
-      a.pairs = pairs; a.pair_len = pair_len; a.pair_num = pair_num; a.side_src = side_src; a.kvol = kvol;
+      a.pairs = pairs; a.pair_len = pair_len; a.pair_num = pair_num; a.side_src = side_src; a.kvol = kvol; a.chunk = chunk;
       const int mb = static_cast<int>(ceil_div(cs, 16)), nb = static_cast<int>(ceil_div(cd, 16));
       const int nbp = nb <= 1 ? 1 : nb <= 2 ? 2 : nb <= 4 ? 4 : 8;
       const int mbp = mb <= 1 ? 1 : mb <= 2 ? 2 : mb <= 4 ? 4 : 8;
@@ -1631,7 +1635,7 @@ extern "C" int fv2p_sparse_conv_wgrad_pairs(const float* src, int64_t n_src, int
         if (st_env < 0) { const char* e = getenv("FV2P_WGRAD_ST"); st_env = e ? atoi(e) : 0; }
         const int st64 = st_env ? st_env : (static_cast<long long>(chunks) * kvol > 1200 ? 32 : 64);
         const int st = (as + bs <= 2) ? st64 : 32;
-        const size_t lds = static_cast<size_t>(2) * st * (cs + cd) * sizeof(float) + 2 * kPairsPerChunk * sizeof(int);
+        const size_t lds = static_cast<size_t>(2) * st * (cs + cd) * sizeof(float) + 2 * kPairsMax * sizeof(int);
         if (as == 1 && bs == 1 && st == 64) hipLaunchKernelGGL((conv_wgrad_pairs_dma<1, 1, 64>), grid, block, lds, stream, a, partial);
         else if (as == 1 && bs == 1) hipLaunchKernelGGL((conv_wgrad_pairs_dma<1, 1, 32>), grid, block, lds, stream, a, partial);
         else if (as == 2 && bs == 1) hipLaunchKernelGGL((conv_wgrad_pairs_dma<2, 1, 32>), grid, block, lds, stream, a, partial);
@@ -1648,7 +1652,7 @@ extern "C" int fv2p_sparse_conv_wgrad_pairs(const float* src, int64_t n_src, int
       }
       const long long per_chunk = static_cast<long long>(kvol) * cs * cd;
       hipLaunchKernelGGL(wgrad_reduce_pairs, dim3(static_cast<unsigned>(ceil_div(per_chunk, 16))), dim3(256), 0, stream, partial, pair_num, kvol,
-                         cs, cd, dweight + static_cast<long long>(s0) * c_dst + d0, static_cast<long long>(c_src) * c_dst, c_dst);
+                         chunk, cs, cd, dweight + static_cast<long long>(s0) * c_dst + d0, static_cast<long long>(c_src) * c_dst, c_dst);
     }
   }
   FV2P_LAUNCH_CHECK();
