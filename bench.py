@@ -1,17 +1,23 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the pcdet.ops hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
 
-A "step" is one training step of the sparse 3-D backbone over one batch of synthetic KITTI-shaped clouds
-whose points are already resident in HBM:  HIP voxelisation (points_to_voxel) -> MeanVFE -> backbone
-forward (8-9 hashed rulebook builds + 12-21 fused MFMA sparse convs + BN/ReLU) -> loss -> backward ->
-AdamW step.  Workload at N=1 = BASELINE.json configs[1] (VoxelBackBone8x, batch 4, KITTI grid 0.05 m,
-16384-point clouds) extended with the backward pass the metric asks for.  Weak scaling: every rank keeps
-batch 4 (DistributedDataParallel over RCCL); value = clouds processed by all ranks / max-over-ranks time.
+N > 1 without a launcher in the environment: this process starts `python -m torch.distributed.run --nproc-per-node N
+bench.py ...` as a CHILD process (it has not touched the GPU) and exits with the child's code; under torchrun (RANK set)
+it is one rank.  One process per GPU, RCCL all-reduce of the gradients (DistributedDataParallel), weak scaling: every
+rank keeps its own batch; value = clouds processed by all ranks / max-over-ranks time.
 
-Rank 0 prints ONE JSON line with `roofline` (dominant kernel, timed live with events on the launch stream)
-and, at N=1, `cpu_baseline` (the oracle port of the reference algorithm on the host cores, bounded sample).
+--workload fv2p (default, BASELINE configs[2]): one training step of the FV2P detector replay
+(fv2p_harness/fv2p_model.py: fv2p.yaml, car only) on batch 3 of synthetic 16384-point KITTI-shaped clouds resident in
+HBM: HIP voxelisation + MeanVFE -> VoxelResBackBone8x (sparse convs) -> dense() -> BEV backbone + anchor head ->
+per-sample FPS to 16384 key points -> 5 x (3-NN + interpolation) decoder -> point head (points_in_boxes) -> RoI head
+(top-9000 rotated NMS -> 512, 3-D IoU target sampling, RoI point pool, BEV bilinear gather, ball query + grouping) ->
+three losses -> backward -> gradient clipping -> AdamW.
+--workload backbone (BASELINE configs[1] + backward): the sparse backbone alone, batch 4.
+
+Rank 0 prints ONE JSON line with `roofline` (dominant kernel, timed live with events on the launch stream) and, at N=1,
+`cpu_baseline` (the oracle port of the reference algorithms on the host cores, bounded sample).
 """
 import argparse
 import json
@@ -23,6 +29,8 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 for p in (REPO, os.path.join(REPO, "from-voxel-to-point_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # read when the HIP runtime initialises: set before any torch.cuda call
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -38,7 +46,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=4, help="clouds per GPU per step")
+    ap.add_argument("--workload", choices=["fv2p", "backbone"], default="fv2p")
+    ap.add_argument("--batch", type=int, default=0, help="clouds per GPU per step (0: 3 for fv2p, 4 for backbone)")
     ap.add_argument("--points", type=int, default=16384)
     ap.add_argument("--backbone", choices=["8x", "res8x"], default="8x")
     ap.add_argument("--cpu-clouds", type=int, default=64, help="clouds in the cpu_baseline sample, ~0.2 s each, capped at 25 s (0 = skip)")
@@ -55,8 +64,27 @@ def parse():
     ap.add_argument("--lean-adamw", type=int, default=1, help="1: torch's fused AdamW kernels called on cached tensor lists (fv2p_harness/optim.py); 0: torch.optim.AdamW(fused=True)")
     ap.add_argument("--pin-cores", type=int, default=16, help="cores per rank to pin this process to (0: leave the affinity alone)")
     ap.add_argument("--phases", action="store_true", help="diagnostic: host issue time and synchronised wall time per phase (stderr)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous check without a GPU: ranks join a gloo group, reduce, rank 0 prints n_gpus")
     ap.add_argument("--pyprofile", action="store_true", help="cProfile the timed steps (host-overhead hunting; prints to stderr)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.batch <= 0:
+        args.batch = 3 if args.workload == "fv2p" else 4
+    if args.steps == 300 and args.workload == "fv2p" and "--steps" not in sys.argv:
+        args.steps, args.warmup = 40, (args.warmup if "--warmup" in sys.argv else 5)
+    return args
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as a child process tree and relay its exit code.
+    This process has not initialised the GPU (no torch.cuda call yet) and it spawns, never execs."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
 
 
 def build_step(args, device, rank, world):
@@ -169,6 +197,177 @@ def build_step(args, device, rank, world):
     return model, step, voxelize, pool
 
 
+def build_fv2p_step(args, device, rank, world):
+    """BASELINE configs[2]: one optimiser step of the FV2P detector replay on `args.batch` clouds per rank."""
+    from fv2p_harness import dist_utils, synth
+    from fv2p_harness.fv2p_model import FV2PConfig, FV2PDetector, pad_gt_boxes
+    from fv2p_harness.optim import LeanAdamW
+    from fv2p_harness.prefetch import BatchPrefetcher
+    from pcdet.datasets.processor.voxel_generator import points_to_voxel_batch
+    from pcdet.ops import spconv
+
+    cfg = FV2PConfig
+    torch.manual_seed(0)
+    model = FV2PDetector(cfg).to(device)
+    net = dist_utils.wrap_ddp(model, device, find_unused_parameters=False)   # every parameter takes part in every step
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = LeanAdamW(params, lr=1e-3, weight_decay=0.01) if args.lean_adamw else torch.optim.AdamW(params, lr=1e-3, weight_decay=0.01, fused=True)
+    n_pool = 4
+    pool = []
+    for seeds in dist_utils.rank_seeds(rank, n_pool, args.batch):
+        clouds, boxes = [], []
+        for seed in seeds:
+            pts, bx = synth.lidar_cloud(seed, args.points, return_boxes=True)
+            clouds.append(torch.from_numpy(pts).to(device))
+            boxes.append(bx)
+        pool.append((clouds, pad_gt_boxes(boxes, device, max_gt=40)))
+    n_uniform = cfg.nms_post + cfg.roi_per_image
+
+    def voxelize(clouds):
+        return points_to_voxel_batch(clouds, synth.KITTI_VOXEL, synth.KITTI_RANGE, cfg.max_points_per_voxel, cfg.max_voxels, mean_vfe=True)
+
+    pre = None
+    if args.prefetch:
+        with torch.no_grad():
+            f0, c0 = voxelize(pool[0][0])
+            recipe = spconv.rulebook_recipe(model.backbone_3d(f0, c0, args.batch)[0].indice_dict, c0)
+
+        def produce(i):
+            feats, coords = voxelize(pool[i % n_pool][0])
+            if args.prefetch > 1:
+                spconv.attach_rulebooks(coords, spconv.build_rulebooks(recipe, coords, args.batch, pair_lists=bool(args.pair_lists)))
+            return feats, coords
+
+        pre = BatchPrefetcher(produce, device, workers=args.prefetch_workers)
+
+    def step(i):
+        clouds, gt = pool[i % n_pool]
+        if pre is None:
+            feats, coords = voxelize(clouds)
+        else:
+            if pre.pending == 0:
+                step.next_submit = i
+            while pre.pending < args.prefetch_depth:
+                pre.submit(step.next_submit)
+                step.next_submit += 1
+            feats, coords = pre.get()
+        u = torch.rand(len(clouds), n_uniform, device=device)
+        loss = net(clouds, feats, coords, gt, u)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, cfg.grad_norm_clip, foreach=True)   # GRAD_NORM_CLIP (train_utils.py:43)
+        opt.step()
+        return loss
+
+    def step_phases(i, acc):
+        def phase(name, fn):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = fn()
+            t1 = time.perf_counter()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            a = acc.setdefault(name, [0.0, 0.0])
+            a[0] += t1 - t0
+            a[1] += t2 - t0
+            return r
+        clouds, gt = pool[i % n_pool]
+        feats, coords = phase("voxelise+vfe", lambda: voxelize(clouds))
+        u = torch.rand(len(clouds), n_uniform, device=device)
+        m = model
+        st = {}
+
+        def fwd_3d():
+            st["out"], st["levels"] = m.backbone_3d(feats, coords, len(clouds))
+        phase("backbone_3d", fwd_3d)
+
+        def fwd_2d():
+            d = st["out"].dense()
+            st["bev"] = m.backbone_2d(d.view(len(clouds), -1, d.shape[3], d.shape[4]))
+            st["rpn"] = m.dense_head(st["bev"], gt)
+        phase("bev+anchor_head", fwd_2d)
+        phase("fps", lambda: st.__setitem__("key", m.post_pfe.sample_keypoints(clouds)))
+        orig = m.post_pfe.sample_keypoints
+        m.post_pfe.sample_keypoints = lambda c: st["key"]
+        try:
+            phase("decoder", lambda: st.__setitem__("dec", m.post_pfe(clouds, st["levels"])))
+        finally:
+            m.post_pfe.sample_keypoints = orig
+        key, pf = st["dec"]
+        phase("point_head", lambda: st.__setitem__("ph", m.point_head(key, pf, gt)))
+        l_rpn, ps, pb = st["rpn"]
+        l_pt, pscore = st["ph"]
+        phase("roi_head", lambda: st.__setitem__("rh", m.roi_head(key, pf, pscore, st["bev"], ps, pb, gt, u)))
+        loss = l_rpn + l_pt + st["rh"][0]
+        opt.zero_grad(set_to_none=True)
+        phase("backward", lambda: loss.backward())
+        phase("clip+optimizer", lambda: (torch.nn.utils.clip_grad_norm_(params, cfg.grad_norm_clip, foreach=True), opt.step()))
+
+    def close():
+        if pre is not None:
+            while pre.pending:
+                pre.get()
+            pre.close()
+
+    step.phases = step_phases
+    step.close = close
+    return model, step, voxelize, pool
+
+
+def fps_probe(model, pool, args, device):
+    """Furthest point sampling is a chain of M - 1 dependent rounds on one workgroup per sample: latency, not a
+    roofline — reported as microseconds per round, timed with events on the launch stream."""
+    from pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as pn2
+    xyz = torch.stack([c[:, :3] for c in pool[0][0]]).contiguous()
+    m = model.cfg.num_keypoints
+    for _ in range(2):
+        pn2.furthest_point_sample(xyz, m)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    e0.record()
+    for _ in range(reps):
+        pn2.furthest_point_sample(xyz, m)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    return {"kernel": "furthest point sampling (one workgroup per sample)", "ms_per_call": round(ms, 3), "rounds": m - 1,
+            "us_per_round": round(ms * 1e3 / (m - 1), 4), "samples_in_flight": xyz.shape[0], "points": xyz.shape[1]}
+
+
+def cpu_baseline_fv2p(model, args):
+    """The same detector replay on the host: every op answered by the oracle port of the reference algorithm (oracle/backend.py),
+    sparse convs by the oracle's gather-mm-scatter, dense layers by torch CPU.  Bounded sample: one step at batch 1."""
+    import oracle
+    from fv2p_harness import synth
+    from fv2p_harness.backbone import mean_vfe
+    from fv2p_harness.fv2p_model import pad_gt_boxes
+    from oracle.backend import oracle_backend
+    from oracle.spconv_cpu import cpu_mirror
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
+    torch.set_num_threads(cores)
+    ref = cpu_mirror(model)
+    cfg = model.cfg
+    pts, bx = synth.lidar_cloud(7, args.points, return_boxes=True)
+    t0 = time.perf_counter()
+    v, c, k = oracle.points_to_voxel(pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, cfg.max_points_per_voxel, cfg.max_voxels)
+    feats = mean_vfe(torch.from_numpy(v), torch.from_numpy(k))
+    coords = torch.from_numpy(np.concatenate([np.zeros((c.shape[0], 1), np.int32), c], 1))
+    u = torch.rand(1, cfg.nms_post + cfg.roi_per_image)
+    with oracle_backend():
+        loss = ref([torch.from_numpy(pts)], feats, coords, pad_gt_boxes([bx], "cpu", max_gt=40), u)
+        loss.backward()
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "point clouds/s", "cores": cores, "kind": "port",
+            "sample": f"1 FV2P train step (forward + backward, no optimiser) at batch 1 on one synthetic {args.points}-point cloud: oracle "
+                      f"voxeliser, rulebooks, per-offset gather/mm/scatter sparse convs, single-thread C ports of FPS / 3-NN / NMS / "
+                      f"IoU / pools, torch-CPU dense layers ({cores} threads), {dt:.1f} s"}
+
+
 def roofline_probe(model, voxelize, pool, args, device):
     """Times the dominant kernel (fused sparse-conv rows kernel of the widest-work layer) with events on the
     stream it is launched on, and prices it with SURVEY §8(d)'s algorithmic flops / bytes."""
@@ -273,6 +472,16 @@ def cpu_baseline(model, args):
                       f"dense-grid-equivalent rulebook + per-offset gather/mm/scatter backbone fwd+bwd (torch CPU, {cores} threads), {dt:.1f} s"}
 
 
+def workload_name(args):
+    if args.workload == "fv2p":
+        return ("FV2P (fv2p.yaml, car only) end-to-end train step: HIP voxelise + MeanVFE, VoxelResBackBone8x, BEV backbone + anchor "
+                "head, FPS to 16384 key points, voxel-to-point decoder, point head, IoU-guided RoI head, losses, backward, grad clip, "
+                "AdamW; KITTI grid 0.05 m [41,1600,1408], LiDAR-like synthetic clouds with 20-40 car boxes")
+    return (("VoxelBackBone8x" if args.backbone == "8x" else "VoxelResBackBone8x") +
+            " train step (HIP voxelise + MeanVFE + sparse backbone fwd + bwd + AdamW), KITTI grid 0.05 m [41,1600,1408], LiDAR-like "
+            "synthetic clouds")
+
+
 def pin_cores(local, n_local, cores):
     """Keeps this rank's threads (training, autograd, input pipeline, HIP runtime helpers) on one compact block of cores.
     On the two-socket GPU boxes the unpinned step wanders between 1.78 and 2.0 ms as its threads migrate across sockets;
@@ -294,8 +503,20 @@ def pin_cores(local, n_local, cores):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))
     from fv2p_harness import dist_utils
     rank, world, local = dist_utils.env_world()
+    assert world == args.gpus, f"--gpus {args.gpus} but the launcher started {world} ranks"
+    if args.dry_run:
+        dist_utils.init_distributed("gloo")
+        t = dist_utils.max_over_ranks(float(rank + 1))
+        n = dist.get_world_size() if dist.is_initialized() else 1
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": n, "max_over_ranks": t}))
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
     pinned = pin_cores(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)), args.pin_cores)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
     # FV2P_FORCE_DEVICE / FV2P_DIST_BACKEND: test hooks to exercise the multi-rank path on a one-GPU box (all ranks on one
@@ -310,7 +531,8 @@ def main():
 
     if args.switch_interval > 0:
         sys.setswitchinterval(args.switch_interval)
-    model, step, voxelize, pool = build_step(args, device, rank, world)
+    build = build_fv2p_step if args.workload == "fv2p" else build_step
+    model, step, voxelize, pool = build(args, device, rank, world)
     for i in range(args.warmup):
         step(i)
     dist_utils.barrier()
@@ -356,19 +578,27 @@ def main():
             "metric": METRIC, "value": round(clouds / dt, 2), "unit": "point clouds/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("VoxelBackBone8x" if args.backbone == "8x" else "VoxelResBackBone8x") +
-                       " train step (HIP voxelise + MeanVFE + sparse backbone fwd + bwd + AdamW), KITTI grid 0.05 m "
-                       "[41,1600,1408], LiDAR-like synthetic clouds", "batch_per_gpu": args.batch, "points_per_cloud": args.points,
+            "config": {"workload": workload_name(args), "batch_per_gpu": args.batch, "points_per_cloud": args.points,
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "host_cores_per_rank": len(pinned) if pinned else "unpinned",
                        "input_pipeline": {0: "in line", 1: "thread voxelises batch t+1 during step t",
                                           2: "thread voxelises batch t+1 and builds its rulebooks during step t",
                                           3: "DIAGNOSTIC: prepared batches reused, not a benchmark configuration"}[min(args.prefetch, 3)]},
         }
-        if not args.no_roofline:
-            result["roofline"] = roofline_probe(model, voxelize, pool, args, device)
-        if world == 1 and args.cpu_clouds > 0:
-            result["cpu_baseline"] = cpu_baseline(model, args)
+        if args.workload == "fv2p":
+            if not args.no_roofline:
+                # dominant kernel of the step (profiles/r02_fv2p_kernel_stats.csv): the fused sparse conv of the residual
+                # backbone's heaviest layer, priced against the fp32-MFMA roofline; FPS (latency-bound) reported beside it
+                sparse = model.backbone_3d
+                result["roofline"] = roofline_probe(sparse, voxelize, [pool[0][0]], args, device)
+                result["fps"] = fps_probe(model, pool, args, device)
+            if world == 1 and args.cpu_clouds > 0:
+                result["cpu_baseline"] = cpu_baseline_fv2p(model, args)
+        else:
+            if not args.no_roofline:
+                result["roofline"] = roofline_probe(model, voxelize, pool, args, device)
+            if world == 1 and args.cpu_clouds > 0:
+                result["cpu_baseline"] = cpu_baseline(model, args)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

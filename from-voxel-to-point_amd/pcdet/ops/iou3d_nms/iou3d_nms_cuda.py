@@ -8,8 +8,10 @@ import fv2p_native as _nat
 
 
 def _check(t, name, cuda=True):
-    if not isinstance(t, torch.Tensor) or t.is_cuda != cuda or not t.is_contiguous():
+    if not isinstance(t, torch.Tensor) or not t.is_contiguous() or (not cuda and t.is_cuda):
         raise _nat.Fv2pError(f"{name} must be a contiguous {'CUDA' if cuda else 'CPU'} tensor")
+    if cuda:
+        _nat.require_cuda(t)
 
 
 def boxes_overlap_bev_gpu(boxes_a, boxes_b, ans_overlap):

@@ -98,3 +98,17 @@ def test_core_blocks_are_disjoint_per_local_rank(monkeypatch):
     mask = set(range(256))
     monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cores: (_ for _ in ()).throw(OSError("not permitted")), raising=False)
     assert bench.pin_cores(0, 1, 16) is None
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher in the environment starts two ranks as a child torchrun and relays
+    rank 0's line (tools/scripts/dist_train.sh:26 in the reference); --dry-run keeps the GPU out of it."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    out = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-run"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    assert json.loads(line)["n_gpus"] == 2
