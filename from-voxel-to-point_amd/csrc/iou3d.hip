@@ -246,6 +246,108 @@ __global__ __launch_bounds__(256) void nms_greedy(int n, int col_blocks, const u
   if (threadIdx.x == 0) *num_keep = s_count;
 }
 
+// ---- batched, truncated NMS (proposal layers keep only the first `max_keep` survivors) --------------------------------
+// The first K survivors of the greedy pass depend only on the rows up to the K-th survivor, so the suppression mask is
+// produced in growing chunks of row blocks and each chunk's kernels return at once when their sample already holds K
+// survivors (flag in the workspace): no host round trip, and with a high threshold (few suppressions) a 9000-box
+// proposal set touches 16 of its 141 row blocks.  grid (col_blocks, chunk row blocks, samples).
+template <int NORMAL>
+__global__ __launch_bounds__(64) void nms_mask_rows(int n, float thresh, const float* __restrict__ boxes_all, int col_blocks, int rb0,
+                                                    unsigned long long* __restrict__ mask_all, int chunk_rows, const int* __restrict__ done) {
+  const int s = blockIdx.z;
+  if (done[s]) return;
+  const int cb = blockIdx.x, rb = rb0 + blockIdx.y;
+  if (cb < rb || rb >= col_blocks) return;
+  const float* boxes = boxes_all + static_cast<int64_t>(s) * n * 7;
+  unsigned long long* mask = mask_all + static_cast<int64_t>(s) * chunk_rows * 64 * col_blocks;
+  __shared__ float cbox[64 * 7];
+  const int lane = threadIdx.x;
+  const int col_size = min(n - cb * 64, 64), row_size = min(n - rb * 64, 64);
+  if (lane < col_size)
+    for (int j = 0; j < 7; ++j) cbox[lane * 7 + j] = boxes[(cb * 64 + lane) * 7 + j];
+  __syncthreads();
+  if (lane < row_size) {
+    const int row = rb * 64 + lane;
+    float a[7];
+    for (int j = 0; j < 7; ++j) a[j] = boxes[row * 7 + j];
+    unsigned long long bits = 0ull;
+    const int start = (rb == cb) ? lane + 1 : 0;
+    for (int i = start; i < col_size; ++i) {
+      const float v = NORMAL ? iou_normal(a, cbox + i * 7) : iou_bev(a, cbox + i * 7);
+      if (v > thresh) bits |= 1ull << i;
+    }
+    mask[static_cast<int64_t>(blockIdx.y * 64 + lane) * col_blocks + cb] = bits;
+  }
+}
+
+// greedy pass over the row blocks [rb0, rb0 + nrb) of one sample per workgroup; remv[] and the survivor count persist in
+// the workspace between chunks.  Same per-block scheme as nms_greedy.
+__global__ __launch_bounds__(256) void nms_greedy_rows(int n, int col_blocks, int rb0, int nrb, int chunk_rows, int max_keep,
+                                                       const unsigned long long* __restrict__ mask_all, unsigned long long* __restrict__ remv_all,
+                                                       long long* __restrict__ keep_all, int keep_stride, int* __restrict__ num_keep, int* __restrict__ done) {
+  const int s = blockIdx.x;
+  if (done[s]) return;
+  extern __shared__ unsigned long long remv[];
+  __shared__ unsigned long long s_kept;
+  __shared__ int s_count;
+  __shared__ int s_list[64];
+  const unsigned long long* mask = mask_all + static_cast<int64_t>(s) * chunk_rows * 64 * col_blocks;
+  unsigned long long* remv_g = remv_all + static_cast<int64_t>(s) * col_blocks;
+  long long* keep = keep_all + static_cast<int64_t>(s) * keep_stride;
+  for (int j = threadIdx.x; j < col_blocks; j += 256) remv[j] = rb0 ? remv_g[j] : 0ull;
+  if (threadIdx.x == 0) s_count = rb0 ? num_keep[s] : 0;
+  __syncthreads();
+  const int rb1 = min(rb0 + nrb, col_blocks);
+  bool full = false;
+  for (int b = rb0; b < rb1 && !full; ++b) {
+    const int lb = b - rb0;
+    if (threadIdx.x < 64) {
+      const int lane = threadIdx.x;
+      const int row = b * 64 + lane;
+      const unsigned long long diag = (row < n) ? mask[static_cast<int64_t>(lb * 64 + lane) * col_blocks + b] : 0ull;
+      const int lim = min(64, n - b * 64);
+      unsigned long long cur = remv[b];
+      if (lim < 64) cur |= ~0ull << lim;
+      unsigned long long kept = 0ull;
+#pragma unroll
+      for (int t = 0; t < 64; ++t) {
+        const unsigned long long d = lane_word(diag, t);
+        if (!((cur >> t) & 1ull)) { kept |= 1ull << t; cur |= d; }
+      }
+      if (lane == 0) s_kept = kept;
+      const int base = s_count;
+      if ((kept >> lane) & 1ull) {
+        const int rank = __popcll(kept & ((1ull << lane) - 1ull));
+        if (base + rank < keep_stride) keep[base + rank] = row;
+        s_list[rank] = lane;
+      }
+    }
+    __syncthreads();
+    const unsigned long long kept = s_kept;
+    const int total = s_count + __popcll(kept);
+    full = max_keep > 0 && total >= max_keep;   // uniform: every thread reads the same LDS words
+    const int ncols = col_blocks - (b + 1);
+    if (kept && ncols > 0 && !full) {
+      const int nk = __popcll(kept);
+      for (int e = threadIdx.x; e < nk * ncols; e += 256) {
+        const int ki = e / ncols, j = b + 1 + e % ncols;
+        const unsigned long long v = mask[static_cast<int64_t>(lb * 64 + s_list[ki]) * col_blocks + j];
+        if (v) atomicOr(&remv[j], v);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_count = total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int c = s_count;
+    num_keep[s] = (max_keep > 0 && c > max_keep) ? max_keep : c;
+    if (full || rb1 >= col_blocks) done[s] = 1;
+  }
+  if (!full && rb1 < col_blocks)
+    for (int j = threadIdx.x; j < col_blocks; j += 256) remv_g[j] = remv[j];
+}
+
 }  // namespace fv2p
 using namespace fv2p;
 
@@ -294,6 +396,54 @@ extern "C" int fv2p_nms(const float* boxes, int n, float thresh, int normal, int
   else hipLaunchKernelGGL(nms_mask<0>, dim3(tiles), dim3(64), 0, stream, n, thresh, boxes, cb, mask);
   hipLaunchKernelGGL(nms_greedy, dim3(1), dim3(256), cb * sizeof(unsigned long long), stream, n, cb, mask,
                      reinterpret_cast<long long*>(keep), num_keep);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
+static int nms_chunk_rows(int cb, int max_keep) {   // row blocks whose mask is resident at a time
+  if (max_keep <= 0) return cb;
+  const int first = (2 * max_keep + 63) / 64;
+  int longest = first, covered = first, cur = first;
+  while (covered < cb) { cur *= 4; covered += cur; longest = cur; }
+  return longest < cb ? longest : cb;
+}
+extern "C" size_t fv2p_nms_batch_ws_bytes(int batch, int n, int max_keep) {
+  const int64_t nn = n > 0 ? n : 1, cb = ceil_div(nn, 64);
+  const int64_t bb = batch > 0 ? batch : 1;
+  Sizer s;
+  s.take<unsigned long long>(static_cast<size_t>(bb) * nms_chunk_rows(static_cast<int>(cb), max_keep) * 64 * cb);
+  s.take<unsigned long long>(static_cast<size_t>(bb) * cb);
+  s.take<int>(static_cast<size_t>(bb));
+  return s.bytes();
+}
+extern "C" int fv2p_nms_batch(const float* boxes, int batch, int n, float thresh, int normal, int max_keep, int64_t* keep, int keep_stride,
+                              int* num_keep, void* ws, size_t ws_bytes, fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FV2P_REQUIRE(batch >= 0 && n >= 0 && (num_keep || !batch), FV2P_EINVAL, "nms_batch: bad arguments");
+  if (batch == 0) return 0;
+  FV2P_HIP(hipMemsetAsync(num_keep, 0, sizeof(int) * batch, stream));
+  if (n == 0) return 0;
+  FV2P_REQUIRE(boxes && keep && keep_stride >= (max_keep > 0 ? (max_keep < n ? max_keep : n) : n), FV2P_EINVAL, "nms_batch: keep buffer too short");
+  FV2P_REQUIRE(ws && ws_bytes >= fv2p_nms_batch_ws_bytes(batch, n, max_keep), FV2P_EWORKSPACE, "nms_batch: workspace too small");
+  const int cb = static_cast<int>(ceil_div(n, 64));
+  FV2P_REQUIRE(static_cast<size_t>(cb) * 8 <= 60000 && batch <= 65535, FV2P_ELIMIT, "nms_batch: too many boxes or samples");
+  const int chunk_rows = nms_chunk_rows(cb, max_keep);
+  Carver c(ws, ws_bytes);
+  unsigned long long* mask = c.take<unsigned long long>(static_cast<size_t>(batch) * chunk_rows * 64 * cb);
+  unsigned long long* remv = c.take<unsigned long long>(static_cast<size_t>(batch) * cb);
+  int* done = c.take<int>(static_cast<size_t>(batch));
+  FV2P_HIP(hipMemsetAsync(done, 0, sizeof(int) * batch, stream));
+  int rb0 = 0, span = max_keep > 0 ? (2 * max_keep + 63) / 64 : cb;
+  while (rb0 < cb) {
+    const int nrb = span < cb - rb0 ? span : cb - rb0;
+    const dim3 grid(cb, nrb, batch);
+    if (normal) hipLaunchKernelGGL(nms_mask_rows<1>, grid, dim3(64), 0, stream, n, thresh, boxes, cb, rb0, mask, chunk_rows, done);
+    else hipLaunchKernelGGL(nms_mask_rows<0>, grid, dim3(64), 0, stream, n, thresh, boxes, cb, rb0, mask, chunk_rows, done);
+    hipLaunchKernelGGL(nms_greedy_rows, dim3(batch), dim3(256), cb * sizeof(unsigned long long), stream, n, cb, rb0, nrb, chunk_rows, max_keep,
+                       mask, remv, reinterpret_cast<long long*>(keep), keep_stride, num_keep, done);
+    rb0 += nrb;
+    span *= 4;
+  }
   FV2P_LAUNCH_CHECK();
   return 0;
 }

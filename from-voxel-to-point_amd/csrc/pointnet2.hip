@@ -11,6 +11,7 @@
 // re-writes `temp` in global memory every round).
 #include "common.hpp"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace fv2p {
 
@@ -174,6 +175,31 @@ __global__ void group_points_batch_grad_k(int64_t total, int c, int n, int npoin
   const int64_t bc = t / per, rem = t % per;
   const int b = static_cast<int>(bc / c);
   atomicAdd(&grad_points[bc * n + idx[b * per + rem]], grad_out[t]);
+}
+// Same gradient with the scatter kept on chip: a wave owns one (b, c) row of grad_points, accumulates the row's
+// npoints*nsample contributions into its LDS slice with ds_add_f32 (neighbouring queries share points: collisions are
+// resolved by the LDS atomic unit instead of L2 round trips) and adds the slice to the row once.  grad_out is read
+// exactly once, coalesced; the sample's index list comes from L1/L2 (the WAVES rows of a workgroup share it).
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void group_points_batch_grad_lds_k(int64_t rows, int c, int n, int per, const float* __restrict__ grad_out,
+                                                                            const int* __restrict__ idx, float* __restrict__ grad_points) {
+  extern __shared__ float acc_lds[];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * WAVES + w;
+  if (row >= rows) return;   // no workgroup barrier below: waves are independent
+  float* a = acc_lds + w * n;
+  for (int i = lane; i < n; i += 64) a[i] = 0.f;
+  const float* g = grad_out + row * per;
+  const int* id = idx + (row / c) * per;
+  int e = lane;
+  for (; e + 192 < per; e += 256) {   // four independent loads in flight per lane
+    const int i0 = id[e], i1 = id[e + 64], i2 = id[e + 128], i3 = id[e + 192];
+    const float g0 = g[e], g1 = g[e + 64], g2 = g[e + 128], g3 = g[e + 192];
+    atomicAdd(&a[i0], g0); atomicAdd(&a[i1], g1); atomicAdd(&a[i2], g2); atomicAdd(&a[i3], g3);
+  }
+  for (; e < per; e += 64) atomicAdd(&a[id[e]], g[e]);
+  float* out = grad_points + row * n;
+  for (int i = lane; i < n; i += 64) out[i] += a[i];
 }
 // gather: points (B,C,N), idx (B,M) -> out (B,C,M)
 __global__ void gather_points_k(int64_t total, int c, int n, int m, const float* __restrict__ points, const int* __restrict__ idx,
@@ -503,6 +529,160 @@ __global__ __launch_bounds__(1024) void fps_bucket_k(int n, int m, int bs, const
     if (pr[q] != 0xffffffffu) temp[index_of(pr[q])] = pt[q];
 }
 
+// ---- wave-bucket furthest point sampling -------------------------------------------------------------------------------
+// Third form of the same sampler (bit-identical picks).  fps_bucket_k gives every THREAD a bucket of PPT Morton-neighbours:
+// a touched bucket is a serial PPT-point loop in one lane while 63 lanes idle, and 16 waves repeat the per-round
+// bookkeeping on four SIMDs.  Here a bucket is the 64 points one WAVE holds in one register slot (lane = point), eight
+// waves (two per SIMD) hold S slots each:
+//   * skip test: lanes 0..S-1 of a wave evaluate the box bound of the wave's S buckets at once (one ballot);
+//   * a touched bucket updates its 64 points with one pass of VALU ops and re-derives its maximum with a DPP reduction;
+//   * arg-max = (float maximum, then smallest reference priority among the points that hold it): two 32-bit reductions,
+//     exact for ties (lattice inputs, exhausted clouds) without a 64-bit compare chain;
+//   * per round one LDS exchange of 8 wave candidates and one barrier (double buffered).
+// Points, running distances and priorities stay in registers for all m rounds (5*S VGPRs: S <= 40, n <= 20480).
+// Wave reductions as explicit DPP instruction chains: v_max/min_*_dpp take the permuted operand directly (one instruction per
+// step; hipcc's update_dpp + fmaxf lowers to mov, mov_dpp, canonicalise, max).  quad_perm xor-1, xor-2, row_half_mirror and
+// row_mirror leave every lane of a 16-lane row with the row's result; row_bcast:15 / :31 carry it into lane 63.  The two wait
+// states a DPP read needs after the VALU write of its source are the s_nop 1 in front of every step.
+#define FV2P_ROW_CHAIN(op)                                                        \
+  "s_nop 1\n\t" op " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
+  "s_nop 1\n\t" op " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" \
+  "s_nop 1\n\t" op " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"     \
+  "s_nop 1\n\t" op " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+#define FV2P_WAVE_CHAIN(op)                                                      \
+  FV2P_ROW_CHAIN(op)                                                             \
+  "s_nop 1\n\t" op " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"       \
+  "s_nop 1\n\t" op " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"       \
+  "s_nop 1"
+__device__ __forceinline__ float row_max_f32(float v) { asm volatile(FV2P_ROW_CHAIN("v_max_f32_dpp") "s_nop 1" : "+v"(v)); return v; }
+__device__ __forceinline__ uint32_t row_min_u32(uint32_t v) { asm volatile(FV2P_ROW_CHAIN("v_min_u32_dpp") "s_nop 1" : "+v"(v)); return v; }
+__device__ __forceinline__ float wave_max_f32(float v) {   // wave-uniform
+  asm volatile(FV2P_WAVE_CHAIN("v_max_f32_dpp") : "+v"(v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_min_f32(float v) {
+  asm volatile(FV2P_WAVE_CHAIN("v_min_f32_dpp") : "+v"(v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+  asm volatile(FV2P_WAVE_CHAIN("v_min_u32_dpp") : "+v"(v));
+  return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
+}
+__device__ __forceinline__ float lane_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+
+constexpr int kFpsWaves = 8;
+template <int S>
+__global__ __launch_bounds__(kFpsWaves * 64) void fps_wave_k(int n, int m, int bs, const float* __restrict__ dataset,
+                                                             const uint64_t* __restrict__ keys, float* __restrict__ temp, int* __restrict__ idxs) {
+  if (m <= 0) return;
+  extern __shared__ uint32_t s_prio[];   // [S][kFpsWaves * 64]: reference priority of every point (read only when its bucket is touched)
+  __shared__ __attribute__((aligned(16))) float s_bucket[kFpsWaves][S][4];   // candidate of every bucket: x, y, z, -
+  __shared__ __attribute__((aligned(16))) uint32_t s_wave[2][kFpsWaves][4];   // candidate of every wave: max bits, priority, slot, -
+  int log2bs = 0;
+  while ((1 << (log2bs + 1)) <= bs) ++log2bs;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  dataset += static_cast<int64_t>(b) * n * 3;
+  keys += static_cast<int64_t>(b) * n;
+  temp += static_cast<int64_t>(b) * n;
+  idxs += static_cast<int64_t>(b) * m;
+  auto prio_of = [&](int k) -> uint32_t {   // reference tie order of original index k (see fps_bucket_k): smaller wins
+    const uint32_t owner = static_cast<uint32_t>(k) & static_cast<uint32_t>(bs - 1);
+    return ((__brev(owner) >> (32 - log2bs)) << 16) | static_cast<uint32_t>(k >> log2bs);
+  };
+  auto index_of = [&](uint32_t pr) -> int { return static_cast<int>(((pr & 0xffffu) << log2bs) | (__brev(pr >> 16) >> (32 - log2bs))); };
+  float px[S], py[S], pz[S], pt[S];
+  // lane s < S of this wave keeps the state of the wave's bucket s: box, running maximum, priority of the point holding it
+  float lo0 = 0.f, lo1 = 0.f, lo2 = 0.f, hi0 = 0.f, hi1 = 0.f, hi2 = 0.f, bmax = -2.f;
+  uint32_t bprio = 0xffffffffu;
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int pos = (s * kFpsWaves + w) * 64 + lane;   // neighbouring buckets of the Morton order go to different waves
+    const bool ok = pos < n;
+    const int k = static_cast<int>(keys[ok ? pos : n - 1] & 0xffffffull);   // clamped: no divergent load
+    const float x = dataset[k * 3], y = dataset[k * 3 + 1], z = dataset[k * 3 + 2], t = temp[k];
+    s_prio[s * (kFpsWaves * 64) + tid] = ok ? prio_of(k) : 0xffffffffu;   // only this thread ever reads it back
+    px[s] = ok ? x : 0.f;
+    py[s] = ok ? y : 0.f;
+    pz[s] = ok ? z : 0.f;
+    pt[s] = ok ? t : -2.f;   // an empty slot never holds a maximum (running distances are >= 0)
+    // box of the bucket, kept by lane s
+    const float bx0 = wave_min_f32(ok ? x : INFINITY), bx1 = wave_max_f32(ok ? x : -INFINITY);
+    const float by0 = wave_min_f32(ok ? y : INFINITY), by1 = wave_max_f32(ok ? y : -INFINITY);
+    const float bz0 = wave_min_f32(ok ? z : INFINITY), bz1 = wave_max_f32(ok ? z : -INFINITY);
+    if (lane == s) { lo0 = bx0; hi0 = bx1; lo1 = by0; hi1 = by1; lo2 = bz0; hi2 = bz1; }
+    __builtin_amdgcn_sched_barrier(0);   // one slot at a time: the S loads are not all hoisted to the top (register pressure)
+  }
+  // bucket s: recompute (max, priority, candidate coordinates) from the registers; wave-uniform control flow
+  auto refresh = [&](auto, const int s) {   // s is a constant after unrolling
+    const uint32_t myp = s_prio[s * (kFpsWaves * 64) + tid];   // issued first: its latency hides behind the max reduction
+    const float mx = wave_max_f32(pt[s]);
+    const uint32_t pm = wave_min_u32(pt[s] == mx ? myp : 0xffffffffu);
+    const int leader = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(__ballot(myp == pm && pt[s] == mx))) - 1);
+    const float cx = lane_f(px[s], leader), cy = lane_f(py[s], leader), cz = lane_f(pz[s], leader);
+    if (lane == s) { bmax = mx; bprio = pm; }
+    if (lane == 0) *reinterpret_cast<float4*>(&s_bucket[w][s][0]) = make_float4(cx, cy, cz, 0.f);
+  };
+#pragma unroll
+  for (int q = 0; q < S; ++q) refresh(std::integral_constant<int, 0>{}, q);
+  // wave candidate from the S bucket states
+  uint32_t wbits = 0, wprio = 0xffffffffu, wslot = 0;
+  auto wave_best = [&]() {
+    const float v = lane < S ? bmax : -3.f;
+    const float mx = wave_max_f32(v);
+    const uint32_t pm = wave_min_u32((lane < S && v == mx) ? bprio : 0xffffffffu);
+    wslot = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(__ballot(lane < S && v == mx && bprio == pm))) - 1));
+    wbits = __float_as_uint(fmaxf(mx, 0.f));   // every real maximum is >= 0: unsigned order == float order; empty wave -> 0 with priority ~0
+    wprio = pm;
+  };
+  wave_best();
+  float x1 = dataset[0], y1 = dataset[1], z1 = dataset[2];
+  if (tid == 0) idxs[0] = 0;
+  for (int j = 1; j < m; ++j) {
+    // which of my wave's buckets can the new point still lower?  (box bound in sqdist's operation order: exact skip)
+    const float gx = fmaxf(fmaxf(lo0 - x1, x1 - hi0), 0.f);
+    const float gy = fmaxf(fmaxf(lo1 - y1, y1 - hi1), 0.f);
+    const float gz = fmaxf(fmaxf(lo2 - z1, z1 - hi2), 0.f);
+    const float lb = gx * gx + gy * gy + gz * gz;
+    const uint64_t touch = __ballot(lane < S && lb < bmax);
+    if (touch) {
+      // straight-line, wave-uniform tests (groups of eight first): every slot's update is a plain diamond, so the register
+      // arrays are updated in place (a switch over the slot made hipcc keep two copies of pt[] and hoist the distance passes)
+#pragma unroll
+      for (int g = 0; g < S; g += 8) {
+        if ((touch >> g) & 0xffull) {
+#pragma unroll
+          for (int q = g; q < g + 8; ++q) {
+            if ((touch >> q) & 1ull) {
+              float ax = x1, ay = y1, az = z1;
+              asm volatile("" : "+v"(ax), "+v"(ay), "+v"(az));   // pins the distance pass inside its branch
+              pt[q] = fminf(sqdist(px[q], py[q], pz[q], ax, ay, az), pt[q]);
+              refresh(std::integral_constant<int, 0>{}, q);
+            }
+          }
+        }
+      }
+      wave_best();
+    }
+    const int buf = j & 1;
+    if (lane == 0) *reinterpret_cast<uint4*>(&s_wave[buf][w][0]) = make_uint4(wbits, wprio, wslot, 0u);
+    lds_barrier();
+    // 8 wave candidates, one per lane of the first row; every wave derives the same winner
+    const uint4 c = lane < kFpsWaves ? *reinterpret_cast<const uint4*>(&s_wave[buf][lane][0]) : make_uint4(0u, 0xffffffffu, 0u, 0u);
+    const float gmax = lane_f(row_max_f32(__uint_as_float(c.x)), 0);
+    const uint32_t gprio = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(row_min_u32(__uint_as_float(c.x) == gmax ? c.y : 0xffffffffu)), 0));
+    const int gw = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(__ballot(lane < kFpsWaves && __uint_as_float(c.x) == gmax && c.y == gprio))) - 1);
+    const int gslot = __builtin_amdgcn_readlane(static_cast<int>(c.z), gw);
+    const float4 p = *reinterpret_cast<const float4*>(&s_bucket[gw][gslot][0]);
+    x1 = p.x; y1 = p.y; z1 = p.z;
+    if (tid == 0) idxs[j] = index_of(gprio);
+  }
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const uint32_t myp = s_prio[s * (kFpsWaves * 64) + tid];
+    if (myp != 0xffffffffu) temp[index_of(myp)] = pt[s];
+  }
+}
+
 // ------------------------------------------------------------------ three_nn / interpolate --------
 // one query per thread, known points staged through LDS; strict '<' keeps the lowest index on ties
 // (interpolate_gpu.cu:37-55; the reference's double best* hold float values: float compares are identical).
@@ -730,7 +910,21 @@ extern "C" int fv2p_group_points_batch_grad(int b, int c, int n, int npoints, in
   const int64_t total = static_cast<int64_t>(b) * c * npoints * nsample;
   if (total <= 0) return 0;
   FV2P_REQUIRE(grad_out && idx && grad_points, FV2P_EINVAL, "group_points_grad: null pointer");
-  hipLaunchKernelGGL(group_points_batch_grad_k, G1D(total), 0, STREAM(s), total, c, n, npoints, nsample, grad_out, idx, grad_points);
+  const int64_t rows = static_cast<int64_t>(b) * c;
+  const int64_t per = static_cast<int64_t>(npoints) * nsample;
+  if (n <= 16384 && per >= 64 && per < (1ll << 30) && rows < (1ll << 30)) {   // one row's accumulator fits a wave's share of LDS
+    const int iper = static_cast<int>(per);
+#define FV2P_GG(W)                                                                                                          \
+  hipLaunchKernelGGL((group_points_batch_grad_lds_k<W>), dim3(static_cast<unsigned>((rows + W - 1) / W)), dim3(W * 64),    \
+                     static_cast<size_t>(W) * n * sizeof(float), STREAM(s), rows, c, n, iper, grad_out, idx, grad_points)
+    if (n <= 2048) FV2P_GG(8);
+    else if (n <= 4096) FV2P_GG(4);
+    else if (n <= 8192) FV2P_GG(2);
+    else FV2P_GG(1);
+#undef FV2P_GG
+  } else {
+    hipLaunchKernelGGL(group_points_batch_grad_k, G1D(total), 0, STREAM(s), total, c, n, npoints, nsample, grad_out, idx, grad_points);
+  }
   FV2P_LAUNCH_CHECK();
   return 0;
 }
@@ -773,7 +967,7 @@ extern "C" int fv2p_group_points_stack_grad(int b, int m, int c, int n, int nsam
 
 // measured on MI355X: 1.43-1.52 us/round against 1.62 for the plain kernel at n = 16384; the Morton pre-pass (bbox, keys,
 // 3-4 radix passes) costs ~0.15 ms, so short sampling runs stay on the plain kernel
-static bool fps_bucketed_applies(int n, int m) { return n >= 2048 && n <= 16384 && m >= 1024; }
+static bool fps_bucketed_applies(int n, int m) { return n >= 2048 && n <= 48 * kFpsWaves * 64 && m >= 1024; }
 
 extern "C" size_t fv2p_furthest_point_sampling_ws_bytes(int b, int n) {
   const int64_t total = static_cast<int64_t>(b > 0 ? b : 1) * (n > 0 ? n : 1);
@@ -807,8 +1001,30 @@ extern "C" int fv2p_furthest_point_sampling(int b, int n, int m, const float* da
     int sbits = 0;
     while ((1 << sbits) < b) ++sbits;
     if (int rc = radix_sort_u64(keys, tmp, total, 24, 48 + sbits, rws, rb, st)) return rc;
+    static int form = -1;   // FV2P_FPS_FORM=thread keeps the per-thread buckets of round 1 (the parity tests run every form)
+    if (form < 0) { const char* e = getenv("FV2P_FPS_FORM"); form = (e && e[0] == 't') ? 0 : 1; }
+    const int slots = static_cast<int>(ceil_div(n, kFpsWaves * 64));
     const int ppt = static_cast<int>(ceil_div(n, 1024));
-    if (ppt <= 4) hipLaunchKernelGGL((fps_bucket_k<4>), dim3(b), dim3(1024), 0, st, n, m, bs, dataset, keys, temp, idxs);
+    if (form == 1 || ppt > 16) {
+#define FV2P_FPS(SS)                                                                                                       \
+  do {                                                                                                                     \
+    const size_t lds = static_cast<size_t>(SS) * kFpsWaves * 64 * sizeof(uint32_t);                                         \
+    static bool big = false;                                                                                               \
+    if (lds > 48 * 1024 && !big) {                                                                                         \
+      FV2P_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_wave_k<SS>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                   static_cast<int>(lds)));                                                                \
+      big = true;                                                                                                          \
+    }                                                                                                                      \
+    hipLaunchKernelGGL((fps_wave_k<SS>), dim3(b), dim3(kFpsWaves * 64), lds, st, n, m, bs, dataset, keys, temp, idxs);      \
+  } while (0)
+      if (slots <= 8) FV2P_FPS(8);
+      else if (slots <= 16) FV2P_FPS(16);
+      else if (slots <= 24) FV2P_FPS(24);
+      else if (slots <= 32) FV2P_FPS(32);
+      else if (slots <= 40) FV2P_FPS(40);
+      else FV2P_FPS(48);
+#undef FV2P_FPS
+    } else if (ppt <= 4) hipLaunchKernelGGL((fps_bucket_k<4>), dim3(b), dim3(1024), 0, st, n, m, bs, dataset, keys, temp, idxs);
     else if (ppt <= 8) hipLaunchKernelGGL((fps_bucket_k<8>), dim3(b), dim3(1024), 0, st, n, m, bs, dataset, keys, temp, idxs);
     else hipLaunchKernelGGL((fps_bucket_k<16>), dim3(b), dim3(1024), 0, st, n, m, bs, dataset, keys, temp, idxs);
     FV2P_LAUNCH_CHECK();

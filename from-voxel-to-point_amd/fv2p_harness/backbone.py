@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 
 from pcdet.ops import spconv
+from pcdet.ops.spconv.norm import batch_norm_relu
 
 
 def _block(cin, cout, k, norm_fn, indice_key, stride=1, padding=0, conv_type="subm"):
@@ -34,14 +35,31 @@ class _BasicBlock(spconv.SparseModule):
         self.bn2 = norm_fn(planes)
 
     def forward(self, x):
-        identity = x
-        out = self.conv1(x)
-        out.features = self.relu(self.bn1(out.features))
-        out = self.conv2(out)
-        out.features = self.bn2(out.features)
-        out.features = out.features + identity.features
-        out.features = self.relu(out.features)
+        identity = x.features
+        out = _conv_bn(self.conv1, self.bn1, self.relu, x)
+        out = _conv_bn(self.conv2, self.bn2, None, out)
+        out.features = self.relu(out.features + identity)
         return out
+
+
+def bn_act(bn, feats, relu=None):
+    """BatchNorm1d (+ReLU) on [N, C] rows: the fused HIP op where it applies (GPU, fp32, plain modules), else the modules."""
+    y = batch_norm_relu(bn, feats, relu)
+    if y is None:
+        y = bn(feats)
+        y = relu(y) if relu is not None else y
+    return y
+
+
+def _conv_bn(conv, bn, relu, x):
+    """conv -> BatchNorm1d (-> ReLU) the way SparseSequential runs the reference's post_act_block: offered to the conv as one
+    fused call (BatchNorm sums taken in the conv epilogue), else module by module."""
+    out = conv(x, _post=(bn, relu))
+    if getattr(out, "_fv2p_post_done", False):
+        out._fv2p_post_done = False
+    else:
+        out.features = bn_act(bn, out.features, relu)
+    return out
 
 
 class VoxelBackBone8x(nn.Module):

@@ -33,7 +33,7 @@ from pcdet.ops.roiaware_pool3d import roiaware_pool3d_utils
 from pcdet.ops.roipoint_pool3d import roipoint_pool3d_utils
 from pcdet.models.backbones_3d.pfe import bev_grid_pooling
 
-from .backbone import VoxelResBackBone8x
+from .backbone import VoxelResBackBone8x, bn_act
 
 TWO_PI = 2.0 * math.pi
 
@@ -147,6 +147,22 @@ def mlp1d(cin, widths, out=None, conv=False, bn_kw=None, dropout_after_first=Non
     if out is not None:
         layers.append(mk(cin, out, True))
     return nn.Sequential(*layers)
+
+
+def run_rows(seq, x):
+    """nn.Sequential of Linear / BatchNorm1d / ReLU over [N, C] rows, with every BatchNorm1d (+ReLU) pair as one fused op."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.BatchNorm1d) and x.dim() == 2:
+            relu = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU) else None
+            x = bn_act(m, x, relu)
+            i += 1 + (relu is not None)
+        else:
+            x = m(x)
+            i += 1
+    return x
 
 
 # ---------------------------------------------------------------- dense BEV part ----------------------
@@ -289,7 +305,7 @@ class LateralBlock(nn.Module):
         lateral = pn2_stack.three_interpolate(level.features, nn_idx, weight)
         if self.net is None:
             return lateral
-        return F.relu(self.net(lateral) + self.downsample(bottom))
+        return F.relu(run_rows(self.net, lateral) + run_rows(self.downsample, bottom))
 
 
 class V2PDecoder(nn.Module):
@@ -329,16 +345,35 @@ class V2PDecoder(nn.Module):
             out.append(xyz[idx])
         return torch.stack(out)                                                  # (B, M, 3)
 
-    def forward(self, clouds, levels):
+    def start_sampling(self, clouds):
+        """Enqueues sample_keypoints on a side stream (GPU tensors only); returns a handle for forward()."""
+        if not clouds[0].is_cuda:
+            return None
+        dev = clouds[0].device
+        side = self.__dict__.get("_side_stream")
+        if side is None or side.device != dev:
+            side = self.__dict__["_side_stream"] = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            key = self.sample_keypoints(clouds)
+        return key, side
+
+    def forward(self, clouds, levels, key_job=None):
         cfg = self.cfg
-        key = self.sample_keypoints(clouds)
+        if key_job is None:
+            key = self.sample_keypoints(clouds)
+        else:
+            key, side = key_job
+            torch.cuda.current_stream(key.device).wait_stream(side)
+            key.record_stream(torch.cuda.current_stream(key.device))
         b, m, _ = key.shape
         key_xyz = key.view(-1, 3)
         key_cnt = torch.full((b,), m, dtype=torch.int32, device=key.device)
         x = self.decode_block_init(levels[cfg.init_source], None, key_xyz, key_cnt)
         for name, _, _, _ in cfg.decode_levels:
             x = self.decode_blocks_map[name](levels[name], x, key_xyz, key_cnt)
-        return key, self.decode_block_out(x)
+        return key, run_rows(self.decode_block_out, x)
 
 
 # ---------------------------------------------------------------- point head ---------------------------
@@ -365,12 +400,34 @@ class PointHead(nn.Module):
         return labels.view(-1)
 
     def forward(self, key, feats, gt):
-        logits = self.cls_layers(feats)                                          # (B*M, 1)
+        logits = run_rows(self.cls_layers, feats)                                # (B*M, 1)
         labels = self.assign(key, gt)
         pos = labels > 0
         w = ((labels == 0) | pos).float() / pos.sum().float().clamp_min(1.0)
         loss = sigmoid_focal(logits, pos.float().unsqueeze(-1), w).sum() * self.cfg.point_cls_weight
         return loss, torch.sigmoid(logits).max(dim=-1).values
+
+
+def sa_msg_grid(sa, xyz, features, centres):
+    """PointnetSAModuleMSG.forward (pointnet2_modules.py:30-62) for the bn=False, use_xyz=True, max-pool module of the RoI head,
+    with the first shared-MLP layer taken out of the neighbourhood: it is linear in [xyz_j - c_i ; f_j], so
+    W1 [xyz_j - c_i ; f_j] = (W1f f_j + W1x xyz_j) - W1x c_i is one GEMM per POINT (512 per RoI) and one per CENTRE (216) instead
+    of one per (centre, sample) pair (216 x 16 / 32); what is grouped is the 64-channel product, not the 131-channel input.
+    Same parameters, same result up to fp32 summation order.  xyz (R, N, 3), features (R, C, N), centres (R, M, 3) -> (R, sum C_k, M)."""
+    outs = []
+    xyz_t = xyz.transpose(1, 2)                                                  # (R, 3, N)
+    ctr_t = centres.transpose(1, 2)                                              # (R, 3, M)
+    for grouper, mlp in zip(sa.groupers, sa.mlps):
+        layers = list(mlp)
+        w1 = layers[0].weight[:, :, 0, 0]                                        # (C1, 3 + C)
+        per_point = (torch.matmul(w1[:, 3:], features) + torch.matmul(w1[:, :3], xyz_t)).contiguous()   # (R, C1, N)
+        per_centre = torch.matmul(w1[:, :3], ctr_t)                              # (R, C1, M)
+        idx = pn2_batch.ball_query(grouper.radius, grouper.nsample, xyz, centres)
+        h = pn2_batch.grouping_operation(per_point, idx) - per_centre.unsqueeze(-1)                     # (R, C1, M, ns)
+        for layer in layers[1:]:
+            h = layer(h)
+        outs.append(h.amax(dim=-1))
+    return torch.cat(outs, dim=1)
 
 
 # ---------------------------------------------------------------- RoI head ------------------------------
@@ -429,16 +486,15 @@ class IoUGuidedRoIHead(nn.Module):
         cfg = self.cfg
         b = scores.shape[0]
         top_s, top_i = torch.topk(scores, k=min(cfg.nms_pre, scores.shape[1]), dim=1)     # descending: the order NMS wants
+        cand = torch.gather(boxes, 1, top_i.unsqueeze(-1).expand(-1, -1, 7)).contiguous()
+        keep, cnt = iou3d_nms_cuda.nms_batch_device(cand, cfg.nms_thresh, cfg.nms_post)   # the first nms_post survivors per sample
+        k = keep.shape[1]
+        valid = torch.arange(k, device=boxes.device)[None] < cnt[:, None]
+        keep = torch.where(valid, keep, torch.zeros_like(keep))
         rois = boxes.new_zeros(b, cfg.nms_post, 7)
         roi_scores = boxes.new_zeros(b, cfg.nms_post)
-        slot = torch.arange(cfg.nms_post, device=boxes.device)
-        for i in range(b):
-            cand = boxes[i][top_i[i]].contiguous()
-            keep, cnt = iou3d_nms_cuda.nms_device(cand, cfg.nms_thresh, False)
-            k = keep[:cfg.nms_post].clamp(0, cand.shape[0] - 1)
-            valid = slot[:k.shape[0]] < cnt
-            rois[i, :k.shape[0]] = torch.where(valid[:, None], cand[k], rois[i, :k.shape[0]])
-            roi_scores[i, :k.shape[0]] = torch.where(valid, top_s[i][k], roi_scores[i, :k.shape[0]])
+        rois[:, :k] = torch.gather(cand, 1, keep.unsqueeze(-1).expand(-1, -1, 7)) * valid.unsqueeze(-1)
+        roi_scores[:, :k] = torch.gather(top_s, 1, keep) * valid
         return rois, roi_scores
 
     # -- ProposalTargetLayer.sample_rois_for_rcnn / subsample_rois (proposal_target_layer.py:92-217) without host round trips
@@ -535,7 +591,7 @@ class IoUGuidedRoIHead(nn.Module):
         g_bev = self.bev_grid_pool_layer({"spatial_features_before_head": bev, "spatial_features_stride": 8}, world.view(b, -1, 3))
         g_bev = g_bev.view(world.shape[0], world.shape[1], -1).permute(0, 2, 1).contiguous()
         # point stream: multi-scale ball query around the grid points (:258-275)
-        _, g_pt = self.SA_modules[0](pooled[..., 0:3].contiguous(), merged, local.contiguous())
+        g_pt = sa_msg_grid(self.SA_modules[0], pooled[..., 0:3].contiguous(), merged, local.contiguous())
         grid = torch.cat((g_pt, g_bev), dim=1)
         pc = self.grid_interact_fc_layer(grid.view(grid.shape[0], -1, 1))
         # corner geometry stream (feature_adaptor/nn_modules.py:6-60): roi-frame corners without rotation or centre
@@ -603,12 +659,15 @@ class FV2PDetector(nn.Module):
         """clouds: list of (N_b, 4) point tensors; voxel_features / voxel_coords: MeanVFE output + (b, z, y, x) coords of
         the same clouds; gt_boxes (B, G, 8) zero padded; uniforms (B, nms_post + roi_per_image) in [0, 1)."""
         b = len(clouds)
+        # key-point sampling needs the raw points only: it runs beside the two backbones on its own stream (three workgroups
+        # for 16 k dependent rounds) and is joined where the decoder starts
+        key_job = self.post_pfe.start_sampling(clouds)
         out, levels = self.backbone_3d(voxel_features, voxel_coords, b)
         dense = out.dense()                                                      # HeightCompression (height_compression.py:10-26)
         spatial = dense.view(b, dense.shape[1] * dense.shape[2], dense.shape[3], dense.shape[4])
         bev = self.backbone_2d(spatial)
         loss_rpn, prop_scores, prop_boxes = self.dense_head(bev, gt_boxes)
-        key, point_feats = self.post_pfe(clouds, levels)
+        key, point_feats = self.post_pfe(clouds, levels, key_job)
         loss_point, point_scores = self.point_head(key, point_feats, gt_boxes)
         loss_rcnn, aux = self.roi_head(key, point_feats, point_scores, bev, prop_scores, prop_boxes, gt_boxes, uniforms)
         if self.taps is not None:

@@ -82,5 +82,11 @@ class BEVGridPooling(nn.Module):
         batch_size, num_keypoints, _ = keypoints.shape
         feats = self.interpolate_from_bev_features(keypoints, batch_dict['spatial_features_before_head'], batch_size,
                                                    bev_stride=batch_dict['spatial_features_stride'])
-        feats = self.point_bev_feature_compress(feats.view(batch_size * num_keypoints, -1))
+        feats = feats.view(batch_size * num_keypoints, -1)
+        mods = list(self.point_bev_feature_compress)
+        if len(mods) == 3:   # Linear -> BatchNorm1d -> ReLU: the pair after the GEMM as one fused op where it applies
+            from pcdet.ops.spconv.norm import batch_norm_relu
+            feats = mods[0](feats)
+            fused = batch_norm_relu(mods[1], feats, mods[2])
+            feats = fused if fused is not None else mods[2](mods[1](feats))
         return feats.view(batch_size, num_keypoints, -1)

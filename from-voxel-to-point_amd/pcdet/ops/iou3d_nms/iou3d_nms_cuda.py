@@ -54,6 +54,22 @@ def nms_device(boxes, thresh, normal=False):
     return keep, cnt
 
 
+def nms_batch_device(boxes, thresh, max_keep=0, normal=False):
+    """boxes (B, n, 7), each sample sorted by descending score -> (keep (B, K) int64, count (B) int32) on the device, with
+    K = min(max_keep, n) survivors per sample at most (max_keep <= 0: all of them, K = n).  One launch sequence for the whole
+    batch, no host synchronisation; rows of `keep` past `count` are undefined."""
+    _check(boxes, "boxes")
+    b, n, _ = boxes.shape
+    k = min(max_keep, n) if max_keep > 0 else n
+    keep = torch.empty((b, max(k, 1)), dtype=torch.int64, device=boxes.device)
+    cnt = torch.zeros((b,), dtype=torch.int32, device=boxes.device)
+    with _nat.device_guard(boxes.device):
+        ws = _nat.workspace(_nat.lib().fv2p_nms_batch_ws_bytes(b, n, int(max_keep)), boxes.device)
+        _nat.call("fv2p_nms_batch", boxes, b, n, float(thresh), int(bool(normal)), int(max_keep), keep, keep.shape[1], cnt, ws, ws.numel(),
+                  _nat.stream())
+    return keep, cnt
+
+
 def nms_gpu(boxes, keep, nms_overlap_thresh):
     return _nms(boxes, keep, nms_overlap_thresh, False)
 

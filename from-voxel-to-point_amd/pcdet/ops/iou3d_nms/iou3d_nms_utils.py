@@ -47,25 +47,32 @@ def boxes_iou3d_gpu(boxes_a, boxes_b):
     return iou3d
 
 
-def _nms(boxes, scores, thresh, pre_maxsize, normal):
+def _nms(boxes, scores, thresh, pre_maxsize, normal, post_maxsize=None):
     assert boxes.shape[1] == 7
     order = scores.sort(0, descending=True)[1]
     if pre_maxsize is not None:
         order = order[:pre_maxsize]
     boxes = boxes[order].contiguous()
-    keep, cnt = iou3d_nms_cuda.nms_device(boxes, thresh, normal)
+    if post_maxsize is not None and post_maxsize > 0:
+        # the caller keeps selected[:NMS_POST_MAXSIZE] (model_nms_utils.py:16-20): the greedy pass stops at that survivor
+        keep, cnt = iou3d_nms_cuda.nms_batch_device(boxes.unsqueeze(0), thresh, int(post_maxsize), normal)
+        keep = keep[0]
+    else:
+        keep, cnt = iou3d_nms_cuda.nms_device(boxes, thresh, normal)
     num_out = int(cnt.item())  # the survivor count is a tensor shape: one 4-byte D2H instead of the N*N/8-byte mask
     return order[keep[:num_out]].contiguous(), None
 
 
 def nms_gpu(boxes, scores, thresh, pre_maxsize=None, **kwargs):
-    """Rotated NMS: returns (indices into `boxes` of the survivors, in descending score order; None) (:494-509)."""
-    return _nms(boxes, scores, thresh, pre_maxsize, False)
+    """Rotated NMS: returns (indices into `boxes` of the survivors, in descending score order; None) (:494-509).
+    The reference's callers pass their whole NMS config as keyword arguments (model_nms_utils.py:14-16); when it carries
+    NMS_POST_MAXSIZE only that many survivors are produced — the caller slices the list to exactly that length."""
+    return _nms(boxes, scores, thresh, pre_maxsize, False, kwargs.get("NMS_POST_MAXSIZE"))
 
 
 def nms_normal_gpu(boxes, scores, thresh, **kwargs):
     """Axis-aligned (heading ignored) NMS (:512-526)."""
-    return _nms(boxes, scores, thresh, None, True)
+    return _nms(boxes, scores, thresh, None, True, kwargs.get("NMS_POST_MAXSIZE"))
 
 
 def batch_boxes_iou3d_gpu(boxes_a, boxes_b):

@@ -245,6 +245,13 @@ int fv2p_boxes_iou_bev(const float* boxes_a, int num_a, const float* boxes_b, in
 size_t fv2p_nms_ws_bytes(int n);
 int fv2p_nms(const float* boxes, int n, float thresh, int normal, int64_t* keep, int* num_keep, void* ws,
              size_t ws_bytes, fv2p_stream_t stream);
+/* Batched, truncated form for proposal layers (roi_head_template.py:46-101 loops `class_agnostic_nms` over the samples and
+ * keeps `selected[:NMS_POST_MAXSIZE]`, model_nms_utils.py:16-20): boxes [batch, n, 7] sorted by descending score per sample,
+ * keep [batch, keep_stride] i64, num_keep [batch] i32, both on the device.  max_keep > 0 stops each sample's greedy pass
+ * at its max_keep-th survivor (identical to the head of the full list); max_keep <= 0 keeps all. */
+size_t fv2p_nms_batch_ws_bytes(int batch, int n, int max_keep);
+int fv2p_nms_batch(const float* boxes, int batch, int n, float thresh, int normal, int max_keep, int64_t* keep,
+                   int keep_stride, int* num_keep, void* ws, size_t ws_bytes, fv2p_stream_t stream);
 int fv2p_boxes_iou_bev_cpu(const float* boxes_a, int num_a, const float* boxes_b, int num_b, float* ans_iou);
 
 /* ---- A15 / A18: point-in-box, RoI-aware voxel pooling, RoI point pooling ------------------------

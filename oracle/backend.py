@@ -59,6 +59,17 @@ def _nms(boxes, n, thresh, normal, keep, cnt, ws, ws_bytes, stream):
     cnt.fill_(len(k))
 
 
+def _nms_batch(boxes, b, n, thresh, normal, max_keep, keep, keep_stride, cnt, ws, ws_bytes, stream):
+    bx = _np(boxes).reshape(b, n, 7)
+    keep.zero_()
+    for s in range(b):
+        k = oracle.nms(bx[s], -np.arange(n, dtype=np.float32), thresh, None, bool(normal))
+        if max_keep > 0:
+            k = k[:max_keep]      # model_nms_utils.py:20: selected[:NMS_POST_MAXSIZE]
+        keep[s, :len(k)] = torch.from_numpy(np.asarray(k, np.int64))
+        cnt[s] = len(k)
+
+
 def _overlap_bev(a, na, bb, nb, out, stream):
     _fill(out, oracle.boxes_bev(_np(a).reshape(na, 7), _np(bb).reshape(nb, 7), "overlap"))
 
@@ -107,6 +118,7 @@ _TABLE = {
     "fv2p_furthest_point_sampling": _fps,
     "fv2p_points_in_boxes": _points_in_boxes,
     "fv2p_nms": _nms,
+    "fv2p_nms_batch": _nms_batch,
     "fv2p_boxes_overlap_bev": _overlap_bev,
     "fv2p_roipoint_pool3d": _roipoint,
     "fv2p_ball_query_batch": _ball_query_batch,

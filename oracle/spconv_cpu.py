@@ -38,7 +38,7 @@ class CpuSparseConv(spconv.SparseModule):
         self.weight = torch.nn.Parameter(src.weight.detach().cpu().clone())
         self.bias = None if src.bias is None else torch.nn.Parameter(src.bias.detach().cpu().clone())
 
-    def forward(self, x):
+    def forward(self, x, _post=None):   # _post: the fused conv+BN offer of the product's SparseSequential, never taken here
         c = self.cfg
         ind = x.indices.numpy()
         key = c["indice_key"]

@@ -115,7 +115,8 @@ def test_roi_head_on_identical_inputs_matches_cpu_oracle(gpu, cpu_run):
     assert torch.equal(ag["sampled_rois"].cpu(), ac["sampled_rois"])
     assert rel(ag["roi_iou"].cpu(), ac["roi_iou"]) < 1e-5
     assert abs(lg.item() - lc.item()) < 1e-3 * max(1.0, abs(lc.item()))
-    assert rel(fg.cpu(), fc) < 2e-3 and rel(bg.cpu(), bc) < 2e-3
+    assert fg is None and fc is None          # the RoI point pool carries no gradient (reference: under no_grad, iouguided_roi_head.py:178)
+    assert rel(bg.cpu(), bc) < 2e-3
     gp, cp = dict(head_g.named_parameters()), dict(ref.roi_head.named_parameters())
     for name in ("grid_interact_fc_layer.0.weight", "xyz_up_layer.0.weight", "SA_modules.0.mlps.1.0.weight", "reg_layers.7.weight"):
         a, b = gp[name].grad.cpu().double(), cp[name].grad.double()

@@ -56,3 +56,31 @@ def test_nms_ext_convention_and_errors(gpu):
         iou3d_nms_cuda.nms_gpu(tb, keep.to(gpu), 0.5)      # keep must be a CPU tensor
     empty = iou3d_nms_utils.nms_gpu(torch.zeros((0, 7), device=gpu), torch.zeros((0,), device=gpu), 0.5)[0]
     assert empty.numel() == 0
+
+
+@pytest.mark.parametrize("n,thresh,max_keep,normal", [(9000, 0.8, 512, False), (9000, 0.1, 512, False), (4096, 0.05, 500, False),
+                                                      (3000, 0.3, 0, False), (700, 0.5, 100, True), (65, 0.3, 64, False), (40, 0.3, 512, False)])
+def test_batched_truncated_nms_is_the_head_of_the_full_list(gpu, n, thresh, max_keep, normal):
+    """fv2p_nms_batch: three samples in one launch sequence; with max_keep the greedy pass stops early, and what it returns
+    is exactly the first max_keep survivors of the full pass (low thresholds force several mask chunks)."""
+    sets = [random_boxes(100 + s, n) for s in range(3)]
+    keep, cnt = iou3d_nms_cuda.nms_batch_device(torch.from_numpy(np.stack(sets)).to(gpu), thresh, max_keep, normal)
+    keep, cnt = keep.cpu().numpy(), cnt.cpu().numpy()
+    for s in range(3):
+        ref = oracle.nms(sets[s], -np.arange(n, dtype=np.float32), thresh, normal=normal)
+        if max_keep > 0:
+            ref = ref[:max_keep]
+        assert cnt[s] == len(ref)
+        assert np.array_equal(keep[s, :cnt[s]], ref)
+
+
+def test_nms_gpu_honours_the_callers_post_maxsize(gpu):
+    """The reference's class_agnostic_nms passes its whole config as keywords (model_nms_utils.py:14-16) and then keeps
+    selected[:NMS_POST_MAXSIZE]: with the keyword present nms_gpu returns exactly that head."""
+    boxes = random_boxes(11, 5000)
+    scores = np.random.default_rng(5).permutation(5000).astype(np.float32)
+    tb, ts = torch.from_numpy(boxes).to(gpu), torch.from_numpy(scores).to(gpu)
+    cfg = dict(NMS_TYPE="nms_gpu", MULTI_CLASSES_NMS=False, NMS_PRE_MAXSIZE=4096, NMS_POST_MAXSIZE=100, NMS_THRESH=0.4)
+    keep, _ = iou3d_nms_utils.nms_gpu(tb, ts, 0.4, pre_maxsize=4096, **{k: v for k, v in cfg.items() if k != "NMS_PRE_MAXSIZE"})
+    ref = oracle.nms(boxes, scores, 0.4, pre_maxsize=4096)[:100]
+    assert np.array_equal(keep.cpu().numpy(), ref)

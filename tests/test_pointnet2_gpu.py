@@ -41,6 +41,16 @@ def test_fps_ties_follow_reference_reduction(gpu):
     assert np.array_equal(out.cpu().numpy(), ref)
 
 
+def test_fps_lattice_ties_on_the_wave_bucket_kernel(gpu):
+    """Same tie rule on the register-resident wave-bucket kernel (n >= 2048, m >= 1024): a 16 x 16 x 16 lattice makes almost
+    every round a many-way tie, and sampling more points than there are exhausts the cloud (all distances zero)."""
+    g = np.stack(np.meshgrid(np.arange(16), np.arange(16), np.arange(16), indexing="ij"), -1).reshape(1, -1, 3).astype(np.float32)
+    for m in (1500, 4096, 4500):
+        out = bu.furthest_point_sample(T(g, gpu), m)
+        ref, _ = oracle.furthest_point_sample(g, m)
+        assert np.array_equal(out.cpu().numpy(), ref), m
+
+
 def test_ball_query_group_gather_batch(gpu):
     """RoI-head shapes (iouguided_roi_head.py:276): many small samples, 512 points, 216 centres, radii 0.8 / 1.6."""
     rng = np.random.default_rng(0)
@@ -174,7 +184,8 @@ def test_errors_are_exceptions_not_exit(gpu):
         bu.ball_query(1.0, 8, torch.zeros(1, 10, 3), torch.zeros(1, 4, 3))  # CPU tensors: the reference would exit(-1)
 
 
-@pytest.mark.parametrize("n,m,b", [(16384, 2048, 2), (4099, 1500, 3), (2048, 2048, 1), (9000, 1024, 2), (9000, 64, 2)])
+@pytest.mark.parametrize("n,m,b", [(16384, 2048, 2), (4099, 1500, 3), (2048, 2048, 1), (9000, 1024, 2), (9000, 64, 2), (16384, 16384, 3),
+                                   (20000, 16384, 2), (24576, 4096, 1), (24577, 1100, 1), (15000, 16384, 1), (12289, 3000, 2)])
 def test_fps_bucketed_kernel_indices_and_running_distances(gpu, n, m, b):
     """The bucketed (lazy) FPS kernel — Morton-sorted buckets skipped when the new point cannot lower any of their
     running distances — must be indistinguishable from the reference loop: same indices AND same final `temp`
