@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--lean-adamw", type=int, default=1, help="1: torch's fused AdamW kernels called on cached tensor lists (fv2p_harness/optim.py); 0: torch.optim.AdamW(fused=True)")
     ap.add_argument("--pin-cores", type=int, default=16, help="cores per rank to pin this process to (0: leave the affinity alone)")
     ap.add_argument("--phases", action="store_true", help="diagnostic: host issue time and synchronised wall time per phase (stderr)")
+    ap.add_argument("--torch-profile", action="store_true", help="diagnostic: torch.profiler over 3 steps, top ops by device time (stderr)")
+    ap.add_argument("--bev-channels-last", type=int, default=0, help="fv2p: BEV backbone + anchor head in channels_last memory format")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous check without a GPU: ranks join a gloo group, reduce, rank 0 prints n_gpus")
     ap.add_argument("--pyprofile", action="store_true", help="cProfile the timed steps (host-overhead hunting; prints to stderr)")
     args = ap.parse_args()
@@ -209,6 +211,10 @@ def build_fv2p_step(args, device, rank, world):
     cfg = FV2PConfig
     torch.manual_seed(0)
     model = FV2PDetector(cfg).to(device)
+    if args.bev_channels_last:
+        model.backbone_2d.to(memory_format=torch.channels_last)
+        model.dense_head.to(memory_format=torch.channels_last)
+        model.bev_channels_last = True
     net = dist_utils.wrap_ddp(model, device, find_unused_parameters=False)   # every parameter takes part in every step
     params = [p for p in model.parameters() if p.requires_grad]
     opt = LeanAdamW(params, lr=1e-3, weight_decay=0.01) if args.lean_adamw else torch.optim.AdamW(params, lr=1e-3, weight_decay=0.01, fused=True)
@@ -543,6 +549,13 @@ def main():
             step.phases(args.warmup + i, acc)
         for k, (h, w) in acc.items():
             print(f"[phases] {k:14s} host issue {h / 20 * 1e3:7.3f} ms   synchronised wall {w / 20 * 1e3:7.3f} ms", file=sys.stderr)
+    if args.torch_profile and rank == 0:
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as tp:
+            for i in range(3):
+                step(args.warmup + i)
+            torch.cuda.synchronize()
+        print(tp.key_averages().table(sort_by="self_cuda_time_total", row_limit=70, max_name_column_width=60), file=sys.stderr)
     prof = None
     if args.pyprofile:
         import cProfile

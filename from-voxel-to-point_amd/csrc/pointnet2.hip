@@ -571,6 +571,14 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 __device__ __forceinline__ float lane_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 
 constexpr int kFpsWaves = 8;
+// compile-time loop: f(integral_constant<int, Q>) for Q in [A, B) — register arrays are only ever indexed by constants
+template <int A, int B, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (A < B) {
+    f(std::integral_constant<int, A>{});
+    static_for<A + 1, B>(f);
+  }
+}
 template <int S>
 __global__ __launch_bounds__(kFpsWaves * 64) void fps_wave_k(int n, int m, int bs, const float* __restrict__ dataset,
                                                              const uint64_t* __restrict__ keys, float* __restrict__ temp, int* __restrict__ idxs) {
@@ -612,25 +620,38 @@ __global__ __launch_bounds__(kFpsWaves * 64) void fps_wave_k(int n, int m, int b
     if (lane == s) { lo0 = bx0; hi0 = bx1; lo1 = by0; hi1 = by1; lo2 = bz0; hi2 = bz1; }
     __builtin_amdgcn_sched_barrier(0);   // one slot at a time: the S loads are not all hoisted to the top (register pressure)
   }
-  // bucket s: recompute (max, priority, candidate coordinates) from the registers; wave-uniform control flow
-  auto refresh = [&](auto, const int s) {   // s is a constant after unrolling
+  // bucket s: recompute (max, priority, candidate coordinates) from the registers; wave-uniform control flow.  The priority
+  // reduction only runs when several points share the maximum.
+  auto refresh = [&](auto sc) __attribute__((always_inline)) {
+    constexpr int s = decltype(sc)::value;
     const uint32_t myp = s_prio[s * (kFpsWaves * 64) + tid];   // issued first: its latency hides behind the max reduction
     const float mx = wave_max_f32(pt[s]);
-    const uint32_t pm = wave_min_u32(pt[s] == mx ? myp : 0xffffffffu);
-    const int leader = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(__ballot(myp == pm && pt[s] == mx))) - 1);
+    const uint64_t holders = __ballot(pt[s] == mx);
+    int leader = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(holders)) - 1);
+    uint32_t pm = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(myp), leader));
+    if (holders & (holders - 1)) {
+      pm = wave_min_u32(pt[s] == mx ? myp : 0xffffffffu);
+      leader = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(__ballot(myp == pm && pt[s] == mx))) - 1);
+    }
     const float cx = lane_f(px[s], leader), cy = lane_f(py[s], leader), cz = lane_f(pz[s], leader);
     if (lane == s) { bmax = mx; bprio = pm; }
     if (lane == 0) *reinterpret_cast<float4*>(&s_bucket[w][s][0]) = make_float4(cx, cy, cz, 0.f);
   };
-#pragma unroll
-  for (int q = 0; q < S; ++q) refresh(std::integral_constant<int, 0>{}, q);
-  // wave candidate from the S bucket states
+  static_for<0, S>(refresh);
+  // wave candidate from the S bucket states (every stored maximum is exact: a touched bucket is refreshed at once; keeping
+  // stale upper bounds and refreshing only the buckets that reach the top was measured slower, 1.44 vs 1.02 us per round)
   uint32_t wbits = 0, wprio = 0xffffffffu, wslot = 0;
-  auto wave_best = [&]() {
+  auto wave_best = [&]() __attribute__((always_inline)) {
     const float v = lane < S ? bmax : -3.f;
     const float mx = wave_max_f32(v);
-    const uint32_t pm = wave_min_u32((lane < S && v == mx) ? bprio : 0xffffffffu);
-    wslot = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(__ballot(lane < S && v == mx && bprio == pm))) - 1));
+    const uint64_t top = __ballot(lane < S && v == mx);
+    int slot = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(top)) - 1);
+    uint32_t pm = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(bprio), slot));
+    if (top & (top - 1)) {
+      pm = wave_min_u32((lane < S && v == mx) ? bprio : 0xffffffffu);
+      slot = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(__ballot(lane < S && v == mx && bprio == pm))) - 1);
+    }
+    wslot = static_cast<uint32_t>(slot);
     wbits = __float_as_uint(fmaxf(mx, 0.f));   // every real maximum is >= 0: unsigned order == float order; empty wave -> 0 with priority ~0
     wprio = pm;
   };
@@ -647,20 +668,19 @@ __global__ __launch_bounds__(kFpsWaves * 64) void fps_wave_k(int n, int m, int b
     if (touch) {
       // straight-line, wave-uniform tests (groups of eight first): every slot's update is a plain diamond, so the register
       // arrays are updated in place (a switch over the slot made hipcc keep two copies of pt[] and hoist the distance passes)
-#pragma unroll
-      for (int g = 0; g < S; g += 8) {
-        if ((touch >> g) & 0xffull) {
-#pragma unroll
-          for (int q = g; q < g + 8; ++q) {
+      static_for<0, (S + 7) / 8>([&](auto gc) __attribute__((always_inline)) {
+        constexpr int g = decltype(gc)::value * 8;
+        if ((touch >> g) & 0xffull)
+          static_for<g, (g + 8 < S ? g + 8 : S)>([&](auto qc) __attribute__((always_inline)) {
+            constexpr int q = decltype(qc)::value;
             if ((touch >> q) & 1ull) {
               float ax = x1, ay = y1, az = z1;
               asm volatile("" : "+v"(ax), "+v"(ay), "+v"(az));   // pins the distance pass inside its branch
               pt[q] = fminf(sqdist(px[q], py[q], pz[q], ax, ay, az), pt[q]);
-              refresh(std::integral_constant<int, 0>{}, q);
+              refresh(qc);
             }
-          }
-        }
-      }
+          });
+      });
       wave_best();
     }
     const int buf = j & 1;
@@ -669,8 +689,13 @@ __global__ __launch_bounds__(kFpsWaves * 64) void fps_wave_k(int n, int m, int b
     // 8 wave candidates, one per lane of the first row; every wave derives the same winner
     const uint4 c = lane < kFpsWaves ? *reinterpret_cast<const uint4*>(&s_wave[buf][lane][0]) : make_uint4(0u, 0xffffffffu, 0u, 0u);
     const float gmax = lane_f(row_max_f32(__uint_as_float(c.x)), 0);
-    const uint32_t gprio = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(row_min_u32(__uint_as_float(c.x) == gmax ? c.y : 0xffffffffu)), 0));
-    const int gw = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(__ballot(lane < kFpsWaves && __uint_as_float(c.x) == gmax && c.y == gprio))) - 1);
+    const uint64_t gtop = __ballot(lane < kFpsWaves && __uint_as_float(c.x) == gmax);
+    int gw = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(gtop)) - 1);
+    uint32_t gprio = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(c.y), gw));
+    if (gtop & (gtop - 1)) {
+      gprio = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(row_min_u32(__uint_as_float(c.x) == gmax ? c.y : 0xffffffffu)), 0));
+      gw = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(__ballot(lane < kFpsWaves && __uint_as_float(c.x) == gmax && c.y == gprio))) - 1);
+    }
     const int gslot = __builtin_amdgcn_readlane(static_cast<int>(c.z), gw);
     const float4 p = *reinterpret_cast<const float4*>(&s_bucket[gw][gslot][0]);
     x1 = p.x; y1 = p.y; z1 = p.z;

@@ -579,29 +579,38 @@ class IoUGuidedRoIHead(nn.Module):
         world = rotate_z(local, r[:, 6]) + r[:, None, 0:3]
         return world, local
 
-    def forward_rois(self, key, feats, scores, bev, rois):
-        cfg = self.cfg
-        b = key.shape[0]
+    def prepare(self, bev, prop_scores, prop_boxes, gt, uniforms):
+        """Everything of the second stage that needs no key points: proposals, target sampling, the RoI grids, the BEV stream and
+        the corner-geometry stream.  The detector runs it before it joins the key-point sampling stream."""
+        b = bev.shape[0]
+        rois, _ = self.proposals(prop_scores, prop_boxes)
+        s_rois, s_gt, s_iou = self.sample_targets(rois, gt, uniforms)
+        gt_ct = self.canonical_targets(s_rois, s_gt)
+        world, local = self.grid_points(s_rois)
+        # BEV stream: bilinear gather at the grid points + channel compression (:243-255)
+        g_bev = self.bev_grid_pool_layer({"spatial_features_before_head": bev, "spatial_features_stride": 8}, world.view(b, -1, 3))
+        g_bev = g_bev.view(world.shape[0], world.shape[1], -1).permute(0, 2, 1).contiguous()
+        # corner geometry stream (feature_adaptor/nn_modules.py:6-60): roi-frame corners without rotation or centre
+        t = s_rois.new_tensor(((1, 1, -1), (1, -1, -1), (-1, -1, -1), (-1, 1, -1), (1, 1, 1), (1, -1, 1), (-1, -1, 1), (-1, 1, 1))) / 2
+        corners = s_rois.reshape(-1, 7)[:, None, 3:6] * t[None]
+        cge = self.cge_inter(self.cge_up(corners.transpose(1, 2).unsqueeze(3).contiguous()).squeeze(-1))
+        return dict(rois=rois, s_rois=s_rois, s_gt=s_gt, s_iou=s_iou, gt_ct=gt_ct, local=local, g_bev=g_bev, cge=cge)
+
+    def finish(self, key, feats, scores, prep):
+        rois = prep["s_rois"]
         pooled = self.pool_points(key, feats, scores, rois)                                        # (B*n, 512, 5 + C)
         xyz_in = pooled[..., 0:5].transpose(1, 2).unsqueeze(3).contiguous()
         pt_in = pooled[..., 5:].transpose(1, 2).unsqueeze(3).contiguous()
         merged = self.merge_down_layer(torch.cat((self.xyz_up_layer(xyz_in), pt_in), dim=1)).squeeze(3).contiguous()
-        world, local = self.grid_points(rois)
-        # BEV stream: bilinear gather at the grid points + channel compression (:243-255)
-        g_bev = self.bev_grid_pool_layer({"spatial_features_before_head": bev, "spatial_features_stride": 8}, world.view(b, -1, 3))
-        g_bev = g_bev.view(world.shape[0], world.shape[1], -1).permute(0, 2, 1).contiguous()
         # point stream: multi-scale ball query around the grid points (:258-275)
-        g_pt = sa_msg_grid(self.SA_modules[0], pooled[..., 0:3].contiguous(), merged, local.contiguous())
-        grid = torch.cat((g_pt, g_bev), dim=1)
+        g_pt = sa_msg_grid(self.SA_modules[0], pooled[..., 0:3].contiguous(), merged, prep["local"].contiguous())
+        grid = torch.cat((g_pt, prep["g_bev"]), dim=1)
         pc = self.grid_interact_fc_layer(grid.view(grid.shape[0], -1, 1))
-        # corner geometry stream (feature_adaptor/nn_modules.py:6-60): roi-frame corners without rotation or centre
-        t = rois.new_tensor(((1, 1, -1), (1, -1, -1), (-1, -1, -1), (-1, 1, -1), (1, 1, 1), (1, -1, 1), (-1, -1, 1), (-1, 1, 1))) / 2
-        corners = rois.reshape(-1, 7)[:, None, 3:6] * t[None]
-        cge = self.cge_inter(self.cge_up(corners.transpose(1, 2).unsqueeze(3).contiguous()).squeeze(-1))
-        shared = self.feature_fusion(torch.cat((pc, cge), dim=1))
+        shared = self.feature_fusion(torch.cat((pc, prep["cge"]), dim=1))
         cls = self.cls_layers(shared).squeeze(-1)                                                  # (B*n, 1)
         reg = self.reg_layers(shared).squeeze(-1)                                                  # (B*n, 8): [iou, 7 residuals]
-        return cls, reg[:, 1:], reg[:, :1]
+        loss = self.losses(rois, prep["s_gt"], prep["gt_ct"], prep["s_iou"], cls, reg[:, 1:], reg[:, :1])
+        return loss, {"rois": prep["rois"], "sampled_rois": rois, "roi_iou": prep["s_iou"]}
 
     def losses(self, rois, gt_src, gt_ct, iou, cls, reg, iou_pred):
         """get_box_cls_layer_loss / get_box_reg_layer_loss / get_box_iouscore_layer_loss (:137-265), CLS_SCORE_TYPE roi_iou."""
@@ -632,12 +641,7 @@ class IoUGuidedRoIHead(nn.Module):
         return loss_cls + loss_reg + loss_corner + loss_iou
 
     def forward(self, key, feats, point_scores, bev, prop_scores, prop_boxes, gt, uniforms):
-        rois, _ = self.proposals(prop_scores, prop_boxes)
-        s_rois, s_gt, s_iou = self.sample_targets(rois, gt, uniforms)
-        gt_ct = self.canonical_targets(s_rois, s_gt)
-        cls, reg, iou_pred = self.forward_rois(key, feats, point_scores, bev, s_rois)
-        aux = {"rois": rois, "sampled_rois": s_rois, "roi_iou": s_iou}
-        return self.losses(s_rois, s_gt, gt_ct, s_iou, cls, reg, iou_pred), aux
+        return self.finish(key, feats, point_scores, self.prepare(bev, prop_scores, prop_boxes, gt, uniforms))
 
 
 # ---------------------------------------------------------------- the detector -------------------------
@@ -665,11 +669,14 @@ class FV2PDetector(nn.Module):
         out, levels = self.backbone_3d(voxel_features, voxel_coords, b)
         dense = out.dense()                                                      # HeightCompression (height_compression.py:10-26)
         spatial = dense.view(b, dense.shape[1] * dense.shape[2], dense.shape[3], dense.shape[4])
+        if getattr(self, "bev_channels_last", False):
+            spatial = spatial.contiguous(memory_format=torch.channels_last)
         bev = self.backbone_2d(spatial)
         loss_rpn, prop_scores, prop_boxes = self.dense_head(bev, gt_boxes)
+        prep = self.roi_head.prepare(bev, prop_scores, prop_boxes, gt_boxes, uniforms)   # still no key points needed
         key, point_feats = self.post_pfe(clouds, levels, key_job)
         loss_point, point_scores = self.point_head(key, point_feats, gt_boxes)
-        loss_rcnn, aux = self.roi_head(key, point_feats, point_scores, bev, prop_scores, prop_boxes, gt_boxes, uniforms)
+        loss_rcnn, aux = self.roi_head.finish(key, point_feats, point_scores, prep)
         if self.taps is not None:
             self.taps.update(keypoints=key, point_features=point_feats, point_scores=point_scores, bev=bev, prop_boxes=prop_boxes,
                              prop_scores=prop_scores, loss_rpn=loss_rpn, loss_point=loss_point, loss_rcnn=loss_rcnn, **aux)
