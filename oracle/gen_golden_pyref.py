@@ -1,0 +1,160 @@
+"""Generates tests/golden/pyref_*.npz from the reference's own pure-Python functions (build container only).
+
+Pins, with outputs of the reference code itself, the pieces of the hot path and of the replay harness that the reference
+implements in importable Python:
+
+  spconv/structure.py            scatter_nd, SparseConvTensor.dense()                      (imported by path: numpy + torch only)
+  spconv/ops.py:20-43            get_conv_output_size, get_deconv_output_size              (function defs compiled out of the file)
+  vfe/mean_vfe.py:14-31          MeanVFE.forward                                            (method compiled out of the class)
+  utils/common_utils.py          get_voxel_centers, rotate_points_along_z, limit_period     (imported by path)
+  utils/box_utils.py             boxes_to_corners_3d, in_hull, boxes_iou_normal,
+                                 boxes3d_lidar_to_aligned_bev_boxes, boxes3d_nearest_bev_iou, enlarge_box3d
+  utils/box_coder_utils.py       ResidualCoder.encode_torch / decode_torch                  (imported by path)
+  utils/loss_utils.py            SigmoidFocalClassificationLoss, WeightedSmoothL1Loss.smooth_l1_loss
+
+Modules that import the CUDA extensions at load time cannot be imported as a whole, so single definitions are taken out
+of their syntax tree and compiled against torch (CPU).  Nothing of the reference is copied into the repository: the
+fixtures hold inputs and outputs only.  Run:   python oracle/gen_golden_pyref.py
+"""
+import ast
+import importlib.util
+import os
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/pcdet"
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+def by_path(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def extract(rel, names, ns):
+    """Compiles the named top-level defs / classes of a reference file into the namespace `ns`."""
+    path = os.path.join(REF, rel)
+    tree = ast.parse(open(path).read())
+    body = [n for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name in names]
+    assert len(body) == len(names), (rel, names)
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+def method(rel, cls, name, ns):
+    path = os.path.join(REF, rel)
+    tree = ast.parse(open(path).read())
+    c = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls][0]
+    f = [n for n in c.body if isinstance(n, ast.FunctionDef) and n.name == name]
+    assert len(f) == 1
+    exec(compile(ast.Module(body=f, type_ignores=[]), path, "exec"), ns)
+    return ns[name]
+
+
+def random_boxes(rng, n, spread=20.0):
+    xy = rng.uniform(-spread, spread, size=(n, 2))
+    z = rng.uniform(-1.5, 0.5, size=(n, 1))
+    dims = np.array([3.9, 1.6, 1.56]) * rng.uniform(0.7, 1.3, size=(n, 3))
+    yaw = rng.uniform(-np.pi, np.pi, size=(n, 1))
+    return np.concatenate([xy, z, dims, yaw], 1).astype(np.float32)
+
+
+def main():
+    save = lambda name, **kw: (np.savez_compressed(os.path.join(OUT, f"pyref_{name}.npz"), **kw), print(name, {k: np.asarray(v).shape for k, v in kw.items()}))
+    rng = np.random.default_rng(2024)
+
+    # ---- scatter_nd / dense ------------------------------------------------------------------------------------------------
+    st = by_path("ref_structure", "ops/spconv/structure.py")
+    shape, batch, c = [5, 12, 9], 3, 7
+    cells = rng.permutation(batch * int(np.prod(shape)))[:200]
+    idx = np.stack(np.unravel_index(cells, [batch] + shape), 1).astype(np.int32)
+    feats = rng.standard_normal((200, c)).astype(np.float32)
+    x = st.SparseConvTensor(torch.from_numpy(feats), torch.from_numpy(idx), shape, batch)
+    save("dense", features=feats, indices=idx, spatial_shape=np.array(shape), batch_size=batch,
+         dense_channels_first=x.dense().numpy(), dense_channels_last=x.dense(channels_first=False).numpy(),
+         scatter_nd=st.scatter_nd(torch.from_numpy(idx).long(), torch.from_numpy(feats), [batch] + shape + [c]).numpy())
+
+    # ---- conv output sizes ---------------------------------------------------------------------------------------------------
+    ns = extract("ops/spconv/ops.py", ["get_conv_output_size", "get_deconv_output_size"], {})
+    cases, conv, deconv = [], [], []
+    for size in ([41, 1600, 1408], [21, 800, 704], [11, 400, 352], [5, 200, 176], [7, 9, 10], [40, 1504, 1504]):
+        for k, s, p, d in (([3, 3, 3], [2, 2, 2], [1, 1, 1], [1, 1, 1]), ([3, 3, 3], [2, 2, 2], [0, 1, 1], [1, 1, 1]),
+                           ([3, 1, 1], [2, 1, 1], [0, 0, 0], [1, 1, 1]), ([3, 3, 3], [1, 1, 1], [1, 1, 1], [1, 1, 1]),
+                           ([2, 2, 2], [2, 2, 2], [0, 0, 0], [1, 1, 1]), ([3, 3, 3], [1, 1, 1], [2, 2, 2], [2, 2, 2])):
+            cases.append(size + k + s + p + d)
+            conv.append(ns["get_conv_output_size"](size, k, s, p, d))
+            deconv.append(ns["get_deconv_output_size"](size, k, s, p, d, [0, 0, 0]))
+    save("conv_output_size", cases=np.array(cases), conv=np.array(conv), deconv=np.array(deconv))
+
+    # ---- MeanVFE -----------------------------------------------------------------------------------------------------------------
+    fwd = method("models/backbones_3d/vfe/mean_vfe.py", "MeanVFE", "forward", {"torch": torch})
+    num = rng.integers(0, 6, size=300).astype(np.int32)      # 0 .. 5 points, zero-point voxels included
+    vox = rng.standard_normal((300, 5, 4)).astype(np.float32)
+    vox *= (np.arange(5)[None, :, None] < num[:, None, None])   # zero padding past num_points, as the voxeliser writes it
+    bd = {"voxels": torch.from_numpy(vox), "voxel_num_points": torch.from_numpy(num)}
+    save("mean_vfe", voxels=vox, num_points=num, voxel_features=fwd(None, bd)["voxel_features"].numpy())
+
+    # ---- common_utils --------------------------------------------------------------------------------------------------------------
+    cu = by_path("ref_common_utils", "utils/common_utils.py")
+    coords = np.stack([rng.integers(0, 41, 400), rng.integers(0, 1600, 400), rng.integers(0, 1408, 400)], 1).astype(np.int32)
+    centres = {str(f): cu.get_voxel_centers(torch.from_numpy(coords), f, [0.05, 0.05, 0.1], [0, -40, -3, 70.4, 40, 1]).numpy() for f in (1, 2, 4, 8)}
+    pts = rng.standard_normal((50, 6, 5)).astype(np.float32)
+    ang = rng.uniform(-4, 4, 50).astype(np.float32)
+    val = rng.uniform(-10, 10, 200).astype(np.float32)
+    save("common_utils", coords=coords, **{f"centres_x{k}": v for k, v in centres.items()}, points=pts, angle=ang,
+         rotated=cu.rotate_points_along_z(torch.from_numpy(pts), torch.from_numpy(ang)).numpy(), val=val,
+         limit_period_pi=cu.limit_period(torch.from_numpy(val), 0.5, np.pi).numpy(),
+         limit_period_2pi=cu.limit_period(torch.from_numpy(val), 0.0, 2 * np.pi).numpy())
+
+    # ---- box_utils ---------------------------------------------------------------------------------------------------------------------
+    import scipy
+    from scipy.spatial import Delaunay
+    bns = {"torch": torch, "np": np, "scipy": scipy, "Delaunay": Delaunay, "common_utils": cu}
+    extract("utils/box_utils.py", ["in_hull", "boxes_to_corners_3d", "boxes_iou_normal", "boxes3d_lidar_to_aligned_bev_boxes",
+                                   "boxes3d_nearest_bev_iou", "enlarge_box3d"], bns)
+    boxes = random_boxes(rng, 24, spread=8.0)
+    corners = bns["boxes_to_corners_3d"](torch.from_numpy(boxes)).numpy()
+    pts = rng.uniform(-11, 11, size=(4000, 3)).astype(np.float32)
+    pts[:, 2] = rng.uniform(-2.5, 1.5, 4000)
+    # keep points at least 2 cm away from every face of every box: the hull test, the CUDA point-in-box test (margin 1e-5) and the CPU one (margin 1e-2) all agree there
+    keep = np.ones(len(pts), bool)
+    for b in boxes:
+        loc = pts - b[:3]
+        c, s = np.cos(-b[6]), np.sin(-b[6])
+        lx, ly = loc[:, 0] * c - loc[:, 1] * s, loc[:, 0] * s + loc[:, 1] * c
+        for v, h in ((lx, b[3] / 2), (ly, b[4] / 2), (loc[:, 2], b[5] / 2)):
+            keep &= np.abs(np.abs(v) - h) > 2e-2
+    pts = pts[keep]
+    inside = np.stack([bns["in_hull"](pts.astype(np.float64), corners[i].astype(np.float64)) for i in range(len(boxes))])
+    a, b2 = random_boxes(rng, 60, 6.0), random_boxes(rng, 40, 6.0)
+    bev_a = bns["boxes3d_lidar_to_aligned_bev_boxes"](torch.from_numpy(a))
+    save("box_utils", boxes=boxes, corners=corners, points=pts, inside=inside.astype(np.int32), boxes_a=a, boxes_b=b2,
+         aligned_bev_a=bev_a.numpy(), nearest_bev_iou=bns["boxes3d_nearest_bev_iou"](torch.from_numpy(a), torch.from_numpy(b2)).numpy(),
+         iou_normal_aa=bns["boxes_iou_normal"](bev_a, bev_a).numpy(),
+         enlarged=bns["enlarge_box3d"](torch.from_numpy(boxes), [0.2, 0.2, 0.2]).numpy())
+
+    # ---- box coder + losses ------------------------------------------------------------------------------------------------------------
+    bc = by_path("ref_box_coder", "utils/box_coder_utils.py")
+    coder = bc.ResidualCoder()
+    g, an = random_boxes(rng, 100), random_boxes(rng, 100)
+    enc = coder.encode_torch(torch.from_numpy(g.copy()), torch.from_numpy(an.copy()))
+    dec = coder.decode_torch(enc, torch.from_numpy(an.copy()))
+    lns = {"torch": torch, "np": np, "nn": torch.nn, "F": torch.nn.functional}
+    extract("utils/loss_utils.py", ["SigmoidFocalClassificationLoss"], lns)
+    sl1 = method("utils/loss_utils.py", "WeightedSmoothL1Loss", "smooth_l1_loss", {"torch": torch})
+    logits = rng.standard_normal((2, 500, 1)).astype(np.float32) * 3
+    onehot = (rng.uniform(size=(2, 500, 1)) < 0.1).astype(np.float32)
+    w = rng.uniform(0, 1, size=(2, 500)).astype(np.float32)
+    focal = lns["SigmoidFocalClassificationLoss"](alpha=0.25, gamma=2.0)(torch.from_numpy(logits), torch.from_numpy(onehot), torch.from_numpy(w))
+    diff = rng.standard_normal(1000).astype(np.float32)
+    save("coder_losses", gt=g, anchors=an, encoded=enc.numpy(), decoded=dec.numpy(), logits=logits, onehot=onehot, weights=w,
+         focal=focal.numpy(), diff=diff, smooth_l1_beta9=sl1(torch.from_numpy(diff), 1.0 / 9.0).numpy(),
+         smooth_l1_beta1=sl1(torch.from_numpy(diff), 1.0).numpy())
+
+
+if __name__ == "__main__":
+    main()

@@ -58,12 +58,15 @@ def cpu_run():
     inputs = make_inputs(SmallFV2P, 2, 4096)
     with oracle_backend():
         loss = ref(*inputs)
-        loss.backward()
-    return model, ref, inputs, loss
+        # first-stage + point losses first (their gradients are compared with the GPU run), then the second stage on top
+        (ref.taps["loss_rpn"] + ref.taps["loss_point"]).backward(retain_graph=True)
+        stage1 = {k: p.grad.clone() for k, p in ref.named_parameters() if p.grad is not None}
+        ref.taps["loss_rcnn"].backward()
+    return model, ref, inputs, loss, stage1
 
 
 def test_cpu_replay_runs_and_trains_every_parameter(cpu_run):
-    _, ref, _, loss = cpu_run
+    _, ref, _, loss, _ = cpu_run
     assert torch.isfinite(loss)
     missing = [k for k, p in ref.named_parameters() if p.grad is None]
     assert not missing, missing
@@ -74,27 +77,34 @@ def test_cpu_replay_runs_and_trains_every_parameter(cpu_run):
 
 @pytest.mark.gpu
 def test_fv2p_step_matches_cpu_oracle(gpu, cpu_run):
-    model, ref, inputs, ref_loss = cpu_run
+    model, ref, inputs, ref_loss, stage1 = cpu_run
     net = model.to(gpu)
     net.taps = {}
     clouds, feats, coords, gt, u = inputs
     loss = net([c.to(gpu) for c in clouds], feats.to(gpu), coords.to(gpu), gt.to(gpu), u.to(gpu))
-    loss.backward()
     g, c = net.taps, ref.taps
+    # gradients of the first-stage + point losses only: the second stage's RoIs are a top-k + NMS over network outputs and may
+    # legitimately differ between two float implementations (it is compared on identical inputs in the next test)
+    (g["loss_rpn"] + g["loss_point"]).backward(retain_graph=True)
     assert torch.equal(g["keypoints"].cpu(), c["keypoints"])                          # FPS order: bit-exact
     assert rel(g["point_features"].detach().cpu(), c["point_features"].detach()) < 1e-3
     assert rel(g["bev"].detach().cpu(), c["bev"].detach()) < 1e-3
     assert abs(g["loss_point"].item() - c["loss_point"].item()) < 1e-3 * max(1.0, abs(c["loss_point"].item()))
     assert abs(g["loss_rpn"].item() - c["loss_rpn"].item()) < 1e-3 * max(1.0, abs(c["loss_rpn"].item()))
     gp = dict(net.named_parameters())
-    for name in ("backbone_3d.conv_input.0.weight", "post_pfe.decode_block_out.0.weight", "point_head.cls_layers.0.weight"):
-        a, b = gp[name].grad.cpu().double(), dict(ref.named_parameters())[name].grad.double()
-        assert float((a - b).norm() / b.norm().clamp_min(1e-12)) < 2e-2, name
+    for name in ("backbone_3d.conv_input.0.weight", "backbone_3d.conv3.1.conv2.weight", "backbone_2d.blocks.0.1.weight",
+                 "post_pfe.decode_block_out.0.weight", "post_pfe.decode_blocks_map.x_conv3.net.0.weight", "point_head.cls_layers.0.weight"):
+        a, b = gp[name].grad.cpu().double(), stage1[name].double()
+        assert float((a - b).norm() / b.norm().clamp_min(1e-12)) < 1e-2, name
+    g["loss_rcnn"].backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+    if torch.equal(g["sampled_rois"].cpu(), c["sampled_rois"]):
+        assert abs(g["loss_rcnn"].item() - c["loss_rcnn"].item()) < 2e-3 * max(1.0, abs(c["loss_rcnn"].item()))
 
 
 @pytest.mark.gpu
 def test_roi_head_on_identical_inputs_matches_cpu_oracle(gpu, cpu_run):
-    model, ref, inputs, _ = cpu_run
+    model, ref, inputs, _, _ = cpu_run
     head_g = model.roi_head.to(gpu)
     t = ref.taps
     gt, u = inputs[3], inputs[4]
