@@ -1,224 +1,161 @@
-"""Batched pointnet2 autograd functions — call surface of the reference's
-pcdet/ops/pointnet2/pointnet2_batch/pointnet2_utils.py:10-380 (FPS, gather, three_nn, three_interpolate, grouping,
-ball_query, QueryAndGroup, GroupAll, top3_interpolate[_with_grad])."""
-from typing import Tuple
+"""Batched pointnet2 operators behind the names of the reference's
+pcdet/ops/pointnet2/pointnet2_batch/pointnet2_utils.py:10-380 (FurthestPointSampling, GatherOperation, ThreeNN, ThreeInterpolate,
+GroupingOperation, BallQuery and their `.apply` aliases, QueryAndGroup, GroupAll, top3_interpolate[_with_grad]).
 
+Each operator is a forward / backward function pair calling the C ABI directly (pcdet/ops/_glue.py); the ext-module name
+`pointnet2_batch_cuda` with the reference's wrapper signatures lives next to this file for third-party callers."""
 import torch
 import torch.nn as nn
-from torch.autograd import Function
 
-from . import pointnet2_batch_cuda as pointnet2
-
-
-def _i32(*shape, device):
-    return torch.empty(shape, dtype=torch.int32, device=device)
+from ... import _glue as G
 
 
-def _f32(*shape, device):
-    return torch.empty(shape, dtype=torch.float32, device=device)
+# ---- sampling / gathering ------------------------------------------------------------------------------------------------------
+def _fps(saved, xyz, npoint):
+    """xyz (B, N, 3) -> (B, npoint) int32: index 0 first, then the farthest remaining point each round."""
+    b, n, _ = xyz.shape
+    idx = G.new(xyz, (b, npoint), torch.int32)
+    running = G.new(xyz, (b, n), fill=1e10)
+    ws = G.scratch("fv2p_furthest_point_sampling_ws_bytes", xyz.device, b, n)
+    G.run("fv2p_furthest_point_sampling", b, n, npoint, xyz, running, idx, ws, ws.numel())
+    return idx
 
 
-class FurthestPointSampling(Function):
-    @staticmethod
-    def forward(ctx, xyz: torch.Tensor, npoint: int) -> torch.Tensor:
-        """xyz (B,N,3) -> (B,npoint) int32 indices; first index 0, then iterative farthest point."""
-        assert xyz.is_contiguous()
-        B, N, _ = xyz.size()
-        output = _i32(B, npoint, device=xyz.device)
-        temp = _f32(B, N, device=xyz.device).fill_(1e10)
-        pointnet2.furthest_point_sampling_wrapper(B, N, npoint, xyz, temp, output)
-        return output
-
-    @staticmethod
-    def backward(xyz, a=None):
-        return None, None
+def _gather(saved, features, idx):
+    """features (B, C, N), idx (B, M) -> (B, C, M)."""
+    b, c, n = features.shape
+    m = idx.shape[1]
+    out = G.new(features, (b, c, m))
+    G.run("fv2p_gather_points", b, c, n, m, features, idx, out)
+    saved.update(idx=idx, shape=(b, c, n, m))
+    return out
 
 
-furthest_point_sample = FurthestPointSampling.apply
+def _gather_grad(saved, grad):
+    b, c, n, m = saved["shape"]
+    g = torch.zeros((b, c, n), dtype=torch.float32, device=grad.device)
+    G.run("fv2p_gather_points_grad", b, c, n, m, grad.contiguous(), saved["idx"], g)
+    return g
 
 
-class GatherOperation(Function):
-    @staticmethod
-    def forward(ctx, features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
-        """features (B,C,N), idx (B,npoint) -> (B,C,npoint)."""
-        assert features.is_contiguous()
-        assert idx.is_contiguous()
-        B, npoint = idx.size()
-        _, C, N = features.size()
-        output = _f32(B, C, npoint, device=features.device)
-        pointnet2.gather_points_wrapper(B, C, N, npoint, features, idx, output)
-        ctx.for_backwards = (idx, C, N)
-        return output
-
-    @staticmethod
-    def backward(ctx, grad_out):
-        idx, C, N = ctx.for_backwards
-        B, npoint = idx.size()
-        grad_features = torch.zeros((B, C, N), dtype=torch.float32, device=grad_out.device)
-        pointnet2.gather_points_grad_wrapper(B, C, N, npoint, grad_out.contiguous(), idx, grad_features)
-        return grad_features, None
+# ---- nearest neighbours and interpolation -------------------------------------------------------------------------------------------
+def _three_nn(saved, unknown, known):
+    """unknown (B, N, 3), known (B, M, 3) -> (distances (B, N, 3), indices (B, N, 3)) of the three nearest known points."""
+    b, n, _ = unknown.shape
+    d2 = G.new(unknown, (b, n, 3))
+    idx = G.new(unknown, (b, n, 3), torch.int32)
+    G.run("fv2p_three_nn_batch", b, n, known.shape[1], unknown, known, d2, idx)
+    return d2.sqrt(), idx
 
 
-gather_operation = GatherOperation.apply
+def _interp(saved, features, idx, weight):
+    """features (B, C, M), idx / weight (B, N, 3) -> (B, C, N)."""
+    b, c, m = features.shape
+    n = idx.shape[1]
+    out = G.new(features, (b, c, n))
+    G.run("fv2p_three_interpolate_batch", b, c, m, n, features, idx, weight, out)
+    saved.update(idx=idx, weight=weight, shape=(b, c, m, n))
+    return out
 
 
-class ThreeNN(Function):
-    @staticmethod
-    def forward(ctx, unknown: torch.Tensor, known: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        """unknown (B,N,3), known (B,M,3) -> (dist (B,N,3) l2 distances, idx (B,N,3))."""
-        assert unknown.is_contiguous()
-        assert known.is_contiguous()
-        B, N, _ = unknown.size()
-        m = known.size(1)
-        dist2 = _f32(B, N, 3, device=unknown.device)
-        idx = _i32(B, N, 3, device=unknown.device)
-        pointnet2.three_nn_wrapper(B, N, m, unknown, known, dist2, idx)
-        return torch.sqrt(dist2), idx
-
-    @staticmethod
-    def backward(ctx, a=None, b=None):
-        return None, None
+def _interp_grad(saved, grad):
+    b, c, m, n = saved["shape"]
+    g = torch.zeros((b, c, m), dtype=torch.float32, device=grad.device)
+    G.run("fv2p_three_interpolate_batch_grad", b, c, n, m, grad.contiguous(), saved["idx"], saved["weight"], g)
+    return g
 
 
-three_nn = ThreeNN.apply
+# ---- ball query and grouping ----------------------------------------------------------------------------------------------------------
+def _ball(saved, radius, nsample, xyz, new_xyz):
+    """xyz (B, N, 3), new_xyz (B, M, 3) -> (B, M, nsample) int32, the first nsample points within `radius` in index order."""
+    b, n, _ = xyz.shape
+    m = new_xyz.shape[1]
+    idx = torch.zeros((b, m, nsample), dtype=torch.int32, device=xyz.device)
+    G.run("fv2p_ball_query_batch", b, n, m, float(radius), nsample, new_xyz, xyz, idx)
+    return idx
 
 
-class ThreeInterpolate(Function):
-    @staticmethod
-    def forward(ctx, features: torch.Tensor, idx: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
-        """features (B,C,M), idx (B,N,3), weight (B,N,3) -> (B,C,N)."""
-        assert features.is_contiguous()
-        assert idx.is_contiguous()
-        assert weight.is_contiguous()
-        B, c, m = features.size()
-        n = idx.size(1)
-        ctx.three_interpolate_for_backward = (idx, weight, m)
-        output = _f32(B, c, n, device=features.device)
-        pointnet2.three_interpolate_wrapper(B, c, m, n, features, idx, weight, output)
-        return output
-
-    @staticmethod
-    def backward(ctx, grad_out: torch.Tensor):
-        idx, weight, m = ctx.three_interpolate_for_backward
-        B, c, n = grad_out.size()
-        grad_features = torch.zeros((B, c, m), dtype=torch.float32, device=grad_out.device)
-        pointnet2.three_interpolate_grad_wrapper(B, c, n, m, grad_out.contiguous(), idx, weight, grad_features)
-        return grad_features, None, None
+def _group(saved, features, idx):
+    """features (B, C, N), idx (B, M, S) -> (B, C, M, S)."""
+    b, c, n = features.shape
+    _, m, s = idx.shape
+    out = G.new(features, (b, c, m, s))
+    G.run("fv2p_group_points_batch", b, c, n, m, s, features, idx, out)
+    saved.update(idx=idx, shape=(b, c, n, m, s))
+    return out
 
 
-three_interpolate = ThreeInterpolate.apply
+def _group_grad(saved, grad):
+    b, c, n, m, s = saved["shape"]
+    g = torch.zeros((b, c, n), dtype=torch.float32, device=grad.device)
+    G.run("fv2p_group_points_batch_grad", b, c, n, m, s, grad.contiguous(), saved["idx"], g)
+    return g
 
 
-class GroupingOperation(Function):
-    @staticmethod
-    def forward(ctx, features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
-        """features (B,C,N), idx (B,npoint,nsample) -> (B,C,npoint,nsample)."""
-        assert features.is_contiguous()
-        assert idx.is_contiguous()
-        B, nfeatures, nsample = idx.size()
-        _, C, N = features.size()
-        output = _f32(B, C, nfeatures, nsample, device=features.device)
-        pointnet2.group_points_wrapper(B, C, N, nfeatures, nsample, features, idx, output)
-        ctx.for_backwards = (idx, N)
-        return output
-
-    @staticmethod
-    def backward(ctx, grad_out: torch.Tensor):
-        idx, N = ctx.for_backwards
-        B, C, npoint, nsample = grad_out.size()
-        grad_features = torch.zeros((B, C, N), dtype=torch.float32, device=grad_out.device)
-        pointnet2.group_points_grad_wrapper(B, C, N, npoint, nsample, grad_out.contiguous(), idx, grad_features)
-        return grad_features, None
-
-
-grouping_operation = GroupingOperation.apply
-
-
-class BallQuery(Function):
-    @staticmethod
-    def forward(ctx, radius: float, nsample: int, xyz: torch.Tensor, new_xyz: torch.Tensor) -> torch.Tensor:
-        """xyz (B,N,3), new_xyz (B,npoint,3) -> idx (B,npoint,nsample) int32."""
-        assert new_xyz.is_contiguous()
-        assert xyz.is_contiguous()
-        B, N, _ = xyz.size()
-        npoint = new_xyz.size(1)
-        idx = torch.zeros((B, npoint, nsample), dtype=torch.int32, device=xyz.device)
-        pointnet2.ball_query_wrapper(B, N, npoint, radius, nsample, new_xyz, xyz, idx)
-        return idx
-
-    @staticmethod
-    def backward(ctx, a=None):
-        return None, None, None, None
-
-
-ball_query = BallQuery.apply
+FurthestPointSampling = G.autograd_op("FurthestPointSampling", _fps)
+GatherOperation = G.autograd_op("GatherOperation", _gather, _gather_grad)
+ThreeNN = G.autograd_op("ThreeNN", _three_nn)
+ThreeInterpolate = G.autograd_op("ThreeInterpolate", _interp, _interp_grad)
+GroupingOperation = G.autograd_op("GroupingOperation", _group, _group_grad)
+BallQuery = G.autograd_op("BallQuery", _ball)
+furthest_point_sample, gather_operation = FurthestPointSampling.apply, GatherOperation.apply
+three_nn, three_interpolate = ThreeNN.apply, ThreeInterpolate.apply
+grouping_operation, ball_query = GroupingOperation.apply, BallQuery.apply
 
 
 class QueryAndGroup(nn.Module):
+    """Ball query around new_xyz, then the neighbours' centred coordinates (and features) gathered into (B, 3 + C, M, S)."""
+
     def __init__(self, radius: float, nsample: int, use_xyz: bool = True):
         super().__init__()
         self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
 
-    def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: torch.Tensor = None) -> Tuple[torch.Tensor]:
-        """xyz (B,N,3), new_xyz (B,npoint,3), features (B,C,N) -> (B, 3+C, npoint, nsample)."""
+    def forward(self, xyz, new_xyz, features=None):
         idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
-        xyz_trans = xyz.transpose(1, 2).contiguous()
-        grouped_xyz = grouping_operation(xyz_trans, idx)
-        grouped_xyz -= new_xyz.transpose(1, 2).unsqueeze(-1)
-        if features is not None:
-            grouped_features = grouping_operation(features, idx)
-            new_features = torch.cat([grouped_xyz, grouped_features], dim=1) if self.use_xyz else grouped_features
-        else:
+        rel = grouping_operation(xyz.transpose(1, 2).contiguous(), idx) - new_xyz.transpose(1, 2).unsqueeze(-1)
+        if features is None:
             assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
-            new_features = grouped_xyz
-        return new_features
+            return rel
+        grouped = grouping_operation(features, idx)
+        return torch.cat([rel, grouped], dim=1) if self.use_xyz else grouped
 
 
 class GroupAll(nn.Module):
+    """One group holding every point: (B, 3 + C, 1, N)."""
+
     def __init__(self, use_xyz: bool = True):
         super().__init__()
         self.use_xyz = use_xyz
 
-    def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: torch.Tensor = None):
-        grouped_xyz = xyz.transpose(1, 2).unsqueeze(2)
-        if features is not None:
-            grouped_features = features.unsqueeze(2)
-            new_features = torch.cat([grouped_xyz, grouped_features], dim=1) if self.use_xyz else grouped_features
-        else:
-            new_features = grouped_xyz
-        return new_features
+    def forward(self, xyz, new_xyz, features=None):
+        coords = xyz.transpose(1, 2).unsqueeze(2)
+        if features is None:
+            return coords
+        return torch.cat([coords, features.unsqueeze(2)], dim=1) if self.use_xyz else features.unsqueeze(2)
+
+
+def _inverse_distance_weights(dist):
+    w = 1.0 / (dist + 1e-8)
+    return w / w.sum(dim=-1, keepdim=True)
 
 
 def top3_interpolate(xyz, new_xyz, feats, nsamples=None):
-    """xyz (N,3) with feats (N,Cf) -> inverse-distance interpolation at new_xyz (M,3): (M,Cf)
-    (Voxel-to-Point decoder, reference :292-326; gradient flows to feats only)."""
-    if not (len(xyz.shape) == len(new_xyz.shape) == len(feats.shape) == 2):
+    """Features feats (N, C) at xyz (N, 3) interpolated onto new_xyz (M, 3) from the three nearest sources with
+    inverse-distance weights -> (M, C); the gradient reaches feats only (Voxel-to-Point decoder, reference :292-326)."""
+    if not (xyz.dim() == new_xyz.dim() == feats.dim() == 2):
         raise NotImplementedError
-    xyz_batch = xyz.unsqueeze(dim=0)
-    new_xyz_batch = new_xyz.unsqueeze(dim=0)
-    feats_batch = feats.unsqueeze(dim=0).permute(0, 2, 1).contiguous()
-    dist, idx = three_nn(new_xyz_batch.contiguous(), xyz_batch.contiguous())
-    dist_recip = 1.0 / (dist + 1e-8)
-    norm = torch.sum(dist_recip, dim=2, keepdim=True)
-    weight = dist_recip / norm
-    out = three_interpolate(feats_batch, idx, weight).contiguous()
-    return out.permute(0, 2, 1).squeeze(dim=0)
+    dist, idx = three_nn(new_xyz.unsqueeze(0).contiguous(), xyz.unsqueeze(0).contiguous())
+    out = three_interpolate(feats.t().unsqueeze(0).contiguous(), idx, _inverse_distance_weights(dist))
+    return out[0].t()
 
 
 def top3_interpolate_with_grad(xyz, new_xyz, feats, nsamples=None):
-    """As top3_interpolate, but the weights are recomputed from gathered coordinates so that gradients also reach
-    xyz / new_xyz (reference :329-380)."""
-    if not (len(xyz.shape) == len(new_xyz.shape) == len(feats.shape) == 2):
+    """Same interpolation with the weights recomputed from gathered coordinates, so that gradients also reach xyz and
+    new_xyz (reference :329-380)."""
+    if not (xyz.dim() == new_xyz.dim() == feats.dim() == 2):
         raise NotImplementedError
-    xyz_batch = xyz.unsqueeze(dim=0)
-    new_xyz_batch = new_xyz.detach().unsqueeze(dim=0)
-    feats_batch = feats.unsqueeze(dim=0).permute(0, 2, 1).contiguous()
-    trans_xyz_batch = xyz.unsqueeze(dim=0).permute(0, 2, 1).contiguous()
-    _, idx = three_nn(new_xyz_batch.contiguous(), xyz_batch.contiguous())
-    threenn_xyz = grouping_operation(trans_xyz_batch, idx).squeeze(dim=0).permute(1, 2, 0).contiguous()
-    threenn_feats = grouping_operation(feats_batch, idx).squeeze(dim=0).permute(1, 2, 0).contiguous()
-    dist = torch.norm((threenn_xyz - new_xyz.unsqueeze(dim=1).expand(-1, idx.shape[-1], -1)), dim=-1)
-    dist_recip = 1.0 / (dist + 1e-8)
-    norm = torch.sum(dist_recip, dim=1, keepdim=True)
-    weight = dist_recip / norm
-    return torch.sum(threenn_feats * weight.unsqueeze(-1), dim=1)
+    _, idx = three_nn(new_xyz.detach().unsqueeze(0).contiguous(), xyz.unsqueeze(0).contiguous())
+    near_xyz = grouping_operation(xyz.t().unsqueeze(0).contiguous(), idx)[0].permute(1, 2, 0)        # (M, 3, 3)
+    near_feats = grouping_operation(feats.t().unsqueeze(0).contiguous(), idx)[0].permute(1, 2, 0)    # (M, 3, C)
+    weight = _inverse_distance_weights((near_xyz - new_xyz.unsqueeze(1)).norm(dim=-1))
+    return (near_feats * weight.unsqueeze(-1)).sum(dim=1)

@@ -1,151 +1,112 @@
-"""Stacked-batch pointnet2 autograd functions — call surface of the reference's
-pcdet/ops/pointnet2/pointnet2_stack/pointnet2_utils.py:8-262.  Rows of all samples are concatenated and
-`*_batch_cnt` (int32 [B]) gives the rows per sample."""
+"""Stacked-batch pointnet2 operators behind the names of the reference's
+pcdet/ops/pointnet2/pointnet2_stack/pointnet2_utils.py:8-262.  Rows of all samples are concatenated; `*_batch_cnt`
+(int32 [B]) holds the rows per sample.  Forward / backward function pairs on the C ABI (pcdet/ops/_glue.py)."""
 import torch
 import torch.nn as nn
-from torch.autograd import Function
 
-from . import pointnet2_stack_cuda as pointnet2
-
-
-class BallQuery(Function):
-    @staticmethod
-    def forward(ctx, radius: float, nsample: int, xyz: torch.Tensor, xyz_batch_cnt: torch.Tensor, new_xyz: torch.Tensor,
-                new_xyz_batch_cnt):
-        """-> idx (M, nsample) sample-local indices, empty_ball_mask (M) bool."""
-        assert new_xyz.is_contiguous()
-        assert new_xyz_batch_cnt.is_contiguous()
-        assert xyz.is_contiguous()
-        assert xyz_batch_cnt.is_contiguous()
-        B = xyz_batch_cnt.shape[0]
-        M = new_xyz.shape[0]
-        idx = torch.zeros((M, nsample), dtype=torch.int32, device=xyz.device)
-        pointnet2.ball_query_wrapper(B, M, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx)
-        empty_ball_mask = (idx[:, 0] == -1)
-        idx[empty_ball_mask] = 0
-        return idx, empty_ball_mask
-
-    @staticmethod
-    def backward(ctx, a=None):
-        return None, None, None, None
+from ... import _glue as G
 
 
-ball_query = BallQuery.apply
+def _cnt(t):
+    return (t if t.dtype == torch.int32 else t.int()).contiguous()
 
 
-class GroupingOperation(Function):
-    @staticmethod
-    def forward(ctx, features: torch.Tensor, features_batch_cnt: torch.Tensor, idx: torch.Tensor, idx_batch_cnt: torch.Tensor):
-        """features (N,C), idx (M,nsample) -> (M, C, nsample)."""
-        assert features.is_contiguous()
-        assert features_batch_cnt.is_contiguous()
-        assert idx.is_contiguous()
-        assert idx_batch_cnt.is_contiguous()
-        assert features.shape[0] == features_batch_cnt.sum(), \
-            'features: %s, features_batch_cnt: %s' % (str(features.shape), str(features_batch_cnt))
-        assert idx.shape[0] == idx_batch_cnt.sum(), 'idx: %s, idx_batch_cnt: %s' % (str(idx.shape), str(idx_batch_cnt))
-        M, nsample = idx.size()
-        N, C = features.size()
-        B = idx_batch_cnt.shape[0]
-        output = torch.empty((M, C, nsample), dtype=torch.float32, device=features.device)
-        pointnet2.group_points_wrapper(B, M, C, nsample, features, features_batch_cnt, idx, idx_batch_cnt, output)
-        ctx.for_backwards = (B, N, idx, features_batch_cnt, idx_batch_cnt)
-        return output
-
-    @staticmethod
-    def backward(ctx, grad_out: torch.Tensor):
-        B, N, idx, features_batch_cnt, idx_batch_cnt = ctx.for_backwards
-        M, C, nsample = grad_out.size()
-        grad_features = torch.zeros((N, C), dtype=torch.float32, device=grad_out.device)
-        pointnet2.group_points_grad_wrapper(B, M, C, N, nsample, grad_out.contiguous(), idx, idx_batch_cnt, features_batch_cnt,
-                                            grad_features)
-        return grad_features, None, None, None
+def _ball(saved, radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt):
+    """-> (idx (M, nsample) rows LOCAL to the sample, empty_ball_mask (M) bool); empty balls come back as row 0."""
+    m = new_xyz.shape[0]
+    idx = torch.zeros((m, nsample), dtype=torch.int32, device=xyz.device)
+    G.run("fv2p_ball_query_stack", xyz_batch_cnt.shape[0], m, float(radius), nsample, new_xyz, _cnt(new_xyz_batch_cnt), xyz,
+          _cnt(xyz_batch_cnt), idx)
+    empty = idx[:, 0] == -1
+    idx[empty] = 0
+    return idx, empty
 
 
-grouping_operation = GroupingOperation.apply
+def _group(saved, features, features_batch_cnt, idx, idx_batch_cnt):
+    """features (N, C), idx (M, S) sample-local -> (M, C, S)."""
+    if features.shape[0] != int(features_batch_cnt.sum()) or idx.shape[0] != int(idx_batch_cnt.sum()):
+        raise AssertionError(f"rows and batch counts disagree: features {tuple(features.shape)} / {features_batch_cnt.tolist()}, "
+                             f"idx {tuple(idx.shape)} / {idx_batch_cnt.tolist()}")
+    (m, s), (n, c) = idx.shape, features.shape
+    b = idx_batch_cnt.shape[0]
+    out = G.new(features, (m, c, s))
+    G.run("fv2p_group_points_stack", b, m, c, s, features, _cnt(features_batch_cnt), idx, _cnt(idx_batch_cnt), out)
+    saved.update(idx=idx, fc=_cnt(features_batch_cnt), ic=_cnt(idx_batch_cnt), dims=(b, m, c, n, s))
+    return out
+
+
+def _group_grad(saved, grad):
+    b, m, c, n, s = saved["dims"]
+    g = torch.zeros((n, c), dtype=torch.float32, device=grad.device)
+    G.run("fv2p_group_points_stack_grad", b, m, c, n, s, grad.contiguous(), saved["idx"], saved["ic"], saved["fc"], g)
+    return g
+
+
+def _fps(saved, xyz, npoint):
+    """xyz (B, N, 3) -> (B, npoint) int32 (the V2P decoder calls it once per sample, residual_v2p_decoder.py:216)."""
+    b, n, _ = xyz.shape
+    idx = G.new(xyz, (b, npoint), torch.int32)
+    running = G.new(xyz, (b, n), fill=1e10)
+    ws = G.scratch("fv2p_furthest_point_sampling_ws_bytes", xyz.device, b, n)
+    G.run("fv2p_furthest_point_sampling", b, n, npoint, xyz, running, idx, ws, ws.numel())
+    return idx
+
+
+def _three_nn(saved, unknown, unknown_batch_cnt, known, known_batch_cnt):
+    """unknown (N, 3), known (M, 3) -> (distances (N, 3), GLOBAL rows into known (N, 3))."""
+    if unknown.dim() != 2 or unknown.shape[1] != 3 or known.dim() != 2 or known.shape[1] != 3 or len(unknown_batch_cnt) != len(known_batch_cnt):
+        raise AssertionError("three_nn (stack): expects (N, 3) / (M, 3) and one count per sample on both sides")
+    d2 = torch.zeros_like(unknown)
+    idx = torch.zeros(unknown.shape, dtype=torch.int32, device=unknown.device)
+    G.run("fv2p_three_nn_stack", len(unknown_batch_cnt), unknown.shape[0], known.shape[0], unknown.contiguous(), _cnt(unknown_batch_cnt),
+          known.contiguous(), _cnt(known_batch_cnt), d2, idx)
+    return d2.sqrt(), idx
+
+
+def _interp(saved, features, idx, weight):
+    """features (M, C), idx / weight (N, 3) -> (N, C)."""
+    if idx.shape != weight.shape or idx.shape[1] != 3:
+        raise AssertionError("three_interpolate (stack): idx and weight must both be (N, 3)")
+    idx, weight = idx.contiguous(), weight.contiguous()
+    out = torch.zeros((idx.shape[0], features.shape[1]), dtype=features.dtype, device=features.device)
+    G.run("fv2p_three_interpolate_stack", idx.shape[0], features.shape[1], features.contiguous(), idx, weight, out)
+    saved.update(idx=idx, weight=weight, rows=features.shape[0])
+    return out
+
+
+def _interp_grad(saved, grad):
+    g = torch.zeros((saved["rows"], grad.shape[1]), dtype=grad.dtype, device=grad.device)
+    G.run("fv2p_three_interpolate_stack_grad", grad.shape[0], grad.shape[1], grad.contiguous(), saved["idx"], saved["weight"], g)
+    return g
+
+
+BallQuery = G.autograd_op("BallQuery", _ball)
+GroupingOperation = G.autograd_op("GroupingOperation", _group, _group_grad)
+FurthestPointSampling = G.autograd_op("FurthestPointSampling", _fps)
+ThreeNN = G.autograd_op("ThreeNN", _three_nn)
+ThreeInterpolate = G.autograd_op("ThreeInterpolate", _interp, _interp_grad)
+ball_query, grouping_operation = BallQuery.apply, GroupingOperation.apply
+furthest_point_sample = FurthestPointSampling.apply
+three_nn, three_interpolate = ThreeNN.apply, ThreeInterpolate.apply
 
 
 class QueryAndGroup(nn.Module):
+    """-> (new_features (M, 3 + C, S), idx (M, S)): centred neighbour coordinates and features, zeros for empty balls."""
+
     def __init__(self, radius: float, nsample: int, use_xyz: bool = True):
         super().__init__()
         self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
 
-    def forward(self, xyz: torch.Tensor, xyz_batch_cnt: torch.Tensor, new_xyz: torch.Tensor, new_xyz_batch_cnt: torch.Tensor,
-                features: torch.Tensor = None):
-        """-> new_features (M, 3+C, nsample), idx (M, nsample)."""
-        assert xyz.shape[0] == xyz_batch_cnt.sum(), 'xyz: %s, xyz_batch_cnt: %s' % (str(xyz.shape), str(new_xyz_batch_cnt))
-        assert new_xyz.shape[0] == new_xyz_batch_cnt.sum(), \
-            'new_xyz: %s, new_xyz_batch_cnt: %s' % (str(new_xyz.shape), str(new_xyz_batch_cnt))
-        idx, empty_ball_mask = ball_query(self.radius, self.nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)
-        grouped_xyz = grouping_operation(xyz, xyz_batch_cnt, idx, new_xyz_batch_cnt)
-        grouped_xyz -= new_xyz.unsqueeze(-1)
-        grouped_xyz[empty_ball_mask] = 0
-        if features is not None:
-            grouped_features = grouping_operation(features, xyz_batch_cnt, idx, new_xyz_batch_cnt)
-            grouped_features[empty_ball_mask] = 0
-            new_features = torch.cat([grouped_xyz, grouped_features], dim=1) if self.use_xyz else grouped_features
-        else:
+    def forward(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features=None):
+        if xyz.shape[0] != int(xyz_batch_cnt.sum()) or new_xyz.shape[0] != int(new_xyz_batch_cnt.sum()):
+            raise AssertionError(f"rows and batch counts disagree: xyz {tuple(xyz.shape)} / {xyz_batch_cnt.tolist()}, "
+                                 f"new_xyz {tuple(new_xyz.shape)} / {new_xyz_batch_cnt.tolist()}")
+        idx, empty = ball_query(self.radius, self.nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)
+        rel = grouping_operation(xyz, xyz_batch_cnt, idx, new_xyz_batch_cnt) - new_xyz.unsqueeze(-1)
+        rel[empty] = 0
+        if features is None:
             assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
-            new_features = grouped_xyz
-        return new_features, idx
-
-
-class FurthestPointSampling(Function):
-    @staticmethod
-    def forward(ctx, xyz: torch.Tensor, npoint: int):
-        """xyz (B,N,3) -> (B,npoint) int32 (used per sample by the V2P decoder, residual_v2p_decoder.py:216)."""
-        assert xyz.is_contiguous()
-        B, N, _ = xyz.size()
-        output = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
-        temp = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device)
-        pointnet2.furthest_point_sampling_wrapper(B, N, npoint, xyz, temp, output)
-        return output
-
-    @staticmethod
-    def backward(xyz, a=None):
-        return None, None
-
-
-furthest_point_sample = FurthestPointSampling.apply
-
-
-class ThreeNN(Function):
-    @staticmethod
-    def forward(ctx, unknown, unknown_batch_cnt, known, known_batch_cnt):
-        """-> dist (N,3) l2 distances, idx (N,3) GLOBAL rows into `known`."""
-        assert unknown.shape.__len__() == 2 and unknown.shape[1] == 3
-        assert known.shape.__len__() == 2 and known.shape[1] == 3
-        assert unknown_batch_cnt.__len__() == known_batch_cnt.__len__()
-        dist2 = unknown.new_zeros(unknown.shape)
-        idx = unknown_batch_cnt.new_zeros(unknown.shape).int()
-        pointnet2.three_nn_wrapper(unknown.contiguous(), unknown_batch_cnt.contiguous(), known.contiguous(),
-                                   known_batch_cnt.contiguous(), dist2, idx)
-        return torch.sqrt(dist2), idx
-
-    @staticmethod
-    def backward(ctx, a=None, b=None):
-        return None, None
-
-
-three_nn = ThreeNN.apply
-
-
-class ThreeInterpolate(Function):
-    @staticmethod
-    def forward(ctx, features: torch.Tensor, idx: torch.Tensor, weight: torch.Tensor):
-        """features (M,C), idx/weight (N,3) -> (N,C)."""
-        assert idx.shape[0] == weight.shape[0] and idx.shape[1] == weight.shape[1] == 3
-        ctx.three_interpolate_for_backward = (idx, weight, features.shape[0])
-        output = features.new_zeros((idx.shape[0], features.shape[1]))
-        pointnet2.three_interpolate_wrapper(features.contiguous(), idx.contiguous(), weight.contiguous(), output)
-        return output
-
-    @staticmethod
-    def backward(ctx, grad_out: torch.Tensor):
-        idx, weight, M = ctx.three_interpolate_for_backward
-        grad_features = grad_out.new_zeros((M, grad_out.shape[1]))
-        pointnet2.three_interpolate_grad_wrapper(grad_out.contiguous(), idx.contiguous(), weight.contiguous(), grad_features)
-        return grad_features, None, None
-
-
-three_interpolate = ThreeInterpolate.apply
+            return rel, idx
+        grouped = grouping_operation(features, xyz_batch_cnt, idx, new_xyz_batch_cnt)
+        grouped[empty] = 0
+        return (torch.cat([rel, grouped], dim=1) if self.use_xyz else grouped), idx

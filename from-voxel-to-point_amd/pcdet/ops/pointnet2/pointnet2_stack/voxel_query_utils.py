@@ -1,39 +1,27 @@
-"""VoxelQuery / VoxelQueryAndGrouping — surface of the reference's
+"""VoxelQuery / VoxelQueryAndGrouping behind the names of the reference's
 pcdet/ops/pointnet2/pointnet2_stack/voxel_query_utils.py:10-111 (Voxel R-CNN style neighbour-voxel grouping)."""
 import torch
 import torch.nn as nn
-from torch.autograd import Function
 
-from . import pointnet2_stack_cuda as pointnet2
+from ... import _glue as G
 from . import pointnet2_utils
 
 
-class VoxelQuery(Function):
-
-    @staticmethod
-    def forward(ctx, max_range: int, radius: float, nsample: int, xyz: torch.Tensor, new_xyz: torch.Tensor,
-                new_coords: torch.Tensor, point_indices: torch.Tensor):
-        """new_coords (M,4) [b,z,y,x] voxel coords of the queries, point_indices (B,Z,Y,X) voxel -> point row (or -1)
-        -> idx (M,nsample) GLOBAL point rows, empty_ball_mask (M)."""
-        assert new_xyz.is_contiguous()
-        assert xyz.is_contiguous()
-        assert new_coords.is_contiguous()
-        assert point_indices.is_contiguous()
-        M = new_coords.shape[0]
-        B, Z, Y, X = point_indices.shape
-        idx = torch.zeros((M, nsample), dtype=torch.int32, device=xyz.device)
-        z_range, y_range, x_range = max_range
-        pointnet2.voxel_query_wrapper(M, Z, Y, X, nsample, radius, z_range, y_range, x_range, new_xyz, xyz, new_coords,
-                                      point_indices, idx)
-        empty_ball_mask = (idx[:, 0] == -1)
-        idx[empty_ball_mask] = 0
-        return idx, empty_ball_mask
-
-    @staticmethod
-    def backward(ctx, a=None):
-        return None, None, None, None
+def _voxel_query(saved, max_range, radius, nsample, xyz, new_xyz, new_coords, point_indices):
+    """new_coords (M, 4) [b, z, y, x] voxel of every query, point_indices (B, Z, Y, X) voxel -> point row (or -1)
+    -> (idx (M, nsample) GLOBAL point rows, empty_ball_mask (M)); empty queries come back as row 0."""
+    m = new_coords.shape[0]
+    _, z, y, x = point_indices.shape
+    rz, ry, rx = max_range
+    idx = torch.zeros((m, nsample), dtype=torch.int32, device=xyz.device)
+    i32 = lambda t: t if t.dtype == torch.int32 else t.int()
+    G.run("fv2p_voxel_query_stack", m, z, y, x, nsample, float(radius), rz, ry, rx, new_xyz, xyz, i32(new_coords), i32(point_indices), idx)
+    empty = idx[:, 0] == -1
+    idx[empty] = 0
+    return idx, empty
 
 
+VoxelQuery = G.autograd_op("VoxelQuery", _voxel_query)
 voxel_query = VoxelQuery.apply
 
 
@@ -42,33 +30,21 @@ class VoxelQueryAndGrouping(nn.Module):
         super().__init__()
         self.max_range, self.radius, self.nsample = max_range, radius, nsample
 
-    def forward(self, new_coords: torch.Tensor, xyz: torch.Tensor, xyz_batch_cnt: torch.Tensor, new_xyz: torch.Tensor,
-                new_xyz_batch_cnt: torch.Tensor, features: torch.Tensor, voxel2point_indices: torch.Tensor):
-        """-> grouped_features (M,C,nsample), grouped_xyz (M,3,nsample), empty_ball_mask (M).
+    def forward(self, new_coords, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, voxel2point_indices):
+        """-> (grouped_features (M, C, S), grouped_xyz (M, 3, S), empty_ball_mask (M)).
 
-        The global->sample-local index conversion below repeats the reference line for line, including its two
-        successive subtractions (:84-99): with one sample per batch (every BASELINE config that reaches this code)
-        both are no-ops."""
-        assert xyz.shape[0] == xyz_batch_cnt.sum(), 'xyz: %s, xyz_batch_cnt: %s' % (str(xyz.shape), str(new_xyz_batch_cnt))
-        assert new_coords.shape[0] == new_xyz_batch_cnt.sum(), \
-            'new_coords: %s, new_xyz_batch_cnt: %s' % (str(new_coords.shape), str(new_xyz_batch_cnt))
-        batch_size = xyz_batch_cnt.shape[0]
-        idx1, empty_ball_mask1 = voxel_query(self.max_range, self.radius, self.nsample, xyz, new_xyz, new_coords,
-                                             voxel2point_indices)
-        idx1 = idx1.view(batch_size, -1, self.nsample)
-        count = 0
-        for bs_idx in range(batch_size):
-            idx1[bs_idx] -= count
-            count += xyz_batch_cnt[bs_idx]
-        idx1 = idx1.view(-1, self.nsample)
-        idx1[empty_ball_mask1] = 0
-        count = 0
-        for i in range(batch_size):
-            bs_mask = new_coords[:, 0] == i
-            idx1[bs_mask] -= count
-            count += xyz_batch_cnt[i]
-        idx1[empty_ball_mask1] = 0
-        idx, empty_ball_mask = idx1, empty_ball_mask1
-        grouped_xyz = pointnet2_utils.grouping_operation(xyz, xyz_batch_cnt, idx, new_xyz_batch_cnt)
-        grouped_features = pointnet2_utils.grouping_operation(features, xyz_batch_cnt, idx, new_xyz_batch_cnt)
-        return grouped_features, grouped_xyz, empty_ball_mask
+        The query returns global rows; grouping wants rows local to the sample.  The reference converts twice in a row
+        (:84-99: once per sample block of a (B, M/B, S) view, once per batch-index mask) — with one sample per batch, the only
+        case its configs reach, both are no-ops; both are kept so that multi-sample results stay what the reference gives."""
+        if xyz.shape[0] != int(xyz_batch_cnt.sum()) or new_coords.shape[0] != int(new_xyz_batch_cnt.sum()):
+            raise AssertionError("rows and batch counts disagree")
+        idx, empty = voxel_query(self.max_range, self.radius, self.nsample, xyz, new_xyz, new_coords, voxel2point_indices)
+        starts = torch.cumsum(xyz_batch_cnt, 0) - xyz_batch_cnt                                   # first row of every sample
+        b = xyz_batch_cnt.shape[0]
+        idx = (idx.view(b, -1, self.nsample) - starts.view(b, 1, 1).to(idx.dtype)).view(-1, self.nsample)
+        idx[empty] = 0
+        idx = idx - starts[new_coords[:, 0].long()].view(-1, 1).to(idx.dtype)
+        idx[empty] = 0
+        grouped_xyz = pointnet2_utils.grouping_operation(xyz, xyz_batch_cnt, idx.contiguous(), new_xyz_batch_cnt)
+        grouped_features = pointnet2_utils.grouping_operation(features, xyz_batch_cnt, idx.contiguous(), new_xyz_batch_cnt)
+        return grouped_features, grouped_xyz, empty

@@ -1,38 +1,46 @@
-"""RoIPointPool3d — call surface of the reference's pcdet/ops/roipoint_pool3d/roipoint_pool3d_utils.py:9-66
-(used by FV2P's IoUGuidedRoIHead, iouguided_roi_head.py:28,179)."""
+"""RoIPointPool3d behind the names of the reference's pcdet/ops/roipoint_pool3d/roipoint_pool3d_utils.py:9-66 (the point
+stream of FV2P's IoUGuidedRoIHead, iouguided_roi_head.py:28,179), on the C ABI (pcdet/ops/_glue.py)."""
+import torch
 import torch.nn as nn
-from torch.autograd import Function
 
-from ...utils import box_utils
-from . import roipoint_pool3d_cuda
+from .. import _glue as G
+
+
+def _enlarged(boxes3d, extra):
+    """A list widens every side by a fixed amount (box_utils.enlarge_box3d); a scalar scales the sides (expand_box3d)."""
+    big = boxes3d.clone()
+    if isinstance(extra, (list, tuple)):
+        big[..., 3:6] += boxes3d.new_tensor(extra)
+    else:
+        big[..., 3:6] += boxes3d[..., 3:6] * extra
+    return big
+
+
+def _pool(saved, points, point_features, boxes3d, pool_extra_width, num_sampled_points=512):
+    """points (B, N, 3), point_features (B, N, C), boxes3d (B, M, 7) -> (pooled (B, M, S, 3 + C), empty flag (B, M) int32):
+    per enlarged box the first S inside points in index order, wrapped around when there are fewer."""
+    if points.dim() != 3 or points.shape[2] != 3:
+        raise AssertionError("RoIPointPool3d: points must be (B, N, 3)")
+    b, n, _ = points.shape
+    m, c = boxes3d.shape[1], point_features.shape[2]
+    pooled = torch.zeros((b, m, num_sampled_points, 3 + c), dtype=point_features.dtype, device=point_features.device)
+    empty = torch.zeros((b, m), dtype=torch.int32, device=point_features.device)
+    G.run("fv2p_roipoint_pool3d", points.contiguous(), _enlarged(boxes3d, pool_extra_width).contiguous(), point_features.contiguous(),
+          b, n, m, c, num_sampled_points, pooled, empty)
+    return pooled, empty
+
+
+def _no_grad(saved, *grads):
+    raise NotImplementedError   # as the reference (:65-66): the pool is used under no_grad
+
+
+RoIPointPool3dFunction = G.autograd_op("RoIPointPool3dFunction", _pool, _no_grad)
 
 
 class RoIPointPool3d(nn.Module):
     def __init__(self, num_sampled_points=512, pool_extra_width=1.0):
         super().__init__()
-        self.num_sampled_points = num_sampled_points
-        self.pool_extra_width = pool_extra_width
+        self.num_sampled_points, self.pool_extra_width = num_sampled_points, pool_extra_width
 
     def forward(self, points, point_features, boxes3d):
-        """points (B,N,3), point_features (B,N,C), boxes3d (B,M,7) -> (B,M,S,3+C), (B,M)."""
         return RoIPointPool3dFunction.apply(points, point_features, boxes3d, self.pool_extra_width, self.num_sampled_points)
-
-
-class RoIPointPool3dFunction(Function):
-    @staticmethod
-    def forward(ctx, points, point_features, boxes3d, pool_extra_width, num_sampled_points=512):
-        assert points.shape.__len__() == 3 and points.shape[2] == 3
-        batch_size, boxes_num, feature_len = points.shape[0], boxes3d.shape[1], point_features.shape[2]
-        if isinstance(pool_extra_width, list):
-            pooled_boxes3d = box_utils.enlarge_box3d(boxes3d.view(-1, 7), pool_extra_width).view(batch_size, -1, 7)
-        else:
-            pooled_boxes3d = box_utils.expand_box3d(boxes3d.view(-1, 7), pool_extra_width).view(batch_size, -1, 7)
-        pooled_features = point_features.new_zeros((batch_size, boxes_num, num_sampled_points, 3 + feature_len))
-        pooled_empty_flag = point_features.new_zeros((batch_size, boxes_num)).int()
-        roipoint_pool3d_cuda.forward(points.contiguous(), pooled_boxes3d.contiguous(), point_features.contiguous(),
-                                     pooled_features, pooled_empty_flag)
-        return pooled_features, pooled_empty_flag
-
-    @staticmethod
-    def backward(ctx, grad_out):
-        raise NotImplementedError
