@@ -370,7 +370,21 @@ def cpu_baseline_fv2p(model, args):
         loss = ref([torch.from_numpy(pts)], feats, coords, pad_gt_boxes([bx], "cpu", max_gt=40), u)
         loss.backward()
     dt = time.perf_counter() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "point clouds/s", "cores": cores, "kind": "port",
+    # the two host-side paths north_star names, single thread each: the reference voxeliser with its dense
+    # 360 MB coordinate map allocated and filled per call (voxel_generator.py:114, 136-207) and the CPU greedy NMS over the
+    # rotated-IoU matrix of the 9000 proposals of the train config (iou3d_nms.cpp:121-135 + iou3d_cpu.cpp)
+    vt = []
+    for _ in range(5):
+        t1 = time.perf_counter()
+        oracle.points_to_voxel(pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, cfg.max_points_per_voxel, cfg.max_voxels)
+        vt.append(time.perf_counter() - t1)
+    bx = synth.proposal_boxes(1, 9000)
+    t1 = time.perf_counter()
+    kept = oracle.nms(bx, -np.arange(9000, dtype=np.float32), cfg.nms_thresh)
+    nms_s = time.perf_counter() - t1
+    extras = {"voxelize_16384pts_ms": round(sorted(vt)[2] * 1e3, 2), "nms_9000_boxes_ms": round(nms_s * 1e3, 1), "nms_survivors": int(len(kept)),
+              "threads": 1}
+    return {"value": round(1.0 / dt, 4), "unit": "point clouds/s", "cores": cores, "kind": "port", "single_op_baselines": extras,
             "sample": f"1 FV2P train step (forward + backward, no optimiser) at batch 1 on one synthetic {args.points}-point cloud: oracle "
                       f"voxeliser, rulebooks, per-offset gather/mm/scatter sparse convs, single-thread C ports of FPS / 3-NN / NMS / "
                       f"IoU / pools, torch-CPU dense layers ({cores} threads), {dt:.1f} s"}

@@ -708,6 +708,157 @@ __global__ __launch_bounds__(kFpsWaves * 64) void fps_wave_k(int n, int m, int b
   }
 }
 
+// ---- streaming furthest point sampling (clouds too large for one CU's registers: n > 24576, e.g. Waymo's ~180 k) ----------
+// Same picks again, with the points left in memory.  The Morton-sorted cloud is cut into buckets of 256 points (<= 1024
+// buckets: one per thread); a bucket's box, exact running maximum, the priority and the coordinates of the point holding it
+// stay in LDS.  Per round: every thread tests ITS bucket against the new point (box bound, exact), touched buckets are
+// compacted into a list, the 16 waves take them in turn (four coalesced 64-point rows of x, y, z, distance, priority from
+// L2, distance pass, one DPP reduction), then the arg-max over the bucket states picks the next point.  Memory traffic per
+// round is the touched buckets only (a few KB), against all n points for the plain kernel.
+__global__ void fps_stream_prep_k(int64_t total, int n, const float* __restrict__ dataset, const float* __restrict__ temp, const uint64_t* __restrict__ keys,
+                                  int bs, float* __restrict__ sx, float* __restrict__ sy, float* __restrict__ sz, float* __restrict__ sd,
+                                  uint32_t* __restrict__ sp) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  int log2bs = 0;
+  while ((1 << (log2bs + 1)) <= bs) ++log2bs;
+  const int64_t smp = t / n;
+  const int k = static_cast<int>(keys[t] & 0xffffffull);
+  const float* p = dataset + (smp * n + k) * 3;
+  sx[t] = p[0]; sy[t] = p[1]; sz[t] = p[2];
+  sd[t] = temp[smp * n + k];
+  const uint32_t owner = static_cast<uint32_t>(k) & static_cast<uint32_t>(bs - 1);
+  sp[t] = ((__brev(owner) >> (32 - log2bs)) << 16) | static_cast<uint32_t>(k >> log2bs);
+}
+__global__ void fps_stream_post_k(int64_t total, int n, const uint64_t* __restrict__ keys, const float* __restrict__ sd, float* __restrict__ temp) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  temp[(t / n) * n + static_cast<int>(keys[t] & 0xffffffull)] = sd[t];
+}
+
+constexpr int kStreamBucket = 256;
+__global__ __launch_bounds__(1024) void fps_stream_k(int n, int m, int bs, const float* __restrict__ dataset, const float* __restrict__ sx_,
+                                                     const float* __restrict__ sy_, const float* __restrict__ sz_, float* __restrict__ sd_,
+                                                     const uint32_t* __restrict__ sp_, int* __restrict__ idxs) {
+  if (m <= 0) return;
+  __shared__ float s_max[1024];
+  __shared__ uint32_t s_prio[1024];
+  __shared__ __attribute__((aligned(16))) float s_cand[1024][4];
+  __shared__ int s_list[1024];
+  __shared__ int s_count[2];
+  __shared__ __attribute__((aligned(16))) uint32_t s_wave[16][4];
+  int log2bs = 0;
+  while ((1 << (log2bs + 1)) <= bs) ++log2bs;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t base = static_cast<int64_t>(b) * n;
+  const float *sx = sx_ + base, *sy = sy_ + base, *sz = sz_ + base;
+  float* sd = sd_ + base;
+  const uint32_t* sp = sp_ + base;
+  dataset += base * 3;
+  idxs += static_cast<int64_t>(b) * m;
+  const int nb = (n + kStreamBucket - 1) / kStreamBucket;
+  auto index_of = [&](uint32_t pr) -> int { return static_cast<int>(((pr & 0xffffu) << log2bs) | (__brev(pr >> 16) >> (32 - log2bs))); };
+  // one bucket: distance pass against (x1, y1, z1) when `update`, then its exact (max, priority, coordinates) into LDS
+  auto process = [&](int bk, bool update, float x1, float y1, float z1) {
+    float bv = -2.f, bx = 0.f, by = 0.f, bz = 0.f;
+    uint32_t bp = 0xffffffffu;
+#pragma unroll
+    for (int r = 0; r < kStreamBucket / 64; ++r) {
+      const int pos = bk * kStreamBucket + r * 64 + lane;
+      const bool ok = pos < n;
+      const int pc = ok ? pos : n - 1;
+      const float x = sx[pc], y = sy[pc], z = sz[pc];
+      float d = sd[pc];
+      const uint32_t pr = sp[pc];
+      if (update) {
+        d = fminf(sqdist(x, y, z, x1, y1, z1), d);
+        if (ok) sd[pc] = d;
+      }
+      const bool better = ok & ((d > bv) | ((d == bv) & (pr < bp)));
+      bv = better ? d : bv; bp = better ? pr : bp; bx = better ? x : bx; by = better ? y : by; bz = better ? z : bz;
+    }
+    const float mx = wave_max_f32(bv);
+    const uint64_t holders = __ballot(bv == mx);
+    int leader = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(holders)) - 1);
+    uint32_t pm = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(bp), leader));
+    if (holders & (holders - 1)) {
+      pm = wave_min_u32(bv == mx ? bp : 0xffffffffu);
+      leader = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(__ballot(bv == mx && bp == pm))) - 1);
+    }
+    const float cx = lane_f(bx, leader), cy = lane_f(by, leader), cz = lane_f(bz, leader);
+    if (lane == 0) {
+      s_max[bk] = mx;
+      s_prio[bk] = pm;
+      *reinterpret_cast<float4*>(&s_cand[bk][0]) = make_float4(cx, cy, cz, 0.f);
+    }
+  };
+  // my bucket's box (thread t <-> bucket t), from the sorted coordinates
+  float lo0 = INFINITY, lo1 = INFINITY, lo2 = INFINITY, hi0 = -INFINITY, hi1 = -INFINITY, hi2 = -INFINITY;
+  if (tid < nb) {
+    const int e = min(n, (tid + 1) * kStreamBucket);
+    for (int pos = tid * kStreamBucket; pos < e; ++pos) {
+      const float x = sx[pos], y = sy[pos], z = sz[pos];
+      lo0 = fminf(lo0, x); hi0 = fmaxf(hi0, x); lo1 = fminf(lo1, y); hi1 = fmaxf(hi1, y); lo2 = fminf(lo2, z); hi2 = fmaxf(hi2, z);
+    }
+  } else {
+    s_max[tid] = -2.f;
+    s_prio[tid] = 0xffffffffu;
+  }
+  for (int bk = w; bk < nb; bk += 16) process(bk, false, 0.f, 0.f, 0.f);
+  if (tid == 0) { s_count[0] = 0; s_count[1] = 0; idxs[0] = 0; }
+  __syncthreads();
+  float x1 = dataset[0], y1 = dataset[1], z1 = dataset[2];
+  for (int j = 1; j < m; ++j) {
+    const int buf = j & 1;
+    // 1. which buckets can the new point still lower?  (box bound in sqdist's operation order: exact skip)
+    const float gx = fmaxf(fmaxf(lo0 - x1, x1 - hi0), 0.f);
+    const float gy = fmaxf(fmaxf(lo1 - y1, y1 - hi1), 0.f);
+    const float gz = fmaxf(fmaxf(lo2 - z1, z1 - hi2), 0.f);
+    const float lb = gx * gx + gy * gy + gz * gz;
+    const bool touch = tid < nb && lb < s_max[tid];
+    const uint64_t tm = __ballot(touch);
+    if (tm) {
+      int off = 0;
+      if (lane == 0) off = atomicAdd(&s_count[buf], __popcll(tm));
+      off = __builtin_amdgcn_readfirstlane(off);
+      if (touch) s_list[off + __popcll(tm & ((1ull << lane) - 1ull))] = tid;
+    }
+    __syncthreads();
+    // 2. the waves share the touched buckets
+    const int nt = s_count[buf];
+    for (int i = w; i < nt; i += 16) process(s_list[i], true, x1, y1, z1);
+    if (tid == 0) s_count[buf ^ 1] = 0;
+    __syncthreads();   // also orders the distance stores before the next round's loads (same CU, workgroup scope)
+    // 3. arg-max over the bucket states: one per thread, wave reduction, 16 wave candidates
+    const float v = s_max[tid];
+    const uint32_t pv = s_prio[tid];
+    const float wm = wave_max_f32(v);
+    const uint64_t top = __ballot(v == wm);
+    int wl = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(top)) - 1);
+    uint32_t wp = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(pv), wl));
+    if (top & (top - 1)) {
+      wp = wave_min_u32(v == wm ? pv : 0xffffffffu);
+      wl = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(__ballot(v == wm && pv == wp))) - 1);
+    }
+    if (lane == 0) *reinterpret_cast<uint4*>(&s_wave[w][0]) = make_uint4(__float_as_uint(fmaxf(wm, 0.f)), wp, static_cast<uint32_t>(w * 64 + wl), 0u);
+    __syncthreads();
+    const uint4 c = lane < 16 ? *reinterpret_cast<const uint4*>(&s_wave[lane][0]) : make_uint4(0u, 0xffffffffu, 0u, 0u);
+    const float gmax = lane_f(row_max_f32(__uint_as_float(c.x)), 0);
+    const uint64_t gtop = __ballot(lane < 16 && __uint_as_float(c.x) == gmax);
+    int gw = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(gtop)) - 1);
+    uint32_t gprio = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(c.y), gw));
+    if (gtop & (gtop - 1)) {
+      gprio = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(row_min_u32(__uint_as_float(c.x) == gmax ? c.y : 0xffffffffu)), 0));
+      gw = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(__ballot(lane < 16 && __uint_as_float(c.x) == gmax && c.y == gprio))) - 1);
+    }
+    const int gb = __builtin_amdgcn_readlane(static_cast<int>(c.z), gw);
+    const float4 p = *reinterpret_cast<const float4*>(&s_cand[gb][0]);
+    x1 = p.x; y1 = p.y; z1 = p.z;
+    if (tid == 0) idxs[j] = index_of(gprio);
+    // s_wave is rewritten only after the next round's two barriers: no fourth barrier needed
+  }
+}
+
 // ------------------------------------------------------------------ three_nn / interpolate --------
 // one query per thread, known points staged through LDS; strict '<' keeps the lowest index on ties
 // (interpolate_gpu.cu:37-55; the reference's double best* hold float values: float compares are identical).
@@ -992,7 +1143,7 @@ extern "C" int fv2p_group_points_stack_grad(int b, int m, int c, int n, int nsam
 
 // measured on MI355X: 1.43-1.52 us/round against 1.62 for the plain kernel at n = 16384; the Morton pre-pass (bbox, keys,
 // 3-4 radix passes) costs ~0.15 ms, so short sampling runs stay on the plain kernel
-static bool fps_bucketed_applies(int n, int m) { return n >= 2048 && n <= 48 * kFpsWaves * 64 && m >= 1024; }
+static bool fps_bucketed_applies(int n, int m) { return n >= 2048 && n <= 1024 * kStreamBucket && m >= 256; }
 
 extern "C" size_t fv2p_furthest_point_sampling_ws_bytes(int b, int n) {
   const int64_t total = static_cast<int64_t>(b > 0 ? b : 1) * (n > 0 ? n : 1);
@@ -1001,6 +1152,7 @@ extern "C" size_t fv2p_furthest_point_sampling_ws_bytes(int b, int n) {
   s.take<uint64_t>(static_cast<size_t>(total));
   s.take<uint64_t>(static_cast<size_t>(total));
   s.take<char>(radix_sort_ws_bytes(total));
+  if (n > 48 * kFpsWaves * 64) s.take<float>(static_cast<size_t>(total) * 5);   // streaming kernel: sorted x, y, z, distance, priority
   return s.bytes();
 }
 
@@ -1026,6 +1178,16 @@ extern "C" int fv2p_furthest_point_sampling(int b, int n, int m, const float* da
     int sbits = 0;
     while ((1 << sbits) < b) ++sbits;
     if (int rc = radix_sort_u64(keys, tmp, total, 24, 48 + sbits, rws, rb, st)) return rc;
+    if (n > 48 * kFpsWaves * 64) {   // does not fit one CU's registers: streaming kernel on the sorted copy
+      float* sx = c.take<float>(static_cast<size_t>(total) * 5);
+      float *sy = sx + total, *sz = sy + total, *sd = sz + total;
+      uint32_t* sp = reinterpret_cast<uint32_t*>(sd + total);
+      hipLaunchKernelGGL(fps_stream_prep_k, G1D(total), 0, st, total, n, dataset, temp, keys, bs, sx, sy, sz, sd, sp);
+      hipLaunchKernelGGL(fps_stream_k, dim3(b), dim3(1024), 0, st, n, m, bs, dataset, sx, sy, sz, sd, sp, idxs);
+      hipLaunchKernelGGL(fps_stream_post_k, G1D(total), 0, st, total, n, keys, sd, temp);
+      FV2P_LAUNCH_CHECK();
+      return 0;
+    }
     static int form = -1;   // FV2P_FPS_FORM=thread keeps the per-thread buckets of round 1 (the parity tests run every form)
     if (form < 0) { const char* e = getenv("FV2P_FPS_FORM"); form = (e && e[0] == 't') ? 0 : 1; }
     const int slots = static_cast<int>(ceil_div(n, kFpsWaves * 64));

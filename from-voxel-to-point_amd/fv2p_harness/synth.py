@@ -88,3 +88,14 @@ def lidar_cloud(seed, n_points=16384, pc_range=KITTI_RANGE, fov_deg=45.0, n_beam
 def waymo_like_cloud(seed, n_points=180000, return_boxes=False):
     return lidar_cloud(seed, n_points=n_points, pc_range=WAYMO_RANGE, fov_deg=180.0, az_step_deg=0.13,
                        return_boxes=return_boxes)
+
+
+def proposal_boxes(seed, n, spread=35.0):
+    """n rotated car-sized boxes clustered around n/12 centres, like a first-stage detector's output before NMS."""
+    rng = np.random.default_rng(seed)
+    centers = rng.uniform(-spread, spread, size=(max(n // 12, 1), 2))
+    xy = centers[rng.integers(0, centers.shape[0], n)] + rng.normal(0, 0.6, size=(n, 2))
+    z = rng.uniform(-1.5, 0.5, size=(n, 1))
+    dims = np.array([3.9, 1.6, 1.56]) * rng.uniform(0.7, 1.3, size=(n, 3))
+    yaw = rng.uniform(-np.pi, np.pi, size=(n, 1))
+    return np.concatenate([xy, z, dims, yaw], 1).astype(np.float32)

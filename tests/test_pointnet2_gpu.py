@@ -185,13 +185,15 @@ def test_errors_are_exceptions_not_exit(gpu):
 
 
 @pytest.mark.parametrize("n,m,b", [(16384, 2048, 2), (4099, 1500, 3), (2048, 2048, 1), (9000, 1024, 2), (9000, 64, 2), (16384, 16384, 3),
-                                   (20000, 16384, 2), (24576, 4096, 1), (24577, 1100, 1), (15000, 16384, 1), (12289, 3000, 2)])
+                                   (20000, 16384, 2), (24576, 4096, 1), (15000, 16384, 1), (12289, 3000, 2),
+                                   (24577, 1100, 1), (40000, 4096, 2), (180000, 2048, 1), (100000, 16384, 1), (262144, 300, 1)])
 def test_fps_bucketed_kernel_indices_and_running_distances(gpu, n, m, b):
     """The bucketed (lazy) FPS kernel — Morton-sorted buckets skipped when the new point cannot lower any of their
     running distances — must be indistinguishable from the reference loop: same indices AND same final `temp`
     (sampling_gpu.cu:100-216), also with duplicated points (exact ties) and n not a multiple of the bucket size."""
     from pcdet.ops.pointnet2.pointnet2_batch import pointnet2_batch_cuda as ext
-    pts = np.stack([synth.lidar_cloud(3 * n + s, n)[:, :3] for s in range(b)])
+    gen = synth.waymo_like_cloud if n > 30000 else synth.lidar_cloud      # n > 24576 runs the streaming kernel (points stay in memory)
+    pts = np.stack([gen(3 * n + s, n)[:, :3] for s in range(b)])
     pts[:, n // 2: n // 2 + 200] = pts[:, :200]          # duplicates: zero distances and exact ties
     ref_idx, ref_temp = oracle.furthest_point_sample(pts, m)
     xyz = T(pts, gpu)
