@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=["fv2p", "backbone"], default="fv2p")
+    ap.add_argument("--workload", choices=["fv2p", "backbone", "mgaf"], default="fv2p")
     ap.add_argument("--batch", type=int, default=0, help="clouds per GPU per step (0: 3 for fv2p, 4 for backbone)")
     ap.add_argument("--points", type=int, default=16384)
     ap.add_argument("--backbone", choices=["8x", "res8x"], default="8x")
@@ -71,6 +71,8 @@ def parse():
     args = ap.parse_args()
     if args.batch <= 0:
         args.batch = 3 if args.workload == "fv2p" else 4
+    if args.workload == "mgaf" and "--steps" not in sys.argv:
+        args.steps, args.warmup = 30, (args.warmup if "--warmup" in sys.argv else 5)
     if args.workload == "fv2p" and "--prefetch" not in sys.argv:
         args.prefetch = 0   # measured: the input-pipeline thread does not pay here (65.3 vs 63.7 ms per step); the step is not launch bound
     if args.steps == 300 and args.workload == "fv2p" and "--steps" not in sys.argv:
@@ -97,8 +99,12 @@ def build_step(args, device, rank, world):
     from pcdet.datasets.processor.voxel_generator import points_to_voxel_batch
 
     torch.manual_seed(0)
-    cls = VoxelBackBone8x if args.backbone == "8x" else VoxelResBackBone8x
-    model = cls(4, [1408, 1600, 40]).to(device)
+    if args.workload == "mgaf":   # BASELINE configs[3]: sparse backbone + DCN BEV backbone + centre head (fv2p_harness/mgaf_model.py)
+        from fv2p_harness.mgaf_model import MGAFDetector
+        model = MGAFDetector().to(device)
+    else:
+        cls = VoxelBackBone8x if args.backbone == "8x" else VoxelResBackBone8x
+        model = cls(4, [1408, 1600, 40]).to(device)
     from fv2p_harness import dist_utils
 
     class TrainStep(torch.nn.Module):
@@ -110,6 +116,8 @@ def build_step(args, device, rank, world):
             self.body = body
 
         def forward(self, feats, coords, batch):
+            if args.workload == "mgaf":
+                return self.body(feats, coords, batch)
             out, _ = self.body(feats, coords, batch)
             return out.features.square().mean()
 
@@ -133,7 +141,8 @@ def build_step(args, device, rank, world):
         # the input pipeline also builds the batch's rulebooks (they depend on coordinates only): recipe from one pass
         with torch.no_grad():
             f0, c0 = voxelize(pool[0])
-            recipe = spconv.rulebook_recipe(model(f0, c0, args.batch)[0].indice_dict, c0)
+            sparse = model.backbone_3d if args.workload == "mgaf" else model
+            recipe = spconv.rulebook_recipe(sparse(f0, c0, args.batch)[0].indice_dict, c0)
 
         cache = {}
 
@@ -390,6 +399,20 @@ def cpu_baseline_fv2p(model, args):
                       f"IoU / pools, torch-CPU dense layers ({cores} threads), {dt:.1f} s"}
 
 
+def conv_kernel_name(cin, cout):
+    """The variant csrc/sparse_conv.hip dispatches for a whole-fragment forward conv of these channel counts (launch_vec)."""
+    cinp = 16 if cin <= 16 else 32 if cin <= 32 else 64 if cin <= 64 else 128
+    nb = (cout + 15) // 16
+    nbp = 1 if nb <= 1 else 2 if nb <= 2 else 4 if nb <= 4 else 8
+    if cin % 16 or cout % 16 or cin > 128 or cout > 128:
+        return "conv_rows_vec / conv_rows_scalar (fv2p_sparse_conv_rows)"
+    if cinp * nbp <= 512 and nbp % 4 == 0:
+        return f"conv_rows_dma<{cinp},{nbp},false> (fv2p_sparse_conv_rows)"
+    if cinp * nbp == 1024:
+        return "conv_rows_dma<128,4,false>, two column halves per launch (fv2p_sparse_conv_rows)"
+    return f"conv_rows_pipe<{cinp},{nbp},false> (fv2p_sparse_conv_rows)"
+
+
 def roofline_probe(model, voxelize, pool, args, device):
     """Times the dominant kernel (fused sparse-conv rows kernel of the widest-work layer) with events on the
     stream it is launched on, and prices it with SURVEY §8(d)'s algorithmic flops / bytes."""
@@ -449,7 +472,7 @@ def roofline_probe(model, voxelize, pool, args, device):
     except (OSError, KeyError, ValueError):
         pass
     return {"bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "traffic": traffic,
-            "kernel": "conv_rows_dma<64,4,false> (fv2p_sparse_conv_rows)",
+            "kernel": conv_kernel_name(cin, cout),
             "layer": layer,
             "avg_kernel_us": round(dur_s * 1e6, 2), "alg_flops": flops, "alg_bytes": bytes_alg}
 
@@ -499,6 +522,10 @@ def workload_name(args):
         return ("FV2P (fv2p.yaml, car only) end-to-end train step: HIP voxelise + MeanVFE, VoxelResBackBone8x, BEV backbone + anchor "
                 "head, FPS to 16384 key points, voxel-to-point decoder, point head, IoU-guided RoI head, losses, backward, grad clip, "
                 "AdamW; KITTI grid 0.05 m [41,1600,1408], LiDAR-like synthetic clouds with 20-40 car boxes")
+    if args.workload == "mgaf":
+        return ("MGAF-3DSSD layer replay: HIP voxelise + MeanVFE, VoxelBackBone8x, DCNBEVBackbone (3 x MdeformConvBlock), CenterAFHeadSingle "
+                "(DCNv2 feature adaption dg=4, seven heads) forward + backward + AdamW with a surrogate loss (the head's target assignment and "
+                "loss terms are not replayed); KITTI grid, LiDAR-like synthetic clouds")
     return (("VoxelBackBone8x" if args.backbone == "8x" else "VoxelResBackBone8x") +
             " train step (HIP voxelise + MeanVFE + sparse backbone fwd + bwd + AdamW), KITTI grid 0.05 m [41,1600,1408], LiDAR-like "
             "synthetic clouds")
@@ -623,6 +650,10 @@ def main():
                 result["fps"] = fps_probe(model, pool, args, device)
             if world == 1 and args.cpu_clouds > 0:
                 result["cpu_baseline"] = cpu_baseline_fv2p(model, args)
+        elif args.workload == "mgaf":
+            result["metric"] = "point clouds/sec fwd+bwd (MGAF-3DSSD layer replay, KITTI shape)"
+            if not args.no_roofline:
+                result["roofline"] = roofline_probe(model.backbone_3d, voxelize, pool, args, device)
         else:
             if not args.no_roofline:
                 result["roofline"] = roofline_probe(model, voxelize, pool, args, device)

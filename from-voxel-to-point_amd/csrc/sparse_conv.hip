@@ -457,6 +457,21 @@ __global__ __launch_bounds__(256) void conv_rows_dma(ConvArgs a) {
   constexpr int NCB = NB / 4;  // forward only
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 15, g = lane >> 4;
   const int row0 = xcd_major_tile(blockIdx.x, gridDim.x) * 64 + wave * 16;
+  if (gridDim.y > 1) {
+    // column split (128 x 128 layers: two 64 KB weight buffers do not fit next to each other): workgroup y computes the
+    // destination columns [16 NB y, 16 NB (y + 1)) from its own slice of W_k; every per-column pointer moves with it
+    const int off = blockIdx.y * NB * 16;
+    a.w += WT ? static_cast<long long>(off) * a.w_ld : off;
+    a.dst += off;
+    a.c_dst = NB * 16;
+    if (a.bias) a.bias += off;
+    if (a.stats) a.stats += off;
+    if (a.bn_x) {
+      a.bn_x += off; a.bn_mean += off; a.bn_invstd += off;
+      if (a.bn_gamma) a.bn_gamma += off;
+      if (a.bn_beta) a.bn_beta += off;
+    }
+  }
   unsigned long long t_begin = 0;
   if (a.trace) t_begin = __builtin_readcyclecounter();
   // rows past the end compute on the last row's neighbours and are never stored (no masks in the loop)
@@ -1342,6 +1357,18 @@ static void launch_vec(const ConvArgs& a, hipStream_t s) {
     if (impl == 0 && whole && a.kvol > 1) {
       ConvArgs b = a; b.trace = g_conv_trace;
       hipLaunchKernelGGL((conv_rows_dma<CINP, NB, WT>), dim3(blocks), dim3(256), 2 * CINP * NB * 16 * sizeof(float), s, b);
+      return;
+    }
+  }
+  if constexpr (CINP * NB == 1024 && NB == 8) {
+    // 128 -> 128: the LDS-DMA kernel on two column halves (grid.y), 2 x 32 KB of weights per workgroup.  The gathered rows are
+    // read by both halves (L2 hits); twice the workgroups also fill the chip better at the 10 k rows these layers have.
+    const bool whole = a.c_src == CINP && a.c_dst == NB * 16 && (a.w_ld & 3) == 0 && (a.w_kstride & 3) == 0 &&
+                       (reinterpret_cast<uintptr_t>(a.w) & 15) == 0 && (a.ld_dst & 3) == 0 &&
+                       (reinterpret_cast<uintptr_t>(a.dst) & 15) == 0 && (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0);
+    if (impl == 0 && whole && a.kvol > 1) {
+      ConvArgs b = a; b.trace = nullptr;
+      hipLaunchKernelGGL((conv_rows_dma<CINP, 4, WT>), dim3(blocks, 2), dim3(256), 2 * CINP * 4 * 16 * sizeof(float), s, b);
       return;
     }
   }

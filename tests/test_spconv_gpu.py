@@ -455,7 +455,7 @@ def test_conv_epilogue_statistics_equal_the_column_sums(gpu, impl):
     batch, shape = 2, [9, 20, 18]
     try:
         fv2p_native.call("fv2p_sparse_conv_set_impl", impl)
-        for cin, cout, subm in [(4, 16, True), (16, 16, True), (32, 64, False), (64, 64, True), (64, 128, True), (24, 40, False), (160, 144, True)]:
+        for cin, cout, subm in [(4, 16, True), (16, 16, True), (32, 64, False), (64, 64, True), (64, 128, True), (128, 128, True), (24, 40, False), (160, 144, True)]:
             ind, feats, x = make_input(cin + cout, batch, shape, 1100, cin, gpu)
             rb = ops.build_rulebook(x.indices, batch, shape, 3, 1 if subm else 2, 1, 1, 0, subm)
             n_out = rb.outids.shape[0]
@@ -545,7 +545,7 @@ def test_backward_data_conv_leaves_the_batchnorm_backward_sums(gpu):
     import fv2p_native
     slots = int(fv2p_native.lib().fv2p_sparse_conv_stat_slots())
     batch, shape = 2, [9, 20, 18]
-    for cin, cout in [(16, 32), (64, 64), (32, 160), (160, 64), (24, 40)]:     # conv cin -> cout; its dX has c_src = cout, c_dst = cin
+    for cin, cout in [(16, 32), (64, 64), (128, 128), (64, 128), (32, 160), (160, 64), (24, 40)]:     # conv cin -> cout; its dX has c_src = cout, c_dst = cin
         ind, feats, x = make_input(cin * 3 + cout, batch, shape, 1100, cin, gpu)
         rb = ops.build_rulebook(x.indices, batch, shape, 3, 1, 1, 1, 0, True)
         n = x.features.shape[0]
