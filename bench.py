@@ -65,6 +65,7 @@ def parse():
     ap.add_argument("--pin-cores", type=int, default=16, help="cores per rank to pin this process to (0: leave the affinity alone)")
     ap.add_argument("--phases", action="store_true", help="diagnostic: host issue time and synchronised wall time per phase (stderr)")
     ap.add_argument("--torch-profile", action="store_true", help="diagnostic: torch.profiler over 3 steps, top ops by device time (stderr)")
+    ap.add_argument("--miopen-find", type=int, default=0, help="torch.backends.cudnn.benchmark: let MIOpen time its solvers for the dense 2-D convs")
     ap.add_argument("--bev-channels-last", type=int, default=0, help="fv2p: BEV backbone + anchor head in channels_last memory format")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous check without a GPU: ranks join a gloo group, reduce, rank 0 prints n_gpus")
     ap.add_argument("--pyprofile", action="store_true", help="cProfile the timed steps (host-overhead hunting; prints to stderr)")
@@ -580,6 +581,7 @@ def main():
 
     if args.switch_interval > 0:
         sys.setswitchinterval(args.switch_interval)
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
     build = build_fv2p_step if args.workload == "fv2p" else build_step
     model, step, voxelize, pool = build(args, device, rank, world)
     for i in range(args.warmup):

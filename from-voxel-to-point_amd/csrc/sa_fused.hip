@@ -1,0 +1,354 @@
+// Fused grid set-abstraction of the RoI head (A11 consumers: PointnetSAModuleMSG as IoUGuidedRoIHead builds it,
+// pcdet/models/roi_heads/iouguided_roi_head.py:52-76, 258-275; pcdet/ops/pointnet2/pointnet2_batch/pointnet2_modules.py:30-62).
+//
+// The reference materialises, per radius, the grouped tensor (R, 3 + C, M, S) — 1.39 GB at R = 384 RoIs, M = 216 grid centres,
+// S = 32 samples — and runs its shared MLP (1x1 convs + ReLU) over it as plain GEMMs, then max-pools over the S samples.  With
+// the first (linear) layer applied per POINT and per CENTRE beforehand (fv2p_harness/fv2p_model.py: sa_msg_grid), what is left
+// per (centre i, sample s) is
+//        h1 = relu(P[idx[i, s], :] - Q[i, :])          64 channels, P = per-point, Q = per-centre first-layer products
+//        h2 = relu(W2 h1)                               second shared-MLP layer, 64 x 64
+//        out[i, :] = max_s h2
+// and this file computes that without any grouped tensor: a wave gathers 16 sample rows (256 B each, one float4 per lane and
+// 16-channel block), runs the 64 x 64 layer on fp32 MFMA against W2 fragments resident in LDS, and reduces the maximum over
+// the rows in registers.  The product is formed TRANSPOSED (h2^T = W2 h1^T): then a lane that supplied the channels
+// 16j + 4g .. + 3 of sample row r as the B operand receives the channels 16b + 4g .. + 3 of the same row in its accumulators,
+// i.e. results have the operand layout and chain into the next product (backward: dh1^T = W2^T dh2^T) without any shuffle.
+//
+// Backward recomputes h1 / h2 (nothing but `out` was stored), routes d out to the samples that attain the maximum (evenly
+// among exact ties, as torch.amax; tied samples are repeats of one point here: ball query pads with the first hit), and
+// produces dP (scatter-add into an LDS tile per RoI and 32-channel half, flushed once), dQ (row sums, direct stores) and
+// dW2 (MFMA over the sample rows after an LDS transpose; one partial tile per workgroup, summed by a second launch).
+#include "common.hpp"
+
+namespace fv2p {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kSaC = 64;          // channels of both layers
+constexpr int kSaCentres = 16;    // centres per workgroup (forward)
+
+#define FV2P_SA_ROWOP(op, v, ctrl) asm volatile("s_nop 1\n\t" op " %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(v))
+// reduce over the 16 lanes of a DPP row (= the 16 sample rows of a tile; lanes sharing l / 16 hold the same channels)
+__device__ __forceinline__ float row16_max(float v) {
+  FV2P_SA_ROWOP("v_max_f32_dpp", v, "quad_perm:[1,0,3,2]");
+  FV2P_SA_ROWOP("v_max_f32_dpp", v, "quad_perm:[2,3,0,1]");
+  FV2P_SA_ROWOP("v_max_f32_dpp", v, "row_half_mirror");
+  FV2P_SA_ROWOP("v_max_f32_dpp", v, "row_mirror");
+  return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  FV2P_SA_ROWOP("v_add_f32_dpp", v, "quad_perm:[1,0,3,2]");
+  FV2P_SA_ROWOP("v_add_f32_dpp", v, "quad_perm:[2,3,0,1]");
+  FV2P_SA_ROWOP("v_add_f32_dpp", v, "row_half_mirror");
+  FV2P_SA_ROWOP("v_add_f32_dpp", v, "row_mirror");
+  return v;
+}
+
+// LDS image of a 64 x 64 row-major matrix A for the role "A operand of D = A * X^T": frag[b][j][lane] (float4) =
+// A[16 b + lane % 16][16 j + 4 (lane / 16) .. + 3]
+__device__ __forceinline__ void stage_frag(const float* __restrict__ a, bool transpose, float* __restrict__ lds) {
+  for (int e = threadIdx.x; e < 16 * 64; e += blockDim.x) {
+    const int lane = e & 63, bj = e >> 6, b = bj >> 2, j = bj & 3;
+    const int row = 16 * b + (lane & 15), col = 16 * j + 4 * (lane >> 4);
+    float4 v;
+    if (!transpose) v = *reinterpret_cast<const float4*>(a + row * kSaC + col);
+    else v = make_float4(a[(col + 0) * kSaC + row], a[(col + 1) * kSaC + row], a[(col + 2) * kSaC + row], a[(col + 3) * kSaC + row]);
+    *reinterpret_cast<float4*>(lds + e * 4) = v;
+  }
+}
+// acc[b] += A-fragments(lds)[b][j] * x[j]   (x[j] = this lane's float4 of channel block j of its row)
+__device__ __forceinline__ void mma64(const float* __restrict__ frag, int lane, const float4 (&x)[4], f32x4 (&acc)[4]) {
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 a = *reinterpret_cast<const float4*>(frag + ((b * 4 + j) * 64 + lane) * 4);
+      acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x[j].x, acc[b], 0, 0, 0);
+      acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x[j].y, acc[b], 0, 0, 0);
+      acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x[j].z, acc[b], 0, 0, 0);
+      acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x[j].w, acc[b], 0, 0, 0);
+    }
+  }
+}
+__device__ __forceinline__ float4 relu_sub(float4 p, float4 q) {
+  return make_float4(fmaxf(p.x - q.x, 0.f), fmaxf(p.y - q.y, 0.f), fmaxf(p.z - q.z, 0.f), fmaxf(p.w - q.w, 0.f));
+}
+
+// ------------------------------------------------------------------ forward ---------------------------------------------------
+// grid (ceil(M / 16), R), block 256: wave w handles centres 16 * blockIdx.x + w, w + 4, ...
+__global__ __launch_bounds__(256) void sa_grid_fwd_k(int n, int m, int s, const float* __restrict__ P, const float* __restrict__ Q,
+                                                     const int* __restrict__ idx, const float* __restrict__ W2, float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float wfrag[16 * 64 * 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 15, g = lane >> 4;
+  const int r = blockIdx.y;
+  stage_frag(W2, false, wfrag);
+  __syncthreads();
+  const float* Pr = P + static_cast<long long>(r) * n * kSaC;
+  for (int ci = wave; ci < kSaCentres; ci += 4) {
+    const int i = blockIdx.x * kSaCentres + ci;
+    if (i >= m) break;
+    const float* q = Q + (static_cast<long long>(r) * m + i) * kSaC + 4 * g;
+    float4 qv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) qv[j] = *reinterpret_cast<const float4*>(q + 16 * j);
+    const int* id = idx + (static_cast<long long>(r) * m + i) * s;
+    float best[4][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) best[b][e] = 0.f;   // relu output: the maximum is >= 0
+    for (int t = 0; t < s; t += 16) {
+      const float* p = Pr + static_cast<long long>(id[t + row]) * kSaC + 4 * g;
+      float4 x[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[j] = relu_sub(*reinterpret_cast<const float4*>(p + 16 * j), qv[j]);
+      f32x4 acc[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      mma64(wfrag, lane, x, acc);
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) best[b][e] = fmaxf(best[b][e], acc[b][e]);
+    }
+    // lane (row, g) holds channels 16 b + 4 g + e of sample row `row`: maximum over the 16 lanes of the DPP row
+    float* o = out + (static_cast<long long>(r) * m + i) * kSaC + 4 * g;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      float4 v;
+      v.x = row16_max(best[b][0]); v.y = row16_max(best[b][1]); v.z = row16_max(best[b][2]); v.w = row16_max(best[b][3]);
+      if (row == 0) *reinterpret_cast<float4*>(o + 16 * b) = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ backward --------------------------------------------------
+// grid (2, R): workgroup (h, r) owns the channel half h of dP / dQ (channels 32 h .. 32 h + 31) and the row half h of dW2
+// (output channels c' in the same range) of RoI r; block 256, wave w takes centres w, w + 4, ...  S <= 32.
+constexpr int kSaTs = 72;   // row stride of the transpose tiles (floats): 64 + 8, conflict-light both ways
+template <int TILES>         // samples per centre / 16: register arrays below are indexed by compile-time tile numbers only
+__global__ __launch_bounds__(256) void sa_grid_bwd_k(int n, int m, const float* __restrict__ P, const float* __restrict__ Q,
+                                                     const int* __restrict__ idx, const float* __restrict__ W2, const float* __restrict__ out,
+                                                     const float* __restrict__ dout, float* __restrict__ dP, float* __restrict__ dQ,
+                                                     float* __restrict__ dW2_partial) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* wfrag = lds;                          // W2      as A operand (forward recompute)      16 KB
+  float* wtfrag = lds + 16 * 64 * 4;           // W2^T    as A operand (dh1^T = W2^T dh2^T)     16 KB
+  float* tile = wtfrag + 16 * 64 * 4;          // per wave: two 16 x 72 transpose tiles (dh2, h1)
+  float* dpt = tile + 4 * 2 * 16 * kSaTs;      // dP accumulator of this RoI and channel half: [n][32]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 15, g = lane >> 4;
+  const int half = blockIdx.x, r = blockIdx.y;
+  stage_frag(W2, false, wfrag);
+  stage_frag(W2, true, wtfrag);
+  for (int e = threadIdx.x; e < n * 32; e += 256) dpt[e] = 0.f;
+  __syncthreads();
+  float* t_dh2 = tile + wave * 2 * 16 * kSaTs;
+  float* t_h1 = t_dh2 + 16 * kSaTs;
+  const float* Pr = P + static_cast<long long>(r) * n * kSaC;
+  // dW2 rows c' = 32 half + 16 bb + ..., all 64 columns: 2 x 4 accumulator tiles, summed over every sample row this wave sees
+  f32x4 dw[2][4];
+#pragma unroll
+  for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+    for (int bc = 0; bc < 4; ++bc) dw[bb][bc] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int s = TILES * 16;
+  for (int i = wave; i < m; i += 4) {
+    const float* q = Q + (static_cast<long long>(r) * m + i) * kSaC + 4 * g;
+    float4 qv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) qv[j] = *reinterpret_cast<const float4*>(q + 16 * j);
+    const int* id = idx + (static_cast<long long>(r) * m + i) * s;
+    const float* o = out + (static_cast<long long>(r) * m + i) * kSaC + 4 * g;
+    const float* go = dout + (static_cast<long long>(r) * m + i) * kSaC + 4 * g;
+    // pass 1: recompute h2, count the samples that attain the stored maximum (per channel)
+    float cnt[4][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cnt[b][e] = 0.f;
+    float4 mx[4], gd[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { mx[b] = *reinterpret_cast<const float4*>(o + 16 * b); gd[b] = *reinterpret_cast<const float4*>(go + 16 * b); }
+    float4 x[TILES][4];
+    f32x4 h2[TILES][4];
+    int src[TILES];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      src[t] = id[16 * t + row];
+      const float* p = Pr + static_cast<long long>(src[t]) * kSaC + 4 * g;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[t][j] = relu_sub(*reinterpret_cast<const float4*>(p + 16 * j), qv[j]);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) h2[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      mma64(wfrag, lane, x[t], h2[t]);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const float mv[4] = {mx[b].x, mx[b].y, mx[b].z, mx[b].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cnt[b][e] += (h2[t][b][e] == mv[e] && mv[e] > 0.f) ? 1.f : 0.f;
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cnt[b][e] = row16_sum(cnt[b][e]);
+    // pass 2 per tile: dh2, dh1 = (W2^T dh2) * [h1 > 0], scatter / reduce, dW2 += dh2^T h1
+    float dq[2][4];
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dq[bb][e] = 0.f;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      float4 dh2[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const float mv[4] = {mx[b].x, mx[b].y, mx[b].z, mx[b].w}, gv[4] = {gd[b].x, gd[b].y, gd[b].z, gd[b].w};
+        float d[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = (h2[t][b][e] == mv[e] && mv[e] > 0.f) ? gv[e] / cnt[b][e] : 0.f;
+        dh2[b] = make_float4(d[0], d[1], d[2], d[3]);
+      }
+      // dh1^T block bb of this half: channels 32 half + 16 bb + 4 g + e
+      f32x4 d1[2];
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        d1[bb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int b = 2 * half + bb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 a = *reinterpret_cast<const float4*>(wtfrag + ((b * 4 + j) * 64 + lane) * 4);
+          d1[bb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, dh2[j].x, d1[bb], 0, 0, 0);
+          d1[bb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, dh2[j].y, d1[bb], 0, 0, 0);
+          d1[bb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, dh2[j].z, d1[bb], 0, 0, 0);
+          d1[bb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, dh2[j].w, d1[bb], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        const float4 h = half ? x[t][2 + bb] : x[t][bb];   // (a runtime index would push the array into scratch)
+        const float hv[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = hv[e] > 0.f ? d1[bb][e] : 0.f;
+          dq[bb][e] += v;
+          if (v != 0.f) atomicAdd(&dpt[src[t] * 32 + 16 * bb + 4 * g + e], v);
+        }
+      }
+      // dW2[c'][c] += sum_rows dh2[row][c'] h1[row][c]: rows become the K dimension -> transpose both tiles through LDS
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        *reinterpret_cast<float4*>(t_h1 + row * kSaTs + 16 * b + 4 * g) = x[t][b];
+        if ((b >> 1) == half) *reinterpret_cast<float4*>(t_dh2 + row * kSaTs + 16 * (b & 1) + 4 * g) = dh2[b];
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's own LDS writes (tiles are private to the wave)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {       // K step: sample rows 4 ks + g
+        float a[2], bcol[4];
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) a[bb] = t_dh2[(4 * ks + g) * kSaTs + 16 * bb + row];       // A[m = c' % 16][k = row]
+#pragma unroll
+        for (int bc = 0; bc < 4; ++bc) bcol[bc] = t_h1[(4 * ks + g) * kSaTs + 16 * bc + row];      // B[k = row][n = c % 16]
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+          for (int bc = 0; bc < 4; ++bc) dw[bb][bc] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[bb], bcol[bc], dw[bb][bc], 0, 0, 0);
+      }
+    }
+    // dQ[i][c] = - sum over the centre's samples of dh1 (the 16 lanes of the DPP row), this half's 32 channels
+    float* dqo = dQ + (static_cast<long long>(r) * m + i) * kSaC + 32 * half + 4 * g;
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) {
+      float4 v;
+      v.x = -row16_sum(dq[bb][0]); v.y = -row16_sum(dq[bb][1]); v.z = -row16_sum(dq[bb][2]); v.w = -row16_sum(dq[bb][3]);
+      if (row == 0) *reinterpret_cast<float4*>(dqo + 16 * bb) = v;
+    }
+  }
+  __syncthreads();
+  // flush dP (each (RoI, half) tile is owned by this workgroup: plain stores)
+  float* dpo = dP + static_cast<long long>(r) * n * kSaC + 32 * half;
+  for (int e = threadIdx.x; e < n * 8; e += 256) {
+    const int pt = e >> 3, c4 = (e & 7) * 4;
+    *reinterpret_cast<float4*>(dpo + static_cast<long long>(pt) * kSaC + c4) = *reinterpret_cast<const float4*>(dpt + pt * 32 + c4);
+  }
+  // dW2 partial of this workgroup: the four waves' accumulators summed through LDS (the transpose tiles are free now)
+  float* red = tile;   // [4 waves][2][4][256] floats = 32 KB > tile space: reuse wfrag + wtfrag as well (all waves are past them)
+  __syncthreads();
+  float* buf = lds;    // 32 KB of fragments + tiles: enough for 4 x 2 x 4 x 64 x 4 floats = 32 KB
+  (void)red;
+#pragma unroll
+  for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+    for (int bc = 0; bc < 4; ++bc)
+      *reinterpret_cast<f32x4*>(buf + (((wave * 2 + bb) * 4 + bc) * 64 + lane) * 4) = dw[bb][bc];
+  __syncthreads();
+  // accumulator (bb, bc) of lane l holds dW2[32 half + 16 bb + 4 (l / 16) + e][16 bc + l % 16]
+  float* dwo = dW2_partial + (static_cast<long long>(r) * 2 + half) * 32 * kSaC;
+  for (int e = threadIdx.x; e < 2 * 4 * 64 * 4; e += 256) {
+    const int comp = e & 3, l = (e >> 2) & 63, bc = (e >> 8) & 3, bb = e >> 10;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) v += buf[(((w * 2 + bb) * 4 + bc) * 64 + l) * 4 + comp];
+    dwo[(16 * bb + 4 * (l >> 4) + comp) * kSaC + 16 * bc + (l & 15)] = v;
+  }
+}
+
+// dW2[c'][c] = sum over RoIs of the partial tiles (fixed order: deterministic)
+__global__ void sa_grid_dw_reduce_k(int rois, const float* __restrict__ partial, float* __restrict__ dW2) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= kSaC * kSaC) return;
+  const int cp = t / kSaC, c = t % kSaC, half = cp / 32, lr = cp % 32;
+  float s = 0.f;
+  for (int r = 0; r < rois; ++r) s += partial[((static_cast<long long>(r) * 2 + half) * 32 + lr) * kSaC + c];
+  dW2[t] = s;
+}
+
+}  // namespace fv2p
+using namespace fv2p;
+
+static bool sa_shapes_ok(int rois, int n, int m, int s, int c) {
+  return rois >= 1 && n >= 1 && m >= 1 && c == kSaC && (s == 16 || s == 32) && rois <= 65535;
+}
+
+extern "C" int fv2p_sa_grid_supported(int n, int m, int s, int c) {
+  return (c == kSaC && (s == 16 || s == 32) && n >= 1 && m >= 1 && static_cast<size_t>(n) * 32 * 4 <= 96 * 1024) ? 1 : 0;
+}
+
+extern "C" int fv2p_sa_grid_fwd(const float* per_point, const float* per_centre, const int* idx, const float* w2, int rois, int n, int m,
+                                int s, int c, float* out, fv2p_stream_t stream) {
+  FV2P_REQUIRE(sa_shapes_ok(rois, n, m, s, c), FV2P_EINVAL, "sa_grid: needs 64 channels and 16 or 32 samples per centre");
+  FV2P_REQUIRE(per_point && per_centre && idx && w2 && out, FV2P_EINVAL, "sa_grid_fwd: null pointer");
+  hipLaunchKernelGGL(sa_grid_fwd_k, dim3(static_cast<unsigned>(ceil_div(m, kSaCentres)), rois), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     n, m, s, per_point, per_centre, idx, w2, out);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t fv2p_sa_grid_bwd_ws_bytes(int rois) {
+  Sizer sz;
+  sz.take<float>(static_cast<size_t>(rois > 0 ? rois : 1) * kSaC * kSaC);
+  return sz.bytes();
+}
+
+extern "C" int fv2p_sa_grid_bwd(const float* per_point, const float* per_centre, const int* idx, const float* w2, const float* out,
+                                const float* grad_out, int rois, int n, int m, int s, int c, float* grad_point, float* grad_centre,
+                                float* grad_w2, void* ws, size_t ws_bytes, fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FV2P_REQUIRE(sa_shapes_ok(rois, n, m, s, c) && fv2p_sa_grid_supported(n, m, s, c), FV2P_EINVAL, "sa_grid_bwd: unsupported shape");
+  FV2P_REQUIRE(per_point && per_centre && idx && w2 && out && grad_out && grad_point && grad_centre && grad_w2, FV2P_EINVAL, "sa_grid_bwd: null pointer");
+  FV2P_REQUIRE(ws && ws_bytes >= fv2p_sa_grid_bwd_ws_bytes(rois), FV2P_EWORKSPACE, "sa_grid_bwd: workspace too small");
+  Carver cv(ws, ws_bytes);
+  float* partial = cv.take<float>(static_cast<size_t>(rois) * kSaC * kSaC);
+  const size_t lds = (2 * 16 * 64 * 4 + 4 * 2 * 16 * kSaTs + static_cast<size_t>(n) * 32) * sizeof(float);
+  static size_t attr_for = 0;
+  if (lds > 48 * 1024 && lds > attr_for) {
+    FV2P_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sa_grid_bwd_k<1>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    FV2P_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sa_grid_bwd_k<2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    attr_for = lds;
+  }
+  if (s == 16) hipLaunchKernelGGL(sa_grid_bwd_k<1>, dim3(2, rois), dim3(256), lds, stream, n, m, per_point, per_centre, idx, w2, out, grad_out, grad_point, grad_centre, partial);
+  else hipLaunchKernelGGL(sa_grid_bwd_k<2>, dim3(2, rois), dim3(256), lds, stream, n, m, per_point, per_centre, idx, w2, out, grad_out, grad_point, grad_centre, partial);
+  hipLaunchKernelGGL(sa_grid_dw_reduce_k, dim3(16), dim3(256), 0, stream, rois, partial, grad_w2);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}

@@ -27,6 +27,7 @@ import torch.nn.functional as F
 
 from pcdet.ops.iou3d_nms import iou3d_nms_cuda, iou3d_nms_utils
 from pcdet.ops.pointnet2.pointnet2_batch import pointnet2_modules as pn2_batch_modules
+from pcdet.ops.pointnet2.pointnet2_batch import fused as pn2_fused
 from pcdet.ops.pointnet2.pointnet2_batch import pointnet2_utils as pn2_batch
 from pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as pn2_stack
 from pcdet.ops.roiaware_pool3d import roiaware_pool3d_utils
@@ -420,11 +421,21 @@ def sa_msg_grid(sa, xyz, features, centres):
     for grouper, mlp in zip(sa.groupers, sa.mlps):
         layers = list(mlp)
         w1 = layers[0].weight[:, :, 0, 0]                                        # (C1, 3 + C)
+        idx = pn2_batch.ball_query(grouper.radius, grouper.nsample, xyz, centres)
+        tail = layers[1:]
+        fusable = (len(tail) == 3 and isinstance(tail[0], nn.ReLU) and isinstance(tail[1], nn.Conv2d) and isinstance(tail[2], nn.ReLU)
+                   and tail[1].bias is None and tail[1].weight.shape[:2] == (w1.shape[0], w1.shape[0]) and xyz.is_cuda)
+        if fusable:
+            # rows of 64 channels per point / centre; gather, second layer, ReLU and the max over the samples in one kernel
+            per_point = torch.matmul(features.transpose(1, 2), w1[:, 3:].t()) + torch.matmul(xyz, w1[:, :3].t())      # (R, N, C1)
+            per_centre = torch.matmul(centres, w1[:, :3].t())                                                          # (R, M, C1)
+            if pn2_fused.supported(per_point, idx):
+                outs.append(pn2_fused.sa_grid_max(per_point, per_centre, idx, tail[1].weight[:, :, 0, 0]).transpose(1, 2))
+                continue
         per_point = (torch.matmul(w1[:, 3:], features) + torch.matmul(w1[:, :3], xyz_t)).contiguous()   # (R, C1, N)
         per_centre = torch.matmul(w1[:, :3], ctr_t)                              # (R, C1, M)
-        idx = pn2_batch.ball_query(grouper.radius, grouper.nsample, xyz, centres)
         h = pn2_batch.grouping_operation(per_point, idx) - per_centre.unsqueeze(-1)                     # (R, C1, M, ns)
-        for layer in layers[1:]:
+        for layer in tail:
             h = layer(h)
         outs.append(h.amax(dim=-1))
     return torch.cat(outs, dim=1)

@@ -338,6 +338,20 @@ int fv2p_three_interpolate_stack(int n, int c, const float* features, const int*
 int fv2p_three_interpolate_stack_grad(int n, int c, const float* grad_out, const int* idx, const float* weight,
                                       float* grad_features, fv2p_stream_t stream);
 
+/* ---- A11 consumer: fused grid set-abstraction (gather -> shared-MLP layer -> max over the samples) ---------------------
+ * The part of PointnetSAModuleMSG.forward (pointnet2_batch/pointnet2_modules.py:30-62) that follows the ball query, for the
+ * bn=False module of IoUGuidedRoIHead (iouguided_roi_head.py:52-76) after its first, linear layer has been applied per point
+ * and per centre:  out[r, i, :] = max_s relu(W2 relu(per_point[r, idx[r, i, s], :] - per_centre[r, i, :])).
+ * per_point [rois, n, c], per_centre [rois, m, c], idx [rois, m, s] i32 (ball query output), w2 [c, c] (Conv2d weight),
+ * out / grad_out [rois, m, c]; c = 64, s in {16, 32}.  No grouped tensor exists in either direction; backward recomputes. */
+int fv2p_sa_grid_supported(int n, int m, int s, int c);
+int fv2p_sa_grid_fwd(const float* per_point, const float* per_centre, const int* idx, const float* w2, int rois, int n, int m,
+                     int s, int c, float* out, fv2p_stream_t stream);
+size_t fv2p_sa_grid_bwd_ws_bytes(int rois);
+int fv2p_sa_grid_bwd(const float* per_point, const float* per_centre, const int* idx, const float* w2, const float* out,
+                     const float* grad_out, int rois, int n, int m, int s, int c, float* grad_point, float* grad_centre,
+                     float* grad_w2, void* ws, size_t ws_bytes, fv2p_stream_t stream);
+
 /* ---- A13: modulated deformable convolution (DCNv2; DCNv1 = mask of ones) -------------------------
  * Replace DCN.modulated_deform_conv_forward / _backward and DCN.deform_conv_forward / _backward
  * (pcdet/ops/DeformableConvolutionV2PyTorch/src/vision.cpp:6-12 -> src/modulated_deform_conv.h:10-86 ->

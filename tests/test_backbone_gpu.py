@@ -36,11 +36,11 @@ def test_backbone_forward_backward_matches_cpu_oracle(gpu, front_end, cls):
     torch.manual_seed(0)
     model = cls(4, [1408, 1600, 40]).to(gpu)
     ref = cpu_mirror(model)
-    feats, coords = make_batch(gpu, [3, 4], 8192)
+    feats, coords = make_batch(gpu, [3, 4, 5, 6], 16384)      # BASELINE configs[1]: batch 4, 16384-point clouds, full KITTI grid
     f_gpu = feats.clone().requires_grad_(True)
     f_cpu = feats.cpu().clone().requires_grad_(True)
-    out, ms = model(f_gpu, coords, 2)
-    rout, rms = ref(f_cpu, coords.cpu(), 2)
+    out, ms = model(f_gpu, coords, 4)
+    rout, rms = ref(f_cpu, coords.cpu(), 4)
     assert list(out.spatial_shape) == [2, 200, 176]
     assert torch.equal(out.indices.cpu(), rout.indices)           # integer outputs: bit-exact
     for k in ms:

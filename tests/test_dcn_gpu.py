@@ -91,3 +91,43 @@ def test_mgaf_block_shapes_and_pack(gpu):
     assert pack(torch.randn(1, 16, 8, 8, device=gpu)).shape == (1, 16, 8, 8)
     with pytest.raises(Exception):
         blk.cpu()(torch.randn(1, 128, 8, 8))  # "Not implemented on the CPU", as the reference dispatcher
+
+
+@pytest.mark.parametrize("cin,dg", [(256, 4), (128, 1)])
+def test_mgaf_full_size_maps_forward_backward_vs_oracle(gpu, cin, dg):
+    """BASELINE configs[3] shapes: the head's feature adaption [B, 256, 200, 176] with four deformable groups
+    (center_af_head_single.py:44-49) and the first backbone block [B, 128, 200, 176] with one (dcn_bev_backbone.py:56-62).
+    One sample against the float64 oracle (forward 1e-4, all five gradients 1e-3), then batch 4: every sample of the batched
+    call must equal its single-sample result bit for bit (pixels of different samples never share a tile's arithmetic)."""
+    torch.manual_seed(cin)
+    H, W = 200, 176
+    x = torch.randn(1, cin, H, W)
+    offset = torch.randn(1, dg * 18, H, W) * 1.2
+    # Bilinear sampling has a kink at integer positions.  Of the 2.5 M offsets here a handful fall within 1e-5 of an integer, where
+    # fp32 (the reference's and this kernel's arithmetic: 136 - 4e-6 == 136) and the float64 oracle take different one-sided
+    # derivatives; move those off the kink so that both sides differentiate the same piece.
+    near = (offset - offset.round()).abs() < 1e-3
+    offset = torch.where(near, offset + 4e-3, offset)
+    mask = torch.sigmoid(torch.randn(1, dg * 9, H, W))
+    m = ModulatedDeformConv(cin, cin, 3, stride=1, padding=1, deformable_groups=dg, bias=False).to(gpu)
+    gx, go, gm = (t.clone().to(gpu).requires_grad_(True) for t in (x, offset, mask))
+    y = m(gx, go, gm)
+    cx, co, cm = (t.clone().double().requires_grad_(True) for t in (x, offset, mask))
+    w, b = m.weight.detach().cpu().double().requires_grad_(True), m.bias.detach().cpu().double()
+    ref = dcn_oracle.modulated_deform_conv(cx, co, cm, w, b, (1, 1), (1, 1), (1, 1), dg)
+    assert rel(y, ref) < 1e-4
+    g = torch.randn(ref.shape)
+    y.backward(g.to(gpu))
+    ref.backward(g.double())
+    assert rel(gx.grad, cx.grad) < 1e-3
+    assert rel(go.grad, co.grad) < 1e-3
+    assert rel(gm.grad, cm.grad) < 1e-3
+    assert rel(m.weight.grad, w.grad) < 1e-3
+    del ref, cx, co, cm
+    with torch.no_grad():
+        xs = torch.cat([x, x.flip(3), x * 0.5, x.roll(7, 2)]).to(gpu)
+        os_ = torch.cat([offset, offset * 0.5, -offset, offset.roll(3, 3)]).to(gpu)
+        ms = torch.cat([mask, mask.flip(2), mask, mask * 0.9]).to(gpu)
+        y4 = m(xs, os_, ms)
+        for i in range(4):
+            assert torch.equal(y4[i:i + 1], m(xs[i:i + 1].contiguous(), os_[i:i + 1].contiguous(), ms[i:i + 1].contiguous())), i

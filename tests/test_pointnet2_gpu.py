@@ -202,3 +202,35 @@ def test_fps_bucketed_kernel_indices_and_running_distances(gpu, n, m, b):
     ext.furthest_point_sampling_wrapper(b, n, m, xyz, temp, idx)
     assert np.array_equal(idx.cpu().numpy(), ref_idx)
     assert np.array_equal(temp.cpu().numpy(), ref_temp)
+
+
+@pytest.mark.parametrize("r,n,m,s", [(5, 100, 30, 16), (3, 512, 216, 32), (2, 768, 17, 16), (1, 64, 1, 32)])
+def test_fused_grid_set_abstraction_matches_the_grouped_formulation(gpu, r, n, m, s):
+    """csrc/sa_fused.hip against the grouped-tensor formulation it replaces (grouping_operation + 1x1 conv + ReLU + max over the
+    samples, pointnet2_modules.py:30-62): forward 1e-5, gradients for points, centres and the weight 1e-4 relative.  The index
+    lists contain repeats (ball query pads with its first hit), i.e. exact ties of the maximum."""
+    from pcdet.ops.pointnet2.pointnet2_batch import fused
+    g = torch.Generator().manual_seed(r * 1000 + n)
+    pp = torch.randn(r, n, 64, generator=g).to(gpu).requires_grad_(True)
+    pc = (torch.randn(r, m, 64, generator=g) * 0.5).to(gpu).requires_grad_(True)
+    w2 = (torch.randn(64, 64, generator=g) * 0.2).to(gpu).requires_grad_(True)
+    idx = torch.randint(0, n, (r, m, s), generator=g, dtype=torch.int32)
+    idx[:, :, s // 2:] = idx[:, :, :1]                       # padded tail: repeats of the first hit
+    idx[:, ::3, :] = idx[:, ::3, :1]                         # centres with a single distinct neighbour
+    idx = idx.to(gpu)
+    assert fused.supported(pp, idx)
+    out = fused.sa_grid_max(pp, pc, idx, w2)
+    go = torch.randn(out.shape, generator=g).to(gpu)
+    out.backward(go)
+    got = [t.grad.clone() for t in (pp, pc, w2)]
+    for t in (pp, pc, w2):
+        t.grad = None
+    grouped = bu.grouping_operation(pp.transpose(1, 2).contiguous(), idx)                  # (r, 64, m, s)
+    h1 = torch.relu(grouped - pc.transpose(1, 2).unsqueeze(-1))
+    h2 = torch.relu(torch.einsum("oc,rcms->roms", w2, h1))
+    ref = h2.amax(dim=-1).transpose(1, 2)
+    ref.backward(go)
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+    assert rel(out, ref) < 1e-5
+    for a, t in zip(got, (pp, pc, w2)):
+        assert rel(a, t.grad) < 1e-4

@@ -34,9 +34,13 @@ def conv(only=None):
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     waymo = bool(os.environ.get("FV2P_WAYMO"))   # BASELINE configs[4]: ~180 k points per cloud, 0.1 m voxels, [41, 1504, 1504] grid
-    model = VoxelBackBone8x(4, [1504, 1504, 40] if waymo else [1408, 1600, 40]).to(dev)
+    res = bool(os.environ.get("FV2P_RES"))       # BASELINE configs[2]: the FV2P step's VoxelResBackBone8x at batch 3
+    if res:
+        from fv2p_harness.backbone import VoxelResBackBone8x
+    nbatch = 3 if res else 4
+    model = (VoxelResBackBone8x if res else VoxelBackBone8x)(4, [1504, 1504, 40] if waymo else [1408, 1600, 40]).to(dev)
     feats, coords = [], []
-    for b in range(4):
+    for b in range(nbatch):
         if waymo:
             v, c, n = points_to_voxel_gpu(torch.from_numpy(synth.waymo_like_cloud(b, 180000)).to(dev), synth.WAYMO_VOXEL, synth.WAYMO_RANGE, 5, True, 150000)
         else:
@@ -44,14 +48,16 @@ def conv(only=None):
         feats.append(mean_vfe(v, n))
         coords.append(torch.nn.functional.pad(c, (1, 0), value=b))
     recs = []
+    bench_seeds = True
 
     def hook(mod, inp, out):
         x = inp[0]
         rb = x.indice_dict[mod.indice_key]
-        recs.append((mod, x.features.detach(), rb, out.features.shape[0]))
+        if bench_seeds and mod.indice_key is not None:
+            recs.append((mod, x.features.detach(), rb, out.features.shape[0]))
     hs = [m.register_forward_hook(hook) for m in model.modules() if isinstance(m, SparseConvolution)]
     with torch.no_grad():
-        model(torch.cat(feats), torch.cat(coords), 4)
+        model(torch.cat(feats), torch.cat(coords), nbatch)
     for h in hs:
         h.remove()
     if only is not None:  # just the roofline kernel (bench.py's probe): forward conv of the layer with most flops

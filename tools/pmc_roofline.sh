@@ -1,18 +1,40 @@
 #!/bin/bash
-# HBM traffic of the roofline kernel (MI355X_MICROARCH.md §HBM): FETCH_SIZE and WRITE_SIZE in separate --pmc passes,
-# counters only together with --kernel-trace.  Run on the GPU box:  bash tools/pmc_roofline.sh
+# HBM traffic of the roofline kernel (MI355X_MICROARCH.md, HBM section): FETCH_SIZE and WRITE_SIZE in separate --pmc passes,
+# counters only together with --kernel-trace.  Run on the GPU box:  bash tools/pmc_roofline.sh  [round tag, default r02]
+# The kernel measured is the forward conv of the layer with the most flops of the FV2P step's VoxelResBackBone8x at batch 3
+# (FV2P_RES=1 python3 tools/microbench.py convone), the very launch bench.py's roofline probe times.
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
+export FV2P_RES=1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$c -o pmc -- python3 tools/microbench.py convone > gpurun_out/pmc_$c.log 2>&1
 done
-python3 - <<'PY'
-import csv, glob
+grep "roofline kernel" gpurun_out/pmc_FETCH_SIZE.log
+python3 - "$TAG" <<'PY'
+import csv, glob, json, re, sys
+tag = sys.argv[1]
+out = {}
+layer = None
+for line in open("gpurun_out/pmc_FETCH_SIZE.log"):
+    if line.startswith("roofline kernel:"):
+        layer = line.strip()
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob(f"gpurun_out/pmc_{c}/*counter_collection.csv"):
-        rows = [r for r in csv.DictReader(open(f)) if "conv_rows_dma<64, 4, false>" in r["Kernel_Name"] and r["Counter_Name"] == c]
-        big = max(int(r["Grid_Size"]) for r in rows) if rows else 0
-        rows = [r for r in rows if int(r["Grid_Size"]) == big]
-        vals = [float(r["Counter_Value"]) for r in rows]
-        if vals:
-            print(c, "kernel", rows[0]["Kernel_Name"][:60], "dispatches", len(vals), "avg counter (KiB)", sum(vals) / len(vals))
+        rows = [r for r in csv.DictReader(open(f)) if "conv_rows_dma" in r["Kernel_Name"] and "false>" in r["Kernel_Name"] and r["Counter_Name"] == c]
+        if not rows:
+            continue
+        # the timed launch repeats: take the kernel / grid with the most dispatches
+        key = max({(r["Kernel_Name"], r["Grid_Size"]) for r in rows}, key=lambda k: sum((r["Kernel_Name"], r["Grid_Size"]) == k for r in rows))
+        sel = [float(r["Counter_Value"]) for r in rows if (r["Kernel_Name"], r["Grid_Size"]) == key]
+        out[c] = {"kernel": key[0][:80], "grid": int(key[1]), "dispatches": len(sel), "avg_KiB": sum(sel) / len(sel)}
+        print(c, out[c])
+if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
+    fetch, write = out["FETCH_SIZE"]["avg_KiB"], out["WRITE_SIZE"]["avg_KiB"]
+    res = {"kernel": out["FETCH_SIZE"]["kernel"], "layer_line": layer, "dispatches": out["FETCH_SIZE"]["dispatches"],
+           "FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB": write,
+           "fetch_correction": "x2: gfx950 FETCH_SIZE tallies 128-B requests at 64 B for 16-B/lane reads (MI355X_MICROARCH.md, HBM section)",
+           "traffic_bytes_per_launch": int((2 * fetch + write) * 1024), "traffic_bytes_per_launch_uncorrected": int((fetch + write) * 1024),
+           "command": "bash tools/pmc_roofline.sh (two separate rocprofv3 --pmc passes with --kernel-trace only)"}
+    json.dump(res, open(f"gpurun_out/{tag}_pmc_roofline.json", "w"), indent=1)
+    print(json.dumps(res))
 PY
