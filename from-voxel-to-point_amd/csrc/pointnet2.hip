@@ -681,7 +681,8 @@ __global__ __launch_bounds__(kFpsWaves * 64) void fps_wave_k(int n, int m, int b
             }
           });
       });
-      wave_best();
+      // running distances only fall: while the bucket holding the wave's candidate is untouched, the candidate stands
+      if ((touch >> wslot) & 1ull) wave_best();
     }
     const int buf = j & 1;
     if (lane == 0) *reinterpret_cast<uint4*>(&s_wave[buf][w][0]) = make_uint4(wbits, wprio, wslot, 0u);

@@ -27,21 +27,188 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kSaC = 64;          // channels of both layers
 constexpr int kSaCentres = 16;    // centres per workgroup (forward)
 
-#define FV2P_SA_ROWOP(op, v, ctrl) asm volatile("s_nop 1\n\t" op " %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(v))
-// reduce over the 16 lanes of a DPP row (= the 16 sample rows of a tile; lanes sharing l / 16 hold the same channels)
-__device__ __forceinline__ float row16_max(float v) {
-  FV2P_SA_ROWOP("v_max_f32_dpp", v, "quad_perm:[1,0,3,2]");
-  FV2P_SA_ROWOP("v_max_f32_dpp", v, "quad_perm:[2,3,0,1]");
-  FV2P_SA_ROWOP("v_max_f32_dpp", v, "row_half_mirror");
-  FV2P_SA_ROWOP("v_max_f32_dpp", v, "row_mirror");
-  return v;
+// Reductions over the 16 lanes of a DPP row (= the 16 sample rows of a tile; lanes sharing l / 16 hold the same channels), 8 or 16
+// values at a time, each as ONE asm statement in step-major order: the DPP read of a value is then N instructions behind the
+// write it depends on (the two wait states a DPP operand needs are covered by the other values' instructions) and the
+// compiler cannot slip a register copy in front of a step.  quad_perm xor-1, xor-2, row_half_mirror, row_mirror: every lane
+// of the row ends with the row's result.
+__device__ __forceinline__ void row16_max_n(float (&v)[16]) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %6, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %7, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %9, %9, %9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %10, %10, %10 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %11, %11, %11 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %12, %12, %12 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %13, %13, %13 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %14, %14, %14 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %15, %15, %15 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %5, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %6, %6, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %7, %7, %7 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %8, %8, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %9, %9, %9 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %10, %10, %10 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %11, %11, %11 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %12, %12, %12 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %13, %13, %13 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %14, %14, %14 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %15, %15, %15 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %4, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %5, %5, %5 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %6, %6, %6 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %7, %7, %7 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %8, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %9, %9, %9 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %10, %10, %10 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %11, %11, %11 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %12, %12, %12 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %13, %13, %13 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %14, %14, %14 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %15, %15, %15 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %2, %2, %2 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %3, %3, %3 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %4, %4, %4 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %5, %5, %5 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %6, %6, %6 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %7, %7, %7 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %8, %8, %8 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %9, %9, %9 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %10, %10, %10 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %11, %11, %11 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %12, %12, %12 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %13, %13, %13 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %14, %14, %14 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %15, %15, %15 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
 }
-__device__ __forceinline__ float row16_sum(float v) {
-  FV2P_SA_ROWOP("v_add_f32_dpp", v, "quad_perm:[1,0,3,2]");
-  FV2P_SA_ROWOP("v_add_f32_dpp", v, "quad_perm:[2,3,0,1]");
-  FV2P_SA_ROWOP("v_add_f32_dpp", v, "row_half_mirror");
-  FV2P_SA_ROWOP("v_add_f32_dpp", v, "row_mirror");
-  return v;
+__device__ __forceinline__ void row16_sum_n(float (&v)[16]) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %6, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %7, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %8, %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %9, %9, %9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %10, %10, %10 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %11, %11, %11 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %12, %12, %12 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %13, %13, %13 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %14, %14, %14 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %15, %15, %15 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %5, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %6, %6, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %7, %7, %7 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %8, %8, %8 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %9, %9, %9 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %10, %10, %10 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %11, %11, %11 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %12, %12, %12 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %13, %13, %13 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %14, %14, %14 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %15, %15, %15 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %4, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %5, %5, %5 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %6, %6, %6 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %7, %7, %7 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %8, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %9, %9, %9 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %10, %10, %10 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %11, %11, %11 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %12, %12, %12 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %13, %13, %13 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %14, %14, %14 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %15, %15, %15 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %4, %4, %4 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %5, %5, %5 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %6, %6, %6 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %7, %7, %7 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %8, %8, %8 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %9, %9, %9 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %10, %10, %10 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %11, %11, %11 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %12, %12, %12 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %13, %13, %13 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %14, %14, %14 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %15, %15, %15 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
+}
+__device__ __forceinline__ void row16_sum_n(float (&v)[8]) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %4, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %5, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %6, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %7, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %4, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %5, %5, %5 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %6, %6, %6 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %7, %7, %7 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %4, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %5, %5, %5 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %6, %6, %6 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %7, %7, %7 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %4, %4, %4 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %5, %5, %5 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %6, %6, %6 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %7, %7, %7 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
 }
 
 // LDS image of a 64 x 64 row-major matrix A for the role "A operand of D = A * X^T": frag[b][j][lane] (float4) =
@@ -58,16 +225,20 @@ __device__ __forceinline__ void stage_frag(const float* __restrict__ a, bool tra
 }
 // acc[b] += A-fragments(lds)[b][j] * x[j]   (x[j] = this lane's float4 of channel block j of its row)
 __device__ __forceinline__ void mma64(const float* __restrict__ frag, int lane, const float4 (&x)[4], f32x4 (&acc)[4]) {
+  // j outer, the four accumulator blocks inner: consecutive MFMAs belong to different dependency chains
 #pragma unroll
-  for (int b = 0; b < 4; ++b) {
+  for (int j = 0; j < 4; ++j) {
+    float4 a[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float4 a = *reinterpret_cast<const float4*>(frag + ((b * 4 + j) * 64 + lane) * 4);
-      acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x[j].x, acc[b], 0, 0, 0);
-      acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x[j].y, acc[b], 0, 0, 0);
-      acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x[j].z, acc[b], 0, 0, 0);
-      acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x[j].w, acc[b], 0, 0, 0);
-    }
+    for (int b = 0; b < 4; ++b) a[b] = *reinterpret_cast<const float4*>(frag + ((b * 4 + j) * 64 + lane) * 4);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b].x, x[j].x, acc[b], 0, 0, 0);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b].y, x[j].y, acc[b], 0, 0, 0);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b].z, x[j].z, acc[b], 0, 0, 0);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b].w, x[j].w, acc[b], 0, 0, 0);
   }
 }
 __device__ __forceinline__ float4 relu_sub(float4 p, float4 q) {
@@ -113,11 +284,15 @@ __global__ __launch_bounds__(256) void sa_grid_fwd_k(int n, int m, int s, const 
     }
     // lane (row, g) holds channels 16 b + 4 g + e of sample row `row`: maximum over the 16 lanes of the DPP row
     float* o = out + (static_cast<long long>(r) * m + i) * kSaC + 4 * g;
+    float flat[16];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      float4 v;
-      v.x = row16_max(best[b][0]); v.y = row16_max(best[b][1]); v.z = row16_max(best[b][2]); v.w = row16_max(best[b][3]);
-      if (row == 0) *reinterpret_cast<float4*>(o + 16 * b) = v;
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) flat[4 * b + e] = best[b][e];
+    row16_max_n(flat);
+    if (row == 0) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) *reinterpret_cast<float4*>(o + 16 * b) = make_float4(flat[4 * b], flat[4 * b + 1], flat[4 * b + 2], flat[4 * b + 3]);
     }
   }
 }
@@ -188,10 +363,18 @@ __global__ __launch_bounds__(256) void sa_grid_bwd_k(int n, int m, const float* 
         for (int e = 0; e < 4; ++e) cnt[b][e] += (h2[t][b][e] == mv[e] && mv[e] > 0.f) ? 1.f : 0.f;
       }
     }
+    {
+      float flat[16];
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+      for (int b = 0; b < 4; ++b)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) cnt[b][e] = row16_sum(cnt[b][e]);
+        for (int e = 0; e < 4; ++e) flat[4 * b + e] = cnt[b][e];
+      row16_sum_n(flat);
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cnt[b][e] = flat[4 * b + e];
+    }
     // pass 2 per tile: dh2, dh1 = (W2^T dh2) * [h1 > 0], scatter / reduce, dW2 += dh2^T h1
     float dq[2][4];
 #pragma unroll
@@ -210,19 +393,19 @@ __global__ __launch_bounds__(256) void sa_grid_bwd_k(int n, int m, const float* 
         dh2[b] = make_float4(d[0], d[1], d[2], d[3]);
       }
       // dh1^T block bb of this half: channels 32 half + 16 bb + 4 g + e
-      f32x4 d1[2];
+      f32x4 d1[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-      for (int bb = 0; bb < 2; ++bb) {
-        d1[bb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int b = 2 * half + bb;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float4 a = *reinterpret_cast<const float4*>(wtfrag + ((b * 4 + j) * 64 + lane) * 4);
-          d1[bb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, dh2[j].x, d1[bb], 0, 0, 0);
-          d1[bb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, dh2[j].y, d1[bb], 0, 0, 0);
-          d1[bb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, dh2[j].z, d1[bb], 0, 0, 0);
-          d1[bb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, dh2[j].w, d1[bb], 0, 0, 0);
-        }
+      for (int j = 0; j < 4; ++j) {
+        const float4 a0 = *reinterpret_cast<const float4*>(wtfrag + (((2 * half) * 4 + j) * 64 + lane) * 4);
+        const float4 a1 = *reinterpret_cast<const float4*>(wtfrag + (((2 * half + 1) * 4 + j) * 64 + lane) * 4);
+        d1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, dh2[j].x, d1[0], 0, 0, 0);
+        d1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, dh2[j].x, d1[1], 0, 0, 0);
+        d1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, dh2[j].y, d1[0], 0, 0, 0);
+        d1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, dh2[j].y, d1[1], 0, 0, 0);
+        d1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, dh2[j].z, d1[0], 0, 0, 0);
+        d1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, dh2[j].z, d1[1], 0, 0, 0);
+        d1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, dh2[j].w, d1[0], 0, 0, 0);
+        d1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, dh2[j].w, d1[1], 0, 0, 0);
       }
 #pragma unroll
       for (int bb = 0; bb < 2; ++bb) {
@@ -257,11 +440,15 @@ __global__ __launch_bounds__(256) void sa_grid_bwd_k(int n, int m, const float* 
     }
     // dQ[i][c] = - sum over the centre's samples of dh1 (the 16 lanes of the DPP row), this half's 32 channels
     float* dqo = dQ + (static_cast<long long>(r) * m + i) * kSaC + 32 * half + 4 * g;
+    float flat[8];
 #pragma unroll
-    for (int bb = 0; bb < 2; ++bb) {
-      float4 v;
-      v.x = -row16_sum(dq[bb][0]); v.y = -row16_sum(dq[bb][1]); v.z = -row16_sum(dq[bb][2]); v.w = -row16_sum(dq[bb][3]);
-      if (row == 0) *reinterpret_cast<float4*>(dqo + 16 * bb) = v;
+    for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) flat[4 * bb + e] = dq[bb][e];
+    row16_sum_n(flat);
+    if (row == 0) {
+      *reinterpret_cast<float4*>(dqo) = make_float4(-flat[0], -flat[1], -flat[2], -flat[3]);
+      *reinterpret_cast<float4*>(dqo + 16) = make_float4(-flat[4], -flat[5], -flat[6], -flat[7]);
     }
   }
   __syncthreads();
@@ -311,7 +498,7 @@ static bool sa_shapes_ok(int rois, int n, int m, int s, int c) {
 }
 
 extern "C" int fv2p_sa_grid_supported(int n, int m, int s, int c) {
-  return (c == kSaC && (s == 16 || s == 32) && n >= 1 && m >= 1 && static_cast<size_t>(n) * 32 * 4 <= 96 * 1024) ? 1 : 0;
+  return (c == kSaC && (s == 16 || s == 32) && n >= 1 && m >= 1 && static_cast<size_t>(n) * 32 * 4 <= 80 * 1024) ? 1 : 0;   // backward: 69 KB of fragments / tiles + the dP tile within 160 KB of LDS
 }
 
 extern "C" int fv2p_sa_grid_fwd(const float* per_point, const float* per_centre, const int* idx, const float* w2, int rois, int n, int m,

@@ -415,7 +415,7 @@ def sa_msg_grid(sa, xyz, features, centres):
     W1 [xyz_j - c_i ; f_j] = (W1f f_j + W1x xyz_j) - W1x c_i is one GEMM per POINT (512 per RoI) and one per CENTRE (216) instead
     of one per (centre, sample) pair (216 x 16 / 32); what is grouped is the 64-channel product, not the 131-channel input.
     Same parameters, same result up to fp32 summation order.  xyz (R, N, 3), features (R, C, N), centres (R, M, 3) -> (R, sum C_k, M)."""
-    outs = []
+    outs, rows = [], None
     xyz_t = xyz.transpose(1, 2)                                                  # (R, 3, N)
     ctr_t = centres.transpose(1, 2)                                              # (R, 3, M)
     for grouper, mlp in zip(sa.groupers, sa.mlps):
@@ -427,7 +427,9 @@ def sa_msg_grid(sa, xyz, features, centres):
                    and tail[1].bias is None and tail[1].weight.shape[:2] == (w1.shape[0], w1.shape[0]) and xyz.is_cuda)
         if fusable:
             # rows of 64 channels per point / centre; gather, second layer, ReLU and the max over the samples in one kernel
-            per_point = torch.matmul(features.transpose(1, 2), w1[:, 3:].t()) + torch.matmul(xyz, w1[:, :3].t())      # (R, N, C1)
+            if rows is None:
+                rows = features.transpose(1, 2).contiguous().view(-1, features.shape[1])   # point-major once: one plain 2-D GEMM per scale
+            per_point = torch.mm(rows, w1[:, 3:].t()).view(xyz.shape[0], xyz.shape[1], -1) + torch.matmul(xyz, w1[:, :3].t())   # (R, N, C1)
             per_centre = torch.matmul(centres, w1[:, :3].t())                                                          # (R, M, C1)
             if pn2_fused.supported(per_point, idx):
                 outs.append(pn2_fused.sa_grid_max(per_point, per_centre, idx, tail[1].weight[:, :, 0, 0]).transpose(1, 2))

@@ -5,7 +5,7 @@ its ball query, for the bn=False shared MLP of the RoI head, without the grouped
 
 per_point (R, N, 64) / per_centre (R, M, 64) are the first (linear) shared-MLP layer applied to the points and to the centres,
 idx (R, M, S) the ball-query result, w2 (64, 64) the second layer's 1x1-conv weight.  Gradients for per_point, per_centre and
-w2.  GPU only; `supported()` tells whether the kernel covers a shape (64 channels, 16 or 32 samples, N <= 768)."""
+w2.  GPU only; `supported()` tells whether the kernel covers a shape (64 channels, 16 or 32 samples, N <= 640)."""
 import torch
 
 import fv2p_native as _nat
