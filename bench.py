@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=["fv2p", "backbone", "mgaf"], default="fv2p")
+    ap.add_argument("--workload", choices=["fv2p", "fv2p-waymo", "backbone", "mgaf"], default="fv2p")
     ap.add_argument("--batch", type=int, default=0, help="clouds per GPU per step (0: 3 for fv2p, 4 for backbone)")
     ap.add_argument("--points", type=int, default=16384)
     ap.add_argument("--backbone", choices=["8x", "res8x"], default="8x")
@@ -71,7 +71,14 @@ def parse():
     ap.add_argument("--pyprofile", action="store_true", help="cProfile the timed steps (host-overhead hunting; prints to stderr)")
     args = ap.parse_args()
     if args.batch <= 0:
-        args.batch = 3 if args.workload == "fv2p" else 4
+        args.batch = 3 if args.workload == "fv2p" else 2 if args.workload == "fv2p-waymo" else 4
+    if args.workload == "fv2p-waymo":
+        if "--points" not in sys.argv:
+            args.points = 180000
+        if "--steps" not in sys.argv:
+            args.steps, args.warmup = 20, (args.warmup if "--warmup" in sys.argv else 4)
+        if "--prefetch" not in sys.argv:
+            args.prefetch = 0
     if args.workload == "mgaf" and "--steps" not in sys.argv:
         args.steps, args.warmup = 30, (args.warmup if "--warmup" in sys.argv else 5)
     if args.workload == "fv2p" and "--prefetch" not in sys.argv:
@@ -214,13 +221,15 @@ def build_step(args, device, rank, world):
 def build_fv2p_step(args, device, rank, world):
     """BASELINE configs[2]: one optimiser step of the FV2P detector replay on `args.batch` clouds per rank."""
     from fv2p_harness import dist_utils, synth
-    from fv2p_harness.fv2p_model import FV2PConfig, FV2PDetector, pad_gt_boxes
+    from fv2p_harness.fv2p_model import FV2PConfig, FV2PDetector, FV2PWaymoConfig, pad_gt_boxes
     from fv2p_harness.optim import LeanAdamW
     from fv2p_harness.prefetch import BatchPrefetcher
     from pcdet.datasets.processor.voxel_generator import points_to_voxel_batch
     from pcdet.ops import spconv
 
-    cfg = FV2PConfig
+    waymo = args.workload == "fv2p-waymo"
+    cfg = FV2PWaymoConfig if waymo else FV2PConfig
+    vsize, prange = np.array(cfg.voxel_size, np.float32), np.array(cfg.point_cloud_range, np.float32)
     torch.manual_seed(0)
     model = FV2PDetector(cfg).to(device)
     if args.bev_channels_last:
@@ -235,14 +244,18 @@ def build_fv2p_step(args, device, rank, world):
     for seeds in dist_utils.rank_seeds(rank, n_pool, args.batch):
         clouds, boxes = [], []
         for seed in seeds:
-            pts, bx = synth.lidar_cloud(seed, args.points, return_boxes=True)
+            if waymo:   # 360-degree cloud; the fifth feature (elongation) is a second uniform channel
+                pts, bx = synth.waymo_like_cloud(seed, args.points, return_boxes=True)
+                pts = np.concatenate([pts, np.random.default_rng(seed).uniform(0, 1, (pts.shape[0], 1)).astype(np.float32)], 1)
+            else:
+                pts, bx = synth.lidar_cloud(seed, args.points, return_boxes=True)
             clouds.append(torch.from_numpy(pts).to(device))
             boxes.append(bx)
         pool.append((clouds, pad_gt_boxes(boxes, device, max_gt=40)))
     n_uniform = cfg.nms_post + cfg.roi_per_image
 
     def voxelize(clouds):
-        return points_to_voxel_batch(clouds, synth.KITTI_VOXEL, synth.KITTI_RANGE, cfg.max_points_per_voxel, cfg.max_voxels, mean_vfe=True)
+        return points_to_voxel_batch(clouds, vsize, prange, cfg.max_points_per_voxel, cfg.max_voxels, mean_vfe=True)
 
     pre = None
     if args.prefetch:
@@ -519,6 +532,9 @@ def cpu_baseline(model, args):
 
 
 def workload_name(args):
+    if args.workload == "fv2p-waymo":
+        return ("FV2P (waymo_fv2p_e30.yaml, Vehicle) end-to-end train step on Waymo-shaped synthetic clouds (~180 k points, 360 degrees, "
+                "0.1 m voxels, grid [41,1504,1504], five point features): same stages as the KITTI step, streaming FPS kernel")
     if args.workload == "fv2p":
         return ("FV2P (fv2p.yaml, car only) end-to-end train step: HIP voxelise + MeanVFE, VoxelResBackBone8x, BEV backbone + anchor "
                 "head, FPS to 16384 key points, voxel-to-point decoder, point head, IoU-guided RoI head, losses, backward, grad clip, "
@@ -582,7 +598,7 @@ def main():
     if args.switch_interval > 0:
         sys.setswitchinterval(args.switch_interval)
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
-    build = build_fv2p_step if args.workload == "fv2p" else build_step
+    build = build_fv2p_step if args.workload in ("fv2p", "fv2p-waymo") else build_step
     model, step, voxelize, pool = build(args, device, rank, world)
     for i in range(args.warmup):
         step(i)
@@ -643,7 +659,12 @@ def main():
                                           2: "thread voxelises batch t+1 and builds its rulebooks during step t",
                                           3: "DIAGNOSTIC: prepared batches reused, not a benchmark configuration"}[min(args.prefetch, 3)]},
         }
-        if args.workload == "fv2p":
+        if args.workload == "fv2p-waymo":
+            result["metric"] = "point clouds/sec fwd+bwd (FV2P, Waymo shape: 180k points, 0.1 m voxels)"
+            if not args.no_roofline:
+                result["roofline"] = roofline_probe(model.backbone_3d, voxelize, [pool[0][0]], args, device)
+                result["fps"] = fps_probe(model, pool, args, device)
+        elif args.workload == "fv2p":
             if not args.no_roofline:
                 # dominant kernel of the step (profiles/r02_fv2p_kernel_stats.csv): the fused sparse conv of the residual
                 # backbone's heaviest layer, priced against the fp32-MFMA roofline; FPS (latency-bound) reported beside it

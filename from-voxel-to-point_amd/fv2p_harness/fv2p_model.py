@@ -74,6 +74,19 @@ class FV2PConfig:
     grad_norm_clip = 10.0
 
 
+class FV2PWaymoConfig(FV2PConfig):
+    """waymo_fv2p_e30.yaml + waymo_dataset.yaml (BASELINE configs[4]): one class (Vehicle), ~180 k points per cloud, 0.1 m voxels,
+    five point features, three instead of five convs per BEV block; decoder, point head and RoI head as on KITTI."""
+    point_cloud_range = (-75.2, -75.2, -2.0, 75.2, 75.2, 4.0)
+    voxel_size = (0.1, 0.1, 0.15)
+    grid_size = (1504, 1504, 40)
+    max_voxels = 80000
+    num_point_features = 5
+    bev_layers = (3, 3)
+    anchor_size, anchor_bottom = (4.7, 2.1, 1.7), 0.0
+    matched_thr, unmatched_thr = 0.55, 0.4
+
+
 # ---------------------------------------------------------------- small shared pieces -----------------
 def limit_period(val, offset, period):
     return val - torch.floor(val / period + offset) * period

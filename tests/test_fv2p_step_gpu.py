@@ -13,7 +13,7 @@ import torch
 import oracle
 from fv2p_harness import synth
 from fv2p_harness.backbone import mean_vfe
-from fv2p_harness.fv2p_model import FV2PConfig, FV2PDetector, pad_gt_boxes
+from fv2p_harness.fv2p_model import FV2PConfig, FV2PDetector, FV2PWaymoConfig, pad_gt_boxes
 from oracle.backend import oracle_backend
 from oracle.spconv_cpu import cpu_mirror
 
@@ -131,3 +131,51 @@ def test_roi_head_on_identical_inputs_matches_cpu_oracle(gpu, cpu_run):
     for name in ("grid_interact_fc_layer.0.weight", "xyz_up_layer.0.weight", "SA_modules.0.mlps.1.0.weight", "reg_layers.7.weight"):
         a, b = gp[name].grad.cpu().double(), cp[name].grad.double()
         assert float((a - b).norm() / b.norm().clamp_min(1e-12)) < 5e-3, name
+
+
+class SmallWaymoFV2P(FV2PWaymoConfig):
+    """BASELINE configs[4] shape at reduced size: half the Waymo range (BEV map 94 x 94), 0.1 m voxels, five point features,
+    30 000-point clouds (> 24 576: the streaming FPS kernel), 2048 key points."""
+    point_cloud_range = (-37.6, -37.6, -2.0, 37.6, 37.6, 4.0)
+    grid_size = (752, 752, 40)
+    num_keypoints = 2048
+    nms_pre, nms_post = 1024, 128
+    roi_per_image = 32
+    num_sampled_points = 128
+    dp_ratio = 0.0
+
+
+@pytest.mark.gpu
+def test_waymo_shaped_step_matches_cpu_oracle(gpu):
+    cfg = SmallWaymoFV2P
+    torch.manual_seed(1)
+    model = FV2PDetector(cfg)
+    ref = cpu_mirror(model)
+    ref.taps = {}
+    rng = np.array(cfg.point_cloud_range, np.float32)
+    vs = np.array(cfg.voxel_size, np.float32)
+    clouds, boxes, feats, coords = [], [], [], []
+    for b in range(2):
+        pts, bx = synth.lidar_cloud(70 + b, 30000, pc_range=rng, fov_deg=180.0, az_step_deg=0.13, return_boxes=True)
+        pts = np.concatenate([pts, np.random.default_rng(b).uniform(0, 1, (pts.shape[0], 1)).astype(np.float32)], 1)
+        clouds.append(torch.from_numpy(pts))
+        boxes.append(bx)
+        v, c, k = oracle.points_to_voxel(pts, vs, rng, 5, cfg.max_voxels)
+        feats.append(mean_vfe(torch.from_numpy(v), torch.from_numpy(k)))
+        coords.append(torch.from_numpy(np.concatenate([np.full((c.shape[0], 1), b, np.int32), c], 1)))
+    gt = pad_gt_boxes(boxes, "cpu")
+    u = torch.rand(2, cfg.nms_post + cfg.roi_per_image, generator=torch.Generator().manual_seed(2))
+    feats, coords = torch.cat(feats), torch.cat(coords)
+    with oracle_backend():
+        ref(clouds, feats, coords, gt, u)
+    net = model.to(gpu)
+    net.taps = {}
+    net([c.to(gpu) for c in clouds], feats.to(gpu), coords.to(gpu), gt.to(gpu), u.to(gpu))
+    g, c = net.taps, ref.taps
+    assert torch.equal(g["keypoints"].cpu(), c["keypoints"])                          # streaming FPS: bit-exact
+    assert rel(g["point_features"].detach().cpu(), c["point_features"].detach()) < 1e-3
+    assert rel(g["bev"].detach().cpu(), c["bev"].detach()) < 1e-3
+    for name in ("loss_rpn", "loss_point"):
+        assert abs(g[name].item() - c[name].item()) < 1e-3 * max(1.0, abs(c[name].item())), name
+    (g["loss_rpn"] + g["loss_point"] + g["loss_rcnn"]).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
