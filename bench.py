@@ -612,11 +612,11 @@ def main():
             print(f"[phases] {k:14s} host issue {h / 20 * 1e3:7.3f} ms   synchronised wall {w / 20 * 1e3:7.3f} ms", file=sys.stderr)
     if args.torch_profile and rank == 0:
         from torch.profiler import ProfilerActivity, profile
-        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as tp:
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as tp:
             for i in range(3):
                 step(args.warmup + i)
             torch.cuda.synchronize()
-        print(tp.key_averages().table(sort_by="self_cuda_time_total", row_limit=70, max_name_column_width=60), file=sys.stderr)
+        print(tp.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=90, max_name_column_width=50, max_shapes_column_width=70), file=sys.stderr)
     prof = None
     if args.pyprofile:
         import cProfile

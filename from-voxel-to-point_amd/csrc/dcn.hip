@@ -281,161 +281,6 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_k(DcnGeom g, const float* __
   }
 }
 
-// ---------------------------------------------------------------- backward: data, patch-tiled ---------
-// Same arithmetic as dcn_bwd_data_k with the scatter kept on chip.  The plain kernel sends four global fp32 atomics per (pixel,
-// tap, channel): 1.3 G at the MGAF head ([4, 256, 200, 176], dg = 4), which is what its run time is made of.  Here a workgroup
-// owns an 8 x 8 patch of output pixels and, for one 64-channel group at a time, accumulates the dx contributions of all nine
-// taps in an LDS tile that covers the patch plus a halo of kDcnHalo input pixels (ds_add_f32); taps that land outside the tile
-// (large offsets) still go to memory directly.  The tile is flushed once per channel group: (8 + 2 halo)^2 x 64 atomics instead
-// of 64 x 9 x 4 x 64.  grad_mask / grad_offset of a (pixel, tap, deformable group) come from one workgroup only: the first channel
-// group of a deformable group stores, later ones add (plain read-modify-write by the same lane).  Needs (Cin / dg) % 64 == 0,
-// stride 1.
-constexpr int kDcnHalo = 3;
-constexpr int kDcnTile = 8 + 2 * kDcnHalo;
-template <int JO>
-__global__ __launch_bounds__(256) void dcn_bwd_data_tile_k(DcnGeom g, const float* __restrict__ x, const float* __restrict__ wt,
-                                                           const float* __restrict__ offset, const float* __restrict__ mask,
-                                                           const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ doff,
-                                                           float* __restrict__ dmask) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* wfrag = lds;                        // [JO][64 lanes][4]
-  float* tile = lds + JO * 64 * 4;           // [kDcnTile][kDcnTile][64]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, gq = lane >> 4;
-  const int b = blockIdx.z, py0 = blockIdx.y * 8, px0 = blockIdx.x * 8;
-  const int K = g.kh * g.kw, cpg = g.Cin / g.dg;
-  const long long plane = static_cast<long long>(g.Ho) * g.Wo;
-  // A fragment rows: lane r of wave w is output pixel (py0 + 2 w + r / 8, px0 + r % 8)
-  const int ay = py0 + 2 * wave + (r >> 3), ax = px0 + (r & 7);
-  const bool alive = ay < g.Ho && ax < g.Wo;
-  float4 av[JO];
-#pragma unroll
-  for (int j = 0; j < JO; ++j) {
-    av[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int c = 16 * j + 4 * gq;
-    if (alive && c < g.Cout) av[j] = ld4(dy + ((static_cast<long long>(b) * g.Ho + ay) * g.Wo + ax) * g.Cout + c);
-  }
-  // epilogue view: lane (n = channel within the chunk, q) post-processes pixels 4 q + reg of the wave's 16
-  const int n = lane & 15, q = lane >> 4;
-  int ey[4], ex[4];
-#pragma unroll
-  for (int reg = 0; reg < 4; ++reg) {
-    const int p16 = 4 * q + reg;
-    ey[reg] = py0 + 2 * wave + (p16 >> 3);
-    ex[reg] = px0 + (p16 & 7);
-  }
-  const float* xb = x + static_cast<long long>(b) * g.H * g.W * g.Cin;
-  float* dxb = dx + static_cast<long long>(b) * g.H * g.W * g.Cin;
-  const int ty0 = py0 * g.sh - g.ph - kDcnHalo, tx0 = px0 * g.sw - g.pw - kDcnHalo;   // image coordinates of the tile's corner
-  for (int cg = 0; cg < g.Cin; cg += 64) {
-    const int dgi = cg / cpg;
-    const bool first_of_group = (cg % cpg) == 0;
-    __syncthreads();
-    for (int e = threadIdx.x; e < kDcnTile * kDcnTile * 64; e += 256) tile[e] = 0.f;
-    for (int k = 0; k < K; ++k) {
-      Taps tp[4];
-      float mk[4];
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        mk[reg] = 0.f;
-        tp[reg].valid = 0;
-        tp[reg].o[0] = tp[reg].o[1] = tp[reg].o[2] = tp[reg].o[3] = -1;
-        tp[reg].w[0] = tp[reg].w[1] = tp[reg].w[2] = tp[reg].w[3] = 0.f;
-        tp[reg].lh = tp[reg].lw = 0.f;
-        if (ey[reg] < g.Ho && ex[reg] < g.Wo) tp[reg] = pixel_taps(g, offset, mask, b, ey[reg], ex[reg], k, dgi, &mk[reg]);
-      }
-      // where each tap lands in the LDS tile (float index of channel 0), -1: outside the tile -> global atomic
-      int lofs[4][4];
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg)
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-          lofs[reg][qq] = -1;
-          const int o = tp[reg].o[qq];
-          if (o >= 0) {
-            const int hy = o / g.W, hx = o - hy * g.W;
-            const int ly = hy - ty0, lx = hx - tx0;
-            if (ly >= 0 && ly < kDcnTile && lx >= 0 && lx < kDcnTile) lofs[reg][qq] = (ly * kDcnTile + lx) * 64;
-          }
-        }
-      float gm[4] = {0.f, 0.f, 0.f, 0.f}, gh[4] = {0.f, 0.f, 0.f, 0.f}, gw[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int c0 = cg; c0 < cg + 64; c0 += 16) {
-        __syncthreads();
-        for (int e = threadIdx.x; e < 16 * (JO * 4); e += 256) {   // B[co][ci] = wt[k][c0 + ci][co] in fragment order
-          const int ci = e / (JO * 4), co = (e % (JO * 4)) * 4;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          const float* p = wt + (static_cast<long long>(k) * g.Cin + c0 + ci) * g.Cout + co;
-          if (co + 3 < g.Cout) v = ld4(p);
-          else {
-            if (co < g.Cout) v.x = p[0];
-            if (co + 1 < g.Cout) v.y = p[1];
-            if (co + 2 < g.Cout) v.z = p[2];
-          }
-          *reinterpret_cast<float4*>(&wfrag[(((co >> 4) * 64) + ((co >> 2) & 3) * 16 + ci) * 4]) = v;
-        }
-        __syncthreads();
-        f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < JO; ++j) {
-          const float4 bv = *reinterpret_cast<const float4*>(&wfrag[(j * 64 + lane) * 4]);
-          d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].x, bv.x, d, 0, 0, 0);
-          d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].y, bv.y, d, 0, 0, 0);
-          d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].z, bv.z, d, 0, 0, 0);
-          d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].w, bv.w, d, 0, 0, 0);
-        }
-        const int ci = c0 + n, lc = c0 - cg + n;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const Taps& t = tp[reg];
-          if (!t.valid) continue;
-          const float gcol = d[reg];
-          float v[4];
-#pragma unroll
-          for (int qq = 0; qq < 4; ++qq) {
-            v[qq] = 0.f;
-            if (t.o[qq] >= 0) {
-              v[qq] = xb[static_cast<long long>(t.o[qq]) * g.Cin + ci];
-              const float c = gcol * mk[reg] * t.w[qq];
-              if (lofs[reg][qq] >= 0) atomicAdd(&tile[lofs[reg][qq] + lc], c);
-              else atomicAdd(&dxb[static_cast<long long>(t.o[qq]) * g.Cin + ci], c);
-            }
-          }
-          const float val = t.w[0] * v[0] + t.w[1] * v[1] + t.w[2] * v[2] + t.w[3] * v[3];
-          gm[reg] += gcol * val;
-          const float hw = 1.f - t.lw, hh = 1.f - t.lh;
-          gh[reg] += gcol * mk[reg] * (-hw * v[0] - t.lw * v[1] + hw * v[2] + t.lw * v[3]);
-          gw[reg] += gcol * mk[reg] * (-hh * v[0] + hh * v[1] - t.lh * v[2] + t.lh * v[3]);
-        }
-      }
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        float a = gm[reg], bh = gh[reg], bw = gw[reg];
-#pragma unroll
-        for (int s = 1; s < 16; s <<= 1) {
-          a += __shfl_xor(a, s, 64); bh += __shfl_xor(bh, s, 64); bw += __shfl_xor(bw, s, 64);
-        }
-        if (n == 0 && ey[reg] < g.Ho && ex[reg] < g.Wo) {
-          const long long pos = static_cast<long long>(ey[reg]) * g.Wo + ex[reg];
-          float* pm = dmask + ((static_cast<long long>(b) * g.dg + dgi) * K + k) * plane + pos;
-          float* ob = doff + (static_cast<long long>(b) * g.dg + dgi) * 2 * K * plane;
-          float* ph = ob + (2 * k) * plane + pos;
-          float* pw = ob + (2 * k + 1) * plane + pos;
-          if (first_of_group) { *pm = a; *ph = bh; *pw = bw; }
-          else { *pm += a; *ph += bh; *pw += bw; }
-        }
-      }
-    }
-    __syncthreads();
-    // flush: tile pixel (ly, lx) is image pixel (ty0 + ly, tx0 + lx); neighbouring patches overlap in the halo -> atomics
-    for (int e = threadIdx.x; e < kDcnTile * kDcnTile * 64; e += 256) {
-      const float v = tile[e];
-      if (v == 0.f) continue;
-      const int c = e & 63, pix = e >> 6, ly = pix / kDcnTile, lx = pix - ly * kDcnTile;
-      const int hy = ty0 + ly, hx = tx0 + lx;
-      if (hy >= 0 && hy < g.H && hx >= 0 && hx < g.W) atomicAdd(&dxb[(static_cast<long long>(hy) * g.W + hx) * g.Cin + cg + c], v);
-    }
-  }
-}
-
 // ---------------------------------------------------------------- backward: weight ---------------------
 // grid (pixel chunks, K, Cin/16); block 256 = 4 waves splitting the chunk's pixels; A_mfma[m = ci][kk = pixel] =
 // modulated sample, B_mfma[kk = pixel][n = co] = dy; partial [chunk][k][ci][co] tiles, reduced by wgrad-style sum.
@@ -566,25 +411,9 @@ extern "C" int fv2p_dcn_backward(const float* x_nhwc, const float* wt, const flo
                "dcn_backward: workspace too small");
   const unsigned blocks = static_cast<unsigned>(ceil_div(npix, 64));
   const int jo = static_cast<int>(ceil_div(g.Cout, 16));
-  static int tiled = -1;   // FV2P_DCN_TILED=0 keeps the plain scatter kernel (the parity tests run both)
-  if (tiled < 0) { const char* e = getenv("FV2P_DCN_TILED"); tiled = e ? atoi(e) : 1; }
-  const bool use_tile = tiled && (g.Cin / g.dg) % 64 == 0 && g.sh == 1 && g.sw == 1 && g.Ho >= 8 && g.Wo >= 8 && g.B <= 65535 && (jo == 8 || jo == 16);
-  if (use_tile) {
-    const dim3 pgrid(static_cast<unsigned>(ceil_div(g.Wo, 8)), static_cast<unsigned>(ceil_div(g.Ho, 8)), g.B);
-#define DCN_BT(JO)                                                                                                         \
-  do {                                                                                                                     \
-    const size_t lds = (JO * 64 * 4 + kDcnTile * kDcnTile * 64) * sizeof(float);                                            \
-    static bool set = false;                                                                                               \
-    if (!set) { FV2P_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_bwd_data_tile_k<JO>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds))); set = true; } \
-    hipLaunchKernelGGL((dcn_bwd_data_tile_k<JO>), pgrid, dim3(256), lds, stream, g, x_nhwc, wt, offset, mask, dy_nhwc, dx_nhwc, doffset, dmask); \
-  } while (0)
-    if (jo == 8) DCN_BT(8); else DCN_BT(16);
-#undef DCN_BT
-  } else {
 #define DCN_BD(JO) hipLaunchKernelGGL((dcn_bwd_data_k<JO>), dim3(blocks), dim3(256), JO * 64 * 4 * sizeof(float), stream, g, x_nhwc, wt, offset, mask, dy_nhwc, dx_nhwc, doffset, dmask)
-    if (jo <= 1) DCN_BD(1); else if (jo <= 2) DCN_BD(2); else if (jo <= 4) DCN_BD(4); else if (jo <= 8) DCN_BD(8); else DCN_BD(16);
+  if (jo <= 1) DCN_BD(1); else if (jo <= 2) DCN_BD(2); else if (jo <= 4) DCN_BD(4); else if (jo <= 8) DCN_BD(8); else DCN_BD(16);
 #undef DCN_BD
-  }
   const unsigned chunks = static_cast<unsigned>(ceil_div(npix, kDcnPixChunk));
   float* partial = static_cast<float*>(ws);
   const dim3 grid(chunks, K, static_cast<unsigned>(ceil_div(g.Cin, 16)));

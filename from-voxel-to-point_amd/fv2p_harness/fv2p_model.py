@@ -422,13 +422,24 @@ class PointHead(nn.Module):
         return loss, torch.sigmoid(logits).max(dim=-1).values
 
 
-def sa_msg_grid(sa, xyz, features, centres):
+def rows_linear(x, weight, bias=None):
+    """y[r] = x[r] @ weight.T (+ bias) for x (R, N, Cin) and a conv / linear weight (Cout, Cin[, 1, 1]), as a batched product with
+    the weight broadcast over R.  The forward is the same GEMM; the point is the weight gradient: autograd then forms it per RoI
+    (R products with K = N) and sums over R, instead of one product with K = R * N = 196 608 and a 3 .. 256-wide output, which
+    rocBLAS runs at a few TFLOP/s."""
+    w = weight.reshape(weight.shape[0], -1).t().unsqueeze(0).expand(x.shape[0], -1, -1)
+    y = torch.bmm(x, w)
+    return y if bias is None else y + bias
+
+
+def sa_msg_grid(sa, xyz, features, centres, rows=None):
     """PointnetSAModuleMSG.forward (pointnet2_modules.py:30-62) for the bn=False, use_xyz=True, max-pool module of the RoI head,
     with the first shared-MLP layer taken out of the neighbourhood: it is linear in [xyz_j - c_i ; f_j], so
     W1 [xyz_j - c_i ; f_j] = (W1f f_j + W1x xyz_j) - W1x c_i is one GEMM per POINT (512 per RoI) and one per CENTRE (216) instead
     of one per (centre, sample) pair (216 x 16 / 32); what is grouped is the 64-channel product, not the 131-channel input.
-    Same parameters, same result up to fp32 summation order.  xyz (R, N, 3), features (R, C, N), centres (R, M, 3) -> (R, sum C_k, M)."""
-    outs, rows = [], None
+    Same parameters, same result up to fp32 summation order.  xyz (R, N, 3), features (R, C, N) (or `rows` = the same point-major,
+    (R, N, C)), centres (R, M, 3) -> (R, sum C_k, M)."""
+    outs = []
     xyz_t = xyz.transpose(1, 2)                                                  # (R, 3, N)
     ctr_t = centres.transpose(1, 2)                                              # (R, 3, M)
     for grouper, mlp in zip(sa.groupers, sa.mlps):
@@ -441,12 +452,14 @@ def sa_msg_grid(sa, xyz, features, centres):
         if fusable:
             # rows of 64 channels per point / centre; gather, second layer, ReLU and the max over the samples in one kernel
             if rows is None:
-                rows = features.transpose(1, 2).contiguous().view(-1, features.shape[1])   # point-major once: one plain 2-D GEMM per scale
-            per_point = torch.mm(rows, w1[:, 3:].t()).view(xyz.shape[0], xyz.shape[1], -1) + torch.matmul(xyz, w1[:, :3].t())   # (R, N, C1)
-            per_centre = torch.matmul(centres, w1[:, :3].t())                                                          # (R, M, C1)
+                rows = features.transpose(1, 2).contiguous()                     # point-major (R, N, C)
+            per_point = rows_linear(rows, w1[:, 3:]) + rows_linear(xyz, w1[:, :3])                                     # (R, N, C1)
+            per_centre = rows_linear(centres, w1[:, :3])                                                               # (R, M, C1)
             if pn2_fused.supported(per_point, idx):
                 outs.append(pn2_fused.sa_grid_max(per_point, per_centre, idx, tail[1].weight[:, :, 0, 0]).transpose(1, 2))
                 continue
+        if features is None:
+            features = rows.transpose(1, 2).contiguous()
         per_point = (torch.matmul(w1[:, 3:], features) + torch.matmul(w1[:, :3], xyz_t)).contiguous()   # (R, C1, N)
         per_centre = torch.matmul(w1[:, :3], ctr_t)                              # (R, C1, M)
         h = pn2_batch.grouping_operation(per_point, idx) - per_centre.unsqueeze(-1)                     # (R, C1, M, ns)
@@ -625,11 +638,16 @@ class IoUGuidedRoIHead(nn.Module):
     def finish(self, key, feats, scores, prep):
         rois = prep["s_rois"]
         pooled = self.pool_points(key, feats, scores, rois)                                        # (B*n, 512, 5 + C)
-        xyz_in = pooled[..., 0:5].transpose(1, 2).unsqueeze(3).contiguous()
-        pt_in = pooled[..., 5:].transpose(1, 2).unsqueeze(3).contiguous()
-        merged = self.merge_down_layer(torch.cat((self.xyz_up_layer(xyz_in), pt_in), dim=1)).squeeze(3).contiguous()
+        # xyz_up_layer / merge_down_layer are 1x1 convs over the 512 pooled points of each RoI (:223-236): applied point-major, as
+        # batched row products (same weights; see rows_linear) - the pooled tensor already is (RoI, point, channel)
+        h = pooled[..., 0:5]
+        for layer in self.xyz_up_layer:
+            h = rows_linear(h, layer.weight, layer.bias) if isinstance(layer, nn.Conv2d) else layer(h)
+        h = torch.cat((h, pooled[..., 5:]), dim=2)
+        for layer in self.merge_down_layer:
+            h = rows_linear(h, layer.weight, layer.bias) if isinstance(layer, nn.Conv2d) else layer(h)
         # point stream: multi-scale ball query around the grid points (:258-275)
-        g_pt = sa_msg_grid(self.SA_modules[0], pooled[..., 0:3].contiguous(), merged, prep["local"].contiguous())
+        g_pt = sa_msg_grid(self.SA_modules[0], pooled[..., 0:3].contiguous(), None, prep["local"].contiguous(), rows=h)
         grid = torch.cat((g_pt, prep["g_bev"]), dim=1)
         pc = self.grid_interact_fc_layer(grid.view(grid.shape[0], -1, 1))
         shared = self.feature_fusion(torch.cat((pc, prep["cge"]), dim=1))
