@@ -65,6 +65,7 @@ def parse():
     ap.add_argument("--pin-cores", type=int, default=16, help="cores per rank to pin this process to (0: leave the affinity alone)")
     ap.add_argument("--phases", action="store_true", help="diagnostic: host issue time and synchronised wall time per phase (stderr)")
     ap.add_argument("--torch-profile", action="store_true", help="diagnostic: torch.profiler over 3 steps, top ops by device time (stderr)")
+    ap.add_argument("--point-stream", type=int, default=1, help="fv2p: decoder + point head on their own stream (A/B switch)")
     ap.add_argument("--miopen-find", type=int, default=0, help="torch.backends.cudnn.benchmark: let MIOpen time its solvers for the dense 2-D convs")
     ap.add_argument("--bev-channels-last", type=int, default=0, help="fv2p: BEV backbone + anchor head in channels_last memory format")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous check without a GPU: ranks join a gloo group, reduce, rank 0 prints n_gpus")
@@ -229,6 +230,8 @@ def build_fv2p_step(args, device, rank, world):
 
     waymo = args.workload == "fv2p-waymo"
     cfg = FV2PWaymoConfig if waymo else FV2PConfig
+    if not args.point_stream:
+        cfg = type("Cfg", (cfg,), {"point_branch_stream": False})
     vsize, prange = np.array(cfg.voxel_size, np.float32), np.array(cfg.point_cloud_range, np.float32)
     torch.manual_seed(0)
     model = FV2PDetector(cfg).to(device)

@@ -72,6 +72,7 @@ class FV2PConfig:
     interact_filters, cge_up, cge_interact, fuse_filters = (256, 256), (64, 64), (128,), (256,)
     cls_fc, reg_fc, dp_ratio = (256, 256), (256, 256), 0.3
     grad_norm_clip = 10.0
+    point_branch_stream = True     # decoder + point head on their own stream (their backward then overlaps the dense convs')
 
 
 class FV2PWaymoConfig(FV2PConfig):
@@ -718,13 +719,36 @@ class FV2PDetector(nn.Module):
         bev = self.backbone_2d(spatial)
         loss_rpn, prop_scores, prop_boxes = self.dense_head(bev, gt_boxes)
         prep = self.roi_head.prepare(bev, prop_scores, prop_boxes, gt_boxes, uniforms)   # still no key points needed
-        key, point_feats = self.post_pfe(clouds, levels, key_job)
-        loss_point, point_scores = self.point_head(key, point_feats, gt_boxes)
+        key, point_feats, loss_point, point_scores = self.point_branch(clouds, levels, key_job, gt_boxes)
         loss_rcnn, aux = self.roi_head.finish(key, point_feats, point_scores, prep)
         if self.taps is not None:
             self.taps.update(keypoints=key, point_features=point_feats, point_scores=point_scores, bev=bev, prop_boxes=prop_boxes,
                              prop_scores=prop_scores, loss_rpn=loss_rpn, loss_point=loss_point, loss_rcnn=loss_rcnn, **aux)
         return loss_rpn + loss_point + loss_rcnn
+
+
+    def point_branch(self, clouds, levels, key_job, gt_boxes):
+        """Decoder + point head.  Their only gradient is the point loss (the RoI head pools the point features under no_grad), so
+        in backward this chain of ~150 small kernels is independent of the BEV / anchor / RoI chain until both reach the sparse
+        backbone.  Run on its own stream in the forward pass, autograd replays it on that stream in the backward pass, beside the
+        dense convolutions' gradients on the main stream."""
+        if not (self.cfg.point_branch_stream and clouds[0].is_cuda and key_job is not None):
+            key, feats = self.post_pfe(clouds, levels, key_job)
+            loss, scores = self.point_head(key, feats, gt_boxes)
+            return key, feats, loss, scores
+        dev = clouds[0].device
+        side = self.__dict__.get("_point_stream")
+        if side is None or side.device != dev:
+            side = self.__dict__["_point_stream"] = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            key, feats = self.post_pfe(clouds, levels, key_job)
+            loss, scores = self.point_head(key, feats, gt_boxes)
+        main.wait_stream(side)
+        for t in (key, feats, loss, scores):
+            t.record_stream(main)
+        return key, feats, loss, scores
 
 
 def pad_gt_boxes(box_lists, device, max_gt=None):
