@@ -481,10 +481,12 @@ def roofline_probe(model, voxelize, pool, args, device):
     # (tools/pmc_roofline.sh) whose summary is committed under profiles/; reported only for the very layer they measured.
     traffic = None
     layer = f"{'subm' if mod.subm else 'conv'} {cin}->{cout} key={mod.indice_key} n_in={rec['n_in']} n_out={rec['n_out']} pairs={rec['pairs']}"
-    try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_roofline.json")) as f:
+    try:   # reported only for the very layer the counters were collected on (same channels, rows and pairs)
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_roofline.json")) as f:
             pmc = json.load(f)
-        if pmc["layer"] == layer:
+        import re
+        mt = re.search(r"(\d+)->(\d+) key=(\S+) n=(\d+) pairs=(\d+)", pmc.get("layer_line", ""))
+        if mt and (int(mt.group(1)), int(mt.group(2)), mt.group(3), int(mt.group(4)), int(mt.group(5))) == (cin, cout, mod.indice_key, rec["n_in"], rec["pairs"]):
             traffic = pmc["traffic_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass

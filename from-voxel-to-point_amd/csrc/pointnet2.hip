@@ -584,8 +584,7 @@ __global__ __launch_bounds__(kFpsWaves * 64) void fps_wave_k(int n, int m, int b
                                                              const uint64_t* __restrict__ keys, float* __restrict__ temp, int* __restrict__ idxs) {
   if (m <= 0) return;
   extern __shared__ uint32_t s_prio[];   // [S][kFpsWaves * 64]: reference priority of every point (read only when its bucket is touched)
-  __shared__ __attribute__((aligned(16))) float s_bucket[kFpsWaves][S][4];   // candidate of every bucket: x, y, z, -
-  __shared__ __attribute__((aligned(16))) uint32_t s_wave[2][kFpsWaves][4];   // candidate of every wave: max bits, priority, slot, -
+  __shared__ __attribute__((aligned(16))) uint32_t s_wave[2][kFpsWaves][8];   // candidate of every wave: max bits, priority, x, y, z, -
   int log2bs = 0;
   while ((1 << (log2bs + 1)) <= bs) ++log2bs;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -600,7 +599,7 @@ __global__ __launch_bounds__(kFpsWaves * 64) void fps_wave_k(int n, int m, int b
   auto index_of = [&](uint32_t pr) -> int { return static_cast<int>(((pr & 0xffffu) << log2bs) | (__brev(pr >> 16) >> (32 - log2bs))); };
   float px[S], py[S], pz[S], pt[S];
   // lane s < S of this wave keeps the state of the wave's bucket s: box, running maximum, priority of the point holding it
-  float lo0 = 0.f, lo1 = 0.f, lo2 = 0.f, hi0 = 0.f, hi1 = 0.f, hi2 = 0.f, bmax = -2.f;
+  float lo0 = 0.f, lo1 = 0.f, lo2 = 0.f, hi0 = 0.f, hi1 = 0.f, hi2 = 0.f, bmax = -2.f, bcx = 0.f, bcy = 0.f, bcz = 0.f;
   uint32_t bprio = 0xffffffffu;
 #pragma unroll
   for (int s = 0; s < S; ++s) {
@@ -634,13 +633,13 @@ __global__ __launch_bounds__(kFpsWaves * 64) void fps_wave_k(int n, int m, int b
       leader = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(__ballot(myp == pm && pt[s] == mx))) - 1);
     }
     const float cx = lane_f(px[s], leader), cy = lane_f(py[s], leader), cz = lane_f(pz[s], leader);
-    if (lane == s) { bmax = mx; bprio = pm; }
-    if (lane == 0) *reinterpret_cast<float4*>(&s_bucket[w][s][0]) = make_float4(cx, cy, cz, 0.f);
+    if (lane == s) { bmax = mx; bprio = pm; bcx = cx; bcy = cy; bcz = cz; }   // the bucket's candidate point travels with its state
   };
   static_for<0, S>(refresh);
   // wave candidate from the S bucket states (every stored maximum is exact: a touched bucket is refreshed at once; keeping
   // stale upper bounds and refreshing only the buckets that reach the top was measured slower, 1.44 vs 1.02 us per round)
   uint32_t wbits = 0, wprio = 0xffffffffu, wslot = 0;
+  float wcx = 0.f, wcy = 0.f, wcz = 0.f;
   auto wave_best = [&]() __attribute__((always_inline)) {
     const float v = lane < S ? bmax : -3.f;
     const float mx = wave_max_f32(v);
@@ -654,6 +653,7 @@ __global__ __launch_bounds__(kFpsWaves * 64) void fps_wave_k(int n, int m, int b
     wslot = static_cast<uint32_t>(slot);
     wbits = __float_as_uint(fmaxf(mx, 0.f));   // every real maximum is >= 0: unsigned order == float order; empty wave -> 0 with priority ~0
     wprio = pm;
+    wcx = lane_f(bcx, slot); wcy = lane_f(bcy, slot); wcz = lane_f(bcz, slot);
   };
   wave_best();
   float x1 = dataset[0], y1 = dataset[1], z1 = dataset[2];
@@ -685,10 +685,14 @@ __global__ __launch_bounds__(kFpsWaves * 64) void fps_wave_k(int n, int m, int b
       if ((touch >> wslot) & 1ull) wave_best();
     }
     const int buf = j & 1;
-    if (lane == 0) *reinterpret_cast<uint4*>(&s_wave[buf][w][0]) = make_uint4(wbits, wprio, wslot, 0u);
+    if (lane == 0) {
+      *reinterpret_cast<uint4*>(&s_wave[buf][w][0]) = make_uint4(wbits, wprio, __float_as_uint(wcx), __float_as_uint(wcy));
+      s_wave[buf][w][4] = __float_as_uint(wcz);
+    }
     lds_barrier();
-    // 8 wave candidates, one per lane of the first row; every wave derives the same winner
+    // 8 wave candidates (with their points), one per lane of the first row; every wave derives the same winner
     const uint4 c = lane < kFpsWaves ? *reinterpret_cast<const uint4*>(&s_wave[buf][lane][0]) : make_uint4(0u, 0xffffffffu, 0u, 0u);
+    const uint32_t cz_bits = lane < kFpsWaves ? s_wave[buf][lane][4] : 0u;
     const float gmax = lane_f(row_max_f32(__uint_as_float(c.x)), 0);
     const uint64_t gtop = __ballot(lane < kFpsWaves && __uint_as_float(c.x) == gmax);
     int gw = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(gtop)) - 1);
@@ -697,9 +701,9 @@ __global__ __launch_bounds__(kFpsWaves * 64) void fps_wave_k(int n, int m, int b
       gprio = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(row_min_u32(__uint_as_float(c.x) == gmax ? c.y : 0xffffffffu)), 0));
       gw = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(__ballot(lane < kFpsWaves && __uint_as_float(c.x) == gmax && c.y == gprio))) - 1);
     }
-    const int gslot = __builtin_amdgcn_readlane(static_cast<int>(c.z), gw);
-    const float4 p = *reinterpret_cast<const float4*>(&s_bucket[gw][gslot][0]);
-    x1 = p.x; y1 = p.y; z1 = p.z;
+    x1 = __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(c.z), gw)));
+    y1 = __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(c.w), gw)));
+    z1 = __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cz_bits), gw)));
     if (tid == 0) idxs[j] = index_of(gprio);
   }
 #pragma unroll

@@ -232,8 +232,9 @@ def fps():
     from fv2p_harness import synth
     from pcdet.ops.pointnet2.pointnet2_batch import pointnet2_utils as bu
     dev = torch.device("cuda:0")
-    for n, m, b in [(16384, 16384, 1), (16384, 16384, 4), (16384, 4096, 4), (20000, 16384, 1)]:
-        pts = torch.from_numpy(np.stack([synth.lidar_cloud(i, n)[:, :3] for i in range(b)])).to(dev)
+    for n, m, b in [(16384, 16384, 1), (16384, 16384, 3), (16384, 4096, 4), (20000, 16384, 1), (24576, 16384, 2), (40000, 16384, 2), (180000, 16384, 2)]:
+        gen = synth.waymo_like_cloud if n > 30000 else synth.lidar_cloud    # n > 24576: the streaming kernel
+        pts = torch.from_numpy(np.stack([gen(i, n)[:, :3] for i in range(b)])).to(dev)
         t = timeit(lambda: bu.furthest_point_sample(pts, m), reps=3, warm=1)
         print(f"FPS B={b} N={n} M={m}: {t / 1e3:8.2f} ms  ({t / m:6.3f} us/round)")
     kp = torch.from_numpy(synth.lidar_cloud(1, 16384)[None, :, :3]).to(dev)
@@ -253,6 +254,42 @@ def nms():
         scores = torch.rand(n, device=dev)
         t = timeit(lambda: iou3d_nms_utils.nms_gpu(boxes, scores, th), reps=5, warm=1)
         print(f"nms_gpu N={n} thr={th}: {t:8.1f} us")
+    # proposal layer of the FV2P step: three samples, 9000 sorted boxes each, first 512 survivors (fv2p_nms_batch)
+    from pcdet.ops.iou3d_nms import iou3d_nms_cuda
+    batch = torch.from_numpy(np.stack([random_boxes(7 + i, 9000) for i in range(3)])).to(dev)
+    for keep in (512, 0):
+        t = timeit(lambda: iou3d_nms_cuda.nms_batch_device(batch, 0.8, keep), reps=5, warm=1)
+        print(f"nms_batch B=3 N=9000 thr=0.8 max_keep={keep}: {t:8.1f} us")
+
+
+def sa():
+    from pcdet.ops.pointnet2.pointnet2_batch import fused, pointnet2_utils as bu
+    dev = torch.device("cuda:0")
+    r, n, m = 384, 512, 216
+    g = torch.Generator().manual_seed(0)
+    xyz = (torch.rand(r, n, 3, generator=g) * torch.tensor([7.0, 5.0, 4.0]) - torch.tensor([3.5, 2.5, 2.0])).to(dev)
+    ctr = (torch.rand(r, m, 3, generator=g) * torch.tensor([4.0, 1.6, 1.5]) - torch.tensor([2.0, 0.8, 0.75])).to(dev)
+    pp = torch.randn(r, n, 64, generator=g).to(dev).requires_grad_(True)
+    pc = torch.randn(r, m, 64, generator=g).to(dev).requires_grad_(True)
+    w2 = (torch.randn(64, 64, generator=g) * 0.1).to(dev).requires_grad_(True)
+    for radius, s in ((0.8, 16), (1.6, 32)):
+        idx = bu.ball_query(radius, s, xyz, ctr)
+        tf = timeit(lambda: fused.sa_grid_max(pp, pc, idx, w2), reps=10, warm=2)
+        out = fused.sa_grid_max(pp, pc, idx, w2)
+        go = torch.randn_like(out)
+        tb = timeit(lambda: out.backward(go, retain_graph=True), reps=10, warm=2)
+        flops = 2.0 * r * m * s * 64 * 64
+        print(f"fused grid SA R={r} M={m} S={s}: fwd {tf:7.1f} us ({flops / tf / 1e6:5.1f} TF/s)  bwd {tb:7.1f} us")
+
+        def grouped():
+            gpt = bu.grouping_operation(pp.transpose(1, 2).contiguous(), idx)
+            h2 = torch.relu(torch.einsum("oc,rcms->roms", w2, torch.relu(gpt - pc.transpose(1, 2).unsqueeze(-1))))
+            return h2.amax(dim=-1)
+        tg = timeit(lambda: grouped(), reps=3, warm=1)
+        ref = grouped()
+        gr = torch.randn_like(ref)
+        tgb = timeit(lambda: ref.backward(gr, retain_graph=True), reps=3, warm=1)
+        print(f"   grouped formulation (group_points + einsum + relu + amax): fwd {tg:7.1f} us  bwd {tgb:7.1f} us")
 
 
 def bn():
@@ -316,7 +353,7 @@ if __name__ == "__main__":
     if which == "convone":
         conv(only=20)
         sys.exit(0)
-    for name, fn in (("conv", conv), ("dcn", dcn), ("fps", fps), ("nms", nms), ("bn", bn), ("bev", bev)):
+    for name, fn in (("conv", conv), ("dcn", dcn), ("fps", fps), ("nms", nms), ("sa", sa), ("bn", bn), ("bev", bev)):
         if which in (name, "all"):
             print(f"==== {name}")
             fn()
