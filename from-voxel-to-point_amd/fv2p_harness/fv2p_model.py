@@ -89,6 +89,18 @@ class FV2PWaymoConfig(FV2PConfig):
 
 
 # ---------------------------------------------------------------- small shared pieces -----------------
+_SIDE_STREAMS = {}
+
+
+def side_stream(role, device):
+    """One HIP stream per (role, device) for the whole process.  Kept outside the modules: a stream is not copyable, and the
+    CPU mirror of a model (oracle.spconv_cpu.cpu_mirror) is a deep copy of it."""
+    key = (role, torch.device(device).index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 def limit_period(val, offset, period):
     return val - torch.floor(val / period + offset) * period
 
@@ -365,9 +377,7 @@ class V2PDecoder(nn.Module):
         if not clouds[0].is_cuda:
             return None
         dev = clouds[0].device
-        side = self.__dict__.get("_side_stream")
-        if side is None or side.device != dev:
-            side = self.__dict__["_side_stream"] = torch.cuda.Stream(device=dev)
+        side = side_stream("fps", dev)
         main = torch.cuda.current_stream(dev)
         side.wait_stream(main)
         with torch.cuda.stream(side):
@@ -737,9 +747,7 @@ class FV2PDetector(nn.Module):
             loss, scores = self.point_head(key, feats, gt_boxes)
             return key, feats, loss, scores
         dev = clouds[0].device
-        side = self.__dict__.get("_point_stream")
-        if side is None or side.device != dev:
-            side = self.__dict__["_point_stream"] = torch.cuda.Stream(device=dev)
+        side = side_stream("point", dev)
         main = torch.cuda.current_stream(dev)
         side.wait_stream(main)
         with torch.cuda.stream(side):

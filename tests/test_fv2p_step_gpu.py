@@ -100,6 +100,9 @@ def test_fv2p_step_matches_cpu_oracle(gpu, cpu_run):
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
     if torch.equal(g["sampled_rois"].cpu(), c["sampled_rois"]):
         assert abs(g["loss_rcnn"].item() - c["loss_rcnn"].item()) < 2e-3 * max(1.0, abs(c["loss_rcnn"].item()))
+    # bench.py's cpu_baseline leg mirrors a model that has already stepped on the GPU: its side streams must not be module state
+    net.taps = None
+    assert next(cpu_mirror(net).parameters()).device.type == "cpu"
 
 
 @pytest.mark.gpu
