@@ -54,6 +54,10 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--prefetch", type=int, default=2,
                     help="input-pipeline thread prepares batch t+1 while batch t trains: 2 = voxelisation + rulebooks, 1 = voxelisation, 0 = all in line")
+    ap.add_argument("--ahead", type=int, default=0,
+                    help="no thread: batch t+1 is prepared on a side stream between forward and backward of step t (2 = voxelisation + rulebooks, 1 = voxelisation); FV2P workloads default to 2")
+    ap.add_argument("--ahead-priority", type=int, default=-1, help="stream priority of the --ahead side stream (-1 = high: a hardware queue of its own)")
+    ap.add_argument("--cloud-streams", type=int, default=1, help="voxelise the clouds of a batch on one stream each (FV2P workloads)")
     ap.add_argument("--pair-lists", type=int, default=1, help="prefetch also materialises the reference-format pair lists (pair-split weight gradient)")
     ap.add_argument("--switch-interval", type=float, default=0.0, help="sys.setswitchinterval (s); 0 keeps Python's default 5 ms")
     ap.add_argument("--prefetch-depth", type=int, default=3, help="batches the input pipeline keeps in flight")
@@ -64,6 +68,8 @@ def parse():
     ap.add_argument("--lean-adamw", type=int, default=1, help="1: torch's fused AdamW kernels called on cached tensor lists (fv2p_harness/optim.py); 0: torch.optim.AdamW(fused=True)")
     ap.add_argument("--pin-cores", type=int, default=16, help="cores per rank to pin this process to (0: leave the affinity alone)")
     ap.add_argument("--phases", action="store_true", help="diagnostic: host issue time and synchronised wall time per phase (stderr)")
+    ap.add_argument("--phase-kernels", action="store_true", help="diagnostic (with --phases): launches and device time per phase instead of wall times")
+    ap.add_argument("--sync-debug", action="store_true", help="diagnostic: one step under torch.cuda.set_sync_debug_mode('warn'); every host-blocking torch call with its call site (stderr)")
     ap.add_argument("--torch-profile", action="store_true", help="diagnostic: torch.profiler over 3 steps, top ops by device time (stderr)")
     ap.add_argument("--point-stream", type=int, default=1, help="fv2p: decoder + point head on their own stream (A/B switch)")
     ap.add_argument("--miopen-find", type=int, default=0, help="torch.backends.cudnn.benchmark: let MIOpen time its solvers for the dense 2-D convs")
@@ -84,6 +90,8 @@ def parse():
         args.steps, args.warmup = 30, (args.warmup if "--warmup" in sys.argv else 5)
     if args.workload == "fv2p" and "--prefetch" not in sys.argv:
         args.prefetch = 0   # measured: the input-pipeline thread does not pay here (65.3 vs 63.7 ms per step); the step is not launch bound
+    if args.workload in ("fv2p", "fv2p-waymo") and "--ahead" not in sys.argv and not args.prefetch:
+        args.ahead = 2
     if args.steps == 300 and args.workload == "fv2p" and "--steps" not in sys.argv:
         args.steps, args.warmup = 40, (args.warmup if "--warmup" in sys.argv else 5)
     return args
@@ -224,7 +232,7 @@ def build_fv2p_step(args, device, rank, world):
     from fv2p_harness import dist_utils, synth
     from fv2p_harness.fv2p_model import FV2PConfig, FV2PDetector, FV2PWaymoConfig, pad_gt_boxes
     from fv2p_harness.optim import LeanAdamW
-    from fv2p_harness.prefetch import BatchPrefetcher
+    from fv2p_harness.prefetch import BatchAhead, BatchPrefetcher
     from pcdet.datasets.processor.voxel_generator import points_to_voxel_batch
     from pcdet.ops import spconv
 
@@ -257,26 +265,32 @@ def build_fv2p_step(args, device, rank, world):
         pool.append((clouds, pad_gt_boxes(boxes, device, max_gt=40)))
     n_uniform = cfg.nms_post + cfg.roi_per_image
 
-    def voxelize(clouds):
-        return points_to_voxel_batch(clouds, vsize, prange, cfg.max_points_per_voxel, cfg.max_voxels, mean_vfe=True)
+    def voxelize(clouds, cloud_streams=bool(args.cloud_streams)):
+        return points_to_voxel_batch(clouds, vsize, prange, cfg.max_points_per_voxel, cfg.max_voxels, mean_vfe=True, cloud_streams=cloud_streams)
 
-    pre = None
-    if args.prefetch:
+    pre = ahead = None
+    if args.prefetch or args.ahead:
         with torch.no_grad():
             f0, c0 = voxelize(pool[0][0])
             recipe = spconv.rulebook_recipe(model.backbone_3d(f0, c0, args.batch)[0].indice_dict, c0)
+        level = args.prefetch or args.ahead
 
         def produce(i):
-            feats, coords = voxelize(pool[i % n_pool][0])
-            if args.prefetch > 1:
+            feats, coords = voxelize(pool[i % n_pool][0], cloud_streams=bool(args.cloud_streams) and not args.ahead)
+            if level > 1:
                 spconv.attach_rulebooks(coords, spconv.build_rulebooks(recipe, coords, args.batch, pair_lists=bool(args.pair_lists)))
             return feats, coords
 
-        pre = BatchPrefetcher(produce, device, workers=args.prefetch_workers)
+        if args.prefetch:
+            pre = BatchPrefetcher(produce, device, workers=args.prefetch_workers)
+        else:
+            ahead = BatchAhead(produce, device, priority=args.ahead_priority)
 
     def step(i):
         clouds, gt = pool[i % n_pool]
-        if pre is None:
+        if ahead is not None:
+            feats, coords = ahead.take(i)
+        elif pre is None:
             feats, coords = voxelize(clouds)
         else:
             if pre.pending == 0:
@@ -287,6 +301,8 @@ def build_fv2p_step(args, device, rank, world):
             feats, coords = pre.get()
         u = torch.rand(len(clouds), n_uniform, device=device)
         loss = net(clouds, feats, coords, gt, u)
+        if ahead is not None:
+            ahead.prepare(i + 1)   # between forward and backward: its host waits see the side stream only
         opt.zero_grad(set_to_none=True)
         loss.backward()
         torch.nn.utils.clip_grad_norm_(params, cfg.grad_norm_clip, foreach=True)   # GRAD_NORM_CLIP (train_utils.py:43)
@@ -296,6 +312,19 @@ def build_fv2p_step(args, device, rank, world):
     def step_phases(i, acc):
         def phase(name, fn):
             torch.cuda.synchronize()
+            if args.phase_kernels:   # launches and device time per phase (slow: one profiler session per phase)
+                from torch.profiler import ProfilerActivity, profile
+                with profile(activities=[ProfilerActivity.CUDA]) as tp:
+                    r = fn()
+                    torch.cuda.synchronize()
+                ev = [e for e in tp.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+                k = acc.setdefault("kernels:" + name, [0.0, 0.0])
+                k[0] += len(ev)
+                k[1] += sum(e.device_time for e in ev) * 1e-6
+                small = acc.setdefault("kernels<10us:" + name, [0.0, 0.0])
+                small[0] += sum(1 for e in ev if e.device_time < 10)
+                small[1] += sum(e.device_time for e in ev if e.device_time < 10) * 1e-6
+                return r
             t0 = time.perf_counter()
             r = fn()
             t1 = time.perf_counter()
@@ -614,7 +643,27 @@ def main():
         for i in range(20):
             step.phases(args.warmup + i, acc)
         for k, (h, w) in acc.items():
-            print(f"[phases] {k:14s} host issue {h / 20 * 1e3:7.3f} ms   synchronised wall {w / 20 * 1e3:7.3f} ms", file=sys.stderr)
+            if k.startswith("kernels"):
+                print(f"[phases] {k:34s} {h / 20:7.1f} launches   device time {w / 20 * 1e3:7.3f} ms", file=sys.stderr)
+            else:
+                print(f"[phases] {k:14s} host issue {h / 20 * 1e3:7.3f} ms   synchronised wall {w / 20 * 1e3:7.3f} ms", file=sys.stderr)
+    if args.sync_debug and rank == 0:
+        import traceback
+        import warnings
+
+        def show(message, category, filename, lineno, file=None, line=None):
+            mine = [f for f in traceback.extract_stack()[:-1] if "from-voxel-to-point_amd" in f.filename or f.filename.endswith("bench.py")]
+            where = " <- ".join(f"{os.path.basename(f.filename)}:{f.lineno}" for f in reversed(mine[-3:]))
+            print(f"[sync] {str(message)[:60]} at {where}", file=sys.stderr)
+        keep = warnings.showwarning
+        warnings.showwarning = show
+        warnings.simplefilter("always")
+        torch.cuda.set_sync_debug_mode("warn")
+        step(args.warmup)
+        torch.cuda.set_sync_debug_mode("default")
+        warnings.showwarning = keep
+        warnings.simplefilter("default")
+        torch.cuda.synchronize()
     if args.torch_profile and rank == 0:
         from torch.profiler import ProfilerActivity, profile
         with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as tp:
@@ -636,7 +685,7 @@ def main():
     if prof is not None:
         prof.disable()
         import pstats
-        pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(28)
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(70)
     dist_utils.barrier()
     torch.cuda.synchronize()
     dt = dist_utils.max_over_ranks(time.perf_counter() - t0, device)
@@ -660,9 +709,12 @@ def main():
             "config": {"workload": workload_name(args), "batch_per_gpu": args.batch, "points_per_cloud": args.points,
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "host_cores_per_rank": len(pinned) if pinned else "unpinned",
-                       "input_pipeline": {0: "in line", 1: "thread voxelises batch t+1 during step t",
-                                          2: "thread voxelises batch t+1 and builds its rulebooks during step t",
-                                          3: "DIAGNOSTIC: prepared batches reused, not a benchmark configuration"}[min(args.prefetch, 3)]},
+                       "input_pipeline": ({1: "batch t+1 voxelised on a side stream between forward and backward of step t (same thread)",
+                                           2: "batch t+1 voxelised and its rulebooks built on a side stream between forward and backward of step t (same thread)"}[min(args.ahead, 2)]
+                                          if args.ahead and not args.prefetch else
+                                          {0: "in line", 1: "thread voxelises batch t+1 during step t",
+                                           2: "thread voxelises batch t+1 and builds its rulebooks during step t",
+                                           3: "DIAGNOSTIC: prepared batches reused, not a benchmark configuration"}[min(args.prefetch, 3)])},
         }
         if args.workload == "fv2p-waymo":
             result["metric"] = "point clouds/sec fwd+bwd (FV2P, Waymo shape: 180k points, 0.1 m voxels)"

@@ -19,6 +19,7 @@
 // cin-block group); valid rows are compacted with a wave64 ballot so only real pairs reach the MFMA.
 #include "common.hpp"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace fv2p {
 
@@ -781,6 +782,259 @@ __global__ __launch_bounds__(256) void conv_rows_act(ConvArgs a) {
   }
 }
 
+// ---- pair-compacted tile with the reduction dimension split over the waves ---------------------------------------------------
+// At the 5-10 pairs per row of the backbones' deep levels an output-stationary 16-row MFMA group is mostly zero rows: of
+// the 27 offsets a tile visits, a row has a neighbour at ~38 % of them, so ~60 % of the MFMA issue slots of conv_rows_dma
+// multiply zeros (and its 64 KB weight double buffer limits a CU to two workgroups, which the 155 tiles of a 10 k-row level
+// cannot even fill).  Here the MFMA work follows the pair count:
+//   * prologue: the tile's slice of the table goes through one ballot compaction per offset into LDS
+//     ([offset][slot] -> source row / tile row, padded with "no row"), offsets without any pair are dropped from the loop;
+//   * wave w owns the source channels [w CINP/4, (w+1) CINP/4) for ALL rows of the tile and all 64 columns of the launch:
+//     its slice of W_k (CINP/4 x 64 floats = 16 or 32 VGPRs) comes straight from L2 into registers, no LDS staging, no
+//     barrier in the offset loop, no imbalance between the waves whatever the compaction leaves;
+//   * per offset only ceil(pairs / 16) row groups are gathered (one or two 16-byte loads per lane) and multiplied.  Three
+//     offsets are in flight per wave: the slot lists of offset j+2 are being read from LDS, the weights and rows of offset
+//     j+1 are on their way from L2, offset j multiplies;
+//   * the products are taken transposed (weights as the MFMA's A operand, gathered rows as B): a lane then holds 16
+//     columns of ONE compacted row, as four 4-register accumulators.  The wave's own LDS buffer keeps a tile row's partial
+//     sums in exactly that order, so a group's accumulators are four 16-byte reads straight into the MFMA C operand (issued
+//     while the group before multiplies) and four 16-byte writes after — no adds, no register shuffles (LDS float atomics
+//     measured 10x slower).  A row occurs once per offset and a wave's LDS operations execute in order, so every sum runs
+//     over ascending k: deterministic; the epilogue adds the four waves' partial sums in wave order.
+// LDS at TM = 64 rows per tile: 4 x 65 x 68 accumulators + the compacted table = 79 KB -> two workgroups per CU; TM = 32: 40 KB.
+template <int CINP, bool WT, int TM>
+__global__ __launch_bounds__(256) void conv_rows_ksplit(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int KS = CINP / 4;      // source channels per wave
+  constexpr int JS = KS / 16;       // 16-byte row pieces per lane and group
+  constexpr int NBV = KS / 4;       // float4 weight registers per wave and offset
+  constexpr int MAXK = 32;
+  constexpr int MAXG = TM / 16;     // row groups an offset can need
+  constexpr int ROWS = TM + 1;      // tile rows + one row that takes the padding slots' sums of zeros
+  constexpr int LDR = 68;           // floats per accumulator row: 64 + 4, consecutive rows start 4 banks apart
+  float* accl = lds;                                              // [wave][row ROWS][LDR]; column c of a row at (c >> 4) * 16 + (c & 3) * 4 + ((c >> 2) & 3)
+  int* s_idx = reinterpret_cast<int*>(lds + 4 * ROWS * LDR);      // [MAXK][TM] source row of slot p (-1: padding)
+  unsigned char* s_row = reinterpret_cast<unsigned char*>(s_idx + MAXK * TM);   // [MAXK][TM] tile row of slot p
+  int* s_cnt = reinterpret_cast<int*>(s_row + MAXK * TM);         // [MAXK]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, g = lane >> 4;
+  const int row0 = xcd_major_tile(blockIdx.x, gridDim.x) * TM;
+  if (gridDim.y > 1) {   // column split as in conv_rows_dma
+    const int off = blockIdx.y * 64;
+    a.w += WT ? static_cast<long long>(off) * a.w_ld : off;
+    a.dst += off;
+    if (a.bias) a.bias += off;
+    if (a.stats) a.stats += off;
+    if (a.bn_x) {
+      a.bn_x += off; a.bn_mean += off; a.bn_invstd += off;
+      if (a.bn_gamma) a.bn_gamma += off;
+      if (a.bn_beta) a.bn_beta += off;
+    }
+  }
+  a.c_dst = 64;
+  unsigned long long t_begin = 0, t_pro = 0, t_wait = 0, t_mark = 0;
+  if (a.trace) t_begin = __builtin_readcyclecounter();
+  {
+    float4* z = reinterpret_cast<float4*>(accl);
+    for (int e = tid; e < 4 * ROWS * LDR / 4; e += 256) z[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  {
+    // the wave's offsets k = wave, wave + 4, ...: all table loads first, then one ballot compaction each
+    const int row = row0 + lane;
+    const bool mine = lane < TM && row < a.n_dst;
+    int tv[MAXK / 4];
+#pragma unroll
+    for (int u = 0; u < MAXK / 4; ++u) {
+      const int k = wave + 4 * u;
+      tv[u] = (mine && k < a.kvol) ? a.tab[static_cast<long long>(a.flip ? (a.kvol - 1 - k) : k) * a.n_dst + row] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < MAXK / 4; ++u) {
+      const int k = wave + 4 * u;
+      if (k < a.kvol) {   // uniform
+        const int t = tv[u];
+        const unsigned long long vote = __ballot(t >= 0);
+        const int cnt = __popcll(vote), below = __popcll(vote & lanemask_lt());
+        const int slot = t >= 0 ? below : cnt + (lane - below);   // lanes < TM: a permutation of 0..TM-1, every slot is written
+        if (slot < TM) {
+          s_idx[k * TM + slot] = t;
+          s_row[k * TM + slot] = static_cast<unsigned char>(t >= 0 ? lane : TM);   // padding: the spare row
+        }
+        if (lane == 0) s_cnt[k] = cnt;
+      }
+    }
+  }
+  __syncthreads();
+  const int cntv = lane < a.kvol ? s_cnt[lane] : 0;   // lane k: pairs of offset k in this tile
+  unsigned long long todo = __ballot(cntv > 0);
+  // per-lane byte offsets of the weight registers relative to W_k
+  int boff[NBV];
+#pragma unroll
+  for (int u = 0; u < NBV; ++u) {
+    const int jj = u >> 2, x = u & 3;   // !WT: x = t (k-step), WT: x = i (column block)
+    boff[u] = WT ? ((4 * r + x) * a.w_ld + KS * wave + 16 * jj + 4 * g) * 4 : ((KS * wave + 16 * jj + 4 * g + x) * a.w_ld + 4 * r) * 4;
+  }
+  const float* zero_row = g_zero_row + KS * wave + 4 * g;
+  const long long src_col = KS * wave + 4 * g;
+  float* my_acc = accl + wave * ROWS * LDR + g * 16;   // + row * LDR: this lane's 16 columns of a row (four 16-byte words)
+
+  struct Meta { int k, cnt; int idx[MAXG]; int row[MAXG]; };
+  // stage I: the slot lists of an offset (source row and tile row of slot 16 grp + (lane & 15))
+  auto read_meta = [&](Meta& m) {
+#pragma unroll
+    for (int grp = 0; grp < MAXG; ++grp) {
+      m.idx[grp] = s_idx[m.k * TM + grp * 16 + r];
+      m.row[grp] = s_row[m.k * TM + grp * 16 + r];
+    }
+  };
+  // stage L: weights and gathered rows on their way
+  auto issue = [&](const Meta& m, f32x4 (&A)[MAXG][JS], f32x4 (&B)[NBV]) {
+    const float* wk = a.w + static_cast<long long>(m.k) * a.w_kstride;
+#pragma unroll
+    for (int u = 0; u < NBV; ++u) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(B[u]) : "v"(boff[u]), "s"(wk) : "memory");
+#pragma unroll
+    for (int grp = 0; grp < MAXG; ++grp) {
+      if (grp * 16 < m.cnt) {   // uniform
+        const int idx = m.idx[grp];
+        const float* p = idx >= 0 ? a.src + static_cast<long long>(idx) * a.ld_src + src_col : zero_row;
+        gather_async<JS>(A[grp], p);
+      }
+    }
+  };
+  auto wait = [&](f32x4 (&A)[MAXG][JS], f32x4 (&B)[NBV]) {
+    // s_waitcnt vmcnt(0) that every prefetched register passes through: their uses are ordered after it
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+#pragma unroll
+    for (int grp = 0; grp < MAXG; ++grp)
+#pragma unroll
+      for (int jj = 0; jj < JS; ++jj) asm volatile("" : "+v"(A[grp][jj]));
+#pragma unroll
+    for (int u = 0; u < NBV; ++u) asm volatile("" : "+v"(B[u]));
+  };
+  // stage C: acc[i][reg] of lane (g, r) is column 16 g + 4 reg + i of the group's slot r.  One straight-line body per group
+  // count (no branch between the groups of an offset): the next group's accumulator reads sit above this group's MFMAs
+  auto groups = [&](auto ng_, const Meta& m, const f32x4 (&A)[MAXG][JS], const f32x4 (&B)[NBV]) {
+    constexpr int NG = decltype(ng_)::value;
+    f32x4 c[NG][4];
+    f32x4* p[NG];
+#pragma unroll
+    for (int grp = 0; grp < NG; ++grp) p[grp] = reinterpret_cast<f32x4*>(my_acc + m.row[grp] * LDR);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[0][i] = p[0][i];
+#pragma unroll
+    for (int grp = 0; grp < NG; ++grp) {
+      if (grp + 1 < NG) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c[grp + 1 < NG ? grp + 1 : grp][i] = p[grp + 1 < NG ? grp + 1 : grp][i];
+      }
+#pragma unroll
+      for (int jj = 0; jj < JS; ++jj)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            c[grp][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(WT ? B[jj * 4 + i][t] : B[jj * 4 + t][i], A[grp][jj][t], c[grp][i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) p[grp][i] = c[grp][i];
+    }
+  };
+  auto compute = [&](const Meta& m, const f32x4 (&A)[MAXG][JS], const f32x4 (&B)[NBV]) {
+    const int ng = (m.cnt + 15) >> 4;   // uniform
+    if constexpr (MAXG == 2) {
+      if (ng == 1) groups(std::integral_constant<int, 1>{}, m, A, B);
+      else groups(std::integral_constant<int, 2>{}, m, A, B);
+    } else {
+      if (ng == 1) groups(std::integral_constant<int, 1>{}, m, A, B);
+      else if (ng == 2) groups(std::integral_constant<int, 2>{}, m, A, B);
+      else if (ng == 3) groups(std::integral_constant<int, 3>{}, m, A, B);
+      else groups(std::integral_constant<int, 4>{}, m, A, B);
+    }
+  };
+  auto next_offset = [&](Meta& m) {   // pops the next non-empty offset; cnt = 0 when there is none
+    if (todo) {
+      m.k = __builtin_ctzll(todo);
+      m.cnt = __builtin_amdgcn_readlane(cntv, m.k);
+      todo &= todo - 1;
+    } else {
+      m.k = 0; m.cnt = 0;
+    }
+  };
+  if (a.trace) t_pro = __builtin_readcyclecounter();
+  if (todo) {
+    f32x4 A0[MAXG][JS], B0[NBV], A1[MAXG][JS], B1[NBV];
+    Meta m0, m1, m2;   // m0: multiplying, m1: loads in flight, m2: slot lists being read
+    next_offset(m0); read_meta(m0);
+    next_offset(m1); if (m1.cnt) read_meta(m1);
+    issue(m0, A0, B0);
+    while (true) {
+      next_offset(m2); if (m2.cnt) read_meta(m2);
+      if (a.trace) t_mark = __builtin_readcyclecounter();
+      wait(A0, B0);
+      if (a.trace) t_wait += __builtin_readcyclecounter() - t_mark;
+      if (m1.cnt) issue(m1, A1, B1);
+      compute(m0, A0, B0);
+      if (!m1.cnt) break;
+      next_offset(m0); if (m0.cnt) read_meta(m0);
+      if (a.trace) t_mark = __builtin_readcyclecounter();
+      wait(A1, B1);
+      if (a.trace) t_wait += __builtin_readcyclecounter() - t_mark;
+      if (m2.cnt) issue(m2, A0, B0);
+      compute(m1, A1, B1);
+      if (!m2.cnt) break;
+      // rotate: (m2 -> multiplying next with A0/B0, m0 -> loads next)
+      m1 = m0; m0 = m2;
+    }
+  }
+  if (a.trace && tid == 0) {   // the trace buffer has 4 records per 64 rows: every workgroup of a <= 2 x 2 split launch
+    const int rec = blockIdx.y * gridDim.x + blockIdx.x;
+    if (rec < 4 * ((a.n_dst + 63) / 64)) {
+      unsigned hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      a.trace[rec * 8 + 0] = hw;
+      a.trace[rec * 8 + 1] = xcc;
+      a.trace[rec * 8 + 2] = t_begin;
+      a.trace[rec * 8 + 3] = __builtin_readcyclecounter();
+      a.trace[rec * 8 + 4] = t_pro;
+      a.trace[rec * 8 + 5] = t_wait;   // clocks wave 0 spent waiting for the prefetched rows and weights
+    }
+  }
+  __syncthreads();
+  // epilogue: wave w stores tile rows 16 w .. 16 w + 15; lane (q, n) holds rows 4 q + reg, columns 4 n + i like an MFMA tile
+  if (wave >= MAXG) return;
+  const int q = lane >> 4, n = lane & 15;
+  f32x4 acc[4];
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float* at = accl + (16 * wave + 4 * q + reg) * LDR + (n >> 2) * 16 + i * 4 + (n & 3);   // column 4 n + i
+      acc[i][reg] = ((at[0] + at[ROWS * LDR]) + at[2 * ROWS * LDR]) + at[3 * ROWS * LDR];
+    }
+  const int wrow0 = row0 + 16 * wave;
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const int row = wrow0 + q * 4 + reg;
+    if (row >= a.n_dst) continue;
+    float4 o = make_float4(acc[0][reg], acc[1][reg], acc[2][reg], acc[3][reg]);
+    if (a.bias) { const float4 b = *reinterpret_cast<const float4*>(a.bias + 4 * n); o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w; }
+    float4* p = reinterpret_cast<float4*>(a.dst + static_cast<long long>(row) * a.ld_dst + 4 * n);
+    if (a.accumulate) { const float4 old = *p; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+    *p = o;
+  }
+  if (a.stats) {
+    float vals[4][4];
+    int cols[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      cols[i] = 4 * n + i;
+      const float b = a.bias ? a.bias[cols[i]] : 0.f;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) vals[i][reg] = acc[i][reg] + b;
+    }
+    tile_stats<4>(a, vals, cols, wrow0);
+  }
+}
+
 // Compacted variant: the workgroup owns TM destination rows whose accumulators live in LDS.  For every kernel
 // offset the rows that actually have a neighbour are compacted (wave64 ballot + prefix) into a list, and only
 // ceil(n_k / 16) MFMA row groups are issued (round-robin over the 4 waves) instead of TM/16 — the MFMA work follows
@@ -1322,14 +1576,41 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ pa
 // dense tile, 2 = compacted tile, 3 = register-staged pipeline.  FV2P_CONV_IMPL=dense|cmp|pipe presets it;
 // fv2p_sparse_conv_set_impl() lets the parity tests run every variant in one process.
 static int g_conv_impl = -1;
+static int g_ksplit_auto = 1;   // FV2P_CONV_KSPLIT=0 keeps the round-1 kernels in auto mode (comparison runs)
+static int g_ksplit_tm = 0;     // FV2P_KSPLIT_TM: rows per tile (32 or 64); 0 = by launch shape
+static size_t g_ksplit_pad = 0; // FV2P_KSPLIT_PAD: extra dynamic LDS bytes per workgroup (limits the workgroups resident on a CU)
 static int g_wgrad_dma = 1;   // pair-split weight gradient: 1 = LDS-DMA kernel where the shapes allow, 0 = register-staged kernel
 static unsigned long long* g_conv_trace = nullptr;
 static int conv_impl() {
   if (g_conv_impl < 0) {
     const char* e = getenv("FV2P_CONV_IMPL");
-    g_conv_impl = (e && e[0] == 'd') ? 1 : (e && e[0] == 'c') ? 2 : (e && e[0] == 'p') ? 3 : 0;
+    g_conv_impl = (e && e[0] == 'd') ? 1 : (e && e[0] == 'c') ? 2 : (e && e[0] == 'p') ? 3 : (e && e[0] == 'k') ? 4 : 0;
+    const char* ks = getenv("FV2P_CONV_KSPLIT");
+    g_ksplit_auto = ks ? atoi(ks) : 1;
+    const char* tm = getenv("FV2P_KSPLIT_TM");
+    g_ksplit_tm = tm ? atoi(tm) : 0;
+    const char* pad = getenv("FV2P_KSPLIT_PAD");
+    g_ksplit_pad = pad ? static_cast<size_t>(atoi(pad)) : 0;
   }
   return g_conv_impl;
+}
+
+static constexpr size_t ksplit_lds(int tm) { return 4 * static_cast<size_t>(tm + 1) * 68 * sizeof(float) + 32 * tm * sizeof(int) + 32 * tm + 32 * sizeof(int); }
+// impl 4 forces the pair-compacted K-split tile wherever its shapes allow.  In auto mode it takes every launch with 64 or 128
+// source channels and whole 64-column blocks (measured against conv_rows_dma, profiles/r02_microbench.txt: 128 -> 128 at
+// 9 919 rows 127 -> 77 us, 64 -> 64 at 22 331 rows 66 -> 54 us, at 141 294 rows 264 -> 232 us), except permuted launches with
+// 64 source channels: there the offset-skipping tile on parity-ordered rows stays ahead (17.9 vs 61 us at 32 -> 64).
+template <int CINP>
+static bool ksplit_wanted(const ConvArgs& a) {
+  const int impl = conv_impl();
+  if (impl == 4) return true;
+  return impl == 0 && g_ksplit_auto && a.kvol > 1 && !(a.perm && CINP == 64);
+}
+// rows per tile: 32 fill a 10 k-row level's launch with twice the workgroups (forward), 64 halve the weight traffic per pair
+template <bool WT>
+static int ksplit_rows(const ConvArgs& a) {
+  if (g_ksplit_tm == 32 || g_ksplit_tm == 64) return g_ksplit_tm;
+  return (!WT && a.n_dst < 65536) ? 32 : 64;
 }
 
 template <int CINP, int NB, bool WT>
@@ -1344,6 +1625,24 @@ static void launch_vec(const ConvArgs& a, hipStream_t s) {
     return;
   }
   const unsigned blocks = static_cast<unsigned>(ceil_div(a.n_dst, 64));
+  if constexpr ((CINP == 64 || CINP == 128) && NB % 4 == 0) {
+    // pair-compacted K-split tile: whole 64-column blocks, whole fragments
+    const bool whole = a.c_src == CINP && a.c_dst == NB * 16 && (a.w_ld & 3) == 0 && (a.w_kstride & 3) == 0 &&
+                       (reinterpret_cast<uintptr_t>(a.w) & 15) == 0 && (a.ld_dst & 3) == 0 &&
+                       (reinterpret_cast<uintptr_t>(a.dst) & 15) == 0 && (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0);
+    if (whole && a.kvol <= 32 && ksplit_wanted<CINP>(a)) {
+      ConvArgs b = a; b.trace = g_conv_trace;
+      if (ksplit_rows<WT>(a) == 32) {
+        const size_t lds = ksplit_lds(32) + g_ksplit_pad;
+        static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_ksplit<CINP, WT, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
+        if (once) { hipLaunchKernelGGL((conv_rows_ksplit<CINP, WT, 32>), dim3(static_cast<unsigned>(ceil_div(a.n_dst, 32)), NB / 4), dim3(256), lds, s, b); return; }
+      } else {
+        const size_t lds = ksplit_lds(64) + g_ksplit_pad;
+        static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_ksplit<CINP, WT, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
+        if (once) { hipLaunchKernelGGL((conv_rows_ksplit<CINP, WT, 64>), dim3(blocks, NB / 4), dim3(256), lds, s, b); return; }
+      }
+    }
+  }
   if constexpr (CINP * NB <= 512 && (WT || NB % 4 == 0)) {
     // LDS-DMA kernel: whole fragments only (every lane's 16-byte source must exist and be aligned)
     const bool whole = a.c_src == CINP && a.c_dst == NB * 16 && (a.w_ld & 3) == 0 && (a.w_kstride & 3) == 0 &&
@@ -1434,7 +1733,7 @@ extern "C" int fv2p_sparse_conv_set_trace(unsigned long long* trace) {
 }
 
 extern "C" int fv2p_sparse_conv_set_impl(int impl) {
-  FV2P_REQUIRE(impl >= 0 && impl <= 3, FV2P_EINVAL, "impl must be 0 (auto), 1 (dense), 2 (compacted) or 3 (pipelined)");
+  FV2P_REQUIRE(impl >= 0 && impl <= 4, FV2P_EINVAL, "impl must be 0 (auto), 1 (dense), 2 (compacted), 3 (pipelined) or 4 (pair-compacted K-split)");
   fv2p::g_conv_impl = impl;
   fv2p::g_wgrad_dma = impl == 0;   // forcing any variant also selects the register-staged pair-split weight gradient
   return 0;

@@ -442,7 +442,9 @@ at::Tensor sparse_conv_bn_relu(const at::Tensor& features, const at::Tensor& wei
 // points_to_voxel_batch(mean_vfe=True): one stream per cloud, one host synchronisation for the voxel counts, then
 // MeanVFE + collate (voxel_mean_collate) -> (features [sum M, ndim], coords [sum M, 4] int32)
 std::vector<at::Tensor> voxelize_batch_mean(const std::vector<at::Tensor>& clouds, std::vector<double> voxel_size, std::vector<double> range_lo,
-                                            std::vector<int64_t> grid, int64_t max_points, int64_t max_voxels) {
+                                            std::vector<int64_t> grid, int64_t max_points, int64_t max_voxels, bool cloud_streams) {
+  // cloud_streams = false keeps every launch on the calling stream: the choice of a caller that is itself a side stream
+  // (streams share a few hardware queues, and a cloud stream that lands in the training stream's queue waits behind it)
   TORCH_CHECK(!clouds.empty() && voxel_size.size() == 3 && range_lo.size() == 3 && grid.size() == 3, "voxelize_batch_mean: bad arguments");
   const at::Tensor& first = clouds[0];
   c10::DeviceGuard guard(first.device());
@@ -470,7 +472,7 @@ std::vector<at::Tensor> voxelize_batch_mean(const std::vector<at::Tensor>& cloud
       evs->second.push_back(e);
     }
   }
-  TORCH_CHECK(hipEventRecord(evs->first, main.stream()) == hipSuccess, "hipEventRecord failed");
+  if (cloud_streams) TORCH_CHECK(hipEventRecord(evs->first, main.stream()) == hipSuccess, "hipEventRecord failed");
   std::vector<at::Tensor> vox(nb), coors(nb), num(nb);
   at::Tensor counts = at::empty({static_cast<int64_t>(nb)}, first.options().dtype(at::kInt));
   for (size_t b = 0; b < nb; ++b) {
@@ -481,19 +483,21 @@ std::vector<at::Tensor> voxelize_batch_mean(const std::vector<at::Tensor>& cloud
     vox[b] = at::empty({max_voxels, max_points, ndim}, pts.options());
     coors[b] = at::empty({max_voxels, 3}, pts.options().dtype(at::kInt));
     num[b] = at::empty({max_voxels}, pts.options().dtype(at::kInt));
-    hipStream_t st = (*pool)[b].stream();
-    TORCH_CHECK(hipStreamWaitEvent(st, evs->first, 0) == hipSuccess, "hipStreamWaitEvent failed");
+    hipStream_t st = cloud_streams ? (*pool)[b].stream() : main.stream();
+    if (cloud_streams) TORCH_CHECK(hipStreamWaitEvent(st, evs->first, 0) == hipSuccess, "hipStreamWaitEvent failed");
     at::Tensor ws;
     {
-      c10::hip::HIPStreamGuard sg((*pool)[b]);
+      c10::hip::HIPStreamGuard sg(cloud_streams ? (*pool)[b] : main);
       ws = workspace(fv2p_points_to_voxel_ws_bytes(n, static_cast<int>(max_voxels)), pts, static_cast<void*>(st));
     }
     check(fv2p_points_to_voxel(pts.data_ptr<float>(), n, static_cast<int>(ndim), vs, lo, gr, static_cast<int>(max_points),
                                static_cast<int>(max_voxels), vox[b].data_ptr<float>(), coors[b].data_ptr<int>(), num[b].data_ptr<int>(),
                                counts.data_ptr<int>() + b, ws.data_ptr(), static_cast<size_t>(ws.numel()), static_cast<void*>(st)),
           "fv2p_points_to_voxel");
-    TORCH_CHECK(hipEventRecord(evs->second[b], st) == hipSuccess, "hipEventRecord failed");
-    TORCH_CHECK(hipStreamWaitEvent(main.stream(), evs->second[b], 0) == hipSuccess, "hipStreamWaitEvent failed");
+    if (cloud_streams) {
+      TORCH_CHECK(hipEventRecord(evs->second[b], st) == hipSuccess, "hipEventRecord failed");
+      TORCH_CHECK(hipStreamWaitEvent(main.stream(), evs->second[b], 0) == hipSuccess, "hipStreamWaitEvent failed");
+    }
   }
   const at::Tensor counts_host = counts.cpu();   // the one synchronisation of the batch
   const int* ch = counts_host.data_ptr<int>();
@@ -597,7 +601,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("gate_weights", &gate_weights, "aliases of the conv weights whose gradients are joined from the side stream at the end of backward");
   m.def("sparse_conv", &sparse_conv, "fused sparse convolution with autograd (tables from a Rulebook)");
   m.def("batch_norm_relu", &batch_norm_relu, "BatchNorm1d (+ReLU) on [N, C] with autograd");
-  m.def("voxelize_batch_mean", &voxelize_batch_mean, py::call_guard<py::gil_scoped_release>(),
+  m.def("voxelize_batch_mean", &voxelize_batch_mean, py::arg("clouds"), py::arg("voxel_size"), py::arg("range_lo"), py::arg("grid"),
+        py::arg("max_points"), py::arg("max_voxels"), py::arg("cloud_streams") = true, py::call_guard<py::gil_scoped_release>(),
         "voxelise a batch of clouds + MeanVFE + collate, without the GIL");
   m.def("build_rulebook_chain", &build_rulebook_chain, py::call_guard<py::gil_scoped_release>(),
         "build a chain of rulebooks (and pair lists) from root coordinates, without the GIL");

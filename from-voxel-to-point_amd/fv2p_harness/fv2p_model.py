@@ -90,6 +90,18 @@ class FV2PWaymoConfig(FV2PConfig):
 
 # ---------------------------------------------------------------- small shared pieces -----------------
 _SIDE_STREAMS = {}
+_CONSTS = {}
+_CORNER_SIGNS = ((1, 1, -1), (1, -1, -1), (-1, -1, -1), (-1, 1, -1), (1, 1, 1), (1, -1, 1), (-1, -1, 1), (-1, 1, 1))
+
+
+def dconst(like, values, dtype=torch.float32):
+    """A small constant as a tensor on `like`'s device, uploaded once per (device, value): `like.new_tensor(list)` and indexing
+    with a Python list both stage a pageable host buffer, and that copy makes the host wait for everything queued on the stream."""
+    key = (like.device, dtype, values)
+    t = _CONSTS.get(key)
+    if t is None:
+        t = _CONSTS[key] = torch.tensor(values, dtype=dtype, device=like.device)
+    return t
 
 
 def side_stream(role, device):
@@ -149,7 +161,7 @@ def smooth_l1(diff, beta):
 
 def box_corners(boxes):
     """(M, 7) -> (M, 8, 3) corner order of box_utils.boxes_to_corners_3d (:28-53)."""
-    t = boxes.new_tensor(((1, 1, -1), (1, -1, -1), (-1, -1, -1), (-1, 1, -1), (1, 1, 1), (1, -1, 1), (-1, -1, 1), (-1, 1, 1))) / 2
+    t = dconst(boxes, _CORNER_SIGNS, boxes.dtype) / 2
     c = boxes[:, None, 3:6] * t[None]
     return rotate_z(c, boxes[:, 6]) + boxes[:, None, 0:3]
 
@@ -158,7 +170,7 @@ def nearest_bev_boxes(b):
     """boxes3d_lidar_to_aligned_bev_boxes (box_utils.py:337-348): (..., 7) -> (..., 4) axis-aligned footprint."""
     rot = limit_period(b[..., 6], 0.5, math.pi).abs()
     swap = (rot >= math.pi / 4).unsqueeze(-1)
-    dims = torch.where(swap, b[..., [4, 3]], b[..., [3, 4]])
+    dims = torch.where(swap, b[..., 3:5].flip(-1), b[..., 3:5])
     return torch.cat((b[..., 0:2] - dims / 2, b[..., 0:2] + dims / 2), dim=-1)
 
 
@@ -323,9 +335,10 @@ class LateralBlock(nn.Module):
     def forward(self, level, bottom, key_xyz, key_cnt):
         cfg = self.cfg
         idx = level.indices
-        vs = idx.new_tensor(cfg.voxel_size, dtype=torch.float32) * self.stride
-        centres = (idx[:, [3, 2, 1]].float() + 0.5) * vs + idx.new_tensor(cfg.point_cloud_range[:3], dtype=torch.float32)
-        vox_cnt = torch.bincount(idx[:, 0].long(), minlength=key_cnt.shape[0]).int()   # rows of a level are grouped by sample
+        vs = dconst(idx, tuple(float(v) * self.stride for v in cfg.voxel_size))
+        centres = (idx[:, 1:4].flip(-1).float() + 0.5) * vs + dconst(idx, tuple(float(v) for v in cfg.point_cloud_range[:3]))
+        # rows of a level are grouped by sample; counted without torch.bincount, which reads the maximum back to the host
+        vox_cnt = (idx[:, 0:1] == torch.arange(key_cnt.shape[0], device=idx.device, dtype=idx.dtype)).sum(0, dtype=torch.int32)
         dist, nn_idx = pn2_stack.three_nn(key_xyz, key_cnt, centres.contiguous(), vox_cnt)
         recip = 1.0 / (dist + 1e-8)
         weight = recip / recip.sum(dim=1, keepdim=True)
@@ -415,13 +428,13 @@ class PointHead(nn.Module):
     def assign(self, key, gt):
         boxes = gt[..., :7].contiguous()
         ext = boxes.clone()
-        ext[..., 3:6] += boxes.new_tensor(self.cfg.gt_extra_width)
+        ext[..., 3:6] += dconst(boxes, tuple(float(v) for v in self.cfg.gt_extra_width), boxes.dtype)
         # zero-padded rows must stay empty boxes after the enlargement
         ext = torch.where((boxes[..., 3:6].abs().sum(-1, keepdim=True) > 0), ext, boxes)
         inside = roiaware_pool3d_utils.points_in_boxes_gpu(key, boxes) >= 0
         near = roiaware_pool3d_utils.points_in_boxes_gpu(key, ext) >= 0
         labels = inside.long()
-        labels[inside ^ near] = -1
+        labels.masked_fill_(inside ^ near, -1)
         return labels.view(-1)
 
     def forward(self, key, feats, gt):
@@ -641,7 +654,7 @@ class IoUGuidedRoIHead(nn.Module):
         g_bev = self.bev_grid_pool_layer({"spatial_features_before_head": bev, "spatial_features_stride": 8}, world.view(b, -1, 3))
         g_bev = g_bev.view(world.shape[0], world.shape[1], -1).permute(0, 2, 1).contiguous()
         # corner geometry stream (feature_adaptor/nn_modules.py:6-60): roi-frame corners without rotation or centre
-        t = s_rois.new_tensor(((1, 1, -1), (1, -1, -1), (-1, -1, -1), (-1, 1, -1), (1, 1, 1), (1, -1, 1), (-1, -1, 1), (-1, 1, 1))) / 2
+        t = dconst(s_rois, _CORNER_SIGNS, s_rois.dtype) / 2
         corners = s_rois.reshape(-1, 7)[:, None, 3:6] * t[None]
         cge = self.cge_inter(self.cge_up(corners.transpose(1, 2).unsqueeze(3).contiguous()).squeeze(-1))
         return dict(rois=rois, s_rois=s_rois, s_gt=s_gt, s_iou=s_iou, gt_ct=gt_ct, local=local, g_bev=g_bev, cge=cge)

@@ -87,6 +87,50 @@ class BatchPrefetcher(object):
             w.thread.join(timeout=5)
 
 
+class BatchAhead(object):
+    """The same hand-over without a thread: prepare(i) enqueues batch i on a side stream from the training thread itself —
+    called between the forward and the backward pass of the step before — and take(i) orders the training stream after it.
+    The preparation's host synchronisations (voxel counts, rulebook sizes) then wait for the side stream only, whose work is
+    a few hundred microseconds, instead of for everything the training stream still has queued: the host can run a whole
+    step ahead of the device.  Pays when the step is device bound; a thread pays when it is launch bound."""
+
+    def __init__(self, produce, device, priority=0):
+        self.produce, self.device = produce, device
+        self.stream = torch.cuda.Stream(device=device, priority=priority)
+        self.ready = {}       # i -> (batch, event on the side stream)
+        self.current = None   # batch handed out by the last take()
+        self.retired = []     # (batch, event on the training stream after which nothing touches it, step that recorded it)
+
+    def prepare(self, i):
+        if i in self.ready:
+            return
+        # blocks of a finished batch return to the side stream's pool in stream order (see _Worker._run).  Only batches retired
+        # a full step ago are let go here: the side stream must not wait for an event the device has yet to reach, or the
+        # preparation's host synchronisations would wait for the training stream after all.
+        while self.retired and self.retired[0][2] <= i - 2:
+            old, ev, _ = self.retired.pop(0)
+            self.stream.wait_event(ev)
+            del old
+        with torch.cuda.stream(self.stream):
+            out = self.produce(i)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.ready[i] = (out, ev)
+
+    def take(self, i):
+        """Batch i (prepared now if prepare(i) was not called).  Contract as BatchPrefetcher.get: use it until the next take()."""
+        self.prepare(i)
+        out, ev = self.ready.pop(i)
+        main = torch.cuda.current_stream(self.device)
+        if self.current is not None:
+            done = torch.cuda.Event()
+            done.record(main)
+            self.retired.append((self.current, done, i))
+        main.wait_event(ev)
+        self.current = out
+        return out
+
+
 def _walk(obj, fn, seen=None):
     """Applies fn to every CUDA tensor reachable from obj (containers, object attributes, attached rulebooks)."""
     seen = set() if seen is None else seen

@@ -71,7 +71,7 @@ def _launch(points, voxel_size, coors_range, grid, max_points, max_voxels):
     return voxels, coors, num, count
 
 
-def points_to_voxel_batch(points_list, voxel_size, coors_range, max_points=35, max_voxels=20000, mean_vfe=False):
+def points_to_voxel_batch(points_list, voxel_size, coors_range, max_points=35, max_voxels=20000, mean_vfe=False, cloud_streams=True):
     """Voxelises the clouds of one batch concurrently — one HIP stream per cloud, a single host sync for all voxel
     counts — and returns the collated batch the models consume (dataset.collate_batch, pcdet/datasets/dataset.py:152-183):
     voxels [sum M, max_points, ndim], coords [sum M, 4] (batch, z, y, x) int32, num_points [sum M] int32.
@@ -87,7 +87,7 @@ def points_to_voxel_batch(points_list, voxel_size, coors_range, max_points=35, m
         # without the interpreter lock: an input-pipeline thread then barely competes with the training thread for it
         with _nat.device_guard(dev):
             feats, coords = ext.voxelize_batch_mean(list(points_list), [float(v) for v in voxel_size], [float(v) for v in coors_range[:3]],
-                                                    [int(g) for g in grid], int(max_points), int(max_voxels))
+                                                    [int(g) for g in grid], int(max_points), int(max_voxels), bool(cloud_streams))
         return feats, coords
     main = torch.cuda.current_stream(dev)
     pool = _STREAMS.setdefault((dev.index, main.cuda_stream), [])   # per calling stream: concurrent pipeline threads never share

@@ -10,7 +10,12 @@ def _enlarged(boxes3d, extra):
     """A list widens every side by a fixed amount (box_utils.enlarge_box3d); a scalar scales the sides (expand_box3d)."""
     big = boxes3d.clone()
     if isinstance(extra, (list, tuple)):
-        big[..., 3:6] += boxes3d.new_tensor(extra)
+        # Python scalars become kernel arguments; a tensor built from the list would be a blocking host-to-device copy
+        if len(set(extra)) == 1:
+            big[..., 3:6] += extra[0]
+        else:
+            for axis, e in enumerate(extra):
+                big[..., 3 + axis] += e
     else:
         big[..., 3:6] += boxes3d[..., 3:6] * extra
     return big

@@ -54,7 +54,7 @@ def test_subm_conv_forward_backward_vs_oracle(gpu, front_end, cin, cout):
     assert rel_err(x.features.grad.cpu().numpy(), din.numpy()) < RTOL
     assert rel_err(conv.weight.grad.cpu().numpy(), dw.numpy()) < RTOL
 
-@pytest.mark.parametrize("impl", [1, 2, 3])
+@pytest.mark.parametrize("impl", [1, 2, 3, 4])
 def test_conv_kernel_variants_agree_with_oracle(gpu, impl):
     """Every kernel variant behind fv2p_sparse_conv_rows (plain dense tile / compacted / register-staged pipeline;
     the default heuristic = LDS-DMA tile is what all other tests run) gives the oracle's features and input gradient,
@@ -445,7 +445,7 @@ def test_deferred_weight_gradient_join_gives_the_same_gradients(gpu):
                 assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("impl", [0, 1, 2, 3])
+@pytest.mark.parametrize("impl", [0, 1, 2, 3, 4])
 def test_conv_epilogue_statistics_equal_the_column_sums(gpu, impl):
     """fv2p_sparse_conv_rows_stats (C ABI): dst is bit-identical to fv2p_sparse_conv_rows and the slots of `stats` add up to
     the fp64 column sums / sums of squares of dst — for every kernel variant, with and without a bias, rows not a multiple
@@ -538,13 +538,23 @@ def test_batchnorm_sums_from_conv_epilogues_match_the_separate_passes(gpu):
             assert err < 1e-5, (it, j, tuple(a.shape), err)
 
 
-def test_backward_data_conv_leaves_the_batchnorm_backward_sums(gpu):
+@pytest.mark.parametrize("impl", [0, 4])
+def test_backward_data_conv_leaves_the_batchnorm_backward_sums(gpu, impl):
     """fv2p_sparse_conv_rows_bnbwd (C ABI): dst equals the plain backward-data conv bit for bit; the slots add up to
     sum dz and sum dz * xhat (dz = dst * [y > 0]) computed in float64 from the same fp32 xhat — in the epilogue
-    (c_src <= 128) and by the pass after the conv (c_src = 160)."""
+    (c_src <= 128) and by the pass after the conv (c_src = 160); on the default kernels and on the pair-compacted tile."""
     import fv2p_native
     slots = int(fv2p_native.lib().fv2p_sparse_conv_stat_slots())
     batch, shape = 2, [9, 20, 18]
+    fv2p_native.call("fv2p_sparse_conv_set_impl", impl)
+    try:
+        _bnbwd_cases(gpu, slots, batch, shape)
+    finally:
+        fv2p_native.call("fv2p_sparse_conv_set_impl", 0)
+
+
+def _bnbwd_cases(gpu, slots, batch, shape):
+    import fv2p_native
     for cin, cout in [(16, 32), (64, 64), (128, 128), (64, 128), (32, 160), (160, 64), (24, 40)]:     # conv cin -> cout; its dX has c_src = cout, c_dst = cin
         ind, feats, x = make_input(cin * 3 + cout, batch, shape, 1100, cin, gpu)
         rb = ops.build_rulebook(x.indices, batch, shape, 3, 1, 1, 1, 0, True)
@@ -576,7 +586,9 @@ def test_backward_data_conv_leaves_the_batchnorm_backward_sums(gpu):
 def test_backward_data_of_strided_conv_with_parity_ordered_tiles(gpu):
     """fv2p_rulebook_class_perm + fv2p_sparse_conv_rows_perm / _bnbwd(perm): the permutation is a stable grouping of
     the input rows by (coordinate + padding) mod stride, and the backward-data conv that takes it (tiles visit only the
-    offsets their rows use) returns bit-identical rows and the same BatchNorm sums as the launch in plain row order."""
+    offsets their rows use) returns the rows and the BatchNorm sums of the launch in plain row order — bit-identical where
+    both launches run the same kernel family; with 64 source channels and whole 64-column blocks the plain launch is the
+    pair-compacted K-split tile and the permuted one the offset-skipping tile: two fixed summation orders, 2e-6 apart."""
     import fv2p_native
     slots = int(fv2p_native.lib().fv2p_sparse_conv_stat_slots())
     batch, shape = 2, [11, 40, 36]
@@ -601,7 +613,9 @@ def test_backward_data_of_strided_conv_with_parity_ordered_tiles(gpu):
         fv2p_native.call("fv2p_sparse_conv_rows", g, n_out, cout, w, kvol, tab, n, cin, int(flip), 1, None, ref, fv2p_native.stream())
         dst = torch.empty_like(ref)
         fv2p_native.call("fv2p_sparse_conv_rows_perm", g, n_out, cout, w, kvol, tab, n, cin, int(flip), 1, None, dst, perm, fv2p_native.stream())
-        assert torch.equal(dst, ref), (cin, cout, stride)
+        mixed = cout == 64 and cin % 64 == 0
+        close = lambda a, b: float((a - b).abs().max() / b.abs().max()) < 2e-6
+        assert close(dst, ref) if mixed else torch.equal(dst, ref), (cin, cout, stride)
         bn_x = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32) * 2 + 1).to(gpu)
         par = [torch.from_numpy(rng.uniform(0.3, 1.5, cin).astype(np.float32)).to(gpu) for _ in range(4)]
         outs = []
@@ -610,6 +624,6 @@ def test_backward_data_of_strided_conv_with_parity_ordered_tiles(gpu):
             stats = torch.zeros((slots, 2, cin), dtype=torch.float64, device=gpu)
             fv2p_native.call("fv2p_sparse_conv_rows_bnbwd", g, n_out, cout, w, kvol, tab, n, cin, int(flip), 1, dst, bn_x, par[0], par[1], par[2], par[3], 1,
                              stats, p, fv2p_native.stream())
-            assert torch.equal(dst, ref)
+            assert close(dst, ref) if (mixed and p is not None) else torch.equal(dst, ref)
             outs.append(stats.sum(0).cpu().numpy())
-        assert np.allclose(outs[0], outs[1], rtol=1e-11, atol=1e-9)
+        assert np.allclose(outs[0], outs[1], rtol=1e-5 if mixed else 1e-11, atol=1e-3 if mixed else 1e-9)

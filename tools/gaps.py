@@ -10,7 +10,7 @@ import sys
 from collections import defaultdict
 
 path = sys.argv[1]
-marker = sys.argv[2] if len(sys.argv) > 2 else "fps_"
+marker = sys.argv[2] if len(sys.argv) > 2 else "fps_bbox_k"
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 25
 rows = []
 with open(path) as f:
@@ -60,3 +60,26 @@ for lo, hi in steps:
     for s, e, name, q in rows[lo:hi]:
         per[q] += e - s
 print("kernel time per stream/queue (ms/step):", {k: round(v / n / 1e6, 3) for k, v in per.items()})
+# the busiest stream's own idle time: what it waits for (another stream's kernel running meanwhile, or nothing = the host)
+main_q = max(per, key=per.get)
+wait = defaultdict(lambda: [0.0, 0])
+for lo, hi in steps:
+    seg = rows[lo:hi]
+    mine = [r for r in seg if r[3] == main_q]
+    others = [r for r in seg if r[3] != main_q]
+    for a, b in zip(mine, mine[1:]):
+        g0, g1 = a[1], b[0]
+        if g1 - g0 < 2000:
+            continue
+        cover, who = 0, "(no kernel on any stream: host)"
+        for s_, e_, name, q in others:
+            ov = min(e_, g1) - max(s_, g0)
+            if ov > cover:
+                cover, who = ov, name[:60]
+        key = (who if cover > 0.5 * (g1 - g0) else "(no kernel on any stream: host)", b[2][:60])
+        wait[key][0] += g1 - g0
+        wait[key][1] += 1
+tot = sum(v[0] for v in wait.values())
+print(f"stream {main_q}: idle {tot / n / 1e6:.3f} ms/step in gaps >= 2 us;  ms/step  count/step  running elsewhere -> next kernel on this stream")
+for (who, nxt), (g, c) in sorted(wait.items(), key=lambda kv: -kv[1][0])[:top]:
+    print(f"  {g / n / 1e6:7.3f}  {c / n:6.1f}   {who}  ->  {nxt}")

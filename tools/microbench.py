@@ -131,12 +131,27 @@ def conv(only=None):
             import collections
             import fv2p_native
             nblk = (n_out + 63) // 64
-            tr = torch.zeros(nblk * 8, dtype=torch.int64, device="cuda")
+            tr = torch.zeros(4 * nblk * 8, dtype=torch.int64, device="cuda")   # the K-split tile records up to 4 workgroups per 64 rows
             fv2p_native.call("fv2p_sparse_conv_set_trace", tr)
             ops.indice_conv(f, w, rb, None, n_out, False, mod.subm)
             torch.cuda.synchronize()
             fv2p_native.call("fv2p_sparse_conv_set_trace", None)
-            tr = tr.cpu().numpy().reshape(nblk, 8)
+            full = tr.cpu().numpy().reshape(4 * nblk, 8)
+            live = full[full[:, 2] > 0]
+            if len(live) > nblk:   # every workgroup of a split launch: placement and timeline
+                key = list(zip((live[:, 1] & 0xF).tolist(), ((live[:, 0] >> 13) & 7).tolist(), ((live[:, 0] >> 12) & 1).tolist(), ((live[:, 0] >> 8) & 0xF).tolist()))
+                per_cu = collections.Counter(key)
+                d = (live[:, 3] - live[:, 2]).astype(float)
+                t_first, t_last = live[:, 2].min(), live[:, 3].max()
+                busy = collections.defaultdict(float)
+                for kk, dd in zip(key, d):
+                    busy[kk] += dd
+                print(f"all workgroups: {len(live)} on {len(per_cu)} CUs, workgroups/CU histogram {sorted(collections.Counter(per_cu.values()).items())}; "
+                      f"span {t_last - t_first} clocks; workgroup clocks: median {np.median(d):.0f} max {d.max():.0f} sum/256 CUs {d.sum() / 256:.0f}; "
+                      f"last start {live[:, 2].max() - t_first}; wait clocks median {np.median(live[:, 5]):.0f}")
+                ends = np.sort(live[:, 3] - t_first)
+                print("  workgroups still running at 25/50/75/90 % of the span:", [int((ends > q * (t_last - t_first)).sum()) for q in (0.25, 0.5, 0.75, 0.9)])
+            tr = full[:nblk]
             hw, xcc, t0, t1 = tr[:, 0], tr[:, 1] & 0xF, tr[:, 2], tr[:, 3]
             cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
             place = collections.Counter(zip(xcc.tolist(), se.tolist(), sh.tolist(), cu.tolist()))
