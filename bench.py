@@ -56,6 +56,8 @@ def parse():
                     help="input-pipeline thread prepares batch t+1 while batch t trains: 2 = voxelisation + rulebooks, 1 = voxelisation, 0 = all in line")
     ap.add_argument("--ahead", type=int, default=0,
                     help="no thread: batch t+1 is prepared on a side stream between forward and backward of step t (2 = voxelisation + rulebooks, 1 = voxelisation); FV2P workloads default to 2")
+    ap.add_argument("--watchdog", type=int, default=900, help="seconds the measurement may take before it is stopped and repeated in line (0: run in this process, no limit)")
+    ap.add_argument("--fps-ahead", type=int, default=1, help="FV2P workloads: key points of batch t+1 are sampled (FPS side stream) during the backward pass of step t")
     ap.add_argument("--ahead-priority", type=int, default=-1, help="stream priority of the --ahead side stream (-1 = high: a hardware queue of its own)")
     ap.add_argument("--cloud-streams", type=int, default=1, help="voxelise the clouds of a batch on one stream each (FV2P workloads)")
     ap.add_argument("--pair-lists", type=int, default=1, help="prefetch also materialises the reference-format pair lists (pair-split weight gradient)")
@@ -90,24 +92,59 @@ def parse():
         args.steps, args.warmup = 30, (args.warmup if "--warmup" in sys.argv else 5)
     if args.workload == "fv2p" and "--prefetch" not in sys.argv:
         args.prefetch = 0   # measured: the input-pipeline thread does not pay here (65.3 vs 63.7 ms per step); the step is not launch bound
-    if args.workload in ("fv2p", "fv2p-waymo") and "--ahead" not in sys.argv and not args.prefetch:
-        args.ahead = 2
+    # --ahead 2 measured no better than in line once the blocking host copies were gone (42.4 vs 41.2 ms per step): off by default
     if args.steps == 300 and args.workload == "fv2p" and "--steps" not in sys.argv:
         args.steps, args.warmup = 40, (args.warmup if "--warmup" in sys.argv else 5)
     return args
 
 
+SAFE_FLAGS = ["--fps-ahead", "0", "--ahead", "0", "--prefetch", "0"]   # every side-stream input pipeline off: the plain in-line step
+
+
 def launch_ranks(args):
-    """`python bench.py --gpus N` outside a launcher: start the N ranks as a child process tree and relay its exit code.
-    This process has not initialised the GPU (no torch.cuda call yet) and it spawns, never execs."""
+    """`python bench.py [--gpus N]` outside a launcher: run the measurement as a child process tree (N ranks under
+    torch.distributed.run, or one plain process), relay its exit code.  This process has not initialised the GPU (no torch.cuda
+    call yet) and it spawns, never execs.  The child runs under a time limit (--watchdog seconds): a step that overlaps four
+    streams can in principle hang the device queue (one arrangement tried this round did), and a hung benchmark
+    reports nothing — on a timeout the tree is killed and the measurement repeated once with the side-stream pipelines off."""
+    import signal
     import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd).returncode
+    env = dict(os.environ, FV2P_BENCH_INNER="1")
+    attempts = [[]] + ([SAFE_FLAGS] if args.workload in ("fv2p", "fv2p-waymo") and args.watchdog > 0 else [])
+    rc = 1
+    for extra in attempts:
+        if args.gpus > 1:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+                   "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:] + extra
+        else:
+            cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + extra
+        child = subprocess.Popen(cmd, env=env, start_new_session=True)
+        try:
+            return child.wait(timeout=args.watchdog if args.watchdog > 0 else None)
+        except subprocess.TimeoutExpired:
+            print(f"[bench] no result after {args.watchdog} s: stopping the run" + ("" if extra else " and repeating it with " + " ".join(SAFE_FLAGS)), file=sys.stderr)
+            # the tree this call created, nothing else: the launcher's workers may sit in sessions of their own
+            try:
+                import psutil
+                tree = psutil.Process(child.pid).children(recursive=True)
+            except Exception:
+                tree = []
+            for proc in tree:
+                try:
+                    proc.kill()
+                except Exception:
+                    pass
+            try:
+                os.killpg(child.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            child.wait()
+            rc = 124
+    return rc
 
 
 def build_step(args, device, rank, world):
@@ -286,6 +323,8 @@ def build_fv2p_step(args, device, rank, world):
         else:
             ahead = BatchAhead(produce, device, priority=args.ahead_priority)
 
+    key_jobs = {}
+
     def step(i):
         clouds, gt = pool[i % n_pool]
         if ahead is not None:
@@ -300,9 +339,13 @@ def build_fv2p_step(args, device, rank, world):
                 step.next_submit += 1
             feats, coords = pre.get()
         u = torch.rand(len(clouds), n_uniform, device=device)
-        loss = net(clouds, feats, coords, gt, u)
+        loss = net(clouds, feats, coords, gt, u, key_job=key_jobs.pop(i, None))
         if ahead is not None:
             ahead.prepare(i + 1)   # between forward and backward: its host waits see the side stream only
+        if args.fps_ahead:
+            # the key points of the next batch need its raw points only: sampled on the FPS stream during this step's backward pass
+            key_jobs.clear()
+            key_jobs[i + 1] = model.post_pfe.start_sampling(pool[(i + 1) % n_pool][0])
         opt.zero_grad(set_to_none=True)
         loss.backward()
         torch.nn.utils.clip_grad_norm_(params, cfg.grad_norm_clip, foreach=True)   # GRAD_NORM_CLIP (train_utils.py:43)
@@ -445,8 +488,11 @@ def cpu_baseline_fv2p(model, args):
                       f"IoU / pools, torch-CPU dense layers ({cores} threads), {dt:.1f} s"}
 
 
-def conv_kernel_name(cin, cout):
+def conv_kernel_name(cin, cout, n_dst=0):
     """The variant csrc/sparse_conv.hip dispatches for a whole-fragment forward conv of these channel counts (launch_vec)."""
+    if cin in (64, 128) and cout % 64 == 0 and cout <= 128 and os.environ.get("FV2P_CONV_KSPLIT", "1") != "0":
+        halves = ", two column halves per launch" if cout == 128 else ""
+        return f"conv_rows_ksplit<{cin},false,{32 if n_dst < 65536 else 64}>{halves} (fv2p_sparse_conv_rows)"
     cinp = 16 if cin <= 16 else 32 if cin <= 32 else 64 if cin <= 64 else 128
     nb = (cout + 15) // 16
     nbp = 1 if nb <= 1 else 2 if nb <= 2 else 4 if nb <= 4 else 8
@@ -520,7 +566,7 @@ def roofline_probe(model, voxelize, pool, args, device):
     except (OSError, KeyError, ValueError):
         pass
     return {"bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "traffic": traffic,
-            "kernel": conv_kernel_name(cin, cout),
+            "kernel": conv_kernel_name(cin, cout, rec["n_out"]),
             "layer": layer,
             "avg_kernel_us": round(dur_s * 1e6, 2), "alg_flops": flops, "alg_bytes": bytes_alg}
 
@@ -603,8 +649,10 @@ def pin_cores(local, n_local, cores):
 
 def main():
     args = parse()
-    if args.gpus > 1 and "RANK" not in os.environ:
+    if "RANK" not in os.environ and "FV2P_BENCH_INNER" not in os.environ and (args.gpus > 1 or (args.watchdog > 0 and not args.dry_run)):
         sys.exit(launch_ranks(args))
+    if os.environ.get("FV2P_BENCH_TEST_HANG") and args.fps_ahead:   # test hook of the watchdog (tests/test_dist_cpu.py)
+        time.sleep(10 ** 6)
     from fv2p_harness import dist_utils
     rank, world, local = dist_utils.env_world()
     assert world == args.gpus, f"--gpus {args.gpus} but the launcher started {world} ranks"
@@ -716,6 +764,8 @@ def main():
                                            2: "thread voxelises batch t+1 and builds its rulebooks during step t",
                                            3: "DIAGNOSTIC: prepared batches reused, not a benchmark configuration"}[min(args.prefetch, 3)])},
         }
+        if args.workload in ("fv2p", "fv2p-waymo") and args.fps_ahead:
+            result["config"]["input_pipeline"] += "; key points (FPS) of batch t+1 sampled on a side stream during the backward pass of step t"
         if args.workload == "fv2p-waymo":
             result["metric"] = "point clouds/sec fwd+bwd (FV2P, Waymo shape: 180k points, 0.1 m voxels)"
             if not args.no_roofline:

@@ -18,6 +18,7 @@ boxes that can match nothing.  Random sampling consumes uniforms drawn from one 
 code (tests: oracle-backed ops) sees the same draws.
 """
 import math
+import os
 from functools import partial
 
 import numpy as np
@@ -727,14 +728,19 @@ class FV2PDetector(nn.Module):
         self.roi_head = IoUGuidedRoIHead(cfg)
         self.taps = None    # set to a dict to collect intermediate results (parity tests)
 
-    def forward(self, clouds, voxel_features, voxel_coords, gt_boxes, uniforms):
+    def forward(self, clouds, voxel_features, voxel_coords, gt_boxes, uniforms, key_job=None):
         """clouds: list of (N_b, 4) point tensors; voxel_features / voxel_coords: MeanVFE output + (b, z, y, x) coords of
-        the same clouds; gt_boxes (B, G, 8) zero padded; uniforms (B, nms_post + roi_per_image) in [0, 1)."""
+        the same clouds; gt_boxes (B, G, 8) zero padded; uniforms (B, nms_post + roi_per_image) in [0, 1).
+        key_job: handle of post_pfe.start_sampling(clouds) when the caller has enqueued the key-point sampling of this batch
+        already (it needs the raw points only, so an input pipeline can run it during the step before)."""
         b = len(clouds)
         # key-point sampling needs the raw points only: it runs beside the two backbones on its own stream (three workgroups
         # for 16 k dependent rounds) and is joined where the decoder starts
-        key_job = self.post_pfe.start_sampling(clouds)
+        if key_job is None:
+            key_job = self.post_pfe.start_sampling(clouds)
         out, levels = self.backbone_3d(voxel_features, voxel_coords, b)
+        # (starting the point branch here, beside the BEV layers, hung the device in one run of two — measured, cause not found;
+        # it starts after the RoI head's preparation instead)
         dense = out.dense()                                                      # HeightCompression (height_compression.py:10-26)
         spatial = dense.view(b, dense.shape[1] * dense.shape[2], dense.shape[3], dense.shape[4])
         if getattr(self, "bev_channels_last", False):
@@ -742,15 +748,15 @@ class FV2PDetector(nn.Module):
         bev = self.backbone_2d(spatial)
         loss_rpn, prop_scores, prop_boxes = self.dense_head(bev, gt_boxes)
         prep = self.roi_head.prepare(bev, prop_scores, prop_boxes, gt_boxes, uniforms)   # still no key points needed
-        key, point_feats, loss_point, point_scores = self.point_branch(clouds, levels, key_job, gt_boxes)
+        branch = self.point_branch_start(clouds, levels, key_job, gt_boxes)
+        key, point_feats, loss_point, point_scores = self.point_branch_join(branch)
         loss_rcnn, aux = self.roi_head.finish(key, point_feats, point_scores, prep)
         if self.taps is not None:
             self.taps.update(keypoints=key, point_features=point_feats, point_scores=point_scores, bev=bev, prop_boxes=prop_boxes,
                              prop_scores=prop_scores, loss_rpn=loss_rpn, loss_point=loss_point, loss_rcnn=loss_rcnn, **aux)
         return loss_rpn + loss_point + loss_rcnn
 
-
-    def point_branch(self, clouds, levels, key_job, gt_boxes):
+    def point_branch_start(self, clouds, levels, key_job, gt_boxes):
         """Decoder + point head.  Their only gradient is the point loss (the RoI head pools the point features under no_grad), so
         in backward this chain of ~150 small kernels is independent of the BEV / anchor / RoI chain until both reach the sparse
         backbone.  Run on its own stream in the forward pass, autograd replays it on that stream in the backward pass, beside the
@@ -758,18 +764,23 @@ class FV2PDetector(nn.Module):
         if not (self.cfg.point_branch_stream and clouds[0].is_cuda and key_job is not None):
             key, feats = self.post_pfe(clouds, levels, key_job)
             loss, scores = self.point_head(key, feats, gt_boxes)
-            return key, feats, loss, scores
+            return (key, feats, loss, scores), None
         dev = clouds[0].device
         side = side_stream("point", dev)
-        main = torch.cuda.current_stream(dev)
-        side.wait_stream(main)
+        side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             key, feats = self.post_pfe(clouds, levels, key_job)
             loss, scores = self.point_head(key, feats, gt_boxes)
-        main.wait_stream(side)
-        for t in (key, feats, loss, scores):
-            t.record_stream(main)
-        return key, feats, loss, scores
+        return (key, feats, loss, scores), side
+
+    def point_branch_join(self, branch):
+        outs, side = branch
+        if side is not None:
+            main = torch.cuda.current_stream(outs[0].device)
+            main.wait_stream(side)
+            for t in outs:
+                t.record_stream(main)
+        return outs
 
 
 def pad_gt_boxes(box_lists, device, max_gt=None):

@@ -112,3 +112,19 @@ def test_bench_launches_its_own_ranks():
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     assert json.loads(line)["n_gpus"] == 2
+
+
+def test_bench_watchdog_repeats_a_hung_run_in_line():
+    """A measurement that produces nothing within --watchdog seconds is stopped (its own process group) and repeated once with
+    the side-stream input pipelines off; FV2P_BENCH_TEST_HANG makes the first attempt sleep forever."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "FV2P_BENCH_INNER")}
+    env["FV2P_BENCH_TEST_HANG"] = "1"
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    out = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-run", "--watchdog", "20"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "repeating it with --fps-ahead 0" in out.stderr
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    assert json.loads(line)["n_gpus"] == 2

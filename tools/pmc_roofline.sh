@@ -20,7 +20,7 @@ for line in open("gpurun_out/pmc_FETCH_SIZE.log"):
         layer = line.strip()
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob(f"gpurun_out/pmc_{c}/*counter_collection.csv"):
-        rows = [r for r in csv.DictReader(open(f)) if "conv_rows_dma" in r["Kernel_Name"] and "false>" in r["Kernel_Name"] and r["Counter_Name"] == c]
+        rows = [r for r in csv.DictReader(open(f)) if ("conv_rows_ksplit" in r["Kernel_Name"] or "conv_rows_dma" in r["Kernel_Name"]) and "false" in r["Kernel_Name"] and r["Counter_Name"] == c]
         if not rows:
             continue
         # the timed launch repeats: take the kernel / grid with the most dispatches
