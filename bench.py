@@ -92,6 +92,8 @@ def parse():
         args.steps, args.warmup = 30, (args.warmup if "--warmup" in sys.argv else 5)
     if args.workload == "fv2p" and "--prefetch" not in sys.argv:
         args.prefetch = 0   # measured: the input-pipeline thread does not pay here (65.3 vs 63.7 ms per step); the step is not launch bound
+    if args.workload == "fv2p-waymo" and "--fps-ahead" not in sys.argv:
+        args.fps_ahead = 0   # measured: the 34 ms sampler of the 180 k-point clouds outlasts the backward pass it would hide behind (68.7 vs 64.8 ms)
     # --ahead 2 measured no better than in line once the blocking host copies were gone (42.4 vs 41.2 ms per step): off by default
     if args.steps == 300 and args.workload == "fv2p" and "--steps" not in sys.argv:
         args.steps, args.warmup = 40, (args.warmup if "--warmup" in sys.argv else 5)
