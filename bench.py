@@ -384,6 +384,31 @@ def build_fv2p_step(args, device, rank, world):
         u = torch.rand(len(clouds), n_uniform, device=device)
         m = model
         st = {}
+        wrapped = []
+        if args.phase_kernels:   # second level: the RoI / anchor / point heads by method (each its own profiler session)
+            outer = phase
+
+            def wrap(obj, name, label):
+                fn = getattr(obj, name)
+                wrapped.append((obj, name, name in vars(obj)))
+                def call(*a, **k):
+                    if st.get("in_session"):   # a wrapped method calling another one: counted with the caller
+                        return fn(*a, **k)
+                    st["in_session"] = True
+                    try:
+                        return outer(label, lambda: fn(*a, **k))
+                    finally:
+                        st["in_session"] = False
+                setattr(obj, name, call)
+            for name in ("proposals", "sample_targets", "canonical_targets", "pool_points", "grid_points", "finish", "losses"):
+                wrap(m.roi_head, name, "  roi." + name)
+            wrap(m.dense_head, "assign", "  anchor.assign")
+            wrap(m.point_head, "assign", "  point.assign")
+
+            def phase(name, fn):   # the enclosing phases must not open a session around the wrapped methods
+                if name in ("roi_head", "bev+anchor_head", "point_head"):
+                    return fn()
+                return outer(name, fn)
 
         def fwd_3d():
             st["out"], st["levels"] = m.backbone_3d(feats, coords, len(clouds))
@@ -410,6 +435,11 @@ def build_fv2p_step(args, device, rank, world):
         opt.zero_grad(set_to_none=True)
         phase("backward", lambda: loss.backward())
         phase("clip+optimizer", lambda: (torch.nn.utils.clip_grad_norm_(params, cfg.grad_norm_clip, foreach=True), opt.step()))
+        for obj, name, own in wrapped:
+            if own:
+                setattr(obj, name, getattr(obj, name))
+            else:
+                obj.__dict__.pop(name, None)
 
     def close():
         if pre is not None:

@@ -35,6 +35,8 @@ from pcdet.ops.roiaware_pool3d import roiaware_pool3d_utils
 from pcdet.ops.roipoint_pool3d import roipoint_pool3d_utils
 from pcdet.models.backbones_3d.pfe import bev_grid_pooling
 
+import fv2p_native as _nat
+
 from .backbone import VoxelResBackBone8x, bn_act
 
 TWO_PI = 2.0 * math.pi
@@ -568,6 +570,24 @@ class IoUGuidedRoIHead(nn.Module):
         b, r, _ = rois.shape
         n = cfg.roi_per_image
         iou = torch.stack([iou3d_nms_utils.boxes_iou3d_gpu(rois[i], gt[i, :, :7].contiguous()) for i in range(b)])   # (B, R, G)
+        if rois.is_cuda and r <= 1024:
+            # one launch for the batch (csrc/targets.hip); the tensor formulation below is its statement in torch ops and what a
+            # CPU run takes (tests/test_fv2p_step_gpu.py compares the two bit for bit)
+            rois, gt, uniforms = rois.contiguous(), gt.contiguous(), uniforms.contiguous().float()
+            s_rois, s_gt = rois.new_empty(b, n, 7), gt.new_empty(b, n, gt.shape[-1])
+            s_iou, s_index = rois.new_empty(b, n), torch.empty((b, n), dtype=torch.int32, device=rois.device)
+            with _nat.device_guard(rois.device):
+                _nat.call("fv2p_roi_sample_targets", iou.contiguous(), rois, gt, uniforms, b, r, gt.shape[1], n, gt.shape[-1],
+                          float(min(cfg.reg_fg, cfg.cls_fg)), float(cfg.cls_bg_lo), float(cfg.reg_fg), int(round(cfg.fg_ratio * n)),
+                          float(cfg.hard_bg_ratio), s_rois, s_gt, s_iou, s_index, _nat.stream())
+            return s_rois, s_gt, s_iou
+        return self.sample_targets_tensor_ops(iou, rois, gt, uniforms)
+
+    @torch.no_grad()
+    def sample_targets_tensor_ops(self, iou, rois, gt, uniforms):
+        cfg = self.cfg
+        b, r, _ = rois.shape
+        n = cfg.roi_per_image
         max_ov, assign = iou.max(dim=2)
         fg = max_ov >= min(cfg.reg_fg, cfg.cls_fg)
         easy = max_ov < cfg.cls_bg_lo

@@ -254,6 +254,19 @@ int fv2p_nms_batch(const float* boxes, int batch, int n, float thresh, int norma
                    int keep_stride, int* num_keep, void* ws, size_t ws_bytes, fv2p_stream_t stream);
 int fv2p_boxes_iou_bev_cpu(const float* boxes_a, int num_a, const float* boxes_b, int num_b, float* ans_iou);
 
+/* ---- (f).4: second-stage target sampling --------------------------------------------------------
+ * Replaces ProposalTargetLayer.sample_rois_for_rcnn / subsample_rois
+ * (pcdet/models/roi_heads/target_assigner/proposal_target_layer.py:92-217; thresholds of ROI_HEAD.TARGET_CONFIG) for a whole
+ * batch in one launch, without nonzero() / .item() round trips.  iou (B,R,G): 3-D IoU of every RoI with every (zero padded)
+ * ground-truth box; rois (B,R,7); gt (B,G,gt_w); uniforms (B,R+n) in [0,1): the first R order the foreground set (random
+ * permutation), the last n pick with replacement.  Per sample: best box per RoI (first maximum), foreground = overlap >=
+ * fg_thresh, hard background = [bg_lo, reg_fg), easy = < bg_lo; min(foreground, fg_quota) foreground RoIs in permuted order
+ * (all n picked with replacement when there is no background), the rest hard (floor(rest * hard_ratio), capped) then easy
+ * background, with replacement.  Outputs s_rois (B,n,7), s_gt (B,n,gt_w), s_iou (B,n), s_index (B,n) i32. */
+int fv2p_roi_sample_targets(const float* iou, const float* rois, const float* gt, const float* uniforms, int batch, int r, int g, int n,
+                            int gt_w, float fg_thresh, float bg_lo, float reg_fg, int fg_quota, float hard_ratio, float* s_rois,
+                            float* s_gt, float* s_iou, int* s_index, fv2p_stream_t stream);
+
 /* ---- A15 / A18: point-in-box, RoI-aware voxel pooling, RoI point pooling ------------------------
  * Replace roiaware_pool3d_cuda.{points_in_boxes_gpu, points_in_boxes_cpu, forward, backward}
  * (pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:29-177, kernels roiaware_pool3d_kernel.cu:16-359) and

@@ -182,3 +182,39 @@ def test_waymo_shaped_step_matches_cpu_oracle(gpu):
         assert abs(g[name].item() - c[name].item()) < 1e-3 * max(1.0, abs(c[name].item())), name
     (g["loss_rpn"] + g["loss_point"] + g["loss_rcnn"]).backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+@pytest.mark.gpu
+def test_roi_target_sampling_kernel_equals_its_tensor_formulation(gpu):
+    """fv2p_roi_sample_targets (ProposalTargetLayer.subsample_rois, proposal_target_layer.py:92-217, for a batch in one launch)
+    against the same rule written in torch ops: sampled RoIs, their boxes and overlaps bit for bit — mixed sets, no foreground,
+    no background at all (picks with replacement), no easy / no hard background."""
+    from fv2p_harness.fv2p_model import IoUGuidedRoIHead
+    import fv2p_native
+    head = IoUGuidedRoIHead(SmallFV2P)
+    cfg = SmallFV2P
+    r, n, g = 128, cfg.roi_per_image, 12
+    rng = np.random.default_rng(5)
+    cases = []
+    base = rng.uniform(0, 1, size=(4, r, g)).astype(np.float32) ** 3          # mostly low overlaps, a few high
+    cases.append(base)
+    cases.append(np.minimum(base, 0.5).astype(np.float32))                     # no foreground
+    cases.append((0.6 + 0.4 * base).astype(np.float32))                        # no background: all picked with replacement
+    cases.append(np.where(base < 0.1, 0.2, base).astype(np.float32))           # no easy background
+    cases.append(np.where((base >= 0.1) & (base < 0.55), 0.05, base).astype(np.float32))   # no hard background
+    cases.append(np.zeros_like(base))                                          # nothing overlaps
+    for iou_np in cases:
+        iou = torch.from_numpy(iou_np).to(gpu)
+        b = iou.shape[0]
+        rois = torch.from_numpy(rng.standard_normal((b, r, 7)).astype(np.float32)).to(gpu)
+        gt = torch.from_numpy(rng.standard_normal((b, g, 8)).astype(np.float32)).to(gpu)
+        u = torch.from_numpy(rng.uniform(0, 1, size=(b, r + n)).astype(np.float32)).to(gpu)
+        u[:, 3] = u[:, 7]                                                      # equal keys: the permutation is a stable sort
+        want = head.sample_targets_tensor_ops(iou, rois, gt, u)
+        s_rois, s_gt = rois.new_empty(b, n, 7), gt.new_empty(b, n, 8)
+        s_iou, s_index = rois.new_empty(b, n), torch.empty((b, n), dtype=torch.int32, device=gpu)
+        fv2p_native.call("fv2p_roi_sample_targets", iou, rois, gt, u, b, r, g, n, 8, float(min(cfg.reg_fg, cfg.cls_fg)), float(cfg.cls_bg_lo),
+                         float(cfg.reg_fg), int(round(cfg.fg_ratio * n)), float(cfg.hard_bg_ratio), s_rois, s_gt, s_iou, s_index, fv2p_native.stream())
+        assert torch.equal(s_rois, want[0]) and torch.equal(s_iou, want[2])
+        # the box of a RoI whose best overlap is shared by several boxes is the first of them in both formulations
+        assert torch.equal(s_gt, want[1])
