@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--ahead", type=int, default=0,
                     help="no thread: batch t+1 is prepared on a side stream between forward and backward of step t (2 = voxelisation + rulebooks, 1 = voxelisation); FV2P workloads default to 2")
     ap.add_argument("--watchdog", type=int, default=900, help="seconds the measurement may take before it is stopped and repeated in line (0: run in this process, no limit)")
+    ap.add_argument("--dense-stream", type=int, default=1, help="FV2P workloads: BEV backbone + anchor head + RoI preparation on a side stream beside decoder + point head (0: the point branch on a side stream after the preparation)")
     ap.add_argument("--fps-ahead", type=int, default=1, help="FV2P workloads: key points of batch t+1 are sampled (FPS side stream) during the backward pass of step t")
     ap.add_argument("--ahead-priority", type=int, default=-1, help="stream priority of the --ahead side stream (-1 = high: a hardware queue of its own)")
     ap.add_argument("--cloud-streams", type=int, default=1, help="voxelise the clouds of a batch on one stream each (FV2P workloads)")
@@ -92,6 +93,8 @@ def parse():
         args.steps, args.warmup = 30, (args.warmup if "--warmup" in sys.argv else 5)
     if args.workload == "fv2p" and "--prefetch" not in sys.argv:
         args.prefetch = 0   # measured: the input-pipeline thread does not pay here (65.3 vs 63.7 ms per step); the step is not launch bound
+    if args.workload == "fv2p-waymo" and "--dense-stream" not in sys.argv:
+        args.dense_stream = 0   # measured 68.1 vs 64.9 ms: the 34 ms sampler is the critical chain at 180 k points either way
     if args.workload == "fv2p-waymo" and "--fps-ahead" not in sys.argv:
         args.fps_ahead = 0   # measured: the 34 ms sampler of the 180 k-point clouds outlasts the backward pass it would hide behind (68.7 vs 64.8 ms)
     # --ahead 2 measured no better than in line once the blocking host copies were gone (42.4 vs 41.2 ms per step): off by default
@@ -100,7 +103,7 @@ def parse():
     return args
 
 
-SAFE_FLAGS = ["--fps-ahead", "0", "--ahead", "0", "--prefetch", "0"]   # every side-stream input pipeline off: the plain in-line step
+SAFE_FLAGS = ["--fps-ahead", "0", "--ahead", "0", "--prefetch", "0", "--dense-stream", "0"]   # every side-stream input pipeline off: the plain in-line step
 
 
 def launch_ranks(args):
@@ -279,6 +282,8 @@ def build_fv2p_step(args, device, rank, world):
     cfg = FV2PWaymoConfig if waymo else FV2PConfig
     if not args.point_stream:
         cfg = type("Cfg", (cfg,), {"point_branch_stream": False})
+    if not args.dense_stream:
+        cfg = type("Cfg", (cfg,), {"dense_branch_stream": False})
     vsize, prange = np.array(cfg.voxel_size, np.float32), np.array(cfg.point_cloud_range, np.float32)
     torch.manual_seed(0)
     model = FV2PDetector(cfg).to(device)
@@ -681,6 +686,10 @@ def pin_cores(local, n_local, cores):
 
 def main():
     args = parse()
+    if os.environ.get("FV2P_FAULTHANDLER"):   # kill -USR1 prints every thread's Python stack (where a hung run is blocked)
+        import faulthandler
+        import signal
+        faulthandler.register(signal.SIGUSR1, all_threads=True)
     if "RANK" not in os.environ and "FV2P_BENCH_INNER" not in os.environ and (args.gpus > 1 or (args.watchdog > 0 and not args.dry_run)):
         sys.exit(launch_ranks(args))
     if os.environ.get("FV2P_BENCH_TEST_HANG") and args.fps_ahead:   # test hook of the watchdog (tests/test_dist_cpu.py)

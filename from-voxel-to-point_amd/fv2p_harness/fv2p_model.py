@@ -76,6 +76,7 @@ class FV2PConfig:
     cls_fc, reg_fc, dp_ratio = (256, 256), (256, 256), 0.3
     grad_norm_clip = 10.0
     point_branch_stream = True     # decoder + point head on their own stream (their backward then overlaps the dense convs')
+    dense_branch_stream = True     # instead: BEV backbone + anchor head + second-stage preparation on a side stream from the end of the sparse backbone on
 
 
 class FV2PWaymoConfig(FV2PConfig):
@@ -759,22 +760,43 @@ class FV2PDetector(nn.Module):
         if key_job is None:
             key_job = self.post_pfe.start_sampling(clouds)
         out, levels = self.backbone_3d(voxel_features, voxel_coords, b)
-        # (starting the point branch here, beside the BEV layers, hung the device in one run of two — measured, cause not found;
-        # it starts after the RoI head's preparation instead)
+        if self.cfg.dense_branch_stream and clouds[0].is_cuda:
+            # From here the step has two independent branches until the RoI head's `finish`: the dense one (HeightCompression, BEV
+            # backbone, anchor head, second-stage preparation: large MIOpen kernels) on a side stream, and decoder + point head
+            # (~150 small kernels) on the calling stream; autograd replays each on its stream in the backward pass, where the
+            # dense convolutions' gradients overlap the point branch again.  (The mirror arrangement — point branch on a side
+            # stream started right after the sparse backbone — hung the device queue in every second run; it remains below in its
+            # safe form, started after the preparation, for cfg.dense_branch_stream = False.)
+            dev = clouds[0].device
+            side, main = side_stream("dense", dev), torch.cuda.current_stream(dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                bev, loss_rpn, prop_scores, prop_boxes = self.dense_branch(out, b, gt_boxes)
+                prep = self.roi_head.prepare(bev, prop_scores, prop_boxes, gt_boxes, uniforms)
+            key, point_feats = self.post_pfe(clouds, levels, key_job)
+            loss_point, point_scores = self.point_head(key, point_feats, gt_boxes)
+            main.wait_stream(side)
+            for t in [bev, loss_rpn, prop_scores, prop_boxes] + [v for v in prep.values() if torch.is_tensor(v)]:
+                t.record_stream(main)
+        else:
+            bev, loss_rpn, prop_scores, prop_boxes = self.dense_branch(out, b, gt_boxes)
+            prep = self.roi_head.prepare(bev, prop_scores, prop_boxes, gt_boxes, uniforms)   # still no key points needed
+            branch = self.point_branch_start(clouds, levels, key_job, gt_boxes)
+            key, point_feats, loss_point, point_scores = self.point_branch_join(branch)
+        loss_rcnn, aux = self.roi_head.finish(key, point_feats, point_scores, prep)
+        if self.taps is not None:
+            self.taps.update(keypoints=key, point_features=point_feats, point_scores=point_scores, bev=bev, prop_boxes=prop_boxes,
+                             prop_scores=prop_scores, loss_rpn=loss_rpn, loss_point=loss_point, loss_rcnn=loss_rcnn, **aux)
+        return loss_rpn + loss_point + loss_rcnn
+
+    def dense_branch(self, out, b, gt_boxes):
         dense = out.dense()                                                      # HeightCompression (height_compression.py:10-26)
         spatial = dense.view(b, dense.shape[1] * dense.shape[2], dense.shape[3], dense.shape[4])
         if getattr(self, "bev_channels_last", False):
             spatial = spatial.contiguous(memory_format=torch.channels_last)
         bev = self.backbone_2d(spatial)
         loss_rpn, prop_scores, prop_boxes = self.dense_head(bev, gt_boxes)
-        prep = self.roi_head.prepare(bev, prop_scores, prop_boxes, gt_boxes, uniforms)   # still no key points needed
-        branch = self.point_branch_start(clouds, levels, key_job, gt_boxes)
-        key, point_feats, loss_point, point_scores = self.point_branch_join(branch)
-        loss_rcnn, aux = self.roi_head.finish(key, point_feats, point_scores, prep)
-        if self.taps is not None:
-            self.taps.update(keypoints=key, point_features=point_feats, point_scores=point_scores, bev=bev, prop_boxes=prop_boxes,
-                             prop_scores=prop_scores, loss_rpn=loss_rpn, loss_point=loss_point, loss_rcnn=loss_rcnn, **aux)
-        return loss_rpn + loss_point + loss_rcnn
+        return bev, loss_rpn, prop_scores, prop_boxes
 
     def point_branch_start(self, clouds, levels, key_job, gt_boxes):
         """Decoder + point head.  Their only gradient is the point loss (the RoI head pools the point features under no_grad), so
