@@ -60,7 +60,9 @@ def parse():
     ap.add_argument("--dense-stream", type=int, default=1, help="FV2P workloads: BEV backbone + anchor head + RoI preparation on a side stream beside decoder + point head (0: the point branch on a side stream after the preparation)")
     ap.add_argument("--fps-ahead", type=int, default=1, help="FV2P workloads: key points of batch t+1 are sampled (FPS side stream) during the backward pass of step t")
     ap.add_argument("--ahead-priority", type=int, default=-1, help="stream priority of the --ahead side stream (-1 = high: a hardware queue of its own)")
-    ap.add_argument("--cloud-streams", type=int, default=1, help="voxelise the clouds of a batch on one stream each (FV2P workloads)")
+    ap.add_argument("--cloud-streams", type=int, default=0,
+                    help="FV2P workloads: voxelise the clouds of a batch on one stream each (measured: no gain at batch 3, and at Waymo size the extra "
+                         "streams share hardware queues with the 34 ms sampler: 67.1 vs 56.7 ms per step)")
     ap.add_argument("--pair-lists", type=int, default=1, help="prefetch also materialises the reference-format pair lists (pair-split weight gradient)")
     ap.add_argument("--switch-interval", type=float, default=0.0, help="sys.setswitchinterval (s); 0 keeps Python's default 5 ms")
     ap.add_argument("--prefetch-depth", type=int, default=3, help="batches the input pipeline keeps in flight")
@@ -93,10 +95,6 @@ def parse():
         args.steps, args.warmup = 30, (args.warmup if "--warmup" in sys.argv else 5)
     if args.workload == "fv2p" and "--prefetch" not in sys.argv:
         args.prefetch = 0   # measured: the input-pipeline thread does not pay here (65.3 vs 63.7 ms per step); the step is not launch bound
-    if args.workload == "fv2p-waymo" and "--dense-stream" not in sys.argv:
-        args.dense_stream = 0   # measured 68.1 vs 64.9 ms: the 34 ms sampler is the critical chain at 180 k points either way
-    if args.workload == "fv2p-waymo" and "--fps-ahead" not in sys.argv:
-        args.fps_ahead = 0   # measured: the 34 ms sampler of the 180 k-point clouds outlasts the backward pass it would hide behind (68.7 vs 64.8 ms)
     # --ahead 2 measured no better than in line once the blocking host copies were gone (42.4 vs 41.2 ms per step): off by default
     if args.steps == 300 and args.workload == "fv2p" and "--steps" not in sys.argv:
         args.steps, args.warmup = 40, (args.warmup if "--warmup" in sys.argv else 5)
