@@ -157,6 +157,29 @@ __global__ void pairwise_bev(int na, const float* __restrict__ A, int nb, const 
   out[t] = MODE == 0 ? box_overlap(a, b) : iou_bev(a, b);
 }
 
+// 3-D IoU of every box of A with every box of B, per sample of a batch (boxes_iou3d_gpu, iou3d_nms_utils.py:454-491, whose
+// torch composition this follows operation for operation: BEV overlap x height overlap / clamped union, result clamped to [0, 1])
+__global__ void pairwise_iou3d_batch(int na, const float* __restrict__ A, int nb, const float* __restrict__ B, int b_stride,
+                                     float* __restrict__ out) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= static_cast<int64_t>(na) * nb) return;
+  const int s = blockIdx.y, ia = static_cast<int>(t / nb), ib = static_cast<int>(t % nb);
+  float a[7], b[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    a[j] = A[(static_cast<int64_t>(s) * na + ia) * 7 + j];
+    b[j] = B[(static_cast<int64_t>(s) * nb + ib) * b_stride + j];
+  }
+  const float a_max = a[2] + a[5] / 2, a_min = a[2] - a[5] / 2, b_max = b[2] + b[5] / 2, b_min = b[2] - b[5] / 2;
+  const float oh = fmaxf(fminf(a_max, b_max) - fmaxf(a_min, b_min), 0.f);
+  const float o3 = box_overlap(a, b) * oh;
+  const float vol_a = a[3] * a[4] * a[5], vol_b = b[3] * b[4] * b[5];
+  float iou = o3 / fmaxf(vol_a + vol_b - o3, 1e-6f);
+  iou = iou < 0.f ? 0.f : iou;
+  iou = iou > 1.f ? 1.f : iou;
+  out[static_cast<int64_t>(s) * na * nb + t] = iou;
+}
+
 // one wave per upper-triangular 64x64 tile; lane = row box, loop over the 64 column boxes staged in LDS
 template <int NORMAL>
 __global__ __launch_bounds__(64) void nms_mask(int n, float thresh, const float* __restrict__ boxes, int col_blocks,
@@ -359,6 +382,18 @@ static int pairwise(int mode, const float* a, int na, const float* b, int nb, fl
   const dim3 grid(static_cast<unsigned>(ceil_div(total, 256))), block(256);
   if (mode == 0) hipLaunchKernelGGL(pairwise_bev<0>, grid, block, 0, static_cast<hipStream_t>(s), na, a, nb, b, out);
   else hipLaunchKernelGGL(pairwise_bev<1>, grid, block, 0, static_cast<hipStream_t>(s), na, a, nb, b, out);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fv2p_boxes_iou3d_batch(const float* boxes_a, int batch, int num_a, const float* boxes_b, int num_b, int b_stride,
+                                      float* ans_iou, fv2p_stream_t stream) {
+  FV2P_REQUIRE(batch >= 0 && num_a >= 0 && num_b >= 0 && b_stride >= 7 && batch <= 65535, FV2P_EINVAL, "boxes_iou3d_batch: bad sizes");
+  if (batch == 0 || num_a == 0 || num_b == 0) return 0;
+  FV2P_REQUIRE(boxes_a && boxes_b && ans_iou, FV2P_EINVAL, "boxes_iou3d_batch: null pointer");
+  const int64_t total = static_cast<int64_t>(num_a) * num_b;
+  hipLaunchKernelGGL(pairwise_iou3d_batch, dim3(static_cast<unsigned>(ceil_div(total, 256)), batch), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     num_a, boxes_a, num_b, boxes_b, b_stride, ans_iou);
   FV2P_LAUNCH_CHECK();
   return 0;
 }

@@ -570,7 +570,13 @@ class IoUGuidedRoIHead(nn.Module):
         cfg = self.cfg
         b, r, _ = rois.shape
         n = cfg.roi_per_image
-        iou = torch.stack([iou3d_nms_utils.boxes_iou3d_gpu(rois[i], gt[i, :, :7].contiguous()) for i in range(b)])   # (B, R, G)
+        if rois.is_cuda:
+            rois, gt = rois.contiguous(), gt.contiguous()
+            iou = rois.new_empty(b, r, gt.shape[1])
+            with _nat.device_guard(rois.device):   # boxes_iou3d_gpu for the batch in one launch (same float operations)
+                _nat.call("fv2p_boxes_iou3d_batch", rois, b, r, gt, gt.shape[1], gt.shape[-1], iou, _nat.stream())
+        else:
+            iou = torch.stack([iou3d_nms_utils.boxes_iou3d_gpu(rois[i], gt[i, :, :7].contiguous()) for i in range(b)])   # (B, R, G)
         if rois.is_cuda and r <= 1024:
             # one launch for the batch (csrc/targets.hip); the tensor formulation below is its statement in torch ops and what a
             # CPU run takes (tests/test_fv2p_step_gpu.py compares the two bit for bit)

@@ -252,6 +252,12 @@ int fv2p_nms(const float* boxes, int n, float thresh, int normal, int64_t* keep,
 size_t fv2p_nms_batch_ws_bytes(int batch, int n, int max_keep);
 int fv2p_nms_batch(const float* boxes, int batch, int n, float thresh, int normal, int max_keep, int64_t* keep,
                    int keep_stride, int* num_keep, void* ws, size_t ws_bytes, fv2p_stream_t stream);
+/* boxes_iou3d_gpu (pcdet/ops/iou3d_nms/iou3d_nms_utils.py:454-491) for a batch in one launch: boxes_a [batch, num_a, 7], boxes_b
+ * [batch, num_b, b_stride >= 7] (e.g. gt boxes with their class id), ans_iou [batch, num_a, num_b] = BEV overlap x height overlap
+ * / max(vol_a + vol_b - overlap, 1e-6), clamped to [0, 1] — the same float operations in the same order as the per-sample
+ * composition of boxes_overlap_bev_gpu with torch ops. */
+int fv2p_boxes_iou3d_batch(const float* boxes_a, int batch, int num_a, const float* boxes_b, int num_b, int b_stride, float* ans_iou,
+                           fv2p_stream_t stream);
 int fv2p_boxes_iou_bev_cpu(const float* boxes_a, int num_a, const float* boxes_b, int num_b, float* ans_iou);
 
 /* ---- (f).4: second-stage target sampling --------------------------------------------------------

@@ -84,3 +84,22 @@ def test_nms_gpu_honours_the_callers_post_maxsize(gpu):
     keep, _ = iou3d_nms_utils.nms_gpu(tb, ts, 0.4, pre_maxsize=4096, **{k: v for k, v in cfg.items() if k != "NMS_PRE_MAXSIZE"})
     ref = oracle.nms(boxes, scores, 0.4, pre_maxsize=4096)[:100]
     assert np.array_equal(keep.cpu().numpy(), ref)
+
+
+@pytest.mark.gpu
+def test_batched_iou3d_equals_the_per_sample_composition(gpu):
+    """fv2p_boxes_iou3d_batch == boxes_iou3d_gpu per sample (bit for bit: the same float operations in the same order), with
+    ground-truth rows of 8 values (class id last) and zero-padded rows."""
+    import fv2p_native
+    from pcdet.ops.iou3d_nms import iou3d_nms_utils
+    a = torch.from_numpy(np.stack([random_boxes(3 + i, 200, spread=8.0) for i in range(3)])).to(gpu)
+    g7 = np.stack([random_boxes(30 + i, 24, spread=8.0) for i in range(3)])
+    g8 = np.concatenate([g7, np.ones((3, 24, 1), np.float32)], 2)
+    g8[:, 20:] = 0
+    b = torch.from_numpy(g8).to(gpu)
+    out = torch.empty((3, 200, 24), device=gpu)
+    fv2p_native.call("fv2p_boxes_iou3d_batch", a, 3, 200, b, 24, 8, out, fv2p_native.stream())
+    for i in range(3):
+        want = iou3d_nms_utils.boxes_iou3d_gpu(a[i], b[i, :, :7].contiguous())
+        assert torch.equal(out[i], want)
+    assert float(out.max()) > 0.05

@@ -363,12 +363,97 @@ def bev():
     print(f"bev gather [{b},{c},{h},{w}] x {n} pts: fwd {t_f:7.1f} us ({byt / t_f / 1e6:5.2f} TB/s)  bwd {t_b:7.1f} us | torch composition fwd {t_rf:7.1f} us bwd {t_rb:7.1f} us")
 
 
+def oproof():
+    """Per-op roofline fractions with SURVEY 8(d)'s algorithmic bytes / flops at the FV2P step's shapes.
+    HBM ops are priced against 8 TB/s, the brute-force searches against the 157.3 TFLOP/s fp32 vector peak as well."""
+    from fv2p_harness import synth
+    from pcdet.datasets.processor.voxel_generator import points_to_voxel_batch
+    from pcdet.ops.iou3d_nms import iou3d_nms_cuda, iou3d_nms_utils
+    from pcdet.ops.pointnet2.pointnet2_batch import pointnet2_utils as bu
+    from pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as su
+    from pcdet.ops.roiaware_pool3d import roiaware_pool3d_utils
+    from pcdet.ops.roipoint_pool3d import roipoint_pool3d_utils
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from boxes_util import random_boxes
+    dev = torch.device("cuda:0")
+    HBM, VEC = 8000.0, 157.3   # GB/s, TFLOP/s
+    rows = []
+
+    def add(name, t_us, nbytes=None, flops=None, note=""):
+        gbs = nbytes / t_us / 1e3 if nbytes else None
+        tf = flops / t_us / 1e6 if flops else None
+        rows.append((name, t_us, gbs, gbs / HBM if gbs else None, tf, tf / VEC if tf else None, note))
+
+    # voxeliser: 16 N + M (max_pts * 16 + 12 + 4)
+    pts = [torch.from_numpy(synth.lidar_cloud(i, 16384)).to(dev) for i in range(3)]
+    vs, rng = np.array([0.05, 0.05, 0.1], np.float32), np.array([0, -40, -3, 70.4, 40, 1], np.float32)
+    f, c = points_to_voxel_batch(pts, vs, rng, 5, 16000, mean_vfe=True, cloud_streams=False)
+    m = f.shape[0]
+    t = timeit(lambda: points_to_voxel_batch(pts, vs, rng, 5, 16000, mean_vfe=True, cloud_streams=False), reps=10, warm=2)
+    add("points_to_voxel + MeanVFE, 3 x 16384 pts", t, 16.0 * 3 * 16384 + m * (5 * 16 + 12 + 4), note=f"{m} voxels; includes the host wait for the counts")
+    # stacked three_nn / interpolate of the decoder: 3 x 16384 key points against a level's voxel centres
+    key = torch.cat([p[:, :3] for p in pts]).contiguous()
+    kc = torch.full((3,), 16384, dtype=torch.int32, device=dev)
+    for nk, ch in ((35146, 16), (22331, 64), (9919, 128)):
+        known = (torch.rand(nk, 3, device=dev) * torch.tensor([70.4, 80.0, 4.0], device=dev) + torch.tensor([0.0, -40.0, -3.0], device=dev)).contiguous()
+        cnt = torch.tensor([nk // 3, nk // 3, nk - 2 * (nk // 3)], dtype=torch.int32, device=dev)
+        t = timeit(lambda: su.three_nn(key, kc, known, cnt), reps=5, warm=1)
+        nu = key.shape[0]
+        add(f"three_nn (stack) {nu} x {nk // 3} per sample", t, 12.0 * (nu + nk) + 24.0 * nu, 8.0 * nu * (nk / 3), "brute force, LDS tiled")
+        dist, idx = su.three_nn(key, kc, known, cnt)
+        w = torch.rand(nu, 3, device=dev)
+        feats = torch.randn(nk, ch, device=dev, requires_grad=True)
+        t = timeit(lambda: su.three_interpolate(feats, idx, w), reps=10, warm=2)
+        add(f"three_interpolate (stack) {nu} x C={ch}", t, 4.0 * ch * (3 * nu + nu) + 24.0 * nu)
+        out = su.three_interpolate(feats, idx, w)
+        g = torch.randn_like(out)
+        t = timeit(lambda: out.backward(g, retain_graph=True), reps=10, warm=2)
+        add(f"three_interpolate grad {nu} x C={ch}", t, 4.0 * ch * (3 * nu + nu) + 24.0 * nu, note="scatter-add")
+    # batch grouping at the RoI head's shape: 384 RoIs x 512 points, 216 centres, 16 / 32 samples, C = 64 + 3
+    r, n, mc, ch = 384, 512, 216, 67
+    xyz = torch.rand(r, n, 3, device=dev)
+    ctr = torch.rand(r, mc, 3, device=dev)
+    featb = torch.randn(r, ch, n, device=dev, requires_grad=True)
+    for ns, rad in ((16, 0.2), (32, 0.4)):
+        t = timeit(lambda: bu.ball_query(rad, ns, xyz, ctr), reps=10, warm=2)
+        add(f"ball_query R={r} N={n} M={mc} ns={ns}", t, 12.0 * r * (n + mc) + 4.0 * r * mc * ns, 8.0 * r * mc * n)
+        idx = bu.ball_query(rad, ns, xyz, ctr)
+        t = timeit(lambda: bu.grouping_operation(featb, idx), reps=10, warm=2)
+        add(f"group_points R={r} C={ch} M={mc} ns={ns}", t, 4.0 * ch * r * mc * ns * 2 + 4.0 * r * mc * ns)
+        out = bu.grouping_operation(featb, idx)
+        g = torch.randn_like(out)
+        t = timeit(lambda: out.backward(g, retain_graph=True), reps=10, warm=2)
+        add(f"group_points grad R={r} C={ch} M={mc} ns={ns}", t, 4.0 * ch * r * mc * ns * 2 + 4.0 * r * mc * ns, note="LDS accumulator per (RoI, channel) row")
+    # NMS of the proposal layer and the RoI-head IoU / pools
+    batch = torch.from_numpy(np.stack([random_boxes(7 + i, 9000) for i in range(3)])).to(dev)
+    t = timeit(lambda: iou3d_nms_cuda.nms_batch_device(batch, 0.8, 512), reps=5, warm=1)
+    add("nms_batch 3 x 9000 -> 512 (truncated)", t, 3 * (28.0 * 9000 + 9000.0 * 9000 / 8), 3 * 9000.0 * 9000 / 2 * 300, "priced as the FULL mask (8(d)); only ~1/9 of the row blocks are evaluated")
+    t = timeit(lambda: iou3d_nms_cuda.nms_batch_device(batch, 0.8, 0), reps=3, warm=1)
+    add("nms_batch 3 x 9000, all survivors", t, 3 * (28.0 * 9000 + 9000.0 * 9000 / 8), 3 * 9000.0 * 9000 / 2 * 300)
+    a, b2 = batch[0, :512].contiguous(), batch[1, :40].contiguous()
+    t = timeit(lambda: iou3d_nms_utils.boxes_iou3d_gpu(a, b2), reps=10, warm=2)
+    add("boxes_iou3d 512 x 40", t, 28.0 * 552 + 4.0 * 512 * 40, 512 * 40 * 300.0, "launch latency")
+    kp = torch.stack([p[:, :3] for p in pts]).contiguous()
+    gt = batch[:, :40].contiguous()
+    t = timeit(lambda: roiaware_pool3d_utils.points_in_boxes_gpu(kp, gt), reps=10, warm=2)
+    add("points_in_boxes 3 x 16384 pts x 40 boxes", t, 3 * (12.0 * 16384 + 28.0 * 40 + 4.0 * 16384))
+    pool = roipoint_pool3d_utils.RoIPointPool3d(num_sampled_points=512, pool_extra_width=(1.0, 1.0, 1.0))
+    fe = torch.randn(3, 16384, 130, device=dev)
+    rois = batch[:, :128].contiguous()
+    t = timeit(lambda: pool(kp, fe, rois), reps=5, warm=1)
+    add("roipoint_pool3d 3 x 128 RoIs x 512 pts x (3+130)", t, 3 * 128 * 512 * 133 * 4.0, note="bytes written (8(d))")
+    print(f"{'op':58s} {'us':>9s} {'GB/s':>8s} {'of HBM':>7s} {'TFLOP/s':>8s} {'of vec':>7s}  note")
+    for name, t_us, gbs, fh, tf, fv, note in rows:
+        fmt = lambda v, w, p: (f"{v:{w}.{p}f}" if v is not None else " " * w)
+        print(f"{name:58s} {t_us:9.1f} {fmt(gbs, 8, 1)} {fmt(fh, 7, 3)} {fmt(tf, 8, 2)} {fmt(fv, 7, 3)}  {note}")
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which == "convone":
         conv(only=20)
         sys.exit(0)
-    for name, fn in (("conv", conv), ("dcn", dcn), ("fps", fps), ("nms", nms), ("sa", sa), ("bn", bn), ("bev", bev)):
+    for name, fn in (("conv", conv), ("dcn", dcn), ("fps", fps), ("nms", nms), ("sa", sa), ("bn", bn), ("bev", bev), ("oproof", oproof)):
         if which in (name, "all"):
             print(f"==== {name}")
             fn()
