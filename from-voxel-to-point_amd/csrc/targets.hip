@@ -104,3 +104,108 @@ extern "C" int fv2p_roi_sample_targets(const float* iou, const float* rois, cons
   FV2P_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- first-stage (anchor) target assignment ---------------------------------------------------------------------------------------
+// AxisAlignedTargetAssigner.assign_targets_single (pcdet/models/dense_heads/target_assigner/axis_aligned_target_assigner.py:66-210)
+// for the whole batch in two launches: nearest-BEV IoU of every anchor with every ground-truth box, per-box maximum (pass 1),
+// then per anchor: best box (first maximum), label = box class when the overlap reaches matched_thr or the anchor attains a box's
+// (non-zero) maximum, 0 below unmatched_thr, -1 (ignored) in between, and the ResidualCoder regression target of positive anchors.
+// Every float operation follows the tensor formulation of the replay harness (AnchorHead.assign_tensor_ops) in its order.
+namespace fv2p {
+
+__device__ __forceinline__ float aligned_iou(const float4 a, float area_a, const float4 g) {
+  const float lx = fmaxf(a.x, g.x), ly = fmaxf(a.y, g.y), hx = fminf(a.z, g.z), hy = fminf(a.w, g.w);
+  const float inter = fmaxf(hx - lx, 0.f) * fmaxf(hy - ly, 0.f);
+  const float area_g = (g.z - g.x) * (g.w - g.y);
+  return inter / fmaxf(area_a + area_g - inter, 1e-6f);
+}
+
+__global__ __launch_bounds__(256) void anchor_box_max_k(int n_anchor, int g, const float4* __restrict__ anchor_bev, const float4* __restrict__ gt_bev,
+                                                        unsigned* __restrict__ g_max_bits) {
+  extern __shared__ float4 s_gt[];
+  const int b = blockIdx.y, a = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int j = threadIdx.x; j < g; j += blockDim.x) s_gt[j] = gt_bev[b * g + j];
+  __syncthreads();
+  if (a >= n_anchor) return;
+  const float4 ab = anchor_bev[a];
+  const float area_a = (ab.z - ab.x) * (ab.w - ab.y);
+  for (int j = 0; j < g; ++j) {
+    const float iou = aligned_iou(ab, area_a, s_gt[j]);
+    if (iou > 0.f) atomicMax(&g_max_bits[b * g + j], __float_as_uint(iou));   // overlaps are >= 0: unsigned order = float order
+  }
+}
+
+__global__ __launch_bounds__(256) void anchor_label_k(int n_anchor, int g, int gt_w, const float4* __restrict__ anchor_bev,
+                                                      const float* __restrict__ anchors, const float4* __restrict__ gt_bev,
+                                                      const float* __restrict__ gt, const unsigned* __restrict__ g_max_bits, float matched_thr,
+                                                      float unmatched_thr, int* __restrict__ labels, float* __restrict__ reg) {
+  extern __shared__ float4 s_gt[];
+  float* s_max = reinterpret_cast<float*>(s_gt + g);
+  const int b = blockIdx.y, a = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int j = threadIdx.x; j < g; j += blockDim.x) {
+    s_gt[j] = gt_bev[b * g + j];
+    const float m = __uint_as_float(g_max_bits[b * g + j]);
+    s_max[j] = m == 0.f ? -1.f : m;   // a box nothing overlaps forces no anchor
+  }
+  __syncthreads();
+  if (a >= n_anchor) return;
+  const float4 ab = anchor_bev[a];
+  const float area_a = (ab.z - ab.x) * (ab.w - ab.y);
+  float best = aligned_iou(ab, area_a, s_gt[0]);
+  int arg = 0;
+  bool forced = best == s_max[0];
+  for (int j = 1; j < g; ++j) {
+    const float iou = aligned_iou(ab, area_a, s_gt[j]);
+    if (iou > best) { best = iou; arg = j; }
+    forced = forced || iou == s_max[j];
+  }
+  const float* gb = gt + (static_cast<long long>(b) * g + arg) * gt_w;
+  int label = -1;
+  if (best < unmatched_thr) label = 0;
+  if (forced || best >= matched_thr) label = static_cast<int>(gb[7]);
+  const long long o = static_cast<long long>(b) * n_anchor + a;
+  labels[o] = label;
+  float r[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (label > 0) {   // ResidualCoder.encode_torch (box_coder_utils.py:13-46)
+    const float* an = anchors + static_cast<long long>(a) * 7;
+    const float ax = fmaxf(an[3], 1e-5f), ay = fmaxf(an[4], 1e-5f), az = fmaxf(an[5], 1e-5f);
+    const float bx = fmaxf(gb[3], 1e-5f), by = fmaxf(gb[4], 1e-5f), bz = fmaxf(gb[5], 1e-5f);
+    const float diag = sqrtf(ax * ax + ay * ay);
+    r[0] = (gb[0] - an[0]) / diag;
+    r[1] = (gb[1] - an[1]) / diag;
+    r[2] = (gb[2] - an[2]) / az;
+    r[3] = logf(bx / ax);
+    r[4] = logf(by / ay);
+    r[5] = logf(bz / az);
+    r[6] = gb[6] - an[6];
+  }
+#pragma unroll
+  for (int c = 0; c < 7; ++c) reg[o * 7 + c] = r[c];
+}
+
+}  // namespace fv2p
+
+extern "C" size_t fv2p_anchor_assign_ws_bytes(int batch, int g) { return static_cast<size_t>(batch > 0 ? batch : 1) * (g > 0 ? g : 1) * sizeof(unsigned); }
+
+extern "C" int fv2p_anchor_assign(const float* anchor_bev, const float* anchors, int n_anchor, const float* gt_bev, const float* gt, int batch, int g,
+                                  int gt_w, float matched_thr, float unmatched_thr, int* labels, float* reg, void* ws, size_t ws_bytes,
+                                  fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FV2P_REQUIRE(batch >= 0 && batch <= 65535 && n_anchor >= 1 && g >= 1 && g <= 1024 && gt_w >= 8, FV2P_EINVAL,
+               "anchor_assign: need at least one anchor, 1..1024 (padded) boxes of >= 8 values (class id at [7])");
+  if (batch == 0) return 0;
+  FV2P_REQUIRE(anchor_bev && anchors && gt_bev && gt && labels && reg && ws, FV2P_EINVAL, "anchor_assign: null pointer");
+  FV2P_REQUIRE(ws_bytes >= fv2p_anchor_assign_ws_bytes(batch, g), FV2P_EINVAL, "anchor_assign: workspace too small");
+  FV2P_REQUIRE((reinterpret_cast<uintptr_t>(anchor_bev) & 15) == 0 && (reinterpret_cast<uintptr_t>(gt_bev) & 15) == 0, FV2P_EINVAL,
+               "anchor_assign: the (x0, y0, x1, y1) footprints must be 16-byte aligned");
+  unsigned* g_max = static_cast<unsigned*>(ws);
+  FV2P_HIP(hipMemsetAsync(g_max, 0, static_cast<size_t>(batch) * g * sizeof(unsigned), stream));
+  const dim3 grid(static_cast<unsigned>((n_anchor + 255) / 256), batch), block(256);
+  hipLaunchKernelGGL(anchor_box_max_k, grid, block, g * sizeof(float4), stream, n_anchor, g, reinterpret_cast<const float4*>(anchor_bev),
+                     reinterpret_cast<const float4*>(gt_bev), g_max);
+  hipLaunchKernelGGL(anchor_label_k, grid, block, g * (sizeof(float4) + sizeof(float)), stream, n_anchor, g, gt_w,
+                     reinterpret_cast<const float4*>(anchor_bev), anchors, reinterpret_cast<const float4*>(gt_bev), gt, g_max, matched_thr,
+                     unmatched_thr, labels, reg);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}

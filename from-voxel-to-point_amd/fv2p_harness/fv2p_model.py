@@ -263,6 +263,22 @@ class AnchorHead(nn.Module):
     @torch.no_grad()
     def assign(self, gt):
         """gt (B, G, 8) zero padded -> labels (B, A) in {-1, 0, cls}, reg targets (B, A, 7)."""
+        if gt.is_cuda and gt.shape[-1] >= 8:
+            # two launches for the batch (csrc/targets.hip); assign_tensor_ops is the same rule in torch ops (and the CPU path)
+            b, g, a = gt.shape[0], gt.shape[1], self.anchors.shape[0]
+            gt = gt.contiguous()
+            gb = nearest_bev_boxes(gt[..., :7]).contiguous()
+            labels = torch.empty((b, a), dtype=torch.int32, device=gt.device)
+            reg = gt.new_empty(b, a, 7)
+            with _nat.device_guard(gt.device):
+                ws = _nat.workspace(int(_nat.lib().fv2p_anchor_assign_ws_bytes(b, g)), gt.device)
+                _nat.call("fv2p_anchor_assign", self.anchor_bev, self.anchors, a, gb, gt, b, g, gt.shape[-1], float(self.cfg.matched_thr),
+                          float(self.cfg.unmatched_thr), labels, reg, ws, ws.numel(), _nat.stream())
+            return labels, reg
+        return self.assign_tensor_ops(gt)
+
+    @torch.no_grad()
+    def assign_tensor_ops(self, gt):
         cfg = self.cfg
         gb = nearest_bev_boxes(gt[..., :7])                                     # (B, G, 4)
         ab = self.anchor_bev                                                    # (A, 4)

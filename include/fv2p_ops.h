@@ -273,6 +273,16 @@ int fv2p_roi_sample_targets(const float* iou, const float* rois, const float* gt
                             int gt_w, float fg_thresh, float bg_lo, float reg_fg, int fg_quota, float hard_ratio, float* s_rois,
                             float* s_gt, float* s_iou, int* s_index, fv2p_stream_t stream);
 
+/* First-stage target assignment for a batch (AxisAlignedTargetAssigner.assign_targets_single,
+ * pcdet/models/dense_heads/target_assigner/axis_aligned_target_assigner.py:66-210, one class): anchor_bev [A,4] and gt_bev
+ * [B,G,4] are the nearest-BEV footprints (x0,y0,x1,y1) of anchors [A,7] and gt [B,G,gt_w] (class id at [7], zero rows = padding).
+ * labels [B,A] i32: the best box's class where its overlap >= matched_thr or the anchor attains a box's non-zero maximum, 0 below
+ * unmatched_thr, -1 in between; reg [B,A,7]: ResidualCoder target of the positive anchors, zero elsewhere. */
+size_t fv2p_anchor_assign_ws_bytes(int batch, int g);
+int fv2p_anchor_assign(const float* anchor_bev, const float* anchors, int n_anchor, const float* gt_bev, const float* gt, int batch, int g,
+                       int gt_w, float matched_thr, float unmatched_thr, int* labels, float* reg, void* ws, size_t ws_bytes,
+                       fv2p_stream_t stream);
+
 /* ---- A15 / A18: point-in-box, RoI-aware voxel pooling, RoI point pooling ------------------------
  * Replace roiaware_pool3d_cuda.{points_in_boxes_gpu, points_in_boxes_cpu, forward, backward}
  * (pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:29-177, kernels roiaware_pool3d_kernel.cu:16-359) and

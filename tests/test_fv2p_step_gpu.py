@@ -247,3 +247,24 @@ def test_stream_arrangements_give_the_same_step(gpu):
         assert abs(other[0] - runs[0][0]) < 1e-5 * max(1.0, abs(runs[0][0]))
         for k, g0 in runs[0][3].items():
             assert float((other[3][k] - g0).norm() / g0.norm().clamp_min(1e-12)) < 1e-4, k
+
+
+@pytest.mark.gpu
+def test_anchor_assignment_kernel_equals_its_tensor_formulation(gpu):
+    """fv2p_anchor_assign (AxisAlignedTargetAssigner, axis_aligned_target_assigner.py:66-210, for a batch in two launches) against
+    AnchorHead.assign_tensor_ops: labels bit for bit (matched / forced / ignored / background), regression targets 1e-6; with
+    zero-padded boxes, a sample without boxes and a box no anchor overlaps."""
+    from fv2p_harness.fv2p_model import AnchorHead
+    head = AnchorHead(SmallFV2P, 128).to(gpu)
+    boxes = []
+    for s in range(3):
+        _, bx = synth.lidar_cloud(11 + s, 2048, pc_range=np.array(SmallFV2P.point_cloud_range, np.float32), return_boxes=True)
+        boxes.append(bx)
+    boxes[2] = boxes[2][:0]                                        # a sample without ground truth
+    boxes[1] = np.concatenate([boxes[1], np.array([[500.0, 500.0, 0.0, 3.9, 1.6, 1.5, 0.3]], np.float32)])   # outside every anchor
+    gt = pad_gt_boxes(boxes, gpu, max_gt=48)
+    lab, reg = head.assign(gt)
+    lab_t, reg_t = head.assign_tensor_ops(gt)
+    assert torch.equal(lab, lab_t)
+    assert int((lab > 0).sum()) > 0 and int((lab == -1).sum()) > 0 and int((lab[2] != 0).sum()) == 0
+    assert float((reg - reg_t).abs().max()) < 1e-6
