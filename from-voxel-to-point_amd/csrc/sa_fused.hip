@@ -301,6 +301,8 @@ __global__ __launch_bounds__(256) void sa_grid_fwd_k(int n, int m, int s, const 
 // grid (2, R): workgroup (h, r) owns the channel half h of dP / dQ (channels 32 h .. 32 h + 31) and the row half h of dW2
 // (output channels c' in the same range) of RoI r; block 256, wave w takes centres w, w + 4, ...  S <= 32.
 constexpr int kSaTs = 72;   // row stride of the transpose tiles (floats): 64 + 8, conflict-light both ways
+constexpr int kSaDp = 33;   // row stride of the dP tile (floats): odd, so the scatter's rows (arbitrary points) spread over all LDS banks —
+                            // with 32 every row starts on bank 0 or 32 and a wave's 64 adds fall on 8 banks
 template <int TILES>         // samples per centre / 16: register arrays below are indexed by compile-time tile numbers only
 __global__ __launch_bounds__(256) void sa_grid_bwd_k(int n, int m, const float* __restrict__ P, const float* __restrict__ Q,
                                                      const int* __restrict__ idx, const float* __restrict__ W2, const float* __restrict__ out,
@@ -310,12 +312,12 @@ __global__ __launch_bounds__(256) void sa_grid_bwd_k(int n, int m, const float* 
   float* wfrag = lds;                          // W2      as A operand (forward recompute)      16 KB
   float* wtfrag = lds + 16 * 64 * 4;           // W2^T    as A operand (dh1^T = W2^T dh2^T)     16 KB
   float* tile = wtfrag + 16 * 64 * 4;          // per wave: two 16 x 72 transpose tiles (dh2, h1)
-  float* dpt = tile + 4 * 2 * 16 * kSaTs;      // dP accumulator of this RoI and channel half: [n][32]
+  float* dpt = tile + 4 * 2 * 16 * kSaTs;      // dP accumulator of this RoI and channel half: [n][kSaDp]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 15, g = lane >> 4;
   const int half = blockIdx.x, r = blockIdx.y;
   stage_frag(W2, false, wfrag);
   stage_frag(W2, true, wtfrag);
-  for (int e = threadIdx.x; e < n * 32; e += 256) dpt[e] = 0.f;
+  for (int e = threadIdx.x; e < n * kSaDp; e += 256) dpt[e] = 0.f;
   __syncthreads();
   float* t_dh2 = tile + wave * 2 * 16 * kSaTs;
   float* t_h1 = t_dh2 + 16 * kSaTs;
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(256) void sa_grid_bwd_k(int n, int m, const float* 
         for (int e = 0; e < 4; ++e) {
           const float v = hv[e] > 0.f ? d1[bb][e] : 0.f;
           dq[bb][e] += v;
-          if (v != 0.f) atomicAdd(&dpt[src[t] * 32 + 16 * bb + 4 * g + e], v);
+          if (v != 0.f) atomicAdd(&dpt[src[t] * kSaDp + 16 * bb + 4 * g + e], v);
         }
       }
       // dW2[c'][c] += sum_rows dh2[row][c'] h1[row][c]: rows become the K dimension -> transpose both tiles through LDS
@@ -456,7 +458,8 @@ __global__ __launch_bounds__(256) void sa_grid_bwd_k(int n, int m, const float* 
   float* dpo = dP + static_cast<long long>(r) * n * kSaC + 32 * half;
   for (int e = threadIdx.x; e < n * 8; e += 256) {
     const int pt = e >> 3, c4 = (e & 7) * 4;
-    *reinterpret_cast<float4*>(dpo + static_cast<long long>(pt) * kSaC + c4) = *reinterpret_cast<const float4*>(dpt + pt * 32 + c4);
+    const float* t4 = dpt + pt * kSaDp + c4;
+    *reinterpret_cast<float4*>(dpo + static_cast<long long>(pt) * kSaC + c4) = make_float4(t4[0], t4[1], t4[2], t4[3]);
   }
   // dW2 partial of this workgroup: the four waves' accumulators summed through LDS (the transpose tiles are free now)
   float* red = tile;   // [4 waves][2][4][256] floats = 32 KB > tile space: reuse wfrag + wtfrag as well (all waves are past them)
@@ -498,7 +501,7 @@ static bool sa_shapes_ok(int rois, int n, int m, int s, int c) {
 }
 
 extern "C" int fv2p_sa_grid_supported(int n, int m, int s, int c) {
-  return (c == kSaC && (s == 16 || s == 32) && n >= 1 && m >= 1 && static_cast<size_t>(n) * 32 * 4 <= 80 * 1024) ? 1 : 0;   // backward: 69 KB of fragments / tiles + the dP tile within 160 KB of LDS
+  return (c == kSaC && (s == 16 || s == 32) && n >= 1 && m >= 1 && static_cast<size_t>(n) * kSaDp * 4 <= 84 * 1024) ? 1 : 0;   // backward: 69 KB of fragments / tiles + the dP tile within 160 KB of LDS
 }
 
 extern "C" int fv2p_sa_grid_fwd(const float* per_point, const float* per_centre, const int* idx, const float* w2, int rois, int n, int m,
@@ -526,7 +529,7 @@ extern "C" int fv2p_sa_grid_bwd(const float* per_point, const float* per_centre,
   FV2P_REQUIRE(ws && ws_bytes >= fv2p_sa_grid_bwd_ws_bytes(rois), FV2P_EWORKSPACE, "sa_grid_bwd: workspace too small");
   Carver cv(ws, ws_bytes);
   float* partial = cv.take<float>(static_cast<size_t>(rois) * kSaC * kSaC);
-  const size_t lds = (2 * 16 * 64 * 4 + 4 * 2 * 16 * kSaTs + static_cast<size_t>(n) * 32) * sizeof(float);
+  const size_t lds = (2 * 16 * 64 * 4 + 4 * 2 * 16 * kSaTs + static_cast<size_t>(n) * kSaDp) * sizeof(float);
   static size_t attr_for = 0;
   if (lds > 48 * 1024 && lds > attr_for) {
     FV2P_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sa_grid_bwd_k<1>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
