@@ -180,7 +180,81 @@ __global__ void pairwise_iou3d_batch(int na, const float* __restrict__ A, int nb
   out[static_cast<int64_t>(s) * na * nb + t] = iou;
 }
 
-// one wave per upper-triangular 64x64 tile; lane = row box, loop over the 64 column boxes staged in LDS
+// Rotated boxes: a pair whose bounding circles are apart cannot overlap, and at proposal-layer densities ~97 % of the pairs of a
+// 64 x 64 tile are such pairs.  A lane's row box meets the tile's column boxes one by one, so skipping per lane would not help (some
+// lane always has a near partner); instead every lane first collects its near columns as a bit mask (a few flops per pair), the
+// tile's candidates are numbered by a wave prefix sum, and the ~1000-instruction overlap is evaluated for 64 candidates at a time,
+// whatever rows they belong to.  The suppression bits are exactly those of the plain loop (the pre-test only drops pairs whose
+// overlap is zero).
+__device__ __forceinline__ bool circles_apart(const float* a, const float* b) {
+  const float dx = a[0] - b[0], dy = a[1] - b[1];
+  const float ra = 0.5f * sqrtf(a[3] * a[3] + a[4] * a[4]), rb = 0.5f * sqrtf(b[3] * b[3] + b[4] * b[4]);
+  const float reach = (ra + rb) * 1.001f + 1e-4f;   // margin: a pair is dropped only when it is clearly apart
+  return dx * dx + dy * dy > reach * reach;
+}
+
+// suppression words of one 64 x 64 tile: word of row box `lane` = the column boxes it suppresses (bit i = column cb * 64 + i)
+template <int NORMAL>
+__device__ __forceinline__ unsigned long long nms_tile(int n, float thresh, const float* __restrict__ boxes, int rb, int cb) {
+  __shared__ float cbox[64 * 7];
+  __shared__ float rbox[64 * 7];
+  __shared__ unsigned long long s_cand[64], s_bits[64];
+  __shared__ int s_ex[65];
+  const int lane = threadIdx.x;
+  const int col_size = min(n - cb * 64, 64), row_size = min(n - rb * 64, 64);
+  if (lane < col_size)
+    for (int j = 0; j < 7; ++j) cbox[lane * 7 + j] = boxes[(cb * 64 + lane) * 7 + j];
+  if (lane < row_size)
+    for (int j = 0; j < 7; ++j) rbox[lane * 7 + j] = boxes[(rb * 64 + lane) * 7 + j];
+  __syncthreads();
+  if (NORMAL) {   // axis-aligned overlap is a handful of flops: no pre-test
+    unsigned long long bits = 0ull;
+    if (lane < row_size) {
+      const int start = (rb == cb) ? lane + 1 : 0;
+      for (int i = start; i < col_size; ++i)
+        if (iou_normal(rbox + lane * 7, cbox + i * 7) > thresh) bits |= 1ull << i;
+    }
+    return bits;
+  }
+  unsigned long long cand = 0ull;
+  if (lane < row_size) {
+    const int start = (rb == cb) ? lane + 1 : 0;
+    for (int i = start; i < col_size; ++i)
+      if (!circles_apart(rbox + lane * 7, cbox + i * 7)) cand |= 1ull << i;
+  }
+  // exclusive prefix sum of the candidate counts over the 64 lanes
+  const int cnt = __popcll(cand);
+  int incl = cnt;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int up = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += up;
+  }
+  s_ex[lane] = incl - cnt;
+  if (lane == 63) s_ex[64] = incl;
+  s_cand[lane] = cand;
+  s_bits[lane] = 0ull;
+  __syncthreads();
+  const int total = s_ex[64];
+  for (int base = 0; base < total; base += 64) {
+    const int k = base + lane;
+    if (k < total) {
+      int r = 0;   // the row whose candidates contain number k: largest r with s_ex[r] <= k
+#pragma unroll
+      for (int step = 32; step >= 1; step >>= 1)
+        if (r + step < 64 && s_ex[r + step] <= k) r += step;
+      int j = k - s_ex[r];
+      unsigned long long m = s_cand[r];
+      for (; j > 0; --j) m &= m - 1;   // drop the j lowest candidates
+      const int c = __builtin_ctzll(m);
+      if (iou_bev(rbox + r * 7, cbox + c * 7) > thresh) atomicOr(&s_bits[r], 1ull << c);
+    }
+  }
+  __syncthreads();
+  return s_bits[lane];
+}
+
+// one wave per upper-triangular 64x64 tile
 template <int NORMAL>
 __global__ __launch_bounds__(64) void nms_mask(int n, float thresh, const float* __restrict__ boxes, int col_blocks,
                                                unsigned long long* __restrict__ mask) {
@@ -188,24 +262,9 @@ __global__ __launch_bounds__(64) void nms_mask(int n, float thresh, const float*
   int t = blockIdx.x, rb = 0, rem = col_blocks;
   while (t >= rem) { t -= rem; --rem; ++rb; }
   const int cb = rb + t;
-  __shared__ float cbox[64 * 7];
-  const int lane = threadIdx.x;
-  const int col_size = min(n - cb * 64, 64), row_size = min(n - rb * 64, 64);
-  if (lane < col_size)
-    for (int j = 0; j < 7; ++j) cbox[lane * 7 + j] = boxes[(cb * 64 + lane) * 7 + j];
-  __syncthreads();
-  if (lane < row_size) {
-    const int row = rb * 64 + lane;
-    float a[7];
-    for (int j = 0; j < 7; ++j) a[j] = boxes[row * 7 + j];
-    unsigned long long bits = 0ull;
-    const int start = (rb == cb) ? lane + 1 : 0;
-    for (int i = start; i < col_size; ++i) {
-      const float v = NORMAL ? iou_normal(a, cbox + i * 7) : iou_bev(a, cbox + i * 7);
-      if (v > thresh) bits |= 1ull << i;
-    }
-    mask[static_cast<int64_t>(row) * col_blocks + cb] = bits;
-  }
+  const unsigned long long bits = nms_tile<NORMAL>(n, thresh, boxes, rb, cb);
+  const int row = rb * 64 + static_cast<int>(threadIdx.x);
+  if (row < n) mask[static_cast<int64_t>(row) * col_blocks + cb] = bits;
 }
 
 // Greedy pass of iou3d_nms.cpp:121-135 on the device: one workgroup, remv[] in LDS.
@@ -274,19 +333,6 @@ __global__ __launch_bounds__(256) void nms_greedy(int n, int col_blocks, const u
 // produced in growing chunks of row blocks and each chunk's kernels return at once when their sample already holds K
 // survivors (flag in the workspace): no host round trip, and with a high threshold (few suppressions) a 9000-box
 // proposal set touches 16 of its 141 row blocks.  grid (col_blocks, chunk row blocks, samples).
-// Rotated boxes: a pair whose bounding circles are apart cannot overlap, and at proposal-layer densities ~97 % of the pairs of a
-// 64 x 64 tile are such pairs.  A lane's row box meets the tile's column boxes one by one, so skipping per lane would not help (some
-// lane always has a near partner); instead every lane first collects its near columns as a bit mask (a few flops per pair), the
-// tile's candidates are numbered by a wave prefix sum, and the ~1000-instruction overlap is evaluated for 64 candidates at a time,
-// whatever rows they belong to.  The suppression bits are exactly those of the plain loop (the pre-test only drops pairs whose
-// overlap is zero).
-__device__ __forceinline__ bool circles_apart(const float* a, const float* b) {
-  const float dx = a[0] - b[0], dy = a[1] - b[1];
-  const float ra = 0.5f * sqrtf(a[3] * a[3] + a[4] * a[4]), rb = 0.5f * sqrtf(b[3] * b[3] + b[4] * b[4]);
-  const float reach = (ra + rb) * 1.001f + 1e-4f;   // margin: a pair is dropped only when it is clearly apart
-  return dx * dx + dy * dy > reach * reach;
-}
-
 template <int NORMAL>
 __global__ __launch_bounds__(64) void nms_mask_rows(int n, float thresh, const float* __restrict__ boxes_all, int col_blocks, int rb0,
                                                     unsigned long long* __restrict__ mask_all, int chunk_rows, const int* __restrict__ done) {
@@ -296,63 +342,9 @@ __global__ __launch_bounds__(64) void nms_mask_rows(int n, float thresh, const f
   if (cb < rb || rb >= col_blocks) return;
   const float* boxes = boxes_all + static_cast<int64_t>(s) * n * 7;
   unsigned long long* mask = mask_all + static_cast<int64_t>(s) * chunk_rows * 64 * col_blocks;
-  __shared__ float cbox[64 * 7];
-  __shared__ float rbox[64 * 7];
-  __shared__ unsigned long long s_cand[64], s_bits[64];
-  __shared__ int s_ex[65];
+  const unsigned long long bits = nms_tile<NORMAL>(n, thresh, boxes, rb, cb);
   const int lane = threadIdx.x;
-  const int col_size = min(n - cb * 64, 64), row_size = min(n - rb * 64, 64);
-  if (lane < col_size)
-    for (int j = 0; j < 7; ++j) cbox[lane * 7 + j] = boxes[(cb * 64 + lane) * 7 + j];
-  if (lane < row_size)
-    for (int j = 0; j < 7; ++j) rbox[lane * 7 + j] = boxes[(rb * 64 + lane) * 7 + j];
-  __syncthreads();
-  if (NORMAL) {   // axis-aligned overlap is a handful of flops: no pre-test
-    if (lane < row_size) {
-      unsigned long long bits = 0ull;
-      const int start = (rb == cb) ? lane + 1 : 0;
-      for (int i = start; i < col_size; ++i)
-        if (iou_normal(rbox + lane * 7, cbox + i * 7) > thresh) bits |= 1ull << i;
-      mask[static_cast<int64_t>(blockIdx.y * 64 + lane) * col_blocks + cb] = bits;
-    }
-    return;
-  }
-  unsigned long long cand = 0ull;
-  if (lane < row_size) {
-    const int start = (rb == cb) ? lane + 1 : 0;
-    for (int i = start; i < col_size; ++i)
-      if (!circles_apart(rbox + lane * 7, cbox + i * 7)) cand |= 1ull << i;
-  }
-  // exclusive prefix sum of the candidate counts over the 64 lanes
-  const int cnt = __popcll(cand);
-  int incl = cnt;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int up = __shfl_up(incl, d, 64);
-    if (lane >= d) incl += up;
-  }
-  s_ex[lane] = incl - cnt;
-  if (lane == 63) s_ex[64] = incl;
-  s_cand[lane] = cand;
-  s_bits[lane] = 0ull;
-  __syncthreads();
-  const int total = s_ex[64];
-  for (int base = 0; base < total; base += 64) {
-    const int k = base + lane;
-    if (k < total) {
-      int r = 0;   // the row whose candidates contain number k: largest r with s_ex[r] <= k
-#pragma unroll
-      for (int step = 32; step >= 1; step >>= 1)
-        if (r + step < 64 && s_ex[r + step] <= k) r += step;
-      int j = k - s_ex[r];
-      unsigned long long m = s_cand[r];
-      for (; j > 0; --j) m &= m - 1;   // drop the j lowest candidates
-      const int c = __builtin_ctzll(m);
-      if (iou_bev(rbox + r * 7, cbox + c * 7) > thresh) atomicOr(&s_bits[r], 1ull << c);
-    }
-  }
-  __syncthreads();
-  if (lane < row_size) mask[static_cast<int64_t>(blockIdx.y * 64 + lane) * col_blocks + cb] = s_bits[lane];
+  if (rb * 64 + lane < n) mask[static_cast<int64_t>(blockIdx.y * 64 + lane) * col_blocks + cb] = bits;
 }
 
 // greedy pass over the row blocks [rb0, rb0 + nrb) of one sample per workgroup; remv[] and the survivor count persist in
