@@ -209,3 +209,152 @@ extern "C" int fv2p_anchor_assign(const float* anchor_bev, const float* anchors,
   FV2P_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- first-stage losses in one pass -------------------------------------------------------------------------------------------------
+// AnchorHeadTemplate.get_cls_layer_loss / get_box_reg_layer_loss (pcdet/models/dense_heads/anchor_head_template.py:98-206) with
+// SigmoidFocalClassificationLoss (alpha, gamma = 2), WeightedSmoothL1Loss (beta) on the sin-difference encoded residuals and the
+// direction-bin cross entropy (two bins), normalised per sample by max(#positive anchors, 1) and divided by the batch size: the
+// reference composes ~45 element-wise torch ops over [B, A, .] tensors (and autograd ~70 more in the backward pass); here one
+// kernel leaves the three weighted loss sums and the gradients with respect to the three logit tensors.
+namespace fv2p {
+
+__global__ __launch_bounds__(256) void anchor_pos_count_k(int n_anchor, const int* __restrict__ labels, int* __restrict__ pos) {
+  const int b = blockIdx.y, a = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool t = a < n_anchor && labels[static_cast<long long>(b) * n_anchor + a] > 0;
+  const int c = __popcll(__ballot(t));
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(&pos[b], c);
+}
+
+struct AnchorLossArgs {
+  int n_anchor, batch;
+  const float *cls, *box, *dirs, *reg_t, *anchor_rot;
+  const int *labels, *pos;
+  float alpha, beta, dir_offset, w_cls, w_loc, w_dir;
+  float *dcls, *dbox, *ddirs;
+  double* partial;   // [blocks.x * batch][3]
+};
+
+__global__ __launch_bounds__(256) void anchor_loss_k(AnchorLossArgs p) {
+  const int b = blockIdx.y, a = blockIdx.x * blockDim.x + threadIdx.x;
+  const float norm = fmaxf(static_cast<float>(p.pos[b]), 1.f);
+  double l_cls = 0.0, l_loc = 0.0, l_dir = 0.0;
+  if (a < p.n_anchor) {
+    const long long o = static_cast<long long>(b) * p.n_anchor + a;
+    const int label = p.labels[o];
+    const bool t = label > 0;
+    const float inv_b = 1.f / static_cast<float>(p.batch);
+    // classification: focal loss on the sigmoid, weight 1 / norm for positive and negative anchors, 0 for ignored ones
+    const float x = p.cls[o];
+    const float w = (label == 0 || t) ? 1.f / norm : 0.f;
+    const float pr = 1.f / (1.f + expf(-x));
+    const float aw = t ? p.alpha : 1.f - p.alpha;
+    const float pt = t ? 1.f - pr : pr;
+    const float bce = fmaxf(x, 0.f) - (t ? x : 0.f) + log1pf(expf(-fabsf(x)));
+    l_cls = static_cast<double>(aw * pt * pt * bce * w);
+    const float dpt = t ? -pr * (1.f - pr) : pr * (1.f - pr);
+    p.dcls[o] = aw * w * (2.f * pt * dpt * bce + pt * pt * (pr - (t ? 1.f : 0.f))) * inv_b * p.w_cls;
+    // localisation and direction: positive anchors only
+    float db[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dd[2] = {0.f, 0.f};
+    if (t) {
+      const float* bx = p.box + o * 7;
+      const float* rt = p.reg_t + o * 7;
+      const float rw = 1.f / norm;
+      float loc = 0.f;
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        float d, chain = 1.f;
+        if (j < 6) d = bx[j] - rt[j];
+        else {
+          const float sb = sinf(bx[6]), cb = cosf(bx[6]), sr = sinf(rt[6]), cr = cosf(rt[6]);
+          d = sb * cr - cb * sr;
+          chain = cb * cr + sb * sr;
+        }
+        const float n = fabsf(d);
+        loc += n < p.beta ? 0.5f * n * n / p.beta : n - 0.5f * p.beta;
+        const float g = n < p.beta ? d / p.beta : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+        db[j] = g * chain * rw * inv_b * p.w_loc;
+      }
+      l_loc = static_cast<double>(loc * rw);
+      // direction bin of the target heading (two bins over [0, 2 pi) from dir_offset)
+      const float two_pi = 6.283185307179586f;
+      const float v = rt[6] + p.anchor_rot[a] - p.dir_offset;
+      const float lp = v - floorf(v / two_pi + 0.f) * two_pi;
+      int bin = static_cast<int>(floorf(lp / (two_pi / 2.f)));
+      bin = bin < 0 ? 0 : (bin > 1 ? 1 : bin);
+      const float z0 = p.dirs[o * 2], z1 = p.dirs[o * 2 + 1];
+      const float mz = fmaxf(z0, z1);
+      const float e0 = expf(z0 - mz), e1 = expf(z1 - mz), se = e0 + e1;
+      const float lse = mz + logf(se);
+      l_dir = static_cast<double>((lse - (bin ? z1 : z0)) * rw);
+      dd[0] = (e0 / se - (bin == 0 ? 1.f : 0.f)) * rw * inv_b * p.w_dir;
+      dd[1] = (e1 / se - (bin == 1 ? 1.f : 0.f)) * rw * inv_b * p.w_dir;
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) p.dbox[o * 7 + j] = db[j];
+    p.ddirs[o * 2] = dd[0];
+    p.ddirs[o * 2 + 1] = dd[1];
+  }
+  // block sums in double, one partial row per block (summed in block order by the reduce launch: deterministic)
+  __shared__ double s_red[3][4];
+  double v3[3] = {l_cls, l_loc, l_dir};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    double v = v3[c];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    if ((threadIdx.x & 63) == 0) s_red[c][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const double v = s_red[threadIdx.x][0] + s_red[threadIdx.x][1] + s_red[threadIdx.x][2] + s_red[threadIdx.x][3];
+    p.partial[(static_cast<long long>(b) * gridDim.x + blockIdx.x) * 3 + threadIdx.x] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void anchor_loss_reduce_k(int rows, int batch, const double* __restrict__ partial, float w_cls, float w_loc, float w_dir,
+                                                            float* __restrict__ loss) {
+  __shared__ double s[3][256];
+  double acc[3] = {0.0, 0.0, 0.0};
+  for (int r = threadIdx.x; r < rows; r += 256)
+    for (int c = 0; c < 3; ++c) acc[c] += partial[static_cast<long long>(r) * 3 + c];
+  for (int c = 0; c < 3; ++c) s[c][threadIdx.x] = acc[c];
+  __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if (threadIdx.x < d)
+      for (int c = 0; c < 3; ++c) s[c][threadIdx.x] += s[c][threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    loss[0] = static_cast<float>((s[0][0] * w_cls + s[1][0] * w_loc + s[2][0] * w_dir) / batch);
+    loss[1] = static_cast<float>(s[0][0] / batch * w_cls);
+    loss[2] = static_cast<float>(s[1][0] / batch * w_loc);
+    loss[3] = static_cast<float>(s[2][0] / batch * w_dir);
+  }
+}
+
+}  // namespace fv2p
+
+extern "C" size_t fv2p_anchor_loss_ws_bytes(int batch, int n_anchor) {
+  const size_t blocks = static_cast<size_t>((n_anchor + 255) / 256) * (batch > 0 ? batch : 1);
+  return blocks * 3 * sizeof(double) + 64 * sizeof(int);
+}
+
+extern "C" int fv2p_anchor_loss(const float* cls, const float* box, const float* dirs, const int* labels, const float* reg_t,
+                                const float* anchor_rot, int batch, int n_anchor, float alpha, float beta, float dir_offset, float w_cls,
+                                float w_loc, float w_dir, float* loss4, float* dcls, float* dbox, float* ddirs, void* ws, size_t ws_bytes,
+                                fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FV2P_REQUIRE(batch >= 1 && batch <= 64 && n_anchor >= 1, FV2P_EINVAL, "anchor_loss: 1..64 samples, at least one anchor");
+  FV2P_REQUIRE(cls && box && dirs && labels && reg_t && anchor_rot && loss4 && dcls && dbox && ddirs && ws, FV2P_EINVAL, "anchor_loss: null pointer");
+  FV2P_REQUIRE(ws_bytes >= fv2p_anchor_loss_ws_bytes(batch, n_anchor), FV2P_EINVAL, "anchor_loss: workspace too small");
+  const unsigned bx = static_cast<unsigned>((n_anchor + 255) / 256);
+  int* pos = static_cast<int*>(ws);
+  double* partial = reinterpret_cast<double*>(static_cast<char*>(ws) + 64 * sizeof(int));
+  FV2P_HIP(hipMemsetAsync(pos, 0, 64 * sizeof(int), stream));
+  hipLaunchKernelGGL(anchor_pos_count_k, dim3(bx, batch), dim3(256), 0, stream, n_anchor, labels, pos);
+  AnchorLossArgs a{n_anchor, batch, cls, box, dirs, reg_t, anchor_rot, labels, pos, alpha, beta, dir_offset, w_cls, w_loc, w_dir, dcls, dbox, ddirs, partial};
+  hipLaunchKernelGGL(anchor_loss_k, dim3(bx, batch), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(anchor_loss_reduce_k, dim3(1), dim3(256), 0, stream, static_cast<int>(bx) * batch, batch, partial, w_cls, w_loc, w_dir, loss4);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}

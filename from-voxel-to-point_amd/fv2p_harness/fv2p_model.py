@@ -233,6 +233,28 @@ class BEVBackbone(nn.Module):
         return torch.cat(ups, dim=1)
 
 
+class AnchorLossFn(torch.autograd.Function):
+    """fv2p_anchor_loss: focal + smooth-L1 (sin-difference heading) + direction-bin losses of AnchorHeadTemplate.get_loss
+    (anchor_head_template.py:98-206) for a batch; the forward launch leaves the gradients with respect to the three logit tensors."""
+
+    @staticmethod
+    def forward(ctx, cls, box, dirs, labels, reg_t, anchor_rot, cfg):
+        b, a = labels.shape
+        out = cls.new_empty(4)
+        dcls, dbox, ddirs = torch.empty_like(cls), torch.empty_like(box), torch.empty_like(dirs)
+        with _nat.device_guard(cls.device):
+            ws = _nat.workspace(int(_nat.lib().fv2p_anchor_loss_ws_bytes(b, a)), cls.device)
+            _nat.call("fv2p_anchor_loss", cls, box, dirs, labels, reg_t, anchor_rot, b, a, 0.25, 1.0 / 9.0, float(cfg.dir_offset),
+                      float(cfg.rpn_w["cls"]), float(cfg.rpn_w["loc"]), float(cfg.rpn_w["dir"]), out, dcls, dbox, ddirs, ws, ws.numel(), _nat.stream())
+        ctx.save_for_backward(dcls, dbox, ddirs)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        dcls, dbox, ddirs = ctx.saved_tensors
+        return dcls * g, dbox * g, ddirs * g, None, None, None, None
+
+
 class AnchorHead(nn.Module):
     """AnchorHeadSingle + AxisAlignedTargetAssigner for one class (anchor_head_single.py, anchor_head_template.py,
     axis_aligned_target_assigner.py:132-212), targets assigned for the whole batch at once."""
@@ -259,6 +281,7 @@ class AnchorHead(nn.Module):
         a[..., 6] = torch.tensor(cfg.anchor_rotations).view(1, 1, na)
         self.register_buffer("anchors", a.view(-1, 7), persistent=False)
         self.register_buffer("anchor_bev", nearest_bev_boxes(a.view(-1, 7)), persistent=False)
+        self.register_buffer("anchor_rot", a.view(-1, 7)[:, 6].contiguous(), persistent=False)
 
     @torch.no_grad()
     def assign(self, gt):
@@ -308,6 +331,18 @@ class AnchorHead(nn.Module):
         box = self.conv_box(feat).permute(0, 2, 3, 1).reshape(b, -1, 7)
         dirs = self.conv_dir_cls(feat).permute(0, 2, 3, 1).reshape(b, -1, cfg.num_dir_bins)
         labels, reg_t = self.assign(gt)
+        if cls.is_cuda and cfg.num_dir_bins == 2:
+            # the three losses and their logit gradients in one pass (csrc/targets.hip); anchor_losses_tensor_ops states the same
+            # in torch ops (and is the CPU path)
+            loss = AnchorLossFn.apply(cls.contiguous(), box.contiguous(), dirs.contiguous(), labels.contiguous(), reg_t.contiguous(),
+                                      self.anchor_rot, cfg)
+        else:
+            loss = self.anchor_losses_tensor_ops(cls, box, dirs, labels, reg_t)
+        return loss, cls.detach().squeeze(-1), self.decode_proposals(box, dirs)
+
+    def anchor_losses_tensor_ops(self, cls, box, dirs, labels, reg_t):
+        cfg = self.cfg
+        b = cls.shape[0]
         pos = labels > 0
         norm = pos.sum(1, keepdim=True).float().clamp_min(1.0)
         # classification (anchor_head_template.py:98-131)
@@ -326,14 +361,18 @@ class AnchorHead(nn.Module):
         dir_t = dir_t.clamp(0, cfg.num_dir_bins - 1)
         dir_w = pos.float() / pos.float().sum(-1, keepdim=True).clamp_min(1.0)
         loss_dir = (F.cross_entropy(dirs.permute(0, 2, 1), dir_t, reduction="none") * dir_w).sum() / b * cfg.rpn_w["dir"]
-        # proposals for the second stage (generate_predicted_boxes :222-275)
+        return loss_cls + loss_loc + loss_dir
+
+    def decode_proposals(self, box, dirs):
+        """Proposals for the second stage (generate_predicted_boxes, anchor_head_template.py:222-275)."""
+        cfg = self.cfg
         with torch.no_grad():
             boxes = residual_decode(box.detach(), self.anchors[None])
             period = TWO_PI / cfg.num_dir_bins
             rot = limit_period(boxes[..., 6] - cfg.dir_offset, cfg.dir_limit_offset, period)
             rot = rot + cfg.dir_offset + period * dirs.detach().argmax(-1).to(boxes.dtype)
             boxes = torch.cat((boxes[..., :6], rot.unsqueeze(-1)), dim=-1)
-        return loss_cls + loss_loc + loss_dir, cls.detach().squeeze(-1), boxes
+        return boxes
 
 
 # ---------------------------------------------------------------- voxel-to-point decoder --------------

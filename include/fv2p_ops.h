@@ -283,6 +283,16 @@ int fv2p_anchor_assign(const float* anchor_bev, const float* anchors, int n_anch
                        int gt_w, float matched_thr, float unmatched_thr, int* labels, float* reg, void* ws, size_t ws_bytes,
                        fv2p_stream_t stream);
 
+/* First-stage losses of a batch in one pass (AnchorHeadTemplate.get_cls_layer_loss / get_box_reg_layer_loss,
+ * pcdet/models/dense_heads/anchor_head_template.py:98-206; SigmoidFocalClassificationLoss with gamma = 2, WeightedSmoothL1Loss on
+ * the sin-difference encoded residuals, two direction bins): cls [B,A,1], box [B,A,7], dirs [B,A,2] logits, labels [B,A] i32 and
+ * reg_t [B,A,7] from fv2p_anchor_assign, anchor_rot [A].  loss4 = {total, cls, loc, dir} (already weighted and divided by B);
+ * dcls / dbox / ddirs = d total / d logits. */
+size_t fv2p_anchor_loss_ws_bytes(int batch, int n_anchor);
+int fv2p_anchor_loss(const float* cls, const float* box, const float* dirs, const int* labels, const float* reg_t, const float* anchor_rot,
+                     int batch, int n_anchor, float alpha, float beta, float dir_offset, float w_cls, float w_loc, float w_dir, float* loss4,
+                     float* dcls, float* dbox, float* ddirs, void* ws, size_t ws_bytes, fv2p_stream_t stream);
+
 /* ---- A15 / A18: point-in-box, RoI-aware voxel pooling, RoI point pooling ------------------------
  * Replace roiaware_pool3d_cuda.{points_in_boxes_gpu, points_in_boxes_cpu, forward, backward}
  * (pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:29-177, kernels roiaware_pool3d_kernel.cu:16-359) and

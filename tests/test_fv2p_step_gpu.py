@@ -268,3 +268,30 @@ def test_anchor_assignment_kernel_equals_its_tensor_formulation(gpu):
     assert torch.equal(lab, lab_t)
     assert int((lab > 0).sum()) > 0 and int((lab == -1).sum()) > 0 and int((lab[2] != 0).sum()) == 0
     assert float((reg - reg_t).abs().max()) < 1e-6
+
+
+@pytest.mark.gpu
+def test_anchor_loss_kernel_equals_its_tensor_formulation(gpu):
+    """fv2p_anchor_loss (focal + smooth-L1 with the sin-difference heading + direction bins, anchor_head_template.py:98-206) against
+    AnchorHead.anchor_losses_tensor_ops: the loss within 1e-5, the gradients of the three logit tensors within 1e-4 (relative L2),
+    also for a sample without positive anchors."""
+    from fv2p_harness.fv2p_model import AnchorHead, AnchorLossFn
+    torch.manual_seed(4)
+    head = AnchorHead(SmallFV2P, 128).to(gpu)
+    boxes = []
+    for s in range(3):
+        _, bx = synth.lidar_cloud(21 + s, 2048, pc_range=np.array(SmallFV2P.point_cloud_range, np.float32), return_boxes=True)
+        boxes.append(bx)
+    boxes[1] = boxes[1][:0]
+    gt = pad_gt_boxes(boxes, gpu, max_gt=48)
+    labels, reg_t = head.assign(gt)
+    a = labels.shape[1]
+    mk = lambda c, scale: (torch.randn(3, a, c, device=gpu) * scale).requires_grad_(True)
+    cls, box, dirs = mk(1, 2.0), mk(7, 0.5), mk(2, 1.0)
+    want = head.anchor_losses_tensor_ops(cls, box, dirs, labels, reg_t)
+    gw = torch.autograd.grad(want, (cls, box, dirs))
+    got = AnchorLossFn.apply(cls, box, dirs, labels, reg_t, head.anchor_rot, SmallFV2P)
+    gg = torch.autograd.grad(got * 1.0, (cls, box, dirs))
+    assert abs(got.item() - want.item()) < 1e-5 * max(1.0, abs(want.item()))
+    for x, y in zip(gg, gw):
+        assert float((x - y).norm() / y.norm().clamp_min(1e-12)) < 1e-4
