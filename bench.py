@@ -56,7 +56,8 @@ def parse():
                     help="input-pipeline thread prepares batch t+1 while batch t trains: 2 = voxelisation + rulebooks, 1 = voxelisation, 0 = all in line")
     ap.add_argument("--ahead", type=int, default=0,
                     help="no thread: batch t+1 is prepared on a side stream between forward and backward of step t (2 = voxelisation + rulebooks, 1 = voxelisation); FV2P workloads default to 2")
-    ap.add_argument("--watchdog", type=int, default=900, help="seconds the measurement may take before it is stopped and repeated in line (0: run in this process, no limit)")
+    ap.add_argument("--watchdog", type=int, default=600, help="seconds a supervised measurement may stay silent outside its step loop before it is stopped and repeated with the side-stream arrangements off (0: run in this process, unsupervised)")
+    ap.add_argument("--stall", type=int, default=60, help="seconds a supervised measurement may stay silent inside its step loop")
     ap.add_argument("--dense-stream", type=int, default=1, help="FV2P workloads: BEV backbone + anchor head + RoI preparation on a side stream beside decoder + point head (0: the point branch on a side stream after the preparation)")
     ap.add_argument("--fps-ahead", type=int, default=1, help="FV2P workloads: key points of batch t+1 are sampled (FPS side stream) during the backward pass of step t")
     ap.add_argument("--ahead-priority", type=int, default=-1, help="stream priority of the --ahead side stream (-1 = high: a hardware queue of its own)")
@@ -104,20 +105,44 @@ def parse():
 SAFE_FLAGS = ["--fps-ahead", "0", "--ahead", "0", "--prefetch", "0", "--dense-stream", "0"]   # every side-stream input pipeline off: the plain in-line step
 
 
-def launch_ranks(args):
-    """`python bench.py [--gpus N]` outside a launcher: run the measurement as a child process tree (N ranks under
-    torch.distributed.run, or one plain process), relay its exit code.  This process has not initialised the GPU (no torch.cuda
-    call yet) and it spawns, never execs.  The child runs under a time limit (--watchdog seconds): a step that overlaps four
-    streams can in principle hang the device queue (one arrangement tried this round did), and a hung benchmark
-    reports nothing — on a timeout the tree is killed and the measurement repeated once with the side-stream pipelines off."""
+def beat(phase):
+    """Heartbeat of a supervised measurement (see supervise): "<time> <phase>" into the file the supervisor watches."""
+    path = os.environ.get("FV2P_BENCH_HEARTBEAT")
+    if path:
+        try:
+            with open(path, "w") as f:
+                f.write(f"{time.time()} {phase}")
+        except OSError:
+            pass
+
+
+def supervise(args):
+    """Runs the measurement as a child process and watches its heartbeat.  Two places use it:
+
+    * `python bench.py [--gpus N]` outside a launcher: the child is the N ranks under torch.distributed.run, or one plain process
+      (this process has not initialised the GPU and it spawns, never execs);
+    * a rank started by somebody else's launcher (RANK set): the rank process stays a supervisor and the real rank is its child,
+      with the launcher's environment.
+
+    Why: a step that overlaps several HIP streams can hang the device queue — measured this round: one arrangement always, the
+    arrangement in use on about one box in six (every run on such a box, none on the others; it disappears with 8 hardware
+    queues, which cost 50 % of the step).  A hung benchmark reports nothing, so: the child writes a heartbeat after every step;
+    when a stepping child is silent for --stall seconds (or a child that has not started stepping for --watchdog seconds) its
+    process tree is killed — only what this call created — and the measurement is repeated once with the side-stream arrangements off
+    (SAFE_FLAGS: the plain point-branch stream, sampling in the step; 38.4 instead of 34.3 ms per step)."""
     import signal
     import socket
     import subprocess
-    env = dict(os.environ, FV2P_BENCH_INNER="1")
+    import tempfile
+    ranked = "RANK" in os.environ
     attempts = [[]] + ([SAFE_FLAGS] if args.workload in ("fv2p", "fv2p-waymo") and args.watchdog > 0 else [])
     rc = 1
     for extra in attempts:
-        if args.gpus > 1:
+        hb = tempfile.NamedTemporaryFile(prefix="fv2p_bench_hb_", delete=False)
+        hb.close()
+        os.unlink(hb.name)
+        env = dict(os.environ, FV2P_BENCH_INNER="1", FV2P_BENCH_HEARTBEAT=hb.name)
+        if args.gpus > 1 and not ranked:
             with socket.socket() as sk:
                 sk.bind(("127.0.0.1", 0))
                 port = sk.getsockname()[1]
@@ -126,27 +151,57 @@ def launch_ranks(args):
         else:
             cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + extra
         child = subprocess.Popen(cmd, env=env, start_new_session=True)
-        try:
-            return child.wait(timeout=args.watchdog if args.watchdog > 0 else None)
-        except subprocess.TimeoutExpired:
-            print(f"[bench] no result after {args.watchdog} s: stopping the run" + ("" if extra else " and repeating it with " + " ".join(SAFE_FLAGS)), file=sys.stderr)
-            # the tree this call created, nothing else: the launcher's workers may sit in sessions of their own
-            try:
-                import psutil
-                tree = psutil.Process(child.pid).children(recursive=True)
-            except Exception:
-                tree = []
-            for proc in tree:
-                try:
-                    proc.kill()
-                except Exception:
-                    pass
+
+        def stop(*_):   # the launcher above us ends the job: take the child along
             try:
                 os.killpg(child.pid, signal.SIGKILL)
             except ProcessLookupError:
                 pass
-            child.wait()
-            rc = 124
+            os._exit(143)
+        previous = signal.signal(signal.SIGTERM, stop) if ranked else None
+        started, hung = time.time(), None
+        while child.poll() is None:
+            time.sleep(0.5)
+            if args.watchdog <= 0:
+                continue
+            now = time.time()
+            try:
+                with open(hb.name) as f:
+                    t, phase = f.read().split(None, 1)
+                limit = args.stall if phase.strip() in ("step", "sync") else args.watchdog
+                if now - float(t) > limit:
+                    hung = f"no heartbeat for {limit} s in phase '{phase.strip()}'"
+            except (OSError, ValueError):
+                if now - started > args.watchdog:
+                    hung = f"no heartbeat within {args.watchdog} s"
+            if hung:
+                break
+        if previous is not None:
+            signal.signal(signal.SIGTERM, previous)
+        try:
+            os.unlink(hb.name)
+        except OSError:
+            pass
+        if hung is None:
+            return child.returncode
+        print(f"[bench] {hung}: stopping the run" + ("" if extra else " and repeating it with " + " ".join(SAFE_FLAGS)), file=sys.stderr)
+        # the tree this call created, nothing else: the launcher's workers may sit in sessions of their own
+        try:
+            import psutil
+            tree = psutil.Process(child.pid).children(recursive=True)
+        except Exception:
+            tree = []
+        for proc in tree:
+            try:
+                proc.kill()
+            except Exception:
+                pass
+        try:
+            os.killpg(child.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        child.wait()
+        rc = 124
     return rc
 
 
@@ -688,15 +743,23 @@ def main():
         import faulthandler
         import signal
         faulthandler.register(signal.SIGUSR1, all_threads=True)
-    if "RANK" not in os.environ and "FV2P_BENCH_INNER" not in os.environ and (args.gpus > 1 or (args.watchdog > 0 and not args.dry_run)):
-        sys.exit(launch_ranks(args))
-    if os.environ.get("FV2P_BENCH_TEST_HANG") and args.fps_ahead:   # test hook of the watchdog (tests/test_dist_cpu.py)
+    if "FV2P_BENCH_INNER" not in os.environ:
+        outside = "RANK" not in os.environ
+        guarded = args.watchdog > 0 and args.workload in ("fv2p", "fv2p-waymo") and (not args.dry_run or os.environ.get("FV2P_BENCH_TEST_HANG"))
+        if (outside and args.gpus > 1) or guarded:
+            sys.exit(supervise(args))
+    beat("start")
+    if os.environ.get("FV2P_BENCH_TEST_HANG") == "1" and args.fps_ahead:   # test hook of the watchdog (tests/test_dist_cpu.py): a run that stops stepping
+        beat("step")
         time.sleep(10 ** 6)
     from fv2p_harness import dist_utils
     rank, world, local = dist_utils.env_world()
     assert world == args.gpus, f"--gpus {args.gpus} but the launcher started {world} ranks"
     if args.dry_run:
         dist_utils.init_distributed("gloo")
+        if os.environ.get("FV2P_BENCH_TEST_HANG") == "2" and args.fps_ahead:   # ... stops stepping with its process group (and rank 0's store) alive
+            beat("step")
+            time.sleep(10 ** 6)
         t = dist_utils.max_over_ranks(float(rank + 1))
         n = dist.get_world_size() if dist.is_initialized() else 1
         if rank == 0:
@@ -723,8 +786,10 @@ def main():
     model, step, voxelize, pool = build(args, device, rank, world)
     for i in range(args.warmup):
         step(i)
+        beat("step")
     dist_utils.barrier()
     torch.cuda.synchronize()
+    beat("step")
     if args.phases and rank == 0:
         acc = {}
         for i in range(20):
@@ -767,8 +832,11 @@ def main():
     stamps = []
     for i in range(args.steps):
         step(args.warmup + i)
+        if (i & 3) == 3:
+            beat("step")
         if args.step_times:
             stamps.append(time.perf_counter())
+    beat("sync")
     if prof is not None:
         prof.disable()
         import pstats
@@ -776,6 +844,7 @@ def main():
     dist_utils.barrier()
     torch.cuda.synchronize()
     dt = dist_utils.max_over_ranks(time.perf_counter() - t0, device)
+    beat("post")   # probes and the CPU baseline follow: long host phases
     if rank == 0:   # leak check at a glance: what the caching allocator holds after the timed steps
         print("[memory] allocated %.1f MB, peak %.1f MB, reserved %.1f MB" % (torch.cuda.memory_allocated(device) / 2**20,
               torch.cuda.max_memory_allocated(device) / 2**20, torch.cuda.memory_reserved(device) / 2**20), file=sys.stderr)
@@ -805,6 +874,9 @@ def main():
         }
         if args.workload in ("fv2p", "fv2p-waymo") and args.fps_ahead:
             result["config"]["input_pipeline"] += "; key points (FPS) of batch t+1 sampled on a side stream during the backward pass of step t"
+        if args.workload in ("fv2p", "fv2p-waymo"):
+            result["config"]["streams"] = ("dense branch (BEV backbone, anchor head, RoI preparation) on a side stream beside decoder + point head" if args.dense_stream
+                                           else "decoder + point head on a side stream after the RoI preparation" if args.point_stream else "one stream")
         if args.workload == "fv2p-waymo":
             result["metric"] = "point clouds/sec fwd+bwd (FV2P, Waymo shape: 180k points, 0.1 m voxels)"
             if not args.no_roofline:

@@ -123,8 +123,31 @@ def test_bench_watchdog_repeats_a_hung_run_in_line():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "FV2P_BENCH_INNER")}
     env["FV2P_BENCH_TEST_HANG"] = "1"
     bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
-    out = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-run", "--watchdog", "20"], env=env, capture_output=True, text=True, timeout=300)
+    out = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-run", "--watchdog", "60", "--stall", "5"], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "repeating it with --fps-ahead 0" in out.stderr
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    assert json.loads(line)["n_gpus"] == 2
+
+
+def test_ranks_of_an_outside_launcher_supervise_themselves():
+    """Under somebody else's launcher (RANK set) every rank process stays a supervisor and runs the real rank as its child: when the
+    ranks stop stepping — here with their process group and rank 0's store alive — each supervisor stops its child and starts it
+    again with the side-stream arrangements off; the second set of ranks meets at the same master port and reports."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "FV2P_BENCH_INNER")}
+    env["FV2P_BENCH_TEST_HANG"] = "2"
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           bench, "--gpus", "2", "--dry-run", "--watchdog", "60", "--stall", "5"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert out.stderr.count("repeating it with --fps-ahead 0") == 2
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     assert json.loads(line)["n_gpus"] == 2
