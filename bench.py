@@ -335,8 +335,7 @@ def build_fv2p_step(args, device, rank, world):
     cfg = FV2PWaymoConfig if waymo else FV2PConfig
     if not args.point_stream:
         cfg = type("Cfg", (cfg,), {"point_branch_stream": False})
-    if not args.dense_stream:
-        cfg = type("Cfg", (cfg,), {"dense_branch_stream": False})
+    cfg = type("Cfg", (cfg,), {"dense_branch_stream": bool(args.dense_stream)})
     vsize, prange = np.array(cfg.voxel_size, np.float32), np.array(cfg.point_cloud_range, np.float32)
     torch.manual_seed(0)
     model = FV2PDetector(cfg).to(device)

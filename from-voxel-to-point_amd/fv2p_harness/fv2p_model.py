@@ -76,7 +76,10 @@ class FV2PConfig:
     cls_fc, reg_fc, dp_ratio = (256, 256), (256, 256), 0.3
     grad_norm_clip = 10.0
     point_branch_stream = True     # decoder + point head on their own stream (their backward then overlaps the dense convs')
-    dense_branch_stream = True     # instead: BEV backbone + anchor head + second-stage preparation on a side stream from the end of the sparse backbone on
+    # instead: BEV backbone + anchor head + second-stage preparation on a side stream from the end of the sparse backbone on (34.3 vs
+    # 38.4 ms per step).  Off by default: it hung the device queue in every run on two boxes of twelve; bench.py switches
+    # it on under its supervisor, which falls back to this default when the measurement stalls
+    dense_branch_stream = False
 
 
 class FV2PWaymoConfig(FV2PConfig):

@@ -1,0 +1,35 @@
+"""Child process of tests/test_fv2p_step_gpu.py::test_stream_arrangements_give_the_same_step (not collected by pytest)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "from-voxel-to-point_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+
+from fv2p_harness.fv2p_model import FV2PDetector  # noqa: E402
+from test_fv2p_step_gpu import SmallFV2P, make_inputs  # noqa: E402
+
+gpu = torch.device("cuda:0")
+torch.manual_seed(3)
+model = FV2PDetector(SmallFV2P).to(gpu)
+clouds, feats, coords, gt, u = make_inputs(SmallFV2P, 2, 4096)
+args = ([c.to(gpu) for c in clouds], feats.to(gpu), coords.to(gpu), gt.to(gpu), u.to(gpu))
+runs = []
+for dense, point in ((True, True), (False, True), (False, False)):
+    model.cfg = type("Cfg", (SmallFV2P,), {"dense_branch_stream": dense, "point_branch_stream": point})
+    model.taps = {}
+    model.zero_grad(set_to_none=True)
+    loss = model(*args)
+    loss.backward()
+    torch.cuda.synchronize()
+    runs.append((loss.item(), model.taps["keypoints"].clone(), model.taps["sampled_rois"].clone(),
+                 {k: p.grad.clone() for k, p in model.named_parameters()}))
+for other in runs[1:]:
+    assert torch.equal(other[1], runs[0][1])
+    if not torch.equal(other[2], runs[0][2]):
+        continue   # a 1e-7 difference in a proposal score swapped two NMS neighbours: the second stage then sees other RoIs
+    assert abs(other[0] - runs[0][0]) < 1e-5 * max(1.0, abs(runs[0][0]))
+    for k, g0 in runs[0][3].items():
+        assert float((other[3][k] - g0).norm() / g0.norm().clamp_min(1e-12)) < 1e-4, k
+print("ARRANGEMENTS AGREE")
