@@ -124,9 +124,10 @@ def supervise(args):
     * a rank started by somebody else's launcher (RANK set): the rank process stays a supervisor and the real rank is its child,
       with the launcher's environment.
 
-    Why: a step that overlaps several HIP streams can hang the device queue — measured this round: one arrangement always, the
-    arrangement in use on about one box in six (every run on such a box, none on the others; it disappears with 8 hardware
-    queues, which cost 50 % of the step).  A hung benchmark reports nothing, so: the child writes a heartbeat after every step;
+    Why: a step that overlaps several HIP streams can hang the device queue — measured this round: one arrangement always (it
+    disappears with 8 hardware queues, which cost 50 % of the step), the arrangement in use during MIOpen's first-call solver
+    search on cold caches (one fresh box in three, until build_fv2p_step took those steps on one stream).  A hung benchmark
+    reports nothing, so: the child writes a heartbeat after every step;
     when a stepping child is silent for --stall seconds (or a child that has not started stepping for --watchdog seconds) its
     process tree is killed — only what this call created — and the measurement is repeated once with the side-stream arrangements off
     (SAFE_FLAGS: the plain point-branch stream, sampling in the step; 38.4 instead of 34.3 ms per step)."""
