@@ -138,11 +138,11 @@ def supervise(args):
     ranked = "RANK" in os.environ
     attempts = [[]] + ([SAFE_FLAGS] if args.workload in ("fv2p", "fv2p-waymo") and args.watchdog > 0 else [])
     rc = 1
-    for extra in attempts:
+    for attempt, extra in enumerate(attempts):
         hb = tempfile.NamedTemporaryFile(prefix="fv2p_bench_hb_", delete=False)
         hb.close()
         os.unlink(hb.name)
-        env = dict(os.environ, FV2P_BENCH_INNER="1", FV2P_BENCH_HEARTBEAT=hb.name)
+        env = dict(os.environ, FV2P_BENCH_INNER="1", FV2P_BENCH_HEARTBEAT=hb.name, FV2P_BENCH_ATTEMPT=str(attempt))
         if args.gpus > 1 and not ranked:
             with socket.socket() as sk:
                 sk.bind(("127.0.0.1", 0))

@@ -18,6 +18,12 @@ def init_distributed(backend, device=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+        attempt = os.environ.get("FV2P_BENCH_ATTEMPT", "0")
+        if attempt != "0":
+            # ranks restarted by bench.py's supervisor meet at the launcher's store again: its keys of the first attempt (the dead
+            # ranks' addresses) are still there, so this attempt talks under a prefix of its own
+            store, rank, world = next(iter(dist.rendezvous("env://", rank=rank, world_size=world)))
+            kw.update(store=dist.PrefixStore(f"fv2p_attempt_{attempt}", store), rank=rank, world_size=world)
         dist.init_process_group(backend, **kw)
     return rank, world
 
