@@ -96,6 +96,12 @@ def parse():
         args.steps, args.warmup = 30, (args.warmup if "--warmup" in sys.argv else 5)
     if args.workload == "fv2p" and "--prefetch" not in sys.argv:
         args.prefetch = 0   # measured: the input-pipeline thread does not pay here (65.3 vs 63.7 ms per step); the step is not launch bound
+    if args.gpus > 1 and "--dense-stream" not in sys.argv:
+        # the dense-branch arrangement is fast only while the process drives no further side stream (with the input-pipeline stream or
+        # the point-branch stream beside it the step takes 54 - 63 instead of 34 ms, four hardware queues); a rank of a multi-GPU job
+        # also drives RCCL's stream, which could not be measured on the one-GPU boxes of this round: the arrangement that ran beside
+        # seven streams without loss (point branch after the RoI preparation, 38.4 ms) is the default there
+        args.dense_stream = 0
     # --ahead 2 measured no better than in line once the blocking host copies were gone (42.4 vs 41.2 ms per step): off by default
     if args.steps == 300 and args.workload == "fv2p" and "--steps" not in sys.argv:
         args.steps, args.warmup = 40, (args.warmup if "--warmup" in sys.argv else 5)
