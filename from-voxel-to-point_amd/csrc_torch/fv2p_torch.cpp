@@ -472,11 +472,15 @@ std::vector<at::Tensor> voxelize_batch_mean(const std::vector<at::Tensor>& cloud
       evs->second.push_back(e);
     }
   }
+  // contiguous copies (if any) are made on the calling stream BEFORE the fork event and live until the function returns: the
+  // per-cloud streams read them behind that event, and the calling stream is joined with them again below
+  std::vector<at::Tensor> dense_clouds(nb);
+  for (size_t b = 0; b < nb; ++b) dense_clouds[b] = clouds[b].contiguous();
   if (cloud_streams) TORCH_CHECK(hipEventRecord(evs->first, main.stream()) == hipSuccess, "hipEventRecord failed");
   std::vector<at::Tensor> vox(nb), coors(nb), num(nb);
   at::Tensor counts = at::empty({static_cast<int64_t>(nb)}, first.options().dtype(at::kInt));
   for (size_t b = 0; b < nb; ++b) {
-    const at::Tensor pts = clouds[b].contiguous();
+    const at::Tensor& pts = dense_clouds[b];
     require_f32_cuda(pts, "points");
     const int64_t n = pts.size(0), ndim = pts.size(1);
     // per-cloud outputs are allocated on the calling stream and handed to the cloud's stream behind the fork event

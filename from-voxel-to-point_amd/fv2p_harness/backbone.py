@@ -54,7 +54,8 @@ def bn_act(bn, feats, relu=None):
 def _conv_bn(conv, bn, relu, x):
     """conv -> BatchNorm1d (-> ReLU) the way SparseSequential runs the reference's post_act_block: offered to the conv as one
     fused call (BatchNorm sums taken in the conv epilogue), else module by module."""
-    out = conv(x, _post=(bn, relu))
+    hooked = bool(conv._forward_hooks or conv._forward_pre_hooks or conv._backward_hooks)   # a hook on the conv sees the conv's own output
+    out = conv(x) if hooked else conv(x, _post=(bn, relu))
     if getattr(out, "_fv2p_post_done", False):
         out._fv2p_post_done = False
     else:

@@ -73,7 +73,8 @@ class SparseSequential(SparseModule):
             if is_spconv_module(module):
                 assert isinstance(input, SparseConvTensor)
                 self._sparity_dict[k] = input.sparity
-                if is_sparse_conv(module) and i < len(items) and isinstance(items[i][1], nn.BatchNorm1d) and input.indices.shape[0] != 0:
+                hooked = bool(module._forward_hooks or module._forward_pre_hooks or module._backward_hooks)   # a hook on the conv must see the conv's own output
+                if is_sparse_conv(module) and not hooked and i < len(items) and isinstance(items[i][1], nn.BatchNorm1d) and input.indices.shape[0] != 0:
                     # conv -> BatchNorm1d (-> ReLU), the reference's post_act_block: offered to the conv as one fused call
                     relu = items[i + 1][1] if i + 1 < len(items) and isinstance(items[i + 1][1], nn.ReLU) else None
                     input = module(input, _post=(items[i][1], relu))

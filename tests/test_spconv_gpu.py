@@ -9,6 +9,7 @@ import ctypes
 import numpy as np
 import pytest
 import torch
+import torch.nn as nn
 import torch.nn.functional as F
 
 import oracle
@@ -627,3 +628,17 @@ def test_backward_data_of_strided_conv_with_parity_ordered_tiles(gpu):
             assert close(dst, ref) if (mixed and p is not None) else torch.equal(dst, ref)
             outs.append(stats.sum(0).cpu().numpy())
         assert np.allclose(outs[0], outs[1], rtol=1e-5 if mixed else 1e-11, atol=1e-3 if mixed else 1e-9)
+
+
+def test_a_hook_on_a_conv_sees_the_convs_own_output(gpu):
+    """SparseSequential offers conv -> BatchNorm1d -> ReLU to the conv as one fused call; a forward hook on the conv (feature taps,
+    the roofline probe) must still see what the reference's hook sees: the conv output before BatchNorm / ReLU."""
+    ind, feats, x = make_input(9, 2, [9, 20, 18], 900, 16, gpu)
+    seq = spconv.SparseSequential(spconv.SubMConv3d(16, 32, 3, padding=1, bias=False, indice_key="s"), nn.BatchNorm1d(32), nn.ReLU()).to(gpu)
+    plain = seq(x).features.clone()
+    seen = []
+    h = list(seq.children())[0].register_forward_hook(lambda m, i, o: seen.append(o.features.clone()))
+    hooked = seq(x).features.clone()
+    h.remove()
+    assert float((hooked - plain).abs().max()) < 1e-5 * float(plain.abs().max())       # same result either way
+    assert float(seen[0].min()) < 0 and not torch.equal(seen[0], hooked)             # ... and the hook saw pre-BN / pre-ReLU values
