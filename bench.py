@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--stall", type=int, default=60, help="seconds a supervised measurement may stay silent inside its step loop")
     ap.add_argument("--dense-stream", type=int, default=1, help="FV2P workloads: BEV backbone + anchor head + RoI preparation on a side stream beside decoder + point head (0: the point branch on a side stream after the preparation)")
     ap.add_argument("--fps-ahead", type=int, default=1, help="FV2P workloads: key points of batch t+1 are sampled (FPS side stream) during the backward pass of step t")
+    ap.add_argument("--ahead-stream", default="fps", choices=["fps", "own"], help="--ahead: prepare the next batch on the key-point sampling stream (in front of that batch's sampler) or on a stream of its own")
     ap.add_argument("--ahead-priority", type=int, default=-1, help="stream priority of the --ahead side stream (-1 = high: a hardware queue of its own)")
     ap.add_argument("--cloud-streams", type=int, default=0,
                     help="FV2P workloads: voxelise the clouds of a batch on one stream each (measured: no gain at batch 3, and at Waymo size the extra "
@@ -102,7 +103,11 @@ def parse():
         # also drives RCCL's stream, which could not be measured on the one-GPU boxes of this round: the arrangement that ran beside
         # seven streams without loss (point branch after the RoI preparation, 38.4 ms) is the default there
         args.dense_stream = 0
-    # --ahead 2 measured no better than in line once the blocking host copies were gone (42.4 vs 41.2 ms per step): off by default
+    if args.workload in ("fv2p", "fv2p-waymo") and "--ahead" not in sys.argv and not args.prefetch:
+        # batch t+1 is voxelised and its rulebooks are built on the sampling stream, in front of that batch's sampler, between forward
+        # and backward of step t: the sparse backbone of step t+1 then starts without its five host waits (33.65 -> 32.75 ms).  On a
+        # stream of its own the same preparation costs the step 20 - 30 ms (a fifth stream on four hardware queues)
+        args.ahead = 2
     if args.steps == 300 and args.workload == "fv2p" and "--steps" not in sys.argv:
         args.steps, args.warmup = 40, (args.warmup if "--warmup" in sys.argv else 5)
     return args
@@ -387,7 +392,8 @@ def build_fv2p_step(args, device, rank, world):
         if args.prefetch:
             pre = BatchPrefetcher(produce, device, workers=args.prefetch_workers)
         else:
-            ahead = BatchAhead(produce, device, priority=args.ahead_priority)
+            from fv2p_harness.fv2p_model import side_stream
+            ahead = BatchAhead(produce, device, priority=args.ahead_priority, stream=side_stream("fps", device) if args.ahead_stream == "fps" else None)
 
     key_jobs = {}
 
@@ -881,7 +887,7 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "host_cores_per_rank": len(pinned) if pinned else "unpinned",
                        "input_pipeline": ({1: "batch t+1 voxelised on a side stream between forward and backward of step t (same thread)",
-                                           2: "batch t+1 voxelised and its rulebooks built on a side stream between forward and backward of step t (same thread)"}[min(args.ahead, 2)]
+                                           2: "batch t+1 voxelised and its rulebooks built on the key-point sampling stream between forward and backward of step t (same thread)"}[min(args.ahead, 2)]
                                           if args.ahead and not args.prefetch else
                                           {0: "in line", 1: "thread voxelises batch t+1 during step t",
                                            2: "thread voxelises batch t+1 and builds its rulebooks during step t",

@@ -94,9 +94,10 @@ class BatchAhead(object):
     a few hundred microseconds, instead of for everything the training stream still has queued: the host can run a whole
     step ahead of the device.  Pays when the step is device bound; a thread pays when it is launch bound."""
 
-    def __init__(self, produce, device, priority=0):
+    def __init__(self, produce, device, priority=0, stream=None):
         self.produce, self.device = produce, device
-        self.stream = torch.cuda.Stream(device=device, priority=priority)
+        # `stream`: an existing side stream to share (a process should not drive more side streams than it needs: four hardware queues)
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=device, priority=priority)
         self.ready = {}       # i -> (batch, event on the side stream)
         self.current = None   # batch handed out by the last take()
         self.retired = []     # (batch, event on the training stream after which nothing touches it, step that recorded it)
