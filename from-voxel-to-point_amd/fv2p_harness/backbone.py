@@ -42,6 +42,44 @@ class _BasicBlock(spconv.SparseModule):
         return out
 
 
+class _FoldedBasicBlock(spconv.SparseModule):
+    """_BasicBlock for inference: both BatchNorms folded into their convs (fold_batchnorm)."""
+
+    def __init__(self, block):
+        super().__init__()
+        from pcdet.ops.spconv.modules import fold_conv_bn
+        self.conv1, self.conv2 = fold_conv_bn(block.conv1, block.bn1), fold_conv_bn(block.conv2, block.bn2)
+        self.relu = nn.ReLU()
+
+    def forward(self, x):
+        identity = x.features
+        out = self.conv1(x)
+        out.features = self.relu(out.features)
+        out = self.conv2(out)
+        out.features = self.relu(out.features + identity)
+        return out
+
+
+def fold_batchnorm(module):
+    """SURVEY 8(f).3, inference: a copy of a sparse backbone (or any module tree of SparseSequential / residual blocks) in which every
+    conv -> BatchNorm1d pair is one biased conv carrying the BatchNorm's running statistics — the eval-mode network with a third
+    of the launches (no BatchNorm kernels at all).  The original is left untouched."""
+    import copy
+    m = copy.deepcopy(module).eval()
+
+    def fold(mod):
+        for name, child in list(mod.named_children()):
+            if isinstance(child, _BasicBlock):
+                setattr(mod, name, _FoldedBasicBlock(child))
+            elif isinstance(child, spconv.SparseSequential):
+                fold(child)
+                setattr(mod, name, child.fused())
+            else:
+                fold(child)
+    fold(m)
+    return m
+
+
 def bn_act(bn, feats, relu=None):
     """BatchNorm1d (+ReLU) on [N, C] rows: the fused HIP op where it applies (GPU, fp32, plain modules), else the modules."""
     y = batch_norm_relu(bn, feats, relu)

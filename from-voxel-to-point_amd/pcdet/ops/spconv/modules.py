@@ -102,30 +102,37 @@ class SparseSequential(SparseModule):
         """Folds every (SparseConvolution, BatchNorm1d) pair into one biased conv for inference
         (the reference's `fused()` is documented "don't use this", modules.py:138-185; the folding here
         uses the standard sqrt(var + eps) so the fused net equals conv -> eval-mode BN)."""
-        from .conv import SparseConvolution
         mods = list(self._modules.values())
         out, i = [], 0
         while i < len(mods):
             m = mods[i]
             if is_sparse_conv(m) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm1d):
-                bn = mods[i + 1]
-                conv = SparseConvolution(ndim=m.ndim, in_channels=m.in_channels, out_channels=m.out_channels,
-                                         kernel_size=m.kernel_size, stride=m.stride, padding=m.padding,
-                                         dilation=m.dilation, groups=m.groups, bias=True, subm=m.subm,
-                                         output_padding=m.output_padding, transposed=m.transposed, inverse=m.inverse,
-                                         indice_key=m.indice_key, fused_bn=True)
-                conv.to(m.weight.device)
-                with torch.no_grad():
-                    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
-                    conv.weight.copy_(m.weight * scale)
-                    b0 = m.bias if m.bias is not None else torch.zeros_like(bn.running_mean)
-                    conv.bias.copy_((b0 - bn.running_mean) * scale + bn.bias)
-                out.append(conv)
+                out.append(fold_conv_bn(m, mods[i + 1]))
                 i += 2
             else:
                 out.append(m)
                 i += 1
         return SparseSequential(*out)
+
+
+def fold_conv_bn(m, bn):
+    """One biased SparseConvolution = conv `m` followed by BatchNorm1d `bn` in eval mode (inference):
+    W' = W * gamma / sqrt(var + eps),  b' = (b - mean) * gamma / sqrt(var + eps) + beta."""
+    from .conv import SparseConvolution
+    conv = SparseConvolution(ndim=m.ndim, in_channels=m.in_channels, out_channels=m.out_channels,
+                             kernel_size=m.kernel_size, stride=m.stride, padding=m.padding,
+                             dilation=m.dilation, groups=m.groups, bias=True, subm=m.subm,
+                             output_padding=m.output_padding, transposed=m.transposed, inverse=m.inverse,
+                             indice_key=m.indice_key, fused_bn=True)
+    conv.to(m.weight.device)
+    with torch.no_grad():
+        gamma = bn.weight if bn.weight is not None else torch.ones_like(bn.running_var)
+        beta = bn.bias if bn.bias is not None else torch.zeros_like(bn.running_mean)
+        scale = gamma / torch.sqrt(bn.running_var + bn.eps)
+        conv.weight.copy_(m.weight * scale)
+        b0 = m.bias if m.bias is not None else torch.zeros_like(bn.running_mean)
+        conv.bias.copy_((b0 - bn.running_mean) * scale + beta)
+    return conv
 
 
 class ToDense(SparseModule):

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 import torch
 
+import oracle
 from fv2p_harness import synth
 from fv2p_harness.backbone import VoxelBackBone8x, VoxelResBackBone8x, mean_vfe
 from oracle.spconv_cpu import cpu_mirror
@@ -126,3 +127,33 @@ def test_lean_adamw_equals_torch_fused_adamw(gpu):
     for pa, pb in zip(ps_a, ps_b):
         assert torch.equal(pa, pb)
         assert torch.equal(a.state[pa]["exp_avg_sq"], b.state[pb]["exp_avg_sq"]) and torch.equal(a.state[pa]["step"], b.state[pb]["step"])
+
+
+@pytest.mark.gpu
+def test_batchnorm_folded_backbone_equals_the_eval_mode_backbone(gpu):
+    """SURVEY 8(f).3 at inference: fold_batchnorm(VoxelResBackBone8x) — every conv -> BatchNorm1d pair one biased conv, residual
+    blocks included — gives the eval-mode network's features (1e-4) and contains no BatchNorm module any more."""
+    import torch.nn as nn
+    from fv2p_harness.backbone import VoxelResBackBone8x, fold_batchnorm
+    torch.manual_seed(5)
+    net = VoxelResBackBone8x(4, [1408, 1600, 40]).to(gpu)
+    for m in net.modules():
+        if isinstance(m, nn.BatchNorm1d):   # statistics and affine parameters as after some training
+            m.running_mean.normal_(0, 0.3)
+            m.running_var.uniform_(0.5, 2.0)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+    net.eval()
+    folded = fold_batchnorm(net)
+    assert not any(isinstance(m, nn.BatchNorm1d) for m in folded.modules())
+    pts = synth.lidar_cloud(3, 16384)
+    v, c, k = oracle.points_to_voxel(pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 16000)
+    feats = mean_vfe(torch.from_numpy(v), torch.from_numpy(k)).to(gpu)
+    coords = torch.from_numpy(np.concatenate([np.zeros((c.shape[0], 1), np.int32), c], 1)).to(gpu)
+    with torch.no_grad():
+        a, la = net(feats, coords, 1)
+        b, lb = folded(feats, coords, 1)
+    rel = lambda x, y: float((x - y).abs().max() / y.abs().max().clamp_min(1e-12))
+    assert torch.equal(a.indices, b.indices) and rel(b.features, a.features) < 1e-4
+    for key in la:
+        assert rel(lb[key].features, la[key].features) < 1e-4, key
