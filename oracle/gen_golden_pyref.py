@@ -11,6 +11,8 @@ implements in importable Python:
                                  boxes3d_lidar_to_aligned_bev_boxes, boxes3d_nearest_bev_iou, enlarge_box3d
   utils/box_coder_utils.py       ResidualCoder.encode_torch / decode_torch                  (imported by path)
   utils/loss_utils.py            SigmoidFocalClassificationLoss, WeightedSmoothL1Loss.smooth_l1_loss
+  dense_heads/target_assigner/axis_aligned_target_assigner.py:130-215   AxisAlignedTargetAssigner.assign_targets_single
+                                 (method compiled out of the class; Tensor.cuda is the identity while it runs)
 
 Modules that import the CUDA extensions at load time cannot be imported as a whole, so single definitions are taken out
 of their syntax tree and compiled against torch (CPU).  Nothing of the reference is copied into the repository: the
@@ -154,6 +156,44 @@ def main():
     save("coder_losses", gt=g, anchors=an, encoded=enc.numpy(), decoded=dec.numpy(), logits=logits, onehot=onehot, weights=w,
          focal=focal.numpy(), diff=diff, smooth_l1_beta9=sl1(torch.from_numpy(diff), 1.0 / 9.0).numpy(),
          smooth_l1_beta1=sl1(torch.from_numpy(diff), 1.0).numpy())
+
+    # ---- first-stage target assignment ------------------------------------------------------------------------------------------------
+    # AxisAlignedTargetAssigner.assign_targets_single (axis_aligned_target_assigner.py:130-215) as the reference runs it for
+    # fv2p.yaml (match_height False, POS_FRACTION -1, NORM_BY_NUM_EXAMPLES False).  The method moves index tensors with
+    # `.cuda()`; the container has no GPU, so Tensor.cuda is the identity while it runs (a runtime shim, the source is untouched).
+    import types
+    sys_path_root = os.path.dirname(REPO)
+    import sys
+    for pth in (REPO, os.path.join(REPO, "from-voxel-to-point_amd")):
+        if pth not in sys.path:
+            sys.path.insert(0, pth)
+    from fv2p_harness import synth
+    from fv2p_harness.fv2p_model import AnchorHead, FV2PConfig
+
+    class Small(FV2PConfig):   # tests/test_fv2p_step_gpu.py::SmallFV2P
+        point_cloud_range = (0.0, -20.0, -3.0, 35.2, 20.0, 1.0)
+        grid_size = (704, 800, 40)
+    anchors = AnchorHead(Small, 128).anchors.clone()
+    assign = method("models/dense_heads/target_assigner/axis_aligned_target_assigner.py", "AxisAlignedTargetAssigner", "assign_targets_single",
+                    {"torch": torch, "np": np, "box_utils": types.SimpleNamespace(boxes3d_nearest_bev_iou=bns["boxes3d_nearest_bev_iou"]),
+                     "iou3d_nms_utils": None})
+    me = types.SimpleNamespace(match_height=False, pos_fraction=None, sample_size=512, norm_by_num_examples=False, box_coder=coder)
+    keep_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        out = {}
+        for smp in range(2):
+            _, bx = synth.lidar_cloud(31 + smp, 2048, pc_range=np.array(Small.point_cloud_range, np.float32), return_boxes=True)
+            if smp == 1:   # a box outside every anchor: its maximum overlap is zero, it must force nothing
+                bx = np.concatenate([bx, np.array([[500.0, 500.0, 0.0, 3.9, 1.6, 1.5, 0.3]], np.float32)])
+            gt = torch.from_numpy(bx.astype(np.float32))
+            r = assign(me, anchors, gt, torch.ones(len(bx), dtype=torch.int32), matched_threshold=Small.matched_thr, unmatched_threshold=Small.unmatched_thr)
+            out[f"gt{smp}"] = bx.astype(np.float32)
+            out[f"labels{smp}"] = r["box_cls_labels"].numpy()
+            out[f"targets{smp}"] = r["box_reg_targets"].numpy()
+    finally:
+        torch.Tensor.cuda = keep_cuda
+    save("anchor_assign", anchors=anchors.numpy(), **out)
 
 
 if __name__ == "__main__":
