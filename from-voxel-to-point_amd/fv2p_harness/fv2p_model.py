@@ -178,6 +178,15 @@ def box_corners(boxes):
     return rotate_z(c, boxes[:, 6]) + boxes[:, None, 0:3]
 
 
+def corner_loss_lidar(pred, gt):
+    """loss_utils.get_corner_loss_lidar (:217-241): per box the mean over the eight corners of smooth-L1(beta 1) of the corner
+    distance to the ground-truth box or to its heading-flipped twin, whichever is nearer.  (N, 7) x (N, 7) -> (N,)."""
+    pc, gc = box_corners(pred), box_corners(gt)
+    gflip = box_corners(torch.cat((gt[:, :6], gt[:, 6:7] + math.pi), dim=1))
+    dist = torch.minimum((pc - gc).norm(dim=2), (pc - gflip).norm(dim=2))
+    return smooth_l1(dist, 1.0).mean(dim=1)
+
+
 def nearest_bev_boxes(b):
     """boxes3d_lidar_to_aligned_bev_boxes (box_utils.py:337-348): (..., 7) -> (..., 4) axis-aligned footprint."""
     rot = limit_period(b[..., 6], 0.5, math.pi).abs()
@@ -789,10 +798,7 @@ class IoUGuidedRoIHead(nn.Module):
         world = rotate_z(local.unsqueeze(1), r7[:, 6]).squeeze(1)
         world = torch.cat((world[:, :3] + r7[:, :3], world[:, 3:6], world[:, 6:7] + r7[:, 6:7]), dim=1)   # decoded against the roi's heading
         g = gt_src.reshape(-1, gt_src.shape[-1])[:, :7]
-        pc, gc = box_corners(world), box_corners(g)
-        gflip = box_corners(torch.cat((g[:, :6], g[:, 6:7] + math.pi), dim=1))
-        dist = torch.minimum((pc - gc).norm(dim=2), (pc - gflip).norm(dim=2))
-        loss_corner = (smooth_l1(dist, 1.0).mean(dim=1) * fg).sum() / n_fg
+        loss_corner = (corner_loss_lidar(world, g) * fg).sum() / n_fg
         # IoU score head: smooth-l1 on the rois above REG_FG_THRESH, labels renormalised to [-1, 1]
         lab = (iou - 0.5) * 2
         valid = (lab >= (cfg.reg_fg - 0.5) * 2).float()

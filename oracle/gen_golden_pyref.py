@@ -11,6 +11,7 @@ implements in importable Python:
                                  boxes3d_lidar_to_aligned_bev_boxes, boxes3d_nearest_bev_iou, enlarge_box3d
   utils/box_coder_utils.py       ResidualCoder.encode_torch / decode_torch                  (imported by path)
   utils/loss_utils.py            SigmoidFocalClassificationLoss, WeightedSmoothL1Loss.smooth_l1_loss
+  utils/loss_utils.py:217-241    get_corner_loss_lidar
   dense_heads/target_assigner/axis_aligned_target_assigner.py:130-215   AxisAlignedTargetAssigner.assign_targets_single
                                  (method compiled out of the class; Tensor.cuda is the identity while it runs)
 
@@ -156,6 +157,16 @@ def main():
     save("coder_losses", gt=g, anchors=an, encoded=enc.numpy(), decoded=dec.numpy(), logits=logits, onehot=onehot, weights=w,
          focal=focal.numpy(), diff=diff, smooth_l1_beta9=sl1(torch.from_numpy(diff), 1.0 / 9.0).numpy(),
          smooth_l1_beta1=sl1(torch.from_numpy(diff), 1.0).numpy())
+
+    # ---- corner loss --------------------------------------------------------------------------------------------------------------------
+    cns = {"torch": torch, "np": np, "nn": torch.nn, "F": torch.nn.functional, "box_utils": None}
+    import types as _types
+    cns["box_utils"] = _types.SimpleNamespace(boxes_to_corners_3d=bns["boxes_to_corners_3d"])
+    extract("utils/loss_utils.py", ["WeightedSmoothL1Loss", "get_corner_loss_lidar"], cns)
+    pb, gb = random_boxes(rng, 200, 10.0), random_boxes(rng, 200, 10.0)
+    gb[:100] = pb[:100] + rng.normal(0, 0.15, size=(100, 7)).astype(np.float32)      # near pairs: the quadratic branch of smooth-L1
+    gb[50:100, 6] += np.pi                                                            # ... and the heading-flipped twin
+    save("corner_loss", pred=pb, gt=gb, loss=cns["get_corner_loss_lidar"](torch.from_numpy(pb), torch.from_numpy(gb)).numpy())
 
     # ---- first-stage target assignment ------------------------------------------------------------------------------------------------
     # AxisAlignedTargetAssigner.assign_targets_single (axis_aligned_target_assigner.py:130-215) as the reference runs it for
