@@ -12,6 +12,7 @@ implements in importable Python:
   utils/box_coder_utils.py       ResidualCoder.encode_torch / decode_torch                  (imported by path)
   utils/loss_utils.py            SigmoidFocalClassificationLoss, WeightedSmoothL1Loss.smooth_l1_loss
   utils/loss_utils.py:217-241    get_corner_loss_lidar
+  roi_heads/roi_withiou_head_template.py:101-131   RoIWithIoUHeadTemplate.assign_targets (canonical transformation; stub target layer)
   dense_heads/target_assigner/axis_aligned_target_assigner.py:130-215   AxisAlignedTargetAssigner.assign_targets_single
                                  (method compiled out of the class; Tensor.cuda is the identity while it runs)
 
@@ -167,6 +168,19 @@ def main():
     gb[:100] = pb[:100] + rng.normal(0, 0.15, size=(100, 7)).astype(np.float32)      # near pairs: the quadratic branch of smooth-L1
     gb[50:100, 6] += np.pi                                                            # ... and the heading-flipped twin
     save("corner_loss", pred=pb, gt=gb, loss=cns["get_corner_loss_lidar"](torch.from_numpy(pb), torch.from_numpy(gb)).numpy())
+
+    # ---- second-stage canonical transformation ----------------------------------------------------------------------------------------
+    # RoIWithIoUHeadTemplate.assign_targets (roi_withiou_head_template.py:101-131) behind a stub proposal_target_layer that hands
+    # over the sampled rois / boxes: what remains is the roi-frame transformation and the heading folding
+    canon = method("models/roi_heads/roi_withiou_head_template.py", "RoIWithIoUHeadTemplate", "assign_targets", {"torch": torch, "np": np, "common_utils": cu})
+    rois = np.stack([random_boxes(rng, 64, 15.0), random_boxes(rng, 64, 15.0)])
+    gts = rois + rng.normal(0, 0.4, size=rois.shape).astype(np.float32)
+    gts[..., 6] = rng.uniform(-2 * np.pi, 2 * np.pi, size=gts.shape[:2])          # every heading quadrant
+    gts = np.concatenate([gts, np.ones(gts.shape[:2] + (1,), np.float32)], -1).astype(np.float32)
+    stub = _types.SimpleNamespace(proposal_target_layer=_types.SimpleNamespace(
+        forward=lambda bd: {"rois": torch.from_numpy(rois.copy()), "gt_of_rois": torch.from_numpy(gts.copy())}))
+    td = canon(stub, {"batch_size": 2})
+    save("canonical_targets", rois=rois, gt_of_rois=gts, canonical=td["gt_of_rois"].numpy(), src=td["gt_of_rois_src"].numpy())
 
     # ---- first-stage target assignment ------------------------------------------------------------------------------------------------
     # AxisAlignedTargetAssigner.assign_targets_single (axis_aligned_target_assigner.py:130-215) as the reference runs it for
