@@ -12,6 +12,7 @@ implements in importable Python:
   utils/box_coder_utils.py       ResidualCoder.encode_torch / decode_torch                  (imported by path)
   utils/loss_utils.py            SigmoidFocalClassificationLoss, WeightedSmoothL1Loss.smooth_l1_loss
   utils/loss_utils.py:217-241    get_corner_loss_lidar
+  dense_heads/target_assigner/anchor_generator.py:17-61   AnchorGenerator.generate_anchors (imported by path)
   roi_heads/roi_withiou_head_template.py:101-131   RoIWithIoUHeadTemplate.assign_targets (canonical transformation; stub target layer)
   dense_heads/target_assigner/axis_aligned_target_assigner.py:130-215   AxisAlignedTargetAssigner.assign_targets_single
                                  (method compiled out of the class; Tensor.cuda is the identity while it runs)
@@ -181,6 +182,23 @@ def main():
         forward=lambda bd: {"rois": torch.from_numpy(rois.copy()), "gt_of_rois": torch.from_numpy(gts.copy())}))
     td = canon(stub, {"batch_size": 2})
     save("canonical_targets", rois=rois, gt_of_rois=gts, canonical=td["gt_of_rois"].numpy(), src=td["gt_of_rois_src"].numpy())
+
+    # ---- anchors -------------------------------------------------------------------------------------------------------------------------
+    # AnchorGenerator.generate_anchors (anchor_generator.py:17-61; `.cuda()` an identity here) with fv2p.yaml's ANCHOR_GENERATOR_CONFIG
+    # (Car: 3.9 x 1.6 x 1.56, rotations 0 / 1.57, bottom -1.78, align_center False) on the KITTI BEV map and on the reduced map
+    # of the parity tests; flattened the way AnchorHeadTemplate uses them (y, x, rotation)
+    import hashlib
+    ag = by_path("ref_anchor_generator", "models/dense_heads/target_assigner/anchor_generator.py")
+    acfg = [{"anchor_sizes": [[3.9, 1.6, 1.56]], "anchor_rotations": [0, 1.57], "anchor_bottom_heights": [-1.78], "align_center": False}]
+    keep_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        big = ag.AnchorGenerator([0, -40.0, -3, 70.4, 40.0, 1], acfg).generate_anchors([np.array([176, 200])])[0][0].view(-1, 7).numpy()
+        small = ag.AnchorGenerator([0, -20.0, -3, 35.2, 20.0, 1], acfg).generate_anchors([np.array([88, 100])])[0][0].view(-1, 7).numpy()
+    finally:
+        torch.Tensor.cuda = keep_cuda
+    save("anchors", small=small, kitti_every_97th=big[::97].copy(), kitti_shape=np.array(big.shape),
+         kitti_sha256=np.frombuffer(hashlib.sha256(np.ascontiguousarray(big).tobytes()).digest(), np.uint8))
 
     # ---- first-stage target assignment ------------------------------------------------------------------------------------------------
     # AxisAlignedTargetAssigner.assign_targets_single (axis_aligned_target_assigner.py:130-215) as the reference runs it for
