@@ -12,6 +12,7 @@ implements in importable Python:
   utils/box_coder_utils.py       ResidualCoder.encode_torch / decode_torch                  (imported by path)
   utils/loss_utils.py            SigmoidFocalClassificationLoss, WeightedSmoothL1Loss.smooth_l1_loss
   utils/loss_utils.py:217-241    get_corner_loss_lidar
+  roi_heads/iouguided_roi_head.py:195-220   get_global_grid_points_of_roi / get_dense_grid_points (methods compiled out of the class)
   dense_heads/target_assigner/anchor_generator.py:17-61   AnchorGenerator.generate_anchors (imported by path)
   roi_heads/roi_withiou_head_template.py:101-131   RoIWithIoUHeadTemplate.assign_targets (canonical transformation; stub target layer)
   dense_heads/target_assigner/axis_aligned_target_assigner.py:130-215   AxisAlignedTargetAssigner.assign_targets_single
@@ -182,6 +183,14 @@ def main():
         forward=lambda bd: {"rois": torch.from_numpy(rois.copy()), "gt_of_rois": torch.from_numpy(gts.copy())}))
     td = canon(stub, {"batch_size": 2})
     save("canonical_targets", rois=rois, gt_of_rois=gts, canonical=td["gt_of_rois"].numpy(), src=td["gt_of_rois_src"].numpy())
+
+    # ---- RoI grid points ------------------------------------------------------------------------------------------------------------------
+    gns = {"torch": torch, "np": np, "common_utils": cu}
+    dense_pts = method("models/roi_heads/iouguided_roi_head.py", "IoUGuidedRoIHead", "get_dense_grid_points", dict(gns))
+    glob_pts = method("models/roi_heads/iouguided_roi_head.py", "IoUGuidedRoIHead", "get_global_grid_points_of_roi", dict(gns))
+    rb = np.stack([random_boxes(rng, 40, 20.0), random_boxes(rng, 40, 20.0)])
+    world, local = glob_pts(_types.SimpleNamespace(get_dense_grid_points=dense_pts), torch.from_numpy(rb), 6)
+    save("roi_grid_points", rois=rb, world=world.numpy(), local=local.numpy())
 
     # ---- anchors -------------------------------------------------------------------------------------------------------------------------
     # AnchorGenerator.generate_anchors (anchor_generator.py:17-61; `.cuda()` an identity here) with fv2p.yaml's ANCHOR_GENERATOR_CONFIG
