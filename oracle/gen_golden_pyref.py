@@ -13,6 +13,7 @@ implements in importable Python:
   utils/loss_utils.py            SigmoidFocalClassificationLoss, WeightedSmoothL1Loss.smooth_l1_loss
   utils/loss_utils.py:217-241    get_corner_loss_lidar
   roi_heads/iouguided_roi_head.py:195-220   get_global_grid_points_of_roi / get_dense_grid_points (methods compiled out of the class)
+  dense_heads/anchor_head_template.py:229-276   AnchorHeadTemplate.generate_predicted_boxes (stub head)
   dense_heads/target_assigner/anchor_generator.py:17-61   AnchorGenerator.generate_anchors (imported by path)
   roi_heads/roi_withiou_head_template.py:101-131   RoIWithIoUHeadTemplate.assign_targets (canonical transformation; stub target layer)
   dense_heads/target_assigner/axis_aligned_target_assigner.py:130-215   AxisAlignedTargetAssigner.assign_targets_single
@@ -191,6 +192,20 @@ def main():
     rb = np.stack([random_boxes(rng, 40, 20.0), random_boxes(rng, 40, 20.0)])
     world, local = glob_pts(_types.SimpleNamespace(get_dense_grid_points=dense_pts), torch.from_numpy(rb), 6)
     save("roi_grid_points", rois=rb, world=world.numpy(), local=local.numpy())
+
+    # ---- first-stage box decoding ----------------------------------------------------------------------------------------------------------
+    # AnchorHeadTemplate.generate_predicted_boxes (anchor_head_template.py:229-276) behind a stub head: ResidualCoder decoding against the
+    # anchors and the direction-bin correction of the heading (DIR_OFFSET 0.78539, DIR_LIMIT_OFFSET 0, two bins)
+    gen_boxes = method("models/dense_heads/anchor_head_template.py", "AnchorHeadTemplate", "generate_predicted_boxes",
+                       {"torch": torch, "np": np, "common_utils": cu, "box_coder_utils": bc})
+    anc = torch.from_numpy(random_boxes(rng, 300, 30.0))
+    box_p = torch.from_numpy(rng.normal(0, 0.4, size=(2, 300, 7)).astype(np.float32))
+    dir_p = torch.from_numpy(rng.normal(0, 1.0, size=(2, 300, 2)).astype(np.float32))
+    cls_p = torch.from_numpy(rng.normal(0, 1.0, size=(2, 300, 1)).astype(np.float32))
+    head_stub = _types.SimpleNamespace(anchors=anc, use_multihead=False, box_coder=coder,
+                                       model_cfg=_types.SimpleNamespace(DIR_OFFSET=0.78539, DIR_LIMIT_OFFSET=0.0, NUM_DIR_BINS=2))
+    _, dec = gen_boxes(head_stub, 2, cls_p, box_p.clone(), dir_p)
+    save("predicted_boxes", anchors=anc.numpy(), box_preds=box_p.numpy(), dir_preds=dir_p.numpy(), boxes=dec.numpy())
 
     # ---- anchors -------------------------------------------------------------------------------------------------------------------------
     # AnchorGenerator.generate_anchors (anchor_generator.py:17-61; `.cuda()` an identity here) with fv2p.yaml's ANCHOR_GENERATOR_CONFIG
