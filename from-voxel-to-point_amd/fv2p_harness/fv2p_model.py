@@ -780,14 +780,11 @@ class IoUGuidedRoIHead(nn.Module):
         loss = self.losses(rois, prep["s_gt"], prep["gt_ct"], prep["s_iou"], cls, reg[:, 1:], reg[:, :1])
         return loss, {"rois": prep["rois"], "sampled_rois": rois, "roi_iou": prep["s_iou"]}
 
-    def losses(self, rois, gt_src, gt_ct, iou, cls, reg, iou_pred):
-        """get_box_cls_layer_loss / get_box_reg_layer_loss / get_box_iouscore_layer_loss (:137-265), CLS_SCORE_TYPE roi_iou."""
-        cfg = self.cfg
-        iou = iou.view(-1)
-        soft = ((iou - cfg.cls_bg) / (cfg.cls_fg - cfg.cls_bg)).clamp(0, 1)     # 1 above fg, 0 below bg, linear in between
-        soft = torch.where(iou > cfg.cls_fg, torch.ones_like(soft), torch.where(iou < cfg.cls_bg, torch.zeros_like(soft), soft))
-        loss_cls = F.binary_cross_entropy(torch.sigmoid(cls.view(-1)), soft, reduction="none").mean()   # every label >= 0
-        fg = (iou > cfg.reg_fg).float()
+    @staticmethod
+    def reg_losses(rois, gt_src, gt_ct, fg, reg):
+        """get_box_reg_layer_loss (roi_withiou_head_template.py:133-195): smooth-L1 (beta 1/9) on the ResidualCoder targets of the
+        canonical boxes against the size-only roi anchor, and the corner regularisation of the boxes decoded back into the
+        LiDAR frame; both averaged over the foreground rois (fg: (B*n,) 0/1).  Returns (loss_reg, loss_corner)."""
         n_fg = fg.sum().clamp_min(1.0)
         r7 = rois.reshape(-1, 7)
         anchor = torch.cat((torch.zeros_like(r7[:, :3]), r7[:, 3:6], torch.zeros_like(r7[:, 6:7])), dim=1)
@@ -799,6 +796,17 @@ class IoUGuidedRoIHead(nn.Module):
         world = torch.cat((world[:, :3] + r7[:, :3], world[:, 3:6], world[:, 6:7] + r7[:, 6:7]), dim=1)   # decoded against the roi's heading
         g = gt_src.reshape(-1, gt_src.shape[-1])[:, :7]
         loss_corner = (corner_loss_lidar(world, g) * fg).sum() / n_fg
+        return loss_reg, loss_corner
+
+    def losses(self, rois, gt_src, gt_ct, iou, cls, reg, iou_pred):
+        """get_box_cls_layer_loss / get_box_reg_layer_loss / get_box_iouscore_layer_loss (:137-265), CLS_SCORE_TYPE roi_iou."""
+        cfg = self.cfg
+        iou = iou.view(-1)
+        soft = ((iou - cfg.cls_bg) / (cfg.cls_fg - cfg.cls_bg)).clamp(0, 1)     # 1 above fg, 0 below bg, linear in between
+        soft = torch.where(iou > cfg.cls_fg, torch.ones_like(soft), torch.where(iou < cfg.cls_bg, torch.zeros_like(soft), soft))
+        loss_cls = F.binary_cross_entropy(torch.sigmoid(cls.view(-1)), soft, reduction="none").mean()   # every label >= 0
+        fg = (iou > cfg.reg_fg).float()
+        loss_reg, loss_corner = self.reg_losses(rois, gt_src, gt_ct, fg, reg)
         # IoU score head: smooth-l1 on the rois above REG_FG_THRESH, labels renormalised to [-1, 1]
         lab = (iou - 0.5) * 2
         valid = (lab >= (cfg.reg_fg - 0.5) * 2).float()

@@ -12,6 +12,7 @@ implements in importable Python:
   utils/box_coder_utils.py       ResidualCoder.encode_torch / decode_torch                  (imported by path)
   utils/loss_utils.py            SigmoidFocalClassificationLoss, WeightedSmoothL1Loss.smooth_l1_loss
   utils/loss_utils.py:217-241    get_corner_loss_lidar
+  roi_heads/roi_withiou_head_template.py:133-195   RoIWithIoUHeadTemplate.get_box_reg_layer_loss (stub head, fv2p.yaml LOSS_CONFIG)
   roi_heads/iouguided_roi_head.py:195-220   get_global_grid_points_of_roi / get_dense_grid_points (methods compiled out of the class)
   dense_heads/anchor_head_template.py:229-276   AnchorHeadTemplate.generate_predicted_boxes (stub head)
   dense_heads/target_assigner/anchor_generator.py:17-61   AnchorGenerator.generate_anchors (imported by path)
@@ -184,6 +185,28 @@ def main():
         forward=lambda bd: {"rois": torch.from_numpy(rois.copy()), "gt_of_rois": torch.from_numpy(gts.copy())}))
     td = canon(stub, {"batch_size": 2})
     save("canonical_targets", rois=rois, gt_of_rois=gts, canonical=td["gt_of_rois"].numpy(), src=td["gt_of_rois_src"].numpy())
+
+    # ---- second-stage regression + corner loss ------------------------------------------------------------------------------------------
+    # RoIWithIoUHeadTemplate.get_box_reg_layer_loss (roi_withiou_head_template.py:133-195) behind a stub head with fv2p.yaml's
+    # LOSS_CONFIG (smooth-l1, CORNER_LOSS_REGULARIZATION, unit weights); inputs: the canonical targets made above
+    reg_loss = method("models/roi_heads/roi_withiou_head_template.py", "RoIWithIoUHeadTemplate", "get_box_reg_layer_loss",
+                      {"torch": torch, "np": np, "F": torch.nn.functional, "common_utils": cu,
+                       "loss_utils": _types.SimpleNamespace(get_corner_loss_lidar=cns["get_corner_loss_lidar"])})
+    keep_cuda2 = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        l1 = cns["WeightedSmoothL1Loss"](code_weights=[1.0] * 7)
+    finally:
+        torch.Tensor.cuda = keep_cuda2
+    rstub = _types.SimpleNamespace(box_coder=coder, reg_loss_func=l1, model_cfg=_types.SimpleNamespace(LOSS_CONFIG=_types.SimpleNamespace(
+        REG_LOSS="smooth-l1", CORNER_LOSS_REGULARIZATION=True, LOSS_WEIGHTS={"rcnn_reg_weight": 1.0, "rcnn_corner_weight": 1.0})))
+    rcnn_reg = rng.normal(0, 0.3, size=(128, 7)).astype(np.float32)
+    valid = (rng.uniform(size=(2, 64)) < 0.4).astype(np.int64)
+    frd = {"reg_valid_mask": torch.from_numpy(valid), "gt_of_rois": td["gt_of_rois"].clone(), "gt_of_rois_src": td["gt_of_rois_src"].clone(),
+           "rcnn_reg": torch.from_numpy(rcnn_reg), "rois": torch.from_numpy(rois.copy())}
+    total, tb = reg_loss(rstub, frd)
+    save("roi_reg_loss", rois=rois, gt_canonical=td["gt_of_rois"].numpy(), gt_src=td["gt_of_rois_src"].numpy(), rcnn_reg=rcnn_reg, valid=valid,
+         loss_reg=np.float32(tb["rcnn_loss_reg"]), loss_corner=np.float32(tb["rcnn_loss_corner"]), total=np.float32(total.item()))
 
     # ---- RoI grid points ------------------------------------------------------------------------------------------------------------------
     gns = {"torch": torch, "np": np, "common_utils": cu}
