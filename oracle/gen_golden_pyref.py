@@ -13,6 +13,8 @@ implements in importable Python:
   utils/loss_utils.py            SigmoidFocalClassificationLoss, WeightedSmoothL1Loss.smooth_l1_loss
   utils/loss_utils.py:217-241    get_corner_loss_lidar
   roi_heads/roi_withiou_head_template.py:133-195   RoIWithIoUHeadTemplate.get_box_reg_layer_loss (stub head, fv2p.yaml LOSS_CONFIG)
+  roi_heads/target_assigner/proposal_target_layer.py:20-86   ProposalTargetLayer.forward (labels from the overlaps; stub sampler)
+  roi_heads/roi_withiou_head_template.py:196-265   get_box_cls_layer_loss, get_box_iouscore_layer_loss
   roi_heads/iouguided_roi_head.py:195-220   get_global_grid_points_of_roi / get_dense_grid_points (methods compiled out of the class)
   dense_heads/anchor_head_template.py:229-276   AnchorHeadTemplate.generate_predicted_boxes (stub head)
   dense_heads/target_assigner/anchor_generator.py:17-61   AnchorGenerator.generate_anchors (imported by path)
@@ -207,6 +209,36 @@ def main():
     total, tb = reg_loss(rstub, frd)
     save("roi_reg_loss", rois=rois, gt_canonical=td["gt_of_rois"].numpy(), gt_src=td["gt_of_rois_src"].numpy(), rcnn_reg=rcnn_reg, valid=valid,
          loss_reg=np.float32(tb["rcnn_loss_reg"]), loss_corner=np.float32(tb["rcnn_loss_corner"]), total=np.float32(total.item()))
+
+    # ---- second-stage labels, classification and IoU-score losses, total ----------------------------------------------------------------
+    # ProposalTargetLayer.forward (proposal_target_layer.py:20-86, CLS_SCORE_TYPE roi_iou) behind a stub sampler, then
+    # get_box_cls_layer_loss / get_box_iouscore_layer_loss / get_box_reg_layer_loss (roi_withiou_head_template.py:133-265)
+    ptl_fwd = method("models/roi_heads/target_assigner/proposal_target_layer.py", "ProposalTargetLayer", "forward", {"torch": torch, "np": np})
+    ious = rng.uniform(0, 1, size=(2, 64)).astype(np.float32)
+    ious[0, :4] = [0.25, 0.75, 0.55, 0.5500001]                                       # the thresholds themselves
+    tcfg = _types.SimpleNamespace(REG_FG_THRESH=0.55, CLS_SCORE_TYPE="roi_iou", CLS_BG_THRESH=0.25, CLS_FG_THRESH=0.75)
+    ptl = _types.SimpleNamespace(roi_sampler_cfg=tcfg, sample_rois_for_rcnn=lambda batch_dict: (
+        torch.from_numpy(rois.copy()), torch.from_numpy(gts.copy()), torch.from_numpy(ious.copy()), torch.zeros(2, 64), torch.ones(2, 64, dtype=torch.long)))
+    tgt = ptl_fwd(ptl, {"batch_size": 2})
+    lns2 = {"torch": torch, "np": np, "F": torch.nn.functional, "common_utils": cu,
+            "loss_utils": _types.SimpleNamespace(get_corner_loss_lidar=cns["get_corner_loss_lidar"])}
+    cls_loss = method("models/roi_heads/roi_withiou_head_template.py", "RoIWithIoUHeadTemplate", "get_box_cls_layer_loss", dict(lns2))
+    iou_loss = method("models/roi_heads/roi_withiou_head_template.py", "RoIWithIoUHeadTemplate", "get_box_iouscore_layer_loss", dict(lns2))
+    hstub = _types.SimpleNamespace(box_coder=coder, reg_loss_func=l1, model_cfg=_types.SimpleNamespace(
+        TARGET_CONFIG=tcfg, LOSS_CONFIG=_types.SimpleNamespace(
+            REG_LOSS="smooth-l1", CLS_LOSS="BinaryCrossEntropy", IOUSCORE_LOSS="smooth-l1", CORNER_LOSS_REGULARIZATION=True,
+            LOSS_WEIGHTS={"rcnn_cls_weight": 1.0, "rcnn_reg_weight": 1.0, "rcnn_corner_weight": 1.0, "rcnn_iouscore_weight": 1.0})))
+    rcnn_cls = rng.normal(0, 1.5, size=(128, 1)).astype(np.float32)
+    rcnn_iou = rng.normal(0, 0.5, size=(128, 1)).astype(np.float32)
+    frd2 = {"rcnn_cls": torch.from_numpy(rcnn_cls), "rcnn_cls_labels": tgt["rcnn_cls_labels"], "distribution_dict": {}, "rcnn_iouscore": torch.from_numpy(rcnn_iou),
+            "batch_size": 2, "gt_iou_of_rois": tgt["gt_iou_of_rois"], "reg_valid_mask": tgt["reg_valid_mask"], "gt_of_rois": td["gt_of_rois"].clone(),
+            "gt_of_rois_src": td["gt_of_rois_src"].clone(), "rcnn_reg": torch.from_numpy(rcnn_reg), "rois": torch.from_numpy(rois.copy())}
+    l_cls, _ = cls_loss(hstub, frd2)
+    l_iou, _ = iou_loss(hstub, frd2)
+    l_reg, _ = reg_loss(hstub, frd2)
+    save("roi_losses", rois=rois, gt_canonical=td["gt_of_rois"].numpy(), gt_src=td["gt_of_rois_src"].numpy(), ious=ious, rcnn_cls=rcnn_cls, rcnn_reg=rcnn_reg,
+         rcnn_iou=rcnn_iou, cls_labels=tgt["rcnn_cls_labels"].numpy(), reg_valid=tgt["reg_valid_mask"].numpy(), loss_cls=np.float32(l_cls.item()),
+         loss_iou=np.float32(float(l_iou)), loss_reg=np.float32(l_reg.item()), total=np.float32(l_cls.item() + float(l_iou) + l_reg.item()))
 
     # ---- RoI grid points ------------------------------------------------------------------------------------------------------------------
     gns = {"torch": torch, "np": np, "common_utils": cu}
