@@ -16,6 +16,7 @@ implements in importable Python:
   roi_heads/target_assigner/proposal_target_layer.py:20-86   ProposalTargetLayer.forward (labels from the overlaps; stub sampler)
   roi_heads/roi_withiou_head_template.py:196-265   get_box_cls_layer_loss, get_box_iouscore_layer_loss
   roi_heads/iouguided_roi_head.py:195-220   get_global_grid_points_of_roi / get_dense_grid_points (methods compiled out of the class)
+  dense_heads/anchor_head_template.py:101-218   get_cls_layer_loss, get_box_reg_layer_loss, add_sin_difference, get_direction_target (stub head)
   dense_heads/anchor_head_template.py:229-276   AnchorHeadTemplate.generate_predicted_boxes (stub head)
   dense_heads/target_assigner/anchor_generator.py:17-61   AnchorGenerator.generate_anchors (imported by path)
   roi_heads/roi_withiou_head_template.py:101-131   RoIWithIoUHeadTemplate.assign_targets (canonical transformation; stub target layer)
@@ -316,6 +317,36 @@ def main():
     finally:
         torch.Tensor.cuda = keep_cuda
     save("anchor_assign", anchors=anchors.numpy(), **out)
+
+    # ---- first-stage losses ---------------------------------------------------------------------------------------------------------------
+    # AnchorHeadTemplate.get_cls_layer_loss + get_box_reg_layer_loss (anchor_head_template.py:101-218) behind a stub head with
+    # fv2p.yaml's loss configuration, on the labels / targets the reference assigner produced above (every non-background anchor
+    # of the two samples plus 2000 background ones)
+    lab = np.stack([out["labels0"], out["labels1"]])
+    tgt_reg = np.stack([out["targets0"], out["targets1"]])
+    pick = np.unique(np.concatenate([np.nonzero((lab != 0).any(0))[0], rng.choice(lab.shape[1], 2000, replace=False)]))
+    lab_s, tgt_s, anc_s = lab[:, pick].copy(), tgt_reg[:, pick].copy(), anchors.numpy()[pick].copy()
+    n_s = len(pick)
+    p_cls = rng.normal(-2.0, 2.0, size=(2, n_s, 1)).astype(np.float32)
+    p_box = (tgt_s + rng.normal(0, 0.3, size=tgt_s.shape)).astype(np.float32)
+    p_dir = rng.normal(0, 1.0, size=(2, n_s, 2)).astype(np.float32)
+    ans = {"torch": torch, "np": np, "common_utils": cu, "box_coder_utils": bc}
+    extract("utils/loss_utils.py", ["WeightedCrossEntropyLoss"], lns)
+    sin_diff = method("models/dense_heads/anchor_head_template.py", "AnchorHeadTemplate", "add_sin_difference", dict(ans))
+    dir_tgt = method("models/dense_heads/anchor_head_template.py", "AnchorHeadTemplate", "get_direction_target", dict(ans))
+    a_cls = method("models/dense_heads/anchor_head_template.py", "AnchorHeadTemplate", "get_cls_layer_loss", dict(ans))
+    a_reg = method("models/dense_heads/anchor_head_template.py", "AnchorHeadTemplate", "get_box_reg_layer_loss", dict(ans))
+    astub = _types.SimpleNamespace(
+        num_class=1, use_multihead=False, num_anchors_per_location=1, anchors=torch.from_numpy(anc_s), add_sin_difference=sin_diff, get_direction_target=dir_tgt,
+        cls_loss_func=lns["SigmoidFocalClassificationLoss"](alpha=0.25, gamma=2.0), reg_loss_func=l1, dir_loss_func=lns["WeightedCrossEntropyLoss"](),
+        model_cfg=_types.SimpleNamespace(DIR_OFFSET=0.78539, NUM_DIR_BINS=2, LOSS_CONFIG=_types.SimpleNamespace(
+            LOSS_WEIGHTS={"cls_weight": 1.0, "loc_weight": 2.0, "dir_weight": 0.2})),
+        forward_ret_dict={"cls_preds": torch.from_numpy(p_cls), "box_cls_labels": torch.from_numpy(lab_s.copy()), "box_preds": torch.from_numpy(p_box),
+                          "dir_cls_preds": torch.from_numpy(p_dir), "box_reg_targets": torch.from_numpy(tgt_s)})
+    lc, tbc = a_cls(astub)
+    lb, tbb = a_reg(astub)
+    save("anchor_losses", anchors=anc_s, labels=lab_s, reg_targets=tgt_s, cls=p_cls, box=p_box, dirs=p_dir, loss_cls=np.float32(tbc["rpn_loss_cls"]),
+         loss_loc=np.float32(tbb["rpn_loss_loc"]), loss_dir=np.float32(tbb["rpn_loss_dir"]), total=np.float32(lc.item() + lb.item()))
 
 
 if __name__ == "__main__":
