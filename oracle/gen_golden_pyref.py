@@ -16,6 +16,8 @@ implements in importable Python:
   roi_heads/target_assigner/proposal_target_layer.py:20-86   ProposalTargetLayer.forward (labels from the overlaps; stub sampler)
   roi_heads/roi_withiou_head_template.py:196-265   get_box_cls_layer_loss, get_box_iouscore_layer_loss
   roi_heads/iouguided_roi_head.py:195-220   get_global_grid_points_of_roi / get_dense_grid_points (methods compiled out of the class)
+  dense_heads/point_head_simple.py:21-50, point_head_template.py:49-164   assign_targets, assign_stack_targets, get_cls_layer_loss
+                                 (stub head; the point-in-box op answered by oracle.points_in_boxes_gpu)
   dense_heads/anchor_head_template.py:101-218   get_cls_layer_loss, get_box_reg_layer_loss, add_sin_difference, get_direction_target (stub head)
   dense_heads/anchor_head_template.py:229-276   AnchorHeadTemplate.generate_predicted_boxes (stub head)
   dense_heads/target_assigner/anchor_generator.py:17-61   AnchorGenerator.generate_anchors (imported by path)
@@ -347,6 +349,34 @@ def main():
     lb, tbb = a_reg(astub)
     save("anchor_losses", anchors=anc_s, labels=lab_s, reg_targets=tgt_s, cls=p_cls, box=p_box, dirs=p_dir, loss_cls=np.float32(tbc["rpn_loss_cls"]),
          loss_loc=np.float32(tbb["rpn_loss_loc"]), loss_dir=np.float32(tbb["rpn_loss_dir"]), total=np.float32(lc.item() + lb.item()))
+
+    # ---- point head: targets and loss ------------------------------------------------------------------------------------------------------
+    # PointHeadSimple.assign_targets + PointHeadTemplate.assign_stack_targets / get_cls_layer_loss (point_head_simple.py:21-50,
+    # point_head_template.py:49-164) behind a stub head; the point-in-box op they call is answered by the oracle's restatement of
+    # the CUDA kernel (pinned against in_hull above), so what is pinned here is the label rule (inside = 1, inside the box enlarged by
+    # GT_EXTRA_WIDTH only = ignored) and the loss normalisation
+    import oracle as _oracle
+    pib = _types.SimpleNamespace(points_in_boxes_gpu=lambda pts, bxs: torch.from_numpy(_oracle.points_in_boxes_gpu(pts.numpy(), bxs.numpy())))
+    pns = {"torch": torch, "np": np, "roiaware_pool3d_utils": pib, "common_utils": cu, "box_utils": _types.SimpleNamespace(enlarge_box3d=bns["enlarge_box3d"])}
+    stack_t = method("models/dense_heads/point_head_template.py", "PointHeadTemplate", "assign_stack_targets", dict(pns))
+    simple_t = method("models/dense_heads/point_head_simple.py", "PointHeadSimple", "assign_targets", dict(pns))
+    p_loss = method("models/dense_heads/point_head_template.py", "PointHeadTemplate", "get_cls_layer_loss", dict(pns))
+    kp, gb = [], []
+    for smp in range(2):
+        pts_s, bx = synth.lidar_cloud(51 + smp, 4096, pc_range=np.array(Small.point_cloud_range, np.float32), return_boxes=True)
+        kp.append(pts_s[::2, :3])
+        gb.append(np.concatenate([bx[:20], np.ones((20, 1), np.float32)], 1).astype(np.float32))
+    kp, gb = np.stack(kp).astype(np.float32), np.stack(gb)
+    coords = np.concatenate([np.repeat(np.arange(2, dtype=np.float32), kp.shape[1])[:, None], kp.reshape(-1, 3)], 1)
+    pstub = _types.SimpleNamespace(num_class=1, model_cfg=_types.SimpleNamespace(TARGET_CONFIG=_types.SimpleNamespace(GT_EXTRA_WIDTH=[0.2, 0.2, 0.2]),
+                                                                                  LOSS_CONFIG=_types.SimpleNamespace(LOSS_WEIGHTS={"point_cls_weight": 4.0})),
+                                   cls_loss_func=lns["SigmoidFocalClassificationLoss"](alpha=0.25, gamma=2.0))
+    pstub.assign_stack_targets = lambda **kw: stack_t(pstub, **kw)
+    tdp = simple_t(pstub, {"point_coords": torch.from_numpy(coords), "gt_boxes": torch.from_numpy(gb)})
+    logits = rng.normal(-1.0, 2.0, size=(coords.shape[0], 1)).astype(np.float32)
+    pstub.forward_ret_dict = {"point_cls_labels": tdp["point_cls_labels"], "point_cls_preds": torch.from_numpy(logits)}
+    pl, ptb = p_loss(pstub)
+    save("point_head", keypoints=kp, gt=gb, labels=tdp["point_cls_labels"].numpy(), logits=logits, loss=np.float32(pl.item()), positives=np.float32(ptb["point_pos_num"]))
 
 
 if __name__ == "__main__":
