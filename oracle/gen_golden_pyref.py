@@ -16,6 +16,7 @@ implements in importable Python:
   roi_heads/target_assigner/proposal_target_layer.py:20-86   ProposalTargetLayer.forward (labels from the overlaps; stub sampler)
   roi_heads/roi_withiou_head_template.py:196-265   get_box_cls_layer_loss, get_box_iouscore_layer_loss
   roi_heads/iouguided_roi_head.py:195-220   get_global_grid_points_of_roi / get_dense_grid_points (methods compiled out of the class)
+  backbones_2d/base_bev_backbone.py   BaseBEVBackbone (imported by path)
   dense_heads/point_head_simple.py:21-50, point_head_template.py:49-164   assign_targets, assign_stack_targets, get_cls_layer_loss
                                  (stub head; the point-in-box op answered by oracle.points_in_boxes_gpu)
   dense_heads/anchor_head_template.py:101-218   get_cls_layer_loss, get_box_reg_layer_loss, add_sin_difference, get_direction_target (stub head)
@@ -377,6 +378,21 @@ def main():
     pstub.forward_ret_dict = {"point_cls_labels": tdp["point_cls_labels"], "point_cls_preds": torch.from_numpy(logits)}
     pl, ptb = p_loss(pstub)
     save("point_head", keypoints=kp, gt=gb, labels=tdp["point_cls_labels"].numpy(), logits=logits, loss=np.float32(pl.item()), positives=np.float32(ptb["point_pos_num"]))
+
+    # ---- BEV backbone -----------------------------------------------------------------------------------------------------------------------
+    # BaseBEVBackbone (backbones_2d/base_bev_backbone.py, imported by path) with fv2p.yaml's layout (LAYER_NUMS [5, 5], strides [1, 2],
+    # upsample strides [1, 2]) at a sixteenth of the channels: parameters by name + one training-mode forward pass
+    class _Cfg(dict):
+        __getattr__ = dict.__getitem__
+    bb = by_path("ref_bev_backbone", "models/backbones_2d/base_bev_backbone.py")
+    torch.manual_seed(11)
+    ref_bev = bb.BaseBEVBackbone(_Cfg(LAYER_NUMS=[5, 5], LAYER_STRIDES=[1, 2], NUM_FILTERS=[8, 16], UPSAMPLE_STRIDES=[1, 2], NUM_UPSAMPLE_FILTERS=[16, 16]), 16)
+    for prm in ref_bev.parameters():
+        if prm.dim() == 1:
+            prm.data.uniform_(0.5, 1.5)          # BatchNorm weights / biases away from their 1 / 0 defaults
+    x_bev = torch.randn(2, 16, 24, 20)
+    y_bev = ref_bev({"spatial_features": x_bev})["spatial_features_2d"]
+    save("bev_backbone", x=x_bev.numpy(), y=y_bev.detach().numpy(), **{"p:" + k: v.detach().numpy() for k, v in ref_bev.state_dict().items()})
 
 
 if __name__ == "__main__":
