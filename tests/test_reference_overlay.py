@@ -2,7 +2,8 @@
 
 A temporary tree is assembled from symlinks — every entry of /root/reference/pcdet except `ops`, which points at this
 repo's pcdet/ops — and a fresh interpreter imports the reference's backbones, decoder, heads and detectors from it
-(the import surface pcdet/models/** expects).  Third-party packages the image lacks (cv2, numba, mmcv,
+(the import surface pcdet/models/** expects); the reference's two sparse backbones, built on this repo's spconv
+modules, have the parameter names and shapes of the replay harness's re-declarations.  Third-party packages the image lacks (cv2, numba, mmcv,
 shapely, easydict, ...) are replaced by empty stand-in modules inside that interpreter: they are not part of the boundary.
 Skipped where /root/reference does not exist (the GPU box)."""
 import os
@@ -51,6 +52,13 @@ from pcdet.models.backbones_3d.pfe.residual_v2p_decoder import ResidualVoxelToPo
 net = VoxelResBackBone8x(ed.EasyDict(), input_channels=4, grid_size=__import__("numpy").array([1408, 1600, 40]))
 n_conv = sum(isinstance(m, spconv.SparseConvolution) for m in net.modules())
 assert n_conv == 21, n_conv
+# ... and the replay harness re-declares the same networks: parameter / buffer names and shapes agree one to one
+import numpy as np
+from fv2p_harness import backbone as hb
+for ref_cls, own_cls in ((VoxelResBackBone8x, hb.VoxelResBackBone8x), (VoxelBackBone8x, hb.VoxelBackBone8x)):
+    ref_sd = {k: tuple(v.shape) for k, v in ref_cls(ed.EasyDict(), input_channels=4, grid_size=np.array([1408, 1600, 40])).state_dict().items()}
+    own_sd = {k: tuple(v.shape) for k, v in own_cls(4, [1408, 1600, 40]).state_dict().items()}
+    assert ref_sd == own_sd, (sorted(set(ref_sd.items()) ^ set(own_sd.items()))[:8])
 print("OVERLAY_OK", len(mods), n_conv)
 '''
 
