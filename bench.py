@@ -735,7 +735,7 @@ def workload_name(args):
         return ("FV2P (waymo_fv2p_e30.yaml, Vehicle) end-to-end train step on Waymo-shaped synthetic clouds (~180 k points, 360 degrees, "
                 "0.1 m voxels, grid [41,1504,1504], five point features): same stages as the KITTI step, streaming FPS kernel")
     if args.workload == "fv2p":
-        return ("FV2P (fv2p.yaml, car only) end-to-end train step: HIP voxelise + MeanVFE, VoxelResBackBone8x, BEV backbone + anchor "
+        return ("FV2P (fv2p.yaml: CLASS_NAMES ['Car'], its three anchor sets = 6 anchors per BEV cell) end-to-end train step: HIP voxelise + MeanVFE, VoxelResBackBone8x, BEV backbone + anchor "
                 "head, FPS to 16384 key points, voxel-to-point decoder, point head, IoU-guided RoI head, losses, backward, grad clip, "
                 "AdamW; KITTI grid 0.05 m [41,1600,1408], LiDAR-like synthetic clouds with 20-40 car boxes")
     if args.workload == "mgaf":

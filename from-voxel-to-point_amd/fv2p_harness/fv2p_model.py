@@ -53,8 +53,11 @@ class FV2PConfig:
     bev_layers, bev_strides, bev_filters = (5, 5), (1, 2), (128, 256)
     bev_up_strides, bev_up_filters = (1, 2), (256, 256)
     # AnchorHeadSingle (Car)
-    anchor_size, anchor_rotations, anchor_bottom = (3.9, 1.6, 1.56), (0.0, 1.57), -1.78
-    matched_thr, unmatched_thr = 0.6, 0.45
+    # ANCHOR_GENERATOR_CONFIG of fv2p.yaml: three entries although CLASS_NAMES is ['Car'] — the reference's head has 6 anchors per
+    # location, of which the Pedestrian / Cyclist ones never see a box of their class and are background throughout
+    # (axis_aligned_target_assigner.py:57-83).  (size, bottom height, matched threshold, unmatched threshold) per entry; class ids 1..
+    anchor_rotations = (0.0, 1.57)
+    anchor_classes = (((3.9, 1.6, 1.56), -1.78, 0.6, 0.45), ((0.8, 0.6, 1.73), -0.6, 0.5, 0.35), ((1.76, 0.6, 1.73), -0.6, 0.5, 0.35))
     dir_offset, dir_limit_offset, num_dir_bins = 0.78539, 0.0, 2
     rpn_w = dict(cls=1.0, loc=2.0, dir=0.2)
     # decoder
@@ -91,8 +94,7 @@ class FV2PWaymoConfig(FV2PConfig):
     max_voxels = 80000
     num_point_features = 5
     bev_layers = (3, 3)
-    anchor_size, anchor_bottom = (4.7, 2.1, 1.7), 0.0
-    matched_thr, unmatched_thr = 0.55, 0.4
+    anchor_classes = (((4.7, 2.1, 1.7), 0.0, 0.55, 0.4),)     # waymo_fv2p_e30.yaml: Vehicle only
 
 
 # ---------------------------------------------------------------- small shared pieces -----------------
@@ -279,49 +281,82 @@ class AnchorHead(nn.Module):
     def __init__(self, cfg, cin):
         super().__init__()
         self.cfg = cfg
-        na = len(cfg.anchor_rotations)
+        nr, nc = len(cfg.anchor_rotations), len(cfg.anchor_classes)
+        na = nr * nc
         self.conv_cls = nn.Conv2d(cin, na, 1)
         self.conv_box = nn.Conv2d(cin, na * 7, 1)
         self.conv_dir_cls = nn.Conv2d(cin, na * cfg.num_dir_bins, 1)
         nn.init.constant_(self.conv_cls.bias, -math.log((1 - 0.01) / 0.01))
         nn.init.normal_(self.conv_box.weight, mean=0, std=0.001)
-        # anchors [H, W, rot, 7] flattened (anchor_generator.py:20-61: align_center False -> linspace over the range)
+        # anchors [H, W, class, rot, 7] flattened (anchor_generator.py:20-61: align_center False -> linspace over the range; the
+        # per-class sets concatenated the way AnchorHeadTemplate does it, torch.cat(self.anchors, dim=-3))
         r = cfg.point_cloud_range
         w, h = cfg.grid_size[0] // 8, cfg.grid_size[1] // 8
         xs = torch.arange(r[0], r[3] + 1e-5, step=(r[3] - r[0]) / (w - 1), dtype=torch.float32)
         ys = torch.arange(r[1], r[4] + 1e-5, step=(r[4] - r[1]) / (h - 1), dtype=torch.float32)
-        a = torch.zeros(h, w, na, 7)
-        a[..., 0] = xs.view(1, w, 1)
-        a[..., 1] = ys.view(h, 1, 1)
-        a[..., 3:6] = torch.tensor(cfg.anchor_size)
-        a[..., 2] = cfg.anchor_bottom + cfg.anchor_size[2] / 2
-        a[..., 6] = torch.tensor(cfg.anchor_rotations).view(1, 1, na)
+        a = torch.zeros(h, w, nc, nr, 7)
+        a[..., 0] = xs.view(1, w, 1, 1)
+        a[..., 1] = ys.view(h, 1, 1, 1)
+        for c, (size, bottom, _, _) in enumerate(cfg.anchor_classes):
+            a[:, :, c, :, 3:6] = torch.tensor(size)
+            a[:, :, c, :, 2] = bottom
+        a[..., 6] = torch.tensor(cfg.anchor_rotations).view(1, 1, 1, nr)
+        a[..., 2] += a[..., 5] / 2                                              # bottom height -> box centre (anchor_generator.py:58)
         self.register_buffer("anchors", a.view(-1, 7), persistent=False)
-        self.register_buffer("anchor_bev", nearest_bev_boxes(a.view(-1, 7)), persistent=False)
         self.register_buffer("anchor_rot", a.view(-1, 7)[:, 6].contiguous(), persistent=False)
+        for c in range(nc):   # the target assigner works class by class on that class's anchors (y, x, rot)
+            ac = a[:, :, c].reshape(-1, 7).contiguous()
+            self.register_buffer(f"anchors_c{c}", ac, persistent=False)
+            self.register_buffer(f"anchor_bev_c{c}", nearest_bev_boxes(ac), persistent=False)
 
     @torch.no_grad()
     def assign(self, gt):
-        """gt (B, G, 8) zero padded -> labels (B, A) in {-1, 0, cls}, reg targets (B, A, 7)."""
-        if gt.is_cuda and gt.shape[-1] >= 8:
-            # two launches for the batch (csrc/targets.hip); assign_tensor_ops is the same rule in torch ops (and the CPU path)
-            b, g, a = gt.shape[0], gt.shape[1], self.anchors.shape[0]
-            gt = gt.contiguous()
-            gb = nearest_bev_boxes(gt[..., :7]).contiguous()
-            labels = torch.empty((b, a), dtype=torch.int32, device=gt.device)
-            reg = gt.new_empty(b, a, 7)
-            with _nat.device_guard(gt.device):
-                ws = _nat.workspace(int(_nat.lib().fv2p_anchor_assign_ws_bytes(b, g)), gt.device)
-                _nat.call("fv2p_anchor_assign", self.anchor_bev, self.anchors, a, gb, gt, b, g, gt.shape[-1], float(self.cfg.matched_thr),
-                          float(self.cfg.unmatched_thr), labels, reg, ws, ws.numel(), _nat.stream())
-            return labels, reg
-        return self.assign_tensor_ops(gt)
-
-    @torch.no_grad()
-    def assign_tensor_ops(self, gt):
+        """gt (B, G, 8) zero padded -> labels (B, A) in {-1, 0, cls}, reg targets (B, A, 7).  Class by class
+        (AxisAlignedTargetAssigner.assign_targets :36-128): the anchors of entry c meet the boxes of class c + 1 only."""
         cfg = self.cfg
-        gb = nearest_bev_boxes(gt[..., :7])                                     # (B, G, 4)
-        ab = self.anchor_bev                                                    # (A, 4)
+        nc, nr, b = len(cfg.anchor_classes), len(cfg.anchor_rotations), gt.shape[0]
+        labels, regs = [], []
+        for c, (_, _, matched, unmatched) in enumerate(cfg.anchor_classes):
+            gt_c = gt if nc == 1 else torch.where((gt[..., 7:8] == c + 1), gt, torch.zeros_like(gt))   # other classes' rows become padding
+            one = self.assign_one_kernel if (gt.is_cuda and gt.shape[-1] >= 8) else self.assign_one_tensor_ops
+            lab, reg = one(gt_c, getattr(self, f"anchors_c{c}"), getattr(self, f"anchor_bev_c{c}"), matched, unmatched)
+            labels.append(lab.view(b, -1, 1, nr))
+            regs.append(reg.view(b, -1, 1, nr, 7))
+        if nc == 1:
+            return labels[0].view(b, -1), regs[0].view(b, -1, 7)
+        return torch.cat(labels, dim=2).reshape(b, -1), torch.cat(regs, dim=2).reshape(b, -1, 7)
+
+    def assign_tensor_ops(self, gt):
+        """The same rule in torch ops only (the CPU path; the kernel is compared with it bit for bit)."""
+        cfg = self.cfg
+        nc, nr, b = len(cfg.anchor_classes), len(cfg.anchor_rotations), gt.shape[0]
+        labels, regs = [], []
+        for c, (_, _, matched, unmatched) in enumerate(cfg.anchor_classes):
+            gt_c = gt if nc == 1 else torch.where((gt[..., 7:8] == c + 1), gt, torch.zeros_like(gt))
+            lab, reg = self.assign_one_tensor_ops(gt_c, getattr(self, f"anchors_c{c}"), getattr(self, f"anchor_bev_c{c}"), matched, unmatched)
+            labels.append(lab.view(b, -1, 1, nr))
+            regs.append(reg.view(b, -1, 1, nr, 7))
+        return torch.cat(labels, dim=2).reshape(b, -1), torch.cat(regs, dim=2).reshape(b, -1, 7)
+
+    @staticmethod
+    @torch.no_grad()
+    def assign_one_kernel(gt, anchors, anchor_bev, matched, unmatched):
+        # two launches for the batch (csrc/targets.hip); assign_one_tensor_ops is the same rule in torch ops
+        b, g, a = gt.shape[0], gt.shape[1], anchors.shape[0]
+        gt = gt.contiguous()
+        gb = nearest_bev_boxes(gt[..., :7]).contiguous()
+        labels = torch.empty((b, a), dtype=torch.int32, device=gt.device)
+        reg = gt.new_empty(b, a, 7)
+        with _nat.device_guard(gt.device):
+            ws = _nat.workspace(int(_nat.lib().fv2p_anchor_assign_ws_bytes(b, g)), gt.device)
+            _nat.call("fv2p_anchor_assign", anchor_bev, anchors, a, gb, gt, b, g, gt.shape[-1], float(matched), float(unmatched), labels, reg, ws,
+                      ws.numel(), _nat.stream())
+        return labels, reg
+
+    @staticmethod
+    @torch.no_grad()
+    def assign_one_tensor_ops(gt, anchors, ab, matched, unmatched):
+        gb = nearest_bev_boxes(gt[..., :7])                                     # (B, G, 4); ab (A, 4)
         lo = torch.maximum(ab[None, :, None, 0:2], gb[:, None, :, 0:2])
         hi = torch.minimum(ab[None, :, None, 2:4], gb[:, None, :, 2:4])
         inter = (hi - lo).clamp_min(0).prod(-1)                                 # (B, A, G)
@@ -334,10 +369,10 @@ class AnchorHead(nn.Module):
         forced = (iou == g_max[:, None, :]).any(dim=2)
         cls = torch.gather(gt[..., 7], 1, a_arg).int()
         labels = torch.full_like(cls, -1)
-        labels = torch.where(a_max < cfg.unmatched_thr, torch.zeros_like(labels), labels)
-        labels = torch.where(forced | (a_max >= cfg.matched_thr), cls, labels)
-        matched = torch.gather(gt[..., :7], 1, a_arg.unsqueeze(-1).expand(-1, -1, 7))
-        reg = residual_encode(matched, self.anchors[None].expand_as(matched))
+        labels = torch.where(a_max < unmatched, torch.zeros_like(labels), labels)
+        labels = torch.where(forced | (a_max >= matched), cls, labels)
+        matched_gt = torch.gather(gt[..., :7], 1, a_arg.unsqueeze(-1).expand(-1, -1, 7))
+        reg = residual_encode(matched_gt, anchors[None].expand_as(matched_gt))
         reg = torch.where((labels > 0).unsqueeze(-1), reg, torch.zeros_like(reg))
         return labels, reg
 

@@ -296,9 +296,10 @@ def main():
     from fv2p_harness import synth
     from fv2p_harness.fv2p_model import AnchorHead, FV2PConfig
 
-    class Small(FV2PConfig):   # tests/test_fv2p_step_gpu.py::SmallFV2P
+    class Small(FV2PConfig):   # tests/test_fv2p_step_gpu.py::SmallFV2P, the Car entry of ANCHOR_GENERATOR_CONFIG only
         point_cloud_range = (0.0, -20.0, -3.0, 35.2, 20.0, 1.0)
         grid_size = (704, 800, 40)
+        anchor_classes = FV2PConfig.anchor_classes[:1]
     anchors = AnchorHead(Small, 128).anchors.clone()
     assign = method("models/dense_heads/target_assigner/axis_aligned_target_assigner.py", "AxisAlignedTargetAssigner", "assign_targets_single",
                     {"torch": torch, "np": np, "box_utils": types.SimpleNamespace(boxes3d_nearest_bev_iou=bns["boxes3d_nearest_bev_iou"]),
@@ -313,13 +314,44 @@ def main():
             if smp == 1:   # a box outside every anchor: its maximum overlap is zero, it must force nothing
                 bx = np.concatenate([bx, np.array([[500.0, 500.0, 0.0, 3.9, 1.6, 1.5, 0.3]], np.float32)])
             gt = torch.from_numpy(bx.astype(np.float32))
-            r = assign(me, anchors, gt, torch.ones(len(bx), dtype=torch.int32), matched_threshold=Small.matched_thr, unmatched_threshold=Small.unmatched_thr)
+            r = assign(me, anchors, gt, torch.ones(len(bx), dtype=torch.int32), matched_threshold=Small.anchor_classes[0][2], unmatched_threshold=Small.anchor_classes[0][3])
             out[f"gt{smp}"] = bx.astype(np.float32)
             out[f"labels{smp}"] = r["box_cls_labels"].numpy()
             out[f"targets{smp}"] = r["box_reg_targets"].numpy()
     finally:
         torch.Tensor.cuda = keep_cuda
     save("anchor_assign", anchors=anchors.numpy(), **out)
+
+    # ---- the three anchor sets of fv2p.yaml and the batch-level assignment -----------------------------------------------------------------
+    # ANCHOR_GENERATOR_CONFIG has a Car, a Pedestrian and a Cyclist entry although CLASS_NAMES is ['Car']: AnchorGenerator builds all
+    # three sets, AnchorHeadTemplate concatenates them (torch.cat(anchors, dim=-3)), and AxisAlignedTargetAssigner.assign_targets
+    # (:36-128) assigns class by class — the Pedestrian / Cyclist anchors never meet a box of their class
+    acfg3 = [dict(class_name="Car", anchor_sizes=[[3.9, 1.6, 1.56]], anchor_rotations=[0, 1.57], anchor_bottom_heights=[-1.78], align_center=False,
+                  matched_threshold=0.6, unmatched_threshold=0.45),
+             dict(class_name="Pedestrian", anchor_sizes=[[0.8, 0.6, 1.73]], anchor_rotations=[0, 1.57], anchor_bottom_heights=[-0.6], align_center=False,
+                  matched_threshold=0.5, unmatched_threshold=0.35),
+             dict(class_name="Cyclist", anchor_sizes=[[1.76, 0.6, 1.73]], anchor_rotations=[0, 1.57], anchor_bottom_heights=[-0.6], align_center=False,
+                  matched_threshold=0.5, unmatched_threshold=0.35)]
+    batch_assign = method("models/dense_heads/target_assigner/axis_aligned_target_assigner.py", "AxisAlignedTargetAssigner", "assign_targets",
+                          {"torch": torch, "np": np})
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        sets3 = ag.AnchorGenerator([0, -20.0, -3, 35.2, 20.0, 1], acfg3).generate_anchors([np.array([88, 100])] * 3)[0]
+        flat3 = torch.cat(sets3, dim=-3).view(-1, 7)
+        me3 = types.SimpleNamespace(match_height=False, pos_fraction=None, sample_size=512, norm_by_num_examples=False, box_coder=coder,
+                                    class_names=np.array(["Car"]), anchor_class_names=[c["class_name"] for c in acfg3], use_multihead=False,
+                                    matched_thresholds={c["class_name"]: c["matched_threshold"] for c in acfg3},
+                                    unmatched_thresholds={c["class_name"]: c["unmatched_threshold"] for c in acfg3})
+        me3.assign_targets_single = lambda *a, **k: assign(me3, *a, **k)
+        gt3 = np.zeros((2, 48, 8), np.float32)
+        for smp in range(2):
+            n = len(out[f"gt{smp}"])
+            gt3[smp, :n, :7] = out[f"gt{smp}"]
+            gt3[smp, :n, 7] = 1.0
+        r3 = batch_assign(me3, sets3, torch.from_numpy(gt3))
+    finally:
+        torch.Tensor.cuda = keep_cuda
+    save("anchor_assign3", anchors=flat3.numpy(), gt=gt3, labels=r3["box_cls_labels"].numpy(), targets=r3["box_reg_targets"].numpy())
 
     # ---- first-stage losses ---------------------------------------------------------------------------------------------------------------
     # AnchorHeadTemplate.get_cls_layer_loss + get_box_reg_layer_loss (anchor_head_template.py:101-218) behind a stub head with

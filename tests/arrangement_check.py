@@ -31,5 +31,6 @@ for other in runs[1:]:
         continue   # a 1e-7 difference in a proposal score swapped two NMS neighbours: the second stage then sees other RoIs
     assert abs(other[0] - runs[0][0]) < 1e-5 * max(1.0, abs(runs[0][0]))
     for k, g0 in runs[0][3].items():
-        assert float((other[3][k] - g0).norm() / g0.norm().clamp_min(1e-12)) < 1e-4, k
+        # (the bias of a conv that feeds BatchNorm has a zero gradient up to rounding: absolute floor beside the relative bound)
+        assert float((other[3][k] - g0).norm()) < 1e-4 * float(g0.norm()) + 1e-6 * g0.numel() ** 0.5, k
 print("ARRANGEMENTS AGREE")
