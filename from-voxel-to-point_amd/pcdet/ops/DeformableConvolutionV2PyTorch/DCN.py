@@ -1,6 +1,5 @@
 """`DCN` — the extension module of the reference's DeformableConvolutionV2PyTorch (src/vision.cpp:6-12) as a Python
-shim over libfv2p_ops: same six function names and positional arguments.  The deformable PSROI pooling pair is bound
-by the reference but used by no model and is not implemented here."""
+shim over libfv2p_ops: same six function names and positional arguments."""
 import torch
 
 import fv2p_native as _nat
@@ -81,9 +80,40 @@ def deform_conv_backward(input, weight, bias, offset, grad_output, kernel_h, ker
     return [gi, go, gw, gb]
 
 
-def deform_psroi_pooling_forward(*args, **kwargs):
-    raise NotImplementedError("deformable PSROI pooling is bound by the reference but used by no model; not provided")
+def _ps_geom(input, bbox, trans, no_trans, spatial_scale, output_dim, group_size, pooled_size, part_size, sample_per_part, trans_std):
+    if not input.is_cuda:
+        raise _nat.Fv2pError("Not implemented on the CPU")  # as the reference dispatcher (deform_psroi_pooling.h)
+    assert bbox.is_cuda and (no_trans or trans.is_cuda), "rois / trans must be a CUDA tensor"
+    B, C, H, W = input.shape
+    assert C == output_dim, "input channels and output channels must equal"   # deform_psroi_pooling_cuda.cu:291
+    classes = 1 if no_trans else trans.shape[1] // 2
+    return (B, C, H, W, bbox.shape[0], int(no_trans), float(spatial_scale), output_dim, group_size, pooled_size, part_size,
+            sample_per_part, float(trans_std), classes)
 
 
-def deform_psroi_pooling_backward(*args, **kwargs):
-    raise NotImplementedError("deformable PSROI pooling is bound by the reference but used by no model; not provided")
+def deform_psroi_pooling_forward(input, bbox, trans, no_trans, spatial_scale, output_dim, group_size, pooled_size, part_size,
+                                 sample_per_part, trans_std):
+    """-> (output, top_count), both [num_rois, output_dim, pooled, pooled] (deform_psroi_pooling_cuda.cu:264-341).
+    bbox [num_rois, 5] = (batch index, x1, y1, x2, y2); trans [>= num_rois, 2 * num_classes, part, part] (ignored with no_trans)."""
+    g = _ps_geom(input, bbox, trans, no_trans, spatial_scale, output_dim, group_size, pooled_size, part_size, sample_per_part, trans_std)
+    x = input.float().contiguous()
+    out = torch.empty((bbox.shape[0], output_dim, pooled_size, pooled_size), dtype=torch.float32, device=input.device)
+    top_count = torch.zeros_like(out)
+    with _nat.device_guard(input.device):
+        _nat.call("fv2p_deform_psroi_pool_forward", x, bbox.float().contiguous(), None if no_trans else trans.float().contiguous(), *g,
+                  out, top_count, _nat.stream())
+    return out.to(input.dtype), top_count.to(input.dtype)
+
+
+def deform_psroi_pooling_backward(out_grad, input, bbox, trans, top_count, no_trans, spatial_scale, output_dim, group_size, pooled_size,
+                                  part_size, sample_per_part, trans_std):
+    """-> (input_grad, trans_grad) (deform_psroi_pooling_cuda.cu:343-418); trans_grad has trans's shape."""
+    g = _ps_geom(input, bbox, trans, no_trans, spatial_scale, output_dim, group_size, pooled_size, part_size, sample_per_part, trans_std)
+    x = input.float().contiguous()
+    dx = torch.zeros_like(x)
+    dtrans = torch.zeros_like(trans, dtype=torch.float32).contiguous()
+    with _nat.device_guard(input.device):
+        _nat.call("fv2p_deform_psroi_pool_backward", out_grad.float().contiguous(), x, bbox.float().contiguous(),
+                  None if no_trans else trans.float().contiguous(), top_count.float().contiguous(), *g, dx,
+                  None if no_trans else dtrans, _nat.stream())
+    return dx.to(input.dtype), dtrans.to(trans.dtype)

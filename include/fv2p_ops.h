@@ -413,6 +413,28 @@ int fv2p_dcn_backward(const float* x_nhwc, const float* wt, const float* offset,
                       int deformable_group, float* dx_nhwc, float* doffset, float* dmask, float* dwt, void* ws,
                       size_t ws_bytes, fv2p_stream_t stream);
 
+/* ---- A14: deformable position-sensitive RoI pooling ----------------------------------------------
+ * Replace DCN.deform_psroi_pooling_forward / _backward
+ * (pcdet/ops/DeformableConvolutionV2PyTorch/src/vision.cpp:11-12 -> src/deform_psroi_pooling.h ->
+ * src/cuda/deform_psroi_pooling_cuda.cu:264-418; kernels :59-147, :149-262; caller functions/deform_psroi_pooling_func.py:15-64).
+ * Reference layouts: data / grad_data [B, C, H, W]; rois [R, 5] = (batch index, x1, y1, x2, y2) in image pixels;
+ * trans / grad_trans [>=R, 2*num_classes, part, part] (NULL with no_trans, num_classes then counts as 1);
+ * out / top_count / grad_out [R, output_dim, pooled, pooled] (top_count = samples that fell on the map, as float).
+ * C must equal output_dim * group_size^2 (the reference asserts C == output_dim and reads beyond the map for
+ * group_size > 1).  An RoI whose batch index is outside [0, B) pools to zeros with count 0.
+ * backward: grad_data and grad_trans must be zeroed by the caller (accumulated with atomics). */
+int fv2p_deform_psroi_pool_forward(const float* data, const float* rois, const float* trans, int batch, int channels,
+                                   int height, int width, int num_rois, int no_trans, float spatial_scale,
+                                   int output_dim, int group_size, int pooled_size, int part_size,
+                                   int sample_per_part, float trans_std, int num_classes, float* out,
+                                   float* top_count, fv2p_stream_t stream);
+int fv2p_deform_psroi_pool_backward(const float* grad_out, const float* data, const float* rois, const float* trans,
+                                    const float* top_count, int batch, int channels, int height, int width,
+                                    int num_rois, int no_trans, float spatial_scale, int output_dim,
+                                    int group_size, int pooled_size, int part_size, int sample_per_part,
+                                    float trans_std, int num_classes, float* grad_data, float* grad_trans,
+                                    fv2p_stream_t stream);
+
 /* ---- (f).3: BatchNorm1d (+ReLU) over sparse-tensor features [N, C] --------------------------------
  * The pair every conv of the reference backbones is followed by: nn.BatchNorm1d(eps=1e-3, momentum=0.01) + nn.ReLU
  * (pcdet/models/backbones_3d/spconv_backbone.py:8-27, :75), applied to SparseConvTensor.features by
