@@ -120,13 +120,15 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize=3, stride=1, paddin
     """Hashed rulebook build (fv2p_rulebook_begin/finish). Returns a `Rulebook`."""
     _nat.require_cuda(indices)
     ndim = indices.shape[1] - 1
-    if ndim not in (2, 3):
-        raise NotImplementedError("fv2p rulebook supports 2-D and 3-D sparse tensors")
+    if ndim not in (2, 3, 4):
+        raise NotImplementedError("fv2p rulebook supports 2-D, 3-D and 4-D sparse tensors")
     ksize, stride, padding = _as_list(ksize, ndim), _as_list(stride, ndim), _as_list(padding, ndim)
     dilation, out_padding = _as_list(dilation, ndim), _as_list(out_padding, ndim)
     for d, s in zip(dilation, stride):
         assert any([s == 1, d == 1]), "don't support this."
     spatial_shape = [int(s) for s in spatial_shape]
+    if ndim == 4:
+        return _build_rulebook_4d(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, out_padding, subm, transpose)
     if subm:
         out_shape = spatial_shape
     elif transpose:
@@ -174,6 +176,69 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize=3, stride=1, paddin
     rb = Rulebook(outids, indices, tab_in, tab_out, num, spatial_shape, kvol, bool(subm))
     rb.out_spatial_shape = out_shape
     rb.geom = (tuple(ksize), tuple(stride), tuple(padding), tuple(dilation), tuple(out_padding), bool(subm), bool(transpose))
+    rb.batch_size = int(batch_size)
+    return rb
+
+
+def nd_tables(indices, batch_size, in_shape, out_shape, ksize, stride, padding, dilation, subm):
+    """Neighbour tables of an N-D rulebook from sorted cell keys (torch sort / unique / searchsorted on the tensors' device):
+    the definition spconv_ops.h:27-140 + geometry.h:25-84 reduce to when stride or dilation is 1 — output cell o and kernel
+    offset k (row-major index, last dimension fastest) pair with input cell p iff o * stride = p + padding - k * dilation,
+    submanifold: stride 1, padding = ksize // 2 (spconv_ops.h:76-80), outputs = the active inputs.  Output rows of a regular
+    conv are in ascending (batch, cell) order, the order the reference's GPU path gets from torch::_unique.
+    -> (outids [M, 1 + N] i32, tab_in [K, n_in] i32: output row fed by input i through offset k or -1,
+        tab_out [K, M] i32: input row feeding output o through offset k or -1).
+    Used for 4-D tensors only (SparseConv4d / SubMConv4d: API surface of the reference, no config builds one); the 2-D / 3-D
+    rulebooks are the hashed HIP build above."""
+    dev = indices.device
+    nd = len(in_shape)
+    n = int(indices.shape[0])
+    lng = lambda v: torch.tensor([int(x) for x in v], dtype=torch.int64, device=dev)
+    if subm:
+        stride, padding = [1] * nd, [k // 2 for k in ksize]
+    k_t, s_t, p_t, d_t, o_t = lng(ksize), lng(stride), lng(padding), lng(dilation), lng(out_shape)
+    kvol = int(np.prod(ksize))
+    vol = int(np.prod(out_shape))
+    offs = torch.stack(torch.meshgrid(*[torch.arange(int(k), device=dev) for k in ksize], indexing="ij"), dim=-1).reshape(kvol, nd)
+    mult = lng([int(np.prod(out_shape[i + 1:])) for i in range(nd)])
+    coords, b = indices[:, 1:].long(), indices[:, 0].long()
+    numer = coords.unsqueeze(0) + p_t - offs.unsqueeze(1) * d_t                      # [K, n, nd] = o * stride
+    o = torch.div(numer, s_t, rounding_mode="floor")
+    valid = ((numer - o * s_t == 0) & (o >= 0) & (o < o_t)).all(dim=-1)                # [K, n]
+    keys = torch.where(valid, (o * mult).sum(-1) + b.unsqueeze(0) * vol, torch.full((), -1, dtype=torch.int64, device=dev))
+    rows = torch.arange(n, dtype=torch.int32, device=dev).unsqueeze(0).expand(kvol, n)
+    if subm:
+        in_keys, order = torch.sort((coords * mult).sum(-1) + b * vol)
+        pos = torch.searchsorted(in_keys, keys.reshape(-1)).reshape(kvol, n).clamp_(max=max(n - 1, 0))
+        hit = valid & (in_keys[pos] == keys) if n else valid
+        tab_in = torch.where(hit, order[pos].int(), torch.full((), -1, dtype=torch.int32, device=dev)) if n else rows.clone()
+        outids, m = indices, n
+    else:
+        uniq = torch.unique(keys[valid])                                               # sorted
+        m = int(uniq.numel())
+        pos = torch.searchsorted(uniq, keys.reshape(-1)).reshape(kvol, n)
+        tab_in = torch.where(valid, pos.int(), torch.full((), -1, dtype=torch.int32, device=dev))
+        cell = uniq % vol
+        outids = torch.stack([uniq // vol] + [(cell // mult[i]) % o_t[i] for i in range(nd)], dim=1).int()
+        hit = valid
+    tab_out = torch.full((kvol, m), -1, dtype=torch.int32, device=dev)
+    kk = torch.arange(kvol, device=dev).unsqueeze(1).expand(kvol, n)
+    tab_out[kk[hit], tab_in[hit].long()] = rows[hit]
+    return outids.contiguous(), tab_in.contiguous(), tab_out.contiguous()
+
+
+def _build_rulebook_4d(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, out_padding, subm, transpose):
+    if transpose:
+        raise NotImplementedError("4-D transposed sparse convolution: the reference has no SparseConvTranspose4d either (conv.py:233-480)")
+    out_shape = spatial_shape if subm else get_conv_output_size(spatial_shape, ksize, stride, padding, dilation)
+    if indices.dtype != torch.int32:
+        indices = indices.int()
+    indices = indices.contiguous()
+    outids, tab_in, tab_out = nd_tables(indices, batch_size, spatial_shape, out_shape, ksize, stride, padding, dilation, subm)
+    kvol = int(np.prod(ksize))
+    rb = Rulebook(outids, indices, tab_in, tab_out, None, spatial_shape, kvol, bool(subm))
+    rb.out_spatial_shape = out_shape
+    rb.geom = (tuple(ksize), tuple(stride), tuple(padding), tuple(dilation), tuple(out_padding), bool(subm), False)
     rb.batch_size = int(batch_size)
     return rb
 
