@@ -22,8 +22,9 @@ def get_indice_pairs_3d(indices, batchSize, outSpatialShape, spatialShape, ksize
     return _pairs(indices, batchSize, outSpatialShape, spatialShape, ksize, stride, padding, dilation, outPadding, subM, transpose)
 
 
-def get_indice_pairs_4d(*args, **kwargs):
-    raise NotImplementedError("4-D sparse tensors are not supported by the fv2p rulebook (no reference model uses them)")
+def get_indice_pairs_4d(indices, batchSize, outSpatialShape, spatialShape, ksize, stride, padding, dilation, outPadding,
+                        subM, transpose):
+    return _pairs(indices, batchSize, outSpatialShape, spatialShape, ksize, stride, padding, dilation, outPadding, subM, transpose)
 
 
 def get_indice_pairs_grid_2d(indices, gridOut, batchSize, outSpatialShape, spatialShape, ksize, stride, padding, dilation,

@@ -78,7 +78,9 @@ def random_boxes(rng, n, spread=20.0):
 
 
 def main():
-    save = lambda name, **kw: (np.savez_compressed(os.path.join(OUT, f"pyref_{name}.npz"), **kw), print(name, {k: np.asarray(v).shape for k, v in kw.items()}))
+    import sys
+    only = set(sys.argv[1:])       # `python oracle/gen_golden_pyref.py rotate_iou` rewrites that fixture only
+    save = lambda name, **kw: (not only or name in only) and (np.savez_compressed(os.path.join(OUT, f"pyref_{name}.npz"), **kw), print(name, {k: np.asarray(v).shape for k, v in kw.items()}))
     rng = np.random.default_rng(2024)
 
     # ---- scatter_nd / dense ------------------------------------------------------------------------------------------------
@@ -425,6 +427,47 @@ def main():
     x_bev = torch.randn(2, 16, 24, 20)
     y_bev = ref_bev({"spatial_features": x_bev})["spatial_features_2d"]
     save("bev_backbone", x=x_bev.numpy(), y=y_bev.detach().numpy(), **{"p:" + k: v.detach().numpy() for k, v in ref_bev.state_dict().items()})
+
+    # ---- rotated BEV overlap: the reference's OTHER implementation -------------------------------------------------------------------------
+    # datasets/kitti/kitti_object_eval_python/rotate_iou.py:17-260 (the evaluation code's quadrilateral intersection: segment crossings +
+    # corners inside the other box, vertices sorted around their mean, triangle fan) is numba.cuda device code written in plain Python:
+    # with `numba.jit` / `cuda.jit` as identity decorators and `cuda.local.array` as a float32 numpy array it runs as is.  It is
+    # independent of iou3d_nms_kernel.cu's algorithm (A16), which the oracle restates, and differs from it only where that kernel is
+    # approximate by construction (its point-in-box margin of 1e-2 and 1e-8 guards).  rbbox = (x, y, dx, dy, -heading): the evaluation
+    # code turns clockwise, the LiDAR boxes counter-clockwise.
+    import sys as _sys
+    nb = _types.ModuleType("numba")
+    ident = lambda *a, **k: (a[0] if len(a) == 1 and callable(a[0]) and not k else (lambda f: f))
+    nb.jit, nb.float32 = ident, np.float32
+    nbc = _types.ModuleType("numba.cuda")
+    nbc.jit, nbc.local = ident, _types.SimpleNamespace(array=lambda shape, dtype: np.zeros(shape, dtype))
+    nb.cuda = nbc
+    had = {k: _sys.modules.get(k) for k in ("numba", "numba.cuda")}
+    _sys.modules["numba"], _sys.modules["numba.cuda"] = nb, nbc
+    try:
+        riou = by_path("ref_rotate_iou", "datasets/kitti/kitti_object_eval_python/rotate_iou.py")
+    finally:
+        for k, v in had.items():
+            if v is None:
+                _sys.modules.pop(k, None)
+            else:
+                _sys.modules[k] = v
+    rr = np.random.default_rng(77)
+    n = 600
+    pa, pb = np.zeros((n, 7), np.float32), np.zeros((n, 7), np.float32)
+    for bx in (pa, pb):
+        bx[:, :2], bx[:, 2] = rr.uniform(-3, 3, (n, 2)), rr.uniform(-1, 1, n)
+        bx[:, 3], bx[:, 4], bx[:, 5] = rr.uniform(1.5, 5, n), rr.uniform(1, 2.5, n), rr.uniform(1, 2, n)
+        bx[:, 6] = rr.uniform(-np.pi, np.pi, n)
+    pb[:40, :2], pb[:40, 6] = pa[:40, :2], pa[:40, 6] + np.float32(np.pi / 2)   # same centre, crossed (identical boxes are degenerate in that code: 0 for 17 of 40 tried)
+    pb[40:80, :2] = pa[40:80, :2] + rr.uniform(-0.3, 0.3, (40, 2))   # near-identical centres, different headings
+    pb[80:120, 3:5] = pa[80:120, 3:5] * 0.4                       # a small box ...
+    pb[80:120, :2] = pa[80:120, :2]                               # ... inside a large one
+    pb[120:160, :2] = pa[120:160, :2] + 20                        # far apart
+    as_r = lambda q: np.array([q[0], q[1], q[3], q[4], -q[6]], np.float32)
+    inter = np.array([riou.inter(as_r(p), as_r(q)) for p, q in zip(pa, pb)], np.float64)
+    iou = np.array([riou.devRotateIoUEval(as_r(p), as_r(q), -1) for p, q in zip(pa, pb)], np.float64)
+    save("rotate_iou", boxes_a=pa, boxes_b=pb, overlap=inter, iou=iou)
 
 
 if __name__ == "__main__":

@@ -24,6 +24,10 @@ def test_rulebook_4d_matches_the_restatement(gpu, case):
     outids, pairs, num = ops.get_indice_pairs(torch.from_numpy(ind).to(gpu), batch, shape, k, s, p, d, 0, subm, False)
     assert outids.dtype == torch.int32 and pairs.dtype == torch.int32 and pairs.shape == (int(np.prod(k)), 2, n)
     assert np.array_equal(outids.cpu().numpy(), o_out)
+    from pcdet.ops.spconv import sparse_conv_ext as ext       # the pybind name of the reference (all.cc:28-29)
+    e_out, e_pairs, e_num = ext.get_indice_pairs_4d(torch.from_numpy(ind).to(gpu), batch, list(o_out.max(0)[1:] + 1) if len(o_out) else shape, shape,
+                                                    k, s, p, d, [0] * 4, int(subm), 0)
+    assert torch.equal(e_out, outids) and torch.equal(e_pairs, pairs) and torch.equal(e_num, num)
     num, pairs = num.cpu().numpy(), pairs.cpu().numpy()
     assert np.array_equal(num, o_num)
     for kk, (a, b) in enumerate(zip(canon_pairs(pairs, num), canon_pairs(o_pairs, o_num))):
