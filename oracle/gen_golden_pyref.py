@@ -23,6 +23,8 @@ implements in importable Python:
   dense_heads/anchor_head_template.py:229-276   AnchorHeadTemplate.generate_predicted_boxes (stub head)
   dense_heads/target_assigner/anchor_generator.py:17-61   AnchorGenerator.generate_anchors (imported by path)
   roi_heads/roi_withiou_head_template.py:101-131   RoIWithIoUHeadTemplate.assign_targets (canonical transformation; stub target layer)
+  datasets/kitti/kitti_object_eval_python/rotate_iou.py:17-260   inter, devRotateIoUEval (numba.cuda device code run as plain Python)
+  ops/spconv/test_utils.py:144-193   generate_sparse_data (the reference's sparse / dense test-data generator)
   dense_heads/target_assigner/axis_aligned_target_assigner.py:130-215   AxisAlignedTargetAssigner.assign_targets_single
                                  (method compiled out of the class; Tensor.cuda is the identity while it runs)
 
@@ -468,6 +470,15 @@ def main():
     inter = np.array([riou.inter(as_r(p), as_r(q)) for p, q in zip(pa, pb)], np.float64)
     iou = np.array([riou.devRotateIoUEval(as_r(p), as_r(q), -1) for p, q in zip(pa, pb)], np.float64)
     save("rotate_iou", boxes_a=pa, boxes_b=pb, overlap=inter, iou=iou)
+
+    # ---- the reference's own sparse test data ---------------------------------------------------------------------------------------------
+    # spconv/test_utils.py:144-193 generate_sparse_data (imported by path: numpy only; upstream spconv's test_conv.py — SparseConv3d against
+    # nn.Conv3d on this generator's `features_dense` — was not vendored with it, tests/ restate that test): unique random cells per sample,
+    # uniform features, and the dense tensor the generator scatters itself.  Indices come out as (z, y, x, batch).
+    tu = by_path("ref_spconv_test_utils", "ops/spconv/test_utils.py")
+    np.random.seed(484)
+    sd = tu.generate_sparse_data([19, 18, 17], [1500, 1300], 16)
+    save("sparse_data", features=sd["features"], indices=sd["indices"], features_dense=sd["features_dense"], spatial_shape=np.array([19, 18, 17]))
 
 
 if __name__ == "__main__":
