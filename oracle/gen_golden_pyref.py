@@ -24,6 +24,7 @@ implements in importable Python:
   dense_heads/target_assigner/anchor_generator.py:17-61   AnchorGenerator.generate_anchors (imported by path)
   roi_heads/roi_withiou_head_template.py:101-131   RoIWithIoUHeadTemplate.assign_targets (canonical transformation; stub target layer)
   datasets/kitti/kitti_object_eval_python/rotate_iou.py:17-260   inter, devRotateIoUEval (numba.cuda device code run as plain Python)
+  datasets/kitti/kitti_object_eval_python/eval.py:121-147        d3_box_overlap_kernel (3-D IoU from the BEV intersection; def compiled out of the file)
   ops/spconv/test_utils.py:144-193   generate_sparse_data (the reference's sparse / dense test-data generator)
   dense_heads/target_assigner/axis_aligned_target_assigner.py:130-215   AxisAlignedTargetAssigner.assign_targets_single
                                  (method compiled out of the class; Tensor.cuda is the identity while it runs)
@@ -469,7 +470,17 @@ def main():
     as_r = lambda q: np.array([q[0], q[1], q[3], q[4], -q[6]], np.float32)
     inter = np.array([riou.inter(as_r(p), as_r(q)) for p, q in zip(pa, pb)], np.float64)
     iou = np.array([riou.devRotateIoUEval(as_r(p), as_r(q), -1) for p, q in zip(pa, pb)], np.float64)
-    save("rotate_iou", boxes_a=pa, boxes_b=pb, overlap=inter, iou=iou)
+    # 3-D IoU of the same pairs from the evaluation code's d3_box_overlap_kernel (kitti_object_eval_python/eval.py:121-147, compiled out of the
+    # file: its module imports numba and the package-relative rotate_iou), fed with the BEV intersections above.  It works on camera boxes
+    # (x, y_bottom, z, l, h, w, ry) with y pointing down: a LiDAR box (cx, cy, cz, dx, dy, dz, heading) is (cx, -(cz - dz/2), cy, dx, dz, dy, -heading).
+    d3 = extract("datasets/kitti/kitti_object_eval_python/eval.py", ["d3_box_overlap_kernel"], {"numba": nb, "np": np})["d3_box_overlap_kernel"]
+    cam = lambda q: np.array([[q[0], -(q[2] - q[5] / 2), q[1], q[3], q[5], q[4], -q[6]]], np.float64)
+    iou3d = np.zeros(n, np.float64)
+    for i, (p, q) in enumerate(zip(pa, pb)):
+        rinc = np.array([[inter[i]]], np.float64)
+        d3(cam(p.astype(np.float64)), cam(q.astype(np.float64)), rinc, -1)
+        iou3d[i] = rinc[0, 0]
+    save("rotate_iou", boxes_a=pa, boxes_b=pb, overlap=inter, iou=iou, iou3d=iou3d)
 
     # ---- the reference's own sparse test data ---------------------------------------------------------------------------------------------
     # spconv/test_utils.py:144-193 generate_sparse_data (imported by path: numpy only; upstream spconv's test_conv.py — SparseConv3d against
