@@ -23,6 +23,7 @@ implements in importable Python:
   dense_heads/anchor_head_template.py:229-276   AnchorHeadTemplate.generate_predicted_boxes (stub head)
   dense_heads/target_assigner/anchor_generator.py:17-61   AnchorGenerator.generate_anchors (imported by path)
   roi_heads/roi_withiou_head_template.py:101-131   RoIWithIoUHeadTemplate.assign_targets (canonical transformation; stub target layer)
+  roi_heads/roi_head_template.py:46-99 + model_utils/model_nms_utils.py:6-25   RoIHeadTemplate.proposal_layer around class_agnostic_nms
   datasets/kitti/kitti_object_eval_python/rotate_iou.py:17-260   inter, devRotateIoUEval (numba.cuda device code run as plain Python)
   datasets/kitti/kitti_object_eval_python/eval.py:121-147        d3_box_overlap_kernel (3-D IoU from the BEV intersection; def compiled out of the file)
   ops/spconv/test_utils.py:144-193   generate_sparse_data (the reference's sparse / dense test-data generator)
@@ -481,6 +482,34 @@ def main():
         d3(cam(p.astype(np.float64)), cam(q.astype(np.float64)), rinc, -1)
         iou3d[i] = rinc[0, 0]
     save("rotate_iou", boxes_a=pa, boxes_b=pb, overlap=inter, iou=iou, iou3d=iou3d)
+
+    # ---- proposal layer of the second stage --------------------------------------------------------------------------------------------------
+    # RoIHeadTemplate.proposal_layer (roi_heads/roi_head_template.py:46-99, method compiled out of the class) around
+    # model_nms_utils.class_agnostic_nms (model_utils/model_nms_utils.py:6-25, def compiled out of the file): per sample max over classes,
+    # top NMS_PRE_MAXSIZE by score, NMS, first NMS_POST_MAXSIZE survivors, zero padding, labels + 1.  `iou3d_nms_utils.nms_gpu` — the op
+    # under test elsewhere — is answered by oracle.nms on the already sorted candidates, so the fixture pins the Python composition.
+    import oracle as _oracle
+    def _nms_gpu(boxes, scores, thresh, pre_maxsize=None, **kwargs):
+        keep = _oracle.nms(boxes.numpy(), scores.numpy(), thresh, pre_maxsize=pre_maxsize)
+        return torch.from_numpy(keep).long(), None
+    pns = {"torch": torch, "iou3d_nms_utils": _types.SimpleNamespace(nms_gpu=_nms_gpu)}
+    extract("models/model_utils/model_nms_utils.py", ["class_agnostic_nms"], pns)
+    prop_layer = method("models/roi_heads/roi_head_template.py", "RoIHeadTemplate", "proposal_layer", pns)
+    class _Nms(dict):
+        __getattr__ = dict.__getitem__
+    nms_cfg = _Nms(NMS_TYPE="nms_gpu", MULTI_CLASSES_NMS=False, NMS_PRE_MAXSIZE=1000, NMS_POST_MAXSIZE=128, NMS_THRESH=0.8)
+    rp = np.random.default_rng(31)
+    pb_, ps_ = [], []
+    for centres, per in ((60, 25), (300, 5)):          # sample 0: 60 clusters -> fewer than 128 survivors (padding); sample 1: more than 128 (cut)
+        base = random_boxes(rp, centres, spread=30.0)
+        bx = np.repeat(base, per, 0) + rp.normal(0, 0.05, (centres * per, 7)).astype(np.float32)
+        pb_.append(bx[rp.permutation(len(bx))].astype(np.float32))
+        ps_.append(rp.normal(0, 2, len(bx)).astype(np.float32))
+    pbx, psc = np.stack(pb_), np.stack(ps_)
+    bd = {"batch_size": 2, "batch_box_preds": torch.from_numpy(pbx), "batch_cls_preds": torch.from_numpy(psc)[..., None]}
+    bd = prop_layer(_types.SimpleNamespace(), bd, nms_cfg)
+    save("proposal_layer", boxes=pbx, scores=psc, rois=bd["rois"].numpy(), roi_scores=bd["roi_scores"].numpy(), roi_labels=bd["roi_labels"].numpy(),
+         nms_pre=1000, nms_post=128, nms_thresh=np.float32(0.8))
 
     # ---- the reference's own sparse test data ---------------------------------------------------------------------------------------------
     # spconv/test_utils.py:144-193 generate_sparse_data (imported by path: numpy only; upstream spconv's test_conv.py — SparseConv3d against
