@@ -23,6 +23,7 @@ implements in importable Python:
   dense_heads/anchor_head_template.py:229-276   AnchorHeadTemplate.generate_predicted_boxes (stub head)
   dense_heads/target_assigner/anchor_generator.py:17-61   AnchorGenerator.generate_anchors (imported by path)
   roi_heads/roi_withiou_head_template.py:101-131   RoIWithIoUHeadTemplate.assign_targets (canonical transformation; stub target layer)
+  backbones_3d/pfe/residual_v2p_decoder.py:46-313 + pointnet2_batch/pointnet2_utils.py:292-326   ResidualVoxelToPointDecoder around top3_interpolate
   roi_heads/roi_head_template.py:46-99 + model_utils/model_nms_utils.py:6-25   RoIHeadTemplate.proposal_layer around class_agnostic_nms
   datasets/kitti/kitti_object_eval_python/rotate_iou.py:17-260   inter, devRotateIoUEval (numba.cuda device code run as plain Python)
   datasets/kitti/kitti_object_eval_python/eval.py:121-147        d3_box_overlap_kernel (3-D IoU from the BEV intersection; def compiled out of the file)
@@ -510,6 +511,61 @@ def main():
     bd = prop_layer(_types.SimpleNamespace(), bd, nms_cfg)
     save("proposal_layer", boxes=pbx, scores=psc, rois=bd["rois"].numpy(), roi_scores=bd["roi_scores"].numpy(), roi_labels=bd["roi_labels"].numpy(),
          nms_pre=1000, nms_post=128, nms_thresh=np.float32(0.8))
+
+    # ---- voxel-to-point decoder ------------------------------------------------------------------------------------------------------------------
+    # ResidualVoxelToPointDecoder + LateralBottomResBlock (backbones_3d/pfe/residual_v2p_decoder.py:46-313, classes compiled out of the file:
+    # its module imports the CUDA extensions) around pointnet2_batch_utils.top3_interpolate (pointnet2_batch/pointnet2_utils.py:292-326, def
+    # compiled out of the file).  The three ops underneath — furthest_point_sample, three_nn, three_interpolate — are answered by the
+    # oracle, so the fixture pins the Python of the paper's decoder: key points per sample incl. the short-cloud rule (:218-220), voxel
+    # centres per level, inverse-distance weights, the residual blocks and their parameter names.  fv2p.yaml's block layout at an eighth
+    # of the channels, 1 024 key points, one cloud shorter than that.
+    def _three_nn(unknown, known):
+        d2, idx = _oracle.three_nn_batch(unknown.numpy(), known.numpy())
+        return torch.sqrt(torch.from_numpy(d2)), torch.from_numpy(idx)          # pointnet2_utils.py:92-93
+    def _three_interpolate(features, idx, weight):
+        return torch.from_numpy(_oracle.three_interpolate_batch(features.detach().numpy(), idx.numpy(), weight.detach().numpy()))
+    def _fps(xyz, npoint):
+        return torch.from_numpy(_oracle.furthest_point_sample(xyz.numpy(), npoint)[0])
+    tns = {"torch": torch, "three_nn": _three_nn, "three_interpolate": _three_interpolate}
+    extract("ops/pointnet2/pointnet2_batch/pointnet2_utils.py", ["top3_interpolate"], tns)
+    dns = {"torch": torch, "nn": torch.nn, "common_utils": cu, "pointnet2_batch_utils": _types.SimpleNamespace(top3_interpolate=tns["top3_interpolate"]),
+           "pointnet2_stack_utils": _types.SimpleNamespace(furthest_point_sample=_fps)}
+    extract("models/backbones_3d/pfe/residual_v2p_decoder.py", ["LateralBottomResBlock", "ResidualVoxelToPointDecoder"], dns)
+    class _C(dict):
+        __getattr__ = dict.__getitem__
+    blk = lambda stride, lat, out: _C(LATERAL_DOWNSAMPLE_FACTOR=stride, BOTTOM_DOWNSAMPLE_FACTOR=1, LATERAL_CHANNELS=lat, OUT_CHANNELS=out, NSAMPLE=3)
+    dec_levels = (("x_conv4", 8, 16, 32), ("x_conv3", 4, 8, 24), ("x_conv2", 2, 4, 20), ("x_conv1", 1, 2, 16))
+    dcfg = _C(POINT_SOURCE="raw_points", SAMPLE_METHOD="FPS", NUM_KEYPOINTS=1024, FEATURES_SOURCE=["x_conv4", "x_conv3", "x_conv2", "x_conv1"],
+              INIT_BLOCK=_C(blk(8, 16, 16), SOURCE="x_conv4"), DECODE_BLOCKS=_C({n: blk(st, lat, out) for n, st, lat, out in dec_levels}),
+              OUT_BLOCK=_C(OUT_CHANNELS=16, NSAMPLE=3))
+    d_vs, d_rng = [0.05, 0.05, 0.1], [0.0, -12.8, -3.0, 25.6, 12.8, 1.0]           # grid 512 x 512 x 40
+    torch.manual_seed(23)
+    ref_dec = dns["ResidualVoxelToPointDecoder"](dcfg, d_vs, d_rng)
+    for prm in ref_dec.parameters():
+        if prm.dim() == 1:
+            prm.data.uniform_(0.5, 1.5)
+    rd = np.random.default_rng(41)
+    pts, lvl = [], {}
+    for b_i, n_pts in enumerate((3000, 900)):                                      # the second cloud is shorter than NUM_KEYPOINTS
+        xyz = np.stack([rd.uniform(0.5, 25.0, n_pts), rd.uniform(-12.0, 12.0, n_pts), rd.uniform(-2.5, 0.5, n_pts)], 1)
+        pts.append(np.concatenate([np.full((n_pts, 1), b_i), xyz, rd.random((n_pts, 1))], 1).astype(np.float32))
+    pts_all = np.concatenate(pts)
+    for (name, stride, lat, _), n_vox in zip(dec_levels, (400, 900, 1500, 2500)):
+        gz, gy, gx = (41 + stride - 1) // stride, 512 // stride, 512 // stride
+        rows = []
+        for b_i in range(2):
+            cells = rd.choice(gz * gy * gx, n_vox, replace=False)
+            rows.append(np.stack([np.full(n_vox, b_i), cells // (gy * gx), (cells // gx) % gy, cells % gx], 1))
+        lvl[name] = (np.concatenate(rows).astype(np.int32), rd.standard_normal((2 * n_vox, lat)).astype(np.float32))
+    bdict = {"batch_size": 2, "points": torch.from_numpy(pts_all),
+             "multi_scale_3d_features": {k: _types.SimpleNamespace(indices=torch.from_numpy(i), features=torch.from_numpy(f)) for k, (i, f) in lvl.items()}}
+    ref_dec.train()
+    key_ref = ref_dec.get_sampled_points(bdict)
+    od = ref_dec(bdict)
+    save("v2p_decoder", points=pts_all, keypoints=key_ref.numpy(), point_coords=od["point_coords"].numpy(), point_features=od["point_features"].detach().numpy(),
+         voxel_size=np.array(d_vs, np.float32), point_cloud_range=np.array(d_rng, np.float32),
+         **{f"ind:{k}": i for k, (i, f) in lvl.items()}, **{f"feat:{k}": f for k, (i, f) in lvl.items()},
+         **{"p:" + k: v.detach().numpy() for k, v in ref_dec.state_dict().items()})
 
     # ---- the reference's own sparse test data ---------------------------------------------------------------------------------------------
     # spconv/test_utils.py:144-193 generate_sparse_data (imported by path: numpy only; upstream spconv's test_conv.py — SparseConv3d against
