@@ -24,6 +24,7 @@ implements in importable Python:
   dense_heads/target_assigner/anchor_generator.py:17-61   AnchorGenerator.generate_anchors (imported by path)
   roi_heads/roi_withiou_head_template.py:101-131   RoIWithIoUHeadTemplate.assign_targets (canonical transformation; stub target layer)
   backbones_3d/pfe/residual_v2p_decoder.py:46-313 + pointnet2_batch/pointnet2_utils.py:292-326   ResidualVoxelToPointDecoder around top3_interpolate
+  pointnet2_batch/pointnet2_modules.py:10-98 + pointnet2_utils.py:231-264   PointnetSAModuleMSG around QueryAndGroup (grid set abstraction)
   roi_heads/roi_head_template.py:46-99 + model_utils/model_nms_utils.py:6-25   RoIHeadTemplate.proposal_layer around class_agnostic_nms
   datasets/kitti/kitti_object_eval_python/rotate_iou.py:17-260   inter, devRotateIoUEval (numba.cuda device code run as plain Python)
   datasets/kitti/kitti_object_eval_python/eval.py:121-147        d3_box_overlap_kernel (3-D IoU from the BEV intersection; def compiled out of the file)
@@ -566,6 +567,36 @@ def main():
          voxel_size=np.array(d_vs, np.float32), point_cloud_range=np.array(d_rng, np.float32),
          **{f"ind:{k}": i for k, (i, f) in lvl.items()}, **{f"feat:{k}": f for k, (i, f) in lvl.items()},
          **{"p:" + k: v.detach().numpy() for k, v in ref_dec.state_dict().items()})
+
+    # ---- grid set abstraction of the second stage -------------------------------------------------------------------------------------------------
+    # PointnetSAModuleMSG + QueryAndGroup (pointnet2_batch/pointnet2_modules.py:10-98, pointnet2_utils.py:231-264; classes compiled out of their
+    # files) with ball_query / grouping_operation answered by the oracle: the module IoUGuidedRoIHead builds for its grid points
+    # (iouguided_roi_head.py:52-76: radii 0.8 / 1.6, 16 / 32 samples, mlps [C -> 64 -> 64] x 2, use_xyz, no BatchNorm; C = 32 instead of 128 input channels) on 4 RoIs of 512
+    # canonical points and the 216 grid points of each, one RoI empty (all points at the origin, :188).  Pins what the fused kernel
+    # (first layer per point / per centre, gather + second layer + max in one launch) has to reproduce.
+    from typing import List as _List, Tuple as _Tuple
+    def _ball_query(radius, nsample, xyz, new_xyz):
+        return torch.from_numpy(_oracle.ball_query_batch(radius, nsample, xyz.numpy(), new_xyz.numpy()))
+    def _grouping(features, idx):
+        return torch.from_numpy(_oracle.group_points_batch(features.detach().numpy(), idx.numpy()))
+    uns = {"torch": torch, "nn": torch.nn, "Tuple": _Tuple, "ball_query": _ball_query, "grouping_operation": _grouping}
+    extract("ops/pointnet2/pointnet2_batch/pointnet2_utils.py", ["QueryAndGroup"], uns)
+    mns = {"torch": torch, "nn": torch.nn, "F": torch.nn.functional, "List": _List, "pointnet2_utils": _types.SimpleNamespace(QueryAndGroup=uns["QueryAndGroup"])}
+    extract("ops/pointnet2/pointnet2_batch/pointnet2_modules.py", ["_PointnetSAModuleBase", "PointnetSAModuleMSG"], mns)
+    torch.manual_seed(29)
+    ref_sa = mns["PointnetSAModuleMSG"](npoint=216, radii=[0.8, 1.6], nsamples=[16, 32], mlps=[[32, 64, 64], [32, 64, 64]], use_xyz=True, bn=False)
+    rs = np.random.default_rng(53)
+    n_roi = 4
+    sa_xyz = (rs.uniform(-1, 1, (n_roi, 512, 3)) * np.array([2.6, 1.4, 1.0])).astype(np.float32)
+    sa_xyz[2, 300:] = sa_xyz[2, :212]                                   # a RoI pooled from fewer points than slots: repeats
+    sa_feat = rs.standard_normal((n_roi, 32, 512)).astype(np.float32)
+    sa_feat[2, :, 300:] = sa_feat[2, :, :212]
+    sa_xyz[3], sa_feat[3] = 0, 0                                        # an empty RoI
+    sizes = np.array([[3.9, 1.6, 1.56]], np.float32) * rs.uniform(0.8, 1.2, (n_roi, 3)).astype(np.float32)
+    gi = (np.stack(np.meshgrid(np.arange(6), np.arange(6), np.arange(6), indexing="ij"), -1).reshape(1, 216, 3).astype(np.float32) + 0.5) / 6
+    sa_grid = (gi * sizes[:, None] - sizes[:, None] / 2).astype(np.float32)
+    _, sa_out = ref_sa(torch.from_numpy(sa_xyz), torch.from_numpy(sa_feat), torch.from_numpy(sa_grid))
+    save("sa_grid", xyz=sa_xyz, features=sa_feat, grid=sa_grid, out=sa_out.detach().numpy(), **{"p:" + k: v.detach().numpy() for k, v in ref_sa.state_dict().items()})
 
     # ---- the reference's own sparse test data ---------------------------------------------------------------------------------------------
     # spconv/test_utils.py:144-193 generate_sparse_data (imported by path: numpy only; upstream spconv's test_conv.py — SparseConv3d against
