@@ -784,18 +784,30 @@ class IoUGuidedRoIHead(nn.Module):
         rois, _ = self.proposals(prop_scores, prop_boxes)
         s_rois, s_gt, s_iou = self.sample_targets(rois, gt, uniforms)
         gt_ct = self.canonical_targets(s_rois, s_gt)
+        return dict(rois=rois, s_rois=s_rois, s_gt=s_gt, s_iou=s_iou, gt_ct=gt_ct, **self.roi_streams(bev, s_rois))
+
+    def roi_streams(self, bev, s_rois, bev_stride=8):
+        """The two streams of forward_single_loop (iouguided_roi_head.py:223-304) that need no key points: the RoI grids with the BEV
+        features gathered at them, and the corner-geometry embedding."""
+        b = bev.shape[0]
         world, local = self.grid_points(s_rois)
         # BEV stream: bilinear gather at the grid points + channel compression (:243-255)
-        g_bev = self.bev_grid_pool_layer({"spatial_features_before_head": bev, "spatial_features_stride": 8}, world.view(b, -1, 3))
+        g_bev = self.bev_grid_pool_layer({"spatial_features_before_head": bev, "spatial_features_stride": bev_stride}, world.view(b, -1, 3))
         g_bev = g_bev.view(world.shape[0], world.shape[1], -1).permute(0, 2, 1).contiguous()
         # corner geometry stream (feature_adaptor/nn_modules.py:6-60): roi-frame corners without rotation or centre
         t = dconst(s_rois, _CORNER_SIGNS, s_rois.dtype) / 2
         corners = s_rois.reshape(-1, 7)[:, None, 3:6] * t[None]
         cge = self.cge_inter(self.cge_up(corners.transpose(1, 2).unsqueeze(3).contiguous()).squeeze(-1))
-        return dict(rois=rois, s_rois=s_rois, s_gt=s_gt, s_iou=s_iou, gt_ct=gt_ct, local=local, g_bev=g_bev, cge=cge)
+        return dict(local=local, g_bev=g_bev, cge=cge)
 
     def finish(self, key, feats, scores, prep):
         rois = prep["s_rois"]
+        cls, reg = self.predict(key, feats, scores, rois, prep)
+        loss = self.losses(rois, prep["s_gt"], prep["gt_ct"], prep["s_iou"], cls, reg[:, 1:], reg[:, :1])
+        return loss, {"rois": prep["rois"], "sampled_rois": rois, "roi_iou": prep["s_iou"]}
+
+    def predict(self, key, feats, scores, rois, prep):
+        """forward_single_loop (iouguided_roi_head.py:223-304) from the pooled points on: -> (rcnn_cls (B*n, 1), [iou, 7 residuals] (B*n, 8))."""
         pooled = self.pool_points(key, feats, scores, rois)                                        # (B*n, 512, 5 + C)
         # xyz_up_layer / merge_down_layer are 1x1 convs over the 512 pooled points of each RoI (:223-236): applied point-major, as
         # batched row products (same weights; see rows_linear) - the pooled tensor already is (RoI, point, channel)
@@ -812,8 +824,7 @@ class IoUGuidedRoIHead(nn.Module):
         shared = self.feature_fusion(torch.cat((pc, prep["cge"]), dim=1))
         cls = self.cls_layers(shared).squeeze(-1)                                                  # (B*n, 1)
         reg = self.reg_layers(shared).squeeze(-1)                                                  # (B*n, 8): [iou, 7 residuals]
-        loss = self.losses(rois, prep["s_gt"], prep["gt_ct"], prep["s_iou"], cls, reg[:, 1:], reg[:, :1])
-        return loss, {"rois": prep["rois"], "sampled_rois": rois, "roi_iou": prep["s_iou"]}
+        return cls, reg
 
     @staticmethod
     def reg_losses(rois, gt_src, gt_ct, fg, reg):

@@ -25,6 +25,8 @@ implements in importable Python:
   roi_heads/roi_withiou_head_template.py:101-131   RoIWithIoUHeadTemplate.assign_targets (canonical transformation; stub target layer)
   backbones_3d/pfe/residual_v2p_decoder.py:46-313 + pointnet2_batch/pointnet2_utils.py:292-326   ResidualVoxelToPointDecoder around top3_interpolate
   pointnet2_batch/pointnet2_modules.py:10-98 + pointnet2_utils.py:231-264   PointnetSAModuleMSG around QueryAndGroup (grid set abstraction)
+  roi_heads/iouguided_roi_head.py:144-193 + roipoint_pool3d/roipoint_pool3d_utils.py:31-63   roipool3d_gpu around RoIPointPool3dFunction
+  roi_heads/iouguided_roi_head.py:11-304   IoUGuidedRoIHead.__init__ + forward_single_loop over the classes above (whole second-stage forward)
   roi_heads/roi_head_template.py:46-99 + model_utils/model_nms_utils.py:6-25   RoIHeadTemplate.proposal_layer around class_agnostic_nms
   datasets/kitti/kitti_object_eval_python/rotate_iou.py:17-260   inter, devRotateIoUEval (numba.cuda device code run as plain Python)
   datasets/kitti/kitti_object_eval_python/eval.py:121-147        d3_box_overlap_kernel (3-D IoU from the BEV intersection; def compiled out of the file)
@@ -597,6 +599,85 @@ def main():
     sa_grid = (gi * sizes[:, None] - sizes[:, None] / 2).astype(np.float32)
     _, sa_out = ref_sa(torch.from_numpy(sa_xyz), torch.from_numpy(sa_feat), torch.from_numpy(sa_grid))
     save("sa_grid", xyz=sa_xyz, features=sa_feat, grid=sa_grid, out=sa_out.detach().numpy(), **{"p:" + k: v.detach().numpy() for k, v in ref_sa.state_dict().items()})
+
+    # ---- point stream of the second stage: RoI point pooling in the RoI frame ------------------------------------------------------------------------
+    # IoUGuidedRoIHead.roipool3d_gpu (roi_heads/iouguided_roi_head.py:144-193, method compiled out of the class) around RoIPointPool3dFunction.forward
+    # (roipoint_pool3d/roipoint_pool3d_utils.py:31-63, class compiled out of the file) with `roipoint_pool3d_cuda.forward` answered by the oracle:
+    # per-point [score, depth / DEPTH_NORMALIZER - 0.5, features], boxes enlarged by POOL_EXTRA_WIDTH (a list: enlarge_box3d), pooled points
+    # moved into the RoI frame (centre, then rotation by -heading), empty RoIs zeroed.
+    def _pool_fwd(points, boxes, feats, pooled, flag):
+        pf, fl = _oracle.roipoint_pool3d(points.numpy(), feats.numpy(), boxes.numpy(), pooled.shape[2])
+        pooled.copy_(torch.from_numpy(pf)), flag.copy_(torch.from_numpy(fl))
+    rpn = {"torch": torch, "nn": torch.nn, "Function": torch.autograd.Function, "box_utils": _types.SimpleNamespace(enlarge_box3d=bns["enlarge_box3d"]),
+           "roipoint_pool3d_cuda": _types.SimpleNamespace(forward=_pool_fwd)}
+    extract("ops/roipoint_pool3d/roipoint_pool3d_utils.py", ["RoIPointPool3d", "RoIPointPool3dFunction"], rpn)
+    hns = {"torch": torch, "common_utils": cu}
+    pool_m = method("models/roi_heads/iouguided_roi_head.py", "IoUGuidedRoIHead", "roipool3d_gpu", hns)
+    rq = np.random.default_rng(61)
+    n_key, n_roi, c_pt = 2048, 16, 8
+    key_xyz = np.stack([rq.uniform(0, 40, (2, n_key)), rq.uniform(-20, 20, (2, n_key)), rq.uniform(-2.5, 0.5, (2, n_key))], -1).astype(np.float32)
+    rois_p = np.stack([random_boxes(rq, n_roi, spread=18.0) for _ in range(2)])
+    rois_p[..., 0] += 20
+    rois_p[:, -1, :3] = (200.0, 200.0, 0.0)                                     # nothing near: empty flag
+    rois_p[:, 0, 3:6] *= 0.4                                                    # a small box: fewer points than slots, repeated to fill them
+    pstub2 = _types.SimpleNamespace(model_cfg=_C(ROI_POINT_POOL=_C(DEPTH_NORMALIZER=70.0)),
+                                    roipoint_pool3d_layer=rpn["RoIPointPool3d"](num_sampled_points=64, pool_extra_width=[0.4, 0.4, 0.4]))
+    bd2 = {"batch_size": 2, "point_coords": torch.from_numpy(np.concatenate([np.repeat(np.arange(2, dtype=np.float32), n_key)[:, None], key_xyz.reshape(-1, 3)], 1)),
+           "point_features": torch.from_numpy(rq.standard_normal((2 * n_key, c_pt)).astype(np.float32)),
+           "point_cls_scores": torch.from_numpy(rq.random(2 * n_key).astype(np.float32))}
+    pooled_ref = pool_m(pstub2, bd2, torch.from_numpy(rois_p))
+    save("roi_point_pool", keypoints=key_xyz, point_features=bd2["point_features"].numpy(), point_scores=bd2["point_cls_scores"].numpy(), rois=rois_p,
+         pooled=pooled_ref.numpy())
+
+    # ---- second stage, forward_single_loop as a whole -----------------------------------------------------------------------------------------------------
+    # The reference's own IoUGuidedRoIHead class (roi_heads/iouguided_roi_head.py:11-304: __init__, roipool3d_gpu, the grid points, forward_single_loop;
+    # class compiled out of its file) over the reference classes pinned one by one above (RoIPointPool3d, PointnetSAModuleMSG), its
+    # CornerGeometryEncodeModule / FeatureFusionModule (feature_adaptor/nn_modules.py, imported by path), BEVGridPooling + bilinear_interpolate_torch
+    # (backbones_3d/pfe/bev_grid_pooling.py, compiled out of the file) and boxes_to_CTcorners_3d (utils/box_utils.py:56-87).  The base class is
+    # reduced to what __init__ reads (make_fc_layers of roi_withiou_head_template.py:29-43, num_class, the coder's code size); the CUDA ops are the
+    # oracle's.  fv2p.yaml's head at reduced widths: 3^3 grid points, 128 pooled points, no dropout (DP_RATIO 0), training-mode BatchNorm.
+    nnm = by_path("ref_roi_nn_modules", "models/roi_heads/feature_adaptor/nn_modules.py")
+    gns = extract("models/backbones_3d/pfe/bev_grid_pooling.py", ["bilinear_interpolate_torch", "BEVGridPooling"], {"torch": torch, "nn": torch.nn})
+    ctn = extract("utils/box_utils.py", ["boxes_to_CTcorners_3d"], {"torch": torch, "np": np, "common_utils": cu})
+    class _HeadBase(torch.nn.Module):
+        def __init__(self, num_class, model_cfg):
+            super().__init__()
+            self.num_class, self.model_cfg, self.box_coder = num_class, model_cfg, _types.SimpleNamespace(code_size=7)
+    _HeadBase.make_fc_layers = method("models/roi_heads/roi_withiou_head_template.py", "RoIWithIoUHeadTemplate", "make_fc_layers", {"nn": torch.nn})
+    ins = {"torch": torch, "nn": torch.nn, "pointnet2_modules": _types.SimpleNamespace(PointnetSAModuleMSG=mns["PointnetSAModuleMSG"]),
+           "roipoint_pool3d_utils": _types.SimpleNamespace(RoIPointPool3d=rpn["RoIPointPool3d"]), "common_utils": cu,
+           "box_utils": _types.SimpleNamespace(boxes_to_CTcorners_3d=ctn["boxes_to_CTcorners_3d"]), "RoIWithIoUHeadTemplate": _HeadBase,
+           "CornerGeometryEncodeModule": nnm.CornerGeometryEncodeModule, "FeatureFusionModule": nnm.FeatureFusionModule, "BEVGridPooling": gns["BEVGridPooling"]}
+    extract("models/roi_heads/iouguided_roi_head.py", ["IoUGuidedRoIHead"], ins)
+    hcfg = _C(BEV_GRID_POOL=_C(IN_CHANNELS=32, OUT_CHANNELS=16), ROI_POINT_POOL=_C(NUM_SAMPLED_POINTS=128, POOL_EXTRA_WIDTH=[1.0, 1.0, 1.0], DEPTH_NORMALIZER=70.0),
+              USE_BN=False, XYZ_UP_LAYER=[32, 32], ROI_GRID_POOL=_C(GRID_SIZE=3, SA_CONFIG=_C(NPOINTS=[27], RADIUS=[[0.8, 1.6]], NSAMPLE=[[16, 32]], MLPS=[[[64, 64], [64, 64]]])),
+              GRID_INTERACT=_C(INTERACT_FILTERS=[32, 32]), DP_RATIO=0, CGE_MODULE=_C(UP_FILTERS=[16, 16], INTERACT_FILTERS=[32]), FUSE_FILTERS=[32],
+              CLS_FC=[32, 32], REG_FC=[32, 32], TARGET_CONFIG=_C(CLS_SCORE_TYPE="roi_iou"))
+    h_vs, h_rng = [0.05, 0.05, 0.1], [0.0, -6.4, -3.0, 12.8, 6.4, 1.0]
+    torch.manual_seed(37)
+    ref_head = ins["IoUGuidedRoIHead"](input_channels=32, model_cfg=hcfg, point_cloud_range=h_rng, voxel_size=h_vs, num_class=1)
+    with torch.no_grad():
+        ref_head.reg_layers[-1].weight.normal_(0, 0.1)            # away from its 0.001 init: the residuals should carry signal
+        for prm in ref_head.parameters():
+            if prm.dim() == 1:
+                prm.uniform_(0.5, 1.5)
+    ref_head.train()
+    rh = np.random.default_rng(67)
+    n_key2, n_roi2 = 1024, 8
+    key2 = np.stack([rh.uniform(0.2, 12.6, (2, n_key2)), rh.uniform(-6.2, 6.2, (2, n_key2)), rh.uniform(-2.5, 0.5, (2, n_key2))], -1).astype(np.float32)
+    rois2 = np.stack([random_boxes(rh, n_roi2, spread=4.5) for _ in range(2)])
+    rois2[..., 0] += 6.4
+    rois2[0, -1, :2] = (60.0, 60.0)                                # off the map and away from every point
+    bev2 = rh.standard_normal((2, 32, 32, 32)).astype(np.float32)
+    bd3 = {"batch_size": 2, "point_coords": torch.from_numpy(np.concatenate([np.repeat(np.arange(2, dtype=np.float32), n_key2)[:, None], key2.reshape(-1, 3)], 1)),
+           "point_features": torch.from_numpy(rh.standard_normal((2 * n_key2, 32)).astype(np.float32)),
+           "point_cls_scores": torch.from_numpy(rh.random(2 * n_key2).astype(np.float32)),
+           "spatial_features_before_head": torch.from_numpy(bev2), "spatial_features_stride": 8}
+    r_cls, r_reg, r_iou = ref_head.forward_single_loop(bd3, torch.from_numpy(rois2))
+    save("roi_head_forward", keypoints=key2, point_features=bd3["point_features"].numpy(), point_scores=bd3["point_cls_scores"].numpy(), rois=rois2, bev=bev2,
+         voxel_size=np.array(h_vs, np.float32), point_cloud_range=np.array(h_rng, np.float32),
+         rcnn_cls=r_cls.detach().numpy(), rcnn_reg=r_reg.detach().numpy(), rcnn_iou=r_iou.detach().numpy(),
+         **{"p:" + k: v.detach().numpy() for k, v in ref_head.state_dict().items()})
 
     # ---- the reference's own sparse test data ---------------------------------------------------------------------------------------------
     # spconv/test_utils.py:144-193 generate_sparse_data (imported by path: numpy only; upstream spconv's test_conv.py — SparseConv3d against
