@@ -1,8 +1,6 @@
 """Set-abstraction / feature-propagation modules on the batched pointnet2 ops — class names, constructor keywords
 and parameter names (`groupers`, `mlps`, `mlps_gate`, `mlp`) of the reference's
 pcdet/ops/pointnet2/pointnet2_batch/pointnet2_modules.py:10-280 so checkpoints and configs carry over."""
-from typing import List
-
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -26,16 +24,36 @@ def _sample_centres(xyz, npoint):
     return pointnet2_utils.gather_operation(xyz_flipped, idx).transpose(1, 2).contiguous()
 
 
+def _scales(npoint, radii, nsamples, mlps, use_xyz):
+    """One (grouper, channel widths) per scale.  With use_xyz the first width grows by 3 IN the caller's list, as in the reference
+    (:80-81) — configs that reuse the list see the same numbers here as there."""
+    assert len(radii) == len(nsamples) == len(mlps)
+    for radius, nsample, widths in zip(radii, nsamples, mlps):
+        grouper = pointnet2_utils.QueryAndGroup(radius, nsample, use_xyz=use_xyz) if npoint is not None else pointnet2_utils.GroupAll(use_xyz)
+        if use_xyz:
+            widths[0] += 3
+        yield grouper, widths
+
+
+def _shared_mlp(widths, bn, relu=True):
+    """1x1 Conv2d (bias-free) [+ BatchNorm2d] [+ ReLU] per consecutive pair of widths: indices 0, 1(, 2) ... of the Sequential."""
+    layers = []
+    for cin, cout in zip(widths[:-1], widths[1:]):
+        layers.append(nn.Conv2d(cin, cout, kernel_size=1, bias=False))
+        if bn:
+            layers.append(nn.BatchNorm2d(cout))
+        if relu:
+            layers.append(nn.ReLU())
+    return nn.Sequential(*layers)
+
+
 class _PointnetSAModuleBase(nn.Module):
 
     def __init__(self):
         super().__init__()
-        self.npoint = None
-        self.groupers = None
-        self.mlps = None
-        self.pool_method = 'max_pool'
+        self.npoint, self.groupers, self.mlps, self.pool_method = None, None, None, 'max_pool'
 
-    def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, new_xyz=None) -> (torch.Tensor, torch.Tensor):
+    def forward(self, xyz, features=None, new_xyz=None):
         """xyz (B,N,3), features (B,C,N) -> new_xyz (B,npoint,3), new_features (B, sum_k mlps[k][-1], npoint)."""
         if new_xyz is None:
             new_xyz = _sample_centres(xyz, self.npoint)
@@ -47,87 +65,55 @@ class _PointnetSAModuleBase(nn.Module):
 
 
 class PointnetSAModuleMSG(_PointnetSAModuleBase):
-    """Pointnet set abstraction layer with multiscale grouping"""
+    """Set abstraction with multi-scale grouping: per scale a ball query + grouping, a shared MLP and a pool over the samples."""
 
-    def __init__(self, *, npoint: int, radii: List[float], nsamples: List[int], mlps: List[List[int]], bn: bool = True,
-                 use_xyz: bool = True, pool_method='max_pool'):
+    def __init__(self, *, npoint, radii, nsamples, mlps, bn=True, use_xyz=True, pool_method='max_pool'):
         super().__init__()
-        assert len(radii) == len(nsamples) == len(mlps)
-        self.npoint = npoint
-        self.groupers = nn.ModuleList()
-        self.mlps = nn.ModuleList()
-        for radius, nsample, mlp_spec in zip(radii, nsamples, mlps):
-            self.groupers.append(pointnet2_utils.QueryAndGroup(radius, nsample, use_xyz=use_xyz)
-                                 if npoint is not None else pointnet2_utils.GroupAll(use_xyz))
-            if use_xyz:
-                mlp_spec[0] += 3  # in place, like the reference (:80-81)
-            layers = []
-            for k in range(len(mlp_spec) - 1):
-                layers.append(nn.Conv2d(mlp_spec[k], mlp_spec[k + 1], kernel_size=1, bias=False))
-                if bn:
-                    layers.append(nn.BatchNorm2d(mlp_spec[k + 1]))
-                layers.append(nn.ReLU())
-            self.mlps.append(nn.Sequential(*layers))
-        self.pool_method = pool_method
+        self.npoint, self.pool_method = npoint, pool_method
+        self.groupers, self.mlps = nn.ModuleList(), nn.ModuleList()
+        for grouper, widths in _scales(npoint, radii, nsamples, mlps, use_xyz):
+            self.groupers.append(grouper)
+            self.mlps.append(_shared_mlp(widths, bn))
 
 
 class PointnetSAModule(PointnetSAModuleMSG):
-    """Pointnet set abstraction layer"""
+    """Single-scale set abstraction."""
 
-    def __init__(self, *, mlp: List[int], npoint: int = None, radius: float = None, nsample: int = None,
-                 bn: bool = True, use_xyz: bool = True, pool_method='max_pool'):
-        super().__init__(mlps=[mlp], npoint=npoint, radii=[radius], nsamples=[nsample], bn=bn, use_xyz=use_xyz,
-                         pool_method=pool_method)
+    def __init__(self, *, mlp, npoint=None, radius=None, nsample=None, bn=True, use_xyz=True, pool_method='max_pool'):
+        super().__init__(mlps=[mlp], npoint=npoint, radii=[radius], nsamples=[nsample], bn=bn, use_xyz=use_xyz, pool_method=pool_method)
 
 
 class PointnetFPModule(nn.Module):
-    r"""Propigates the features of one set to another"""
+    """Feature propagation: inverse-distance interpolation from the three nearest known points, concatenated with the skip features."""
 
-    def __init__(self, *, mlp: List[int], bn: bool = True):
+    def __init__(self, *, mlp, bn=True):
         super().__init__()
-        layers = []
-        for k in range(len(mlp) - 1):
-            layers.extend([nn.Conv2d(mlp[k], mlp[k + 1], kernel_size=1, bias=False), nn.BatchNorm2d(mlp[k + 1]), nn.ReLU()])
-        self.mlp = nn.Sequential(*layers)
+        self.mlp = _shared_mlp(mlp, True)      # the reference always builds the BatchNorm here (:132-137)
 
-    def forward(self, unknown: torch.Tensor, known: torch.Tensor, unknow_feats: torch.Tensor,
-                known_feats: torch.Tensor) -> torch.Tensor:
+    def forward(self, unknown, known, unknow_feats, known_feats):
         """unknown (B,n,3), known (B,m,3), unknow_feats (B,C1,n), known_feats (B,C2,m) -> (B, mlp[-1], n)."""
-        if known is not None:
-            dist, idx = pointnet2_utils.three_nn(unknown, known)
-            dist_recip = 1.0 / (dist + 1e-8)
-            norm = torch.sum(dist_recip, dim=2, keepdim=True)
-            weight = dist_recip / norm
-            interpolated_feats = pointnet2_utils.three_interpolate(known_feats, idx, weight).contiguous()
+        if known is None:
+            spread = known_feats.expand(*known_feats.size()[0:2], unknown.size(1)).contiguous()
         else:
-            interpolated_feats = known_feats.expand(*known_feats.size()[0:2], unknown.size(1)).contiguous()
-        new_features = torch.cat([interpolated_feats, unknow_feats], dim=1) if unknow_feats is not None else interpolated_feats
-        return self.mlp(new_features.unsqueeze(-1).contiguous()).squeeze(-1)
+            dist, idx = pointnet2_utils.three_nn(unknown, known)
+            closeness = 1.0 / (dist + 1e-8)
+            spread = pointnet2_utils.three_interpolate(known_feats, idx, closeness / closeness.sum(dim=2, keepdim=True)).contiguous()
+        stacked = spread if unknow_feats is None else torch.cat([spread, unknow_feats], dim=1)
+        return self.mlp(stacked.unsqueeze(-1).contiguous()).squeeze(-1)
 
 
 class PointnetSAModuleMSGGated(nn.Module):
-    """Multiscale grouping with a sigmoid gate branch per scale (fork addition, reference :172-276)."""
+    """Multi-scale grouping with a sigmoid gate branch per scale (fork addition, reference :172-276): mlps[k] is Conv2d + ReLU per
+    layer, mlps_gate[k] the bare Conv2d stack, output = pool(mlps(g) * sigmoid(mlps_gate(g)))."""
 
-    def __init__(self, *, npoint: int, radii: List[float], nsamples: List[int], mlps: List[List[int]], bn: bool = True,
-                 use_xyz: bool = True, pool_method='max_pool'):
+    def __init__(self, *, npoint, radii, nsamples, mlps, bn=True, use_xyz=True, pool_method='max_pool'):
         super().__init__()
-        assert len(radii) == len(nsamples) == len(mlps)
-        self.npoint = npoint
-        self.groupers = nn.ModuleList()
-        self.mlps = nn.ModuleList()
-        self.mlps_gate = nn.ModuleList()
-        for radius, nsample, mlp_spec in zip(radii, nsamples, mlps):
-            self.groupers.append(pointnet2_utils.QueryAndGroup(radius, nsample, use_xyz=use_xyz)
-                                 if npoint is not None else pointnet2_utils.GroupAll(use_xyz))
-            if use_xyz:
-                mlp_spec[0] += 3
-            main, gate = [], []
-            for k in range(len(mlp_spec) - 1):
-                main.extend([nn.Conv2d(mlp_spec[k], mlp_spec[k + 1], kernel_size=1, bias=False), nn.ReLU()])
-                gate.append(nn.Conv2d(mlp_spec[k], mlp_spec[k + 1], kernel_size=1, bias=False))
-            self.mlps.append(nn.Sequential(*main))
-            self.mlps_gate.append(nn.Sequential(*gate))
-        self.pool_method = pool_method
+        self.npoint, self.pool_method = npoint, pool_method
+        self.groupers, self.mlps, self.mlps_gate = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        for grouper, widths in _scales(npoint, radii, nsamples, mlps, use_xyz):
+            self.groupers.append(grouper)
+            self.mlps.append(_shared_mlp(widths, False))
+            self.mlps_gate.append(_shared_mlp(widths, False, relu=False))
         self.init_weights()
 
     def init_weights(self):
@@ -140,12 +126,11 @@ class PointnetSAModuleMSGGated(nn.Module):
                 nn.init.constant_(m.weight, 1.0)
                 nn.init.constant_(m.bias, 0)
 
-    def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, new_xyz=None) -> (torch.Tensor, torch.Tensor):
+    def forward(self, xyz, features=None, new_xyz=None):
         if new_xyz is None:
             new_xyz = _sample_centres(xyz, self.npoint)
         outs = []
         for grouper, mlp, gate in zip(self.groupers, self.mlps, self.mlps_gate):
             g = grouper(xyz, new_xyz, features).contiguous()
-            f = mlp(g) * torch.sigmoid(gate(g))
-            outs.append(_pool(f, self.pool_method).squeeze(-1))
+            outs.append(_pool(mlp(g) * torch.sigmoid(gate(g)), self.pool_method).squeeze(-1))
         return new_xyz, torch.cat(outs, dim=1)

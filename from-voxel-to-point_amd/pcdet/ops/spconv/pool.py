@@ -1,4 +1,6 @@
-"""SparseMaxPool{2d,3d} — surface of reference spconv/pool.py:21-85 (output = max(0, neighbours))."""
+"""SparseMaxPool2d / SparseMaxPool3d — surface of the reference's spconv/pool.py:21-85.  A pooled row is the maximum over the
+active inputs its kernel window covers, starting from zero (the reference zero-fills the output, pool_ops.h:25-57), so features
+below zero pool to zero."""
 from . import functional as Fsp
 from . import ops
 from .modules import SparseModule
@@ -6,35 +8,29 @@ from .structure import SparseConvTensor
 
 
 class SparseMaxPool(SparseModule):
+    """forward(SparseConvTensor) -> SparseConvTensor on the rulebook of a regular (or, with subm, submanifold) convolution window."""
 
     def __init__(self, ndim, kernel_size, stride=1, padding=0, dilation=1, subm=False):
-        super(SparseMaxPool, self).__init__()
-        as_list = lambda v: list(v) if isinstance(v, (list, tuple)) else [v] * ndim
-        self.ndim = ndim
-        self.kernel_size = as_list(kernel_size)
-        self.stride = as_list(stride)
-        self.padding = as_list(padding)
-        self.subm = subm
-        self.dilation = as_list(dilation)
+        super().__init__()
+        per_dim = lambda v: list(v) if isinstance(v, (list, tuple)) else [v] * ndim
+        self.ndim, self.subm = ndim, subm
+        self.kernel_size, self.stride, self.padding, self.dilation = (per_dim(v) for v in (kernel_size, stride, padding, dilation))
 
     def forward(self, input):
         assert isinstance(input, SparseConvTensor)
-        rb = ops.build_rulebook(input.indices, input.batch_size, input.spatial_shape, self.kernel_size, self.stride,
-                                self.padding, self.dilation, 0, self.subm)
-        out_features = Fsp.indice_maxpool(input.features, rb, None, rb.outids.shape[0])
-        out_tensor = SparseConvTensor(out_features, rb.outids, rb.out_spatial_shape, input.batch_size)
-        out_tensor.indice_dict = input.indice_dict
-        out_tensor.grid = input.grid
-        return out_tensor
+        book = ops.build_rulebook(input.indices, input.batch_size, input.spatial_shape, self.kernel_size, self.stride, self.padding,
+                                  self.dilation, 0, self.subm)
+        pooled = Fsp.indice_maxpool(input.features, book, None, book.outids.shape[0])
+        out = SparseConvTensor(pooled, book.outids, book.out_spatial_shape, input.batch_size)
+        out.indice_dict, out.grid = input.indice_dict, input.grid
+        return out
 
 
-class SparseMaxPool2d(SparseMaxPool):
-
+def _fixed_ndim(name, ndim):
     def __init__(self, kernel_size, stride=1, padding=0, dilation=1):
-        super(SparseMaxPool2d, self).__init__(2, kernel_size, stride, padding, dilation)
+        SparseMaxPool.__init__(self, ndim, kernel_size, stride, padding, dilation)
+    return type(name, (SparseMaxPool,), {"__init__": __init__, "__module__": __name__})
 
 
-class SparseMaxPool3d(SparseMaxPool):
-
-    def __init__(self, kernel_size, stride=1, padding=0, dilation=1):
-        super(SparseMaxPool3d, self).__init__(3, kernel_size, stride, padding, dilation)
+SparseMaxPool2d = _fixed_ndim("SparseMaxPool2d", 2)
+SparseMaxPool3d = _fixed_ndim("SparseMaxPool3d", 3)
