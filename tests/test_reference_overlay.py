@@ -3,7 +3,7 @@
 A temporary tree is assembled from symlinks — every entry of /root/reference/pcdet except `ops`, which points at this
 repo's pcdet/ops — and a fresh interpreter imports the reference's backbones, decoder, heads and detectors from it
 (the import surface pcdet/models/** expects); the reference's two sparse backbones, built on this repo's spconv
-modules, have the parameter names and shapes of the replay harness's re-declarations.  Third-party packages the image lacks (cv2, numba, mmcv,
+modules, have the parameter names and shapes of the replay harness's re-declarations and, with one state dict, compute the same features at every level (both run on the host through the oracle's conv shim).  Third-party packages the image lacks (cv2, numba, mmcv,
 shapely, easydict, ...) are replaced by empty stand-in modules inside that interpreter: they are not part of the boundary.
 Skipped where /root/reference does not exist (the GPU box)."""
 import os
@@ -30,7 +30,12 @@ if not hasattr(nb, "jit"):
     nb.jit = lambda *a, **k: (lambda f: f)
 ed = sys.modules["easydict"]
 if not hasattr(ed, "EasyDict"):
-    ed.EasyDict = type("EasyDict", (dict,), {"__getattr__": dict.__getitem__, "__setattr__": dict.__setitem__})
+    def _attr(self, key):
+        try:
+            return self[key]
+        except KeyError:
+            raise AttributeError(key)
+    ed.EasyDict = type("EasyDict", (dict,), {"__getattr__": _attr, "__setattr__": dict.__setitem__})
 sg = sys.modules["shapely.geometry"]
 if not hasattr(sg, "Polygon"):
     sg.Polygon = object
@@ -59,6 +64,30 @@ for ref_cls, own_cls in ((VoxelResBackBone8x, hb.VoxelResBackBone8x), (VoxelBack
     ref_sd = {k: tuple(v.shape) for k, v in ref_cls(ed.EasyDict(), input_channels=4, grid_size=np.array([1408, 1600, 40])).state_dict().items()}
     own_sd = {k: tuple(v.shape) for k, v in own_cls(4, [1408, 1600, 40]).state_dict().items()}
     assert ref_sd == own_sd, (sorted(set(ref_sd.items()) ^ set(own_sd.items()))[:8])
+# ... and compute the same function: the reference class and the harness class with one state dict, both run on the host through
+# the oracle's conv shim (oracle.spconv_cpu.cpu_mirror swaps every SparseConvolution of a module tree), training-mode BatchNorm
+import torch
+from oracle.spconv_cpu import cpu_mirror
+rng = np.random.default_rng(3)
+grid = [96, 80, 24]                                              # x, y, z cells; sparse_shape = [25, 80, 96]
+cells = rng.choice(2 * 24 * 80 * 96, 1500, replace=False)
+coords = np.stack([cells // (24 * 80 * 96), (cells // (80 * 96)) % 24, (cells // 96) % 80, cells % 96], 1).astype(np.int32)
+coords = coords[np.lexsort((coords[:, 3], coords[:, 2], coords[:, 1], coords[:, 0]))]
+feats = torch.from_numpy(rng.standard_normal((1500, 4)).astype(np.float32))
+for ref_cls, own_cls in ((VoxelResBackBone8x, hb.VoxelResBackBone8x), (VoxelBackBone8x, hb.VoxelBackBone8x)):
+    torch.manual_seed(5)
+    ref_net = ref_cls(ed.EasyDict(), input_channels=4, grid_size=np.array(grid))
+    own_net = own_cls(4, grid)
+    own_net.load_state_dict(ref_net.state_dict(), strict=True)
+    ref_cpu, own_cpu = cpu_mirror(ref_net).train(), cpu_mirror(own_net).train()
+    bd = ref_cpu({"voxel_features": feats.clone(), "voxel_coords": torch.from_numpy(coords), "batch_size": 2})
+    out, levels = own_cpu(feats.clone(), torch.from_numpy(coords), 2)
+    enc = bd["encoded_spconv_tensor"]
+    assert torch.equal(enc.indices, out.indices) and list(enc.spatial_shape) == list(out.spatial_shape)
+    assert float((enc.features - out.features).abs().max()) < 1e-5 * float(enc.features.abs().max()), ref_cls.__name__
+    for name, lvl in bd["multi_scale_3d_features"].items():
+        assert torch.equal(lvl.indices, levels[name].indices), name
+        assert float((lvl.features - levels[name].features).abs().max()) < 1e-5 * float(lvl.features.abs().max()), name
 print("OVERLAY_OK", len(mods), n_conv)
 '''
 
@@ -71,6 +100,6 @@ def test_reference_models_import_against_this_ops_package(tmp_path):
         if name != "ops":
             os.symlink(os.path.join(REF, name), root / name)
     os.symlink(os.path.join(REPO, "from-voxel-to-point_amd", "pcdet", "ops"), root / "ops")
-    env = dict(os.environ, PYTHONPATH=os.pathsep.join([str(tmp_path), os.path.join(REPO, "from-voxel-to-point_amd")]))
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([str(tmp_path), os.path.join(REPO, "from-voxel-to-point_amd"), REPO]))
     out = subprocess.run([sys.executable, "-c", SCRIPT], env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "OVERLAY_OK" in out.stdout, out.stderr[-3000:]
