@@ -5,7 +5,7 @@
 caller-allocated outputs from oracle/ (the reference algorithms restated).  The L2 glue, the autograd Functions and the
 harness model therefore execute unchanged on the host and give the reference-side answer for a whole op sequence;
 the GPU run of the same code is compared against it (tests/test_fv2p_step_gpu.py) and bench.py's cpu_baseline leg times it.
-Only symbols the FV2P step reaches are answered; anything else raises.  Never imported by the product package."""
+Only symbols the FV2P step (the harness's, or the reference's own model classes over this package: tests/test_reference_overlay.py) reaches are answered; anything else raises.  Never imported by the product package."""
 import contextlib
 
 import numpy as np
@@ -111,7 +111,28 @@ def _bev_bwd(grad_out, b, c, h, w, channels_first, x, y, n, grad_bev, ws, ws_byt
     _fill(grad_bev, np.transpose(res, (0, 3, 1, 2)) if channels_first else res)
 
 
+def _three_nn_batch(b, n, m, unknown, known, dist2, idx, stream):
+    d2, i = oracle.three_nn_batch(_np(unknown).reshape(b, n, 3), _np(known).reshape(b, m, 3))
+    _fill(dist2, d2), _fill(idx, i)
+
+
+def _three_interp_batch(b, c, m, n, points, idx, weight, out, stream):
+    _fill(out, oracle.three_interpolate_batch(_np(points).reshape(b, c, m), _np(idx).reshape(b, n, 3), _np(weight).reshape(b, n, 3)))
+
+
+def _three_interp_batch_grad(b, c, n, m, grad_out, idx, weight, grad_points, stream):
+    g, i, w = _np(grad_out).reshape(b, c, n).astype(np.float64), _np(idx).reshape(b, n, 3).astype(np.int64), _np(weight).reshape(b, n, 3).astype(np.float64)
+    acc = np.zeros((b, c, m), np.float64)
+    for s in range(b):
+        for k in range(3):
+            np.add.at(acc[s].T, i[s, :, k], (g[s] * w[s, :, k]).T)          # interpolate_gpu.cu:107-149: grad_points[idx] += grad_out * weight
+    _fill(grad_points, acc.astype(np.float32))
+
+
 _TABLE = {
+    "fv2p_three_nn_batch": _three_nn_batch,
+    "fv2p_three_interpolate_batch": _three_interp_batch,
+    "fv2p_three_interpolate_batch_grad": _three_interp_batch_grad,
     "fv2p_three_nn_stack": _three_nn_stack,
     "fv2p_three_interpolate_stack": _three_interp_stack,
     "fv2p_three_interpolate_stack_grad": _three_interp_stack_grad,

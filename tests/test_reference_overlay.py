@@ -5,7 +5,9 @@ repo's pcdet/ops — and a fresh interpreter imports the reference's backbones, 
 (the import surface pcdet/models/** expects); the reference's two sparse backbones, built on this repo's spconv
 modules, have the parameter names and shapes of the replay harness's re-declarations and, with one state dict, compute the same features at every level (both run on the host through the oracle's conv shim).  Third-party packages the image lacks (cv2, numba, mmcv,
 shapely, easydict, ...) are replaced by empty stand-in modules inside that interpreter: they are not part of the boundary.
-Skipped where /root/reference does not exist (the GPU box)."""
+Then the reference's own ResidualVoxelToPointDecoder and IoUGuidedRoIHead (unmodified classes) run on the host as consumers of this package's
+Python layer, every C-ABI call answered by the oracle, and reproduce the fixtures written from the same classes with the ops stubbed out
+directly.  Skipped where /root/reference does not exist (the GPU box)."""
 import os
 import subprocess
 import sys
@@ -88,6 +90,64 @@ for ref_cls, own_cls in ((VoxelResBackBone8x, hb.VoxelResBackBone8x), (VoxelBack
     for name, lvl in bd["multi_scale_3d_features"].items():
         assert torch.equal(lvl.indices, levels[name].indices), name
         assert float((lvl.features - levels[name].features).abs().max()) < 1e-5 * float(lvl.features.abs().max()), name
+# ---- the reference's own decoder and second-stage head, unmodified, as consumers of this package's Python layer -------------------------
+# Every C-ABI call is answered by the oracle (oracle.backend), so the reference classes run on the host through pcdet.ops' wrappers
+# (argument order, layouts, dtypes, autograd Functions) exactly as they would on the HIP library; the expected outputs are the fixtures
+# oracle/gen_golden_pyref.py wrote from the same classes with the ops stubbed out directly (tests/golden/pyref_v2p_decoder.npz,
+# pyref_roi_head_forward.npz) — the two routes differ only by this package's glue.
+import types, yaml
+from oracle.backend import oracle_backend
+torch.Tensor.cuda = lambda self, *a, **k: self                    # loss_utils.WeightedSmoothL1Loss moves its code weights in __init__
+def ED(d):
+    return ed.EasyDict({k: ED(v) for k, v in d.items()}) if isinstance(d, dict) else d
+gold = lambda name: np.load(os.path.join(os.environ["FV2P_GOLDEN"], "pyref_%s.npz" % name))
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+yml = yaml.safe_load(open("/root/reference/tools/cfgs/kitti_models/FV2P/fv2p.yaml"))["MODEL"]
+
+g = gold("v2p_decoder")
+dcfg = ED(yml["POST_PFE"])
+dcfg.NUM_KEYPOINTS = 1024
+for blk, (lat, out_c) in {"x_conv4": (16, 32), "x_conv3": (8, 24), "x_conv2": (4, 20), "x_conv1": (2, 16)}.items():
+    dcfg.DECODE_BLOCKS[blk].LATERAL_CHANNELS, dcfg.DECODE_BLOCKS[blk].OUT_CHANNELS = lat, out_c
+dcfg.INIT_BLOCK.LATERAL_CHANNELS = dcfg.INIT_BLOCK.OUT_CHANNELS = dcfg.OUT_BLOCK.OUT_CHANNELS = 16
+dec = ResidualVoxelToPointDecoder(dcfg, [float(v) for v in g["voxel_size"]], [float(v) for v in g["point_cloud_range"]]).train()
+dec.load_state_dict({k[2:]: t(g[k]) for k in g.files if k.startswith("p:")}, strict=True)
+bd = {"batch_size": 2, "points": t(g["points"]),
+      "multi_scale_3d_features": {n: types.SimpleNamespace(indices=t(g["ind:" + n]), features=t(g["feat:" + n])) for n in ("x_conv1", "x_conv2", "x_conv3", "x_conv4")}}
+with oracle_backend():
+    bd = dec(bd)
+assert torch.equal(bd["point_coords"], t(g["point_coords"])), "key points through this package's furthest_point_sample differ"
+assert float((bd["point_features"] - t(g["point_features"])).abs().max()) < 1e-5 * float(np.abs(g["point_features"]).max())
+
+from pcdet.models.roi_heads.iouguided_roi_head import IoUGuidedRoIHead
+g = gold("roi_head_forward")
+hcfg = ED(yml["ROI_HEAD"])
+hcfg.BEV_GRID_POOL.IN_CHANNELS, hcfg.BEV_GRID_POOL.OUT_CHANNELS = 32, 16
+hcfg.ROI_POINT_POOL.NUM_SAMPLED_POINTS, hcfg.ROI_POINT_POOL.POOL_EXTRA_WIDTH = 128, [1.0, 1.0, 1.0]
+hcfg.XYZ_UP_LAYER, hcfg.CLS_FC, hcfg.REG_FC, hcfg.FUSE_FILTERS, hcfg.DP_RATIO = [32, 32], [32, 32], [32, 32], [32], 0
+hcfg.ROI_GRID_POOL.GRID_SIZE, hcfg.ROI_GRID_POOL.SA_CONFIG.NPOINTS = 3, [27]
+hcfg.GRID_INTERACT.INTERACT_FILTERS, hcfg.CGE_MODULE.UP_FILTERS, hcfg.CGE_MODULE.INTERACT_FILTERS = [32, 32], [16, 16], [32]
+head = IoUGuidedRoIHead(input_channels=32, model_cfg=hcfg, point_cloud_range=[float(v) for v in g["point_cloud_range"]],
+                        voxel_size=[float(v) for v in g["voxel_size"]], num_class=1).train()
+missing = head.load_state_dict({k[2:]: t(g[k]) for k in g.files if k.startswith("p:")}, strict=False)
+assert not missing.unexpected_keys and all(k.startswith("reg_loss_func") for k in missing.missing_keys), missing
+n_key = g["keypoints"].shape[1]
+bd = {"batch_size": 2, "point_coords": torch.cat((torch.arange(2.).repeat_interleave(n_key)[:, None], t(g["keypoints"]).view(-1, 3)), 1),
+      "point_features": t(g["point_features"]), "point_cls_scores": t(g["point_scores"]),
+      "spatial_features_before_head": t(g["bev"]), "spatial_features_stride": 8}
+with oracle_backend():
+    r_cls, r_reg, r_iou = head.forward_single_loop(bd, t(g["rois"]))
+for got, want in ((r_cls, g["rcnn_cls"]), (r_reg, g["rcnn_reg"]), (r_iou, g["rcnn_iou"])):
+    assert float((got.detach() - t(want)).abs().max()) < 1e-5 * max(1.0, float(np.abs(want).max()))
+# the reference's PointHeadSimple: targets through this package's roiaware points_in_boxes_gpu wrapper (point_head_template.py:84-91)
+from pcdet.models.dense_heads.point_head_simple import PointHeadSimple
+g = gold("point_head")
+ph = PointHeadSimple(num_class=1, input_channels=16, model_cfg=ED(yml["POINT_HEAD"]))
+kp = g["keypoints"]
+coords = torch.cat((torch.arange(float(kp.shape[0])).repeat_interleave(kp.shape[1])[:, None], t(kp).view(-1, 3)), 1)
+with oracle_backend():
+    td = ph.assign_targets({"point_coords": coords, "gt_boxes": t(g["gt"]), "batch_size": kp.shape[0]})
+assert np.array_equal(td["point_cls_labels"].numpy(), g["labels"])
 print("OVERLAY_OK", len(mods), n_conv)
 '''
 
@@ -100,6 +160,7 @@ def test_reference_models_import_against_this_ops_package(tmp_path):
         if name != "ops":
             os.symlink(os.path.join(REF, name), root / name)
     os.symlink(os.path.join(REPO, "from-voxel-to-point_amd", "pcdet", "ops"), root / "ops")
-    env = dict(os.environ, PYTHONPATH=os.pathsep.join([str(tmp_path), os.path.join(REPO, "from-voxel-to-point_amd"), REPO]))
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([str(tmp_path), os.path.join(REPO, "from-voxel-to-point_amd"), REPO]),
+               FV2P_GOLDEN=os.path.join(REPO, "tests", "golden"))
     out = subprocess.run([sys.executable, "-c", SCRIPT], env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "OVERLAY_OK" in out.stdout, out.stderr[-3000:]
