@@ -792,7 +792,7 @@ class IoUGuidedRoIHead(nn.Module):
         b = bev.shape[0]
         world, local = self.grid_points(s_rois)
         # BEV stream: bilinear gather at the grid points + channel compression (:243-255)
-        g_bev = self.bev_grid_pool_layer({"spatial_features_before_head": bev, "spatial_features_stride": bev_stride}, world.view(b, -1, 3))
+        g_bev = self.bev_grid_pool_layer({"batch_size": b, "spatial_features_before_head": bev, "spatial_features_stride": bev_stride}, world.view(b, -1, 3))
         g_bev = g_bev.view(world.shape[0], world.shape[1], -1).permute(0, 2, 1).contiguous()
         # corner geometry stream (feature_adaptor/nn_modules.py:6-60): roi-frame corners without rotation or centre
         t = dconst(s_rois, _CORNER_SIGNS, s_rois.dtype) / 2
