@@ -150,6 +150,21 @@ coords = torch.cat((torch.arange(float(kp.shape[0])).repeat_interleave(kp.shape[
 with oracle_backend():
     td = ph.assign_targets({"point_coords": coords, "gt_boxes": t(g["gt"]), "batch_size": kp.shape[0]})
 assert np.array_equal(td["point_cls_labels"].numpy(), g["labels"])
+# the Waymo-shaped workload (bench.py --workload fv2p-waymo, BASELINE configs[4]): the reference's detector built from its
+# waymo_fv2p_e30.yaml has the parameters and buffers of the harness's FV2PWaymoConfig detector, name for name and shape for shape
+from pcdet.models.detectors.fv2p import FromVoxelToPoint
+from fv2p_harness import fv2p_model as fm
+wy = yaml.safe_load(open("/root/reference/tools/cfgs/waymo_models/FV2P/waymo_fv2p_e30.yaml"))
+W = fm.FV2PWaymoConfig
+dataset = types.SimpleNamespace(class_names=wy["CLASS_NAMES"], point_feature_encoder=types.SimpleNamespace(num_point_features=W.num_point_features),
+                                grid_size=np.array(W.grid_size), point_cloud_range=np.array(W.point_cloud_range, np.float32), voxel_size=list(W.voxel_size))
+ref_w = FromVoxelToPoint(model_cfg=ED(wy["MODEL"]), num_class=1, dataset=dataset)
+ren = lambda k: (k.replace("roi_head.CGE_module.corners_up_layer.", "roi_head.cge_up.").replace("roi_head.CGE_module.corners_inter_layer.", "roi_head.cge_inter.")
+                  .replace("roi_head.feature_fusion.fuse_layer.", "roi_head.feature_fusion."))
+ref_sd = {ren(k): tuple(v.shape) for k, v in ref_w.state_dict().items() if k != "global_step"}
+own_sd = {k: tuple(v.shape) for k, v in fm.FV2PDetector(W).state_dict().items()}
+assert ref_sd == own_sd and len(own_sd) == 380, sorted(set(ref_sd.items()) ^ set(own_sd.items()))[:8]
+assert tuple(ref_w.dense_head.anchors[0].shape) == (1, 188, 188, 1, 2, 7)           # Vehicle only: 2 anchors per BEV cell
 print("OVERLAY_OK", len(mods), n_conv)
 '''
 
