@@ -1,5 +1,5 @@
 """Layer replay of the MGAF-3DSSD detector's dense part (BASELINE configs[3]: mgaf-3dssd_3classes.yaml) as a consumer of this
-repo's `pcdet.ops`: VoxelBackBone8x -> HeightCompression -> DCNBEVBackbone (three levels, one MdeformConvBlock per level,
+repo's `pcdet.ops`: VoxelResBackBone8x -> HeightCompression -> DCNBEVBackbone (three levels, one MdeformConvBlock per level,
 pcdet/models/backbones_2d/dcn_bev_backbone.py:10-132) -> CenterAFHeadSingle (shared conv, modulated deformable feature
 adaption with four deformable groups, seven convolutional heads with the segmentation-guided attention,
 pcdet/models/dense_heads/center_af_head_single.py:8-110).
@@ -17,7 +17,7 @@ import torch.nn as nn
 from pcdet.ops.DeformableConvolutionV2PyTorch.modules.mdeformable_conv_block import MdeformConvBlock
 from pcdet.ops.DeformableConvolutionV2PyTorch.modules.modulated_deform_conv import ModulatedDeformConv
 
-from .backbone import VoxelBackBone8x
+from .backbone import VoxelResBackBone8x
 
 
 class MGAFConfig:
@@ -95,7 +95,7 @@ class MGAFDetector(nn.Module):
     def __init__(self, cfg=MGAFConfig, offset_init_std=0.05):
         super().__init__()
         self.cfg = cfg
-        self.backbone_3d = VoxelBackBone8x(cfg.num_point_features, list(cfg.grid_size))
+        self.backbone_3d = VoxelResBackBone8x(cfg.num_point_features, list(cfg.grid_size))     # BACKBONE_3D of both MGAF yamls
         self.backbone_2d = DCNBEVBackbone(cfg, 256)
         self.dense_head = CenterAFHead(cfg, self.backbone_2d.num_bev_features)
         # the reference zero-initialises the offset / mask predictors (all offsets 0 at step 0); a trained net has moved away from

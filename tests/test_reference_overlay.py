@@ -165,6 +165,18 @@ ref_sd = {ren(k): tuple(v.shape) for k, v in ref_w.state_dict().items() if k != 
 own_sd = {k: tuple(v.shape) for k, v in fm.FV2PDetector(W).state_dict().items()}
 assert ref_sd == own_sd and len(own_sd) == 380, sorted(set(ref_sd.items()) ^ set(own_sd.items()))[:8]
 assert tuple(ref_w.dense_head.anchors[0].shape) == (1, 188, 188, 1, 2, 7)           # Vehicle only: 2 anchors per BEV cell
+# the MGAF-3DSSD layer replay (bench.py --workload mgaf, BASELINE configs[3]): the reference's MGAF3DSSD detector built from
+# mgaf-3dssd_3classes.yaml (VoxelResBackBone8x, DCNBEVBackbone on this repo's MdeformConvBlock, CenterAFHeadSingle) against the
+# harness's MGAFDetector: 361 parameters / buffers, same names (the harness keeps the seven heads in a ModuleDict) and shapes
+from pcdet.models.detectors.mgaf_3dssd import MGAF3DSSD
+from fv2p_harness import mgaf_model as mm
+my = yaml.safe_load(open("/root/reference/tools/cfgs/kitti_models/MGAF-3DSSD/mgaf-3dssd_3classes.yaml"))
+dataset = types.SimpleNamespace(class_names=my["CLASS_NAMES"], point_feature_encoder=types.SimpleNamespace(num_point_features=4), grid_size=np.array([1408, 1600, 40]),
+                                point_cloud_range=np.array([0, -40, -3, 70.4, 40, 1], np.float32), voxel_size=[0.05, 0.05, 0.1])
+ref_m = MGAF3DSSD(model_cfg=ED(my["MODEL"]), num_class=len(my["CLASS_NAMES"]), dataset=dataset)
+ref_sd = {k: tuple(v.shape) for k, v in ref_m.state_dict().items() if k != "global_step"}
+own_sd = {k.replace("dense_head.heads.", "dense_head."): tuple(v.shape) for k, v in mm.MGAFDetector(mm.MGAFConfig).state_dict().items()}
+assert ref_sd == own_sd and len(own_sd) == 361, sorted(set(ref_sd.items()) ^ set(own_sd.items()))[:8]
 print("OVERLAY_OK", len(mods), n_conv)
 '''
 
