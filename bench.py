@@ -739,7 +739,7 @@ def workload_name(args):
                 "head, FPS to 16384 key points, voxel-to-point decoder, point head, IoU-guided RoI head, losses, backward, grad clip, "
                 "AdamW; KITTI grid 0.05 m [41,1600,1408], LiDAR-like synthetic clouds with 20-40 car boxes")
     if args.workload == "mgaf":
-        return ("MGAF-3DSSD layer replay: HIP voxelise + MeanVFE, VoxelBackBone8x, DCNBEVBackbone (3 x MdeformConvBlock), CenterAFHeadSingle "
+        return ("MGAF-3DSSD layer replay: HIP voxelise + MeanVFE, VoxelResBackBone8x, DCNBEVBackbone (3 x MdeformConvBlock), CenterAFHeadSingle "
                 "(DCNv2 feature adaption dg=4, seven heads) forward + backward + AdamW with a surrogate loss (the head's target assignment and "
                 "loss terms are not replayed); KITTI grid, LiDAR-like synthetic clouds")
     return (("VoxelBackBone8x" if args.backbone == "8x" else "VoxelResBackBone8x") +
