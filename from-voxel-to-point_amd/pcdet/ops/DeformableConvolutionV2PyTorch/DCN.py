@@ -6,8 +6,7 @@ import fv2p_native as _nat
 
 
 def _geom(input, weight, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, group, deformable_group):
-    if not input.is_cuda:
-        raise _nat.Fv2pError("Not implemented on the CPU")  # as the reference dispatcher (modulated_deform_conv.h:43)
+    _nat.require_cuda(input)  # raises on a CPU tensor, as the reference dispatcher does ("Not implemented on the CPU", modulated_deform_conv.h:43)
     if group != 1:
         raise NotImplementedError("fv2p DCN: groups > 1 is not supported (no reference config uses it)")
     B, C, H, W = input.shape
@@ -81,9 +80,7 @@ def deform_conv_backward(input, weight, bias, offset, grad_output, kernel_h, ker
 
 
 def _ps_geom(input, bbox, trans, no_trans, spatial_scale, output_dim, group_size, pooled_size, part_size, sample_per_part, trans_std):
-    if not input.is_cuda:
-        raise _nat.Fv2pError("Not implemented on the CPU")  # as the reference dispatcher (deform_psroi_pooling.h)
-    assert bbox.is_cuda and (no_trans or trans.is_cuda), "rois / trans must be a CUDA tensor"
+    _nat.require_cuda(input, bbox, *(() if no_trans else (trans,)))  # as the reference dispatcher (deform_psroi_pooling.h: "Not implemented on the CPU")
     B, C, H, W = input.shape
     assert C == output_dim, "input channels and output channels must equal"   # deform_psroi_pooling_cuda.cu:291
     classes = 1 if no_trans else trans.shape[1] // 2

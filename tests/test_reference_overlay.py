@@ -177,6 +177,32 @@ ref_m = MGAF3DSSD(model_cfg=ED(my["MODEL"]), num_class=len(my["CLASS_NAMES"]), d
 ref_sd = {k: tuple(v.shape) for k, v in ref_m.state_dict().items() if k != "global_step"}
 own_sd = {k.replace("dense_head.heads.", "dense_head."): tuple(v.shape) for k, v in mm.MGAFDetector(mm.MGAFConfig).state_dict().items()}
 assert ref_sd == own_sd and len(own_sd) == 361, sorted(set(ref_sd.items()) ^ set(own_sd.items()))[:8]
+# ... and its dense part computes the same seven head maps: the reference's DCNBEVBackbone + CenterAFHeadSingle (on this package's
+# MdeformConvBlock / ModulatedDeformConv, DCN forward answered by the oracle) against the harness's re-declarations, one state dict,
+# offset / mask predictors moved off their zero initialisation, training-mode BatchNorm
+torch.manual_seed(3)
+with torch.no_grad():
+    for sub in ref_m.modules():
+        if hasattr(sub, "conv_offset_mask"):
+            sub.conv_offset_mask.weight.normal_(0, 0.05)
+head_names = dict(mm.MGAFConfig.heads)
+own_m = mm.MGAFDetector(mm.MGAFConfig, offset_init_std=0.0)
+own_m.load_state_dict({(k.replace("dense_head.", "dense_head.heads.") if k.split(".")[1] in head_names else k): v
+                       for k, v in ref_m.state_dict().items() if k != "global_step"}, strict=True)
+ref_m.train(), own_m.train()
+ref_m.dense_head.assign_targets = lambda gt_boxes: {}
+x = torch.randn(2, 256, 24, 20)
+with oracle_backend(), torch.no_grad():
+    dd = ref_m.backbone_2d({"spatial_features": x.clone()})
+    dd["gt_boxes"] = None
+    try:
+        ref_m.dense_head(dd)
+    except KeyError as e:
+        assert e.args[0] == "ind_target"       # the target-based box generation that follows the predictions in training mode
+    preds = own_m.dense_head(own_m.backbone_2d(x.clone()))
+for name, got in preds.items():
+    want = ref_m.dense_head.forward_ret_dict[name + "_pred"]
+    assert got.shape == want.shape and float((got - want).abs().max()) <= 1e-5 * float(want.abs().max()), name
 print("OVERLAY_OK", len(mods), n_conv)
 '''
 
