@@ -254,7 +254,18 @@ ref_cpu, own_cpu = cpu_mirror(ref).train(), cpu_mirror(own).train()
 stash, layer = {}, ref_cpu.roi_head.proposal_layer
 def proposal_layer(batch_dict, nms_config):
     out = layer(batch_dict, nms_config=nms_config)
-    stash["rois"], stash["roi_scores"] = out["rois"].clone(), out["roi_scores"].clone()
+    stash["rois"], stash["roi_scores"] = out["rois"].clone(), out["roi_scores"].clone()          # compared with the harness's proposals below
+    # With random weights no proposal reaches the foreground thresholds and the regression / corner / IoU terms of the second stage
+    # would be zero on both sides.  The head is therefore fed jittered ground-truth boxes from here on (a third nearly exact, a third
+    # displaced by ~0.3 m, a third by metres), so the reference's sampler draws foreground, hard and easy background.
+    gen = torch.Generator().manual_seed(9)
+    for smp in range(out["rois"].shape[0]):
+        boxes = batch_dict["gt_boxes"][smp]
+        boxes = boxes[boxes[:, 3] > 0][:, :7]
+        pick = boxes[torch.arange(out["rois"].shape[1]) % boxes.shape[0]]
+        tier = (torch.arange(out["rois"].shape[1]) // boxes.shape[0]) % 3
+        sigma = torch.tensor([0.03, 0.3, 3.0])[tier][:, None] * torch.tensor([1.0, 1.0, 0.3, 0.2, 0.2, 0.2, 0.3])[None]
+        out["rois"][smp] = pick + sigma * torch.randn(pick.shape, generator=gen)
     return out
 ref_cpu.roi_head.proposal_layer = proposal_layer
 close = lambda a, b, tol: float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max()))
@@ -278,7 +289,9 @@ assert close(loss_rpn.detach(), tb["rpn_loss"] if torch.is_tensor(tb["rpn_loss"]
 assert abs(float(loss_point) - float(tb["point_loss_cls"])) <= 1e-6 * float(tb["point_loss_cls"]), "point loss"
 assert close(rois, stash["rois"], 1e-6) and torch.equal(roi_scores, stash["roi_scores"]), "proposals"
 assert close(cls.view(-1), fr["rcnn_cls"].view(-1).detach(), 1e-4) and close(reg[:, 1:], fr["rcnn_reg"].detach(), 1e-4) and close(reg[:, :1], fr["rcnn_iouscore"].detach(), 1e-4)
-assert abs(float(loss_rcnn) - float(tb["rcnn_loss"])) <= 1e-5 * max(1.0, float(tb["rcnn_loss"])), "second-stage loss"
+ref_rcnn = float(tb["rcnn_loss"]) + float(tb["rcnn_loss_iouscore"])      # get_loss logs 'rcnn_loss' before it adds the IoU-score term (roi_withiou_head_template.py:274-277)
+assert abs(float(loss_rcnn) - ref_rcnn) <= 1e-5 * max(1.0, ref_rcnn), "second-stage loss"
+assert tb["num_sample_fg"] > 0 and tb["num_sample_bg"] > 0 and float(tb["rcnn_loss_reg"]) > 0 and float(tb["rcnn_loss_iouscore"]) > 0, tb   # every term carries weight
 total = float(loss_rpn + loss_point + loss_rcnn)
 assert abs(total - float(ret["loss"])) <= 1e-6 * float(ret["loss"]), (total, float(ret["loss"]))
 # ... and the same gradients: backward through the reference's graph (this package's autograd Functions: batched three_interpolate, grouping,
