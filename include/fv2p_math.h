@@ -13,7 +13,7 @@
 #ifndef FV2P_MATH_H_
 #define FV2P_MATH_H_
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define FV2P_HD __host__ __device__ __forceinline__
 #else
 #define FV2P_HD static inline
