@@ -128,7 +128,7 @@ extern "C" int fv2p_sparse_maxpool_fwd(const float* in, int64_t n_in, int c, con
   FV2P_REQUIRE(c >= 1 && kvol >= 1 && n_out >= 0, FV2P_EINVAL, "maxpool_fwd: bad sizes");
   if (n_out == 0) return 0;
   FV2P_REQUIRE(in && tab && out, FV2P_EINVAL, "maxpool_fwd: null pointer");
-  hipLaunchKernelGGL(maxpool_fwd, FV2P_GRID1D(n_out * c), 0, static_cast<hipStream_t>(s), in, c, tab, kvol, (int)n_out, flip_k, out);
+  hipLaunchKernelGGL(maxpool_fwd, FV2P_GRID1D(n_out * c), 0, static_cast<hipStream_t>(s), in, c, tab, kvol, (int)n_out, flip_k & 1, out);
   FV2P_LAUNCH_CHECK();
   return 0;
 }
@@ -146,7 +146,7 @@ extern "C" int fv2p_sparse_group_fwd(const float* in, int64_t n_in, int c, const
   FV2P_REQUIRE(c >= 1 && kvol >= 1 && n_out >= 0, FV2P_EINVAL, "group_fwd: bad sizes");
   if (n_out == 0) return 0;
   FV2P_REQUIRE(in && tab && out, FV2P_EINVAL, "group_fwd: null pointer");
-  hipLaunchKernelGGL(group_fwd, FV2P_GRID1D(n_out * c * kvol), 0, static_cast<hipStream_t>(s), in, c, tab, kvol, (int)n_out, flip_k, out);
+  hipLaunchKernelGGL(group_fwd, FV2P_GRID1D(n_out * c * kvol), 0, static_cast<hipStream_t>(s), in, c, tab, kvol, (int)n_out, flip_k & 1, out);
   FV2P_LAUNCH_CHECK();
   return 0;
 }
@@ -155,7 +155,7 @@ extern "C" int fv2p_sparse_group_bwd(const float* grad, int64_t n_out, int c, co
   FV2P_REQUIRE(c >= 1 && kvol >= 1 && n_in >= 0, FV2P_EINVAL, "group_bwd: bad sizes");
   if (n_in == 0) return 0;
   FV2P_REQUIRE(grad && tab && din, FV2P_EINVAL, "group_bwd: null pointer");
-  hipLaunchKernelGGL(group_bwd, FV2P_GRID1D(n_in * c), 0, static_cast<hipStream_t>(s), grad, (int)n_out, c, tab, kvol, (int)n_in, flip_k, din);
+  hipLaunchKernelGGL(group_bwd, FV2P_GRID1D(n_in * c), 0, static_cast<hipStream_t>(s), grad, (int)n_out, c, tab, kvol, (int)n_in, flip_k & 1, din);
   FV2P_LAUNCH_CHECK();
   return 0;
 }

@@ -39,6 +39,7 @@ struct ConvArgs {
   // backward sums  (sum dz, sum dz * xhat), dz = dst * [y > 0], from the BatchNorm input bn_x (same shape as dst)
   const float* bn_x; const float* bn_mean; const float* bn_invstd; const float* bn_gamma; const float* bn_beta; int bn_relu;
   const int* perm;                                   // optional row order: tile t owns destination rows perm[64t .. 64t+63]
+  const int* plan;                                   // optional cost-balanced tiling (conv_rows_ksplit): tile t owns rows [plan[t], plan[t+1])
 };
 
 // ---- BatchNorm statistics in the epilogue --------------------------------------------------------
@@ -817,7 +818,13 @@ __global__ __launch_bounds__(256) void conv_rows_ksplit(ConvArgs a) {
   unsigned char* s_row = reinterpret_cast<unsigned char*>(s_idx + MAXK * TM);   // [MAXK][TM] tile row of slot p
   int* s_cnt = reinterpret_cast<int*>(s_row + MAXK * TM);         // [MAXK]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, g = lane >> 4;
-  const int row0 = xcd_major_tile(blockIdx.x, gridDim.x) * TM;
+  // rows of this workgroup: a fixed TM-row tile, or — with a plan (fv2p_conv_plan_build) — the t-th of gridDim.x row ranges of
+  // equal cost (pairs per row, floored), taken in sub-tiles of at most TM rows of equal size
+  const int tile = xcd_major_tile(blockIdx.x, gridDim.x);
+  int r_begin = tile * TM, r_end = min(r_begin + TM, a.n_dst);
+  if (a.plan) { r_begin = a.plan[tile]; r_end = a.plan[tile + 1]; }
+  const int n_sub = (r_end - r_begin + TM - 1) / TM;
+  const int sub_rows = n_sub > 0 ? (r_end - r_begin + n_sub - 1) / n_sub : 0;
   if (gridDim.y > 1) {   // column split as in conv_rows_dma
     const int off = blockIdx.y * 64;
     a.w += WT ? static_cast<long long>(off) * a.w_ld : off;
@@ -833,6 +840,8 @@ __global__ __launch_bounds__(256) void conv_rows_ksplit(ConvArgs a) {
   a.c_dst = 64;
   unsigned long long t_begin = 0, t_pro = 0, t_wait = 0, t_mark = 0;
   if (a.trace) t_begin = __builtin_readcyclecounter();
+  for (int row0 = r_begin; row0 < r_end; row0 += sub_rows) {
+  const int row_end = min(row0 + sub_rows, r_end);
   {
     float4* z = reinterpret_cast<float4*>(accl);
     for (int e = tid; e < 4 * ROWS * LDR / 4; e += 256) z[e] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -840,7 +849,7 @@ __global__ __launch_bounds__(256) void conv_rows_ksplit(ConvArgs a) {
   {
     // the wave's offsets k = wave, wave + 4, ...: all table loads first, then one ballot compaction each
     const int row = row0 + lane;
-    const bool mine = lane < TM && row < a.n_dst;
+    const bool mine = lane < TM && row < row_end;
     int tv[MAXK / 4];
 #pragma unroll
     for (int u = 0; u < MAXK / 4; ++u) {
@@ -888,28 +897,21 @@ __global__ __launch_bounds__(256) void conv_rows_ksplit(ConvArgs a) {
   };
   // stage L: weights and gathered rows on their way
   auto issue = [&](const Meta& m, f32x4 (&A)[MAXG][JS], f32x4 (&B)[NBV]) {
-    const float* wk = a.w + static_cast<long long>(m.k) * a.w_kstride;
+    // plain loads: the compiler tracks them (vmcnt) and waits at their first use, the MFMA block of the NEXT stage — inline-asm
+    // loads with a hand-placed s_waitcnt (round 2) broke when the register allocator copied a destination register between the
+    // load and the wait (a copy of a register the data has not reached yet), which any change to the control flow can provoke
+    const char* wk = reinterpret_cast<const char*>(a.w + static_cast<long long>(m.k) * a.w_kstride);
 #pragma unroll
-    for (int u = 0; u < NBV; ++u) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(B[u]) : "v"(boff[u]), "s"(wk) : "memory");
+    for (int u = 0; u < NBV; ++u) B[u] = *reinterpret_cast<const f32x4*>(wk + boff[u]);
 #pragma unroll
     for (int grp = 0; grp < MAXG; ++grp) {
-      if (grp * 16 < m.cnt) {   // uniform
-        const int idx = m.idx[grp];
-        const float* p = idx >= 0 ? a.src + static_cast<long long>(idx) * a.ld_src + src_col : zero_row;
-        gather_async<JS>(A[grp], p);
-      }
+      const int idx = m.idx[grp];   // groups past the offset's pairs read the zero row (padding slots): no branch, no undefined registers
+      const float* p = (grp * 16 < m.cnt && idx >= 0) ? a.src + static_cast<long long>(idx) * a.ld_src + src_col : zero_row;
+#pragma unroll
+      for (int jj = 0; jj < JS; ++jj) A[grp][jj] = *reinterpret_cast<const f32x4*>(p + 16 * jj);
     }
   };
-  auto wait = [&](f32x4 (&A)[MAXG][JS], f32x4 (&B)[NBV]) {
-    // s_waitcnt vmcnt(0) that every prefetched register passes through: their uses are ordered after it
-    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
-#pragma unroll
-    for (int grp = 0; grp < MAXG; ++grp)
-#pragma unroll
-      for (int jj = 0; jj < JS; ++jj) asm volatile("" : "+v"(A[grp][jj]));
-#pragma unroll
-    for (int u = 0; u < NBV; ++u) asm volatile("" : "+v"(B[u]));
-  };
+  auto wait = [&](f32x4 (&A)[MAXG][JS], f32x4 (&B)[NBV]) {};
   // stage C: acc[i][reg] of lane (g, r) is column 16 g + 4 reg + i of the group's slot r.  One straight-line body per group
   // count (no branch between the groups of an offset): the next group's accumulator reads sit above this group's MFMAs
   auto groups = [&](auto ng_, const Meta& m, const f32x4 (&A)[MAXG][JS], const f32x4 (&B)[NBV]) {
@@ -1000,7 +1002,7 @@ __global__ __launch_bounds__(256) void conv_rows_ksplit(ConvArgs a) {
   }
   __syncthreads();
   // epilogue: wave w stores tile rows 16 w .. 16 w + 15; lane (q, n) holds rows 4 q + reg, columns 4 n + i like an MFMA tile
-  if (wave >= MAXG) return;
+  if (wave < MAXG) {
   const int q = lane >> 4, n = lane & 15;
   f32x4 acc[4];
 #pragma unroll
@@ -1014,7 +1016,7 @@ __global__ __launch_bounds__(256) void conv_rows_ksplit(ConvArgs a) {
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) {
     const int row = wrow0 + q * 4 + reg;
-    if (row >= a.n_dst) continue;
+    if (row >= row_end) continue;
     float4 o = make_float4(acc[0][reg], acc[1][reg], acc[2][reg], acc[3][reg]);
     if (a.bias) { const float4 b = *reinterpret_cast<const float4*>(a.bias + 4 * n); o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w; }
     float4* p = reinterpret_cast<float4*>(a.dst + static_cast<long long>(row) * a.ld_dst + 4 * n);
@@ -1023,7 +1025,7 @@ __global__ __launch_bounds__(256) void conv_rows_ksplit(ConvArgs a) {
   }
   if (a.stats) {
     float vals[4][4];
-    int cols[4];
+    int cols[4], rows[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       cols[i] = 4 * n + i;
@@ -1031,7 +1033,12 @@ __global__ __launch_bounds__(256) void conv_rows_ksplit(ConvArgs a) {
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) vals[i][reg] = acc[i][reg] + b;
     }
-    tile_stats<4>(a, vals, cols, wrow0);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) rows[reg] = (wrow0 + q * 4 + reg < row_end) ? wrow0 + q * 4 + reg : -1;
+    tile_stats_rows<4>(a, vals, cols, rows);
+  }
+  }
+  if (row0 + sub_rows < r_end) __syncthreads();   // the next sub-tile clears the accumulators the epilogue above reads
   }
 }
 
@@ -1595,6 +1602,48 @@ static int conv_impl() {
   return g_conv_impl;
 }
 
+// ---- cost-balanced tiling plan (fv2p_conv_plan_build) ---------------------------------------------------------------------------
+// At the 5-20 pairs per row of the backbones' deep levels equal-ROW tiles carry unequal work: the 620 workgroups of the res4
+// layer lasted 90 k clocks at the median and 180 k at the maximum, all resident at once, so the launch ended with the heaviest
+// tile while the MFMA pipes were 0.37 busy chip-wide (profiles/r02_pmc_mfma.json).  A plan cuts the rows into T contiguous
+// ranges of equal COST instead, cost(row) = max(pairs(row), kPlanFloor): the floor prices the per-offset overhead of a sparse
+// tile (a tile visits every non-empty offset whatever its fill) and bounds the rows of a range.  The plan lives in the ints that
+// follow the table ([kvol][n_dst]) in the caller's allocation: [magic, levels, then per level l the T_l + 1 bounds], levels
+// T_l = 256, 384, 512, 768, ... up to about n_dst / 16, so that one plan serves every launch shape (column blocks, direction).
+constexpr int kPlanMagic = 0x706c616e;   // "plan"
+constexpr int kPlanFloor = 8;
+static inline int plan_tiles(int level) { return ((level & 1) ? 384 : 256) << (level >> 1); }
+static inline int plan_levels(int64_t n_dst) {
+  int l = 1;
+  while (l < 24 && plan_tiles(l) <= n_dst / 16) ++l;
+  return l;
+}
+static inline int64_t plan_level_offset(int level) {   // ints from the plan header to the bounds of `level`
+  int64_t off = 2;
+  for (int l = 0; l < level; ++l) off += plan_tiles(l) + 1;
+  return off;
+}
+static int g_plan_rows = 0;   // FV2P_PLAN_ROWS: rows per tile the level choice aims at (0 = default)
+static int g_plan_on = -1;    // FV2P_CONV_PLAN=0 ignores plans (comparison runs)
+// level whose tile count is nearest (in ratio) to n_dst / rows-per-tile; at least 512 workgroups (2 per CU) where the rows allow
+static int plan_pick_level(int64_t n_dst, int col_blocks) {
+  if (g_plan_on < 0) {
+    const char* e = getenv("FV2P_CONV_PLAN"); g_plan_on = e ? atoi(e) : 1;
+    const char* r = getenv("FV2P_PLAN_ROWS"); g_plan_rows = r ? atoi(r) : 0;
+  }
+  if (!g_plan_on) return -1;
+  const double rows = g_plan_rows > 0 ? g_plan_rows : 44.0;
+  double want = static_cast<double>(n_dst) / rows;
+  if (want * col_blocks < 512.0) want = 512.0 / col_blocks;
+  const int levels = plan_levels(n_dst);
+  int best = 0; double best_r = 1e30;
+  for (int l = 0; l < levels; ++l) {
+    const double t = plan_tiles(l), ratio = t > want ? t / want : want / t;
+    if (ratio < best_r) { best_r = ratio; best = l; }
+  }
+  return best;
+}
+
 static constexpr size_t ksplit_lds(int tm) { return 4 * static_cast<size_t>(tm + 1) * 68 * sizeof(float) + 32 * tm * sizeof(int) + 32 * tm + 32 * sizeof(int); }
 // impl 4 forces the pair-compacted K-split tile wherever its shapes allow.  In auto mode it takes every launch with 64 or 128
 // source channels and whole 64-column blocks (measured against conv_rows_dma, profiles/r02_microbench.txt: 128 -> 128 at
@@ -1632,6 +1681,15 @@ static void launch_vec(const ConvArgs& a, hipStream_t s) {
                        (reinterpret_cast<uintptr_t>(a.dst) & 15) == 0 && (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0);
     if (whole && a.kvol <= 32 && ksplit_wanted<CINP>(a)) {
       ConvArgs b = a; b.trace = g_conv_trace;
+      const int level = a.plan ? plan_pick_level(a.n_dst, NB / 4) : -1;   // a.plan: the plan header behind the table
+      b.plan = nullptr;
+      if (level >= 0) {
+        b.plan = a.plan + plan_level_offset(level);
+        const size_t lds = ksplit_lds(64) + g_ksplit_pad;
+        static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_ksplit<CINP, WT, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
+        if (once) { hipLaunchKernelGGL((conv_rows_ksplit<CINP, WT, 64>), dim3(static_cast<unsigned>(plan_tiles(level)), NB / 4), dim3(256), lds, s, b); return; }
+        b.plan = nullptr;
+      }
       if (ksplit_rows<WT>(a) == 32) {
         const size_t lds = ksplit_lds(32) + g_ksplit_pad;
         static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_ksplit<CINP, WT, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
@@ -1723,6 +1781,40 @@ static int dispatch_conv(const ConvArgs& a, hipStream_t s) {
   return 0;
 }
 
+// cost(row) = max(pairs of the row, kPlanFloor): one thread per destination row, coalesced over the rows of every offset
+__global__ __launch_bounds__(256) void plan_cost_k(const int* __restrict__ tab, int kvol, int n_dst, int* __restrict__ cost) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= n_dst) return;
+  int c = 0;
+  for (int k = 0; k < kvol; ++k) c += tab[static_cast<long long>(k) * n_dst + row] >= 0;
+  cost[row] = max(c, kPlanFloor);
+}
+// bounds of every level: entry t of a level with T tiles = first row whose exclusive cost prefix reaches total * t / T
+__global__ __launch_bounds__(256) void plan_bounds_k(const int* __restrict__ prefix, const int* __restrict__ total_p, int n_dst, int levels,
+                                                     int* __restrict__ plan) {
+  const long long e = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  if (e == 0) { plan[0] = kPlanMagic; plan[1] = levels; }
+  long long base = 0;
+  for (int l = 0; l < levels; ++l) {
+    const int tiles = ((l & 1) ? 384 : 256) << (l >> 1);
+    if (e < base + tiles + 1) {
+      const int t = static_cast<int>(e - base);
+      int lo = 0, hi = n_dst;   // first row in [0, n_dst] with prefix[row] >= target (prefix[n_dst] = total)
+      if (t >= tiles) lo = n_dst;
+      else if (t > 0) {
+        const long long target = (static_cast<long long>(*total_p) * t + tiles - 1) / tiles;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (prefix[mid] >= target) hi = mid; else lo = mid + 1;
+        }
+      } else lo = 0;
+      plan[2 + e] = lo;
+      return;
+    }
+    base += tiles + 1;
+  }
+}
+
 }  // namespace fv2p
 
 using namespace fv2p;
@@ -1765,7 +1857,9 @@ static int conv_rows_impl(const float* src, int64_t n_src, int c_src, const floa
       a.src = src + s0; a.ld_src = c_src; a.c_src = cs;
       a.w = transpose_w ? weight + static_cast<long long>(d0) * w_cols + s0 : weight + static_cast<long long>(s0) * w_cols + d0;
       a.w_kstride = static_cast<long long>(w_rows) * w_cols; a.w_ld = w_cols;
-      a.tab = tab; a.n_dst = static_cast<int>(n_dst); a.kvol = kvol; a.flip = flip_k;
+      a.tab = tab; a.n_dst = static_cast<int>(n_dst); a.kvol = kvol; a.flip = flip_k & 1;
+      // FV2P_TAB_PLANNED: the caller's table allocation continues with the plan fv2p_conv_plan_build wrote
+      a.plan = (flip_k & 2) ? tab + static_cast<long long>(kvol) * n_dst : nullptr;
       a.bias = (bias && s0 == 0) ? bias + d0 : nullptr;
       a.dst = dst + d0; a.ld_dst = c_dst; a.c_dst = cd; a.accumulate = s0 > 0;
       int rc = transpose_w ? dispatch_conv<true>(a, stream) : dispatch_conv<false>(a, stream);
@@ -1791,6 +1885,40 @@ extern "C" int fv2p_sparse_conv_rows_perm(const float* src, int64_t n_src, int c
 }
 
 extern "C" int fv2p_sparse_conv_stat_slots(void) { return kStatSlots; }
+extern "C" int64_t fv2p_conv_plan_ints(int64_t n_dst) {
+  if (n_dst <= 0) return 0;
+  return plan_level_offset(plan_levels(n_dst));
+}
+
+extern "C" size_t fv2p_conv_plan_ws_bytes(int64_t n_dst) {
+  const int64_t n = n_dst > 0 ? n_dst : 1;
+  return align_up(static_cast<size_t>(n) * sizeof(int)) + align_up(static_cast<size_t>(n) * sizeof(int)) + align_up(sizeof(int)) + align_up(scan_ws_bytes(n));
+}
+
+extern "C" int fv2p_conv_plan_build(int* tab, int kvol, int64_t n_dst, void* ws, size_t ws_bytes, fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FV2P_REQUIRE(kvol >= 1 && n_dst >= 0, FV2P_EINVAL, "conv_plan_build: bad sizes");
+  if (n_dst == 0) return 0;
+  FV2P_REQUIRE(tab && ws, FV2P_EINVAL, "conv_plan_build: null pointer");
+  FV2P_REQUIRE(n_dst < (1ll << 31) - 64 && static_cast<long long>(kvol) * n_dst < (1ll << 31), FV2P_ELIMIT, "conv_plan_build: too many rows");
+  FV2P_REQUIRE(ws_bytes >= fv2p_conv_plan_ws_bytes(n_dst), FV2P_EWORKSPACE, "conv_plan_build: workspace too small");
+  Carver c(ws, ws_bytes);
+  int* cost = c.take<int>(static_cast<size_t>(n_dst));
+  int* prefix = c.take<int>(static_cast<size_t>(n_dst));
+  int* total = c.take<int>(1);
+  const size_t sb = scan_ws_bytes(n_dst);
+  void* sws = c.take<char>(sb);
+  const int n = static_cast<int>(n_dst);
+  hipLaunchKernelGGL(plan_cost_k, dim3(static_cast<unsigned>(ceil_div(n_dst, 256))), dim3(256), 0, stream, tab, kvol, n, cost);
+  if (int rc = exclusive_scan_i32(cost, prefix, n_dst, total, sws, sb, stream)) return rc;
+  const int levels = plan_levels(n_dst);
+  const int64_t entries = plan_level_offset(levels) - 2;
+  hipLaunchKernelGGL(plan_bounds_k, dim3(static_cast<unsigned>(ceil_div(entries, 256))), dim3(256), 0, stream, prefix, total, n, levels,
+                     tab + static_cast<long long>(kvol) * n_dst);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
 
 extern "C" int fv2p_sparse_conv_rows_stats(const float* src, int64_t n_src, int c_src, const float* weight, int kvol, const int* tab,
                                            int64_t n_dst, int c_dst, int flip_k, int transpose_w, const float* bias, float* dst,
@@ -1873,7 +2001,7 @@ extern "C" int fv2p_sparse_conv_wgrad(const float* src, int64_t n_src, int c_src
     WgradArgs a;
     a.src = src + s0; a.ld_src = c_src; a.c_src = cs;
     a.grad = grad + d0; a.ld_grad = c_dst; a.c_grad = cd;
-    a.tab = tab; a.n_dst = static_cast<int>(n_dst); a.kvol = kvol; a.flip = flip_k;
+    a.tab = tab; a.n_dst = static_cast<int>(n_dst); a.kvol = kvol; a.flip = flip_k & 1;
     a.dw = dweight + static_cast<long long>(s0) * c_dst + d0; a.dw_kstride = static_cast<long long>(c_src) * c_dst; a.dw_ld = c_dst;
     const int mb = static_cast<int>(ceil_div(cs, 16));
     const int nb = static_cast<int>(ceil_div(cd, 16));

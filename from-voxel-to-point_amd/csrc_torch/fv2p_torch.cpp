@@ -560,12 +560,17 @@ std::vector<std::vector<at::Tensor>> build_rulebook_chain(const at::Tensor& root
                               transpose, &n_out, ws.data_ptr(), static_cast<size_t>(ws.numel()), stream),
           "fv2p_rulebook_begin");
     const auto iopt = root.options();
-    at::Tensor tab_in = at::empty({kvol, n_in}, iopt), tab_out, outids;
+    // tables with room for the conv kernels' tiling plan behind them (fv2p_conv_plan_ints; built on first use, ops.Rulebook._plan)
+    auto table = [&](int64_t rows) {
+      const int64_t cells = static_cast<int64_t>(kvol) * rows;
+      return at::empty({cells + fv2p_conv_plan_ints(rows)}, iopt).narrow(0, 0, cells).view({static_cast<int64_t>(kvol), rows});
+    };
+    at::Tensor tab_in = table(n_in), tab_out, outids;
     if (subm) {
-      if (!symmetric) tab_out = at::empty({kvol, n_out}, iopt);
+      if (!symmetric) tab_out = table(n_out);
     } else {
       outids = at::empty({n_out, 4}, iopt);
-      tab_out = at::empty({kvol, n_out}, iopt);
+      tab_out = table(n_out);
     }
     check(fv2p_rulebook_finish(ind.data_ptr<int>(), n_in, static_cast<int>(batch), in_shape, out_shape, ksize, stride, padding, dilation, subm,
                                transpose, n_out, outids.defined() ? outids.data_ptr<int>() : nullptr, tab_in.data_ptr<int>(),

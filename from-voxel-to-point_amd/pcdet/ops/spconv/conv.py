@@ -158,7 +158,8 @@ def _conv_bn_relu(self, features, rb, n_out, post, weight=None):
         return None
     if not (features.is_cuda and features.dtype == torch.float32 and self.weight.dtype == torch.float32 and features.dim() == 2):
         return None
-    (tab_f, flip_f), (tab_b, flip_b) = (rb.in_table(), rb.out_table()) if self.inverse else (rb.out_table(), rb.in_table())
+    cin, cout = self.in_channels, self.out_channels   # forward gathers cin-channel rows, backward-data cout-channel rows
+    (tab_f, flip_f), (tab_b, flip_b) = (rb.in_table(cin), rb.out_table(cout)) if self.inverse else (rb.out_table(cin), rb.in_table(cout))
     centre = (rb.kvol // 2) if (rb.subm and rb.tab_out is None and not self.inverse) else -1
     have = rb._wpairs is not None and rb._num is not None
     out = ext.sparse_conv_bn_relu(features, weight, tab_f, flip_f, tab_b, flip_b, n_out, centre, rb._wpairs if have else None,

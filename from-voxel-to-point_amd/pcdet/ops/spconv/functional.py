@@ -121,7 +121,8 @@ def _dispatch(fn_cls):
         if (ext is not None and features.is_cuda and features.dtype == torch.float32 and filters.dtype == torch.float32
                 and features.dim() == 2 and not torch.is_autocast_enabled()):
             rb = ops._rulebook_of(indice_pairs, indice_pair_num, features.shape[0], num_activate_out, fn_cls.INVERSE)
-            (tab_f, flip_f), (tab_b, flip_b) = (rb.in_table(), rb.out_table()) if fn_cls.INVERSE else (rb.out_table(), rb.in_table())
+            cin, cout = filters.shape[-2], filters.shape[-1]   # forward gathers cin-channel rows, backward-data cout-channel rows
+            (tab_f, flip_f), (tab_b, flip_b) = (rb.in_table(cin), rb.out_table(cout)) if fn_cls.INVERSE else (rb.out_table(cin), rb.in_table(cout))
             centre = (rb.kvol // 2) if (rb.subm and rb.tab_out is None and not fn_cls.INVERSE) else -1
             have = rb._wpairs is not None and rb._num is not None   # pair lists already materialised (prefetch): pair-split wgrad
             return ext.sparse_conv(features, filters, tab_f, flip_f, tab_b, flip_b, num_activate_out, centre,

@@ -37,6 +37,18 @@ def _pad3(v, fill):
     return [fill] * (3 - len(v)) + v
 
 
+def alloc_table(kvol, n, device):
+    """[kvol, n] int32 neighbour table whose allocation continues with room for the conv kernels' tiling plan
+    (include/fv2p_ops.h: fv2p_conv_plan_ints / FV2P_TAB_PLANNED)."""
+    extra = int(_nat.lib().fv2p_conv_plan_ints(int(n))) if device.type == "cuda" else 0
+    flat = torch.empty((kvol * n + extra,), dtype=torch.int32, device=device)
+    return flat[:kvol * n].view(kvol, n)
+
+
+_PLAN_CHANNELS = (64, 128)   # source channel counts whose conv kernel (conv_rows_ksplit) takes a tiling plan
+TAB_FLIP, TAB_PLANNED = 1, 2
+
+
 class Rulebook(object):
     """Neighbour tables of one (indice_key) rulebook.
 
@@ -54,12 +66,36 @@ class Rulebook(object):
         self._wpairs = None   # compacted pair lists for the weight gradient (== _pairs once that exists)
         self._perm_in = None  # strided conv: input rows grouped by parity class (tile order of the backward-data conv)
 
-    # -- tables as the kernels want them: (table, flip_k)
-    def out_table(self):
-        return (self.tab_in, 1) if self.tab_out is None else (self.tab_out, 0)
+    # -- tables as the kernels want them: (table, flag word: TAB_FLIP | TAB_PLANNED)
+    def out_table(self, c_src=None):
+        if self.tab_out is None:
+            return (self.tab_in, TAB_FLIP | self._plan("tab_in", c_src))   # pairs per row are the same under the flip
+        return (self.tab_out, self._plan("tab_out", c_src))
 
-    def in_table(self):
-        return (self.tab_in, 0)
+    def in_table(self, c_src=None):
+        return (self.tab_in, self._plan("tab_in", c_src))
+
+    def _plan(self, which, c_src):
+        """TAB_PLANNED once the table carries a tiling plan; built on the first conv with `c_src` source channels that can
+        use one, when the table was allocated with room behind it (alloc_table)."""
+        done = self.__dict__.setdefault("_planned", {})
+        if which in done:
+            return done[which]
+        if c_src not in _PLAN_CHANNELS:
+            return 0
+        tab = getattr(self, which)
+        flag = 0
+        if tab is not None and tab.is_cuda and tab.numel() > 0 and tab.is_contiguous():
+            kvol, n = tab.shape
+            extra = int(_nat.lib().fv2p_conv_plan_ints(n))
+            room = tab.untyped_storage().nbytes() // 4 - (tab.storage_offset() + kvol * n)
+            if room >= extra:
+                with _nat.device_guard(tab.device):
+                    ws = _nat.workspace(_nat.lib().fv2p_conv_plan_ws_bytes(n), tab.device)
+                    _nat.call("fv2p_conv_plan_build", tab, kvol, n, ws, ws.numel(), _nat.stream())
+                flag = TAB_PLANNED
+        done[which] = flag
+        return flag
 
     @property
     def indice_pair_num(self):
@@ -158,13 +194,13 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize=3, stride=1, paddin
         geom = (g["in_shape"], g["out_shape"], g["ksize"], g["stride"], g["padding"], g["dilation"], int(subm), int(transpose))
         _nat.call("fv2p_rulebook_begin", ind4, n_in, int(batch_size), *geom, ctypes.addressof(n_out_host), ws, ws.numel(), _nat.stream())
         n_out = int(n_out_host.value)
-        tab_in = torch.empty((kvol, n_in), dtype=torch.int32, device=dev)
+        tab_in = alloc_table(kvol, n_in, dev)
         num = None
         if subm:
-            outids4, tab_out = None, (None if symmetric else torch.empty((kvol, n_out), dtype=torch.int32, device=dev))
+            outids4, tab_out = None, (None if symmetric else alloc_table(kvol, n_out, dev))
         else:
             outids4 = torch.empty((n_out, 4), dtype=torch.int32, device=dev)
-            tab_out = torch.empty((kvol, n_out), dtype=torch.int32, device=dev)
+            tab_out = alloc_table(kvol, n_out, dev)
         _nat.call("fv2p_rulebook_finish", ind4, n_in, int(batch_size), *geom, n_out, outids4, tab_in, tab_out, num, ws, ws.numel(),
                   _nat.stream())
     if subm:
@@ -265,8 +301,8 @@ def _rulebook_of(indice_pairs, indice_pair_num, n_src_rows, num_activate_out, in
     kvol, _, plen = pairs.shape
     n_in = n_src_rows if not inverse else num_activate_out
     n_out = num_activate_out if not inverse else n_src_rows
-    tab_in = torch.empty((kvol, n_in), dtype=torch.int32, device=pairs.device)
-    tab_out = torch.empty((kvol, n_out), dtype=torch.int32, device=pairs.device)
+    tab_in = alloc_table(kvol, n_in, pairs.device)
+    tab_out = alloc_table(kvol, n_out, pairs.device)
     with _nat.device_guard(pairs.device):
         _nat.call("fv2p_pairs_to_tables", pairs, num, kvol, plen, n_in, n_out, tab_in, tab_out, _nat.stream())
     rb = Rulebook.__new__(Rulebook)
@@ -300,7 +336,7 @@ def indice_conv(features, filters, indice_pairs, indice_pair_num, num_activate_o
     rb = _rulebook_of(indice_pairs, indice_pair_num, features.shape[0], num_activate_out, inverse)
     cin, cout = filters.shape[-2], filters.shape[-1]
     w = filters.reshape(-1, cin, cout)
-    table, flip = rb.in_table() if inverse else rb.out_table()
+    table, flip = rb.in_table(cin) if inverse else rb.out_table(cin)
     return _conv_rows(features, w, table, flip, num_activate_out, cout, False, bias)
 
 
@@ -318,7 +354,7 @@ def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_nu
     feats, w, g = f32(features).contiguous(), f32(filters).reshape(-1, cin, cout).contiguous(), f32(out_bp).contiguous()
     kvol = w.shape[0]
     # forward used table F (dst rows = outputs); its transpose-direction table B has dst rows = inputs
-    (tab_f, flip_f), (tab_b, flip_b) = (rb.in_table(), rb.out_table()) if inverse else (rb.out_table(), rb.in_table())
+    (tab_f, flip_f), (tab_b, flip_b) = (rb.in_table(), rb.out_table(cout)) if inverse else (rb.out_table(), rb.in_table(cout))
     din = _conv_rows(g, w, tab_b, flip_b, features.shape[0], cin, True)
     dw = torch.empty_like(w)
     with _nat.device_guard(feats.device):

@@ -122,9 +122,24 @@ int fv2p_pairs_to_tables(const int* pairs, const int* indice_num, int kvol, int6
  *   forward        : src=features[n_in,Cin],  tab=tab_out, n_dst=n_out, c_dst=Cout, transpose_w=0
  *   backward data  : src=dOut[n_out,Cout],    tab=tab_in,  n_dst=n_in,  c_dst=Cin,  transpose_w=1
  *   inverse conv   : src=features[n_out,Cin'], tab=tab_in, n_dst=n_in,  transpose_w=0
- * flip_k!=0 reads table row K-1-k for offset k (subm symmetry, lets subm reuse tab_in as tab_out).
+ * flip_k is a flag word: bit 0 (FV2P_TAB_FLIP) reads table row K-1-k for offset k (subm symmetry, lets subm reuse
+ * tab_in as tab_out); bit 1 (FV2P_TAB_PLANNED, conv entry points only) promises that the table's allocation continues
+ * with the tiling plan fv2p_conv_plan_build wrote behind it (see below).  The reference has no counterpart of the
+ * plan: its gather -> mm -> scatter loop balances by construction (one GEMM per offset, spconv_ops.h:300-357).
  * fp32 in / fp32 accumulate on v_mfma_f32_16x16x4_f32; deterministic (fixed k order, no atomics).
  */
+#define FV2P_TAB_FLIP 1
+#define FV2P_TAB_PLANNED 2
+/* Cost-balanced tiling of a table's destination rows for the fused conv kernels.  A table `tab` [kvol][n_dst] allocated
+ * with fv2p_conv_plan_ints(n_dst) extra ints behind it can be given a plan once (it depends on the table only, so every
+ * conv that shares the rulebook — forward, flipped submanifold backward, any channel count — reuses it): the rows are cut
+ * into contiguous ranges of equal cost, cost(row) = max(pairs of the row, 8), for tile counts 256, 384, 512, 768, ...;
+ * a launch picks the level that suits its shape and a workgroup processes one range.  Results are bit-identical with
+ * and without a plan (every row's sum still runs over ascending k inside one workgroup); only the work per workgroup
+ * changes: equal-row tiles carry up to 2x the median pairs at the 5-20 pairs per row of the backbones' deep levels. */
+int64_t fv2p_conv_plan_ints(int64_t n_dst);
+size_t fv2p_conv_plan_ws_bytes(int64_t n_dst);
+int fv2p_conv_plan_build(int* tab, int kvol, int64_t n_dst, void* ws, size_t ws_bytes, fv2p_stream_t stream);
 /* Test / tuning hook: force one kernel variant of fv2p_sparse_conv_rows for the calls that follow
  * (0 = heuristic, 1 = plain dense tile, 2 = compacted tile, 3 = register-staged pipeline).  All variants compute
  * the same sum in the same k order. */

@@ -642,3 +642,76 @@ def test_a_hook_on_a_conv_sees_the_convs_own_output(gpu):
     h.remove()
     assert float((hooked - plain).abs().max()) < 1e-5 * float(plain.abs().max())       # same result either way
     assert float(seen[0].min()) < 0 and not torch.equal(seen[0], hooked)             # ... and the hook saw pre-BN / pre-ReLU values
+
+
+def _plan_of(tab, level_tiles):
+    """Host view of the plan behind a table (include/fv2p_ops.h: [magic, levels, per level T + 1 bounds])."""
+    kvol, n = tab.shape
+    flat = torch.empty(0, dtype=torch.int32, device=tab.device).set_(tab.untyped_storage(), tab.storage_offset() + kvol * n,
+                                                                      (tab.untyped_storage().nbytes() // 4 - tab.storage_offset() - kvol * n,))
+    plan = flat.cpu().numpy()
+    assert plan[0] == 0x706c616e
+    off, out = 2, {}
+    for lvl in range(int(plan[1])):
+        t = (384 if lvl & 1 else 256) << (lvl >> 1)
+        out[t] = plan[off:off + t + 1]
+        off += t + 1
+    return out[level_tiles] if level_tiles else out
+
+
+@pytest.mark.parametrize("cin,cout,subm", [(64, 64, True), (128, 128, True), (64, 128, False), (128, 128, False)])
+def test_tiling_plan_changes_no_bit(gpu, cin, cout, subm):
+    """fv2p_conv_plan_build + FV2P_TAB_PLANNED: the cost-balanced tiling is a pure scheduling change — forward, backward-data
+    (flipped table for submanifold layers) are bit for bit those of the equal-row tiling, the BatchNorm sums of the epilogue
+    (fp64 atomics) equal to 1e-12; the plan's bounds are monotone, cover [0, n) and every range's cost is within one
+    row's cost of total / T.  Clustered cloud: dense blobs beside isolated cells, so equal rows are not equal work."""
+    import fv2p_native
+    slots = int(fv2p_native.lib().fv2p_sparse_conv_stat_slots())
+    batch, shape = 2, [21, 60, 56]
+    rng = np.random.default_rng(cin + cout + subm)
+    cells = set()
+    for b in range(batch):
+        for _ in range(14):   # blobs
+            c = rng.integers([2, 4, 4], [19, 56, 52])
+            pts = np.unique(np.clip(np.round(c + rng.standard_normal((700, 3)) * [1.2, 2.5, 2.5]).astype(int), 0, np.array(shape) - 1), axis=0)
+            cells.update((b, *p) for p in pts.tolist())
+        lone = rng.integers(0, shape, (2500, 3))
+        cells.update((b, *p) for p in lone.tolist())
+    ind = np.array(sorted(cells), np.int32)
+    ind = ind[rng.permutation(ind.shape[0])]
+    x = torch.from_numpy(rng.standard_normal((ind.shape[0], cin)).astype(np.float32)).to(gpu)
+    indices = torch.from_numpy(ind).to(gpu)
+    rb = ops.build_rulebook(indices, batch, shape, 3, 1 if subm else 2, 1, 1, 0, subm)
+    n_out = rb.outids.shape[0]
+    w = torch.from_numpy(rng.standard_normal((27, cin, cout)).astype(np.float32) * 0.1).to(gpu)
+    g = torch.from_numpy(rng.standard_normal((n_out, cout)).astype(np.float32)).to(gpu)
+    bias = torch.from_numpy(rng.standard_normal(cout).astype(np.float32)).to(gpu)
+
+    def run(planned):
+        (tab_f, flag_f), (tab_b, flag_b) = rb.out_table(cin if planned else None), rb.in_table(cout if planned else None)
+        assert bool(flag_f & ops.TAB_PLANNED) == planned and bool(flag_b & ops.TAB_PLANNED) == planned
+        y = torch.empty((n_out, cout), device=gpu)
+        stats = torch.zeros((slots, 2, cout), dtype=torch.float64, device=gpu)
+        fv2p_native.call("fv2p_sparse_conv_rows_stats", x, x.shape[0], cin, w, 27, tab_f, n_out, cout, int(flag_f), 0, bias, y, stats, fv2p_native.stream())
+        dx = torch.empty((x.shape[0], cin), device=gpu)
+        fv2p_native.call("fv2p_sparse_conv_rows", g, n_out, cout, w, 27, tab_b, x.shape[0], cin, int(flag_b), 1, None, dx, fv2p_native.stream())
+        return y, stats.sum(0), dx
+
+    plain = run(False)
+    planned = run(True)
+    assert torch.equal(plain[0], planned[0]) and torch.equal(plain[2], planned[2])
+    # the epilogue's BatchNorm sums are fp64 atomics into slots chosen by workgroup index: same addends, another order
+    assert float((plain[1] - planned[1]).abs().max()) <= 1e-12 * float(plain[1].abs().max())
+    # the forward result against the oracle once (the plain tiling is held to it everywhere else)
+    _, pairs, num = oracle.indice_pairs(ind, batch, shape, [3, 3, 3], [1, 1, 1] if subm else [2, 2, 2], [1, 1, 1], [1, 1, 1], subm=subm)
+    ref = oracle.indice_conv(x.cpu().numpy(), w.cpu().numpy(), pairs, num, n_out, subm=subm).numpy() + bias.cpu().numpy()
+    assert rel_err(planned[0].cpu().numpy(), ref) < RTOL
+    # structure of the plan behind the forward table
+    tab, _ = rb.out_table(cin)
+    cost = np.maximum((tab.cpu().numpy() >= 0).sum(0), 8)
+    for tiles, bounds in _plan_of(tab, None).items():
+        assert bounds[0] == 0 and bounds[-1] == tab.shape[1] and (np.diff(bounds) >= 0).all()
+        per = np.add.reduceat(np.concatenate([cost, [0]]), np.minimum(bounds[:-1], cost.size))
+        per[np.diff(bounds) == 0] = 0
+        assert per.sum() == cost.sum()
+        assert per.max() <= cost.sum() / tiles + cost.max() + 1, (tiles, per.max(), cost.sum() / tiles)

@@ -190,7 +190,7 @@ def conv(only=None):
         t_f = timeit(lambda: ops.indice_conv(f, w, rb, None, n_out, False, mod.subm))
         cin, cout = mod.in_channels, mod.out_channels
         w3 = w.reshape(-1, cin, cout)
-        tab_b, flip_b = rb.in_table()
+        tab_b, flip_b = rb.in_table(cout)
         t_dx = timeit(lambda: ops._conv_rows(g, w3, tab_b, flip_b, f.shape[0], cin, True))
         extra = ""
         if not mod.subm and not mod.transposed:   # strided conv: backward-data with the rows grouped by parity class
