@@ -82,6 +82,11 @@ def parse():
     ap.add_argument("--point-stream", type=int, default=1, help="fv2p: decoder + point head on their own stream (A/B switch)")
     ap.add_argument("--miopen-find", type=int, default=0, help="torch.backends.cudnn.benchmark: let MIOpen time its solvers for the dense 2-D convs")
     ap.add_argument("--bev-channels-last", type=int, default=0, help="fv2p: BEV backbone + anchor head in channels_last memory format")
+    ap.add_argument("--impl", choices=["native", "refstyle"], default="native",
+                    help="refstyle: the timed steps themselves run in the reference's call structure (fv2p_harness/refstyle.py); the default run "
+                         "times that structure beside the native step for vs_baseline (--refstyle-steps)")
+    ap.add_argument("--inline-steps", type=int, default=10, help="FV2P workloads: extra steps on ONE stream with nothing prepared ahead, reported as inline_ms_per_step (0 = skip)")
+    ap.add_argument("--refstyle-steps", type=int, default=6, help="FV2P workload: extra steps in the reference's call structure, reported as baseline / vs_baseline (0 = skip)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous check without a GPU: ranks join a gloo group, reduce, rank 0 prints n_gpus")
     ap.add_argument("--pyprofile", action="store_true", help="cProfile the timed steps (host-overhead hunting; prints to stderr)")
     args = ap.parse_args()
@@ -98,12 +103,9 @@ def parse():
         args.steps, args.warmup = 30, (args.warmup if "--warmup" in sys.argv else 5)
     if args.workload == "fv2p" and "--prefetch" not in sys.argv:
         args.prefetch = 0   # measured: the input-pipeline thread does not pay here (65.3 vs 63.7 ms per step); the step is not launch bound
-    if args.gpus > 1 and "--dense-stream" not in sys.argv:
-        # the dense-branch arrangement is fast only while the process drives no further side stream (with the input-pipeline stream or
-        # the point-branch stream beside it the step takes 54 - 63 instead of 34 ms, four hardware queues); a rank of a multi-GPU job
-        # also drives RCCL's stream, which could not be measured on the one-GPU boxes of this round: the arrangement that ran beside
-        # seven streams without loss (point branch after the RoI preparation, 38.4 ms) is the default there
-        args.dense_stream = 0
+    # ONE stream arrangement for every N: a 1 -> 8 scan compares like with like and the N = 1 point of a scaling run is the headline
+    # run (round 2 switched multi-GPU ranks to another arrangement; RCCL's stream beside the dense-branch stream is unmeasured — the
+    # in-line figure `inline_ms_per_step` is the arrangement-free number to fall back on)
     if args.workload in ("fv2p", "fv2p-waymo") and "--ahead" not in sys.argv and not args.prefetch:
         # batch t+1 is voxelised and its rulebooks are built on the sampling stream, in front of that batch's sampler, between forward
         # and backward of step t: the sparse backbone of step t+1 then starts without its five host waits (33.65 -> 32.75 ms).  On a
@@ -122,8 +124,10 @@ def beat(phase):
     path = os.environ.get("FV2P_BENCH_HEARTBEAT")
     if path:
         try:
-            with open(path, "w") as f:
+            tmp = f"{path}.{os.getpid()}"
+            with open(tmp, "w") as f:
                 f.write(f"{time.time()} {phase}")
+            os.replace(tmp, path)     # the supervisor never reads a half-written file
         except OSError:
             pass
 
@@ -173,6 +177,7 @@ def supervise(args):
             os._exit(143)
         previous = signal.signal(signal.SIGTERM, stop) if ranked else None
         started, hung = time.time(), None
+        last = (started, "start")     # the last heartbeat that parsed
         while child.poll() is None:
             time.sleep(0.5)
             if args.watchdog <= 0:
@@ -181,12 +186,12 @@ def supervise(args):
             try:
                 with open(hb.name) as f:
                     t, phase = f.read().split(None, 1)
-                limit = args.stall if phase.strip() in ("step", "sync") else args.watchdog
-                if now - float(t) > limit:
-                    hung = f"no heartbeat for {limit} s in phase '{phase.strip()}'"
+                last = (float(t), phase.strip())
             except (OSError, ValueError):
-                if now - started > args.watchdog:
-                    hung = f"no heartbeat within {args.watchdog} s"
+                pass
+            limit = args.stall if last[1] in ("step", "sync") else args.watchdog
+            if now - last[0] > limit:
+                hung = f"no heartbeat for {limit} s in phase '{last[1]}'"
             if hung:
                 break
         if previous is not None:
@@ -240,9 +245,9 @@ def build_step(args, device, rank, world):
             super().__init__()
             self.body = body
 
-        def forward(self, feats, coords, batch):
+        def forward(self, feats, coords, batch, gt=None):
             if args.workload == "mgaf":
-                return self.body(feats, coords, batch)
+                return self.body(feats, coords, batch, gt)
             out, _ = self.body(feats, coords, batch)
             return out.features.square().mean()
 
@@ -252,8 +257,18 @@ def build_step(args, device, rank, world):
         torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.01, fused=True)  # one multi-tensor kernel per step
     # a small pool of distinct batches, points resident in HBM; seeds differ per rank
     n_pool = 4
-    pool = [[torch.from_numpy(synth.lidar_cloud(seed, args.points)).to(device) for seed in seeds]
-            for seeds in dist_utils.rank_seeds(rank, n_pool, args.batch)]
+    pool, gts = [], []
+    for seeds in dist_utils.rank_seeds(rank, n_pool, args.batch):
+        got = [synth.lidar_cloud(seed, args.points, return_boxes=True) for seed in seeds]
+        pool.append([torch.from_numpy(p).to(device) for p, _ in got])
+        if args.workload == "mgaf":   # (B, G, 8) zero padded; the synthetic boxes take the three classes of mgaf-3dssd_3classes.yaml in turn
+            gt = np.zeros((len(got), 40, 8), np.float32)
+            for i, (_, bx) in enumerate(got):
+                k = min(len(bx), 40)
+                gt[i, :k, :7], gt[i, :k, 7] = bx[:k], 1 + np.arange(k) % 3
+            gts.append(torch.from_numpy(gt).to(device))
+        else:
+            gts.append(None)
 
     def voxelize(clouds):
         # voxelise + MeanVFE + collate: (features [sum M, 4], coords [sum M, 4]) straight from the voxeliser's outputs
@@ -295,7 +310,7 @@ def build_step(args, device, rank, world):
                 pre.submit(step.next_submit)
                 step.next_submit += 1
             feats, coords = pre.get()
-        loss = net(feats, coords, args.batch)
+        loss = net(feats, coords, args.batch, gts[i % n_pool])
         opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()
@@ -319,7 +334,7 @@ def build_step(args, device, rank, world):
         else:  # input pipeline off the clock here: this mode times the training thread's phases
             pre.submit(i)
             feats, coords = pre.get()
-        loss = phase("forward", lambda: net(feats, coords, args.batch))
+        loss = phase("forward", lambda: net(feats, coords, args.batch, gts[i % n_pool]))
         opt.zero_grad(set_to_none=True)
         phase("backward", lambda: loss.backward())
         phase("optimizer", lambda: opt.step())
@@ -441,6 +456,31 @@ def build_fv2p_step(args, device, rank, world):
         opt.step()
         return loss
 
+    from fv2p_harness import refstyle
+    cfg_inline = refstyle.inline_config(cfg)
+
+    def step_inline(i, reference=False):
+        """The same optimiser step with nothing arranged around it: one stream, the batch voxelised and its key points sampled in
+        line — what the boundary itself delivers to an unmodified detector.  reference=True: in the reference's call structure
+        (fv2p_harness/refstyle.py), the baseline of vs_baseline."""
+        model.cfg = cfg_inline
+        key_jobs.clear()
+        clouds, gt = pool[i % n_pool]
+
+        def body():
+            feats, coords = voxelize(clouds, cloud_streams=False)
+            u = torch.rand(len(clouds), n_uniform, device=device)
+            loss = net(clouds, feats, coords, gt, u)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(params, cfg.grad_norm_clip, foreach=True)
+            opt.step()
+            return loss
+        if reference:
+            with refstyle.reference_call_structure():
+                return body()
+        return body()
+
     def step_phases(i, acc):
         def phase(name, fn):
             torch.cuda.synchronize()
@@ -536,6 +576,7 @@ def build_fv2p_step(args, device, rank, world):
 
     step.phases = step_phases
     step.close = close
+    step.inline = step_inline
     return model, step, voxelize, pool
 
 
@@ -560,12 +601,38 @@ def fps_probe(model, pool, args, device):
             "us_per_round": round(ms * 1e3 / (m - 1), 4), "samples_in_flight": xyz.shape[0], "points": xyz.shape[1]}
 
 
+def cpu_model_string():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def median_time(fn, reps, warm=0, budget_s=None):
+    """Median wall time of fn() over up to `reps` calls after `warm` untimed ones; stops early once `budget_s` is used up."""
+    for _ in range(warm):
+        fn()
+    ts, t_all = [], time.perf_counter()
+    for _ in range(reps):
+        t = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t)
+        if budget_s is not None and time.perf_counter() - t_all > budget_s:
+            break
+    return float(np.median(ts)), ts
+
+
 def cpu_baseline_fv2p(model, args):
     """The same detector replay on the host: every op answered by the oracle port of the reference algorithm (oracle/backend.py),
-    sparse convs by the oracle's gather-mm-scatter, dense layers by torch CPU.  Bounded sample: one step at batch 1."""
+    sparse convs by the oracle's gather-mm-scatter, dense layers by torch CPU.  Protocol: one untimed warm-up step
+    (thread pools, oneDNN primitives and first-touch allocations stay off the clock), then the MEDIAN of up to three timed steps at
+    batch 1 (bounded at ~75 s of timed work); beside it the single-thread paths `north_star` and BASELINE.md name (B1 - B4)."""
     import oracle
     from fv2p_harness import synth
-    from fv2p_harness.backbone import mean_vfe
+    from fv2p_harness.backbone import VoxelBackBone8x, mean_vfe
     from fv2p_harness.fv2p_model import pad_gt_boxes
     from oracle.backend import oracle_backend
     from oracle.spconv_cpu import cpu_mirror
@@ -578,33 +645,60 @@ def cpu_baseline_fv2p(model, args):
     ref = cpu_mirror(model)
     cfg = model.cfg
     pts, bx = synth.lidar_cloud(7, args.points, return_boxes=True)
-    t0 = time.perf_counter()
-    v, c, k = oracle.points_to_voxel(pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, cfg.max_points_per_voxel, cfg.max_voxels)
-    feats = mean_vfe(torch.from_numpy(v), torch.from_numpy(k))
-    coords = torch.from_numpy(np.concatenate([np.zeros((c.shape[0], 1), np.int32), c], 1))
-    u = torch.rand(1, cfg.nms_post + cfg.roi_per_image)
-    with oracle_backend():
-        loss = ref([torch.from_numpy(pts)], feats, coords, pad_gt_boxes([bx], "cpu", max_gt=40), u)
-        loss.backward()
-    dt = time.perf_counter() - t0
-    # the two host-side paths north_star names, single thread each: the reference voxeliser with its dense
-    # 360 MB coordinate map allocated and filled per call (voxel_generator.py:114, 136-207) and the CPU greedy NMS over the
-    # rotated-IoU matrix of the 9000 proposals of the train config (iou3d_nms.cpp:121-135 + iou3d_cpu.cpp)
-    vt = []
-    for _ in range(5):
-        t1 = time.perf_counter()
-        oracle.points_to_voxel(pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, cfg.max_points_per_voxel, cfg.max_voxels)
-        vt.append(time.perf_counter() - t1)
-    bx = synth.proposal_boxes(1, 9000)
-    t1 = time.perf_counter()
-    kept = oracle.nms(bx, -np.arange(9000, dtype=np.float32), cfg.nms_thresh)
-    nms_s = time.perf_counter() - t1
-    extras = {"voxelize_16384pts_ms": round(sorted(vt)[2] * 1e3, 2), "nms_9000_boxes_ms": round(nms_s * 1e3, 1), "nms_survivors": int(len(kept)),
-              "threads": 1}
-    return {"value": round(1.0 / dt, 4), "unit": "point clouds/s", "cores": cores, "kind": "port", "single_op_baselines": extras,
-            "sample": f"1 FV2P train step (forward + backward, no optimiser) at batch 1 on one synthetic {args.points}-point cloud: oracle "
-                      f"voxeliser, rulebooks, per-offset gather/mm/scatter sparse convs, single-thread C ports of FPS / 3-NN / NMS / "
-                      f"IoU / pools, torch-CPU dense layers ({cores} threads), {dt:.1f} s"}
+    gt = pad_gt_boxes([bx], "cpu", max_gt=40)
+
+    def one_step():
+        v, c, k = oracle.points_to_voxel(pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, cfg.max_points_per_voxel, cfg.max_voxels)
+        feats = mean_vfe(torch.from_numpy(v), torch.from_numpy(k))
+        coords = torch.from_numpy(np.concatenate([np.zeros((c.shape[0], 1), np.int32), c], 1))
+        u = torch.rand(1, cfg.nms_post + cfg.roi_per_image)
+        ref.zero_grad(set_to_none=True)
+        with oracle_backend():
+            loss = ref([torch.from_numpy(pts)], feats, coords, gt, u)
+            loss.backward()
+    dt, step_samples = median_time(one_step, 3, warm=1, budget_s=75.0)
+    torch.set_num_threads(1)
+    # B1: the reference voxeliser with its dense 360 MB coordinate map allocated and filled per call (voxel_generator.py:114, 136-207)
+    vox, _ = median_time(lambda: oracle.points_to_voxel(pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, cfg.max_points_per_voxel, cfg.max_voxels), 20, warm=3, budget_s=10.0)
+    # B2: rotated BEV IoU matrix, 512 x 512 (iou3d_cpu.cpp:232-252)
+    b512 = synth.proposal_boxes(3, 512)
+    iou512, _ = median_time(lambda: oracle.boxes_bev(b512, b512, "iou"), 20, warm=2, budget_s=5.0)
+    # B3: greedy NMS over the rotated-IoU matrix (iou3d_nms.cpp:121-135 + iou3d_cpu.cpp), score-sorted input.  Proposal-like
+    # (tight clusters: most boxes are suppressed early) and the all-survivor worst case of the greedy loop
+    order = lambda n: -np.arange(n, dtype=np.float32)
+    near = synth.proposal_boxes(1, 9000, tight=True)
+    kept_near = oracle.nms(near, order(9000), cfg.nms_thresh)
+    nms_near, _ = median_time(lambda: oracle.nms(near, order(9000), cfg.nms_thresh), 3, budget_s=20.0)
+    far = synth.proposal_boxes(1, 9000)
+    kept_far = oracle.nms(far, order(9000), cfg.nms_thresh)
+    nms_far, _ = median_time(lambda: oracle.nms(far, order(9000), cfg.nms_thresh), 3, budget_s=12.0)
+    b4096 = synth.proposal_boxes(2, 4096, tight=True)
+    kept4096 = oracle.nms(b4096, order(4096), 0.1)
+    nms4096, _ = median_time(lambda: oracle.nms(b4096, order(4096), 0.1), 3, budget_s=10.0)
+    # B4: BASELINE configs[1] on the host: VoxelBackBone8x forward at batch 4, per-offset gather / mm / scatter (torch CPU, all threads)
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    bb = cpu_mirror(VoxelBackBone8x(4, [1408, 1600, 40]))
+    feats, coords = [], []
+    for b in range(4):
+        v, c, k = oracle.points_to_voxel(synth.lidar_cloud(10 * b, args.points), synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 16000)
+        feats.append(mean_vfe(torch.from_numpy(v), torch.from_numpy(k)))
+        coords.append(torch.from_numpy(np.concatenate([np.full((c.shape[0], 1), b, np.int32), c], 1)))
+    feats, coords = torch.cat(feats), torch.cat(coords)
+    with torch.no_grad():
+        b4, _ = median_time(lambda: bb(feats, coords, 4), 5, warm=1, budget_s=25.0)
+    extras = {"B1_voxelize_16384pts_ms": round(vox * 1e3, 2),
+              "B2_bev_iou_512x512_ms": round(iou512 * 1e3, 2), "B2_pairs_per_s": round(512 * 512 / iou512),
+              "B3_nms_9000_thr0.8_proposal_like_ms": round(nms_near * 1e3, 1), "B3_survivors_proposal_like": int(len(kept_near)),
+              "B3_nms_9000_thr0.8_all_survivors_ms": round(nms_far * 1e3, 1), "B3_survivors_worst_case": int(len(kept_far)),
+              "B3_nms_4096_thr0.1_ms": round(nms4096 * 1e3, 1), "B3_survivors_4096": int(len(kept4096)),
+              "B4_backbone8x_fwd_batch4_clouds_per_s": round(4 / b4, 3), "B4_threads": cores,
+              "threads": 1, "protocol": "warm-ups then median (BASELINE.md 2); B1-B3 single thread, B4 torch CPU"}
+    return {"value": round(1.0 / dt, 4), "unit": "point clouds/s", "cores": cores, "kind": "port", "cpu": cpu_model_string(),
+            "step_samples_s": [round(t, 2) for t in step_samples], "single_op_baselines": extras,
+            "sample": f"median of {len(step_samples)} FV2P train steps (forward + backward, no optimiser) at batch 1 on one synthetic {args.points}-point cloud after one "
+                      f"untimed warm-up step: oracle voxeliser, rulebooks, per-offset gather/mm/scatter sparse convs, single-thread C ports of FPS / 3-NN / "
+                      f"NMS / IoU / pools, torch-CPU dense layers ({cores} threads), {dt:.1f} s per step"}
 
 
 def conv_kernel_name(cin, cout, n_dst=0):
@@ -739,9 +833,9 @@ def workload_name(args):
                 "head, FPS to 16384 key points, voxel-to-point decoder, point head, IoU-guided RoI head, losses, backward, grad clip, "
                 "AdamW; KITTI grid 0.05 m [41,1600,1408], LiDAR-like synthetic clouds with 20-40 car boxes")
     if args.workload == "mgaf":
-        return ("MGAF-3DSSD layer replay: HIP voxelise + MeanVFE, VoxelResBackBone8x, DCNBEVBackbone (3 x MdeformConvBlock), CenterAFHeadSingle "
-                "(DCNv2 feature adaption dg=4, seven heads) forward + backward + AdamW with a surrogate loss (the head's target assignment and "
-                "loss terms are not replayed); KITTI grid, LiDAR-like synthetic clouds")
+        return ("MGAF-3DSSD (mgaf-3dssd_3classes.yaml) train step: HIP voxelise + MeanVFE, VoxelResBackBone8x, DCNBEVBackbone (3 x MdeformConvBlock), "
+                "CenterAFHeadSingle (DCNv2 feature adaption dg=4, seven heads), CenterTargetAssigner as batch tensor ops on the device, the head's "
+                "eight loss terms, backward, AdamW; KITTI grid, LiDAR-like synthetic clouds whose boxes take the three classes in turn")
     return (("VoxelBackBone8x" if args.backbone == "8x" else "VoxelResBackBone8x") +
             " train step (HIP voxelise + MeanVFE + sparse backbone fwd + bwd + AdamW), KITTI grid 0.05 m [41,1600,1408], LiDAR-like "
             "synthetic clouds")
@@ -819,6 +913,8 @@ def main():
     dist_utils.barrier()
     torch.cuda.synchronize()
     beat("step")
+    if args.phases or args.sync_debug or args.torch_profile:
+        beat("diag")     # long host phases: the --watchdog limit applies, not --stall
     if args.phases and rank == 0:
         acc = {}
         for i in range(20):
@@ -857,10 +953,20 @@ def main():
         import cProfile
         prof = cProfile.Profile()
         prof.enable()
+    fv2p = args.workload in ("fv2p", "fv2p-waymo")
+    if args.impl == "refstyle":
+        assert fv2p, "--impl refstyle is an FV2P workload"
+        run_step = lambda i: step.inline(i, reference=True)
+        for i in range(2):
+            run_step(i)
+        dist_utils.barrier()
+        torch.cuda.synchronize()
+    else:
+        run_step = step
     t0 = time.perf_counter()
     stamps = []
     for i in range(args.steps):
-        step(args.warmup + i)
+        run_step(args.warmup + i)
         if (i & 3) == 3:
             beat("step")
         if args.step_times:
@@ -873,6 +979,27 @@ def main():
     dist_utils.barrier()
     torch.cuda.synchronize()
     dt = dist_utils.max_over_ranks(time.perf_counter() - t0, device)
+
+    def extra_leg(k, warm, **kw):
+        """k more steps through step.inline, timed like the headline (barrier + synchronize on both sides, max over ranks)."""
+        for i in range(warm):
+            step.inline(args.warmup + args.steps + i, **kw)
+            beat("step")
+        dist_utils.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(k):
+            step.inline(args.warmup + args.steps + warm + i, **kw)
+            beat("step")
+        dist_utils.barrier()
+        torch.cuda.synchronize()
+        return dist_utils.max_over_ranks(time.perf_counter() - t1, device) / k
+    inline_s = refstyle_s = None
+    if fv2p and args.impl == "native" and not args.dry_run:
+        if args.inline_steps > 0:
+            inline_s = extra_leg(args.inline_steps, 2)
+        if args.refstyle_steps > 0 and args.workload == "fv2p":
+            refstyle_s = extra_leg(args.refstyle_steps, 2, reference=True)
     beat("post")   # probes and the CPU baseline follow: long host phases
     if rank == 0:   # leak check at a glance: what the caching allocator holds after the timed steps
         print("[memory] allocated %.1f MB, peak %.1f MB, reserved %.1f MB" % (torch.cuda.memory_allocated(device) / 2**20,
@@ -906,6 +1033,28 @@ def main():
         if args.workload in ("fv2p", "fv2p-waymo"):
             result["config"]["streams"] = ("dense branch (BEV backbone, anchor head, RoI preparation) on a side stream beside decoder + point head" if args.dense_stream
                                            else "decoder + point head on a side stream after the RoI preparation" if args.point_stream else "one stream")
+            result["config"]["stream_arrangement_same_for_every_n_gpus"] = True
+            attempt = int(os.environ.get("FV2P_BENCH_ATTEMPT", "0"))
+            result["attempt"], result["retried_after_hang"] = attempt, attempt > 0
+            if args.impl == "refstyle":
+                result["config"]["impl"] = "refstyle: the reference's call structure (fv2p_harness/refstyle.py), one stream"
+                result["config"]["streams"] = result["config"]["input_pipeline"] = "one stream, in line"
+            if inline_s is not None:
+                # the boundary's own figure: what an unmodified detector dropped onto this pcdet.ops gets, no stream scheduling of the harness
+                result["inline_ms_per_step"] = round(inline_s * 1e3, 3)
+                result["inline_value"] = round(args.batch * world / inline_s, 2)
+            if refstyle_s is not None:
+                base = args.batch * world / refstyle_s
+                result["vs_baseline"] = round(result["value"] / base, 3)
+                result["baseline"] = {
+                    "kind": "reference call structure on this GPU (not a published number: BASELINE.md has none)",
+                    "value": round(base, 2), "unit": "point clouds/s", "ms_per_step": round(refstyle_s * 1e3, 3), "steps": args.refstyle_steps,
+                    "vs_inline": round((args.batch * world / inline_s) / base, 3) if inline_s else None,
+                    "what": "same step, same weights and clouds: per-offset gather -> mm -> scatter-add sparse convs with the host read of indiceNum "
+                            "(spconv_ops.h:260-457), separate BatchNorm1d / ReLU, dense() by scatter + permute, plain one-workgroup FPS kernel in line, "
+                            "grouped set abstraction (pointnet2_modules.py:30-62), one full NMS per sample, tensor-op target assignment and losses, "
+                            "one stream; voxeliser, rulebook build, 3-NN / pooling kernels and MIOpen layers as in the native step (a lower bound "
+                            "on the reference's own step time)"}
         if args.workload == "fv2p-waymo":
             result["metric"] = "point clouds/sec fwd+bwd (FV2P, Waymo shape: 180k points, 0.1 m voxels)"
             if not args.no_roofline:
@@ -921,7 +1070,7 @@ def main():
             if world == 1 and args.cpu_clouds > 0:
                 result["cpu_baseline"] = cpu_baseline_fv2p(model, args)
         elif args.workload == "mgaf":
-            result["metric"] = "point clouds/sec fwd+bwd (MGAF-3DSSD layer replay, KITTI shape)"
+            result["metric"] = "point clouds/sec fwd+bwd (MGAF-3DSSD, KITTI shape)"
             if not args.no_roofline:
                 result["roofline"] = roofline_probe(model.backbone_3d, voxelize, pool, args, device)
         else:

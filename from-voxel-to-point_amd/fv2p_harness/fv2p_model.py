@@ -78,6 +78,7 @@ class FV2PConfig:
     interact_filters, cge_up, cge_interact, fuse_filters = (256, 256), (64, 64), (128,), (256,)
     cls_fc, reg_fc, dp_ratio = (256, 256), (256, 256), 0.3
     grad_norm_clip = 10.0
+    key_stream = True              # key-point sampling on its own stream beside the two backbones (False: in line, where the decoder asks for it)
     point_branch_stream = True     # decoder + point head on their own stream (their backward then overlaps the dense convs')
     # instead: BEV backbone + anchor head + second-stage preparation on a side stream from the end of the sparse backbone on (34.3 vs
     # 38.4 ms per step).  Off by default: it hung the device queue in every run on two boxes of twelve; bench.py switches
@@ -98,6 +99,10 @@ class FV2PWaymoConfig(FV2PConfig):
 
 
 # ---------------------------------------------------------------- small shared pieces -----------------
+# False: target assignment, target sampling and the first-stage losses run as their tensor formulations on the GPU too — what
+# fv2p_harness.refstyle.reference_call_structure() switches to (the batch kernels of csrc/targets.hip have no counterpart in the
+# reference, whose Python does this work op by op)
+KERNEL_GLUE = True
 _SIDE_STREAMS = {}
 _CONSTS = {}
 _CORNER_SIGNS = ((1, 1, -1), (1, -1, -1), (-1, -1, -1), (-1, 1, -1), (1, 1, 1), (1, -1, 1), (-1, -1, 1), (-1, 1, 1))
@@ -318,7 +323,7 @@ class AnchorHead(nn.Module):
         labels, regs = [], []
         for c, (_, _, matched, unmatched) in enumerate(cfg.anchor_classes):
             gt_c = gt if nc == 1 else torch.where((gt[..., 7:8] == c + 1), gt, torch.zeros_like(gt))   # other classes' rows become padding
-            one = self.assign_one_kernel if (gt.is_cuda and gt.shape[-1] >= 8) else self.assign_one_tensor_ops
+            one = self.assign_one_kernel if (gt.is_cuda and gt.shape[-1] >= 8 and KERNEL_GLUE) else self.assign_one_tensor_ops
             lab, reg = one(gt_c, getattr(self, f"anchors_c{c}"), getattr(self, f"anchor_bev_c{c}"), matched, unmatched)
             labels.append(lab.view(b, -1, 1, nr))
             regs.append(reg.view(b, -1, 1, nr, 7))
@@ -383,7 +388,7 @@ class AnchorHead(nn.Module):
         box = self.conv_box(feat).permute(0, 2, 3, 1).reshape(b, -1, 7)
         dirs = self.conv_dir_cls(feat).permute(0, 2, 3, 1).reshape(b, -1, cfg.num_dir_bins)
         labels, reg_t = self.assign(gt)
-        if cls.is_cuda and cfg.num_dir_bins == 2:
+        if cls.is_cuda and cfg.num_dir_bins == 2 and KERNEL_GLUE:
             # the three losses and their logit gradients in one pass (csrc/targets.hip); anchor_losses_tensor_ops states the same
             # in torch ops (and is the CPU path)
             loss = AnchorLossFn.apply(cls.contiguous(), box.contiguous(), dirs.contiguous(), labels.contiguous(), reg_t.contiguous(),
@@ -661,6 +666,13 @@ class IoUGuidedRoIHead(nn.Module):
         b = scores.shape[0]
         top_s, top_i = torch.topk(scores, k=min(cfg.nms_pre, scores.shape[1]), dim=1)     # descending: the order NMS wants
         cand = torch.gather(boxes, 1, top_i.unsqueeze(-1).expand(-1, -1, 7)).contiguous()
+        if not KERNEL_GLUE:   # the reference's loop: one nms_gpu per sample over all candidates, the cut afterwards (roi_head_template.py:60-85)
+            rois, roi_scores = boxes.new_zeros(b, cfg.nms_post, 7), boxes.new_zeros(b, cfg.nms_post)
+            for i in range(b):
+                sel, _ = iou3d_nms_utils.nms_gpu(cand[i], top_s[i], cfg.nms_thresh)
+                sel = sel[:cfg.nms_post]
+                rois[i, :len(sel)], roi_scores[i, :len(sel)] = cand[i][sel], top_s[i][sel]
+            return rois, roi_scores
         keep, cnt = iou3d_nms_cuda.nms_batch_device(cand, cfg.nms_thresh, cfg.nms_post)   # the first nms_post survivors per sample
         k = keep.shape[1]
         valid = torch.arange(k, device=boxes.device)[None] < cnt[:, None]
@@ -677,14 +689,14 @@ class IoUGuidedRoIHead(nn.Module):
         cfg = self.cfg
         b, r, _ = rois.shape
         n = cfg.roi_per_image
-        if rois.is_cuda:
+        if rois.is_cuda and KERNEL_GLUE:
             rois, gt = rois.contiguous(), gt.contiguous()
             iou = rois.new_empty(b, r, gt.shape[1])
             with _nat.device_guard(rois.device):   # boxes_iou3d_gpu for the batch in one launch (same float operations)
                 _nat.call("fv2p_boxes_iou3d_batch", rois, b, r, gt, gt.shape[1], gt.shape[-1], iou, _nat.stream())
         else:
             iou = torch.stack([iou3d_nms_utils.boxes_iou3d_gpu(rois[i], gt[i, :, :7].contiguous()) for i in range(b)])   # (B, R, G)
-        if rois.is_cuda and r <= 1024:
+        if rois.is_cuda and r <= 1024 and KERNEL_GLUE:
             # one launch for the batch (csrc/targets.hip); the tensor formulation below is its statement in torch ops and what a
             # CPU run takes (tests/test_fv2p_step_gpu.py compares the two bit for bit)
             rois, gt, uniforms = rois.contiguous(), gt.contiguous(), uniforms.contiguous().float()
@@ -886,7 +898,7 @@ class FV2PDetector(nn.Module):
         b = len(clouds)
         # key-point sampling needs the raw points only: it runs beside the two backbones on its own stream (three workgroups
         # for 16 k dependent rounds) and is joined where the decoder starts
-        if key_job is None:
+        if key_job is None and self.cfg.key_stream:
             key_job = self.post_pfe.start_sampling(clouds)
         out, levels = self.backbone_3d(voxel_features, voxel_coords, b)
         if self.cfg.dense_branch_stream and clouds[0].is_cuda:

@@ -138,8 +138,27 @@ def _dcn_forward(x_nhwc, wt, bias, offset, mask, b, h, w, cin, cout, ho, wo, kh,
     y_nhwc.copy_(y.permute(0, 2, 3, 1).reshape(b * ho * wo, cout))
 
 
+def _dcn_backward(x_nhwc, wt, offset, mask, dy_nhwc, b, h, w, cin, cout, ho, wo, kh, kw, sh, sw, ph, pw, dh, dw, dg, dx_nhwc, doffset, dmask, dwt,
+                  ws, ws_bytes, stream):
+    """modulated_deform_conv_cuda.cu:127-280 through autograd of the oracle's forward (float64 inside, one rounding at the end)."""
+    from oracle import dcn_oracle
+    with torch.enable_grad():
+        x = x_nhwc.view(b, h, w, cin).permute(0, 3, 1, 2).double().requires_grad_(True)
+        weight = wt.view(kh, kw, cin, cout).permute(3, 2, 0, 1).double().requires_grad_(True)
+        off = offset.view(b, dg * 2 * kh * kw, ho, wo).double().requires_grad_(True)
+        msk = mask.view(b, dg * kh * kw, ho, wo).double().requires_grad_(True)
+        y = dcn_oracle.modulated_deform_conv(x, off, msk, weight, None, (sh, sw), (ph, pw), (dh, dw), dg)
+        dy = dy_nhwc.view(b, ho, wo, cout).permute(0, 3, 1, 2).double()
+        gx, gw, go, gm = torch.autograd.grad(y, (x, weight, off, msk), dy)
+    dx_nhwc.copy_(gx.permute(0, 2, 3, 1).reshape(dx_nhwc.shape).float())
+    doffset.copy_(go.reshape(doffset.shape).float())
+    dmask.copy_(gm.reshape(dmask.shape).float())
+    dwt.copy_(gw.permute(2, 3, 1, 0).reshape(dwt.shape).float())
+
+
 _TABLE = {
     "fv2p_dcn_forward": _dcn_forward,
+    "fv2p_dcn_backward": _dcn_backward,
     "fv2p_three_nn_batch": _three_nn_batch,
     "fv2p_three_interpolate_batch": _three_interp_batch,
     "fv2p_three_interpolate_batch_grad": _three_interp_batch_grad,

@@ -157,3 +157,43 @@ def test_batchnorm_folded_backbone_equals_the_eval_mode_backbone(gpu):
     assert torch.equal(a.indices, b.indices) and rel(b.features, a.features) < 1e-4
     for key in la:
         assert rel(lb[key].features, la[key].features) < 1e-4, key
+
+
+def test_first_layer_gradient_noise_floor_against_float64(gpu):
+    """Why ONE parameter of the step tests gets 1e-2 instead of 2e-3 (tests/test_fv2p_step_gpu.py, test_mgaf_head.py): the
+    gradient of the sparse backbone's first conv weight sits at the end of a backward chain through 21 train-mode BatchNorms, each
+    of which subtracts two means — float32 rounding differences between two correct implementations reach several 1e-3 there.
+    Measured here against a float64 run of the same network (the reference's call structure in torch ops, which takes any dtype):
+    the HIP path is no further from float64 than the float32 torch formulation is, for every parameter."""
+    from fv2p_harness import refstyle
+    torch.manual_seed(0)
+    model = VoxelResBackBone8x(4, [1408, 1600, 40]).to(gpu)
+    feats, coords = make_batch(gpu, [3, 4], 8192)
+    g = None
+
+    def run(net, x, ref_mode):
+        nonlocal g
+        net.zero_grad(set_to_none=True)
+        if ref_mode:
+            with refstyle.reference_call_structure():
+                out, _ = net(x, coords, 2)
+        else:
+            out, _ = net(x, coords, 2)
+        if g is None:
+            g = torch.randn(out.features.shape, device=gpu, generator=torch.Generator(device=gpu).manual_seed(1))
+        (out.features * g.to(out.features.dtype)).sum().backward()
+        return {k: p.grad.double().clone() for k, p in net.named_parameters() if p.grad is not None}
+    native = run(model, feats, False)
+    torch32 = run(model, feats, True)
+    import copy
+    torch64 = run(copy.deepcopy(model).double(), feats.double(), True)
+    worst = []
+    for name, want in torch64.items():
+        if name.endswith(("conv1.bias", "conv2.bias")) or float(want.norm()) < 1e-12:
+            continue   # a bias in front of train-mode BatchNorm: analytically zero gradient
+        e_native = float((native[name] - want).norm() / want.norm())
+        e_torch = float((torch32[name] - want).norm() / want.norm())
+        worst.append((e_native, e_torch, name))
+        assert e_native <= 2.0 * e_torch + 2e-4, (name, e_native, e_torch)
+    worst.sort(reverse=True)
+    print("largest float32 deviations from float64 (HIP path, torch float32, parameter):", [(f"{a:.1e}", f"{b:.1e}", n) for a, b, n in worst[:4]])

@@ -29,6 +29,17 @@ class SmallFV2P(FV2PConfig):
     dp_ratio = 0.0          # dropout draws differ between devices
 
 
+GRAD_TOL = 2e-3     # relative L2 per parameter gradient, GPU kernels against the host run
+# ... except the one parameter at the far end of the backward chain (21 train-mode BatchNorms deep), where two correct float32
+# implementations separate by ~5e-3; tests/test_backbone_gpu.py::test_first_layer_gradient_noise_floor_against_float64 holds the
+# HIP path to "no further from float64 than torch's float32 formulation" for every parameter
+FIRST_LAYER, FIRST_LAYER_TOL = "backbone_3d.conv_input.0.weight", 1e-2
+
+
+def grad_tol(name):
+    return FIRST_LAYER_TOL if name == FIRST_LAYER else GRAD_TOL
+
+
 def rel(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
@@ -91,13 +102,23 @@ def test_fv2p_step_matches_cpu_oracle(gpu, cpu_run):
     assert rel(g["bev"].detach().cpu(), c["bev"].detach()) < 1e-3
     assert abs(g["loss_point"].item() - c["loss_point"].item()) < 1e-3 * max(1.0, abs(c["loss_point"].item()))
     assert abs(g["loss_rpn"].item() - c["loss_rpn"].item()) < 1e-3 * max(1.0, abs(c["loss_rpn"].item()))
+    # EVERY parameter the first-stage + point losses reach, relative L2 (the host run of this very Python is held to the reference's
+    # own detector within 3e-3 per parameter, tests/test_reference_overlay.py): 2e-3, not six hand-picked names at 1e-2
     gp = dict(net.named_parameters())
-    for name in ("backbone_3d.conv_input.0.weight", "backbone_3d.conv3.1.conv2.weight", "backbone_2d.blocks.0.1.weight",
-                 "post_pfe.decode_block_out.0.weight", "post_pfe.decode_blocks_map.x_conv3.net.0.weight", "point_head.cls_layers.0.weight"):
-        a, b = gp[name].grad.cpu().double(), stage1[name].double()
-        assert float((a - b).norm() / b.norm().clamp_min(1e-12)) < 1e-2, name
+    worst = ("", 0.0)
+    for name, want in stage1.items():
+        a, b = gp[name].grad.cpu().double(), want.double()
+        if float(b.norm()) < 1e-10:      # a parameter the two losses do not reach (second-stage layers): both sides zero
+            assert float(a.norm()) < 1e-8, name
+            continue
+        err = float((a - b).norm() / b.norm())
+        worst = max(worst, (name, err), key=lambda t: t[1])
+        assert err < grad_tol(name), (name, err)
+    print(f"worst first-stage gradient: {worst[0]} {worst[1]:.2e}")
     g["loss_rcnn"].backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+    # the second-stage loss is compared unconditionally in test_roi_head_on_identical_inputs_matches_cpu_oracle (both heads are fed
+    # the host run's proposals there); here the two runs' own proposals may differ by a swapped pair of near-equal scores
     if torch.equal(g["sampled_rois"].cpu(), c["sampled_rois"]):
         assert abs(g["loss_rcnn"].item() - c["loss_rcnn"].item()) < 2e-3 * max(1.0, abs(c["loss_rcnn"].item()))
     # bench.py's cpu_baseline leg mirrors a model that has already stepped on the GPU: its side streams must not be module state
@@ -131,9 +152,49 @@ def test_roi_head_on_identical_inputs_matches_cpu_oracle(gpu, cpu_run):
     assert fg is None and fc is None          # the RoI point pool carries no gradient (reference: under no_grad, iouguided_roi_head.py:178)
     assert rel(bg.cpu(), bc) < 2e-3
     gp, cp = dict(head_g.named_parameters()), dict(ref.roi_head.named_parameters())
-    for name in ("grid_interact_fc_layer.0.weight", "xyz_up_layer.0.weight", "SA_modules.0.mlps.1.0.weight", "reg_layers.7.weight"):
-        a, b = gp[name].grad.cpu().double(), cp[name].grad.double()
-        assert float((a - b).norm() / b.norm().clamp_min(1e-12)) < 5e-3, name
+    for name, p in cp.items():           # every parameter of the head
+        if p.grad is None:
+            assert gp[name].grad is None, name
+            continue
+        a, b = gp[name].grad.cpu().double(), p.grad.double()
+        assert float((a - b).norm() / b.norm().clamp_min(1e-12)) < GRAD_TOL, name
+
+
+@pytest.mark.gpu
+def test_reference_call_structure_is_the_same_step(gpu, cpu_run):
+    """fv2p_harness.refstyle (bench.py's vs_baseline leg: per-offset gather -> mm -> scatter-add sparse convs, separate BatchNorm /
+    ReLU modules, grouped set abstraction, per-sample NMS, tensor-op target assignment, plain FPS kernel, one stream) computes the
+    step of the default path: same key points and proposals, features / losses within 1e-3, gradients within GRAD_TOL."""
+    from fv2p_harness import refstyle
+    model, _, inputs, _, _ = cpu_run
+    clouds, feats, coords, gt, u = inputs
+    args = ([c.to(gpu) for c in clouds], feats.to(gpu), coords.to(gpu), gt.to(gpu), u.to(gpu))
+    net = model.to(gpu)
+    runs = []
+    for ref_mode in (False, True):
+        net.taps = {}
+        net.zero_grad(set_to_none=True)
+        net.cfg = refstyle.inline_config(SmallFV2P) if ref_mode else SmallFV2P
+        if ref_mode:
+            with refstyle.reference_call_structure():
+                loss = net(*args)
+                (net.taps["loss_rpn"] + net.taps["loss_point"]).backward()
+        else:
+            loss = net(*args)
+            (net.taps["loss_rpn"] + net.taps["loss_point"]).backward()
+        runs.append((dict(net.taps), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}, loss.detach()))
+    net.cfg, net.taps = SmallFV2P, None
+    (ta, ga, la), (tb, gb, lb) = runs
+    assert torch.equal(ta["keypoints"], tb["keypoints"])
+    assert rel(tb["point_features"].detach().cpu(), ta["point_features"].detach().cpu()) < 1e-3
+    assert rel(tb["bev"].detach().cpu(), ta["bev"].detach().cpu()) < 1e-3
+    for name in ("loss_rpn", "loss_point"):
+        assert abs(ta[name].item() - tb[name].item()) < 1e-3 * max(1.0, abs(ta[name].item())), name
+    assert set(ga) == set(gb)
+    for name, b in ga.items():
+        if float(b.norm()) < 1e-10:
+            continue
+        assert float((gb[name].double() - b.double()).norm() / b.double().norm()) < grad_tol(name), name
 
 
 class SmallWaymoFV2P(FV2PWaymoConfig):

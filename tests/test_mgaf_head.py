@@ -1,0 +1,154 @@
+"""MGAF-3DSSD dense head (BASELINE configs[3]) — the harness's target assignment and losses (fv2p_harness/mgaf_model.py) against
+fixtures written by the reference's own CenterTargetAssigner and CenterAFHeadTemplate (oracle/gen_golden_center_head.py):
+
+  pyref_center_targets.npz   heat map, indices, masks, regression targets from the reference class; exact for the integer outputs
+                             and the float32 heat map, 1e-6 for the float targets (the segmentation map is cv2 in the reference
+                             and not in the fixture: it is held by its own properties below)
+  pyref_center_losses.npz    the eight loss terms and the gradients of the seven head maps from the reference's get_loss
+
+and the whole MGAFDetector step on the HIP ops against the same Python on the host (oracle backend, DCN forward / backward
+answered by oracle/dcn_oracle.py) at a reduced map size."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fv2p_harness import mgaf_model as mm
+from oracle.backend import oracle_backend
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def cfg_of(fix):
+    return type("Cfg", (mm.MGAFConfig,), {"point_cloud_range": tuple(float(v) for v in fix["point_cloud_range"]),
+                                          "voxel_size": tuple(float(v) for v in fix["voxel_size"])})
+
+
+def check_targets(dev):
+    fix = np.load(os.path.join(GOLD, "pyref_center_targets.npz"))
+    tg = mm.center_targets(torch.from_numpy(fix["gt_boxes"]).to(dev), cfg_of(fix), 3)
+    assert tuple(tg["hm_target"].shape) == fix["hm_target"].shape
+    assert np.array_equal(tg["ind_target"].cpu().numpy(), fix["ind_target"])
+    assert np.array_equal(tg["mask_target"].cpu().numpy(), fix["mask_target"])
+    assert np.array_equal(tg["xsys_target"].cpu().numpy(), fix["xsys_target"])
+    assert np.array_equal(tg["src_box_target"].cpu().numpy(), fix["src_box_target"])
+    # exp() of the two float64 libraries may differ in the last bit before the rounding to float32
+    assert np.abs(tg["hm_target"].cpu().numpy() - fix["hm_target"]).max() <= 1e-7
+    assert np.array_equal(tg["hm_target"].cpu().numpy() == 1, fix["hm_target"] == 1)          # the peaks the focal loss counts
+    assert np.abs(tg["anno_box_target"].cpu().numpy() - fix["anno_box_target"]).max() <= 1e-6
+    assert int(fix["mask_target"].sum()) == 22
+    return tg, fix
+
+
+def test_center_targets_equal_the_reference_assigner():
+    tg, fix = check_targets("cpu")
+    # segmentation map (unpinned: cv2 in the reference): every object's rounded centre pixel is foreground, the map is binary,
+    # and its area is within the footprint areas' sum (edge pixels add at most a one-pixel rim)
+    segm = tg["segm_target"][:, 0].numpy()
+    assert set(np.unique(segm)) <= {0.0, 1.0}
+    gt, mask = fix["gt_boxes"], fix["mask_target"]
+    for s in range(gt.shape[0]):
+        for k in range(mask.shape[1]):
+            if mask[s, k]:
+                x, y = fix["xsys_target"][s, k].astype(int)
+                assert segm[s, y, x] == 1.0
+        area = sum(float(gt[s, k, 3] * gt[s, k, 4]) / 0.16 for k in range(min(gt.shape[1], mask.shape[1])) if mask[s, k])   # 0.4 m pixels
+        rim = sum(2 * float(gt[s, k, 3] + gt[s, k, 4]) / 0.4 + 4 for k in range(min(gt.shape[1], mask.shape[1])) if mask[s, k])
+        assert 0 < segm[s].sum() <= area + rim
+
+
+def check_losses(dev, tol_loss, tol_grad):
+    fix = np.load(os.path.join(GOLD, "pyref_center_losses.npz"))
+    cfg = cfg_of(fix)
+    names = [n for n, _ in mm.MGAFConfig.heads]
+    preds = {n: torch.from_numpy(fix["pred_" + n]).to(dev).requires_grad_(True) for n in names}
+    tg = mm.center_targets(torch.from_numpy(fix["gt_boxes"]).to(dev), cfg, 3)
+    tg["segm_target"] = torch.from_numpy(fix["segm_target"]).to(dev)
+    loss, terms = mm.center_losses(preds, tg, cfg)
+    for n, v in terms.items():
+        want = float(fix["term_" + n])
+        assert abs(float(v.detach()) - want) <= tol_loss * max(1.0, abs(want)), (n, float(v.detach()), want)
+    assert abs(float(loss.detach()) - float(fix["loss"])) <= tol_loss * abs(float(fix["loss"]))
+    grads = torch.autograd.grad(loss, [preds[n] for n in names])
+    for n, g in zip(names, grads):
+        want = fix["grad_" + n]
+        err = np.linalg.norm(g.cpu().numpy().astype(np.float64) - want) / max(np.linalg.norm(want), 1e-12)
+        assert err <= tol_grad, (n, err)
+
+
+def test_center_losses_equal_the_reference_head():
+    with oracle_backend():
+        check_losses("cpu", 1e-5, 1e-5)
+
+
+@pytest.mark.gpu
+def test_center_targets_and_losses_on_the_gpu(gpu):
+    check_targets(gpu)
+    check_losses(gpu, 1e-5, 1e-4)
+
+
+class SmallMGAF(mm.MGAFConfig):
+    """Reduced step: quarter range (BEV map 48 x 44), the yaml's layer list with two convs per level instead of five."""
+    point_cloud_range = (0.0, -9.6, -3.0, 17.6, 9.6, 1.0)
+    grid_size = (352, 384, 40)
+    layer_nums = (2, 2, 2)
+
+
+def small_inputs():
+    import oracle
+    from fv2p_harness import synth
+    from fv2p_harness.backbone import mean_vfe
+    rng = np.array(SmallMGAF.point_cloud_range, np.float32)
+    feats, coords, boxes = [], [], []
+    for b in range(2):
+        pts, bx = synth.lidar_cloud(90 + b, 3000, pc_range=rng, return_boxes=True)
+        v, c, k = oracle.points_to_voxel(pts, synth.KITTI_VOXEL, rng, 5, 16000)
+        feats.append(mean_vfe(torch.from_numpy(v), torch.from_numpy(k)))
+        coords.append(torch.from_numpy(np.concatenate([np.full((c.shape[0], 1), b, np.int32), c], 1)))
+        boxes.append(bx)
+    g = max(len(b) for b in boxes)
+    gt = np.zeros((2, g, 8), np.float32)
+    for i, bx in enumerate(boxes):
+        gt[i, :len(bx), :7] = bx
+        gt[i, :len(bx), 7] = 1 + (np.arange(len(bx)) % 3)
+    return torch.cat(feats), torch.cat(coords), torch.from_numpy(gt)
+
+
+@pytest.mark.gpu
+def test_mgaf_step_matches_cpu_oracle(gpu):
+    """MGAFDetector (VoxelResBackBone8x, DCNBEVBackbone, CenterAFHead with the DCNv2 feature adaption, target assignment, eight
+    loss terms) forward + backward on the HIP ops against the same modules on the host: head maps 1e-4 (1e-3 through the 21-layer
+    sparse backbone and BatchNorm), loss terms 1e-3, every parameter gradient 2e-3 relative L2."""
+    from oracle.spconv_cpu import cpu_mirror
+    torch.manual_seed(0)
+    model = mm.MGAFDetector(SmallMGAF)
+    ref = cpu_mirror(model)
+    feats, coords, gt = small_inputs()
+    ref.taps = {}
+    with oracle_backend():
+        loss_c = ref(feats, coords, 2, gt)
+        loss_c.backward()
+    net = model.to(gpu)
+    net.taps = {}
+    loss_g = net(feats.to(gpu), coords.to(gpu), 2, gt.to(gpu))
+    loss_g.backward()
+    assert int(ref.taps["targets"]["mask_target"].sum()) > 0
+    for k in ("ind_target", "mask_target", "segm_target", "hm_target"):
+        assert torch.equal(net.taps["targets"][k].cpu(), ref.taps["targets"][k]), k
+    for name, want in ref.taps["preds"].items():
+        got = net.taps["preds"][name].detach().cpu()
+        assert float((got - want.detach()).abs().max()) <= 1e-3 * float(want.detach().abs().max()), name
+    for name, want in ref.taps["terms"].items():
+        assert abs(float(net.taps["terms"][name]) - float(want)) <= 1e-3 * max(1.0, abs(float(want))), name
+    gp = dict(net.named_parameters())
+    worst = ("", 0.0)
+    for name, p in ref.named_parameters():
+        if not p.requires_grad:          # the DCN layers' frozen bias (modules/modulated_deform_conv.py:38-41: added, never trained)
+            continue
+        assert p.grad is not None and gp[name].grad is not None, name
+        a, b = gp[name].grad.cpu().double(), p.grad.double()
+        err = float((a - b).norm() / b.norm().clamp_min(1e-12))
+        worst = max(worst, (name, err), key=lambda t: t[1])
+        assert err < (1e-2 if name == "backbone_3d.conv_input.0.weight" else 2e-3), (name, err)   # see tests/test_fv2p_step_gpu.py: FIRST_LAYER
+    print("worst MGAF gradient:", worst)
