@@ -705,6 +705,8 @@ def conv_kernel_name(cin, cout, n_dst=0):
     """The variant csrc/sparse_conv.hip dispatches for a whole-fragment forward conv of these channel counts (launch_vec)."""
     if cin in (64, 128) and cout % 64 == 0 and cout <= 128 and os.environ.get("FV2P_CONV_KSPLIT", "1") != "0":
         halves = ", two column halves per launch" if cout == 128 else ""
+        if os.environ.get("FV2P_CONV_PLAN", "1") != "0":
+            return f"conv_rows_ksplit<{cin},false,64>{halves}, group-balanced tiling plan (fv2p_conv_plan_build + fv2p_sparse_conv_rows)"
         return f"conv_rows_ksplit<{cin},false,{32 if n_dst < 65536 else 64}>{halves} (fv2p_sparse_conv_rows)"
     cinp = 16 if cin <= 16 else 32 if cin <= 32 else 64 if cin <= 64 else 128
     nb = (cout + 15) // 16

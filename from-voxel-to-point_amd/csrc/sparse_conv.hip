@@ -25,6 +25,15 @@ namespace fv2p {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// compile-time loop: f(std::integral_constant<int, A>{}), ..., f(std::integral_constant<int, B - 1>{})
+template <int A, int B, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (A < B) {
+    f(std::integral_constant<int, A>{});
+    static_for<A + 1, B>(f);
+  }
+}
+
 struct ConvArgs {
   const float* src; int ld_src; int c_src;          // c_src: valid source channels in this launch
   const float* w; long long w_kstride; int w_ld;     // W_k = w + k*w_kstride, row stride w_ld
@@ -696,7 +705,14 @@ __global__ __launch_bounds__(256) void conv_rows_act(ConvArgs a) {
         todo &= todo - 1;
         issue_w(k, lds + ((it + 1) & 1) * WSZ);
         idx_nxt = idx_lds[k * 64 + wave * 16 + r];
-        gather_async<J>(a_nxt, row_ptr(idx_nxt));
+        if constexpr (J < 8) gather_async<J>(a_nxt, row_ptr(idx_nxt));
+        else {
+          // 128 source channels: the compiler placed the a_cur = a_nxt copies ABOVE the hand-written wait (a copy of registers the loads
+          // had not reached; tools/check_async_asm.py) — plain tracked loads here (this shape runs only when the K-split tile is switched off)
+          const float* p = row_ptr(idx_nxt);
+#pragma unroll
+          for (int j = 0; j < J; ++j) a_nxt[j] = *reinterpret_cast<const f32x4*>(p + 16 * j);
+        }
       }
       if (__ballot(idx_cur >= 0) != 0ull) {
 #pragma unroll
@@ -731,12 +747,14 @@ __global__ __launch_bounds__(256) void conv_rows_act(ConvArgs a) {
         }
       }
       if (!more) break;
-      wait_loads<J>(a_nxt, idx_nxt);
+      if constexpr (J < 8) wait_loads<J>(a_nxt, idx_nxt);
+      else asm volatile("s_waitcnt vmcnt(0)" : : : "memory");   // the weights' LDS-DMA
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < J; ++j) a_cur[j] = a_nxt[j];
       idx_cur = idx_nxt;
     }
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");   // nothing in flight (the last round issued no loads): stated for tools/check_async_asm.py
   }
   // epilogue: accumulator i of lane (q, n) is output column  WT ? NB*n + i : 64*(i/4) + 4*n + i%4; rows through perm
   const int q = lane >> 4, n = lane & 15;
@@ -803,7 +821,7 @@ __global__ __launch_bounds__(256) void conv_rows_act(ConvArgs a) {
 //     measured 10x slower).  A row occurs once per offset and a wave's LDS operations execute in order, so every sum runs
 //     over ascending k: deterministic; the epilogue adds the four waves' partial sums in wave order.
 // LDS at TM = 64 rows per tile: 4 x 65 x 68 accumulators + the compacted table = 79 KB -> two workgroups per CU; TM = 32: 40 KB.
-template <int CINP, bool WT, int TM>
+template <int CINP, bool WT, int TM, int GPS = 1>
 __global__ __launch_bounds__(256) void conv_rows_ksplit(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int KS = CINP / 4;      // source channels per wave
@@ -838,7 +856,7 @@ __global__ __launch_bounds__(256) void conv_rows_ksplit(ConvArgs a) {
     }
   }
   a.c_dst = 64;
-  unsigned long long t_begin = 0, t_pro = 0, t_wait = 0, t_mark = 0;
+  unsigned long long t_begin = 0, t_pro = 0, t_wait = 0, t_mark = 0, t_issue = 0, t_comp = 0;
   if (a.trace) t_begin = __builtin_readcyclecounter();
   for (int row0 = r_begin; row0 < r_end; row0 += sub_rows) {
   const int row_end = min(row0 + sub_rows, r_end);
@@ -874,7 +892,6 @@ __global__ __launch_bounds__(256) void conv_rows_ksplit(ConvArgs a) {
   }
   __syncthreads();
   const int cntv = lane < a.kvol ? s_cnt[lane] : 0;   // lane k: pairs of offset k in this tile
-  unsigned long long todo = __ballot(cntv > 0);
   // per-lane byte offsets of the weight registers relative to W_k
   int boff[NBV];
 #pragma unroll
@@ -886,106 +903,120 @@ __global__ __launch_bounds__(256) void conv_rows_ksplit(ConvArgs a) {
   const long long src_col = KS * wave + 4 * g;
   float* my_acc = accl + wave * ROWS * LDR + g * 16;   // + row * LDR: this lane's 16 columns of a row (four 16-byte words)
 
-  struct Meta { int k, cnt; int idx[MAXG]; int row[MAXG]; };
-  // stage I: the slot lists of an offset (source row and tile row of slot 16 grp + (lane & 15))
-  auto read_meta = [&](Meta& m) {
+  // ---- the tile's work as a flat list of STEPS, one 16-slot row group of one offset each (offsets ascending, groups ascending) --------
+  // Round 2 walked the offsets and issued all loads of the next offset in one burst before the MFMA block.  Measured (round 3, trace of
+  // wave 0): that burst costs 285 clocks per group with one workgroup per CU and 900 - 1070 with two — the CU's single vector-memory
+  // address unit takes 16 clocks per dwordx4 wave instruction (64 B/clk), eight waves queue on it, and a wave that is stuck issuing
+  // loads issues no MFMA: the matrix pipes idled 43 % of the time at either occupancy.  Now every step has the same shape (the weight
+  // slice: NBV loads, one row group: JS loads), so its loads are spread over the MFMA block of the step before, one load behind each of
+  // the first MFMAs (32 clocks apart, twice the address unit's time per load): the queue never builds up and the pipes keep running.
+  // A second group of an offset reloads the offset's weights (L1 hits, +8 loads for ~1 step in 5).  Same shape for every step also
+  // means no conditional load: nothing for the register allocator to merge (tools/check_async_asm.py).
+  unsigned char* my_steps = reinterpret_cast<unsigned char*>(s_cnt + MAXK) + wave * 112;   // [wave][<= 27 * MAXG + 1] : k | first group << 5 | past-the-end << 7
+  // GPS row groups per step (template): 1 where an offset rarely has more than 16 pairs in a tile (the KITTI levels under a tiling
+  // plan), 2 for full 64-row tiles of dense levels (three groups per offset are the rule there: the weights are loaded once per two
+  // groups; an offset with an odd number of groups multiplies one group of zero rows)
+  int n_steps;
+  {
+    const int ns = (((cntv + 15) >> 4) + GPS - 1) / GPS;   // lane k: steps of offset k
+    int incl = ns;
 #pragma unroll
-    for (int grp = 0; grp < MAXG; ++grp) {
-      m.idx[grp] = s_idx[m.k * TM + grp * 16 + r];
-      m.row[grp] = s_row[m.k * TM + grp * 16 + r];
+    for (int d = 1; d < 32; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+    n_steps = __builtin_amdgcn_readlane(incl, 31);
+    const int first = incl - ns;
+    for (int gq = 0; gq < ns; ++gq) my_steps[first + gq] = static_cast<unsigned char>(lane | ((gq * GPS) << 5));
+    if (lane == 0) my_steps[n_steps] = 0x80;   // one step past the end (offset 0's weights, the zero row): loads that nobody uses
+  }
+  struct Step { int k, ng; int idx[GPS], row[GPS]; };   // ng: row groups of the step that hold pairs (uniform)
+  auto read_step = [&](int j, Step& m) {   // j <= n_steps
+    const int st = __builtin_amdgcn_readfirstlane(static_cast<int>(my_steps[j]));
+    m.k = st & 0x1f;
+    const int grp = (st >> 5) & 3;
+    const bool dummy = (st & 0x80) != 0;   // uniform
+    m.ng = dummy ? 0 : min(GPS, ((__builtin_amdgcn_readlane(cntv, m.k) + 15) >> 4) - grp);
+#pragma unroll
+    for (int u = 0; u < GPS; ++u) {
+      const bool none = dummy || grp + u >= MAXG;   // uniform; slots past the offset's pairs hold (-1, spare row) already
+      m.idx[u] = none ? -1 : s_idx[m.k * TM + (grp + u) * 16 + r];
+      m.row[u] = none ? TM : s_row[m.k * TM + (grp + u) * 16 + r];
     }
   };
-  // stage L: weights and gathered rows on their way
-  auto issue = [&](const Meta& m, f32x4 (&A)[MAXG][JS], f32x4 (&B)[NBV]) {
-    // plain loads: the compiler tracks them (vmcnt) and waits at their first use, the MFMA block of the NEXT stage — inline-asm
-    // loads with a hand-placed s_waitcnt (round 2) broke when the register allocator copied a destination register between the
-    // load and the wait (a copy of a register the data has not reached yet), which any change to the control flow can provoke
-    const char* wk = reinterpret_cast<const char*>(a.w + static_cast<long long>(m.k) * a.w_kstride);
-#pragma unroll
-    for (int u = 0; u < NBV; ++u) B[u] = *reinterpret_cast<const f32x4*>(wk + boff[u]);
-#pragma unroll
-    for (int grp = 0; grp < MAXG; ++grp) {
-      const int idx = m.idx[grp];   // groups past the offset's pairs read the zero row (padding slots): no branch, no undefined registers
-      const float* p = (grp * 16 < m.cnt && idx >= 0) ? a.src + static_cast<long long>(idx) * a.ld_src + src_col : zero_row;
-#pragma unroll
-      for (int jj = 0; jj < JS; ++jj) A[grp][jj] = *reinterpret_cast<const f32x4*>(p + 16 * jj);
+  constexpr int NLOAD = NBV + GPS * JS;
+  // load number q of a step: the weight registers first, then the row pieces
+  auto load_one = [&](auto q_, const Step& m, f32x4 (&A)[GPS][JS], f32x4 (&B)[NBV]) {
+    constexpr int q = decltype(q_)::value;
+    if constexpr (q < NBV) {
+      const float* wk = a.w + static_cast<long long>(m.k) * a.w_kstride;
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(B[q]) : "v"(boff[q]), "s"(wk) : "memory");
+    } else if constexpr (q < NLOAD) {
+      constexpr int u = (q - NBV) / JS, jj = (q - NBV) % JS;
+      const float* p = m.idx[u] >= 0 ? a.src + static_cast<long long>(m.idx[u]) * a.ld_src + src_col : zero_row;
+      load16_at<64 * jj>(A[u][jj], p);
     }
   };
-  auto wait = [&](f32x4 (&A)[MAXG][JS], f32x4 (&B)[NBV]) {};
-  // stage C: acc[i][reg] of lane (g, r) is column 16 g + 4 reg + i of the group's slot r.  One straight-line body per group
-  // count (no branch between the groups of an offset): the next group's accumulator reads sit above this group's MFMAs
-  auto groups = [&](auto ng_, const Meta& m, const f32x4 (&A)[MAXG][JS], const f32x4 (&B)[NBV]) {
-    constexpr int NG = decltype(ng_)::value;
-    f32x4 c[NG][4];
-    f32x4* p[NG];
+  auto issue_all = [&](const Step& m, f32x4 (&A)[GPS][JS], f32x4 (&B)[NBV]) {
+    static_for<0, NLOAD>([&](auto q) { load_one(q, m, A, B); });
+  };
+  auto wait = [&](f32x4 (&A)[GPS][JS], f32x4 (&B)[NBV]) {
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
 #pragma unroll
-    for (int grp = 0; grp < NG; ++grp) p[grp] = reinterpret_cast<f32x4*>(my_acc + m.row[grp] * LDR);
+    for (int u = 0; u < GPS; ++u)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) c[0][i] = p[0][i];
+      for (int jj = 0; jj < JS; ++jj) asm volatile("" : "+v"(A[u][jj]));
 #pragma unroll
-    for (int grp = 0; grp < NG; ++grp) {
-      if (grp + 1 < NG) {
+    for (int u = 0; u < NBV; ++u) asm volatile("" : "+v"(B[u]));
+  };
+  // one step: per group the accumulators of its 16 slots from LDS, JS * 16 MFMAs, accumulators back; the loads of step `nxt` sit
+  // behind the first MFMAs.  acc[i] of lane (g, r) is column 16 g + 4 reg + i of slot r
+  auto compute = [&](const Step& m, const f32x4 (&A)[GPS][JS], const f32x4 (&B)[NBV], const Step& nxt, f32x4 (&An)[GPS][JS], f32x4 (&Bn)[NBV]) {
+    constexpr int QUADS = JS * 4;                                  // blocks of four MFMAs (128 clocks of matrix pipe) of one group
+    constexpr int LPQ = (NLOAD + QUADS - 2) / (QUADS - 1);         // loads behind each block of the FIRST group (always multiplied): every
+    static_for<0, GPS>([&](auto u_) {                              // load of the next step is issued whatever this step's group count
+      constexpr int u = decltype(u_)::value;
+      if (u == 0 || u < m.ng) {   // uniform: a step's later groups exist for offsets with more than 16 u pairs only
+        f32x4* p = reinterpret_cast<f32x4*>(my_acc + m.row[u] * LDR);
+        f32x4 c[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) c[grp + 1 < NG ? grp + 1 : grp][i] = p[grp + 1 < NG ? grp + 1 : grp][i];
-      }
-#pragma unroll
-      for (int jj = 0; jj < JS; ++jj)
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int i = 0; i < 4; ++i) c[i] = p[i];
+        static_for<0, JS * 4>([&](auto q_) {
+          constexpr int q = decltype(q_)::value, jj = q / 4, t = q % 4;
 #pragma unroll
           for (int i = 0; i < 4; ++i)
-            c[grp][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(WT ? B[jj * 4 + i][t] : B[jj * 4 + t][i], A[grp][jj][t], c[grp][i], 0, 0, 0);
+            c[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(WT ? B[jj * 4 + i][t] : B[jj * 4 + t][i], A[u][jj][t], c[i], 0, 0, 0);
+          if constexpr (u == 0)
+            static_for<0, LPQ>([&](auto v_) { load_one(std::integral_constant<int, q * LPQ + decltype(v_)::value>{}, nxt, An, Bn); });
+        });
 #pragma unroll
-      for (int i = 0; i < 4; ++i) p[grp][i] = c[grp][i];
-    }
-  };
-  auto compute = [&](const Meta& m, const f32x4 (&A)[MAXG][JS], const f32x4 (&B)[NBV]) {
-    const int ng = (m.cnt + 15) >> 4;   // uniform
-    if constexpr (MAXG == 2) {
-      if (ng == 1) groups(std::integral_constant<int, 1>{}, m, A, B);
-      else groups(std::integral_constant<int, 2>{}, m, A, B);
-    } else {
-      if (ng == 1) groups(std::integral_constant<int, 1>{}, m, A, B);
-      else if (ng == 2) groups(std::integral_constant<int, 2>{}, m, A, B);
-      else if (ng == 3) groups(std::integral_constant<int, 3>{}, m, A, B);
-      else groups(std::integral_constant<int, 4>{}, m, A, B);
-    }
-  };
-  auto next_offset = [&](Meta& m) {   // pops the next non-empty offset; cnt = 0 when there is none
-    if (todo) {
-      m.k = __builtin_ctzll(todo);
-      m.cnt = __builtin_amdgcn_readlane(cntv, m.k);
-      todo &= todo - 1;
-    } else {
-      m.k = 0; m.cnt = 0;
-    }
+        for (int i = 0; i < 4; ++i) p[i] = c[i];
+      }
+    });
+    static_assert(LPQ * QUADS >= NLOAD, "every load of the next step must be issued inside the first group's block");
   };
   if (a.trace) t_pro = __builtin_readcyclecounter();
-  if (todo) {
-    f32x4 A0[MAXG][JS], B0[NBV], A1[MAXG][JS], B1[NBV];
-    Meta m0, m1, m2;   // m0: multiplying, m1: loads in flight, m2: slot lists being read
-    next_offset(m0); read_meta(m0);
-    next_offset(m1); if (m1.cnt) read_meta(m1);
-    issue(m0, A0, B0);
-    while (true) {
-      next_offset(m2); if (m2.cnt) read_meta(m2);
+  if (n_steps > 0) {
+    f32x4 A0[GPS][JS], B0[NBV], A1[GPS][JS], B1[NBV];
+    Step m0, m1;
+    read_step(0, m0);
+    issue_all(m0, A0, B0);
+    read_step(1, m1);
+    for (int j = 0; j < n_steps; j += 2) {
       if (a.trace) t_mark = __builtin_readcyclecounter();
       wait(A0, B0);
-      if (a.trace) t_wait += __builtin_readcyclecounter() - t_mark;
-      if (m1.cnt) issue(m1, A1, B1);
-      compute(m0, A0, B0);
-      if (!m1.cnt) break;
-      next_offset(m0); if (m0.cnt) read_meta(m0);
+      if (a.trace) { const unsigned long long t = __builtin_readcyclecounter(); t_wait += t - t_mark; t_mark = t; }
+      compute(m0, A0, B0, m1, A1, B1);
+      if (a.trace) t_comp += __builtin_readcyclecounter() - t_mark;
+      if (j + 1 >= n_steps) break;
+      read_step(j + 2 <= n_steps ? j + 2 : n_steps, m0);
       if (a.trace) t_mark = __builtin_readcyclecounter();
       wait(A1, B1);
-      if (a.trace) t_wait += __builtin_readcyclecounter() - t_mark;
-      if (m2.cnt) issue(m2, A0, B0);
-      compute(m1, A1, B1);
-      if (!m2.cnt) break;
-      // rotate: (m2 -> multiplying next with A0/B0, m0 -> loads next)
-      m1 = m0; m0 = m2;
+      if (a.trace) { const unsigned long long t = __builtin_readcyclecounter(); t_wait += t - t_mark; t_mark = t; }
+      compute(m1, A1, B1, m0, A0, B0);
+      if (a.trace) t_comp += __builtin_readcyclecounter() - t_mark;
+      read_step(j + 3 <= n_steps ? j + 3 : n_steps, m1);
     }
   }
+  // the loads of the step past the end (issued during the last step, used by nobody) are drained before their registers are reused
+  asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
   if (a.trace && tid == 0) {   // the trace buffer has 4 records per 64 rows: every workgroup of a <= 2 x 2 split launch
     const int rec = blockIdx.y * gridDim.x + blockIdx.x;
     if (rec < 4 * ((a.n_dst + 63) / 64)) {
@@ -998,6 +1029,8 @@ __global__ __launch_bounds__(256) void conv_rows_ksplit(ConvArgs a) {
       a.trace[rec * 8 + 3] = __builtin_readcyclecounter();
       a.trace[rec * 8 + 4] = t_pro;
       a.trace[rec * 8 + 5] = t_wait;   // clocks wave 0 spent waiting for the prefetched rows and weights
+      a.trace[rec * 8 + 6] = t_issue;  // ... issuing the next offset's loads
+      a.trace[rec * 8 + 7] = t_comp;   // ... in the accumulator read / MFMA / accumulator write blocks
     }
   }
   __syncthreads();
@@ -1585,6 +1618,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ pa
 static int g_conv_impl = -1;
 static int g_ksplit_auto = 1;   // FV2P_CONV_KSPLIT=0 keeps the round-1 kernels in auto mode (comparison runs)
 static int g_ksplit_tm = 0;     // FV2P_KSPLIT_TM: rows per tile (32 or 64); 0 = by launch shape
+static int g_ksplit_gps = 0;    // FV2P_KSPLIT_GPS=1: one row group per step at every size (comparison runs)
 static size_t g_ksplit_pad = 0; // FV2P_KSPLIT_PAD: extra dynamic LDS bytes per workgroup (limits the workgroups resident on a CU)
 static int g_wgrad_dma = 1;   // pair-split weight gradient: 1 = LDS-DMA kernel where the shapes allow, 0 = register-staged kernel
 static unsigned long long* g_conv_trace = nullptr;
@@ -1596,6 +1630,8 @@ static int conv_impl() {
     g_ksplit_auto = ks ? atoi(ks) : 1;
     const char* tm = getenv("FV2P_KSPLIT_TM");
     g_ksplit_tm = tm ? atoi(tm) : 0;
+    const char* gps = getenv("FV2P_KSPLIT_GPS");
+    g_ksplit_gps = gps ? atoi(gps) : 0;
     const char* pad = getenv("FV2P_KSPLIT_PAD");
     g_ksplit_pad = pad ? static_cast<size_t>(atoi(pad)) : 0;
   }
@@ -1631,7 +1667,7 @@ static int plan_pick_level(int64_t n_dst, int col_blocks) {
     const char* e = getenv("FV2P_CONV_PLAN"); g_plan_on = e ? atoi(e) : 1;
     const char* r = getenv("FV2P_PLAN_ROWS"); g_plan_rows = r ? atoi(r) : 0;
   }
-  if (!g_plan_on) return -1;
+  if (!g_plan_on || n_dst > 65536) return -1;   // beyond ~1000 tiles the dispatcher balances by itself; full 64-row tiles reload the fewest weights
   const double rows = g_plan_rows > 0 ? g_plan_rows : 44.0;
   double want = static_cast<double>(n_dst) / rows;
   if (want * col_blocks < 512.0) want = 512.0 / col_blocks;
@@ -1644,7 +1680,7 @@ static int plan_pick_level(int64_t n_dst, int col_blocks) {
   return best;
 }
 
-static constexpr size_t ksplit_lds(int tm) { return 4 * static_cast<size_t>(tm + 1) * 68 * sizeof(float) + 32 * tm * sizeof(int) + 32 * tm + 32 * sizeof(int); }
+static constexpr size_t ksplit_lds(int tm) { return 4 * static_cast<size_t>(tm + 1) * 68 * sizeof(float) + 32 * tm * sizeof(int) + 32 * tm + 32 * sizeof(int) + 4 * 112; }
 // impl 4 forces the pair-compacted K-split tile wherever its shapes allow.  In auto mode it takes every launch with 64 or 128
 // source channels and whole 64-column blocks (measured against conv_rows_dma, profiles/r02_microbench.txt: 128 -> 128 at
 // 9 919 rows 127 -> 77 us, 64 -> 64 at 22 331 rows 66 -> 54 us, at 141 294 rows 264 -> 232 us), except permuted launches with
@@ -1682,22 +1718,26 @@ static void launch_vec(const ConvArgs& a, hipStream_t s) {
     if (whole && a.kvol <= 32 && ksplit_wanted<CINP>(a)) {
       ConvArgs b = a; b.trace = g_conv_trace;
       const int level = a.plan ? plan_pick_level(a.n_dst, NB / 4) : -1;   // a.plan: the plan header behind the table
-      b.plan = nullptr;
-      if (level >= 0) {
-        b.plan = a.plan + plan_level_offset(level);
-        const size_t lds = ksplit_lds(64) + g_ksplit_pad;
-        static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_ksplit<CINP, WT, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
-        if (once) { hipLaunchKernelGGL((conv_rows_ksplit<CINP, WT, 64>), dim3(static_cast<unsigned>(plan_tiles(level)), NB / 4), dim3(256), lds, s, b); return; }
-        b.plan = nullptr;
+      b.plan = level >= 0 ? a.plan + plan_level_offset(level) : nullptr;
+      const unsigned tiles = level >= 0 ? static_cast<unsigned>(plan_tiles(level)) : 0u;
+      // row groups per step (FV2P_KSPLIT_GPS=2: two, the second multiplied only where it holds pairs)
+      const int gps = g_ksplit_gps == 2 ? 2 : 1;   // measured: two groups per step gain nothing at either size (KITTI 55 vs 53 us, Waymo 254 vs 256): opt-in
+      const size_t lds64 = ksplit_lds(64) + g_ksplit_pad;
+      if (level >= 0 || ksplit_rows<WT>(a) == 64) {
+        const dim3 grid(level >= 0 ? tiles : blocks, NB / 4);
+        if (gps == 2) {
+          static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_ksplit<CINP, WT, 64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
+          if (once) { hipLaunchKernelGGL((conv_rows_ksplit<CINP, WT, 64, 2>), grid, dim3(256), lds64, s, b); return; }
+        } else {
+          static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_ksplit<CINP, WT, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
+          if (once) { hipLaunchKernelGGL((conv_rows_ksplit<CINP, WT, 64>), grid, dim3(256), lds64, s, b); return; }
+        }
       }
-      if (ksplit_rows<WT>(a) == 32) {
+      b.plan = nullptr;
+      {
         const size_t lds = ksplit_lds(32) + g_ksplit_pad;
         static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_ksplit<CINP, WT, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
         if (once) { hipLaunchKernelGGL((conv_rows_ksplit<CINP, WT, 32>), dim3(static_cast<unsigned>(ceil_div(a.n_dst, 32)), NB / 4), dim3(256), lds, s, b); return; }
-      } else {
-        const size_t lds = ksplit_lds(64) + g_ksplit_pad;
-        static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_ksplit<CINP, WT, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
-        if (once) { hipLaunchKernelGGL((conv_rows_ksplit<CINP, WT, 64>), dim3(blocks, NB / 4), dim3(256), lds, s, b); return; }
       }
     }
   }
@@ -1779,6 +1819,96 @@ static int dispatch_conv(const ConvArgs& a, hipStream_t s) {
 #undef FV2P_VEC_CASE
 #undef FV2P_SCALAR_CASE
   return 0;
+}
+
+// ---- exact plan for tables of <= kPlanExactRows rows ------------------------------------------------------------------------------
+// A tile's time is its number of MFMA row groups, sum_k ceil(pairs_k / 16) (measured: correlation 0.92, 3.5 k clocks per group at 128
+// channels), and equal PAIRS do not mean equal groups: a planar neighbourhood has 9 busy offsets, a full 3-D one 27, so equal-cost
+// tiles of the res4 level span 23 .. 45 groups.  Here the bounds come from the groups themselves: for a budget G, reach_G(s) = the
+// longest run of rows from s (at most 64) whose groups stay <= G; greedy tiles s -> s + reach_G(s) are the fewest tiles of cost <= G
+// (the cost of a run only grows with its length).  All starts in parallel for 16 budgets at once, one workgroup per budget walks
+// its chain in LDS (pointer doubling, then 8 steps per anchor), and every level takes the smallest budget whose tile count fits:
+// 28 .. 36 groups per tile instead of 23 .. 45.
+constexpr int kPlanExactRows = 32767;
+constexpr int kPlanBudgets = 16;
+__constant__ int c_plan_budget[kPlanBudgets] = {28, 30, 32, 34, 36, 38, 40, 42, 44, 46, 48, 52, 56, 60, 64, 72};
+constexpr unsigned long long kPlanOnes = 0x0102040810204081ull;   // 9 fields of 7 bits
+
+// three 64-bit words per row: offset k counts in field k % 9 of word k / 9
+__global__ __launch_bounds__(256) void plan_rowwords_k(const int* __restrict__ tab, int kvol, int n_dst, unsigned long long* __restrict__ words) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= n_dst) return;
+  unsigned long long w[3] = {0ull, 0ull, 0ull};
+  for (int k = 0; k < kvol; ++k)
+    if (tab[static_cast<long long>(k) * n_dst + row] >= 0) w[k / 9] |= 1ull << (7 * (k % 9));
+  words[row] = w[0]; words[n_dst + row] = w[1]; words[2 * static_cast<long long>(n_dst) + row] = w[2];
+}
+__device__ __forceinline__ int plan_groups(unsigned long long c) {   // sum over the 9 fields of ceil(count / 16), counts <= 64
+  const unsigned long long g = ((c + 15ull * kPlanOnes) >> 4) & (7ull * kPlanOnes);
+  return static_cast<int>((g * kPlanOnes) >> 56) & 0x7f;
+}
+__global__ __launch_bounds__(256) void plan_reach_k(const unsigned long long* __restrict__ words, int n_dst, unsigned char* __restrict__ reach) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= n_dst) return;
+  unsigned long long c0 = 0ull, c1 = 0ull, c2 = 0ull;
+  const int end = min(n_dst, s + 64);
+  int j = 0, r = s;
+  for (; r < end && j < kPlanBudgets; ++r) {
+    c0 += words[r]; c1 += words[n_dst + r]; c2 += words[2 * static_cast<long long>(n_dst) + r];
+    const int g = plan_groups(c0) + plan_groups(c1) + plan_groups(c2);
+    while (j < kPlanBudgets && g > c_plan_budget[j]) {   // rows s .. r - 1 fit budget j, row r does not
+      reach[static_cast<long long>(j) * n_dst + s] = static_cast<unsigned char>(max(r - s, 1));
+      ++j;
+    }
+  }
+  for (; j < kPlanBudgets; ++j) reach[static_cast<long long>(j) * n_dst + s] = static_cast<unsigned char>(end - s);
+}
+// one workgroup per budget: tile starts 0, 0 + reach(0), ... -> walk[j][t], count[j]
+__global__ __launch_bounds__(1024) void plan_walk_k(const unsigned char* __restrict__ reach, int n_dst, int* __restrict__ walk, int* __restrict__ count) {
+  extern __shared__ unsigned short plan_lds[];
+  unsigned short* A = plan_lds;                  // [n + 1]
+  unsigned short* B = plan_lds + (n_dst + 1);    // [n + 1]
+  const int j = blockIdx.x, tid = threadIdx.x;
+  const unsigned char* rj = reach + static_cast<long long>(j) * n_dst;
+  int* wj = walk + static_cast<long long>(j) * n_dst;
+  for (int s = tid; s <= n_dst; s += 1024) A[s] = static_cast<unsigned short>(s < n_dst ? min(s + rj[s], n_dst) : n_dst);
+  __syncthreads();
+  for (int s = tid; s <= n_dst; s += 1024) B[s] = A[A[s]];   // 2 steps
+  __syncthreads();
+  for (int s = tid; s <= n_dst; s += 1024) A[s] = B[B[s]];   // 4 steps
+  __syncthreads();
+  for (int s = tid; s <= n_dst; s += 1024) B[s] = A[A[s]];   // 8 steps
+  __syncthreads();
+  __shared__ int n_anchor;
+  if (tid == 0) {   // anchors: every 8th tile start, kept in A (no longer needed)
+    int p = 0, a = 0;
+    while (p < n_dst) { A[a++] = static_cast<unsigned short>(p); p = B[p]; }
+    n_anchor = a;
+  }
+  __syncthreads();
+  const int na = n_anchor;
+  for (int a = tid; a < na; a += 1024) {
+    int p = A[a], i = 0;
+    for (; i < 8 && p < n_dst; ++i) { wj[8 * a + i] = p; p = min(p + rj[p], n_dst); }
+    if (a == na - 1) count[j] = 8 * a + i;
+  }
+}
+// per level: the smallest budget whose tiles fit the level's tile count replaces the equal-cost bounds
+__global__ __launch_bounds__(256) void plan_select_k(const int* __restrict__ walk, const int* __restrict__ count, int n_dst, int levels, int* __restrict__ plan) {
+  const long long e = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  long long base = 0;
+  for (int l = 0; l < levels; ++l) {
+    const int tiles = ((l & 1) ? 384 : 256) << (l >> 1);
+    if (e < base + tiles + 1) {
+      const int t = static_cast<int>(e - base);
+      int pick = -1;
+      for (int j = 0; j < kPlanBudgets; ++j)
+        if (count[j] <= tiles) { pick = j; break; }
+      if (pick >= 0) plan[2 + e] = (t < count[pick]) ? walk[static_cast<long long>(pick) * n_dst + t] : n_dst;
+      return;
+    }
+    base += tiles + 1;
+  }
 }
 
 // cost(row) = max(pairs of the row, kPlanFloor): one thread per destination row, coalesced over the rows of every offset
@@ -1892,7 +2022,11 @@ extern "C" int64_t fv2p_conv_plan_ints(int64_t n_dst) {
 
 extern "C" size_t fv2p_conv_plan_ws_bytes(int64_t n_dst) {
   const int64_t n = n_dst > 0 ? n_dst : 1;
-  return align_up(static_cast<size_t>(n) * sizeof(int)) + align_up(static_cast<size_t>(n) * sizeof(int)) + align_up(sizeof(int)) + align_up(scan_ws_bytes(n));
+  size_t b = align_up(static_cast<size_t>(n) * sizeof(int)) + align_up(static_cast<size_t>(n) * sizeof(int)) + align_up(sizeof(int)) + align_up(scan_ws_bytes(n));
+  if (n <= kPlanExactRows)   // row words, reach bytes, walks and counts of the exact plan
+    b += align_up(3 * static_cast<size_t>(n) * sizeof(unsigned long long)) + align_up(static_cast<size_t>(kPlanBudgets) * n) +
+         align_up(static_cast<size_t>(kPlanBudgets) * n * sizeof(int)) + align_up(kPlanBudgets * sizeof(int));
+  return b;
 }
 
 extern "C" int fv2p_conv_plan_build(int* tab, int kvol, int64_t n_dst, void* ws, size_t ws_bytes, fv2p_stream_t stream_) {
@@ -1913,8 +2047,25 @@ extern "C" int fv2p_conv_plan_build(int* tab, int kvol, int64_t n_dst, void* ws,
   if (int rc = exclusive_scan_i32(cost, prefix, n_dst, total, sws, sb, stream)) return rc;
   const int levels = plan_levels(n_dst);
   const int64_t entries = plan_level_offset(levels) - 2;
-  hipLaunchKernelGGL(plan_bounds_k, dim3(static_cast<unsigned>(ceil_div(entries, 256))), dim3(256), 0, stream, prefix, total, n, levels,
-                     tab + static_cast<long long>(kvol) * n_dst);
+  int* plan = tab + static_cast<long long>(kvol) * n_dst;
+  hipLaunchKernelGGL(plan_bounds_k, dim3(static_cast<unsigned>(ceil_div(entries, 256))), dim3(256), 0, stream, prefix, total, n, levels, plan);
+  static int exact = -1;   // FV2P_PLAN_EXACT=0 keeps the equal-cost bounds (comparison runs)
+  if (exact < 0) { const char* e = getenv("FV2P_PLAN_EXACT"); exact = e ? atoi(e) : 1; }
+  if (exact && kvol >= 8 && kvol <= 27 && n_dst >= 1024 && n_dst <= kPlanExactRows) {
+    unsigned long long* words = c.take<unsigned long long>(3 * static_cast<size_t>(n_dst));
+    unsigned char* reach = c.take<unsigned char>(static_cast<size_t>(kPlanBudgets) * n_dst);
+    int* walk = c.take<int>(static_cast<size_t>(kPlanBudgets) * n_dst);
+    int* count = c.take<int>(kPlanBudgets);
+    const unsigned blocks = static_cast<unsigned>(ceil_div(n_dst, 256));
+    hipLaunchKernelGGL(plan_rowwords_k, dim3(blocks), dim3(256), 0, stream, tab, kvol, n, words);
+    hipLaunchKernelGGL(plan_reach_k, dim3(blocks), dim3(256), 0, stream, words, n, reach);
+    const size_t lds = 2 * static_cast<size_t>(n_dst + 1) * sizeof(unsigned short);
+    static bool big = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&plan_walk_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) == hipSuccess; }();
+    if (big || lds <= 48 * 1024) {
+      hipLaunchKernelGGL(plan_walk_k, dim3(kPlanBudgets), dim3(1024), lds, stream, reach, n, walk, count);
+      hipLaunchKernelGGL(plan_select_k, dim3(static_cast<unsigned>(ceil_div(entries, 256))), dim3(256), 0, stream, walk, count, n, levels, plan);
+    }
+  }
   FV2P_LAUNCH_CHECK();
   return 0;
 }

@@ -316,6 +316,17 @@ struct SparseConvFn : public torch::autograd::Function<SparseConvFn> {
     }
     if (ctx->needs_input_grad(0)) {
       din = at::empty_like(features);
+      // backward data = a conv with W_k^T.  For the shapes of the K-split tile (64 / 128 gradient channels) the transposed slices are
+      // materialised once ([K][Cout][Cin], one small copy kernel) and the conv reads them as a plain weight: reading W_k transposed in
+      // place gathers 64-byte pieces of 16 rows per load — half of every cache line fetched is thrown away, and the K-split tile is bound
+      // by exactly that traffic (measured: subm 128->128 backward data 85 -> 56 us)
+      at::Tensor wt;
+      int transpose_w = 1;
+      if ((cout == 64 || cout == 128) && cin % 64 == 0 && cin <= 128 && kvol > 1) {
+        wt = weight.view({kvol, cin, cout}).transpose(1, 2).contiguous();
+        transpose_w = 0;
+      }
+      const float* w_bwd = wt.defined() ? wt.data_ptr<float>() : weight.data_ptr<float>();
       auto* bn_node = reinterpret_cast<torch::autograd::CppNode<BnReluFn>*>(ctx->saved_data["bn_node"].toInt());
       bool fused = false;
       if (bn_node && fuse_bn_stats() && cout <= 128 && cin <= 1024) {
@@ -327,8 +338,8 @@ struct SparseConvFn : public torch::autograd::Function<SparseConvFn> {
           const auto bsaved = bctx.get_saved_variables();   // x, mean, invstd, weight, bias of the BatchNorm
           const at::Tensor &bx = bsaved[0], &bmean = bsaved[1], &binv = bsaved[2], &bw = bsaved[3], &bb = bsaved[4];
           if (bx.defined() && bx.sizes() == din.sizes() && bx.is_contiguous()) {
-            check(fv2p_sparse_conv_rows_bnbwd(g.data_ptr<float>(), g.size(0), static_cast<int>(cout), weight.data_ptr<float>(), static_cast<int>(kvol),
-                                              tab_b.data_ptr<int>(), features.size(0), static_cast<int>(cin), flip_b, 1, din.data_ptr<float>(),
+            check(fv2p_sparse_conv_rows_bnbwd(g.data_ptr<float>(), g.size(0), static_cast<int>(cout), w_bwd, static_cast<int>(kvol),
+                                              tab_b.data_ptr<int>(), features.size(0), static_cast<int>(cin), flip_b, transpose_w, din.data_ptr<float>(),
                                               bx.data_ptr<float>(), bmean.data_ptr<float>(), binv.data_ptr<float>(),
                                               bw.defined() ? bw.data_ptr<float>() : nullptr, bb.defined() ? bb.data_ptr<float>() : nullptr,
                                               bctx.saved_data["relu"].toBool() ? 1 : 0, ring.buf[b].data_ptr<double>(), perm_b, stream),
@@ -344,8 +355,8 @@ struct SparseConvFn : public torch::autograd::Function<SparseConvFn> {
         }
       }
       if (!fused)
-        check(fv2p_sparse_conv_rows_perm(g.data_ptr<float>(), g.size(0), static_cast<int>(cout), weight.data_ptr<float>(), static_cast<int>(kvol),
-                                         tab_b.data_ptr<int>(), features.size(0), static_cast<int>(cin), flip_b, 1, nullptr, din.data_ptr<float>(),
+        check(fv2p_sparse_conv_rows_perm(g.data_ptr<float>(), g.size(0), static_cast<int>(cout), w_bwd, static_cast<int>(kvol),
+                                         tab_b.data_ptr<int>(), features.size(0), static_cast<int>(cin), flip_b, transpose_w, nullptr, din.data_ptr<float>(),
                                          perm_b, stream),
               "fv2p_sparse_conv_rows (backward data)");
     }

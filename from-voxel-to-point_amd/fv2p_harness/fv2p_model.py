@@ -455,7 +455,8 @@ class LateralBlock(nn.Module):
         centres = (idx[:, 1:4].flip(-1).float() + 0.5) * vs + dconst(idx, tuple(float(v) for v in cfg.point_cloud_range[:3]))
         # rows of a level are grouped by sample; counted without torch.bincount, which reads the maximum back to the host
         vox_cnt = (idx[:, 0:1] == torch.arange(key_cnt.shape[0], device=idx.device, dtype=idx.dtype)).sum(0, dtype=torch.int32)
-        dist, nn_idx = pn2_stack.three_nn(key_xyz, key_cnt, centres.contiguous(), vox_cnt)
+        # the known points are voxel centres of pitch vs: a grid of two pitches per cell holds <= 8 of them per cell
+        dist, nn_idx = pn2_stack.three_nn(key_xyz, key_cnt, centres.contiguous(), vox_cnt, 2.0 * float(cfg.voxel_size[0]) * self.stride)
         recip = 1.0 / (dist + 1e-8)
         weight = recip / recip.sum(dim=1, keepdim=True)
         lateral = pn2_stack.three_interpolate(level.features, nn_idx, weight)

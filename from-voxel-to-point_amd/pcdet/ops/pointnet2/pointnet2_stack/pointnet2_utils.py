@@ -1,6 +1,8 @@
 """Stacked-batch pointnet2 operators behind the names of the reference's
 pcdet/ops/pointnet2/pointnet2_stack/pointnet2_utils.py:8-262.  Rows of all samples are concatenated; `*_batch_cnt`
 (int32 [B]) holds the rows per sample.  Forward / backward function pairs on the C ABI (pcdet/ops/_glue.py)."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -52,14 +54,25 @@ def _fps(saved, xyz, npoint):
     return idx
 
 
-def _three_nn(saved, unknown, unknown_batch_cnt, known, known_batch_cnt):
-    """unknown (N, 3), known (M, 3) -> (distances (N, 3), GLOBAL rows into known (N, 3))."""
+GRID_MIN_KNOWN = 1024     # below this the tiled scan is as fast as building a grid
+
+
+def _three_nn(saved, unknown, unknown_batch_cnt, known, known_batch_cnt, cell=None):
+    """unknown (N, 3), known (M, 3) -> (distances (N, 3), GLOBAL rows into known (N, 3)).
+    cell (optional, not in the reference's signature): spacing hint for the grid search (fv2p_three_nn_stack_grid) that answers
+    large known sets — same result as the scan, bit for bit; None lets the library estimate it."""
     if unknown.dim() != 2 or unknown.shape[1] != 3 or known.dim() != 2 or known.shape[1] != 3 or len(unknown_batch_cnt) != len(known_batch_cnt):
         raise AssertionError("three_nn (stack): expects (N, 3) / (M, 3) and one count per sample on both sides")
     d2 = torch.zeros_like(unknown)
     idx = torch.zeros(unknown.shape, dtype=torch.int32, device=unknown.device)
-    G.run("fv2p_three_nn_stack", len(unknown_batch_cnt), unknown.shape[0], known.shape[0], unknown.contiguous(), _cnt(unknown_batch_cnt),
-          known.contiguous(), _cnt(known_batch_cnt), d2, idx)
+    nb = len(unknown_batch_cnt)
+    if known.shape[0] >= GRID_MIN_KNOWN and nb <= 64 and os.environ.get("FV2P_NN_GRID", "1") != "0":
+        ws = G.scratch("fv2p_three_nn_grid_ws_bytes", unknown.device, nb, known.shape[0])
+        G.run("fv2p_three_nn_stack_grid", nb, unknown.shape[0], known.shape[0], unknown.contiguous(), _cnt(unknown_batch_cnt),
+              known.contiguous(), _cnt(known_batch_cnt), float(cell) if cell else 0.0, d2, idx, ws, ws.numel())
+    else:
+        G.run("fv2p_three_nn_stack", nb, unknown.shape[0], known.shape[0], unknown.contiguous(), _cnt(unknown_batch_cnt),
+              known.contiguous(), _cnt(known_batch_cnt), d2, idx)
     return d2.sqrt(), idx
 
 

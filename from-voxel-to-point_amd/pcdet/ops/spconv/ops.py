@@ -355,7 +355,11 @@ def indice_conv_backward(features, filters, out_bp, indice_pairs, indice_pair_nu
     kvol = w.shape[0]
     # forward used table F (dst rows = outputs); its transpose-direction table B has dst rows = inputs
     (tab_f, flip_f), (tab_b, flip_b) = (rb.in_table(), rb.out_table(cout)) if inverse else (rb.out_table(), rb.in_table(cout))
-    din = _conv_rows(g, w, tab_b, flip_b, features.shape[0], cin, True)
+    if cout in _PLAN_CHANNELS and cin % 64 == 0 and cin <= 128 and kvol > 1:
+        # the K-split tile's shapes: W_k^T materialised once and read as a plain weight (csrc_torch/fv2p_torch.cpp has the measurement)
+        din = _conv_rows(g, w.transpose(1, 2).contiguous(), tab_b, flip_b, features.shape[0], cin, False)
+    else:
+        din = _conv_rows(g, w, tab_b, flip_b, features.shape[0], cin, True)
     dw = torch.empty_like(w)
     with _nat.device_guard(feats.device):
         if rb._wpairs is not None and rb._num is not None:

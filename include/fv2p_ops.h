@@ -383,6 +383,15 @@ int fv2p_three_nn_batch(int b, int n, int m, const float* unknown, const float* 
 int fv2p_three_nn_stack(int b, int n, int m, const float* unknown, const int* unknown_batch_cnt,
                         const float* known, const int* known_batch_cnt, float* dist2, int* idx,
                         fv2p_stream_t stream);
+/* fv2p_three_nn_stack through a uniform grid over the known points: the same idx / dist2, bit for bit (every distance is the scan's
+ * float expression, the three best are kept under the (distance, index) order = "strict < over ascending index", and the search
+ * around a query stops only when every unseen point is provably farther than its third best), in time proportional to the points
+ * near each query instead of all of them.  cell: grid spacing in the points' unit (e.g. two voxel pitches of the level the known
+ * points are centres of); <= 0 lets the library estimate one.  The reference has no counterpart (interpolate_gpu.cu:16-73 scans). */
+size_t fv2p_three_nn_grid_ws_bytes(int b, int64_t m);
+int fv2p_three_nn_stack_grid(int b, int n, int m, const float* unknown, const int* unknown_batch_cnt,
+                             const float* known, const int* known_batch_cnt, float cell, float* dist2, int* idx,
+                             void* ws, size_t ws_bytes, fv2p_stream_t stream);
 int fv2p_three_interpolate_batch(int b, int c, int m, int n, const float* points, const int* idx,
                                  const float* weight, float* out, fv2p_stream_t stream);
 int fv2p_three_interpolate_batch_grad(int b, int c, int n, int m, const float* grad_out, const int* idx,

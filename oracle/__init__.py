@@ -28,6 +28,27 @@ def lib():
     return _LIB
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def contracted():
+    """Inside the block every oracle function runs from liboracle_fma.so: the same C with fused multiply-adds wherever a product
+    feeds a sum (gcc -ffp-contract=fast -mfma), the arithmetic an nvcc build of the reference's kernels performs by default.
+    For the contraction audit only (tools/fma_audit.py)."""
+    global _LIB
+    path = os.path.join(_HERE, "liboracle_fma.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".c")]
+    if not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "fma"])
+    plain = lib()
+    _LIB = ctypes.CDLL(path)
+    try:
+        yield
+    finally:
+        _LIB = plain
+
+
 def _p(a, t):
     return a.ctypes.data_as(ctypes.POINTER(t))
 

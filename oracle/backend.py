@@ -29,6 +29,10 @@ def _three_nn_stack(b, n, m, unknown, ucnt, known, kcnt, dist2, idx, stream):
     _fill(dist2, d2), _fill(idx, i)
 
 
+def _three_nn_stack_grid(b, n, m, unknown, ucnt, known, kcnt, cell, dist2, idx, ws, ws_bytes, stream):
+    _three_nn_stack(b, n, m, unknown, ucnt, known, kcnt, dist2, idx, stream)      # the grid search is the same function, bit for bit
+
+
 def _three_interp_stack(n, c, feats, idx, weight, out, stream):
     f, i, w = _np(feats), _np(idx).astype(np.int64), _np(weight)
     _fill(out, (w[:, 0:1] * f[i[:, 0]] + w[:, 1:2] * f[i[:, 1]]) + w[:, 2:3] * f[i[:, 2]])   # interpolate_gpu.cu (stack): left to right
@@ -163,6 +167,7 @@ _TABLE = {
     "fv2p_three_interpolate_batch": _three_interp_batch,
     "fv2p_three_interpolate_batch_grad": _three_interp_batch_grad,
     "fv2p_three_nn_stack": _three_nn_stack,
+    "fv2p_three_nn_stack_grid": _three_nn_stack_grid,
     "fv2p_three_interpolate_stack": _three_interp_stack,
     "fv2p_three_interpolate_stack_grad": _three_interp_stack_grad,
     "fv2p_furthest_point_sampling": _fps,

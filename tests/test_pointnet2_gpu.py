@@ -234,3 +234,33 @@ def test_fused_grid_set_abstraction_matches_the_grouped_formulation(gpu, r, n, m
     assert rel(out, ref) < 1e-5
     for a, t in zip(got, (pp, pc, w2)):
         assert rel(a, t.grad) < 1e-4
+
+
+@pytest.mark.parametrize("cell", [None, 0.8, 0.1, 7.0])
+def test_three_nn_grid_search_is_the_scan_bit_for_bit(gpu, cell):
+    """fv2p_three_nn_stack_grid against the oracle's scan: decoder shapes (16384 key points per sample against the voxel centres of a
+    level: lattice, exact ties everywhere), a sample with two known points (untouched slots: index 0, inf), a sample whose queries
+    lie far outside the known points' box (ring limit -> per-query scan), with and without a spacing hint, hints far too small and
+    far too large.  idx and distances bit for bit."""
+    rng = np.random.default_rng(4)
+    knowns, unknowns = [], []
+    for s, (nk, nu) in enumerate([(12000, 16384), (9000, 16384), (2, 300), (1500, 400)]):
+        c = synth.lidar_cloud(20 + s, max(nk, 64))[:, :3]
+        k = np.unique(np.floor(c / 0.4).astype(np.int64), axis=0)
+        k = ((k + 0.5) * 0.4).astype(np.float32)[:nk]
+        k = k[rng.permutation(k.shape[0])]
+        u = synth.lidar_cloud(30 + s, nu)[:, :3]
+        if s == 3:
+            u = u + np.float32([300.0, -200.0, 40.0])          # far from every known point
+        if s == 1:
+            u[:500] = k[rng.integers(0, k.shape[0], 500)] - np.float32(0.2)    # cell corners: up to 8 equidistant centres
+        knowns.append(k); unknowns.append(u.astype(np.float32))
+    kc, uc = np.array([k.shape[0] for k in knowns], np.int32), np.array([u.shape[0] for u in unknowns], np.int32)
+    known, unknown = np.concatenate(knowns), np.concatenate(unknowns)
+    assert known.shape[0] >= su.GRID_MIN_KNOWN
+    dist, idx = su.three_nn(T(unknown, gpu), T(uc, gpu), T(known, gpu), T(kc, gpu), cell)
+    d2, ridx = oracle.three_nn_stack(unknown, uc, known, kc)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    assert np.array_equal(dist.cpu().numpy(), np.sqrt(d2))
+    lo = int(uc[:2].sum())
+    assert np.isinf(np.sqrt(d2)[lo:lo + 300, 2]).all()          # the two-point sample really has untouched slots

@@ -708,10 +708,28 @@ def test_tiling_plan_changes_no_bit(gpu, cin, cout, subm):
     assert rel_err(planned[0].cpu().numpy(), ref) < RTOL
     # structure of the plan behind the forward table
     tab, _ = rb.out_table(cin)
-    cost = np.maximum((tab.cpu().numpy() >= 0).sum(0), 8)
+    act = tab.cpu().numpy() >= 0
+    cost = np.maximum(act.sum(0), 8)
+    n = tab.shape[1]
+    csum = np.concatenate([np.zeros((act.shape[0], 1), np.int64), np.cumsum(act, 1)], 1)
+    exact_levels = 0
     for tiles, bounds in _plan_of(tab, None).items():
-        assert bounds[0] == 0 and bounds[-1] == tab.shape[1] and (np.diff(bounds) >= 0).all()
+        assert bounds[0] == 0 and bounds[-1] == n and (np.diff(bounds) >= 0).all()
+        rows = np.diff(bounds)
+        groups = np.ceil((csum[:, bounds[1:]] - csum[:, bounds[:-1]]) / 16).sum(0)
         per = np.add.reduceat(np.concatenate([cost, [0]]), np.minimum(bounds[:-1], cost.size))
-        per[np.diff(bounds) == 0] = 0
+        per[rows == 0] = 0
         assert per.sum() == cost.sum()
-        assert per.max() <= cost.sum() / tiles + cost.max() + 1, (tiles, per.max(), cost.sum() / tiles)
+        if rows.max() <= 64 and groups.max() <= 72 and (rows[rows > 0].min() < rows.max()):
+            # exact plan (n <= 32767): greedy runs under one budget of MFMA row groups — every tile but the last of the chain is
+            # maximal: one more row would exceed the budget its level chose, or the 64-row cap
+            exact_levels += 1
+            budget = next(g for g in (28, 30, 32, 34, 36, 38, 40, 42, 44, 46, 48, 52, 56, 60, 64, 72) if groups.max() <= g)
+            live = np.nonzero(rows)[0]
+            for t in live[:-1]:
+                if rows[t] < 64:
+                    more = np.ceil((csum[:, bounds[t + 1] + 1] - csum[:, bounds[t]]) / 16).sum()
+                    assert more > budget or rows[t] == 1, (tiles, t, more, budget)
+        else:   # equal-cost plan
+            assert per.max() <= cost.sum() / tiles + cost.max() + 1, (tiles, per.max(), cost.sum() / tiles)
+    assert exact_levels > 0 or n > 32767 or n < 1024

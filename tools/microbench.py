@@ -191,7 +191,10 @@ def conv(only=None):
         cin, cout = mod.in_channels, mod.out_channels
         w3 = w.reshape(-1, cin, cout)
         tab_b, flip_b = rb.in_table(cout)
-        t_dx = timeit(lambda: ops._conv_rows(g, w3, tab_b, flip_b, f.shape[0], cin, True))
+        if cout in (64, 128) and cin % 64 == 0 and cin <= 128:   # as ops.indice_conv_backward: W_k^T materialised (the copy is inside the clock)
+            t_dx = timeit(lambda: ops._conv_rows(g, w3.transpose(1, 2).contiguous(), tab_b, flip_b, f.shape[0], cin, False))
+        else:
+            t_dx = timeit(lambda: ops._conv_rows(g, w3, tab_b, flip_b, f.shape[0], cin, True))
         extra = ""
         if not mod.subm and not mod.transposed:   # strided conv: backward-data with the rows grouped by parity class
             import ctypes

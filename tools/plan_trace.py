@@ -64,6 +64,10 @@ for key in sys.argv[1:] or ["res4"]:
         print(f"{key} half {half}: dur median {np.median(d):.0f} min {d.min():.0f} max {d.max():.0f}; rows {rows.min()}..{rows.max()} pairs {pairs.min()}..{pairs.max()} "
               f"groups {groups.min():.0f}..{groups.max():.0f} (mean {groups.mean():.1f}) offsets {nonempty.min()}..{nonempty.max()}; fit dur = {coef[0]:.0f}*groups + {coef[1]:.0f}*rows + {coef[2]:.0f}; "
               f"corr(dur, groups) {np.corrcoef(d, groups)[0, 1]:.2f} corr(dur, rows) {np.corrcoef(d, rows)[0, 1]:.2f} corr(dur,pairs) {np.corrcoef(d, pairs)[0, 1]:.2f}")
+        lv = live[half * T:(half + 1) * T]
+        nz = d > 0
+        print(f"     wave 0 clocks per group: total {np.median(d[nz] / groups[nz]):.0f}  wait {np.median(lv[nz, 5] / groups[nz]):.0f}  issue {np.median(lv[nz, 6] / groups[nz]):.0f}  "
+              f"compute {np.median(lv[nz, 7] / groups[nz]):.0f}  prologue {np.median(lv[nz, 4] - lv[nz, 2]):.0f} (per tile)")
         order = np.argsort(d)
         for i in list(order[:4]) + list(order[-4:]):
             print(f"   wg {i}: dur {d[i]:.0f} rows {rows[i]} pairs {pairs[i]} groups {groups[i]:.0f} offsets {nonempty[i]} xcc {live[half * T + i, 1] & 0xF}")
