@@ -772,7 +772,7 @@ def roofline_probe(model, voxelize, pool, args, device):
     traffic = None
     layer = f"{'subm' if mod.subm else 'conv'} {cin}->{cout} key={mod.indice_key} n_in={rec['n_in']} n_out={rec['n_out']} pairs={rec['pairs']}"
     try:   # reported only for the very layer the counters were collected on (same channels, rows and pairs)
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_roofline.json")) as f:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_roofline.json")) as f:
             pmc = json.load(f)
         import re
         mt = re.search(r"(\d+)->(\d+) key=(\S+) n=(\d+) pairs=(\d+)", pmc.get("layer_line", ""))

@@ -1901,10 +1901,12 @@ __global__ __launch_bounds__(256) void plan_select_k(const int* __restrict__ wal
     const int tiles = ((l & 1) ? 384 : 256) << (l >> 1);
     if (e < base + tiles + 1) {
       const int t = static_cast<int>(e - base);
+      if (e == 0) { plan[0] = kPlanMagic; plan[1] = levels; }
       int pick = -1;
       for (int j = 0; j < kPlanBudgets; ++j)
         if (count[j] <= tiles) { pick = j; break; }
       if (pick >= 0) plan[2 + e] = (t < count[pick]) ? walk[static_cast<long long>(pick) * n_dst + t] : n_dst;
+      else plan[2 + e] = static_cast<int>(min(static_cast<long long>(n_dst), static_cast<long long>(t) * ((n_dst + tiles - 1) / tiles)));   // no budget fits: equal rows
       return;
     }
     base += tiles + 1;
@@ -2043,15 +2045,15 @@ extern "C" int fv2p_conv_plan_build(int* tab, int kvol, int64_t n_dst, void* ws,
   const size_t sb = scan_ws_bytes(n_dst);
   void* sws = c.take<char>(sb);
   const int n = static_cast<int>(n_dst);
-  hipLaunchKernelGGL(plan_cost_k, dim3(static_cast<unsigned>(ceil_div(n_dst, 256))), dim3(256), 0, stream, tab, kvol, n, cost);
-  if (int rc = exclusive_scan_i32(cost, prefix, n_dst, total, sws, sb, stream)) return rc;
   const int levels = plan_levels(n_dst);
   const int64_t entries = plan_level_offset(levels) - 2;
   int* plan = tab + static_cast<long long>(kvol) * n_dst;
-  hipLaunchKernelGGL(plan_bounds_k, dim3(static_cast<unsigned>(ceil_div(entries, 256))), dim3(256), 0, stream, prefix, total, n, levels, plan);
   static int exact = -1;   // FV2P_PLAN_EXACT=0 keeps the equal-cost bounds (comparison runs)
   if (exact < 0) { const char* e = getenv("FV2P_PLAN_EXACT"); exact = e ? atoi(e) : 1; }
-  if (exact && kvol >= 8 && kvol <= 27 && n_dst >= 1024 && n_dst <= kPlanExactRows) {
+  const size_t lds = 2 * static_cast<size_t>(n_dst + 1) * sizeof(unsigned short);
+  static bool big = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&plan_walk_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) == hipSuccess; }();
+  if (exact && kvol >= 8 && kvol <= 27 && n_dst >= 1024 && n_dst <= kPlanExactRows && (big || lds <= 48 * 1024)) {
+    // group-balanced bounds: four launches (row words, reach of 16 budgets, one chain walk per budget, selection per level)
     unsigned long long* words = c.take<unsigned long long>(3 * static_cast<size_t>(n_dst));
     unsigned char* reach = c.take<unsigned char>(static_cast<size_t>(kPlanBudgets) * n_dst);
     int* walk = c.take<int>(static_cast<size_t>(kPlanBudgets) * n_dst);
@@ -2059,12 +2061,13 @@ extern "C" int fv2p_conv_plan_build(int* tab, int kvol, int64_t n_dst, void* ws,
     const unsigned blocks = static_cast<unsigned>(ceil_div(n_dst, 256));
     hipLaunchKernelGGL(plan_rowwords_k, dim3(blocks), dim3(256), 0, stream, tab, kvol, n, words);
     hipLaunchKernelGGL(plan_reach_k, dim3(blocks), dim3(256), 0, stream, words, n, reach);
-    const size_t lds = 2 * static_cast<size_t>(n_dst + 1) * sizeof(unsigned short);
-    static bool big = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&plan_walk_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) == hipSuccess; }();
-    if (big || lds <= 48 * 1024) {
-      hipLaunchKernelGGL(plan_walk_k, dim3(kPlanBudgets), dim3(1024), lds, stream, reach, n, walk, count);
-      hipLaunchKernelGGL(plan_select_k, dim3(static_cast<unsigned>(ceil_div(entries, 256))), dim3(256), 0, stream, walk, count, n, levels, plan);
-    }
+    hipLaunchKernelGGL(plan_walk_k, dim3(kPlanBudgets), dim3(1024), lds, stream, reach, n, walk, count);
+    hipLaunchKernelGGL(plan_select_k, dim3(static_cast<unsigned>(ceil_div(entries, 256))), dim3(256), 0, stream, walk, count, n, levels, plan);
+  } else {
+    // equal-cost bounds: cost per row, prefix sums, binary search per bound
+    hipLaunchKernelGGL(plan_cost_k, dim3(static_cast<unsigned>(ceil_div(n_dst, 256))), dim3(256), 0, stream, tab, kvol, n, cost);
+    if (int rc = exclusive_scan_i32(cost, prefix, n_dst, total, sws, sb, stream)) return rc;
+    hipLaunchKernelGGL(plan_bounds_k, dim3(static_cast<unsigned>(ceil_div(entries, 256))), dim3(256), 0, stream, prefix, total, n, levels, plan);
   }
   FV2P_LAUNCH_CHECK();
   return 0;

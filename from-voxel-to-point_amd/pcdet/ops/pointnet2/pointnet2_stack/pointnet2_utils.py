@@ -54,7 +54,10 @@ def _fps(saved, xyz, npoint):
     return idx
 
 
-GRID_MIN_KNOWN = 1024     # below this the tiled scan is as fast as building a grid
+# known points below which the tiled scan stays ahead of building a grid (measured, profiles/r03_microbench_nn.txt: at the KITTI levels,
+# 5 - 35 k voxel centres for 49 152 queries, the scan takes 84 - 492 us and the grid 170 - 1 350 us — nine launches to build it and
+# latency-bound walks; at the Waymo levels, 24 - 110 k centres, the grid takes 108 - 419 us against 339 - 1 525 us)
+GRID_MIN_KNOWN = 20000
 
 
 def _three_nn(saved, unknown, unknown_batch_cnt, known, known_batch_cnt, cell=None):

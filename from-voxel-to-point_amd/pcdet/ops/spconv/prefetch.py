@@ -38,7 +38,9 @@ def rulebook_recipe(indice_dict, root_indices):
             src = by_out[src_ptr]
         else:
             continue  # built from indices this pass did not produce: cannot be replayed from the root alone
-        recipe.append((key, src, [int(v) for v in rb.spatial_shape], rb.geom))
+        # eighth entry: the recorded pass gave this (submanifold) table a tiling plan -> replays build it with the rulebook, off the
+        # training stream (ops.Rulebook.build_plan)
+        recipe.append((key, src, [int(v) for v in rb.spatial_shape], tuple(rb.geom[:7]) + (bool(rb.__dict__.get("_planned", {}).get("tab_in")),)))
         if not rb.subm:
             by_out[rb.outids.data_ptr()] = key
     return recipe
@@ -58,11 +60,13 @@ def build_rulebooks(recipe, indices, batch_size, pair_lists=True):
         return _build_chain(ext, recipe, root, batch_size, pair_lists)
     out = {}
     for key, src, shape, geom in recipe:
-        ksize, stride, padding, dilation, out_padding, subm, transpose = geom
+        ksize, stride, padding, dilation, out_padding, subm, transpose = geom[:7]
         ind = root if src is None else out[src].outids
         out[key] = ops.build_rulebook(ind, batch_size, shape, list(ksize), list(stride), list(padding), list(dilation),
                                       list(out_padding), subm, transpose)
         out[key].prefetched = True
+        if len(geom) > 7 and geom[7]:
+            out[key].build_plan()
         if pair_lists and (subm or _few_offsets(ksize)):  # compacted pair lists: the weight gradient splits its work by them
             out[key].wgrad_pairs()   # (measured: a win for subm rulebooks and for kernels of < 8 offsets, a loss for other strided ones)
     return out
@@ -83,7 +87,7 @@ def _build_chain(ext, recipe, root, batch_size, pair_lists):
     keys = [r[0] for r in recipe]
     specs, shapes = [], []
     for key, src, shape, geom in recipe:
-        ksize, stride, padding, dilation, out_padding, subm, transpose = (list(g) if isinstance(g, tuple) else g for g in geom)
+        ksize, stride, padding, dilation, out_padding, subm, transpose = (list(g) if isinstance(g, tuple) else g for g in geom[:7])
         if subm:
             out_shape = list(shape)
         elif transpose:
@@ -102,9 +106,12 @@ def _build_chain(ext, recipe, root, batch_size, pair_lists):
         subm = geom[5]
         rb = ops.Rulebook(ind if subm else outids, ind, tab_in, tab_out, num, shape, int(tab_in.shape[0]), bool(subm))
         rb.out_spatial_shape = out_shape
-        rb.geom, rb.batch_size, rb.prefetched = geom, int(batch_size), True
+        rb.geom, rb.batch_size, rb.prefetched = tuple(geom[:7]), int(batch_size), True
         rb._wpairs = pairs
         rb._perm_in = perm if os.environ.get("FV2P_DX_PERM", "1") != "0" else None   # strided conv: input rows by parity class = tile order of its backward-data conv
+        if len(geom) > 7 and geom[7]:
+            with _nat.device_guard(root.device):
+                rb.build_plan()
         out[key] = rb
     return out
 

@@ -237,7 +237,7 @@ def test_fused_grid_set_abstraction_matches_the_grouped_formulation(gpu, r, n, m
 
 
 @pytest.mark.parametrize("cell", [None, 0.8, 0.1, 7.0])
-def test_three_nn_grid_search_is_the_scan_bit_for_bit(gpu, cell):
+def test_three_nn_grid_search_is_the_scan_bit_for_bit(gpu, cell, monkeypatch):
     """fv2p_three_nn_stack_grid against the oracle's scan: decoder shapes (16384 key points per sample against the voxel centres of a
     level: lattice, exact ties everywhere), a sample with two known points (untouched slots: index 0, inf), a sample whose queries
     lie far outside the known points' box (ring limit -> per-query scan), with and without a spacing hint, hints far too small and
@@ -257,7 +257,7 @@ def test_three_nn_grid_search_is_the_scan_bit_for_bit(gpu, cell):
         knowns.append(k); unknowns.append(u.astype(np.float32))
     kc, uc = np.array([k.shape[0] for k in knowns], np.int32), np.array([u.shape[0] for u in unknowns], np.int32)
     known, unknown = np.concatenate(knowns), np.concatenate(unknowns)
-    assert known.shape[0] >= su.GRID_MIN_KNOWN
+    monkeypatch.setattr(su, "GRID_MIN_KNOWN", 0)              # the grid path is the one under test, whatever the size threshold
     dist, idx = su.three_nn(T(unknown, gpu), T(uc, gpu), T(known, gpu), T(kc, gpu), cell)
     d2, ridx = oracle.three_nn_stack(unknown, uc, known, kc)
     assert np.array_equal(idx.cpu().numpy(), ridx)

@@ -687,9 +687,19 @@ def test_tiling_plan_changes_no_bit(gpu, cin, cout, subm):
     g = torch.from_numpy(rng.standard_normal((n_out, cout)).astype(np.float32)).to(gpu)
     bias = torch.from_numpy(rng.standard_normal(cout).astype(np.float32)).to(gpu)
 
+    def plan(tab):   # through the C ABI: the Python layer plans submanifold tables only, and from their second conv on (ops.Rulebook._plan)
+        kv, nn_ = tab.shape
+        ws = fv2p_native.workspace(int(fv2p_native.lib().fv2p_conv_plan_ws_bytes(nn_)), tab.device)
+        fv2p_native.call("fv2p_conv_plan_build", tab, kv, nn_, ws, ws.numel(), fv2p_native.stream())
+
     def run(planned):
-        (tab_f, flag_f), (tab_b, flag_b) = rb.out_table(cin if planned else None), rb.in_table(cout if planned else None)
-        assert bool(flag_f & ops.TAB_PLANNED) == planned and bool(flag_b & ops.TAB_PLANNED) == planned
+        (tab_f, flag_f), (tab_b, flag_b) = rb.out_table(), rb.in_table()
+        assert not (flag_f | flag_b) & ops.TAB_PLANNED
+        if planned:
+            plan(tab_f)
+            if tab_b.data_ptr() != tab_f.data_ptr():
+                plan(tab_b)
+            flag_f, flag_b = flag_f | ops.TAB_PLANNED, flag_b | ops.TAB_PLANNED
         y = torch.empty((n_out, cout), device=gpu)
         stats = torch.zeros((slots, 2, cout), dtype=torch.float64, device=gpu)
         fv2p_native.call("fv2p_sparse_conv_rows_stats", x, x.shape[0], cin, w, 27, tab_f, n_out, cout, int(flag_f), 0, bias, y, stats, fv2p_native.stream())
@@ -707,7 +717,7 @@ def test_tiling_plan_changes_no_bit(gpu, cin, cout, subm):
     ref = oracle.indice_conv(x.cpu().numpy(), w.cpu().numpy(), pairs, num, n_out, subm=subm).numpy() + bias.cpu().numpy()
     assert rel_err(planned[0].cpu().numpy(), ref) < RTOL
     # structure of the plan behind the forward table
-    tab, _ = rb.out_table(cin)
+    tab, _ = rb.out_table()
     act = tab.cpu().numpy() >= 0
     cost = np.maximum(act.sum(0), 8)
     n = tab.shape[1]
@@ -733,3 +743,19 @@ def test_tiling_plan_changes_no_bit(gpu, cin, cout, subm):
         else:   # equal-cost plan
             assert per.max() <= cost.sum() / tiles + cost.max() + 1, (tiles, per.max(), cost.sum() / tiles)
     assert exact_levels > 0 or n > 32767 or n < 1024
+
+
+def test_python_layer_plans_submanifold_tables_from_the_second_conv(gpu):
+    """ops.Rulebook._plan: no plan for strided rulebooks (two convs per table cannot repay ~80 us), none for the first conv on a
+    submanifold table, a plan from the second request on; build_plan() (input pipelines) builds it at once; other channel counts never."""
+    ind, feats, x = make_input(5, 2, [9, 20, 18], 1500, 64, gpu)
+    sub = ops.build_rulebook(x.indices, 2, [9, 20, 18], 3, 1, 1, 1, 0, True)
+    strided = ops.build_rulebook(x.indices, 2, [9, 20, 18], 3, 2, 1, 1, 0, False)
+    assert not strided.out_table(64)[1] & ops.TAB_PLANNED and not strided.in_table(128)[1] & ops.TAB_PLANNED
+    assert not sub.out_table(32)[1] & ops.TAB_PLANNED
+    assert not sub.out_table(64)[1] & ops.TAB_PLANNED            # first request
+    assert sub.in_table(64)[1] & ops.TAB_PLANNED                 # second request (same table: submanifold symmetry)
+    assert sub.out_table(32)[1] & ops.TAB_PLANNED                # built: every later call carries the flag, kernels without plan support ignore it
+    fresh = ops.build_rulebook(x.indices, 2, [9, 20, 18], 3, 1, 1, 1, 0, True)
+    fresh.build_plan()
+    assert fresh.out_table()[1] & ops.TAB_PLANNED

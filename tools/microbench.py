@@ -218,6 +218,20 @@ def conv(only=None):
         fl = 2.0 * p * cin * cout
         name = f"{'subm' if mod.subm else 'conv'} {cin}->{cout} {mod.indice_key}"
         print(f"{name:34s} {f.shape[0]:6d} {n_out:6d} {p:8d} {t_f:8.1f} {fl / t_f / 1e6:6.1f} {t_dx:8.1f} {t_all - t_dx:8.1f} {fl / max(t_all - t_dx, 1e-3) / 1e6:6.1f} {t_allp - t_dx:8.1f} {fl / max(t_allp - t_dx, 1e-3) / 1e6:6.1f}{extra}")
+    # tiling-plan build per table (fv2p_conv_plan_build: what the first 64 / 128-channel conv on a rulebook pays once)
+    import fv2p_native
+    seen = set()
+    for mod, f, rb, n_out in recs:
+        if mod.indice_key in seen or mod.in_channels not in (64, 128):
+            continue
+        seen.add(mod.indice_key)
+        for name, tab in (("tab_in", rb.tab_in), ("tab_out", rb.tab_out)):
+            if tab is None:
+                continue
+            kv, nn_ = tab.shape
+            ws = fv2p_native.workspace(int(fv2p_native.lib().fv2p_conv_plan_ws_bytes(nn_)), tab.device)
+            t = timeit(lambda: fv2p_native.call("fv2p_conv_plan_build", tab, kv, nn_, ws, ws.numel(), fv2p_native.stream()), reps=20, warm=3)
+            print(f"plan build {mod.indice_key} {name} [{kv} x {nn_}]: {t:.1f} us")
     # rulebook build timings
     x = torch.cat(coords)
     for subm, k, s, p in [(True, 3, 1, 1), (False, 3, 2, 1)]:
@@ -260,6 +274,41 @@ def fps():
         known = torch.rand(1, v, 3, device=dev) * 70
         t = timeit(lambda: bu.three_nn(kp, known), reps=5, warm=1)
         print(f"three_nn 16384 x {v}: {t:8.1f} us ({8.0 * 16384 * v / t / 1e6:6.2f} TFLOP/s)")
+
+
+def nn():
+    """Decoder-shaped 3-NN: 3 x 16384 key points (the clouds' own points) against the voxel centres of the four backbone levels,
+    scan (fv2p_three_nn_stack) vs grid (fv2p_three_nn_stack_grid) with the lattice hint and with the library's own spacing estimate."""
+    from fv2p_harness import synth
+    from pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as su
+    dev = torch.device("cuda:0")
+    waymo = bool(os.environ.get("FV2P_WAYMO"))
+    nb = 2 if waymo else 3
+    clouds = [synth.waymo_like_cloud(b, 180000) if waymo else synth.lidar_cloud(b, 16384) for b in range(nb)]
+    vsz = np.array([0.1, 0.1, 0.15] if waymo else [0.05, 0.05, 0.1], np.float32)
+    lo = np.array([-75.2, -75.2, -2.0] if waymo else [0.0, -40.0, -3.0], np.float32)
+    rng = np.random.default_rng(0)
+    keys = [c[rng.permutation(c.shape[0])[:16384], :3] for c in clouds]
+    key = torch.from_numpy(np.concatenate(keys)).to(dev).contiguous()
+    kc = torch.full((nb,), 16384, dtype=torch.int32, device=dev)
+    for stride in (1, 2, 4, 8):
+        cen, cnt = [], []
+        for c in clouds:
+            cell = np.unique(np.floor((c[:, :3] - lo) / (vsz * stride)).astype(np.int64), axis=0)
+            cen.append(((cell + 0.5) * (vsz * stride) + lo).astype(np.float32))
+            cnt.append(cell.shape[0])
+        known = torch.from_numpy(np.concatenate(cen)).to(dev).contiguous()
+        kcnt = torch.tensor(cnt, dtype=torch.int32, device=dev)
+        os.environ["FV2P_NN_GRID"] = "0"
+        t_scan = timeit(lambda: su.three_nn(key, kc, known, kcnt), reps=5, warm=1)
+        d0, i0 = su.three_nn(key, kc, known, kcnt)
+        os.environ["FV2P_NN_GRID"] = "1"
+        t_hint = timeit(lambda: su.three_nn(key, kc, known, kcnt, 2.0 * float(vsz[0]) * stride), reps=10, warm=2)
+        t_auto = timeit(lambda: su.three_nn(key, kc, known, kcnt), reps=10, warm=2)
+        d1, i1 = su.three_nn(key, kc, known, kcnt, 2.0 * float(vsz[0]) * stride)
+        same = bool(torch.equal(i0, i1) and torch.equal(d0, d1))
+        print(f"three_nn {key.shape[0]} queries x {known.shape[0]} voxel centres (stride {stride}): scan {t_scan:8.1f} us   grid, lattice hint {t_hint:7.1f} us   "
+              f"grid, estimated spacing {t_auto:7.1f} us   identical {same}")
 
 
 def nms():
@@ -456,7 +505,7 @@ if __name__ == "__main__":
     if which == "convone":
         conv(only=20)
         sys.exit(0)
-    for name, fn in (("conv", conv), ("dcn", dcn), ("fps", fps), ("nms", nms), ("sa", sa), ("bn", bn), ("bev", bev), ("oproof", oproof)):
+    for name, fn in (("conv", conv), ("dcn", dcn), ("fps", fps), ("nn", nn), ("nms", nms), ("sa", sa), ("bn", bn), ("bev", bev), ("oproof", oproof)):
         if which in (name, "all"):
             print(f"==== {name}")
             fn()
