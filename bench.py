@@ -966,6 +966,7 @@ def main():
     else:
         run_step = step
     t0 = time.perf_counter()
+    host0, proc0 = time.thread_time(), time.process_time()
     stamps = []
     for i in range(args.steps):
         run_step(args.warmup + i)
@@ -973,6 +974,8 @@ def main():
             beat("step")
         if args.step_times:
             stamps.append(time.perf_counter())
+    host_ms = (time.thread_time() - host0) / args.steps * 1e3    # CPU time of the stepping thread / of the whole process per step, up to
+    proc_ms = (time.process_time() - proc0) / args.steps * 1e3   # the last launch (the final wait for the device is not in it)
     beat("sync")
     if prof is not None:
         prof.disable()
@@ -1030,6 +1033,8 @@ def main():
                                            2: "thread voxelises batch t+1 and builds its rulebooks during step t",
                                            3: "DIAGNOSTIC: prepared batches reused, not a benchmark configuration"}[min(args.prefetch, 3)])},
         }
+        # how close the step is to being bound by the host issuing its launches: CPU time of the stepping thread per step (beside ms_per_step)
+        result["host_thread_cpu_ms_per_step"], result["host_process_cpu_ms_per_step"] = round(host_ms, 3), round(proc_ms, 3)
         if args.workload in ("fv2p", "fv2p-waymo") and args.fps_ahead:
             result["config"]["input_pipeline"] += "; key points (FPS) of batch t+1 sampled on a side stream during the backward pass of step t"
         if args.workload in ("fv2p", "fv2p-waymo"):

@@ -714,12 +714,19 @@ __global__ __launch_bounds__(kFpsWaves * 64) void fps_wave_k(int n, int m, int b
 }
 
 // ---- streaming furthest point sampling (clouds too large for one CU's registers: n > 24576, e.g. Waymo's ~180 k) ----------
-// Same picks again, with the points left in memory.  The Morton-sorted cloud is cut into buckets of 256 points (<= 1024
-// buckets: one per thread); a bucket's box, exact running maximum, the priority and the coordinates of the point holding it
-// stay in LDS.  Per round: every thread tests ITS bucket against the new point (box bound, exact), touched buckets are
-// compacted into a list, the 16 waves take them in turn (four coalesced 64-point rows of x, y, z, distance, priority from
-// L2, distance pass, one DPP reduction), then the arg-max over the bucket states picks the next point.  Memory traffic per
-// round is the touched buckets only (a few KB), against all n points for the plain kernel.
+// Same picks again, with the points left in memory: fps_wave_k with its register slots replaced by rows of a Morton-sorted SoA
+// copy (x, y, z, running distance, reference priority) that stays in L2.  A bucket is kStreamBucket = 256 consecutive points of
+// that order (<= 1024 buckets: one per thread of the 16 waves); bucket `bk` belongs to lane bk / 16 of wave bk % 16 — Morton
+// neighbours go to different waves, so the cluster of buckets a new point touches spreads over all of them.  The owner LANE
+// keeps the bucket's box, exact running maximum, the priority and the coordinates of the point that holds it in registers;
+// the owner WAVE is the only one that ever reads or writes the bucket's distances, so a round needs no list of touched
+// buckets, no LDS state and ONE barrier (the exchange of the 16 wave candidates, double buffered):
+//   box test per lane (exact skip: sqdist's operations in sqdist's order) -> ballot -> the wave walks its touched buckets two at
+//   a time (the loads of both in flight before the first distance pass: 2 x 4 rows x 5 arrays) -> bucket state back to its lane
+//   -> arg-max over the 64 lane states -> wave candidate to LDS -> barrier -> every wave derives the same winner.
+// Round 2's form compacted the touched buckets into an LDS list between two extra barriers and kept the states in LDS
+// (2.1 us/round at n = 180 000); the kernel also claims its CU (>= 97 VGPRs at four waves per SIMD, v127 below): beside a
+// training step other workgroups shared the CU and stretched the sampler from 34.8 to 45.7 ms (profiles/README.md, round 2).
 __global__ void fps_stream_prep_k(int64_t total, int n, const float* __restrict__ dataset, const float* __restrict__ temp, const uint64_t* __restrict__ keys,
                                   int bs, float* __restrict__ sx, float* __restrict__ sy, float* __restrict__ sz, float* __restrict__ sd,
                                   uint32_t* __restrict__ sp) {
@@ -741,17 +748,19 @@ __global__ void fps_stream_post_k(int64_t total, int n, const uint64_t* __restri
   temp[(t / n) * n + static_cast<int>(keys[t] & 0xffffffull)] = sd[t];
 }
 
-constexpr int kStreamBucket = 256;
-__global__ __launch_bounds__(1024) void fps_stream_k(int n, int m, int bs, const float* __restrict__ dataset, const float* __restrict__ sx_,
-                                                     const float* __restrict__ sy_, const float* __restrict__ sz_, float* __restrict__ sd_,
-                                                     const uint32_t* __restrict__ sp_, int* __restrict__ idxs) {
+constexpr int kStreamWaves = 16;
+constexpr int kStreamRows = 4;                      // rows of 64 points per bucket
+constexpr int kStreamBucket = 64 * kStreamRows;
+struct StreamRows { float x[kStreamRows], y[kStreamRows], z[kStreamRows], d[kStreamRows]; uint32_t p[kStreamRows]; };
+__global__ __launch_bounds__(kStreamWaves * 64) void fps_stream_k(int n, int m, int bs, const float* __restrict__ dataset,
+                                                                  const float* __restrict__ sx_, const float* __restrict__ sy_,
+                                                                  const float* __restrict__ sz_, float* __restrict__ sd_,
+                                                                  const uint32_t* __restrict__ sp_, int* __restrict__ idxs,
+                                                                  unsigned long long* __restrict__ trace) {
   if (m <= 0) return;
-  __shared__ float s_max[1024];
-  __shared__ uint32_t s_prio[1024];
-  __shared__ __attribute__((aligned(16))) float s_cand[1024][4];
-  __shared__ int s_list[1024];
-  __shared__ int s_count[2];
-  __shared__ __attribute__((aligned(16))) uint32_t s_wave[16][4];
+  unsigned long long t_test = 0, t_buckets = 0, t_best = 0, t_barrier = 0, t_pick = 0, t_mark = 0, n_touched = 0;   // test hook: clocks per phase (fv2p_fps_set_trace)
+  asm volatile("v_mov_b32 v127, 0" ::: "v127");   // 128 VGPRs per wave x 4 waves per SIMD = the SIMD's register file: no other workgroup joins this CU
+  __shared__ __attribute__((aligned(16))) uint32_t s_wave[2][kStreamWaves][8];   // candidate of every wave: max bits, priority, x, y, z, -
   int log2bs = 0;
   while ((1 << (log2bs + 1)) <= bs) ++log2bs;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -763,24 +772,33 @@ __global__ __launch_bounds__(1024) void fps_stream_k(int n, int m, int bs, const
   idxs += static_cast<int64_t>(b) * m;
   const int nb = (n + kStreamBucket - 1) / kStreamBucket;
   auto index_of = [&](uint32_t pr) -> int { return static_cast<int>(((pr & 0xffffu) << log2bs) | (__brev(pr >> 16) >> (32 - log2bs))); };
-  // one bucket: distance pass against (x1, y1, z1) when `update`, then its exact (max, priority, coordinates) into LDS
-  auto process = [&](int bk, bool update, float x1, float y1, float z1) {
+  // my bucket (lane * 16 + w): box, running maximum (-2: no such bucket), priority and coordinates of the point holding it
+  float lo0 = 0.f, lo1 = 0.f, lo2 = 0.f, hi0 = 0.f, hi1 = 0.f, hi2 = 0.f, bmax = -2.f, bcx = 0.f, bcy = 0.f, bcz = 0.f;
+  uint32_t bprio = 0xffffffffu;
+  // rows of the bucket of lane `l` (wave-uniform): positions past n are clamped (no divergent load) and masked in `fold`
+  auto fetch = [&](int l, StreamRows& r) __attribute__((always_inline)) {
+    const int p0 = (l * kStreamWaves + w) * kStreamBucket + lane;
+#pragma unroll
+    for (int q = 0; q < kStreamRows; ++q) {
+      const int pc = min(p0 + q * 64, n - 1);
+      r.x[q] = sx[pc]; r.y[q] = sy[pc]; r.z[q] = sz[pc]; r.d[q] = sd[pc]; r.p[q] = sp[pc];
+    }
+  };
+  // distance pass (when `update`) and the bucket's exact (max, priority, coordinates) back into lane l's registers
+  auto fold = [&](int l, StreamRows& r, bool update, bool boxes, float x1, float y1, float z1) __attribute__((always_inline)) {
+    const int p0 = (l * kStreamWaves + w) * kStreamBucket + lane;
     float bv = -2.f, bx = 0.f, by = 0.f, bz = 0.f;
     uint32_t bp = 0xffffffffu;
 #pragma unroll
-    for (int r = 0; r < kStreamBucket / 64; ++r) {
-      const int pos = bk * kStreamBucket + r * 64 + lane;
-      const bool ok = pos < n;
-      const int pc = ok ? pos : n - 1;
-      const float x = sx[pc], y = sy[pc], z = sz[pc];
-      float d = sd[pc];
-      const uint32_t pr = sp[pc];
+    for (int q = 0; q < kStreamRows; ++q) {
+      const bool ok = p0 + q * 64 < n;
+      float d = r.d[q];
       if (update) {
-        d = fminf(sqdist(x, y, z, x1, y1, z1), d);
-        if (ok) sd[pc] = d;
+        d = fminf(sqdist(r.x[q], r.y[q], r.z[q], x1, y1, z1), d);
+        if (ok) sd[p0 + q * 64] = d;
       }
-      const bool better = ok & ((d > bv) | ((d == bv) & (pr < bp)));
-      bv = better ? d : bv; bp = better ? pr : bp; bx = better ? x : bx; by = better ? y : by; bz = better ? z : bz;
+      const bool better = ok & ((d > bv) | ((d == bv) & (r.p[q] < bp)));
+      bv = better ? d : bv; bp = better ? r.p[q] : bp; bx = better ? r.x[q] : bx; by = better ? r.y[q] : by; bz = better ? r.z[q] : bz;
     }
     const float mx = wave_max_f32(bv);
     const uint64_t holders = __ballot(bv == mx);
@@ -791,76 +809,98 @@ __global__ __launch_bounds__(1024) void fps_stream_k(int n, int m, int bs, const
       leader = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(__ballot(bv == mx && bp == pm))) - 1);
     }
     const float cx = lane_f(bx, leader), cy = lane_f(by, leader), cz = lane_f(bz, leader);
-    if (lane == 0) {
-      s_max[bk] = mx;
-      s_prio[bk] = pm;
-      *reinterpret_cast<float4*>(&s_cand[bk][0]) = make_float4(cx, cy, cz, 0.f);
+    if (lane == l) { bmax = mx; bprio = pm; bcx = cx; bcy = cy; bcz = cz; }
+    if (boxes) {
+      float a0 = INFINITY, a1 = INFINITY, a2 = INFINITY, c0 = -INFINITY, c1 = -INFINITY, c2 = -INFINITY;
+#pragma unroll
+      for (int q = 0; q < kStreamRows; ++q)
+        if (p0 + q * 64 < n) {
+          a0 = fminf(a0, r.x[q]); c0 = fmaxf(c0, r.x[q]); a1 = fminf(a1, r.y[q]); c1 = fmaxf(c1, r.y[q]); a2 = fminf(a2, r.z[q]); c2 = fmaxf(c2, r.z[q]);
+        }
+      a0 = wave_min_f32(a0); a1 = wave_min_f32(a1); a2 = wave_min_f32(a2);
+      c0 = wave_max_f32(c0); c1 = wave_max_f32(c1); c2 = wave_max_f32(c2);
+      if (lane == l) { lo0 = a0; lo1 = a1; lo2 = a2; hi0 = c0; hi1 = c1; hi2 = c2; }
     }
   };
-  // my bucket's box (thread t <-> bucket t), from the sorted coordinates
-  float lo0 = INFINITY, lo1 = INFINITY, lo2 = INFINITY, hi0 = -INFINITY, hi1 = -INFINITY, hi2 = -INFINITY;
-  if (tid < nb) {
-    const int e = min(n, (tid + 1) * kStreamBucket);
-    for (int pos = tid * kStreamBucket; pos < e; ++pos) {
-      const float x = sx[pos], y = sy[pos], z = sz[pos];
-      lo0 = fminf(lo0, x); hi0 = fmaxf(hi0, x); lo1 = fminf(lo1, y); hi1 = fmaxf(hi1, y); lo2 = fminf(lo2, z); hi2 = fmaxf(hi2, z);
-    }
-  } else {
-    s_max[tid] = -2.f;
-    s_prio[tid] = 0xffffffffu;
+  for (int l = 0; l * kStreamWaves + w < nb; ++l) {
+    StreamRows r;
+    fetch(l, r);
+    fold(l, r, false, true, 0.f, 0.f, 0.f);
   }
-  for (int bk = w; bk < nb; bk += 16) process(bk, false, 0.f, 0.f, 0.f);
-  if (tid == 0) { s_count[0] = 0; s_count[1] = 0; idxs[0] = 0; }
-  __syncthreads();
+  // wave candidate from the 64 lane states
+  uint32_t wbits = 0, wprio = 0xffffffffu;
+  int wlane = 0;
+  float wcx = 0.f, wcy = 0.f, wcz = 0.f;
+  auto wave_best = [&]() __attribute__((always_inline)) {
+    const float mx = wave_max_f32(bmax);
+    const uint64_t top = __ballot(bmax == mx);
+    int l = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(top)) - 1);
+    uint32_t pm = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(bprio), l));
+    if (top & (top - 1)) {
+      pm = wave_min_u32(bmax == mx ? bprio : 0xffffffffu);
+      l = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(__ballot(bmax == mx && bprio == pm))) - 1);
+    }
+    wlane = l;
+    wbits = __float_as_uint(fmaxf(mx, 0.f));   // every real maximum is >= 0: unsigned order == float order; a wave without buckets -> 0 with priority ~0
+    wprio = pm;
+    wcx = lane_f(bcx, l); wcy = lane_f(bcy, l); wcz = lane_f(bcz, l);
+  };
+  wave_best();
   float x1 = dataset[0], y1 = dataset[1], z1 = dataset[2];
+  if (tid == 0) idxs[0] = 0;
   for (int j = 1; j < m; ++j) {
-    const int buf = j & 1;
-    // 1. which buckets can the new point still lower?  (box bound in sqdist's operation order: exact skip)
+    if (trace) t_mark = __builtin_readcyclecounter();
     const float gx = fmaxf(fmaxf(lo0 - x1, x1 - hi0), 0.f);
     const float gy = fmaxf(fmaxf(lo1 - y1, y1 - hi1), 0.f);
     const float gz = fmaxf(fmaxf(lo2 - z1, z1 - hi2), 0.f);
     const float lb = gx * gx + gy * gy + gz * gz;
-    const bool touch = tid < nb && lb < s_max[tid];
-    const uint64_t tm = __ballot(touch);
-    if (tm) {
-      int off = 0;
-      if (lane == 0) off = atomicAdd(&s_count[buf], __popcll(tm));
-      off = __builtin_amdgcn_readfirstlane(off);
-      if (touch) s_list[off + __popcll(tm & ((1ull << lane) - 1ull))] = tid;
+    uint64_t touch = __ballot(lb < bmax);   // bmax == -2 where the lane has no bucket
+    if (trace) { const unsigned long long t = __builtin_readcyclecounter(); t_test += t - t_mark; t_mark = t; n_touched += __popcll(touch); }
+    if (touch) {
+      const bool mine = (touch >> wlane) & 1ull;
+      while (touch) {
+        const int l0 = __builtin_ctzll(touch);
+        touch &= touch - 1;
+        const bool two = touch != 0;
+        const int l1 = two ? __builtin_ctzll(touch) : l0;
+        touch &= touch - 1;   // (0 & ~0 stays 0)
+        StreamRows ra, rb;
+        fetch(l0, ra);
+        if (two) fetch(l1, rb);
+        fold(l0, ra, true, false, x1, y1, z1);
+        if (two) fold(l1, rb, true, false, x1, y1, z1);
+      }
+      if (trace) { const unsigned long long t = __builtin_readcyclecounter(); t_buckets += t - t_mark; t_mark = t; }
+      // running distances only fall: while the bucket holding the wave's candidate is untouched, the candidate stands
+      if (mine) wave_best();
+      if (trace) { const unsigned long long t = __builtin_readcyclecounter(); t_best += t - t_mark; t_mark = t; }
     }
-    __syncthreads();
-    // 2. the waves share the touched buckets
-    const int nt = s_count[buf];
-    for (int i = w; i < nt; i += 16) process(s_list[i], true, x1, y1, z1);
-    if (tid == 0) s_count[buf ^ 1] = 0;
-    __syncthreads();   // also orders the distance stores before the next round's loads (same CU, workgroup scope)
-    // 3. arg-max over the bucket states: one per thread, wave reduction, 16 wave candidates
-    const float v = s_max[tid];
-    const uint32_t pv = s_prio[tid];
-    const float wm = wave_max_f32(v);
-    const uint64_t top = __ballot(v == wm);
-    int wl = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(top)) - 1);
-    uint32_t wp = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(pv), wl));
-    if (top & (top - 1)) {
-      wp = wave_min_u32(v == wm ? pv : 0xffffffffu);
-      wl = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(__ballot(v == wm && pv == wp))) - 1);
+    const int buf = j & 1;
+    if (lane == 0) {
+      *reinterpret_cast<uint4*>(&s_wave[buf][w][0]) = make_uint4(wbits, wprio, __float_as_uint(wcx), __float_as_uint(wcy));
+      s_wave[buf][w][4] = __float_as_uint(wcz);
     }
-    if (lane == 0) *reinterpret_cast<uint4*>(&s_wave[w][0]) = make_uint4(__float_as_uint(fmaxf(wm, 0.f)), wp, static_cast<uint32_t>(w * 64 + wl), 0u);
-    __syncthreads();
-    const uint4 c = lane < 16 ? *reinterpret_cast<const uint4*>(&s_wave[lane][0]) : make_uint4(0u, 0xffffffffu, 0u, 0u);
+    lds_barrier();   // the waves talk through LDS only; a bucket's distances are read and written by its own wave alone
+    if (trace) { const unsigned long long t = __builtin_readcyclecounter(); t_barrier += t - t_mark; t_mark = t; }
+    const uint4 c = lane < kStreamWaves ? *reinterpret_cast<const uint4*>(&s_wave[buf][lane][0]) : make_uint4(0u, 0xffffffffu, 0u, 0u);
+    const uint32_t cz_bits = lane < kStreamWaves ? s_wave[buf][lane][4] : 0u;
     const float gmax = lane_f(row_max_f32(__uint_as_float(c.x)), 0);
-    const uint64_t gtop = __ballot(lane < 16 && __uint_as_float(c.x) == gmax);
+    const uint64_t gtop = __ballot(lane < kStreamWaves && __uint_as_float(c.x) == gmax);
     int gw = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(gtop)) - 1);
     uint32_t gprio = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(c.y), gw));
     if (gtop & (gtop - 1)) {
       gprio = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(row_min_u32(__uint_as_float(c.x) == gmax ? c.y : 0xffffffffu)), 0));
-      gw = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(__ballot(lane < 16 && __uint_as_float(c.x) == gmax && c.y == gprio))) - 1);
+      gw = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(__ballot(lane < kStreamWaves && __uint_as_float(c.x) == gmax && c.y == gprio))) - 1);
     }
-    const int gb = __builtin_amdgcn_readlane(static_cast<int>(c.z), gw);
-    const float4 p = *reinterpret_cast<const float4*>(&s_cand[gb][0]);
-    x1 = p.x; y1 = p.y; z1 = p.z;
+    x1 = __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(c.z), gw)));
+    y1 = __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(c.w), gw)));
+    z1 = __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cz_bits), gw)));
     if (tid == 0) idxs[j] = index_of(gprio);
-    // s_wave is rewritten only after the next round's two barriers: no fourth barrier needed
+    if (trace) t_pick += __builtin_readcyclecounter() - t_mark;
+  }
+  if (trace && lane == 0 && b == 0) {
+    unsigned long long* t = trace + w * 8;
+    t[0] = t_test; t[1] = t_buckets; t[2] = t_best; t[3] = t_barrier; t[4] = t_pick; t[5] = n_touched; t[6] = static_cast<unsigned long long>(m); t[7] = static_cast<unsigned long long>(nb);
   }
 }
 
@@ -1277,6 +1317,10 @@ extern "C" int fv2p_group_points_stack_grad(int b, int m, int c, int n, int nsam
 
 // measured on MI355X: 1.43-1.52 us/round against 1.62 for the plain kernel at n = 16384; the Morton pre-pass (bbox, keys,
 // 3-4 radix passes) costs ~0.15 ms, so short sampling runs stay on the plain kernel
+static unsigned long long* g_fps_trace = nullptr;
+// test hook: the streaming sampler writes, for sample 0, trace[8 * wave + {0..7}] = clocks in {box test, touched buckets, wave arg-max,
+// candidate exchange + barrier, winner selection}, touched buckets summed over the rounds, rounds, buckets.  NULL switches it off.
+extern "C" int fv2p_fps_set_trace(unsigned long long* trace) { g_fps_trace = trace; return 0; }
 static bool fps_bucketed_applies(int n, int m) { return n >= 2048 && n <= 1024 * kStreamBucket && m >= 256; }
 
 extern "C" size_t fv2p_furthest_point_sampling_ws_bytes(int b, int n) {
@@ -1317,7 +1361,7 @@ extern "C" int fv2p_furthest_point_sampling(int b, int n, int m, const float* da
       float *sy = sx + total, *sz = sy + total, *sd = sz + total;
       uint32_t* sp = reinterpret_cast<uint32_t*>(sd + total);
       hipLaunchKernelGGL(fps_stream_prep_k, G1D(total), 0, st, total, n, dataset, temp, keys, bs, sx, sy, sz, sd, sp);
-      hipLaunchKernelGGL(fps_stream_k, dim3(b), dim3(1024), 0, st, n, m, bs, dataset, sx, sy, sz, sd, sp, idxs);
+      hipLaunchKernelGGL(fps_stream_k, dim3(b), dim3(kStreamWaves * 64), 0, st, n, m, bs, dataset, sx, sy, sz, sd, sp, idxs, g_fps_trace);
       hipLaunchKernelGGL(fps_stream_post_k, G1D(total), 0, st, total, n, keys, sd, temp);
       FV2P_LAUNCH_CHECK();
       return 0;

@@ -3,10 +3,20 @@
 // Replaces DCN.deform_psroi_pooling_forward / _backward
 // (pcdet/ops/DeformableConvolutionV2PyTorch/src/vision.cpp:11-12 -> src/deform_psroi_pooling.h ->
 // src/cuda/deform_psroi_pooling_cuda.cu:264-418, kernels :59-147 forward, :149-262 backward).
-// Arithmetic is the reference's, operation for operation in fp32 and without contraction: RoI corners rounded half away
-// from zero, scaled, moved by -0.5; a bin is `sample_per_part`^2 bilinear samples of ONE channel plane (floor / ceil
-// corners of the clamped position), samples outside [-0.5, size - 0.5] are skipped and the bin is the mean of the rest;
-// the learned shift of a bin is trans[n, 2*class + {0,1}, part_h, part_w] * trans_std * RoI size.
+// Arithmetic follows the reference's expression by expression: RoI corners rounded half away from zero, scaled, moved by -0.5;
+// a bin is `sample_per_part`^2 bilinear samples of ONE channel plane (floor / ceil corners of the clamped position), samples
+// outside [-0.5, size - 0.5] are skipped and the bin is the mean of the rest; the learned shift of a bin is
+// trans[n, 2*class + {0,1}, part_h, part_w] * trans_std * RoI size.
+// The reference writes several of these with double literals in float code (`round(x) * scale - 0.5`, `max(d, 0.1)`, `w < -0.5`,
+// `min(max(w, 0.), width - 1.)`, :88-96, :131-136), which C++ evaluates in double and rounds once on assignment.  Each of them is a
+// SINGLE operation on float operands whose double result is then rounded to float — (double)(a*b) - 0.5, a comparison against an
+// exactly representable bound, a min / max that returns one of its arguments, and max(d, 0.1): no float lies in [0.1, 0.1f) — so the
+// float operation written here gives the same float (IEEE: one correctly rounded operation).  What is NOT pinned is contraction: nvcc
+// may fuse `wstart + iw * sub_bin` and the bilinear blend into FMAs (its default), this file is built with -ffp-contract=off; a
+// sample within one ulp of a bin border can then take the other corner.  tests/test_psroi_gpu.py::test_samples_on_bin_borders_and_on_the_map_limits holds the exact cases.
+// group_size: the reference's Python asserts channels == output_dim (modules/deform_psroi_pooling.py), which leaves only
+// group_size == 1 usable; ps_check accepts the kernel's own condition (channels == output_dim * group_size^2) and the Python layer
+// repeats the reference's assert.
 // Layout stays the reference's NCHW: every bin samples one plane, and neighbouring lanes are neighbouring bins of the
 // same plane, so their taps fall into the same few cache lines.
 // What differs from the reference's launch: the grid covers every bin once (no 4096-block cap with a grid-stride loop),

@@ -14,10 +14,13 @@
 // 16j + 4g .. + 3 of sample row r as the B operand receives the channels 16b + 4g .. + 3 of the same row in its accumulators,
 // i.e. results have the operand layout and chain into the next product (backward: dh1^T = W2^T dh2^T) without any shuffle.
 //
-// Backward recomputes h1 / h2 (nothing but `out` was stored), routes d out to the samples that attain the maximum (evenly
-// among exact ties, as torch.amax; tied samples are repeats of one point here: ball query pads with the first hit), and
-// produces dP (scatter-add into an LDS tile per RoI and 32-channel half, flushed once), dQ (row sums, direct stores) and
-// dW2 (MFMA over the sample rows after an LDS transpose; one partial tile per workgroup, summed by a second launch).
+// The forward pass also stores, per centre and channel, WHICH sample attained the maximum (one byte; the first one in sample
+// order, as the reference's F.max_pool2d does, pointnet2_modules.py:57-59; 255 = the maximum is 0, no gradient).  Backward
+// recomputes h1 only (a gather and a subtraction), routes d out to that sample, and produces dP (scatter-add into an LDS tile
+// per RoI and 32-channel half, flushed once), dQ (row sums, direct stores) and dW2 (MFMA over the sample rows after an LDS
+// transpose; one partial tile per workgroup, summed by a second launch).  Rounds 1-2 stored nothing but `out` and recomputed
+// h2 to find the maxima again: half of the backward pass's MFMA work (64 of 128 per 16-sample tile), twice — once per
+// channel half.
 #include "common.hpp"
 
 namespace fv2p {
@@ -248,7 +251,8 @@ __device__ __forceinline__ float4 relu_sub(float4 p, float4 q) {
 // ------------------------------------------------------------------ forward ---------------------------------------------------
 // grid (ceil(M / 16), R), block 256: wave w handles centres 16 * blockIdx.x + w, w + 4, ...
 __global__ __launch_bounds__(256) void sa_grid_fwd_k(int n, int m, int s, const float* __restrict__ P, const float* __restrict__ Q,
-                                                     const int* __restrict__ idx, const float* __restrict__ W2, float* __restrict__ out) {
+                                                     const int* __restrict__ idx, const float* __restrict__ W2, float* __restrict__ out,
+                                                     unsigned char* __restrict__ arg) {
   __shared__ __attribute__((aligned(16))) float wfrag[16 * 64 * 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 15, g = lane >> 4;
   const int r = blockIdx.y;
@@ -264,6 +268,7 @@ __global__ __launch_bounds__(256) void sa_grid_fwd_k(int n, int m, int s, const 
     for (int j = 0; j < 4; ++j) qv[j] = *reinterpret_cast<const float4*>(q + 16 * j);
     const int* id = idx + (static_cast<long long>(r) * m + i) * s;
     float best[4][4];
+    uint32_t late = 0;   // bit 4 b + e: this lane's best value of that channel came from the second tile (s <= 32)
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -280,7 +285,10 @@ __global__ __launch_bounds__(256) void sa_grid_fwd_k(int n, int m, int s, const 
 #pragma unroll
       for (int b = 0; b < 4; ++b)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) best[b][e] = fmaxf(best[b][e], acc[b][e]);
+        for (int e = 0; e < 4; ++e) {
+          if (t != 0 && acc[b][e] > best[b][e]) late |= 1u << (4 * b + e);   // strict: the earlier sample keeps a tie
+          best[b][e] = fmaxf(best[b][e], acc[b][e]);
+        }
     }
     // lane (row, g) holds channels 16 b + 4 g + e of sample row `row`: maximum over the 16 lanes of the DPP row
     float* o = out + (static_cast<long long>(r) * m + i) * kSaC + 4 * g;
@@ -294,30 +302,55 @@ __global__ __launch_bounds__(256) void sa_grid_fwd_k(int n, int m, int s, const 
 #pragma unroll
       for (int b = 0; b < 4; ++b) *reinterpret_cast<float4*>(o + 16 * b) = make_float4(flat[4 * b], flat[4 * b + 1], flat[4 * b + 2], flat[4 * b + 3]);
     }
+    if (arg) {
+      // first sample (in sample order) that attains the maximum: lanes holding it offer -(their sample number), the row maximum of
+      // that is the smallest number; a lane's own first is its first tile unless the second was strictly larger
+      float cand[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const bool holds = best[k >> 2][k & 3] == flat[k] && flat[k] > 0.f;
+        cand[k] = holds ? -static_cast<float>(((late >> k) & 1u) * 16u + static_cast<uint32_t>(row)) : -255.f;
+      }
+      row16_max_n(cand);
+      if (row == 0) {
+        unsigned char* a = arg + (static_cast<long long>(r) * m + i) * kSaC + 4 * g;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const uint32_t packed = static_cast<uint32_t>(-cand[4 * b]) | (static_cast<uint32_t>(-cand[4 * b + 1]) << 8) |
+                                  (static_cast<uint32_t>(-cand[4 * b + 2]) << 16) | (static_cast<uint32_t>(-cand[4 * b + 3]) << 24);
+          *reinterpret_cast<uint32_t*>(a + 16 * b) = packed;
+        }
+      }
+    }
   }
 }
 
 // ------------------------------------------------------------------ backward --------------------------------------------------
 // grid (2, R): workgroup (h, r) owns the channel half h of dP / dQ (channels 32 h .. 32 h + 31) and the row half h of dW2
-// (output channels c' in the same range) of RoI r; block 256, wave w takes centres w, w + 4, ...  S <= 32.
+// (output channels c' in the same range) of RoI r; block 512 (256), wave w takes centres w, w + 8 (4), ...  S <= 32.
 constexpr int kSaTs = 72;   // row stride of the transpose tiles (floats): 64 + 8, conflict-light both ways
 constexpr int kSaDp = 33;   // row stride of the dP tile (floats): odd, so the scatter's rows (arbitrary points) spread over all LDS banks —
                             // with 32 every row starts on bank 0 or 32 and a wave's 64 adds fall on 8 banks
-template <int TILES>         // samples per centre / 16: register arrays below are indexed by compile-time tile numbers only
-__global__ __launch_bounds__(256) void sa_grid_bwd_k(int n, int m, const float* __restrict__ P, const float* __restrict__ Q,
-                                                     const int* __restrict__ idx, const float* __restrict__ W2, const float* __restrict__ out,
+// kSaBwdWaves = 8 where the dP tile leaves room for eight waves' transpose tiles (n <= 589), two per SIMD: one wave's gathers, LDS
+// atomics and transposes run beside the other's MFMAs (one workgroup per CU either way: the dP tile); 4 above that.
+template <int TILES, int kSaBwdWaves>   // TILES = samples per centre / 16: register arrays below are indexed by compile-time tile numbers only
+__global__ __launch_bounds__(kSaBwdWaves * 64) void sa_grid_bwd_k(int n, int m, const float* __restrict__ P, const float* __restrict__ Q,
+                                                     const int* __restrict__ idx, const float* __restrict__ W2, const unsigned char* __restrict__ arg,
                                                      const float* __restrict__ dout, float* __restrict__ dP, float* __restrict__ dQ,
                                                      float* __restrict__ dW2_partial) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* wfrag = lds;                          // W2      as A operand (forward recompute)      16 KB
-  float* wtfrag = lds + 16 * 64 * 4;           // W2^T    as A operand (dh1^T = W2^T dh2^T)     16 KB
-  float* tile = wtfrag + 16 * 64 * 4;          // per wave: two 16 x 72 transpose tiles (dh2, h1)
-  float* dpt = tile + 4 * 2 * 16 * kSaTs;      // dP accumulator of this RoI and channel half: [n][kSaDp]
+  float* wtfrag = lds;                         // W2^T    as A operand (dh1^T = W2^T dh2^T), this half's two row blocks only: 8 KB
+  float* tile = wtfrag + 8 * 64 * 4;           // per wave: two 16 x 72 transpose tiles (dh2, h1)
+  float* dpt = tile + kSaBwdWaves * 2 * 16 * kSaTs;      // dP accumulator of this RoI and channel half: [n][kSaDp]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 15, g = lane >> 4;
   const int half = blockIdx.x, r = blockIdx.y;
-  stage_frag(W2, false, wfrag);
-  stage_frag(W2, true, wtfrag);
-  for (int e = threadIdx.x; e < n * kSaDp; e += 256) dpt[e] = 0.f;
+  // fragments [bb][j][lane] of W2^T rows 32 half + 16 bb + lane % 16, columns 16 j + 4 (lane / 16) .. + 3
+  for (int e = threadIdx.x; e < 8 * 64; e += kSaBwdWaves * 64) {
+    const int l = e & 63, bj = e >> 6, bb = bj >> 2, j = bj & 3;
+    const int rw = 32 * static_cast<int>(blockIdx.x) + 16 * bb + (l & 15), col = 16 * j + 4 * (l >> 4);
+    *reinterpret_cast<float4*>(wtfrag + e * 4) = make_float4(W2[(col + 0) * kSaC + rw], W2[(col + 1) * kSaC + rw], W2[(col + 2) * kSaC + rw], W2[(col + 3) * kSaC + rw]);
+  }
+  for (int e = threadIdx.x; e < n * kSaDp; e += kSaBwdWaves * 64) dpt[e] = 0.f;
   __syncthreads();
   float* t_dh2 = tile + wave * 2 * 16 * kSaTs;
   float* t_h1 = t_dh2 + 16 * kSaTs;
@@ -329,25 +362,19 @@ __global__ __launch_bounds__(256) void sa_grid_bwd_k(int n, int m, const float* 
 #pragma unroll
     for (int bc = 0; bc < 4; ++bc) dw[bb][bc] = f32x4{0.f, 0.f, 0.f, 0.f};
   constexpr int s = TILES * 16;
-  for (int i = wave; i < m; i += 4) {
+  for (int i = wave; i < m; i += kSaBwdWaves) {
     const float* q = Q + (static_cast<long long>(r) * m + i) * kSaC + 4 * g;
     float4 qv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) qv[j] = *reinterpret_cast<const float4*>(q + 16 * j);
     const int* id = idx + (static_cast<long long>(r) * m + i) * s;
-    const float* o = out + (static_cast<long long>(r) * m + i) * kSaC + 4 * g;
+    const unsigned char* am = arg + (static_cast<long long>(r) * m + i) * kSaC + 4 * g;
     const float* go = dout + (static_cast<long long>(r) * m + i) * kSaC + 4 * g;
-    // pass 1: recompute h2, count the samples that attain the stored maximum (per channel)
-    float cnt[4][4];
+    uint32_t who[4];   // byte e of who[b]: the sample that attained the maximum of channel 16 b + 4 g + e (255: none)
+    float4 gd[4];
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) cnt[b][e] = 0.f;
-    float4 mx[4], gd[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) { mx[b] = *reinterpret_cast<const float4*>(o + 16 * b); gd[b] = *reinterpret_cast<const float4*>(go + 16 * b); }
+    for (int b = 0; b < 4; ++b) { who[b] = *reinterpret_cast<const uint32_t*>(am + 16 * b); gd[b] = *reinterpret_cast<const float4*>(go + 16 * b); }
     float4 x[TILES][4];
-    f32x4 h2[TILES][4];
     int src[TILES];
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
@@ -355,27 +382,6 @@ __global__ __launch_bounds__(256) void sa_grid_bwd_k(int n, int m, const float* 
       const float* p = Pr + static_cast<long long>(src[t]) * kSaC + 4 * g;
 #pragma unroll
       for (int j = 0; j < 4; ++j) x[t][j] = relu_sub(*reinterpret_cast<const float4*>(p + 16 * j), qv[j]);
-#pragma unroll
-      for (int b = 0; b < 4; ++b) h2[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-      mma64(wfrag, lane, x[t], h2[t]);
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const float mv[4] = {mx[b].x, mx[b].y, mx[b].z, mx[b].w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) cnt[b][e] += (h2[t][b][e] == mv[e] && mv[e] > 0.f) ? 1.f : 0.f;
-      }
-    }
-    {
-      float flat[16];
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) flat[4 * b + e] = cnt[b][e];
-      row16_sum_n(flat);
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) cnt[b][e] = flat[4 * b + e];
     }
     // pass 2 per tile: dh2, dh1 = (W2^T dh2) * [h1 > 0], scatter / reduce, dW2 += dh2^T h1
     float dq[2][4];
@@ -388,18 +394,18 @@ __global__ __launch_bounds__(256) void sa_grid_bwd_k(int n, int m, const float* 
       float4 dh2[4];
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        const float mv[4] = {mx[b].x, mx[b].y, mx[b].z, mx[b].w}, gv[4] = {gd[b].x, gd[b].y, gd[b].z, gd[b].w};
+        const float gv[4] = {gd[b].x, gd[b].y, gd[b].z, gd[b].w};
         float d[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) d[e] = (h2[t][b][e] == mv[e] && mv[e] > 0.f) ? gv[e] / cnt[b][e] : 0.f;
+        for (int e = 0; e < 4; ++e) d[e] = ((who[b] >> (8 * e)) & 0xffu) == static_cast<uint32_t>(16 * t + row) ? gv[e] : 0.f;
         dh2[b] = make_float4(d[0], d[1], d[2], d[3]);
       }
       // dh1^T block bb of this half: channels 32 half + 16 bb + 4 g + e
       f32x4 d1[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float4 a0 = *reinterpret_cast<const float4*>(wtfrag + (((2 * half) * 4 + j) * 64 + lane) * 4);
-        const float4 a1 = *reinterpret_cast<const float4*>(wtfrag + (((2 * half + 1) * 4 + j) * 64 + lane) * 4);
+        const float4 a0 = *reinterpret_cast<const float4*>(wtfrag + ((0 * 4 + j) * 64 + lane) * 4);
+        const float4 a1 = *reinterpret_cast<const float4*>(wtfrag + ((1 * 4 + j) * 64 + lane) * 4);
         d1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, dh2[j].x, d1[0], 0, 0, 0);
         d1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, dh2[j].x, d1[1], 0, 0, 0);
         d1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, dh2[j].y, d1[0], 0, 0, 0);
@@ -456,16 +462,14 @@ __global__ __launch_bounds__(256) void sa_grid_bwd_k(int n, int m, const float* 
   __syncthreads();
   // flush dP (each (RoI, half) tile is owned by this workgroup: plain stores)
   float* dpo = dP + static_cast<long long>(r) * n * kSaC + 32 * half;
-  for (int e = threadIdx.x; e < n * 8; e += 256) {
+  for (int e = threadIdx.x; e < n * 8; e += kSaBwdWaves * 64) {
     const int pt = e >> 3, c4 = (e & 7) * 4;
     const float* t4 = dpt + pt * kSaDp + c4;
     *reinterpret_cast<float4*>(dpo + static_cast<long long>(pt) * kSaC + c4) = make_float4(t4[0], t4[1], t4[2], t4[3]);
   }
-  // dW2 partial of this workgroup: the four waves' accumulators summed through LDS (the transpose tiles are free now)
-  float* red = tile;   // [4 waves][2][4][256] floats = 32 KB > tile space: reuse wfrag + wtfrag as well (all waves are past them)
+  // dW2 partial of this workgroup: the waves' accumulators summed through LDS (the transpose tiles are free now)
   __syncthreads();
-  float* buf = lds;    // 32 KB of fragments + tiles: enough for 4 x 2 x 4 x 64 x 4 floats = 32 KB
-  (void)red;
+  float* buf = lds;    // fragments + tiles (8 + 74 KB, all waves are past them): room for 8 waves x 2 x 4 x 64 x 4 floats = 64 KB
 #pragma unroll
   for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
@@ -474,11 +478,11 @@ __global__ __launch_bounds__(256) void sa_grid_bwd_k(int n, int m, const float* 
   __syncthreads();
   // accumulator (bb, bc) of lane l holds dW2[32 half + 16 bb + 4 (l / 16) + e][16 bc + l % 16]
   float* dwo = dW2_partial + (static_cast<long long>(r) * 2 + half) * 32 * kSaC;
-  for (int e = threadIdx.x; e < 2 * 4 * 64 * 4; e += 256) {
+  for (int e = threadIdx.x; e < 2 * 4 * 64 * 4; e += kSaBwdWaves * 64) {
     const int comp = e & 3, l = (e >> 2) & 63, bc = (e >> 8) & 3, bb = e >> 10;
     float v = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) v += buf[(((w * 2 + bb) * 4 + bc) * 64 + l) * 4 + comp];
+    for (int w = 0; w < kSaBwdWaves; ++w) v += buf[(((w * 2 + bb) * 4 + bc) * 64 + l) * 4 + comp];
     dwo[(16 * bb + 4 * (l >> 4) + comp) * kSaC + 16 * bc + (l & 15)] = v;
   }
 }
@@ -501,15 +505,15 @@ static bool sa_shapes_ok(int rois, int n, int m, int s, int c) {
 }
 
 extern "C" int fv2p_sa_grid_supported(int n, int m, int s, int c) {
-  return (c == kSaC && (s == 16 || s == 32) && n >= 1 && m >= 1 && static_cast<size_t>(n) * kSaDp * 4 <= 84 * 1024) ? 1 : 0;   // backward: 69 KB of fragments / tiles + the dP tile within 160 KB of LDS
+  return (c == kSaC && (s == 16 || s == 32) && n >= 1 && m >= 1 && static_cast<size_t>(n) * kSaDp * 4 <= 114 * 1024) ? 1 : 0;   // backward: 45 KB of fragments / tiles (four waves) + the dP tile within 160 KB of LDS
 }
 
 extern "C" int fv2p_sa_grid_fwd(const float* per_point, const float* per_centre, const int* idx, const float* w2, int rois, int n, int m,
-                                int s, int c, float* out, fv2p_stream_t stream) {
+                                int s, int c, float* out, unsigned char* arg, fv2p_stream_t stream) {
   FV2P_REQUIRE(sa_shapes_ok(rois, n, m, s, c), FV2P_EINVAL, "sa_grid: needs 64 channels and 16 or 32 samples per centre");
   FV2P_REQUIRE(per_point && per_centre && idx && w2 && out, FV2P_EINVAL, "sa_grid_fwd: null pointer");
   hipLaunchKernelGGL(sa_grid_fwd_k, dim3(static_cast<unsigned>(ceil_div(m, kSaCentres)), rois), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     n, m, s, per_point, per_centre, idx, w2, out);
+                     n, m, s, per_point, per_centre, idx, w2, out, arg);
   FV2P_LAUNCH_CHECK();
   return 0;
 }
@@ -520,24 +524,32 @@ extern "C" size_t fv2p_sa_grid_bwd_ws_bytes(int rois) {
   return sz.bytes();
 }
 
-extern "C" int fv2p_sa_grid_bwd(const float* per_point, const float* per_centre, const int* idx, const float* w2, const float* out,
+extern "C" int fv2p_sa_grid_bwd(const float* per_point, const float* per_centre, const int* idx, const float* w2, const unsigned char* arg,
                                 const float* grad_out, int rois, int n, int m, int s, int c, float* grad_point, float* grad_centre,
                                 float* grad_w2, void* ws, size_t ws_bytes, fv2p_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   FV2P_REQUIRE(sa_shapes_ok(rois, n, m, s, c) && fv2p_sa_grid_supported(n, m, s, c), FV2P_EINVAL, "sa_grid_bwd: unsupported shape");
-  FV2P_REQUIRE(per_point && per_centre && idx && w2 && out && grad_out && grad_point && grad_centre && grad_w2, FV2P_EINVAL, "sa_grid_bwd: null pointer");
+  FV2P_REQUIRE(per_point && per_centre && idx && w2 && arg && grad_out && grad_point && grad_centre && grad_w2, FV2P_EINVAL, "sa_grid_bwd: null pointer");
   FV2P_REQUIRE(ws && ws_bytes >= fv2p_sa_grid_bwd_ws_bytes(rois), FV2P_EWORKSPACE, "sa_grid_bwd: workspace too small");
   Carver cv(ws, ws_bytes);
   float* partial = cv.take<float>(static_cast<size_t>(rois) * kSaC * kSaC);
-  const size_t lds = (2 * 16 * 64 * 4 + 4 * 2 * 16 * kSaTs + static_cast<size_t>(n) * kSaDp) * sizeof(float);
-  static size_t attr_for = 0;
-  if (lds > 48 * 1024 && lds > attr_for) {
-    FV2P_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sa_grid_bwd_k<1>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    FV2P_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sa_grid_bwd_k<2>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    attr_for = lds;
-  }
-  if (s == 16) hipLaunchKernelGGL(sa_grid_bwd_k<1>, dim3(2, rois), dim3(256), lds, stream, n, m, per_point, per_centre, idx, w2, out, grad_out, grad_point, grad_centre, partial);
-  else hipLaunchKernelGGL(sa_grid_bwd_k<2>, dim3(2, rois), dim3(256), lds, stream, n, m, per_point, per_centre, idx, w2, out, grad_out, grad_point, grad_centre, partial);
+  auto lds_of = [&](int waves) { return (8 * 64 * 4 + static_cast<size_t>(waves) * 2 * 16 * kSaTs + static_cast<size_t>(n) * kSaDp) * sizeof(float); };
+  const int waves = lds_of(8) <= 160 * 1024 ? 8 : 4;
+  const size_t lds = lds_of(waves);
+  static bool roomy[4] = {false, false, false, false};   // per kernel instance: the dynamic-LDS limit is raised once
+  bool& raised = roomy[(s == 32 ? 2 : 0) + (waves == 8 ? 1 : 0)];
+  auto launch = [&](auto kernel) -> int {
+    if (lds > 48 * 1024 && !raised) {
+      FV2P_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      raised = true;
+    }
+    hipLaunchKernelGGL(kernel, dim3(2, rois), dim3(waves * 64), lds, stream, n, m, per_point, per_centre, idx, w2, arg, grad_out, grad_point, grad_centre, partial);
+    return 0;
+  };
+  int rc;
+  if (s == 16) rc = waves == 8 ? launch(&sa_grid_bwd_k<1, 8>) : launch(&sa_grid_bwd_k<1, 4>);
+  else rc = waves == 8 ? launch(&sa_grid_bwd_k<2, 8>) : launch(&sa_grid_bwd_k<2, 4>);
+  if (rc) return rc;
   hipLaunchKernelGGL(sa_grid_dw_reduce_k, dim3(16), dim3(256), 0, stream, rois, partial, grad_w2);
   FV2P_LAUNCH_CHECK();
   return 0;

@@ -54,9 +54,10 @@ def _fps(saved, xyz, npoint):
     return idx
 
 
-# known points below which the tiled scan stays ahead of building a grid (measured, profiles/r03_microbench_nn.txt: at the KITTI levels,
-# 5 - 35 k voxel centres for 49 152 queries, the scan takes 84 - 492 us and the grid 170 - 1 350 us — nine launches to build it and
-# latency-bound walks; at the Waymo levels, 24 - 110 k centres, the grid takes 108 - 419 us against 339 - 1 525 us)
+# known points PER SAMPLE below which the tiled scan stays ahead of building a grid (measured, profiles/r03_microbench_nn.txt: at the
+# KITTI levels, 5 - 35 k voxel centres over four samples for 49 152 queries, the scan takes 84 - 492 us and the grid 170 - 1 850 us — the
+# scan's cost goes with the sample's own points, the grid pays nine launches and 2 M cells to clear and scan; at the Waymo levels,
+# 24 - 110 k centres in one sample, the grid takes 108 - 419 us against 339 - 1 525 us)
 GRID_MIN_KNOWN = 20000
 
 
@@ -69,7 +70,7 @@ def _three_nn(saved, unknown, unknown_batch_cnt, known, known_batch_cnt, cell=No
     d2 = torch.zeros_like(unknown)
     idx = torch.zeros(unknown.shape, dtype=torch.int32, device=unknown.device)
     nb = len(unknown_batch_cnt)
-    if known.shape[0] >= GRID_MIN_KNOWN and nb <= 64 and os.environ.get("FV2P_NN_GRID", "1") != "0":
+    if known.shape[0] >= GRID_MIN_KNOWN * nb and nb <= 64 and os.environ.get("FV2P_NN_GRID", "1") != "0":
         ws = G.scratch("fv2p_three_nn_grid_ws_bytes", unknown.device, nb, known.shape[0])
         G.run("fv2p_three_nn_stack_grid", nb, unknown.shape[0], known.shape[0], unknown.contiguous(), _cnt(unknown_batch_cnt),
               known.contiguous(), _cnt(known_batch_cnt), float(cell) if cell else 0.0, d2, idx, ws, ws.numel())

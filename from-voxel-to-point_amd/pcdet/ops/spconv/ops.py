@@ -46,7 +46,7 @@ def alloc_table(kvol, n, device):
 
 
 _PLAN_CHANNELS = (64, 128)   # source channel counts whose conv kernel (conv_rows_ksplit) takes a tiling plan
-PLAN_FROM_REQUEST = 2        # a table gets its plan when the N-th conv asks for one (1: at once — tests, ahead-of-time builders)
+PLAN_FROM_REQUEST = 3        # a table gets its plan when the N-th FORWARD conv asks for one (1: at once — tests, ahead-of-time builders)
 TAB_FLIP, TAB_PLANNED = 1, 2
 
 
@@ -70,28 +70,31 @@ class Rulebook(object):
     # -- tables as the kernels want them: (table, flag word: TAB_FLIP | TAB_PLANNED)
     def out_table(self, c_src=None):
         if self.tab_out is None:
-            return (self.tab_in, TAB_FLIP | self._plan("tab_in", c_src))   # pairs per row are the same under the flip
-        return (self.tab_out, self._plan("tab_out", c_src))
+            return (self.tab_in, TAB_FLIP | self._plan("tab_in", c_src, True))   # pairs per row are the same under the flip
+        return (self.tab_out, self._plan("tab_out", c_src, True))
 
     def in_table(self, c_src=None):
-        return (self.tab_in, self._plan("tab_in", c_src))
+        return (self.tab_in, self._plan("tab_in", c_src, False))
 
     def build_plan(self):
         """Builds the tiling plan of a submanifold rulebook now (input pipelines call it off the training stream)."""
         if self.subm and "tab_in" not in self.__dict__.get("_planned", {}):
             self.__dict__.setdefault("_plan_requests", {})["tab_in"] = PLAN_FROM_REQUEST
-            self._plan("tab_in", _PLAN_CHANNELS[0])
+            self._plan("tab_in", _PLAN_CHANNELS[0], True)
 
-    def _plan(self, which, c_src):
-        """TAB_PLANNED once the table carries a tiling plan; built on the first conv with `c_src` source channels that can
-        use one, when the table was allocated with room behind it (alloc_table)."""
+    def _plan(self, which, c_src, forward):
+        """TAB_PLANNED once the table carries a tiling plan; built when the PLAN_FROM_REQUEST-th forward conv with `c_src` source
+        channels that can use one asks, if the table was allocated with room behind it (alloc_table)."""
         done = self.__dict__.setdefault("_planned", {})
         if which in done:
             return done[which]
-        if c_src not in _PLAN_CHANNELS or not self.subm:
-            return 0       # strided rulebooks serve one forward and one backward conv: a plan (~80 us to build) cannot pay for itself
-        # ... and a submanifold one pays from its second conv on (measured: 78 - 95 us per plan against 15 - 30 us saved per conv):
-        # the first conv on a table runs on equal-row tiles, the second request builds the plan (residual blocks issue eight per table)
+        if c_src not in _PLAN_CHANNELS or not self.subm or not forward:
+            return 0       # strided rulebooks serve one forward and one backward conv: a plan (55 - 70 us to build) cannot pay for itself
+        # ... and a submanifold one saves 10 - 18 us per conv (profiles/r03_microbench_conv_kitti.txt): the two residual blocks of a
+        # stage put four forward and four backward convs on one table — built at the third, the plan serves two + four of them (net
+        # ~25 - 50 us per table when built in line, all of it when an input pipeline builds it ahead, prefetch.py); the two convs per
+        # table of the plain backbone never pay for one (measured: 1.64 -> 2.04 ms per step with plans from the second conv on).
+        # Backward convs use a plan that is there and never cause one.
         uses = self.__dict__.setdefault("_plan_requests", {})
         uses[which] = uses.get(which, 0) + 1
         if uses[which] < PLAN_FROM_REQUEST:

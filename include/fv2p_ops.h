@@ -378,6 +378,10 @@ int fv2p_group_points_stack_grad(int b, int m, int c, int n, int nsample, const 
 size_t fv2p_furthest_point_sampling_ws_bytes(int b, int n);
 int fv2p_furthest_point_sampling(int b, int n, int m, const float* dataset, float* temp, int* idxs, void* ws,
                                  size_t ws_bytes, fv2p_stream_t stream);
+/* Profiling hook of the streaming sampler (n > 24 576): when non-NULL (device memory, 16 x 8 entries), sample 0 writes
+ * trace[8 * wave + {0..7}] = shader clocks spent in {box test, touched buckets, wave arg-max, candidate exchange + barrier,
+ * winner selection}, the touched buckets summed over the rounds, the rounds, the buckets.  NULL switches it off. */
+int fv2p_fps_set_trace(unsigned long long* trace);
 int fv2p_three_nn_batch(int b, int n, int m, const float* unknown, const float* known, float* dist2, int* idx,
                         fv2p_stream_t stream);
 int fv2p_three_nn_stack(int b, int n, int m, const float* unknown, const int* unknown_batch_cnt,
@@ -406,12 +410,16 @@ int fv2p_three_interpolate_stack_grad(int n, int c, const float* grad_out, const
  * bn=False module of IoUGuidedRoIHead (iouguided_roi_head.py:52-76) after its first, linear layer has been applied per point
  * and per centre:  out[r, i, :] = max_s relu(W2 relu(per_point[r, idx[r, i, s], :] - per_centre[r, i, :])).
  * per_point [rois, n, c], per_centre [rois, m, c], idx [rois, m, s] i32 (ball query output), w2 [c, c] (Conv2d weight),
- * out / grad_out [rois, m, c]; c = 64, s in {16, 32}.  No grouped tensor exists in either direction; backward recomputes. */
+ * out / grad_out [rois, m, c]; c = 64, s in {16, 32}.  No grouped tensor exists in either direction.
+ * arg [rois, m, c] u8 (forward: optional, may be NULL for inference; backward: required): the sample 0 .. s-1 that attained the
+ * maximum of (centre, channel) — the first one in sample order, which is where F.max_pool2d sends the gradient
+ * (pointnet2_modules.py:57-59) — or 255 where the maximum is 0 (ReLU inactive for every sample: no gradient).  Backward
+ * recomputes relu(per_point - per_centre) only. */
 int fv2p_sa_grid_supported(int n, int m, int s, int c);
 int fv2p_sa_grid_fwd(const float* per_point, const float* per_centre, const int* idx, const float* w2, int rois, int n, int m,
-                     int s, int c, float* out, fv2p_stream_t stream);
+                     int s, int c, float* out, unsigned char* arg, fv2p_stream_t stream);
 size_t fv2p_sa_grid_bwd_ws_bytes(int rois);
-int fv2p_sa_grid_bwd(const float* per_point, const float* per_centre, const int* idx, const float* w2, const float* out,
+int fv2p_sa_grid_bwd(const float* per_point, const float* per_centre, const int* idx, const float* w2, const unsigned char* arg,
                      const float* grad_out, int rois, int n, int m, int s, int c, float* grad_point, float* grad_centre,
                      float* grad_w2, void* ws, size_t ws_bytes, fv2p_stream_t stream);
 

@@ -36,6 +36,30 @@ CASES = [  # batch, channels, H, W, rois, pooled, part, classes, spp, trans_std,
 ]
 
 
+def test_samples_on_bin_borders_and_on_the_map_limits(gpu):
+    """RoIs whose samples fall EXACTLY on the limits of the inside test (w == -0.5, w == width - 0.5) and on integer pixel positions
+    (floor == ceil corner): integer corners on a power-of-two lattice, so every position is exact in float32 and in float64.  The
+    reference evaluates these tests with double literals (deform_psroi_pooling_cuda.cu:131-136), the kernel in float32 (psroi.hip
+    header: each is one correctly rounded operation) — counts and values must agree with the oracle run in either precision."""
+    h = w = 16
+    data = np.random.default_rng(5).standard_normal((1, 2, h, w)).astype(np.float32)
+    boxes = np.array([[0, 0, 0, 15, 15],        # start -0.5, end 7.5: bins of 2, samples -0.5, 0.5, ... (first one ON the lower limit)
+                      [0, 1, 1, 31, 31],        # start 0, end 15.5 (ON the upper limit of a 16-wide map after scaling)
+                      [0, -2, -2, 13, 13],      # start -1.5: first samples outside, then -0.5 exactly
+                      [0, 18, 18, 33, 33],      # start 8.5, unit steps: the last sample ON the upper limit 15.5 (inside)
+                      [0, 20, 20, 35, 35],      # start 9.5: the last sample at 16.5 (outside)
+                      [0, 7, 7, 7, 7]], np.float32)   # one pixel: 0.5 wide, bins of 0.125
+    conf = (1, 0.5, 2, 1, 4, 4, 2, 0.0)
+    want32, cnt32 = ps.deform_psroi_pooling_forward(data, boxes, None, True, *conf[1:])
+    want64, cnt64 = ps.deform_psroi_pooling_forward(data.astype(np.float64), boxes.astype(np.float64), None, True, *conf[1:])
+    assert np.array_equal(cnt32, cnt64)
+    d, b = torch.from_numpy(data).to(gpu), torch.from_numpy(boxes).to(gpu)
+    out, cnt = DCN.deform_psroi_pooling_forward(d, b, d.new(), *conf)
+    assert np.array_equal(cnt.cpu().numpy(), cnt64), "inside test on the limits differs"
+    assert 0 < (cnt64 < 4).mean() < 1
+    assert np.abs(out.cpu().numpy() - want64).max() < 1e-6
+
+
 @pytest.mark.parametrize("cfg", CASES)
 @pytest.mark.parametrize("no_trans", [False, True])
 def test_forward_and_backward_match_the_oracle(gpu, cfg, no_trans):

@@ -745,17 +745,24 @@ def test_tiling_plan_changes_no_bit(gpu, cin, cout, subm):
     assert exact_levels > 0 or n > 32767 or n < 1024
 
 
-def test_python_layer_plans_submanifold_tables_from_the_second_conv(gpu):
-    """ops.Rulebook._plan: no plan for strided rulebooks (two convs per table cannot repay ~80 us), none for the first conv on a
-    submanifold table, a plan from the second request on; build_plan() (input pipelines) builds it at once; other channel counts never."""
+def test_python_layer_plans_submanifold_tables_from_the_third_forward_conv(gpu):
+    """ops.Rulebook._plan: no plan for strided rulebooks (two convs per table cannot repay 55 - 70 us), none for the first two forward
+    convs on a submanifold table (the plain backbone's two per table never repay one), a plan from the third forward request on (the
+    residual blocks' four + four); backward convs use a plan that is there but never cause one; build_plan() (input pipelines)
+    builds it at once; other channel counts never."""
     ind, feats, x = make_input(5, 2, [9, 20, 18], 1500, 64, gpu)
     sub = ops.build_rulebook(x.indices, 2, [9, 20, 18], 3, 1, 1, 1, 0, True)
     strided = ops.build_rulebook(x.indices, 2, [9, 20, 18], 3, 2, 1, 1, 0, False)
-    assert not strided.out_table(64)[1] & ops.TAB_PLANNED and not strided.in_table(128)[1] & ops.TAB_PLANNED
+    for _ in range(4):
+        assert not strided.out_table(64)[1] & ops.TAB_PLANNED and not strided.in_table(128)[1] & ops.TAB_PLANNED
     assert not sub.out_table(32)[1] & ops.TAB_PLANNED
-    assert not sub.out_table(64)[1] & ops.TAB_PLANNED            # first request
-    assert sub.in_table(64)[1] & ops.TAB_PLANNED                 # second request (same table: submanifold symmetry)
-    assert sub.out_table(32)[1] & ops.TAB_PLANNED                # built: every later call carries the flag, kernels without plan support ignore it
+    assert not sub.out_table(64)[1] & ops.TAB_PLANNED            # first forward request
+    for _ in range(4):
+        assert not sub.in_table(64)[1] & ops.TAB_PLANNED         # backward requests do not count
+    assert not sub.out_table(64)[1] & ops.TAB_PLANNED            # second
+    assert sub.out_table(64)[1] & ops.TAB_PLANNED                # third: built
+    assert sub.in_table(64)[1] & ops.TAB_PLANNED                 # same table (submanifold symmetry): the backward convs get it too
+    assert sub.out_table(32)[1] & ops.TAB_PLANNED                # every later call carries the flag, kernels without plan support ignore it
     fresh = ops.build_rulebook(x.indices, 2, [9, 20, 18], 3, 1, 1, 1, 0, True)
     fresh.build_plan()
     assert fresh.out_table()[1] & ops.TAB_PLANNED

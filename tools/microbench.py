@@ -276,6 +276,28 @@ def fps():
         print(f"three_nn 16384 x {v}: {t:8.1f} us ({8.0 * 16384 * v / t / 1e6:6.2f} TFLOP/s)")
 
 
+def fpstrace():
+    """Where a round of the streaming sampler goes: clocks per phase and wave (fv2p_fps_set_trace)."""
+    import fv2p_native
+    from fv2p_harness import synth
+    from pcdet.ops.pointnet2.pointnet2_batch import pointnet2_utils as bu
+    dev = torch.device("cuda:0")
+    for n in (40000, 180000):
+        pts = torch.from_numpy(synth.waymo_like_cloud(0, n)[None, :, :3]).to(dev)
+        bu.furthest_point_sample(pts, 2048)
+        tr = torch.zeros(16 * 8, dtype=torch.int64, device=dev)
+        fv2p_native.call("fv2p_fps_set_trace", tr)
+        bu.furthest_point_sample(pts, 16384)
+        torch.cuda.synchronize()
+        fv2p_native.call("fv2p_fps_set_trace", None)
+        t = tr.cpu().numpy().reshape(16, 8).astype(np.float64)
+        rounds = t[0, 6]
+        print(f"n = {n}: {int(t[0, 7])} buckets, {int(rounds)} rounds; clocks per round and wave: box test, touched buckets, wave arg-max, exchange + barrier, pick | touched buckets per round")
+        for w in range(16):
+            print("  wave %2d: %7.1f %7.1f %7.1f %7.1f %7.1f | %5.2f" % ((w,) + tuple(t[w, :5] / rounds) + (t[w, 5] / rounds,)))
+        print("  mean   : %7.1f %7.1f %7.1f %7.1f %7.1f | %5.2f   sum %7.1f" % (tuple(t[:, :5].mean(0) / rounds) + (t[:, 5].mean() / rounds, t[:, :5].mean(0).sum() / rounds)))
+
+
 def nn():
     """Decoder-shaped 3-NN: 3 x 16384 key points (the clouds' own points) against the voxel centres of the four backbone levels,
     scan (fv2p_three_nn_stack) vs grid (fv2p_three_nn_stack_grid) with the lattice hint and with the library's own spacing estimate."""
@@ -505,7 +527,7 @@ if __name__ == "__main__":
     if which == "convone":
         conv(only=20)
         sys.exit(0)
-    for name, fn in (("conv", conv), ("dcn", dcn), ("fps", fps), ("nn", nn), ("nms", nms), ("sa", sa), ("bn", bn), ("bev", bev), ("oproof", oproof)):
+    for name, fn in (("conv", conv), ("dcn", dcn), ("fps", fps), ("fpstrace", fpstrace), ("nn", nn), ("nms", nms), ("sa", sa), ("bn", bn), ("bev", bev), ("oproof", oproof)):
         if which in (name, "all"):
             print(f"==== {name}")
             fn()
