@@ -714,91 +714,96 @@ __global__ __launch_bounds__(kFpsWaves * 64) void fps_wave_k(int n, int m, int b
 }
 
 // ---- streaming furthest point sampling (clouds too large for one CU's registers: n > 24576, e.g. Waymo's ~180 k) ----------
-// Same picks again, with the points left in memory: fps_wave_k with its register slots replaced by rows of a Morton-sorted SoA
-// copy (x, y, z, running distance, reference priority) that stays in L2.  A bucket is kStreamBucket = 256 consecutive points of
-// that order (<= 1024 buckets: one per thread of the 16 waves); bucket `bk` belongs to lane bk / 16 of wave bk % 16 — Morton
-// neighbours go to different waves, so the cluster of buckets a new point touches spreads over all of them.  The owner LANE
-// keeps the bucket's box, exact running maximum, the priority and the coordinates of the point that holds it in registers;
-// the owner WAVE is the only one that ever reads or writes the bucket's distances, so a round needs no list of touched
-// buckets, no LDS state and ONE barrier (the exchange of the 16 wave candidates, double buffered):
-//   box test per lane (exact skip: sqdist's operations in sqdist's order) -> ballot -> the wave walks its touched buckets two at
-//   a time (the loads of both in flight before the first distance pass: 2 x 4 rows x 5 arrays) -> bucket state back to its lane
-//   -> arg-max over the 64 lane states -> wave candidate to LDS -> barrier -> every wave derives the same winner.
+// Same picks again, with the points left in memory: fps_wave_k with its register slots replaced by a Morton-sorted SoA copy
+// (x, y, z, running distance, reference priority; every sample padded to whole buckets with points that never hold a maximum)
+// that stays in L2.  A bucket is kStreamBucket = 256 consecutive points of that order (<= 1024 buckets: one per thread of the 16
+// waves), four per lane: five 16-byte loads fetch it.  Bucket `bk` belongs to lane bk / 16 of wave bk % 16 — Morton neighbours
+// go to different waves, so the cluster of buckets a new point touches spreads over all of them.  The owner LANE keeps the
+// bucket's box, exact running maximum, the priority and the coordinates of the point that holds it in registers; the owner WAVE
+// is the only one that ever reads or writes the bucket's distances, so a round needs no list of touched buckets, no LDS state
+// and ONE barrier (the exchange of the 16 wave candidates, double buffered):
+//   box test per lane (exact skip: sqdist's operations in sqdist's order) -> ballot -> the wave walks its touched buckets three
+//   at a time (all their loads in flight before the first distance pass) -> bucket state back to its lane -> arg-max over the 64
+//   lane states -> wave candidate to LDS -> barrier -> every wave derives the same winner.
 // Round 2's form compacted the touched buckets into an LDS list between two extra barriers and kept the states in LDS
 // (2.1 us/round at n = 180 000); the kernel also claims its CU (>= 97 VGPRs at four waves per SIMD, v127 below): beside a
 // training step other workgroups shared the CU and stretched the sampler from 34.8 to 45.7 ms (profiles/README.md, round 2).
-__global__ void fps_stream_prep_k(int64_t total, int n, const float* __restrict__ dataset, const float* __restrict__ temp, const uint64_t* __restrict__ keys,
-                                  int bs, float* __restrict__ sx, float* __restrict__ sy, float* __restrict__ sz, float* __restrict__ sd,
-                                  uint32_t* __restrict__ sp) {
-  const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+__global__ void fps_stream_prep_k(int64_t total, int n, int ns, const float* __restrict__ dataset, const float* __restrict__ temp,
+                                  const uint64_t* __restrict__ keys, int bs, float* __restrict__ sx, float* __restrict__ sy, float* __restrict__ sz,
+                                  float* __restrict__ sd, uint32_t* __restrict__ sp) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;   // over the padded copies: ns = n rounded up to whole buckets
   if (t >= total) return;
+  const int64_t smp = t / ns;
+  const int pos = static_cast<int>(t - smp * ns);
+  if (pos >= n) {   // padding of the last bucket: a point that never holds a maximum (running distances are >= 0) and never moves
+    sx[t] = 0.f; sy[t] = 0.f; sz[t] = 0.f; sd[t] = -2.f; sp[t] = 0xffffffffu;
+    return;
+  }
   int log2bs = 0;
   while ((1 << (log2bs + 1)) <= bs) ++log2bs;
-  const int64_t smp = t / n;
-  const int k = static_cast<int>(keys[t] & 0xffffffull);
+  const int k = static_cast<int>(keys[smp * n + pos] & 0xffffffull);
   const float* p = dataset + (smp * n + k) * 3;
   sx[t] = p[0]; sy[t] = p[1]; sz[t] = p[2];
   sd[t] = temp[smp * n + k];
   const uint32_t owner = static_cast<uint32_t>(k) & static_cast<uint32_t>(bs - 1);
   sp[t] = ((__brev(owner) >> (32 - log2bs)) << 16) | static_cast<uint32_t>(k >> log2bs);
 }
-__global__ void fps_stream_post_k(int64_t total, int n, const uint64_t* __restrict__ keys, const float* __restrict__ sd, float* __restrict__ temp) {
+__global__ void fps_stream_post_k(int64_t total, int n, int ns, const uint64_t* __restrict__ keys, const float* __restrict__ sd, float* __restrict__ temp) {
   const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= total) return;
-  temp[(t / n) * n + static_cast<int>(keys[t] & 0xffffffull)] = sd[t];
+  const int64_t smp = t / n;
+  temp[smp * n + static_cast<int>(keys[t] & 0xffffffull)] = sd[smp * ns + (t - smp * n)];
 }
 
 constexpr int kStreamWaves = 16;
-constexpr int kStreamRows = 4;                      // rows of 64 points per bucket
-constexpr int kStreamBucket = 64 * kStreamRows;
-struct StreamRows { float x[kStreamRows], y[kStreamRows], z[kStreamRows], d[kStreamRows]; uint32_t p[kStreamRows]; };
+constexpr int kStreamBucket = 256;                  // points per bucket: four consecutive points per lane, one 16-byte load per array
+struct StreamRows { float4 x, y, z, d; uint4 p; };
 __global__ __launch_bounds__(kStreamWaves * 64) void fps_stream_k(int n, int m, int bs, const float* __restrict__ dataset,
                                                                   const float* __restrict__ sx_, const float* __restrict__ sy_,
                                                                   const float* __restrict__ sz_, float* __restrict__ sd_,
                                                                   const uint32_t* __restrict__ sp_, int* __restrict__ idxs,
                                                                   unsigned long long* __restrict__ trace) {
   if (m <= 0) return;
-  unsigned long long t_test = 0, t_buckets = 0, t_best = 0, t_barrier = 0, t_pick = 0, t_mark = 0, n_touched = 0;   // test hook: clocks per phase (fv2p_fps_set_trace)
+  unsigned long long t_test = 0, t_fetch = 0, t_first = 0, t_buckets = 0, t_best = 0, t_barrier = 0, t_pick = 0, t_mark = 0, n_touched = 0;   // test hook: clocks per phase (fv2p_fps_set_trace)
   asm volatile("v_mov_b32 v127, 0" ::: "v127");   // 128 VGPRs per wave x 4 waves per SIMD = the SIMD's register file: no other workgroup joins this CU
   __shared__ __attribute__((aligned(16))) uint32_t s_wave[2][kStreamWaves][8];   // candidate of every wave: max bits, priority, x, y, z, -
   int log2bs = 0;
   while ((1 << (log2bs + 1)) <= bs) ++log2bs;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int64_t base = static_cast<int64_t>(b) * n;
+  const int nb = (n + kStreamBucket - 1) / kStreamBucket;
+  const int64_t base = static_cast<int64_t>(b) * nb * kStreamBucket;   // the sorted copies are padded to whole buckets (fps_stream_prep_k)
   const float *sx = sx_ + base, *sy = sy_ + base, *sz = sz_ + base;
   float* sd = sd_ + base;
   const uint32_t* sp = sp_ + base;
-  dataset += base * 3;
+  dataset += static_cast<int64_t>(b) * n * 3;
   idxs += static_cast<int64_t>(b) * m;
-  const int nb = (n + kStreamBucket - 1) / kStreamBucket;
   auto index_of = [&](uint32_t pr) -> int { return static_cast<int>(((pr & 0xffffu) << log2bs) | (__brev(pr >> 16) >> (32 - log2bs))); };
   // my bucket (lane * 16 + w): box, running maximum (-2: no such bucket), priority and coordinates of the point holding it
   float lo0 = 0.f, lo1 = 0.f, lo2 = 0.f, hi0 = 0.f, hi1 = 0.f, hi2 = 0.f, bmax = -2.f, bcx = 0.f, bcy = 0.f, bcz = 0.f;
   uint32_t bprio = 0xffffffffu;
-  // rows of the bucket of lane `l` (wave-uniform): positions past n are clamped (no divergent load) and masked in `fold`
+  // the bucket of lane `l` (wave-uniform): five 16-byte loads per lane, 1 KB per wave instruction
   auto fetch = [&](int l, StreamRows& r) __attribute__((always_inline)) {
-    const int p0 = (l * kStreamWaves + w) * kStreamBucket + lane;
-#pragma unroll
-    for (int q = 0; q < kStreamRows; ++q) {
-      const int pc = min(p0 + q * 64, n - 1);
-      r.x[q] = sx[pc]; r.y[q] = sy[pc]; r.z[q] = sz[pc]; r.d[q] = sd[pc]; r.p[q] = sp[pc];
-    }
+    const int p0 = (l * kStreamWaves + w) * kStreamBucket + lane * 4;
+    r.x = *reinterpret_cast<const float4*>(sx + p0); r.y = *reinterpret_cast<const float4*>(sy + p0); r.z = *reinterpret_cast<const float4*>(sz + p0);
+    r.d = *reinterpret_cast<const float4*>(sd + p0); r.p = *reinterpret_cast<const uint4*>(sp + p0);
   };
   // distance pass (when `update`) and the bucket's exact (max, priority, coordinates) back into lane l's registers
   auto fold = [&](int l, StreamRows& r, bool update, bool boxes, float x1, float y1, float z1) __attribute__((always_inline)) {
-    const int p0 = (l * kStreamWaves + w) * kStreamBucket + lane;
-    float bv = -2.f, bx = 0.f, by = 0.f, bz = 0.f;
+    const int p0 = (l * kStreamWaves + w) * kStreamBucket + lane * 4;
+    const float xs[4] = {r.x.x, r.x.y, r.x.z, r.x.w}, ys[4] = {r.y.x, r.y.y, r.y.z, r.y.w}, zs[4] = {r.z.x, r.z.y, r.z.z, r.z.w};
+    const uint32_t ps[4] = {r.p.x, r.p.y, r.p.z, r.p.w};
+    float ds[4] = {r.d.x, r.d.y, r.d.z, r.d.w};
+    if (update) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ds[q] = fminf(sqdist(xs[q], ys[q], zs[q], x1, y1, z1), ds[q]);   // padding: min(., -2) stays -2
+      *reinterpret_cast<float4*>(sd + p0) = make_float4(ds[0], ds[1], ds[2], ds[3]);
+    }
+    float bv = -3.f, bx = 0.f, by = 0.f, bz = 0.f;
     uint32_t bp = 0xffffffffu;
 #pragma unroll
-    for (int q = 0; q < kStreamRows; ++q) {
-      const bool ok = p0 + q * 64 < n;
-      float d = r.d[q];
-      if (update) {
-        d = fminf(sqdist(r.x[q], r.y[q], r.z[q], x1, y1, z1), d);
-        if (ok) sd[p0 + q * 64] = d;
-      }
-      const bool better = ok & ((d > bv) | ((d == bv) & (r.p[q] < bp)));
-      bv = better ? d : bv; bp = better ? r.p[q] : bp; bx = better ? r.x[q] : bx; by = better ? r.y[q] : by; bz = better ? r.z[q] : bz;
+    for (int q = 0; q < 4; ++q) {
+      const bool better = (ds[q] > bv) | ((ds[q] == bv) & (ps[q] < bp));
+      bv = better ? ds[q] : bv; bp = better ? ps[q] : bp; bx = better ? xs[q] : bx; by = better ? ys[q] : by; bz = better ? zs[q] : bz;
     }
     const float mx = wave_max_f32(bv);
     const uint64_t holders = __ballot(bv == mx);
@@ -813,9 +818,9 @@ __global__ __launch_bounds__(kStreamWaves * 64) void fps_stream_k(int n, int m, 
     if (boxes) {
       float a0 = INFINITY, a1 = INFINITY, a2 = INFINITY, c0 = -INFINITY, c1 = -INFINITY, c2 = -INFINITY;
 #pragma unroll
-      for (int q = 0; q < kStreamRows; ++q)
-        if (p0 + q * 64 < n) {
-          a0 = fminf(a0, r.x[q]); c0 = fmaxf(c0, r.x[q]); a1 = fminf(a1, r.y[q]); c1 = fmaxf(c1, r.y[q]); a2 = fminf(a2, r.z[q]); c2 = fmaxf(c2, r.z[q]);
+      for (int q = 0; q < 4; ++q)
+        if (p0 + q < n) {
+          a0 = fminf(a0, xs[q]); c0 = fmaxf(c0, xs[q]); a1 = fminf(a1, ys[q]); c1 = fmaxf(c1, ys[q]); a2 = fminf(a2, zs[q]); c2 = fmaxf(c2, zs[q]);
         }
       a0 = wave_min_f32(a0); a1 = wave_min_f32(a1); a2 = wave_min_f32(a2);
       c0 = wave_max_f32(c0); c1 = wave_max_f32(c1); c2 = wave_max_f32(c2);
@@ -858,17 +863,24 @@ __global__ __launch_bounds__(kStreamWaves * 64) void fps_stream_k(int n, int m, 
     if (trace) { const unsigned long long t = __builtin_readcyclecounter(); t_test += t - t_mark; t_mark = t; n_touched += __popcll(touch); }
     if (touch) {
       const bool mine = (touch >> wlane) & 1ull;
-      while (touch) {
+      while (touch) {   // up to three buckets per pass: all their loads in flight before the first distance pass
         const int l0 = __builtin_ctzll(touch);
         touch &= touch - 1;
         const bool two = touch != 0;
         const int l1 = two ? __builtin_ctzll(touch) : l0;
         touch &= touch - 1;   // (0 & ~0 stays 0)
-        StreamRows ra, rb;
+        const bool three = touch != 0;
+        const int l2 = three ? __builtin_ctzll(touch) : l0;
+        touch &= touch - 1;
+        StreamRows ra, rb, rc;
         fetch(l0, ra);
         if (two) fetch(l1, rb);
+        if (three) fetch(l2, rc);
+        if (trace) { const unsigned long long t = __builtin_readcyclecounter(); t_fetch += t - t_mark; t_mark = t; }
         fold(l0, ra, true, false, x1, y1, z1);
+        if (trace) { const unsigned long long t = __builtin_readcyclecounter(); t_first += t - t_mark; t_mark = t; }
         if (two) fold(l1, rb, true, false, x1, y1, z1);
+        if (three) fold(l2, rc, true, false, x1, y1, z1);
       }
       if (trace) { const unsigned long long t = __builtin_readcyclecounter(); t_buckets += t - t_mark; t_mark = t; }
       // running distances only fall: while the bucket holding the wave's candidate is untouched, the candidate stands
@@ -900,7 +912,7 @@ __global__ __launch_bounds__(kStreamWaves * 64) void fps_stream_k(int n, int m, 
   }
   if (trace && lane == 0 && b == 0) {
     unsigned long long* t = trace + w * 8;
-    t[0] = t_test; t[1] = t_buckets; t[2] = t_best; t[3] = t_barrier; t[4] = t_pick; t[5] = n_touched; t[6] = static_cast<unsigned long long>(m); t[7] = static_cast<unsigned long long>(nb);
+    t[0] = t_test; t[1] = t_fetch; t[2] = t_first; t[3] = t_buckets; t[4] = t_best; t[5] = t_barrier; t[6] = t_pick; t[7] = n_touched;
   }
 }
 
@@ -1026,23 +1038,38 @@ __global__ __launch_bounds__(256) void three_nn_stack_k(int B, int N, const floa
   }
 }
 
-// ---- 3-NN through a uniform grid over the known points ----------------------------------------------------------------------------
+// ---- 3-NN through a hashed uniform grid over the known points ---------------------------------------------------------------------
 // The brute-force scan above costs 8 N_u N_k flops whatever the geometry (6.6 % of the vector peak at best, 0.9 ms per level at Waymo
 // size).  The decoder's known points are voxel centres: a query's three nearest sit within a cell or two of a grid whose spacing is a
 // couple of lattice steps.  Exactness (same idx and dist^2 as the scan, bit for bit): every candidate's distance is sqdist() — the
 // scan's float operations in the scan's order — the running best three are kept under the (distance, index) order, which is what
 // "strict < in ascending index order" produces, and the search stops only when every unseen point is provably farther than the third
 // best: after the block of cells within Chebyshev radius R around the query's cell, an unseen point is at least (R - 1e-3) cells away
-// (the 1e-3 covers the float rounding of the cell assignment).  Queries that would need more than kNNMaxRing rings scan their sample.
-constexpr int kNNCells = 1 << 19;      // cells per sample (the spacing grows until the grid fits)
-constexpr int kNNMaxRing = 6;
+// (the 1e-3 covers the float rounding of the cell assignment).  Queries the first block (R = 1) does not settle scan their sample, one
+// wave per query (nn_rest_k).  The cells live in an open-addressing hash table keyed by (sample, cell) — 2 slots per known point — so the spacing stays what the
+// caller asked for whatever the extent of the cloud (round 3's first form was a dense grid of 2^19 cells per sample: at KITTI extent
+// the spacing grew 3.5 x, a cell held ~60 points and the walk was 4 x slower than the scan it replaced).
+constexpr unsigned long long kNNEmpty = ~0ull;
 struct NNGeo { float lo[3]; float h, inv_h; int dim[3]; };
 
-__global__ __launch_bounds__(256) void nn_bbox_k(int B, const float* __restrict__ known, const int* __restrict__ known_cnt, float* __restrict__ bbox) {
+__device__ __forceinline__ unsigned int nn_hash(unsigned long long k) {   // 64-bit finaliser (splitmix), low bits taken by the caller
+  k ^= k >> 30; k *= 0xbf58476d1ce4e5b9ull;
+  k ^= k >> 27; k *= 0x94d049bb133111ebull;
+  k ^= k >> 31;
+  return static_cast<unsigned int>(k);
+}
+// per-sample bounding box: grid (B, chunks), ordered-int atomics on a float box initialised by nn_box_init_k
+__device__ __forceinline__ int nn_ord(float v) { const int i = __float_as_int(v); return i >= 0 ? i : i ^ 0x7fffffff; }
+__device__ __forceinline__ float nn_unord(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+__global__ void nn_box_init_k(int B, int* __restrict__ bbox) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < B * 6) bbox[t] = (t % 6) < 3 ? 0x7fffffff : static_cast<int>(0x80000000u);
+}
+__global__ __launch_bounds__(256) void nn_bbox_k(int B, const float* __restrict__ known, const int* __restrict__ known_cnt, int* __restrict__ bbox) {
   const int bs = blockIdx.x;
   const int start = stack_start(bs, known_cnt), m = known_cnt[bs];
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (int k = threadIdx.x; k < m; k += 256)
+  for (int k = blockIdx.y * 256 + threadIdx.x; k < m; k += gridDim.y * 256)
     for (int a = 0; a < 3; ++a) { const float v = known[(static_cast<int64_t>(start) + k) * 3 + a]; lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); }
   __shared__ float red[6][256];
   for (int a = 0; a < 3; ++a) { red[a][threadIdx.x] = lo[a]; red[3 + a][threadIdx.x] = hi[a]; }
@@ -1055,64 +1082,90 @@ __global__ __launch_bounds__(256) void nn_bbox_k(int B, const float* __restrict_
       }
     __syncthreads();
   }
-  if (threadIdx.x < 6) bbox[bs * 6 + threadIdx.x] = red[threadIdx.x][0];
+  if (threadIdx.x < 3 && red[threadIdx.x][0] < INFINITY) atomicMin(&bbox[bs * 6 + threadIdx.x], nn_ord(red[threadIdx.x][0]));
+  else if (threadIdx.x >= 3 && threadIdx.x < 6 && red[threadIdx.x][0] > -INFINITY) atomicMax(&bbox[bs * 6 + threadIdx.x], nn_ord(red[threadIdx.x][0]));
 }
-__global__ void nn_setup_k(int B, const float* __restrict__ bbox, const int* __restrict__ known_cnt, float cell, NNGeo* __restrict__ geo) {
+__global__ void nn_setup_k(int B, const int* __restrict__ bbox, const int* __restrict__ known_cnt, float cell, NNGeo* __restrict__ geo) {
   const int bs = blockIdx.x * blockDim.x + threadIdx.x;
   if (bs >= B) return;
   NNGeo g;
   float ext[3];
+  const bool any = known_cnt[bs] > 0;
   for (int a = 0; a < 3; ++a) {
-    g.lo[a] = bbox[bs * 6 + a];
-    ext[a] = fmaxf(bbox[bs * 6 + 3 + a] - g.lo[a], 0.f);
-    if (!(ext[a] < INFINITY)) { ext[a] = 0.f; g.lo[a] = 0.f; }   // empty sample
+    g.lo[a] = any ? nn_unord(bbox[bs * 6 + a]) : 0.f;
+    ext[a] = any ? fmaxf(nn_unord(bbox[bs * 6 + 3 + a]) - g.lo[a], 0.f) : 0.f;
+    if (!(ext[a] < INFINITY) || !(g.lo[a] > -INFINITY)) { ext[a] = 0.f; g.lo[a] = 0.f; }   // non-finite input: one cell, the walk degenerates to the scan
   }
   const int m = max(known_cnt[bs], 1);
   float h = cell > 0.f ? cell : 1.5f * sqrtf(fmaxf(ext[0] * ext[1], 1e-6f) / m);   // no hint: ~2 points per cell of a surface-like cloud
   h = fmaxf(h, 1e-4f);
-  for (int it = 0; it < 64; ++it) {   // grow the spacing until the grid fits the cell budget
-    const double cells = (floor(ext[0] / h) + 1.0) * (floor(ext[1] / h) + 1.0) * (floor(ext[2] / h) + 1.0);
-    if (cells <= kNNCells) break;
-    h *= 1.26f;
+  for (int it = 0; it < 64; ++it) {   // at most 2^18 cells along an axis (the cell number must fit 54 bits beside the sample)
+    if (fmaxf(fmaxf(ext[0], ext[1]), ext[2]) / h < 262143.f) break;
+    h *= 2.f;
   }
   g.h = h; g.inv_h = 1.f / h;
   for (int a = 0; a < 3; ++a) g.dim[a] = static_cast<int>(floorf(ext[a] / h)) + 1;
   geo[bs] = g;
 }
 __device__ __forceinline__ int nn_cell_coord(float v, float lo, float inv_h) { return static_cast<int>(floorf((v - lo) * inv_h)); }
-__device__ __forceinline__ int nn_cell_of(const NNGeo& g, float x, float y, float z) {
+__device__ __forceinline__ unsigned long long nn_key(int bs, const NNGeo& g, int cx, int cy, int cz) {
+  return (static_cast<unsigned long long>(bs) << 54) | ((static_cast<unsigned long long>(cz) * g.dim[1] + cy) * g.dim[0] + cx);
+}
+__device__ __forceinline__ unsigned long long nn_key_of(int bs, const NNGeo& g, float x, float y, float z) {
   const int cx = min(max(nn_cell_coord(x, g.lo[0], g.inv_h), 0), g.dim[0] - 1);
   const int cy = min(max(nn_cell_coord(y, g.lo[1], g.inv_h), 0), g.dim[1] - 1);
   const int cz = min(max(nn_cell_coord(z, g.lo[2], g.inv_h), 0), g.dim[2] - 1);
-  return (cz * g.dim[1] + cy) * g.dim[0] + cx;
+  return nn_key(bs, g, cx, cy, cz);
 }
-__global__ __launch_bounds__(256) void nn_count_k(int B, int M, const float* __restrict__ known, const int* __restrict__ known_cnt,
-                                                  const NNGeo* __restrict__ geo, int* __restrict__ count) {
+// claims (or finds) the slot of every known point's cell and counts the cell's points; slot_of[k] saves the scatter pass the probing
+__global__ __launch_bounds__(256) void nn_insert_k(int B, int M, const float* __restrict__ known, const int* __restrict__ known_cnt,
+                                                   const NNGeo* __restrict__ geo, unsigned int mask, unsigned long long* __restrict__ keys,
+                                                   int* __restrict__ count, int* __restrict__ slot_of) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= M) return;
   int bs, st;
   stack_locate(k, B, known_cnt, &bs, &st);
   const NNGeo g = geo[bs];
-  atomicAdd(&count[static_cast<int64_t>(bs) * kNNCells + nn_cell_of(g, known[k * 3], known[k * 3 + 1], known[k * 3 + 2])], 1);
+  const unsigned long long key = nn_key_of(bs, g, known[k * 3], known[k * 3 + 1], known[k * 3 + 2]);
+  unsigned int s = nn_hash(key) & mask;
+  for (;;) {
+    const unsigned long long was = atomicCAS(&keys[s], kNNEmpty, key);
+    if (was == kNNEmpty || was == key) break;
+    s = (s + 1) & mask;
+  }
+  atomicAdd(&count[s], 1);
+  slot_of[k] = static_cast<int>(s);
 }
 // sorted[pos] = (x, y, z, index within the sample); the order inside a cell is whatever the atomics give — the search orders by (d, index)
 __global__ __launch_bounds__(256) void nn_scatter_k(int B, int M, const float* __restrict__ known, const int* __restrict__ known_cnt,
-                                                    const NNGeo* __restrict__ geo, const int* __restrict__ start, int* __restrict__ count,
+                                                    const int* __restrict__ slot_of, const int* __restrict__ start, int* __restrict__ count,
                                                     float4* __restrict__ sorted) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= M) return;
   int bs, st;
   stack_locate(k, B, known_cnt, &bs, &st);
-  const NNGeo g = geo[bs];
-  const float x = known[k * 3], y = known[k * 3 + 1], z = known[k * 3 + 2];
-  const int64_t c = static_cast<int64_t>(bs) * kNNCells + nn_cell_of(g, x, y, z);
-  const int pos = start[c] + atomicSub(&count[c], 1) - 1;
-  sorted[pos] = make_float4(x, y, z, __int_as_float(k - st));
+  const int s = slot_of[k];
+  const int pos = start[s] + atomicSub(&count[s], 1) - 1;
+  sorted[pos] = make_float4(known[k * 3], known[k * 3 + 1], known[k * 3 + 2], __int_as_float(k - st));
 }
+__device__ __forceinline__ int nn_find(const unsigned long long* __restrict__ keys, unsigned int mask, unsigned long long key) {
+  unsigned int s = nn_hash(key) & mask;
+  for (;;) {
+    const unsigned long long k = keys[s];
+    if (k == key) return static_cast<int>(s);
+    if (k == kNNEmpty) return -1;
+    s = (s + 1) & mask;
+  }
+}
+// First pass: one query per thread, the 27 cells around its own (the three cells of an x row are probed together: their loads do not
+// wait for each other).  A query whose third best is provably nearer than anything outside that block is finished; the others go on
+// the `todo` list — expanding ring by ring through a hash table costs ~100 dependent probes for the second ring alone, and a thread
+// that does it holds its whole wave back (measured: 2.5 - 4.5 ms at the KITTI levels when stragglers walked six rings).
 __global__ __launch_bounds__(256) void nn_query_k(int B, int N, const float* __restrict__ unknown, const int* __restrict__ unk_cnt,
-                                                  const float* __restrict__ known, const int* __restrict__ known_cnt, const NNGeo* __restrict__ geo,
-                                                  const int* __restrict__ start, const float4* __restrict__ sorted, float* __restrict__ dist2,
-                                                  int* __restrict__ idx) {
+                                                  const int* __restrict__ known_cnt, const NNGeo* __restrict__ geo, unsigned int mask,
+                                                  const unsigned long long* __restrict__ keys, const int* __restrict__ start,
+                                                  const float4* __restrict__ sorted, float* __restrict__ dist2, int* __restrict__ idx,
+                                                  int* __restrict__ todo, int* __restrict__ todo_count) {
   const int q = blockIdx.x * 256 + threadIdx.x;
   if (q >= N) return;
   int bs, tmp;
@@ -1120,39 +1173,90 @@ __global__ __launch_bounds__(256) void nn_query_k(int B, int N, const float* __r
   const NNGeo g = geo[bs];
   const float ux = unknown[q * 3], uy = unknown[q * 3 + 1], uz = unknown[q * 3 + 2];
   const int known_start = stack_start(bs, known_cnt), m = known_cnt[bs];
-  const int* st = start + static_cast<int64_t>(bs) * kNNCells;
-  const int qx = nn_cell_coord(ux, g.lo[0], g.inv_h), qy = nn_cell_coord(uy, g.lo[1], g.inv_h), qz = nn_cell_coord(uz, g.lo[2], g.inv_h);
+  // the query's own cell, clamped into int range first (a query far outside the box must not overflow the arithmetic below)
+  const int qx = static_cast<int>(fminf(fmaxf(floorf((ux - g.lo[0]) * g.inv_h), -1048576.f), 1048576.f));
+  const int qy = static_cast<int>(fminf(fmaxf(floorf((uy - g.lo[1]) * g.inv_h), -1048576.f), 1048576.f));
+  const int qz = static_cast<int>(fminf(fmaxf(floorf((uz - g.lo[2]) * g.inv_h), -1048576.f), 1048576.f));
   Best3 bst;
   best3_init(bst);
-  bool done = m == 0;
-  for (int R = 1; !done && R <= kNNMaxRing; ++R) {
-    const int z0 = max(qz - R, 0), z1 = min(qz + R, g.dim[2] - 1), y0 = max(qy - R, 0), y1 = min(qy + R, g.dim[1] - 1);
-    const int x0 = max(qx - R, 0), x1 = min(qx + R, g.dim[0] - 1);
-    for (int cz = z0; cz <= z1; ++cz)
-      for (int cy = y0; cy <= y1; ++cy) {
-        const bool inner_zy = R > 1 && abs(cz - qz) < R && abs(cy - qy) < R;   // then only the two x faces of the shell are new
-        for (int cx = x0; cx <= x1; ++cx) {
-          if (inner_zy && abs(cx - qx) < R) { cx = min(qx + R - 1, x1); continue; }   // skip the block searched before
-          const int c = (cz * g.dim[1] + cy) * g.dim[0] + cx;
-          for (int p = st[c], pe = st[c + 1]; p < pe; ++p) {
-            const float4 v = sorted[p];
-            best3_merge_one(bst, sqdist(ux, uy, uz, v.x, v.y, v.z), __float_as_int(v.w));
-          }
-        }
+  const int z0 = max(qz - 1, 0), z1 = min(qz + 1, g.dim[2] - 1), y0 = max(qy - 1, 0), y1 = min(qy + 1, g.dim[1] - 1);
+  const int x0 = max(qx - 1, 0), x1 = min(qx + 1, g.dim[0] - 1);
+  for (int cz = z0; cz <= z1; ++cz)
+    for (int cy = y0; cy <= y1; ++cy) {
+      int sl[3];
+      unsigned long long want[3], got[3];
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const int cx = x0 + e;
+        const bool in = cx <= x1;
+        want[e] = nn_key(bs, g, in ? cx : x0, cy, cz);
+        sl[e] = static_cast<int>(nn_hash(want[e]) & mask);
+        got[e] = in ? keys[sl[e]] : kNNEmpty;
       }
-    const float reach = (static_cast<float>(R) - 1e-3f) * g.h;
-    done = bst.d3 < reach * reach ||
-           (x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.dim[0] - 1 && y1 == g.dim[1] - 1 && z1 == g.dim[2] - 1);   // the whole grid has been seen
+      int pb[3], pe[3];
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        while (got[e] != want[e] && got[e] != kNNEmpty) { sl[e] = static_cast<int>((static_cast<unsigned int>(sl[e]) + 1u) & mask); got[e] = keys[sl[e]]; }
+        const bool hit = got[e] == want[e];
+        pb[e] = hit ? start[sl[e]] : 0;
+        pe[e] = hit ? start[sl[e] + 1] : 0;
+      }
+#pragma unroll
+      for (int e = 0; e < 3; ++e)
+        for (int p = pb[e]; p < pe[e]; ++p) {
+          const float4 v = sorted[p];
+          best3_merge_one(bst, sqdist(ux, uy, uz, v.x, v.y, v.z), __float_as_int(v.w));
+        }
+    }
+  const float reach = (1.f - 1e-3f) * g.h;
+  const bool done = m == 0 || bst.d3 < reach * reach ||
+                    (x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.dim[0] - 1 && y1 == g.dim[1] - 1 && z1 == g.dim[2] - 1);   // the whole grid has been seen
+  if (done) {
+    dist2[q * 3] = bst.d1; dist2[q * 3 + 1] = bst.d2; dist2[q * 3 + 2] = bst.d3;
+    idx[q * 3] = bst.i1 + known_start; idx[q * 3 + 1] = bst.i2 + known_start; idx[q * 3 + 2] = bst.i3 + known_start;
+  } else {
+    todo[atomicAdd(todo_count, 1)] = q;
   }
-  if (!done) {   // far from everything: the plain scan of this query's sample
+}
+// Second pass: one WAVE per unfinished query scans the query's sample — lane l takes the known points l, l + 64, ... in ascending
+// index order (strict '<': the lowest index of equal distances within the lane), and the 64 lists of three are merged under the
+// (distance, index) order by three rounds of "smallest head" (float minimum, then the lowest index among its holders).
+__global__ __launch_bounds__(256) void nn_rest_k(int B, const float* __restrict__ unknown, const int* __restrict__ unk_cnt,
+                                                 const float* __restrict__ known, const int* __restrict__ known_cnt,
+                                                 const int* __restrict__ todo, const int* __restrict__ todo_count,
+                                                 float* __restrict__ dist2, int* __restrict__ idx) {
+  const int lane = threadIdx.x & 63;
+  const int total = *todo_count, waves = gridDim.x * 4;
+  for (int t = blockIdx.x * 4 + (threadIdx.x >> 6); t < total; t += waves) {
+    const int q = todo[t];
+    int bs, tmp;
+    stack_locate(q, B, unk_cnt, &bs, &tmp);
+    const float ux = unknown[q * 3], uy = unknown[q * 3 + 1], uz = unknown[q * 3 + 2];
+    const int known_start = stack_start(bs, known_cnt), m = known_cnt[bs];
+    Best3 bst;
     best3_init(bst);
-    for (int k = 0; k < m; ++k) {
+    for (int k = lane; k < m; k += 64) {
       const float* p = known + (static_cast<int64_t>(known_start) + k) * 3;
       best3_push(bst, sqdist(ux, uy, uz, p[0], p[1], p[2]), k);
     }
+    // heads are (d1, i1); a lane with fewer than three points has inf heads with index 0 — the reference leaves such slots at
+    // (inf -> 1e40 cast, index 0) as well, and inf == inf ties resolve to index 0 either way
+    float od[3];
+    int oi[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float mn = wave_min_f32(bst.d1);
+      const uint32_t mi = wave_min_u32(bst.d1 == mn ? static_cast<uint32_t>(bst.i1) : 0xffffffffu);
+      od[r] = mn; oi[r] = static_cast<int>(mi);
+      if (bst.d1 == mn && static_cast<uint32_t>(bst.i1) == mi && mn < INFINITY) {   // pop (an inf head stays: every further round yields inf, 0 again)
+        bst.d1 = bst.d2; bst.i1 = bst.i2; bst.d2 = bst.d3; bst.i2 = bst.i3; bst.d3 = INFINITY; bst.i3 = 0;
+      }
+    }
+    if (lane == 0) {
+      dist2[q * 3] = od[0]; dist2[q * 3 + 1] = od[1]; dist2[q * 3 + 2] = od[2];
+      idx[q * 3] = oi[0] + known_start; idx[q * 3 + 1] = oi[1] + known_start; idx[q * 3 + 2] = oi[2] + known_start;
+    }
   }
-  dist2[q * 3] = bst.d1; dist2[q * 3 + 1] = bst.d2; dist2[q * 3 + 2] = bst.d3;
-  idx[q * 3] = bst.i1 + known_start; idx[q * 3 + 1] = bst.i2 + known_start; idx[q * 3 + 2] = bst.i3 + known_start;
 }
 
 // batch interpolate: points (B,C,M) channel-major, idx/weight (B,N,3) -> out (B,C,N)
@@ -1318,8 +1422,9 @@ extern "C" int fv2p_group_points_stack_grad(int b, int m, int c, int n, int nsam
 // measured on MI355X: 1.43-1.52 us/round against 1.62 for the plain kernel at n = 16384; the Morton pre-pass (bbox, keys,
 // 3-4 radix passes) costs ~0.15 ms, so short sampling runs stay on the plain kernel
 static unsigned long long* g_fps_trace = nullptr;
-// test hook: the streaming sampler writes, for sample 0, trace[8 * wave + {0..7}] = clocks in {box test, touched buckets, wave arg-max,
-// candidate exchange + barrier, winner selection}, touched buckets summed over the rounds, rounds, buckets.  NULL switches it off.
+// test hook: the streaming sampler writes, for sample 0, trace[8 * wave + {0..7}] = clocks in {box test, issuing a pass's loads, first
+// bucket of a pass (wait + distance pass + reduction), the pass's other buckets, wave arg-max, candidate exchange + barrier, winner
+// selection}, touched buckets summed over the rounds.  NULL switches it off.
 extern "C" int fv2p_fps_set_trace(unsigned long long* trace) { g_fps_trace = trace; return 0; }
 static bool fps_bucketed_applies(int n, int m) { return n >= 2048 && n <= 1024 * kStreamBucket && m >= 256; }
 
@@ -1330,7 +1435,8 @@ extern "C" size_t fv2p_furthest_point_sampling_ws_bytes(int b, int n) {
   s.take<uint64_t>(static_cast<size_t>(total));
   s.take<uint64_t>(static_cast<size_t>(total));
   s.take<char>(radix_sort_ws_bytes(total));
-  if (n > 48 * kFpsWaves * 64) s.take<float>(static_cast<size_t>(total) * 5);   // streaming kernel: sorted x, y, z, distance, priority
+  if (n > 48 * kFpsWaves * 64)   // streaming kernel: sorted x, y, z, distance, priority, every sample padded to whole buckets
+    s.take<float>(static_cast<size_t>(b > 0 ? b : 1) * static_cast<size_t>(ceil_div(n, kStreamBucket)) * kStreamBucket * 5);
   return s.bytes();
 }
 
@@ -1357,12 +1463,14 @@ extern "C" int fv2p_furthest_point_sampling(int b, int n, int m, const float* da
     while ((1 << sbits) < b) ++sbits;
     if (int rc = radix_sort_u64(keys, tmp, total, 24, 48 + sbits, rws, rb, st)) return rc;
     if (n > 48 * kFpsWaves * 64) {   // does not fit one CU's registers: streaming kernel on the sorted copy
-      float* sx = c.take<float>(static_cast<size_t>(total) * 5);
-      float *sy = sx + total, *sz = sy + total, *sd = sz + total;
-      uint32_t* sp = reinterpret_cast<uint32_t*>(sd + total);
-      hipLaunchKernelGGL(fps_stream_prep_k, G1D(total), 0, st, total, n, dataset, temp, keys, bs, sx, sy, sz, sd, sp);
+      const int ns = static_cast<int>(ceil_div(n, kStreamBucket)) * kStreamBucket;
+      const int64_t padded = static_cast<int64_t>(b) * ns;
+      float* sx = c.take<float>(static_cast<size_t>(padded) * 5);
+      float *sy = sx + padded, *sz = sy + padded, *sd = sz + padded;
+      uint32_t* sp = reinterpret_cast<uint32_t*>(sd + padded);
+      hipLaunchKernelGGL(fps_stream_prep_k, G1D(padded), 0, st, padded, n, ns, dataset, temp, keys, bs, sx, sy, sz, sd, sp);
       hipLaunchKernelGGL(fps_stream_k, dim3(b), dim3(kStreamWaves * 64), 0, st, n, m, bs, dataset, sx, sy, sz, sd, sp, idxs, g_fps_trace);
-      hipLaunchKernelGGL(fps_stream_post_k, G1D(total), 0, st, total, n, keys, sd, temp);
+      hipLaunchKernelGGL(fps_stream_post_k, G1D(total), 0, st, total, n, ns, keys, sd, temp);
       FV2P_LAUNCH_CHECK();
       return 0;
     }
@@ -1428,36 +1536,54 @@ extern "C" int fv2p_three_nn_stack(int b, int n, int m, const float* unknown, co
   FV2P_LAUNCH_CHECK();
   return 0;
 }
-extern "C" size_t fv2p_three_nn_grid_ws_bytes(int b, int64_t m) {
-  const size_t cells = static_cast<size_t>(b > 0 ? b : 1) * kNNCells;
-  return align_up(static_cast<size_t>(b > 0 ? b : 1) * 6 * sizeof(float)) + align_up(static_cast<size_t>(b > 0 ? b : 1) * sizeof(NNGeo)) +
-         align_up(cells * sizeof(int)) + align_up((cells + 1) * sizeof(int)) + align_up(static_cast<size_t>(m > 0 ? m : 1) * sizeof(float4)) +
-         align_up(scan_ws_bytes(static_cast<int64_t>(cells)));
+static int64_t nn_slots(int64_t m) {   // hash-table slots: a power of two >= 2 m
+  int64_t t = 1024;
+  while (t < 2 * m) t <<= 1;
+  return t;
+}
+extern "C" size_t fv2p_three_nn_grid_ws_bytes(int b, int64_t n, int64_t m) {
+  const size_t bb = static_cast<size_t>(b > 0 ? b : 1), mm = static_cast<size_t>(m > 0 ? m : 1);
+  const size_t slots = static_cast<size_t>(nn_slots(static_cast<int64_t>(mm)));
+  return align_up(bb * 6 * sizeof(int)) + align_up(bb * sizeof(NNGeo)) + align_up(slots * sizeof(unsigned long long)) + align_up(slots * sizeof(int)) +
+         align_up((slots + 1) * sizeof(int)) + align_up(mm * sizeof(int)) + align_up(mm * sizeof(float4)) +
+         align_up(scan_ws_bytes(static_cast<int64_t>(slots))) + align_up(sizeof(int)) +
+         align_up(static_cast<size_t>(n > 0 ? n : 1) * sizeof(int));   // ... and the list of queries the first pass leaves over
 }
 extern "C" int fv2p_three_nn_stack_grid(int b, int n, int m, const float* unknown, const int* unknown_batch_cnt, const float* known,
                                         const int* known_batch_cnt, float cell, float* dist2, int* idx, void* ws, size_t ws_bytes, fv2p_stream_t s) {
   FV2P_REQUIRE(b >= 1 && n >= 0 && m >= 0, FV2P_EINVAL, "three_nn_stack_grid: bad sizes");
   if (n == 0) return 0;
   FV2P_REQUIRE(unknown && unknown_batch_cnt && known_batch_cnt && dist2 && idx && (known || m == 0), FV2P_EINVAL, "three_nn_stack_grid: null pointer");
-  FV2P_REQUIRE(b <= 64, FV2P_ELIMIT, "three_nn_stack_grid: at most 64 samples");
-  FV2P_REQUIRE(ws && ws_bytes >= fv2p_three_nn_grid_ws_bytes(b, m), FV2P_EWORKSPACE, "three_nn_stack_grid: workspace too small");
+  FV2P_REQUIRE(b <= 512, FV2P_ELIMIT, "three_nn_stack_grid: at most 512 samples");
+  FV2P_REQUIRE(ws && ws_bytes >= fv2p_three_nn_grid_ws_bytes(b, n, m), FV2P_EWORKSPACE, "three_nn_stack_grid: workspace too small");
   hipStream_t st = STREAM(s);
-  const int64_t cells = static_cast<int64_t>(b) * kNNCells;
+  const int64_t slots = nn_slots(m > 0 ? m : 1);
   Carver c(ws, ws_bytes);
-  float* bbox = c.take<float>(static_cast<size_t>(b) * 6);
+  int* bbox = c.take<int>(static_cast<size_t>(b) * 6);
   NNGeo* geo = c.take<NNGeo>(static_cast<size_t>(b));
-  int* count = c.take<int>(static_cast<size_t>(cells));
-  int* start = c.take<int>(static_cast<size_t>(cells) + 1);
+  unsigned long long* keys = c.take<unsigned long long>(static_cast<size_t>(slots));
+  int* count = c.take<int>(static_cast<size_t>(slots));
+  int* start = c.take<int>(static_cast<size_t>(slots) + 1);
+  int* slot_of = c.take<int>(static_cast<size_t>(m > 0 ? m : 1));
   float4* sorted = c.take<float4>(static_cast<size_t>(m > 0 ? m : 1));
-  const size_t sb = scan_ws_bytes(cells);
+  const size_t sb = scan_ws_bytes(slots);
   void* sws = c.take<char>(sb);
-  hipLaunchKernelGGL(nn_bbox_k, dim3(b), dim3(256), 0, st, b, known, known_batch_cnt, bbox);
-  hipLaunchKernelGGL(nn_setup_k, dim3(1), dim3(64), 0, st, b, bbox, known_batch_cnt, cell, geo);
-  FV2P_HIP(hipMemsetAsync(count, 0, static_cast<size_t>(cells) * sizeof(int), st));
-  if (m > 0) hipLaunchKernelGGL(nn_count_k, G1D(m), 0, st, b, m, known, known_batch_cnt, geo, count);
-  if (int rc = exclusive_scan_i32(count, start, cells, start + cells, sws, sb, st)) return rc;
-  if (m > 0) hipLaunchKernelGGL(nn_scatter_k, G1D(m), 0, st, b, m, known, known_batch_cnt, geo, start, count, sorted);
-  hipLaunchKernelGGL(nn_query_k, G1D(n), 0, st, b, n, unknown, unknown_batch_cnt, known, known_batch_cnt, geo, start, sorted, dist2, idx);
+  int* todo_count = c.take<int>(1);
+  int* todo = c.take<int>(static_cast<size_t>(n));
+  const unsigned int mask = static_cast<unsigned int>(slots - 1);
+  const unsigned chunks = static_cast<unsigned>(std::min<int64_t>(64, std::max<int64_t>(1, ceil_div(m, 4096))));
+  hipLaunchKernelGGL(nn_box_init_k, dim3(static_cast<unsigned>(ceil_div(b * 6, 64))), dim3(64), 0, st, b, bbox);
+  hipLaunchKernelGGL(nn_bbox_k, dim3(b, chunks), dim3(256), 0, st, b, known, known_batch_cnt, bbox);
+  hipLaunchKernelGGL(nn_setup_k, dim3(static_cast<unsigned>(ceil_div(b, 64))), dim3(64), 0, st, b, bbox, known_batch_cnt, cell, geo);
+  FV2P_HIP(hipMemsetAsync(keys, 0xff, static_cast<size_t>(slots) * sizeof(unsigned long long), st));
+  FV2P_HIP(hipMemsetAsync(count, 0, static_cast<size_t>(slots) * sizeof(int), st));
+  FV2P_HIP(hipMemsetAsync(todo_count, 0, sizeof(int), st));
+  if (m > 0) hipLaunchKernelGGL(nn_insert_k, G1D(m), 0, st, b, m, known, known_batch_cnt, geo, mask, keys, count, slot_of);
+  if (int rc = exclusive_scan_i32(count, start, slots, start + slots, sws, sb, st)) return rc;
+  if (m > 0) hipLaunchKernelGGL(nn_scatter_k, G1D(m), 0, st, b, m, known, known_batch_cnt, slot_of, start, count, sorted);
+  hipLaunchKernelGGL(nn_query_k, G1D(n), 0, st, b, n, unknown, unknown_batch_cnt, known_batch_cnt, geo, mask, keys, start, sorted, dist2, idx, todo, todo_count);
+  hipLaunchKernelGGL(nn_rest_k, dim3(static_cast<unsigned>(std::min<int64_t>(2048, ceil_div(n, 4)))), dim3(256), 0, st, b, unknown, unknown_batch_cnt, known, known_batch_cnt,
+                     todo, todo_count, dist2, idx);
   FV2P_LAUNCH_CHECK();
   return 0;
 }

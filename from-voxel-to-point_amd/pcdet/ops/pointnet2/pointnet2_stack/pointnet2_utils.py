@@ -70,8 +70,8 @@ def _three_nn(saved, unknown, unknown_batch_cnt, known, known_batch_cnt, cell=No
     d2 = torch.zeros_like(unknown)
     idx = torch.zeros(unknown.shape, dtype=torch.int32, device=unknown.device)
     nb = len(unknown_batch_cnt)
-    if known.shape[0] >= GRID_MIN_KNOWN * nb and nb <= 64 and os.environ.get("FV2P_NN_GRID", "1") != "0":
-        ws = G.scratch("fv2p_three_nn_grid_ws_bytes", unknown.device, nb, known.shape[0])
+    if known.shape[0] >= GRID_MIN_KNOWN * nb and nb <= 512 and os.environ.get("FV2P_NN_GRID", "1") != "0":
+        ws = G.scratch("fv2p_three_nn_grid_ws_bytes", unknown.device, nb, unknown.shape[0], known.shape[0])
         G.run("fv2p_three_nn_stack_grid", nb, unknown.shape[0], known.shape[0], unknown.contiguous(), _cnt(unknown_batch_cnt),
               known.contiguous(), _cnt(known_batch_cnt), float(cell) if cell else 0.0, d2, idx, ws, ws.numel())
     else:

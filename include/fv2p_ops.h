@@ -379,20 +379,23 @@ size_t fv2p_furthest_point_sampling_ws_bytes(int b, int n);
 int fv2p_furthest_point_sampling(int b, int n, int m, const float* dataset, float* temp, int* idxs, void* ws,
                                  size_t ws_bytes, fv2p_stream_t stream);
 /* Profiling hook of the streaming sampler (n > 24 576): when non-NULL (device memory, 16 x 8 entries), sample 0 writes
- * trace[8 * wave + {0..7}] = shader clocks spent in {box test, touched buckets, wave arg-max, candidate exchange + barrier,
- * winner selection}, the touched buckets summed over the rounds, the rounds, the buckets.  NULL switches it off. */
+ * trace[8 * wave + {0..7}] = shader clocks spent in {box test, issuing the loads of a pass over the touched buckets, the first
+ * bucket of a pass (wait + distance pass + reduction), the pass's other buckets, wave arg-max, candidate exchange + barrier,
+ * winner selection}, the touched buckets summed over the rounds.  NULL switches it off. */
 int fv2p_fps_set_trace(unsigned long long* trace);
 int fv2p_three_nn_batch(int b, int n, int m, const float* unknown, const float* known, float* dist2, int* idx,
                         fv2p_stream_t stream);
 int fv2p_three_nn_stack(int b, int n, int m, const float* unknown, const int* unknown_batch_cnt,
                         const float* known, const int* known_batch_cnt, float* dist2, int* idx,
                         fv2p_stream_t stream);
-/* fv2p_three_nn_stack through a uniform grid over the known points: the same idx / dist2, bit for bit (every distance is the scan's
- * float expression, the three best are kept under the (distance, index) order = "strict < over ascending index", and the search
- * around a query stops only when every unseen point is provably farther than its third best), in time proportional to the points
- * near each query instead of all of them.  cell: grid spacing in the points' unit (e.g. two voxel pitches of the level the known
- * points are centres of); <= 0 lets the library estimate one.  The reference has no counterpart (interpolate_gpu.cu:16-73 scans). */
-size_t fv2p_three_nn_grid_ws_bytes(int b, int64_t m);
+/* fv2p_three_nn_stack through a hashed uniform grid over the known points (2 table slots per point): the same idx / dist2, bit
+ * for bit.  Every distance is the scan's float expression, the three best are kept under the (distance, index) order = "strict <
+ * over ascending index", and a query is settled by the 27 cells around its own only when every point outside them is provably
+ * farther than its third best; the other queries scan their sample, one wave each.  Time goes with the points near each query
+ * instead of all of them.  cell: grid spacing in the points' unit (e.g. two voxel pitches of the level the known points are
+ * centres of); <= 0 lets the library estimate one.  n = queries, m = known points.  The reference has no counterpart
+ * (interpolate_gpu.cu:16-73 scans). */
+size_t fv2p_three_nn_grid_ws_bytes(int b, int64_t n, int64_t m);
 int fv2p_three_nn_stack_grid(int b, int n, int m, const float* unknown, const int* unknown_batch_cnt,
                              const float* known, const int* known_batch_cnt, float cell, float* dist2, int* idx,
                              void* ws, size_t ws_bytes, fv2p_stream_t stream);

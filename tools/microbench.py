@@ -291,11 +291,11 @@ def fpstrace():
         torch.cuda.synchronize()
         fv2p_native.call("fv2p_fps_set_trace", None)
         t = tr.cpu().numpy().reshape(16, 8).astype(np.float64)
-        rounds = t[0, 6]
-        print(f"n = {n}: {int(t[0, 7])} buckets, {int(rounds)} rounds; clocks per round and wave: box test, touched buckets, wave arg-max, exchange + barrier, pick | touched buckets per round")
+        rounds = 16383.0
+        print(f"n = {n}: clocks per round and wave: box test, load issue, first bucket, other buckets, wave arg-max, exchange + barrier, pick | touched buckets per round")
         for w in range(16):
-            print("  wave %2d: %7.1f %7.1f %7.1f %7.1f %7.1f | %5.2f" % ((w,) + tuple(t[w, :5] / rounds) + (t[w, 5] / rounds,)))
-        print("  mean   : %7.1f %7.1f %7.1f %7.1f %7.1f | %5.2f   sum %7.1f" % (tuple(t[:, :5].mean(0) / rounds) + (t[:, 5].mean() / rounds, t[:, :5].mean(0).sum() / rounds)))
+            print("  wave %2d: %7.1f %7.1f %7.1f %7.1f %7.1f %7.1f %7.1f | %5.2f" % ((w,) + tuple(t[w, :7] / rounds) + (t[w, 7] / rounds,)))
+        print("  mean   : %7.1f %7.1f %7.1f %7.1f %7.1f %7.1f %7.1f | %5.2f   sum %7.1f" % (tuple(t[:, :7].mean(0) / rounds) + (t[:, 7].mean() / rounds, t[:, :7].mean(0).sum() / rounds)))
 
 
 def nn():
@@ -325,12 +325,14 @@ def nn():
         t_scan = timeit(lambda: su.three_nn(key, kc, known, kcnt), reps=5, warm=1)
         d0, i0 = su.three_nn(key, kc, known, kcnt)
         os.environ["FV2P_NN_GRID"] = "1"
-        t_hint = timeit(lambda: su.three_nn(key, kc, known, kcnt, 2.0 * float(vsz[0]) * stride), reps=10, warm=2)
+        su.GRID_MIN_KNOWN = 0    # the grid whatever the size: the threshold of the Python layer is what this table is for
+        pitch = float(vsz[0]) * stride
+        t_hint = {f: timeit(lambda: su.three_nn(key, kc, known, kcnt, f * pitch), reps=10, warm=2) for f in (1.0, 2.0, 3.0, 4.0)}
         t_auto = timeit(lambda: su.three_nn(key, kc, known, kcnt), reps=10, warm=2)
-        d1, i1 = su.three_nn(key, kc, known, kcnt, 2.0 * float(vsz[0]) * stride)
+        d1, i1 = su.three_nn(key, kc, known, kcnt, 2.0 * pitch)
         same = bool(torch.equal(i0, i1) and torch.equal(d0, d1))
-        print(f"three_nn {key.shape[0]} queries x {known.shape[0]} voxel centres (stride {stride}): scan {t_scan:8.1f} us   grid, lattice hint {t_hint:7.1f} us   "
-              f"grid, estimated spacing {t_auto:7.1f} us   identical {same}")
+        print(f"three_nn {key.shape[0]} queries x {known.shape[0]} voxel centres (stride {stride}): scan {t_scan:8.1f} us   grid, cell = 1 / 2 / 3 / 4 voxel pitches "
+              + " / ".join(f"{t_hint[f]:6.1f}" for f in (1.0, 2.0, 3.0, 4.0)) + f" us   estimated spacing {t_auto:7.1f} us   identical {same}")
 
 
 def nms():
@@ -501,7 +503,21 @@ def oproof():
     # NMS of the proposal layer and the RoI-head IoU / pools
     batch = torch.from_numpy(np.stack([random_boxes(7 + i, 9000) for i in range(3)])).to(dev)
     t = timeit(lambda: iou3d_nms_cuda.nms_batch_device(batch, 0.8, 512), reps=5, warm=1)
-    add("nms_batch 3 x 9000 -> 512 (truncated)", t, 3 * (28.0 * 9000 + 9000.0 * 9000 / 8), 3 * 9000.0 * 9000 / 2 * 300, "priced as the FULL mask (8(d)); only ~1/9 of the row blocks are evaluated")
+    # priced by the tiles the launch sequence EXECUTES (a sample stops at the end of the chunk of row blocks that holds its 512-th survivor;
+    # a row block evaluates the column blocks at and right of it): 64 x 64 overlaps of ~300 flop and 64 mask words per tile
+    keep, cnt = iou3d_nms_cuda.nms_batch_device(batch, 0.8, 512)
+    keep, cnt = keep.cpu().numpy(), cnt.cpu().numpy()
+    cb, first, tiles = (9000 + 63) // 64, (2 * 512 + 63) // 64, 0
+    for smp in range(3):
+        last_row = int(keep[smp, 511]) if cnt[smp] >= 512 else 9000 - 1
+        end, span = first, first
+        while end < min(cb, last_row // 64 + 1):
+            span *= 4
+            end += span
+        end = min(end, cb)
+        tiles += sum(cb - rb for rb in range(end))
+    add("nms_batch 3 x 9000 -> 512 (truncated)", t, 3 * 28.0 * 9000 + tiles * 64 * 8.0, tiles * 4096.0 * 300,
+        f"priced by the {tiles} executed 64 x 64 tiles ({tiles / (3 * cb * (cb + 1) / 2):.2f} of the full triangle)")
     t = timeit(lambda: iou3d_nms_cuda.nms_batch_device(batch, 0.8, 0), reps=3, warm=1)
     add("nms_batch 3 x 9000, all survivors", t, 3 * (28.0 * 9000 + 9000.0 * 9000 / 8), 3 * 9000.0 * 9000 / 2 * 300)
     a, b2 = batch[0, :512].contiguous(), batch[1, :40].contiguous()
