@@ -23,6 +23,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
@@ -62,6 +63,9 @@ def parse():
     ap.add_argument("--fps-ahead", type=int, default=1, help="FV2P workloads: key points of batch t+1 are sampled (FPS side stream) during the backward pass of step t")
     ap.add_argument("--ahead-at", default="mid", choices=["start", "mid"], help="where a step enqueues the preparation / sampling of the next batch: before its forward pass (measured 40.8 vs 33.0 ms per step) or between forward and backward")
     ap.add_argument("--ahead-stream", default="fps", choices=["fps", "own"], help="--ahead: prepare the next batch on the key-point sampling stream (in front of that batch's sampler) or on a stream of its own")
+    ap.add_argument("--ahead-thread", type=int, default=-1, help="--ahead / --fps-ahead: the preparation of the next batch (its host waits for the voxel counts and rulebook sizes: "
+                    "4.7 ms of the stepping thread per step when called in line) runs on a helper thread, joined at the top of the next step.  Default: on for "
+                    "fv2p-waymo (measured 35.8 -> 33.2 ms per step), off for fv2p (32.4 - 32.5 against 32.8 ms, and one 41 ms run)")
     ap.add_argument("--ahead-priority", type=int, default=-1, help="stream priority of the --ahead side stream (-1 = high: a hardware queue of its own)")
     ap.add_argument("--cloud-streams", type=int, default=0,
                     help="FV2P workloads: voxelise the clouds of a batch on one stream each (measured: no gain at batch 3, and at Waymo size the extra "
@@ -106,6 +110,8 @@ def parse():
     # ONE stream arrangement for every N: a 1 -> 8 scan compares like with like and the N = 1 point of a scaling run is the headline
     # run (round 2 switched multi-GPU ranks to another arrangement; RCCL's stream beside the dense-branch stream is unmeasured — the
     # in-line figure `inline_ms_per_step` is the arrangement-free number to fall back on)
+    if args.ahead_thread < 0:
+        args.ahead_thread = 1 if args.workload == "fv2p-waymo" else 0
     if args.workload in ("fv2p", "fv2p-waymo") and "--ahead" not in sys.argv and not args.prefetch:
         # batch t+1 is voxelised and its rulebooks are built on the sampling stream, in front of that batch's sampler, between forward
         # and backward of step t: the sparse backbone of step t+1 then starts without its five host waits (33.65 -> 32.75 ms).  On a
@@ -114,6 +120,32 @@ def parse():
     if args.steps == 300 and args.workload == "fv2p" and "--steps" not in sys.argv:
         args.steps, args.warmup = 40, (args.warmup if "--warmup" in sys.argv else 5)
     return args
+
+
+class Later(object):
+    """One job at a time on a helper thread; join() waits for it and re-raises what it raised."""
+
+    def __init__(self):
+        self.thread, self.error = None, None
+
+    def run(self, fn, *args):
+        self.join()
+
+        def body():
+            try:
+                fn(*args)
+            except BaseException as e:   # noqa: BLE001 - surfaced by join()
+                self.error = e
+        self.thread = threading.Thread(target=body, daemon=True)
+        self.thread.start()
+
+    def join(self):
+        if self.thread is not None:
+            self.thread.join()
+            self.thread = None
+        if self.error is not None:
+            e, self.error = self.error, None
+            raise e
 
 
 SAFE_FLAGS = ["--fps-ahead", "0", "--ahead", "0", "--prefetch", "0", "--dense-stream", "0"]   # every side-stream input pipeline off: the plain in-line step
@@ -421,7 +453,10 @@ def build_fv2p_step(args, device, rank, world):
     cfg_safe = type("Cfg", (cfg,), {"dense_branch_stream": False, "point_branch_stream": False}) if args.dense_stream else cfg
     safe_first = 0 if os.environ.get("FV2P_BENCH_SAFE_FIRST") == "0" else 2
 
+    later = Later()
+
     def step(i):
+        later.join()   # the helper thread that prepared this batch (and started its key-point sampling) during the step before
         model.cfg = cfg_safe if i < min(safe_first, args.warmup) else cfg
         clouds, gt = pool[i % n_pool]
         if ahead is not None:
@@ -438,18 +473,28 @@ def build_fv2p_step(args, device, rank, world):
         u = torch.rand(len(clouds), n_uniform, device=device)
         job = key_jobs.pop(i, None)
 
-        def next_batch():
+        def next_batch(threaded=False):
+            if threaded:
+                torch.cuda.set_device(device)
             if ahead is not None:
                 ahead.prepare(i + 1)   # its host waits see the side stream only
             if args.fps_ahead:
                 # the key points of the next batch need its raw points only: sampled on the FPS stream beside this step
                 key_jobs.clear()
-                key_jobs[i + 1] = model.post_pfe.start_sampling(pool[(i + 1) % n_pool][0])
+                key_jobs[i + 1] = model.post_pfe.start_sampling(pool[(i + 1) % n_pool][0], wait=not threaded)
+
+        def enqueue_next():
+            # the preparation blocks its caller on the voxel counts and the rulebook sizes (library calls, interpreter lock released):
+            # on a helper thread the stepping thread goes straight on to the backward pass
+            if args.ahead_thread and (ahead is not None or args.fps_ahead):
+                later.run(next_batch, True)
+            else:
+                next_batch()
         if args.ahead_at == "start":
-            next_batch()
+            enqueue_next()
         loss = net(clouds, feats, coords, gt, u, key_job=job)
         if args.ahead_at == "mid":
-            next_batch()   # between forward and backward
+            enqueue_next()   # between forward and backward
         opt.zero_grad(set_to_none=True)
         loss.backward()
         torch.nn.utils.clip_grad_norm_(params, cfg.grad_norm_clip, foreach=True)   # GRAD_NORM_CLIP (train_utils.py:43)
@@ -463,6 +508,7 @@ def build_fv2p_step(args, device, rank, world):
         """The same optimiser step with nothing arranged around it: one stream, the batch voxelised and its key points sampled in
         line — what the boundary itself delivers to an unmodified detector.  reference=True: in the reference's call structure
         (fv2p_harness/refstyle.py), the baseline of vs_baseline."""
+        later.join()
         model.cfg = cfg_inline
         key_jobs.clear()
         clouds, gt = pool[i % n_pool]
@@ -482,6 +528,8 @@ def build_fv2p_step(args, device, rank, world):
         return body()
 
     def step_phases(i, acc):
+        later.join()
+
         def phase(name, fn):
             torch.cuda.synchronize()
             if args.phase_kernels:   # launches and device time per phase (slow: one profiler session per phase)
@@ -569,6 +617,7 @@ def build_fv2p_step(args, device, rank, world):
                 obj.__dict__.pop(name, None)
 
     def close():
+        later.join()
         if pre is not None:
             while pre.pending:
                 pre.get()

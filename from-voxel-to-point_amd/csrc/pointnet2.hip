@@ -1045,8 +1045,8 @@ __global__ __launch_bounds__(256) void three_nn_stack_k(int B, int N, const floa
 // scan's float operations in the scan's order — the running best three are kept under the (distance, index) order, which is what
 // "strict < in ascending index order" produces, and the search stops only when every unseen point is provably farther than the third
 // best: after the block of cells within Chebyshev radius R around the query's cell, an unseen point is at least (R - 1e-3) cells away
-// (the 1e-3 covers the float rounding of the cell assignment).  Queries the first block (R = 1) does not settle scan their sample, one
-// wave per query (nn_rest_k).  The cells live in an open-addressing hash table keyed by (sample, cell) — 2 slots per known point — so the spacing stays what the
+// (the 1e-3 covers the float rounding of the cell assignment).  Queries the first block (R = 1) does not settle get a wave each
+// (nn_rest_k: shells up to R = 6 dealt to the lanes, then the scan of the sample).  The cells live in an open-addressing hash table keyed by (sample, cell) — 2 slots per known point — so the spacing stays what the
 // caller asked for whatever the extent of the cloud (round 3's first form was a dense grid of 2^19 cells per sample: at KITTI extent
 // the spacing grew 3.5 x, a cell held ~60 points and the walk was 4 x slower than the scan it replaced).
 constexpr unsigned long long kNNEmpty = ~0ull;
@@ -1157,10 +1157,11 @@ __device__ __forceinline__ int nn_find(const unsigned long long* __restrict__ ke
     s = (s + 1) & mask;
   }
 }
-// First pass: one query per thread, the 27 cells around its own (the three cells of an x row are probed together: their loads do not
-// wait for each other).  A query whose third best is provably nearer than anything outside that block is finished; the others go on
-// the `todo` list — expanding ring by ring through a hash table costs ~100 dependent probes for the second ring alone, and a thread
-// that does it holds its whole wave back (measured: 2.5 - 4.5 ms at the KITTI levels when stragglers walked six rings).
+// First pass: one query per thread, the 27 cells around its own — all 27 first probes issued together, then the segment bounds of the
+// cells that exist, then their points: three rounds of loads that do not wait for each other instead of 27 dependent chains.  A query
+// whose third best is provably nearer than anything outside that block is finished; the others leave their three candidates in
+// dist2 / idx (local indices) and go on the `todo` list — expanding ring by ring costs ~100 dependent probes for the second ring alone,
+// and a thread that does it holds its whole wave back (measured: 2.5 - 4.5 ms at the KITTI levels when stragglers walked six rings).
 __global__ __launch_bounds__(256) void nn_query_k(int B, int N, const float* __restrict__ unknown, const int* __restrict__ unk_cnt,
                                                   const int* __restrict__ known_cnt, const NNGeo* __restrict__ geo, unsigned int mask,
                                                   const unsigned long long* __restrict__ keys, const int* __restrict__ start,
@@ -1177,53 +1178,62 @@ __global__ __launch_bounds__(256) void nn_query_k(int B, int N, const float* __r
   const int qx = static_cast<int>(fminf(fmaxf(floorf((ux - g.lo[0]) * g.inv_h), -1048576.f), 1048576.f));
   const int qy = static_cast<int>(fminf(fmaxf(floorf((uy - g.lo[1]) * g.inv_h), -1048576.f), 1048576.f));
   const int qz = static_cast<int>(fminf(fmaxf(floorf((uz - g.lo[2]) * g.inv_h), -1048576.f), 1048576.f));
-  Best3 bst;
-  best3_init(bst);
   const int z0 = max(qz - 1, 0), z1 = min(qz + 1, g.dim[2] - 1), y0 = max(qy - 1, 0), y1 = min(qy + 1, g.dim[1] - 1);
   const int x0 = max(qx - 1, 0), x1 = min(qx + 1, g.dim[0] - 1);
-  for (int cz = z0; cz <= z1; ++cz)
-    for (int cy = y0; cy <= y1; ++cy) {
-      int sl[3];
-      unsigned long long want[3], got[3];
+  int sl[27];
+  unsigned long long want[27], got[27];
 #pragma unroll
-      for (int e = 0; e < 3; ++e) {
-        const int cx = x0 + e;
-        const bool in = cx <= x1;
-        want[e] = nn_key(bs, g, in ? cx : x0, cy, cz);
-        sl[e] = static_cast<int>(nn_hash(want[e]) & mask);
-        got[e] = in ? keys[sl[e]] : kNNEmpty;
-      }
-      int pb[3], pe[3];
+  for (int c = 0; c < 27; ++c) {
+    const int cx = x0 + c % 3, cy = y0 + (c / 3) % 3, cz = z0 + c / 9;
+    const bool in = cx <= x1 && cy <= y1 && cz <= z1;
+    want[c] = nn_key(bs, g, in ? cx : 0, in ? cy : 0, in ? cz : 0);
+    sl[c] = static_cast<int>(nn_hash(want[c]) & mask);
+    got[c] = in ? keys[sl[c]] : kNNEmpty;
+  }
+  int pb[27], pe[27];
 #pragma unroll
-      for (int e = 0; e < 3; ++e) {
-        while (got[e] != want[e] && got[e] != kNNEmpty) { sl[e] = static_cast<int>((static_cast<unsigned int>(sl[e]) + 1u) & mask); got[e] = keys[sl[e]]; }
-        const bool hit = got[e] == want[e];
-        pb[e] = hit ? start[sl[e]] : 0;
-        pe[e] = hit ? start[sl[e] + 1] : 0;
-      }
+  for (int c = 0; c < 27; ++c) {
+    while (got[c] != want[c] && got[c] != kNNEmpty) { sl[c] = static_cast<int>((static_cast<unsigned int>(sl[c]) + 1u) & mask); got[c] = keys[sl[c]]; }
+    const bool hit = got[c] == want[c];
+    pb[c] = hit ? start[sl[c]] : 0;
+    pe[c] = hit ? start[sl[c] + 1] : 0;
+  }
+  Best3 bst;
+  best3_init(bst);
 #pragma unroll
-      for (int e = 0; e < 3; ++e)
-        for (int p = pb[e]; p < pe[e]; ++p) {
-          const float4 v = sorted[p];
-          best3_merge_one(bst, sqdist(ux, uy, uz, v.x, v.y, v.z), __float_as_int(v.w));
-        }
+  for (int c = 0; c < 27; ++c)
+    for (int p = pb[c]; p < pe[c]; ++p) {
+      const float4 v = sorted[p];
+      best3_merge_one(bst, sqdist(ux, uy, uz, v.x, v.y, v.z), __float_as_int(v.w));
     }
   const float reach = (1.f - 1e-3f) * g.h;
   const bool done = m == 0 || bst.d3 < reach * reach ||
                     (x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.dim[0] - 1 && y1 == g.dim[1] - 1 && z1 == g.dim[2] - 1);   // the whole grid has been seen
-  if (done) {
-    dist2[q * 3] = bst.d1; dist2[q * 3 + 1] = bst.d2; dist2[q * 3 + 2] = bst.d3;
-    idx[q * 3] = bst.i1 + known_start; idx[q * 3 + 1] = bst.i2 + known_start; idx[q * 3 + 2] = bst.i3 + known_start;
-  } else {
-    todo[atomicAdd(todo_count, 1)] = q;
+  const int off = done ? known_start : 0;   // unfinished: candidates stay local, the second pass starts from them
+  dist2[q * 3] = bst.d1; dist2[q * 3 + 1] = bst.d2; dist2[q * 3 + 2] = bst.d3;
+  idx[q * 3] = bst.i1 + off; idx[q * 3 + 1] = bst.i2 + off; idx[q * 3 + 2] = bst.i3 + off;
+  if (!done) todo[atomicAdd(todo_count, 1)] = q;
+}
+// the 64 lanes' lists of three merged under the (distance, index) order: three rounds of "smallest head" (float minimum, then the
+// lowest index among its holders); heads are consumed.  An all-inf round yields (inf, 0), the scan's untouched slot.
+__device__ __forceinline__ void nn_wave_top3(Best3 b, float (&od)[3], int (&oi)[3]) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const float mn = wave_min_f32(b.d1);
+    const uint32_t mi = wave_min_u32(b.d1 == mn ? static_cast<uint32_t>(b.i1) : 0xffffffffu);
+    od[r] = mn; oi[r] = static_cast<int>(mi);
+    if (b.d1 == mn && static_cast<uint32_t>(b.i1) == mi && mn < INFINITY) { b.d1 = b.d2; b.i1 = b.i2; b.d2 = b.d3; b.i2 = b.i3; b.d3 = INFINITY; b.i3 = 0; }
   }
 }
-// Second pass: one WAVE per unfinished query scans the query's sample — lane l takes the known points l, l + 64, ... in ascending
-// index order (strict '<': the lowest index of equal distances within the lane), and the 64 lists of three are merged under the
-// (distance, index) order by three rounds of "smallest head" (float minimum, then the lowest index among its holders).
+constexpr int kNNMaxRing = 6;
+// Second pass: one WAVE per unfinished query.  The shells R = 2 .. kNNMaxRing around the query's cell are walked with the cells of a
+// shell dealt to the lanes (98, 218, 386 ... cells: two to fourteen probes per lane instead of hundreds per thread); after every shell
+// the lanes' candidates are merged and the bound of the header comment is tested.  What six shells do not settle scans the sample:
+// lane l takes the known points l, l + 64, ... in ascending index order (strict '<' keeps the lowest index within the lane).
 __global__ __launch_bounds__(256) void nn_rest_k(int B, const float* __restrict__ unknown, const int* __restrict__ unk_cnt,
-                                                 const float* __restrict__ known, const int* __restrict__ known_cnt,
-                                                 const int* __restrict__ todo, const int* __restrict__ todo_count,
+                                                 const float* __restrict__ known, const int* __restrict__ known_cnt, const NNGeo* __restrict__ geo,
+                                                 unsigned int mask, const unsigned long long* __restrict__ keys, const int* __restrict__ start,
+                                                 const float4* __restrict__ sorted, const int* __restrict__ todo, const int* __restrict__ todo_count,
                                                  float* __restrict__ dist2, int* __restrict__ idx) {
   const int lane = threadIdx.x & 63;
   const int total = *todo_count, waves = gridDim.x * 4;
@@ -1231,26 +1241,58 @@ __global__ __launch_bounds__(256) void nn_rest_k(int B, const float* __restrict_
     const int q = todo[t];
     int bs, tmp;
     stack_locate(q, B, unk_cnt, &bs, &tmp);
+    const NNGeo g = geo[bs];
     const float ux = unknown[q * 3], uy = unknown[q * 3 + 1], uz = unknown[q * 3 + 2];
     const int known_start = stack_start(bs, known_cnt), m = known_cnt[bs];
+    const int qx = static_cast<int>(fminf(fmaxf(floorf((ux - g.lo[0]) * g.inv_h), -1048576.f), 1048576.f));
+    const int qy = static_cast<int>(fminf(fmaxf(floorf((uy - g.lo[1]) * g.inv_h), -1048576.f), 1048576.f));
+    const int qz = static_cast<int>(fminf(fmaxf(floorf((uz - g.lo[2]) * g.inv_h), -1048576.f), 1048576.f));
     Best3 bst;
     best3_init(bst);
-    for (int k = lane; k < m; k += 64) {
-      const float* p = known + (static_cast<int64_t>(known_start) + k) * 3;
-      best3_push(bst, sqdist(ux, uy, uz, p[0], p[1], p[2]), k);
+    if (lane == 0) {   // what the first pass found in the 27 cells (local indices)
+      bst.d1 = dist2[q * 3]; bst.d2 = dist2[q * 3 + 1]; bst.d3 = dist2[q * 3 + 2];
+      bst.i1 = idx[q * 3]; bst.i2 = idx[q * 3 + 1]; bst.i3 = idx[q * 3 + 2];
     }
-    // heads are (d1, i1); a lane with fewer than three points has inf heads with index 0 — the reference leaves such slots at
-    // (inf -> 1e40 cast, index 0) as well, and inf == inf ties resolve to index 0 either way
     float od[3];
     int oi[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const float mn = wave_min_f32(bst.d1);
-      const uint32_t mi = wave_min_u32(bst.d1 == mn ? static_cast<uint32_t>(bst.i1) : 0xffffffffu);
-      od[r] = mn; oi[r] = static_cast<int>(mi);
-      if (bst.d1 == mn && static_cast<uint32_t>(bst.i1) == mi && mn < INFINITY) {   // pop (an inf head stays: every further round yields inf, 0 again)
-        bst.d1 = bst.d2; bst.i1 = bst.i2; bst.d2 = bst.d3; bst.i2 = bst.i3; bst.d3 = INFINITY; bst.i3 = 0;
+    bool done = false;
+    for (int R = 2; !done && R <= kNNMaxRing; ++R) {
+      // shell R = the (2R+1)^3 block minus the (2R-1)^3 block inside it: the two z faces ((2R+1)^2 cells each), then per inner z layer the
+      // two y faces ((2R+1) cells each) and the two x faces ((2R-1) cells each)
+      const int side = 2 * R + 1, face = side * side, ring = 4 * side - 4, cells = 2 * face + (side - 2) * ring;
+      for (int c = lane; c < cells; c += 64) {
+        int dx, dy, dz;
+        if (c < 2 * face) {
+          dz = c < face ? -R : R;
+          const int e = c < face ? c : c - face;
+          dy = e / side - R; dx = e % side - R;
+        } else {
+          const int e = c - 2 * face;
+          dz = e / ring - R + 1;
+          const int f = e % ring;
+          if (f < 2 * side) { dy = f < side ? -R : R; dx = (f < side ? f : f - side) - R; }
+          else { const int h2 = f - 2 * side, k = side - 2; dx = h2 < k ? -R : R; dy = (h2 < k ? h2 : h2 - k) - R + 1; }
+        }
+        const int cx = qx + dx, cy = qy + dy, cz = qz + dz;
+        if (cx < 0 || cy < 0 || cz < 0 || cx >= g.dim[0] || cy >= g.dim[1] || cz >= g.dim[2]) continue;
+        const int sl = nn_find(keys, mask, nn_key(bs, g, cx, cy, cz));
+        if (sl < 0) continue;
+        for (int p = start[sl], pe = start[sl + 1]; p < pe; ++p) {
+          const float4 v = sorted[p];
+          best3_merge_one(bst, sqdist(ux, uy, uz, v.x, v.y, v.z), __float_as_int(v.w));
+        }
       }
+      nn_wave_top3(bst, od, oi);
+      const float reach = (static_cast<float>(R) - 1e-3f) * g.h;
+      done = od[2] < reach * reach || (qx - R <= 0 && qy - R <= 0 && qz - R <= 0 && qx + R >= g.dim[0] - 1 && qy + R >= g.dim[1] - 1 && qz + R >= g.dim[2] - 1);
+    }
+    if (!done) {   // far from everything: the plain scan of this query's sample
+      best3_init(bst);
+      for (int k = lane; k < m; k += 64) {
+        const float* p = known + (static_cast<int64_t>(known_start) + k) * 3;
+        best3_push(bst, sqdist(ux, uy, uz, p[0], p[1], p[2]), k);
+      }
+      nn_wave_top3(bst, od, oi);
     }
     if (lane == 0) {
       dist2[q * 3] = od[0]; dist2[q * 3 + 1] = od[1]; dist2[q * 3 + 2] = od[2];
@@ -1583,7 +1625,7 @@ extern "C" int fv2p_three_nn_stack_grid(int b, int n, int m, const float* unknow
   if (m > 0) hipLaunchKernelGGL(nn_scatter_k, G1D(m), 0, st, b, m, known, known_batch_cnt, slot_of, start, count, sorted);
   hipLaunchKernelGGL(nn_query_k, G1D(n), 0, st, b, n, unknown, unknown_batch_cnt, known_batch_cnt, geo, mask, keys, start, sorted, dist2, idx, todo, todo_count);
   hipLaunchKernelGGL(nn_rest_k, dim3(static_cast<unsigned>(std::min<int64_t>(2048, ceil_div(n, 4)))), dim3(256), 0, st, b, unknown, unknown_batch_cnt, known, known_batch_cnt,
-                     todo, todo_count, dist2, idx);
+                     geo, mask, keys, start, sorted, todo, todo_count, dist2, idx);
   FV2P_LAUNCH_CHECK();
   return 0;
 }

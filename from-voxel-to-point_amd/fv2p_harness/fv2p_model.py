@@ -502,14 +502,17 @@ class V2PDecoder(nn.Module):
             out.append(xyz[idx])
         return torch.stack(out)                                                  # (B, M, 3)
 
-    def start_sampling(self, clouds):
-        """Enqueues sample_keypoints on a side stream (GPU tensors only); returns a handle for forward()."""
+    def start_sampling(self, clouds, wait=True):
+        """Enqueues sample_keypoints on a side stream (GPU tensors only); returns a handle for forward().
+        wait=False: the clouds are known to be complete (an input pipeline's own buffers) — the side stream is not ordered after
+        the calling thread's current stream (a helper thread's current stream is the default one: waiting for it would put the
+        sampler behind whatever the training thread has queued)."""
         if not clouds[0].is_cuda:
             return None
         dev = clouds[0].device
         side = side_stream("fps", dev)
-        main = torch.cuda.current_stream(dev)
-        side.wait_stream(main)
+        if wait:
+            side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             key = self.sample_keypoints(clouds)
         return key, side

@@ -58,7 +58,7 @@ def _fps(saved, xyz, npoint):
 # KITTI levels, 5 - 35 k voxel centres over four samples for 49 152 queries, the scan takes 84 - 492 us and the grid 170 - 1 850 us — the
 # scan's cost goes with the sample's own points, the grid pays nine launches and 2 M cells to clear and scan; at the Waymo levels,
 # 24 - 110 k centres in one sample, the grid takes 108 - 419 us against 339 - 1 525 us)
-GRID_MIN_KNOWN = 20000
+GRID_MIN_KNOWN = 3000
 
 
 def _three_nn(saved, unknown, unknown_batch_cnt, known, known_batch_cnt, cell=None):

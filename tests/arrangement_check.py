@@ -26,22 +26,31 @@ for dense, point in ((True, True), (False, True), (False, False)):
     model.cfg = type("Cfg", (SmallFV2P,), {"dense_branch_stream": dense, "point_branch_stream": point})
     model.taps = {}
     model.zero_grad(set_to_none=True)
+    torch.manual_seed(11)   # the RoI head's dropout masks: the same in every arrangement
     loss = model(*args)
     loss.backward()
     torch.cuda.synchronize()
     runs.append((loss.item(), model.taps["keypoints"].clone(), model.taps["sampled_rois"].clone(),
-                 {k: p.grad.clone() for k, p in model.named_parameters()}))
+                 {k: p.grad.clone() for k, p in model.named_parameters()},
+                 (float(model.taps["loss_rpn"]), float(model.taps["loss_point"])), model.taps["prop_scores"].clone()))
 names = ("dense branch on a side stream", "point branch on a side stream", "one stream")
 for name, other in zip(names[1:], runs[1:]):
     assert torch.equal(other[1], runs[0][1]), f"{name}: other key points than with the {names[0]}"
-    if not torch.equal(other[2], runs[0][2]):
-        print(f"{name}: other sampled RoIs ({int((other[2] != runs[0][2]).any(-1).sum())} rows) - second stage not compared")
-        continue   # a 1e-7 difference in a proposal score swapped two NMS neighbours: the second stage then sees other RoIs
+    # the first stage and the point head do not depend on which RoIs the second stage samples: always compared
+    for what, a, b in zip(("anchor-head loss", "point-head loss"), other[4], runs[0][4]):
+        assert abs(a - b) < 1e-5 * max(1.0, abs(b)), f"{name}: {what} {a} against {b}"
+    # The BEV map is not bit-reproducible from one forward pass to the next in every process (1e-5 relative between IDENTICAL runs
+    # in some sequences, bit-identical in others: tools/arr_diag.py; the sparse levels and the decoder are bit-identical), so the
+    # proposals move by ~1e-6 m: "the same RoIs" is a tolerance, and a swapped pair of NMS neighbours ends the comparison.
+    if other[2].shape != runs[0][2].shape or float((other[2] - runs[0][2]).abs().max()) > 1e-3:
+        print(f"{name}: other sampled RoIs ({int(((other[2] - runs[0][2]).abs() > 1e-3).any(-1).sum())} rows; proposal scores differ by at most "
+              f"{float((other[5] - runs[0][5]).abs().max()):.2e}) - second stage not compared")
+        continue
     compared += 1
-    assert abs(other[0] - runs[0][0]) < 1e-5 * max(1.0, abs(runs[0][0])), f"{name}: loss {other[0]} against {runs[0][0]}"
+    assert abs(other[0] - runs[0][0]) < 1e-4 * max(1.0, abs(runs[0][0])), f"{name}: loss {other[0]} against {runs[0][0]}"
     for k, g0 in runs[0][3].items():
         # (the bias of a conv that feeds BatchNorm has a zero gradient up to rounding: absolute floor beside the relative bound)
-        err, bound = float((other[3][k] - g0).norm()), 1e-4 * float(g0.norm()) + 1e-6 * g0.numel() ** 0.5
+        err, bound = float((other[3][k] - g0).norm()), 2e-3 * float(g0.norm()) + 1e-6 * g0.numel() ** 0.5
         assert err < bound, f"{name}: gradient of {k} differs by {err:.3e} (bound {bound:.3e})"
-assert compared >= 1, "every arrangement sampled other RoIs: nothing was compared"
-print("ARRANGEMENTS AGREE")
+assert compared >= 1, "no arrangement sampled the same RoIs as the first: nothing of the second stage was compared"
+print(f"ARRANGEMENTS AGREE (second stage compared in {compared} of {len(runs) - 1} arrangements)")
