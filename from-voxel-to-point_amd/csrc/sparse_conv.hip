@@ -1661,21 +1661,34 @@ static inline int64_t plan_level_offset(int level) {   // ints from the plan hea
 }
 static int g_plan_rows = 0;   // FV2P_PLAN_ROWS: rows per tile the level choice aims at (0 = default)
 static int g_plan_on = -1;    // FV2P_CONV_PLAN=0 ignores plans (comparison runs)
-// level whose tile count is nearest (in ratio) to n_dst / rows-per-tile; at least 512 workgroups (2 per CU) where the rows allow
+// Level (tile count) of a launch: the chip holds 512 of these workgroups at once (2 per CU: LDS), so a launch runs in
+// ceil(tiles x column blocks / 512) rounds of about n_dst / tiles rows each — the level with the smallest product wins, the fewer
+// (larger: less weight traffic per pair) tiles on a tie; a level is eligible while its average tile leaves the balancer room below
+// the 64-row limit (<= 58 rows).  Round 3 first took the level nearest to 44 rows per tile: 29 446 rows x 64 channels got 768 tiles =
+// one and a half rounds, 63 us where 512 tiles take one round.  FV2P_PLAN_ROWS forces the old rule with that row target.
 static int plan_pick_level(int64_t n_dst, int col_blocks) {
   if (g_plan_on < 0) {
     const char* e = getenv("FV2P_CONV_PLAN"); g_plan_on = e ? atoi(e) : 1;
     const char* r = getenv("FV2P_PLAN_ROWS"); g_plan_rows = r ? atoi(r) : 0;
   }
   if (!g_plan_on || n_dst > 65536) return -1;   // beyond ~1000 tiles the dispatcher balances by itself; full 64-row tiles reload the fewest weights
-  const double rows = g_plan_rows > 0 ? g_plan_rows : 44.0;
-  double want = static_cast<double>(n_dst) / rows;
-  if (want * col_blocks < 512.0) want = 512.0 / col_blocks;
   const int levels = plan_levels(n_dst);
-  int best = 0; double best_r = 1e30;
+  if (g_plan_rows > 0) {
+    double want = static_cast<double>(n_dst) / g_plan_rows;
+    if (want * col_blocks < 512.0) want = 512.0 / col_blocks;
+    int best = 0; double best_r = 1e30;
+    for (int l = 0; l < levels; ++l) {
+      const double t = plan_tiles(l), ratio = t > want ? t / want : want / t;
+      if (ratio < best_r) { best_r = ratio; best = l; }
+    }
+    return best;
+  }
+  int best = levels - 1; double best_cost = 1e30;
   for (int l = 0; l < levels; ++l) {
-    const double t = plan_tiles(l), ratio = t > want ? t / want : want / t;
-    if (ratio < best_r) { best_r = ratio; best = l; }
+    const double t = plan_tiles(l), rows = static_cast<double>(n_dst) / t;
+    if (rows > 58.0) continue;
+    const double cost = static_cast<double>(ceil_div(static_cast<int64_t>(t) * col_blocks, 512)) * rows;
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = l; }   // ascending tile counts: a tie keeps the fewer tiles
   }
   return best;
 }

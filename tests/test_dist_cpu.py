@@ -151,3 +151,25 @@ def test_ranks_of_an_outside_launcher_supervise_themselves():
     assert out.stderr.count("repeating it with --fps-ahead 0") == 2
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     assert json.loads(line)["n_gpus"] == 2
+
+
+def test_helper_thread_runs_one_job_and_surfaces_its_error():
+    """bench.Later (the helper thread that prepares the next batch beside the backward pass): run() starts a job, join() waits for it,
+    a second run() waits for the first, and what a job raises comes out of the next join()."""
+    import threading
+    import bench
+    later, seen, gate = bench.Later(), [], threading.Event()
+    later.join()                                            # nothing pending: no-op
+    later.run(lambda: (gate.wait(5), seen.append("a")))
+    assert seen == []
+    gate.set()
+    later.run(seen.append, "b")                             # joins the first job before starting the second
+    later.join()
+    assert seen == ["a", "b"]
+
+    def boom():
+        raise ValueError("from the helper")
+    later.run(boom)
+    with pytest.raises(ValueError, match="from the helper"):
+        later.join()
+    later.join()                                            # the error is reported once

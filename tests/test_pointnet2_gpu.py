@@ -236,6 +236,42 @@ def test_fused_grid_set_abstraction_matches_the_grouped_formulation(gpu, r, n, m
         assert rel(a, t.grad) < 1e-4
 
 
+def test_fused_grid_set_abstraction_records_the_first_sample_that_attains_the_maximum(gpu):
+    """fv2p_sa_grid_fwd's arg output (what backward routes the gradient by): per (centre, channel) the FIRST sample in sample order
+    that attains the maximum — F.max_pool2d's index (pointnet2_modules.py:57-59) — or 255 where the maximum is 0.  Index lists with
+    padded repeats (ball query pads with its first hit): the repeats are exact ties, the recorded sample must be the earliest
+    slot holding the winning point."""
+    import fv2p_native
+    r, n, m, s = 4, 200, 37, 32
+    g = torch.Generator().manual_seed(9)
+    pp = torch.randn(r, n, 64, generator=g).to(gpu)
+    pc = (torch.randn(r, m, 64, generator=g) * 0.5).to(gpu)
+    w2 = (torch.randn(64, 64, generator=g) * 0.2).to(gpu)
+    idx = torch.randint(0, n, (r, m, s), generator=g, dtype=torch.int32)
+    idx[:, :, 20:] = idx[:, :, :1]                           # padded tail
+    idx[:, 5, :] = idx[:, 5, :1]                             # a centre with one distinct neighbour
+    idx[:, :, 7] = idx[:, :, 3]                              # a repeat in the middle
+    idx = idx.to(gpu)
+    out = torch.empty(r, m, 64, device=gpu)
+    arg = torch.empty(r, m, 64, dtype=torch.uint8, device=gpu)
+    fv2p_native.call("fv2p_sa_grid_fwd", pp, pc, idx, w2, r, n, m, s, 64, out, arg, fv2p_native.stream())
+    grouped = bu.grouping_operation(pp.transpose(1, 2).contiguous(), idx)                  # (r, 64, m, s)
+    h2 = torch.relu(torch.einsum("oc,rcms->roms", w2, torch.relu(grouped - pc.transpose(1, 2).unsqueeze(-1))))   # (r, 64, m, s)
+    best = h2.argmax(dim=-1).transpose(1, 2)                                               # (r, m, 64): some sample holding the maximum
+    a = arg.long()
+    live = out > 0
+    assert bool((a[~live] == 255).all()) and bool((a[live] < s).all()) and int(live.sum()) > 1000
+    # the recorded sample holds the same POINT as torch's arg-max sample ...
+    pt_of = lambda samp: torch.gather(idx.long().unsqueeze(2).expand(r, m, 64, s), 3, samp.clamp(max=s - 1).unsqueeze(-1)).squeeze(-1)
+    same_point = pt_of(a) == pt_of(best)
+    # (two different points within rounding of each other can swap between the MFMA and the einsum order: a handful at most)
+    assert int((~same_point & live).sum()) <= 8, int((~same_point & live).sum())
+    # ... and is the EARLIEST slot holding that point
+    slots = idx.long().unsqueeze(2).expand(r, m, 64, s) == pt_of(a).unsqueeze(-1)
+    first = slots.float().argmax(dim=-1)
+    assert bool((first[live] == a[live]).all())
+
+
 @pytest.mark.parametrize("cell", [None, 0.8, 0.1, 7.0])
 def test_three_nn_grid_search_is_the_scan_bit_for_bit(gpu, cell, monkeypatch):
     """fv2p_three_nn_stack_grid against the oracle's scan: decoder shapes (16384 key points per sample against the voxel centres of a

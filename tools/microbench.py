@@ -473,7 +473,9 @@ def oproof():
     for nk, ch in ((35146, 16), (22331, 64), (9919, 128)):
         known = (torch.rand(nk, 3, device=dev) * torch.tensor([70.4, 80.0, 4.0], device=dev) + torch.tensor([0.0, -40.0, -3.0], device=dev)).contiguous()
         cnt = torch.tensor([nk // 3, nk // 3, nk - 2 * (nk // 3)], dtype=torch.int32, device=dev)
+        os.environ["FV2P_NN_GRID"] = "0"   # the scan itself (uniform random points here; the decoder's lattices go through the hashed grid: microbench nn)
         t = timeit(lambda: su.three_nn(key, kc, known, cnt), reps=5, warm=1)
+        os.environ.pop("FV2P_NN_GRID")
         nu = key.shape[0]
         add(f"three_nn (stack) {nu} x {nk // 3} per sample", t, 12.0 * (nu + nk) + 24.0 * nu, 8.0 * nu * (nk / 3), "brute force, LDS tiled")
         dist, idx = su.three_nn(key, kc, known, cnt)
