@@ -999,6 +999,8 @@ def main():
                 step(args.warmup + i)
             torch.cuda.synchronize()
         print(tp.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=90, max_name_column_width=50, max_shapes_column_width=70), file=sys.stderr)
+        # the host side of the same steps (both the stepping and the autograd thread): where the launches are issued from
+        print(tp.key_averages().table(sort_by="self_cpu_time_total", row_limit=60, max_name_column_width=60), file=sys.stderr)
     prof = None
     if args.pyprofile:
         import cProfile

@@ -300,3 +300,32 @@ def test_three_nn_grid_search_is_the_scan_bit_for_bit(gpu, cell, monkeypatch):
     assert np.array_equal(dist.cpu().numpy(), np.sqrt(d2))
     lo = int(uc[:2].sum())
     assert np.isinf(np.sqrt(d2)[lo:lo + 300, 2]).all()          # the two-point sample really has untouched slots
+
+
+@pytest.mark.parametrize("stride", [1, 4])
+def test_three_nn_grid_is_the_scan_at_waymo_size(gpu, stride, monkeypatch):
+    """BASELINE configs[4] size (the oracle's scan would take minutes): the hashed-grid search against this library's own scan, which
+    the tests above pin to the oracle — 2 x 16 384 queries (the clouds' own points plus 2 000 scattered far and wide: sparse regions
+    are where the second pass with its shells and its per-wave scan runs) against the voxel centres of a Waymo-shaped level
+    (~57 k per sample at stride 1), with the decoder's spacing hint.  idx and distances bit for bit."""
+    import os
+    vsz = np.float32([0.1, 0.1, 0.15]) * stride
+    lo = np.float32([-75.2, -75.2, -2.0])
+    rng = np.random.default_rng(8)
+    knowns, unknowns = [], []
+    for s in range(2):
+        c = synth.waymo_like_cloud(40 + s, 180000)[:, :3]
+        cell = np.unique(np.floor((c - lo) / vsz).astype(np.int64), axis=0)
+        knowns.append(((cell + 0.5) * vsz + lo).astype(np.float32))
+        u = c[rng.permutation(c.shape[0])[:16384]].copy()
+        u[:2000] = rng.uniform([-90, -90, -4], [90, 90, 6], (2000, 3)).astype(np.float32)
+        unknowns.append(u.astype(np.float32))
+    kc, uc = np.array([k.shape[0] for k in knowns], np.int32), np.array([u.shape[0] for u in unknowns], np.int32)
+    known, unknown = T(np.concatenate(knowns), gpu), T(np.concatenate(unknowns), gpu)
+    monkeypatch.setenv("FV2P_NN_GRID", "0")
+    d0, i0 = su.three_nn(unknown, T(uc, gpu), known, T(kc, gpu))
+    monkeypatch.setenv("FV2P_NN_GRID", "1")
+    monkeypatch.setattr(su, "GRID_MIN_KNOWN", 0)
+    d1, i1 = su.three_nn(unknown, T(uc, gpu), known, T(kc, gpu), 2.0 * float(vsz[0]))
+    assert int(kc.min()) > (50000 if stride == 1 else 10000)
+    assert torch.equal(i0, i1) and torch.equal(d0, d1)

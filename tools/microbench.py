@@ -293,7 +293,8 @@ def fpstrace():
         t = tr.cpu().numpy().reshape(16, 8).astype(np.float64)
         rounds = 16383.0
         print(f"n = {n}: clocks per round and wave: box test, load issue, first bucket, other buckets, wave arg-max, exchange + barrier, pick | touched buckets per round")
-        for w in range(16):
+        t = t[t[:, 6] > 0]   # the waves that ran (8 of the 16 trace rows)
+        for w in range(t.shape[0]):
             print("  wave %2d: %7.1f %7.1f %7.1f %7.1f %7.1f %7.1f %7.1f | %5.2f" % ((w,) + tuple(t[w, :7] / rounds) + (t[w, 7] / rounds,)))
         print("  mean   : %7.1f %7.1f %7.1f %7.1f %7.1f %7.1f %7.1f | %5.2f   sum %7.1f" % (tuple(t[:, :7].mean(0) / rounds) + (t[:, 7].mean() / rounds, t[:, :7].mean(0).sum() / rounds)))
 
