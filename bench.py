@@ -386,7 +386,7 @@ def build_fv2p_step(args, device, rank, world):
     """BASELINE configs[2]: one optimiser step of the FV2P detector replay on `args.batch` clouds per rank."""
     from fv2p_harness import dist_utils, synth
     from fv2p_harness.fv2p_model import FV2PConfig, FV2PDetector, FV2PWaymoConfig, pad_gt_boxes
-    from fv2p_harness.optim import LeanAdamW
+    from fv2p_harness.optim import LeanAdamW, clip_grad_norm_
     from fv2p_harness.prefetch import BatchAhead, BatchPrefetcher
     from pcdet.datasets.processor.voxel_generator import points_to_voxel_batch
     from pcdet.ops import spconv
@@ -495,9 +495,10 @@ def build_fv2p_step(args, device, rank, world):
         loss = net(clouds, feats, coords, gt, u, key_job=job)
         if args.ahead_at == "mid":
             enqueue_next()   # between forward and backward
-        opt.zero_grad(set_to_none=True)
+        for p in params:     # opt.zero_grad(set_to_none=True) without its hooks and grouping (0.35 -> 0.03 ms of host time)
+            p.grad = None
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(params, cfg.grad_norm_clip, foreach=True)   # GRAD_NORM_CLIP (train_utils.py:43)
+        clip_grad_norm_(params, cfg.grad_norm_clip)   # GRAD_NORM_CLIP (train_utils.py:43); torch's own foreach kernels, less Python
         opt.step()
         return loss
 
@@ -519,7 +520,7 @@ def build_fv2p_step(args, device, rank, world):
             loss = net(clouds, feats, coords, gt, u)
             opt.zero_grad(set_to_none=True)
             loss.backward()
-            torch.nn.utils.clip_grad_norm_(params, cfg.grad_norm_clip, foreach=True)
+            (torch.nn.utils.clip_grad_norm_(params, cfg.grad_norm_clip, foreach=True) if reference else clip_grad_norm_(params, cfg.grad_norm_clip))
             opt.step()
             return loss
         if reference:

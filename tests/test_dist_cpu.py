@@ -173,3 +173,21 @@ def test_helper_thread_runs_one_job_and_surfaces_its_error():
     with pytest.raises(ValueError, match="from the helper"):
         later.join()
     later.join()                                            # the error is reported once
+
+
+def test_lean_gradient_clipping_is_torchs_bit_for_bit():
+    """fv2p_harness.optim.clip_grad_norm_ (the bench step's GRAD_NORM_CLIP, train_utils.py:43): the same foreach kernels in the same
+    order as torch.nn.utils.clip_grad_norm_ — total norm and clipped gradients bit for bit, clipping active and inactive, parameters
+    without a gradient skipped."""
+    from fv2p_harness.optim import clip_grad_norm_
+    torch.manual_seed(0)
+    for scale, max_norm in ((3.0, 2.0), (0.01, 10.0)):
+        ps = [torch.nn.Parameter(torch.randn(s)) for s in [(3, 4), (10,), (5, 5, 2), (7,)]]
+        for p in ps[:3]:
+            p.grad = torch.randn_like(p) * scale
+        qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+        for p, q in zip(ps[:3], qs[:3]):
+            q.grad = p.grad.clone()
+        a = clip_grad_norm_(ps, max_norm)
+        b = torch.nn.utils.clip_grad_norm_(qs, max_norm, foreach=True)
+        assert torch.equal(a, b) and all(torch.equal(p.grad, q.grad) for p, q in zip(ps[:3], qs[:3])) and ps[3].grad is None
