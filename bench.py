@@ -455,8 +455,15 @@ def build_fv2p_step(args, device, rank, world):
 
     later = Later()
 
+    # diagnostic: FV2P_BENCH_HOST_DELAY="<where>:<ms>" makes the stepping thread sleep at one point of every step (where = start, mid,
+    # end) — a step that grows by the delay is bound by the host at that point, one that does not has slack there
+    delay_at, delay_s = (os.environ.get("FV2P_BENCH_HOST_DELAY", ":0").split(":") + ["0"])[:2]
+    delay_s = float(delay_s) * 1e-3
+
     def step(i):
         later.join()   # the helper thread that prepared this batch (and started its key-point sampling) during the step before
+        if delay_at == "start" and delay_s > 0:
+            time.sleep(delay_s)
         model.cfg = cfg_safe if i < min(safe_first, args.warmup) else cfg
         clouds, gt = pool[i % n_pool]
         if ahead is not None:
@@ -497,7 +504,11 @@ def build_fv2p_step(args, device, rank, world):
             enqueue_next()   # between forward and backward
         for p in params:     # opt.zero_grad(set_to_none=True) without its hooks and grouping (0.35 -> 0.03 ms of host time)
             p.grad = None
+        if delay_at == "mid" and delay_s > 0:
+            time.sleep(delay_s)
         loss.backward()
+        if delay_at == "end" and delay_s > 0:
+            time.sleep(delay_s)
         clip_grad_norm_(params, cfg.grad_norm_clip)   # GRAD_NORM_CLIP (train_utils.py:43); torch's own foreach kernels, less Python
         opt.step()
         return loss
