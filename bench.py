@@ -63,6 +63,10 @@ def parse():
     ap.add_argument("--fps-ahead", type=int, default=1, help="FV2P workloads: key points of batch t+1 are sampled (FPS side stream) during the backward pass of step t")
     ap.add_argument("--ahead-at", default="mid", choices=["start", "mid"], help="where a step enqueues the preparation / sampling of the next batch: before its forward pass (measured 40.8 vs 33.0 ms per step) or between forward and backward")
     ap.add_argument("--ahead-stream", default="fps", choices=["fps", "own"], help="--ahead: prepare the next batch on the key-point sampling stream (in front of that batch's sampler) or on a stream of its own")
+    ap.add_argument("--dense-wgrad", type=int, default=0, help="FV2P workloads: the weight gradients of the dense 2-D convs (BEV backbone, heads) run on the weight-gradient "
+                    "side stream beside their data gradients (fv2p_harness/dense_wgrad.py).  Off: measured 31.7 against 32.2 - 32.3 ms per step in one run and "
+                    "41.0 in the next — MIOpen's data- and weight-gradient kernels each fill the chip, so there is little to overlap, and a second busy "
+                    "side stream sometimes lands in the training stream's hardware queue")
     ap.add_argument("--ahead-thread", type=int, default=-1, help="--ahead / --fps-ahead: the preparation of the next batch (its host waits for the voxel counts and rulebook sizes: "
                     "4.7 ms of the stepping thread per step when called in line) runs on a helper thread, joined at the top of the next step.  Default: on for "
                     "fv2p-waymo (measured 35.8 -> 33.2 ms per step), off for fv2p (32.4 - 32.5 against 32.8 ms, and one 41 ms run)")
@@ -148,7 +152,7 @@ class Later(object):
             raise e
 
 
-SAFE_FLAGS = ["--fps-ahead", "0", "--ahead", "0", "--prefetch", "0", "--dense-stream", "0"]   # every side-stream input pipeline off: the plain in-line step
+SAFE_FLAGS = ["--fps-ahead", "0", "--ahead", "0", "--prefetch", "0", "--dense-stream", "0", "--dense-wgrad", "0"]   # every side-stream input pipeline off: the plain in-line step
 
 
 def beat(phase):
@@ -395,7 +399,7 @@ def build_fv2p_step(args, device, rank, world):
     cfg = FV2PWaymoConfig if waymo else FV2PConfig
     if not args.point_stream:
         cfg = type("Cfg", (cfg,), {"point_branch_stream": False})
-    cfg = type("Cfg", (cfg,), {"dense_branch_stream": bool(args.dense_stream)})
+    cfg = type("Cfg", (cfg,), {"dense_branch_stream": bool(args.dense_stream), "dense_wgrad_stream": bool(args.dense_wgrad)})
     vsize, prange = np.array(cfg.voxel_size, np.float32), np.array(cfg.point_cloud_range, np.float32)
     torch.manual_seed(0)
     model = FV2PDetector(cfg).to(device)
@@ -450,7 +454,7 @@ def build_fv2p_step(args, device, rank, world):
     # run both branches on the calling stream, the rest the arrangement asked for.  (Not the point-branch stream for those two steps:
     # a process that has used both side streams runs the dense-branch arrangement at 55 instead of 34 ms per step — a fifth active
     # stream on four hardware queues.)
-    cfg_safe = type("Cfg", (cfg,), {"dense_branch_stream": False, "point_branch_stream": False}) if args.dense_stream else cfg
+    cfg_safe = type("Cfg", (cfg,), {"dense_branch_stream": False, "point_branch_stream": False, "dense_wgrad_stream": False}) if args.dense_stream else cfg
     safe_first = 0 if os.environ.get("FV2P_BENCH_SAFE_FIRST") == "0" else 2
 
     later = Later()

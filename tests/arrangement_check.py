@@ -22,8 +22,8 @@ model(*args).backward()
 torch.cuda.synchronize()
 runs = []
 compared = 0
-for dense, point in ((True, True), (False, True), (False, False)):
-    model.cfg = type("Cfg", (SmallFV2P,), {"dense_branch_stream": dense, "point_branch_stream": point})
+for dense, point, wgrad in ((True, True, False), (False, True, False), (False, False, False), (True, True, True)):
+    model.cfg = type("Cfg", (SmallFV2P,), {"dense_branch_stream": dense, "point_branch_stream": point, "dense_wgrad_stream": wgrad})
     model.taps = {}
     model.zero_grad(set_to_none=True)
     torch.manual_seed(11)   # the RoI head's dropout masks: the same in every arrangement
@@ -33,7 +33,8 @@ for dense, point in ((True, True), (False, True), (False, False)):
     runs.append((loss.item(), model.taps["keypoints"].clone(), model.taps["sampled_rois"].clone(),
                  {k: p.grad.clone() for k, p in model.named_parameters()},
                  (float(model.taps["loss_rpn"]), float(model.taps["loss_point"])), model.taps["prop_scores"].clone()))
-names = ("dense branch on a side stream", "point branch on a side stream", "one stream")
+names = ("dense branch on a side stream", "point branch on a side stream", "one stream",
+         "dense branch on a side stream, its weight gradients on the weight-gradient stream (bench.py's arrangement)")
 for name, other in zip(names[1:], runs[1:]):
     assert torch.equal(other[1], runs[0][1]), f"{name}: other key points than with the {names[0]}"
     # the first stage and the point head do not depend on which RoIs the second stage samples: always compared
