@@ -808,9 +808,21 @@ class IoUGuidedRoIHead(nn.Module):
         features gathered at them, and the corner-geometry embedding."""
         b = bev.shape[0]
         world, local = self.grid_points(s_rois)
-        # BEV stream: bilinear gather at the grid points + channel compression (:243-255)
-        g_bev = self.bev_grid_pool_layer({"batch_size": b, "spatial_features_before_head": bev, "spatial_features_stride": bev_stride}, world.view(b, -1, 3))
-        g_bev = g_bev.view(world.shape[0], world.shape[1], -1).permute(0, 2, 1).contiguous()
+        # BEV stream: bilinear gather at the grid points + channel compression (:243-255).  The g grid points of a column (same x
+        # and y index, z fastest: grid_points) share their BEV position — the rotation is about z — so the reference's g^3 gathers
+        # per RoI are g^2 different ones: gathered and compressed once per column and broadcast over z (autograd sums the g
+        # gradients of a column before the scatter: 6 x fewer float atomics into the map, 6 x fewer rows through the Linear +
+        # BatchNorm1d of the compression — whose batch statistics are those of the repeated rows; only the n / (n - 1) factor of its
+        # running variance sees 13 824 instead of 82 944 rows).  Values equal the per-point form to rounding (tested).
+        batch_dict = {"batch_size": b, "spatial_features_before_head": bev, "spatial_features_stride": bev_stride}
+        g = self.cfg.grid_size_roi
+        if KERNEL_GLUE and world.shape[1] == g ** 3:
+            column = world.view(world.shape[0], g * g, g, 3)[:, :, 0]
+            g_bev = self.bev_grid_pool_layer(batch_dict, column.reshape(b, -1, 3))
+            g_bev = g_bev.view(world.shape[0], g * g, 1, -1).expand(-1, -1, g, -1).reshape(world.shape[0], g ** 3, -1)
+        else:
+            g_bev = self.bev_grid_pool_layer(batch_dict, world.view(b, -1, 3)).view(world.shape[0], world.shape[1], -1)
+        g_bev = g_bev.permute(0, 2, 1).contiguous()
         # corner geometry stream (feature_adaptor/nn_modules.py:6-60): roi-frame corners without rotation or centre
         t = dconst(s_rois, _CORNER_SIGNS, s_rois.dtype) / 2
         corners = s_rois.reshape(-1, 7)[:, None, 3:6] * t[None]

@@ -407,3 +407,40 @@ def test_dense_weight_gradients_on_the_side_stream_are_torchs(gpu):
     assert g1["7.weight"] is None and g1["7.bias"] is not None
     n2, y2, gx2, g2 = run(False)                            # switching back leaves torch's own path
     assert n2 == 0 and torch.equal(y2, y0)
+
+
+@pytest.mark.gpu
+def test_bev_stream_per_grid_column_equals_the_per_point_gather(gpu):
+    """IoUGuidedRoIHead.roi_streams: the g grid points of a column share their BEV position, so the harness gathers and compresses once
+    per column and broadcasts over z.  Against the reference's form (every one of the g^3 points gathered, bev_grid_pooling.py:68-125;
+    fv2p_model.KERNEL_GLUE = False): the compressed BEV stream to 1e-5 (train-mode BatchNorm over repeated rows: the same statistics),
+    the gradients of the map and of the compression weights to 1e-4 relative."""
+    from fv2p_harness import fv2p_model
+    from fv2p_harness.fv2p_model import IoUGuidedRoIHead
+    torch.manual_seed(2)
+    head = IoUGuidedRoIHead(SmallFV2P).to(gpu)
+    b, n = 2, 24
+    bev = torch.randn(b, SmallFV2P.bev_pool_in, 100, 88, device=gpu, requires_grad=True)
+    rois = torch.cat((torch.rand(b, n, 2, device=gpu) * torch.tensor([30.0, 36.0], device=gpu) + torch.tensor([2.0, -18.0], device=gpu),
+                      torch.rand(b, n, 1, device=gpu) - 1.0, torch.rand(b, n, 3, device=gpu) * 2 + 1.5, torch.rand(b, n, 1, device=gpu) * 6.28), dim=-1)
+    go = None
+    outs = []
+    for glue in (False, True):
+        fv2p_model.KERNEL_GLUE = glue
+        try:
+            for p in head.parameters():
+                p.grad = None
+            bev.grad = None
+            g_bev = head.roi_streams(bev, rois)["g_bev"]
+            go = torch.randn_like(g_bev) if go is None else go
+            g_bev.backward(go)
+            outs.append((g_bev.detach().clone(), bev.grad.clone(),
+                         {k: p.grad.clone() for k, p in head.bev_grid_pool_layer.named_parameters() if p.grad is not None}))
+        finally:
+            fv2p_model.KERNEL_GLUE = True
+    rel = lambda a, r: float((a - r).abs().max() / r.abs().max().clamp_min(1e-12))
+    assert outs[0][0].shape == outs[1][0].shape and rel(outs[1][0], outs[0][0]) < 1e-5
+    assert rel(outs[1][1], outs[0][1]) < 1e-4
+    assert len(outs[0][2]) >= 2
+    for k in outs[0][2]:
+        assert rel(outs[1][2][k], outs[0][2][k]) < 1e-4, k
