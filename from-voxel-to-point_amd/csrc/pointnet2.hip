@@ -1348,6 +1348,37 @@ __global__ void three_interp_stack_grad_k(int64_t total, int c, const float* __r
   atomicAdd(&grad_features[static_cast<int64_t>(idx[pt * 3 + 2]) * c + ch], go * weight[pt * 3 + 2]);
 }
 
+// Gradient of the stack interpolation WITHOUT float atomics: the (query, slot) entries that read a known row are collected per row
+// (integer atomics: count, scan, fill), then every (row, channel) sums its entries — one plain store per output, rows nobody read get
+// their zero from the same store (no fill launch).  The order of a row's entries is whatever the fill's atomics give, so the sum's
+// rounding can differ from run to run exactly as the atomic form's does; sorting the lists would cost more than the kernel saves.
+__global__ void interp_count_k(int64_t entries, int m, const int* __restrict__ idx, int* __restrict__ count) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= entries) return;
+  const int r = idx[e];
+  if (r >= 0 && r < m) atomicAdd(&count[r], 1);
+}
+__global__ void interp_fill_k(int64_t entries, int m, const int* __restrict__ idx, const int* __restrict__ start, int* __restrict__ count,
+                              int* __restrict__ list) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= entries) return;
+  const int r = idx[e];
+  if (r >= 0 && r < m) list[start[r] + atomicSub(&count[r], 1) - 1] = static_cast<int>(e);
+}
+__global__ void interp_gather_grad_k(int64_t total, int c, const float* __restrict__ grad_out, const float* __restrict__ weight,
+                                     const int* __restrict__ start, const int* __restrict__ list, float* __restrict__ grad_features) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int64_t row = t / c;
+  const int ch = static_cast<int>(t % c);
+  float acc = 0.f;
+  for (int i = start[row], e1 = start[row + 1]; i < e1; ++i) {
+    const int e = list[i];
+    acc += grad_out[static_cast<int64_t>(e / 3) * c + ch] * weight[e];
+  }
+  grad_features[t] = acc;
+}
+
 static int fps_ref_block(int n) {  // opt_n_threads (cuda_utils.h:10-14): 2^floor(log2 n) clamped to [1, 1024]
   int p = 1;
   while (p * 2 <= n && p < 1024) p *= 2;
@@ -1662,6 +1693,34 @@ extern "C" int fv2p_three_interpolate_stack_grad(int n, int c, const float* grad
   if (total <= 0) return 0;
   FV2P_REQUIRE(grad_out && idx && weight && grad_features, FV2P_EINVAL, "three_interpolate_stack_grad: null pointer");
   hipLaunchKernelGGL(three_interp_stack_grad_k, G1D(total), 0, STREAM(s), total, c, grad_out, idx, weight, grad_features);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" size_t fv2p_three_interpolate_stack_grad_ws_bytes(int n, int m) {
+  const size_t mm = static_cast<size_t>(m > 0 ? m : 1), nn = static_cast<size_t>(n > 0 ? n : 1);
+  return align_up(mm * sizeof(int)) + align_up((mm + 1) * sizeof(int)) + align_up(nn * 3 * sizeof(int)) + align_up(scan_ws_bytes(static_cast<int64_t>(mm)));
+}
+extern "C" int fv2p_three_interpolate_stack_grad_gather(int n, int c, int m, const float* grad_out, const int* idx, const float* weight,
+                                                        float* grad_features, void* ws, size_t ws_bytes, fv2p_stream_t s) {
+  FV2P_REQUIRE(n >= 0 && c >= 0 && m >= 0, FV2P_EINVAL, "three_interpolate_stack_grad_gather: bad sizes");
+  const int64_t total = static_cast<int64_t>(m) * c;
+  if (total <= 0) return 0;
+  FV2P_REQUIRE(grad_features && (n == 0 || (grad_out && idx && weight)), FV2P_EINVAL, "three_interpolate_stack_grad_gather: null pointer");
+  FV2P_REQUIRE(static_cast<int64_t>(n) * 3 < (1ll << 31), FV2P_ELIMIT, "three_interpolate_stack_grad_gather: too many queries");
+  FV2P_REQUIRE(ws && ws_bytes >= fv2p_three_interpolate_stack_grad_ws_bytes(n, m), FV2P_EWORKSPACE, "three_interpolate_stack_grad_gather: workspace too small");
+  hipStream_t st = STREAM(s);
+  Carver cv(ws, ws_bytes);
+  int* count = cv.take<int>(static_cast<size_t>(m));
+  int* start = cv.take<int>(static_cast<size_t>(m) + 1);
+  int* list = cv.take<int>(static_cast<size_t>(n > 0 ? n : 1) * 3);
+  const size_t sb = scan_ws_bytes(m);
+  void* sws = cv.take<char>(sb);
+  const int64_t entries = static_cast<int64_t>(n) * 3;
+  FV2P_HIP(hipMemsetAsync(count, 0, static_cast<size_t>(m) * sizeof(int), st));
+  if (entries > 0) hipLaunchKernelGGL(interp_count_k, G1D(entries), 0, st, entries, m, idx, count);
+  if (int rc = exclusive_scan_i32(count, start, m, start + m, sws, sb, st)) return rc;
+  if (entries > 0) hipLaunchKernelGGL(interp_fill_k, G1D(entries), 0, st, entries, m, idx, start, count, list);
+  hipLaunchKernelGGL(interp_gather_grad_k, G1D(total), 0, st, total, c, grad_out, weight, start, list, grad_features);
   FV2P_LAUNCH_CHECK();
   return 0;
 }

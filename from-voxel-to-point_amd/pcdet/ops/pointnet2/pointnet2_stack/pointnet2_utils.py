@@ -91,9 +91,22 @@ def _interp(saved, features, idx, weight):
     return out
 
 
+# The gather form of the interpolation gradient (fv2p_three_interpolate_stack_grad_gather: per-row entry lists, no float atomics, no
+# zero fill) is opt-in (FV2P_INTERP_GATHER=1): measured on MI355X it loses wherever a few known rows are read by many queries —
+# one thread then walks a list of thousands (profiles/r03_op_roofline.txt: 0.9 - 2.0 ms against 0.13 - 0.24 ms of the scatter form
+# at 49 152 queries) — and does not pay in the FV2P step either (31.3 - 31.5 against 30.8 - 31.1 ms per step).
+GATHER_GRAD_MIN_QUERIES = 8192
+
+
 def _interp_grad(saved, grad):
-    g = torch.zeros((saved["rows"], grad.shape[1]), dtype=grad.dtype, device=grad.device)
-    G.run("fv2p_three_interpolate_stack_grad", grad.shape[0], grad.shape[1], grad.contiguous(), saved["idx"], saved["weight"], g)
+    n, c, m = grad.shape[0], grad.shape[1], saved["rows"]
+    if n >= GATHER_GRAD_MIN_QUERIES and os.environ.get("FV2P_INTERP_GATHER", "0") == "1":
+        g = torch.empty((m, c), dtype=grad.dtype, device=grad.device)
+        ws = G.scratch("fv2p_three_interpolate_stack_grad_ws_bytes", grad.device, n, m)
+        G.run("fv2p_three_interpolate_stack_grad_gather", n, c, m, grad.contiguous(), saved["idx"], saved["weight"], g, ws, ws.numel())
+        return g
+    g = torch.zeros((m, c), dtype=grad.dtype, device=grad.device)
+    G.run("fv2p_three_interpolate_stack_grad", n, c, grad.contiguous(), saved["idx"], saved["weight"], g)
     return g
 
 

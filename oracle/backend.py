@@ -46,6 +46,10 @@ def _three_interp_stack_grad(n, c, grad_out, idx, weight, grad_feats, stream):
     _fill(grad_feats, acc.astype(np.float32))
 
 
+def _three_interp_stack_grad_gather(n, c, m, grad_out, idx, weight, grad_feats, ws, ws_bytes, stream):
+    _three_interp_stack_grad(n, c, grad_out, idx, weight, grad_feats, stream)
+
+
 def _fps(b, n, m, xyz, temp, idxs, ws, ws_bytes, stream):
     out, t = oracle.furthest_point_sample(_np(xyz).reshape(b, n, 3), m)
     _fill(idxs, out), _fill(temp, t)
@@ -170,6 +174,7 @@ _TABLE = {
     "fv2p_three_nn_stack_grid": _three_nn_stack_grid,
     "fv2p_three_interpolate_stack": _three_interp_stack,
     "fv2p_three_interpolate_stack_grad": _three_interp_stack_grad,
+    "fv2p_three_interpolate_stack_grad_gather": _three_interp_stack_grad_gather,
     "fv2p_furthest_point_sampling": _fps,
     "fv2p_points_in_boxes": _points_in_boxes,
     "fv2p_nms": _nms,

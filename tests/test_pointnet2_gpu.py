@@ -329,3 +329,39 @@ def test_three_nn_grid_is_the_scan_at_waymo_size(gpu, stride, monkeypatch):
     d1, i1 = su.three_nn(unknown, T(uc, gpu), known, T(kc, gpu), 2.0 * float(vsz[0]))
     assert int(kc.min()) > (50000 if stride == 1 else 10000)
     assert torch.equal(i0, i1) and torch.equal(d0, d1)
+
+
+@pytest.mark.parametrize("n,m,c", [(49152, 35146, 16), (49152, 5186, 128), (9000, 700, 64), (10, 5, 4)])
+def test_interpolation_gradient_gather_form_equals_the_scatter_form(gpu, n, m, c, monkeypatch):
+    """fv2p_three_interpolate_stack_grad_gather (entry lists per known row, no float atomics, no zero fill) against the oracle's
+    float64 accumulation and against the scatter form, at the decoder's shapes: rows nobody reads come out exactly zero, rows read
+    by hundreds of queries (a skewed idx) agree to 1e-5 relative; through the autograd op FV2P_INTERP_GATHER=1 selects it (the default
+    stays the scatter form: the gather form measured slower on skewed lists)."""
+    import fv2p_native
+    rng = np.random.default_rng(n + c)
+    idx = rng.integers(0, m, (n, 3)).astype(np.int32)
+    idx[: n // 4] = rng.integers(0, max(m // 50, 1), (n // 4, 3))          # hot rows: long entry lists
+    idx[:, 2][rng.random(n) < 0.1] = idx[:, 0][rng.random(n) < 0.1][0] if n > 10 else idx[0, 0]
+    unread = np.setdiff1d(np.arange(m), idx.reshape(-1))
+    w = rng.random((n, 3)).astype(np.float32)
+    g = rng.standard_normal((n, c)).astype(np.float32)
+    want = np.zeros((m, c), np.float64)
+    for k in range(3):
+        np.add.at(want, idx[:, k], g.astype(np.float64) * w[:, k:k + 1])
+    tg, ti, tw = T(g, gpu), T(idx, gpu), T(w, gpu)
+    out = torch.full((m, c), 7.0, device=gpu)                              # no zero fill expected of the caller
+    ws = torch.empty(int(fv2p_native.lib().fv2p_three_interpolate_stack_grad_ws_bytes(n, m)), dtype=torch.uint8, device=gpu)
+    fv2p_native.call("fv2p_three_interpolate_stack_grad_gather", n, c, m, tg, ti, tw, out, ws, ws.numel(), fv2p_native.stream())
+    got = out.cpu().numpy()
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() < 1e-5 * scale
+    if unread.size:
+        assert not got[unread].any()
+    feats = torch.randn(m, c, device=gpu, requires_grad=True)
+    monkeypatch.setenv("FV2P_INTERP_GATHER", "1")
+    su.three_interpolate(feats, ti, tw).backward(tg)                       # the autograd op: gather form from 8192 queries on
+    assert np.abs(feats.grad.cpu().numpy() - want).max() < 1e-5 * scale
+    monkeypatch.setenv("FV2P_INTERP_GATHER", "0")
+    feats.grad = None
+    su.three_interpolate(feats, ti, tw).backward(tg)
+    assert np.abs(feats.grad.cpu().numpy() - want).max() < 1e-5 * scale
