@@ -93,7 +93,7 @@ def _interp(saved, features, idx, weight):
 
 # The gather form of the interpolation gradient (fv2p_three_interpolate_stack_grad_gather: per-row entry lists, no float atomics, no
 # zero fill) is opt-in (FV2P_INTERP_GATHER=1): measured on MI355X it loses wherever a few known rows are read by many queries —
-# one thread then walks a list of thousands (profiles/r03_op_roofline.txt: 0.9 - 2.0 ms against 0.13 - 0.24 ms of the scatter form
+# one thread then walks a list of thousands (profiles/r03_op_roofline.txt: 0.8 - 1.6 ms against 0.09 - 0.33 ms of the scatter form
 # at 49 152 queries) — and does not pay in the FV2P step either (31.3 - 31.5 against 30.8 - 31.1 ms per step).
 GATHER_GRAD_MIN_QUERIES = 8192
 

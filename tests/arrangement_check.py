@@ -52,9 +52,10 @@ for name, other in zip(names[1:], runs[1:]):
     for k, g0 in runs[0][3].items():
         # In a process whose BEV map is not reproducible the 1e-5 of the forward pass grows on the way back: the sparse backbone and
         # the decoder sit at the far end of the backward chain (the tolerances of test_fv2p_step_gpu.py: 2e-3, 2e-2 at the deep end).
-        # (The bias of a conv that feeds BatchNorm has a zero gradient up to rounding: absolute floor beside the relative bound.)
+        # (The bias of a conv that feeds BatchNorm has a zero gradient up to rounding — 4e-6 in norm was seen in a process with the
+        # non-reproducible map: absolute floor beside the relative bound.)
         rel = 2e-2 if k.startswith(("backbone_3d.", "post_pfe.")) else 2e-3
-        err, bound = float((other[3][k] - g0).norm()), rel * float(g0.norm()) + 1e-6 * g0.numel() ** 0.5
+        err, bound = float((other[3][k] - g0).norm()), rel * float(g0.norm()) + 2e-5 * g0.numel() ** 0.5
         assert err < bound, f"{name}: gradient of {k} differs by {err:.3e} (bound {bound:.3e})"
 assert compared >= 1, "no arrangement sampled the same RoIs as the first: nothing of the second stage was compared"
 print(f"ARRANGEMENTS AGREE (second stage compared in {compared} of {len(runs) - 1} arrangements)")
