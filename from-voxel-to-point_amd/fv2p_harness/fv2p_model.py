@@ -253,9 +253,24 @@ class BEVBackbone(nn.Module):
     def forward(self, x):
         ups = []
         for blk, de in zip(self.blocks, self.deblocks):
-            x = blk(x)
-            ups.append(de(x))
+            x = self._block(blk, x)
+            ups.append(de(x))   # (the 1 x 1 ConvTranspose2d of the first level issued as a 1 x 1 conv measured 0.15 ms per step slower)
         return torch.cat(ups, dim=1)
+
+    @staticmethod
+    def _block(blk, x):
+        """blk(x) with the leading ZeroPad2d(1) + Conv2d(padding=0) pair of the reference's block (base_bev_backbone.py:27-33) issued as
+        one zero-padded convolution: the same sums, without the padded copy of the map (108 MB written and read again at the FV2P size,
+        and its slice copy in the backward pass).  The module list keeps the reference's layout (state dicts load unchanged)."""
+        mods = list(blk)
+        if (KERNEL_GLUE and len(mods) >= 2 and isinstance(mods[0], nn.ZeroPad2d) and type(mods[1]) is nn.Conv2d and "forward" not in mods[1].__dict__
+                and tuple(mods[0].padding) == (1, 1, 1, 1) and tuple(mods[1].padding) == (0, 0) and mods[1].padding_mode == "zeros"):
+            c = mods[1]
+            x = F.conv2d(x, c.weight, c.bias, c.stride, (1, 1), c.dilation, c.groups)
+            mods = mods[2:]
+        for m in mods:
+            x = m(x)
+        return x
 
 
 class AnchorLossFn(torch.autograd.Function):
