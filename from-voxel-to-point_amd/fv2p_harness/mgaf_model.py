@@ -65,8 +65,9 @@ class DCNBEVBackbone(nn.Module):
 
     def forward(self, x):
         ups = []
+        from .fv2p_model import BEVBackbone
         for blk, de in zip(self.blocks, self.deblocks):
-            x = blk(x)
+            x = BEVBackbone._block(blk, x)   # the leading ZeroPad2d + Conv2d pair as one zero-padded convolution (same sums, no padded copy)
             ups.append(de(x))
         return torch.cat(ups, dim=1)
 
