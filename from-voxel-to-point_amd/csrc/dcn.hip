@@ -18,6 +18,7 @@
 // [B, dg*2*K, Ho, Wo] / [B, dg*K, Ho, Wo] with (2*(i*kw+j), +1) = (dh, dw).
 #include "common.hpp"
 #include <stdlib.h>
+#include <stdio.h>
 
 namespace fv2p {
 
@@ -401,6 +402,203 @@ __global__ void dcn_reduce_k(const float* __restrict__ partial, int chunks, long
   out[t] = s;
 }
 
+// ================================================================ round 4 kernels ==================
+
+__device__ __forceinline__ void glds16(const float* gsrc, float* lds_dst) {
+  const unsigned dst = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<uintptr_t>(lds_dst)));
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+
+struct Corner4 {
+  unsigned o[4];
+  float w[4];
+  float m;
+};
+
+__device__ __forceinline__ void make_corners(const DcnGeom& g, bool live, int b, float h_im, float w_im, float m, unsigned lane_bytes, Corner4& t) {
+  const bool valid = live && (h_im > -1.f && w_im > -1.f && h_im < static_cast<float>(g.H) && w_im < static_cast<float>(g.W));
+  const float hf = floorf(h_im), wf = floorf(w_im);
+  const int h_low = static_cast<int>(hf), w_low = static_cast<int>(wf);
+  const int h_high = h_low + 1, w_high = w_low + 1;
+  const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+  const bool hl = valid && h_low >= 0, hhi = valid && h_high <= g.H - 1, wl = w_low >= 0, whi = w_high <= g.W - 1;
+  t.w[0] = (hl && wl) ? hh * hw : 0.f;
+  t.w[1] = (hl && whi) ? hh * lw : 0.f;
+  t.w[2] = (hhi && wl) ? lh * hw : 0.f;
+  t.w[3] = (hhi && whi) ? lh * lw : 0.f;
+  t.m = valid ? m : 0.f;
+  const int h0 = min(max(h_low, 0), g.H - 1), h1 = min(max(h_high, 0), g.H - 1);
+  const int w0 = min(max(w_low, 0), g.W - 1), w1 = min(max(w_high, 0), g.W - 1);
+  const unsigned row0 = static_cast<unsigned>((b * g.H + h0) * g.W), row1 = static_cast<unsigned>((b * g.H + h1) * g.W);
+  const unsigned pitch = static_cast<unsigned>(g.Cin) * 4u;
+  t.o[0] = (row0 + w0) * pitch + lane_bytes;
+  t.o[1] = (row0 + w1) * pitch + lane_bytes;
+  t.o[2] = (row1 + w0) * pitch + lane_bytes;
+  t.o[3] = (row1 + w1) * pitch + lane_bytes;
+}
+
+__device__ __forceinline__ f32x4 ldx4(const char* base, unsigned off) { return *reinterpret_cast<const f32x4*>(base + off); }
+
+// x NHWC [B,H,W,Cin]; wt_oc [K][Cout][Cin]; y NHWC [npix][Cout].
+// Block = 4 waves, wave = MB*16 pixels x NB*16 output channels (grid.y = column blocks of NB*16).  Product formed transposed:
+// A = weights (rows = output channels, LDS), B = modulated bilinear samples (columns = pixels, registers of the lane that gathered them).
+template <int NB, int MB>
+__global__ __launch_bounds__(256, 2) void dcn_fwd2_k(DcnGeom g, const float* __restrict__ x, const float* __restrict__ wt_oc,
+                                                     const float* __restrict__ bias, const float* __restrict__ offset,
+                                                     const float* __restrict__ mask, float* __restrict__ y, long long pix_base) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x NB x 256 floats
+  constexpr int FRAG = NB * 256;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 15, gq = lane >> 4;
+  const long long npix = static_cast<long long>(g.B) * g.Ho * g.Wo;
+  const int plane = g.Ho * g.Wo;
+  const int K = g.kh * g.kw, cpg = g.Cin / g.dg, cps = cpg / 16, segs = K * g.dg, steps = segs * cps;
+  const int col0 = blockIdx.y * (NB * 16);
+  const long long tile0 = pix_base + static_cast<long long>(blockIdx.x) * (64 * MB) + wave * (16 * MB);
+  // this lane's pixels
+  bool live[MB];
+  int pb[MB], pho[MB], pwo[MB], ppos[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const long long pix = tile0 + mb * 16 + n;
+    live[mb] = pix < npix;
+    const long long pp = live[mb] ? pix : 0;
+    pb[mb] = static_cast<int>(pp / plane);
+    ppos[mb] = static_cast<int>(pp % plane);
+    pho[mb] = ppos[mb] / g.Wo;
+    pwo[mb] = ppos[mb] % g.Wo;
+  }
+  // weight rows this lane feeds to the LDS-DMA: piece nb (1 KB = 64 lanes x 16 B), lane (n, gq) <- wt_oc[k][col0 + nb*16 + n][c0 + 4 gq ..]
+  constexpr int NDMA = (NB + 3) / 4;
+  const float* wrow[NDMA];
+#pragma unroll
+  for (int i = 0; i < NDMA; ++i) {
+    const int nb = wave + 4 * i;
+    const int co = min(col0 + nb * 16 + n, g.Cout - 1);
+    wrow[i] = wt_oc + static_cast<long long>(co) * g.Cin + 4 * gq;
+  }
+  auto dma = [&](int k, int c0, float* buf) {
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+      const int nb = wave + 4 * i;
+      if (nb < NB) glds16(wrow[i] + (static_cast<long long>(k) * g.Cout * g.Cin + c0), buf + nb * 256);
+    }
+  };
+  Corner4 t[MB];
+  float roh[MB], row_[MB], rom[MB];   // raw offsets / mask of the NEXT segment
+  auto load_offsets = [&](int k, int dgi) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const float* ob = offset + (static_cast<long long>(pb[mb]) * g.dg + dgi) * 2 * K * plane + ppos[mb];
+      roh[mb] = ob[static_cast<long long>(2 * k) * plane];
+      row_[mb] = ob[static_cast<long long>(2 * k + 1) * plane];
+      rom[mb] = mask[((static_cast<long long>(pb[mb]) * g.dg + dgi) * K + k) * plane + ppos[mb]];
+    }
+  };
+  auto set_taps = [&](int k) {
+    const int i = k / g.kw, j = k % g.kw;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const float h_im = static_cast<float>(pho[mb] * g.sh - g.ph + i * g.dh) + roh[mb];
+      const float w_im = static_cast<float>(pwo[mb] * g.sw - g.pw + j * g.dw) + row_[mb];
+      make_corners(g, live[mb], pb[mb], h_im, w_im, rom[mb], 16u * gq, t[mb]);
+    }
+  };
+  f32x4 raw[MB][4];
+  auto gather = [&](int c0) {
+    const char* xc = reinterpret_cast<const char*>(x + c0);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) raw[mb][q] = ldx4(xc, t[mb].o[q]);
+  };
+  auto combine = [&](f32x4 (&bs)[MB]) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      f32x4 a;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = t[mb].w[0] * raw[mb][0][e];
+        v = __builtin_fmaf(t[mb].w[1], raw[mb][1][e], v);
+        v = __builtin_fmaf(t[mb].w[2], raw[mb][2][e], v);
+        v = __builtin_fmaf(t[mb].w[3], raw[mb][3][e], v);
+        a[e] = v * t[mb].m;
+      }
+      bs[mb] = a;
+    }
+  };
+  f32x4 acc[NB][MB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // prologue: segment 0 taps, step 0 operands
+  load_offsets(0, 0);
+  set_taps(0);
+  if (segs > 1) load_offsets(g.dg > 1 ? 0 : 1, g.dg > 1 ? 1 : 0);   // segment 1 = (tap, group) after (0, 0)
+  dma(0, 0, lds);
+  gather(0);
+  f32x4 bs[MB];
+  combine(bs);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int k = 0, dgi = 0, c = 0;   // position of step s
+  for (int s = 0; s < steps; ++s) {
+    float* cur = lds + (s & 1) * FRAG;
+    // position of step s + 1
+    int c1 = c + 1, dg1 = dgi, k1 = k;
+    if (c1 == cps) { c1 = 0; ++dg1; if (dg1 == g.dg) { dg1 = 0; ++k1; } }
+    const bool more = s + 1 < steps;
+    if (more) {
+      if (c1 == 0) set_taps(k1);                    // offsets were fetched at the first step of this segment
+      dma(k1, (dg1 * cps + c1) * 16, lds + ((s + 1) & 1) * FRAG);
+      gather((dg1 * cps + c1) * 16);
+      if (c1 == 0) {                                // fetch the offsets of the segment after that
+        int dg2 = dg1 + 1, k2 = k1;
+        if (dg2 == g.dg) { dg2 = 0; ++k2; }
+        if (k2 < K) load_offsets(k2, dg2);
+      }
+    }
+    f32x4 af[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) af[nb] = *reinterpret_cast<const f32x4*>(&cur[(nb * 64 + lane) * 4]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[nb][j], bs[mb][j], acc[nb][mb], 0, 0, 0);
+    if (more) combine(bs);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    c = c1; dgi = dg1; k = k1;
+  }
+  // epilogue: acc[nb][mb][reg] = y[pixel mb*16 + n][col0 + nb*16 + 4 gq + reg]
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const long long pix = tile0 + mb * 16 + n;
+    if (pix >= npix) continue;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int col = col0 + nb * 16 + 4 * gq;
+      if (col >= g.Cout) continue;
+      f32x4 v = acc[nb][mb];
+      float* dst = y + pix * g.Cout + col;
+      if (col + 3 < g.Cout && (g.Cout & 3) == 0) {
+        if (bias) { const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + col); v += bb; }
+        *reinterpret_cast<f32x4*>(dst) = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (col + e < g.Cout) dst[e] = v[e] + (bias ? bias[col + e] : 0.f);
+      }
+    }
+  }
+}
+
+
 static int dcn_check(const DcnGeom& g) {
   FV2P_REQUIRE(g.B >= 0 && g.H >= 1 && g.W >= 1 && g.Cin >= 1 && g.Cout >= 1 && g.kh >= 1 && g.kw >= 1 && g.sh >= 1 && g.sw >= 1 &&
                    g.dh >= 1 && g.dw >= 1 && g.dg >= 1 && g.Ho >= 1 && g.Wo >= 1,
@@ -420,7 +618,63 @@ using namespace fv2p;
                       int ph, int pw, int dh, int dw, int deformable_group
 #define DCN_GEOM_INIT DcnGeom g = {batch, height, width, c_in, c_out, h_out, w_out, kh, kw, sh, sw, ph, pw, dh, dw, deformable_group}
 
-extern "C" int fv2p_dcn_forward(const float* x_nhwc, const float* wt, const float* bias, const float* offset, const float* mask,
+
+static int dcn_cu_count() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+    else cus = 256;
+  }
+  return cus;
+}
+
+template <int NB, int MB>
+static void dcn_fwd_launch(const DcnGeom& g, const float* x, const float* wt_oc, const float* bias, const float* offset, const float* mask,
+                           float* y, long long pix_base, long long npix_part, int col_blocks, hipStream_t stream) {
+  if (npix_part <= 0) return;
+  const dim3 grid(static_cast<unsigned>(ceil_div(npix_part, 64 * MB)), static_cast<unsigned>(col_blocks));
+  hipLaunchKernelGGL((dcn_fwd2_k<NB, MB>), grid, dim3(256), 2 * NB * 256 * sizeof(float), stream, g, x, wt_oc, bias, offset, mask, y, pix_base);
+}
+
+// wt_oc: weight permuted to [kh*kw][Cout][Cin] (input channels contiguous: what the LDS-DMA of the forward kernel fetches 16 bytes at a time)
+extern "C" int fv2p_dcn_forward(const float* x_nhwc, const float* wt_oc, const float* bias, const float* offset, const float* mask,
+                                DCN_GEOM_ARGS, float* y_nhwc, fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DCN_GEOM_INIT;
+  if (int rc = dcn_check(g)) return rc;
+  const long long npix = static_cast<long long>(g.B) * g.Ho * g.Wo;
+  if (npix == 0) return 0;
+  FV2P_REQUIRE(x_nhwc && wt_oc && offset && mask && y_nhwc, FV2P_EINVAL, "dcn_forward: null pointer");
+  FV2P_REQUIRE(static_cast<long long>(g.B) * g.H * g.W * g.Cin * 4 < (1ll << 32), FV2P_ELIMIT, "dcn_forward: input above 4 GiB (split the batch)");
+  // Tile plan.  A workgroup computes 64*MB pixels x 16*NB columns; per-pixel arithmetic does not depend on the plan (every output element
+  // is one fused multiply-add chain over (tap, channel) in a fixed order), so results are identical for every batch size.
+  // Whole rounds of 128-pixel tiles, then the remainder as 64-pixel tiles: the last round costs half a tile per CU.
+  const int cus = dcn_cu_count();
+  const int nb_all = static_cast<int>(ceil_div(g.Cout, 16));
+  const char* force = getenv("FV2P_DCN_FWD_PLAN");   // development: "<NB>,<MB>"
+  int fnb = 0, fmb = 0;
+  if (force) sscanf(force, "%d,%d", &fnb, &fmb);
+  int NBsel = nb_all <= 4 ? 4 : (nb_all <= 8 ? 8 : 16);
+  if (fnb) NBsel = fnb;
+  const int col_blocks = static_cast<int>(ceil_div(nb_all, NBsel));
+  const long long tiles128 = npix / 128;
+  long long big = (tiles128 / cus) * cus;   // whole rounds
+  if (NBsel == 16) big = 0;                 // <16,2> does not fit the register file
+  if (fmb == 1) big = 0;
+  if (fmb == 2) big = tiles128;
+  const long long big_pix = big * 128;
+#define DCN_F(NB) do { dcn_fwd_launch<NB, 2>(g, x_nhwc, wt_oc, bias, offset, mask, y_nhwc, 0, big_pix, col_blocks, stream); \
+                       dcn_fwd_launch<NB, 1>(g, x_nhwc, wt_oc, bias, offset, mask, y_nhwc, big_pix, npix - big_pix, col_blocks, stream); } while (0)
+  if (NBsel == 4) DCN_F(4);
+  else if (NBsel == 8) DCN_F(8);
+  else dcn_fwd_launch<16, 1>(g, x_nhwc, wt_oc, bias, offset, mask, y_nhwc, 0, npix, col_blocks, stream);
+#undef DCN_F
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fv2p_dcn_forward_v1(const float* x_nhwc, const float* wt, const float* bias, const float* offset, const float* mask,
                                 DCN_GEOM_ARGS, float* y_nhwc, fv2p_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   DCN_GEOM_INIT;

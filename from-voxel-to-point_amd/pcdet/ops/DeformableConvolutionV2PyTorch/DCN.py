@@ -18,8 +18,15 @@ def _geom(input, weight, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, d
 
 
 def _wt(weight):
+    """[Cout, Cin, kh, kw] -> [kh*kw][Cin][Cout]: the backward kernels' layout (output channels contiguous)."""
     cout, cin, kh, kw = weight.shape
     return weight.permute(2, 3, 1, 0).reshape(kh * kw, cin, cout).contiguous()
+
+
+def _wt_oc(weight):
+    """[Cout, Cin, kh, kw] -> [kh*kw][Cout][Cin]: the forward kernel's layout (input channels contiguous)."""
+    cout, cin, kh, kw = weight.shape
+    return weight.permute(2, 3, 0, 1).reshape(kh * kw, cout, cin).contiguous()
 
 
 def modulated_deform_conv_forward(input, weight, bias, offset, mask, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w,
@@ -31,7 +38,7 @@ def modulated_deform_conv_forward(input, weight, bias, offset, mask, kernel_h, k
     x = input.float().permute(0, 2, 3, 1).contiguous()
     y = torch.empty((B * Ho * Wo, Cout), dtype=torch.float32, device=input.device)
     with _nat.device_guard(input.device):
-        _nat.call("fv2p_dcn_forward", x, _wt(weight.float()), bias.float().contiguous() if bias is not None else None,
+        _nat.call("fv2p_dcn_forward", x, _wt_oc(weight.float()), bias.float().contiguous() if bias is not None else None,
                   offset.float().contiguous(), mask.float().contiguous(), *g, y, _nat.stream())
     return y.view(B, Ho, Wo, Cout).permute(0, 3, 1, 2).contiguous().to(input.dtype)
 

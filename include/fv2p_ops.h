@@ -438,13 +438,14 @@ int fv2p_sa_grid_bwd(const float* per_point, const float* per_centre, const int*
  * (pcdet/ops/DeformableConvolutionV2PyTorch/src/vision.cpp:6-12 -> src/modulated_deform_conv.h:10-86 ->
  * src/cuda/modulated_deform_conv_cuda.cu:19-280, kernels src/cuda/modulated_deform_im2col_cuda.cuh:24-328).
  * Fused implicit GEMM: no `columns` buffer.  Activations are NHWC on this side of the boundary:
- *   x_nhwc [B,H,W,Cin], y_nhwc / dy_nhwc [B*Ho*Wo, Cout], wt = weight permuted to [kh*kw][Cin][Cout];
+ *   x_nhwc [B,H,W,Cin], y_nhwc / dy_nhwc [B*Ho*Wo, Cout]; the weight [Cout,Cin,kh,kw] arrives permuted: forward takes
+ *   wt_oc = [kh*kw][Cout][Cin] (input channels contiguous), backward wt = [kh*kw][Cin][Cout] (output channels contiguous);
  *   offset [B, dg*2*kh*kw, Ho, Wo] ((2k, 2k+1) = (dh, dw)), mask [B, dg*kh*kw, Ho, Wo] — reference layouts.
  * groups == 1; Cin / deformable_group must be a multiple of 16; Cout <= 256.
  * backward: dx_nhwc must be zeroed by the caller (tap scatter uses atomics); doffset, dmask, dwt are fully written
  * (dwt [kh*kw][Cin][Cout]; the bias gradient is a plain column sum done by the caller).
  */
-int fv2p_dcn_forward(const float* x_nhwc, const float* wt, const float* bias, const float* offset,
+int fv2p_dcn_forward(const float* x_nhwc, const float* wt_oc, const float* bias, const float* offset,
                      const float* mask, int batch, int height, int width, int c_in, int c_out, int h_out,
                      int w_out, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
                      int deformable_group, float* y_nhwc, fv2p_stream_t stream);

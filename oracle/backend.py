@@ -137,10 +137,10 @@ def _three_interp_batch_grad(b, c, n, m, grad_out, idx, weight, grad_points, str
     _fill(grad_points, acc.astype(np.float32))
 
 
-def _dcn_forward(x_nhwc, wt, bias, offset, mask, b, h, w, cin, cout, ho, wo, kh, kw, sh, sw, ph, pw, dh, dw, dg, y_nhwc, stream):
+def _dcn_forward(x_nhwc, wt_oc, bias, offset, mask, b, h, w, cin, cout, ho, wo, kh, kw, sh, sw, ph, pw, dh, dw, dg, y_nhwc, stream):
     from oracle import dcn_oracle
     x = x_nhwc.view(b, h, w, cin).permute(0, 3, 1, 2)
-    weight = wt.view(kh, kw, cin, cout).permute(3, 2, 0, 1)
+    weight = wt_oc.view(kh, kw, cout, cin).permute(2, 3, 0, 1)   # the forward entry takes [kh*kw][Cout][Cin]
     y = dcn_oracle.modulated_deform_conv(x, offset.view(b, dg * 2 * kh * kw, ho, wo), mask.view(b, dg * kh * kw, ho, wo), weight, bias,
                                          (sh, sw), (ph, pw), (dh, dw), dg)
     y_nhwc.copy_(y.permute(0, 2, 3, 1).reshape(b * ho * wo, cout))
