@@ -19,6 +19,7 @@
 #include "common.hpp"
 #include <stdlib.h>
 #include <stdio.h>
+#include <algorithm>
 
 namespace fv2p {
 
@@ -599,6 +600,497 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd2_k(DcnGeom g, const float* __r
 }
 
 
+
+// ---------------------------------------------------------------- backward, pass 1: column gradients -------------
+// dcol[p, k, ci] = sum_co dy[p, co] * W[k][ci][co]  (the reference's gemm into `columns`, modulated_deform_conv_cuda.cu:196-204),
+// formed transposed (A = W rows ci from LDS, B = dy rows of the wave's pixels, resident in registers for the whole kernel), so that a
+// lane ends up with FOUR ADJACENT CHANNELS of ONE pixel: exactly the float4 it gathers from x at the four bilinear corners.  Epilogue per
+// (tap, group, 32-channel block):  D_q += <dcol, x[corner q]>  (-> grad_mask, grad_offset at the end of the (tap, group) segment,
+// modulated_deform_im2col_cuda.cuh:256-328) and  colg[p, k, ci] = dcol * mask  (what pass 2 sums into grad_input, :196-254).
+struct CornerB {
+  unsigned o[4];
+  float w[4];
+  float m, lh, lw;
+  unsigned vb;   // bit q: corner q is inside the map (and the sample valid)
+};
+
+__device__ __forceinline__ void make_corners_b(const DcnGeom& g, bool live, int b, float h_im, float w_im, float m, unsigned lane_bytes, CornerB& t) {
+  const bool valid = live && (h_im > -1.f && w_im > -1.f && h_im < static_cast<float>(g.H) && w_im < static_cast<float>(g.W));
+  const float hf = floorf(h_im), wf = floorf(w_im);
+  const int h_low = static_cast<int>(hf), w_low = static_cast<int>(wf);
+  const int h_high = h_low + 1, w_high = w_low + 1;
+  const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+  const bool hl = valid && h_low >= 0, hhi = valid && h_high <= g.H - 1, wl = w_low >= 0, whi = w_high <= g.W - 1;
+  t.w[0] = (hl && wl) ? hh * hw : 0.f;
+  t.w[1] = (hl && whi) ? hh * lw : 0.f;
+  t.w[2] = (hhi && wl) ? lh * hw : 0.f;
+  t.w[3] = (hhi && whi) ? lh * lw : 0.f;
+  t.vb = (hl && wl ? 1u : 0u) | (hl && whi ? 2u : 0u) | (hhi && wl ? 4u : 0u) | (hhi && whi ? 8u : 0u);
+  t.m = valid ? m : 0.f;
+  t.lh = lh; t.lw = lw;
+  const int h0 = min(max(h_low, 0), g.H - 1), h1 = min(max(h_high, 0), g.H - 1);
+  const int w0 = min(max(w_low, 0), g.W - 1), w1 = min(max(w_high, 0), g.W - 1);
+  const unsigned row0 = static_cast<unsigned>((b * g.H + h0) * g.W), row1 = static_cast<unsigned>((b * g.H + h1) * g.W);
+  const unsigned pitch = static_cast<unsigned>(g.Cin) * 4u;
+  t.o[0] = (row0 + w0) * pitch + lane_bytes;
+  t.o[1] = (row0 + w1) * pitch + lane_bytes;
+  t.o[2] = (row1 + w0) * pitch + lane_bytes;
+  t.o[3] = (row1 + w1) * pitch + lane_bytes;
+}
+
+// JO = ceil(Cout / 16); NBP = 16-pixel blocks per wave; block = 4 waves = 64 * NBP pixels; step = (tap, group, 16 * MC input channels)
+template <int JO, int NBP, int MC>
+__global__ __launch_bounds__(256, 2) void dcn_bwd_col_k(DcnGeom g, const float* __restrict__ x, const float* __restrict__ wt,
+                                                        const float* __restrict__ offset, const float* __restrict__ mask,
+                                                        const float* __restrict__ dy, float* __restrict__ colg, float* __restrict__ doff,
+                                                        float* __restrict__ dmask, long long pix_base) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x (2 x JO) pieces of 256 floats
+  constexpr int FRAG = MC * JO * 256, CS = 16 * MC;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 15, gq = lane >> 4;
+  const long long npix = static_cast<long long>(g.B) * g.Ho * g.Wo;
+  const int plane = g.Ho * g.Wo;
+  const int K = g.kh * g.kw, cpg = g.Cin / g.dg, cps = cpg / CS, segs = K * g.dg, steps = segs * cps;   // cpg % CS == 0
+  const long long tile0 = pix_base + static_cast<long long>(blockIdx.x) * (64 * NBP) + wave * (16 * NBP);
+  bool live[NBP];
+  int pb[NBP], pho[NBP], pwo[NBP], ppos[NBP];
+  unsigned cbase[NBP];   // byte offset of colg[p][0][4 gq]
+  f32x4 dyr[NBP][JO];
+#pragma unroll
+  for (int np = 0; np < NBP; ++np) {
+    const long long pix = tile0 + np * 16 + n;
+    live[np] = pix < npix;
+    const long long pp = live[np] ? pix : 0;
+    pb[np] = static_cast<int>(pp / plane);
+    ppos[np] = static_cast<int>(pp % plane);
+    pho[np] = ppos[np] / g.Wo;
+    pwo[np] = ppos[np] % g.Wo;
+    cbase[np] = static_cast<unsigned>((pp * K * g.Cin + 4 * gq) * 4);
+#pragma unroll
+    for (int jb = 0; jb < JO; ++jb) {
+      const int c = 16 * jb + 4 * gq;
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (live[np]) {
+        const float* p = dy + pp * g.Cout + c;
+        if (c + 3 < g.Cout && (g.Cout & 3) == 0) v = *reinterpret_cast<const f32x4*>(p);
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (c + e < g.Cout) v[e] = p[e];
+        }
+      }
+      dyr[np][jb] = v;
+    }
+  }
+  // LDS-DMA pieces: piece (mc, jb), lane (n, gq) <- wt[k][ci0 + mc*16 + n][16 jb + 4 gq ..]; pieces dealt to the waves round robin
+  constexpr int NP = MC * JO, NDMA = (NP + 3) / 4;
+  auto dma = [&](int k, int ci0, float* buf) {
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+      const int pc = wave + 4 * i;
+      if (pc < NP) {
+        const int mc = pc / JO, jb = pc % JO;
+        const int co = min(16 * jb + 4 * gq, g.Cout - 4);
+        glds16(wt + (static_cast<long long>(k) * g.Cin + ci0 + mc * 16 + n) * g.Cout + co, buf + pc * 256);
+      }
+    }
+  };
+  CornerB t[NBP];
+  float roh[NBP], row_[NBP], rom[NBP];
+  auto load_offsets = [&](int k, int dgi) {
+#pragma unroll
+    for (int np = 0; np < NBP; ++np) {
+      const float* ob = offset + (static_cast<long long>(pb[np]) * g.dg + dgi) * 2 * K * plane + ppos[np];
+      roh[np] = ob[static_cast<long long>(2 * k) * plane];
+      row_[np] = ob[static_cast<long long>(2 * k + 1) * plane];
+      rom[np] = mask[((static_cast<long long>(pb[np]) * g.dg + dgi) * K + k) * plane + ppos[np]];
+    }
+  };
+  auto set_taps = [&](int k) {
+    const int i = k / g.kw, j = k % g.kw;
+#pragma unroll
+    for (int np = 0; np < NBP; ++np) {
+      const float h_im = static_cast<float>(pho[np] * g.sh - g.ph + i * g.dh) + roh[np];
+      const float w_im = static_cast<float>(pwo[np] * g.sw - g.pw + j * g.dw) + row_[np];
+      make_corners_b(g, live[np], pb[np], h_im, w_im, rom[np], 16u * gq, t[np]);
+    }
+  };
+  float Dq[NBP][4];
+#pragma unroll
+  for (int np = 0; np < NBP; ++np) Dq[np][0] = Dq[np][1] = Dq[np][2] = Dq[np][3] = 0.f;
+  load_offsets(0, 0);
+  set_taps(0);
+  if (segs > 1) load_offsets(g.dg > 1 ? 0 : 1, g.dg > 1 ? 1 : 0);
+  dma(0, 0, lds);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int k = 0, dgi = 0, c = 0;
+  for (int s = 0; s < steps; ++s) {
+    float* cur = lds + (s & 1) * FRAG;
+    int c1 = c + 1, dg1 = dgi, k1 = k;
+    if (c1 == cps) { c1 = 0; ++dg1; if (dg1 == g.dg) { dg1 = 0; ++k1; } }
+    const bool more = s + 1 < steps;
+    const int ci0 = (dgi * cps + c) * CS;
+    if (more) dma(k1, (dg1 * cps + c1) * CS, lds + ((s + 1) & 1) * FRAG);
+    // x at the four corners of this step's channels (consumed by the epilogue, after the MFMAs)
+    f32x4 raw[NBP][MC][4];
+    {
+      const char* xc = reinterpret_cast<const char*>(x + ci0);
+#pragma unroll
+      for (int np = 0; np < NBP; ++np)
+#pragma unroll
+        for (int mc = 0; mc < MC; ++mc)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) raw[np][mc][q] = ldx4(xc + mc * 64, t[np].o[q]);
+    }
+    f32x4 acc[MC][NBP];
+#pragma unroll
+    for (int mc = 0; mc < MC; ++mc)
+#pragma unroll
+      for (int np = 0; np < NBP; ++np) acc[mc][np] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jb = 0; jb < JO; ++jb) {
+      f32x4 af[MC];
+#pragma unroll
+      for (int mc = 0; mc < MC; ++mc) af[mc] = *reinterpret_cast<const f32x4*>(&cur[((mc * JO + jb) * 64 + lane) * 4]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mc = 0; mc < MC; ++mc)
+#pragma unroll
+          for (int np = 0; np < NBP; ++np) acc[mc][np] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mc][j], dyr[np][jb][j], acc[mc][np], 0, 0, 0);
+    }
+    // epilogue: acc[mc][np][e] = dcol[pixel np*16 + n][ci0 + mc*16 + 4 gq + e]
+    {
+      char* cg = reinterpret_cast<char*>(colg + (static_cast<long long>(k) * g.Cin + ci0));
+#pragma unroll
+      for (int np = 0; np < NBP; ++np)
+#pragma unroll
+        for (int mc = 0; mc < MC; ++mc) {
+          const f32x4 d = acc[mc][np];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float a = Dq[np][q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a = __builtin_fmaf(d[e], raw[np][mc][q][e], a);
+            Dq[np][q] = a;
+          }
+          if (live[np]) *reinterpret_cast<f32x4*>(cg + mc * 64 + cbase[np]) = d * t[np].m;
+        }
+    }
+    if (c1 == 0 || !more) {
+      // end of the (tap, group) segment: reduce D_q over the four channel quarters (lanes n, n+16, n+32, n+48), write grad_mask / grad_offset
+#pragma unroll
+      for (int np = 0; np < NBP; ++np) {
+        float D[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float a = Dq[np][q];
+          a += __shfl_xor(a, 16, 64);
+          a += __shfl_xor(a, 32, 64);
+          D[q] = (t[np].vb >> q) & 1u ? a : 0.f;
+          Dq[np][q] = 0.f;
+        }
+        if (gq == 0 && live[np]) {
+          const float lh = t[np].lh, lw = t[np].lw, hh = 1.f - lh, hw = 1.f - lw, m = t[np].m;
+          const float gm = t[np].w[0] * D[0] + t[np].w[1] * D[1] + t[np].w[2] * D[2] + t[np].w[3] * D[3];
+          const float gh = m * (-hw * D[0] - lw * D[1] + hw * D[2] + lw * D[3]);
+          const float gw = m * (-hh * D[0] + hh * D[1] - lh * D[2] + lh * D[3]);
+          dmask[((static_cast<long long>(pb[np]) * g.dg + dgi) * K + k) * plane + ppos[np]] = gm;
+          float* ob = doff + (static_cast<long long>(pb[np]) * g.dg + dgi) * 2 * K * plane + ppos[np];
+          ob[static_cast<long long>(2 * k) * plane] = gh;
+          ob[static_cast<long long>(2 * k + 1) * plane] = gw;
+        }
+      }
+      if (more) {
+        set_taps(k1);
+        int dg2 = dg1 + 1, k2 = k1;
+        if (dg2 == g.dg) { dg2 = 0; ++k2; }
+        if (k2 < K) load_offsets(k2, dg2);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    c = c1; dgi = dg1; k = k1;
+  }
+}
+
+
+// ---------------------------------------------------------------- backward, pass 2: grad_input in gather form -------
+// The reference scatters every column gradient to its four bilinear corners with atomicAdd (modulated_deform_im2col_cuda.cuh:196-254):
+// 1.3 G float atomics at the MGAF head's shape and a sum whose order changes from run to run.  Here every input pixel (and deformable
+// group) owns a list of the samples that touch it - built with INTEGER atomics (count, scan, fill: the totals are exact whatever the
+// order), put into ascending sample order inside the gathering wave - and sums them itself: no float atomics, no zero fill, and the
+// same bits on every run.
+//   entry = {src = ((pixel * K + tap) << 2) | corner, bilinear weight of that corner}
+__device__ __forceinline__ void sample_corners(const DcnGeom& g, int ho, int wo, int k, float off_h, float off_w, int (&ty)[4], int (&tx)[4],
+                                               float (&wq)[4]) {
+  const int i = k / g.kw, j = k % g.kw;
+  const float h_im = static_cast<float>(ho * g.sh - g.ph + i * g.dh) + off_h;
+  const float w_im = static_cast<float>(wo * g.sw - g.pw + j * g.dw) + off_w;
+  const bool valid = (h_im > -1.f && w_im > -1.f && h_im < static_cast<float>(g.H) && w_im < static_cast<float>(g.W));
+  const float hf = floorf(h_im), wf = floorf(w_im);
+  const int h_low = static_cast<int>(hf), w_low = static_cast<int>(wf);
+  const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+  ty[0] = ty[1] = h_low; ty[2] = ty[3] = h_low + 1;
+  tx[0] = tx[2] = w_low; tx[1] = tx[3] = w_low + 1;
+  wq[0] = hh * hw; wq[1] = hh * lw; wq[2] = lh * hw; wq[3] = lh * lw;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (!(valid && ty[q] >= 0 && ty[q] <= g.H - 1 && tx[q] >= 0 && tx[q] <= g.W - 1)) wq[q] = 0.f;   // weight 0 = no entry
+}
+
+// one thread per sample (b, group, tap, output pixel): FILL = 0 counts the entries of every target, FILL = 1 writes them
+// (cursor[t] starts at the list's first slot and ends at its end: list t = [cursor[t - 1], cursor[t]) afterwards)
+template <int FILL>
+__global__ __launch_bounds__(256) void dcn_index_k(DcnGeom g, const float* __restrict__ offset, int* __restrict__ cursor, uint2* __restrict__ entries) {
+  const int plane = g.Ho * g.Wo, K = g.kh * g.kw;
+  const long long total = static_cast<long long>(g.B) * g.dg * K * plane;
+  const long long id = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  if (id >= total) return;
+  const int pos = static_cast<int>(id % plane);
+  const int k = static_cast<int>((id / plane) % K);
+  const int bd = static_cast<int>(id / (static_cast<long long>(plane) * K));   // b * dg + dgi
+  const int b = bd / g.dg;
+  const float* ob = offset + static_cast<long long>(bd) * 2 * K * plane + pos;
+  const float off_h = ob[static_cast<long long>(2 * k) * plane], off_w = ob[static_cast<long long>(2 * k + 1) * plane];
+  int ty[4], tx[4];
+  float wq[4];
+  sample_corners(g, pos / g.Wo, pos % g.Wo, k, off_h, off_w, ty, tx, wq);
+  const long long pix = static_cast<long long>(b) * plane + pos;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (wq[q] == 0.f) continue;
+    const long long t = (static_cast<long long>(bd) * g.H + ty[q]) * g.W + tx[q];
+    const int slot = atomicAdd(&cursor[t], 1);
+    if (FILL) entries[slot] = make_uint2(static_cast<unsigned>((pix * K + k) * 4 + q), __float_as_uint(wq[q]));
+  }
+}
+
+// Lists longer than a wave (more than 64 samples on one input pixel) are put in order here, one workgroup per list, up to 4096 entries;
+// beyond that the list keeps its fill order: the sum is still complete, only its rounding may differ between runs.
+constexpr int kDcnLongList = 4096;
+__global__ __launch_bounds__(256) void dcn_index_sort_long_k(const int* __restrict__ ends, long long ntargets, uint2* __restrict__ entries) {
+  __shared__ uint2 buf[kDcnLongList];
+  __shared__ int queue[256], qn;
+  const long long per = (ntargets + gridDim.x - 1) / gridDim.x;
+  const long long t0 = static_cast<long long>(blockIdx.x) * per, t1 = min(t0 + per, ntargets);
+  for (long long base = t0; base < t1; base += 256) {
+    if (threadIdx.x == 0) qn = 0;
+    __syncthreads();
+    const long long t = base + threadIdx.x;
+    if (t < t1) {
+      const int n = ends[t] - (t ? ends[t - 1] : 0);
+      if (n > 64 && n <= kDcnLongList) queue[atomicAdd(&qn, 1)] = static_cast<int>(t - base);
+    }
+    __syncthreads();
+    const int nq = qn;
+    for (int qi = 0; qi < nq; ++qi) {   // which list comes first does not matter: lists are disjoint
+      const long long tt = base + queue[qi];
+      const int start = tt ? ends[tt - 1] : 0, n = ends[tt] - start;
+      for (int i = threadIdx.x; i < n; i += 256) buf[i] = entries[start + i];
+      __syncthreads();
+      for (int i = threadIdx.x; i < n; i += 256) {
+        const uint2 e = buf[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += buf[j].x < e.x;
+        entries[start + rank] = e;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// one wave per (target pixel, deformable group); lane = VEC adjacent channels of the group
+template <int VEC>
+__global__ __launch_bounds__(256) void dcn_col2im_k(DcnGeom g, const float* __restrict__ colg, const int* __restrict__ ends,
+                                                    const uint2* __restrict__ entries, float* __restrict__ dx) {
+  __shared__ uint2 sorted[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long HW = static_cast<long long>(g.H) * g.W, ntargets = static_cast<long long>(g.B) * g.dg * HW;
+  const long long t = static_cast<long long>(blockIdx.x) * 4 + wave;
+  if (t >= ntargets) return;
+  const int K = g.kh * g.kw, cpg = g.Cin / g.dg;
+  const int bd = static_cast<int>(t / HW), b = bd / g.dg, dgi = bd % g.dg;
+  const long long tp = static_cast<long long>(b) * HW + t % HW;   // pixel of x / dx
+  const int start = t ? ends[t - 1] : 0, n = ends[t] - start;
+  const uint2* list = entries + start;
+  const bool in_lds = n <= 64;
+  if (in_lds) {
+    uint2 e = make_uint2(0xffffffffu, 0u);
+    if (lane < n) e = list[lane];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) rank += static_cast<unsigned>(__shfl(static_cast<int>(e.x), j, 64)) < e.x;
+    if (lane < n) sorted[wave][rank] = e;
+    // the wave reads its own slots only: LDS operations of one wave execute in order, no barrier
+  }
+  for (int c0 = 0; c0 < cpg; c0 += 64 * VEC) {
+    const int c = c0 + lane * VEC;
+    const bool act = c < cpg;
+    const float* col = colg + static_cast<long long>(dgi) * cpg + (act ? c : 0);
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+    int i = 0;
+    for (; i + 4 <= n; i += 4) {
+      uint2 e[4];
+      float vals[4][VEC];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) e[u] = in_lds ? sorted[wave][i + u] : list[i + u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* p = col + static_cast<long long>(e[u].x >> 2) * g.Cin;
+        if constexpr (VEC == 4) { const f32x4 v = *reinterpret_cast<const f32x4*>(p); vals[u][0] = v[0]; vals[u][1] = v[1]; vals[u][2] = v[2]; vals[u][3] = v[3]; }
+        else if constexpr (VEC == 2) { const float2 v = *reinterpret_cast<const float2*>(p); vals[u][0] = v.x; vals[u][1] = v.y; }
+        else vals[u][0] = p[0];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = __builtin_fmaf(__uint_as_float(e[u].y), vals[u][v], acc[v]);
+    }
+    for (; i < n; ++i) {
+      const uint2 e = in_lds ? sorted[wave][i] : list[i];
+      const float* p = col + static_cast<long long>(e.x >> 2) * g.Cin;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] = __builtin_fmaf(__uint_as_float(e.y), p[v], acc[v]);
+    }
+    if (act) {
+      float* out = dx + tp * g.Cin + dgi * cpg + c;
+      if constexpr (VEC == 4) *reinterpret_cast<f32x4*>(out) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+      else if constexpr (VEC == 2) *reinterpret_cast<float2*>(out) = make_float2(acc[0], acc[1]);
+      else out[0] = acc[0];
+    }
+  }
+}
+
+// ---------------------------------------------------------------- backward: weight gradient ------------------------
+// dW[k][ci][co] = sum_p col[p, k, ci] * dy[p, co], col = mask * bilinear sample of x (the forward's operand).  One workgroup =
+// (pixel range, tap, 128 input channels, 128 output channels); per 16-pixel step all 256 threads build the col tile [16 px][128 ci]
+// (a thread = one pixel, four adjacent channels: four 16-byte corner loads, as in the forward) and copy the dy tile [16 px][128 co] into
+// LDS, pixel-major; a wave then multiplies its 64 x 64 corner of the tile (A[ci][px] and B[px][co] read one float per lane and MFMA).
+// Loads of step s + 1 are in flight during the MFMAs of step s.  Partial tiles of the pixel ranges are summed in a fixed order (dcn_reduce_k).
+constexpr int kDwPitch = 132;   // floats per pixel row of an LDS tile: rows 4 pixels apart land 16 banks apart
+template <int DUMMY>
+__global__ __launch_bounds__(256, 2) void dcn_bwd_weight2_k(DcnGeom g, const float* __restrict__ x, const float* __restrict__ offset,
+                                                            const float* __restrict__ mask, const float* __restrict__ dy, int pix_per_block,
+                                                            float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 buffers x (col tile 16 x 132 + dy tile 16 x 132)
+  constexpr int TILE = 16 * kDwPitch, BUF = 2 * TILE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, gq = lane >> 4;
+  const int K = g.kh * g.kw, cpg = g.Cin / g.dg, plane = g.Ho * g.Wo;
+  const int ci_tiles = static_cast<int>((g.Cin + 127) / 128);
+  const int k = blockIdx.y, ci0 = (blockIdx.z % ci_tiles) * 128, co0 = (blockIdx.z / ci_tiles) * 128;
+  const long long npix = static_cast<long long>(g.B) * plane;
+  const long long p_begin = static_cast<long long>(blockIdx.x) * pix_per_block, p_end = min(p_begin + pix_per_block, npix);
+  // staging role: pixel tid >> 4 of the step, channel quads (tid & 15) and (tid & 15) + 16
+  const int spx = tid >> 4, cq = tid & 15;
+  const int i_k = k / g.kw, j_k = k % g.kw;
+  f32x4 raw[2][4], dyv[2];
+  float wq[2][4], mk[2];
+  float roh[2], row_[2], rom[2];
+  auto load_offsets = [&](long long p) {   // raw offsets / mask of pixel p for this thread's two channel quads
+    const bool ok = p < p_end;
+    const long long pp = ok ? p : p_begin;
+    const int b = static_cast<int>(pp / plane), pos = static_cast<int>(pp % plane);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int ci = ci0 + 64 * h + 4 * cq;
+      const int dgi = min(ci, g.Cin - 1) / cpg;
+      const float* ob = offset + (static_cast<long long>(b) * g.dg + dgi) * 2 * K * plane + pos;
+      roh[h] = ob[static_cast<long long>(2 * k) * plane];
+      row_[h] = ob[static_cast<long long>(2 * k + 1) * plane];
+      rom[h] = mask[((static_cast<long long>(b) * g.dg + dgi) * K + k) * plane + pos];
+    }
+  };
+  auto issue = [&](long long p) {   // corner loads + dy loads of pixel p (taps from the raw offsets fetched one step earlier)
+    const bool ok = p < p_end;
+    const long long pp = ok ? p : p_begin;
+    const int b = static_cast<int>(pp / plane), pos = static_cast<int>(pp % plane);
+    const int ho = pos / g.Wo, wo = pos % g.Wo;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int ci = ci0 + 64 * h + 4 * cq;
+      const bool cok = ok && ci < g.Cin;
+      Corner4 t;
+      const float h_im = static_cast<float>(ho * g.sh - g.ph + i_k * g.dh) + roh[h];
+      const float w_im = static_cast<float>(wo * g.sw - g.pw + j_k * g.dw) + row_[h];
+      make_corners(g, cok, b, h_im, w_im, rom[h], static_cast<unsigned>(min(ci, g.Cin - 4)) * 4u, t);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { raw[h][q] = ldx4(reinterpret_cast<const char*>(x), t.o[q]); wq[h][q] = t.w[q]; }
+      mk[h] = t.m;
+      const int co = co0 + 64 * h + 4 * cq;
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ok && co < g.Cout) v = *reinterpret_cast<const f32x4*>(dy + pp * g.Cout + co);   // Cout % 4 == 0
+      dyv[h] = v;
+    }
+  };
+  auto stage = [&](float* buf) {   // combine + write both tiles, pixel-major
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f32x4 a;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = wq[h][0] * raw[h][0][e];
+        v = __builtin_fmaf(wq[h][1], raw[h][1][e], v);
+        v = __builtin_fmaf(wq[h][2], raw[h][2][e], v);
+        v = __builtin_fmaf(wq[h][3], raw[h][3][e], v);
+        a[e] = v * mk[h];
+      }
+      *reinterpret_cast<f32x4*>(&buf[spx * kDwPitch + 64 * h + 4 * cq]) = a;
+      *reinterpret_cast<f32x4*>(&buf[TILE + spx * kDwPitch + 64 * h + 4 * cq]) = dyv[h];
+    }
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int wi = wave >> 1, wj = wave & 1;
+  const long long steps = (p_end - p_begin + 15) / 16;
+  if (steps > 0) {
+    load_offsets(p_begin + spx);
+    issue(p_begin + spx);
+    if (steps > 1) load_offsets(p_begin + 16 + spx);
+    stage(lds);
+  }
+  __syncthreads();
+  for (long long s = 0; s < steps; ++s) {
+    const float* cur = lds + (s & 1) * BUF;
+    const bool more = s + 1 < steps;
+    if (more) {
+      issue(p_begin + (s + 1) * 16 + spx);
+      if (s + 2 < steps) load_offsets(p_begin + (s + 2) * 16 + spx);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) av[a] = cur[(4 * gq + j) * kDwPitch + (wi * 4 + a) * 16 + r];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) bv[c] = cur[TILE + (4 * gq + j) * kDwPitch + (wj * 4 + c) * 16 + r];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[c], acc[a][c], 0, 0, 0);
+    }
+    if (more) stage(lds + ((s + 1) & 1) * BUF);
+    __syncthreads();
+  }
+  // acc[a][c][e] = dW[k][ci0 + (wi*4 + a)*16 + 4 gq + e][co0 + (wj*4 + c)*16 + r]
+  float* out = partial + (static_cast<long long>(blockIdx.x) * K + k) * g.Cin * g.Cout;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int ci = ci0 + (wi * 4 + a) * 16 + 4 * gq + e;
+      if (ci >= g.Cin) continue;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int co = co0 + (wj * 4 + c) * 16 + r;
+        if (co < g.Cout) out[static_cast<long long>(ci) * g.Cout + co] = acc[a][c][e];
+      }
+    }
+}
+
 static int dcn_check(const DcnGeom& g) {
   FV2P_REQUIRE(g.B >= 0 && g.H >= 1 && g.W >= 1 && g.Cin >= 1 && g.Cout >= 1 && g.kh >= 1 && g.kw >= 1 && g.sh >= 1 && g.sw >= 1 &&
                    g.dh >= 1 && g.dw >= 1 && g.dg >= 1 && g.Ho >= 1 && g.Wo >= 1,
@@ -674,6 +1166,129 @@ extern "C" int fv2p_dcn_forward(const float* x_nhwc, const float* wt_oc, const f
   return 0;
 }
 
+
+// ---- backward: workspace carving shared by the size query and the call
+struct DcnBwdPlan {
+  long long npix, ntargets, max_entries;
+  int splits, pix_per_block, ci_tiles, co_tiles;
+};
+static DcnBwdPlan dcn_bwd_plan(const DcnGeom& g) {
+  DcnBwdPlan p;
+  const int K = g.kh * g.kw;
+  p.npix = static_cast<long long>(g.B) * g.Ho * g.Wo;
+  p.ntargets = static_cast<long long>(g.B) * g.dg * g.H * g.W;
+  p.max_entries = p.npix * g.dg * K * 4;
+  p.ci_tiles = static_cast<int>(ceil_div(g.Cin, 128));
+  p.co_tiles = static_cast<int>(ceil_div(g.Cout, 128));
+  const long long cols = static_cast<long long>(K) * p.ci_tiles * p.co_tiles;
+  long long s = (2ll * dcn_cu_count()) / cols;            // one resident round of workgroups (two per CU)
+  const long long smax = ceil_div(p.npix > 0 ? p.npix : 1, 64);
+  if (s > smax) s = smax;
+  if (s < 1) s = 1;
+  long long ppb = ceil_div(ceil_div(p.npix > 0 ? p.npix : 1, s), 16) * 16;
+  p.pix_per_block = static_cast<int>(ppb);
+  p.splits = static_cast<int>(ceil_div(p.npix > 0 ? p.npix : 1, ppb));
+  return p;
+}
+template <typename C>
+static void dcn_bwd_carve(C& c, const DcnGeom& g, const DcnBwdPlan& p, float** colg, int** cursor, uint2** entries, void** scan_ws, float** partial) {
+  const int K = g.kh * g.kw;
+  *colg = c.template take<float>(static_cast<size_t>(p.npix) * K * g.Cin);
+  *cursor = c.template take<int>(static_cast<size_t>(p.ntargets) + 1);
+  *entries = c.template take<uint2>(static_cast<size_t>(p.max_entries));
+  *scan_ws = c.template take<char>(scan_ws_bytes(p.ntargets));
+  *partial = c.template take<float>(static_cast<size_t>(p.splits) * K * g.Cin * g.Cout);
+}
+struct SizerC : Sizer {
+  template <typename T> T* take(size_t n) { Sizer::take<T>(n); return nullptr; }
+};
+
+extern "C" size_t fv2p_dcn_backward_ws_bytes(int batch, int height, int width, int h_out, int w_out, int c_in, int c_out, int kh, int kw,
+                                             int deformable_group) {
+  DcnGeom g = {batch, height, width, c_in, c_out, h_out, w_out, kh, kw, 1, 1, 0, 0, 1, 1, deformable_group > 0 ? deformable_group : 1};
+  const DcnBwdPlan p = dcn_bwd_plan(g);
+  SizerC s;
+  float *a, *e; int* b; uint2* c; void* d;
+  dcn_bwd_carve(s, g, p, &a, &b, &c, &d, &e);
+  return s.bytes();
+}
+
+template <int JO, int NBP, int MC>
+static void dcn_col_launch(const DcnGeom& g, const float* x, const float* wt, const float* offset, const float* mask, const float* dy, float* colg,
+                           float* doff, float* dmask, long long pix_base, long long npix_part, hipStream_t stream) {
+  if (npix_part <= 0) return;
+  hipLaunchKernelGGL((dcn_bwd_col_k<JO, NBP, MC>), dim3(static_cast<unsigned>(ceil_div(npix_part, 64 * NBP))), dim3(256),
+                     2 * MC * JO * 256 * sizeof(float), stream, g, x, wt, offset, mask, dy, colg, doff, dmask, pix_base);
+}
+
+// dx_nhwc, doffset, dmask, dwt are fully written (nothing to zero).  wt = [kh*kw][Cin][Cout].
+extern "C" int fv2p_dcn_backward(const float* x_nhwc, const float* wt, const float* offset, const float* mask, const float* dy_nhwc,
+                                 DCN_GEOM_ARGS, float* dx_nhwc, float* doffset, float* dmask, float* dwt, void* ws, size_t ws_bytes,
+                                 fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DCN_GEOM_INIT;
+  if (int rc = dcn_check(g)) return rc;
+  FV2P_REQUIRE((g.Cout & 3) == 0, FV2P_ELIMIT, "dcn_backward: output channels must be a multiple of 4 (pad the weight)");
+  const long long npix = static_cast<long long>(g.B) * g.Ho * g.Wo;
+  const int K = g.kh * g.kw;
+  FV2P_REQUIRE(dwt, FV2P_EINVAL, "dcn_backward: null dwt");
+  const long long nin = static_cast<long long>(g.B) * g.H * g.W;
+  if (npix == 0) {
+    FV2P_HIP(hipMemsetAsync(dwt, 0, sizeof(float) * (size_t)K * g.Cin * g.Cout, stream));
+    if (nin > 0 && dx_nhwc) FV2P_HIP(hipMemsetAsync(dx_nhwc, 0, sizeof(float) * (size_t)nin * g.Cin, stream));
+    return 0;
+  }
+  FV2P_REQUIRE(x_nhwc && wt && offset && mask && dy_nhwc && dx_nhwc && doffset && dmask, FV2P_EINVAL, "dcn_backward: null pointer");
+  FV2P_REQUIRE(nin * g.Cin * 4 < (1ll << 32) && npix * K * g.Cin * 4 < (1ll << 32), FV2P_ELIMIT,
+               "dcn_backward: input or column gradients above 4 GiB (split the batch)");
+  const DcnBwdPlan p = dcn_bwd_plan(g);
+  FV2P_REQUIRE(p.max_entries < (1ll << 31) && npix * K * 4 < (1ll << 32), FV2P_ELIMIT, "dcn_backward: too many samples (split the batch)");
+  FV2P_REQUIRE(ws && ws_bytes >= fv2p_dcn_backward_ws_bytes(g.B, g.H, g.W, g.Ho, g.Wo, g.Cin, g.Cout, g.kh, g.kw, g.dg), FV2P_EWORKSPACE,
+               "dcn_backward: workspace too small");
+  Carver c(ws, ws_bytes);
+  float *colg, *partial; int* cursor; uint2* entries; void* sws;
+  dcn_bwd_carve(c, g, p, &colg, &cursor, &entries, &sws, &partial);
+  // 1. per-target sample lists
+  FV2P_HIP(hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)(p.ntargets + 1), stream));
+  const long long nsamples = npix * g.dg * K;
+  const unsigned iblocks = static_cast<unsigned>(ceil_div(nsamples, 256));
+  hipLaunchKernelGGL((dcn_index_k<0>), dim3(iblocks), dim3(256), 0, stream, g, offset, cursor, entries);
+  if (int rc = exclusive_scan_i32(cursor, cursor, p.ntargets, nullptr, sws, scan_ws_bytes(p.ntargets), stream)) return rc;
+  hipLaunchKernelGGL((dcn_index_k<1>), dim3(iblocks), dim3(256), 0, stream, g, offset, cursor, entries);
+  hipLaunchKernelGGL(dcn_index_sort_long_k, dim3(static_cast<unsigned>(std::min<long long>(1024, ceil_div(p.ntargets, 256)))), dim3(256), 0, stream,
+                     cursor, p.ntargets, entries);
+  // 2. column gradients, grad_mask, grad_offset
+  const int cus = dcn_cu_count();
+  const int jo = static_cast<int>(ceil_div(g.Cout, 16));
+  const bool mc2 = (g.Cin / g.dg) % 32 == 0;
+  const long long tiles128 = npix / 128;
+  long long big = (tiles128 / cus) * cus;
+  const char* force = getenv("FV2P_DCN_BWD_PLAN");   // development: "<NBP>"
+  if (force && atoi(force) == 1) big = 0;
+  if (force && atoi(force) == 2) big = tiles128;
+  const long long big_pix = big * 128;
+#define DCN_C(JO, MC) do { if (JO <= 8) dcn_col_launch<JO, (JO <= 8 ? 2 : 1), MC>(g, x_nhwc, wt, offset, mask, dy_nhwc, colg, doffset, dmask, 0, big_pix, stream); \
+                           dcn_col_launch<JO, 1, MC>(g, x_nhwc, wt, offset, mask, dy_nhwc, colg, doffset, dmask, JO <= 8 ? big_pix : 0, JO <= 8 ? npix - big_pix : npix, stream); } while (0)
+#define DCN_CJ(JO) do { if (mc2) DCN_C(JO, 2); else DCN_C(JO, 1); } while (0)
+  if (jo <= 1) DCN_CJ(1); else if (jo <= 2) DCN_CJ(2); else if (jo <= 4) DCN_CJ(4); else if (jo <= 8) DCN_CJ(8); else DCN_CJ(16);
+#undef DCN_CJ
+#undef DCN_C
+  // 3. grad_input
+  const int cpg = g.Cin / g.dg;
+  const unsigned gblocks = static_cast<unsigned>(ceil_div(p.ntargets, 4));
+  if (cpg % 4 == 0 && cpg > 128) hipLaunchKernelGGL((dcn_col2im_k<4>), dim3(gblocks), dim3(256), 0, stream, g, colg, cursor, entries, dx_nhwc);
+  else if (cpg > 64) hipLaunchKernelGGL((dcn_col2im_k<2>), dim3(gblocks), dim3(256), 0, stream, g, colg, cursor, entries, dx_nhwc);
+  else hipLaunchKernelGGL((dcn_col2im_k<1>), dim3(gblocks), dim3(256), 0, stream, g, colg, cursor, entries, dx_nhwc);
+  // 4. weight gradient
+  const dim3 wgrid(static_cast<unsigned>(p.splits), static_cast<unsigned>(K), static_cast<unsigned>(p.ci_tiles * p.co_tiles));
+  hipLaunchKernelGGL((dcn_bwd_weight2_k<0>), wgrid, dim3(256), 2 * 2 * 16 * kDwPitch * sizeof(float), stream, g, x_nhwc, offset, mask, dy_nhwc,
+                     p.pix_per_block, partial);
+  const long long per_chunk = static_cast<long long>(K) * g.Cin * g.Cout;
+  hipLaunchKernelGGL(dcn_reduce_k, dim3(static_cast<unsigned>(ceil_div(per_chunk, 256))), dim3(256), 0, stream, partial, p.splits, per_chunk, dwt);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int fv2p_dcn_forward_v1(const float* x_nhwc, const float* wt, const float* bias, const float* offset, const float* mask,
                                 DCN_GEOM_ARGS, float* y_nhwc, fv2p_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -691,7 +1306,7 @@ extern "C" int fv2p_dcn_forward_v1(const float* x_nhwc, const float* wt, const f
   return 0;
 }
 
-extern "C" size_t fv2p_dcn_backward_ws_bytes(int batch, int h_out, int w_out, int c_in, int c_out, int kh, int kw) {
+extern "C" size_t fv2p_dcn_backward_ws_bytes_v1(int batch, int h_out, int w_out, int c_in, int c_out, int kh, int kw) {
   const long long npix = static_cast<long long>(batch) * h_out * w_out;
   const long long chunks = ceil_div(npix > 0 ? npix : 1, kDcnPixChunk);
   Sizer s;
@@ -700,7 +1315,7 @@ extern "C" size_t fv2p_dcn_backward_ws_bytes(int batch, int h_out, int w_out, in
 }
 
 // dx_nhwc must be zeroed by the caller (atomically accumulated); doff / dmask / dwt are fully written.
-extern "C" int fv2p_dcn_backward(const float* x_nhwc, const float* wt, const float* offset, const float* mask, const float* dy_nhwc,
+extern "C" int fv2p_dcn_backward_v1(const float* x_nhwc, const float* wt, const float* offset, const float* mask, const float* dy_nhwc,
                                  DCN_GEOM_ARGS, float* dx_nhwc, float* doffset, float* dmask, float* dwt, void* ws, size_t ws_bytes,
                                  fv2p_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -714,7 +1329,7 @@ extern "C" int fv2p_dcn_backward(const float* x_nhwc, const float* wt, const flo
     return 0;
   }
   FV2P_REQUIRE(x_nhwc && wt && offset && mask && dy_nhwc && dx_nhwc && doffset && dmask, FV2P_EINVAL, "dcn_backward: null pointer");
-  FV2P_REQUIRE(ws && ws_bytes >= fv2p_dcn_backward_ws_bytes(g.B, g.Ho, g.Wo, g.Cin, g.Cout, g.kh, g.kw), FV2P_EWORKSPACE,
+  FV2P_REQUIRE(ws && ws_bytes >= fv2p_dcn_backward_ws_bytes_v1(g.B, g.Ho, g.Wo, g.Cin, g.Cout, g.kh, g.kw), FV2P_EWORKSPACE,
                "dcn_backward: workspace too small");
   const unsigned blocks = static_cast<unsigned>(ceil_div(npix, 64));
   const int jo = static_cast<int>(ceil_div(g.Cout, 16));
@@ -732,3 +1347,4 @@ extern "C" int fv2p_dcn_backward(const float* x_nhwc, const float* wt, const flo
   FV2P_LAUNCH_CHECK();
   return 0;
 }
+

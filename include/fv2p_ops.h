@@ -441,15 +441,20 @@ int fv2p_sa_grid_bwd(const float* per_point, const float* per_centre, const int*
  *   x_nhwc [B,H,W,Cin], y_nhwc / dy_nhwc [B*Ho*Wo, Cout]; the weight [Cout,Cin,kh,kw] arrives permuted: forward takes
  *   wt_oc = [kh*kw][Cout][Cin] (input channels contiguous), backward wt = [kh*kw][Cin][Cout] (output channels contiguous);
  *   offset [B, dg*2*kh*kw, Ho, Wo] ((2k, 2k+1) = (dh, dw)), mask [B, dg*kh*kw, Ho, Wo] — reference layouts.
- * groups == 1; Cin / deformable_group must be a multiple of 16; Cout <= 256.
- * backward: dx_nhwc must be zeroed by the caller (tap scatter uses atomics); doffset, dmask, dwt are fully written
- * (dwt [kh*kw][Cin][Cout]; the bias gradient is a plain column sum done by the caller).
+ * groups == 1; Cin / deformable_group must be a multiple of 16; Cout <= 256 (backward: Cout a multiple of 4).
+ * backward (modulated_deform_conv_cuda.cu:127-280): dx_nhwc, doffset, dmask, dwt are FULLY written, nothing to zero
+ * (dwt [kh*kw][Cin][Cout]; the bias gradient is a plain column sum done by the caller).  No float atomics: the column
+ * gradients go through the workspace ([B*Ho*Wo][kh*kw][Cin], the reference's `columns`), every input pixel then sums the
+ * samples that touch it in ascending sample order (lists built with integer atomics), so all four gradients are
+ * bit-identical from run to run (lists above 4096 samples on ONE input pixel keep an arbitrary order).
+ * Each of x, the column gradients and the sample count must stay below 2^32 bytes / 2^31 entries (split the batch).
  */
 int fv2p_dcn_forward(const float* x_nhwc, const float* wt_oc, const float* bias, const float* offset,
                      const float* mask, int batch, int height, int width, int c_in, int c_out, int h_out,
                      int w_out, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
                      int deformable_group, float* y_nhwc, fv2p_stream_t stream);
-size_t fv2p_dcn_backward_ws_bytes(int batch, int h_out, int w_out, int c_in, int c_out, int kh, int kw);
+size_t fv2p_dcn_backward_ws_bytes(int batch, int height, int width, int h_out, int w_out, int c_in, int c_out, int kh,
+                                  int kw, int deformable_group);
 int fv2p_dcn_backward(const float* x_nhwc, const float* wt, const float* offset, const float* mask,
                       const float* dy_nhwc, int batch, int height, int width, int c_in, int c_out, int h_out,
                       int w_out, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,

@@ -10,10 +10,20 @@
 #include <random>
 #include "../../include/fv2p_ops.h"
 
+#define CK(e) do { hipError_t r = (e); if (r != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(r), __LINE__); exit(1); } } while (0)
 #define GEOM int, int, int, int, int, int, int, int, int, int, int, int, int, int, int, int
 extern "C" int fv2p_dcn_forward_v1(const float*, const float*, const float*, const float*, const float*, GEOM, float*, void*);
+extern "C" size_t fv2p_dcn_backward_ws_bytes_v1(int, int, int, int, int, int, int);
+extern "C" int fv2p_dcn_backward_v1(const float*, const float*, const float*, const float*, const float*, GEOM, float*, float*, float*, float*, void*, size_t, void*);
 
-#define CK(e) do { hipError_t r = (e); if (r != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(r), __LINE__); exit(1); } } while (0)
+static void compare(const char* name, const float* da, const float* db, size_t n) {
+  std::vector<float> a(n), c(n);
+  CK(hipMemcpy(a.data(), da, n * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(c.data(), db, n * 4, hipMemcpyDeviceToHost));
+  double maxd = 0, maxv = 0; size_t bad = 0, neq = 0;
+  for (size_t i = 0; i < n; ++i) { double d = fabs((double)a[i] - c[i]); if (!(d <= 1e30)) ++bad; if (d > maxd) maxd = d; if (fabs(a[i]) > maxv) maxv = fabs(a[i]); if (memcmp(&a[i], &c[i], 4)) ++neq; }
+  printf("    %-8s max abs diff %.3e (max |ref| %.3e, rel %.3e, non-finite %zu, differing words %zu of %zu)\n", name, maxd, maxv, maxd / (maxv > 0 ? maxv : 1), bad, neq, n);
+}
+
 
 template <typename F>
 static float time_us(F f, int reps) {
@@ -76,5 +86,35 @@ int main(int argc, char** argv) {
   float t2 = time_us([&] { fv2p_dcn_forward(x, wt, b, off, m, B, H, W, C, CO, H, W, 3, 3, 1, 1, 1, 1, 1, 1, dg, y2, nullptr); }, reps);
   printf("  forward v1 %9.1f us (%6.1f TF/s, %.3f of peak)   new %9.1f us (%6.1f TF/s, %.3f of peak)\n", t1, fl / t1 / 1e6, fl / t1 / 1e6 / 157.3, t2, fl / t2 / 1e6,
          fl / t2 / 1e6 / 157.3);
+  // ---- backward
+  const size_t nin = npix;
+  float *dy, *dx1, *dx2, *dx3, *do1, *do2, *do3, *dm1, *dm2, *dm3, *dw1, *dw2, *dw3;
+  std::vector<float> hdy(npix * CO);
+  for (auto& v : hdy) v = nd(rng);
+  CK(hipMalloc(&dy, hdy.size() * 4)); CK(hipMemcpy(dy, hdy.data(), hdy.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMalloc(&dx1, nin * C * 4)); CK(hipMalloc(&dx2, nin * C * 4)); CK(hipMalloc(&dx3, nin * C * 4));
+  CK(hipMalloc(&do1, hoff.size() * 4)); CK(hipMalloc(&do2, hoff.size() * 4)); CK(hipMalloc(&do3, hoff.size() * 4));
+  CK(hipMalloc(&dm1, hm.size() * 4)); CK(hipMalloc(&dm2, hm.size() * 4)); CK(hipMalloc(&dm3, hm.size() * 4));
+  CK(hipMalloc(&dw1, hw.size() * 4)); CK(hipMalloc(&dw2, hw.size() * 4)); CK(hipMalloc(&dw3, hw.size() * 4));
+  const size_t ws1b = fv2p_dcn_backward_ws_bytes_v1(B, H, W, C, CO, 3, 3), ws2b = fv2p_dcn_backward_ws_bytes(B, H, W, H, W, C, CO, 3, 3, dg);
+  void *ws1, *ws2;
+  CK(hipMalloc(&ws1, ws1b)); CK(hipMalloc(&ws2, ws2b));
+  printf("  backward workspace: v1 %.1f MB, new %.1f MB\n", ws1b / 1e6, ws2b / 1e6);
+  CK(hipMemset(dx1, 0, nin * C * 4));
+  rc = fv2p_dcn_backward_v1(x, w, off, m, dy, B, H, W, C, CO, H, W, 3, 3, 1, 1, 1, 1, 1, 1, dg, dx1, do1, dm1, dw1, ws1, ws1b, nullptr);
+  if (rc) { printf("bwd v1 rc %d: %s\n", rc, fv2p_last_error()); return 1; }
+  CK(hipMemset(dx2, 0xff, nin * C * 4)); CK(hipMemset(dx3, 0xff, nin * C * 4));
+  rc = fv2p_dcn_backward(x, w, off, m, dy, B, H, W, C, CO, H, W, 3, 3, 1, 1, 1, 1, 1, 1, dg, dx2, do2, dm2, dw2, ws2, ws2b, nullptr);
+  if (rc) { printf("bwd new rc %d: %s\n", rc, fv2p_last_error()); return 1; }
+  rc = fv2p_dcn_backward(x, w, off, m, dy, B, H, W, C, CO, H, W, 3, 3, 1, 1, 1, 1, 1, 1, dg, dx3, do3, dm3, dw3, ws2, ws2b, nullptr);
+  CK(hipDeviceSynchronize());
+  printf("  backward new vs v1:\n");
+  compare("dx", dx1, dx2, nin * C); compare("doffset", do1, do2, hoff.size()); compare("dmask", dm1, dm2, hm.size()); compare("dW", dw1, dw2, hw.size());
+  printf("  backward new, run 1 vs run 2 (must be bit-identical):\n");
+  compare("dx", dx2, dx3, nin * C); compare("doffset", do2, do3, hoff.size()); compare("dmask", dm2, dm3, hm.size()); compare("dW", dw2, dw3, hw.size());
+  float tb1 = time_us([&] { hipMemsetAsync(dx1, 0, nin * C * 4, 0); fv2p_dcn_backward_v1(x, w, off, m, dy, B, H, W, C, CO, H, W, 3, 3, 1, 1, 1, 1, 1, 1, dg, dx1, do1, dm1, dw1, ws1, ws1b, nullptr); }, reps);
+  float tb2 = time_us([&] { fv2p_dcn_backward(x, w, off, m, dy, B, H, W, C, CO, H, W, 3, 3, 1, 1, 1, 1, 1, 1, dg, dx2, do2, dm2, dw2, ws2, ws2b, nullptr); }, reps);
+  printf("  backward v1 %9.1f us (%6.1f TF/s, %.3f of peak)   new %9.1f us (%6.1f TF/s, %.3f of peak)\n", tb1, 2 * fl / tb1 / 1e6, 2 * fl / tb1 / 1e6 / 157.3, tb2,
+         2 * fl / tb2 / 1e6, 2 * fl / tb2 / 1e6 / 157.3);
   return 0;
 }
