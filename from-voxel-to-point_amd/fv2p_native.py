@@ -220,7 +220,7 @@ def workspace(nbytes, device):
     key = (idx, torch._C._cuda_getCurrentRawStream(idx))
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes) * 2, 1 << 22), dtype=torch.uint8, device=device)
+        buf = torch.empty(max(int(nbytes) * (2 if nbytes < (1 << 28) else 1), 1 << 22), dtype=torch.uint8, device=device)   # small requests double (fewer regrowths), large ones are taken as asked
         _WS[key] = buf
     return buf
 

@@ -45,24 +45,31 @@ def modulated_deform_conv_forward(input, weight, bias, offset, mask, kernel_h, k
 
 def modulated_deform_conv_backward(input, weight, bias, offset, mask, grad_output, kernel_h, kernel_w, stride_h, stride_w, pad_h,
                                    pad_w, dilation_h, dilation_w, group, deformable_group, im2col_step):
-    """-> [grad_input, grad_offset, grad_mask, grad_weight, grad_bias] (modulated_deform_conv_cuda.cu:127-280)."""
+    """-> [grad_input, grad_offset, grad_mask, grad_weight, grad_bias] (modulated_deform_conv_cuda.cu:127-280).
+    No float atomics anywhere: the five gradients are bit-identical from run to run (include/fv2p_ops.h, A13)."""
     g = _geom(input, weight, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, group, deformable_group)
     B, H, W, C, Cout, Ho, Wo = g[:7]
     dev = input.device
     x = input.float().permute(0, 2, 3, 1).contiguous()
     dy = grad_output.float().permute(0, 2, 3, 1).contiguous().view(B * Ho * Wo, Cout)
-    dx = torch.zeros_like(x)
+    wt = _wt(weight.float())
+    pad = (-Cout) % 4            # the kernels read output channels four at a time: pad with zero columns
+    if pad:
+        dy = torch.nn.functional.pad(dy, (0, pad))
+        wt = torch.nn.functional.pad(wt, (0, pad))
+        g = g[:4] + (Cout + pad,) + g[5:]
+    dx = torch.empty_like(x)
     doff = torch.empty_like(offset, dtype=torch.float32).contiguous()
     dmask = torch.empty_like(mask, dtype=torch.float32).contiguous()
-    dwt = torch.empty((kernel_h * kernel_w, C, Cout), dtype=torch.float32, device=dev)
+    dwt = torch.empty((kernel_h * kernel_w, C, Cout + pad), dtype=torch.float32, device=dev)
     with _nat.device_guard(dev):
-        nb = _nat.lib().fv2p_dcn_backward_ws_bytes(B, Ho, Wo, C, Cout, kernel_h, kernel_w)
+        nb = _nat.lib().fv2p_dcn_backward_ws_bytes(B, H, W, Ho, Wo, C, Cout + pad, kernel_h, kernel_w, deformable_group)
         ws = _nat.workspace(nb, dev)
-        _nat.call("fv2p_dcn_backward", x, _wt(weight.float()), offset.float().contiguous(), mask.float().contiguous(), dy, *g, dx, doff,
+        _nat.call("fv2p_dcn_backward", x, wt, offset.float().contiguous(), mask.float().contiguous(), dy, *g, dx, doff,
                   dmask, dwt, ws, ws.numel(), _nat.stream())
     grad_input = dx.permute(0, 3, 1, 2).contiguous()
-    grad_weight = dwt.view(kernel_h, kernel_w, C, Cout).permute(3, 2, 0, 1).contiguous()
-    grad_bias = dy.sum(dim=0)
+    grad_weight = dwt[:, :, :Cout].reshape(kernel_h, kernel_w, C, Cout).permute(3, 2, 0, 1).contiguous()
+    grad_bias = dy[:, :Cout].sum(dim=0)
     return [grad_input, doff, dmask, grad_weight, grad_bias]
 
 
