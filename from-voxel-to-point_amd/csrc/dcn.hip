@@ -1,25 +1,27 @@
-// A13 — modulated deformable convolution (DCNv2) as fused implicit GEMMs on fp32 MFMA.
+// A13 — modulated deformable convolution (DCNv2) as implicit GEMMs on fp32 MFMA.
 //
 // Replaces DCN.modulated_deform_conv_{forward,backward} (pcdet/ops/DeformableConvolutionV2PyTorch/src/vision.cpp:6-12,
-// src/cuda/modulated_deform_conv_cuda.cu:19-280, kernels modulated_deform_im2col_cuda.cuh:24-328).  The reference
-// writes a [Cin*kh*kw, B*Ho*Wo] `columns` buffer (1.3 GB for the MGAF head) and runs cuBLAS on it, and its backward
-// scatters with atomics from three element-wise kernels.  Here the bilinear samples are produced inside the GEMM
-// operand fetch, so no columns buffer exists in either direction:
+// src/cuda/modulated_deform_conv_cuda.cu:19-280, kernels modulated_deform_im2col_cuda.cuh:24-328).  The reference writes a
+// [Cin*kh*kw, B*Ho*Wo] `columns` buffer (1.3 GB for the MGAF head), runs cuBLAS on it, and scatters grad_input with atomicAdd.  Here:
 //
-//   forward   y[p, co]        = b[co] + sum_{k,ci} m[p,k] * bilin(x, p, k)[ci] * W[k][ci][co]
-//   backward  dcol[p, k, ci]  = sum_co dy[p, co] * W[k][ci][co]           (MFMA, A = dy rows, B = W_k^T)
-//             dx    += scatter(dcol * m * tap weights)                     (epilogue, atomics on the 4 taps)
-//             dm[p,k], doff[p,k] = reductions of dcol * bilin / d bilin    (epilogue, wave shuffles over ci)
-//             dW[k][ci][co] = sum_p m*bilin(x,p,k)[ci] * dy[p, co]         (MFMA over pixel chunks, deterministic reduce)
+//   forward   y[p, co]       = b[co] + sum_{k,ci} m[p,k] * bilin(x, p, k)[ci] * W[k][ci][co]        dcn_fwd_k: samples built in the operand fetch
+//   backward  dcol[p, k, ci] = sum_co dy[p, co] * W[k][ci][co]                                      dcn_bwd_col_k (dy resident in registers)
+//             dm[p,k], doff[p,k] = <dcol, bilin> , <dcol, d bilin / d pos>                           its epilogue (x corners gathered like the forward)
+//             dx[t, ci]      = sum over the samples touching pixel t of  weight * m * dcol           dcn_index_k + dcn_col2im_k: a GATHER, no float atomics
+//             dW[k][ci][co]  = sum_p m * bilin(x, p, k)[ci] * dy[p, co]                             dcn_bwd_weight_k, partial tiles summed in a fixed order
 //
-// Activations are NHWC here (16-byte channel vectors per tap); the Python layer permutes once on entry/exit, as the
-// reference itself computes NHWC and permutes (modulated_deform_conv_cuda.cu:78,118).  Sampling follows
-// mdmcn_im2col_bilinear (:24-54) and the validity test of :176 exactly; offsets/masks keep the reference layout
-// [B, dg*2*K, Ho, Wo] / [B, dg*K, Ho, Wo] with (2*(i*kw+j), +1) = (dh, dw).
+// All four products are formed TRANSPOSED (weights or dy as the MFMA's A operand): a lane then owns four adjacent channels of one pixel,
+// which is both what it gathers from x (one 16-byte load per bilinear corner) and what it stores.  Every output element is one fused
+// multiply-add chain in a fixed order, independent of tile shapes and batch size; the backward is bit-identical from run to run.
+// Activations are NHWC here; the Python layer permutes once on entry/exit, as the reference itself computes NHWC and permutes
+// (modulated_deform_conv_cuda.cu:78,118).  Sampling follows mdmcn_im2col_bilinear (:24-54) and the validity test of :176; offsets / masks
+// keep the reference layout [B, dg*2*K, Ho, Wo] / [B, dg*K, Ho, Wo] with (2*(i*kw+j), +1) = (dh, dw).  Out-of-map corners are read at the
+// nearest in-map pixel with weight 0 (loads are unconditional).
 #include "common.hpp"
 #include <stdlib.h>
 #include <stdio.h>
 #include <algorithm>
+#include <type_traits>
 
 namespace fv2p {
 
@@ -29,372 +31,6 @@ struct DcnGeom {
   int B, H, W, Cin, Cout, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw, dg;
 };
 
-struct Taps {
-  int o[4];     // element offsets (pixel index in [0, H*W)) of the 4 taps, -1 if outside
-  float w[4];   // bilinear weights hh*hw, hh*lw, lh*hw, lh*lw
-  float lh, lw; // fractional parts
-  int valid;    // the reference's whole-sample validity (h_im > -1 && w_im > -1 && h_im < H && w_im < W)
-};
-
-__device__ __forceinline__ Taps make_taps(const DcnGeom& g, float h_im, float w_im) {
-  Taps t;
-  t.valid = (h_im > -1.f && w_im > -1.f && h_im < static_cast<float>(g.H) && w_im < static_cast<float>(g.W));
-  const int h_low = static_cast<int>(floorf(h_im)), w_low = static_cast<int>(floorf(w_im));
-  const int h_high = h_low + 1, w_high = w_low + 1;
-  const float lh = h_im - h_low, lw = w_im - w_low, hh = 1.f - lh, hw = 1.f - lw;
-  t.lh = lh; t.lw = lw;
-  t.w[0] = hh * hw; t.w[1] = hh * lw; t.w[2] = lh * hw; t.w[3] = lh * lw;
-  const bool hl = h_low >= 0, hhi = h_high <= g.H - 1, wl = w_low >= 0, whi = w_high <= g.W - 1;
-  t.o[0] = (t.valid && hl && wl) ? h_low * g.W + w_low : -1;
-  t.o[1] = (t.valid && hl && whi) ? h_low * g.W + w_high : -1;
-  t.o[2] = (t.valid && hhi && wl) ? h_high * g.W + w_low : -1;
-  t.o[3] = (t.valid && hhi && whi) ? h_high * g.W + w_high : -1;
-  return t;
-}
-
-// sample position of output pixel (b, ho, wo), kernel tap k = i*kw + j, deformable group dgi
-__device__ __forceinline__ Taps pixel_taps(const DcnGeom& g, const float* __restrict__ offset, const float* __restrict__ mask, int b, int ho,
-                                           int wo, int k, int dgi, float* m) {
-  const int K = g.kh * g.kw, i = k / g.kw, j = k % g.kw;
-  const long long plane = static_cast<long long>(g.Ho) * g.Wo, pos = static_cast<long long>(ho) * g.Wo + wo;
-  const float* ob = offset + (static_cast<long long>(b) * g.dg + dgi) * 2 * K * plane;
-  const float off_h = ob[(2 * k) * plane + pos], off_w = ob[(2 * k + 1) * plane + pos];
-  *m = mask[((static_cast<long long>(b) * g.dg + dgi) * K + k) * plane + pos];
-  const float h_im = static_cast<float>(ho * g.sh - g.ph + i * g.dh) + off_h;
-  const float w_im = static_cast<float>(wo * g.sw - g.pw + j * g.dw) + off_w;
-  return make_taps(g, h_im, w_im);
-}
-
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-
-// B fragment staging: 16 source rows x COLS columns of a row-major [rows][ld] matrix -> fragment order (see sparse_conv.hip)
-template <int NB>
-__device__ __forceinline__ void stage16(const float* __restrict__ src, int ld, int rows_valid, int cols_valid, float* __restrict__ lds) {
-  constexpr int COLS = NB * 16;
-  for (int e = threadIdx.x; e < 16 * (COLS / 4); e += 256) {
-    const int c = e / (COLS / 4), col = (e % (COLS / 4)) * 4;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    if (c < rows_valid) {
-      const float* p = src + static_cast<long long>(c) * ld + col;
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (col + u < cols_valid) v[u] = p[u];
-    }
-    const int gq = (c >> 2) & 3, t = c & 3;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int cc = col + u;
-      lds[(((cc >> 4) * 64) + gq * 16 + (cc & 15)) * 4 + t] = v[u];
-    }
-  }
-}
-
-// ---------------------------------------------------------------- forward ----------------------------
-// x NHWC [B,H,W,Cin], wt [K][Cin][Cout], y NHWC [B*Ho*Wo, Cout]; block = 64 output pixels, wave = 16 pixels x all Cout.
-// The reduction runs over steps (kernel tap k, 16 input channels): the weight chunk of a step is a [16][Cout] MFMA B fragment in LDS,
-// double buffered — while the MFMAs of step s run, the weight chunk and the bilinear taps of step s + 1 are already in flight
-// (global loads into registers), and one barrier per step hands the buffers over.  Round 1-2 staged every chunk between two barriers
-// and gathered the taps right before their MFMAs: 36 - 41 TFLOP/s (0.23 - 0.26 of the fp32-MFMA peak).
-template <int NB>
-__global__ __launch_bounds__(256) void dcn_fwd_k(DcnGeom g, const float* __restrict__ x, const float* __restrict__ wt,
-                                                 const float* __restrict__ bias, const float* __restrict__ offset,
-                                                 const float* __restrict__ mask, float* __restrict__ y) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // 2 x (16 x NB*16) fragments
-  constexpr int COLS = NB * 16, FRAG = 16 * COLS, IT = (NB + 3) / 4;   // IT float4 of the chunk per thread
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, gq = lane >> 4;
-  const long long npix = static_cast<long long>(g.B) * g.Ho * g.Wo;
-  const long long pix = static_cast<long long>(blockIdx.x) * 64 + wave * 16 + r;
-  const bool live = pix < npix;
-  const int b = live ? static_cast<int>(pix / (g.Ho * g.Wo)) : 0;
-  const int rem = live ? static_cast<int>(pix % (g.Ho * g.Wo)) : 0;
-  const int ho = rem / g.Wo, wo = rem % g.Wo;
-  const int K = g.kh * g.kw, cpg = g.Cin / g.dg, chunks = g.Cin / 16, steps = K * chunks;   // Cin % 16 == 0 (dcn_check)
-  const float* xb = x + static_cast<long long>(b) * g.H * g.W * g.Cin;
-  f32x4 acc[NB];
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // weight chunk of a step: rows c0 .. c0 + 15 of wt[k], this thread's float4s (row c, columns col .. col + 3)
-  auto load_w = [&](int step, float4 (&v)[IT]) {
-    const float* src = wt + (static_cast<long long>(step / chunks) * g.Cin + (step % chunks) * 16) * g.Cout;
-#pragma unroll
-    for (int i = 0; i < IT; ++i) {
-      const int e = threadIdx.x + i * 256;
-      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e < 16 * (COLS / 4)) {
-        const int c = e / (COLS / 4), col = (e % (COLS / 4)) * 4;
-        const float* p = src + static_cast<long long>(c) * g.Cout + col;
-        if (col + 3 < g.Cout) v[i] = ld4(p);
-        else {
-          if (col < g.Cout) v[i].x = p[0];
-          if (col + 1 < g.Cout) v[i].y = p[1];
-          if (col + 2 < g.Cout) v[i].z = p[2];
-        }
-      }
-    }
-  };
-  auto store_w = [&](const float4 (&v)[IT], float* buf) {   // -> fragment order (see sparse_conv.hip)
-#pragma unroll
-    for (int i = 0; i < IT; ++i) {
-      const int e = threadIdx.x + i * 256;
-      if (e < 16 * (COLS / 4)) {
-        const int c = e / (COLS / 4), col = (e % (COLS / 4)) * 4;
-        const int fq = (c >> 2) & 3, t = c & 3;
-        const float u[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
-#pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4) {
-          const int cc = col + k4;
-          buf[(((cc >> 4) * 64) + fq * 16 + (cc & 15)) * 4 + t] = u[k4];
-        }
-      }
-    }
-  };
-  // modulated bilinear sample of this lane's pixel, channels c0 + 4 gq .. + 3 of the step
-  Taps t;
-  float m = 0.f;
-  int t_of = -1;   // the (k, dgi) the taps belong to
-  auto gather = [&](int step) -> float4 {
-    const int k = step / chunks, c = (step % chunks) * 16 + 4 * gq, dgi = c / cpg;
-    if (k * g.dg + dgi != t_of) {
-      t_of = k * g.dg + dgi;
-      m = 0.f;
-      t.valid = 0;
-      t.o[0] = t.o[1] = t.o[2] = t.o[3] = -1;
-      t.w[0] = t.w[1] = t.w[2] = t.w[3] = 0.f;
-      if (live) t = pixel_taps(g, offset, mask, b, ho, wo, k, dgi, &m);
-    }
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (t.o[q] >= 0) {
-        const float4 v = ld4(xb + static_cast<long long>(t.o[q]) * g.Cin + c);
-        a.x += t.w[q] * v.x; a.y += t.w[q] * v.y; a.z += t.w[q] * v.z; a.w += t.w[q] * v.w;
-      }
-    a.x *= m; a.y *= m; a.z *= m; a.w *= m;
-    return a;
-  };
-  float4 wv[IT];
-  load_w(0, wv);
-  float4 a = gather(0);
-  store_w(wv, lds);
-  __syncthreads();
-  for (int s = 0; s < steps; ++s) {
-    float* cur = lds + (s & 1) * FRAG;
-    float4 a_next = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (s + 1 < steps) {
-      load_w(s + 1, wv);
-      a_next = gather(s + 1);
-    }
-    float4 bv[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) bv[nb] = *reinterpret_cast<const float4*>(&cur[(nb * 64 + lane) * 4]);
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bv[nb].x, acc[nb], 0, 0, 0);
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bv[nb].y, acc[nb], 0, 0, 0);
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bv[nb].z, acc[nb], 0, 0, 0);
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bv[nb].w, acc[nb], 0, 0, 0);
-    if (s + 1 < steps) store_w(wv, lds + ((s + 1) & 1) * FRAG);   // the other buffer: every wave left it at the barrier of step s - 1
-    __syncthreads();
-    a = a_next;
-  }
-  const int n = lane & 15, q = lane >> 4;
-  const long long row0 = static_cast<long long>(blockIdx.x) * 64 + wave * 16;
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    const int col = nb * 16 + n;
-    if (col >= g.Cout) continue;
-    const float bb = bias ? bias[col] : 0.f;
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const long long row = row0 + q * 4 + reg;
-      if (row < npix) y[row * g.Cout + col] = acc[nb][reg] + bb;
-    }
-  }
-}
-
-// ---------------------------------------------------------------- backward: data / offset / mask -----
-// One wave = 16 output pixels.  dy fragment (A operand, Cout values per pixel) stays in registers; for every tap k and
-// 16-channel chunk the wave forms dcol[16 pixels][16 ci] with Cout/4 MFMAs against W_k^T (LDS), then turns it into
-// grad_x (atomics on the 4 taps), grad_mask and grad_offset (reduced over ci with shuffles, accumulated over chunks).
-template <int JO>  // Cout padded to 16*JO
-__global__ __launch_bounds__(256) void dcn_bwd_data_k(DcnGeom g, const float* __restrict__ x, const float* __restrict__ wt,
-                                                      const float* __restrict__ offset, const float* __restrict__ mask,
-                                                      const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ doff,
-                                                      float* __restrict__ dmask) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // B fragment: [JO][64 lanes][4]: B[co][ci]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, gq = lane >> 4;
-  const long long npix = static_cast<long long>(g.B) * g.Ho * g.Wo;
-  const long long row0 = static_cast<long long>(blockIdx.x) * 64 + wave * 16;
-  const long long pix = row0 + r;
-  const bool live = pix < npix;
-  const int K = g.kh * g.kw, cpg = g.Cin / g.dg;
-  const long long plane = static_cast<long long>(g.Ho) * g.Wo;
-  // A fragment: lane (r, gq) holds dy[pix_r][16j + 4gq .. +3]
-  float4 av[JO];
-#pragma unroll
-  for (int j = 0; j < JO; ++j) {
-    av[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int c = 16 * j + 4 * gq;
-    if (live && c < g.Cout) av[j] = ld4(dy + pix * g.Cout + c);
-  }
-  // epilogue view: lane (n = ci within chunk, q) owns pixels row0 + 4q + reg
-  const int n = lane & 15, q = lane >> 4;
-  for (int k = 0; k < K; ++k) {
-    for (int dgi = 0; dgi < g.dg; ++dgi) {
-      // taps of the 4 pixels this lane post-processes
-      Taps tp[4];
-      float mk[4];
-      int pb[4];
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const long long p = row0 + q * 4 + reg;
-        mk[reg] = 0.f;
-        pb[reg] = 0;
-        tp[reg].valid = 0;
-        tp[reg].o[0] = tp[reg].o[1] = tp[reg].o[2] = tp[reg].o[3] = -1;
-        tp[reg].w[0] = tp[reg].w[1] = tp[reg].w[2] = tp[reg].w[3] = 0.f;
-        tp[reg].lh = tp[reg].lw = 0.f;
-        if (p < npix) {
-          const int b = static_cast<int>(p / plane), rem = static_cast<int>(p % plane);
-          pb[reg] = b;
-          tp[reg] = pixel_taps(g, offset, mask, b, rem / g.Wo, rem % g.Wo, k, dgi, &mk[reg]);
-        }
-      }
-      float gm[4] = {0.f, 0.f, 0.f, 0.f}, gh[4] = {0.f, 0.f, 0.f, 0.f}, gw[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int c0 = dgi * cpg; c0 < (dgi + 1) * cpg; c0 += 16) {
-        __syncthreads();
-        // B[co][ci] = wt[k][c0 + ci][co]  -> fragment order with source index co: element at ((co>>4)*64 + ((co>>2)&3)*16 + ci)*4 + (co&3)
-        for (int e = threadIdx.x; e < 16 * (JO * 4); e += 256) {
-          const int ci = e / (JO * 4), co = (e % (JO * 4)) * 4;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (c0 + ci < (dgi + 1) * cpg) {
-            const float* p = wt + (static_cast<long long>(k) * g.Cin + c0 + ci) * g.Cout + co;
-            if (co + 3 < g.Cout) v = ld4(p);
-            else {
-              if (co < g.Cout) v.x = p[0];
-              if (co + 1 < g.Cout) v.y = p[1];
-              if (co + 2 < g.Cout) v.z = p[2];
-            }
-          }
-          *reinterpret_cast<float4*>(&lds[(((co >> 4) * 64) + ((co >> 2) & 3) * 16 + ci) * 4]) = v;
-        }
-        __syncthreads();
-        f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < JO; ++j) {
-          const float4 bv = *reinterpret_cast<const float4*>(&lds[(j * 64 + lane) * 4]);
-          d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].x, bv.x, d, 0, 0, 0);
-          d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].y, bv.y, d, 0, 0, 0);
-          d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].z, bv.z, d, 0, 0, 0);
-          d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].w, bv.w, d, 0, 0, 0);
-        }
-        // d[reg] = dcol[pixel row0+4q+reg][ci = c0 + n]
-        const int ci = c0 + n;
-        const bool cok = ci < (dgi + 1) * cpg;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const Taps& t = tp[reg];
-          if (!t.valid || !cok) continue;
-          const float gcol = d[reg];
-          const float* xb = x + static_cast<long long>(pb[reg]) * g.H * g.W * g.Cin + ci;
-          float* dxb = dx + static_cast<long long>(pb[reg]) * g.H * g.W * g.Cin + ci;
-          float v[4];
-#pragma unroll
-          for (int qq = 0; qq < 4; ++qq) {
-            v[qq] = t.o[qq] >= 0 ? xb[static_cast<long long>(t.o[qq]) * g.Cin] : 0.f;
-            if (t.o[qq] >= 0) atomicAdd(&dxb[static_cast<long long>(t.o[qq]) * g.Cin], gcol * mk[reg] * t.w[qq]);
-          }
-          const float val = t.w[0] * v[0] + t.w[1] * v[1] + t.w[2] * v[2] + t.w[3] * v[3];
-          gm[reg] += gcol * val;
-          // d val / d h = -hw*v1 - lw*v2 + hw*v3 + lw*v4 ; d val / d w = -hh*v1 + hh*v2 - lh*v3 + lh*v4 (mdmcn_get_coordinate_weight)
-          const float hw = 1.f - t.lw, hh = 1.f - t.lh;
-          gh[reg] += gcol * mk[reg] * (-hw * v[0] - t.lw * v[1] + hw * v[2] + t.lw * v[3]);
-          gw[reg] += gcol * mk[reg] * (-hh * v[0] + hh * v[1] - t.lh * v[2] + t.lh * v[3]);
-        }
-      }
-      // reduce over the 16 ci lanes (n) and store: (pixel, k, dgi) is owned by exactly one wave
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        float a = gm[reg], bh = gh[reg], bw = gw[reg];
-#pragma unroll
-        for (int s = 1; s < 16; s <<= 1) {
-          a += __shfl_xor(a, s, 64); bh += __shfl_xor(bh, s, 64); bw += __shfl_xor(bw, s, 64);
-        }
-        const long long p = row0 + q * 4 + reg;
-        if (n == 0 && p < npix) {
-          const int b = static_cast<int>(p / plane);
-          const long long pos = p % plane;
-          dmask[((static_cast<long long>(b) * g.dg + dgi) * K + k) * plane + pos] = a;
-          float* ob = doff + (static_cast<long long>(b) * g.dg + dgi) * 2 * K * plane;
-          ob[(2 * k) * plane + pos] = bh;
-          ob[(2 * k + 1) * plane + pos] = bw;
-        }
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------- backward: weight ---------------------
-// grid (pixel chunks, K, Cin/16); block 256 = 4 waves splitting the chunk's pixels; A_mfma[m = ci][kk = pixel] =
-// modulated sample, B_mfma[kk = pixel][n = co] = dy; partial [chunk][k][ci][co] tiles, reduced by wgrad-style sum.
-template <int NB>
-__global__ __launch_bounds__(256) void dcn_bwd_weight_k(DcnGeom g, const float* __restrict__ x, const float* __restrict__ offset,
-                                                        const float* __restrict__ mask, const float* __restrict__ dy, int pix_per_chunk,
-                                                        float* __restrict__ partial) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [16][NB*16]
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, m = lane & 15, gq = lane >> 4;
-  const int k = blockIdx.y, c0 = blockIdx.z * 16, K = g.kh * g.kw, cpg = g.Cin / g.dg;
-  const int dgi = c0 / cpg;
-  const long long npix = static_cast<long long>(g.B) * g.Ho * g.Wo, plane = static_cast<long long>(g.Ho) * g.Wo;
-  constexpr int TILE = 16 * NB * 16;
-  for (int e = threadIdx.x; e < TILE; e += 256) red[e] = 0.f;
-  f32x4 acc[NB];
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const long long p_begin = static_cast<long long>(blockIdx.x) * pix_per_chunk + static_cast<long long>(w) * (pix_per_chunk / 4);
-  const long long p_end = min(p_begin + pix_per_chunk / 4, npix);
-  const int ci = c0 + m;
-  for (long long p0 = p_begin; p0 < p_end; p0 += 4) {
-    const long long p = p0 + gq;
-    float a = 0.f;
-    float bv[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) bv[nb] = 0.f;
-    if (p < p_end) {
-      const int b = static_cast<int>(p / plane), rem = static_cast<int>(p % plane);
-      float mk;
-      const Taps t = pixel_taps(g, offset, mask, b, rem / g.Wo, rem % g.Wo, k, dgi, &mk);
-      if (ci < g.Cin) {
-        const float* xb = x + static_cast<long long>(b) * g.H * g.W * g.Cin + ci;
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq)
-          if (t.o[qq] >= 0) a += t.w[qq] * xb[static_cast<long long>(t.o[qq]) * g.Cin];
-        a *= mk;
-      }
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const int co = nb * 16 + m;
-        if (co < g.Cout) bv[nb] = dy[p * g.Cout + co];
-      }
-    }
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[nb], acc[nb], 0, 0, 0);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) atomicAdd(&red[(gq * 4 + reg) * (NB * 16) + nb * 16 + m], acc[nb][reg]);
-  __syncthreads();
-  float* out = partial + ((static_cast<long long>(blockIdx.x) * K + k) * g.Cin + c0) * g.Cout;
-  for (int e = threadIdx.x; e < TILE; e += 256) {
-    const int cr = e / (NB * 16), cc = e % (NB * 16);
-    if (c0 + cr < g.Cin && cc < g.Cout) out[static_cast<long long>(cr) * g.Cout + cc] = red[e];
-  }
-}
-
 __global__ void dcn_reduce_k(const float* __restrict__ partial, int chunks, long long per_chunk, float* __restrict__ out) {
   const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= per_chunk) return;
@@ -403,7 +39,6 @@ __global__ void dcn_reduce_k(const float* __restrict__ partial, int chunks, long
   out[t] = s;
 }
 
-// ================================================================ round 4 kernels ==================
 
 __device__ __forceinline__ void glds16(const float* gsrc, float* lds_dst) {
   const unsigned dst = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<uintptr_t>(lds_dst)));
@@ -446,7 +81,7 @@ __device__ __forceinline__ f32x4 ldx4(const char* base, unsigned off) { return *
 // Block = 4 waves, wave = MB*16 pixels x NB*16 output channels (grid.y = column blocks of NB*16).  Product formed transposed:
 // A = weights (rows = output channels, LDS), B = modulated bilinear samples (columns = pixels, registers of the lane that gathered them).
 template <int NB, int MB>
-__global__ __launch_bounds__(256, 2) void dcn_fwd2_k(DcnGeom g, const float* __restrict__ x, const float* __restrict__ wt_oc,
+__global__ __launch_bounds__(256, 2) void dcn_fwd_k(DcnGeom g, const float* __restrict__ x, const float* __restrict__ wt_oc,
                                                      const float* __restrict__ bias, const float* __restrict__ offset,
                                                      const float* __restrict__ mask, float* __restrict__ y, long long pix_base) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x NB x 256 floats
@@ -649,7 +284,11 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_col_k(DcnGeom g, const float* 
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 15, gq = lane >> 4;
   const long long npix = static_cast<long long>(g.B) * g.Ho * g.Wo;
   const int plane = g.Ho * g.Wo;
-  const int K = g.kh * g.kw, cpg = g.Cin / g.dg, cps = cpg / CS, segs = K * g.dg, steps = segs * cps;   // cpg % CS == 0
+  const int K = g.kh * g.kw, cpg = g.Cin / g.dg, cps = cpg / CS, segs = K * g.dg;   // cpg % CS == 0
+  // grid.y splits the (tap, group) segments: small maps do not fill the chip with pixel tiles alone
+  const int seg_begin = static_cast<int>(static_cast<long long>(segs) * blockIdx.y / gridDim.y);
+  const int seg_end = static_cast<int>(static_cast<long long>(segs) * (blockIdx.y + 1) / gridDim.y);
+  const int steps = (seg_end - seg_begin) * cps;
   const long long tile0 = pix_base + static_cast<long long>(blockIdx.x) * (64 * NBP) + wave * (16 * NBP);
   bool live[NBP];
   int pb[NBP], pho[NBP], pwo[NBP], ppos[NBP];
@@ -716,13 +355,14 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_col_k(DcnGeom g, const float* 
   float Dq[NBP][4];
 #pragma unroll
   for (int np = 0; np < NBP; ++np) Dq[np][0] = Dq[np][1] = Dq[np][2] = Dq[np][3] = 0.f;
-  load_offsets(0, 0);
-  set_taps(0);
-  if (segs > 1) load_offsets(g.dg > 1 ? 0 : 1, g.dg > 1 ? 1 : 0);
-  dma(0, 0, lds);
+  if (steps <= 0) return;
+  int k = seg_begin / g.dg, dgi = seg_begin % g.dg, c = 0;
+  load_offsets(k, dgi);
+  set_taps(k);
+  if (seg_begin + 1 < seg_end) load_offsets((seg_begin + 1) / g.dg, (seg_begin + 1) % g.dg);
+  dma(k, dgi * cps * CS, lds);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  int k = 0, dgi = 0, c = 0;
   for (int s = 0; s < steps; ++s) {
     float* cur = lds + (s & 1) * FRAG;
     int c1 = c + 1, dg1 = dgi, k1 = k;
@@ -804,7 +444,7 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_col_k(DcnGeom g, const float* 
         set_taps(k1);
         int dg2 = dg1 + 1, k2 = k1;
         if (dg2 == g.dg) { dg2 = 0; ++k2; }
-        if (k2 < K) load_offsets(k2, dg2);
+        if (k2 * g.dg + dg2 < seg_end) load_offsets(k2, dg2);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -816,32 +456,22 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_col_k(DcnGeom g, const float* 
 
 // ---------------------------------------------------------------- backward, pass 2: grad_input in gather form -------
 // The reference scatters every column gradient to its four bilinear corners with atomicAdd (modulated_deform_im2col_cuda.cuh:196-254):
-// 1.3 G float atomics at the MGAF head's shape and a sum whose order changes from run to run.  Here every input pixel (and deformable
-// group) owns a list of the samples that touch it - built with INTEGER atomics (count, scan, fill: the totals are exact whatever the
-// order), put into ascending sample order inside the gathering wave - and sums them itself: no float atomics, no zero fill, and the
-// same bits on every run.
-//   entry = {src = ((pixel * K + tap) << 2) | corner, bilinear weight of that corner}
-__device__ __forceinline__ void sample_corners(const DcnGeom& g, int ho, int wo, int k, float off_h, float off_w, int (&ty)[4], int (&tx)[4],
-                                               float (&wq)[4]) {
-  const int i = k / g.kw, j = k % g.kw;
-  const float h_im = static_cast<float>(ho * g.sh - g.ph + i * g.dh) + off_h;
-  const float w_im = static_cast<float>(wo * g.sw - g.pw + j * g.dw) + off_w;
-  const bool valid = (h_im > -1.f && w_im > -1.f && h_im < static_cast<float>(g.H) && w_im < static_cast<float>(g.W));
-  const float hf = floorf(h_im), wf = floorf(w_im);
-  const int h_low = static_cast<int>(hf), w_low = static_cast<int>(wf);
-  const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
-  ty[0] = ty[1] = h_low; ty[2] = ty[3] = h_low + 1;
-  tx[0] = tx[2] = w_low; tx[1] = tx[3] = w_low + 1;
-  wq[0] = hh * hw; wq[1] = hh * lw; wq[2] = lh * hw; wq[3] = lh * lw;
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-    if (!(valid && ty[q] >= 0 && ty[q] <= g.H - 1 && tx[q] >= 0 && tx[q] <= g.W - 1)) wq[q] = 0.f;   // weight 0 = no entry
-}
+// 1.3 G float atomics at the MGAF head's shape and a sum whose order changes from run to run.  Here every sample is filed under its
+// TOP-LEFT corner pixel ("key": one integer atomic per sample for the count, one for the slot; totals are exact whatever the order), and
+// a wave that owns a 2 x 4 tile of input pixels walks the 3 x 5 keys around it: an entry of key (r, c) adds to the pixels (r, c),
+// (r, c+1), (r+1, c), (r+1, c+1) of the tile with its four bilinear weights.  Keys are visited in a fixed order and every list in
+// ascending sample order (ranked inside the wave), so each pixel's sum has one order: no float atomics, no zero fill, same bits every run.
+//   key grid per (sample, deformable group): (H + 1) x (W + 1), key (h_low + 1, w_low + 1); entry = {src = pixel * K + tap, lh, lw}
+struct DcnEntries {
+  unsigned* src;
+  float* lh;
+  float* lw;
+};
 
-// one thread per sample (b, group, tap, output pixel): FILL = 0 counts the entries of every target, FILL = 1 writes them
-// (cursor[t] starts at the list's first slot and ends at its end: list t = [cursor[t - 1], cursor[t]) afterwards)
+// one thread per sample (b, group, tap, output pixel): FILL = 0 counts the entries of every key, FILL = 1 writes them
+// (cursor[key] starts at the list's first slot and ends at its end: list = [cursor[key - 1], cursor[key]) afterwards)
 template <int FILL>
-__global__ __launch_bounds__(256) void dcn_index_k(DcnGeom g, const float* __restrict__ offset, int* __restrict__ cursor, uint2* __restrict__ entries) {
+__global__ __launch_bounds__(256) void dcn_index_k(DcnGeom g, const float* __restrict__ offset, int* __restrict__ cursor, DcnEntries en) {
   const int plane = g.Ho * g.Wo, K = g.kh * g.kw;
   const long long total = static_cast<long long>(g.B) * g.dg * K * plane;
   const long long id = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
@@ -852,27 +482,29 @@ __global__ __launch_bounds__(256) void dcn_index_k(DcnGeom g, const float* __res
   const int b = bd / g.dg;
   const float* ob = offset + static_cast<long long>(bd) * 2 * K * plane + pos;
   const float off_h = ob[static_cast<long long>(2 * k) * plane], off_w = ob[static_cast<long long>(2 * k + 1) * plane];
-  int ty[4], tx[4];
-  float wq[4];
-  sample_corners(g, pos / g.Wo, pos % g.Wo, k, off_h, off_w, ty, tx, wq);
-  const long long pix = static_cast<long long>(b) * plane + pos;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    if (wq[q] == 0.f) continue;
-    const long long t = (static_cast<long long>(bd) * g.H + ty[q]) * g.W + tx[q];
-    const int slot = atomicAdd(&cursor[t], 1);
-    if (FILL) entries[slot] = make_uint2(static_cast<unsigned>((pix * K + k) * 4 + q), __float_as_uint(wq[q]));
+  const int ho = pos / g.Wo, wo = pos % g.Wo, i = k / g.kw, j = k % g.kw;
+  const float h_im = static_cast<float>(ho * g.sh - g.ph + i * g.dh) + off_h;
+  const float w_im = static_cast<float>(wo * g.sw - g.pw + j * g.dw) + off_w;
+  if (!(h_im > -1.f && w_im > -1.f && h_im < static_cast<float>(g.H) && w_im < static_cast<float>(g.W))) return;   // :237 of the reference
+  const float hf = floorf(h_im), wf = floorf(w_im);
+  const long long key = (static_cast<long long>(bd) * (g.H + 1) + static_cast<int>(hf) + 1) * (g.W + 1) + static_cast<int>(wf) + 1;
+  const int slot = atomicAdd(&cursor[key], 1);
+  if (FILL) {
+    en.src[slot] = static_cast<unsigned>((static_cast<long long>(b) * plane + pos) * K + k);
+    en.lh[slot] = h_im - hf;
+    en.lw[slot] = w_im - wf;
   }
 }
 
-// Lists longer than a wave (more than 64 samples on one input pixel) are put in order here, one workgroup per list, up to 4096 entries;
-// beyond that the list keeps its fill order: the sum is still complete, only its rounding may differ between runs.
+// Lists longer than a wave (more than 64 samples under one key) are put in order here, up to 4096 entries; beyond that a list keeps
+// its fill order: the sum is still complete, only its rounding may differ between runs.
 constexpr int kDcnLongList = 4096;
-__global__ __launch_bounds__(256) void dcn_index_sort_long_k(const int* __restrict__ ends, long long ntargets, uint2* __restrict__ entries) {
-  __shared__ uint2 buf[kDcnLongList];
+__global__ __launch_bounds__(256) void dcn_index_sort_long_k(const int* __restrict__ ends, long long nkeys, DcnEntries en) {
+  __shared__ unsigned bs[kDcnLongList];
+  __shared__ float bh[kDcnLongList], bw[kDcnLongList];
   __shared__ int queue[256], qn;
-  const long long per = (ntargets + gridDim.x - 1) / gridDim.x;
-  const long long t0 = static_cast<long long>(blockIdx.x) * per, t1 = min(t0 + per, ntargets);
+  const long long per = (nkeys + gridDim.x - 1) / gridDim.x;
+  const long long t0 = static_cast<long long>(blockIdx.x) * per, t1 = min(t0 + per, nkeys);
   for (long long base = t0; base < t1; base += 256) {
     if (threadIdx.x == 0) qn = 0;
     __syncthreads();
@@ -886,78 +518,161 @@ __global__ __launch_bounds__(256) void dcn_index_sort_long_k(const int* __restri
     for (int qi = 0; qi < nq; ++qi) {   // which list comes first does not matter: lists are disjoint
       const long long tt = base + queue[qi];
       const int start = tt ? ends[tt - 1] : 0, n = ends[tt] - start;
-      for (int i = threadIdx.x; i < n; i += 256) buf[i] = entries[start + i];
+      for (int i = threadIdx.x; i < n; i += 256) { bs[i] = en.src[start + i]; bh[i] = en.lh[start + i]; bw[i] = en.lw[start + i]; }
       __syncthreads();
       for (int i = threadIdx.x; i < n; i += 256) {
-        const uint2 e = buf[i];
+        const unsigned s = bs[i];
         int rank = 0;
-        for (int j = 0; j < n; ++j) rank += buf[j].x < e.x;
-        entries[start + rank] = e;
+        for (int j = 0; j < n; ++j) rank += bs[j] < s;
+        en.src[start + rank] = s; en.lh[start + rank] = bh[i]; en.lw[start + rank] = bw[i];
       }
       __syncthreads();
     }
   }
 }
 
-// one wave per (target pixel, deformable group); lane = VEC adjacent channels of the group
 template <int VEC>
-__global__ __launch_bounds__(256) void dcn_col2im_k(DcnGeom g, const float* __restrict__ colg, const int* __restrict__ ends,
-                                                    const uint2* __restrict__ entries, float* __restrict__ dx) {
-  __shared__ uint2 sorted[4][64];
+struct ColVec { float v[VEC]; };
+template <int VEC>
+__device__ __forceinline__ ColVec<VEC> col_load(const float* p) {
+  ColVec<VEC> r;
+  if constexpr (VEC == 4) { const f32x4 t = *reinterpret_cast<const f32x4*>(p); r.v[0] = t[0]; r.v[1] = t[1]; r.v[2] = t[2]; r.v[3] = t[3]; }
+  else if constexpr (VEC == 2) { const float2 t = *reinterpret_cast<const float2*>(p); r.v[0] = t.x; r.v[1] = t.y; }
+  else r.v[0] = p[0];
+  return r;
+}
+
+// one wave per (2 x 4 tile of input pixels, sample, deformable group); lane = VEC adjacent channels of the group
+template <int VEC>
+__global__ __launch_bounds__(256) void dcn_col2im_k(DcnGeom g, const float* __restrict__ colg, const int* __restrict__ ends, DcnEntries en,
+                                                    float* __restrict__ dx) {
+  __shared__ unsigned s_src[4][64];
+  __shared__ float s_lh[4][64], s_lw[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long long HW = static_cast<long long>(g.H) * g.W, ntargets = static_cast<long long>(g.B) * g.dg * HW;
-  const long long t = static_cast<long long>(blockIdx.x) * 4 + wave;
-  if (t >= ntargets) return;
-  const int K = g.kh * g.kw, cpg = g.Cin / g.dg;
-  const int bd = static_cast<int>(t / HW), b = bd / g.dg, dgi = bd % g.dg;
-  const long long tp = static_cast<long long>(b) * HW + t % HW;   // pixel of x / dx
-  const int start = t ? ends[t - 1] : 0, n = ends[t] - start;
-  const uint2* list = entries + start;
-  const bool in_lds = n <= 64;
-  if (in_lds) {
-    uint2 e = make_uint2(0xffffffffu, 0u);
-    if (lane < n) e = list[lane];
-    int rank = 0;
-    for (int j = 0; j < n; ++j) rank += static_cast<unsigned>(__shfl(static_cast<int>(e.x), j, 64)) < e.x;
-    if (lane < n) sorted[wave][rank] = e;
-    // the wave reads its own slots only: LDS operations of one wave execute in order, no barrier
-  }
+  const int tiles_c = (g.W + 3) / 4, tiles_r = (g.H + 1) / 2;
+  const long long ntiles = static_cast<long long>(g.B) * g.dg * tiles_r * tiles_c;
+  const long long tile = static_cast<long long>(blockIdx.x) * 4 + wave;
+  if (tile >= ntiles) return;
+  const int cpg = g.Cin / g.dg;
+  const int bd = static_cast<int>(tile / (tiles_r * tiles_c)), b = bd / g.dg, dgi = bd % g.dg;
+  const int tr0 = static_cast<int>((tile / tiles_c) % tiles_r) * 2, tc0 = static_cast<int>(tile % tiles_c) * 4;
+  const int nl = min(5, g.W + 1 - tc0);   // key columns tc0 .. tc0 + nl - 1 exist
+  unsigned* ssrc = s_src[wave];
+  float *slh = s_lh[wave], *slw = s_lw[wave];
   for (int c0 = 0; c0 < cpg; c0 += 64 * VEC) {
     const int c = c0 + lane * VEC;
     const bool act = c < cpg;
     const float* col = colg + static_cast<long long>(dgi) * cpg + (act ? c : 0);
-    float acc[VEC];
+    float acc[2][4][VEC];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
-    int i = 0;
-    for (; i + 4 <= n; i += 4) {
-      uint2 e[4];
-      float vals[4][VEC];
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) e[u] = in_lds ? sorted[wave][i + u] : list[i + u];
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float* p = col + static_cast<long long>(e[u].x >> 2) * g.Cin;
-        if constexpr (VEC == 4) { const f32x4 v = *reinterpret_cast<const f32x4*>(p); vals[u][0] = v[0]; vals[u][1] = v[1]; vals[u][2] = v[2]; vals[u][3] = v[3]; }
-        else if constexpr (VEC == 2) { const float2 v = *reinterpret_cast<const float2*>(p); vals[u][0] = v.x; vals[u][1] = v.y; }
-        else vals[u][0] = p[0];
+        for (int v = 0; v < VEC; ++v) acc[a][e][v] = 0.f;
+    auto add = [&](auto I_, auto J_, unsigned src, float lh, float lw, const ColVec<VEC>& row) {
+      constexpr int I = decltype(I_)::value, J = decltype(J_)::value;
+      const float hh = 1.f - lh, hw = 1.f - lw;
+#pragma unroll
+      for (int dr = 0; dr < 2; ++dr)
+#pragma unroll
+        for (int dc = 0; dc < 2; ++dc) {
+          constexpr int dummy = 0; (void)dummy;
+          const int tr = I - 1 + dr, tc = J - 1 + dc;
+          if (tr < 0 || tr > 1 || tc < 0 || tc > 3) continue;
+          const float w = (dr ? lh : hh) * (dc ? lw : hw);
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) acc[tr][tc][v] = __builtin_fmaf(w, row.v[v], acc[tr][tc][v]);
+        }
+    };
+    // entries [lo, hi) of the wave's LDS stage belong to key (I, J)
+    auto walk = [&](auto I_, auto J_, int lo, int hi) {
+      int e = lo;
+      for (; e + 4 <= hi; e += 4) {
+        unsigned s[4]; float a[4], bq[4]; ColVec<VEC> r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s[u] = ssrc[e + u]; a[u] = slh[e + u]; bq[u] = slw[e + u]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = col_load<VEC>(col + static_cast<long long>(s[u]) * g.Cin);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) add(I_, J_, s[u], a[u], bq[u], r[u]);
       }
+      for (; e < hi; ++e) add(I_, J_, ssrc[e], slh[e], slw[e], col_load<VEC>(col + static_cast<long long>(ssrc[e]) * g.Cin));
+    };
+    auto key_row = [&](auto I_) {
+      constexpr int I = decltype(I_)::value;
+      const int kr = tr0 + I;   // key row; exists for kr <= H
+      if (kr > g.H) return;
+      const long long kbase = (static_cast<long long>(bd) * (g.H + 1) + kr) * (g.W + 1) + tc0;
+      // list bounds of the nl keys: s[j] = end of key kbase + j - 1 (= start of key kbase + j)
+      int bound = 0;
+      if (lane <= nl) { const long long kk = kbase + lane - 1; bound = kk >= 0 ? ends[kk] : 0; }
+      int s[6];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int j = 0; j < 6; ++j) s[j] = __shfl(bound, min(j, nl), 64);
+      const int run0 = s[0], nrun = s[5] - s[0];
+      if (nrun <= 64) {
+        // the five lists are one contiguous run: rank every entry by (list, sample) inside the wave
+        unsigned src = 0xffffffffu; float lh = 0.f, lw = 0.f;
+        int mylist = 8;
+        if (lane < nrun) {
+          src = en.src[run0 + lane]; lh = en.lh[run0 + lane]; lw = en.lw[run0 + lane];
+          mylist = 0;
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) acc[v] = __builtin_fmaf(__uint_as_float(e[u].y), vals[u][v], acc[v]);
-    }
-    for (; i < n; ++i) {
-      const uint2 e = in_lds ? sorted[wave][i] : list[i];
-      const float* p = col + static_cast<long long>(e.x >> 2) * g.Cin;
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) acc[v] = __builtin_fmaf(__uint_as_float(e.y), p[v], acc[v]);
-    }
+          for (int j = 1; j < 5; ++j) mylist += (run0 + lane >= s[j]);
+        }
+        const unsigned long long mine = (static_cast<unsigned long long>(mylist) << 32) | src;
+        int rank = 0;
+        for (int j = 0; j < nrun; ++j) {
+          const unsigned long long o = (static_cast<unsigned long long>(static_cast<unsigned>(__shfl(mylist, j, 64))) << 32) |
+                                       static_cast<unsigned>(__shfl(static_cast<int>(src), j, 64));
+          rank += o < mine;
+        }
+        if (lane < nrun) { ssrc[rank] = src; slh[rank] = lh; slw[rank] = lw; }
+        // (one wave, in-order LDS: no barrier)
+        walk(I_, std::integral_constant<int, 0>{}, s[0] - run0, s[1] - run0);
+        walk(I_, std::integral_constant<int, 1>{}, s[1] - run0, s[2] - run0);
+        walk(I_, std::integral_constant<int, 2>{}, s[2] - run0, s[3] - run0);
+        walk(I_, std::integral_constant<int, 3>{}, s[3] - run0, s[4] - run0);
+        walk(I_, std::integral_constant<int, 4>{}, s[4] - run0, s[5] - run0);
+      } else {
+        auto one = [&](auto J_, int lo, int hi) {
+          const int n = hi - lo;
+          for (int base = 0; base < n; base += 64) {
+            const int cnt = min(64, n - base);
+            unsigned src = 0xffffffffu; float lh = 0.f, lw = 0.f;
+            if (lane < cnt) { src = en.src[lo + base + lane]; lh = en.lh[lo + base + lane]; lw = en.lw[lo + base + lane]; }
+            int rank = lane;                                   // lists above 64 entries were sorted by dcn_index_sort_long_k
+            if (n <= 64) {
+              rank = 0;
+              for (int j = 0; j < cnt; ++j) rank += static_cast<unsigned>(__shfl(static_cast<int>(src), j, 64)) < src;
+            }
+            if (lane < cnt) { ssrc[rank] = src; slh[rank] = lh; slw[rank] = lw; }
+            walk(I_, J_, 0, cnt);
+          }
+        };
+        one(std::integral_constant<int, 0>{}, s[0], s[1]);
+        one(std::integral_constant<int, 1>{}, s[1], s[2]);
+        one(std::integral_constant<int, 2>{}, s[2], s[3]);
+        one(std::integral_constant<int, 3>{}, s[3], s[4]);
+        one(std::integral_constant<int, 4>{}, s[4], s[5]);
+      }
+    };
+    key_row(std::integral_constant<int, 0>{});
+    key_row(std::integral_constant<int, 1>{});
+    key_row(std::integral_constant<int, 2>{});
     if (act) {
-      float* out = dx + tp * g.Cin + dgi * cpg + c;
-      if constexpr (VEC == 4) *reinterpret_cast<f32x4*>(out) = f32x4{acc[0], acc[1], acc[2], acc[3]};
-      else if constexpr (VEC == 2) *reinterpret_cast<float2*>(out) = make_float2(acc[0], acc[1]);
-      else out[0] = acc[0];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = tr0 + a, cc = tc0 + e;
+          if (r >= g.H || cc >= g.W) continue;
+          float* out = dx + ((static_cast<long long>(b) * g.H + r) * g.W + cc) * g.Cin + dgi * cpg + c;
+          if constexpr (VEC == 4) *reinterpret_cast<f32x4*>(out) = f32x4{acc[a][e][0], acc[a][e][1], acc[a][e][2], acc[a][e][3]};
+          else if constexpr (VEC == 2) *reinterpret_cast<float2*>(out) = make_float2(acc[a][e][0], acc[a][e][1]);
+          else out[0] = acc[a][e][0];
+        }
     }
   }
 }
@@ -969,8 +684,7 @@ __global__ __launch_bounds__(256) void dcn_col2im_k(DcnGeom g, const float* __re
 // LDS, pixel-major; a wave then multiplies its 64 x 64 corner of the tile (A[ci][px] and B[px][co] read one float per lane and MFMA).
 // Loads of step s + 1 are in flight during the MFMAs of step s.  Partial tiles of the pixel ranges are summed in a fixed order (dcn_reduce_k).
 constexpr int kDwPitch = 132;   // floats per pixel row of an LDS tile: rows 4 pixels apart land 16 banks apart
-template <int DUMMY>
-__global__ __launch_bounds__(256, 2) void dcn_bwd_weight2_k(DcnGeom g, const float* __restrict__ x, const float* __restrict__ offset,
+__global__ __launch_bounds__(256, 2) void dcn_bwd_weight_k(DcnGeom g, const float* __restrict__ x, const float* __restrict__ offset,
                                                             const float* __restrict__ mask, const float* __restrict__ dy, int pix_per_block,
                                                             float* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 buffers x (col tile 16 x 132 + dy tile 16 x 132)
@@ -1101,8 +815,6 @@ static int dcn_check(const DcnGeom& g) {
   return 0;
 }
 
-static const int kDcnPixChunk = 2048;
-
 }  // namespace fv2p
 using namespace fv2p;
 
@@ -1121,12 +833,11 @@ static int dcn_cu_count() {
   return cus;
 }
 
-template <int NB, int MB>
+template <int NB>
 static void dcn_fwd_launch(const DcnGeom& g, const float* x, const float* wt_oc, const float* bias, const float* offset, const float* mask,
-                           float* y, long long pix_base, long long npix_part, int col_blocks, hipStream_t stream) {
-  if (npix_part <= 0) return;
-  const dim3 grid(static_cast<unsigned>(ceil_div(npix_part, 64 * MB)), static_cast<unsigned>(col_blocks));
-  hipLaunchKernelGGL((dcn_fwd2_k<NB, MB>), grid, dim3(256), 2 * NB * 256 * sizeof(float), stream, g, x, wt_oc, bias, offset, mask, y, pix_base);
+                           float* y, long long npix, int col_blocks, hipStream_t stream) {
+  const dim3 grid(static_cast<unsigned>(ceil_div(npix, 64)), static_cast<unsigned>(col_blocks));
+  hipLaunchKernelGGL((dcn_fwd_k<NB, 1>), grid, dim3(256), 2 * NB * 256 * sizeof(float), stream, g, x, wt_oc, bias, offset, mask, y, 0ll);
 }
 
 // wt_oc: weight permuted to [kh*kw][Cout][Cin] (input channels contiguous: what the LDS-DMA of the forward kernel fetches 16 bytes at a time)
@@ -1139,45 +850,32 @@ extern "C" int fv2p_dcn_forward(const float* x_nhwc, const float* wt_oc, const f
   if (npix == 0) return 0;
   FV2P_REQUIRE(x_nhwc && wt_oc && offset && mask && y_nhwc, FV2P_EINVAL, "dcn_forward: null pointer");
   FV2P_REQUIRE(static_cast<long long>(g.B) * g.H * g.W * g.Cin * 4 < (1ll << 32), FV2P_ELIMIT, "dcn_forward: input above 4 GiB (split the batch)");
-  // Tile plan.  A workgroup computes 64*MB pixels x 16*NB columns; per-pixel arithmetic does not depend on the plan (every output element
-  // is one fused multiply-add chain over (tap, channel) in a fixed order), so results are identical for every batch size.
-  // Whole rounds of 128-pixel tiles, then the remainder as 64-pixel tiles: the last round costs half a tile per CU.
-  const int cus = dcn_cu_count();
+  // A workgroup computes 64 pixels x 16*NB columns (32-pixel wave tiles measured 3 - 8 % slower: half the waves per SIMD).  Per-pixel
+  // arithmetic does not depend on the plan, so results are identical for every batch size.  256 columns go to one workgroup unless the
+  // map is too small to fill the chip: then two column halves, each gathering for itself.
   const int nb_all = static_cast<int>(ceil_div(g.Cout, 16));
-  const char* force = getenv("FV2P_DCN_FWD_PLAN");   // development: "<NB>,<MB>"
-  int fnb = 0, fmb = 0;
-  if (force) sscanf(force, "%d,%d", &fnb, &fmb);
-  int NBsel = nb_all <= 4 ? 4 : (nb_all <= 8 ? 8 : 16);
-  if (fnb) NBsel = fnb;
-  const int col_blocks = static_cast<int>(ceil_div(nb_all, NBsel));
-  const long long tiles128 = npix / 128;
-  long long big = (tiles128 / cus) * cus;   // whole rounds
-  if (NBsel == 16) big = 0;                 // <16,2> does not fit the register file
-  if (fmb == 1) big = 0;
-  if (fmb == 2) big = tiles128;
-  const long long big_pix = big * 128;
-#define DCN_F(NB) do { dcn_fwd_launch<NB, 2>(g, x_nhwc, wt_oc, bias, offset, mask, y_nhwc, 0, big_pix, col_blocks, stream); \
-                       dcn_fwd_launch<NB, 1>(g, x_nhwc, wt_oc, bias, offset, mask, y_nhwc, big_pix, npix - big_pix, col_blocks, stream); } while (0)
-  if (NBsel == 4) DCN_F(4);
-  else if (NBsel == 8) DCN_F(8);
-  else dcn_fwd_launch<16, 1>(g, x_nhwc, wt_oc, bias, offset, mask, y_nhwc, 0, npix, col_blocks, stream);
-#undef DCN_F
+  int nb = nb_all <= 4 ? 4 : (nb_all <= 8 ? 8 : 16);
+  if (nb == 16 && ceil_div(npix, 64) < 2 * dcn_cu_count()) nb = 8;
+  if (const char* force = getenv("FV2P_DCN_FWD_NB")) nb = atoi(force);   // development
+  const int col_blocks = static_cast<int>(ceil_div(nb_all, nb));
+  if (nb == 4) dcn_fwd_launch<4>(g, x_nhwc, wt_oc, bias, offset, mask, y_nhwc, npix, col_blocks, stream);
+  else if (nb == 8) dcn_fwd_launch<8>(g, x_nhwc, wt_oc, bias, offset, mask, y_nhwc, npix, col_blocks, stream);
+  else dcn_fwd_launch<16>(g, x_nhwc, wt_oc, bias, offset, mask, y_nhwc, npix, col_blocks, stream);
   FV2P_LAUNCH_CHECK();
   return 0;
 }
 
-
 // ---- backward: workspace carving shared by the size query and the call
 struct DcnBwdPlan {
-  long long npix, ntargets, max_entries;
+  long long npix, nkeys, max_entries;
   int splits, pix_per_block, ci_tiles, co_tiles;
 };
 static DcnBwdPlan dcn_bwd_plan(const DcnGeom& g) {
   DcnBwdPlan p;
   const int K = g.kh * g.kw;
   p.npix = static_cast<long long>(g.B) * g.Ho * g.Wo;
-  p.ntargets = static_cast<long long>(g.B) * g.dg * g.H * g.W;
-  p.max_entries = p.npix * g.dg * K * 4;
+  p.nkeys = static_cast<long long>(g.B) * g.dg * (g.H + 1) * (g.W + 1);
+  p.max_entries = p.npix * g.dg * K;
   p.ci_tiles = static_cast<int>(ceil_div(g.Cin, 128));
   p.co_tiles = static_cast<int>(ceil_div(g.Cout, 128));
   const long long cols = static_cast<long long>(K) * p.ci_tiles * p.co_tiles;
@@ -1191,12 +889,14 @@ static DcnBwdPlan dcn_bwd_plan(const DcnGeom& g) {
   return p;
 }
 template <typename C>
-static void dcn_bwd_carve(C& c, const DcnGeom& g, const DcnBwdPlan& p, float** colg, int** cursor, uint2** entries, void** scan_ws, float** partial) {
+static void dcn_bwd_carve(C& c, const DcnGeom& g, const DcnBwdPlan& p, float** colg, int** cursor, DcnEntries* entries, void** scan_ws, float** partial) {
   const int K = g.kh * g.kw;
   *colg = c.template take<float>(static_cast<size_t>(p.npix) * K * g.Cin);
-  *cursor = c.template take<int>(static_cast<size_t>(p.ntargets) + 1);
-  *entries = c.template take<uint2>(static_cast<size_t>(p.max_entries));
-  *scan_ws = c.template take<char>(scan_ws_bytes(p.ntargets));
+  *cursor = c.template take<int>(static_cast<size_t>(p.nkeys) + 1);
+  entries->src = c.template take<unsigned>(static_cast<size_t>(p.max_entries));
+  entries->lh = c.template take<float>(static_cast<size_t>(p.max_entries));
+  entries->lw = c.template take<float>(static_cast<size_t>(p.max_entries));
+  *scan_ws = c.template take<char>(scan_ws_bytes(p.nkeys));
   *partial = c.template take<float>(static_cast<size_t>(p.splits) * K * g.Cin * g.Cout);
 }
 struct SizerC : Sizer {
@@ -1208,17 +908,16 @@ extern "C" size_t fv2p_dcn_backward_ws_bytes(int batch, int height, int width, i
   DcnGeom g = {batch, height, width, c_in, c_out, h_out, w_out, kh, kw, 1, 1, 0, 0, 1, 1, deformable_group > 0 ? deformable_group : 1};
   const DcnBwdPlan p = dcn_bwd_plan(g);
   SizerC s;
-  float *a, *e; int* b; uint2* c; void* d;
+  float *a, *e; int* b; DcnEntries c; void* d;
   dcn_bwd_carve(s, g, p, &a, &b, &c, &d, &e);
   return s.bytes();
 }
 
-template <int JO, int NBP, int MC>
+template <int JO, int MC>
 static void dcn_col_launch(const DcnGeom& g, const float* x, const float* wt, const float* offset, const float* mask, const float* dy, float* colg,
-                           float* doff, float* dmask, long long pix_base, long long npix_part, hipStream_t stream) {
-  if (npix_part <= 0) return;
-  hipLaunchKernelGGL((dcn_bwd_col_k<JO, NBP, MC>), dim3(static_cast<unsigned>(ceil_div(npix_part, 64 * NBP))), dim3(256),
-                     2 * MC * JO * 256 * sizeof(float), stream, g, x, wt, offset, mask, dy, colg, doff, dmask, pix_base);
+                           float* doff, float* dmask, long long npix, int seg_split, hipStream_t stream) {
+  hipLaunchKernelGGL((dcn_bwd_col_k<JO, 1, MC>), dim3(static_cast<unsigned>(ceil_div(npix, 64)), static_cast<unsigned>(seg_split)), dim3(256),
+                     2 * MC * JO * 256 * sizeof(float), stream, g, x, wt, offset, mask, dy, colg, doff, dmask, 0ll);
 }
 
 // dx_nhwc, doffset, dmask, dwt are fully written (nothing to zero).  wt = [kh*kw][Cin][Cout].
@@ -1242,109 +941,47 @@ extern "C" int fv2p_dcn_backward(const float* x_nhwc, const float* wt, const flo
   FV2P_REQUIRE(nin * g.Cin * 4 < (1ll << 32) && npix * K * g.Cin * 4 < (1ll << 32), FV2P_ELIMIT,
                "dcn_backward: input or column gradients above 4 GiB (split the batch)");
   const DcnBwdPlan p = dcn_bwd_plan(g);
-  FV2P_REQUIRE(p.max_entries < (1ll << 31) && npix * K * 4 < (1ll << 32), FV2P_ELIMIT, "dcn_backward: too many samples (split the batch)");
+  FV2P_REQUIRE(p.max_entries < (1ll << 31) && npix * K < (1ll << 32), FV2P_ELIMIT, "dcn_backward: too many samples (split the batch)");
   FV2P_REQUIRE(ws && ws_bytes >= fv2p_dcn_backward_ws_bytes(g.B, g.H, g.W, g.Ho, g.Wo, g.Cin, g.Cout, g.kh, g.kw, g.dg), FV2P_EWORKSPACE,
                "dcn_backward: workspace too small");
   Carver c(ws, ws_bytes);
-  float *colg, *partial; int* cursor; uint2* entries; void* sws;
+  float *colg, *partial; int* cursor; DcnEntries entries; void* sws;
   dcn_bwd_carve(c, g, p, &colg, &cursor, &entries, &sws, &partial);
   // 1. per-target sample lists
-  FV2P_HIP(hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)(p.ntargets + 1), stream));
+  FV2P_HIP(hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)(p.nkeys + 1), stream));
   const long long nsamples = npix * g.dg * K;
   const unsigned iblocks = static_cast<unsigned>(ceil_div(nsamples, 256));
   hipLaunchKernelGGL((dcn_index_k<0>), dim3(iblocks), dim3(256), 0, stream, g, offset, cursor, entries);
-  if (int rc = exclusive_scan_i32(cursor, cursor, p.ntargets, nullptr, sws, scan_ws_bytes(p.ntargets), stream)) return rc;
+  if (int rc = exclusive_scan_i32(cursor, cursor, p.nkeys, nullptr, sws, scan_ws_bytes(p.nkeys), stream)) return rc;
   hipLaunchKernelGGL((dcn_index_k<1>), dim3(iblocks), dim3(256), 0, stream, g, offset, cursor, entries);
-  hipLaunchKernelGGL(dcn_index_sort_long_k, dim3(static_cast<unsigned>(std::min<long long>(1024, ceil_div(p.ntargets, 256)))), dim3(256), 0, stream,
-                     cursor, p.ntargets, entries);
+  hipLaunchKernelGGL(dcn_index_sort_long_k, dim3(static_cast<unsigned>(std::min<long long>(1024, ceil_div(p.nkeys, 256)))), dim3(256), 0, stream,
+                     cursor, p.nkeys, entries);
   // 2. column gradients, grad_mask, grad_offset
-  const int cus = dcn_cu_count();
   const int jo = static_cast<int>(ceil_div(g.Cout, 16));
   const bool mc2 = (g.Cin / g.dg) % 32 == 0;
-  const long long tiles128 = npix / 128;
-  long long big = (tiles128 / cus) * cus;
-  const char* force = getenv("FV2P_DCN_BWD_PLAN");   // development: "<NBP>"
-  if (force && atoi(force) == 1) big = 0;
-  if (force && atoi(force) == 2) big = tiles128;
-  const long long big_pix = big * 128;
-#define DCN_C(JO, MC) do { if (JO <= 8) dcn_col_launch<JO, (JO <= 8 ? 2 : 1), MC>(g, x_nhwc, wt, offset, mask, dy_nhwc, colg, doffset, dmask, 0, big_pix, stream); \
-                           dcn_col_launch<JO, 1, MC>(g, x_nhwc, wt, offset, mask, dy_nhwc, colg, doffset, dmask, JO <= 8 ? big_pix : 0, JO <= 8 ? npix - big_pix : npix, stream); } while (0)
-#define DCN_CJ(JO) do { if (mc2) DCN_C(JO, 2); else DCN_C(JO, 1); } while (0)
+  // small maps: the (tap, group) segments of a pixel tile go to several workgroups, in equal shares (550 tiles on 256 CUs are two
+  // rounds with the second almost empty: [4,256,100,88] 1 327 -> 1 182 us with three shares; at 2 200 tiles shares only cost)
+  int seg_split = 1;
+  for (int s = 1; s <= K * g.dg; ++s)
+    if ((K * g.dg) % s == 0) { seg_split = s; if (ceil_div(npix, 64) * s >= 6 * dcn_cu_count()) break; }
+  if (const char* force = getenv("FV2P_DCN_BWD_SPLIT")) seg_split = std::max(1, std::min(atoi(force), K * g.dg));   // development
+#define DCN_CJ(JO) do { if (mc2) dcn_col_launch<JO, 2>(g, x_nhwc, wt, offset, mask, dy_nhwc, colg, doffset, dmask, npix, seg_split, stream); \
+                        else dcn_col_launch<JO, 1>(g, x_nhwc, wt, offset, mask, dy_nhwc, colg, doffset, dmask, npix, seg_split, stream); } while (0)
   if (jo <= 1) DCN_CJ(1); else if (jo <= 2) DCN_CJ(2); else if (jo <= 4) DCN_CJ(4); else if (jo <= 8) DCN_CJ(8); else DCN_CJ(16);
 #undef DCN_CJ
-#undef DCN_C
   // 3. grad_input
   const int cpg = g.Cin / g.dg;
-  const unsigned gblocks = static_cast<unsigned>(ceil_div(p.ntargets, 4));
+  const long long ntiles = static_cast<long long>(g.B) * g.dg * ((g.H + 1) / 2) * ((g.W + 3) / 4);
+  const unsigned gblocks = static_cast<unsigned>(ceil_div(ntiles, 4));
   if (cpg % 4 == 0 && cpg > 128) hipLaunchKernelGGL((dcn_col2im_k<4>), dim3(gblocks), dim3(256), 0, stream, g, colg, cursor, entries, dx_nhwc);
   else if (cpg > 64) hipLaunchKernelGGL((dcn_col2im_k<2>), dim3(gblocks), dim3(256), 0, stream, g, colg, cursor, entries, dx_nhwc);
   else hipLaunchKernelGGL((dcn_col2im_k<1>), dim3(gblocks), dim3(256), 0, stream, g, colg, cursor, entries, dx_nhwc);
   // 4. weight gradient
   const dim3 wgrid(static_cast<unsigned>(p.splits), static_cast<unsigned>(K), static_cast<unsigned>(p.ci_tiles * p.co_tiles));
-  hipLaunchKernelGGL((dcn_bwd_weight2_k<0>), wgrid, dim3(256), 2 * 2 * 16 * kDwPitch * sizeof(float), stream, g, x_nhwc, offset, mask, dy_nhwc,
+  hipLaunchKernelGGL(dcn_bwd_weight_k, wgrid, dim3(256), 2 * 2 * 16 * kDwPitch * sizeof(float), stream, g, x_nhwc, offset, mask, dy_nhwc,
                      p.pix_per_block, partial);
   const long long per_chunk = static_cast<long long>(K) * g.Cin * g.Cout;
   hipLaunchKernelGGL(dcn_reduce_k, dim3(static_cast<unsigned>(ceil_div(per_chunk, 256))), dim3(256), 0, stream, partial, p.splits, per_chunk, dwt);
   FV2P_LAUNCH_CHECK();
   return 0;
 }
-
-extern "C" int fv2p_dcn_forward_v1(const float* x_nhwc, const float* wt, const float* bias, const float* offset, const float* mask,
-                                DCN_GEOM_ARGS, float* y_nhwc, fv2p_stream_t stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  DCN_GEOM_INIT;
-  if (int rc = dcn_check(g)) return rc;
-  const long long npix = static_cast<long long>(g.B) * g.Ho * g.Wo;
-  if (npix == 0) return 0;
-  FV2P_REQUIRE(x_nhwc && wt && offset && mask && y_nhwc, FV2P_EINVAL, "dcn_forward: null pointer");
-  const unsigned blocks = static_cast<unsigned>(ceil_div(npix, 64));
-  const int nb = static_cast<int>(ceil_div(g.Cout, 16));
-#define DCN_FWD(NB) hipLaunchKernelGGL((dcn_fwd_k<NB>), dim3(blocks), dim3(256), 2 * 16 * NB * 16 * sizeof(float), stream, g, x_nhwc, wt, bias, offset, mask, y_nhwc)
-  if (nb <= 1) DCN_FWD(1); else if (nb <= 2) DCN_FWD(2); else if (nb <= 4) DCN_FWD(4); else if (nb <= 8) DCN_FWD(8); else DCN_FWD(16);
-#undef DCN_FWD
-  FV2P_LAUNCH_CHECK();
-  return 0;
-}
-
-extern "C" size_t fv2p_dcn_backward_ws_bytes_v1(int batch, int h_out, int w_out, int c_in, int c_out, int kh, int kw) {
-  const long long npix = static_cast<long long>(batch) * h_out * w_out;
-  const long long chunks = ceil_div(npix > 0 ? npix : 1, kDcnPixChunk);
-  Sizer s;
-  s.take<float>(static_cast<size_t>(chunks) * kh * kw * c_in * c_out);
-  return s.bytes();
-}
-
-// dx_nhwc must be zeroed by the caller (atomically accumulated); doff / dmask / dwt are fully written.
-extern "C" int fv2p_dcn_backward_v1(const float* x_nhwc, const float* wt, const float* offset, const float* mask, const float* dy_nhwc,
-                                 DCN_GEOM_ARGS, float* dx_nhwc, float* doffset, float* dmask, float* dwt, void* ws, size_t ws_bytes,
-                                 fv2p_stream_t stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  DCN_GEOM_INIT;
-  if (int rc = dcn_check(g)) return rc;
-  const long long npix = static_cast<long long>(g.B) * g.Ho * g.Wo;
-  const int K = g.kh * g.kw;
-  FV2P_REQUIRE(dwt, FV2P_EINVAL, "dcn_backward: null dwt");
-  if (npix == 0) {
-    FV2P_HIP(hipMemsetAsync(dwt, 0, sizeof(float) * (size_t)K * g.Cin * g.Cout, stream));
-    return 0;
-  }
-  FV2P_REQUIRE(x_nhwc && wt && offset && mask && dy_nhwc && dx_nhwc && doffset && dmask, FV2P_EINVAL, "dcn_backward: null pointer");
-  FV2P_REQUIRE(ws && ws_bytes >= fv2p_dcn_backward_ws_bytes_v1(g.B, g.Ho, g.Wo, g.Cin, g.Cout, g.kh, g.kw), FV2P_EWORKSPACE,
-               "dcn_backward: workspace too small");
-  const unsigned blocks = static_cast<unsigned>(ceil_div(npix, 64));
-  const int jo = static_cast<int>(ceil_div(g.Cout, 16));
-#define DCN_BD(JO) hipLaunchKernelGGL((dcn_bwd_data_k<JO>), dim3(blocks), dim3(256), JO * 64 * 4 * sizeof(float), stream, g, x_nhwc, wt, offset, mask, dy_nhwc, dx_nhwc, doffset, dmask)
-  if (jo <= 1) DCN_BD(1); else if (jo <= 2) DCN_BD(2); else if (jo <= 4) DCN_BD(4); else if (jo <= 8) DCN_BD(8); else DCN_BD(16);
-#undef DCN_BD
-  const unsigned chunks = static_cast<unsigned>(ceil_div(npix, kDcnPixChunk));
-  float* partial = static_cast<float*>(ws);
-  const dim3 grid(chunks, K, static_cast<unsigned>(ceil_div(g.Cin, 16)));
-#define DCN_BW(NB) hipLaunchKernelGGL((dcn_bwd_weight_k<NB>), grid, dim3(256), 16 * NB * 16 * sizeof(float), stream, g, x_nhwc, offset, mask, dy_nhwc, kDcnPixChunk, partial)
-  if (jo <= 1) DCN_BW(1); else if (jo <= 2) DCN_BW(2); else if (jo <= 4) DCN_BW(4); else if (jo <= 8) DCN_BW(8); else DCN_BW(16);
-#undef DCN_BW
-  const long long per_chunk = static_cast<long long>(K) * g.Cin * g.Cout;
-  hipLaunchKernelGGL(dcn_reduce_k, dim3(static_cast<unsigned>(ceil_div(per_chunk, 256))), dim3(256), 0, stream, partial, (int)chunks, per_chunk, dwt);
-  FV2P_LAUNCH_CHECK();
-  return 0;
-}
-
