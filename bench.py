@@ -381,8 +381,22 @@ def build_step(args, device, rank, world):
                 pre.get()
             pre.close()
 
+    def step_reference(i):
+        """The same optimiser step in the reference's call structure (fv2p_harness/refstyle.py): per-offset gather -> mm -> scatter-add
+        sparse convs, separate BatchNorm1d / ReLU, dense() by scatter + permute, and for MGAF the DCN layers as im2col + one GEMM."""
+        from fv2p_harness import refstyle
+        with refstyle.reference_call_structure(), refstyle.reference_dcn_structure():
+            feats, coords = voxelize(pool[i % n_pool])
+            loss = net(feats, coords, args.batch, gts[i % n_pool])
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+        return loss
+
     step.phases = step_phases
     step.close = close
+    step.reference = step_reference
+    step.gts = gts
     return model, step, voxelize, pool
 
 
@@ -520,14 +534,24 @@ def build_fv2p_step(args, device, rank, world):
     from fv2p_harness import refstyle
     cfg_inline = refstyle.inline_config(cfg)
 
-    def step_inline(i, reference=False):
+    def step_inline(i, reference=False, boundary=False):
         """The same optimiser step with nothing arranged around it: one stream, the batch voxelised and its key points sampled in
-        line — what the boundary itself delivers to an unmodified detector.  reference=True: in the reference's call structure
-        (fv2p_harness/refstyle.py), the baseline of vs_baseline."""
+        line.  boundary=True: additionally without the harness's own model-level restructurings (fv2p_model.KERNEL_GLUE: batched
+        truncated NMS, target-assignment / loss kernels, per-column BEV stream, merged ZeroPad2d + Conv2d) — the reference's call
+        sequence over pcdet.ops (iouguided_roi_head.py:243-255, roi_head_template.py:60-85), i.e. what the boundary alone delivers
+        to an unmodified detector.  reference=True: in the reference's call structure (fv2p_harness/refstyle.py), the baseline of
+        vs_baseline."""
         later.join()
         model.cfg = cfg_inline
         key_jobs.clear()
         clouds, gt = pool[i % n_pool]
+        if boundary:
+            from fv2p_harness import fv2p_model as _fm
+            saved_glue, _fm.KERNEL_GLUE = _fm.KERNEL_GLUE, False
+            try:
+                return step_inline(i, reference=False, boundary=False)
+            finally:
+                _fm.KERNEL_GLUE = saved_glue
 
         def body():
             feats, coords = voxelize(clouds, cloud_streams=False)
@@ -851,6 +875,76 @@ def roofline_probe(model, voxelize, pool, args, device):
             "avg_kernel_us": round(dur_s * 1e6, 2), "alg_flops": flops, "alg_bytes": bytes_alg}
 
 
+def gts_of(step):
+    return getattr(step, "gts", None)
+
+
+def dcn_roofline_probe(model, voxelize, pool, gts, args, device):
+    """Times the forward kernel (one launch per call: dcn_fwd_k) and the whole backward call of the DCN layer with the most
+    flops of the step (the MGAF head's feature adaption, [B, 256, 200, 176], four deformable groups) with events on the launch
+    stream, on the layer's own inputs of a real step; prices both against the fp32-MFMA peak (2 * pixels * Cin * Cout * taps flops
+    forward, twice that backward: SURVEY 8(d))."""
+    import fv2p_native as nat
+    from pcdet.ops.DeformableConvolutionV2PyTorch import DCN
+    from pcdet.ops.DeformableConvolutionV2PyTorch.modules.modulated_deform_conv import ModulatedDeformConv
+    records = []
+
+    def hook(mod, inp, out):
+        x, offset, mask = inp
+        b, c, h, w = x.shape
+        records.append(dict(mod=mod, x=x.detach(), offset=offset.detach(), mask=mask.detach(),
+                            flops=2.0 * b * out.shape[2] * out.shape[3] * c * mod.out_channels * mod.kernel_size[0] * mod.kernel_size[1]))
+
+    hs = [m.register_forward_hook(hook) for m in model.modules() if isinstance(m, ModulatedDeformConv)]
+    with torch.no_grad():
+        feats, coords = voxelize(pool[0])
+        model(feats, coords, args.batch, gts[0] if gts else None)
+    for h in hs:
+        h.remove()
+    out = None
+    layers = []
+    for rec in records:
+        mod = rec["mod"]
+        geom = (mod.kernel_size[0], mod.kernel_size[1], mod.stride[0], mod.stride[1], mod.padding[0], mod.padding[1], mod.dilation[0], mod.dilation[1],
+                mod.groups, mod.deformable_groups, mod.im2col_step)
+        w, bias = mod.weight.detach(), (mod.bias.detach() if mod.bias is not None else None)
+        g = DCN._geom(rec["x"], w, *geom[:10])
+        x_nhwc = rec["x"].permute(0, 2, 3, 1).contiguous()
+        wt_oc, off, msk = DCN._wt_oc(w), rec["offset"].contiguous(), rec["mask"].contiguous()
+        y = torch.empty((g[0] * g[5] * g[6], g[4]), device=device)
+
+        def fwd():
+            nat.call("fv2p_dcn_forward", x_nhwc, wt_oc, bias, off, msk, *g, y, nat.stream())
+        dy = torch.randn(g[0], g[4], g[5], g[6], device=device)
+
+        def bwd():
+            DCN.modulated_deform_conv_backward(rec["x"], w, bias, off, msk, dy, *geom, _x_nhwc=x_nhwc)
+        times = []
+        for fn, reps in ((fwd, 20), (bwd, 10)):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            times.append(e0.elapsed_time(e1) / reps / 1e3)
+        shape = f"[{g[0]},{g[3]}->{g[4]},{g[1]},{g[2]}] dg={g[15]}"
+        layers.append({"layer": shape, "forward_us": round(times[0] * 1e6, 1), "forward_frac": round(rec["flops"] / times[0] / 1e12 / PEAK_MFMA_F32_TFLOPS, 4),
+                       "backward_call_us": round(times[1] * 1e6, 1), "backward_frac": round(2 * rec["flops"] / times[1] / 1e12 / PEAK_MFMA_F32_TFLOPS, 4)})
+        if out is None or rec["flops"] > out[0]:
+            out = (rec["flops"], times[0], shape, g)
+    flops, dur_s, shape, g = out
+    ach = flops / dur_s / 1e12
+    # algorithmic bytes: x once, y once, offsets + masks, weights (SURVEY 8(d)); the kernel is far on the MFMA side of the ridge
+    bytes_alg = 4.0 * (g[0] * g[1] * g[2] * g[3] + g[0] * g[5] * g[6] * (g[4] + 27 * g[15]) + 9 * g[3] * g[4])
+    return {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
+            "kernel": f"dcn_fwd_k<{16 if g[4] > 128 else 8}, 1> (fv2p_dcn_forward)", "layer": "DCNv2 " + shape,
+            "avg_kernel_us": round(dur_s * 1e6, 2), "alg_flops": flops, "alg_bytes": bytes_alg, "dcn_layers": layers}
+
+
 def cpu_baseline(model, args):
     """The reference algorithm restated in oracle/ (dense-map voxeliser, geometry.h rulebook, per-offset
     gather -> mm -> scatter-add) on the host cores, forward + backward, on a bounded sample of the same clouds."""
@@ -1066,12 +1160,24 @@ def main():
         dist_utils.barrier()
         torch.cuda.synchronize()
         return dist_utils.max_over_ranks(time.perf_counter() - t1, device) / k
-    inline_s = refstyle_s = None
+    inline_s = refstyle_s = boundary_s = None
     if fv2p and args.impl == "native" and not args.dry_run:
         if args.inline_steps > 0:
             inline_s = extra_leg(args.inline_steps, 2)
+            boundary_s = extra_leg(args.inline_steps, 2, boundary=True)
         if args.refstyle_steps > 0 and args.workload == "fv2p":
             refstyle_s = extra_leg(args.refstyle_steps, 2, reference=True)
+    if args.workload == "mgaf" and args.refstyle_steps > 0 and not args.dry_run:
+        for i in range(2):
+            step.reference(args.warmup + args.steps + i)
+        dist_utils.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.refstyle_steps):
+            step.reference(args.warmup + args.steps + 2 + i)
+        dist_utils.barrier()
+        torch.cuda.synchronize()
+        refstyle_s = dist_utils.max_over_ranks(time.perf_counter() - t1, device) / args.refstyle_steps
     beat("post")   # probes and the CPU baseline follow: long host phases
     if rank == 0:   # leak check at a glance: what the caching allocator holds after the timed steps
         print("[memory] allocated %.1f MB, peak %.1f MB, reserved %.1f MB" % (torch.cuda.memory_allocated(device) / 2**20,
@@ -1114,21 +1220,26 @@ def main():
                 result["config"]["impl"] = "refstyle: the reference's call structure (fv2p_harness/refstyle.py), one stream"
                 result["config"]["streams"] = result["config"]["input_pipeline"] = "one stream, in line"
             if inline_s is not None:
-                # the boundary's own figure: what an unmodified detector dropped onto this pcdet.ops gets, no stream scheduling of the harness
+                # one stream, nothing prepared ahead, but still with the harness's model-level restructurings (fv2p_model.KERNEL_GLUE)
                 result["inline_ms_per_step"] = round(inline_s * 1e3, 3)
                 result["inline_value"] = round(args.batch * world / inline_s, 2)
+            if boundary_s is not None:
+                # the boundary's own figure: native pcdet.ops, one stream, the reference's call sequence (KERNEL_GLUE off: per-sample NMS,
+                # tensor-op target assignment and losses, per-point BEV stream) - what an unmodified detector dropped onto this pcdet.ops gets
+                result["boundary_ms_per_step"] = round(boundary_s * 1e3, 3)
+                result["boundary_value"] = round(args.batch * world / boundary_s, 2)
             if refstyle_s is not None:
                 base = args.batch * world / refstyle_s
                 result["vs_baseline"] = round(result["value"] / base, 3)
                 result["baseline"] = {
-                    "kind": "reference call structure on this GPU (not a published number: BASELINE.md has none)",
+                    "kind": "self-built restatement of the reference's call structure on this GPU (not a run of the reference, not a published number: BASELINE.md has none)",
                     "value": round(base, 2), "unit": "point clouds/s", "ms_per_step": round(refstyle_s * 1e3, 3), "steps": args.refstyle_steps,
                     "vs_inline": round((args.batch * world / inline_s) / base, 3) if inline_s else None,
+                    "vs_boundary": round((args.batch * world / boundary_s) / base, 3) if boundary_s else None,
                     "what": "same step, same weights and clouds: per-offset gather -> mm -> scatter-add sparse convs with the host read of indiceNum "
                             "(spconv_ops.h:260-457), separate BatchNorm1d / ReLU, dense() by scatter + permute, plain one-workgroup FPS kernel in line, "
                             "grouped set abstraction (pointnet2_modules.py:30-62), one full NMS per sample, tensor-op target assignment and losses, "
-                            "one stream; voxeliser, rulebook build, 3-NN / pooling kernels and MIOpen layers as in the native step (a lower bound "
-                            "on the reference's own step time)"}
+                            "one stream; voxeliser, rulebook build, 3-NN / pooling kernels and MIOpen layers as in the native step"}
         if args.workload == "fv2p-waymo":
             result["metric"] = "point clouds/sec fwd+bwd (FV2P, Waymo shape: 180k points, 0.1 m voxels)"
             if not args.no_roofline:
@@ -1146,7 +1257,19 @@ def main():
         elif args.workload == "mgaf":
             result["metric"] = "point clouds/sec fwd+bwd (MGAF-3DSSD, KITTI shape)"
             if not args.no_roofline:
-                result["roofline"] = roofline_probe(model.backbone_3d, voxelize, pool, args, device)
+                # dominant in-repo kernels of this config are the deformable convolutions (profiles/r04_mgaf_kernel_stats.csv)
+                result["roofline"] = dcn_roofline_probe(model, voxelize, pool, gts_of(step), args, device)
+                result["sparse_conv_roofline"] = roofline_probe(model.backbone_3d, voxelize, pool, args, device)
+            if refstyle_s is not None:
+                base = args.batch * world / refstyle_s
+                result["vs_baseline"] = round(result["value"] / base, 3)
+                result["baseline"] = {
+                    "kind": "self-built restatement of the reference's call structure on this GPU (not a run of the reference, not a published number: BASELINE.md has none)",
+                    "value": round(base, 2), "unit": "point clouds/s", "ms_per_step": round(refstyle_s * 1e3, 3), "steps": args.refstyle_steps,
+                    "what": "same step, same weights and clouds: DCN layers as a `columns` buffer filled by bilinear sampling (F.grid_sample per kernel tap and "
+                            "deformable group) + one GEMM, gradients by autograd (atomics in the sampling op's backward) - the structure of "
+                            "modulated_deform_conv_cuda.cu:19-280; sparse convs per offset gather -> mm -> scatter-add with the host read of indiceNum "
+                            "(spconv_ops.h:260-457), separate BatchNorm1d / ReLU, dense() by scatter + permute; voxeliser, rulebook build and MIOpen layers as in the native step"}
         else:
             if not args.no_roofline:
                 result["roofline"] = roofline_probe(model, voxelize, pool, args, device)

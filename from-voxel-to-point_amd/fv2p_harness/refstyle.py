@@ -20,7 +20,12 @@ its own and with torch ops where it composes them:
 What stays as in the default run, because the reference has the same thing or nothing comparable: the voxeliser (the reference
 voxelises in DataLoader workers on the host, outside the step), the rulebook build (hash tables; the reference's dense-grid build is
 not restated), 3-NN / interpolation / ball query / RoI pooling / point-in-box kernels (same algorithm per call), the dense 2-D
-layers (MIOpen for both).  The figure is therefore a LOWER bound on the reference's step time in its own structure."""
+layers (MIOpen for both).  This is a self-built restatement of the reference's structure, not a run of the reference: the figure
+says what the structure costs on this GPU with this repo's kernels and torch's library ops filling the reference's roles.
+
+MGAF (bench.py --workload mgaf): the same context plus `dcn_im2col_gemm` below in place of the fused DCN kernels — the reference's
+modulated_deform_conv_cuda.cu structure: a `columns` buffer [Cin * kh * kw, B * Ho * Wo] filled by a bilinear im2col, one GEMM on it,
+and a backward pass that scatters grad_input with atomics (autograd of the sampling op)."""
 import contextlib
 import os
 
@@ -36,26 +41,60 @@ from pcdet.ops import _glue as G
 from . import fv2p_model as _model
 
 
+class _GatherMmScatter(torch.autograd.Function):
+    """spconv_ops.h:260-362 (forward) and :364-457 (backward) as ONE autograd node, the way the reference's SparseConvFunction is
+    one node (functional.py:20-77): per kernel offset gather -> mm -> IN-PLACE scatter-add into a preallocated output; the backward
+    pass does the same per offset (input gradient scatter-added in place, weight gradient slice by slice)."""
+
+    @staticmethod
+    def forward(ctx, features, filters, rb, n_out, inverse, subm):
+        kvol = rb.kvol
+        w = filters.reshape(kvol, filters.shape[-2], filters.shape[-1])
+        pairs = rb.indice_pairs                                   # [K, 2, n_in], -1 padded
+        num = rb.indice_pair_num.cpu().tolist()                   # the reference's indiceNum.to(CPU) (:271)
+        src_side, dst_side = (1, 0) if inverse else (0, 1)
+        centre = kvol // 2 if (subm and kvol % 2 == 1) else -1
+        if centre >= 0:
+            out = torch.mm(features, w[centre])                   # :300-303
+        else:
+            out = features.new_zeros((n_out, w.shape[-1]))
+        for k in range(kvol):
+            n = num[k]
+            if n <= 0 or k == centre:
+                continue
+            src = pairs[k, src_side, :n].long()
+            dst = pairs[k, dst_side, :n].long()
+            out.index_add_(0, dst, torch.mm(features.index_select(0, src), w[k]))
+        ctx.save_for_backward(features, filters)
+        ctx.meta = (pairs, num, src_side, dst_side, centre, kvol)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        features, filters = ctx.saved_tensors
+        pairs, num, src_side, dst_side, centre, kvol = ctx.meta
+        grad_out = grad_out.contiguous()
+        w = filters.reshape(kvol, filters.shape[-2], filters.shape[-1])
+        dw = torch.zeros_like(w)
+        if centre >= 0:                                           # :395-401
+            dw[centre] = torch.mm(features.t(), grad_out)
+            din = torch.mm(grad_out, w[centre].t())
+        else:
+            din = torch.zeros_like(features)
+        for k in range(kvol):
+            n = num[k]
+            if n <= 0 or k == centre:
+                continue
+            src = pairs[k, src_side, :n].long()
+            dst = pairs[k, dst_side, :n].long()
+            fin, gout = features.index_select(0, src), grad_out.index_select(0, dst)   # :415-436
+            dw[k] = torch.mm(fin.t(), gout)
+            din.index_add_(0, src, torch.mm(gout, w[k].t()))
+        return din, dw.reshape(filters.shape), None, None, None, None
+
+
 def _gather_mm_scatter(features, filters, rb, n_out, inverse, subm):
-    """spconv_ops.h:260-362 in torch ops (autograd gives the gather / mm / scatter-add backward of :364-457)."""
-    kvol = rb.kvol
-    w = filters.reshape(kvol, filters.shape[-2], filters.shape[-1])
-    pairs = rb.indice_pairs                                   # [K, 2, n_in], -1 padded
-    num = rb.indice_pair_num.cpu().tolist()                   # the reference's indiceNum.to(CPU) (:271)
-    src_side, dst_side = (1, 0) if inverse else (0, 1)
-    centre = kvol // 2 if (subm and kvol % 2 == 1) else -1
-    if centre >= 0:
-        out = torch.mm(features, w[centre])                   # :300-303
-    else:
-        out = features.new_zeros((n_out, w.shape[-1]))
-    for k in range(kvol):
-        n = num[k]
-        if n <= 0 or k == centre:
-            continue
-        src = pairs[k, src_side, :n].long()
-        dst = pairs[k, dst_side, :n].long()
-        out = out.index_add(0, dst, torch.mm(features.index_select(0, src), w[k]))
-    return out
+    return _GatherMmScatter.apply(features, filters, rb, n_out, inverse, subm)
 
 
 def _make_conv(inverse, subm):
@@ -83,6 +122,54 @@ def _fps_plain(saved, xyz, npoint):
     running = G.new(xyz, (b, n), fill=1e10)
     G.run("fv2p_furthest_point_sampling", b, n, npoint, xyz, running, idx, None, 0)
     return idx
+
+
+def dcn_im2col_gemm(input, offset, mask, weight, bias, stride, padding, dilation, groups, deformable_groups, im2col_step):
+    """modulated_deform_conv_cuda.cu:19-125 in library ops: `columns` by bilinear sampling of the whole map once per (kernel tap,
+    deformable group) — F.grid_sample with zero padding and align_corners=True IS mdmcn_im2col_bilinear (corners outside the map
+    contribute nothing, modulated_deform_im2col_cuda.cuh:24-54) — times the modulation mask, then ONE GEMM with the weight viewed
+    [Cout, Cin * kh * kw] (:98-104).  Backward by autograd: GEMMs for the columns' and the weight's gradients (:196-268), grid_sample's
+    backward for grad_input (atomics, as modulated_deform_col2im) and for the offsets (col2im_coord)."""
+    from torch.nn.modules.utils import _pair
+    import torch.nn.functional as F
+    assert groups == 1
+    (sh, sw), (ph, pw), (dh, dw) = _pair(stride), _pair(padding), _pair(dilation)
+    B, C, H, W = input.shape
+    cout, _, kh, kw = weight.shape
+    K, dg = kh * kw, deformable_groups
+    cpg = C // dg
+    Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
+    Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
+    ys = torch.arange(Ho, device=input.device, dtype=torch.float32).view(1, Ho, 1) * sh - ph
+    xs = torch.arange(Wo, device=input.device, dtype=torch.float32).view(1, 1, Wo) * sw - pw
+    off = offset.view(B, dg, K, 2, Ho, Wo)
+    msk = mask.view(B, dg, K, 1, Ho, Wo)
+    cols = []
+    for g in range(dg):
+        xg = input[:, g * cpg:(g + 1) * cpg]
+        for k in range(K):
+            hy = ys + (k // kw) * dh + off[:, g, k, 0]
+            wx = xs + (k % kw) * dw + off[:, g, k, 1]
+            grid = torch.stack((wx * (2.0 / max(W - 1, 1)) - 1.0, hy * (2.0 / max(H - 1, 1)) - 1.0), dim=-1)
+            cols.append(F.grid_sample(xg, grid, mode="bilinear", padding_mode="zeros", align_corners=True) * msk[:, g, k])
+    columns = torch.stack(cols, dim=1).view(B, dg, K, cpg, Ho * Wo).permute(0, 1, 3, 2, 4).reshape(B, C * K, Ho * Wo)   # row = ci * K + k
+    out = torch.matmul(weight.view(1, cout, C * K), columns).view(B, cout, Ho, Wo)
+    return out if bias is None else out + bias.view(1, -1, 1, 1)
+
+
+@contextlib.contextmanager
+def reference_dcn_structure():
+    """ModulatedDeformConvFunction.apply -> dcn_im2col_gemm for the modules of pcdet.ops.DeformableConvolutionV2PyTorch."""
+    from pcdet.ops.DeformableConvolutionV2PyTorch.modules import modulated_deform_conv as _mdc
+
+    class _Shim:
+        apply = staticmethod(dcn_im2col_gemm)
+    saved = _mdc.ModulatedDeformConvFunction
+    try:
+        _mdc.ModulatedDeformConvFunction = _Shim
+        yield
+    finally:
+        _mdc.ModulatedDeformConvFunction = saved
 
 
 @contextlib.contextmanager

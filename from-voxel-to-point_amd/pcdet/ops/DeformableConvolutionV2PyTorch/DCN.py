@@ -29,28 +29,39 @@ def _wt_oc(weight):
     return weight.permute(2, 3, 0, 1).reshape(kh * kw, cout, cin).contiguous()
 
 
+def _forward_nhwc(x, weight, bias, offset, mask, g):
+    """x NHWC contiguous fp32 -> y [B*Ho*Wo, Cout] (the C-ABI call)."""
+    B, H, W, C, Cout, Ho, Wo = g[:7]
+    y = torch.empty((B * Ho * Wo, Cout), dtype=torch.float32, device=x.device)
+    with _nat.device_guard(x.device):
+        _nat.call("fv2p_dcn_forward", x, _wt_oc(weight.float()), bias.float().contiguous() if bias is not None else None,
+                  offset.float().contiguous(), mask.float().contiguous(), *g, y, _nat.stream())
+    return y
+
+
 def modulated_deform_conv_forward(input, weight, bias, offset, mask, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w,
-                                  dilation_h, dilation_w, group, deformable_group, im2col_step):
+                                  dilation_h, dilation_w, group, deformable_group, im2col_step, _keep=None):
     """-> output [B, Cout, Ho, Wo] (contiguous NCHW, as modulated_deform_conv_cuda.cu:118). im2col_step is accepted and
-    irrelevant: there is no columns buffer to chunk."""
+    irrelevant: there is no columns buffer to chunk.  `_keep` (a list, not part of the reference signature) receives the NHWC
+    copy of the input so that the autograd Function can hand it to the backward call instead of permuting again."""
     g = _geom(input, weight, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, group, deformable_group)
     B, H, W, C, Cout, Ho, Wo = g[:7]
     x = input.float().permute(0, 2, 3, 1).contiguous()
-    y = torch.empty((B * Ho * Wo, Cout), dtype=torch.float32, device=input.device)
-    with _nat.device_guard(input.device):
-        _nat.call("fv2p_dcn_forward", x, _wt_oc(weight.float()), bias.float().contiguous() if bias is not None else None,
-                  offset.float().contiguous(), mask.float().contiguous(), *g, y, _nat.stream())
+    if _keep is not None:
+        _keep.append(x)
+    y = _forward_nhwc(x, weight, bias, offset, mask, g)
     return y.view(B, Ho, Wo, Cout).permute(0, 3, 1, 2).contiguous().to(input.dtype)
 
 
 def modulated_deform_conv_backward(input, weight, bias, offset, mask, grad_output, kernel_h, kernel_w, stride_h, stride_w, pad_h,
-                                   pad_w, dilation_h, dilation_w, group, deformable_group, im2col_step):
+                                   pad_w, dilation_h, dilation_w, group, deformable_group, im2col_step, _x_nhwc=None):
     """-> [grad_input, grad_offset, grad_mask, grad_weight, grad_bias] (modulated_deform_conv_cuda.cu:127-280).
-    No float atomics anywhere: the five gradients are bit-identical from run to run (include/fv2p_ops.h, A13)."""
+    No float atomics anywhere: the five gradients are bit-identical from run to run (include/fv2p_ops.h, A13).
+    `_x_nhwc`: the forward's NHWC copy of `input` (see modulated_deform_conv_forward), optional."""
     g = _geom(input, weight, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, group, deformable_group)
     B, H, W, C, Cout, Ho, Wo = g[:7]
     dev = input.device
-    x = input.float().permute(0, 2, 3, 1).contiguous()
+    x = _x_nhwc if _x_nhwc is not None else input.float().permute(0, 2, 3, 1).contiguous()
     dy = grad_output.float().permute(0, 2, 3, 1).contiguous().view(B * Ho * Wo, Cout)
     wt = _wt(weight.float())
     pad = (-Cout) % 4            # the kernels read output channels four at a time: pad with zero columns

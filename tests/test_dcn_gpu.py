@@ -166,3 +166,32 @@ def test_backward_is_bit_identical_run_to_run(gpu, cin, cout, dg, hw, scale):
     if scale > 0:      # at integer positions the one-sided derivative w.r.t. the offset is implementation-defined (test above)
         assert rel(runs[0][1], co.grad) < 1e-4
     assert rel(runs[0][2], cm.grad) < 1e-4
+
+
+@pytest.mark.parametrize("cin,cout,dg", [(64, 64, 4), (32, 48, 1)])
+def test_reference_structure_baseline_is_the_same_op(gpu, cin, cout, dg):
+    """fv2p_harness/refstyle.py:dcn_im2col_gemm - the `columns` + GEMM restatement bench.py --workload mgaf times as `baseline` -
+    computes the same layer as the fused kernels (forward and all gradients; 1e-3: its sampling positions pass through
+    grid_sample's normalised coordinates)."""
+    from fv2p_harness import refstyle
+    torch.manual_seed(5)
+    B, H, W = 2, 20, 24
+    x = torch.randn(B, cin, H, W, device=gpu)
+    offset = torch.randn(B, dg * 18, H, W, device=gpu) * 1.5
+    offset = torch.where((offset - offset.round()).abs() < 1e-2, offset + 3e-2, offset)   # keep off the kinks of the bilinear kernel
+    mask = torch.sigmoid(torch.randn(B, dg * 9, H, W, device=gpu))
+    m = ModulatedDeformConv(cin, cout, 3, stride=1, padding=1, deformable_groups=dg, bias=True).to(gpu)
+    g = torch.randn(B, cout, H, W, device=gpu)
+    res = []
+    for structure in (False, True):
+        gx, go, gm = (t.clone().requires_grad_(True) for t in (x, offset, mask))
+        m.zero_grad()
+        if structure:
+            with refstyle.reference_dcn_structure():
+                y = m(gx, go, gm)
+        else:
+            y = m(gx, go, gm)
+        y.backward(g)
+        res.append([y.detach(), gx.grad, go.grad, gm.grad, m.weight.grad.clone(), m.bias.grad.clone()])
+    for a, b in zip(*res):
+        assert rel(b, a) < 1e-3
