@@ -221,9 +221,12 @@ def decode_rot_binres(reg, bins):
     return ry.view(-1, 1)
 
 
-def center_losses(preds, tg, cfg):
+def center_losses(preds, tg, cfg, peaks=None):
     """CenterAFHeadTemplate.get_loss (center_af_head_template.py:193-460) on the seven head maps `preds` and the targets `tg`
-    -> (total, dict of the eight weighted terms).  Tensor ops only; the one op of this repo it reaches is boxes_iou3d_gpu."""
+    -> (total, dict of the eight weighted terms).  Tensor ops only; the one op of this repo it reaches is boxes_iou3d_gpu.
+    `peaks` [B, K] (parity tests): heat-map cells to score in the IoU-score term instead of this run's own top K, so that two float
+    implementations are compared on the same cells (two near-equal peaks may swap between them); the term records its cells in
+    out["_iou_peaks"]."""
     w = cfg.loss_weights
     b = preds["hm"].shape[0]
     mask, ind = tg["mask_target"].bool(), tg["ind_target"]
@@ -287,7 +290,7 @@ def center_losses(preds, tg, cfg):
         nc, sy, sx = heat.shape[1:]
         top_s, top_i = torch.topk(heat.view(b, nc, -1), kq)                                     # center_utils._topk
         top_s2, top_j = torch.topk(top_s.view(b, -1), kq)
-        inds = top_i.view(b, -1).gather(1, top_j)
+        inds = top_i.view(b, -1).gather(1, top_j) if peaks is None else peaks
         pxs, pys = (inds % sx).float().unsqueeze(-1), torch.div(inds, sx, rounding_mode="floor").float().unsqueeze(-1)
         offq = gather_map(preds["offset"].detach(), inds)
         bxs = (pxs + offq[:, :, 0:1]) * cfg.feature_map_stride * cfg.voxel_size[0] + cfg.point_cloud_range[0]
@@ -314,7 +317,9 @@ def center_losses(preds, tg, cfg):
     score = gather_map(preds["iouscore"], inds).reshape(-1)
     bce = F.binary_cross_entropy(torch.sigmoid(score), label, reduction="none")
     out["iouscore"] = w["iouscore"] * bce.sum() / max(bce.numel(), 1)
-    return sum(out.values()), out
+    total = sum(out.values())
+    out["_iou_peaks"] = inds
+    return total, out
 
 
 class MGAFDetector(nn.Module):

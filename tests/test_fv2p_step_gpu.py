@@ -30,16 +30,18 @@ class SmallFV2P(FV2PConfig):
 
 
 GRAD_TOL = 2e-3     # relative L2 per parameter gradient, GPU kernels against the host run
-# ... except along the DEEP END of the backward chain.  The gradients of the sparse backbone and of the voxel-to-point decoder have
-# passed through every later layer's backward and 20 - 40 train-mode BatchNorms, each subtracting two means; measured: the host run
-# (torch CPU) and the reference-structure run (torch GPU ops, test_reference_call_structure_is_the_same_step) agree with each other
-# better than either agrees with the HIP path — 3e-3 ... 1.5e-2 there, growing with depth (decoder out 2e-3 -> decoder in 6e-3 ->
-# backbone 5e-3 ... 1e-2) — i.e. the fused kernels round differently, they do not compute something else:
-# tests/test_backbone_gpu.py::test_first_layer_gradient_noise_floor_against_float64 holds the HIP path to within 3x of torch
-# float32's own distance from a float64 run of the backbone for every parameter.  Everywhere else (dense BEV layers, heads, RoI
-# head: ~200 parameters) 2e-3 holds, and a backward kernel wrong by 5e-3 fails its own op-level test at 1e-4.
+# ... except along the DEEP END of the backward chain: the gradients of the sparse backbone and of the voxel-to-point decoder have
+# passed through every later layer's backward and 20 - 40 train-mode BatchNorms.  Measured per module group (printed by the test):
+# decoder 3.6e-3, backbone conv_input 1e-3 -> conv1 1.2e-3 -> conv2 2.4e-3 -> conv3 3.6e-3 -> conv4 4.7e-3 (worst: conv4.2.bn1.bias,
+# a sum with heavy cancellation), everything else <= 5e-4.  Both sides are float32 with independent rounding; against a FLOAT64 run of
+# the backbone (tools/f64_gap.py, profiles/r04_f64_gap.txt) the HIP path sits at a median of 1.3 x torch float32's own distance
+# (worst parameter 2.2e-3 for both), and none of the fused pieces moves that figure - K-split partial sums, tiling plan, epilogue
+# statistics, pair-split weight gradients, deferred weight gradients were each switched off in turn; WITHOUT the fused BatchNorm
+# (float64 statistics) the median ratio is 5.2.  The one effect found was the length of the fused multiply-add chain (27 offsets x
+# channels in one chain: forward 1.18e-6 from float64, per-offset products added afterwards as the reference does: 1.00e-6; torch 7.2e-7).
+# Round 3 allowed 2e-2 here.
 DEEP_END = ("backbone_3d.", "post_pfe.")
-DEEP_END_TOL = 2e-2
+DEEP_END_TOL = 6e-3
 
 
 def grad_tol(name):
@@ -116,7 +118,7 @@ def test_fv2p_step_matches_cpu_oracle(gpu, cpu_run):
     # EVERY parameter the first-stage + point losses reach, relative L2 (the host run of this very Python is held to the reference's
     # own detector within 3e-3 per parameter, tests/test_reference_overlay.py): 2e-3, not six hand-picked names at 1e-2
     gp = dict(net.named_parameters())
-    worst, bad = ("", 0.0), []
+    worst, bad, by_group = ("", 0.0), [], {}
     for name, want in stage1.items():
         a, b = gp[name].grad.cpu().double(), want.double()
         if zero_gradient(name):
@@ -126,9 +128,12 @@ def test_fv2p_step_matches_cpu_oracle(gpu, cpu_run):
             continue
         err = float((a - b).norm() / b.norm())
         worst = max(worst, (name, err), key=lambda t: t[1])
+        grp = ".".join(name.split(".")[:2])
+        by_group[grp] = max(by_group.get(grp, 0.0), err)
         if err >= grad_tol(name):
             bad.append((name, f"{err:.2e}"))
     print(f"worst first-stage gradient: {worst[0]} {worst[1]:.2e}")
+    print("largest gradient error per module group:", {k: f"{v:.1e}" for k, v in by_group.items()})
     assert not bad, " ".join(f"{n}={e}" for n, e in bad)
     g["loss_rcnn"].backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())

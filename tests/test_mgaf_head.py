@@ -67,6 +67,8 @@ def check_losses(dev, tol_loss, tol_grad):
     tg["segm_target"] = torch.from_numpy(fix["segm_target"]).to(dev)
     loss, terms = mm.center_losses(preds, tg, cfg)
     for n, v in terms.items():
+        if n.startswith("_"):      # bookkeeping of the term (the scored heat-map cells), not a loss
+            continue
         want = float(fix["term_" + n])
         assert abs(float(v.detach()) - want) <= tol_loss * max(1.0, abs(want)), (n, float(v.detach()), want)
     assert abs(float(loss.detach()) - float(fix["loss"])) <= tol_loss * abs(float(fix["loss"]))
@@ -118,8 +120,10 @@ def small_inputs():
 @pytest.mark.gpu
 def test_mgaf_step_matches_cpu_oracle(gpu):
     """MGAFDetector (VoxelResBackBone8x, DCNBEVBackbone, CenterAFHead with the DCNv2 feature adaption, target assignment, eight
-    loss terms) forward + backward on the HIP ops against the same modules on the host: head maps 1e-4 (1e-3 through the 21-layer
-    sparse backbone and BatchNorm), loss terms 1e-3, every parameter gradient 2e-3 relative L2."""
+    loss terms) forward + backward on the HIP ops against the same modules on the host: target maps bit-exact, head maps 1e-3
+    (through the 21-layer sparse backbone, the DCN BEV backbone and their BatchNorms), all eight loss terms 1e-3 (the IoU-score term on
+    the host run's peak cells when the two runs' top-24 sets differ), every parameter gradient by relative L2 with the per-group bounds
+    stated where they are applied: 3e-3 heads, 6e-3 feature adaption, 2e-2 upstream of it, 3e-2 third BEV level."""
     from oracle.spconv_cpu import cpu_mirror
     torch.manual_seed(0)
     model = mm.MGAFDetector(SmallMGAF)
@@ -139,14 +143,23 @@ def test_mgaf_step_matches_cpu_oracle(gpu):
     for name, want in ref.taps["preds"].items():
         got = net.taps["preds"][name].detach().cpu()
         assert float((got - want.detach()).abs().max()) <= 1e-3 * float(want.detach().abs().max()), name
+    peaks_c, peaks_g = ref.taps["terms"]["_iou_peaks"], net.taps["terms"]["_iou_peaks"].cpu()
     for name, want in ref.taps["terms"].items():
+        if name.startswith("_"):
+            continue
         got, want = float(net.taps["terms"][name].detach()), float(want.detach())
-        # the IoU-score term labels the 24 highest heat-map peaks per sample: two peaks within float32 noise of each other may swap
-        # between the runs, and one other box among 48 moves the mean by up to ~2e-2 (pinned exactly in check_losses on fixed maps)
-        tol = 5e-2 if name == "iouscore" else 1e-3 * max(1.0, abs(want))
-        assert abs(got - want) <= tol, (name, got, want)
+        if name == "iouscore" and not torch.equal(peaks_c, peaks_g):
+            # The IoU-score term scores the 24 highest heat-map peaks per sample; two peaks within float32 noise of each other may swap
+            # between the runs.  Tie-robust form: the HIP run's term re-evaluated on the HOST run's cells (same 1e-3 as every other
+            # term), and the two runs must agree on all but a few cells.
+            same = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(peaks_c, peaks_g))
+            assert same >= peaks_c.numel() - 4, (same, peaks_c.numel())
+            with torch.no_grad():
+                got = float(mm.center_losses({k: v.detach() for k, v in net.taps["preds"].items()}, net.taps["targets"], SmallMGAF,
+                                             peaks=peaks_c.to(gpu))[1]["iouscore"])
+        assert abs(got - want) <= 1e-3 * max(1.0, abs(want)), (name, got, want)
     gp = dict(net.named_parameters())
-    worst, bad = ("", 0.0), []
+    worst, bad, by_group = ("", 0.0), [], {}
     for name, p in ref.named_parameters():
         if not p.requires_grad:          # the DCN layers' frozen bias (modules/modulated_deform_conv.py:38-41: added, never trained)
             continue
@@ -156,14 +169,25 @@ def test_mgaf_step_matches_cpu_oracle(gpu):
         a, b = gp[name].grad.cpu().double(), p.grad.double()
         err = float((a - b).norm() / b.norm().clamp_min(1e-12))
         worst = max(worst, (name, err), key=lambda t: t[1])
-        # tests/test_fv2p_step_gpu.py: DEEP_END — here the chain under the sparse backbone is the whole DCN BEV backbone + head
-        # (its third level — plain torch convolutions on both sides, MIOpen here and oneDNN on the host — already separates by 2e-2);
-        # the offset predictors' gradients come through the bilinear taps' kinks, where float32 and the oracle's float64 pick sides
-        # 3e-3 for the seven heads; everything upstream of the head's deformable feature adaption (its own weight, the shared conv, both
-        # backbones) has crossed the DCN backward — float32 tap atomics here, float64 autograd in the oracle — and the BatchNorm chain
-        # (the heads sit at 1.0e-3 ... 2.0e-3 from run to run — float atomics in the DCN data gradient upstream of them — hence 3e-3)
-        tol = 6e-2 if "conv_offset_mask" in name else 3e-3 if name.startswith("dense_head.heads.") else 3e-2
+        grp = ".".join(name.split(".")[:3 if name.startswith(("backbone_2d", "dense_head")) else 2])
+        by_group[grp] = max(by_group.get(grp, 0.0), err)
+        # Measured per module group (HIP against the host run, printed below): the seven heads <= 1.9e-3, the head's deformable feature
+        # adaption 3.1e-3, its offset / mask predictor 1.2e-2 (gradients through the bilinear kernel's kinks, where float32 and the
+        # oracle's float64 pick sides), shared conv + first two BEV levels + sparse backbone 0.9 ... 1.6e-2 (everything that has crossed
+        # the DCN backward and a chain of train-mode BatchNorms: two float32 implementations, tests/test_fv2p_step_gpu.py DEEP_END),
+        # third BEV level 2.1e-2 - plain torch convolutions on BOTH sides there, MIOpen on the GPU and oneDNN on the host.
+        # Round 3 allowed 6e-2 / 3e-3 / 3e-2 (float atomics in the DCN data gradient moved the heads by 1 ... 2e-3 from run to run;
+        # the backward is bit-reproducible now).
+        if name.startswith("dense_head.heads."):
+            tol = 3e-3
+        elif name.startswith("dense_head.feature_adapt.conv_adaption"):
+            tol = 6e-3
+        elif name.startswith(("backbone_2d.blocks.2", "backbone_2d.deblocks.2")):
+            tol = 3e-2
+        else:
+            tol = 2e-2
         if err >= tol:
             bad.append((name, f"{err:.2e}"))
     print("worst MGAF gradient:", worst)
+    print("largest gradient error per module group:", {k: f"{v:.1e}" for k, v in by_group.items()})
     assert not bad, " ".join(f"{n}={e}" for n, e in bad)
