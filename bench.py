@@ -63,10 +63,6 @@ def parse():
     ap.add_argument("--fps-ahead", type=int, default=1, help="FV2P workloads: key points of batch t+1 are sampled (FPS side stream) during the backward pass of step t")
     ap.add_argument("--ahead-at", default="mid", choices=["start", "mid"], help="where a step enqueues the preparation / sampling of the next batch: before its forward pass (measured 40.8 vs 33.0 ms per step) or between forward and backward")
     ap.add_argument("--ahead-stream", default="fps", choices=["fps", "own"], help="--ahead: prepare the next batch on the key-point sampling stream (in front of that batch's sampler) or on a stream of its own")
-    ap.add_argument("--dense-wgrad", type=int, default=0, help="FV2P workloads: the weight gradients of the dense 2-D convs (BEV backbone, heads) run on the weight-gradient "
-                    "side stream beside their data gradients (fv2p_harness/dense_wgrad.py).  Off: measured 31.7 against 32.2 - 32.3 ms per step in one run and "
-                    "41.0 in the next — MIOpen's data- and weight-gradient kernels each fill the chip, so there is little to overlap, and a second busy "
-                    "side stream sometimes lands in the training stream's hardware queue")
     ap.add_argument("--ahead-thread", type=int, default=-1, help="--ahead / --fps-ahead: the preparation of the next batch (its host waits for the voxel counts and rulebook sizes: "
                     "4.7 ms of the stepping thread per step when called in line) runs on a helper thread, joined at the top of the next step.  Default: on for "
                     "fv2p-waymo (measured 35.8 -> 33.2 ms per step), off for fv2p (32.4 - 32.5 against 32.8 ms, and one 41 ms run)")
@@ -152,7 +148,7 @@ class Later(object):
             raise e
 
 
-SAFE_FLAGS = ["--fps-ahead", "0", "--ahead", "0", "--prefetch", "0", "--dense-stream", "0", "--dense-wgrad", "0"]   # every side-stream input pipeline off: the plain in-line step
+SAFE_FLAGS = ["--fps-ahead", "0", "--ahead", "0", "--prefetch", "0", "--dense-stream", "0"]   # every side-stream input pipeline off: the plain in-line step
 
 
 def beat(phase):
@@ -413,7 +409,7 @@ def build_fv2p_step(args, device, rank, world):
     cfg = FV2PWaymoConfig if waymo else FV2PConfig
     if not args.point_stream:
         cfg = type("Cfg", (cfg,), {"point_branch_stream": False})
-    cfg = type("Cfg", (cfg,), {"dense_branch_stream": bool(args.dense_stream), "dense_wgrad_stream": bool(args.dense_wgrad)})
+    cfg = type("Cfg", (cfg,), {"dense_branch_stream": bool(args.dense_stream)})
     vsize, prange = np.array(cfg.voxel_size, np.float32), np.array(cfg.point_cloud_range, np.float32)
     torch.manual_seed(0)
     model = FV2PDetector(cfg).to(device)
@@ -468,7 +464,7 @@ def build_fv2p_step(args, device, rank, world):
     # run both branches on the calling stream, the rest the arrangement asked for.  (Not the point-branch stream for those two steps:
     # a process that has used both side streams runs the dense-branch arrangement at 55 instead of 34 ms per step — a fifth active
     # stream on four hardware queues.)
-    cfg_safe = type("Cfg", (cfg,), {"dense_branch_stream": False, "point_branch_stream": False, "dense_wgrad_stream": False}) if args.dense_stream else cfg
+    cfg_safe = type("Cfg", (cfg,), {"dense_branch_stream": False, "point_branch_stream": False}) if args.dense_stream else cfg
     safe_first = 0 if os.environ.get("FV2P_BENCH_SAFE_FIRST") == "0" else 2
 
     later = Later()
@@ -752,6 +748,7 @@ def cpu_baseline_fv2p(model, args):
     # B2: rotated BEV IoU matrix, 512 x 512 (iou3d_cpu.cpp:232-252)
     b512 = synth.proposal_boxes(3, 512)
     iou512, _ = median_time(lambda: oracle.boxes_bev(b512, b512, "iou"), 20, warm=2, budget_s=5.0)
+    iou512_mt, _ = median_time(lambda: oracle.boxes_bev(b512, b512, "iou", threads=cores), 20, warm=2, budget_s=3.0)   # OpenMP over rows, all cores
     # B3: greedy NMS over the rotated-IoU matrix (iou3d_nms.cpp:121-135 + iou3d_cpu.cpp), score-sorted input.  Proposal-like
     # (tight clusters: most boxes are suppressed early) and the all-survivor worst case of the greedy loop
     order = lambda n: -np.arange(n, dtype=np.float32)
@@ -764,6 +761,10 @@ def cpu_baseline_fv2p(model, args):
     b4096 = synth.proposal_boxes(2, 4096, tight=True)
     kept4096 = oracle.nms(b4096, order(4096), 0.1)
     nms4096, _ = median_time(lambda: oracle.nms(b4096, order(4096), 0.1), 3, budget_s=10.0)
+    # all cores: the reference's two phases, the pair mask by OpenMP rows (every pair j > i, as the GPU kernel), then the serial greedy pass
+    assert np.array_equal(oracle.nms(near, order(9000), cfg.nms_thresh, threads=cores), kept_near)
+    nms_near_mt, _ = median_time(lambda: oracle.nms(near, order(9000), cfg.nms_thresh, threads=cores), 3, budget_s=8.0)
+    nms4096_mt, _ = median_time(lambda: oracle.nms(b4096, order(4096), 0.1, threads=cores), 3, budget_s=4.0)
     # B4: BASELINE configs[1] on the host: VoxelBackBone8x forward at batch 4, per-offset gather / mm / scatter (torch CPU, all threads)
     torch.set_num_threads(cores)
     torch.manual_seed(0)
@@ -778,11 +779,15 @@ def cpu_baseline_fv2p(model, args):
         b4, _ = median_time(lambda: bb(feats, coords, 4), 5, warm=1, budget_s=25.0)
     extras = {"B1_voxelize_16384pts_ms": round(vox * 1e3, 2),
               "B2_bev_iou_512x512_ms": round(iou512 * 1e3, 2), "B2_pairs_per_s": round(512 * 512 / iou512),
+              "B2_all_cores_ms": round(iou512_mt * 1e3, 2), "B2_all_cores_pairs_per_s": round(512 * 512 / iou512_mt), "B2_B3_all_cores_threads": cores,
+              "B3_nms_9000_thr0.8_all_cores_ms": round(nms_near_mt * 1e3, 1), "B3_nms_9000_all_cores_boxes_per_s": round(9000 / nms_near_mt),
+              "B3_nms_4096_thr0.1_all_cores_ms": round(nms4096_mt * 1e3, 1),
               "B3_nms_9000_thr0.8_proposal_like_ms": round(nms_near * 1e3, 1), "B3_survivors_proposal_like": int(len(kept_near)),
               "B3_nms_9000_thr0.8_all_survivors_ms": round(nms_far * 1e3, 1), "B3_survivors_worst_case": int(len(kept_far)),
               "B3_nms_4096_thr0.1_ms": round(nms4096 * 1e3, 1), "B3_survivors_4096": int(len(kept4096)),
               "B4_backbone8x_fwd_batch4_clouds_per_s": round(4 / b4, 3), "B4_threads": cores,
-              "threads": 1, "protocol": "warm-ups then median (BASELINE.md 2); B1-B3 single thread, B4 torch CPU"}
+              "threads": 1, "protocol": "warm-ups then median (BASELINE.md 2); B1-B3 single thread unless marked all_cores (OpenMP over the rows of the "
+                                            "pair matrix; the all-cores NMS evaluates every pair j > i like the GPU kernel, the single-thread one only the pairs the greedy pass reaches), B4 torch CPU"}
     return {"value": round(1.0 / dt, 4), "unit": "point clouds/s", "cores": cores, "kind": "port", "cpu": cpu_model_string(),
             "step_samples_s": [round(t, 2) for t in step_samples], "single_op_baselines": extras,
             "sample": f"median of {len(step_samples)} FV2P train steps (forward + backward, no optimiser) at batch 1 on one synthetic {args.points}-point cloud after one "
@@ -918,7 +923,7 @@ def dcn_roofline_probe(model, voxelize, pool, gts, args, device):
         dy = torch.randn(g[0], g[4], g[5], g[6], device=device)
 
         def bwd():
-            DCN.modulated_deform_conv_backward(rec["x"], w, bias, off, msk, dy, *geom, _x_nhwc=x_nhwc)
+            DCN.modulated_deform_conv_backward(rec["x"], w, bias, off, msk, dy, *geom)
         times = []
         for fn, reps in ((fwd, 20), (bwd, 10)):
             for _ in range(3):

@@ -1099,8 +1099,11 @@ __global__ void nn_setup_k(int B, const int* __restrict__ bbox, const int* __res
   const int m = max(known_cnt[bs], 1);
   float h = cell > 0.f ? cell : 1.5f * sqrtf(fmaxf(ext[0] * ext[1], 1e-6f) / m);   // no hint: ~2 points per cell of a surface-like cloud
   h = fmaxf(h, 1e-4f);
-  for (int it = 0; it < 64; ++it) {   // at most 2^18 cells along an axis (the cell number must fit 54 bits beside the sample)
-    if (fmaxf(fmaxf(ext[0], ext[1]), ext[2]) / h < 262143.f) break;
+  // At most 4096 cells along an axis: the cell coordinate floor((v - lo) * inv_h) carries a rounding error of ~2e-7 x its value, and the
+  // searches stop on "(R - 1e-3) cells away" - the margin covers coordinates up to ~4000 (a tiny caller hint on a large extent would
+  // otherwise let a query stop with a nearer point just outside its block).  Larger cells only cost time, never exactness.
+  for (int it = 0; it < 64; ++it) {
+    if (fmaxf(fmaxf(ext[0], ext[1]), ext[2]) / h < 4095.f) break;
     h *= 2.f;
   }
   g.h = h; g.inv_h = 1.f / h;

@@ -1732,7 +1732,7 @@ static void launch_vec(const ConvArgs& a, hipStream_t s) {
     const bool whole = a.c_src == CINP && a.c_dst == NB * 16 && (a.w_ld & 3) == 0 && (a.w_kstride & 3) == 0 &&
                        (reinterpret_cast<uintptr_t>(a.w) & 15) == 0 && (a.ld_dst & 3) == 0 &&
                        (reinterpret_cast<uintptr_t>(a.dst) & 15) == 0 && (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0);
-    if (whole && a.kvol <= 32 && ksplit_wanted<CINP>(a)) {
+    if (whole && a.kvol <= 27 && ksplit_wanted<CINP>(a)) {   // 27: a wave's step list holds 27 * MAXG + 1 entries (112 bytes, conv_rows_ksplit)
       ConvArgs b = a; b.trace = g_conv_trace;
       const int level = a.plan ? plan_pick_level(a.n_dst, NB / 4) : -1;   // a.plan: the plan header behind the table
       b.plan = level >= 0 ? a.plan + plan_level_offset(level) : nullptr;

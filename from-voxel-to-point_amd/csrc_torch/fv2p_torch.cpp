@@ -613,68 +613,6 @@ std::vector<std::vector<at::Tensor>> build_rulebook_chain(const at::Tensor& root
   return out;
 }
 
-// ---- dense convolution (Conv2d / ConvTranspose2d of the BEV backbone and the heads) with its weight gradient beside its data gradient ----
-// torch's convolution_backward computes dX and dW one after the other on the calling stream; on the dense branch of a detector's
-// backward pass that chain is what every other stream waits for.  Here dX is computed on the calling stream and dW — for a
-// weight that went through gate_weights() — on the side stream the sparse convs' weight gradients use, joined once by the gate at the
-// end of the branch's backward.  The kernels are MIOpen's either way (at::convolution / at::convolution_backward); only their order in
-// time changes.  Without a gated weight this is torch's conv with torch's backward.
-struct DenseConvFn : public torch::autograd::Function<DenseConvFn> {
-  static at::Tensor forward(AutogradContext* ctx, const at::Tensor& x, const at::Tensor& w, const c10::optional<at::Tensor>& bias,
-                            std::vector<int64_t> stride, std::vector<int64_t> padding, std::vector<int64_t> dilation, bool transposed,
-                            std::vector<int64_t> output_padding, int64_t groups) {
-    at::Tensor out = at::convolution(x, w, bias, stride, padding, dilation, transposed, output_padding, groups);
-    ctx->save_for_backward({x, w});
-    ctx->saved_data["stride"] = stride;
-    ctx->saved_data["padding"] = padding;
-    ctx->saved_data["dilation"] = dilation;
-    ctx->saved_data["transposed"] = transposed;
-    ctx->saved_data["output_padding"] = output_padding;
-    ctx->saved_data["groups"] = groups;
-    ctx->saved_data["bias"] = bias.has_value() && bias->defined() ? bias->size(0) : static_cast<int64_t>(-1);
-    ctx->saved_data["gated"] = is_gated(w);
-    return out;
-  }
-  static variable_list backward(AutogradContext* ctx, variable_list grads) {
-    const auto saved = ctx->get_saved_variables();
-    const at::Tensor &x = saved[0], &w = saved[1];
-    const at::Tensor gy = grads[0];
-    const std::vector<int64_t> stride = ctx->saved_data["stride"].toIntVector(), padding = ctx->saved_data["padding"].toIntVector(),
-                               dilation = ctx->saved_data["dilation"].toIntVector(), output_padding = ctx->saved_data["output_padding"].toIntVector();
-    const bool transposed = ctx->saved_data["transposed"].toBool();
-    const int64_t groups = ctx->saved_data["groups"].toInt(), nbias = ctx->saved_data["bias"].toInt();
-    const std::vector<int64_t> bias_sizes{nbias};
-    const at::OptionalIntArrayRef bs = nbias >= 0 ? at::OptionalIntArrayRef(bias_sizes) : at::OptionalIntArrayRef();
-    const bool nx = ctx->needs_input_grad(0), nw = ctx->needs_input_grad(1), nb = nbias >= 0 && ctx->needs_input_grad(2);
-    const bool defer = nw && x.is_cuda() && ctx->saved_data["gated"].toBool() && wgrad_overlap();
-    c10::DeviceGuard guard(x.device());
-    at::Tensor gx, gw, gb;
-    if (nx || (nw && !defer) || nb)
-      std::tie(gx, gw, gb) = at::convolution_backward(gy, x, w, bs, stride, padding, dilation, transposed, output_padding, groups, {nx, nw && !defer, nb});
-    if (defer) {
-      const int dev = x.device().index();
-      const c10::hip::HIPStream cur = c10::hip::getCurrentHIPStream(static_cast<c10::DeviceIndex>(dev));
-      SideStream& side = side_stream(dev);
-      TORCH_CHECK(hipEventRecord(side.fork, cur.stream()) == hipSuccess, "hipEventRecord failed");
-      TORCH_CHECK(hipStreamWaitEvent(side.stream.stream(), side.fork, 0) == hipSuccess, "hipStreamWaitEvent failed");
-      {
-        c10::hip::HIPStreamGuard sg(side.stream);   // result and workspace come from the side stream's pool
-        gw = std::get<1>(at::convolution_backward(gy, x, w, at::OptionalIntArrayRef(), stride, padding, dilation, transposed, output_padding, groups,
-                                                  {false, true, false}));
-      }
-      c10::hip::HIPCachingAllocator::recordStream(gw.storage().data_ptr(), cur);   // consumed (AccumulateGrad, optimiser) on the training stream after the gate's join
-      std::lock_guard<std::mutex> lock(g_pending_mu);
-      auto& parked = g_pending[dev];
-      for (const at::Tensor& t : {gy, x, w, gw}) parked.push_back(t);
-    }
-    return {gx, gw, gb, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
-  }
-};
-at::Tensor dense_conv(const at::Tensor& x, const at::Tensor& w, const c10::optional<at::Tensor>& bias, std::vector<int64_t> stride,
-                      std::vector<int64_t> padding, std::vector<int64_t> dilation, bool transposed, std::vector<int64_t> output_padding, int64_t groups) {
-  return DenseConvFn::apply(x, w, bias, stride, padding, dilation, transposed, output_padding, groups);
-}
-
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -683,7 +621,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("set_bn_epilogue", &set_bn_epilogue, "BatchNorm sums from the conv epilogues (default) or from BatchNorm's own reduce pass");
   m.def("gate_weights", &gate_weights, "aliases of the conv weights whose gradients are joined from the side stream at the end of backward");
   m.def("sparse_conv", &sparse_conv, "fused sparse convolution with autograd (tables from a Rulebook)");
-  m.def("dense_conv", &dense_conv, "at::convolution whose weight gradient (for a gated weight) runs on the weight-gradient side stream");
   m.def("batch_norm_relu", &batch_norm_relu, "BatchNorm1d (+ReLU) on [N, C] with autograd");
   m.def("voxelize_batch_mean", &voxelize_batch_mean, py::arg("clouds"), py::arg("voxel_size"), py::arg("range_lo"), py::arg("grid"),
         py::arg("max_points"), py::arg("max_voxels"), py::arg("cloud_streams") = true, py::call_guard<py::gil_scoped_release>(),

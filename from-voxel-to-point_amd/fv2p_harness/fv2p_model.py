@@ -84,7 +84,6 @@ class FV2PConfig:
     # 38.4 ms per step).  Off by default: it hung the device queue in every run on two boxes of twelve; bench.py switches
     # it on under its supervisor, which falls back to this default when the measurement stalls
     dense_branch_stream = False
-    dense_wgrad_stream = False   # weight gradients of the dense 2-D convs on the weight-gradient side stream (fv2p_harness/dense_wgrad.py)
 
 
 class FV2PWaymoConfig(FV2PConfig):
@@ -963,9 +962,6 @@ class FV2PDetector(nn.Module):
         return loss_rpn + loss_point + loss_rcnn
 
     def dense_branch(self, out, b, gt_boxes):
-        if out.features.is_cuda:
-            from . import dense_wgrad
-            dense_wgrad.gate((self.backbone_2d, self.dense_head), on=bool(getattr(self.cfg, "dense_wgrad_stream", False)))
         dense = out.dense()                                                      # HeightCompression (height_compression.py:10-26)
         spatial = dense.view(b, dense.shape[1] * dense.shape[2], dense.shape[3], dense.shape[4])
         if getattr(self, "bev_channels_last", False):

@@ -205,4 +205,4 @@ def reference_call_structure():
 
 def inline_config(cfg):
     """cfg with every stream arrangement off: one stream, key points sampled where the decoder asks for them."""
-    return type("Cfg", (cfg,), {"dense_branch_stream": False, "point_branch_stream": False, "key_stream": False, "dense_wgrad_stream": False})
+    return type("Cfg", (cfg,), {"dense_branch_stream": False, "point_branch_stream": False, "key_stream": False})

@@ -40,28 +40,24 @@ def _forward_nhwc(x, weight, bias, offset, mask, g):
 
 
 def modulated_deform_conv_forward(input, weight, bias, offset, mask, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w,
-                                  dilation_h, dilation_w, group, deformable_group, im2col_step, _keep=None):
+                                  dilation_h, dilation_w, group, deformable_group, im2col_step):
     """-> output [B, Cout, Ho, Wo] (contiguous NCHW, as modulated_deform_conv_cuda.cu:118). im2col_step is accepted and
-    irrelevant: there is no columns buffer to chunk.  `_keep` (a list, not part of the reference signature) receives the NHWC
-    copy of the input so that the autograd Function can hand it to the backward call instead of permuting again."""
+    irrelevant: the forward has no columns buffer to chunk.  (A channels-last `input` is taken as it is: no copy.)"""
     g = _geom(input, weight, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, group, deformable_group)
     B, H, W, C, Cout, Ho, Wo = g[:7]
     x = input.float().permute(0, 2, 3, 1).contiguous()
-    if _keep is not None:
-        _keep.append(x)
     y = _forward_nhwc(x, weight, bias, offset, mask, g)
     return y.view(B, Ho, Wo, Cout).permute(0, 3, 1, 2).contiguous().to(input.dtype)
 
 
 def modulated_deform_conv_backward(input, weight, bias, offset, mask, grad_output, kernel_h, kernel_w, stride_h, stride_w, pad_h,
-                                   pad_w, dilation_h, dilation_w, group, deformable_group, im2col_step, _x_nhwc=None):
+                                   pad_w, dilation_h, dilation_w, group, deformable_group, im2col_step):
     """-> [grad_input, grad_offset, grad_mask, grad_weight, grad_bias] (modulated_deform_conv_cuda.cu:127-280).
-    No float atomics anywhere: the five gradients are bit-identical from run to run (include/fv2p_ops.h, A13).
-    `_x_nhwc`: the forward's NHWC copy of `input` (see modulated_deform_conv_forward), optional."""
+    No float atomics anywhere: the five gradients are bit-identical from run to run (include/fv2p_ops.h, A13)."""
     g = _geom(input, weight, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, group, deformable_group)
     B, H, W, C, Cout, Ho, Wo = g[:7]
     dev = input.device
-    x = _x_nhwc if _x_nhwc is not None else input.float().permute(0, 2, 3, 1).contiguous()
+    x = input.float().permute(0, 2, 3, 1).contiguous()
     dy = grad_output.float().permute(0, 2, 3, 1).contiguous().view(B * Ho * Wo, Cout)
     wt = _wt(weight.float())
     pad = (-Cout) % 4            # the kernels read output channels four at a time: pad with zero columns

@@ -11,18 +11,13 @@ class ModulatedDeformConvFunction(Function):
     @staticmethod
     def forward(ctx, input, offset, mask, weight, bias, *loose):
         ctx.geometry = conv_geometry(weight, *loose)
-        keep = []
-        out = DCN.modulated_deform_conv_forward(input, weight, bias, offset, mask, *ctx.geometry, _keep=keep)
-        # the kernels read NHWC: keep that copy for the backward pass (the reference keeps `input` and permutes it again there)
-        ctx.nhwc = keep[0] if input.requires_grad or weight.requires_grad or offset.requires_grad or mask.requires_grad else None
         ctx.save_for_backward(input, offset, mask, weight, bias)
-        return out
+        return DCN.modulated_deform_conv_forward(input, weight, bias, offset, mask, *ctx.geometry)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
         input, offset, mask, weight, bias = ctx.saved_tensors
         d_input, d_offset, d_mask, d_weight, d_bias = DCN.modulated_deform_conv_backward(
-            input, weight, bias, offset, mask, grad_output, *ctx.geometry, _x_nhwc=ctx.nhwc)
-        ctx.nhwc = None
+            input, weight, bias, offset, mask, grad_output, *ctx.geometry)
         return (d_input, d_offset, d_mask, d_weight, d_bias) + (None,) * 6

@@ -213,11 +213,18 @@ def indice_group(features, pairs, num, n_out):
 
 
 # ---------------------------------------------------------------- iou3d / NMS ---------------
-def boxes_bev(boxes_a, boxes_b, mode="iou"):
-    """iou3d_nms_kernel.cu:236-265 restated: pairwise BEV overlap area (mode='overlap') or IoU (mode='iou')."""
+def boxes_bev(boxes_a, boxes_b, mode="iou", threads=None):
+    """iou3d_nms_kernel.cu:236-265 restated: pairwise BEV overlap area (mode='overlap') or IoU (mode='iou').
+    threads: rows in parallel with OpenMP (bench.py's all-core B2 baseline); None = the serial form."""
     a = np.ascontiguousarray(boxes_a, dtype=np.float32)
     b = np.ascontiguousarray(boxes_b, dtype=np.float32)
     out = np.zeros((a.shape[0], b.shape[0]), np.float32)
+    if threads:
+        f = lib().oracle_boxes_bev_mt
+        f.restype = None
+        f.argtypes = [ctypes.POINTER(_f32), ctypes.c_int, ctypes.POINTER(_f32), ctypes.c_int, ctypes.c_int, ctypes.POINTER(_f32), ctypes.c_int]
+        f(_p(a, _f32), a.shape[0], _p(b, _f32), b.shape[0], 1 if mode == "iou" else 0, _p(out, _f32), int(threads))
+        return out
     f = lib().oracle_boxes_bev
     f.restype = None
     f.argtypes = [ctypes.POINTER(_f32), ctypes.c_int, ctypes.POINTER(_f32), ctypes.c_int, ctypes.c_int, ctypes.POINTER(_f32)]
@@ -238,15 +245,22 @@ def boxes_iou3d(boxes_a, boxes_b):
     return np.clip(o3 / np.clip(va + vb - o3, 1e-6, None), 0, 1).astype(np.float32)
 
 
-def nms(boxes, scores, thresh, pre_maxsize=None, normal=False):
+def nms(boxes, scores, thresh, pre_maxsize=None, normal=False, threads=None):
     """iou3d_nms_utils.py:494-526 restated: stable descending score sort, optional cut, greedy suppression.
-    Returns indices into `boxes`."""
+    Returns indices into `boxes`.  threads: the reference's two phases with the pair mask computed by OpenMP rows
+    (bench.py's all-core B3 baseline; same survivors); None = the serial form that evaluates only the pairs it reaches."""
     boxes = np.ascontiguousarray(boxes, dtype=np.float32)
     order = np.argsort(-np.asarray(scores, np.float32), kind="stable")
     if pre_maxsize is not None:
         order = order[:pre_maxsize]
     sb = np.ascontiguousarray(boxes[order])
     keep = np.zeros((max(sb.shape[0], 1),), np.int64)
+    if threads:
+        f = lib().oracle_nms_mt
+        f.restype = ctypes.c_int
+        f.argtypes = [ctypes.POINTER(_f32), ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.POINTER(_i64), ctypes.c_int]
+        num = f(_p(sb, _f32), sb.shape[0], float(thresh), int(normal), _p(keep, _i64), int(threads))
+        return order[keep[:num]]
     f = lib().oracle_nms
     f.restype = ctypes.c_int
     f.argtypes = [ctypes.POINTER(_f32), ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.POINTER(_i64)]

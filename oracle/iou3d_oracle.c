@@ -181,3 +181,35 @@ int oracle_nms(const float* boxes, int n, float thresh, int normal, int64_t* kee
   free(removed);
   return num;
 }
+
+/* ---- all-core forms (BASELINE.md section 2, B2 / B3 "1 thread and all cores (OpenMP)"): the same per-pair arithmetic, rows in parallel */
+void oracle_boxes_bev_mt(const float* a, int na, const float* b, int nb, int mode, float* out, int threads) {
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads)
+  for (int i = 0; i < na; ++i)
+    for (int j = 0; j < nb; ++j)
+      out[(int64_t)i * nb + j] = mode ? oracle_iou_bev(a + i * 7, b + j * 7) : oracle_box_overlap(a + i * 7, b + j * 7);
+}
+
+/* The reference's two phases: the suppression mask of every pair j > i (what nms_kernel computes on the GPU,
+ * iou3d_nms_kernel.cu:268-316; here the rows in parallel), then the serial greedy pass over it (iou3d_nms.cpp:121-135).
+ * Same survivors as oracle_nms, which evaluates only the pairs the greedy pass reaches. */
+int oracle_nms_mt(const float* boxes, int n, float thresh, int normal, int64_t* keep, int threads) {
+  const int64_t words = ((int64_t)n + 63) / 64;
+  uint64_t* mask = (uint64_t*)calloc((size_t)(n > 0 ? n : 1) * (size_t)(words > 0 ? words : 1), sizeof(uint64_t));
+#pragma omp parallel for schedule(dynamic, 16) num_threads(threads)
+  for (int i = 0; i < n; ++i)
+    for (int j = i + 1; j < n; ++j) {
+      float v = normal ? oracle_iou_normal(boxes + i * 7, boxes + j * 7) : oracle_iou_bev(boxes + i * 7, boxes + j * 7);
+      if (v > thresh) mask[(int64_t)i * words + (j >> 6)] |= (uint64_t)1 << (j & 63);
+    }
+  uint64_t* removed = (uint64_t*)calloc((size_t)(words > 0 ? words : 1), sizeof(uint64_t));
+  int num = 0;
+  for (int i = 0; i < n; ++i) {
+    if (removed[i >> 6] & ((uint64_t)1 << (i & 63))) continue;
+    keep[num++] = i;
+    for (int64_t w = i >> 6; w < words; ++w) removed[w] |= mask[(int64_t)i * words + w];
+  }
+  free(removed);
+  free(mask);
+  return num;
+}

@@ -62,3 +62,18 @@ def test_nms_properties():
     assert (np.triu(iou, 1) <= 0.3).all()  # no survivor is suppressed by an earlier survivor
     # idempotence: NMS of the survivors keeps all of them
     assert len(oracle.nms(kb, scores[keep], 0.3)) == len(keep)
+
+
+def test_all_core_forms_equal_the_serial_ones():
+    """oracle_boxes_bev_mt / oracle_nms_mt (bench.py's all-core B2 / B3 baselines): OpenMP over the rows of the
+    pair matrix changes who computes a pair, not what is computed - values and survivors equal the serial forms bit for bit."""
+    import oracle
+    from fv2p_harness import synth
+    b = synth.proposal_boxes(3, 300)
+    assert np.array_equal(oracle.boxes_bev(b, b, "iou"), oracle.boxes_bev(b, b, "iou", threads=4))
+    assert np.array_equal(oracle.boxes_bev(b[:50], b, "overlap"), oracle.boxes_bev(b[:50], b, "overlap", threads=3))
+    for tight, thr in ((True, 0.8), (False, 0.8), (True, 0.1)):
+        bx = synth.proposal_boxes(1, 1500, tight=tight)
+        s = np.random.default_rng(0).standard_normal(1500).astype(np.float32)
+        assert np.array_equal(oracle.nms(bx, s, thr), oracle.nms(bx, s, thr, threads=4))
+    assert len(oracle.nms(b[:0], np.zeros(0, np.float32), 0.5, threads=2)) == 0
