@@ -701,12 +701,14 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_weight_k(DcnGeom g, const floa
   f32x4 raw[2][4], dyv[2];
   float wq[2][4], mk[2];
   float roh[2], row_[2], rom[2];
+  unsigned off0[4] = {0u, 0u, 0u, 0u};
+  const bool one_group = cpg % 128 == 0;   // the 128 input channels of the tile belong to one deformable group: one sampling position per pixel
   auto load_offsets = [&](long long p) {   // raw offsets / mask of pixel p for this thread's two channel quads
     const bool ok = p < p_end;
     const long long pp = ok ? p : p_begin;
     const int b = static_cast<int>(pp / plane), pos = static_cast<int>(pp % plane);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < (one_group ? 1 : 2); ++h) {
       const int ci = ci0 + 64 * h + 4 * cq;
       const int dgi = min(ci, g.Cin - 1) / cpg;
       const float* ob = offset + (static_cast<long long>(b) * g.dg + dgi) * 2 * K * plane + pos;
@@ -724,13 +726,19 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_weight_k(DcnGeom g, const floa
     for (int h = 0; h < 2; ++h) {
       const int ci = ci0 + 64 * h + 4 * cq;
       const bool cok = ok && ci < g.Cin;
-      Corner4 t;
-      const float h_im = static_cast<float>(ho * g.sh - g.ph + i_k * g.dh) + roh[h];
-      const float w_im = static_cast<float>(wo * g.sw - g.pw + j_k * g.dw) + row_[h];
-      make_corners(g, cok, b, h_im, w_im, rom[h], static_cast<unsigned>(min(ci, g.Cin - 4)) * 4u, t);
+      if (h == 1 && one_group) {   // (uniform) both channel quads sample at the same position: the second one is 64 channels further
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { raw[h][q] = ldx4(reinterpret_cast<const char*>(x), t.o[q]); wq[h][q] = t.w[q]; }
-      mk[h] = t.m;
+        for (int q = 0; q < 4; ++q) { raw[1][q] = ldx4(reinterpret_cast<const char*>(x) + 256, off0[q]); wq[1][q] = wq[0][q]; }
+        mk[1] = mk[0];
+      } else {
+        Corner4 t;
+        const float h_im = static_cast<float>(ho * g.sh - g.ph + i_k * g.dh) + roh[h];
+        const float w_im = static_cast<float>(wo * g.sw - g.pw + j_k * g.dw) + row_[h];
+        make_corners(g, cok, b, h_im, w_im, rom[h], static_cast<unsigned>(min(ci, g.Cin - 4)) * 4u, t);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { raw[h][q] = ldx4(reinterpret_cast<const char*>(x), t.o[q]); wq[h][q] = t.w[q]; off0[q] = t.o[q]; }
+        mk[h] = t.m;
+      }
       const int co = co0 + 64 * h + 4 * cq;
       f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
       if (ok && co < g.Cout) v = *reinterpret_cast<const f32x4*>(dy + pp * g.Cout + co);   // Cout % 4 == 0
@@ -866,12 +874,14 @@ extern "C" int fv2p_dcn_forward(const float* x_nhwc, const float* wt_oc, const f
 }
 
 // ---- backward: workspace carving shared by the size query and the call
+static long long kDwBlocksPerCu = 3;   // workgroups of the weight-gradient kernel per CU (156 VGPRs: three fit; measured 2 / 3 / 4: 1390 / 1368 / 1399 us backward at [4,128,200,176]); FV2P_DCN_DW_BPC overrides
 struct DcnBwdPlan {
   long long npix, nkeys, max_entries;
   int splits, pix_per_block, ci_tiles, co_tiles;
 };
 static DcnBwdPlan dcn_bwd_plan(const DcnGeom& g) {
   DcnBwdPlan p;
+  { static bool once = false; if (!once) { once = true; if (const char* e = getenv("FV2P_DCN_DW_BPC")) kDwBlocksPerCu = std::max(1, atoi(e)); } }
   const int K = g.kh * g.kw;
   p.npix = static_cast<long long>(g.B) * g.Ho * g.Wo;
   p.nkeys = static_cast<long long>(g.B) * g.dg * (g.H + 1) * (g.W + 1);
@@ -879,7 +889,7 @@ static DcnBwdPlan dcn_bwd_plan(const DcnGeom& g) {
   p.ci_tiles = static_cast<int>(ceil_div(g.Cin, 128));
   p.co_tiles = static_cast<int>(ceil_div(g.Cout, 128));
   const long long cols = static_cast<long long>(K) * p.ci_tiles * p.co_tiles;
-  long long s = (2ll * dcn_cu_count()) / cols;            // one resident round of workgroups (two per CU)
+  long long s = (kDwBlocksPerCu * dcn_cu_count()) / cols;   // one resident round of workgroups
   const long long smax = ceil_div(p.npix > 0 ? p.npix : 1, 64);
   if (s > smax) s = smax;
   if (s < 1) s = 1;
