@@ -83,33 +83,57 @@ __global__ __launch_bounds__(256) void bev_scatter_k(const float* __restrict__ g
   }
 }
 
-// [B][R][S] -> [B][S][R] through a 32 x 33 LDS tile (R = C, S = H*W for channel-first -> channel-last and back)
+// [B][R][S] -> [B][S][R] (R = C, S = H*W: channel-first -> channel-last, and back with the roles swapped) through a 64 x 65 LDS tile:
+// 16-byte global accesses on both sides (a row of the tile is 256 contiguous bytes in the source, a column 256 contiguous bytes in the
+// destination), scalar LDS accesses with the odd pitch (two lanes per bank at most).  torch's .permute().contiguous() moves the same
+// bytes with a generic strided-copy kernel at a fraction of the bandwidth (the DCN layers' layout copies).
 __global__ __launch_bounds__(256) void transpose_k(const float* __restrict__ in, int rows, long long cols, float* __restrict__ out) {
-  __shared__ float tile[32][33];
+  __shared__ float tile[64][65];
   const long long b = blockIdx.z;
   const float* src = in + b * rows * cols;
   float* dst = out + b * rows * cols;
-  const long long c0 = static_cast<long long>(blockIdx.x) * 32;
-  const int r0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const long long c0 = static_cast<long long>(blockIdx.x) * 64;
+  const int r0 = blockIdx.y * 64;
+  const int q = threadIdx.x & 15, t = threadIdx.x >> 4;   // 16 quads x 16
+  const bool vec_in = (cols & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
+  const bool vec_out = (rows & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
 #pragma unroll
-  for (int j = 0; j < 32; j += 8) {
-    const int r = r0 + ty + j;
-    const long long cc = c0 + tx;
-    if (r < rows && cc < cols) tile[ty + j][tx] = src[static_cast<long long>(r) * cols + cc];
+  for (int j = 0; j < 64; j += 16) {
+    const int r = r0 + t + j;
+    const long long cc = c0 + 4 * q;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r < rows) {
+      const float* p = src + static_cast<long long>(r) * cols + cc;
+      if (vec_in && cc + 3 < cols) { const float4 f = *reinterpret_cast<const float4*>(p); v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w; }
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (cc + e < cols) v[e] = p[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[t + j][4 * q + e] = v[e];
   }
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < 32; j += 8) {
-    const long long cc = c0 + ty + j;
-    const int r = r0 + tx;
-    if (r < rows && cc < cols) dst[cc * rows + r] = tile[tx][ty + j];
+  for (int j = 0; j < 64; j += 16) {
+    const long long cc = c0 + t + j;
+    const int r = r0 + 4 * q;
+    if (cc >= cols) continue;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = tile[4 * q + e][t + j];
+    float* p = dst + cc * rows + r;
+    if (vec_out && r + 3 < rows) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (r + e < rows) p[e] = v[e];
+    }
   }
 }
 
 static int launch_transpose(const float* in, int batch, int rows, long long cols, float* out, hipStream_t stream) {
-  FV2P_REQUIRE(batch <= 65535 && ceil_div(rows, 32) <= 65535, FV2P_ELIMIT, "bev transpose: batch or channel count too large");
-  const dim3 grid(static_cast<unsigned>(ceil_div(cols, 32)), static_cast<unsigned>(ceil_div(rows, 32)), static_cast<unsigned>(batch));
+  FV2P_REQUIRE(batch <= 65535 && ceil_div(rows, 64) <= 65535, FV2P_ELIMIT, "transpose: batch or row count too large");
+  const dim3 grid(static_cast<unsigned>(ceil_div(cols, 64)), static_cast<unsigned>(ceil_div(rows, 64)), static_cast<unsigned>(batch));
   hipLaunchKernelGGL(transpose_k, grid, dim3(256), 0, stream, in, rows, cols, out);
   return 0;
 }
@@ -164,6 +188,18 @@ extern "C" int fv2p_bev_interp_bwd(const float* grad_out, int batch, int c, int 
   }
   if (channels_first)
     if (int rc = launch_transpose(gim, batch, h * w, c, grad_bev, stream)) return rc;   // [B][HW][C] -> [B][C][HW]
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
+// in [batch][rows][cols] -> out [batch][cols][rows]: the NCHW <-> NHWC copies around the NHWC entry points (rows = C, cols = H*W one way,
+// rows = H*W, cols = C the other)
+extern "C" int fv2p_transpose_batched(const float* in, int batch, int64_t rows, int64_t cols, float* out, fv2p_stream_t stream_) {
+  FV2P_REQUIRE(batch >= 0 && rows >= 0 && cols >= 0, FV2P_EINVAL, "transpose_batched: bad sizes");
+  if (batch == 0 || rows == 0 || cols == 0) return 0;
+  FV2P_REQUIRE(in && out && in != out, FV2P_EINVAL, "transpose_batched: null or aliased pointers");
+  FV2P_REQUIRE(rows < (1ll << 31) && ceil_div(cols, 64) < (1ll << 31), FV2P_ELIMIT, "transpose_batched: too large");
+  if (int rc = launch_transpose(in, batch, static_cast<int>(rows), cols, out, static_cast<hipStream_t>(stream_))) return rc;
   FV2P_LAUNCH_CHECK();
   return 0;
 }

@@ -461,6 +461,11 @@ int fv2p_dcn_backward(const float* x_nhwc, const float* wt, const float* offset,
                       int deformable_group, float* dx_nhwc, float* doffset, float* dmask, float* dwt, void* ws,
                       size_t ws_bytes, fv2p_stream_t stream);
 
+/* Layout copies around the NHWC entry points above (and fv2p_bev_interp_*): in [batch][rows][cols] -> out [batch][cols][rows],
+ * e.g. NCHW -> NHWC with rows = C, cols = H*W.  The reference does the same copies with at::permute + contiguous
+ * (modulated_deform_conv_cuda.cu:78,118). */
+int fv2p_transpose_batched(const float* in, int batch, int64_t rows, int64_t cols, float* out, fv2p_stream_t stream);
+
 /* ---- A14: deformable position-sensitive RoI pooling ----------------------------------------------
  * Replace DCN.deform_psroi_pooling_forward / _backward
  * (pcdet/ops/DeformableConvolutionV2PyTorch/src/vision.cpp:11-12 -> src/deform_psroi_pooling.h ->

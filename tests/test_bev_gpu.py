@@ -60,3 +60,15 @@ def test_module_mirror_and_errors(gpu):
     import fv2p_native
     with pytest.raises(fv2p_native.Fv2pError):
         bgp.bilinear_interpolate_torch(torch.randn(4, 4, 3), torch.rand(5), torch.rand(5))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,r,s", [(4, 128, 35200), (2, 50, 77), (1, 3, 1), (3, 64, 130), (1, 257, 63)])
+def test_transpose_batched_is_a_permutation(gpu, b, r, s):
+    """fv2p_transpose_batched ([B][R][S] -> [B][S][R], the NCHW <-> NHWC copies of the DCN layers and the BEV pooling): every element
+    lands where permute + contiguous puts it, for sizes that are and are not multiples of the 64 x 64 tile / of four."""
+    import fv2p_native
+    x = torch.randn(b, r, s, device=gpu)
+    out = torch.full((b, s, r), float("nan"), device=gpu)
+    fv2p_native.call("fv2p_transpose_batched", x, b, r, s, out, fv2p_native.stream())
+    assert torch.equal(out, x.permute(0, 2, 1).contiguous())
