@@ -103,6 +103,7 @@ class FV2PWaymoConfig(FV2PConfig):
 # fv2p_harness.refstyle.reference_call_structure() switches to (the batch kernels of csrc/targets.hip have no counterpart in the
 # reference, whose Python does this work op by op)
 KERNEL_GLUE = True
+FULL_NMS = False   # refstyle.py: nms_gpu without the NMS_CONFIG keywords = every survivor computed, as the reference's kernel does
 _SIDE_STREAMS = {}
 _CONSTS = {}
 _CORNER_SIGNS = ((1, 1, -1), (1, -1, -1), (-1, -1, -1), (-1, 1, -1), (1, 1, 1), (1, -1, 1), (-1, -1, 1), (-1, 1, 1))
@@ -687,8 +688,11 @@ class IoUGuidedRoIHead(nn.Module):
         cand = torch.gather(boxes, 1, top_i.unsqueeze(-1).expand(-1, -1, 7)).contiguous()
         if not KERNEL_GLUE:   # the reference's loop: one nms_gpu per sample over all candidates, the cut afterwards (roi_head_template.py:60-85)
             rois, roi_scores = boxes.new_zeros(b, cfg.nms_post, 7), boxes.new_zeros(b, cfg.nms_post)
+            # the reference hands nms_gpu its whole NMS_CONFIG as keyword arguments (model_nms_utils.py:14-16); this pcdet.ops stops at
+            # NMS_POST_MAXSIZE survivors when it is there.  The reference-structure baseline (refstyle.py) withholds it: its NMS is full.
+            kw = {} if FULL_NMS else dict(NMS_TYPE="nms_gpu", NMS_THRESH=cfg.nms_thresh, NMS_PRE_MAXSIZE=cfg.nms_pre, NMS_POST_MAXSIZE=cfg.nms_post)
             for i in range(b):
-                sel, _ = iou3d_nms_utils.nms_gpu(cand[i], top_s[i], cfg.nms_thresh)
+                sel, _ = iou3d_nms_utils.nms_gpu(cand[i], top_s[i], cfg.nms_thresh, **kw)
                 sel = sel[:cfg.nms_post]
                 rois[i, :len(sel)], roi_scores[i, :len(sel)] = cand[i][sel], top_s[i][sel]
             return rois, roi_scores

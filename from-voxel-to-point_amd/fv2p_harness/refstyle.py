@@ -180,7 +180,7 @@ def reference_call_structure():
              (_structure.SparseConvTensor, "dense", _structure.SparseConvTensor.dense),
              (_pn2_fused, "supported", _pn2_fused.supported),
              (_pn2_stack, "furthest_point_sample", _pn2_stack.furthest_point_sample),
-             (_model, "KERNEL_GLUE", _model.KERNEL_GLUE)]
+             (_model, "KERNEL_GLUE", _model.KERNEL_GLUE), (_model, "FULL_NMS", _model.FULL_NMS)]
     env = os.environ.get("FV2P_DEFER_WGRAD")
     plain_fps = G.autograd_op("FurthestPointSamplingPlain", _fps_plain)
     try:
@@ -192,6 +192,7 @@ def reference_call_structure():
         _pn2_fused.supported = lambda *a, **k: False
         _pn2_stack.furthest_point_sample = plain_fps.apply
         _model.KERNEL_GLUE = False
+        _model.FULL_NMS = True
         os.environ["FV2P_DEFER_WGRAD"] = "0"
         yield
     finally:

@@ -282,8 +282,8 @@ def fpstrace():
     from fv2p_harness import synth
     from pcdet.ops.pointnet2.pointnet2_batch import pointnet2_utils as bu
     dev = torch.device("cuda:0")
-    for n in (40000, 180000):
-        pts = torch.from_numpy(synth.waymo_like_cloud(0, n)[None, :, :3]).to(dev)
+    for n in (16384, 40000, 180000):
+        pts = torch.from_numpy((synth.lidar_cloud(0, n) if n <= 24576 else synth.waymo_like_cloud(0, n))[None, :, :3]).to(dev)
         bu.furthest_point_sample(pts, 2048)
         tr = torch.zeros(16 * 8, dtype=torch.int64, device=dev)
         fv2p_native.call("fv2p_fps_set_trace", tr)
