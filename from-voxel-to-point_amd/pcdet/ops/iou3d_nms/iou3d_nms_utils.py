@@ -31,6 +31,16 @@ def boxes_iou_bev(boxes_a, boxes_b):
 def boxes_iou3d_gpu(boxes_a, boxes_b):
     """(N,7) x (M,7) -> (N,M) 3-D IoU = BEV overlap x height overlap / union, clamped to [0,1] (:454-491)."""
     assert boxes_a.shape[1] == boxes_b.shape[1] == 7
+    if boxes_a.is_cuda and boxes_a.dtype == torch.float32 and boxes_b.dtype == torch.float32 and boxes_a.shape[0] > 0 and boxes_b.shape[0] > 0:
+        # one launch: the same float operations in the same order as the composition below (fv2p_boxes_iou3d_batch with a batch of one;
+        # tests/test_iou3d_gpu.py holds the two bit for bit).  The composition is ~20 small launches: 133 us of launch latency for a
+        # 512 x 40 problem (profiles/r03_op_roofline.txt).
+        import fv2p_native as _nat
+        a, b = boxes_a.contiguous(), boxes_b.contiguous()
+        iou3d = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+        with _nat.device_guard(a.device):
+            _nat.call("fv2p_boxes_iou3d_batch", a, 1, a.shape[0], b, b.shape[0], 7, iou3d, _nat.stream())
+        return iou3d
     a_max = (boxes_a[:, 2] + boxes_a[:, 5] / 2).view(-1, 1)
     a_min = (boxes_a[:, 2] - boxes_a[:, 5] / 2).view(-1, 1)
     b_max = (boxes_b[:, 2] + boxes_b[:, 5] / 2).view(1, -1)

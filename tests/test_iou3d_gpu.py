@@ -86,12 +86,27 @@ def test_nms_gpu_honours_the_callers_post_maxsize(gpu):
     assert np.array_equal(keep.cpu().numpy(), ref)
 
 
+def iou3d_composition(boxes_a, boxes_b):
+    """iou3d_nms_utils.py:454-491 as the reference composes it: boxes_overlap_bev_gpu + a dozen torch ops."""
+    a_max = (boxes_a[:, 2] + boxes_a[:, 5] / 2).view(-1, 1)
+    a_min = (boxes_a[:, 2] - boxes_a[:, 5] / 2).view(-1, 1)
+    b_max = (boxes_b[:, 2] + boxes_b[:, 5] / 2).view(1, -1)
+    b_min = (boxes_b[:, 2] - boxes_b[:, 5] / 2).view(1, -1)
+    overlaps_bev = torch.zeros((boxes_a.shape[0], boxes_b.shape[0]), dtype=torch.float32, device=boxes_a.device)
+    iou3d_nms_cuda.boxes_overlap_bev_gpu(boxes_a.contiguous(), boxes_b.contiguous(), overlaps_bev)
+    overlaps_h = torch.clamp(torch.min(a_max, b_max) - torch.max(a_min, b_min), min=0)
+    overlaps_3d = overlaps_bev * overlaps_h
+    vol_a = (boxes_a[:, 3] * boxes_a[:, 4] * boxes_a[:, 5]).view(-1, 1)
+    vol_b = (boxes_b[:, 3] * boxes_b[:, 4] * boxes_b[:, 5]).view(1, -1)
+    iou3d = overlaps_3d / torch.clamp(vol_a + vol_b - overlaps_3d, min=1e-6)
+    return iou3d.clamp(0, 1)
+
+
 @pytest.mark.gpu
 def test_batched_iou3d_equals_the_per_sample_composition(gpu):
-    """fv2p_boxes_iou3d_batch == boxes_iou3d_gpu per sample (bit for bit: the same float operations in the same order), with
-    ground-truth rows of 8 values (class id last) and zero-padded rows."""
+    """fv2p_boxes_iou3d_batch == the reference's composition per sample (bit for bit: the same float operations in the same order),
+    with ground-truth rows of 8 values (class id last) and zero-padded rows; boxes_iou3d_gpu itself is that kernel with a batch of one."""
     import fv2p_native
-    from pcdet.ops.iou3d_nms import iou3d_nms_utils
     a = torch.from_numpy(np.stack([random_boxes(3 + i, 200, spread=8.0) for i in range(3)])).to(gpu)
     g7 = np.stack([random_boxes(30 + i, 24, spread=8.0) for i in range(3)])
     g8 = np.concatenate([g7, np.ones((3, 24, 1), np.float32)], 2)
@@ -100,6 +115,8 @@ def test_batched_iou3d_equals_the_per_sample_composition(gpu):
     out = torch.empty((3, 200, 24), device=gpu)
     fv2p_native.call("fv2p_boxes_iou3d_batch", a, 3, 200, b, 24, 8, out, fv2p_native.stream())
     for i in range(3):
-        want = iou3d_nms_utils.boxes_iou3d_gpu(a[i], b[i, :, :7].contiguous())
+        want = iou3d_composition(a[i], b[i, :, :7].contiguous())
         assert torch.equal(out[i], want)
+        assert torch.equal(iou3d_nms_utils.boxes_iou3d_gpu(a[i], b[i, :, :7].contiguous()), want)
     assert float(out.max()) > 0.05
+    assert iou3d_nms_utils.boxes_iou3d_gpu(a[0][:0], b[0, :, :7].contiguous()).shape == (0, 24)
