@@ -979,9 +979,9 @@ __global__ __launch_bounds__(256) void conv_rows_ksplit(ConvArgs a) {
         // and is ADDED to the row's running sum afterwards.  One fused multiply-add chain over all (offset, channel) terms - the round 1-3
         // form, accumulators read from LDS before the MFMAs - is 27 x longer and sat 1.5 - 2.5 x further from a float64 run than
         // torch's blocked GEMMs (tools/f64_gap.py); the 16 extra adds per group are free beside 16 JS MFMAs.
-        f32x4 c[4];
+        f32x4 c[4], sum[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) c[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 4; ++i) { c[i] = f32x4{0.f, 0.f, 0.f, 0.f}; sum[i] = p[i]; }   // the running sums travel under the MFMAs
         static_for<0, JS * 4>([&](auto q_) {
           constexpr int q = decltype(q_)::value, jj = q / 4, t = q % 4;
 #pragma unroll
@@ -991,7 +991,7 @@ __global__ __launch_bounds__(256) void conv_rows_ksplit(ConvArgs a) {
             static_for<0, LPQ>([&](auto v_) { load_one(std::integral_constant<int, q * LPQ + decltype(v_)::value>{}, nxt, An, Bn); });
         });
 #pragma unroll
-        for (int i = 0; i < 4; ++i) p[i] = p[i] + c[i];
+        for (int i = 0; i < 4; ++i) p[i] = sum[i] + c[i];
       }
     });
     static_assert(LPQ * QUADS >= NLOAD, "every load of the next step must be issued inside the first group's block");
