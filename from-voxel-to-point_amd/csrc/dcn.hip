@@ -40,6 +40,18 @@ __global__ void dcn_reduce_k(const float* __restrict__ partial, int chunks, long
 }
 
 
+// Workgroup b of a launch runs on XCD b % 8, each XCD with an L2 of its own.  Handing out tiles in launch order gives every XCD every
+// eighth tile: the eight L2s then all hold the same band of the map (a tile's bilinear samples reach into its neighbours' pixels) and
+// each line is fetched from the fabric eight times - 815 MB of L2 fills for 83 MB of input at [4,128,200,176], rocprofv3 FETCH_SIZE.
+// XCD-major order gives every XCD one contiguous eighth of the tiles instead.  (tile, sub): sub is the fast index (column block / share).
+__device__ __forceinline__ void xcd_tile(int n_sub, long long& tile, int& sub) {
+  const long long total = gridDim.x, b = blockIdx.x;
+  const long long x = b & 7, slot = b >> 3;
+  const long long lp = x * (total >> 3) + (x < (total & 7) ? x : (total & 7)) + slot;
+  tile = lp / n_sub;
+  sub = static_cast<int>(lp % n_sub);
+}
+
 __device__ __forceinline__ void glds16(const float* gsrc, float* lds_dst) {
   const unsigned dst = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<uintptr_t>(lds_dst)));
   unsigned keep;
@@ -83,15 +95,18 @@ __device__ __forceinline__ f32x4 ldx4(const char* base, unsigned off) { return *
 template <int NB, int MB>
 __global__ __launch_bounds__(256, 2) void dcn_fwd_k(DcnGeom g, const float* __restrict__ x, const float* __restrict__ wt_oc,
                                                      const float* __restrict__ bias, const float* __restrict__ offset,
-                                                     const float* __restrict__ mask, float* __restrict__ y, long long pix_base) {
+                                                     const float* __restrict__ mask, float* __restrict__ y, long long pix_base, int n_sub) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x NB x 256 floats
   constexpr int FRAG = NB * 256;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 15, gq = lane >> 4;
   const long long npix = static_cast<long long>(g.B) * g.Ho * g.Wo;
   const int plane = g.Ho * g.Wo;
   const int K = g.kh * g.kw, cpg = g.Cin / g.dg, cps = cpg / 16, segs = K * g.dg, steps = segs * cps;
-  const int col0 = blockIdx.y * (NB * 16);
-  const long long tile0 = pix_base + static_cast<long long>(blockIdx.x) * (64 * MB) + wave * (16 * MB);
+  long long tile;
+  int cb;
+  xcd_tile(n_sub, tile, cb);
+  const int col0 = cb * (NB * 16);
+  const long long tile0 = pix_base + tile * (64 * MB) + wave * (16 * MB);
   // this lane's pixels
   bool live[MB];
   int pb[MB], pho[MB], pwo[MB], ppos[MB];
@@ -278,18 +293,21 @@ template <int JO, int NBP, int MC>
 __global__ __launch_bounds__(256, 2) void dcn_bwd_col_k(DcnGeom g, const float* __restrict__ x, const float* __restrict__ wt,
                                                         const float* __restrict__ offset, const float* __restrict__ mask,
                                                         const float* __restrict__ dy, float* __restrict__ colg, float* __restrict__ doff,
-                                                        float* __restrict__ dmask, long long pix_base) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x (2 x JO) pieces of 256 floats
+                                                        float* __restrict__ dmask, long long pix_base, int n_sub) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x (MC x JO) pieces of 256 floats
   constexpr int FRAG = MC * JO * 256, CS = 16 * MC;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n = lane & 15, gq = lane >> 4;
   const long long npix = static_cast<long long>(g.B) * g.Ho * g.Wo;
   const int plane = g.Ho * g.Wo;
   const int K = g.kh * g.kw, cpg = g.Cin / g.dg, cps = cpg / CS, segs = K * g.dg;   // cpg % CS == 0
-  // grid.y splits the (tap, group) segments: small maps do not fill the chip with pixel tiles alone
-  const int seg_begin = static_cast<int>(static_cast<long long>(segs) * blockIdx.y / gridDim.y);
-  const int seg_end = static_cast<int>(static_cast<long long>(segs) * (blockIdx.y + 1) / gridDim.y);
+  // n_sub shares of the (tap, group) segments per pixel tile: small maps do not fill the chip with pixel tiles alone
+  long long tile;
+  int share;
+  xcd_tile(n_sub, tile, share);
+  const int seg_begin = static_cast<int>(static_cast<long long>(segs) * share / n_sub);
+  const int seg_end = static_cast<int>(static_cast<long long>(segs) * (share + 1) / n_sub);
   const int steps = (seg_end - seg_begin) * cps;
-  const long long tile0 = pix_base + static_cast<long long>(blockIdx.x) * (64 * NBP) + wave * (16 * NBP);
+  const long long tile0 = pix_base + tile * (64 * NBP) + wave * (16 * NBP);
   bool live[NBP];
   int pb[NBP], pho[NBP], pwo[NBP], ppos[NBP];
   unsigned cbase[NBP];   // byte offset of colg[p][0][4 gq]
@@ -551,7 +569,10 @@ __global__ __launch_bounds__(256) void dcn_col2im_k(DcnGeom g, const float* __re
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tiles_c = (g.W + 3) / 4, tiles_r = (g.H + 1) / 2;
   const long long ntiles = static_cast<long long>(g.B) * g.dg * tiles_r * tiles_c;
-  const long long tile = static_cast<long long>(blockIdx.x) * 4 + wave;
+  long long blk;
+  int unused;
+  xcd_tile(1, blk, unused);
+  const long long tile = blk * 4 + wave;
   if (tile >= ntiles) return;
   const int cpg = g.Cin / g.dg;
   const int bd = static_cast<int>(tile / (tiles_r * tiles_c)), b = bd / g.dg, dgi = bd % g.dg;
@@ -686,15 +707,21 @@ __global__ __launch_bounds__(256) void dcn_col2im_k(DcnGeom g, const float* __re
 constexpr int kDwPitch = 132;   // floats per pixel row of an LDS tile: rows 4 pixels apart land 16 banks apart
 __global__ __launch_bounds__(256, 2) void dcn_bwd_weight_k(DcnGeom g, const float* __restrict__ x, const float* __restrict__ offset,
                                                             const float* __restrict__ mask, const float* __restrict__ dy, int pix_per_block,
-                                                            float* __restrict__ partial) {
+                                                            int n_ztiles, float* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 buffers x (col tile 16 x 132 + dy tile 16 x 132)
   constexpr int TILE = 16 * kDwPitch, BUF = 2 * TILE;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, gq = lane >> 4;
   const int K = g.kh * g.kw, cpg = g.Cin / g.dg, plane = g.Ho * g.Wo;
   const int ci_tiles = static_cast<int>((g.Cin + 127) / 128);
-  const int k = blockIdx.y, ci0 = (blockIdx.z % ci_tiles) * 128, co0 = (blockIdx.z / ci_tiles) * 128;
+  // one grid dimension, decoded XCD-major: the kh*kw taps (and channel tiles) of one pixel range run on ONE XCD and share its x and dy
+  // lines in that L2 (in launch order they went to all eight: 1 131 MB of L2 fills for 144 MB of x + dy at [4,128,200,176])
+  long long lp;
+  int zt;
+  xcd_tile(n_ztiles, lp, zt);
+  const int k = static_cast<int>(lp % K), split = static_cast<int>(lp / K);
+  const int ci0 = (zt % ci_tiles) * 128, co0 = (zt / ci_tiles) * 128;
   const long long npix = static_cast<long long>(g.B) * plane;
-  const long long p_begin = static_cast<long long>(blockIdx.x) * pix_per_block, p_end = min(p_begin + pix_per_block, npix);
+  const long long p_begin = static_cast<long long>(split) * pix_per_block, p_end = min(p_begin + pix_per_block, npix);
   // staging role: pixel tid >> 4 of the step, channel quads (tid & 15) and (tid & 15) + 16
   const int spx = tid >> 4, cq = tid & 15;
   const int i_k = k / g.kw, j_k = k % g.kw;
@@ -798,7 +825,7 @@ __global__ __launch_bounds__(256, 2) void dcn_bwd_weight_k(DcnGeom g, const floa
     __syncthreads();
   }
   // acc[a][c][e] = dW[k][ci0 + (wi*4 + a)*16 + 4 gq + e][co0 + (wj*4 + c)*16 + r]
-  float* out = partial + (static_cast<long long>(blockIdx.x) * K + k) * g.Cin * g.Cout;
+  float* out = partial + (static_cast<long long>(split) * K + k) * g.Cin * g.Cout;
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -844,8 +871,8 @@ static int dcn_cu_count() {
 template <int NB>
 static void dcn_fwd_launch(const DcnGeom& g, const float* x, const float* wt_oc, const float* bias, const float* offset, const float* mask,
                            float* y, long long npix, int col_blocks, hipStream_t stream) {
-  const dim3 grid(static_cast<unsigned>(ceil_div(npix, 64)), static_cast<unsigned>(col_blocks));
-  hipLaunchKernelGGL((dcn_fwd_k<NB, 1>), grid, dim3(256), 2 * NB * 256 * sizeof(float), stream, g, x, wt_oc, bias, offset, mask, y, 0ll);
+  const dim3 grid(static_cast<unsigned>(ceil_div(npix, 64) * col_blocks));   // one dimension: (tile, column block) decoded XCD-major in the kernel
+  hipLaunchKernelGGL((dcn_fwd_k<NB, 1>), grid, dim3(256), 2 * NB * 256 * sizeof(float), stream, g, x, wt_oc, bias, offset, mask, y, 0ll, col_blocks);
 }
 
 // wt_oc: weight permuted to [kh*kw][Cout][Cin] (input channels contiguous: what the LDS-DMA of the forward kernel fetches 16 bytes at a time)
@@ -926,8 +953,8 @@ extern "C" size_t fv2p_dcn_backward_ws_bytes(int batch, int height, int width, i
 template <int JO, int MC>
 static void dcn_col_launch(const DcnGeom& g, const float* x, const float* wt, const float* offset, const float* mask, const float* dy, float* colg,
                            float* doff, float* dmask, long long npix, int seg_split, hipStream_t stream) {
-  hipLaunchKernelGGL((dcn_bwd_col_k<JO, 1, MC>), dim3(static_cast<unsigned>(ceil_div(npix, 64)), static_cast<unsigned>(seg_split)), dim3(256),
-                     2 * MC * JO * 256 * sizeof(float), stream, g, x, wt, offset, mask, dy, colg, doff, dmask, 0ll);
+  hipLaunchKernelGGL((dcn_bwd_col_k<JO, 1, MC>), dim3(static_cast<unsigned>(ceil_div(npix, 64) * seg_split)), dim3(256),
+                     2 * MC * JO * 256 * sizeof(float), stream, g, x, wt, offset, mask, dy, colg, doff, dmask, 0ll, seg_split);
 }
 
 // dx_nhwc, doffset, dmask, dwt are fully written (nothing to zero).  wt = [kh*kw][Cin][Cout].
@@ -987,9 +1014,9 @@ extern "C" int fv2p_dcn_backward(const float* x_nhwc, const float* wt, const flo
   else if (cpg > 64) hipLaunchKernelGGL((dcn_col2im_k<2>), dim3(gblocks), dim3(256), 0, stream, g, colg, cursor, entries, dx_nhwc);
   else hipLaunchKernelGGL((dcn_col2im_k<1>), dim3(gblocks), dim3(256), 0, stream, g, colg, cursor, entries, dx_nhwc);
   // 4. weight gradient
-  const dim3 wgrid(static_cast<unsigned>(p.splits), static_cast<unsigned>(K), static_cast<unsigned>(p.ci_tiles * p.co_tiles));
+  const dim3 wgrid(static_cast<unsigned>(static_cast<long long>(p.splits) * K * p.ci_tiles * p.co_tiles));
   hipLaunchKernelGGL(dcn_bwd_weight_k, wgrid, dim3(256), 2 * 2 * 16 * kDwPitch * sizeof(float), stream, g, x_nhwc, offset, mask, dy_nhwc,
-                     p.pix_per_block, partial);
+                     p.pix_per_block, p.ci_tiles * p.co_tiles, partial);
   const long long per_chunk = static_cast<long long>(K) * g.Cin * g.Cout;
   hipLaunchKernelGGL(dcn_reduce_k, dim3(static_cast<unsigned>(ceil_div(per_chunk, 256))), dim3(256), 0, stream, partial, p.splits, per_chunk, dwt);
   FV2P_LAUNCH_CHECK();
