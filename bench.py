@@ -866,13 +866,14 @@ def roofline_probe(model, voxelize, pool, args, device):
     traffic = None
     layer = f"{'subm' if mod.subm else 'conv'} {cin}->{cout} key={mod.indice_key} n_in={rec['n_in']} n_out={rec['n_out']} pairs={rec['pairs']}"
     try:   # reported only for the very layer the counters were collected on (same channels, rows and pairs)
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_roofline.json")) as f:
+        prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+        with open(next(p for p in (os.path.join(prof, n) for n in ("r04_pmc_roofline.json", "r03_pmc_roofline.json")) if os.path.exists(p))) as f:
             pmc = json.load(f)
         import re
         mt = re.search(r"(\d+)->(\d+) key=(\S+) n=(\d+) pairs=(\d+)", pmc.get("layer_line", ""))
         if mt and (int(mt.group(1)), int(mt.group(2)), mt.group(3), int(mt.group(4)), int(mt.group(5))) == (cin, cout, mod.indice_key, rec["n_in"], rec["pairs"]):
             traffic = pmc["traffic_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError, StopIteration):
         pass
     return {"bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "traffic": traffic,
             "kernel": conv_kernel_name(cin, cout, rec["n_out"]),
@@ -945,7 +946,18 @@ def dcn_roofline_probe(model, voxelize, pool, gts, args, device):
     ach = flops / dur_s / 1e12
     # algorithmic bytes: x once, y once, offsets + masks, weights; the kernel is far on the MFMA side of the ridge
     bytes_alg = 4.0 * (g[0] * g[1] * g[2] * g[3] + g[0] * g[5] * g[6] * (g[4] + 27 * g[15]) + 9 * g[3] * g[4])
-    return {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
+    # fabric traffic per launch: from the separate rocprofv3 --pmc passes of tools/pmc_dcn.sh, committed under profiles/ (FETCH_SIZE doubled as
+    # MI355X_MICROARCH.md prescribes for gfx950, plus WRITE_SIZE), reported only for the very layer they were collected on
+    traffic = None
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_pmc_dcn_head.json")) as f:
+            pmc = json.load(f)
+        if pmc.get("layer") == "DCNv2 " + shape:
+            k = pmc["kernels"]["dcn_fwd_k"]
+            traffic = k["fetch_bytes_x2"] + k["write_bytes"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4), "traffic": traffic,
             "kernel": f"dcn_fwd_k<{16 if g[4] > 128 else 8}, 1> (fv2p_dcn_forward)", "layer": "DCNv2 " + shape,
             "avg_kernel_us": round(dur_s * 1e6, 2), "alg_flops": flops, "alg_bytes": bytes_alg, "dcn_layers": layers}
 

@@ -389,7 +389,7 @@ def bn():
     from torch import nn
     from pcdet.ops.spconv import norm
     dev = torch.device("cuda:0")
-    for n, c in [(45868, 16), (50783, 32), (29446, 64), (13425, 64), (11446, 128)]:
+    for n, c in [(45868, 16), (50783, 32), (29446, 64), (13425, 64), (11446, 128), (49152, 64), (49152, 128), (49152, 256)]:   # backbone levels, decoder / point-head Linear blocks
         x = torch.randn(n, c, device=dev, requires_grad=True)
         g = torch.randn(n, c, device=dev)
         m = nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(dev)
