@@ -49,6 +49,7 @@ struct ConvArgs {
   const float* bn_x; const float* bn_mean; const float* bn_invstd; const float* bn_gamma; const float* bn_beta; int bn_relu;
   const int* perm;                                   // optional row order: tile t owns destination rows perm[64t .. 64t+63]
   const int* plan;                                   // optional cost-balanced tiling (conv_rows_ksplit): tile t owns rows [plan[t], plan[t+1])
+  int col_blocks;                                    // conv_rows_ksplit: 64-column blocks of a tile, decoded from blockIdx.x (0 / 1: one)
 };
 
 // ---- BatchNorm statistics in the epilogue --------------------------------------------------------
@@ -838,13 +839,18 @@ __global__ __launch_bounds__(256) void conv_rows_ksplit(ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, g = lane >> 4;
   // rows of this workgroup: a fixed TM-row tile, or — with a plan (fv2p_conv_plan_build) — the t-th of gridDim.x row ranges of
   // equal cost (pairs per row, floored), taken in sub-tiles of at most TM rows of equal size
-  const int tile = xcd_major_tile(blockIdx.x, gridDim.x);
+  // One grid dimension, (tile, column block) decoded XCD-major: the two 64-column halves of a 128-column layer are neighbours in that
+  // order, i.e. run on the SAME XCD at about the same time, and the rows the second one gathers are L2 hits.  As grid.y they were
+  // gridDim.x workgroups apart - on another XCD, whose L2 fetched every row again from the fabric.
+  const int ncb = a.col_blocks > 1 ? a.col_blocks : 1;
+  const int lp = xcd_major_tile(blockIdx.x, gridDim.x);
+  const int tile = lp / ncb, cblk = lp % ncb;
   int r_begin = tile * TM, r_end = min(r_begin + TM, a.n_dst);
   if (a.plan) { r_begin = a.plan[tile]; r_end = a.plan[tile + 1]; }
   const int n_sub = (r_end - r_begin + TM - 1) / TM;
   const int sub_rows = n_sub > 0 ? (r_end - r_begin + n_sub - 1) / n_sub : 0;
-  if (gridDim.y > 1) {   // column split as in conv_rows_dma
-    const int off = blockIdx.y * 64;
+  if (ncb > 1) {   // column split as in conv_rows_dma
+    const int off = cblk * 64;
     a.w += WT ? static_cast<long long>(off) * a.w_ld : off;
     a.dst += off;
     if (a.bias) a.bias += off;
@@ -1022,7 +1028,7 @@ __global__ __launch_bounds__(256) void conv_rows_ksplit(ConvArgs a) {
   // the loads of the step past the end (issued during the last step, used by nobody) are drained before their registers are reused
   asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
   if (a.trace && tid == 0) {   // the trace buffer has 4 records per 64 rows: every workgroup of a <= 2 x 2 split launch
-    const int rec = blockIdx.y * gridDim.x + blockIdx.x;
+    const int rec = blockIdx.x;
     if (rec < 4 * ((a.n_dst + 63) / 64)) {
       unsigned hw, xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -1741,7 +1747,8 @@ static void launch_vec(const ConvArgs& a, hipStream_t s) {
       const int gps = g_ksplit_gps == 2 ? 2 : 1;   // measured: two groups per step gain nothing at either size (KITTI 55 vs 53 us, Waymo 254 vs 256): opt-in
       const size_t lds64 = ksplit_lds(64) + g_ksplit_pad;
       if (level >= 0 || ksplit_rows<WT>(a) == 64) {
-        const dim3 grid(level >= 0 ? tiles : blocks, NB / 4);
+        b.col_blocks = NB / 4;
+        const dim3 grid((level >= 0 ? tiles : blocks) * (NB / 4));
         if (gps == 2) {
           static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_ksplit<CINP, WT, 64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
           if (once) { hipLaunchKernelGGL((conv_rows_ksplit<CINP, WT, 64, 2>), grid, dim3(256), lds64, s, b); return; }
@@ -1754,7 +1761,8 @@ static void launch_vec(const ConvArgs& a, hipStream_t s) {
       {
         const size_t lds = ksplit_lds(32) + g_ksplit_pad;
         static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_ksplit<CINP, WT, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
-        if (once) { hipLaunchKernelGGL((conv_rows_ksplit<CINP, WT, 32>), dim3(static_cast<unsigned>(ceil_div(a.n_dst, 32)), NB / 4), dim3(256), lds, s, b); return; }
+        b.col_blocks = NB / 4;
+        if (once) { hipLaunchKernelGGL((conv_rows_ksplit<CINP, WT, 32>), dim3(static_cast<unsigned>(ceil_div(a.n_dst, 32)) * (NB / 4)), dim3(256), lds, s, b); return; }
       }
     }
   }
@@ -1996,6 +2004,7 @@ static int conv_rows_impl(const float* src, int64_t n_src, int c_src, const floa
       const int cs = (c_src - s0) < 128 ? (c_src - s0) : 128;
       ConvArgs a;
       a.trace = nullptr;
+      a.col_blocks = 0;
       a.stats = stats ? stats + d0 : nullptr; a.stats_ld = c_dst;
       a.bn_x = nullptr; a.bn_mean = a.bn_invstd = a.bn_gamma = a.bn_beta = nullptr; a.bn_relu = 0;
       a.perm = perm;   // honoured by the LDS-DMA tile for permuted rows, ignored (plain row order, same result) by the others
