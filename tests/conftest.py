@@ -35,6 +35,26 @@ def gpu():
     return torch.device("cuda:0")
 
 
+import contextlib  # noqa: E402
+
+
+@contextlib.contextmanager
+def deterministic_libraries():
+    """MIOpen's training-mode BatchNorm2d and its atomics-based convolution kernels, and rocBLAS split-K GEMMs, differ in the last bits
+    between two identical calls (tools/bev_repro.py, profiles/r04_bev_repro_*.txt); through a network's ReLU masks that becomes up to
+    3e-3 of a gradient's norm from one run to the next.  Step-level parity tests run their GPU side under MIOpen's deterministic
+    solvers and rocBLAS without atomics, so that their bounds are bounds on a fixed number, not on a distribution."""
+    import torch
+    saved = (torch.backends.cudnn.deterministic, torch.are_deterministic_algorithms_enabled(), torch.is_deterministic_algorithms_warn_only_enabled())
+    torch.backends.cudnn.deterministic = True
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    try:
+        yield
+    finally:
+        torch.backends.cudnn.deterministic = saved[0]
+        torch.use_deterministic_algorithms(saved[1], warn_only=saved[2])
+
+
 @pytest.fixture(params=["compiled", "ctypes"])
 def front_end(request):
     """Runs a test once per Python front end of the library: the compiled autograd binding (lib/fv2p_torch.so) and the
