@@ -1396,35 +1396,73 @@ __global__ void three_interp_stack_grad_k(int64_t total, int c, const float* __r
   atomicAdd(&grad_features[static_cast<int64_t>(idx[pt * 3 + 2]) * c + ch], go * weight[pt * 3 + 2]);
 }
 
-// Gradient of the stack interpolation WITHOUT float atomics: the (query, slot) entries that read a known row are collected per row
-// (integer atomics: count, scan, fill), then every (row, channel) sums its entries — one plain store per output, rows nobody read get
-// their zero from the same store (no fill launch).  The order of a row's entries is whatever the fill's atomics give, so the sum's
-// rounding can differ from run to run exactly as the atomic form's does; sorting the lists would cost more than the kernel saves.
-__global__ void interp_count_k(int64_t entries, int m, const int* __restrict__ idx, int* __restrict__ count) {
+// Gradient of the stack interpolation WITHOUT float atomics, in a FIXED order (round 4).  The (query, slot) entries e = 3 * query + slot
+// are keyed (known row << 32 | e) and radix-sorted: every row's entries are then contiguous and in ascending e, whatever the hardware
+// did.  A group of lanes per known row (one lane = four channels) finds its run by binary search and sums it - rows nobody reads get
+// their zero from the same store (no fill launch), a row read by thousands of queries is walked by one group with every channel in
+// parallel (round 3's form, one THREAD per (row, channel) walking entry lists built with atomics, lost 5 x on such rows and summed in
+// an arbitrary order).
+__global__ void interp_keys_k(int64_t entries, int m, const int* __restrict__ idx, uint64_t* __restrict__ keys) {
   const int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (e >= entries) return;
   const int r = idx[e];
-  if (r >= 0 && r < m) atomicAdd(&count[r], 1);
+  keys[e] = (static_cast<uint64_t>(r >= 0 && r < m ? r : m) << 32) | static_cast<uint64_t>(e);   // out-of-range rows sort behind every row
 }
-__global__ void interp_fill_k(int64_t entries, int m, const int* __restrict__ idx, const int* __restrict__ start, int* __restrict__ count,
-                              int* __restrict__ list) {
-  const int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (e >= entries) return;
-  const int r = idx[e];
-  if (r >= 0 && r < m) list[start[r] + atomicSub(&count[r], 1) - 1] = static_cast<int>(e);
-}
-__global__ void interp_gather_grad_k(int64_t total, int c, const float* __restrict__ grad_out, const float* __restrict__ weight,
-                                     const int* __restrict__ start, const int* __restrict__ list, float* __restrict__ grad_features) {
-  const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (t >= total) return;
-  const int64_t row = t / c;
-  const int ch = static_cast<int>(t % c);
-  float acc = 0.f;
-  for (int i = start[row], e1 = start[row + 1]; i < e1; ++i) {
-    const int e = list[i];
-    acc += grad_out[static_cast<int64_t>(e / 3) * c + ch] * weight[e];
+// TPR lanes per row (power of two, <= 64), each lane four channels per pass
+template <int TPR>
+__global__ __launch_bounds__(256) void interp_gather_sorted_k(int m, int c, int64_t entries, const uint64_t* __restrict__ keys,
+                                                              const float* __restrict__ grad_out, const float* __restrict__ weight,
+                                                              float* __restrict__ grad_features) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const int64_t row = t / TPR;
+  const int sub = static_cast<int>(t % TPR);
+  if (row >= m) return;
+  // first entry of the row: lower bound of (row << 32)
+  const uint64_t want = static_cast<uint64_t>(row) << 32;
+  int64_t lo = 0, hi = entries;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (keys[mid] < want) lo = mid + 1; else hi = mid;
   }
-  grad_features[t] = acc;
+  for (int c0 = 4 * sub; c0 < c; c0 += 4 * TPR) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool vec = c0 + 3 < c && (c & 3) == 0;
+    int64_t i = lo;
+    for (;;) {
+      // four entries of the run in flight
+      uint64_t k[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        k[u] = i + u < entries ? keys[i + u] : ~0ull;
+        ok[u] = (k[u] >> 32) == static_cast<uint64_t>(row);
+      }
+      float4 v[4];
+      float w[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t e = static_cast<uint32_t>(k[u]);
+        w[u] = ok[u] ? weight[e] : 0.f;
+        const float* p = grad_out + static_cast<int64_t>(ok[u] ? e / 3 : 0) * c + c0;
+        if (vec) v[u] = *reinterpret_cast<const float4*>(p);
+        else { v[u].x = p[0]; v[u].y = c0 + 1 < c ? p[1] : 0.f; v[u].z = c0 + 2 < c ? p[2] : 0.f; v[u].w = c0 + 3 < c ? p[3] : 0.f; }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (ok[u]) {   // ascending e: the order is part of the result
+          acc[0] = __builtin_fmaf(w[u], v[u].x, acc[0]); acc[1] = __builtin_fmaf(w[u], v[u].y, acc[1]);
+          acc[2] = __builtin_fmaf(w[u], v[u].z, acc[2]); acc[3] = __builtin_fmaf(w[u], v[u].w, acc[3]);
+        }
+      if (!ok[3]) break;
+      i += 4;
+    }
+    float* out = grad_features + row * c + c0;
+    if (vec) *reinterpret_cast<float4*>(out) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (c0 + u < c) out[u] = acc[u];
+    }
+  }
 }
 
 static int fps_ref_block(int n) {  // opt_n_threads (cuda_utils.h:10-14): 2^floor(log2 n) clamped to [1, 1024]
@@ -1748,8 +1786,9 @@ extern "C" int fv2p_three_interpolate_stack_grad(int n, int c, const float* grad
   return 0;
 }
 extern "C" size_t fv2p_three_interpolate_stack_grad_ws_bytes(int n, int m) {
-  const size_t mm = static_cast<size_t>(m > 0 ? m : 1), nn = static_cast<size_t>(n > 0 ? n : 1);
-  return align_up(mm * sizeof(int)) + align_up((mm + 1) * sizeof(int)) + align_up(nn * 3 * sizeof(int)) + align_up(scan_ws_bytes(static_cast<int64_t>(mm)));
+  const size_t entries = static_cast<size_t>(n > 0 ? n : 1) * 3;
+  (void)m;
+  return 2 * align_up(entries * sizeof(uint64_t)) + align_up(radix_sort_ws_bytes(static_cast<int64_t>(entries)));
 }
 extern "C" int fv2p_three_interpolate_stack_grad_gather(int n, int c, int m, const float* grad_out, const int* idx, const float* weight,
                                                         float* grad_features, void* ws, size_t ws_bytes, fv2p_stream_t s) {
@@ -1760,18 +1799,23 @@ extern "C" int fv2p_three_interpolate_stack_grad_gather(int n, int c, int m, con
   FV2P_REQUIRE(static_cast<int64_t>(n) * 3 < (1ll << 31), FV2P_ELIMIT, "three_interpolate_stack_grad_gather: too many queries");
   FV2P_REQUIRE(ws && ws_bytes >= fv2p_three_interpolate_stack_grad_ws_bytes(n, m), FV2P_EWORKSPACE, "three_interpolate_stack_grad_gather: workspace too small");
   hipStream_t st = STREAM(s);
-  Carver cv(ws, ws_bytes);
-  int* count = cv.take<int>(static_cast<size_t>(m));
-  int* start = cv.take<int>(static_cast<size_t>(m) + 1);
-  int* list = cv.take<int>(static_cast<size_t>(n > 0 ? n : 1) * 3);
-  const size_t sb = scan_ws_bytes(m);
-  void* sws = cv.take<char>(sb);
   const int64_t entries = static_cast<int64_t>(n) * 3;
-  FV2P_HIP(hipMemsetAsync(count, 0, static_cast<size_t>(m) * sizeof(int), st));
-  if (entries > 0) hipLaunchKernelGGL(interp_count_k, G1D(entries), 0, st, entries, m, idx, count);
-  if (int rc = exclusive_scan_i32(count, start, m, start + m, sws, sb, st)) return rc;
-  if (entries > 0) hipLaunchKernelGGL(interp_fill_k, G1D(entries), 0, st, entries, m, idx, start, count, list);
-  hipLaunchKernelGGL(interp_gather_grad_k, G1D(total), 0, st, total, c, grad_out, weight, start, list, grad_features);
+  Carver cv(ws, ws_bytes);
+  uint64_t* keys = cv.take<uint64_t>(static_cast<size_t>(entries > 0 ? entries : 1));
+  uint64_t* tmp = cv.take<uint64_t>(static_cast<size_t>(entries > 0 ? entries : 1));
+  const size_t rb = radix_sort_ws_bytes(entries > 0 ? entries : 1);
+  void* rws = cv.take<char>(rb);
+  if (entries > 0) {
+    hipLaunchKernelGGL(interp_keys_k, G1D(entries), 0, st, entries, m, idx, keys);
+    if (int rc = radix_sort_u64(keys, tmp, entries, 32, 32 + bits_for(static_cast<uint64_t>(m)), rws, rb, st)) return rc;
+  }
+  int tpr = 1;
+  while (tpr < 64 && tpr * 4 < c) tpr *= 2;
+  const int64_t threads = static_cast<int64_t>(m) * tpr;
+#define FV2P_IG(T) hipLaunchKernelGGL((interp_gather_sorted_k<T>), G1D(threads), 0, st, m, c, entries, keys, grad_out, weight, grad_features)
+  switch (tpr) { case 1: FV2P_IG(1); break; case 2: FV2P_IG(2); break; case 4: FV2P_IG(4); break; case 8: FV2P_IG(8); break;
+                 case 16: FV2P_IG(16); break; case 32: FV2P_IG(32); break; default: FV2P_IG(64); }
+#undef FV2P_IG
   FV2P_LAUNCH_CHECK();
   return 0;
 }

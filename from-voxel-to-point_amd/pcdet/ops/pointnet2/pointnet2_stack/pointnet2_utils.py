@@ -91,10 +91,11 @@ def _interp(saved, features, idx, weight):
     return out
 
 
-# The gather form of the interpolation gradient (fv2p_three_interpolate_stack_grad_gather: per-row entry lists, no float atomics, no
-# zero fill) is opt-in (FV2P_INTERP_GATHER=1): measured on MI355X it loses wherever a few known rows are read by many queries —
-# one thread then walks a list of thousands (profiles/r03_op_roofline.txt: 0.8 - 1.6 ms against 0.09 - 0.33 ms of the scatter form
-# at 49 152 queries) — and does not pay in the FV2P step either (31.3 - 31.5 against 30.8 - 31.1 ms per step).
+# The gather form of the interpolation gradient (fv2p_three_interpolate_stack_grad_gather: (row, entry) keys radix-sorted, a lane group
+# per known row sums its run in ascending entry order: no float atomics, no zero fill, BIT-IDENTICAL from run to run) is opt-in
+# (FV2P_INTERP_GATHER=1): it is the deterministic form, not the fast one - eight launches instead of two, and a row read by thousands
+# of queries is walked by one lane group (profiles/r04_op_roofline.txt: 1.2 - 2.1 ms against 0.12 - 0.23 ms of the scatter form on the
+# microbench's random known points, where a few rows hold thousands of entries; a segmented reduction over the sorted keys is the fix).
 GATHER_GRAD_MIN_QUERIES = 8192
 
 

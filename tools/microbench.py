@@ -486,12 +486,13 @@ def oproof():
         add(f"three_interpolate (stack) {nu} x C={ch}", t, 4.0 * ch * (3 * nu + nu) + 24.0 * nu)
         out = su.three_interpolate(feats, idx, w)
         g = torch.randn_like(out)
+        os.environ["FV2P_INTERP_GATHER"] = "0"
         t = timeit(lambda: out.backward(g, retain_graph=True), reps=10, warm=2)
-        add(f"three_interpolate grad {nu} x C={ch}", t, 4.0 * ch * (3 * nu + nu) + 24.0 * nu, note="scatter form (default): zero fill + float atomics")
+        add(f"three_interpolate grad {nu} x C={ch}", t, 4.0 * ch * (3 * nu + nu) + 24.0 * nu, note="scatter form: zero fill + float atomics")
         os.environ["FV2P_INTERP_GATHER"] = "1"
         t = timeit(lambda: out.backward(g, retain_graph=True), reps=10, warm=2)
-        os.environ.pop("FV2P_INTERP_GATHER")
-        add(f"three_interpolate grad {nu} x C={ch}, gather form", t, 4.0 * ch * (3 * nu + nu) + 24.0 * nu, note="opt-in: entry lists per row, no float atomics (random known points: a few rows hold thousands of entries)")
+        os.environ["FV2P_INTERP_GATHER"] = "0"
+        add(f"three_interpolate grad {nu} x C={ch}, gather form", t, 4.0 * ch * (3 * nu + nu) + 24.0 * nu, note="sorted (row, entry) keys + a lane group per row: no float atomics, fixed order")
     # batch grouping at the RoI head's shape: 384 RoIs x 512 points, 216 centres, 16 / 32 samples, C = 64 + 3
     r, n, mc, ch = 384, 512, 216, 67
     xyz = torch.rand(r, n, 3, device=dev)
