@@ -862,8 +862,8 @@ __global__ __launch_bounds__(256) void conv_rows_ksplit(ConvArgs a) {
     }
   }
   a.c_dst = 64;
-  unsigned long long t_begin = 0, t_pro = 0, t_wait = 0, t_mark = 0, t_issue = 0, t_comp = 0;
-  if (a.trace) t_begin = __builtin_readcyclecounter();
+  unsigned long long t_begin = 0, t_pro = 0, t_wait = 0, t_mark = 0, t_issue = 0, t_comp = 0;   // t_issue: the 100 MHz SoC clock at the start (one time base for all XCDs)
+  if (a.trace) { t_begin = __builtin_readcyclecounter(); t_issue = wall_clock64(); }
   for (int row0 = r_begin; row0 < r_end; row0 += sub_rows) {
   const int row_end = min(row0 + sub_rows, r_end);
   {
@@ -1034,12 +1034,12 @@ __global__ __launch_bounds__(256) void conv_rows_ksplit(ConvArgs a) {
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
       a.trace[rec * 8 + 0] = hw;
-      a.trace[rec * 8 + 1] = xcc;
+      a.trace[rec * 8 + 1] = (xcc & 0xffu) | ((wall_clock64() - t_issue) << 32);   // workgroup lifetime in 10 ns ticks above the XCC id
       a.trace[rec * 8 + 2] = t_begin;
       a.trace[rec * 8 + 3] = __builtin_readcyclecounter();
       a.trace[rec * 8 + 4] = t_pro;
       a.trace[rec * 8 + 5] = t_wait;   // clocks wave 0 spent waiting for the prefetched rows and weights
-      a.trace[rec * 8 + 6] = t_issue;  // ... issuing the next offset's loads
+      a.trace[rec * 8 + 6] = t_issue;  // SoC clock (10 ns ticks) at the workgroup's start
       a.trace[rec * 8 + 7] = t_comp;   // ... in the accumulator read / MFMA / accumulator write blocks
     }
   }

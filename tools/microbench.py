@@ -81,6 +81,9 @@ def conv(only=None):
             orders = {"as is": np.arange(mask.size), "mask sort": np.argsort(mask, kind="stable"), "line9 sort": np.argsort(line, kind="stable"),
                       "popcount sort": np.argsort(pc, kind="stable"), "shuffle": np.random.default_rng(0).permutation(mask.size)}
             ind = rb.indices
+            inp = ind.cpu().numpy().astype(np.int64)            # (b, z, y, x): what would XCD-major tiles that are y bands buy?
+            orders["(y, b, z, x) sort"] = np.lexsort((inp[:, 3], inp[:, 1], inp[:, 0], inp[:, 2]))
+            orders["(b, y, z, x) sort"] = np.lexsort((inp[:, 3], inp[:, 1], inp[:, 2], inp[:, 0]))
             # balanced variant: rows sorted by (popcount, mask); 64-row tiles handed out so that the two workgroups a CU
             # receives (taken from a placement trace of this very launch shape) are one heavy and one light tile
             import fv2p_native
@@ -149,6 +152,16 @@ def conv(only=None):
                 print(f"all workgroups: {len(live)} on {len(per_cu)} CUs, workgroups/CU histogram {sorted(collections.Counter(per_cu.values()).items())}; "
                       f"span {t_last - t_first} clocks; workgroup clocks: median {np.median(d):.0f} max {d.max():.0f} sum/256 CUs {d.sum() / 256:.0f}; "
                       f"last start {live[:, 2].max() - t_first}; wait clocks median {np.median(live[:, 5]):.0f}")
+                # one time base for all XCDs: the 100 MHz SoC clock at every workgroup's start and its lifetime in those ticks
+                w0 = live[:, 6].astype(np.int64); life = (live[:, 1] >> 32).astype(np.int64)
+                ok = life > 0
+                if ok.any():
+                    mhz = 100.0 * np.median(d[ok] / life[ok])
+                    print(f"  SoC clock: shader clock {mhz:.0f} MHz; workgroup starts spread over {(w0.max() - w0.min()) / 100:.2f} us; lifetime median {np.median(life) / 100:.2f} "
+                          f"max {life.max() / 100:.2f} us; first start -> last end of the main loop {((w0 + life).max() - w0.min()) / 100:.2f} us; "
+                          f"prologue median {np.median(live[:, 4] - live[:, 2]) / mhz:.2f} us")
+                    starts = np.sort(w0 - w0.min()) / 100
+                    print("  start time of workgroup number 0/64/128/256/384/last (us):", [round(float(starts[min(i, len(starts) - 1)]), 2) for i in (0, 64, 128, 256, 384, len(starts) - 1)])
                 ends = np.sort(live[:, 3] - t_first)
                 print("  workgroups still running at 25/50/75/90 % of the span:", [int((ends > q * (t_last - t_first)).sum()) for q in (0.25, 0.5, 0.75, 0.9)])
             tr = full[:nblk]
