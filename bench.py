@@ -1171,18 +1171,25 @@ def main():
             beat("step")
         dist_utils.barrier()
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
+        t1, h1 = time.perf_counter(), time.thread_time()
         for i in range(k):
             step.inline(args.warmup + args.steps + warm + i, **kw)
             beat("step")
+        leg_host_ms.append((time.thread_time() - h1) / k * 1e3)   # CPU time of the stepping thread up to the last launch
         dist_utils.barrier()
         torch.cuda.synchronize()
         return dist_utils.max_over_ranks(time.perf_counter() - t1, device) / k
     inline_s = refstyle_s = boundary_s = None
+    leg_host_ms = []
+    only = os.environ.get("FV2P_BENCH_LEG", "")   # profiling runs: "boundary" / "inline" times that leg alone
     if fv2p and args.impl == "native" and not args.dry_run:
         if args.inline_steps > 0:
-            inline_s = extra_leg(args.inline_steps, 2)
-            boundary_s = extra_leg(args.inline_steps, 2, boundary=True)
+            if only != "boundary":
+                inline_s = extra_leg(args.inline_steps, 2)
+            if only != "inline":
+                boundary_s = extra_leg(args.inline_steps, 2, boundary=True)
+            if rank == 0:
+                print(f"[bench] host thread ms per step of the extra legs: {[round(v, 2) for v in leg_host_ms]}", file=sys.stderr, flush=True)
         if args.refstyle_steps > 0 and args.workload == "fv2p":
             refstyle_s = extra_leg(args.refstyle_steps, 2, reference=True)
     if args.workload == "mgaf" and args.refstyle_steps > 0 and not args.dry_run:

@@ -1397,71 +1397,151 @@ __global__ void three_interp_stack_grad_k(int64_t total, int c, const float* __r
 }
 
 // Gradient of the stack interpolation WITHOUT float atomics, in a FIXED order (round 4).  The (query, slot) entries e = 3 * query + slot
-// are keyed (known row << 32 | e) and radix-sorted: every row's entries are then contiguous and in ascending e, whatever the hardware
-// did.  A group of lanes per known row (one lane = four channels) finds its run by binary search and sums it - rows nobody reads get
-// their zero from the same store (no fill launch), a row read by thousands of queries is walked by one group with every channel in
-// parallel (round 3's form, one THREAD per (row, channel) walking entry lists built with atomics, lost 5 x on such rows and summed in
-// an arbitrary order).
+// are keyed (known row << 32 | e) and radix-sorted (stable, by the row bits): every row's entries are then one contiguous run in ascending
+// e, whatever the hardware did.  The sorted sequence is cut into SEGMENTS of kInterpSeg entries, one lane group each (one lane = four
+// channels): a run that lies inside one segment is summed and stored directly; a run that crosses segment borders leaves one partial sum
+// per segment, and the group of the segment the run STARTS in adds the partials of the following segments in segment order.  The work per
+// group is bounded whatever the list lengths (a row read by thousands of queries is hundreds of segments summed in parallel, then one
+// short walk over their partials) and the association of every sum is a function of the sorted positions only: bit-identical from run to
+// run.  (The first form of this round, one group per ROW walking its run, took 1.3 - 1.8 ms at the decoder's shapes when a few rows
+// held thousands of entries; round 3's per-(row, channel) THREAD lists, filled with atomics, summed in an arbitrary order.)
+constexpr int kInterpSeg = 32;
 __global__ void interp_keys_k(int64_t entries, int m, const int* __restrict__ idx, uint64_t* __restrict__ keys) {
   const int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (e >= entries) return;
   const int r = idx[e];
   keys[e] = (static_cast<uint64_t>(r >= 0 && r < m ? r : m) << 32) | static_cast<uint64_t>(e);   // out-of-range rows sort behind every row
 }
-// TPR lanes per row (power of two, <= 64), each lane four channels per pass
-template <int TPR>
-__global__ __launch_bounds__(256) void interp_gather_sorted_k(int m, int c, int64_t entries, const uint64_t* __restrict__ keys,
-                                                              const float* __restrict__ grad_out, const float* __restrict__ weight,
-                                                              float* __restrict__ grad_features) {
-  const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-  const int64_t row = t / TPR;
-  const int sub = static_cast<int>(t % TPR);
-  if (row >= m) return;
-  // first entry of the row: lower bound of (row << 32)
-  const uint64_t want = static_cast<uint64_t>(row) << 32;
-  int64_t lo = 0, hi = entries;
-  while (lo < hi) {
-    const int64_t mid = (lo + hi) >> 1;
-    if (keys[mid] < want) lo = mid + 1; else hi = mid;
+// Segment flags: bit 0 the segment's first run continues a run of the segment before (its sum is part[s][0]); bit 1 that run also
+// goes on into the next segment; bit 2 the segment's last run starts here and goes on (its sum is part[s][1]).
+struct Vec4 { float v[4]; };
+__device__ __forceinline__ void interp_store4(float* out, const Vec4& a, bool vec, int c0, int c) {
+  if (vec) *reinterpret_cast<float4*>(out) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+  else {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (c0 + u < c) out[u] = a.v[u];
   }
+}
+__device__ __forceinline__ Vec4 interp_load4(const float* p, bool vec, int c0, int c) {
+  Vec4 r;
+  if (vec) { const float4 q = *reinterpret_cast<const float4*>(p); r.v[0] = q.x; r.v[1] = q.y; r.v[2] = q.z; r.v[3] = q.w; }
+  else {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) r.v[u] = c0 + u < c ? p[u] : 0.f;
+  }
+  return r;
+}
+// TPR lanes per segment (power of two, <= 64), each lane four channels per pass
+template <int TPR>
+__global__ __launch_bounds__(256) void interp_seg_k(int m, int c, int64_t entries, const uint64_t* __restrict__ keys,
+                                                    const float* __restrict__ grad_out, const float* __restrict__ weight,
+                                                    float* __restrict__ grad_features, float* __restrict__ part, int* __restrict__ flags) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const int64_t s = t / TPR;
+  const int sub = static_cast<int>(t % TPR);
+  const int64_t i0 = s * kInterpSeg;
+  if (i0 >= entries) return;
+  const int64_t i1 = i0 + kInterpSeg < entries ? i0 + kInterpSeg : entries;
+  const uint32_t prev = i0 > 0 ? static_cast<uint32_t>(keys[i0 - 1] >> 32) : 0xffffffffu;      // rows are < 2^31: never equal to these two
+  const uint32_t next = i1 < entries ? static_cast<uint32_t>(keys[i1] >> 32) : 0xfffffffeu;
+  const uint32_t um = static_cast<uint32_t>(m);
+  int fl = 0;
   for (int c0 = 4 * sub; c0 < c; c0 += 4 * TPR) {
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     const bool vec = c0 + 3 < c && (c & 3) == 0;
-    int64_t i = lo;
-    for (;;) {
-      // four entries of the run in flight
+    Vec4 acc = {{0.f, 0.f, 0.f, 0.f}};
+    uint32_t cur = static_cast<uint32_t>(keys[i0] >> 32);
+    bool at_start = true;
+    auto flush = [&](bool at_end) {
+      if (cur >= um) return;   // entries whose idx is out of range sort behind every row and count for nothing
+      const bool from_prev = at_start && cur == prev, to_next = at_end && cur == next;
+      if (!from_prev && !to_next) interp_store4(grad_features + static_cast<int64_t>(cur) * c + c0, acc, vec, c0, c);
+      else if (from_prev) { interp_store4(part + (s * 2 + 0) * c + c0, acc, vec, c0, c); fl |= to_next ? 3 : 1; }
+      else { interp_store4(part + (s * 2 + 1) * c + c0, acc, vec, c0, c); fl |= 4; }
+    };
+    for (int64_t i = i0; i < i1; i += 4) {
+      // four entries in flight
       uint64_t k[4];
-      bool ok[4];
+      bool in[4], ok[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        k[u] = i + u < entries ? keys[i + u] : ~0ull;
-        ok[u] = (k[u] >> 32) == static_cast<uint64_t>(row);
+        in[u] = i + u < i1;
+        k[u] = in[u] ? keys[i + u] : ~0ull;
+        ok[u] = in[u] && static_cast<uint32_t>(k[u] >> 32) < um;
       }
-      float4 v[4];
+      Vec4 v[4];
       float w[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const uint32_t e = static_cast<uint32_t>(k[u]);
         w[u] = ok[u] ? weight[e] : 0.f;
-        const float* p = grad_out + static_cast<int64_t>(ok[u] ? e / 3 : 0) * c + c0;
-        if (vec) v[u] = *reinterpret_cast<const float4*>(p);
-        else { v[u].x = p[0]; v[u].y = c0 + 1 < c ? p[1] : 0.f; v[u].z = c0 + 2 < c ? p[2] : 0.f; v[u].w = c0 + 3 < c ? p[3] : 0.f; }
+        v[u] = interp_load4(grad_out + static_cast<int64_t>(ok[u] ? e / 3 : 0) * c + c0, vec, c0, c);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
-        if (ok[u]) {   // ascending e: the order is part of the result
-          acc[0] = __builtin_fmaf(w[u], v[u].x, acc[0]); acc[1] = __builtin_fmaf(w[u], v[u].y, acc[1]);
-          acc[2] = __builtin_fmaf(w[u], v[u].z, acc[2]); acc[3] = __builtin_fmaf(w[u], v[u].w, acc[3]);
-        }
-      if (!ok[3]) break;
-      i += 4;
-    }
-    float* out = grad_features + row * c + c0;
-    if (vec) *reinterpret_cast<float4*>(out) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    else {
+        if (in[u]) {   // ascending e inside a run: the order is part of the result
+          const uint32_t row = static_cast<uint32_t>(k[u] >> 32);
+          if (row != cur) {
+            flush(false);
+            cur = row; at_start = false;
+            acc = Vec4{{0.f, 0.f, 0.f, 0.f}};
+          }
+          if (ok[u]) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) if (c0 + u < c) out[u] = acc[u];
+            for (int q = 0; q < 4; ++q) acc.v[q] = __builtin_fmaf(w[u], v[u].v[q], acc.v[q]);
+          }
+        }
     }
+    flush(true);
+  }
+  if (sub == 0) flags[s] = fl;
+}
+// the runs that cross segment borders: the group of the segment a run starts in adds the following segments' partial sums, in order
+template <int TPR>
+__global__ __launch_bounds__(256) void interp_fix_k(int c, int64_t entries, int64_t segments, const uint64_t* __restrict__ keys,
+                                                    const float* __restrict__ part, const int* __restrict__ flags,
+                                                    float* __restrict__ grad_features) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+  const int64_t s = t / TPR;
+  const int sub = static_cast<int>(t % TPR);
+  if (s >= segments || !(flags[s] & 4)) return;
+  const int64_t i1 = (s + 1) * kInterpSeg < entries ? (s + 1) * kInterpSeg : entries;
+  const int64_t row = static_cast<int64_t>(keys[i1 - 1] >> 32);
+  // how far the run goes: segments s + 1 .. s + len (flags only, sixteen in flight; the last segment of the sequence never goes on)
+  int64_t len = 0;
+  for (bool open = true; open;) {
+    int f[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { const int64_t q = s + 1 + len + u; f[u] = q < segments ? flags[q] : 0; }
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (open) { ++len; open = (f[u] & 2) != 0; }
+  }
+  if (s + len >= segments) len = segments - 1 - s;   // (cannot happen on a consistent flag array)
+  for (int c0 = 4 * sub; c0 < c; c0 += 4 * TPR) {
+    const bool vec = c0 + 3 < c && (c & 3) == 0;
+    Vec4 acc = interp_load4(part + (s * 2 + 1) * c + c0, vec, c0, c);
+    // the partial sums in segment order, the next eight on their way while eight are added (their count is known: no load waits for a flag)
+    auto load8 = [&](int64_t j0, Vec4 (&p)[8]) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t q = s + 1 + (j0 + u < len ? j0 + u : len - 1);
+        p[u] = interp_load4(part + (q * 2 + 0) * c + c0, vec, c0, c);
+      }
+    };
+    Vec4 cur[8], nxt[8];
+    load8(0, cur);
+    for (int64_t j0 = 0; j0 < len; j0 += 8) {
+      if (j0 + 8 < len) load8(j0 + 8, nxt);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (j0 + u < len) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc.v[j] += cur[u].v[j];
+        }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+    }
+    interp_store4(grad_features + row * c + c0, acc, vec, c0, c);
   }
 }
 
@@ -1785,10 +1865,12 @@ extern "C" int fv2p_three_interpolate_stack_grad(int n, int c, const float* grad
   FV2P_LAUNCH_CHECK();
   return 0;
 }
-extern "C" size_t fv2p_three_interpolate_stack_grad_ws_bytes(int n, int m) {
+extern "C" size_t fv2p_three_interpolate_stack_grad_ws_bytes(int n, int c, int m) {
   const size_t entries = static_cast<size_t>(n > 0 ? n : 1) * 3;
+  const size_t segments = (entries + kInterpSeg - 1) / kInterpSeg;
   (void)m;
-  return 2 * align_up(entries * sizeof(uint64_t)) + align_up(radix_sort_ws_bytes(static_cast<int64_t>(entries)));
+  return 2 * align_up(entries * sizeof(uint64_t)) + align_up(radix_sort_ws_bytes(static_cast<int64_t>(entries))) +
+         align_up(segments * 2 * static_cast<size_t>(c > 0 ? c : 1) * sizeof(float)) + align_up(segments * sizeof(int));
 }
 extern "C" int fv2p_three_interpolate_stack_grad_gather(int n, int c, int m, const float* grad_out, const int* idx, const float* weight,
                                                         float* grad_features, void* ws, size_t ws_bytes, fv2p_stream_t s) {
@@ -1797,24 +1879,31 @@ extern "C" int fv2p_three_interpolate_stack_grad_gather(int n, int c, int m, con
   if (total <= 0) return 0;
   FV2P_REQUIRE(grad_features && (n == 0 || (grad_out && idx && weight)), FV2P_EINVAL, "three_interpolate_stack_grad_gather: null pointer");
   FV2P_REQUIRE(static_cast<int64_t>(n) * 3 < (1ll << 31), FV2P_ELIMIT, "three_interpolate_stack_grad_gather: too many queries");
-  FV2P_REQUIRE(ws && ws_bytes >= fv2p_three_interpolate_stack_grad_ws_bytes(n, m), FV2P_EWORKSPACE, "three_interpolate_stack_grad_gather: workspace too small");
+  FV2P_REQUIRE(ws && ws_bytes >= fv2p_three_interpolate_stack_grad_ws_bytes(n, c, m), FV2P_EWORKSPACE, "three_interpolate_stack_grad_gather: workspace too small");
   hipStream_t st = STREAM(s);
   const int64_t entries = static_cast<int64_t>(n) * 3;
+  const int64_t segments = (entries + kInterpSeg - 1) / kInterpSeg;
   Carver cv(ws, ws_bytes);
   uint64_t* keys = cv.take<uint64_t>(static_cast<size_t>(entries > 0 ? entries : 1));
   uint64_t* tmp = cv.take<uint64_t>(static_cast<size_t>(entries > 0 ? entries : 1));
   const size_t rb = radix_sort_ws_bytes(entries > 0 ? entries : 1);
   void* rws = cv.take<char>(rb);
-  if (entries > 0) {
-    hipLaunchKernelGGL(interp_keys_k, G1D(entries), 0, st, entries, m, idx, keys);
-    if (int rc = radix_sort_u64(keys, tmp, entries, 32, 32 + bits_for(static_cast<uint64_t>(m)), rws, rb, st)) return rc;
-  }
+  float* part = cv.take<float>(static_cast<size_t>(segments > 0 ? segments : 1) * 2 * c);
+  int* flags = cv.take<int>(static_cast<size_t>(segments > 0 ? segments : 1));
+  FV2P_HIP(hipMemsetAsync(grad_features, 0, static_cast<size_t>(total) * sizeof(float), st));   // rows nobody reads
+  if (entries == 0) return 0;
+  hipLaunchKernelGGL(interp_keys_k, G1D(entries), 0, st, entries, m, idx, keys);
+  if (int rc = radix_sort_u64(keys, tmp, entries, 32, 32 + bits_for(static_cast<uint64_t>(m)), rws, rb, st)) return rc;
   int tpr = 1;
   while (tpr < 64 && tpr * 4 < c) tpr *= 2;
-  const int64_t threads = static_cast<int64_t>(m) * tpr;
-#define FV2P_IG(T) hipLaunchKernelGGL((interp_gather_sorted_k<T>), G1D(threads), 0, st, m, c, entries, keys, grad_out, weight, grad_features)
-  switch (tpr) { case 1: FV2P_IG(1); break; case 2: FV2P_IG(2); break; case 4: FV2P_IG(4); break; case 8: FV2P_IG(8); break;
-                 case 16: FV2P_IG(16); break; case 32: FV2P_IG(32); break; default: FV2P_IG(64); }
+  const int64_t threads = segments * tpr;
+#define FV2P_IG(T)                                                                                                                \
+  {                                                                                                                               \
+    hipLaunchKernelGGL((interp_seg_k<T>), G1D(threads), 0, st, m, c, entries, keys, grad_out, weight, grad_features, part, flags); \
+    hipLaunchKernelGGL((interp_fix_k<T>), G1D(threads), 0, st, c, entries, segments, keys, part, flags, grad_features);            \
+  }
+  switch (tpr) { case 1: FV2P_IG(1) break; case 2: FV2P_IG(2) break; case 4: FV2P_IG(4) break; case 8: FV2P_IG(8) break;
+                 case 16: FV2P_IG(16) break; case 32: FV2P_IG(32) break; default: FV2P_IG(64) }
 #undef FV2P_IG
   FV2P_LAUNCH_CHECK();
   return 0;

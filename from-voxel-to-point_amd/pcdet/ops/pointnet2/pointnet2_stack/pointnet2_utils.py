@@ -91,19 +91,21 @@ def _interp(saved, features, idx, weight):
     return out
 
 
-# The gather form of the interpolation gradient (fv2p_three_interpolate_stack_grad_gather: (row, entry) keys radix-sorted, a lane group
-# per known row sums its run in ascending entry order: no float atomics, no zero fill, BIT-IDENTICAL from run to run) is opt-in
-# (FV2P_INTERP_GATHER=1): it is the deterministic form, not the fast one - eight launches instead of two, and a row read by thousands
-# of queries is walked by one lane group (profiles/r04_op_roofline.txt: 1.2 - 2.1 ms against 0.12 - 0.23 ms of the scatter form on the
-# microbench's random known points, where a few rows hold thousands of entries; a segmented reduction over the sorted keys is the fix).
+# The interpolation gradient from 8192 queries on is the library's gather form (fv2p_three_interpolate_stack_grad_gather: (row, entry)
+# keys radix-sorted, the sorted sequence summed in 32-entry segments, runs that cross segments closed from the partial sums in segment
+# order): no float atomics, no caller-side zero fill, BIT-IDENTICAL from run to run.  profiles/r04_op_roofline.txt: 139 / 155 / 157 us at
+# C = 16 / 64 / 128 against 115 / 250 / 240 us of the scatter form on the microbench's random known points (a few rows hold thousands of
+# entries there: the atomics contend); on the decoder's own lists, where no row is hot, it is the sort that costs (~40 of ~80 us, against
+# ~50 us scatter): +0.5 ms on the 49 ms in-line step, nothing on the scheduled one.  FV2P_INTERP_GATHER=0 selects the scatter form (zero
+# fill + float atomics, the reference's interpolate_gpu.cu:105-160).
 GATHER_GRAD_MIN_QUERIES = 8192
 
 
 def _interp_grad(saved, grad):
     n, c, m = grad.shape[0], grad.shape[1], saved["rows"]
-    if n >= GATHER_GRAD_MIN_QUERIES and os.environ.get("FV2P_INTERP_GATHER", "0") == "1":
+    if n >= GATHER_GRAD_MIN_QUERIES and os.environ.get("FV2P_INTERP_GATHER", "1") != "0":
         g = torch.empty((m, c), dtype=grad.dtype, device=grad.device)
-        ws = G.scratch("fv2p_three_interpolate_stack_grad_ws_bytes", grad.device, n, m)
+        ws = G.scratch("fv2p_three_interpolate_stack_grad_ws_bytes", grad.device, n, c, m)
         G.run("fv2p_three_interpolate_stack_grad_gather", n, c, m, grad.contiguous(), saved["idx"], saved["weight"], g, ws, ws.numel())
         return g
     g = torch.zeros((m, c), dtype=grad.dtype, device=grad.device)

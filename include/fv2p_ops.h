@@ -408,10 +408,11 @@ int fv2p_three_interpolate_stack(int n, int c, const float* features, const int*
 int fv2p_three_interpolate_stack_grad(int n, int c, const float* grad_out, const int* idx, const float* weight,
                                       float* grad_features, fv2p_stream_t stream);
 /* The same gradient without float atomics, without the caller's zero fill and in a FIXED order: the entries e = 3 * query + slot of
- * idx [n, 3] are keyed (known row, e) and radix-sorted in the workspace, then a group of lanes per known row sums its run in ascending e
- * (one lane = four channels).  Bit-identical from run to run; values equal fv2p_three_interpolate_stack_grad's up to the order of each
- * row's sum (the scatter form adds a row's entries in whatever order its atomics land). */
-size_t fv2p_three_interpolate_stack_grad_ws_bytes(int n, int m);
+ * idx [n, 3] are keyed (known row, e) and radix-sorted in the workspace; the sorted sequence is summed in segments of 32 entries (a lane
+ * group each, one lane = four channels), runs that cross segment borders are closed from the segments' partial sums in segment order.
+ * Bit-identical from run to run; values equal fv2p_three_interpolate_stack_grad's up to the association of each row's sum (the scatter
+ * form adds a row's entries in whatever order its atomics land). */
+size_t fv2p_three_interpolate_stack_grad_ws_bytes(int n, int c, int m);
 int fv2p_three_interpolate_stack_grad_gather(int n, int c, int m, const float* grad_out, const int* idx, const float* weight,
                                              float* grad_features, void* ws, size_t ws_bytes, fv2p_stream_t stream);
 

@@ -331,12 +331,12 @@ def test_three_nn_grid_is_the_scan_at_waymo_size(gpu, stride, monkeypatch):
     assert torch.equal(i0, i1) and torch.equal(d0, d1)
 
 
-@pytest.mark.parametrize("n,m,c", [(49152, 35146, 16), (49152, 5186, 128), (9000, 700, 64), (10, 5, 4)])
+@pytest.mark.parametrize("n,m,c", [(49152, 35146, 16), (49152, 5186, 128), (9000, 700, 64), (9001, 333, 67), (10, 5, 4)])
 def test_interpolation_gradient_gather_form_equals_the_scatter_form(gpu, n, m, c, monkeypatch):
-    """fv2p_three_interpolate_stack_grad_gather (entry lists per known row, no float atomics, no zero fill) against the oracle's
-    float64 accumulation and against the scatter form, at the decoder's shapes: rows nobody reads come out exactly zero, rows read
-    by hundreds of queries (a skewed idx) agree to 1e-5 relative; through the autograd op FV2P_INTERP_GATHER=1 selects it (the default
-    stays the scatter form: the gather form measured slower on skewed lists)."""
+    """fv2p_three_interpolate_stack_grad_gather (sorted (row, entry) keys summed in segments; no float atomics, no zero fill) against the
+    oracle's float64 accumulation and against the scatter form, at the decoder's shapes: rows nobody reads come out exactly zero, rows
+    read by thousands of queries (a skewed idx: runs that cross many segments) agree to 1e-5 relative, two calls agree bit for bit; through
+    the autograd op it is the default from 8192 queries on, FV2P_INTERP_GATHER=0 selects the scatter form."""
     import fv2p_native
     rng = np.random.default_rng(n + c)
     idx = rng.integers(0, m, (n, 3)).astype(np.int32)
@@ -350,9 +350,12 @@ def test_interpolation_gradient_gather_form_equals_the_scatter_form(gpu, n, m, c
         np.add.at(want, idx[:, k], g.astype(np.float64) * w[:, k:k + 1])
     tg, ti, tw = T(g, gpu), T(idx, gpu), T(w, gpu)
     out = torch.full((m, c), 7.0, device=gpu)                              # no zero fill expected of the caller
-    ws = torch.empty(int(fv2p_native.lib().fv2p_three_interpolate_stack_grad_ws_bytes(n, m)), dtype=torch.uint8, device=gpu)
+    ws = torch.empty(int(fv2p_native.lib().fv2p_three_interpolate_stack_grad_ws_bytes(n, c, m)), dtype=torch.uint8, device=gpu)
     fv2p_native.call("fv2p_three_interpolate_stack_grad_gather", n, c, m, tg, ti, tw, out, ws, ws.numel(), fv2p_native.stream())
     got = out.cpu().numpy()
+    out2 = torch.full((m, c), -3.0, device=gpu)
+    fv2p_native.call("fv2p_three_interpolate_stack_grad_gather", n, c, m, tg, ti, tw, out2, ws, ws.numel(), fv2p_native.stream())
+    assert torch.equal(out, out2)                                          # fixed association: bit-identical from call to call
     scale = np.abs(want).max()
     assert np.abs(got - want).max() < 1e-5 * scale
     if unread.size:

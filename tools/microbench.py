@@ -504,8 +504,8 @@ def oproof():
         add(f"three_interpolate grad {nu} x C={ch}", t, 4.0 * ch * (3 * nu + nu) + 24.0 * nu, note="scatter form: zero fill + float atomics")
         os.environ["FV2P_INTERP_GATHER"] = "1"
         t = timeit(lambda: out.backward(g, retain_graph=True), reps=10, warm=2)
-        os.environ["FV2P_INTERP_GATHER"] = "0"
-        add(f"three_interpolate grad {nu} x C={ch}, gather form", t, 4.0 * ch * (3 * nu + nu) + 24.0 * nu, note="sorted (row, entry) keys + a lane group per row: no float atomics, fixed order")
+        os.environ.pop("FV2P_INTERP_GATHER")
+        add(f"three_interpolate grad {nu} x C={ch}, gather form", t, 4.0 * ch * (3 * nu + nu) + 24.0 * nu, note="sorted (row, entry) keys summed in 32-entry segments: no float atomics, fixed order")
     # batch grouping at the RoI head's shape: 384 RoIs x 512 points, 216 centres, 16 / 32 samples, C = 64 + 3
     r, n, mc, ch = 384, 512, 216, 67
     xyz = torch.rand(r, n, 3, device=dev)
