@@ -362,27 +362,59 @@ __global__ __launch_bounds__(kSaBwdWaves * 64) void sa_grid_bwd_k(int n, int m, 
 #pragma unroll
     for (int bc = 0; bc < 4; ++bc) dw[bb][bc] = f32x4{0.f, 0.f, 0.f, 0.f};
   constexpr int s = TILES * 16;
-  for (int i = wave; i < m; i += kSaBwdWaves) {
-    const float* q = Q + (static_cast<long long>(r) * m + i) * kSaC + 4 * g;
-    float4 qv[4];
+  // A centre's inputs come from two dependent rounds of global loads (its sample list, then the rows the list names): ~2 x 2 us that
+  // nothing covered while the centre's own work is 2 - 4 k clocks of matrix pipe - the round-3 kernel spent 13.8 k clocks per centre and
+  // wave.  Now they are two centres deep in flight: while centre i multiplies, the rows / centre vector / arg bytes / gradient of centre
+  // i + W and the sample list of centre i + 2 W are on their way (W = waves of the workgroup).  The prefetches are issued AFTER the
+  // current centre's operands have been consumed into x[][], so that the wait in front of that use has only loads of the iteration
+  // before to wait for.
+  struct Staged { float4 qv[4], gd[4], praw[TILES][4]; uint32_t who[4]; int src[TILES]; };
+  auto centre_of = [&](int i) { return static_cast<long long>(r) * m + (i < m ? i : m - 1); };   // past the end: the last centre again (never used)
+  auto load_list = [&](int i, int (&src)[TILES]) {
+    const int* id = idx + centre_of(i) * s;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) qv[j] = *reinterpret_cast<const float4*>(q + 16 * j);
-    const int* id = idx + (static_cast<long long>(r) * m + i) * s;
-    const unsigned char* am = arg + (static_cast<long long>(r) * m + i) * kSaC + 4 * g;
-    const float* go = dout + (static_cast<long long>(r) * m + i) * kSaC + 4 * g;
+    for (int t = 0; t < TILES; ++t) src[t] = id[16 * t + row];
+  };
+  auto load_rows = [&](int i, Staged& c) {   // c.src holds the list already
+    const long long ctr = centre_of(i);
+    const float* q = Q + ctr * kSaC + 4 * g;
+    const unsigned char* am = arg + ctr * kSaC + 4 * g;
+    const float* go = dout + ctr * kSaC + 4 * g;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      c.qv[j] = *reinterpret_cast<const float4*>(q + 16 * j);
+      c.who[j] = *reinterpret_cast<const uint32_t*>(am + 16 * j);
+      c.gd[j] = *reinterpret_cast<const float4*>(go + 16 * j);
+    }
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+      const float* p = Pr + static_cast<long long>(c.src[t]) * kSaC + 4 * g;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) c.praw[t][j] = *reinterpret_cast<const float4*>(p + 16 * j);
+    }
+  };
+  Staged cur, nxt;
+  int list2[TILES];
+  load_list(wave, cur.src);
+  load_rows(wave, cur);
+  load_list(wave + kSaBwdWaves, nxt.src);
+  for (int i = wave; i < m; i += kSaBwdWaves) {
     uint32_t who[4];   // byte e of who[b]: the sample that attained the maximum of channel 16 b + 4 g + e (255: none)
     float4 gd[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) { who[b] = *reinterpret_cast<const uint32_t*>(am + 16 * b); gd[b] = *reinterpret_cast<const float4*>(go + 16 * b); }
     float4 x[TILES][4];
     int src[TILES];
 #pragma unroll
-    for (int t = 0; t < TILES; ++t) {
-      src[t] = id[16 * t + row];
-      const float* p = Pr + static_cast<long long>(src[t]) * kSaC + 4 * g;
+    for (int b = 0; b < 4; ++b) { who[b] = cur.who[b]; gd[b] = cur.gd[b]; }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) x[t][j] = relu_sub(*reinterpret_cast<const float4*>(p + 16 * j), qv[j]);
+    for (int t = 0; t < TILES; ++t) {
+      src[t] = cur.src[t];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[t][j] = relu_sub(cur.praw[t][j], cur.qv[j]);
     }
+    __builtin_amdgcn_sched_barrier(0);   // the prefetches stay behind the use above
+    load_rows(i + kSaBwdWaves, nxt);
+    load_list(i + 2 * kSaBwdWaves, list2);
+    __builtin_amdgcn_sched_barrier(0);
     // pass 2 per tile: dh2, dh1 = (W2^T dh2) * [h1 > 0], scatter / reduce, dW2 += dh2^T h1
     float dq[2][4];
 #pragma unroll
@@ -458,6 +490,9 @@ __global__ __launch_bounds__(kSaBwdWaves * 64) void sa_grid_bwd_k(int n, int m, 
       *reinterpret_cast<float4*>(dqo) = make_float4(-flat[0], -flat[1], -flat[2], -flat[3]);
       *reinterpret_cast<float4*>(dqo + 16) = make_float4(-flat[4], -flat[5], -flat[6], -flat[7]);
     }
+    cur = nxt;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) nxt.src[t] = list2[t];
   }
   __syncthreads();
   // flush dP (each (RoI, half) tile is owned by this workgroup: plain stores)
@@ -487,14 +522,23 @@ __global__ __launch_bounds__(kSaBwdWaves * 64) void sa_grid_bwd_k(int n, int m, 
   }
 }
 
-// dW2[c'][c] = sum over RoIs of the partial tiles (fixed order: deterministic)
-__global__ void sa_grid_dw_reduce_k(int rois, const float* __restrict__ partial, float* __restrict__ dW2) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= kSaC * kSaC) return;
-  const int cp = t / kSaC, c = t % kSaC, half = cp / 32, lr = cp % 32;
+// dW2[c'][c] = sum over RoIs of the partial tiles: the tiles are one [rois][64 * 64] matrix (row r = the two half tiles of RoI r), the
+// result its column sums.  A workgroup owns 16 columns; its 256 threads are 16 row groups x 16 columns, a thread adds the rows
+// rg, rg + 16, ... in ascending order and the 16 group sums are added in group order: a fixed association (deterministic).  (One
+// thread per column walking all the rows, the round-3 form, took 98 us at 384 RoIs - a fifth of the backward kernel beside it.)
+__global__ __launch_bounds__(256) void sa_grid_dw_reduce_k(int rois, const float* __restrict__ partial, float* __restrict__ dW2) {
+  __shared__ float part[16][17];
+  const int col = blockIdx.x * 16 + (threadIdx.x & 15), rg = threadIdx.x >> 4;
   float s = 0.f;
-  for (int r = 0; r < rois; ++r) s += partial[((static_cast<long long>(r) * 2 + half) * 32 + lr) * kSaC + c];
-  dW2[t] = s;
+  for (int r = rg; r < rois; r += 16) s += partial[static_cast<long long>(r) * (kSaC * kSaC) + col];
+  part[rg][threadIdx.x & 15] = s;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    float v = part[0][threadIdx.x];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) v += part[q][threadIdx.x];
+    dW2[blockIdx.x * 16 + threadIdx.x] = v;
+  }
 }
 
 }  // namespace fv2p
@@ -550,7 +594,7 @@ extern "C" int fv2p_sa_grid_bwd(const float* per_point, const float* per_centre,
   if (s == 16) rc = waves == 8 ? launch(&sa_grid_bwd_k<1, 8>) : launch(&sa_grid_bwd_k<1, 4>);
   else rc = waves == 8 ? launch(&sa_grid_bwd_k<2, 8>) : launch(&sa_grid_bwd_k<2, 4>);
   if (rc) return rc;
-  hipLaunchKernelGGL(sa_grid_dw_reduce_k, dim3(16), dim3(256), 0, stream, rois, partial, grad_w2);
+  hipLaunchKernelGGL(sa_grid_dw_reduce_k, dim3(kSaC * kSaC / 16), dim3(256), 0, stream, rois, partial, grad_w2);
   FV2P_LAUNCH_CHECK();
   return 0;
 }
