@@ -103,6 +103,7 @@ class FV2PWaymoConfig(FV2PConfig):
 # fv2p_harness.refstyle.reference_call_structure() switches to (the batch kernels of csrc/targets.hip have no counterpart in the
 # reference, whose Python does this work op by op)
 KERNEL_GLUE = True
+LINEAR_CHUNK_ROWS = 1024   # run_rows: rows per chunk of a chunked Linear (see there)
 FULL_NMS = False   # refstyle.py: nms_gpu without the NMS_CONFIG keywords = every survivor computed, as the reference's kernel does
 _SIDE_STREAMS = {}
 _CONSTS = {}
@@ -227,6 +228,13 @@ def run_rows(seq, x):
             relu = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU) else None
             x = bn_act(m, x, relu)
             i += 1 + (relu is not None)
+        elif (KERNEL_GLUE and type(m) is nn.Linear and x.dim() == 2 and x.is_cuda and x.shape[0] >= 4 * LINEAR_CHUNK_ROWS
+              and x.shape[0] % LINEAR_CHUNK_ROWS == 0 and "forward" not in m.__dict__):
+            # the same product in chunks of rows (rows_linear): autograd then forms the weight gradient as one batched product over the
+            # chunks (K = 1024 each) and sums them, instead of ONE product with K = 49 152 rows and a 128 .. 256-wide output - eight to
+            # sixteen output tiles on 256 CUs, 130 - 200 us each, 14 of them per step (profiles/r04_fv2p_kernel_stats.csv, `Cijk_Ailk_Bjlk`)
+            x = rows_linear(x.reshape(-1, LINEAR_CHUNK_ROWS, x.shape[1]), m.weight, m.bias).reshape(x.shape[0], -1)
+            i += 1
         else:
             x = m(x)
             i += 1
