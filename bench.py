@@ -264,6 +264,10 @@ def build_step(args, device, rank, world):
     if args.workload == "mgaf":   # BASELINE configs[3]: sparse backbone + DCN BEV backbone + centre head (fv2p_harness/mgaf_model.py)
         from fv2p_harness.mgaf_model import MGAFDetector
         model = MGAFDetector().to(device)
+        if args.bev_channels_last:
+            model.backbone_2d.to(memory_format=torch.channels_last)
+            model.dense_head.to(memory_format=torch.channels_last)
+            model.bev_channels_last = True
     else:
         cls = VoxelBackBone8x if args.backbone == "8x" else VoxelResBackBone8x
         model = cls(4, [1408, 1600, 40]).to(device)

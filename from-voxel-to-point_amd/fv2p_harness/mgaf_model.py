@@ -343,6 +343,8 @@ class MGAFDetector(nn.Module):
         out, _ = self.backbone_3d(voxel_features, voxel_coords, batch_size)
         dense = out.dense()
         spatial = dense.view(batch_size, dense.shape[1] * dense.shape[2], dense.shape[3], dense.shape[4])
+        if getattr(self, "bev_channels_last", False):   # bench.py --bev-channels-last: the 2-D part in NHWC (the DCN kernels' layout)
+            spatial = spatial.contiguous(memory_format=torch.channels_last)
         preds = self.dense_head(self.backbone_2d(spatial))
         if gt_boxes is None:
             return sum(p.square().mean() for p in preds.values())

@@ -17,6 +17,10 @@ def _geom(input, weight, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, d
     return (B, H, W, C, Cout, Ho, Wo, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, deformable_group)
 
 
+def _channels_last(t):
+    return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous()
+
+
 def _to_nhwc(t):
     """[B, C, H, W] (any strides) -> contiguous fp32 [B, H, W, C]: a view for a channels-last tensor, the library's tiled transpose for a
     contiguous one (torch's generic strided copy moves these 70 - 150 MB per DCN layer at a fraction of the bandwidth)."""
@@ -69,12 +73,15 @@ def _forward_nhwc(x, weight, bias, offset, mask, g):
 def modulated_deform_conv_forward(input, weight, bias, offset, mask, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w,
                                   dilation_h, dilation_w, group, deformable_group, im2col_step):
     """-> output [B, Cout, Ho, Wo] (contiguous NCHW, as modulated_deform_conv_cuda.cu:118). im2col_step is accepted and
-    irrelevant: the forward has no columns buffer to chunk.  (A channels-last `input` is taken as it is: no copy.)"""
+    irrelevant: the forward has no columns buffer to chunk.  A channels-last `input` is taken as it is and the output is channels-last
+    too (the kernels' own layout: no copy on either side); grad_input follows the input's format likewise."""
     g = _geom(input, weight, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dilation_h, dilation_w, group, deformable_group)
     B, H, W, C, Cout, Ho, Wo = g[:7]
     x = _to_nhwc(input)
-    y = _forward_nhwc(x, weight, bias, offset, mask, g)
-    return _to_nchw(y.view(B, Ho, Wo, Cout)).to(input.dtype)
+    y = _forward_nhwc(x, weight, bias, offset, mask, g).view(B, Ho, Wo, Cout)
+    if _channels_last(input):   # as torch's own ops: a channels-last input gets a channels-last output (here: the kernel's layout, no copy)
+        return y.permute(0, 3, 1, 2).to(input.dtype)
+    return _to_nchw(y).to(input.dtype)
 
 
 def modulated_deform_conv_backward(input, weight, bias, offset, mask, grad_output, kernel_h, kernel_w, stride_h, stride_w, pad_h,
@@ -101,7 +108,7 @@ def modulated_deform_conv_backward(input, weight, bias, offset, mask, grad_outpu
         ws = _nat.workspace(nb, dev)
         _nat.call("fv2p_dcn_backward", x, wt, offset.float().contiguous(), mask.float().contiguous(), dy, *g, dx, doff,
                   dmask, dwt, ws, ws.numel(), _nat.stream())
-    grad_input = _to_nchw(dx)
+    grad_input = dx.permute(0, 3, 1, 2) if _channels_last(input) else _to_nchw(dx)
     grad_weight = dwt[:, :, :Cout].reshape(kernel_h, kernel_w, C, Cout).permute(3, 2, 0, 1).contiguous()
     grad_bias = dy[:, :Cout].sum(dim=0)
     return [grad_input, doff, dmask, grad_weight, grad_bias]

@@ -195,3 +195,24 @@ def test_reference_structure_baseline_is_the_same_op(gpu, cin, cout, dg):
         res.append([y.detach(), gx.grad, go.grad, gm.grad, m.weight.grad.clone(), m.bias.grad.clone()])
     for a, b in zip(*res):
         assert rel(b, a) < 1e-3
+
+
+def test_channels_last_input_keeps_its_format(gpu):
+    """A channels-last activation is the kernels' own layout: the layer reads it as it is, returns a channels-last output and a
+    channels-last grad_input (as torch's own convolutions do), with the bits of the contiguous call."""
+    torch.manual_seed(11)
+    B, cin, cout, dg, H, W = 2, 32, 48, 2, 14, 10
+    m = ModulatedDeformConv(cin, cout, 3, stride=1, padding=1, deformable_groups=dg, bias=True).to(gpu)
+    x = torch.randn(B, cin, H, W, device=gpu)
+    offset = torch.randn(B, dg * 18, H, W, device=gpu) * 0.7
+    mask = torch.sigmoid(torch.randn(B, dg * 9, H, W, device=gpu))
+    g = torch.randn(B, cout, H, W, device=gpu)
+    xa = x.clone().requires_grad_(True)
+    ya = m(xa, offset, mask)
+    ya.backward(g)
+    xb = x.clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    yb = m(xb, offset, mask)
+    assert yb.is_contiguous(memory_format=torch.channels_last) and not yb.is_contiguous()
+    yb.backward(g.contiguous(memory_format=torch.channels_last))
+    assert torch.equal(ya, yb) and torch.equal(xa.grad, xb.grad)
+    assert ya.is_contiguous() and xa.grad.is_contiguous()
