@@ -160,6 +160,11 @@ def conv(only=None):
                     print(f"  SoC clock: shader clock {mhz:.0f} MHz; workgroup starts spread over {(w0.max() - w0.min()) / 100:.2f} us; lifetime median {np.median(life) / 100:.2f} "
                           f"max {life.max() / 100:.2f} us; first start -> last end of the main loop {((w0 + life).max() - w0.min()) / 100:.2f} us; "
                           f"prologue median {np.median(live[:, 4] - live[:, 2]) / mhz:.2f} us")
+                    share_n = np.array([per_cu[kk] for kk in key])
+                    for sn in sorted(set(share_n.tolist())):
+                        sel = (share_n == sn) & ok
+                        print(f"  workgroups on CUs holding {sn}: {int(sel.sum())}, lifetime median {np.median(life[sel]) / 100:.2f} us, main-loop MFMA clocks (wave 0) median {np.median(live[sel, 7]):.0f}, "
+                              f"wait clocks median {np.median(live[sel, 5]):.0f}")
                     starts = np.sort(w0 - w0.min()) / 100
                     print("  start time of workgroup number 0/64/128/256/384/last (us):", [round(float(starts[min(i, len(starts) - 1)]), 2) for i in (0, 64, 128, 256, 384, len(starts) - 1)])
                 ends = np.sort(live[:, 3] - t_first)
