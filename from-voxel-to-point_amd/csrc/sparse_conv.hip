@@ -802,6 +802,74 @@ __global__ __launch_bounds__(256) void conv_rows_act(ConvArgs a) {
   }
 }
 
+// ---- thin layers (16 / 32 channels, 27 offsets): a wave, 16 destination rows, nothing staged, nothing shared -------------------------
+// At 16 / 32 channels an offset is 4 / 16 MFMAs per 16 rows: conv_rows_pipe / conv_rows_dma (W_k through LDS, a barrier per offset,
+// gathers one offset ahead) spend their time on the barriers and on exposed gather latency - subm 32 -> 32 at 39 k rows took 35 us with
+// the matrix pipe 0.28 busy.  Here a wave works alone: its 27 table entries are read up front, the rows AND the weight fragment of
+// offset k + 2 are requested (straight from L2 / L1 into registers, 1 - 4 KB per offset) while offset k multiplies, and offsets at which
+// none of the 16 rows has a neighbour skip the MFMAs (wave-uniform; their loads are issued all the same: every iteration has the same
+// loads, so the compiler's counted waits stay exact).  No LDS, no barrier, occupancy limited by registers only.
+// Non-transposed product (rows as A, weights as B): the accumulators have the layout conv_epilogue expects.  B of lane (n, g), k-step
+// (j, t), column tile nb = W_k[16 j + 4 g + t][16 nb + n]: 16 bytes along k in the transposed layout (WT), four dwords otherwise.
+template <int CINP, int NB, bool WT, int KVOL>
+__global__ __launch_bounds__(256) void conv_rows_thin(ConvArgs a) {
+  constexpr int J = CINP / 16, D = 2, NST = D + 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+  const int row0 = (xcd_major_tile(blockIdx.x, gridDim.x) * 4 + wave) * 16;
+  if (row0 >= a.n_dst) return;   // (no barrier in this kernel)
+  const int my_row = row0 + r;
+  const bool row_ok = my_row < a.n_dst;
+  int tv[KVOL];
+#pragma unroll
+  for (int k = 0; k < KVOL; ++k) tv[k] = row_ok ? a.tab[static_cast<long long>(a.flip ? (KVOL - 1 - k) : k) * a.n_dst + my_row] : -1;
+  unsigned live = 0;   // bit k: some row of the wave has a neighbour at offset k
+#pragma unroll
+  for (int k = 0; k < KVOL; ++k) live |= (__ballot(tv[k] >= 0) != 0ull ? 1u : 0u) << k;
+  struct Stage { float4 x[J]; float w[J][NB][4]; };
+  Stage st[NST];
+  auto request = [&](auto k_, Stage& s) {
+    constexpr int k = decltype(k_)::value;
+    const float* p = tv[k] >= 0 ? a.src + static_cast<long long>(tv[k]) * a.ld_src + 4 * g : g_zero_row + 4 * g;
+    const float* wk = a.w + static_cast<long long>(k) * a.w_kstride;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      s.x[j] = *reinterpret_cast<const float4*>(p + 16 * j);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        if constexpr (WT) {
+          const float4 q = *reinterpret_cast<const float4*>(wk + static_cast<long long>(16 * nb + r) * a.w_ld + 16 * j + 4 * g);
+          s.w[j][nb][0] = q.x; s.w[j][nb][1] = q.y; s.w[j][nb][2] = q.z; s.w[j][nb][3] = q.w;
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) s.w[j][nb][t] = wk[static_cast<long long>(16 * j + 4 * g + t) * a.w_ld + 16 * nb + r];
+        }
+      }
+    }
+  };
+  f32x4 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  static_for<0, (D < KVOL ? D : KVOL)>([&](auto k_) { request(k_, st[decltype(k_)::value % NST]); });
+  static_for<0, KVOL>([&](auto k_) {
+    constexpr int k = decltype(k_)::value;
+    if constexpr (k + D < KVOL) request(std::integral_constant<int, k + D>{}, st[(k + D) % NST]);
+    __builtin_amdgcn_sched_barrier(0);   // the requests of k + 2 stay in front of the products of k
+    if ((live >> k) & 1u) {
+      const Stage& s = st[k % NST];
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const float xv[4] = {s.x[j].x, s.x[j].y, s.x[j].z, s.x[j].w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[t], s.w[j][nb][t], acc[nb], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  });
+  conv_epilogue<NB>(a, acc, row0);
+}
+
 // ---- pair-compacted tile with the reduction dimension split over the waves ---------------------------------------------------
 // At the 5-10 pairs per row of the backbones' deep levels an output-stationary 16-row MFMA group is mostly zero rows: of
 // the 27 offsets a tile visits, a row has a neighbour at ~38 % of them, so ~60 % of the MFMA issue slots of conv_rows_dma
@@ -1764,6 +1832,21 @@ static void launch_vec(const ConvArgs& a, hipStream_t s) {
         b.col_blocks = NB / 4;
         if (once) { hipLaunchKernelGGL((conv_rows_ksplit<CINP, WT, 32>), dim3(static_cast<unsigned>(ceil_div(a.n_dst, 32)) * (NB / 4)), dim3(256), lds, s, b); return; }
       }
+    }
+  }
+  if constexpr (CINP == 16 && NB == 1) {
+    // 16 -> 16 with the full 3 x 3 x 3 kernel: one wave per 16 rows, operands straight into registers two offsets ahead.  Measured
+    // (FV2P_RES=1 tools/microbench.py conv, 35 k rows): 13.4 us forward / 11.5 us backward data against 14.9 / 13.5 us of the staged
+    // kernels.  NOT at 32 channels: 49 against 35 us (subm 32 -> 32, 39 k rows), 22.4 against 20.1 us (16 -> 32) - a 4 KB weight
+    // fragment per wave and offset through the vector-memory path costs more than the barrier it removes (LDS staging shares it
+    // between the four waves of a workgroup).
+    static const bool thin_on = [] { const char* e = getenv("FV2P_CONV_THIN"); return !e || atoi(e) != 0; }();
+    const bool whole = a.c_src == CINP && a.c_dst == NB * 16 && (a.ld_src & 3) == 0 && (reinterpret_cast<uintptr_t>(a.src) & 15) == 0 &&
+                       (!WT || ((a.w_ld & 3) == 0 && (a.w_kstride & 3) == 0 && (reinterpret_cast<uintptr_t>(a.w) & 15) == 0));
+    if (impl == 0 && thin_on && whole && a.kvol == 27 && !a.perm) {
+      const unsigned groups = static_cast<unsigned>(ceil_div(a.n_dst, 16));
+      hipLaunchKernelGGL((conv_rows_thin<CINP, NB, WT, 27>), dim3(ceil_div(groups, 4u)), dim3(256), 0, s, a);
+      return;
     }
   }
   if constexpr (CINP * NB <= 512 && (WT || NB % 4 == 0)) {
