@@ -20,6 +20,7 @@
 #include "common.hpp"
 #include <stdlib.h>
 #include <type_traits>
+#include <algorithm>
 
 namespace fv2p {
 
@@ -870,6 +871,84 @@ __global__ __launch_bounds__(256) void conv_rows_thin(ConvArgs a) {
   conv_epilogue<NB>(a, acc, row0);
 }
 
+// ---- thin layers with ALL 27 weight matrices resident in LDS (32 channels: 108 KB, one workgroup of 16 waves per CU) -------------------
+// conv_rows_pipe / conv_rows_dma bring W_k (4 KB at 32 -> 32) into LDS once per offset and 64-row workgroup, with a barrier per offset: at
+// 8.5 pairs per row that is 108 KB of weights through the vector-memory path for 70 KB of gathered rows, and the path's issue rate is what
+// bounds these kernels (see conv_rows_thin).  Here a workgroup stays on its CU: the 27 matrices are laid down in LDS once, in MFMA
+// fragment order, and the 16 waves then walk 16-row groups on their own (conv_rows_thin's loop with the weight fragment read from LDS:
+// table entries up front, rows two offsets ahead, MFMAs skipped where no row has a neighbour, no barrier after the prologue).  Workgroup
+// b takes the b-th of gridDim.x contiguous ranges of groups, XCD-major.
+template <int CINP, int NB, bool WT, int KVOL>
+__global__ __launch_bounds__(1024) void conv_rows_res(ConvArgs a, int groups_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [k][j][nb][lane][4]: B fragment of lane (n, g), k-step (j, t), tile nb at t
+  constexpr int J = CINP / 16, D = 2, NST = D + 1, WSZ = CINP * NB * 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+  for (int e = threadIdx.x; e < KVOL * WSZ; e += 1024) {
+    const int k = e / WSZ, q = e % WSZ;
+    int c, col;
+    if (WT) { col = q / CINP; c = q % CINP; } else { c = q / (NB * 16); col = q % (NB * 16); }   // coalesced in either layout
+    const float v = a.w[static_cast<long long>(k) * a.w_kstride + (WT ? static_cast<long long>(col) * a.w_ld + c : static_cast<long long>(c) * a.w_ld + col)];
+    lds[k * WSZ + ((((c >> 4) * NB + (col >> 4)) * 64) + ((c >> 2) & 3) * 16 + (col & 15)) * 4 + (c & 3)] = v;
+  }
+  __syncthreads();
+  const int groups = (a.n_dst + 15) / 16;
+  const int first = xcd_major_tile(blockIdx.x, gridDim.x) * groups_per_wg;
+  const int last = min(first + groups_per_wg, groups);
+  for (int grp = first + wave; grp < last; grp += 16) {
+    const int row0 = grp * 16, my_row = row0 + r;
+    const bool row_ok = my_row < a.n_dst;
+    int tv[KVOL];
+#pragma unroll
+    for (int k = 0; k < KVOL; ++k) tv[k] = row_ok ? a.tab[static_cast<long long>(a.flip ? (KVOL - 1 - k) : k) * a.n_dst + my_row] : -1;
+    unsigned live = 0;   // bit k: some row of the group has a neighbour at offset k
+#pragma unroll
+    for (int k = 0; k < KVOL; ++k) live |= (__ballot(tv[k] >= 0) != 0ull ? 1u : 0u) << k;
+    float4 x[NST][J];
+    auto request = [&](auto k_, float4 (&dst)[J]) {
+      constexpr int k = decltype(k_)::value;
+      const float* p = tv[k] >= 0 ? a.src + static_cast<long long>(tv[k]) * a.ld_src + 4 * g : g_zero_row + 4 * g;
+#pragma unroll
+      for (int j = 0; j < J; ++j) dst[j] = *reinterpret_cast<const float4*>(p + 16 * j);
+    };
+    f32x4 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    static_for<0, D>([&](auto k_) { request(k_, x[decltype(k_)::value % NST]); });
+    // the weight fragment of offset k + 1 is read from LDS while offset k multiplies (every offset: an LDS read costs less than a branch)
+    float4 bv[2][J][NB];
+    auto fragment = [&](int k, float4 (&dst)[J][NB]) {
+      const float* wk = lds + k * WSZ;
+#pragma unroll
+      for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) dst[j][nb] = *reinterpret_cast<const float4*>(&wk[((j * NB + nb) * 64 + lane) * 4]);
+    };
+    fragment(0, bv[0]);
+    static_for<0, KVOL>([&](auto k_) {
+      constexpr int k = decltype(k_)::value;
+      if constexpr (k + D < KVOL) request(std::integral_constant<int, k + D>{}, x[(k + D) % NST]);
+      if constexpr (k + 1 < KVOL) fragment(k + 1, bv[(k + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);   // the requests of k + 2 and the fragment of k + 1 stay in front of the products of k
+      if ((live >> k) & 1u) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          const float4 xv = x[k % NST][j];
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.x, bv[k & 1][j][nb].x, acc[nb], 0, 0, 0);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.y, bv[k & 1][j][nb].y, acc[nb], 0, 0, 0);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.z, bv[k & 1][j][nb].z, acc[nb], 0, 0, 0);
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.w, bv[k & 1][j][nb].w, acc[nb], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    conv_epilogue<NB>(a, acc, row0);
+  }
+}
+
 // ---- pair-compacted tile with the reduction dimension split over the waves ---------------------------------------------------
 // At the 5-10 pairs per row of the backbones' deep levels an output-stationary 16-row MFMA group is mostly zero rows: of
 // the 27 offsets a tile visits, a row has a neighbour at ~38 % of them, so ~60 % of the MFMA issue slots of conv_rows_dma
@@ -1698,6 +1777,15 @@ static int g_ksplit_auto = 1;   // FV2P_CONV_KSPLIT=0 keeps the round-1 kernels 
 static int g_ksplit_tm = 0;     // FV2P_KSPLIT_TM: rows per tile (32 or 64); 0 = by launch shape
 static int g_ksplit_gps = 0;    // FV2P_KSPLIT_GPS=1: one row group per step at every size (comparison runs)
 static size_t g_ksplit_pad = 0; // FV2P_KSPLIT_PAD: extra dynamic LDS bytes per workgroup (limits the workgroups resident on a CU)
+static int conv_cu_count() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+    else cus = 256;
+  }
+  return cus;
+}
 static int g_wgrad_dma = 1;   // pair-split weight gradient: 1 = LDS-DMA kernel where the shapes allow, 0 = register-staged kernel
 static unsigned long long* g_conv_trace = nullptr;
 static int conv_impl() {
@@ -1831,6 +1919,24 @@ static void launch_vec(const ConvArgs& a, hipStream_t s) {
         static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_ksplit<CINP, WT, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
         b.col_blocks = NB / 4;
         if (once) { hipLaunchKernelGGL((conv_rows_ksplit<CINP, WT, 32>), dim3(static_cast<unsigned>(ceil_div(a.n_dst, 32)) * (NB / 4)), dim3(256), lds, s, b); return; }
+      }
+    }
+  }
+  if constexpr (CINP == 32 && NB <= 2) {
+    // 32 source channels, full 3 x 3 x 3 kernel: every W_k resident in LDS, one persistent workgroup of 16 waves per CU
+    static const bool res_on = [] { const char* e = getenv("FV2P_CONV_RES"); return !e || atoi(e) != 0; }();
+    const bool whole = a.c_src == CINP && a.c_dst == NB * 16 && (a.ld_src & 3) == 0 && (reinterpret_cast<uintptr_t>(a.src) & 15) == 0;
+    constexpr size_t res_lds = static_cast<size_t>(27) * CINP * NB * 16 * sizeof(float);
+    // measured (tools/microbench.py conv): subm 32 -> 32 at 39 k rows 29.4 us forward / 29.4 us backward data against 34.7 / 32.3 us of the
+    // staged kernels; at 286 k rows (Waymo) 170 / 170 against 168 / 156 us - with several groups per wave the staged kernels' shared fragment wins back
+    if (impl == 0 && res_on && whole && a.kvol == 27 && !a.perm && a.n_dst <= 65536) {
+      static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_res<CINP, NB, WT, 27>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
+      if (once) {
+        const int groups = static_cast<int>(ceil_div(a.n_dst, 16));
+        const int wgs = std::min(groups, conv_cu_count());
+        const int per = static_cast<int>(ceil_div(groups, wgs));
+        hipLaunchKernelGGL((conv_rows_res<CINP, NB, WT, 27>), dim3(static_cast<unsigned>(ceil_div(groups, per))), dim3(1024), res_lds, s, a, per);
+        return;
       }
     }
   }
