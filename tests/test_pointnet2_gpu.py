@@ -331,7 +331,7 @@ def test_three_nn_grid_is_the_scan_at_waymo_size(gpu, stride, monkeypatch):
     assert torch.equal(i0, i1) and torch.equal(d0, d1)
 
 
-@pytest.mark.parametrize("n,m,c", [(49152, 35146, 16), (49152, 5186, 128), (9000, 700, 64), (9001, 333, 67), (10, 5, 4)])
+@pytest.mark.parametrize("n,m,c", [(49152, 35146, 16), (49152, 5186, 128), (32768, 200000, 32), (9000, 700, 64), (9001, 333, 67), (10, 5, 4)])
 def test_interpolation_gradient_gather_form_equals_the_scatter_form(gpu, n, m, c, monkeypatch):
     """fv2p_three_interpolate_stack_grad_gather (sorted (row, entry) keys summed in segments; no float atomics, no zero fill) against the
     oracle's float64 accumulation and against the scatter form, at the decoder's shapes: rows nobody reads come out exactly zero, rows
