@@ -64,22 +64,44 @@ __global__ __launch_bounds__(256) void bev_gather_k(const float* __restrict__ im
   }
 }
 
-// gim [B][H*W][C] += weights * gout [B][N][C]
+// gim [B][H*W][C] += weights * gout [B][N][C].  A wave takes kBevRun consecutive points; neighbours with the SAME position (the RoI head's
+// grid points come z-fastest: the six points of a column share x and y, iouguided_roi_head.py:243-255) are summed first, in point order,
+// and reach the map as ONE set of atomics - six times fewer of them on that input, nothing lost on any other.
+constexpr int kBevRun = 8;
 __global__ __launch_bounds__(256) void bev_scatter_k(const float* __restrict__ gout, const float* __restrict__ xs, const float* __restrict__ ys,
                                                      int batch, long long n, int h, int w, int c, float* __restrict__ gim) {
-  const long long p = static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
-  if (p >= static_cast<long long>(batch) * n) return;
+  const long long total = static_cast<long long>(batch) * n;
+  const long long p0 = (static_cast<long long>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * kBevRun;
+  if (p0 >= total) return;
   const int lane = threadIdx.x & 63;
-  const long long b = p / n;
-  const Corners k = bev_corners(xs[p], ys[p], h, w);
-  float* base = gim + b * static_cast<long long>(h) * w * c;
-  const float* g = gout + p * c;
+  float x[kBevRun], y[kBevRun];
+  bool last[kBevRun];   // point u closes a group: the next point is elsewhere (or in another sample, or past the end)
+#pragma unroll
+  for (int u = 0; u < kBevRun; ++u) {
+    const long long q = p0 + u < total ? p0 + u : total - 1;
+    x[u] = xs[q]; y[u] = ys[q];
+  }
+#pragma unroll
+  for (int u = 0; u < kBevRun; ++u)
+    last[u] = u == kBevRun - 1 || p0 + u + 1 >= total || x[u + 1 < kBevRun ? u + 1 : u] != x[u] || y[u + 1 < kBevRun ? u + 1 : u] != y[u] ||
+              (p0 + u + 1) / n != (p0 + u) / n;
   for (int ch = lane; ch < c; ch += 64) {
-    const float v = g[ch];
-    atomicAdd(base + k.a * c + ch, v * k.wa);
-    atomicAdd(base + k.b * c + ch, v * k.wb);
-    atomicAdd(base + k.c * c + ch, v * k.wc);
-    atomicAdd(base + k.d * c + ch, v * k.wd);
+    float acc = 0.f;
+#pragma unroll
+    for (int u = 0; u < kBevRun; ++u) {
+      if (p0 + u < total) {   // uniform
+        acc += gout[(p0 + u) * c + ch];
+        if (last[u]) {        // uniform
+          const Corners k = bev_corners(x[u], y[u], h, w);
+          float* base = gim + ((p0 + u) / n) * static_cast<long long>(h) * w * c;
+          atomicAdd(base + k.a * c + ch, acc * k.wa);
+          atomicAdd(base + k.b * c + ch, acc * k.wb);
+          atomicAdd(base + k.c * c + ch, acc * k.wc);
+          atomicAdd(base + k.d * c + ch, acc * k.wd);
+          acc = 0.f;
+        }
+      }
+    }
   }
 }
 
@@ -183,7 +205,7 @@ extern "C" int fv2p_bev_interp_bwd(const float* grad_out, int batch, int c, int 
   if (n > 0) {
     FV2P_REQUIRE(grad_out && x && y, FV2P_EINVAL, "bev_interp_bwd: null pointer");
     const long long pts = static_cast<long long>(batch) * n;
-    hipLaunchKernelGGL(bev_scatter_k, dim3(static_cast<unsigned>(ceil_div(pts, 4))), dim3(256), 0, stream, grad_out, x, y, batch,
+    hipLaunchKernelGGL(bev_scatter_k, dim3(static_cast<unsigned>(ceil_div(pts, 4 * kBevRun))), dim3(256), 0, stream, grad_out, x, y, batch,
                        static_cast<long long>(n), h, w, c, gim);
   }
   if (channels_first)
