@@ -28,7 +28,9 @@ def _pool(saved, points, point_features, boxes3d, pool_extra_width, num_sampled_
         raise AssertionError("RoIPointPool3d: points must be (B, N, 3)")
     b, n, _ = points.shape
     m, c = boxes3d.shape[1], point_features.shape[2]
-    pooled = torch.zeros((b, m, num_sampled_points, 3 + c), dtype=point_features.dtype, device=point_features.device)
+    # the kernel writes every element (zeros for an empty box): no 100 MB fill in front of it, as the reference needs (:54)
+    alloc = torch.empty if point_features.is_cuda else torch.zeros
+    pooled = alloc((b, m, num_sampled_points, 3 + c), dtype=point_features.dtype, device=point_features.device)
     empty = torch.zeros((b, m), dtype=torch.int32, device=point_features.device)
     G.run("fv2p_roipoint_pool3d", points.contiguous(), _enlarged(boxes3d, pool_extra_width).contiguous(), point_features.contiguous(),
           b, n, m, c, num_sampled_points, pooled, empty)
