@@ -1175,11 +1175,20 @@ def main():
             beat("step")
         dist_utils.barrier()
         torch.cuda.synchronize()
+        leg_prof = None
+        if os.environ.get("FV2P_LEG_PROFILE") and rank == 0:   # diagnostic: cProfile of this leg's host side (stderr)
+            import cProfile
+            leg_prof = cProfile.Profile()
+            leg_prof.enable()
         t1, h1 = time.perf_counter(), time.thread_time()
         for i in range(k):
             step.inline(args.warmup + args.steps + warm + i, **kw)
             beat("step")
         leg_host_ms.append((time.thread_time() - h1) / k * 1e3)   # CPU time of the stepping thread up to the last launch
+        if leg_prof is not None:
+            leg_prof.disable()
+            import pstats
+            pstats.Stats(leg_prof, stream=sys.stderr).sort_stats("tottime").print_stats(45)
         dist_utils.barrier()
         torch.cuda.synchronize()
         return dist_utils.max_over_ranks(time.perf_counter() - t1, device) / k
