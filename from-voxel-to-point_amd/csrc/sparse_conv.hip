@@ -1786,6 +1786,14 @@ static int conv_cu_count() {
   }
   return cus;
 }
+// thin-layer kernels of the auto mode: conv_rows_thin (16 -> 16) and conv_rows_res (32 -> 32 / 32 -> 16, weights resident in LDS).
+// -1 = not read yet (FV2P_CONV_THIN / FV2P_CONV_RES preset them, default on); fv2p_sparse_conv_set_paths() switches them at run time
+// so that the parity tests hold each kernel against the staged kernel it replaces in one process.
+static int g_thin_on = -1, g_res_on = -1;
+static bool path_on(int& flag, const char* env) {
+  if (flag < 0) { const char* e = getenv(env); flag = (!e || atoi(e) != 0) ? 1 : 0; }
+  return flag != 0;
+}
 static int g_wgrad_dma = 1;   // pair-split weight gradient: 1 = LDS-DMA kernel where the shapes allow, 0 = register-staged kernel
 static unsigned long long* g_conv_trace = nullptr;
 static int conv_impl() {
@@ -1924,7 +1932,7 @@ static void launch_vec(const ConvArgs& a, hipStream_t s) {
   }
   if constexpr (CINP == 32 && NB <= 2) {
     // 32 source channels, full 3 x 3 x 3 kernel: every W_k resident in LDS, one persistent workgroup of 16 waves per CU
-    static const bool res_on = [] { const char* e = getenv("FV2P_CONV_RES"); return !e || atoi(e) != 0; }();
+    const bool res_on = path_on(g_res_on, "FV2P_CONV_RES");
     const bool whole = a.c_src == CINP && a.c_dst == NB * 16 && (a.ld_src & 3) == 0 && (reinterpret_cast<uintptr_t>(a.src) & 15) == 0;
     constexpr size_t res_lds = static_cast<size_t>(27) * CINP * NB * 16 * sizeof(float);
     // measured (tools/microbench.py conv): subm 32 -> 32 at 39 k rows 29.4 us forward / 29.4 us backward data against 34.7 / 32.3 us of the
@@ -1946,7 +1954,7 @@ static void launch_vec(const ConvArgs& a, hipStream_t s) {
     // kernels.  NOT at 32 channels: 49 against 35 us (subm 32 -> 32, 39 k rows), 22.4 against 20.1 us (16 -> 32) - a 4 KB weight
     // fragment per wave and offset through the vector-memory path costs more than the barrier it removes (LDS staging shares it
     // between the four waves of a workgroup).
-    static const bool thin_on = [] { const char* e = getenv("FV2P_CONV_THIN"); return !e || atoi(e) != 0; }();
+    const bool thin_on = path_on(g_thin_on, "FV2P_CONV_THIN");
     const bool whole = a.c_src == CINP && a.c_dst == NB * 16 && (a.ld_src & 3) == 0 && (reinterpret_cast<uintptr_t>(a.src) & 15) == 0 &&
                        (!WT || ((a.w_ld & 3) == 0 && (a.w_kstride & 3) == 0 && (reinterpret_cast<uintptr_t>(a.w) & 15) == 0));
     if (impl == 0 && thin_on && whole && a.kvol == 27 && !a.perm) {
@@ -2174,6 +2182,13 @@ extern "C" int fv2p_sparse_conv_set_impl(int impl) {
   FV2P_REQUIRE(impl >= 0 && impl <= 4, FV2P_EINVAL, "impl must be 0 (auto), 1 (dense), 2 (compacted), 3 (pipelined) or 4 (pair-compacted K-split)");
   fv2p::g_conv_impl = impl;
   fv2p::g_wgrad_dma = impl == 0;   // forcing any variant also selects the register-staged pair-split weight gradient
+  return 0;
+}
+
+extern "C" int fv2p_sparse_conv_set_paths(int thin_on, int res_on) {
+  FV2P_REQUIRE(thin_on >= -1 && thin_on <= 1 && res_on >= -1 && res_on <= 1, FV2P_EINVAL, "set_paths: 1 = on, 0 = off, -1 = back to the environment's preset");
+  fv2p::g_thin_on = thin_on;
+  fv2p::g_res_on = res_on;
   return 0;
 }
 

@@ -330,6 +330,7 @@ class MGAFDetector(nn.Module):
         self.backbone_2d = DCNBEVBackbone(cfg, 256)
         self.dense_head = CenterAFHead(cfg, self.backbone_2d.num_bev_features)
         self.taps = None    # set to a dict to collect head maps, targets and loss terms (parity tests)
+        self.iou_peaks = None   # parity tests: the heat-map cells the IoU-score term scores ([B, K]; None = this run's own top K)
         # the reference zero-initialises the offset / mask predictors (all offsets 0 at step 0); a trained net has moved away from
         # that, so the replay starts them at small random values: sampling positions are fractional, as in any later step
         if offset_init_std > 0:
@@ -349,7 +350,7 @@ class MGAFDetector(nn.Module):
         if gt_boxes is None:
             return sum(p.square().mean() for p in preds.values())
         targets = center_targets(gt_boxes, self.cfg, dict(self.cfg.heads)["hm"])
-        loss, terms = center_losses(preds, targets, self.cfg)
+        loss, terms = center_losses(preds, targets, self.cfg, peaks=self.iou_peaks)
         if self.taps is not None:
             self.taps.update(preds=preds, targets=targets, terms=terms)
         return loss

@@ -131,18 +131,33 @@ def indice_pairs(indices, batch_size, spatial_shape, ksize, stride, padding, dil
     return out_ids[:m].copy(), pairs, num
 
 
+def _work_dtype(x):
+    """float32 — the reference's arithmetic — unless the caller hands float64 data: the float64 pass exists only to CALIBRATE the
+    step-level parity tests (tests/f64_calibration.py: how far is a float32 run of this very network from its float64 run), it is
+    never the thing compared bit for bit and never a reference restatement."""
+    import torch
+    if isinstance(x, torch.Tensor):
+        return torch.float64 if x.dtype == torch.float64 else torch.float32
+    return torch.float64 if np.asarray(x).dtype == np.float64 else torch.float32
+
+
+def _np_work_dtype(x):
+    return np.float64 if np.asarray(x).dtype == np.float64 else np.float32
+
+
 def indice_conv(features, filters, pairs, num, n_out, inverse=False, subm=False):
     """spconv_ops.h:260-362 (indiceConv<float>) restated with torch CPU ops: zeros output, subM centre GEMM
     first (:300-304), then k = 0..K-1 gather -> mm -> scatter-add (:308-357).  fp32."""
     import torch
-    feats = torch.as_tensor(features, dtype=torch.float32)
-    w = torch.as_tensor(filters, dtype=torch.float32)
+    dt = _work_dtype(features)
+    feats = torch.as_tensor(features, dtype=dt)
+    w = torch.as_tensor(filters, dtype=dt)
     cin, cout = w.shape[-2], w.shape[-1]
     w = w.reshape(-1, cin, cout)
     pairs_t = torch.as_tensor(np.asarray(pairs)).long()
     num = np.asarray(num)
     kvol = w.shape[0]
-    out = torch.zeros((n_out, cout), dtype=torch.float32)
+    out = torch.zeros((n_out, cout), dtype=dt)
     centre = int(np.argmax(num)) if subm else -1  # spconv_ops.h:272-277
     if subm:
         out = torch.mm(feats, w[centre])
@@ -158,9 +173,10 @@ def indice_conv(features, filters, pairs, num, n_out, inverse=False, subm=False)
 def indice_conv_backward(features, filters, out_bp, pairs, num, inverse=False, subm=False):
     """spconv_ops.h:364-457 restated: dW_k = gather(feat)^T gather(dout); dX[in] += dout[out] W_k^T."""
     import torch
-    feats = torch.as_tensor(features, dtype=torch.float32)
-    w = torch.as_tensor(filters, dtype=torch.float32)
-    g = torch.as_tensor(out_bp, dtype=torch.float32)
+    dt = _work_dtype(features)
+    feats = torch.as_tensor(features, dtype=dt)
+    w = torch.as_tensor(filters, dtype=dt)
+    g = torch.as_tensor(out_bp, dtype=dt)
     cin, cout = w.shape[-2], w.shape[-1]
     w3 = w.reshape(-1, cin, cout)
     pairs_t = torch.as_tensor(np.asarray(pairs)).long()
@@ -415,15 +431,16 @@ def three_nn_stack(unknown, unk_cnt, known, known_cnt):
 
 def three_interpolate_batch(features, idx, weight):
     """interpolate_gpu.cu:84-104: features (B,C,M), idx/weight (B,N,3) -> (B,C,N), fp32 left-to-right sum."""
-    f, w = np.asarray(features, np.float32), np.asarray(weight, np.float32)
+    dt = _np_work_dtype(features)
+    f, w = np.asarray(features, dt), np.asarray(weight, dt)
     idx = np.asarray(idx)
     g = np.take_along_axis(f[:, :, None, :], idx[:, None, :, :].astype(np.int64), axis=3)  # (B,C,N,3)
-    return ((w[:, None, :, 0] * g[..., 0] + w[:, None, :, 1] * g[..., 1]) + w[:, None, :, 2] * g[..., 2]).astype(np.float32)
+    return ((w[:, None, :, 0] * g[..., 0] + w[:, None, :, 1] * g[..., 1]) + w[:, None, :, 2] * g[..., 2]).astype(dt)
 
 
 def group_points_batch(features, idx):
     """group_points_gpu.cu:53-72: features (B,C,N), idx (B,npoint,nsample) -> (B,C,npoint,nsample)."""
-    f = np.asarray(features, np.float32)
+    f = np.asarray(features, _np_work_dtype(features))
     idx = np.asarray(idx).astype(np.int64)
     B, C, N = f.shape
     return np.stack([f[b][:, idx[b]] for b in range(B)], 0)

@@ -43,7 +43,7 @@ def _three_interp_stack_grad(n, c, grad_out, idx, weight, grad_feats, stream):
     acc = np.zeros(tuple(grad_feats.shape), np.float64)
     for k in range(3):
         np.add.at(acc, i[:, k], g * w[:, k:k + 1])
-    _fill(grad_feats, acc.astype(np.float32))
+    _fill(grad_feats, acc)
 
 
 def _three_interp_stack_grad_gather(n, c, m, grad_out, idx, weight, grad_feats, ws, ws_bytes, stream):
@@ -101,7 +101,7 @@ def _group_batch_grad(b, c, n, npoints, nsample, grad_out, idx, grad_points, str
     acc = np.zeros((b, c, n), np.float64)
     for s in range(b):
         np.add.at(acc[s].T, i[s], g[s].T)
-    _fill(grad_points, acc.astype(np.float32))
+    _fill(grad_points, acc)
 
 
 def _bev_fwd(bev, b, c, h, w, channels_first, x, y, n, out, ws, ws_bytes, stream):
@@ -134,7 +134,7 @@ def _three_interp_batch_grad(b, c, n, m, grad_out, idx, weight, grad_points, str
     for s in range(b):
         for k in range(3):
             np.add.at(acc[s].T, i[s, :, k], (g[s] * w[s, :, k]).T)          # interpolate_gpu.cu:107-149: grad_points[idx] += grad_out * weight
-    _fill(grad_points, acc.astype(np.float32))
+    _fill(grad_points, acc)
 
 
 def _dcn_forward(x_nhwc, wt_oc, bias, offset, mask, b, h, w, cin, cout, ho, wo, kh, kw, sh, sw, ph, pw, dh, dw, dg, y_nhwc, stream):
@@ -158,10 +158,10 @@ def _dcn_backward(x_nhwc, wt, offset, mask, dy_nhwc, b, h, w, cin, cout, ho, wo,
         y = dcn_oracle.modulated_deform_conv(x, off, msk, weight, None, (sh, sw), (ph, pw), (dh, dw), dg)
         dy = dy_nhwc.view(b, ho, wo, cout).permute(0, 3, 1, 2).double()
         gx, gw, go, gm = torch.autograd.grad(y, (x, weight, off, msk), dy)
-    dx_nhwc.copy_(gx.permute(0, 2, 3, 1).reshape(dx_nhwc.shape).float())
-    doffset.copy_(go.reshape(doffset.shape).float())
-    dmask.copy_(gm.reshape(dmask.shape).float())
-    dwt.copy_(gw.permute(2, 3, 1, 0).reshape(dwt.shape).float())
+    dx_nhwc.copy_(gx.permute(0, 2, 3, 1).reshape(dx_nhwc.shape))      # copy_ rounds once to the caller's dtype
+    doffset.copy_(go.reshape(doffset.shape))
+    dmask.copy_(gm.reshape(dmask.shape))
+    dwt.copy_(gw.permute(2, 3, 1, 0).reshape(dwt.shape))
 
 
 _TABLE = {

@@ -15,10 +15,26 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Per-op parity and reference-golden files first, chain / step-level files last: with `-x` a step-level failure must not hide the per-op
+# rows (round 4: one chain test with a hand-set bound stopped the driver's run before 255 per-op tests).
+_FILE_ORDER = ["test_abi", "test_oracle_golden", "test_voxel_gpu", "test_rulebook_gpu", "test_rulebook_nd_oracle", "test_spconv_gpu",
+               "test_spconv4d_gpu", "test_pointnet2_gpu", "test_pointnet2_oracle", "test_roi_gpu", "test_iou3d_gpu", "test_iou3d_oracle",
+               "test_dcn_gpu", "test_dcn_functions_cpu", "test_psroi_gpu", "test_psroi_oracle", "test_bn_gpu", "test_bn_oracle",
+               "test_bev_gpu", "test_primitives_gpu", "test_pyref_golden", "test_async_asm", "test_fma_audit"]
+_LAST = ["test_backbone_gpu", "test_reference_overlay", "test_dist_cpu", "test_ddp_gpu", "test_fv2p_step_gpu", "test_mgaf_head"]
+
+
 def pytest_collection_modifyitems(config, items):
     # GPU tests never silently pass on a box without a GPU: they are skipped unless selected with -m gpu,
     # and when selected they fail loudly if CUDA/HIP is unavailable (see `gpu` fixture).
-    pass
+    def rank(item):
+        stem = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        if stem in _FILE_ORDER:
+            return _FILE_ORDER.index(stem)
+        if stem in _LAST:
+            return 1000 + _LAST.index(stem)
+        return 500          # a new file: after the known per-op files, before the step-level ones
+    items.sort(key=rank)    # stable: the order inside a file is kept
 
 
 @pytest.fixture(scope="session")

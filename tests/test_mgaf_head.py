@@ -97,14 +97,14 @@ class SmallMGAF(mm.MGAFConfig):
     layer_nums = (2, 2, 2)
 
 
-def small_inputs():
+def small_inputs(cloud_seed=90):
     import oracle
     from fv2p_harness import synth
     from fv2p_harness.backbone import mean_vfe
     rng = np.array(SmallMGAF.point_cloud_range, np.float32)
     feats, coords, boxes = [], [], []
     for b in range(2):
-        pts, bx = synth.lidar_cloud(90 + b, 3000, pc_range=rng, return_boxes=True)
+        pts, bx = synth.lidar_cloud(cloud_seed + b, 3000, pc_range=rng, return_boxes=True)
         v, c, k = oracle.points_to_voxel(pts, synth.KITTI_VOXEL, rng, 5, 16000)
         feats.append(mean_vfe(torch.from_numpy(v), torch.from_numpy(k)))
         coords.append(torch.from_numpy(np.concatenate([np.full((c.shape[0], 1), b, np.int32), c], 1)))
@@ -117,80 +117,95 @@ def small_inputs():
     return torch.cat(feats), torch.cat(coords), torch.from_numpy(gt)
 
 
+def mgaf_group(name):
+    """Coarse module groups (a group's statistic is the worst / the median parameter in it; finer groups are printed, not judged)."""
+    if name.startswith("dense_head."):
+        return ".".join(name.split(".")[:2])
+    return name.split(".")[0]
+
+
+def zero_gradient(name):
+    """A conv bias in front of train-mode BatchNorm: analytically zero gradient, every run holds rounding noise only."""
+    return name.startswith("backbone_3d.") and name.endswith((".conv1.bias", ".conv2.bias"))
+
+
+def host_runs(seed=0, cloud_seed=90):
+    """The step on the host twice: float32 (the oracle run every integer output is compared with) and float64 (the calibration run of
+    tests/f64_calibration.py: same modules, same oracle call table, float paths in double)."""
+    from oracle.spconv_cpu import cpu_mirror
+    torch.manual_seed(seed)
+    model = mm.MGAFDetector(SmallMGAF)
+    feats, coords, gt = small_inputs(cloud_seed)
+    ref, ref64 = cpu_mirror(model), cpu_mirror(model).double()
+    with oracle_backend():
+        for net, cast in ((ref, lambda t: t), (ref64, lambda t: t.double())):
+            net.taps = {}
+            # the one discrete choice inside the loss - which 24 heat-map peaks per sample the IoU-score term scores - is the float32
+            # oracle run's in all three runs (two peaks within rounding of each other swap freely; each run's OWN choice is compared
+            # with it separately): the gradients compared are then gradients of the same function
+            net.iou_peaks = None if net is ref else ref.taps["terms"]["_iou_peaks"]
+            net(cast(feats), coords, 2, cast(gt)).backward()
+    return model, ref, ref64, (feats, coords, gt)
+
+
+def trainable_grads(net):
+    # the DCN layers' frozen bias is added, never trained (modules/modulated_deform_conv.py:38-41)
+    return {k: p.grad for k, p in net.named_parameters() if p.requires_grad and p.grad is not None}
+
+
+def test_float64_host_run_is_the_same_step_and_float32_is_a_percent_away_from_it():
+    """What the calibrated bounds rest on, checked without a GPU: the float64 host run takes the float32 run's decisions (targets bit
+    for bit, same top-24 peak cells up to near-ties), and the float32 run's gradients sit 1e-3 ... 5e-2 from it upstream of the heads -
+    the amplification that makes a hand-set bound a coin."""
+    import f64_calibration as cal
+    _, ref, ref64, _ = host_runs()
+    for k in ("ind_target", "mask_target", "segm_target"):
+        assert torch.equal(ref.taps["targets"][k], ref64.taps["targets"][k].to(ref.taps["targets"][k].dtype)), k
+    assert next(ref64.parameters()).dtype == torch.float64 and ref64.taps["preds"]["hm"].dtype == torch.float64
+    d = cal.distances(trainable_grads(ref), trainable_grads(ref64), zero_gradient)
+    up = [v for n, v in d.items() if n.startswith(("backbone_3d.", "backbone_2d."))]
+    assert len(up) > 100 and 1e-3 < max(up) < 5e-2, (len(up), max(up))
+    assert max(v for n, v in d.items() if n.startswith("dense_head.heads.")) < 1e-2
+
+
 @pytest.mark.gpu
 def test_mgaf_step_matches_cpu_oracle(gpu):
     """MGAFDetector (VoxelResBackBone8x, DCNBEVBackbone, CenterAFHead with the DCNv2 feature adaption, target assignment, eight
-    loss terms) forward + backward on the HIP ops against the same modules on the host: target maps bit-exact, head maps 1e-3
-    (through the 21-layer sparse backbone, the DCN BEV backbone and their BatchNorms), all eight loss terms 1e-3 (the IoU-score term on
-    the host run's peak cells when the two runs' top-24 sets differ), every parameter gradient by relative L2 with the per-group bounds
-    stated where they are applied: 3e-3 heads, 6e-3 feature adaption, 2e-2 upstream of it, 3e-2 third BEV level."""
-    from oracle.spconv_cpu import cpu_mirror
-    torch.manual_seed(0)
-    model = mm.MGAFDetector(SmallMGAF)
-    ref = cpu_mirror(model)
-    feats, coords, gt = small_inputs()
-    ref.taps = {}
-    with oracle_backend():
-        loss_c = ref(feats, coords, 2, gt)
-        loss_c.backward()
+    loss terms) forward + backward on the HIP ops against the same modules on the host.  Integer outputs (target maps, indices,
+    masks) bit-exact against the float32 oracle run.  Floats - head maps, loss terms, every parameter gradient - by the float64-calibrated
+    criterion of tests/f64_calibration.py: the HIP run may be at most K times as far from the host float64 run as the host float32
+    oracle run is (median parameter and pooled vector per module group; floor 1e-4; every parameter within 0.25).  No hand-set bound."""
+    import f64_calibration as cal
+    model, ref, ref64, (feats, coords, gt) = host_runs()
     net = model.to(gpu)
     net.taps = {}
+    peaks = ref.taps["terms"]["_iou_peaks"]
+    net.iou_peaks = peaks.to(gpu)     # the IoU-score term's cells: the float32 oracle run's in all three runs (host_runs)
     from conftest import deterministic_libraries
-    with deterministic_libraries():   # (without: heads 1.7e-3 ... 3.3e-3, upstream 1.3e-2 ... 2.1e-2 over six runs of this test)
+    with deterministic_libraries():   # run-to-run identical on one box (MIOpen / rocBLAS atomics off); box-to-box it is not, hence f64
         loss_g = net(feats.to(gpu), coords.to(gpu), 2, gt.to(gpu))
         loss_g.backward()
     assert int(ref.taps["targets"]["mask_target"].sum()) > 0
     for k in ("ind_target", "mask_target", "segm_target", "hm_target"):
         assert torch.equal(net.taps["targets"][k].cpu(), ref.taps["targets"][k]), k
-    for name, want in ref.taps["preds"].items():
-        got = net.taps["preds"][name].detach().cpu()
-        assert float((got - want.detach()).abs().max()) <= 1e-3 * float(want.detach().abs().max()), name
-    peaks_c, peaks_g = ref.taps["terms"]["_iou_peaks"], net.taps["terms"]["_iou_peaks"].cpu()
-    for name, want in ref.taps["terms"].items():
+    # the HIP run's OWN choice of cells (top 24 heat-map peaks per sample): the oracle run's up to swaps of near-equal peaks
+    with torch.no_grad():
+        own = mm.center_losses({k: v.detach() for k, v in net.taps["preds"].items()}, net.taps["targets"], SmallMGAF)[1]["_iou_peaks"].cpu()
+    same = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(peaks, own))
+    assert same >= peaks.numel() - 4, (same, peaks.numel())
+    rel_max = lambda a, t: float((a.detach().cpu().double() - t.detach().double()).abs().max() / t.detach().double().abs().max())
+    for name, want in ref64.taps["preds"].items():
+        d_hip, d_ref = rel_max(net.taps["preds"][name], want), rel_max(ref.taps["preds"][name], want)
+        print(f"head map {name:9s} max-rel distance to float64: hip {d_hip:.2e}  host32 {d_ref:.2e}")
+        assert d_hip <= max(cal.K * d_ref, cal.FLOOR), (name, d_hip, d_ref)
+    for name, want in ref64.taps["terms"].items():
         if name.startswith("_"):
             continue
-        got, want = float(net.taps["terms"][name].detach()), float(want.detach())
-        if name == "iouscore" and not torch.equal(peaks_c, peaks_g):
-            # The IoU-score term scores the 24 highest heat-map peaks per sample; two peaks within float32 noise of each other may swap
-            # between the runs.  Tie-robust form: the HIP run's term re-evaluated on the HOST run's cells (same 1e-3 as every other
-            # term), and the two runs must agree on all but a few cells.
-            same = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(peaks_c, peaks_g))
-            assert same >= peaks_c.numel() - 4, (same, peaks_c.numel())
-            with torch.no_grad():
-                got = float(mm.center_losses({k: v.detach() for k, v in net.taps["preds"].items()}, net.taps["targets"], SmallMGAF,
-                                             peaks=peaks_c.to(gpu))[1]["iouscore"])
-        assert abs(got - want) <= 1e-3 * max(1.0, abs(want)), (name, got, want)
-    gp = dict(net.named_parameters())
-    worst, bad, by_group = ("", 0.0), [], {}
-    for name, p in ref.named_parameters():
-        if not p.requires_grad:          # the DCN layers' frozen bias (modules/modulated_deform_conv.py:38-41: added, never trained)
-            continue
-        assert p.grad is not None and gp[name].grad is not None, name
-        if name.startswith("backbone_3d.") and name.endswith((".conv1.bias", ".conv2.bias")):
-            continue                     # a conv bias in front of train-mode BatchNorm: analytically zero gradient
-        a, b = gp[name].grad.cpu().double(), p.grad.double()
-        err = float((a - b).norm() / b.norm().clamp_min(1e-12))
-        worst = max(worst, (name, err), key=lambda t: t[1])
-        grp = ".".join(name.split(".")[:3 if name.startswith(("backbone_2d", "dense_head")) else 2])
-        by_group[grp] = max(by_group.get(grp, 0.0), err)
-        # Measured per module group (HIP against the host run, printed below; the same numbers in every run under the deterministic
-        # library settings): the seven heads <= 2.2e-3, the head's deformable feature adaption 3.9e-3, its offset / mask predictor 1.2e-2
-        # (gradients through the bilinear kernel's kinks, where float32 and the oracle's float64 pick sides), shared conv + first two BEV
-        # levels + sparse backbone 0.9 ... 1.7e-2 (everything that has crossed the DCN backward and a chain of train-mode BatchNorms: two
-        # float32 implementations, tests/test_fv2p_step_gpu.py DEEP_END), third BEV level 1.9e-2 - plain torch convolutions on BOTH
-        # sides there, MIOpen on the GPU and oneDNN on the host.
-        # Round 3 allowed 6e-2 / 3e-3 / 3e-2 (float atomics in the DCN data gradient moved the heads by 1 ... 2e-3 from run to run;
-        # the backward is bit-reproducible now).
-        if name.startswith("dense_head.heads."):
-            tol = 3e-3
-        elif name.startswith("dense_head.feature_adapt.conv_adaption"):
-            tol = 6e-3
-        elif name.startswith(("backbone_2d.blocks.2", "backbone_2d.deblocks.2")):
-            tol = 3e-2
-        else:
-            tol = 2e-2
-        if err >= tol:
-            bad.append((name, f"{err:.2e}"))
-    print("worst MGAF gradient:", worst)
-    print("largest gradient error per module group:", {k: f"{v:.1e}" for k, v in by_group.items()})
-    assert not bad, " ".join(f"{n}={e}" for n, e in bad)
+        got, want, host = float(net.taps["terms"][name].detach()), float(want.detach()), float(ref.taps["terms"][name].detach())
+        assert abs(got - want) <= max(cal.K * abs(host - want), cal.FLOOR * max(1.0, abs(want))), (name, got, host, want)
+    rows, bad = cal.compare(trainable_grads(net), trainable_grads(ref), trainable_grads(ref64), mgaf_group, zero_gradient)
+    print(cal.report(rows))
+    fine = lambda n: ".".join(n.split(".")[:3 if n.startswith(("backbone_2d", "dense_head")) else 2])
+    print(cal.report(cal.compare(trainable_grads(net), trainable_grads(ref), trainable_grads(ref64), fine, zero_gradient)[0],
+                     "the same by fine group (printed, not judged)"))
+    assert not bad, "\n".join(bad)

@@ -81,6 +81,57 @@ def test_conv_kernel_variants_agree_with_oracle(gpu, impl):
         fv2p_native.call("fv2p_sparse_conv_set_impl", 0)
 
 
+THIN_ROWS = [15, 16, 17, 4097, 65536, 65537]
+
+
+@pytest.mark.parametrize("n_rows", THIN_ROWS)
+@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 32), (32, 16), (16, 32)])
+def test_thin_layer_kernels_on_and_off_vs_oracle(gpu, cin, cout, n_rows):
+    """conv_rows_thin (16 -> 16: forward and backward data) and conv_rows_res (32 source channels, <= 65 536 rows: 32 -> 32 both
+    directions, 32 -> 16 forward, 16 -> 32 backward data) are what the heuristic launches for the backbones' first two levels; with
+    fv2p_sparse_conv_set_paths(0, 0) the staged kernels take the same launches.  Both settings against the oracle's gather -> mm ->
+    scatter loop (spconv_ops.h:260-457) at 1e-4, forward and input gradient, at row counts around the 16-row group, the 64-row tile
+    and conv_rows_res's 65 536-row gate (65 537 rows: the staged kernel runs in both settings there); and against each other to
+    1e-6 of the output's scale (same k order; the position of a product inside a wave's MFMA chain may differ)."""
+    import fv2p_native
+    batch = 2
+    shape = [5, 12, 12] if n_rows < 100 else [8, 40, 40] if n_rows < 10000 else [12, 96, 96]
+    ind, feats, _ = make_input(cin * 1000 + cout + n_rows, batch, shape, n_rows, cin, gpu)
+    assert ind.shape[0] == n_rows
+    torch.manual_seed(cin + cout)
+    conv = spconv.SubMConv3d(cin, cout, 3, padding=1, bias=False, indice_key="k").to(gpu)
+    w = conv.weight.detach().cpu().numpy()
+    _, pairs, num = oracle.indice_pairs(ind, batch, shape, [3, 3, 3], [1, 1, 1], [1, 1, 1], [1, 1, 1], subm=True)
+    ref = oracle.indice_conv(feats, w, pairs, num, n_rows, subm=True).numpy()
+    g = np.random.default_rng(7).standard_normal(ref.shape).astype(np.float32)
+    din, _ = oracle.indice_conv_backward(feats, w, g, pairs, num, subm=True)
+    got = {}
+    try:
+        for on in (1, 0):
+            fv2p_native.call("fv2p_sparse_conv_set_paths", on, on)
+            x = spconv.SparseConvTensor(torch.from_numpy(feats).to(gpu).requires_grad_(True), torch.from_numpy(ind).to(gpu), shape, batch)
+            y = conv(x)
+            y.features.backward(torch.from_numpy(g).to(gpu))
+            got[on] = (y.features.detach().cpu().numpy(), x.features.grad.cpu().numpy())
+            assert rel_err(got[on][0], ref) < RTOL, ("forward", on)
+            assert rel_err(got[on][1], din.numpy()) < RTOL, ("backward data", on)
+    finally:
+        fv2p_native.call("fv2p_sparse_conv_set_paths", -1, -1)
+    assert rel_err(got[1][0], got[0][0]) < 1e-6 and rel_err(got[1][1], got[0][1]) < 1e-6
+
+
+def test_thin_layer_switch_selects_the_kernels(gpu):
+    """The switch is live (not a process-static read of the environment): the conv kernel trace hook is NULL-safe in both settings and
+    the two settings' outputs are produced by different kernels - seen as different launch counts of conv_rows_thin in rocprof
+    (profiles/r05_*), here as the ABI accepting 1 / 0 / -1 and rejecting anything else."""
+    import fv2p_native
+    for v in (1, 0, -1):
+        fv2p_native.call("fv2p_sparse_conv_set_paths", v, v)
+    with pytest.raises(fv2p_native.Fv2pError):
+        fv2p_native.call("fv2p_sparse_conv_set_paths", 2, 0)
+    fv2p_native.call("fv2p_sparse_conv_set_paths", -1, -1)
+
+
 @pytest.mark.parametrize("k,s,p", [([3, 3, 3], [2, 2, 2], [1, 1, 1]), ([3, 3, 3], [2, 2, 2], [0, 1, 1]), ([3, 1, 1], [2, 1, 1], [0, 0, 0]),
                                    ([2, 2, 2], [2, 2, 2], [0, 0, 0]), ([3, 3, 3], [1, 1, 1], [1, 1, 1])])
 def test_strided_conv_vs_oracle_and_dense(gpu, front_end, k, s, p):
