@@ -31,10 +31,11 @@ struct DcnGeom {
   int B, H, W, Cin, Cout, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw, dg;
 };
 
-__global__ void dcn_reduce_k(const float* __restrict__ partial, int chunks, long long per_chunk, float* __restrict__ out) {
+// out = (accumulate ? out : 0) + partial[0] + partial[1] + ...: a fixed order, also across the batch chunks of one call
+__global__ void dcn_reduce_k(const float* __restrict__ partial, int chunks, long long per_chunk, float* __restrict__ out, int accumulate) {
   const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= per_chunk) return;
-  float s = 0.f;
+  float s = accumulate ? out[t] : 0.f;
   for (int c = 0; c < chunks; ++c) s += partial[c * per_chunk + t];
   out[t] = s;
 }
@@ -875,27 +876,66 @@ static void dcn_fwd_launch(const DcnGeom& g, const float* x, const float* wt_oc,
   hipLaunchKernelGGL((dcn_fwd_k<NB, 1>), grid, dim3(256), 2 * NB * 256 * sizeof(float), stream, g, x, wt_oc, bias, offset, mask, y, 0ll, col_blocks);
 }
 
+// Samples per launch sequence: the kernels address x, the column gradients and the sample lists with 32-bit offsets, so a call is
+// cut into chunks of whole samples that stay below those limits (the reference's im2col_step chunking, modulated_deform_conv_cuda.cu:
+// 85-118, serves the same purpose) - and, for the backward, below kColgCapBytes of column gradients, which bounds the workspace
+// whatever the batch.  Per-pixel arithmetic does not depend on the chunking; the weight gradient adds the chunks in ascending order.
+constexpr long long kColgCapBytes = 3ll << 29;   // 1.5 GiB: the MGAF head at batch 4 (1.30 GB) is still one chunk
+static long long g_colg_cap = kColgCapBytes;     // fv2p_dcn_set_colg_cap (tests: several chunks at shapes the oracle can answer)
+static int dcn_chunk_samples(const DcnGeom& g, bool backward) {
+  const long long K = static_cast<long long>(g.kh) * g.kw;
+  const long long x_bytes = static_cast<long long>(g.H) * g.W * g.Cin * 4;
+  const long long pix = static_cast<long long>(g.Ho) * g.Wo;
+  long long bs = g.B > 0 ? g.B : 1;
+  bs = std::min(bs, ((1ll << 32) - 1) / std::max(x_bytes, 1ll));
+  bs = std::min(bs, ((1ll << 32) - 1) / std::max(pix * std::max<long long>(g.Cout, g.dg * 2 * K) * 4, 1ll));   // y / dy, offset
+  if (backward) {
+    bs = std::min(bs, g_colg_cap / std::max(pix * K * g.Cin * 4, 1ll));
+    bs = std::min(bs, ((1ll << 31) - 1) / std::max(pix * g.dg * K, 1ll));
+  }
+  return static_cast<int>(bs);   // 0: one sample alone is above a limit
+}
+
+extern "C" int fv2p_dcn_set_colg_cap(int64_t bytes) {
+  FV2P_REQUIRE(bytes >= 0, FV2P_EINVAL, "dcn_set_colg_cap: bytes >= 0 (0 = the default)");
+  g_colg_cap = bytes > 0 ? bytes : kColgCapBytes;
+  return 0;
+}
+
 // wt_oc: weight permuted to [kh*kw][Cout][Cin] (input channels contiguous: what the LDS-DMA of the forward kernel fetches 16 bytes at a time)
 extern "C" int fv2p_dcn_forward(const float* x_nhwc, const float* wt_oc, const float* bias, const float* offset, const float* mask,
                                 DCN_GEOM_ARGS, float* y_nhwc, fv2p_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   DCN_GEOM_INIT;
   if (int rc = dcn_check(g)) return rc;
-  const long long npix = static_cast<long long>(g.B) * g.Ho * g.Wo;
-  if (npix == 0) return 0;
+  if (static_cast<long long>(g.B) * g.Ho * g.Wo == 0) return 0;
   FV2P_REQUIRE(x_nhwc && wt_oc && offset && mask && y_nhwc, FV2P_EINVAL, "dcn_forward: null pointer");
-  FV2P_REQUIRE(static_cast<long long>(g.B) * g.H * g.W * g.Cin * 4 < (1ll << 32), FV2P_ELIMIT, "dcn_forward: input above 4 GiB (split the batch)");
-  // A workgroup computes 64 pixels x 16*NB columns (32-pixel wave tiles measured 3 - 8 % slower: half the waves per SIMD).  Per-pixel
-  // arithmetic does not depend on the plan, so results are identical for every batch size.  256 columns go to one workgroup unless the
-  // map is too small to fill the chip: then two column halves, each gathering for itself.
+  const int bs = dcn_chunk_samples(g, false);
+  FV2P_REQUIRE(bs >= 1, FV2P_ELIMIT, "dcn_forward: one sample's input is above 4 GiB");
+  const long long K = static_cast<long long>(g.kh) * g.kw, pix = static_cast<long long>(g.Ho) * g.Wo;
   const int nb_all = static_cast<int>(ceil_div(g.Cout, 16));
-  int nb = nb_all <= 4 ? 4 : (nb_all <= 8 ? 8 : 16);
-  if (nb == 16 && ceil_div(npix, 64) < 2 * dcn_cu_count()) nb = 8;
-  if (const char* force = getenv("FV2P_DCN_FWD_NB")) nb = atoi(force);   // development
-  const int col_blocks = static_cast<int>(ceil_div(nb_all, nb));
-  if (nb == 4) dcn_fwd_launch<4>(g, x_nhwc, wt_oc, bias, offset, mask, y_nhwc, npix, col_blocks, stream);
-  else if (nb == 8) dcn_fwd_launch<8>(g, x_nhwc, wt_oc, bias, offset, mask, y_nhwc, npix, col_blocks, stream);
-  else dcn_fwd_launch<16>(g, x_nhwc, wt_oc, bias, offset, mask, y_nhwc, npix, col_blocks, stream);
+  for (int s0 = 0; s0 < g.B; s0 += bs) {
+    DcnGeom gc = g;
+    gc.B = std::min(bs, g.B - s0);
+    const long long npix = static_cast<long long>(gc.B) * pix;
+    const float* xc = x_nhwc + static_cast<long long>(s0) * g.H * g.W * g.Cin;
+    const float* oc = offset + static_cast<long long>(s0) * g.dg * 2 * K * pix;
+    const float* mc = mask + static_cast<long long>(s0) * g.dg * K * pix;
+    float* yc = y_nhwc + static_cast<long long>(s0) * pix * g.Cout;
+    // A workgroup computes 64 pixels x 16*NB columns (32-pixel wave tiles measured 3 - 8 % slower: half the waves per SIMD).  Per-pixel
+    // arithmetic does not depend on the plan, so results are identical for every batch size.  256 columns go to one workgroup unless the
+    // map is too small to fill the chip: then two column halves, each gathering for itself.
+    int nb = nb_all <= 4 ? 4 : (nb_all <= 8 ? 8 : 16);
+    if (nb == 16 && ceil_div(npix, 64) < 2 * dcn_cu_count()) nb = 8;
+    if (const char* force = getenv("FV2P_DCN_FWD_NB")) {   // development: only the instantiated tiles, anything else is ignored
+      const int f = atoi(force);
+      if (f == 4 || f == 8 || f == 16) nb = std::max(f, nb_all <= 4 ? 4 : (nb_all <= 8 ? 8 : f));
+    }
+    const int col_blocks = static_cast<int>(ceil_div(nb_all, nb));
+    if (nb == 4) dcn_fwd_launch<4>(gc, xc, wt_oc, bias, oc, mc, yc, npix, col_blocks, stream);
+    else if (nb == 8) dcn_fwd_launch<8>(gc, xc, wt_oc, bias, oc, mc, yc, npix, col_blocks, stream);
+    else dcn_fwd_launch<16>(gc, xc, wt_oc, bias, oc, mc, yc, npix, col_blocks, stream);
+  }
   FV2P_LAUNCH_CHECK();
   return 0;
 }
@@ -943,6 +983,7 @@ struct SizerC : Sizer {
 extern "C" size_t fv2p_dcn_backward_ws_bytes(int batch, int height, int width, int h_out, int w_out, int c_in, int c_out, int kh, int kw,
                                              int deformable_group) {
   DcnGeom g = {batch, height, width, c_in, c_out, h_out, w_out, kh, kw, 1, 1, 0, 0, 1, 1, deformable_group > 0 ? deformable_group : 1};
+  g.B = std::max(1, std::min(g.B, dcn_chunk_samples(g, true)));   // the workspace of one chunk serves every chunk
   const DcnBwdPlan p = dcn_bwd_plan(g);
   SizerC s;
   float *a, *e; int* b; DcnEntries c; void* d;
@@ -975,50 +1016,69 @@ extern "C" int fv2p_dcn_backward(const float* x_nhwc, const float* wt, const flo
     return 0;
   }
   FV2P_REQUIRE(x_nhwc && wt && offset && mask && dy_nhwc && dx_nhwc && doffset && dmask, FV2P_EINVAL, "dcn_backward: null pointer");
-  FV2P_REQUIRE(nin * g.Cin * 4 < (1ll << 32) && npix * K * g.Cin * 4 < (1ll << 32), FV2P_ELIMIT,
-               "dcn_backward: input or column gradients above 4 GiB (split the batch)");
-  const DcnBwdPlan p = dcn_bwd_plan(g);
-  FV2P_REQUIRE(p.max_entries < (1ll << 31) && npix * K < (1ll << 32), FV2P_ELIMIT, "dcn_backward: too many samples (split the batch)");
+  const int bs = dcn_chunk_samples(g, true);
+  FV2P_REQUIRE(bs >= 1, FV2P_ELIMIT, "dcn_backward: one sample's input, column gradients or sample list is above the 32-bit limits");
   FV2P_REQUIRE(ws && ws_bytes >= fv2p_dcn_backward_ws_bytes(g.B, g.H, g.W, g.Ho, g.Wo, g.Cin, g.Cout, g.kh, g.kw, g.dg), FV2P_EWORKSPACE,
                "dcn_backward: workspace too small");
+  DcnGeom gmax = g;
+  gmax.B = std::min(bs, g.B);
+  const DcnBwdPlan pmax = dcn_bwd_plan(gmax);
   Carver c(ws, ws_bytes);
   float *colg, *partial; int* cursor; DcnEntries entries; void* sws;
-  dcn_bwd_carve(c, g, p, &colg, &cursor, &entries, &sws, &partial);
-  // 1. per-target sample lists
-  FV2P_HIP(hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)(p.nkeys + 1), stream));
-  const long long nsamples = npix * g.dg * K;
-  const unsigned iblocks = static_cast<unsigned>(ceil_div(nsamples, 256));
-  hipLaunchKernelGGL((dcn_index_k<0>), dim3(iblocks), dim3(256), 0, stream, g, offset, cursor, entries);
-  if (int rc = exclusive_scan_i32(cursor, cursor, p.nkeys, nullptr, sws, scan_ws_bytes(p.nkeys), stream)) return rc;
-  hipLaunchKernelGGL((dcn_index_k<1>), dim3(iblocks), dim3(256), 0, stream, g, offset, cursor, entries);
-  hipLaunchKernelGGL(dcn_index_sort_long_k, dim3(static_cast<unsigned>(std::min<long long>(1024, ceil_div(p.nkeys, 256)))), dim3(256), 0, stream,
-                     cursor, p.nkeys, entries);
-  // 2. column gradients, grad_mask, grad_offset
-  const int jo = static_cast<int>(ceil_div(g.Cout, 16));
-  const bool mc2 = (g.Cin / g.dg) % 32 == 0;
-  // small maps: the (tap, group) segments of a pixel tile go to several workgroups, in equal shares (550 tiles on 256 CUs are two
-  // rounds with the second almost empty: [4,256,100,88] 1 327 -> 1 182 us with three shares; at 2 200 tiles shares only cost)
-  int seg_split = 1;
-  for (int s = 1; s <= K * g.dg; ++s)
-    if ((K * g.dg) % s == 0) { seg_split = s; if (ceil_div(npix, 64) * s >= 6 * dcn_cu_count()) break; }
-  if (const char* force = getenv("FV2P_DCN_BWD_SPLIT")) seg_split = std::max(1, std::min(atoi(force), K * g.dg));   // development
-#define DCN_CJ(JO) do { if (mc2) dcn_col_launch<JO, 2>(g, x_nhwc, wt, offset, mask, dy_nhwc, colg, doffset, dmask, npix, seg_split, stream); \
-                        else dcn_col_launch<JO, 1>(g, x_nhwc, wt, offset, mask, dy_nhwc, colg, doffset, dmask, npix, seg_split, stream); } while (0)
-  if (jo <= 1) DCN_CJ(1); else if (jo <= 2) DCN_CJ(2); else if (jo <= 4) DCN_CJ(4); else if (jo <= 8) DCN_CJ(8); else DCN_CJ(16);
+  dcn_bwd_carve(c, gmax, pmax, &colg, &cursor, &entries, &sws, &partial);
+  const long long pix = static_cast<long long>(g.Ho) * g.Wo;
+  for (int s0 = 0; s0 < g.B; s0 += bs) {
+    DcnGeom gc = g;
+    gc.B = std::min(bs, g.B - s0);
+    const DcnBwdPlan p = dcn_bwd_plan(gc);
+    const long long cpix = static_cast<long long>(gc.B) * pix;
+    const float* xc = x_nhwc + static_cast<long long>(s0) * g.H * g.W * g.Cin;
+    const float* oc = offset + static_cast<long long>(s0) * g.dg * 2 * K * pix;
+    const float* mc = mask + static_cast<long long>(s0) * g.dg * K * pix;
+    const float* dyc = dy_nhwc + static_cast<long long>(s0) * pix * g.Cout;
+    float* dxc = dx_nhwc + static_cast<long long>(s0) * g.H * g.W * g.Cin;
+    float* doc = doffset + static_cast<long long>(s0) * g.dg * 2 * K * pix;
+    float* dmc = dmask + static_cast<long long>(s0) * g.dg * K * pix;
+    // 1. per-target sample lists
+    FV2P_HIP(hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)(p.nkeys + 1), stream));
+    const long long nsamples = cpix * g.dg * K;
+    const unsigned iblocks = static_cast<unsigned>(ceil_div(nsamples, 256));
+    hipLaunchKernelGGL((dcn_index_k<0>), dim3(iblocks), dim3(256), 0, stream, gc, oc, cursor, entries);
+    if (int rc = exclusive_scan_i32(cursor, cursor, p.nkeys, nullptr, sws, scan_ws_bytes(p.nkeys), stream)) return rc;
+    hipLaunchKernelGGL((dcn_index_k<1>), dim3(iblocks), dim3(256), 0, stream, gc, oc, cursor, entries);
+    hipLaunchKernelGGL(dcn_index_sort_long_k, dim3(static_cast<unsigned>(std::min<long long>(1024, ceil_div(p.nkeys, 256)))), dim3(256), 0, stream,
+                       cursor, p.nkeys, entries);
+    // 2. column gradients, grad_mask, grad_offset
+    const int jo = static_cast<int>(ceil_div(g.Cout, 16));
+    const bool mc2 = (g.Cin / g.dg) % 32 == 0;
+    // small maps: the (tap, group) segments of a pixel tile go to several workgroups, in equal shares (550 tiles on 256 CUs are two
+    // rounds with the second almost empty: [4,256,100,88] 1 327 -> 1 182 us with three shares; at 2 200 tiles shares only cost)
+    int seg_split = 1;
+    for (int sp = 1; sp <= K * g.dg; ++sp)
+      if ((K * g.dg) % sp == 0) { seg_split = sp; if (ceil_div(cpix, 64) * sp >= 6 * dcn_cu_count()) break; }
+    if (const char* force = getenv("FV2P_DCN_BWD_SPLIT")) {   // development: a divisor of the segment count or nothing
+      const int f = atoi(force);
+      if (f >= 1 && f <= K * g.dg && (K * g.dg) % f == 0) seg_split = f;
+    }
+#define DCN_CJ(JO) do { if (mc2) dcn_col_launch<JO, 2>(gc, xc, wt, oc, mc, dyc, colg, doc, dmc, cpix, seg_split, stream); \
+                        else dcn_col_launch<JO, 1>(gc, xc, wt, oc, mc, dyc, colg, doc, dmc, cpix, seg_split, stream); } while (0)
+    if (jo <= 1) DCN_CJ(1); else if (jo <= 2) DCN_CJ(2); else if (jo <= 4) DCN_CJ(4); else if (jo <= 8) DCN_CJ(8); else DCN_CJ(16);
 #undef DCN_CJ
-  // 3. grad_input
-  const int cpg = g.Cin / g.dg;
-  const long long ntiles = static_cast<long long>(g.B) * g.dg * ((g.H + 1) / 2) * ((g.W + 3) / 4);
-  const unsigned gblocks = static_cast<unsigned>(ceil_div(ntiles, 4));
-  if (cpg % 4 == 0 && cpg > 128) hipLaunchKernelGGL((dcn_col2im_k<4>), dim3(gblocks), dim3(256), 0, stream, g, colg, cursor, entries, dx_nhwc);
-  else if (cpg > 64) hipLaunchKernelGGL((dcn_col2im_k<2>), dim3(gblocks), dim3(256), 0, stream, g, colg, cursor, entries, dx_nhwc);
-  else hipLaunchKernelGGL((dcn_col2im_k<1>), dim3(gblocks), dim3(256), 0, stream, g, colg, cursor, entries, dx_nhwc);
-  // 4. weight gradient
-  const dim3 wgrid(static_cast<unsigned>(static_cast<long long>(p.splits) * K * p.ci_tiles * p.co_tiles));
-  hipLaunchKernelGGL(dcn_bwd_weight_k, wgrid, dim3(256), 2 * 2 * 16 * kDwPitch * sizeof(float), stream, g, x_nhwc, offset, mask, dy_nhwc,
-                     p.pix_per_block, p.ci_tiles * p.co_tiles, partial);
-  const long long per_chunk = static_cast<long long>(K) * g.Cin * g.Cout;
-  hipLaunchKernelGGL(dcn_reduce_k, dim3(static_cast<unsigned>(ceil_div(per_chunk, 256))), dim3(256), 0, stream, partial, p.splits, per_chunk, dwt);
+    // 3. grad_input
+    const int cpg = g.Cin / g.dg;
+    const long long ntiles = static_cast<long long>(gc.B) * g.dg * ((g.H + 1) / 2) * ((g.W + 3) / 4);
+    const unsigned gblocks = static_cast<unsigned>(ceil_div(ntiles, 4));
+    if (cpg % 4 == 0 && cpg > 128) hipLaunchKernelGGL((dcn_col2im_k<4>), dim3(gblocks), dim3(256), 0, stream, gc, colg, cursor, entries, dxc);
+    else if (cpg > 64) hipLaunchKernelGGL((dcn_col2im_k<2>), dim3(gblocks), dim3(256), 0, stream, gc, colg, cursor, entries, dxc);
+    else hipLaunchKernelGGL((dcn_col2im_k<1>), dim3(gblocks), dim3(256), 0, stream, gc, colg, cursor, entries, dxc);
+    // 4. weight gradient: the chunk's pixel splits, added to dwt in ascending chunk order
+    const dim3 wgrid(static_cast<unsigned>(static_cast<long long>(p.splits) * K * p.ci_tiles * p.co_tiles));
+    hipLaunchKernelGGL(dcn_bwd_weight_k, wgrid, dim3(256), 2 * 2 * 16 * kDwPitch * sizeof(float), stream, gc, xc, oc, mc, dyc,
+                       p.pix_per_block, p.ci_tiles * p.co_tiles, partial);
+    const long long per_chunk = static_cast<long long>(K) * g.Cin * g.Cout;
+    hipLaunchKernelGGL(dcn_reduce_k, dim3(static_cast<unsigned>(ceil_div(per_chunk, 256))), dim3(256), 0, stream, partial, p.splits, per_chunk, dwt,
+                       s0 > 0 ? 1 : 0);
+  }
   FV2P_LAUNCH_CHECK();
   return 0;
 }

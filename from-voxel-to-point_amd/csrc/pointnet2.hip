@@ -1455,7 +1455,8 @@ __device__ __forceinline__ Vec4 interp_load4(const float* p, bool vec, int c0, i
 template <int TPR>
 __global__ __launch_bounds__(256) void interp_seg_k(int m, int c, int64_t entries, const uint64_t* __restrict__ keys,
                                                     const float* __restrict__ grad_out, const float* __restrict__ weight,
-                                                    float* __restrict__ grad_features, float* __restrict__ part, int* __restrict__ flags) {
+                                                    float* __restrict__ grad_features, float* __restrict__ part, int* __restrict__ flags,
+                                                    int aligned) {
   const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   const int64_t s = t / TPR;
   const int sub = static_cast<int>(t % TPR);
@@ -1467,7 +1468,7 @@ __global__ __launch_bounds__(256) void interp_seg_k(int m, int c, int64_t entrie
   const uint32_t um = static_cast<uint32_t>(m);
   int fl = 0;
   for (int c0 = 4 * sub; c0 < c; c0 += 4 * TPR) {
-    const bool vec = c0 + 3 < c && (c & 3) == 0;
+    const bool vec = aligned && c0 + 3 < c && (c & 3) == 0;
     Vec4 acc = {{0.f, 0.f, 0.f, 0.f}};
     uint32_t cur = static_cast<uint32_t>(keys[i0] >> 32);
     bool at_start = true;
@@ -1519,7 +1520,7 @@ __global__ __launch_bounds__(256) void interp_seg_k(int m, int c, int64_t entrie
 template <int TPR>
 __global__ __launch_bounds__(256) void interp_fix_k(int c, int64_t entries, int64_t segments, const uint64_t* __restrict__ keys,
                                                     const float* __restrict__ part, const int* __restrict__ flags,
-                                                    float* __restrict__ grad_features) {
+                                                    float* __restrict__ grad_features, int aligned) {
   const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
   const int64_t s = t / TPR;
   const int sub = static_cast<int>(t % TPR);
@@ -1538,7 +1539,7 @@ __global__ __launch_bounds__(256) void interp_fix_k(int c, int64_t entries, int6
   }
   if (s + len >= segments) len = segments - 1 - s;   // (cannot happen on a consistent flag array)
   for (int c0 = 4 * sub; c0 < c; c0 += 4 * TPR) {
-    const bool vec = c0 + 3 < c && (c & 3) == 0;
+    const bool vec = aligned && c0 + 3 < c && (c & 3) == 0;
     Vec4 acc = interp_load4(part + (s * 2 + 1) * c + c0, vec, c0, c);
     // the partial sums in segment order, the next eight on their way while eight are added (their count is known: no load waits for a flag)
     auto load8 = [&](int64_t j0, Vec4 (&p)[8]) {
@@ -1917,10 +1918,13 @@ extern "C" int fv2p_three_interpolate_stack_grad_gather(int n, int c, int m, con
   int tpr = 1;
   while (tpr < 64 && tpr * 4 < c) tpr *= 2;
   const int64_t threads = segments * tpr;
+  // 16-byte accesses only when every row of both caller buffers starts on a 16-byte boundary (a tensor view with a storage offset
+  // or a C caller's odd pointer falls back to scalar accesses); `part` is carved 256-byte aligned
+  const int aligned = ((reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(grad_features) | reinterpret_cast<uintptr_t>(part)) & 15) == 0;
 #define FV2P_IG(T)                                                                                                                \
   {                                                                                                                               \
-    hipLaunchKernelGGL((interp_seg_k<T>), G1D(threads), 0, st, m, c, entries, keys, grad_out, weight, grad_features, part, flags); \
-    hipLaunchKernelGGL((interp_fix_k<T>), G1D(threads), 0, st, c, entries, segments, keys, part, flags, grad_features);            \
+    hipLaunchKernelGGL((interp_seg_k<T>), G1D(threads), 0, st, m, c, entries, keys, grad_out, weight, grad_features, part, flags, aligned); \
+    hipLaunchKernelGGL((interp_fix_k<T>), G1D(threads), 0, st, c, entries, segments, keys, part, flags, grad_features, aligned);            \
   }
   switch (tpr) { case 1: FV2P_IG(1) break; case 2: FV2P_IG(2) break; case 4: FV2P_IG(4) break; case 8: FV2P_IG(8) break;
                  case 16: FV2P_IG(16) break; case 32: FV2P_IG(32) break; default: FV2P_IG(64) }

@@ -442,7 +442,8 @@ int fv2p_sa_grid_bwd(const float* per_point, const float* per_centre, const int*
  * Replace DCN.modulated_deform_conv_forward / _backward and DCN.deform_conv_forward / _backward
  * (pcdet/ops/DeformableConvolutionV2PyTorch/src/vision.cpp:6-12 -> src/modulated_deform_conv.h:10-86 ->
  * src/cuda/modulated_deform_conv_cuda.cu:19-280, kernels src/cuda/modulated_deform_im2col_cuda.cuh:24-328).
- * Fused implicit GEMM: no `columns` buffer.  Activations are NHWC on this side of the boundary:
+ * Forward: fused implicit GEMM, no `columns` buffer.  Backward: the column GRADIENTS do pass through the workspace (below), at
+ * most 1.5 GiB of them at a time.  Activations are NHWC on this side of the boundary:
  *   x_nhwc [B,H,W,Cin], y_nhwc / dy_nhwc [B*Ho*Wo, Cout]; the weight [Cout,Cin,kh,kw] arrives permuted: forward takes
  *   wt_oc = [kh*kw][Cout][Cin] (input channels contiguous), backward wt = [kh*kw][Cin][Cout] (output channels contiguous);
  *   offset [B, dg*2*kh*kw, Ho, Wo] ((2k, 2k+1) = (dh, dw)), mask [B, dg*kh*kw, Ho, Wo] — reference layouts.
@@ -452,12 +453,18 @@ int fv2p_sa_grid_bwd(const float* per_point, const float* per_centre, const int*
  * gradients go through the workspace ([B*Ho*Wo][kh*kw][Cin], the reference's `columns`), every input pixel then sums the
  * samples that touch it in ascending sample order (lists built with integer atomics), so all four gradients are
  * bit-identical from run to run (lists above 4096 samples on ONE input pixel keep an arbitrary order).
- * Each of x, the column gradients and the sample count must stay below 2^32 bytes / 2^31 entries (split the batch).
+ * Any batch: both entry points cut the call into chunks of whole samples (the reference's im2col_step loop,
+ * modulated_deform_conv_cuda.cu:85-118) so that x, y, offset and the column gradients of a chunk stay below the kernels' 32-bit
+ * limits and the column gradients below 1.5 GiB; fv2p_dcn_backward_ws_bytes is the workspace of ONE chunk.  dx, doffset, dmask
+ * are per sample (identical for every chunking); dwt adds the chunks in ascending order (fixed, run-to-run identical).  Only a
+ * single sample above a limit is refused (FV2P_ELIMIT).
  */
 int fv2p_dcn_forward(const float* x_nhwc, const float* wt_oc, const float* bias, const float* offset,
                      const float* mask, int batch, int height, int width, int c_in, int c_out, int h_out,
                      int w_out, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
                      int deformable_group, float* y_nhwc, fv2p_stream_t stream);
+/* Test hook: the cap on a chunk's column gradients in bytes (0 = back to the 1.5 GiB default). */
+int fv2p_dcn_set_colg_cap(int64_t bytes);
 size_t fv2p_dcn_backward_ws_bytes(int batch, int height, int width, int h_out, int w_out, int c_in, int c_out, int kh,
                                   int kw, int deformable_group);
 int fv2p_dcn_backward(const float* x_nhwc, const float* wt, const float* offset, const float* mask,

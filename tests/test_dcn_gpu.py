@@ -77,6 +77,53 @@ def test_random_offsets_forward_backward_vs_oracle(gpu, cin, cout, dg, stride, d
     assert rel(m.bias.grad, b.grad) < 1e-4
 
 
+@pytest.mark.parametrize("cin,cout,dg,per_chunk", [(32, 48, 2, 2), (16, 16, 1, 1), (64, 64, 4, 3)])
+def test_backward_in_batch_chunks_vs_oracle(gpu, cin, cout, dg, per_chunk):
+    """Both entry points cut a call into chunks of whole samples (32-bit addressing inside the kernels; at most 1.5 GiB of column
+    gradients in the workspace - the reference's im2col_step loop, modulated_deform_conv_cuda.cu:85-118, 217-262).  With the cap
+    lowered to `per_chunk` samples a batch of 5 runs as 2 + 2 + 1 / five single samples / 3 + 2: forward and all five gradients
+    against the float64 oracle at 1e-4; input, offset and mask gradients BIT-IDENTICAL to the unchunked call (per-sample work), the
+    weight gradient within 1e-6 of it (the chunks are added in ascending order) and bit-identical from run to run."""
+    import fv2p_native
+    torch.manual_seed(per_chunk)
+    B, H, W = 5, 11, 13
+    x = torch.randn(B, cin, H, W)
+    offset = torch.randn(B, dg * 18, H, W) * 1.5
+    mask = torch.sigmoid(torch.randn(B, dg * 9, H, W))
+    m = ModulatedDeformConv(cin, cout, 3, stride=1, padding=1, deformable_groups=dg, bias=True).to(gpu)
+    g = torch.randn(B, cout, H, W)
+
+    def run():
+        m.zero_grad(set_to_none=True)
+        gx, go, gm = (t.clone().to(gpu).requires_grad_(True) for t in (x, offset, mask))
+        y = m(gx, go, gm)
+        y.backward(g.to(gpu))
+        return [t.detach().clone() for t in (y, gx.grad, go.grad, gm.grad, m.weight.grad, m.bias.grad)]
+
+    whole = run()
+    colg_per_sample = H * W * 9 * cin * 4
+    ws_whole = int(fv2p_native.lib().fv2p_dcn_backward_ws_bytes(B, H, W, H, W, cin, cout, 3, 3, dg))
+    try:
+        fv2p_native.call("fv2p_dcn_set_colg_cap", per_chunk * colg_per_sample)
+        assert int(fv2p_native.lib().fv2p_dcn_backward_ws_bytes(B, H, W, H, W, cin, cout, 3, 3, dg)) < ws_whole   # one chunk's workspace
+        parts, again = run(), run()
+    finally:
+        fv2p_native.call("fv2p_dcn_set_colg_cap", 0)
+    cx, co, cm = (t.clone().double().requires_grad_(True) for t in (x, offset, mask))
+    w, b = m.weight.detach().cpu().double().requires_grad_(True), m.bias.detach().cpu().double().requires_grad_(True)
+    ref = dcn_oracle.modulated_deform_conv(cx, co, cm, w, b, (1, 1), (1, 1), (1, 1), dg)
+    ref.backward(g.double())
+    for got, want in zip(parts, (ref, cx.grad, co.grad, cm.grad, w.grad, b.grad)):
+        assert rel(got, want) < 1e-4
+    for k in range(4):
+        assert torch.equal(parts[k], whole[k]), k
+    assert rel(parts[4], whole[4]) < 1e-6
+    for a, c in zip(parts, again):
+        assert torch.equal(a, c)
+    with pytest.raises(fv2p_native.Fv2pError):
+        fv2p_native.call("fv2p_dcn_set_colg_cap", -1)
+
+
 def test_mgaf_block_shapes_and_pack(gpu):
     """MdeformConvBlock as DCNBEVBackbone builds it (dcn_bev_backbone.py:56-62), small spatial size."""
     blk = MdeformConvBlock(128, 128, deformable_groups=1).to(gpu)

@@ -86,6 +86,34 @@ def test_ball_query_group_gather_batch(gpu):
     assert nx2.shape == (2, M, 3)
 
 
+@pytest.mark.parametrize("b,n,m", [(384, 512, 216), (7, 512, 217), (3, 100, 5), (2, 70, 1), (1, 1000, 129)])
+@pytest.mark.parametrize("nsample", [16, 32, 5])
+def test_ball_query_batch_kernel_at_the_roi_head_shapes(gpu, b, n, m, nsample):
+    """ball_query_batch_k (a wave per query, 64 candidates per step, ballot-ordered stores) against oracle_ball_query_batch
+    (ball_query_gpu.cu:15-51) bit for bit: the RoI head's 384 x 216 queries over 512 points with 16 / 32 samples, query counts that
+    are not a multiple of the queries per workgroup, balls without a hit (index 0 in every slot: the caller's zero fill), balls with
+    one hit (repeated into every slot), balls with more than 64 hits (the first `nsample` in index order, found in the first 64-candidate
+    step or across steps), fewer points than a step."""
+    rng = np.random.default_rng(b * 1000 + m + nsample)
+    xyz = rng.uniform(-2, 2, (b, n, 3)).astype(np.float32)
+    new = rng.uniform(-2, 2, (b, m, 3)).astype(np.float32)
+    new[:, 0] = 50.0                                     # no point within any radius: zero hits
+    xyz[:, : n // 2] *= 0.05                             # half of the points in a 0.2-wide clump: > 64 hits for centres near it
+    new[:, m // 2] = 0.0
+    if m > 3:
+        new[:, 1] = xyz[:, n - 1] + 1e-4                 # next to the LAST point, away from the clump: few hits, found in the last step
+    for radius in (0.8, 1.6, 0.01):
+        ref = oracle.ball_query_batch(radius, nsample, xyz, new)
+        idx = bu.ball_query(radius, nsample, T(xyz, gpu), T(new, gpu))
+        assert idx.dtype == torch.int32 and tuple(idx.shape) == (b, m, nsample)
+        assert np.array_equal(idx.cpu().numpy(), ref), radius
+        if m > 1:
+            assert not ref[:, 0].any()                             # the far query: no hit, the caller's zero fill stays
+        if radius >= 0.8 and n // 2 > 64:
+            d2 = ((xyz - new[:, m // 2, None, :]) ** 2).sum(-1)
+            assert ((d2 < radius * radius).sum(1) > 64).all()      # the clump really is a > 64-hit ball
+
+
 def test_three_nn_and_interpolate_batch(gpu):
     """V2P decoder shape: 16384 keypoints against the voxel centres of one level (top3_interpolate)."""
     rng = np.random.default_rng(1)
@@ -368,3 +396,41 @@ def test_interpolation_gradient_gather_form_equals_the_scatter_form(gpu, n, m, c
     feats.grad = None
     su.three_interpolate(feats, ti, tw).backward(tg)
     assert np.abs(feats.grad.cpu().numpy() - want).max() < 1e-5 * scale
+
+
+@pytest.mark.parametrize("n,m,c", [(8192, 3000, 64), (20000, 4000, 128), (9001, 333, 20)])
+def test_default_interpolation_gradient_through_autograd_and_from_unaligned_buffers(gpu, n, m, c):
+    """The autograd op's DEFAULT gradient from 8192 queries on (no environment override: the segmented gather form,
+    pointnet2_utils.py _interp_grad) against a float64 accumulation, 1e-5 of the gradient's scale; and the same entry point fed
+    buffers that start 4 bytes past a 16-byte boundary (a tensor view with a storage offset, a C caller's pointer): the kernels
+    fall back to scalar accesses instead of faulting on a misaligned 16-byte access."""
+    import os
+    import fv2p_native
+    assert "FV2P_INTERP_GATHER" not in os.environ and n >= su.GATHER_GRAD_MIN_QUERIES
+    rng = np.random.default_rng(n + m)
+    idx = rng.integers(0, m, (n, 3)).astype(np.int32)
+    idx[: n // 8] = rng.integers(0, 4, (n // 8, 3))                       # four hot rows
+    w = rng.random((n, 3)).astype(np.float32)
+    g = rng.standard_normal((n, c)).astype(np.float32)
+    want = np.zeros((m, c), np.float64)
+    for k in range(3):
+        np.add.at(want, idx[:, k], g.astype(np.float64) * w[:, k:k + 1])
+    scale = np.abs(want).max()
+    feats = torch.randn(m, c, device=gpu, requires_grad=True)
+    su.three_interpolate(feats, T(idx, gpu), T(w, gpu)).backward(T(g, gpu))
+    assert np.abs(feats.grad.cpu().numpy() - want).max() < 1e-5 * scale
+    # unaligned: both float buffers one element into their storage
+    g_store = torch.empty(n * c + 1, device=gpu)
+    g_view = g_store[1:].view(n, c)
+    g_view.copy_(T(g, gpu))
+    out_store = torch.full((m * c + 1,), 9.0, device=gpu)
+    out_view = out_store[1:].view(m, c)
+    assert g_view.data_ptr() % 16 == 4 and out_view.data_ptr() % 16 == 4
+    ws = torch.empty(int(fv2p_native.lib().fv2p_three_interpolate_stack_grad_ws_bytes(n, c, m)), dtype=torch.uint8, device=gpu)
+    fv2p_native.call("fv2p_three_interpolate_stack_grad_gather", n, c, m, g_view, T(idx, gpu), T(w, gpu), out_view, ws, ws.numel(), fv2p_native.stream())
+    torch.cuda.synchronize()
+    assert float(out_store[0]) == 9.0
+    if c % 4 == 0:
+        assert torch.equal(out_view, feats.grad)      # same association as the aligned call: bit-identical
+    else:
+        assert np.abs(out_view.cpu().numpy() - want).max() < 1e-5 * scale

@@ -69,6 +69,43 @@ def test_roipoint_pool3d(gpu, width):
     assert 0 < rf.sum() < B * M
 
 
+@pytest.mark.parametrize("sampled", [512, 64])
+def test_roipoint_pool_kernel_empty_short_and_overfull_boxes(gpu, sampled):
+    """roipoint_pool_k against the oracle (roipoint_pool3d_kernel.cu:38-130) on boxes built to hold exactly 0, 1, sampled - 1, sampled,
+    sampled + 1 and several thousand points: an empty box is flagged and left zero, a short list wraps around (point k % cnt), an
+    overfull one keeps the FIRST `sampled` points in index order; bit for bit, features included.  Points of one box are spread over the
+    whole index range (found by different waves / steps of the scan), and the two samples of the batch differ."""
+    B, N, C = 2, 16384, 37
+    counts = [0, 1, sampled - 1, sampled, sampled + 1, 3000, 0, 2]
+    M = len(counts)
+    rng = np.random.default_rng(sampled)
+    pts = np.zeros((B, N, 3), np.float32)
+    boxes = np.zeros((B, M, 7), np.float32)
+    for b in range(B):
+        pts[b] = rng.uniform(200, 300, (N, 3))                      # far from every box
+        perm = rng.permutation(N)
+        used = 0
+        for j, cnt in enumerate(counts):
+            centre = np.array([10.0 * j, 5.0 * b, 0.0], np.float32)
+            boxes[b, j] = [*centre, 4.0, 2.0, 1.5, 0.3 * j]
+            rows = perm[used:used + cnt]
+            used += cnt
+            pts[b, rows] = centre + rng.uniform(-0.3, 0.3, (cnt, 3)).astype(np.float32)   # well inside, any heading
+    feats = rng.standard_normal((B, N, C)).astype(np.float32)
+    pool = RoIPointPool3d(sampled, 0.0)
+    with torch.no_grad():
+        pooled, flag = pool(torch.from_numpy(pts).to(gpu), torch.from_numpy(feats).to(gpu), torch.from_numpy(boxes).to(gpu))
+    rp, rf = oracle.roipoint_pool3d(pts, feats, boxes, sampled)
+    assert np.array_equal(flag.cpu().numpy(), rf) and np.array_equal(pooled.cpu().numpy(), rp)
+    assert rf.tolist() == [[int(c == 0) for c in counts]] * B
+    inside = oracle.points_in_boxes_gpu(pts, boxes)
+    for b in range(B):
+        assert [(inside[b] == j).sum() for j in range(M)] == counts          # the construction holds what it says
+    assert not pooled[:, 0].any() and not pooled[:, 6].any()
+    one = pooled[0, 1].cpu().numpy()
+    assert (one == one[0]).all()                                             # a single inside point fills every slot
+
+
 @pytest.mark.parametrize("method", ["max", "avg"])
 def test_roiaware_pool3d_forward_backward(gpu, method):
     pts, gt = scene(9, 16384, 1)
