@@ -88,9 +88,9 @@ def parse():
     ap.add_argument("--bev-channels-last", type=int, default=0, help="fv2p: BEV backbone + anchor head in channels_last memory format")
     ap.add_argument("--impl", choices=["native", "refstyle"], default="native",
                     help="refstyle: the timed steps themselves run in the reference's call structure (fv2p_harness/refstyle.py); the default run "
-                         "times that structure beside the native step for vs_baseline (--refstyle-steps)")
+                         "times that structure beside the native step for vs_restated_structure (--refstyle-steps)")
     ap.add_argument("--inline-steps", type=int, default=10, help="FV2P workloads: extra steps on ONE stream with nothing prepared ahead, reported as inline_ms_per_step (0 = skip)")
-    ap.add_argument("--refstyle-steps", type=int, default=6, help="FV2P workload: extra steps in the reference's call structure, reported as baseline / vs_baseline (0 = skip)")
+    ap.add_argument("--refstyle-steps", type=int, default=6, help="FV2P workload: extra steps in the reference's call structure, reported as baseline / vs_restated_structure (vs_baseline itself stays null: BASELINE.md has no published number) (0 = skip)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous check without a GPU: ranks join a gloo group, reduce, rank 0 prints n_gpus")
     ap.add_argument("--pyprofile", action="store_true", help="cProfile the timed steps (host-overhead hunting; prints to stderr)")
     args = ap.parse_args()
@@ -1268,7 +1268,9 @@ def main():
                 result["boundary_value"] = round(args.batch * world / boundary_s, 2)
             if refstyle_s is not None:
                 base = args.batch * world / refstyle_s
-                result["vs_baseline"] = round(result["value"] / base, 3)
+                # BASELINE.md holds no published number for this metric: vs_baseline stays null.  The ratio against the self-built restatement of
+                # the reference's call structure (fv2p_harness/refstyle.py) is reported under its own key; it is not a run of the reference.
+                result["vs_restated_structure"] = round(result["value"] / base, 3)
                 result["baseline"] = {
                     "kind": "self-built restatement of the reference's call structure on this GPU (not a run of the reference, not a published number: BASELINE.md has none)",
                     "value": round(base, 2), "unit": "point clouds/s", "ms_per_step": round(refstyle_s * 1e3, 3), "steps": args.refstyle_steps,
@@ -1300,7 +1302,9 @@ def main():
                 result["sparse_conv_roofline"] = roofline_probe(model.backbone_3d, voxelize, pool, args, device)
             if refstyle_s is not None:
                 base = args.batch * world / refstyle_s
-                result["vs_baseline"] = round(result["value"] / base, 3)
+                # BASELINE.md holds no published number for this metric: vs_baseline stays null.  The ratio against the self-built restatement of
+                # the reference's call structure (fv2p_harness/refstyle.py) is reported under its own key; it is not a run of the reference.
+                result["vs_restated_structure"] = round(result["value"] / base, 3)
                 result["baseline"] = {
                     "kind": "self-built restatement of the reference's call structure on this GPU (not a run of the reference, not a published number: BASELINE.md has none)",
                     "value": round(base, 2), "unit": "point clouds/s", "ms_per_step": round(refstyle_s * 1e3, 3), "steps": args.refstyle_steps,

@@ -1,5 +1,5 @@
 """The FV2P step in the REFERENCE'S CALL STRUCTURE on this GPU — the baseline `north_star`'s ">= 2x the reference spconv+ops
-forward+backward throughput" is measured against (bench.py --impl refstyle, and `vs_baseline` of the default run).
+forward+backward throughput" is measured against (bench.py --impl refstyle, and `vs_restated_structure` of the default run).
 
 The reference's CUDA cannot be built here, so its structure is restated with the same kernels where the reference has a kernel of
 its own and with torch ops where it composes them:

@@ -184,7 +184,7 @@ def test_roi_head_on_identical_inputs_matches_cpu_oracle(gpu, cpu_run):
 
 @pytest.mark.gpu
 def test_reference_call_structure_is_the_same_step(gpu, cpu_run):
-    """fv2p_harness.refstyle (bench.py's vs_baseline leg: per-offset gather -> mm -> scatter-add sparse convs, separate BatchNorm /
+    """fv2p_harness.refstyle (bench.py's vs_restated_structure leg: per-offset gather -> mm -> scatter-add sparse convs, separate BatchNorm /
     ReLU modules, grouped set abstraction, per-sample NMS, tensor-op target assignment, plain FPS kernel, one stream) computes the
     step of the default path: same key points and proposals, features / losses within 1e-3, gradients within GRAD_TOL."""
     from fv2p_harness import refstyle

@@ -9,7 +9,7 @@ import json, sys
 w = sys.argv[1]
 try:
     d = json.loads(open(f"gpurun_out/bench_{w}.json").read().strip().splitlines()[-1])
-    print(w, d["ms_per_step"], d["value"], d.get("inline_ms_per_step"), d.get("boundary_ms_per_step"), d.get("vs_baseline"), d["roofline"]["frac"])
+    print(w, d["ms_per_step"], d["value"], d.get("inline_ms_per_step"), d.get("boundary_ms_per_step"), d.get("vs_restated_structure"), d["roofline"]["frac"])
 except Exception as e:
     print(w, "FAILED", e)
 PY

@@ -7,6 +7,7 @@ SHAPE=${*:-4 256 200 176 4}
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 K="dcn_fwd_k;dcn_bwd_col_k;dcn_bwd_weight_k;dcn_col2im_k;dcn_index_k"
 B=tools/ubench/dcn_bench
+make -s -C tools/ubench dcn_bench || exit 1   # from source against the library of this tree: never a stale binary
 bash tools/pmc_generic.sh $OUT.sq.json "$K" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_LDS" -- $B $SHAPE 3 > /dev/null
 bash tools/pmc_generic.sh $OUT.fetch.json "$K" "FETCH_SIZE" -- $B $SHAPE 3 > /dev/null
 bash tools/pmc_generic.sh $OUT.write.json "$K" "WRITE_SIZE" -- $B $SHAPE 3 > /dev/null
