@@ -463,13 +463,11 @@ def build_fv2p_step(args, device, rank, world):
 
     key_jobs = {}
 
-    # The first calls of every dense conv shape run MIOpen's solver search; with the dense branch on its side stream that search
-    # hung the device on one fresh box in three (never once the search results were cached).  The first two warm-up steps therefore
-    # run both branches on the calling stream, the rest the arrangement asked for.  (Not the point-branch stream for those two steps:
-    # a process that has used both side streams runs the dense-branch arrangement at 55 instead of 34 ms per step — a fifth active
-    # stream on four hardware queues.)
-    cfg_safe = type("Cfg", (cfg,), {"dense_branch_stream": False, "point_branch_stream": False}) if args.dense_stream else cfg
-    safe_first = 0 if os.environ.get("FV2P_BENCH_SAFE_FIRST") == "0" else 2
+    # The first calls of every dense conv shape run MIOpen's solver search; with a branch on a side stream that search hung the device on
+    # one fresh box in three.  The guard lives in the detector (fv2p_model.FV2PDetector.forward: its first SAFE_FIRST_STEPS GPU steps use
+    # the calling stream only), so every caller of the side-stream arrangements has it, not only this file.
+    if os.environ.get("FV2P_BENCH_SAFE_FIRST") == "0":
+        os.environ["FV2P_SAFE_FIRST"] = "0"
 
     later = Later()
 
@@ -482,7 +480,7 @@ def build_fv2p_step(args, device, rank, world):
         later.join()   # the helper thread that prepared this batch (and started its key-point sampling) during the step before
         if delay_at == "start" and delay_s > 0:
             time.sleep(delay_s)
-        model.cfg = cfg_safe if i < min(safe_first, args.warmup) else cfg
+        model.cfg = cfg
         clouds, gt = pool[i % n_pool]
         if ahead is not None:
             feats, coords = ahead.take(i)

@@ -919,6 +919,9 @@ class IoUGuidedRoIHead(nn.Module):
 
 
 # ---------------------------------------------------------------- the detector -------------------------
+SAFE_FIRST_STEPS = 2   # GPU steps a detector takes on the calling stream only before any side-stream arrangement (MIOpen's first-call search)
+
+
 class FV2PDetector(nn.Module):
     """FromVoxelToPoint (detectors/fv2p.py): forward returns the summed training loss of the three heads."""
 
@@ -932,6 +935,7 @@ class FV2PDetector(nn.Module):
         self.point_head = PointHead(cfg, cfg.decoder_out)
         self.roi_head = IoUGuidedRoIHead(cfg)
         self.taps = None    # set to a dict to collect intermediate results (parity tests)
+        self._gpu_steps = 0   # forward passes taken on a GPU so far (the side-stream guard of forward())
 
     def forward(self, clouds, voxel_features, voxel_coords, gt_boxes, uniforms, key_job=None):
         """clouds: list of (N_b, 4) point tensors; voxel_features / voxel_coords: MeanVFE output + (b, z, y, x) coords of
@@ -939,12 +943,20 @@ class FV2PDetector(nn.Module):
         key_job: handle of post_pfe.start_sampling(clouds) when the caller has enqueued the key-point sampling of this batch
         already (it needs the raw points only, so an input pipeline can run it during the step before)."""
         b = len(clouds)
+        # The first calls of every dense conv shape run MIOpen's solver search; with a branch of the step on a side stream that search
+        # hung the device queue on one fresh box in three (never once the results were cached: DESIGN.md 1).  Whoever asks for a
+        # side-stream arrangement therefore gets the detector's first SAFE_FIRST_STEPS GPU steps on the calling stream only, then the
+        # arrangement asked for (FV2P_SAFE_FIRST=0 switches the guard off).
+        on_gpu = clouds[0].is_cuda
+        branch_streams = on_gpu and self._gpu_steps >= (0 if os.environ.get("FV2P_SAFE_FIRST") == "0" else SAFE_FIRST_STEPS)
+        if on_gpu:
+            self._gpu_steps += 1
         # key-point sampling needs the raw points only: it runs beside the two backbones on its own stream (three workgroups
         # for 16 k dependent rounds) and is joined where the decoder starts
         if key_job is None and self.cfg.key_stream:
             key_job = self.post_pfe.start_sampling(clouds)
         out, levels = self.backbone_3d(voxel_features, voxel_coords, b)
-        if self.cfg.dense_branch_stream and clouds[0].is_cuda:
+        if self.cfg.dense_branch_stream and branch_streams:
             # From here the step has two independent branches until the RoI head's `finish`: the dense one (HeightCompression, BEV
             # backbone, anchor head, second-stage preparation: large MIOpen kernels) on a side stream, and decoder + point head
             # (~150 small kernels) on the calling stream; autograd replays each on its stream in the backward pass, where the
@@ -965,7 +977,7 @@ class FV2PDetector(nn.Module):
         else:
             bev, loss_rpn, prop_scores, prop_boxes = self.dense_branch(out, b, gt_boxes)
             prep = self.roi_head.prepare(bev, prop_scores, prop_boxes, gt_boxes, uniforms)   # still no key points needed
-            branch = self.point_branch_start(clouds, levels, key_job, gt_boxes)
+            branch = self.point_branch_start(clouds, levels, key_job, gt_boxes, branch_streams and not self.cfg.dense_branch_stream)
             key, point_feats, loss_point, point_scores = self.point_branch_join(branch)
         loss_rcnn, aux = self.roi_head.finish(key, point_feats, point_scores, prep)
         if self.taps is not None:
@@ -982,12 +994,12 @@ class FV2PDetector(nn.Module):
         loss_rpn, prop_scores, prop_boxes = self.dense_head(bev, gt_boxes)
         return bev, loss_rpn, prop_scores, prop_boxes
 
-    def point_branch_start(self, clouds, levels, key_job, gt_boxes):
+    def point_branch_start(self, clouds, levels, key_job, gt_boxes, allowed=True):
         """Decoder + point head.  Their only gradient is the point loss (the RoI head pools the point features under no_grad), so
         in backward this chain of ~150 small kernels is independent of the BEV / anchor / RoI chain until both reach the sparse
         backbone.  Run on its own stream in the forward pass, autograd replays it on that stream in the backward pass, beside the
         dense convolutions' gradients on the main stream."""
-        if not (self.cfg.point_branch_stream and clouds[0].is_cuda and key_job is not None):
+        if not (allowed and self.cfg.point_branch_stream and clouds[0].is_cuda and key_job is not None):
             key, feats = self.post_pfe(clouds, levels, key_job)
             loss, scores = self.point_head(key, feats, gt_boxes)
             return (key, feats, loss, scores), None

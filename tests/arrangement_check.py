@@ -25,11 +25,14 @@ torch.manual_seed(3)
 model = FV2PDetector(SmallFV2P).to(gpu)
 clouds, feats, coords, gt, u = make_inputs(SmallFV2P, 2, 4096)
 args = ([c.to(gpu) for c in clouds], feats.to(gpu), coords.to(gpu), gt.to(gpu), u.to(gpu))
-# the first step of a process runs on the calling stream only, as in bench.py: MIOpen's first-call solver search on a side stream is the
-# one thing that was ever seen to hang the dense-branch arrangement
-model.cfg = type("Cfg", (SmallFV2P,), {"dense_branch_stream": False, "point_branch_stream": False})
-model(*args).backward()
+# the detector's first SAFE_FIRST_STEPS GPU steps run on the calling stream only whatever arrangement is asked for (fv2p_model.forward):
+# MIOpen's first-call solver search on a side stream is the one thing that was ever seen to hang the dense-branch arrangement
+from fv2p_harness import fv2p_model  # noqa: E402
+model.cfg = type("Cfg", (SmallFV2P,), {"dense_branch_stream": True, "point_branch_stream": True})
+for _ in range(fv2p_model.SAFE_FIRST_STEPS):
+    model(*args).backward()
 torch.cuda.synchronize()
+assert model._gpu_steps == fv2p_model.SAFE_FIRST_STEPS
 runs = []
 compared = 0
 for dense, point in ((True, True), (False, True), (False, False)):
