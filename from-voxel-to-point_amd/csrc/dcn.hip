@@ -890,7 +890,8 @@ static int dcn_chunk_samples(const DcnGeom& g, bool backward) {
   bs = std::min(bs, ((1ll << 32) - 1) / std::max(x_bytes, 1ll));
   bs = std::min(bs, ((1ll << 32) - 1) / std::max(pix * std::max<long long>(g.Cout, g.dg * 2 * K) * 4, 1ll));   // y / dy, offset
   if (backward) {
-    bs = std::min(bs, g_colg_cap / std::max(pix * K * g.Cin * 4, 1ll));
+    bs = std::min(bs, std::max(1ll, g_colg_cap / std::max(pix * K * g.Cin * 4, 1ll)));   // the cap is a preference: never below one sample
+    bs = std::min(bs, ((1ll << 32) - 1) / std::max(pix * K * g.Cin * 4, 1ll));             // ... the 32-bit limit on its column gradients is hard
     bs = std::min(bs, ((1ll << 31) - 1) / std::max(pix * g.dg * K, 1ll));
   }
   return static_cast<int>(bs);   // 0: one sample alone is above a limit

@@ -969,7 +969,10 @@ __global__ __launch_bounds__(1024) void conv_rows_res(ConvArgs a, int groups_per
 //     measured 10x slower).  A row occurs once per offset and a wave's LDS operations execute in order, so every sum runs
 //     over ascending k: deterministic; the epilogue adds the four waves' partial sums in wave order.
 // LDS at TM = 64 rows per tile: 4 x 65 x 68 accumulators + the compacted table = 79 KB -> two workgroups per CU; TM = 32: 40 KB.
-template <int CINP, bool WT, int TM, int GPS = 1>
+// ABL (development, FV2P_KSPLIT_ABL, results INVALID - timing only; profiles/r05_ksplit_ablation.txt): bit 0 drops the steady-state global
+// loads, bit 1 the accumulator round trip through LDS, bit 2 replaces every MFMA by four lane-wise FMAs, bit 3 drops the step bookkeeping
+// (every step re-uses step 0's slot lists).
+template <int CINP, bool WT, int TM, int GPS = 1, int ABL = 0>
 __global__ __launch_bounds__(256) void conv_rows_ksplit(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int KS = CINP / 4;      // source channels per wave
@@ -1082,6 +1085,7 @@ __global__ __launch_bounds__(256) void conv_rows_ksplit(ConvArgs a) {
   }
   struct Step { int k, ng; int idx[GPS], row[GPS]; };   // ng: row groups of the step that hold pairs (uniform)
   auto read_step = [&](int j, Step& m) {   // j <= n_steps
+    if constexpr (ABL & 8) { if (j > 1) return; }
     const int st = __builtin_amdgcn_readfirstlane(static_cast<int>(my_steps[j]));
     m.k = st & 0x1f;
     const int grp = (st >> 5) & 3;
@@ -1134,17 +1138,24 @@ __global__ __launch_bounds__(256) void conv_rows_ksplit(ConvArgs a) {
         // torch's blocked GEMMs (tools/f64_gap.py); the 16 extra adds per group are free beside 16 JS MFMAs.
         f32x4 c[4], sum[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { c[i] = f32x4{0.f, 0.f, 0.f, 0.f}; sum[i] = p[i]; }   // the running sums travel under the MFMAs
+        for (int i = 0; i < 4; ++i) { c[i] = f32x4{0.f, 0.f, 0.f, 0.f}; if constexpr (ABL & 2) sum[i] = A[u][0]; else sum[i] = p[i]; }   // the running sums travel under the MFMAs
         static_for<0, JS * 4>([&](auto q_) {
           constexpr int q = decltype(q_)::value, jj = q / 4, t = q % 4;
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            c[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(WT ? B[jj * 4 + i][t] : B[jj * 4 + t][i], A[u][jj][t], c[i], 0, 0, 0);
-          if constexpr (u == 0)
+          for (int i = 0; i < 4; ++i) {
+            if constexpr (ABL & 4) c[i][t] += (WT ? B[jj * 4 + i][t] : B[jj * 4 + t][i]) * A[u][jj][t];
+            else c[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(WT ? B[jj * 4 + i][t] : B[jj * 4 + t][i], A[u][jj][t], c[i], 0, 0, 0);
+          }
+          if constexpr (u == 0 && !(ABL & 1))
             static_for<0, LPQ>([&](auto v_) { load_one(std::integral_constant<int, q * LPQ + decltype(v_)::value>{}, nxt, An, Bn); });
         });
+        if constexpr (ABL & 2) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) p[i] = sum[i] + c[i];
+          for (int i = 0; i < 4; ++i) { f32x4 v = sum[i] + c[i]; asm volatile("" : : "v"(v)); }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) p[i] = sum[i] + c[i];
+        }
       }
     });
     static_assert(LPQ * QUADS >= NLOAD, "every load of the next step must be issued inside the first group's block");
@@ -1913,6 +1924,15 @@ static void launch_vec(const ConvArgs& a, hipStream_t s) {
       if (level >= 0 || ksplit_rows<WT>(a) == 64) {
         b.col_blocks = NB / 4;
         const dim3 grid((level >= 0 ? tiles : blocks) * (NB / 4));
+        static const int abl = [] { const char* e = getenv("FV2P_KSPLIT_ABL"); return e ? atoi(e) : 0; }();
+        if constexpr (CINP == 128 && !WT) {
+          if (abl) {   // timing-only ablations of the roofline layer's forward kernel (see the template's comment)
+#define FV2P_ABL(V) case V: { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_ksplit<CINP, WT, 64, 1, V>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                              hipLaunchKernelGGL((conv_rows_ksplit<CINP, WT, 64, 1, V>), grid, dim3(256), lds64, s, b); return; }
+            switch (abl) { FV2P_ABL(1) FV2P_ABL(2) FV2P_ABL(3) FV2P_ABL(4) FV2P_ABL(5) FV2P_ABL(6) FV2P_ABL(7) FV2P_ABL(8) FV2P_ABL(9) FV2P_ABL(11) FV2P_ABL(15) default: break; }
+#undef FV2P_ABL
+          }
+        }
         if (gps == 2) {
           static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_ksplit<CINP, WT, 64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
           if (once) { hipLaunchKernelGGL((conv_rows_ksplit<CINP, WT, 64, 2>), grid, dim3(256), lds64, s, b); return; }

@@ -35,8 +35,10 @@ def regs(tok):
 def check_asm(text):
     """-> list of (kernel, line number, instruction, line of the load).  Per kernel: basic blocks from the labels and branches of
     the listing, forward may-analysis of "registers with an un-waited inline-asm load" to a fixed point, then one pass that reports
-    every instruction touching such a register.  Only `s_waitcnt vmcnt(0)` clears the set (the compiler's own vmcnt(N > 0) waits
-    count loads it does not know about, so they promise nothing for these)."""
+    every instruction touching such a register.  `s_waitcnt vmcnt(0)` clears the set; a HAND-PLACED (inline asm) `s_waitcnt vmcnt(N)`
+    retires every pending load that has at least N inline-asm loads issued after it (loads return in issue order; other vector-memory
+    instructions in between only make the real age larger, so the rule is conservative; the kernels issue no stores inside their
+    pipelined loops).  The compiler's own vmcnt(N > 0) waits count loads it does not know about and promise nothing for these."""
     lines = text.split("\n")
     out = []
     i = 0
@@ -95,27 +97,35 @@ def _check_kernel(kernel, lines, lo, hi):
             t.append(b + 1)
         succ.append(t)
 
+    AGE_CAP = 255
+
     def transfer(pending, blk, report=None):
+        # pending: register -> (line of its load, age = inline-asm loads issued after that load on the youngest path)
         pending = dict(pending)
         for no, op, ops, in_asm, ins in blk["ins"]:
             if op == "s_waitcnt":
-                if "vmcnt(0)" in ins:
+                m = re.search(r"vmcnt\((\d+)\)", ins)
+                if m and int(m.group(1)) == 0:
                     pending = {}
+                elif m and in_asm:
+                    keep = int(m.group(1))
+                    pending = {r: v for r, v in pending.items() if v[1] < keep}
                 continue
             if in_asm and (op.startswith("global_load") or op.startswith("buffer_load")) and "lds" not in ins:
                 if report is not None:
                     for t in ops[1:]:
                         for r in regs(t):
                             if r in pending:
-                                report.append((kernel, no, ins, pending[r]))
+                                report.append((kernel, no, ins, pending[r][0]))
+                pending = {r: (at, min(age + 1, AGE_CAP)) for r, (at, age) in pending.items()}
                 for r in regs(ops[0]):
-                    pending[r] = no
+                    pending[r] = (no, 0)
                 continue
             if report is not None:
                 for t in ops:
                     hit = [r for r in regs(t) if r in pending]
                     if hit:
-                        report.append((kernel, no, ins, pending[hit[0]]))
+                        report.append((kernel, no, ins, pending[hit[0]][0]))
                         break
         return pending
 
@@ -126,9 +136,9 @@ def _check_kernel(kernel, lines, lo, hi):
         o = transfer(inn[b], blocks[b])
         for t in succ[b]:
             grew = False
-            for r, at in o.items():
-                if r not in inn[t]:
-                    inn[t][r] = at
+            for r, (at, age) in o.items():
+                if r not in inn[t] or age < inn[t][r][1]:     # the youngest load of a register over all paths: it stays pending longest
+                    inn[t][r] = (at, age)
                     grew = True
             if grew and t not in work:
                 work.append(t)

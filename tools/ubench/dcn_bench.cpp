@@ -2,7 +2,7 @@
 // backward runs give the same bits.  (Values are checked by tests/test_dcn_gpu.py against the float64 oracle.)
 //   hipcc -O2 --offload-arch=gfx950 tools/ubench/dcn_bench.cpp -o tools/ubench/dcn_bench -Lfrom-voxel-to-point_amd/lib -lfv2p_ops \
 //         -Wl,-rpath,'$ORIGIN/../../from-voxel-to-point_amd/lib'
-//   tools/ubench/dcn_bench B C H W dg [reps] [offset scale] [Cout]
+//   tools/ubench/dcn_bench B C H W dg [reps] [offset scale] [Cout] [column-gradient cap per chunk, MB]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -49,6 +49,7 @@ int main(int argc, char** argv) {
   if (argc > 7) oscale = atof(argv[7]);
   if (argc > 8) CO = atoi(argv[8]);
   if (!CO) CO = C;
+  if (argc > 9) fv2p_dcn_set_colg_cap((int64_t)(atof(argv[9]) * 1048576.0));   // cap on a chunk's column gradients in MB (0 = default)
   const int K = 9;
   const size_t npix = (size_t)B * H * W;
   std::mt19937 rng(1234);
