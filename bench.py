@@ -1315,7 +1315,7 @@ def main():
                 result["roofline"] = roofline_probe(model, voxelize, pool, args, device)
             if world == 1 and args.cpu_clouds > 0:
                 result["cpu_baseline"] = cpu_baseline(model, args)
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():   # N ranks, or the one-rank group of FV2P_DDP_SOLO
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -12,8 +12,25 @@ def env_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
+def solo_ddp():
+    """FV2P_DDP_SOLO=1 (measurement hook, bench.py on a one-GPU box): a ONE-rank process group over RCCL and the detector wrapped in
+    DistributedDataParallel all the same, so that DDP's gradient hooks, bucket copies and RCCL's own stream run beside the step's side
+    streams.  A one-rank all-reduce moves nothing; FV2P_DDP_COMM_STANDIN=<us> adds, per bucket and on the communication stream, a copy
+    kernel sized to last about that long (the time a 25 MB bucket occupies a ring over xGMI: ~150 us)."""
+    return os.environ.get("FV2P_DDP_SOLO") == "1"
+
+
 def init_distributed(backend, device=None):
     rank, world, _ = env_world()
+    if world == 1 and solo_ddp() and not dist.is_initialized():
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                **({"device_id": device} if (backend == "nccl" and device is not None) else {}))
+        return rank, world
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -37,11 +54,43 @@ def wrap_ddp(model, device=None, find_unused_parameters=True):
     """find_unused_parameters=True is the reference trainer's setting (tools/train.py:166: its detectors have heads that
     sit out some iterations); a module that uses every parameter each step (the backbone train step of bench.py) passes
     False and saves DDP's extra autograd-graph traversal per iteration."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not solo_ddp()):
         return model
     ids = [device.index] if (device is not None and device.type == "cuda") else None
-    return torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, find_unused_parameters=find_unused_parameters,
-                                                     gradient_as_bucket_view=True)
+    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, find_unused_parameters=find_unused_parameters,
+                                                    gradient_as_bucket_view=True)
+    standin_us = float(os.environ.get("FV2P_DDP_COMM_STANDIN", "0") or 0)
+    if standin_us > 0 and device is not None and device.type == "cuda":
+        net.register_comm_hook(_StandIn(device, standin_us), _standin_hook)
+    return net
+
+
+class _StandIn:
+    """State of the stand-in hook: a communication stream of its own and a scratch buffer."""
+
+    def __init__(self, device, us):
+        self.stream = torch.cuda.Stream(device=device)
+        self.scratch = None
+        self.us = us
+
+
+def _standin_hook(state, bucket):
+    buf = bucket.buffer()
+    fut = dist.all_reduce(buf, async_op=True).get_future()      # the real (one-rank or N-rank) RCCL call on RCCL's stream
+
+    def after(f):
+        t = f.value()[0]
+        if state.scratch is None or state.scratch.numel() < t.numel():
+            state.scratch = torch.empty_like(t)
+        cur = torch.cuda.current_stream(t.device)
+        state.stream.wait_stream(cur)
+        with torch.cuda.stream(state.stream):
+            # a ring all-reduce moves about twice the bucket through each GPU: two device copies of it on the communication stream
+            state.scratch[:t.numel()].copy_(t)
+            t.copy_(state.scratch[:t.numel()])
+        cur.wait_stream(state.stream)
+        return t.div_(dist.get_world_size()) if dist.get_world_size() > 1 else t
+    return fut.then(after)
 
 
 def barrier():

@@ -1,0 +1,80 @@
+#!/bin/bash
+# Every profiles/<tag>_* file of a round from ONE tree in ONE call (run on the GPU box; copy gpurun_out/<tag>_* into profiles/ afterwards).
+#   bash tools/round_profiles.sh r05 [quick]
+# Sections: bench lines (4 workloads), kernel stats of the FV2P step / its boundary leg / MGAF (rocprofv3 --kernel-trace --stats), the per-op
+# tables of tools/microbench.py, the roofline kernel's counters (separate --pmc passes, counters only with --kernel-trace), the in-situ
+# launch times of the roofline kernel, the one-rank DDP stream-budget runs, the step-noise calibration.  profiles/README.md quotes only
+# numbers found in these files.
+TAG=${1:-r05}; QUICK=$2
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+export TMPDIR=/tmp
+O=gpurun_out
+mkdir -p $O
+make -s -C tools/ubench || exit 1
+echo "== tree $(cat .git/HEAD 2>/dev/null) $(date -u +%FT%TZ)" > $O/${TAG}_manifest.txt
+sha256sum from-voxel-to-point_amd/lib/libfv2p_ops.so bench.py >> $O/${TAG}_manifest.txt
+
+echo "== bench lines"
+for w in fv2p mgaf fv2p-waymo backbone; do
+  timeout 900 python3 bench.py --workload $w > $O/${TAG}_bench_${w//-/_}.json 2> $O/bench_$w.err || echo "bench $w FAILED"
+  tail -c 600 $O/${TAG}_bench_${w//-/_}.json | head -c 400; echo
+done
+
+echo "== kernel stats"
+prof() {   # <name> <steps in the table> <bench args...>
+  local name=$1 n=$2; shift 2
+  rm -rf $O/prof_$name
+  timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$name -o s -- python3 bench.py --watchdog 0 "$@" > $O/prof_$name.log 2>&1
+  local f=$(find $O/prof_$name -name '*kernel_stats.csv' | head -1)
+  cp "$f" $O/${TAG}_${name}_kernel_stats.csv && python3 tools/kstats.py $O/${TAG}_${name}_kernel_stats.csv $n 14
+  if [ "$name" = fv2p ]; then
+    local t=$(find $O/prof_$name -name '*kernel_trace.csv' | head -1)
+    python3 tools/insitu_conv.py "$t" > $O/${TAG}_insitu_conv.txt; cat $O/${TAG}_insitu_conv.txt
+    python3 tools/gaps.py "$t" fps_wave_k 30 > $O/${TAG}_fv2p_idle_gaps.txt 2>&1
+  fi
+  rm -rf $O/prof_$name
+}
+prof fv2p 25 --steps 20 --warmup 5 --cpu-clouds 0 --no-roofline --inline-steps 0 --refstyle-steps 0
+FV2P_BENCH_LEG=boundary prof fv2p_boundary 20 --steps 2 --warmup 2 --inline-steps 20 --refstyle-steps 0 --cpu-clouds 0 --no-roofline
+if [ -z "$QUICK" ]; then
+  prof mgaf 13 --workload mgaf --steps 10 --warmup 3 --cpu-clouds 0 --no-roofline --refstyle-steps 0
+  prof fv2p_waymo 14 --workload fv2p-waymo --steps 10 --warmup 4 --cpu-clouds 0 --no-roofline --inline-steps 0
+fi
+
+echo "== per-op tables"
+FV2P_RES=1 python3 tools/microbench.py conv > $O/${TAG}_microbench_conv_kitti.txt 2>&1; tail -32 $O/${TAG}_microbench_conv_kitti.txt
+python3 tools/microbench.py oproof > $O/${TAG}_op_roofline.txt 2>&1; tail -25 $O/${TAG}_op_roofline.txt
+python3 tools/microbench.py fps > $O/${TAG}_microbench_fps.txt 2>&1; tail -12 $O/${TAG}_microbench_fps.txt
+python3 tools/microbench.py dcn > $O/${TAG}_microbench_dcn.txt 2>&1; tail -12 $O/${TAG}_microbench_dcn.txt
+if [ -z "$QUICK" ]; then
+  FV2P_WAYMO=1 python3 tools/microbench.py conv > $O/${TAG}_microbench_conv_waymo.txt 2>&1
+  python3 tools/microbench.py nn > $O/${TAG}_microbench_nn.txt 2>&1
+  python3 tools/microbench.py sa > $O/${TAG}_microbench_sa.txt 2>&1
+fi
+
+echo "== counters of the roofline kernel"
+bash tools/pmc_roofline.sh $TAG > $O/pmc_roofline.log 2>&1; tail -2 $O/pmc_roofline.log
+bash tools/pmc_mfma.sh $TAG > $O/pmc_mfma.log 2>&1; tail -2 $O/pmc_mfma.log
+
+echo "== one-rank DDP: RCCL's stream (and a stand-in for its traffic) beside the step's four streams"
+for mode in plain solo standin; do
+  case $mode in plain) E="";; solo) E="FV2P_DDP_SOLO=1";; standin) E="FV2P_DDP_SOLO=1 FV2P_DDP_COMM_STANDIN=1";; esac
+  env $E timeout 600 python3 bench.py --steps 20 --warmup 5 --cpu-clouds 0 --no-roofline --inline-steps 0 --refstyle-steps 0 > $O/ddp_$mode.json 2> $O/ddp_$mode.err
+  python3 - $mode "$E" <<'PY'
+import json, sys
+mode, env = sys.argv[1], sys.argv[2]
+try:
+    d = json.loads(open(f"gpurun_out/ddp_{mode}.json").read().strip().splitlines()[-1])
+    print(json.dumps({"mode": mode, "env": env, "ms_per_step": d["ms_per_step"], "value": d["value"], "streams": d["config"].get("streams")}))
+except Exception as e:
+    print(json.dumps({"mode": mode, "env": env, "failed": str(e)}))
+PY
+done > $O/${TAG}_ddp_stream_budget.jsonl
+cat $O/${TAG}_ddp_stream_budget.jsonl
+
+if [ -z "$QUICK" ]; then
+  echo "== step-noise calibration (tests/f64_calibration.py)"
+  python3 tools/step_noise.py 8 > $O/${TAG}_step_noise.txt 2>&1; tail -3 $O/${TAG}_step_noise.txt
+  python3 tools/noise_locate.py 4 > $O/${TAG}_noise_locate.txt 2>&1
+fi
+ls -la $O/${TAG}_* | awk '{print $5, $9}'
