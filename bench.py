@@ -1072,6 +1072,13 @@ def main():
             dist.destroy_process_group()
         return
     pinned = pin_cores(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)), args.pin_cores)
+    if (world > 1 or dist_utils.solo_ddp()) and "GPU_MAX_HW_QUEUES" not in os.environ:
+        # The step keeps four streams busy (calling stream, dense branch, key-point sampling + next batch, weight gradients) on the
+        # runtime's four hardware queues; RCCL's stream is a fifth.  Measured on one GPU with a one-rank DDP and a stand-in for the
+        # all-reduce traffic on a communication stream (tools/ddp_stream_matrix.sh, profiles/r05_ddp_stream_matrix.txt): 48.2 ms per
+        # step with 4 queues (the communication stream shares a queue with the 13 ms sampler), 45.5 with 5, 36.7 with 6, 62.2 with 8;
+        # without DDP 4, 6 and 8 queues all give 30.0.  Read by the HIP runtime when it initialises, i.e. after this line.
+        os.environ["GPU_MAX_HW_QUEUES"] = "6"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
     # FV2P_FORCE_DEVICE / FV2P_DIST_BACKEND: test hooks to exercise the multi-rank path on a one-GPU box (all ranks on one
     # device, gloo instead of RCCL); the driver's runs set neither

@@ -1,0 +1,29 @@
+#!/bin/bash
+# Stream budget of the multi-rank arrangement, measured on ONE GPU (no 8-GPU node is available to the builder): the FV2P step under a one-rank
+# DistributedDataParallel over RCCL (FV2P_DDP_SOLO=1: DDP's hooks, bucket views and RCCL's call per bucket) plus a stand-in for the traffic of
+# a real all-reduce on a communication stream of its own (FV2P_DDP_COMM_STANDIN=1: two device copies of every 25 MB bucket), for several
+# stream arrangements and hardware-queue counts.  -> gpurun_out/<tag>_ddp_stream_matrix.txt
+TAG=${1:-r05}
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out
+OUT=gpurun_out/${TAG}_ddp_stream_matrix.txt
+: > $OUT
+run() { local tag=$1; shift; local envs=$1; shift
+  env $envs timeout 600 python3 bench.py --steps 20 --warmup 5 --cpu-clouds 0 --no-roofline --inline-steps 0 --refstyle-steps 0 "$@" > gpurun_out/ddpm_$tag.json 2>gpurun_out/ddpm_$tag.err
+  echo "$tag | $envs $* | $(grep -o '"ms_per_step": [0-9.]*' gpurun_out/ddpm_$tag.json | head -1)" | tee -a $OUT; }
+S="FV2P_DDP_SOLO=1 FV2P_DDP_COMM_STANDIN=1"
+run plain ""
+run plain_hwq6 "GPU_MAX_HW_QUEUES=6"
+run plain_hwq8 "GPU_MAX_HW_QUEUES=8"
+run solo "FV2P_DDP_SOLO=1"
+run solo_hwq6 "FV2P_DDP_SOLO=1 GPU_MAX_HW_QUEUES=6"
+run standin "$S"
+run standin_hwq5 "$S GPU_MAX_HW_QUEUES=5"
+run standin_hwq6 "$S GPU_MAX_HW_QUEUES=6"
+run standin_hwq8 "$S GPU_MAX_HW_QUEUES=8"
+run standin_nowgradstream "$S FV2P_WGRAD_OVERLAP=0"
+run standin_pointstream "$S" --dense-stream 0
+run standin_nobranchstream "$S" --dense-stream 0 --point-stream 0
+run standin_nobranch_nowgrad "$S FV2P_WGRAD_OVERLAP=0" --dense-stream 0 --point-stream 0
+run standin_nofpsahead "$S" --fps-ahead 0
+run standin_hwq6_nowgradstream "$S GPU_MAX_HW_QUEUES=6 FV2P_WGRAD_OVERLAP=0"

@@ -8,7 +8,7 @@ print(len(rows), "kernels,", len(marks), "steps")
 import collections
 acc=collections.defaultdict(list)
 for a,b in zip(marks[len(marks)//2:-1], marks[len(marks)//2+1:]):
-    seg=[r for r in rows[a:b] if "conv_rows_ksplit<128, false, 64, 1>" in r[2]]
+    seg=[r for r in rows[a:b] if "conv_rows_ksplit<128, false, 64, 1" in r[2]]
     for k,r in enumerate(seg):
         acc[(len(seg),k)].append((r[1]-r[0])/1e3)
 for (n,k),v in sorted(acc.items()):

@@ -3,7 +3,7 @@
 #   bash tools/pmc_mfma.sh [round tag, default r02] [kernel-name substring, default "conv_rows_ksplit<128, false"]
 # Counters only together with --kernel-trace; writes gpurun_out/<tag>_pmc_mfma.json.
 TAG=${1:-r02}
-KERNEL=${2:-"conv_rows_ksplit<128, false"}
+KERNEL=${2:-"conv_rows_ksplit<128, false, 64"}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export FV2P_RES=1
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_LDS \
