@@ -40,8 +40,14 @@ GRAD_TOL = 2e-3     # relative L2 per parameter gradient, GPU kernels against th
 # (float64 statistics) the median ratio is 5.2.  The one effect found was the length of the fused multiply-add chain (27 offsets x
 # channels in one chain: forward 1.18e-6 from float64, per-offset products added afterwards as the reference does: 1.00e-6; torch 7.2e-7).
 # Round 3 allowed 2e-2 here.
+# Round 5: the product's FV2P layers are float32-only by contract (they mirror the reference's checks), so the float64-calibrated criterion of
+# tests/f64_calibration.py (used for the sparse backbones and the MGAF step) cannot run this step a third time in float64; the bound
+# here follows the fallback rule instead - at least twice the worst value seen over fresh boxes.  The worst parameter (conv4.2.bn1.bias)
+# measured 4.67e-3 ... 4.7e-3 on every box of rounds 4 and 5 (profiles/r05_gputest_box*.txt: the HIP side is run-to-run identical under
+# the deterministic library settings and the host side is this container's image): DEEP_END_TOL = 1e-2; everything outside the deep end
+# measured <= 5.9e-4 against GRAD_TOL = 2e-3.
 DEEP_END = ("backbone_3d.", "post_pfe.")
-DEEP_END_TOL = 6e-3
+DEEP_END_TOL = 1e-2
 
 
 def grad_tol(name):
