@@ -18,6 +18,16 @@ driver run: 2.3e-2 against a hand-set 2e-2).  This file states the criterion wit
     to be closer to float64 than FLOOR (1e-4, north_star's per-op float tolerance), FLOOR replaces K * d.  In addition EVERY parameter
     must be within WIRING (0.25) of float64: a missing term or a wrong operand shows as O(1) in one parameter and would hide in a median.
 
+ReLU decisions.  Where the rounding noise itself is small (the sparse backbones alone: 1e-6 at the last layers) the distance to float64 is
+not a smooth quantity: profiles/r05_f64_backbone_params.txt lists it parameter by parameter - 6e-7 ... 1e-6 for BOTH float32 runs from the
+output back to one layer, where it jumps to 1e-4 ... 1e-3 and stays there for everything upstream (HIP: at conv4.1.bn1.bias of the
+residual backbone; the host run: one layer later, and again at conv2.2).  One pre-activation within rounding of zero has taken the
+other side of its ReLU than in the float64 run; the first gradient to show it is a BatchNorm bias (a plain sum over the masked rows).
+Any float32 implementation meets such events, where depends on its summation order (for the host run: on the box's BLAS threading),
+so between two jump points the RATIO of the two runs' distances means nothing (x 475 ... x 1400 in that file).  The backbone test
+therefore judges the whole network as one group and passes FLIPS (2e-3: the distance a few such events leave, twice the 4e-4 ... 1e-3
+the HIP run shows on every box - it is run-to-run and box-to-box identical) as its floor instead of FLOOR.
+
 K = 10 is twice the largest ratio seen: tools/step_noise.py (profiles/r05_step_noise_box*.txt: 8 weight seeds x input clouds per box,
 three boxes) gives group ratios hip / host32 of 0.7 ... 5.2 for both statistics, 2.0 typical - the HIP forward pass is 1.3 ... 2.2 x
 as far from float64 as the host's from the first sparse conv on (one MFMA accumulation chain over 27 offsets x channels, against
@@ -28,6 +38,7 @@ import statistics
 
 K = 10.0
 FLOOR = 1e-4
+FLIPS = 2e-3
 WIRING = 0.25
 
 
