@@ -14,6 +14,9 @@
 //                 of a point is its sorted position minus the voxel's start offset.
 // All integer outputs are therefore bit-identical to the sequential loop.
 #include "common.hpp"
+#include <cmath>
+#include <cstring>
+#include <vector>
 #include <type_traits>
 
 namespace fv2p {
@@ -229,5 +232,58 @@ extern "C" int fv2p_points_to_voxel(const float* points, int64_t n, int ndim, co
   hipLaunchKernelGGL(vox_fill, gridN, dim3(T), 0, stream, n, points, ndim, w.words, w.count, w.scalars, max_points,
                      voxels, num_points_per_voxel);
   FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
+
+// ---- host entry point: the reference's own call site of A1 ---------------------------------------------------------------------------
+// VoxelGenerator.generate runs inside forked DataLoader worker processes on numpy arrays (data_processor.py:43-81 -> voxel_generator.py:
+// 75-207), where HIP cannot be initialised.  Like fv2p_points_in_boxes_cpu and fv2p_boxes_iou_bev_cpu this is the reference's CPU
+// entry point served by the library on the calling thread (host pointers, no HIP call): the same sequential first-come scan, with an
+// open-addressing table over the <= max_voxels voxels in place of the reference's dense coor_to_voxelidx grid (360 MB filled per call at
+// the KITTI grid, :114).  Device inputs never come here (the Python layer sends CUDA tensors to fv2p_points_to_voxel).
+extern "C" int fv2p_points_to_voxel_host(const float* points, int64_t n, int ndim, const float voxel_size[3], const float range_lo[3],
+                                         const int grid[3], int max_points, int max_voxels, float* voxels, int* coors,
+                                         int* num_points_per_voxel, int* num_voxels) {
+  FV2P_REQUIRE(n >= 0 && ndim >= 3 && max_points >= 1 && max_voxels >= 0, FV2P_EINVAL, "points_to_voxel_host: bad sizes");
+  FV2P_REQUIRE(num_voxels && (n == 0 || points) && (max_voxels == 0 || (voxels && coors && num_points_per_voxel)), FV2P_EINVAL,
+               "points_to_voxel_host: null pointer");
+  FV2P_REQUIRE(grid[0] > 0 && grid[1] > 0 && grid[2] > 0, FV2P_EINVAL, "points_to_voxel_host: empty grid");
+  std::memset(voxels, 0, sizeof(float) * static_cast<size_t>(max_voxels) * max_points * ndim);
+  std::memset(num_points_per_voxel, 0, sizeof(int) * static_cast<size_t>(max_voxels));
+  size_t cap = 16;
+  while (cap < 2 * static_cast<size_t>(max_voxels) + 2) cap <<= 1;
+  std::vector<long long> keys(cap, -1);
+  std::vector<int> vals(cap, 0);
+  int count = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const float* p = points + i * ndim;
+    int c[3];
+    bool inside = true;
+    for (int j = 0; j < 3; ++j) {
+      // fp32 subtract, fp32 divide, floor (voxel_generator.py:188); the file is built with -ffp-contract=off
+      const float q = std::floor((p[j] - range_lo[j]) / voxel_size[j]);
+      if (!(q >= 0.0f) || !(q < static_cast<float>(grid[j]))) { inside = false; break; }   // (:189-191; NaN coordinates are dropped too)
+      c[j] = static_cast<int>(q);
+    }
+    if (!inside) continue;
+    const long long key = (static_cast<long long>(c[2]) * grid[1] + c[1]) * grid[0] + c[0];
+    size_t h = static_cast<size_t>(static_cast<unsigned long long>(key) * 0x9E3779B97F4A7C15ull) & (cap - 1);
+    while (keys[h] != -1 && keys[h] != key) h = (h + 1) & (cap - 1);
+    int idx;
+    if (keys[h] == key) idx = vals[h];
+    else {
+      if (count >= max_voxels) break;   // (:198-199) the whole scan stops at the first point that would open voxel max_voxels + 1
+      idx = count++;
+      keys[h] = key; vals[h] = idx;
+      coors[3 * idx + 0] = c[2]; coors[3 * idx + 1] = c[1]; coors[3 * idx + 2] = c[0];   // stored (z, y, x) (:192)
+    }
+    const int k = num_points_per_voxel[idx];
+    if (k < max_points) {   // (:204-206)
+      std::memcpy(voxels + (static_cast<size_t>(idx) * max_points + k) * ndim, p, sizeof(float) * ndim);
+      num_points_per_voxel[idx] = k + 1;
+    }
+  }
+  *num_voxels = count;
   return 0;
 }

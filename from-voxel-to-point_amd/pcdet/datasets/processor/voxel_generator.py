@@ -1,15 +1,18 @@
-"""GPU voxeliser behind the reference's `VoxelGenerator` / `points_to_voxel` API.
+"""Voxeliser behind the reference's `VoxelGenerator` / `points_to_voxel` API.
 
 Mirrors pcdet/datasets/processor/voxel_generator.py:5-133 of the reference (class
 `VoxelGenerator`, function `points_to_voxel`): same constructor arguments, properties,
 return triple `(voxels [M,max_points,ndim] f32, coordinates [M,3] i32 (z,y,x), num_points [M] i32)`
-and the same first-come / max_voxels-break semantics — but the work is done by the hashed HIP
-voxeliser `fv2p_points_to_voxel` (csrc/voxelize.hip).  numpy in → numpy out (H2D/D2H around the
-kernel); CUDA tensor in → CUDA tensors out.  There is no CPU implementation here.
+and the same first-come / max_voxels-break semantics.  Two entry points of the native library, chosen by
+WHERE THE DATA IS, never by what happens to be available:
 
-Note for DataLoader workers: HIP cannot be initialised in a forked child of a process that
-already initialised it; voxelise in the main process (e.g. on the collated batch) or use
-`multiprocessing_context="spawn"`.
+* CUDA tensor in -> CUDA tensors out: the hashed HIP voxeliser `fv2p_points_to_voxel` (csrc/voxelize.hip); this is the path of the
+  models and of bench.py (`points_to_voxel_batch`).
+* numpy in -> numpy out: `fv2p_points_to_voxel_host`, the reference's own call site - `VoxelGenerator.generate` runs on numpy arrays in
+  forked DataLoader worker processes (data_processor.py:43-81), where HIP cannot be initialised.  Like `points_in_boxes_cpu` and
+  `boxes_bev_iou_cpu` it is the reference's CPU entry point served by the library (host pointers, the calling thread, no HIP call;
+  importing this module does not initialise HIP).  Same results bit for bit (tests/test_oracle_golden.py holds both to the reference's
+  fixtures).  There is no fallback in either direction: a CUDA tensor never goes to the host function, and without the library both raise.
 """
 import numpy as np
 import torch
@@ -134,9 +137,30 @@ def points_to_voxel(points, voxel_size, coors_range, max_points=35, reverse_inde
         voxel_size = np.array(voxel_size, dtype=pts.dtype)
     if not isinstance(coors_range, np.ndarray):
         coors_range = np.array(coors_range, dtype=pts.dtype)
-    dpts = torch.from_numpy(pts.astype(np.float32, copy=False)).cuda()
-    v, c, n = points_to_voxel_gpu(dpts, voxel_size, coors_range, max_points, reverse_index, max_voxels)
-    return v.cpu().numpy().astype(pts.dtype, copy=False), c.cpu().numpy(), n.cpu().numpy()
+    v, c, n = points_to_voxel_host(pts.astype(np.float32, copy=False), voxel_size, coors_range, max_points, reverse_index, max_voxels)
+    return v.astype(pts.dtype, copy=False), c, n
+
+
+def points_to_voxel_host(points, voxel_size, coors_range, max_points=35, reverse_index=True, max_voxels=20000):
+    """numpy float32 [N, ndim >= 3] -> numpy (voxels, coors, num_points): the library's host entry point (no HIP call)."""
+    pts = np.ascontiguousarray(points, dtype=np.float32)
+    if pts.ndim != 2 or pts.shape[1] < 3:
+        raise ValueError("points must be [N, ndim >= 3]")
+    voxel_size = np.asarray(voxel_size, dtype=np.float32)
+    coors_range = np.asarray(coors_range, dtype=np.float32)
+    grid = _grid_size(voxel_size, coors_range)
+    n, ndim = pts.shape
+    voxels = torch.empty((max_voxels, max_points, ndim), dtype=torch.float32)
+    coors = torch.empty((max_voxels, 3), dtype=torch.int32)
+    num = torch.empty((max_voxels,), dtype=torch.int32)
+    count = torch.zeros((1,), dtype=torch.int32)
+    _nat.call("fv2p_points_to_voxel_host", torch.from_numpy(pts), n, ndim, voxel_size.tolist(), coors_range[:3].tolist(),
+              [int(g) for g in grid], int(max_points), int(max_voxels), voxels, coors, num, count)
+    m = int(count[0])
+    v, c, k = voxels[:m].numpy(), coors[:m].numpy(), num[:m].numpy()
+    if not reverse_index:
+        c = np.ascontiguousarray(c[:, ::-1])
+    return v, c, k
 
 
 class VoxelGenerator(object):

@@ -58,6 +58,14 @@ int fv2p_points_to_voxel(const float* points, int64_t n_points, int ndim, const 
                          float* voxels, int* coors, int* num_points_per_voxel, int* num_voxels,
                          void* ws, size_t ws_bytes, fv2p_stream_t stream);
 
+/* Host entry point of A1: the reference calls VoxelGenerator.generate on numpy arrays inside forked DataLoader workers
+ * (pcdet/datasets/processor/data_processor.py:43-81 -> voxel_generator.py:75-207), where HIP cannot be initialised.  All
+ * pointers are HOST pointers, the scan runs on the calling thread and makes no HIP call; same outputs as above (voxels,
+ * num_points_per_voxel zero-filled by the call), *num_voxels is a host int. */
+int fv2p_points_to_voxel_host(const float* points, int64_t n_points, int ndim, const float voxel_size[3],
+                              const float range_lo[3], const int grid[3], int max_points, int max_voxels,
+                              float* voxels, int* coors, int* num_points_per_voxel, int* num_voxels);
+
 /* ---- A3/A4: sparse-conv rulebook ----------------------------------------------------------
  * Replaces sparse_conv_ext.get_indice_pairs_{2d,3d} (pcdet/ops/spconv/src/all.cc:22-33 ->
  * spconv_ops.h:27-140 getIndicePair<NDim>, kernels indice.cu.h:22-203, CPU geometry.h:24-297).

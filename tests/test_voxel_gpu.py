@@ -16,12 +16,20 @@ pytestmark = pytest.mark.gpu
 GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "voxel_*.npz")))
 
 
+def hip(fn, pts, *args):
+    """The HIP entry point: points as a CUDA tensor (numpy arrays go to the library's host entry point, tests/test_voxel_host.py),
+    results back as numpy."""
+    out = fn(torch.from_numpy(np.ascontiguousarray(pts, dtype=np.float32)).cuda(), *args)
+    assert all(t.is_cuda for t in out)
+    return tuple(t.cpu().numpy() for t in out)
+
+
 @pytest.mark.parametrize("path", GOLD, ids=lambda p: os.path.basename(p)[:-4])
 def test_voxeliser_matches_reference_golden(gpu, path):
     g = np.load(path)
     gen = VoxelGenerator(g["voxel_size"], g["pc_range"], int(g["max_points"]), int(g["max_voxels"]))
     assert np.array_equal(gen.grid_size, g["grid_size"])
-    v, c, n = gen.generate(g["points"])
+    v, c, n = hip(gen.generate, g["points"])
     assert c.dtype == np.int32 and n.dtype == np.int32 and v.dtype == np.float32
     assert np.array_equal(c, g["coors"])
     assert np.array_equal(n, g["num_points"])
@@ -32,7 +40,7 @@ def test_voxeliser_matches_reference_golden(gpu, path):
 @pytest.mark.parametrize("seed,n,mv,mp", [(1, 16384, 16000, 5), (2, 16384, 4000, 5), (3, 40000, 40000, 1), (4, 777, 20000, 35)])
 def test_voxeliser_matches_oracle_on_seeded_clouds(gpu, seed, n, mv, mp):
     pts = synth.lidar_cloud(seed, n)
-    v, c, k = points_to_voxel(pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, mp, True, mv)
+    v, c, k = hip(points_to_voxel, pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, mp, True, mv)
     ov, oc, ok = oracle.points_to_voxel(pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, mp, mv)
     assert np.array_equal(c, oc) and np.array_equal(k, ok) and np.array_equal(v, ov)
 
@@ -52,20 +60,20 @@ def test_voxeliser_waymo_shape_and_device_tensors(gpu):
 
 def test_voxeliser_edge_cases(gpu):
     # empty input
-    v, c, k = points_to_voxel(np.zeros((0, 4), np.float32), synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, True, 100)
+    v, c, k = hip(points_to_voxel, np.zeros((0, 4), np.float32), synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, True, 100)
     assert v.shape == (0, 5, 4) and c.shape == (0, 3) and k.shape == (0,)
     # everything out of range
     pts = np.full((100, 4), 1000.0, np.float32)
-    v, c, k = points_to_voxel(pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, True, 100)
+    v, c, k = hip(points_to_voxel, pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, True, 100)
     assert v.shape[0] == 0
     # all points in ONE voxel, more than max_points
     pts = np.tile(np.array([[10.01, 0.01, -1.01, 0.5]], np.float32), (1000, 1))
     pts[:, 3] = np.arange(1000)
-    v, c, k = points_to_voxel(pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, True, 100)
+    v, c, k = hip(points_to_voxel, pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, True, 100)
     assert v.shape[0] == 1 and int(k[0]) == 5 and np.array_equal(v[0, :, 3], np.arange(5, dtype=np.float32))
     # max_voxels = 1: the second distinct voxel breaks the scan, later points of voxel 0 are lost too
     pts = np.array([[10.01, 0.01, -1.01, 0], [20.0, 0.0, -1.0, 1], [10.02, 0.01, -1.01, 2]], np.float32)
-    v, c, k = points_to_voxel(pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, True, 1)
+    v, c, k = hip(points_to_voxel, pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, True, 1)
     ov, oc, ok = oracle.points_to_voxel(pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 1)
     assert np.array_equal(k, ok) and int(k[0]) == 1 and np.array_equal(v, ov)
 
