@@ -844,8 +844,11 @@ def roofline_probe(model, voxelize, pool, args, device):
     rec = max(records, key=lambda r: r["flops"])
     mod, rb = rec["mod"], rec["rb"]
     w = mod.weight.detach()
-    reps = 50
-    for _ in range(5):
+    # 50 untimed launches first: the probe follows a host-side pause (the hooks above, the .item() reads), and the first launches after
+    # one run at a lower shader clock (57 - 60 us for the first 20 - 50 launches against 52 - 54 us from there on: tools/microbench.py conv
+    # vs convone); the timed region is then 200 back-to-back launches, i.e. launch gaps included
+    reps = 200
+    for _ in range(50):
         ops.indice_conv(rec["feats"], w, rb, rb.indice_pair_num, rec["n_out"], False, mod.subm)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -869,7 +872,7 @@ def roofline_probe(model, voxelize, pool, args, device):
     layer = f"{'subm' if mod.subm else 'conv'} {cin}->{cout} key={mod.indice_key} n_in={rec['n_in']} n_out={rec['n_out']} pairs={rec['pairs']}"
     try:   # reported only for the very layer the counters were collected on (same channels, rows and pairs)
         prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-        with open(next(p for p in (os.path.join(prof, n) for n in ("r04_pmc_roofline.json", "r03_pmc_roofline.json")) if os.path.exists(p))) as f:
+        with open(next(p for p in (os.path.join(prof, n) for n in ("r05_pmc_roofline.json", "r04_pmc_roofline.json", "r03_pmc_roofline.json")) if os.path.exists(p))) as f:
             pmc = json.load(f)
         import re
         mt = re.search(r"(\d+)->(\d+) key=(\S+) n=(\d+) pairs=(\d+)", pmc.get("layer_line", ""))
