@@ -84,6 +84,11 @@ def parse():
     ap.add_argument("--sync-debug", action="store_true", help="diagnostic: one step under torch.cuda.set_sync_debug_mode('warn'); every host-blocking torch call with its call site (stderr)")
     ap.add_argument("--torch-profile", action="store_true", help="diagnostic: torch.profiler over 3 steps, top ops by device time (stderr)")
     ap.add_argument("--point-stream", type=int, default=1, help="fv2p: decoder + point head on their own stream (A/B switch)")
+    ap.add_argument("--wgrad-stream", type=int, default=-1,
+                    help="sparse-conv weight gradients on a second stream beside the backward-data convs (FV2P_WGRAD_OVERLAP).  Default: off for the FV2P "
+                         "workloads (round 5: 29.76 against 29.91 ms per step with it, but every 128-channel backward-data conv beside a weight-gradient "
+                         "launch takes 76 - 132 instead of 57 us - the two cannot share a CU's LDS - and under DistributedDataParallel the stream costs a "
+                         "hardware queue: 36.7 against 35.5 ms, profiles/r05_ddp_stream_matrix.txt), on for the backbone workloads (1.7 against ~2.2 ms)")
     ap.add_argument("--miopen-find", type=int, default=0, help="torch.backends.cudnn.benchmark: let MIOpen time its solvers for the dense 2-D convs")
     ap.add_argument("--bev-channels-last", type=int, default=0, help="fv2p: BEV backbone + anchor head in channels_last memory format")
     ap.add_argument("--impl", choices=["native", "refstyle"], default="native",
@@ -1075,6 +1080,10 @@ def main():
             dist.destroy_process_group()
         return
     pinned = pin_cores(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)), args.pin_cores)
+    if args.wgrad_stream < 0:
+        args.wgrad_stream = 0 if args.workload in ("fv2p", "fv2p-waymo") else 1
+    if "FV2P_WGRAD_OVERLAP" not in os.environ:
+        os.environ["FV2P_WGRAD_OVERLAP"] = str(int(bool(args.wgrad_stream)))     # read once by the compiled binding at its first backward
     if (world > 1 or dist_utils.solo_ddp()) and "GPU_MAX_HW_QUEUES" not in os.environ:
         # The step keeps four streams busy (calling stream, dense branch, key-point sampling + next batch, weight gradients) on the
         # runtime's four hardware queues; RCCL's stream is a fifth.  Measured on one GPU with a one-rank DDP and a stand-in for the
@@ -1259,6 +1268,7 @@ def main():
         if args.workload in ("fv2p", "fv2p-waymo"):
             result["config"]["streams"] = ("dense branch (BEV backbone, anchor head, RoI preparation) on a side stream beside decoder + point head" if args.dense_stream
                                            else "decoder + point head on a side stream after the RoI preparation" if args.point_stream else "one stream")
+            result["config"]["weight_gradient_stream"] = bool(int(os.environ.get("FV2P_WGRAD_OVERLAP", "1")))
             result["config"]["stream_arrangement_same_for_every_n_gpus"] = True
             attempt = int(os.environ.get("FV2P_BENCH_ATTEMPT", "0"))
             result["attempt"], result["retried_after_hang"] = attempt, attempt > 0
