@@ -12,18 +12,23 @@ run() { local tag=$1; shift; local envs=$1; shift
   env $envs timeout 600 python3 bench.py --steps 20 --warmup 5 --cpu-clouds 0 --no-roofline --inline-steps 0 --refstyle-steps 0 "$@" > gpurun_out/ddpm_$tag.json 2>gpurun_out/ddpm_$tag.err
   echo "$tag | $envs $* | $(grep -o '"ms_per_step": [0-9.]*' gpurun_out/ddpm_$tag.json | head -1)" | tee -a $OUT; }
 S="FV2P_DDP_SOLO=1 FV2P_DDP_COMM_STANDIN=1"
-run plain ""
-run plain_hwq6 "GPU_MAX_HW_QUEUES=6"
-run plain_hwq8 "GPU_MAX_HW_QUEUES=8"
-run solo "FV2P_DDP_SOLO=1"
-run solo_hwq6 "FV2P_DDP_SOLO=1 GPU_MAX_HW_QUEUES=6"
-run standin "$S"
-run standin_hwq5 "$S GPU_MAX_HW_QUEUES=5"
-run standin_hwq6 "$S GPU_MAX_HW_QUEUES=6"
-run standin_hwq8 "$S GPU_MAX_HW_QUEUES=8"
-run standin_nowgradstream "$S FV2P_WGRAD_OVERLAP=0"
-run standin_pointstream "$S" --dense-stream 0
-run standin_nobranchstream "$S" --dense-stream 0 --point-stream 0
-run standin_nobranch_nowgrad "$S FV2P_WGRAD_OVERLAP=0" --dense-stream 0 --point-stream 0
-run standin_nofpsahead "$S" --fps-ahead 0
-run standin_hwq6_nowgradstream "$S GPU_MAX_HW_QUEUES=6 FV2P_WGRAD_OVERLAP=0"
+W1="FV2P_WGRAD_OVERLAP=1"; W0="FV2P_WGRAD_OVERLAP=0"     # weight gradients on their own stream / on the calling stream (bench.py's default for FV2P)
+Q4="GPU_MAX_HW_QUEUES=4"                                  # (bench.py itself sets 6 for DDP runs unless the variable is given)
+run plain_wgradstream "$W1 $Q4"
+run plain "$W0 $Q4"
+run plain_hwq6 "$W0 GPU_MAX_HW_QUEUES=6"
+run plain_hwq8 "$W0 GPU_MAX_HW_QUEUES=8"
+run solo "FV2P_DDP_SOLO=1 $W0 $Q4"
+run solo_hwq6 "FV2P_DDP_SOLO=1 $W0 GPU_MAX_HW_QUEUES=6"
+run standin_wgradstream_hwq4 "$S $W1 $Q4"
+run standin_wgradstream_hwq5 "$S $W1 GPU_MAX_HW_QUEUES=5"
+run standin_wgradstream_hwq6 "$S $W1 GPU_MAX_HW_QUEUES=6"
+run standin_wgradstream_hwq8 "$S $W1 GPU_MAX_HW_QUEUES=8"
+run standin_hwq4 "$S $W0 $Q4"
+run standin_hwq5 "$S $W0 GPU_MAX_HW_QUEUES=5"
+run standin_hwq6 "$S $W0 GPU_MAX_HW_QUEUES=6"
+run standin_hwq8 "$S $W0 GPU_MAX_HW_QUEUES=8"
+run standin_hwq4_pointstream "$S $W0 $Q4" --dense-stream 0
+run standin_hwq4_nobranchstream "$S $W0 $Q4" --dense-stream 0 --point-stream 0
+run standin_hwq4_nofpsahead "$S $W0 $Q4" --fps-ahead 0
+run standin_default "$S"
