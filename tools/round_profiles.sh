@@ -46,7 +46,7 @@ FV2P_RES=1 python3 tools/microbench.py conv > $O/${TAG}_microbench_conv_kitti.tx
 python3 tools/microbench.py oproof > $O/${TAG}_op_roofline.txt 2>&1; tail -25 $O/${TAG}_op_roofline.txt
 python3 tools/microbench.py fps > $O/${TAG}_microbench_fps.txt 2>&1; tail -12 $O/${TAG}_microbench_fps.txt
 python3 tools/microbench.py dcn > $O/${TAG}_microbench_dcn.txt 2>&1
-for shape in "4 128 200 176 1" "4 256 100 88 1" "4 256 50 44 1" "4 256 200 176 4"; do tools/ubench/dcn_bench $shape 5 >> $O/${TAG}_microbench_dcn.txt 2>&1; done   # the C-ABI calls alone
+for shape in "4 128 200 176 1" "4 256 100 88 1" "4 256 50 44 1" "4 256 200 176 4"; do tools/ubench/dcn_bench $shape >> $O/${TAG}_microbench_dcn.txt 2>&1; done   # the C-ABI calls alone
 tail -12 $O/${TAG}_microbench_dcn.txt
 if [ -z "$QUICK" ]; then
   FV2P_WAYMO=1 python3 tools/microbench.py conv > $O/${TAG}_microbench_conv_waymo.txt 2>&1
