@@ -86,9 +86,9 @@ def parse():
     ap.add_argument("--point-stream", type=int, default=1, help="fv2p: decoder + point head on their own stream (A/B switch)")
     ap.add_argument("--wgrad-stream", type=int, default=-1,
                     help="sparse-conv weight gradients on a second stream beside the backward-data convs (FV2P_WGRAD_OVERLAP).  Default: off for the FV2P "
-                         "workloads (round 5: 29.76 against 29.91 ms per step with it, but every 128-channel backward-data conv beside a weight-gradient "
+                         "workloads (round 5: 29.85 against 29.92 ms per step with it, but every 128-channel backward-data conv beside a weight-gradient "
                          "launch takes 76 - 132 instead of 57 us - the two cannot share a CU's LDS - and under DistributedDataParallel the stream costs a "
-                         "hardware queue: 36.7 against 35.5 ms, profiles/r05_ddp_stream_matrix.txt), on for the backbone workloads (1.7 against ~2.2 ms)")
+                         "hardware queue: 36.5 against 35.5 ms, profiles/r05_ddp_stream_matrix.txt), on for the backbone workloads (1.7 against ~2.2 ms)")
     ap.add_argument("--miopen-find", type=int, default=0, help="torch.backends.cudnn.benchmark: let MIOpen time its solvers for the dense 2-D convs")
     ap.add_argument("--bev-channels-last", type=int, default=0, help="fv2p: BEV backbone + anchor head in channels_last memory format")
     ap.add_argument("--impl", choices=["native", "refstyle"], default="native",
@@ -1085,11 +1085,12 @@ def main():
     if "FV2P_WGRAD_OVERLAP" not in os.environ:
         os.environ["FV2P_WGRAD_OVERLAP"] = str(int(bool(args.wgrad_stream)))     # read once by the compiled binding at its first backward
     if (world > 1 or dist_utils.solo_ddp()) and "GPU_MAX_HW_QUEUES" not in os.environ:
-        # The step keeps four streams busy (calling stream, dense branch, key-point sampling + next batch, weight gradients) on the
-        # runtime's four hardware queues; RCCL's stream is a fifth.  Measured on one GPU with a one-rank DDP and a stand-in for the
-        # all-reduce traffic on a communication stream (tools/ddp_stream_matrix.sh, profiles/r05_ddp_stream_matrix.txt): 48.2 ms per
-        # step with 4 queues (the communication stream shares a queue with the 13 ms sampler), 45.5 with 5, 36.7 with 6, 62.2 with 8;
-        # without DDP 4, 6 and 8 queues all give 30.0.  Read by the HIP runtime when it initialises, i.e. after this line.
+        # The step keeps three to four streams busy (calling stream, dense branch, key-point sampling + next batch, and - when asked for -
+        # weight gradients) on the runtime's four hardware queues; RCCL's stream is one more.  Measured on one GPU with a one-rank DDP and
+        # a stand-in for the all-reduce traffic on a communication stream (tools/ddp_stream_matrix.sh, profiles/r05_ddp_stream_matrix.txt),
+        # ms per step at 4 / 5 / 6 / 8 queues: 42.4 / 41.2 / 35.5 / 63.0 without the weight-gradient stream (46.9 / 46.9 / 36.5 / 61.2 with
+        # it): with four queues the communication stream shares one with the 13 ms sampler.  Without DDP the count does not matter (29.9 /
+        # 29.9 / 30.1 at 4 / 6 / 8).  Read by the HIP runtime when it initialises, i.e. after this line.
         os.environ["GPU_MAX_HW_QUEUES"] = "6"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
     # FV2P_FORCE_DEVICE / FV2P_DIST_BACKEND: test hooks to exercise the multi-rank path on a one-GPU box (all ranks on one
