@@ -63,9 +63,17 @@ def test_host_voxeliser_edge_cases_and_dtypes():
         points_to_voxel(torch.zeros(10, 4), synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, True, 100)    # CPU torch tensor: refused, not rerouted
 
 
-class _Clouds(torch.utils.data.Dataset):
-    """What the reference's dataset does per sample: voxelise inside __getitem__ (DataProcessor.transform_points_to_voxels)."""
+_WORKER_SCRIPT = r"""
+import sys
+import numpy as np
+import torch
+import oracle
+from fv2p_harness import synth
+from pcdet.datasets.processor.voxel_generator import VoxelGenerator
 
+
+class Clouds(torch.utils.data.Dataset):
+    # what the reference's dataset does per sample: voxelise inside __getitem__ (DataProcessor.transform_points_to_voxels)
     def __init__(self):
         self.gen = VoxelGenerator(synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 16000)
 
@@ -77,13 +85,25 @@ class _Clouds(torch.utils.data.Dataset):
         return {"voxels": v, "coors": c, "num": k, "hip": torch.cuda.is_initialized()}
 
 
+assert not torch.cuda.is_initialized(), "importing pcdet.ops / the voxel generator must not initialise HIP"
+loader = torch.utils.data.DataLoader(Clouds(), batch_size=1, num_workers=2, multiprocessing_context="fork", collate_fn=lambda b: b[0])
+seen = 0
+for i, item in enumerate(loader):
+    ov, oc, ok = oracle.points_to_voxel(synth.lidar_cloud(50 + i, 4096), synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 16000)
+    assert np.array_equal(item["coors"], oc) and np.array_equal(item["num"], ok) and np.array_equal(item["voxels"], ov)
+    assert item["hip"] is False
+    seen += 1
+assert seen == 4 and not torch.cuda.is_initialized()
+print("WORKERS OK")
+"""
+
+
 def test_generate_runs_in_forked_dataloader_workers_without_hip():
-    assert not torch.cuda.is_initialized(), "importing pcdet.ops / the voxel generator must not initialise HIP"
-    loader = torch.utils.data.DataLoader(_Clouds(), batch_size=1, num_workers=2, multiprocessing_context="fork", collate_fn=lambda b: b[0])
-    seen = 0
-    for i, item in enumerate(loader):
-        ov, oc, ok = oracle.points_to_voxel(synth.lidar_cloud(50 + i, 4096), synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 16000)
-        assert np.array_equal(item["coors"], oc) and np.array_equal(item["num"], ok) and np.array_equal(item["voxels"], ov)
-        assert item["hip"] is False
-        seen += 1
-    assert seen == 4 and not torch.cuda.is_initialized()
+    """In a process of its own (whatever this pytest process has initialised by now): importing the package does not initialise HIP, two
+    FORKED DataLoader workers voxelise numpy clouds through `VoxelGenerator.generate` bit-exactly, and nobody has initialised HIP at the end."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([root, os.path.join(root, "from-voxel-to-point_amd"), os.environ.get("PYTHONPATH", "")]))
+    out = subprocess.run([sys.executable, "-c", _WORKER_SCRIPT], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and "WORKERS OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
