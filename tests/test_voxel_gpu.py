@@ -45,6 +45,27 @@ def test_voxeliser_matches_oracle_on_seeded_clouds(gpu, seed, n, mv, mp):
     assert np.array_equal(c, oc) and np.array_equal(k, ok) and np.array_equal(v, ov)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_voxeliser_random_geometries_match_oracle(gpu, seed):
+    """The HIP kernel on the random geometries of tests/test_voxel_host.py (random ranges, voxel sizes, feature widths, max_points /
+    max_voxels with the break hit in about half of the cases, a fifth of the points exactly on cell faces, points outside the range):
+    bit-exact against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    lo = rng.uniform(-50, 0, 3).astype(np.float32)
+    vs = rng.choice([0.05, 0.1, 0.16, 0.2, 0.4], 3).astype(np.float32)
+    cells = rng.integers(3, 60, 3)
+    rng_arr = np.concatenate([lo, lo + vs * cells]).astype(np.float32)
+    n, ndim = int(rng.integers(1, 6000)), int(rng.integers(3, 7))
+    pts = rng.uniform(-0.1, 1.1, (n, ndim)).astype(np.float32)
+    pts[:, :3] = lo + pts[:, :3] * (rng_arr[3:] - lo)
+    snap = rng.random(n) < 0.2
+    pts[snap, :3] = (lo + np.round((pts[snap, :3] - lo) / vs) * vs).astype(np.float32)
+    mp, mv = int(rng.integers(1, 9)), int(rng.integers(1, 400))
+    v, c, k = hip(points_to_voxel, pts, vs, rng_arr, mp, True, mv)
+    ov, oc, ok = oracle.points_to_voxel(pts, vs, rng_arr, mp, mv)
+    assert np.array_equal(c, oc) and np.array_equal(k, ok) and np.array_equal(v, ov)
+
+
 def test_voxeliser_waymo_shape_and_device_tensors(gpu):
     pts = synth.waymo_like_cloud(5, 180000)
     d = torch.from_numpy(pts).to(gpu)

@@ -42,6 +42,28 @@ def test_host_voxeliser_matches_oracle_on_seeded_clouds(seed, n, mv, mp):
     assert np.array_equal(c2, c[:, ::-1]) and np.array_equal(k2, k) and np.array_equal(v2, v)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_host_voxeliser_random_geometries_match_oracle(seed):
+    """Random ranges, voxel sizes, point counts, feature widths, max_points / max_voxels (the max_voxels break hit in about half of the
+    cases), points on cell faces and outside the range: coordinates, counts and payload bit-exact against the oracle's restatement of
+    voxel_generator.py:136-207."""
+    rng = np.random.default_rng(1000 + seed)
+    lo = rng.uniform(-50, 0, 3).astype(np.float32)
+    vs = rng.choice([0.05, 0.1, 0.16, 0.2, 0.4], 3).astype(np.float32)
+    cells = rng.integers(3, 60, 3)
+    rng_arr = np.concatenate([lo, lo + vs * cells]).astype(np.float32)
+    n, ndim = int(rng.integers(1, 6000)), int(rng.integers(3, 7))
+    pts = rng.uniform(-0.1, 1.1, (n, ndim)).astype(np.float32)
+    pts[:, :3] = lo + pts[:, :3] * (rng_arr[3:] - lo)
+    snap = rng.random(n) < 0.2                                       # a fifth of the points exactly on cell faces
+    pts[snap, :3] = (lo + np.round((pts[snap, :3] - lo) / vs) * vs).astype(np.float32)
+    mp, mv = int(rng.integers(1, 9)), int(rng.integers(1, 400))
+    v, c, k = points_to_voxel(pts, vs, rng_arr, mp, True, mv)
+    ov, oc, ok = oracle.points_to_voxel(pts, vs, rng_arr, mp, mv)
+    assert np.array_equal(c, oc) and np.array_equal(k, ok) and np.array_equal(v, ov)
+    assert v.shape[0] <= mv and (k >= 1).all() and (k <= mp).all()
+
+
 def test_host_voxeliser_edge_cases_and_dtypes():
     v, c, k = points_to_voxel(np.zeros((0, 4), np.float32), synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, True, 100)
     assert v.shape == (0, 5, 4) and c.shape == (0, 3) and k.shape == (0,)
