@@ -20,7 +20,7 @@ def pytest_configure(config):
 _FILE_ORDER = ["test_abi", "test_oracle_golden", "test_voxel_host", "test_voxel_gpu", "test_rulebook_gpu", "test_rulebook_nd_oracle", "test_spconv_gpu",
                "test_spconv4d_gpu", "test_pointnet2_gpu", "test_pointnet2_oracle", "test_roi_gpu", "test_iou3d_gpu", "test_iou3d_oracle",
                "test_dcn_gpu", "test_dcn_functions_cpu", "test_psroi_gpu", "test_psroi_oracle", "test_bn_gpu", "test_bn_oracle",
-               "test_bev_gpu", "test_primitives_gpu", "test_pyref_golden", "test_properties_gpu", "test_async_asm", "test_fma_audit"]
+               "test_bev_gpu", "test_primitives_gpu", "test_pyref_golden", "test_properties_gpu", "test_degenerate_gpu", "test_async_asm", "test_fma_audit"]
 _LAST = ["test_backbone_gpu", "test_reference_overlay", "test_dist_cpu", "test_ddp_gpu", "test_fv2p_step_gpu", "test_mgaf_head"]
 
 
