@@ -18,7 +18,7 @@ class _BevInterp(Function):
     @staticmethod
     def forward(ctx, bev, x, y, channels_first):
         _nat.require_cuda(bev, x, y)
-        if bev.dtype != torch.float32:
+        if bev.is_cuda and bev.dtype != torch.float32:
             raise _nat.Fv2pError("bev_grid_pooling: float32 feature maps expected")
         bev = bev.contiguous()
         x, y = x.detach().float().contiguous(), y.detach().float().contiguous()
@@ -27,7 +27,7 @@ class _BevInterp(Function):
         else:
             b, h, w, c = bev.shape
         n = x.shape[1]
-        out = torch.empty((b, n, c), dtype=torch.float32, device=bev.device)
+        out = torch.empty((b, n, c), dtype=bev.dtype, device=bev.device)
         with _nat.device_guard(bev.device):
             ws = _nat.workspace(max(int(_nat.lib().fv2p_bev_interp_ws_bytes(b, c, h, w, int(channels_first))), 16), bev.device)
             _nat.call("fv2p_bev_interp_fwd", bev, b, c, h, w, int(channels_first), x, y, n, out, ws, ws.numel(), _nat.stream())
@@ -39,8 +39,8 @@ class _BevInterp(Function):
     def backward(ctx, grad_out):
         x, y = ctx.saved_tensors
         b, c, h, w, channels_first = ctx.geom
-        g = grad_out.contiguous().float()
-        grad_bev = torch.empty((b, c, h, w) if channels_first else (b, h, w, c), dtype=torch.float32, device=g.device)
+        g = grad_out.contiguous()
+        grad_bev = torch.empty((b, c, h, w) if channels_first else (b, h, w, c), dtype=g.dtype, device=g.device)
         with _nat.device_guard(g.device):
             ws = _nat.workspace(max(b * c * h * w * 4 if channels_first else 16, 16), g.device)
             _nat.call("fv2p_bev_interp_bwd", g, b, c, h, w, int(channels_first), x, y, x.shape[1], grad_bev, ws, ws.numel(), _nat.stream())

@@ -115,7 +115,7 @@ def _bev_bwd(grad_out, b, c, h, w, channels_first, x, y, n, grad_bev, ws, ws_byt
     g = _np(grad_out).reshape(b, n, c)
     xs, ys = _np(x).reshape(b, n), _np(y).reshape(b, n)
     res = [bev_oracle.bilinear_interpolate_grad((h, w, c), xs[k], ys[k], g[k]) for k in range(b)]
-    res = np.stack(res).astype(np.float32)
+    res = np.stack(res)      # float64 sums, rounded once to the caller's dtype
     _fill(grad_bev, np.transpose(res, (0, 3, 1, 2)) if channels_first else res)
 
 

@@ -9,7 +9,8 @@ import numpy as np
 def bilinear_interpolate(im, x, y):
     """im (H, W, C) float32, x (N), y (N) float32 -> (N, C) float32; corners clamped to the map, weights from the
     clamped corners, products summed in the order a, b, c, d — all in float32 like the reference's torch ops."""
-    im = np.asarray(im, np.float32)
+    im = np.asarray(im)
+    im = im if im.dtype == np.float64 else im.astype(np.float32, copy=False)   # float64 maps: the calibration run of tests/f64_calibration.py only
     x, y = np.asarray(x, np.float32), np.asarray(y, np.float32)
     h, w = im.shape[0], im.shape[1]
     x0 = np.floor(x).astype(np.int64)

@@ -29,25 +29,16 @@ class SmallFV2P(FV2PConfig):
     dp_ratio = 0.0          # dropout draws differ between devices
 
 
-GRAD_TOL = 2e-3     # relative L2 per parameter gradient, GPU kernels against the host run
-# ... except along the DEEP END of the backward chain: the gradients of the sparse backbone and of the voxel-to-point decoder have
-# passed through every later layer's backward and 20 - 40 train-mode BatchNorms.  Measured per module group (printed by the test):
-# decoder 3.6e-3, backbone conv_input 1e-3 -> conv1 1.2e-3 -> conv2 2.4e-3 -> conv3 3.6e-3 -> conv4 4.7e-3 (worst: conv4.2.bn1.bias,
-# a sum with heavy cancellation), everything else <= 5e-4.  Both sides are float32 with independent rounding; against a FLOAT64 run of
-# the backbone (tools/f64_gap.py, profiles/r04_f64_gap.txt) the HIP path sits at a median of 1.3 x torch float32's own distance
-# (worst parameter 2.2e-3 for both), and none of the fused pieces moves that figure - K-split partial sums, tiling plan, epilogue
-# statistics, pair-split weight gradients, deferred weight gradients were each switched off in turn; WITHOUT the fused BatchNorm
-# (float64 statistics) the median ratio is 5.2.  The one effect found was the length of the fused multiply-add chain (27 offsets x
-# channels in one chain: forward 1.18e-6 from float64, per-offset products added afterwards as the reference does: 1.00e-6; torch 7.2e-7).
-# Round 3 allowed 2e-2 here.
-# Round 5: the product's FV2P layers are float32-only by contract (they mirror the reference's checks), so the float64-calibrated criterion of
-# tests/f64_calibration.py (used for the sparse backbones and the MGAF step) cannot run this step a third time in float64; the bound
-# here follows the fallback rule instead - at least twice the worst value seen over fresh boxes.  The worst parameter (conv4.2.bn1.bias)
-# measured 4.67e-3 ... 4.7e-3 on every box of rounds 4 and 5 (profiles/r05_gputest_box*.txt: the HIP side is run-to-run identical under
-# the deterministic library settings and the host side is this container's image): DEEP_END_TOL = 1e-2; everything outside the deep end
-# measured <= 5.9e-4 against GRAD_TOL = 2e-3.
+GRAD_TOL = 2e-3     # relative L2 per parameter gradient where both sides see IDENTICAL inputs and a short chain (the RoI head test, the
+#                     reference-call-structure test: two runs on the same GPU)
+# The first-stage gradients of the whole step are held by the float64-calibrated criterion of tests/f64_calibration.py (round 5): the
+# host run is repeated in float64 (the one float32-only layer on that path, the BEV gather, follows the dtype of a HOST tensor; CUDA
+# tensors are float32 or refused as before) and the HIP run may be at most K times as far from it as the float32 oracle run is, per module
+# group.  Rounds 3 - 4 had hand-set bounds here (2e-2, then 6e-3 for the sparse backbone + decoder against a measured 4.7e-3); the
+# measured number turned out to depend on the HOST: 4.67e-3 with 128 or 32 BLAS threads, 5.86e-3 with 6, 1.56e-2 with one
+# (profiles/r05_chain_tests_host_threads.txt) - the float32 oracle run moves, not the HIP run.
 DEEP_END = ("backbone_3d.", "post_pfe.")
-DEEP_END_TOL = 1e-2
+DEEP_END_TOL = 1e-2     # only for test_reference_call_structure_is_the_same_step (HIP against HIP: no host in the comparison)
 
 
 def grad_tol(name):
@@ -92,6 +83,14 @@ def cpu_run():
         (ref.taps["loss_rpn"] + ref.taps["loss_point"]).backward(retain_graph=True)
         stage1 = {k: p.grad.clone() for k, p in ref.named_parameters() if p.grad is not None}
         ref.taps["loss_rcnn"].backward()
+        # the same first stage in float64: the calibration run (tests/f64_calibration.py)
+        ref64 = cpu_mirror(model).double()
+        ref64.taps = {}
+        clouds, feats, coords, gt, u = inputs
+        ref64(clouds, feats.double(), coords, gt, u)
+        (ref64.taps["loss_rpn"] + ref64.taps["loss_point"]).backward()
+        ref.stage1_f64 = {k: p.grad.clone() for k, p in ref64.named_parameters() if p.grad is not None}
+        ref.taps_f64 = ref64.taps
     return model, ref, inputs, loss, stage1
 
 
@@ -119,30 +118,34 @@ def test_fv2p_step_matches_cpu_oracle(gpu, cpu_run):
         # legitimately differ between two float implementations (it is compared on identical inputs in the next test)
         (g["loss_rpn"] + g["loss_point"]).backward(retain_graph=True)
     assert torch.equal(g["keypoints"].cpu(), c["keypoints"])                          # FPS order: bit-exact
-    assert rel(g["point_features"].detach().cpu(), c["point_features"].detach()) < 1e-3
-    assert rel(g["bev"].detach().cpu(), c["bev"].detach()) < 1e-3
-    assert abs(g["loss_point"].item() - c["loss_point"].item()) < 1e-3 * max(1.0, abs(c["loss_point"].item()))
-    assert abs(g["loss_rpn"].item() - c["loss_rpn"].item()) < 1e-3 * max(1.0, abs(c["loss_rpn"].item()))
-    # EVERY parameter the first-stage + point losses reach, relative L2 (the host run of this very Python is held to the reference's
-    # own detector within 3e-3 per parameter, tests/test_reference_overlay.py): 2e-3, not six hand-picked names at 1e-2
-    gp = dict(net.named_parameters())
-    worst, bad, by_group = ("", 0.0), [], {}
-    for name, want in stage1.items():
-        a, b = gp[name].grad.cpu().double(), want.double()
-        if zero_gradient(name):
-            continue
-        if float(b.norm()) < 1e-10:      # a parameter the two losses do not reach (second-stage layers): both sides zero
-            assert float(a.norm()) < 1e-8, name
-            continue
-        err = float((a - b).norm() / b.norm())
-        worst = max(worst, (name, err), key=lambda t: t[1])
-        grp = ".".join(name.split(".")[:2])
-        by_group[grp] = max(by_group.get(grp, 0.0), err)
-        if err >= grad_tol(name):
-            bad.append((name, f"{err:.2e}"))
-    print(f"worst first-stage gradient: {worst[0]} {worst[1]:.2e}")
-    print("largest gradient error per module group:", {k: f"{v:.1e}" for k, v in by_group.items()})
-    assert not bad, " ".join(f"{n}={e}" for n, e in bad)
+    import f64_calibration as cal
+    t64 = ref.taps_f64
+    for name in ("point_features", "bev"):      # features through the 21-layer backbone (+ decoder / BEV backbone): calibrated like the gradients
+        d_hip, d_ref = rel(g[name].detach().cpu(), t64[name].detach()), rel(c[name].detach(), t64[name].detach())
+        print(f"{name:15s} max-rel distance to float64: hip {d_hip:.2e}  host32 {d_ref:.2e}")
+        assert d_hip <= max(cal.K * d_ref, cal.FLOOR), (name, d_hip, d_ref)
+    for name in ("loss_point", "loss_rpn"):
+        got, host, want = g[name].item(), c[name].item(), float(t64[name])
+        assert abs(got - want) <= max(cal.K * abs(host - want), cal.FLOOR * max(1.0, abs(want))), (name, got, host, want)
+    # EVERY parameter the first-stage + point losses reach: the HIP run at most K times as far from the float64 host run as the float32
+    # oracle run is, per module group (median and pooled relative L2; floor 1e-4; every parameter within 0.25)
+    assert torch.equal(ref.taps_f64["keypoints"].float(), c["keypoints"])          # the float64 run takes the float32 run's decisions
+    gp = {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+    reach = {k: v for k, v in ref.stage1_f64.items() if float(v.norm()) >= 1e-10}  # second-stage layers: not reached by the two losses
+    for name in set(ref.stage1_f64) - set(reach):
+        if not zero_gradient(name):
+            assert float(gp[name].norm()) < 1e-8, name
+    group = lambda n: n.split(".")[0]
+    # floor: FLIPS - the same 21-layer backbone as tests/test_backbone_gpu.py sits at the deep end of this chain, and a single ReLU decision
+    # that differs from the float64 run leaves 1e-4 ... 1e-3 in everything upstream of it (HIP: the decoder's median 7.9e-5 against the host
+    # run's 1.3e-6 on the boxes of round 5, a ratio without meaning)
+    rows, bad = cal.compare(gp, stage1, reach, group, zero_gradient, floor=cal.FLIPS)
+    print(cal.report(rows))
+    print(cal.report(cal.compare(gp, stage1, reach, lambda n: ".".join(n.split(".")[:2]), zero_gradient)[0], "the same by sub-module (printed, not judged)"))
+    worst = max(((float((gp[k].cpu().double() - v.double()).norm() / v.double().norm()), k) for k, v in stage1.items()
+                 if k in reach and not zero_gradient(k)))
+    print(f"worst first-stage gradient against the host float32 run (informative): {worst[1]} {worst[0]:.2e}")
+    assert not bad, "\n".join(bad)
     g["loss_rcnn"].backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
     # the second-stage loss is compared unconditionally in test_roi_head_on_identical_inputs_matches_cpu_oracle (both heads are fed
