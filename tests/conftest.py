@@ -13,6 +13,14 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The host side of the parity tests (the oracle's torch-CPU ops) runs small matrices: on a 256-core box torch's default of 128 threads
+    # makes the suite take 6.5 min against 2.9 min single-threaded (profiles/r05_chain_tests_host_threads*.txt).  At most 16 threads;
+    # no test's verdict depends on the count (the chain tests are float64-calibrated: tests/f64_calibration.py).
+    try:
+        import torch
+        torch.set_num_threads(max(1, min(torch.get_num_threads(), 16)))
+    except Exception:
+        pass
 
 
 # Per-op parity and reference-golden files first, chain / step-level files last: with `-x` a step-level failure must not hide the per-op
