@@ -84,6 +84,10 @@ def parse():
     ap.add_argument("--sync-debug", action="store_true", help="diagnostic: one step under torch.cuda.set_sync_debug_mode('warn'); every host-blocking torch call with its call site (stderr)")
     ap.add_argument("--torch-profile", action="store_true", help="diagnostic: torch.profiler over 3 steps, top ops by device time (stderr)")
     ap.add_argument("--point-stream", type=int, default=1, help="fv2p: decoder + point head on their own stream (A/B switch)")
+    ap.add_argument("--grad-sync", choices=["auto", "flat", "ddp"], default="auto",
+                    help="N > 1: how the ranks' gradients are averaged.  flat = one flat buffer and ONE RCCL all-reduce after backward "
+                         "(fv2p_harness.dist_utils.FlatGradAllReduce: 90 MB, under a millisecond over xGMI, nothing beside the step's own streams); "
+                         "ddp = torch DistributedDataParallel (25 MB buckets overlapped with backward).  auto: flat for the FV2P workloads, ddp otherwise")
     ap.add_argument("--wgrad-stream", type=int, default=-1,
                     help="sparse-conv weight gradients on a second stream beside the backward-data convs (FV2P_WGRAD_OVERLAP).  Default: off for the FV2P "
                          "workloads (round 5: 29.85 against 29.92 ms per step with it, but every 128-channel backward-data conv beside a weight-gradient "
@@ -426,8 +430,15 @@ def build_fv2p_step(args, device, rank, world):
         model.backbone_2d.to(memory_format=torch.channels_last)
         model.dense_head.to(memory_format=torch.channels_last)
         model.bev_channels_last = True
-    net = dist_utils.wrap_ddp(model, device, find_unused_parameters=False)   # every parameter takes part in every step
     params = [p for p in model.parameters() if p.requires_grad]
+    flat_sync = None
+    if args.grad_sync == "ddp":
+        net = dist_utils.wrap_ddp(model, device, find_unused_parameters=False)   # every parameter takes part in every step
+    else:
+        net = model
+        if world > 1 or dist_utils.solo_ddp():
+            flat_sync = dist_utils.FlatGradAllReduce(params, device)
+            flat_sync.broadcast_parameters(0)
     opt = LeanAdamW(params, lr=1e-3, weight_decay=0.01) if args.lean_adamw else torch.optim.AdamW(params, lr=1e-3, weight_decay=0.01, fused=True)
     n_pool = 4
     pool = []
@@ -528,6 +539,8 @@ def build_fv2p_step(args, device, rank, world):
         if delay_at == "mid" and delay_s > 0:
             time.sleep(delay_s)
         loss.backward()
+        if flat_sync is not None:
+            flat_sync()      # N > 1: the one collective of the step
         if delay_at == "end" and delay_s > 0:
             time.sleep(delay_s)
         clip_grad_norm_(params, cfg.grad_norm_clip)   # GRAD_NORM_CLIP (train_utils.py:43); torch's own foreach kernels, less Python
@@ -562,6 +575,8 @@ def build_fv2p_step(args, device, rank, world):
             loss = net(clouds, feats, coords, gt, u)
             opt.zero_grad(set_to_none=True)
             loss.backward()
+            if flat_sync is not None:
+                flat_sync()
             (torch.nn.utils.clip_grad_norm_(params, cfg.grad_norm_clip, foreach=True) if reference else clip_grad_norm_(params, cfg.grad_norm_clip))
             opt.step()
             return loss
@@ -1080,6 +1095,8 @@ def main():
             dist.destroy_process_group()
         return
     pinned = pin_cores(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)), args.pin_cores)
+    if args.grad_sync == "auto":
+        args.grad_sync = "flat" if args.workload in ("fv2p", "fv2p-waymo") else "ddp"
     if args.wgrad_stream < 0:
         args.wgrad_stream = 0 if args.workload in ("fv2p", "fv2p-waymo") else 1
     if "FV2P_WGRAD_OVERLAP" not in os.environ:
@@ -1270,6 +1287,7 @@ def main():
             result["config"]["streams"] = ("dense branch (BEV backbone, anchor head, RoI preparation) on a side stream beside decoder + point head" if args.dense_stream
                                            else "decoder + point head on a side stream after the RoI preparation" if args.point_stream else "one stream")
             result["config"]["weight_gradient_stream"] = bool(int(os.environ.get("FV2P_WGRAD_OVERLAP", "1")))
+            result["config"]["gradient_sync"] = ("one flat all-reduce after backward" if args.grad_sync == "flat" else "DistributedDataParallel, 25 MB buckets") if (world > 1 or dist_utils.solo_ddp()) else "none (one rank)"
             result["config"]["stream_arrangement_same_for_every_n_gpus"] = True
             attempt = int(os.environ.get("FV2P_BENCH_ATTEMPT", "0"))
             result["attempt"], result["retried_after_hang"] = attempt, attempt > 0

@@ -93,6 +93,56 @@ def _standin_hook(state, bucket):
     return fut.then(after)
 
 
+class FlatGradAllReduce:
+    """Data parallelism with ONE collective per step: after backward the gradients are packed into one flat fp32 buffer (a multi-tensor
+    copy), averaged with a single all-reduce over RCCL / xGMI, and unpacked.  The FV2P detector has 22.4 M parameters = 90 MB of
+    gradients: one ring all-reduce of that moves ~160 MB through each GPU, well under a millisecond over xGMI, against a 30 ms step -
+    there is nothing worth overlapping, and NOT overlapping keeps RCCL's kernels off the hardware queues while the step's own three
+    streams are busy (one-rank DDP + a communication stand-in beside the backward pass: 36 ms per step; this form: 30.3,
+    profiles/r05_ddp_stream_matrix.txt).  Same result as DistributedDataParallel with every parameter used in every step (mean of the
+    ranks' gradients; tests/test_dist_cpu.py holds the two against each other); parameters without a gradient on this rank contribute
+    zeros, like DDP's find_unused_parameters.  `bench.py --grad-sync flat` (the default for the FV2P workloads) / `ddp`."""
+
+    def __init__(self, params, device=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=self.params[0].device)
+        self.views, off = [], 0
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        self.standin = os.environ.get("FV2P_DDP_COMM_STANDIN", "0") not in ("", "0") and self.flat.is_cuda
+        self.scratch = torch.empty_like(self.flat) if self.standin else None
+
+    def broadcast_parameters(self, src=0):
+        """DDP's constructor does this: every rank starts from rank `src`'s weights (and buffers are the caller's business)."""
+        if self.world > 1:
+            for p in self.params:
+                dist.broadcast(p.data, src)
+
+    @torch.no_grad()
+    def __call__(self):
+        """Average the gradients over the ranks (call between backward and the optimiser step, on the stream the gradients were
+        produced on)."""
+        have = [p.grad is not None for p in self.params]
+        if not all(have):
+            self.flat.zero_()
+        src = [p.grad for p, h in zip(self.params, have) if h]
+        dst = [v for v, h in zip(self.views, have) if h]
+        torch._foreach_copy_(dst, src)
+        if self.world > 1:
+            dist.all_reduce(self.flat)
+            self.flat.div_(self.world)
+        if self.standin:      # measurement on one GPU: the traffic of a ring all-reduce (about twice the buffer through each GPU)
+            self.scratch.copy_(self.flat)
+            self.flat.copy_(self.scratch)
+        if self.world > 1 or self.standin:
+            torch._foreach_copy_(src, dst)          # back into the gradients: one multi-tensor launch
+        for p, v, h in zip(self.params, self.views, have):
+            if not h:
+                p.grad = v.clone()
+
+
 def barrier():
     if dist.is_available() and dist.is_initialized():
         dist.barrier()

@@ -1,8 +1,8 @@
 """Child process of tests/test_ddp_gpu.py (not collected by pytest): one rank of a two-rank DistributedDataParallel run of the FV2P
 step in which BOTH ranks use GPU 0 and talk over gloo (RCCL refuses two ranks on one device; the 8-GPU node is the driver's).
     python tests/ddp_check.py <rank> <world> <port> <out dir>
-Writes <out dir>/rank<r>.pt = {"single": gradients of this rank's batch without DDP, "ddp": gradients after the first DDP backward,
-"losses": the three DDP steps' losses}."""
+Writes <out dir>/rank<r>.pt = {"single": gradients of this rank's batch without DDP, "flat": the same averaged over the ranks by
+dist_utils.FlatGradAllReduce, "ddp": gradients after the first DDP backward, "losses": the three DDP steps' losses}."""
 import os
 import sys
 
@@ -54,6 +54,11 @@ model.zero_grad(set_to_none=True)
 model(*batches[0]).backward()
 torch.cuda.synchronize()
 single = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}
+# ... averaged over the ranks by the flat form (bench.py --grad-sync flat: one buffer, one all-reduce after backward)
+flat_sync = dist_utils.FlatGradAllReduce([p for p in model.parameters() if p.requires_grad], gpu)
+flat_sync()
+torch.cuda.synchronize()
+flat = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}
 model.zero_grad(set_to_none=True)
 # the same batch under DistributedDataParallel, side streams as bench.py arranges them
 model.cfg = cfg_streams
@@ -75,6 +80,6 @@ for i in range(3):
     losses.append(float(loss))
 torch.cuda.synchronize()
 dist_utils.barrier()
-torch.save({"single": single, "ddp": ddp, "losses": losses}, os.path.join(out, f"rank{rank}.pt"))
+torch.save({"single": single, "ddp": ddp, "flat": flat, "losses": losses}, os.path.join(out, f"rank{rank}.pt"))
 torch.distributed.destroy_process_group()
 print(f"RANK {rank} DONE", losses)

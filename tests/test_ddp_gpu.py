@@ -14,7 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 @pytest.mark.gpu
 def test_two_ranks_on_one_gpu_fv2p_ddp(gpu, tmp_path):
-    """Three DDP steps with bench.py's stream arrangement, no hang within the time limit; after the first backward both ranks hold the
+    """Both gradient-averaging forms of bench.py on two ranks: the flat all-reduce after backward gives both ranks exactly the mean of
+    their single-process gradients.  Then three DDP steps with bench.py's stream arrangement, no hang within the time limit; after the first backward both ranks hold the
     same gradients and they are the MEAN of the two ranks' single-process gradients (per parameter: 2e-5 of its norm - the repo's
     float-atomic interpolation gradient alone moves a gradient by 3e-6 between two runs; the forward passes are bit-identical under
     the deterministic library settings of the child)."""
@@ -45,3 +46,8 @@ def test_two_ranks_on_one_gpu_fv2p_ddp(gpu, tmp_path):
         worst = max(worst, (k, err / max(float(mean.norm()), 1e-30)), key=lambda t: t[1])
         assert err < bound, f"{k}: all-reduced gradient differs from the mean of the single-process gradients by {err:.3e} (bound {bound:.3e})"
     print("worst parameter:", worst)
+    # the flat form (one buffer, ONE all-reduce after backward: bench.py's --grad-sync flat) gives every rank the same mean
+    for k, g0 in r0["flat"].items():
+        assert torch.equal(g0, r1["flat"][k]), f"{k}: the ranks hold different gradients after the flat all-reduce"
+        mean = (r0["single"][k].double() + r1["single"][k].double()) / 2
+        assert float((g0.double() - mean).norm()) <= 1e-6 * float(mean.norm()) + 1e-9 * mean.numel() ** 0.5, k

@@ -191,3 +191,59 @@ def test_lean_gradient_clipping_is_torchs_bit_for_bit():
         a = clip_grad_norm_(ps, max_norm)
         b = torch.nn.utils.clip_grad_norm_(qs, max_norm, foreach=True)
         assert torch.equal(a, b) and all(torch.equal(p.grad, q.grad) for p, q in zip(ps[:3], qs[:3])) and ps[3].grad is None
+
+
+def _flat_worker(rank, world, port, out):
+    for p in (REPO, os.path.join(REPO, "from-voxel-to-point_amd"), os.path.join(REPO, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    import copy
+    from fv2p_harness import dist_utils
+    dist_utils.init_distributed("gloo")
+    torch.manual_seed(1 + rank)                     # DIFFERENT initial weights per rank: broadcast_parameters must make them rank 0's
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+    unused = torch.nn.Linear(4, 4)                  # a module rank 1 never runs: its parameters have no gradient there
+    params = list(net.parameters()) + list(unused.parameters())
+    sync = dist_utils.FlatGradAllReduce(params)
+    sync.broadcast_parameters(0)
+    w0 = torch.cat([p.detach().reshape(-1) for p in params])
+    gathered = [torch.zeros_like(w0) for _ in range(world)]
+    dist.all_gather(gathered, w0)
+    ddp_net = torch.nn.parallel.DistributedDataParallel(copy.deepcopy(net))
+    x = torch.randn(5, 6, generator=torch.Generator().manual_seed(10 + rank))      # every rank its own batch
+    loss = net(x).square().mean()
+    if rank == 0:
+        loss = loss + unused(x[:, :4]).square().mean()
+    loss.backward()
+    local = [None if p.grad is None else p.grad.clone() for p in params]
+    sync()
+    ddp_net(x).square().mean().backward()
+    flat = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    ddp = torch.cat([p.grad.reshape(-1) for p in ddp_net.parameters()])
+    g_unused = torch.cat([p.grad.reshape(-1) for p in unused.parameters()])
+    both = [torch.zeros_like(g_unused) for _ in range(world)]
+    dist.all_gather(both, g_unused)
+    loc = torch.cat([(torch.zeros_like(p) if g is None else g).reshape(-1) for p, g in zip(unused.parameters(), local[-2:])])
+    locs = [torch.zeros_like(loc) for _ in range(world)]
+    dist.all_gather(locs, loc)
+    if rank == 0:
+        torch.save({"weights_equal": bool(torch.equal(gathered[0], gathered[1])), "flat_vs_ddp": float((flat - ddp).abs().max()),
+                    "scale": float(ddp.abs().max()), "unused_same": bool(torch.equal(both[0], both[1])),
+                    "unused_is_mean": float((both[0] - (locs[0] + locs[1]) / 2).abs().max()), "unused_norm": float(both[0].norm())}, out)
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_all_reduce_equals_ddp(tmp_path):
+    """fv2p_harness.dist_utils.FlatGradAllReduce (bench.py --grad-sync flat: one flat buffer, ONE all-reduce after backward) on two gloo
+    ranks: after broadcast_parameters every rank holds rank 0's weights; after the call every rank holds the gradients
+    DistributedDataParallel computes for the same batches (mean over the ranks, 1e-6); a parameter that has a gradient on one rank only
+    gets the mean with zeros for the other - DDP's find_unused_parameters behaviour - and the same value on both ranks."""
+    out = str(tmp_path / "flat.pt")
+    port = 29500 + (os.getpid() * 7) % 400
+    mp.spawn(_flat_worker, args=(2, port, out), nprocs=2, join=True)
+    r = torch.load(out)
+    assert r["weights_equal"]
+    assert r["flat_vs_ddp"] <= 1e-6 * max(r["scale"], 1.0), r
+    assert r["unused_same"] and r["unused_is_mean"] <= 1e-7 and r["unused_norm"] > 0, r

@@ -18,17 +18,22 @@ run plain_wgradstream "$W1 $Q4"
 run plain "$W0 $Q4"
 run plain_hwq6 "$W0 GPU_MAX_HW_QUEUES=6"
 run plain_hwq8 "$W0 GPU_MAX_HW_QUEUES=8"
-run solo "FV2P_DDP_SOLO=1 $W0 $Q4"
-run solo_hwq6 "FV2P_DDP_SOLO=1 $W0 GPU_MAX_HW_QUEUES=6"
-run standin_wgradstream_hwq4 "$S $W1 $Q4"
-run standin_wgradstream_hwq5 "$S $W1 GPU_MAX_HW_QUEUES=5"
-run standin_wgradstream_hwq6 "$S $W1 GPU_MAX_HW_QUEUES=6"
-run standin_wgradstream_hwq8 "$S $W1 GPU_MAX_HW_QUEUES=8"
-run standin_hwq4 "$S $W0 $Q4"
-run standin_hwq5 "$S $W0 GPU_MAX_HW_QUEUES=5"
-run standin_hwq6 "$S $W0 GPU_MAX_HW_QUEUES=6"
-run standin_hwq8 "$S $W0 GPU_MAX_HW_QUEUES=8"
-run standin_hwq4_pointstream "$S $W0 $Q4" --dense-stream 0
-run standin_hwq4_nobranchstream "$S $W0 $Q4" --dense-stream 0 --point-stream 0
-run standin_hwq4_nofpsahead "$S $W0 $Q4" --fps-ahead 0
-run standin_default "$S"
+run solo "FV2P_DDP_SOLO=1 $W0 $Q4" --grad-sync ddp
+run solo_hwq6 "FV2P_DDP_SOLO=1 $W0 GPU_MAX_HW_QUEUES=6" --grad-sync ddp
+run standin_wgradstream_hwq4 "$S $W1 $Q4" --grad-sync ddp
+run standin_wgradstream_hwq5 "$S $W1 GPU_MAX_HW_QUEUES=5" --grad-sync ddp
+run standin_wgradstream_hwq6 "$S $W1 GPU_MAX_HW_QUEUES=6" --grad-sync ddp
+run standin_wgradstream_hwq8 "$S $W1 GPU_MAX_HW_QUEUES=8" --grad-sync ddp
+run standin_hwq4 "$S $W0 $Q4" --grad-sync ddp
+run standin_hwq5 "$S $W0 GPU_MAX_HW_QUEUES=5" --grad-sync ddp
+run standin_hwq6 "$S $W0 GPU_MAX_HW_QUEUES=6" --grad-sync ddp
+run standin_hwq8 "$S $W0 GPU_MAX_HW_QUEUES=8" --grad-sync ddp
+run standin_hwq4_pointstream "$S $W0 $Q4" --dense-stream 0 --grad-sync ddp
+run standin_hwq4_nobranchstream "$S $W0 $Q4" --dense-stream 0 --point-stream 0 --grad-sync ddp
+run standin_hwq4_nofpsahead "$S $W0 $Q4" --fps-ahead 0 --grad-sync ddp
+run standin_default_ddp "$S" --grad-sync ddp
+run flat_solo "FV2P_DDP_SOLO=1" --grad-sync flat
+run flat_standin_hwq4 "$S $Q4" --grad-sync flat
+run flat_standin_hwq6 "$S GPU_MAX_HW_QUEUES=6" --grad-sync flat
+run flat_standin_hwq8 "$S GPU_MAX_HW_QUEUES=8" --grad-sync flat
+run flat_standin_default "$S"

@@ -59,7 +59,7 @@ bash tools/pmc_roofline.sh $TAG > $O/pmc_roofline.log 2>&1; tail -2 $O/pmc_roofl
 bash tools/pmc_mfma.sh $TAG > $O/pmc_mfma.log 2>&1; tail -2 $O/pmc_mfma.log
 
 echo "== one-rank DDP: RCCL's stream (and a stand-in for its traffic) beside the step's four streams"
-for mode in plain solo standin; do   # (stdout of these runs may carry a c10d warning inside the JSON line: numbers are taken by pattern)
+for mode in plain solo standin; do   # bench.py defaults: flat gradient sync, six hardware queues for a DDP-like run (numbers taken by pattern: a c10d warning may sit inside the JSON line)
   case $mode in plain) E="";; solo) E="FV2P_DDP_SOLO=1";; standin) E="FV2P_DDP_SOLO=1 FV2P_DDP_COMM_STANDIN=1";; esac
   env $E timeout 600 python3 bench.py --steps 20 --warmup 5 --cpu-clouds 0 --no-roofline --inline-steps 0 --refstyle-steps 0 > $O/ddp_$mode.json 2> $O/ddp_$mode.err
   echo "{\"mode\": \"$mode\", \"env\": \"$E\", $(grep -o '"ms_per_step": [0-9.]*' $O/ddp_$mode.json | head -1), $(grep -o '"value": [0-9.]*' $O/ddp_$mode.json | head -1)}"
