@@ -101,7 +101,9 @@ class FlatGradAllReduce:
     streams are busy (one-rank DDP + a communication stand-in beside the backward pass: 36 ms per step; this form: 30.3,
     profiles/r05_ddp_stream_matrix.txt).  Same result as DistributedDataParallel with every parameter used in every step (mean of the
     ranks' gradients; tests/test_dist_cpu.py holds the two against each other); parameters without a gradient on this rank contribute
-    zeros, like DDP's find_unused_parameters.  `bench.py --grad-sync flat` (the default for the FV2P workloads) / `ddp`."""
+    zeros, like DDP's find_unused_parameters.  Not covered: module BUFFERS (DDP re-broadcasts rank 0's BatchNorm running statistics
+    before every forward; here every rank keeps its own - they do not enter a training step, and a trainer saves rank 0's).
+    `bench.py --grad-sync flat` (the default for the FV2P workloads) / `ddp`."""
 
     def __init__(self, params, device=None):
         self.params = [p for p in params if p.requires_grad]
