@@ -87,7 +87,7 @@ def parse():
     ap.add_argument("--grad-sync", choices=["auto", "flat", "ddp"], default="auto",
                     help="N > 1: how the ranks' gradients are averaged.  flat = one flat buffer and ONE RCCL all-reduce after backward "
                          "(fv2p_harness.dist_utils.FlatGradAllReduce: 90 MB, under a millisecond over xGMI, nothing beside the step's own streams); "
-                         "ddp = torch DistributedDataParallel (25 MB buckets overlapped with backward).  auto: flat for the FV2P workloads, ddp otherwise")
+                         "ddp = torch DistributedDataParallel (25 MB buckets overlapped with backward).  auto = flat")
     ap.add_argument("--wgrad-stream", type=int, default=-1,
                     help="sparse-conv weight gradients on a second stream beside the backward-data convs (FV2P_WGRAD_OVERLAP).  Default: off for the FV2P "
                          "workloads (round 5: 29.85 against 29.92 ms per step with it, but every 128-channel backward-data conv beside a weight-gradient "
@@ -296,7 +296,14 @@ def build_step(args, device, rank, world):
             out, _ = self.body(feats, coords, batch)
             return out.features.square().mean()
 
-    net = dist_utils.wrap_ddp(TrainStep(model), device, find_unused_parameters=False)   # every parameter is used every step
+    flat_sync = None
+    if args.grad_sync == "ddp":
+        net = dist_utils.wrap_ddp(TrainStep(model), device, find_unused_parameters=False)   # every parameter is used every step
+    else:
+        net = TrainStep(model)
+        if world > 1 or dist_utils.solo_ddp():   # one flat all-reduce after backward
+            flat_sync = dist_utils.FlatGradAllReduce([p for p in model.parameters() if p.requires_grad], device)
+            flat_sync.broadcast_parameters(0)
     from fv2p_harness.optim import LeanAdamW
     opt = LeanAdamW(model.parameters(), lr=1e-3, weight_decay=0.01) if device.type == "cuda" and args.lean_adamw else \
         torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.01, fused=True)  # one multi-tensor kernel per step
@@ -358,6 +365,8 @@ def build_step(args, device, rank, world):
         loss = net(feats, coords, args.batch, gts[i % n_pool])
         opt.zero_grad(set_to_none=True)
         loss.backward()
+        if flat_sync is not None:
+            flat_sync()
         opt.step()
         return loss
 
@@ -399,6 +408,8 @@ def build_step(args, device, rank, world):
             loss = net(feats, coords, args.batch, gts[i % n_pool])
             opt.zero_grad(set_to_none=True)
             loss.backward()
+            if flat_sync is not None:
+                flat_sync()
             opt.step()
         return loss
 
@@ -1096,7 +1107,7 @@ def main():
         return
     pinned = pin_cores(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)), args.pin_cores)
     if args.grad_sync == "auto":
-        args.grad_sync = "flat" if args.workload in ("fv2p", "fv2p-waymo") else "ddp"
+        args.grad_sync = "flat"
     if args.wgrad_stream < 0:
         args.wgrad_stream = 0 if args.workload in ("fv2p", "fv2p-waymo") else 1
     if "FV2P_WGRAD_OVERLAP" not in os.environ:
@@ -1281,13 +1292,13 @@ def main():
         }
         # how close the step is to being bound by the host issuing its launches: CPU time of the stepping thread per step (beside ms_per_step)
         result["host_thread_cpu_ms_per_step"], result["host_process_cpu_ms_per_step"] = round(host_ms, 3), round(proc_ms, 3)
+        result["config"]["gradient_sync"] = ("one flat all-reduce after backward" if args.grad_sync == "flat" else "DistributedDataParallel, 25 MB buckets") if (world > 1 or dist_utils.solo_ddp()) else "none (one rank)"
         if args.workload in ("fv2p", "fv2p-waymo") and args.fps_ahead:
             result["config"]["input_pipeline"] += "; key points (FPS) of batch t+1 sampled on a side stream during the backward pass of step t"
         if args.workload in ("fv2p", "fv2p-waymo"):
             result["config"]["streams"] = ("dense branch (BEV backbone, anchor head, RoI preparation) on a side stream beside decoder + point head" if args.dense_stream
                                            else "decoder + point head on a side stream after the RoI preparation" if args.point_stream else "one stream")
             result["config"]["weight_gradient_stream"] = bool(int(os.environ.get("FV2P_WGRAD_OVERLAP", "1")))
-            result["config"]["gradient_sync"] = ("one flat all-reduce after backward" if args.grad_sync == "flat" else "DistributedDataParallel, 25 MB buckets") if (world > 1 or dist_utils.solo_ddp()) else "none (one rank)"
             result["config"]["stream_arrangement_same_for_every_n_gpus"] = True
             attempt = int(os.environ.get("FV2P_BENCH_ATTEMPT", "0"))
             result["attempt"], result["retried_after_hang"] = attempt, attempt > 0
