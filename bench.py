@@ -98,6 +98,7 @@ def parse():
     ap.add_argument("--impl", choices=["native", "refstyle"], default="native",
                     help="refstyle: the timed steps themselves run in the reference's call structure (fv2p_harness/refstyle.py); the default run "
                          "times that structure beside the native step for vs_restated_structure (--refstyle-steps)")
+    ap.add_argument("--sync-leg-steps", type=int, default=10, help="N > 1 (or FV2P_DDP_SOLO=1): extra steps of the same workload under the OTHER gradient synchronisation (ddp when --grad-sync is flat and vice versa), reported under dist.other_sync (0 = skip)")
     ap.add_argument("--inline-steps", type=int, default=10, help="FV2P workloads: extra steps on ONE stream with nothing prepared ahead, reported as inline_ms_per_step (0 = skip)")
     ap.add_argument("--refstyle-steps", type=int, default=6, help="FV2P workload: extra steps in the reference's call structure, reported as baseline / vs_restated_structure (vs_baseline itself stays null: BASELINE.md has no published number) (0 = skip)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous check without a GPU: ranks join a gloo group, reduce, rank 0 prints n_gpus")
@@ -302,8 +303,8 @@ def build_step(args, device, rank, world):
     else:
         net = TrainStep(model)
         if world > 1 or dist_utils.solo_ddp():   # one flat all-reduce after backward
-            flat_sync = dist_utils.FlatGradAllReduce([p for p in model.parameters() if p.requires_grad], device)
-            flat_sync.broadcast_parameters(0)
+            flat_sync = dist_utils.FlatGradAllReduce([p for p in model.parameters() if p.requires_grad], device, module=model)
+            flat_sync.broadcast_parameters(0)   # parameters and buffers, as DistributedDataParallel's constructor
     from fv2p_harness.optim import LeanAdamW
     opt = LeanAdamW(model.parameters(), lr=1e-3, weight_decay=0.01) if device.type == "cuda" and args.lean_adamw else \
         torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.01, fused=True)  # one multi-tensor kernel per step
@@ -362,6 +363,8 @@ def build_step(args, device, rank, world):
                 pre.submit(step.next_submit)
                 step.next_submit += 1
             feats, coords = pre.get()
+        if flat_sync is not None:
+            flat_sync.sync_buffers()   # rank 0's BatchNorm running statistics (DDP's broadcast_buffers=True); nothing at one rank
         loss = net(feats, coords, args.batch, gts[i % n_pool])
         opt.zero_grad(set_to_none=True)
         loss.backward()
@@ -369,6 +372,18 @@ def build_step(args, device, rank, world):
             flat_sync()
         opt.step()
         return loss
+
+    def set_sync(mode):
+        """Switch the gradient synchronisation of the SAME model and optimiser between "flat" and "ddp" (the extra leg of an N > 1 run)."""
+        nonlocal net, flat_sync
+        if mode == "ddp":
+            flat_sync, net = None, dist_utils.wrap_ddp(TrainStep(model), device, find_unused_parameters=False)
+        else:
+            net = TrainStep(model)
+            flat_sync = dist_utils.FlatGradAllReduce([p for p in model.parameters() if p.requires_grad], device, module=model)
+            flat_sync.broadcast_parameters(0)
+    step.set_sync = set_sync
+    step.flat_sync = lambda: flat_sync
 
     def step_phases(i, acc):
         """Same step with a device sync after every phase: (host time until the calls returned, time until the GPU drained)."""
@@ -448,8 +463,8 @@ def build_fv2p_step(args, device, rank, world):
     else:
         net = model
         if world > 1 or dist_utils.solo_ddp():
-            flat_sync = dist_utils.FlatGradAllReduce(params, device)
-            flat_sync.broadcast_parameters(0)
+            flat_sync = dist_utils.FlatGradAllReduce(params, device, module=model)
+            flat_sync.broadcast_parameters(0)   # parameters and buffers, as DistributedDataParallel's constructor
     opt = LeanAdamW(params, lr=1e-3, weight_decay=0.01) if args.lean_adamw else torch.optim.AdamW(params, lr=1e-3, weight_decay=0.01, fused=True)
     n_pool = 4
     pool = []
@@ -542,6 +557,8 @@ def build_fv2p_step(args, device, rank, world):
                 next_batch()
         if args.ahead_at == "start":
             enqueue_next()
+        if flat_sync is not None:
+            flat_sync.sync_buffers()   # rank 0's BatchNorm running statistics (DDP's broadcast_buffers=True); nothing at one rank
         loss = net(clouds, feats, coords, gt, u, key_job=job)
         if args.ahead_at == "mid":
             enqueue_next()   # between forward and backward
@@ -692,9 +709,21 @@ def build_fv2p_step(args, device, rank, world):
                 pre.get()
             pre.close()
 
+    def set_sync(mode):
+        """Switch the gradient synchronisation of the SAME model and optimiser between "flat" and "ddp" (the extra leg of an N > 1 run)."""
+        nonlocal net, flat_sync
+        if mode == "ddp":
+            flat_sync, net = None, dist_utils.wrap_ddp(model, device, find_unused_parameters=False)
+        else:
+            net = model
+            flat_sync = dist_utils.FlatGradAllReduce(params, device, module=model)
+            flat_sync.broadcast_parameters(0)
+
     step.phases = step_phases
     step.close = close
     step.inline = step_inline
+    step.set_sync = set_sync
+    step.flat_sync = lambda: flat_sync
     return model, step, voxelize, pool
 
 
@@ -847,11 +876,8 @@ def conv_kernel_name(cin, cout, n_dst=0):
     return f"conv_rows_pipe<{cinp},{nbp},false> (fv2p_sparse_conv_rows)"
 
 
-def roofline_probe(model, voxelize, pool, args, device):
-    """Times the dominant kernel (fused sparse-conv rows kernel of the widest-work layer) with events on the
-    stream it is launched on, and prices it with SURVEY §8(d)'s algorithmic flops / bytes."""
-    from pcdet.ops import spconv
-    from pcdet.ops.spconv import ops
+def roofline_layer(model, voxelize, pool, args):
+    """The sparse conv layer with the most algorithmic flops of one forward pass over pool[0] (hooks on every SparseConvolution)."""
     from pcdet.ops.spconv.conv import SparseConvolution
 
     records = []
@@ -872,7 +898,36 @@ def roofline_probe(model, voxelize, pool, args, device):
         model(feats, coords, args.batch)
     for h in hs:
         h.remove()
-    rec = max(records, key=lambda r: r["flops"])
+    torch.cuda.synchronize()
+    return max(records, key=lambda r: r["flops"])
+
+
+def in_step_probe(step, rec, first_step, steps=24):
+    """The same layer's FORWARD launches inside ordinary training steps: the library brackets every launch of exactly this shape
+    (channels, kernel volume, rows, table direction) with an event pair on its launch stream (fv2p_sparse_conv_probe_arm / _read).
+    Only the steps on the pool batch the layer was found on match the row count, the others run unbracketed."""
+    import ctypes
+    import fv2p_native as nat
+    mod, rb = rec["mod"], rec["rb"]
+    flip = int(rb.out_table(mod.in_channels)[1]) & 1
+    nat.call("fv2p_sparse_conv_probe_arm", mod.in_channels, mod.out_channels, rb.kvol, rec["n_out"], flip)
+    for i in range(steps):
+        step(first_step + i)
+    torch.cuda.synchronize()
+    us, n = ctypes.c_double(0.0), ctypes.c_int(0)
+    rc = nat.lib().fv2p_sparse_conv_probe_read(ctypes.byref(us), ctypes.byref(n))
+    if rc != 0 or n.value == 0:
+        return None
+    return {"in_step_us": round(us.value / n.value, 2), "in_step_launches": n.value, "in_step_steps": steps}
+
+
+def roofline_probe(model, voxelize, pool, args, device, rec=None, in_step=None):
+    """Times the dominant kernel (fused sparse-conv rows kernel of the widest-work layer) with events on the
+    stream it is launched on, and prices it with SURVEY §8(d)'s algorithmic flops / bytes.  `in_step` (in_step_probe's result) adds the
+    duration of the same layer's forward launches inside timed training steps and the fraction of the roofline that one gives."""
+    from pcdet.ops.spconv import ops
+    if rec is None:
+        rec = roofline_layer(model, voxelize, pool, args)
     mod, rb = rec["mod"], rec["rb"]
     w = mod.weight.detach()
     # 50 untimed launches first: the probe follows a host-side pause (the hooks above, the .item() reads), and the first launches after
@@ -911,10 +966,19 @@ def roofline_probe(model, voxelize, pool, args, device):
             traffic = pmc["traffic_bytes_per_launch"]
     except (OSError, KeyError, ValueError, StopIteration):
         pass
-    return {"bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "traffic": traffic,
-            "kernel": conv_kernel_name(cin, cout, rec["n_out"]),
-            "layer": layer,
-            "avg_kernel_us": round(dur_s * 1e6, 2), "alg_flops": flops, "alg_bytes": bytes_alg}
+    out = {"bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "traffic": traffic,
+           "kernel": conv_kernel_name(cin, cout, rec["n_out"]),
+           "layer": layer,
+           "avg_kernel_us": round(dur_s * 1e6, 2), "alg_flops": flops, "alg_bytes": bytes_alg,
+           "how": "achieved / frac / avg_kernel_us: 200 back-to-back launches of the layer alone after 50 warm-up launches (clock-warm, launch gaps included)"}
+    if in_step:
+        t = in_step["in_step_us"] * 1e-6
+        a = (flops / t / 1e12) if bound == "mfma" else (bytes_alg / t / 1e9)
+        out.update(in_step)
+        out["in_step_achieved"], out["in_step_frac"] = round(a, 3), round(a / peak, 4)
+        out["how"] += ("; in_step_*: the same layer's forward launches inside ordinary training steps of this run, each bracketed by an event pair on its "
+                       "launch stream (event-to-event time: the kernel plus one inter-packet gap); agrees with the rocprofv3 kernel table of the step (profiles/)")
+    return out
 
 
 def gts_of(step):
@@ -1141,6 +1205,8 @@ def main():
         beat("step")
     dist_utils.barrier()
     torch.cuda.synchronize()
+    if step.flat_sync() is not None:
+        step.flat_sync().timed_ms()   # forget the warm-up's all-reduce timings
     beat("step")
     if args.phases or args.sync_debug or args.torch_profile:
         beat("diag")     # long host phases: the --watchdog limit applies, not --stall
@@ -1214,6 +1280,50 @@ def main():
     torch.cuda.synchronize()
     dt = dist_utils.max_over_ranks(time.perf_counter() - t0, device)
 
+    # ---- N > 1: what the collective library actually did (one driver run must explain itself: no 8-GPU box was available to the builder)
+    dist_info = None
+    if (world > 1 or dist_utils.solo_ddp()) and dist.is_initialized():
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)                         # a sum of ones over the ranks the backend really connected
+        fs = step.flat_sync()
+        ar_ms, ar_n = fs.timed_ms() if fs is not None else (0.0, 0)
+        dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_seen_by_all_reduce": int(ones.item()),
+                     "gradient_sync": args.grad_sync,
+                     # events on the stepping stream around the one all-reduce of a step (RCCL's stream waits for it and it for RCCL's)
+                     "allreduce_ms_per_step": round(ar_ms / ar_n, 4) if ar_n else None,
+                     "allreduce_payload_mb": round(fs.flat.numel() * 4 / 2 ** 20, 2) if fs is not None else None,
+                     "buffers": ("rank 0's parameters and buffers broadcast at the start; its floating-point buffers (BatchNorm running statistics) again "
+                                 "before every forward pass as one flat broadcast (DistributedDataParallel's broadcast_buffers=True)") if fs is not None
+                                else "DistributedDataParallel defaults (broadcast_buffers=True)",
+                     "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")}
+        if args.sync_leg_steps > 0 and args.impl == "native":
+            other = "ddp" if args.grad_sync == "flat" else "flat"
+            step.set_sync(other)                      # same model, optimiser, streams and batches: only the synchronisation differs
+            for i in range(3):
+                step(args.warmup + args.steps + i)
+                beat("step")
+            dist_utils.barrier()
+            torch.cuda.synchronize()
+            if step.flat_sync() is not None:
+                step.flat_sync().timed_ms()
+            t1 = time.perf_counter()
+            for i in range(args.sync_leg_steps):
+                step(args.warmup + args.steps + 3 + i)
+                if (i & 3) == 3:
+                    beat("step")
+            dist_utils.barrier()
+            torch.cuda.synchronize()
+            other_s = dist_utils.max_over_ranks(time.perf_counter() - t1, device) / args.sync_leg_steps
+            o_ms, o_n = step.flat_sync().timed_ms() if step.flat_sync() is not None else (0.0, 0)
+            dist_info["other_sync"] = {"gradient_sync": other, "steps": args.sync_leg_steps, "ms_per_step": round(other_s * 1e3, 3),
+                                       "value": round(args.batch * world / other_s, 2),
+                                       "allreduce_ms_per_step": round(o_ms / o_n, 4) if o_n else None}
+            step.set_sync(args.grad_sync)
+            for i in range(2):                        # the legs below run under the headline's synchronisation again
+                step(args.warmup + args.steps + 3 + args.sync_leg_steps + i)
+            dist_utils.barrier()
+            torch.cuda.synchronize()
+
     def extra_leg(k, warm, **kw):
         """k more steps through step.inline, timed like the headline (barrier + synchronize on both sides, max over ranks)."""
         for i in range(warm):
@@ -1272,6 +1382,16 @@ def main():
               tuple(np.percentile(d, [10, 50, 90, 99, 100])), file=sys.stderr)
         top = np.argsort(d)[-4:][::-1]
         print("[step-times] slowest steps (index: ms):", ", ".join("%d: %.2f" % (int(i) + 1, d[i]) for i in top), file=sys.stderr)
+    # the roofline layer inside ordinary steps (every rank steps along: the steps hold the collective; rank 0 reports)
+    rl_rec = rl_in_step = None
+    if not args.no_roofline and args.impl == "native" and not args.dry_run and args.workload != "mgaf":
+        sparse_net = model.backbone_3d if fv2p else model
+        rl_pool = [pool[0][0]] if fv2p else pool
+        rl_rec = roofline_layer(sparse_net, voxelize, rl_pool, args)
+        n_done = args.warmup + args.steps + 64      # past every step index used above; a multiple of the pool size is not needed
+        rl_in_step = in_step_probe(step, rl_rec, n_done - n_done % 4)
+        dist_utils.barrier()
+        beat("post")
     step.close()
     result = None
     if rank == 0:
@@ -1292,6 +1412,8 @@ def main():
         }
         # how close the step is to being bound by the host issuing its launches: CPU time of the stepping thread per step (beside ms_per_step)
         result["host_thread_cpu_ms_per_step"], result["host_process_cpu_ms_per_step"] = round(host_ms, 3), round(proc_ms, 3)
+        if dist_info is not None:
+            result["dist"] = dist_info
         result["config"]["gradient_sync"] = ("one flat all-reduce after backward" if args.grad_sync == "flat" else "DistributedDataParallel, 25 MB buckets") if (world > 1 or dist_utils.solo_ddp()) else "none (one rank)"
         if args.workload in ("fv2p", "fv2p-waymo") and args.fps_ahead:
             result["config"]["input_pipeline"] += "; key points (FPS) of batch t+1 sampled on a side stream during the backward pass of step t"
@@ -1331,14 +1453,14 @@ def main():
         if args.workload == "fv2p-waymo":
             result["metric"] = "point clouds/sec fwd+bwd (FV2P, Waymo shape: 180k points, 0.1 m voxels)"
             if not args.no_roofline:
-                result["roofline"] = roofline_probe(model.backbone_3d, voxelize, [pool[0][0]], args, device)
+                result["roofline"] = roofline_probe(model.backbone_3d, voxelize, [pool[0][0]], args, device, rl_rec, rl_in_step)
                 result["fps"] = fps_probe(model, pool, args, device)
         elif args.workload == "fv2p":
             if not args.no_roofline:
                 # dominant kernel of the step (profiles/r02_fv2p_kernel_stats.csv): the fused sparse conv of the residual
                 # backbone's heaviest layer, priced against the fp32-MFMA roofline; FPS (latency-bound) reported beside it
                 sparse = model.backbone_3d
-                result["roofline"] = roofline_probe(sparse, voxelize, [pool[0][0]], args, device)
+                result["roofline"] = roofline_probe(sparse, voxelize, [pool[0][0]], args, device, rl_rec, rl_in_step)
                 result["fps"] = fps_probe(model, pool, args, device)
             if world == 1 and args.cpu_clouds > 0:
                 result["cpu_baseline"] = cpu_baseline_fv2p(model, args)
@@ -1362,7 +1484,7 @@ def main():
                             "(spconv_ops.h:260-457), separate BatchNorm1d / ReLU, dense() by scatter + permute; voxeliser, rulebook build and MIOpen layers as in the native step"}
         else:
             if not args.no_roofline:
-                result["roofline"] = roofline_probe(model, voxelize, pool, args, device)
+                result["roofline"] = roofline_probe(model, voxelize, pool, args, device, rl_rec, rl_in_step)
             if world == 1 and args.cpu_clouds > 0:
                 result["cpu_baseline"] = cpu_baseline(model, args)
     if dist.is_available() and dist.is_initialized():   # N ranks, or the one-rank group of FV2P_DDP_SOLO

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 #include "../../include/fv2p_ops.h"
 
 namespace fv2p {
@@ -32,6 +33,17 @@ int set_error(int code, const char* fmt, ...);
   } while (0)
 
 #define FV2P_LAUNCH_CHECK() FV2P_HIP(hipGetLastError())
+
+// Development switches (tuning overrides read from the environment, timing-only ablation kernels) exist only in a library built
+// with -DFV2P_DEV=1 (`make DEV=1` -> lib/dev/, used by tools/ and the profile scripts through FV2P_LIB_DIR).  The release library
+// reads no environment variable at all: its kernel choice is a function of the call's arguments and of the run-time setters declared
+// in include/fv2p_ops.h (fv2p_sparse_conv_set_impl / _set_paths, fv2p_dcn_set_colg_cap, ...), and tests/test_abi.py checks that the
+// names below do not occur in its string table.
+#ifdef FV2P_DEV
+#define FV2P_DEV_ENV(name) getenv(name)
+#else
+#define FV2P_DEV_ENV(name) (static_cast<const char*>(nullptr))
+#endif
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }

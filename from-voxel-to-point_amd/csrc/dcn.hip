@@ -928,7 +928,7 @@ extern "C" int fv2p_dcn_forward(const float* x_nhwc, const float* wt_oc, const f
     // map is too small to fill the chip: then two column halves, each gathering for itself.
     int nb = nb_all <= 4 ? 4 : (nb_all <= 8 ? 8 : 16);
     if (nb == 16 && ceil_div(npix, 64) < 2 * dcn_cu_count()) nb = 8;
-    if (const char* force = getenv("FV2P_DCN_FWD_NB")) {   // development: only the instantiated tiles, anything else is ignored
+    if (const char* force = FV2P_DEV_ENV("FV2P_DCN_FWD_NB")) {   // development: only the instantiated tiles, anything else is ignored
       const int f = atoi(force);
       if (f == 4 || f == 8 || f == 16) nb = std::max(f, nb_all <= 4 ? 4 : (nb_all <= 8 ? 8 : f));
     }
@@ -946,10 +946,11 @@ static long long kDwBlocksPerCu = 3;   // workgroups of the weight-gradient kern
 struct DcnBwdPlan {
   long long npix, nkeys, max_entries;
   int splits, pix_per_block, ci_tiles, co_tiles;
+  int splits_cap;   // the most splits any chunk of at most this many samples can get: what `partial` is carved for
 };
 static DcnBwdPlan dcn_bwd_plan(const DcnGeom& g) {
   DcnBwdPlan p;
-  { static bool once = false; if (!once) { once = true; if (const char* e = getenv("FV2P_DCN_DW_BPC")) kDwBlocksPerCu = std::max(1, atoi(e)); } }
+  { static bool once = false; if (!once) { once = true; if (const char* e = FV2P_DEV_ENV("FV2P_DCN_DW_BPC")) kDwBlocksPerCu = std::max(1, atoi(e)); } }
   const int K = g.kh * g.kw;
   p.npix = static_cast<long long>(g.B) * g.Ho * g.Wo;
   p.nkeys = static_cast<long long>(g.B) * g.dg * (g.H + 1) * (g.W + 1);
@@ -964,6 +965,10 @@ static DcnBwdPlan dcn_bwd_plan(const DcnGeom& g) {
   long long ppb = ceil_div(ceil_div(p.npix > 0 ? p.npix : 1, s), 16) * 16;
   p.pix_per_block = static_cast<int>(ppb);
   p.splits = static_cast<int>(ceil_div(p.npix > 0 ? p.npix : 1, ppb));
+  // A SMALLER chunk (the ragged tail of a batch) can get MORE splits than the full one: pix_per_block is rounded up to 16, so
+  // e.g. 100 x 88 px at 3 samples gives 83 splits and at 2 samples 85.  Whatever the sample count, splits <= s <= the resident
+  // round, and the workspace of the largest chunk serves every chunk: carve for that bound.
+  p.splits_cap = static_cast<int>(std::max<long long>(1, std::min<long long>((kDwBlocksPerCu * dcn_cu_count()) / cols, smax)));
   return p;
 }
 template <typename C>
@@ -975,7 +980,7 @@ static void dcn_bwd_carve(C& c, const DcnGeom& g, const DcnBwdPlan& p, float** c
   entries->lh = c.template take<float>(static_cast<size_t>(p.max_entries));
   entries->lw = c.template take<float>(static_cast<size_t>(p.max_entries));
   *scan_ws = c.template take<char>(scan_ws_bytes(p.nkeys));
-  *partial = c.template take<float>(static_cast<size_t>(p.splits) * K * g.Cin * g.Cout);
+  *partial = c.template take<float>(static_cast<size_t>(p.splits_cap) * K * g.Cin * g.Cout);
 }
 struct SizerC : Sizer {
   template <typename T> T* take(size_t n) { Sizer::take<T>(n); return nullptr; }
@@ -1032,6 +1037,8 @@ extern "C" int fv2p_dcn_backward(const float* x_nhwc, const float* wt, const flo
     DcnGeom gc = g;
     gc.B = std::min(bs, g.B - s0);
     const DcnBwdPlan p = dcn_bwd_plan(gc);
+    FV2P_REQUIRE(p.splits <= pmax.splits_cap && p.npix <= pmax.npix && p.nkeys <= pmax.nkeys, FV2P_EWORKSPACE,
+                 "dcn_backward: chunk of %d samples does not fit the workspace carved for %d", gc.B, gmax.B);
     const long long cpix = static_cast<long long>(gc.B) * pix;
     const float* xc = x_nhwc + static_cast<long long>(s0) * g.H * g.W * g.Cin;
     const float* oc = offset + static_cast<long long>(s0) * g.dg * 2 * K * pix;
@@ -1057,7 +1064,7 @@ extern "C" int fv2p_dcn_backward(const float* x_nhwc, const float* wt, const flo
     int seg_split = 1;
     for (int sp = 1; sp <= K * g.dg; ++sp)
       if ((K * g.dg) % sp == 0) { seg_split = sp; if (ceil_div(cpix, 64) * sp >= 6 * dcn_cu_count()) break; }
-    if (const char* force = getenv("FV2P_DCN_BWD_SPLIT")) {   // development: a divisor of the segment count or nothing
+    if (const char* force = FV2P_DEV_ENV("FV2P_DCN_BWD_SPLIT")) {   // development: a divisor of the segment count or nothing
       const int f = atoi(force);
       if (f >= 1 && f <= K * g.dg && (K * g.dg) % f == 0) seg_split = f;
     }

@@ -1708,7 +1708,7 @@ extern "C" int fv2p_furthest_point_sampling(int b, int n, int m, const float* da
   const int bs = fps_ref_block(n);
   hipStream_t st = STREAM(s);
   static int lazy = -1;   // FV2P_FPS_LAZY=0 keeps the plain kernel (the parity tests run both)
-  if (lazy < 0) { const char* e = getenv("FV2P_FPS_LAZY"); lazy = e ? atoi(e) : 1; }
+  if (lazy < 0) { const char* e = FV2P_DEV_ENV("FV2P_FPS_LAZY"); lazy = e ? atoi(e) : 1; }
   if (lazy && ws && ws_bytes >= fv2p_furthest_point_sampling_ws_bytes(b, n) && fps_bucketed_applies(n, m) && b < 65536) {
     const int64_t total = static_cast<int64_t>(b) * n;
     Carver c(ws, ws_bytes);
@@ -1735,7 +1735,7 @@ extern "C" int fv2p_furthest_point_sampling(int b, int n, int m, const float* da
       return 0;
     }
     static int form = -1;   // FV2P_FPS_FORM=thread keeps the per-thread buckets of round 1 (the parity tests run every form)
-    if (form < 0) { const char* e = getenv("FV2P_FPS_FORM"); form = (e && e[0] == 't') ? 0 : 1; }
+    if (form < 0) { const char* e = FV2P_DEV_ENV("FV2P_FPS_FORM"); form = (e && e[0] == 't') ? 0 : 1; }
     const int slots = static_cast<int>(ceil_div(n, kFpsWaves * 64));
     const int ppt = static_cast<int>(ceil_div(n, 1024));
     if (form == 1 || ppt > 16) {

@@ -21,6 +21,8 @@
 #include <stdlib.h>
 #include <type_traits>
 #include <algorithm>
+#include <mutex>
+#include <vector>
 
 namespace fv2p {
 
@@ -1801,23 +1803,23 @@ static int conv_cu_count() {
 // -1 = not read yet (FV2P_CONV_THIN / FV2P_CONV_RES preset them, default on); fv2p_sparse_conv_set_paths() switches them at run time
 // so that the parity tests hold each kernel against the staged kernel it replaces in one process.
 static int g_thin_on = -1, g_res_on = -1;
-static bool path_on(int& flag, const char* env) {
-  if (flag < 0) { const char* e = getenv(env); flag = (!e || atoi(e) != 0) ? 1 : 0; }
+static bool path_on(int& flag, const char* e) {   // e: the development preset (FV2P_DEV_ENV), null in the release library
+  if (flag < 0) flag = (!e || atoi(e) != 0) ? 1 : 0;
   return flag != 0;
 }
 static int g_wgrad_dma = 1;   // pair-split weight gradient: 1 = LDS-DMA kernel where the shapes allow, 0 = register-staged kernel
 static unsigned long long* g_conv_trace = nullptr;
 static int conv_impl() {
   if (g_conv_impl < 0) {
-    const char* e = getenv("FV2P_CONV_IMPL");
+    const char* e = FV2P_DEV_ENV("FV2P_CONV_IMPL");
     g_conv_impl = (e && e[0] == 'd') ? 1 : (e && e[0] == 'c') ? 2 : (e && e[0] == 'p') ? 3 : (e && e[0] == 'k') ? 4 : 0;
-    const char* ks = getenv("FV2P_CONV_KSPLIT");
+    const char* ks = FV2P_DEV_ENV("FV2P_CONV_KSPLIT");
     g_ksplit_auto = ks ? atoi(ks) : 1;
-    const char* tm = getenv("FV2P_KSPLIT_TM");
+    const char* tm = FV2P_DEV_ENV("FV2P_KSPLIT_TM");
     g_ksplit_tm = tm ? atoi(tm) : 0;
-    const char* gps = getenv("FV2P_KSPLIT_GPS");
+    const char* gps = FV2P_DEV_ENV("FV2P_KSPLIT_GPS");
     g_ksplit_gps = gps ? atoi(gps) : 0;
-    const char* pad = getenv("FV2P_KSPLIT_PAD");
+    const char* pad = FV2P_DEV_ENV("FV2P_KSPLIT_PAD");
     g_ksplit_pad = pad ? static_cast<size_t>(atoi(pad)) : 0;
   }
   return g_conv_impl;
@@ -1853,8 +1855,8 @@ static int g_plan_on = -1;    // FV2P_CONV_PLAN=0 ignores plans (comparison runs
 // one and a half rounds, 63 us where 512 tiles take one round.  FV2P_PLAN_ROWS forces the old rule with that row target.
 static int plan_pick_level(int64_t n_dst, int col_blocks) {
   if (g_plan_on < 0) {
-    const char* e = getenv("FV2P_CONV_PLAN"); g_plan_on = e ? atoi(e) : 1;
-    const char* r = getenv("FV2P_PLAN_ROWS"); g_plan_rows = r ? atoi(r) : 0;
+    const char* e = FV2P_DEV_ENV("FV2P_CONV_PLAN"); g_plan_on = e ? atoi(e) : 1;
+    const char* r = FV2P_DEV_ENV("FV2P_PLAN_ROWS"); g_plan_rows = r ? atoi(r) : 0;
   }
   if (!g_plan_on || n_dst > 65536) return -1;   // beyond ~1000 tiles the dispatcher balances by itself; full 64-row tiles reload the fewest weights
   const int levels = plan_levels(n_dst);
@@ -1924,7 +1926,8 @@ static void launch_vec(const ConvArgs& a, hipStream_t s) {
       if (level >= 0 || ksplit_rows<WT>(a) == 64) {
         b.col_blocks = NB / 4;
         const dim3 grid((level >= 0 ? tiles : blocks) * (NB / 4));
-        static const int abl = [] { const char* e = getenv("FV2P_KSPLIT_ABL"); return e ? atoi(e) : 0; }();
+#ifdef FV2P_DEV   // timing-only ablation instances: development builds only (results INVALID by construction)
+        static const int abl = [] { const char* e = FV2P_DEV_ENV("FV2P_KSPLIT_ABL"); return e ? atoi(e) : 0; }();
         if constexpr (CINP == 128 && !WT) {
           if (abl) {   // timing-only ablations of the roofline layer's forward kernel (see the template's comment)
 #define FV2P_ABL(V) case V: { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_ksplit<CINP, WT, 64, 1, V>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
@@ -1933,6 +1936,7 @@ static void launch_vec(const ConvArgs& a, hipStream_t s) {
 #undef FV2P_ABL
           }
         }
+#endif
         if (gps == 2) {
           static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_ksplit<CINP, WT, 64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
           if (once) { hipLaunchKernelGGL((conv_rows_ksplit<CINP, WT, 64, 2>), grid, dim3(256), lds64, s, b); return; }
@@ -1952,7 +1956,7 @@ static void launch_vec(const ConvArgs& a, hipStream_t s) {
   }
   if constexpr (CINP == 32 && NB <= 2) {
     // 32 source channels, full 3 x 3 x 3 kernel: every W_k resident in LDS, one persistent workgroup of 16 waves per CU
-    const bool res_on = path_on(g_res_on, "FV2P_CONV_RES");
+    const bool res_on = path_on(g_res_on, FV2P_DEV_ENV("FV2P_CONV_RES"));
     const bool whole = a.c_src == CINP && a.c_dst == NB * 16 && (a.ld_src & 3) == 0 && (reinterpret_cast<uintptr_t>(a.src) & 15) == 0;
     constexpr size_t res_lds = static_cast<size_t>(27) * CINP * NB * 16 * sizeof(float);
     // measured (tools/microbench.py conv): subm 32 -> 32 at 39 k rows 29.4 us forward / 29.4 us backward data against 34.7 / 32.3 us of the
@@ -1974,7 +1978,7 @@ static void launch_vec(const ConvArgs& a, hipStream_t s) {
     // kernels.  NOT at 32 channels: 49 against 35 us (subm 32 -> 32, 39 k rows), 22.4 against 20.1 us (16 -> 32) - a 4 KB weight
     // fragment per wave and offset through the vector-memory path costs more than the barrier it removes (LDS staging shares it
     // between the four waves of a workgroup).
-    const bool thin_on = path_on(g_thin_on, "FV2P_CONV_THIN");
+    const bool thin_on = path_on(g_thin_on, FV2P_DEV_ENV("FV2P_CONV_THIN"));
     const bool whole = a.c_src == CINP && a.c_dst == NB * 16 && (a.ld_src & 3) == 0 && (reinterpret_cast<uintptr_t>(a.src) & 15) == 0 &&
                        (!WT || ((a.w_ld & 3) == 0 && (a.w_kstride & 3) == 0 && (reinterpret_cast<uintptr_t>(a.w) & 15) == 0));
     if (impl == 0 && thin_on && whole && a.kvol == 27 && !a.perm) {
@@ -2198,6 +2202,49 @@ extern "C" int fv2p_sparse_conv_set_trace(unsigned long long* trace) {
   return 0;
 }
 
+// ---- in-step probe: event pairs around the launches of one layer shape (bench.py roofline.in_step_us) ---------------------------
+namespace {
+struct ConvProbe {
+  bool armed = false;
+  int c_src = 0, c_dst = 0, kvol = 0, flip = 0;
+  int64_t n_dst = 0;
+  int used = 0;
+  std::vector<hipEvent_t> ev;   // 2 per launch
+  std::mutex mu;
+};
+ConvProbe g_probe;
+constexpr int kProbePairs = 512;
+}  // namespace
+
+extern "C" int fv2p_sparse_conv_probe_arm(int c_src, int c_dst, int kvol, int64_t n_dst, int flip) {
+  std::lock_guard<std::mutex> lock(g_probe.mu);
+  if (g_probe.ev.empty()) {
+    g_probe.ev.resize(2 * kProbePairs);
+    for (auto& e : g_probe.ev) FV2P_HIP(hipEventCreate(&e));
+  }
+  g_probe.c_src = c_src; g_probe.c_dst = c_dst; g_probe.kvol = kvol; g_probe.n_dst = n_dst; g_probe.flip = flip & 1;
+  g_probe.used = 0;
+  g_probe.armed = true;
+  return 0;
+}
+
+extern "C" int fv2p_sparse_conv_probe_read(double* sum_us, int* launches) {
+  FV2P_REQUIRE(sum_us && launches, FV2P_EINVAL, "sparse_conv_probe_read: null pointer");
+  std::lock_guard<std::mutex> lock(g_probe.mu);
+  double total = 0.0;
+  for (int i = 0; i < g_probe.used; ++i) {
+    FV2P_HIP(hipEventSynchronize(g_probe.ev[2 * i + 1]));
+    float ms = 0.f;
+    FV2P_HIP(hipEventElapsedTime(&ms, g_probe.ev[2 * i], g_probe.ev[2 * i + 1]));
+    total += static_cast<double>(ms) * 1e3;
+  }
+  *sum_us = total;
+  *launches = g_probe.used;
+  g_probe.used = 0;
+  g_probe.armed = false;
+  return 0;
+}
+
 extern "C" int fv2p_sparse_conv_set_impl(int impl) {
   FV2P_REQUIRE(impl >= 0 && impl <= 4, FV2P_EINVAL, "impl must be 0 (auto), 1 (dense), 2 (compacted), 3 (pipelined) or 4 (pair-compacted K-split)");
   fv2p::g_conv_impl = impl;
@@ -2222,6 +2269,15 @@ static int conv_rows_impl(const float* src, int64_t n_src, int c_src, const floa
   // weight is [K][Cin][Cout] in the reference layout (spconv/conv.py:98-99); with transpose_w the roles of the
   // two channel axes are swapped: W_k^T is used, i.e. weight is [K][c_dst][c_src].
   const int w_rows = transpose_w ? c_dst : c_src, w_cols = transpose_w ? c_src : c_dst;
+  int probe_slot = -1;
+  if (g_probe.armed) {   // (unlocked read of a flag: the probe is armed and read by the thread that measures)
+    std::lock_guard<std::mutex> lock(g_probe.mu);
+    if (g_probe.armed && g_probe.used < kProbePairs && c_src == g_probe.c_src && c_dst == g_probe.c_dst && kvol == g_probe.kvol &&
+        n_dst == g_probe.n_dst && (flip_k & 1) == g_probe.flip && !transpose_w && !bn) {
+      probe_slot = g_probe.used++;
+      FV2P_HIP(hipEventRecord(g_probe.ev[2 * probe_slot], stream));
+    }
+  }
   for (int d0 = 0; d0 < c_dst; d0 += 128) {
     const int cd = (c_dst - d0) < 128 ? (c_dst - d0) : 128;
     for (int s0 = 0; s0 < c_src; s0 += 128) {
@@ -2248,6 +2304,7 @@ static int conv_rows_impl(const float* src, int64_t n_src, int c_src, const floa
       if (rc) return rc;
     }
   }
+  if (probe_slot >= 0) FV2P_HIP(hipEventRecord(g_probe.ev[2 * probe_slot + 1], stream));
   FV2P_LAUNCH_CHECK();
   return 0;
 }
@@ -2299,7 +2356,7 @@ extern "C" int fv2p_conv_plan_build(int* tab, int kvol, int64_t n_dst, void* ws,
   const int64_t entries = plan_level_offset(levels) - 2;
   int* plan = tab + static_cast<long long>(kvol) * n_dst;
   static int exact = -1;   // FV2P_PLAN_EXACT=0 keeps the equal-cost bounds (comparison runs)
-  if (exact < 0) { const char* e = getenv("FV2P_PLAN_EXACT"); exact = e ? atoi(e) : 1; }
+  if (exact < 0) { const char* e = FV2P_DEV_ENV("FV2P_PLAN_EXACT"); exact = e ? atoi(e) : 1; }
   const size_t lds = 2 * static_cast<size_t>(n_dst + 1) * sizeof(unsigned short);
   static bool big = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&plan_walk_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64) == hipSuccess; }();
   if (exact && kvol >= 8 && kvol <= 27 && n_dst >= 1024 && n_dst <= kPlanExactRows && (big || lds <= 48 * 1024)) {
@@ -2356,7 +2413,7 @@ extern "C" int fv2p_sparse_conv_rows_bnbwd(const float* src, int64_t n_src, int 
 
 static int wgrad_rows_per_chunk(int64_t n_dst) {
   static int forced = -1;  // FV2P_WGRAD_RPC: tuning override (multiple of 64)
-  if (forced < 0) { const char* e = getenv("FV2P_WGRAD_RPC"); forced = e ? atoi(e) : 0; }
+  if (forced < 0) { const char* e = FV2P_DEV_ENV("FV2P_WGRAD_RPC"); forced = e ? atoi(e) : 0; }
   if (forced >= 64 && forced <= kWgradMaxChunk) return forced;
   return n_dst > 200000 ? 1024 : 512;
 }
@@ -2490,7 +2547,7 @@ extern "C" int fv2p_sparse_conv_wgrad_pairs(const float* src, int64_t n_src, int
         // 64 x 64: 64-pair stages (64 KB LDS, 2 workgroups per CU) when the launch has about one live workgroup per CU,
         // 32-pair stages (4 per CU) when it has several (measured: 35 vs 43 us at N = 13k, 54 vs 61 us at N = 29k)
         static int st_env = -1;
-        if (st_env < 0) { const char* e = getenv("FV2P_WGRAD_ST"); st_env = e ? atoi(e) : 0; }
+        if (st_env < 0) { const char* e = FV2P_DEV_ENV("FV2P_WGRAD_ST"); st_env = e ? atoi(e) : 0; }
         const int st64 = st_env ? st_env : (static_cast<long long>(chunks) * kvol > 1200 ? 32 : 64);
         const int st = (as + bs <= 2) ? st64 : 32;
         const size_t lds = static_cast<size_t>(2) * st * (cs + cd) * sizeof(float) + 2 * kPairsMax * sizeof(int);

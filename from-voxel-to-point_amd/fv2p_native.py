@@ -12,7 +12,10 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "fv2p_ops.h")
-LIB_PATH = os.path.join(_HERE, "lib", "libfv2p_ops.so")
+# FV2P_LIB_DIR: another build of the same library (tools/ and the profile scripts point it at lib/dev, the -DFV2P_DEV=1 build
+# that reads tuning overrides from the environment; the release library in lib/ reads none)
+LIB_DIR = os.environ.get("FV2P_LIB_DIR") or os.path.join(_HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libfv2p_ops.so")
 
 _SCALARS = {
     "int": ctypes.c_int, "int64_t": ctypes.c_int64, "size_t": ctypes.c_size_t, "float": ctypes.c_float,
@@ -108,7 +111,7 @@ def torch_ext():
     global _EXT
     if _EXT is False:
         _EXT = None
-        path = os.path.join(_HERE, "lib", "fv2p_torch.so")
+        path = os.path.join(LIB_DIR, "fv2p_torch.so")
         if os.environ.get("FV2P_TORCH_EXT", "1") != "0" and os.path.exists(path):
             lib()  # libfv2p_ops.so first (RTLD_GLOBAL), the extension links against it
             import importlib.util

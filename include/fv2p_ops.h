@@ -160,6 +160,13 @@ int fv2p_sparse_conv_set_paths(int thin_on, int res_on);
  * offset loop, end of the prologue, clocks spent waiting at the per-offset barrier (wave 0), 0, 0} (shader clock) to
  * trace[8*blockIdx .. +7] (device memory, >= 8*ceil(n_dst/64) entries).  NULL switches it off. */
 int fv2p_sparse_conv_set_trace(unsigned long long* trace);
+/* Measurement hook (bench.py's roofline.in_step_us): while armed, every conv launch of fv2p_sparse_conv_rows* with exactly these
+ * channel counts, kernel volume, destination rows and table direction (flip_k & 1) is bracketed by a pair of HIP events on the
+ * launch stream (at most 512 pairs; further launches run unbracketed).  fv2p_sparse_conv_probe_read waits for the recorded pairs,
+ * returns their number and the sum of their elapsed times in microseconds, and disarms.  No reference counterpart (its timers are
+ * commented out: spconv_ops.h:305-360). */
+int fv2p_sparse_conv_probe_arm(int c_src, int c_dst, int kvol, int64_t n_dst, int flip);
+int fv2p_sparse_conv_probe_read(double* sum_us, int* launches);
 
 /* fv2p_sparse_conv_rows that also leaves the per-column sum and sum of squares of dst (fp64) in `stats`
  * [fv2p_sparse_conv_stat_slots()][2][c_dst]: the caller passes it zero-filled, the conv epilogue (or, for shapes

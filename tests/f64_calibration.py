@@ -33,13 +33,24 @@ three boxes) gives group ratios hip / host32 of 0.7 ... 5.2 for both statistics,
 as far from float64 as the host's from the first sparse conv on (one MFMA accumulation chain over 27 offsets x channels, against
 per-offset MKL products added afterwards) and the chain multiplies both alike.  The group MAXIMUM is printed but not judged: it is
 heavy-tailed (0.8 ... 45 for single bias vectors the host run happens to hit within 1e-5).  The worst single HIP parameter over all
-trials is 7e-2 from float64; WIRING is 3.5 x that."""
+trials is 7e-2 from float64; WIRING is 3.5 x that.
+
+Per-parameter bound (round 6, ADVICE).  A median and a norm-pooled distance cannot see a 5 - 20 % error in ONE small-norm gradient (a
+BatchNorm bias, a single layer's dW), and WIRING alone only catches O(1).  So every parameter p is also held to
+    d(hip_p, f64_p)  <=  max( K * d(host32_p, f64_p),  2 K * pooled d(host32, f64) of p's group,  PER_PARAM )
+i.e. K times its own host distance, or twice-K times the noise level of its group at these weights and inputs (a parameter the host
+run happens to hit within 1e-5 must not turn its own ratio into the verdict: the heavy tail above), or PER_PARAM = 5e-2 where both are
+tiny.  Against profiles/r05_step_noise*.txt: the worst HIP parameter of the deep groups is 7.3e-2 where the group's pooled host
+distance is 7.6e-3 (bound 0.15), the heads' worst 2.4e-2 (bound 5e-2): every trial of the three boxes passes with a factor >= 2, and
+a single-parameter error of 5 % (shallow groups) to 15 - 20 % (deep end) now fails.  The backbone-only test passes PER_PARAM = 1e-2
+(ten times the 4e-4 ... 1e-3 its parameters show on every box)."""
 import statistics
 
 K = 10.0
 FLOOR = 1e-4
 FLIPS = 2e-3
 WIRING = 0.25
+PER_PARAM = 5e-2
 
 
 def rel_l2(a, truth):
@@ -63,7 +74,7 @@ def pooled(grads, truth, names):
     return (num / max(den, 1e-300)) ** 0.5
 
 
-def compare(hip, host32, host64, group_of, skip=lambda name: False, k=K, floor=FLOOR, wiring=WIRING):
+def compare(hip, host32, host64, group_of, skip=lambda name: False, k=K, floor=FLOOR, wiring=WIRING, per_param=PER_PARAM):
     """-> (rows, failures): rows = [(group, n, hip_max, ref_max, hip_med, ref_med, hip_pooled, ref_pooled)], failures = strings."""
     d_hip = distances(hip, host64, skip)
     d_ref = distances(host32, host64, skip)
@@ -82,6 +93,10 @@ def compare(hip, host32, host64, group_of, skip=lambda name: False, k=K, floor=F
             bad.append(f"{g}: median distance {hmed:.2e} from float64 against the host float32 run's {rmed:.2e} (x{hmed / max(rmed, 1e-300):.1f} > {k})")
         if hpool > max(k * rpool, floor):
             bad.append(f"{g}: pooled distance {hpool:.2e} from float64 against the host float32 run's {rpool:.2e} (x{hpool / max(rpool, 1e-300):.1f} > {k})")
+        for n in names:   # the single parameter: K x its own host distance, 2 K x the group's noise level, or the per-parameter floor
+            bound = max(k * d_ref[n], 2.0 * k * rpool, per_param)
+            if d_hip[n] > bound:
+                bad.append(f"{n}: {d_hip[n]:.2e} from float64 against the host float32 run's {d_ref[n]:.2e}, group pooled {rpool:.2e} (bound {bound:.2e})")
     for name, d in d_hip.items():
         if d > wiring:
             bad.append(f"{name}: {d:.2e} from float64 (> {wiring}: not rounding)")

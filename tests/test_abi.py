@@ -43,3 +43,25 @@ def test_compiled_torch_binding_loads_and_matches_the_abi():
     assert ext is not None, "lib/fv2p_torch.so is missing: build with __graft_entry__.build()"
     assert ext.abi_version() == fv2p_native.lib().fv2p_abi_version() == 1
     assert callable(ext.sparse_conv) and callable(ext.batch_norm_relu)
+
+
+def test_release_library_reads_no_environment_switch():
+    """Round-5 review: development switches (tuning overrides, the timing-only FV2P_KSPLIT_ABL kernels whose results are invalid
+    by construction) must not ship.  The release library is built without -DFV2P_DEV: FV2P_DEV_ENV() is a null constant there
+    (csrc/common.hpp), so none of the variable names — in fact no FV2P_* string at all — survives into its string table, and the
+    csrc/*.hip sources call getenv only through that macro.  lib/dev/ (make DEV=1) is the build that has them."""
+    import re
+    root = os.path.dirname(nat.__file__)
+    release = os.path.join(root, "lib", "libfv2p_ops.so")
+    blob = open(release, "rb").read()
+    for name in (b"FV2P_KSPLIT_ABL", b"FV2P_KSPLIT_PAD", b"FV2P_KSPLIT_TM", b"FV2P_KSPLIT_GPS", b"FV2P_DCN_FWD_NB", b"FV2P_DCN_BWD_SPLIT",
+                 b"FV2P_DCN_DW_BPC", b"FV2P_WGRAD_RPC", b"FV2P_WGRAD_ST", b"FV2P_PLAN_ROWS", b"FV2P_PLAN_EXACT", b"FV2P_FPS_LAZY",
+                 b"FV2P_FPS_FORM", b"FV2P_CONV_IMPL", b"FV2P_CONV_KSPLIT", b"FV2P_CONV_PLAN", b"FV2P_CONV_THIN", b"FV2P_CONV_RES"):
+        assert name not in blob, name
+    assert not re.search(rb"FV2P_[A-Z][A-Z_]{3,}\x00", blob), "an FV2P_* environment name is left in the release library"
+    for f in os.listdir(os.path.join(root, "csrc")):
+        src = open(os.path.join(root, "csrc", f)).read()
+        src = src.replace("#define FV2P_DEV_ENV(name) getenv(name)", "")
+        assert not re.search(r"(?<![\w])getenv\(", src), f
+    # no ablation instance of the roofline kernel among the release library's kernels (template argument ABL != 0)
+    assert not re.search(rb"conv_rows_ksplitILi\d+ELb[01]ELi\d+ELi\d+ELi[1-9]", blob)

@@ -74,7 +74,7 @@ def test_backbone_forward_backward_matches_cpu_oracle(gpu, front_end, cls):
         if dead(n):
             assert gp[n].abs().max().item() < 1e-2
     # judged as ONE group with the ReLU-flip floor (tests/f64_calibration.py: between two flip events the per-stage ratio is meaningless)
-    rows, bad = cal.compare(gp, grads(ref), grads(ref64), lambda n: "backbone", dead, floor=cal.FLIPS)
+    rows, bad = cal.compare(gp, grads(ref), grads(ref64), lambda n: "backbone", dead, floor=cal.FLIPS, per_param=1e-2)
     print(cal.report(rows))
     print(cal.report(cal.compare(gp, grads(ref), grads(ref64), lambda n: n.split(".")[0], dead)[0], "the same by stage (printed, not judged)"))
     assert not bad, "\n".join(bad)

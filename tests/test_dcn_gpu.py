@@ -141,6 +141,61 @@ def test_mgaf_block_shapes_and_pack(gpu):
         blk.cpu()(torch.randn(1, 128, 8, 8))  # "Not implemented on the CPU", as the reference dispatcher
 
 
+def test_backward_ragged_tail_chunk_on_a_large_map(gpu):
+    """A SMALLER tail chunk can need MORE weight-gradient splits than the full chunk the workspace is carved for (pix_per_block is
+    rounded up to 16: 100 x 88 px, three samples -> 83 splits, the two-sample tail -> 85; round-5 ADVICE).  The 11 x 13 px maps of
+    test_backward_in_batch_chunks_vs_oracle cannot show it (their split count is capped by npix / 64).  Batch 5 as 3 + 2 on a
+    100 x 88 map: input / offset / mask gradients bit-identical to the unchunked call, the weight gradient within 1e-6 of it and
+    against the float64 oracle at 1e-4, the same bits on a second run, and a canary behind the workspace stays untouched."""
+    import fv2p_native
+    torch.manual_seed(11)
+    B, H, W, cin, cout, dg = 5, 100, 88, 32, 32, 1
+    x = torch.randn(B, cin, H, W)
+    offset = torch.randn(B, dg * 18, H, W) * 1.5
+    near = (offset - offset.round()).abs() < 1e-3
+    offset = torch.where(near, offset + 4e-3, offset)
+    mask = torch.sigmoid(torch.randn(B, dg * 9, H, W))
+    m = ModulatedDeformConv(cin, cout, 3, stride=1, padding=1, deformable_groups=dg, bias=False).to(gpu)
+    g = torch.randn(B, cout, H, W)
+
+    def run():
+        m.zero_grad(set_to_none=True)
+        gx, go, gm = (t.clone().to(gpu).requires_grad_(True) for t in (x, offset, mask))
+        y = m(gx, go, gm)
+        y.backward(g.to(gpu))
+        return [t.detach().clone() for t in (y, gx.grad, go.grad, gm.grad, m.weight.grad)]
+
+    whole = run()
+    try:
+        fv2p_native.call("fv2p_dcn_set_colg_cap", 3 * H * W * 9 * cin * 4)
+        parts, again = run(), run()
+        # the C-ABI call itself on a workspace of exactly the advertised size with a canary behind it
+        need = int(fv2p_native.lib().fv2p_dcn_backward_ws_bytes(B, H, W, H, W, cin, cout, 3, 3, dg))
+        ws = torch.zeros(need + 4096, dtype=torch.uint8, device=gpu)
+        ws[need:] = 0xA5
+        xh = x.to(gpu).permute(0, 2, 3, 1).contiguous()
+        dyh = g.to(gpu).permute(0, 2, 3, 1).contiguous()
+        wt = m.weight.detach().permute(2, 3, 1, 0).reshape(9, cin, cout).contiguous()
+        dx, doff, dmask, dwt = torch.empty_like(xh), torch.empty_like(offset, device=gpu), torch.empty_like(mask, device=gpu), torch.empty_like(wt)
+        fv2p_native.call("fv2p_dcn_backward", xh, wt, offset.to(gpu), mask.to(gpu), dyh, B, H, W, cin, cout, H, W, 3, 3, 1, 1, 1, 1, 1, 1, dg,
+                         dx, doff, dmask, dwt, ws, need, fv2p_native.stream())
+        torch.cuda.synchronize()
+        assert bool((ws[need:] == 0xA5).all()), "dcn_backward wrote behind its workspace"
+        assert torch.equal(dx.permute(0, 3, 1, 2), parts[1])
+    finally:
+        fv2p_native.call("fv2p_dcn_set_colg_cap", 0)
+    for k in range(4):
+        assert torch.equal(parts[k], whole[k]), k
+    assert rel(parts[4], whole[4]) < 1e-6
+    for a, c in zip(parts, again):
+        assert torch.equal(a, c)
+    cx, co, cm = (t.clone().double().requires_grad_(True) for t in (x, offset, mask))
+    w = m.weight.detach().cpu().double().requires_grad_(True)
+    ref = dcn_oracle.modulated_deform_conv(cx, co, cm, w, torch.zeros(cout, dtype=torch.float64), (1, 1), (1, 1), (1, 1), dg)
+    ref.backward(g.double())
+    assert rel(parts[0], ref) < 1e-4 and rel(parts[4], w.grad) < 1e-4 and rel(parts[1], cx.grad) < 1e-4
+
+
 @pytest.mark.parametrize("cin,dg", [(256, 4), (128, 1)])
 def test_mgaf_full_size_maps_forward_backward_vs_oracle(gpu, cin, dg):
     """BASELINE configs[3] shapes: the head's feature adaption [B, 256, 200, 176] with four deformable groups

@@ -205,9 +205,23 @@ def _flat_worker(rank, world, port, out):
     torch.manual_seed(1 + rank)                     # DIFFERENT initial weights per rank: broadcast_parameters must make them rank 0's
     net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
     unused = torch.nn.Linear(4, 4)                  # a module rank 1 never runs: its parameters have no gradient there
+    never = torch.nn.Linear(3, 3)                   # a module NO rank runs: its gradients must stay None (DDP leaves them alone too)
+    bn = torch.nn.BatchNorm1d(6, momentum=0.5)      # buffers: running statistics + num_batches_tracked
+    with torch.no_grad():
+        bn.running_mean.fill_(float(rank + 1))
+    holder = torch.nn.ModuleList([net, unused, never, bn])
     params = list(net.parameters()) + list(unused.parameters())
-    sync = dist_utils.FlatGradAllReduce(params)
+    sync = dist_utils.FlatGradAllReduce(params + list(never.parameters()), module=holder)
     sync.broadcast_parameters(0)
+    buf0 = bn.running_mean.clone()                  # rank 0's value (1.0) on every rank after the constructor-style broadcast
+    bn.train()
+    bn(torch.randn(8, 6, generator=torch.Generator().manual_seed(50 + rank)))     # per-rank statistics: the buffers drift apart
+    drift = bn.running_mean.clone()
+    sync.sync_buffers(0)                            # DDP's broadcast_buffers=True: rank 0's again
+    bufs = [torch.zeros_like(drift) for _ in range(world)]
+    dist.all_gather(bufs, bn.running_mean.clone())
+    drifts = [torch.zeros_like(drift) for _ in range(world)]
+    dist.all_gather(drifts, drift)
     w0 = torch.cat([p.detach().reshape(-1) for p in params])
     gathered = [torch.zeros_like(w0) for _ in range(world)]
     dist.all_gather(gathered, w0)
@@ -231,7 +245,9 @@ def _flat_worker(rank, world, port, out):
     if rank == 0:
         torch.save({"weights_equal": bool(torch.equal(gathered[0], gathered[1])), "flat_vs_ddp": float((flat - ddp).abs().max()),
                     "scale": float(ddp.abs().max()), "unused_same": bool(torch.equal(both[0], both[1])),
-                    "unused_is_mean": float((both[0] - (locs[0] + locs[1]) / 2).abs().max()), "unused_norm": float(both[0].norm())}, out)
+                    "unused_is_mean": float((both[0] - (locs[0] + locs[1]) / 2).abs().max()), "unused_norm": float(both[0].norm()),
+                    "never_none": all(p.grad is None for p in never.parameters()), "buf_start": float(buf0.mean()),
+                    "buf_drifted": not torch.equal(drifts[0], drifts[1]), "buf_synced": bool(torch.equal(bufs[0], bufs[1]) and torch.equal(bufs[0], drifts[0]))}, out)
     dist.destroy_process_group()
 
 
@@ -239,7 +255,8 @@ def test_flat_gradient_all_reduce_equals_ddp(tmp_path):
     """fv2p_harness.dist_utils.FlatGradAllReduce (bench.py --grad-sync flat: one flat buffer, ONE all-reduce after backward) on two gloo
     ranks: after broadcast_parameters every rank holds rank 0's weights; after the call every rank holds the gradients
     DistributedDataParallel computes for the same batches (mean over the ranks, 1e-6); a parameter that has a gradient on one rank only
-    gets the mean with zeros for the other - DDP's find_unused_parameters behaviour - and the same value on both ranks."""
+    gets the mean with zeros for the other - DDP's find_unused_parameters behaviour - and the same value on both ranks; a parameter no
+    rank used keeps grad None; module buffers are rank 0's after broadcast_parameters and after every sync_buffers()."""
     out = str(tmp_path / "flat.pt")
     port = 29500 + (os.getpid() * 7) % 400
     mp.spawn(_flat_worker, args=(2, port, out), nprocs=2, join=True)
@@ -247,3 +264,6 @@ def test_flat_gradient_all_reduce_equals_ddp(tmp_path):
     assert r["weights_equal"]
     assert r["flat_vs_ddp"] <= 1e-6 * max(r["scale"], 1.0), r
     assert r["unused_same"] and r["unused_is_mean"] <= 1e-7 and r["unused_norm"] > 0, r
+    # round 6: a parameter no rank used keeps grad None; buffers follow rank 0 at the start and at every sync_buffers()
+    assert r["never_none"], r
+    assert r["buf_start"] == 1.0 and r["buf_drifted"] and r["buf_synced"], r
