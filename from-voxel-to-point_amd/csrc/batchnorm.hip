@@ -13,25 +13,9 @@
 //             bn_apply_bwd_k    folds to dbeta, dgamma, c1, c2;  dx = gamma * invstd * (dz - c1 - xhat * c2)
 // The ReLU mask is recomputed from x, so y is not needed by the backward pass.
 #include "common.hpp"
+#include "bn_fold.hpp"
 
 namespace fv2p {
-
-struct BnGeom {
-  long long n;
-  int c, tcols, rpp, nblk;
-  long long rows_per_block;
-};
-
-struct BnFwdFin {   // outputs of the forward finalisation
-  float* mean; float* invstd;
-  float* running_mean; float* running_var; long long* num_batches_tracked;
-  float momentum;   // < 0: cumulative moving average (momentum=None)
-  float eps;
-};
-struct BnBwdFin {
-  float* dgamma; float* dbeta; float* coef;  // coef[0][c] = mean(dz), coef[1][c] = mean(dz * xhat) (0 when running stats were used)
-  int batch_stats;
-};
 
 template <int V>
 struct Vec;
@@ -49,11 +33,13 @@ struct Vec<1> {
 };
 
 // Workgroup-level reduction of per-thread (a, b) channel sums.  partial: [nblk][2][c] doubles.
+// mask_y (backward only, the residual form): the ReLU that follows is relu(bn(x) + identity), so its mask is read from the block's
+// OUTPUT (mask_y > 0) instead of being recomputed from x.
 template <int V, bool BWD>
 __global__ __launch_bounds__(256) void bn_reduce_k(const float* __restrict__ x, const float* __restrict__ dy, BnGeom g,
                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
-                                                   double* __restrict__ partial) {
+                                                   double* __restrict__ partial, const float* __restrict__ mask_y) {
   __shared__ double red[2][256 * V];
   const int tid = threadIdx.x;
   const int rl = tid / g.tcols, cq = tid % g.tcols;
@@ -73,7 +59,7 @@ __global__ __launch_bounds__(256) void bn_reduce_k(const float* __restrict__ x, 
     // U rows in flight per thread: the pass is latency bound (a few MB spread over the whole chip), so the loads of
     // a group are all issued before the first fp64 add
     constexpr int U = 8;
-    auto accumulate = [&](const Vec<V>& xv, const Vec<V>& gv) {
+    auto accumulate = [&](const Vec<V>& xv, const Vec<V>& gv, const Vec<V>& mv) {
       if (!BWD) {
 #pragma unroll
         for (int i = 0; i < V; ++i) { const double d = xv.v[i]; s1[i] += d; s2[i] += d * d; }
@@ -81,7 +67,7 @@ __global__ __launch_bounds__(256) void bn_reduce_k(const float* __restrict__ x, 
 #pragma unroll
         for (int i = 0; i < V; ++i) {
           const float xhat = (xv.v[i] - m[i]) * is[i];
-          const float y = xhat * ga[i] + be[i];
+          const float y = mask_y ? mv.v[i] : xhat * ga[i] + be[i];
           const float dz = (relu && !(y > 0.f)) ? 0.f : gv.v[i];
           s1[i] += dz; s2[i] += static_cast<double>(dz) * xhat;
         }
@@ -89,20 +75,22 @@ __global__ __launch_bounds__(256) void bn_reduce_k(const float* __restrict__ x, 
     };
     long long r = r0 + rl;
     for (; r + static_cast<long long>(U - 1) * g.rpp < r1; r += static_cast<long long>(U) * g.rpp) {
-      Vec<V> xv[U], gv[U];
+      Vec<V> xv[U], gv[U], mv[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         xv[u].load(x + (r + static_cast<long long>(u) * g.rpp) * g.c + col, 0, 0);
         if (BWD) gv[u].load(dy + (r + static_cast<long long>(u) * g.rpp) * g.c + col, 0, 0);
+        if (BWD && mask_y) mv[u].load(mask_y + (r + static_cast<long long>(u) * g.rpp) * g.c + col, 0, 0);
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) accumulate(xv[u], gv[u]);
+      for (int u = 0; u < U; ++u) accumulate(xv[u], gv[u], mv[u]);
     }
     for (; r < r1; r += g.rpp) {
-      Vec<V> xv, gv;
+      Vec<V> xv, gv, mv;
       xv.load(x + r * g.c + col, 0, 0);
       if (BWD) gv.load(dy + r * g.c + col, 0, 0);
-      accumulate(xv, gv);
+      if (BWD && mask_y) mv.load(mask_y + r * g.c + col, 0, 0);
+      accumulate(xv, gv, mv);
     }
   }
   // fold the row lanes: red[.][rl * c + col]
@@ -122,36 +110,17 @@ __global__ __launch_bounds__(256) void bn_reduce_k(const float* __restrict__ x, 
   }
 }
 
-// Folds the [nblk][2][c] partials of channels [e0, e0 + cfold) in a fixed order: L = 256 / cfold lanes per channel take
-// interleaved slices, then an ordered LDS fold.  Returns the two sums of channel e0 + tid (valid for tid < cfold).
-__device__ __forceinline__ void fold_chunk(const BnGeom& g, const double* __restrict__ partial, int e0, int cfold, double (*red)[256],
-                                           double* a_out, double* b_out) {
-  const int tid = threadIdx.x, L = 256 / cfold;
-  const int e = e0 + tid % cfold, lane_q = tid / cfold;
-  double a = 0.0, b = 0.0;
-  if (lane_q < L && e < g.c) {
-#pragma unroll 8
-    for (int q = lane_q; q < g.nblk; q += L) {
-      a += partial[(static_cast<long long>(q) * 2 + 0) * g.c + e];
-      b += partial[(static_cast<long long>(q) * 2 + 1) * g.c + e];
-    }
-  }
-  __syncthreads();
-  red[0][tid] = a; red[1][tid] = b;
-  __syncthreads();
-  a = 0.0; b = 0.0;
-  if (tid < cfold)
-    for (int q = 0; q < L; ++q) { a += red[0][q * cfold + tid]; b += red[1][q * cfold + tid]; }
-  *a_out = a; *b_out = b;
-}
-
 constexpr int kBnMaxC = 1024;
 
-// FOLD: batch statistics come from the partials (training); otherwise mean / invstd are read from memory (eval).
+// FOLD: batch statistics come from the partials (training); otherwise mean / invstd are read from memory (eval mode, or statistics
+// the producing conv's last workgroup has finalised already: bn_fold.hpp).
+// residual (optional): y = relu?((x - mean) * invstd * gamma + beta + residual) - the tail of a residual block
+// (spconv_backbone.py:63-66: out.features += identity; relu) in the same pass.
 template <int V, bool FOLD>
 __global__ __launch_bounds__(256) void bn_apply_fwd_k(const float* __restrict__ x, long long units, BnGeom g, const double* __restrict__ partial,
                                                       BnFwdFin ff, const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
-                                                      float* __restrict__ y, double* __restrict__ zero_next, long long zero_count) {
+                                                      float* __restrict__ y, double* __restrict__ zero_next, long long zero_count,
+                                                      const float* __restrict__ residual) {
   __shared__ double red[2][256];
   // conv-epilogue statistics alternate between two slot buffers: this launch reads one and clears the other for the
   // next fused conv, which runs after it on the stream
@@ -163,27 +132,11 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_k(const float* __restrict__ 
   const int cfold = c < 256 ? c : 256;
   for (int e0 = 0; e0 < c; e0 += cfold) {
     const int e = e0 + tid;
-    float mu_f, is_f;
+    float mu_f = 0.f, is_f = 0.f;
     if (FOLD) {
       double a, b;
-      fold_chunk(g, partial, e0, cfold, red, &a, &b);
-      const double n = static_cast<double>(g.n);
-      const double mu = a / n;
-      double var = b / n - mu * mu;
-      if (var < 0.0) var = 0.0;
-      mu_f = static_cast<float>(mu);
-      is_f = static_cast<float>(1.0 / sqrt(var + static_cast<double>(ff.eps)));
-      if (blockIdx.x == 0 && tid < cfold && e < c) {
-        ff.mean[e] = mu_f;
-        ff.invstd[e] = is_f;
-        if (ff.running_mean) {
-          double f = ff.momentum;
-          if (ff.momentum < 0.f) f = 1.0 / static_cast<double>(ff.num_batches_tracked ? (*ff.num_batches_tracked + 1) : 1);
-          const double unbiased = g.n > 1 ? var * n / (n - 1.0) : var;
-          ff.running_mean[e] = static_cast<float>((1.0 - f) * ff.running_mean[e] + f * mu);
-          ff.running_var[e] = static_cast<float>((1.0 - f) * ff.running_var[e] + f * unbiased);
-        }
-      }
+      fold_chunk<false>(g.nblk, c, partial, e0, cfold, red, &a, &b);
+      if (tid < cfold && e < c) bn_fwd_channel(a, b, g.n, ff, e, blockIdx.x == 0, &mu_f, &is_f);
     } else {
       mu_f = (tid < cfold && e < c) ? ff.mean[e] : 0.f;
       is_f = (tid < cfold && e < c) ? ff.invstd[e] : 0.f;
@@ -200,24 +153,31 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_k(const float* __restrict__ 
   const int cv = c / V;
   for (long long u = static_cast<long long>(blockIdx.x) * 256 + tid; u < units; u += static_cast<long long>(gridDim.x) * 256) {
     const int col = static_cast<int>(u % cv) * V;
-    Vec<V> xv, o;
+    Vec<V> xv, rv, o;
     xv.load(x + u * V, 0, 0);
+    if (residual) rv.load(residual + u * V, 0, 0);
 #pragma unroll
     for (int i = 0; i < V; ++i) {
       const float xhat = (xv.v[i] - sh_mean[col + i]) * sh_scale[col + i];
-      const float t = xhat * sh_gamma[col + i] + sh_shift[col + i];
+      float t = xhat * sh_gamma[col + i] + sh_shift[col + i];
+      if (residual) t = t + rv.v[i];
       o.v[i] = (relu && t <= 0.f) ? 0.f : t;  // NaN passes through, like torch.relu
     }
     o.store(y + u * V);
   }
 }
 
-template <int V>
+// FOLD: (sum dz, sum dz * xhat) come from the partials; otherwise their means c1, c2 are read from bf.coef (finalised, with dgamma and
+// dbeta, by the last workgroup of the backward-data conv that took the sums).
+// mask_y / dz_out (the residual form): the ReLU mask comes from the block's output, and dz = dy * [mask_y > 0] - the gradient of the
+// identity branch - is written beside dx.
+template <int V, bool FOLD>
 __global__ __launch_bounds__(256) void bn_apply_bwd_k(const float* __restrict__ x, const float* __restrict__ dy, long long units, BnGeom g,
                                                       const double* __restrict__ partial, const float* __restrict__ mean,
                                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, int relu, BnBwdFin bf, float* __restrict__ dx,
-                                                      double* __restrict__ zero_next, long long zero_count) {
+                                                      double* __restrict__ zero_next, long long zero_count, const float* __restrict__ mask_y,
+                                                      float* __restrict__ dz_out) {
   __shared__ double red[2][256];
   if (zero_next && blockIdx.x == 0)   // see bn_apply_fwd_k
     for (long long e = threadIdx.x; e < zero_count; e += 256) zero_next[e] = 0.0;
@@ -226,16 +186,21 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_k(const float* __restrict__ 
   const int cfold = c < 256 ? c : 256;
   for (int e0 = 0; e0 < c; e0 += cfold) {
     const int e = e0 + tid;
-    double a, b;
-    fold_chunk(g, partial, e0, cfold, red, &a, &b);
+    double a = 0.0, b = 0.0;
+    if (FOLD) fold_chunk<false>(g.nblk, c, partial, e0, cfold, red, &a, &b);
     if (tid < cfold && e < c) {
-      const double n = static_cast<double>(g.n);
-      if (blockIdx.x == 0) {
-        bf.dbeta[e] = static_cast<float>(a);
-        bf.dgamma[e] = static_cast<float>(b);
+      if (FOLD) {
+        const double n = static_cast<double>(g.n);
+        if (blockIdx.x == 0) {
+          bf.dbeta[e] = static_cast<float>(a);
+          bf.dgamma[e] = static_cast<float>(b);
+        }
+        sh_c1[e] = bf.batch_stats ? static_cast<float>(a / n) : 0.f;
+        sh_c2[e] = bf.batch_stats ? static_cast<float>(b / n) : 0.f;
+      } else {
+        sh_c1[e] = bf.coef[e];
+        sh_c2[e] = bf.coef[c + e];
       }
-      sh_c1[e] = bf.batch_stats ? static_cast<float>(a / n) : 0.f;
-      sh_c2[e] = bf.batch_stats ? static_cast<float>(b / n) : 0.f;
       sh_mean[e] = mean[e];
       sh_is[e] = invstd[e];
       sh_gamma[e] = gamma ? gamma[e] : 1.f;
@@ -246,18 +211,21 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_k(const float* __restrict__ 
   const int cv = c / V;
   for (long long u = static_cast<long long>(blockIdx.x) * 256 + tid; u < units; u += static_cast<long long>(gridDim.x) * 256) {
     const int col = static_cast<int>(u % cv) * V;
-    Vec<V> xv, gv, o;
+    Vec<V> xv, gv, mv, o, z;
     xv.load(x + u * V, 0, 0);
     gv.load(dy + u * V, 0, 0);
+    if (mask_y) mv.load(mask_y + u * V, 0, 0);
 #pragma unroll
     for (int i = 0; i < V; ++i) {
       const float is = sh_is[col + i], ga = sh_gamma[col + i];
       const float xhat = (xv.v[i] - sh_mean[col + i]) * is;
-      const float t = xhat * ga + sh_beta[col + i];
+      const float t = mask_y ? mv.v[i] : xhat * ga + sh_beta[col + i];
       const float dz = (relu && !(t > 0.f)) ? 0.f : gv.v[i];
+      z.v[i] = dz;
       o.v[i] = ga * is * (dz - sh_c1[col + i] - xhat * sh_c2[col + i]);
     }
     o.store(dx + u * V);
+    if (dz_out) z.store(dz_out + u * V);
   }
 }
 
@@ -316,11 +284,11 @@ extern "C" int fv2p_batchnorm_forward(const float* x, int64_t n, int c, float ep
   const long long units = n * c / (vec ? 4 : 1);
   const unsigned blocks = apply_blocks(units);
   if (vec) {
-    hipLaunchKernelGGL((bn_reduce_k<4, false>), dim3(g.nblk), dim3(256), 0, stream, x, nullptr, g, nullptr, nullptr, nullptr, nullptr, 0, partial);
-    hipLaunchKernelGGL((bn_apply_fwd_k<4, true>), dim3(blocks), dim3(256), 0, stream, x, units, g, partial, ff, gamma, beta, relu, y, nullptr, 0);
+    hipLaunchKernelGGL((bn_reduce_k<4, false>), dim3(g.nblk), dim3(256), 0, stream, x, nullptr, g, nullptr, nullptr, nullptr, nullptr, 0, partial, nullptr);
+    hipLaunchKernelGGL((bn_apply_fwd_k<4, true>), dim3(blocks), dim3(256), 0, stream, x, units, g, partial, ff, gamma, beta, relu, y, nullptr, 0, nullptr);
   } else {
-    hipLaunchKernelGGL((bn_reduce_k<1, false>), dim3(g.nblk), dim3(256), 0, stream, x, nullptr, g, nullptr, nullptr, nullptr, nullptr, 0, partial);
-    hipLaunchKernelGGL((bn_apply_fwd_k<1, true>), dim3(blocks), dim3(256), 0, stream, x, units, g, partial, ff, gamma, beta, relu, y, nullptr, 0);
+    hipLaunchKernelGGL((bn_reduce_k<1, false>), dim3(g.nblk), dim3(256), 0, stream, x, nullptr, g, nullptr, nullptr, nullptr, nullptr, 0, partial, nullptr);
+    hipLaunchKernelGGL((bn_apply_fwd_k<1, true>), dim3(blocks), dim3(256), 0, stream, x, units, g, partial, ff, gamma, beta, relu, y, nullptr, 0, nullptr);
   }
   FV2P_LAUNCH_CHECK();
   return 0;
@@ -331,8 +299,8 @@ int fv2p::bn_column_sums(const float* x, int64_t n, int c, double* stats, hipStr
   const bool vec = (c % 4 == 0) && aligned16(x);
   BnGeom g;
   FV2P_REQUIRE(bn_geom(n, c, vec, &g, kStatSlots) == 0, FV2P_ELIMIT, "batchnorm: c=%d exceeds %d", c, vec ? kBnMaxC : 256);
-  if (vec) hipLaunchKernelGGL((bn_reduce_k<4, false>), dim3(g.nblk), dim3(256), 0, stream, x, nullptr, g, nullptr, nullptr, nullptr, nullptr, 0, stats);
-  else hipLaunchKernelGGL((bn_reduce_k<1, false>), dim3(g.nblk), dim3(256), 0, stream, x, nullptr, g, nullptr, nullptr, nullptr, nullptr, 0, stats);
+  if (vec) hipLaunchKernelGGL((bn_reduce_k<4, false>), dim3(g.nblk), dim3(256), 0, stream, x, nullptr, g, nullptr, nullptr, nullptr, nullptr, 0, stats, nullptr);
+  else hipLaunchKernelGGL((bn_reduce_k<1, false>), dim3(g.nblk), dim3(256), 0, stream, x, nullptr, g, nullptr, nullptr, nullptr, nullptr, 0, stats, nullptr);
   FV2P_LAUNCH_CHECK();
   return 0;
 }
@@ -343,8 +311,8 @@ int fv2p::bn_backward_sums(const float* x, const float* dy, int64_t n, int c, co
   const bool vec = (c % 4 == 0) && aligned16(x) && aligned16(dy);
   BnGeom g;
   FV2P_REQUIRE(bn_geom(n, c, vec, &g, kStatSlots) == 0, FV2P_ELIMIT, "batchnorm: c=%d exceeds %d", c, vec ? kBnMaxC : 256);
-  if (vec) hipLaunchKernelGGL((bn_reduce_k<4, true>), dim3(g.nblk), dim3(256), 0, stream, x, dy, g, mean, invstd, gamma, beta, relu, stats);
-  else hipLaunchKernelGGL((bn_reduce_k<1, true>), dim3(g.nblk), dim3(256), 0, stream, x, dy, g, mean, invstd, gamma, beta, relu, stats);
+  if (vec) hipLaunchKernelGGL((bn_reduce_k<4, true>), dim3(g.nblk), dim3(256), 0, stream, x, dy, g, mean, invstd, gamma, beta, relu, stats, nullptr);
+  else hipLaunchKernelGGL((bn_reduce_k<1, true>), dim3(g.nblk), dim3(256), 0, stream, x, dy, g, mean, invstd, gamma, beta, relu, stats, nullptr);
   FV2P_LAUNCH_CHECK();
   return 0;
 }
@@ -364,8 +332,8 @@ extern "C" int fv2p_batchnorm_forward_stats(const float* x, int64_t n, int c, fl
   BnFwdFin ff{mean, invstd, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), momentum, eps};
   const long long units = n * c / (vec ? 4 : 1);
   const unsigned blocks = apply_blocks(units);
-  if (vec) hipLaunchKernelGGL((bn_apply_fwd_k<4, true>), dim3(blocks), dim3(256), 0, stream, x, units, g, stats, ff, gamma, beta, relu, y, zero_next, static_cast<long long>(zero_count));
-  else hipLaunchKernelGGL((bn_apply_fwd_k<1, true>), dim3(blocks), dim3(256), 0, stream, x, units, g, stats, ff, gamma, beta, relu, y, zero_next, static_cast<long long>(zero_count));
+  if (vec) hipLaunchKernelGGL((bn_apply_fwd_k<4, true>), dim3(blocks), dim3(256), 0, stream, x, units, g, stats, ff, gamma, beta, relu, y, zero_next, static_cast<long long>(zero_count), nullptr);
+  else hipLaunchKernelGGL((bn_apply_fwd_k<1, true>), dim3(blocks), dim3(256), 0, stream, x, units, g, stats, ff, gamma, beta, relu, y, zero_next, static_cast<long long>(zero_count), nullptr);
   FV2P_LAUNCH_CHECK();
   return 0;
 }
@@ -383,10 +351,10 @@ extern "C" int fv2p_batchnorm_backward_stats(const float* x, const float* dy, in
   BnBwdFin bf{dgamma, dbeta, nullptr, batch_stats};
   const long long units = n * c / (vec ? 4 : 1);
   const unsigned blocks = apply_blocks(units);
-  if (vec) hipLaunchKernelGGL((bn_apply_bwd_k<4>), dim3(blocks), dim3(256), 0, stream, x, dy, units, g, stats, mean, invstd, gamma, beta, relu, bf, dx,
-                              zero_next, static_cast<long long>(zero_count));
-  else hipLaunchKernelGGL((bn_apply_bwd_k<1>), dim3(blocks), dim3(256), 0, stream, x, dy, units, g, stats, mean, invstd, gamma, beta, relu, bf, dx,
-                          zero_next, static_cast<long long>(zero_count));
+  if (vec) hipLaunchKernelGGL((bn_apply_bwd_k<4, true>), dim3(blocks), dim3(256), 0, stream, x, dy, units, g, stats, mean, invstd, gamma, beta, relu, bf, dx,
+                              zero_next, static_cast<long long>(zero_count), nullptr, nullptr);
+  else hipLaunchKernelGGL((bn_apply_bwd_k<1, true>), dim3(blocks), dim3(256), 0, stream, x, dy, units, g, stats, mean, invstd, gamma, beta, relu, bf, dx,
+                          zero_next, static_cast<long long>(zero_count), nullptr, nullptr);
   FV2P_LAUNCH_CHECK();
   return 0;
 }
@@ -403,8 +371,8 @@ extern "C" int fv2p_batchnorm_apply(const float* x, int64_t n, int c, const floa
   BnFwdFin ff{const_cast<float*>(mean), const_cast<float*>(invstd), nullptr, nullptr, nullptr, 0.f, 0.f};
   const long long units = n * c / (vec ? 4 : 1);
   const unsigned blocks = apply_blocks(units);
-  if (vec) hipLaunchKernelGGL((bn_apply_fwd_k<4, false>), dim3(blocks), dim3(256), 0, stream, x, units, g, nullptr, ff, gamma, beta, relu, y, nullptr, 0);
-  else hipLaunchKernelGGL((bn_apply_fwd_k<1, false>), dim3(blocks), dim3(256), 0, stream, x, units, g, nullptr, ff, gamma, beta, relu, y, nullptr, 0);
+  if (vec) hipLaunchKernelGGL((bn_apply_fwd_k<4, false>), dim3(blocks), dim3(256), 0, stream, x, units, g, nullptr, ff, gamma, beta, relu, y, nullptr, 0, nullptr);
+  else hipLaunchKernelGGL((bn_apply_fwd_k<1, false>), dim3(blocks), dim3(256), 0, stream, x, units, g, nullptr, ff, gamma, beta, relu, y, nullptr, 0, nullptr);
   FV2P_LAUNCH_CHECK();
   return 0;
 }
@@ -426,11 +394,124 @@ extern "C" int fv2p_batchnorm_backward(const float* x, const float* dy, int64_t 
   const long long units = n * c / (vec ? 4 : 1);
   const unsigned blocks = apply_blocks(units);
   if (vec) {
-    hipLaunchKernelGGL((bn_reduce_k<4, true>), dim3(g.nblk), dim3(256), 0, stream, x, dy, g, mean, invstd, gamma, beta, relu, partial);
-    hipLaunchKernelGGL((bn_apply_bwd_k<4>), dim3(blocks), dim3(256), 0, stream, x, dy, units, g, partial, mean, invstd, gamma, beta, relu, bf, dx, nullptr, 0);
+    hipLaunchKernelGGL((bn_reduce_k<4, true>), dim3(g.nblk), dim3(256), 0, stream, x, dy, g, mean, invstd, gamma, beta, relu, partial, nullptr);
+    hipLaunchKernelGGL((bn_apply_bwd_k<4, true>), dim3(blocks), dim3(256), 0, stream, x, dy, units, g, partial, mean, invstd, gamma, beta, relu, bf, dx, nullptr, 0, nullptr, nullptr);
   } else {
-    hipLaunchKernelGGL((bn_reduce_k<1, true>), dim3(g.nblk), dim3(256), 0, stream, x, dy, g, mean, invstd, gamma, beta, relu, partial);
-    hipLaunchKernelGGL((bn_apply_bwd_k<1>), dim3(blocks), dim3(256), 0, stream, x, dy, units, g, partial, mean, invstd, gamma, beta, relu, bf, dx, nullptr, 0);
+    hipLaunchKernelGGL((bn_reduce_k<1, true>), dim3(g.nblk), dim3(256), 0, stream, x, dy, g, mean, invstd, gamma, beta, relu, partial, nullptr);
+    hipLaunchKernelGGL((bn_apply_bwd_k<1, true>), dim3(blocks), dim3(256), 0, stream, x, dy, units, g, partial, mean, invstd, gamma, beta, relu, bf, dx, nullptr, 0, nullptr, nullptr);
+  }
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
+// One workgroup: the fold + finalisation the last workgroup of a conv launch does (conv_stats_done, sparse_conv.hip), for sums that a
+// separate pass took (column counts the conv epilogues do not cover).  Leaves the slots zero like that one.
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_finalize_k(double* __restrict__ stats, long long n, int c, BnFwdFin ff, BnBwdFin bf) {
+  __shared__ double red[2][256];
+  const int tid = threadIdx.x, cfold = c < 256 ? c : 256;
+  for (int e0 = 0; e0 < c; e0 += cfold) {
+    const int e = e0 + tid;
+    double a, b;
+    fold_chunk<false>(kStatSlots, c, stats, e0, cfold, red, &a, &b);
+    if (tid < cfold && e < c) {
+      if (!BWD) {
+        float mu, is;
+        bn_fwd_channel(a, b, n, ff, e, true, &mu, &is);
+      } else {
+        const double nn = static_cast<double>(n);
+        bf.dbeta[e] = static_cast<float>(a);
+        bf.dgamma[e] = static_cast<float>(b);
+        bf.coef[e] = bf.batch_stats ? static_cast<float>(a / nn) : 0.f;
+        bf.coef[c + e] = bf.batch_stats ? static_cast<float>(b / nn) : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < kStatSlots * 2 * c; i += 256) stats[i] = 0.0;
+  if (!BWD && tid == 0 && ff.running_mean && ff.num_batches_tracked) *ff.num_batches_tracked += 1;
+}
+int fv2p::bn_finalize_forward(double* stats, int64_t n, int c, const BnFwdFin& ff, hipStream_t stream) {
+  FV2P_REQUIRE(c <= kBnMaxC, FV2P_ELIMIT, "batchnorm: c=%d exceeds %d", c, kBnMaxC);
+  hipLaunchKernelGGL((bn_finalize_k<false>), dim3(1), dim3(256), 0, stream, stats, static_cast<long long>(n), c, ff, BnBwdFin{nullptr, nullptr, nullptr, 1});
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+int fv2p::bn_finalize_backward(double* stats, int64_t n, int c, const BnBwdFin& bf, hipStream_t stream) {
+  FV2P_REQUIRE(c <= kBnMaxC, FV2P_ELIMIT, "batchnorm: c=%d exceeds %d", c, kBnMaxC);
+  hipLaunchKernelGGL((bn_finalize_k<true>), dim3(1), dim3(256), 0, stream, stats, static_cast<long long>(n), c, BnFwdFin{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f}, bf);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- round 6: statistics finalised by the producer, the residual tail, one-launch forms ------------------------------------------
+
+// y = relu?((x - mean) * invstd * gamma + beta [+ residual]) with given mean / invstd: eval mode, or batch statistics the producing
+// conv's last workgroup finalised (fv2p_sparse_conv_rows_bnfin).  One launch, no fold.
+extern "C" int fv2p_batchnorm_apply_res(const float* x, int64_t n, int c, const float* mean, const float* invstd, const float* gamma,
+                                        const float* beta, int relu, const float* residual, float* y, fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FV2P_REQUIRE(n >= 0 && c >= 1, FV2P_EINVAL, "batchnorm_apply_res: n=%lld c=%d", static_cast<long long>(n), c);
+  if (n == 0) return 0;
+  FV2P_REQUIRE(x && y && mean && invstd, FV2P_EINVAL, "batchnorm_apply_res: null pointer");
+  const bool vec = (c % 4 == 0) && aligned16(x) && aligned16(y) && (!residual || aligned16(residual));
+  BnGeom g;
+  FV2P_REQUIRE(bn_geom(n, c, vec, &g) == 0, FV2P_ELIMIT, "batchnorm: c=%d exceeds %d", c, vec ? kBnMaxC : 256);
+  BnFwdFin ff{const_cast<float*>(mean), const_cast<float*>(invstd), nullptr, nullptr, nullptr, 0.f, 0.f};
+  const long long units = n * c / (vec ? 4 : 1);
+  const unsigned blocks = apply_blocks(units);
+  if (vec) hipLaunchKernelGGL((bn_apply_fwd_k<4, false>), dim3(blocks), dim3(256), 0, stream, x, units, g, nullptr, ff, gamma, beta, relu, y, nullptr, 0, residual);
+  else hipLaunchKernelGGL((bn_apply_fwd_k<1, false>), dim3(blocks), dim3(256), 0, stream, x, units, g, nullptr, ff, gamma, beta, relu, y, nullptr, 0, residual);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
+// dx = gamma * invstd * (dz - c1 - xhat * c2) with c1 = coef[0][c], c2 = coef[1][c] finalised (with dgamma / dbeta) by the last
+// workgroup of the backward-data conv that took the sums (fv2p_sparse_conv_rows_bnbwd_fin).  One launch, no fold.
+extern "C" int fv2p_batchnorm_backward_fin(const float* x, const float* dy, int64_t n, int c, const float* mean, const float* invstd,
+                                           const float* gamma, const float* beta, int relu, const float* coef, float* dx,
+                                           fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FV2P_REQUIRE(n >= 1 && c >= 1, FV2P_EINVAL, "batchnorm_backward_fin: n=%lld c=%d", static_cast<long long>(n), c);
+  FV2P_REQUIRE(x && dy && mean && invstd && dx && coef, FV2P_EINVAL, "batchnorm_backward_fin: null pointer");
+  const bool vec = (c % 4 == 0) && aligned16(x) && aligned16(dy) && aligned16(dx);
+  BnGeom g;
+  FV2P_REQUIRE(bn_geom(n, c, vec, &g) == 0, FV2P_ELIMIT, "batchnorm: c=%d exceeds %d", c, vec ? kBnMaxC : 256);
+  BnBwdFin bf{nullptr, nullptr, const_cast<float*>(coef), 1};
+  const long long units = n * c / (vec ? 4 : 1);
+  const unsigned blocks = apply_blocks(units);
+  if (vec) hipLaunchKernelGGL((bn_apply_bwd_k<4, false>), dim3(blocks), dim3(256), 0, stream, x, dy, units, g, nullptr, mean, invstd, gamma, beta, relu, bf, dx,
+                              nullptr, 0, nullptr, nullptr);
+  else hipLaunchKernelGGL((bn_apply_bwd_k<1, false>), dim3(blocks), dim3(256), 0, stream, x, dy, units, g, nullptr, mean, invstd, gamma, beta, relu, bf, dx,
+                          nullptr, 0, nullptr, nullptr);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
+// Backward of out = relu(bn(x) + identity) (the tail of a residual block): dz = dout * [out > 0] is the identity branch's gradient
+// (written to dz) and the BatchNorm's incoming gradient; dx, dgamma, dbeta as fv2p_batchnorm_backward.  Two launches
+// (reduce with the mask read from `out`, apply) instead of torch's threshold_backward + the two of fv2p_batchnorm_backward.
+extern "C" int fv2p_batchnorm_backward_res(const float* x, const float* out, const float* dout, int64_t n, int c, const float* mean,
+                                           const float* invstd, const float* gamma, const float* beta, int batch_stats, float* dx, float* dz,
+                                           float* dgamma, float* dbeta, void* ws, size_t ws_bytes, fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FV2P_REQUIRE(n >= 1 && c >= 1, FV2P_EINVAL, "batchnorm_backward_res: n=%lld c=%d", static_cast<long long>(n), c);
+  FV2P_REQUIRE(x && out && dout && mean && invstd && dx && dz && dgamma && dbeta && ws, FV2P_EINVAL, "batchnorm_backward_res: null pointer");
+  FV2P_REQUIRE(ws_bytes >= fv2p_batchnorm_ws_bytes(n, c), FV2P_EWORKSPACE, "batchnorm_backward_res: workspace too small");
+  const bool vec = (c % 4 == 0) && aligned16(x) && aligned16(out) && aligned16(dout) && aligned16(dx) && aligned16(dz);
+  BnGeom g;
+  FV2P_REQUIRE(bn_geom(n, c, vec, &g) == 0, FV2P_ELIMIT, "batchnorm: c=%d exceeds %d", c, vec ? kBnMaxC : 256);
+  Carver cv(ws, ws_bytes);
+  double* partial = cv.take<double>(static_cast<size_t>(kBnPartials) * 2 * c);
+  BnBwdFin bf{dgamma, dbeta, nullptr, batch_stats};
+  const long long units = n * c / (vec ? 4 : 1);
+  const unsigned blocks = apply_blocks(units);
+  if (vec) {
+    hipLaunchKernelGGL((bn_reduce_k<4, true>), dim3(g.nblk), dim3(256), 0, stream, x, dout, g, mean, invstd, gamma, beta, 1, partial, out);
+    hipLaunchKernelGGL((bn_apply_bwd_k<4, true>), dim3(blocks), dim3(256), 0, stream, x, dout, units, g, partial, mean, invstd, gamma, beta, 1, bf, dx, nullptr, 0, out, dz);
+  } else {
+    hipLaunchKernelGGL((bn_reduce_k<1, true>), dim3(g.nblk), dim3(256), 0, stream, x, dout, g, mean, invstd, gamma, beta, 1, partial, out);
+    hipLaunchKernelGGL((bn_apply_bwd_k<1, true>), dim3(blocks), dim3(256), 0, stream, x, dout, units, g, partial, mean, invstd, gamma, beta, 1, bf, dx, nullptr, 0, out, dz);
   }
   FV2P_LAUNCH_CHECK();
   return 0;

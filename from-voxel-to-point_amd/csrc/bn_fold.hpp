@@ -1,0 +1,91 @@
+// BatchNorm1d statistics: the fold of the per-slot partial sums and the finalisation (mean / invstd / running statistics forward;
+// dgamma / dbeta / the two means of the input gradient backward), shared by batchnorm.hip and the conv epilogues of sparse_conv.hip.
+//
+// Who finalises (round 6).  The conv kernels leave per-column partial sums in kStatSlots accumulator rows (fp64 atomics from their
+// epilogues).  Rounds 2 - 5 folded those slots in EVERY workgroup of the BatchNorm apply kernel that followed (up to 512 workgroups
+// x 64 slots x 2 x C doubles: most of a 12 us launch at the backbones' sizes).  Now the LAST workgroup of the conv launch itself folds
+// them once (conv_stats_done, sparse_conv.hip) and leaves mean / invstd (or dgamma, dbeta, c1, c2) in memory: apply kernels read
+// 2 - 4 floats per column, and a consumer conv can normalise its gathered rows without any BatchNorm launch in between.
+// The fold order is the one the apply kernels always used (fold_chunk), so the statistics are bit-identical whoever folds.
+#pragma once
+#include "common.hpp"
+
+namespace fv2p {
+
+struct BnGeom {
+  long long n;
+  int c, tcols, rpp, nblk;
+  long long rows_per_block;
+};
+
+struct BnFwdFin {   // outputs of the forward finalisation
+  float* mean; float* invstd;
+  float* running_mean; float* running_var; long long* num_batches_tracked;
+  float momentum;   // < 0: cumulative moving average (momentum=None)
+  float eps;
+};
+struct BnBwdFin {
+  float* dgamma; float* dbeta; float* coef;  // coef[0][c] = mean(dz), coef[1][c] = mean(dz * xhat) (0 when running stats were used)
+  int batch_stats;
+};
+
+// Plain loads (the partials were written by an earlier launch) or agent-scope atomic loads (the partials were accumulated by other
+// workgroups of THIS launch with agent-scope atomics: a plain load may be served from this XCD's L2, which is not coherent with the others)
+template <bool COHERENT>
+__device__ __forceinline__ double stat_load(const double* p) {
+  if constexpr (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+
+// Folds the [nblk][2][c] partials of channels [e0, e0 + cfold) in a fixed order: L = 256 / cfold lanes per channel take
+// interleaved slices, then an ordered LDS fold.  Returns the two sums of channel e0 + tid (valid for tid < cfold).  256 threads.
+template <bool COHERENT>
+__device__ __forceinline__ void fold_chunk(int nblk, int c, const double* __restrict__ partial, int e0, int cfold, double (*red)[256],
+                                           double* a_out, double* b_out, int ld = 0) {
+  if (ld == 0) ld = c;   // row stride of the partials (a conv launch on a column block of a wider layer: ld = all columns)
+  const int tid = threadIdx.x, L = 256 / cfold;
+  const int e = e0 + tid % cfold, lane_q = tid / cfold;
+  double a = 0.0, b = 0.0;
+  if (lane_q < L && e < c) {
+#pragma unroll 8
+    for (int q = lane_q; q < nblk; q += L) {
+      a += stat_load<COHERENT>(partial + (static_cast<long long>(q) * 2 + 0) * ld + e);
+      b += stat_load<COHERENT>(partial + (static_cast<long long>(q) * 2 + 1) * ld + e);
+    }
+  }
+  __syncthreads();
+  red[0][tid] = a; red[1][tid] = b;
+  __syncthreads();
+  a = 0.0; b = 0.0;
+  if (tid < cfold)
+    for (int q = 0; q < L; ++q) { a += red[0][q * cfold + tid]; b += red[1][q * cfold + tid]; }
+  *a_out = a; *b_out = b;
+}
+
+// forward: batch mean / invstd of channel e from its folded sums (a = sum x, b = sum x^2 over n rows); `write` (one workgroup of the
+// launch) also stores them and moves the running statistics.  Same arithmetic wherever it runs.
+__device__ __forceinline__ void bn_fwd_channel(double a, double b, long long n_rows, const BnFwdFin& ff, int e, bool write, float* mu_f, float* is_f) {
+  const double n = static_cast<double>(n_rows);
+  const double mu = a / n;
+  double var = b / n - mu * mu;
+  if (var < 0.0) var = 0.0;
+  *mu_f = static_cast<float>(mu);
+  *is_f = static_cast<float>(1.0 / sqrt(var + static_cast<double>(ff.eps)));
+  if (write) {
+    ff.mean[e] = *mu_f;
+    ff.invstd[e] = *is_f;
+    if (ff.running_mean) {
+      double f = ff.momentum;
+      if (ff.momentum < 0.f) f = 1.0 / static_cast<double>(ff.num_batches_tracked ? (*ff.num_batches_tracked + 1) : 1);
+      const double unbiased = n_rows > 1 ? var * n / (n - 1.0) : var;
+      ff.running_mean[e] = static_cast<float>((1.0 - f) * ff.running_mean[e] + f * mu);
+      ff.running_var[e] = static_cast<float>((1.0 - f) * ff.running_var[e] + f * unbiased);
+    }
+  }
+}
+
+// one-workgroup finalisation of sums a separate pass took (batchnorm.hip)
+int bn_finalize_forward(double* stats, int64_t n, int c, const BnFwdFin& ff, hipStream_t stream);
+int bn_finalize_backward(double* stats, int64_t n, int c, const BnBwdFin& bf, hipStream_t stream);
+
+}  // namespace fv2p

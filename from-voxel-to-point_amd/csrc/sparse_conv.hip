@@ -18,6 +18,7 @@
 // Weight gradient: dW_k = sum_r src[tab[k][r], :]^T * grad[r, :], one wave per (row chunk, k,
 // cin-block group); valid rows are compacted with a wave64 ballot so only real pairs reach the MFMA.
 #include "common.hpp"
+#include "bn_fold.hpp"
 #include <stdlib.h>
 #include <type_traits>
 #include <algorithm>
@@ -50,6 +51,16 @@ struct ConvArgs {
   // backward-data conv whose result is the gradient of a BatchNorm(+ReLU) output: stats then receive that layer's
   // backward sums  (sum dz, sum dz * xhat), dz = dst * [y > 0], from the BatchNorm input bn_x (same shape as dst)
   const float* bn_x; const float* bn_mean; const float* bn_invstd; const float* bn_gamma; const float* bn_beta; int bn_relu;
+  // statistics finalised by the launch's LAST workgroup (conv_stats_done; bn_fold.hpp): on when fin_counter != nullptr
+  unsigned* fin_counter;                             // zero before the launch, zero again after it
+  double* fin_stats; int fin_c;                      // this launch's columns of the slot buffer (unshifted by the kernels' column split), their number
+  BnFwdFin fin_fwd;                                  // forward statistics (bn_x == nullptr): mean / invstd / running statistics of these columns
+  BnBwdFin fin_bwd;                                  // backward sums (bn_x != nullptr): dgamma / dbeta / coef of these columns; coef rows are stats_ld apart
+  int fin_bump;                                      // forward: this launch also advances num_batches_tracked (the last column block of a layer)
+  // BatchNorm (+ReLU) of the SOURCE rows applied on the gather (the reference's bn1 -> relu -> conv2 of a residual block in one kernel):
+  // gathered value v of source channel c becomes relu?((v - pre_mean[c]) * pre_invstd[c] * pre_gamma[c] + pre_beta[c]); "no neighbour" stays 0
+  const float* pre_mean; const float* pre_invstd; const float* pre_gamma; const float* pre_beta; int pre_relu;
+  int dry;                                           // host only: choose the kernel, launch nothing (fv2p_sparse_conv_prenorm_supported)
   const int* perm;                                   // optional row order: tile t owns destination rows perm[64t .. 64t+63]
   const int* plan;                                   // optional cost-balanced tiling (conv_rows_ksplit): tile t owns rows [plan[t], plan[t+1])
   int col_blocks;                                    // conv_rows_ksplit: 64-column blocks of a tile, decoded from blockIdx.x (0 / 1: one)
@@ -104,6 +115,79 @@ __device__ __forceinline__ void tile_stats(const ConvArgs& a, const float (&vals
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) rows[reg] = (row0 + q * 4 + reg < a.n_dst) ? row0 + q * 4 + reg : -1;
   tile_stats_rows<NV>(a, vals, col, rows);
+}
+
+// ---- finalisation by the last workgroup of the launch ------------------------------------------------------------------------------
+// Every workgroup calls this once, at its very end, after its tile_stats atomics.  The atomics are agent-scope (performed at the
+// coherence point of the eight XCDs, not in one XCD's L2), s_waitcnt vmcnt(0) returns when they have been acknowledged, and only then
+// does the workgroup count itself in with one more agent-scope atomic: the workgroup that finds all others counted reads complete
+// sums - with agent-scope loads, a plain load could hit a stale line of its own L2.  No fence anywhere (a release fence writes the
+// whole L2 back on gfx950: 20 us).  It folds the slots in fold_chunk's order, stores mean / invstd (running statistics
+// too) or dgamma / dbeta / c1 / c2, clears the slots for the next launch and resets the counter.
+// scratch: kStatsDoneLds bytes of the kernel's DYNAMIC LDS that nothing else uses any more (no static LDS here: the K-split tile fills a
+// CU's 160 KB with two workgroups to within 768 bytes).
+constexpr size_t kStatsDoneLds = 2 * 256 * sizeof(double) + 16;
+__device__ __forceinline__ void conv_stats_done(const ConvArgs& a, void* scratch) {
+  if (!a.fin_counter) return;   // uniform
+  double (*s_red)[256] = reinterpret_cast<double (*)[256]>(scratch);
+  unsigned& s_last = *reinterpret_cast<unsigned*>(static_cast<char*>(scratch) + 2 * 256 * sizeof(double));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();   // (also: every wave is done with whatever the scratch region held)
+  if (threadIdx.x == 0) {
+    const unsigned total = gridDim.x * gridDim.y;
+    s_last = __hip_atomic_fetch_add(a.fin_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1u ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last || threadIdx.x >= 256) return;   // (a 1024-thread workgroup folds with its first four waves)
+  const int tid = threadIdx.x, c = a.fin_c, ld = a.stats_ld;
+  const int cfold = c < 256 ? c : 256;
+  for (int e0 = 0; e0 < c; e0 += cfold) {
+    const int e = e0 + tid;
+    double sa, sb;
+    fold_chunk<true>(kStatSlots, c, a.fin_stats, e0, cfold, s_red, &sa, &sb, ld);
+    if (tid < cfold && e < c) {
+      if (a.bn_x == nullptr) {
+        float mu, is;
+        bn_fwd_channel(sa, sb, a.n_dst, a.fin_fwd, e, true, &mu, &is);
+      } else {
+        const double n = static_cast<double>(a.n_dst);
+        a.fin_bwd.dbeta[e] = static_cast<float>(sa);
+        a.fin_bwd.dgamma[e] = static_cast<float>(sb);
+        a.fin_bwd.coef[e] = a.fin_bwd.batch_stats ? static_cast<float>(sa / n) : 0.f;
+        a.fin_bwd.coef[ld + e] = a.fin_bwd.batch_stats ? static_cast<float>(sb / n) : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < kStatSlots * 2 * c; i += 256) {
+    const int row = i / c, e = i % c;
+    __hip_atomic_store(a.fin_stats + static_cast<long long>(row) * ld + e, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (tid == 0) {
+    if (a.bn_x == nullptr && a.fin_bump && a.fin_fwd.running_mean && a.fin_fwd.num_batches_tracked) *a.fin_fwd.num_batches_tracked += 1;
+    __hip_atomic_store(a.fin_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// source-row BatchNorm (+ReLU) on the gather: v holds source channels c0 .. c0 + 3 of a row that exists (`valid`; "no neighbour" stays 0).
+// Same operations in the same order as bn_apply_fwd_k (batchnorm.hip): a consumer that normalises on the fly and one that reads the
+// materialised rows multiply bit-identical operands.
+struct PreNorm4 { f32x4 mean, is, ga, be; };
+__device__ __forceinline__ void prenorm_load(const ConvArgs& a, int c0, PreNorm4& p) {
+  p.mean = *reinterpret_cast<const f32x4*>(a.pre_mean + c0);
+  p.is = *reinterpret_cast<const f32x4*>(a.pre_invstd + c0);
+  p.ga = a.pre_gamma ? *reinterpret_cast<const f32x4*>(a.pre_gamma + c0) : f32x4{1.f, 1.f, 1.f, 1.f};
+  p.be = a.pre_beta ? *reinterpret_cast<const f32x4*>(a.pre_beta + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+}
+__device__ __forceinline__ f32x4 prenorm_apply(const PreNorm4& p, f32x4 v, bool valid, int relu) {
+  f32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float xhat = (v[i] - p.mean[i]) * p.is[i];
+    const float t = xhat * p.ga[i] + p.be[i];
+    o[i] = valid ? ((relu && t <= 0.f) ? 0.f : t) : 0.f;
+  }
+  return o;
 }
 
 // ---- B staging --------------------------------------------------------------------------------
@@ -242,6 +326,7 @@ __global__ __launch_bounds__(256) void conv_rows_vec(ConvArgs a) {
     }
   }
   conv_epilogue<NB>(a, acc, row0);
+  conv_stats_done(a, lds);
 }
 
 // ---- software-pipelined variant (CINP*NB <= 256) ---------------------------------------------------
@@ -399,6 +484,7 @@ __global__ __launch_bounds__(256) void conv_rows_pipe(ConvArgs a) {
     }
   }
   conv_epilogue<NB>(a, acc, row0);
+  conv_stats_done(a, lds);
 }
 
 // ---- LDS-DMA variant (the default for full 16-channel multiples) --------------------------------------
@@ -626,6 +712,7 @@ __global__ __launch_bounds__(256) void conv_rows_dma(ConvArgs a) {
     }
     tile_stats<NB>(a, vals, cols, row0);
   }
+  conv_stats_done(a, lds);
 }
 
 // ---- LDS-DMA variant for permuted rows: visits only the offsets its tile uses ----------------------------------------
@@ -803,6 +890,7 @@ __global__ __launch_bounds__(256) void conv_rows_act(ConvArgs a) {
     }
     tile_stats_rows<NB>(a, vals, cols, rows);
   }
+  conv_stats_done(a, lds);
 }
 
 // ---- thin layers (16 / 32 channels, 27 offsets): a wave, 16 destination rows, nothing staged, nothing shared -------------------------
@@ -814,13 +902,20 @@ __global__ __launch_bounds__(256) void conv_rows_act(ConvArgs a) {
 // loads, so the compiler's counted waits stay exact).  No LDS, no barrier, occupancy limited by registers only.
 // Non-transposed product (rows as A, weights as B): the accumulators have the layout conv_epilogue expects.  B of lane (n, g), k-step
 // (j, t), column tile nb = W_k[16 j + 4 g + t][16 nb + n]: 16 bytes along k in the transposed layout (WT), four dwords otherwise.
-template <int CINP, int NB, bool WT, int KVOL>
+// PRE: BatchNorm (+ReLU) of the source rows applied on the gather (ConvArgs::pre_*: the lane's 4 J channels' parameters in registers).
+template <int CINP, int NB, bool WT, int KVOL, bool PRE = false>
 __global__ __launch_bounds__(256) void conv_rows_thin(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // only conv_stats_done's scratch
   constexpr int J = CINP / 16, D = 2, NST = D + 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
   const int row0 = (xcd_major_tile(blockIdx.x, gridDim.x) * 4 + wave) * 16;
-  if (row0 >= a.n_dst) return;   // (no barrier in this kernel)
+  if (row0 < a.n_dst) {   // (no barrier in the conv itself; waves past the end only take part in conv_stats_done)
   const int my_row = row0 + r;
+  PreNorm4 pn[PRE ? J : 1];
+  if constexpr (PRE) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) prenorm_load(a, 16 * j + 4 * g, pn[j]);
+  }
   const bool row_ok = my_row < a.n_dst;
   int tv[KVOL];
 #pragma unroll
@@ -861,7 +956,11 @@ __global__ __launch_bounds__(256) void conv_rows_thin(ConvArgs a) {
       const Stage& s = st[k % NST];
 #pragma unroll
       for (int j = 0; j < J; ++j) {
-        const float xv[4] = {s.x[j].x, s.x[j].y, s.x[j].z, s.x[j].w};
+        float xv[4] = {s.x[j].x, s.x[j].y, s.x[j].z, s.x[j].w};
+        if constexpr (PRE) {
+          const f32x4 v = prenorm_apply(pn[j], f32x4{xv[0], xv[1], xv[2], xv[3]}, tv[k] >= 0, a.pre_relu);
+          xv[0] = v[0]; xv[1] = v[1]; xv[2] = v[2]; xv[3] = v[3];
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -871,6 +970,8 @@ __global__ __launch_bounds__(256) void conv_rows_thin(ConvArgs a) {
     __builtin_amdgcn_sched_barrier(0);
   });
   conv_epilogue<NB>(a, acc, row0);
+  }
+  conv_stats_done(a, lds);
 }
 
 // ---- thin layers with ALL 27 weight matrices resident in LDS (32 channels: 108 KB, one workgroup of 16 waves per CU) -------------------
@@ -880,10 +981,11 @@ __global__ __launch_bounds__(256) void conv_rows_thin(ConvArgs a) {
 // fragment order, and the 16 waves then walk 16-row groups on their own (conv_rows_thin's loop with the weight fragment read from LDS:
 // table entries up front, rows two offsets ahead, MFMAs skipped where no row has a neighbour, no barrier after the prologue).  Workgroup
 // b takes the b-th of gridDim.x contiguous ranges of groups, XCD-major.
-template <int CINP, int NB, bool WT, int KVOL>
+// PRE: BatchNorm (+ReLU) of the source rows applied on the gather (ConvArgs::pre_*).
+template <int CINP, int NB, bool WT, int KVOL, bool PRE = false>
 __global__ __launch_bounds__(1024) void conv_rows_res(ConvArgs a, int groups_per_wg) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [k][j][nb][lane][4]: B fragment of lane (n, g), k-step (j, t), tile nb at t
-  constexpr int J = CINP / 16, D = 2, NST = D + 1, WSZ = CINP * NB * 16;
+  constexpr int J = CINP / 16, D = (PRE && NB > 1) ? 1 : 2, NST = D + 1, WSZ = CINP * NB * 16;   // (PRE at 32 -> 32: rows one offset ahead instead of two, or the 128 registers of a 16-wave workgroup spill)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
   for (int e = threadIdx.x; e < KVOL * WSZ; e += 1024) {
     const int k = e / WSZ, q = e % WSZ;
@@ -893,6 +995,24 @@ __global__ __launch_bounds__(1024) void conv_rows_res(ConvArgs a, int groups_per
     lds[k * WSZ + ((((c >> 4) * NB + (col >> 4)) * 64) + ((c >> 2) & 3) * 16 + (col & 15)) * 4 + (c & 3)] = v;
   }
   __syncthreads();
+  // PRE: the four parameter vectors of the 32 source channels sit behind the weights in LDS ([4][CINP] floats) and are read where a row
+  // piece is normalised (volatile: held in registers across the 27 offsets they push this 128-register kernel into scratch)
+  float* pre_lds = lds + KVOL * WSZ;
+  if constexpr (PRE) {
+    for (int e = threadIdx.x; e < 4 * CINP; e += 1024) {
+      const int which = e / CINP, ch = e % CINP;
+      const float* src = which == 0 ? a.pre_mean : which == 1 ? a.pre_invstd : which == 2 ? a.pre_gamma : a.pre_beta;
+      pre_lds[e] = src ? src[ch] : (which == 2 ? 1.f : 0.f);
+    }
+    __syncthreads();
+  }
+  auto pre_piece = [&](int j, float4 xv, bool valid) -> float4 {
+    PreNorm4 p;
+    const volatile f32x4* q = reinterpret_cast<const volatile f32x4*>(pre_lds + 16 * j + 4 * g);
+    p.mean = q[0]; p.is = q[CINP / 4]; p.ga = q[2 * CINP / 4]; p.be = q[3 * CINP / 4];
+    const f32x4 v = prenorm_apply(p, f32x4{xv.x, xv.y, xv.z, xv.w}, valid, a.pre_relu);
+    return make_float4(v[0], v[1], v[2], v[3]);
+  };
   const int groups = (a.n_dst + 15) / 16;
   const int first = xcd_major_tile(blockIdx.x, gridDim.x) * groups_per_wg;
   const int last = min(first + groups_per_wg, groups);
@@ -902,9 +1022,9 @@ __global__ __launch_bounds__(1024) void conv_rows_res(ConvArgs a, int groups_per
     int tv[KVOL];
 #pragma unroll
     for (int k = 0; k < KVOL; ++k) tv[k] = row_ok ? a.tab[static_cast<long long>(a.flip ? (KVOL - 1 - k) : k) * a.n_dst + my_row] : -1;
-    unsigned live = 0;   // bit k: some row of the group has a neighbour at offset k
+    unsigned live = 0, mine = 0;   // bit k: some row of the group / this lane's row has a neighbour at offset k
 #pragma unroll
-    for (int k = 0; k < KVOL; ++k) live |= (__ballot(tv[k] >= 0) != 0ull ? 1u : 0u) << k;
+    for (int k = 0; k < KVOL; ++k) { live |= (__ballot(tv[k] >= 0) != 0ull ? 1u : 0u) << k; mine |= (tv[k] >= 0 ? 1u : 0u) << k; }
     float4 x[NST][J];
     auto request = [&](auto k_, float4 (&dst)[J]) {
       constexpr int k = decltype(k_)::value;
@@ -934,7 +1054,8 @@ __global__ __launch_bounds__(1024) void conv_rows_res(ConvArgs a, int groups_per
       if ((live >> k) & 1u) {
 #pragma unroll
         for (int j = 0; j < J; ++j) {
-          const float4 xv = x[k % NST][j];
+          float4 xv = x[k % NST][j];
+          if constexpr (PRE) xv = pre_piece(j, xv, (mine >> k) & 1u);
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.x, bv[k & 1][j][nb].x, acc[nb], 0, 0, 0);
 #pragma unroll
@@ -949,6 +1070,7 @@ __global__ __launch_bounds__(1024) void conv_rows_res(ConvArgs a, int groups_per
     });
     conv_epilogue<NB>(a, acc, row0);
   }
+  conv_stats_done(a, lds);
 }
 
 // ---- pair-compacted tile with the reduction dimension split over the waves ---------------------------------------------------
@@ -974,7 +1096,9 @@ __global__ __launch_bounds__(1024) void conv_rows_res(ConvArgs a, int groups_per
 // ABL (development, FV2P_KSPLIT_ABL, results INVALID - timing only; profiles/r05_ksplit_ablation.txt): bit 0 drops the steady-state global
 // loads, bit 1 the accumulator round trip through LDS, bit 2 replaces every MFMA by four lane-wise FMAs, bit 3 drops the step bookkeeping
 // (every step re-uses step 0's slot lists).
-template <int CINP, bool WT, int TM, int GPS = 1, int ABL = 0>
+// PRE: BatchNorm (+ReLU) of the source rows applied to the gathered pieces before they enter the MFMAs (ConvArgs::pre_*; the parameters
+// of the lane's 4 JS source channels stay in registers for the whole launch).
+template <int CINP, bool WT, int TM, int GPS = 1, int ABL = 0, bool PRE = false>
 __global__ __launch_bounds__(256) void conv_rows_ksplit(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int KS = CINP / 4;      // source channels per wave
@@ -1014,6 +1138,11 @@ __global__ __launch_bounds__(256) void conv_rows_ksplit(ConvArgs a) {
     }
   }
   a.c_dst = 64;
+  PreNorm4 pn[PRE ? JS : 1];
+  if constexpr (PRE) {
+#pragma unroll
+    for (int jj = 0; jj < JS; ++jj) prenorm_load(a, KS * wave + 16 * jj + 4 * (lane >> 4), pn[jj]);
+  }
   unsigned long long t_begin = 0, t_pro = 0, t_wait = 0, t_mark = 0, t_issue = 0, t_comp = 0;   // t_issue: the 100 MHz SoC clock at the start (one time base for all XCDs)
   if (a.trace) { t_begin = __builtin_readcyclecounter(); t_issue = wall_clock64(); }
   for (int row0 = r_begin; row0 < r_end; row0 += sub_rows) {
@@ -1141,12 +1270,18 @@ __global__ __launch_bounds__(256) void conv_rows_ksplit(ConvArgs a) {
         f32x4 c[4], sum[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { c[i] = f32x4{0.f, 0.f, 0.f, 0.f}; if constexpr (ABL & 2) sum[i] = A[u][0]; else sum[i] = p[i]; }   // the running sums travel under the MFMAs
+        f32x4 Av[JS];
+#pragma unroll
+        for (int jj = 0; jj < JS; ++jj) {
+          if constexpr (PRE) Av[jj] = prenorm_apply(pn[jj], A[u][jj], m.idx[u] >= 0, a.pre_relu);
+          else Av[jj] = A[u][jj];
+        }
         static_for<0, JS * 4>([&](auto q_) {
           constexpr int q = decltype(q_)::value, jj = q / 4, t = q % 4;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            if constexpr (ABL & 4) c[i][t] += (WT ? B[jj * 4 + i][t] : B[jj * 4 + t][i]) * A[u][jj][t];
-            else c[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(WT ? B[jj * 4 + i][t] : B[jj * 4 + t][i], A[u][jj][t], c[i], 0, 0, 0);
+            if constexpr (ABL & 4) c[i][t] += (WT ? B[jj * 4 + i][t] : B[jj * 4 + t][i]) * Av[jj][t];
+            else c[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(WT ? B[jj * 4 + i][t] : B[jj * 4 + t][i], Av[jj][t], c[i], 0, 0, 0);
           }
           if constexpr (u == 0 && !(ABL & 1))
             static_for<0, LPQ>([&](auto v_) { load_one(std::integral_constant<int, q * LPQ + decltype(v_)::value>{}, nxt, An, Bn); });
@@ -1243,6 +1378,7 @@ __global__ __launch_bounds__(256) void conv_rows_ksplit(ConvArgs a) {
   }
   if (row0 + sub_rows < r_end) __syncthreads();   // the next sub-tile clears the accumulators the epilogue above reads
   }
+  conv_stats_done(a, lds);
 }
 
 // Compacted variant: the workgroup owns TM destination rows whose accumulators live in LDS.  For every kernel
@@ -1376,6 +1512,7 @@ __global__ __launch_bounds__(256) void conv_rows_scalar(ConvArgs a) {
     }
   }
   conv_epilogue<NB>(a, acc, row0);
+  conv_stats_done(a, lds);
 }
 
 // ---- weight gradient ----------------------------------------------------------------------------
@@ -1387,7 +1524,24 @@ struct WgradArgs {
   int rows_per_chunk;
   int skip_k;                                    // offset handled by another launch, or -1
   int k_base, k_count;                           // this launch covers offsets [k_base, k_base + k_count)
+  // BatchNorm (+ReLU) of the gathered operand applied where it enters the MFMA (the conv's forward pass normalised its source rows on the
+  // gather: ConvArgs::pre_*); null = the rows are used as they are
+  const float* pre_mean; const float* pre_invstd; const float* pre_gamma; const float* pre_beta; int pre_relu;
 };
+// the lane's channel `ch` of the gathered operand: value v -> relu?((v - mean) * invstd * gamma + beta), as bn_apply_fwd_k computes it.
+// Padding rows (zeros) become relu?(beta - mean * ...) but meet a zero gradient row: their product stays zero.
+struct PreNorm1 { float mean, is, ga, be; };
+template <class Args>
+__device__ __forceinline__ PreNorm1 prenorm1_load(const Args& a, int ch, int c_src) {
+  PreNorm1 p{0.f, 1.f, 1.f, 0.f};
+  if (a.pre_mean && ch < c_src) { p.mean = a.pre_mean[ch]; p.is = a.pre_invstd[ch]; p.ga = a.pre_gamma ? a.pre_gamma[ch] : 1.f; p.be = a.pre_beta ? a.pre_beta[ch] : 0.f; }
+  return p;
+}
+__device__ __forceinline__ float prenorm1_apply(const PreNorm1& p, float v, int relu) {
+  const float xhat = (v - p.mean) * p.is;
+  const float t = xhat * p.ga + p.be;
+  return (relu && t <= 0.f) ? 0.f : t;
+}
 
 // One WORKGROUP per (row chunk, kernel offset k).  The gathers are latency bound (a dependent table read, then rows
 // scattered over L2/HBM), so the kernel is organised around memory-level parallelism:
@@ -1476,6 +1630,10 @@ __global__ __launch_bounds__(256) void conv_wgrad(WgradArgs a, float* __restrict
       if (pr < kWgStage) *reinterpret_cast<float4*>(&G[pr * LDG + c]) = rg[u];
     }
   };
+  PreNorm1 pn[MBW];
+  const bool pre = a.pre_mean != nullptr;   // uniform
+#pragma unroll
+  for (int i = 0; i < MBW; ++i) pn[i] = prenorm1_load(a, (w * MBW + i) * 16 + m, a.c_src);
   if (cnt > 0) fetch(0);
   for (int p0 = 0; p0 < cnt; p0 += kWgStage) {
     __syncthreads();  // previous stage's LDS reads are done
@@ -1488,7 +1646,7 @@ __global__ __launch_bounds__(256) void conv_wgrad(WgradArgs a, float* __restrict
         const int pr = sl * 4 + g;  // rows beyond npair were parked as zeros
         float av[MBW], bv[NB];
 #pragma unroll
-        for (int i = 0; i < MBW; ++i) av[i] = F[pr * LDF + (w * MBW + i) * 16 + m];
+        for (int i = 0; i < MBW; ++i) { av[i] = F[pr * LDF + (w * MBW + i) * 16 + m]; if (pre) av[i] = prenorm1_apply(pn[i], av[i], a.pre_relu); }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) bv[nb] = G[pr * LDG + nb * 16 + m];
 #pragma unroll
@@ -1531,6 +1689,7 @@ struct WgradPairArgs {
   int side_src;                                 // 0: src rows are pairs[k][0] (forward conv), 1: pairs[k][1] (inverse conv)
   int kvol;
   int chunk;                                    // pairs per workgroup (<= kPairsMax)
+  const float* pre_mean; const float* pre_invstd; const float* pre_gamma; const float* pre_beta; int pre_relu;   // as WgradArgs
 };
 
 template <int MB, int NB>
@@ -1599,6 +1758,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_pairs(WgradPairArgs a, float* 
       if (pr < kWgStage) *reinterpret_cast<float4*>(&G[pr * LDG + c]) = rg[u];
     }
   };
+  PreNorm1 pn[MBW];
+  const bool pre = a.pre_mean != nullptr;   // uniform
+#pragma unroll
+  for (int i = 0; i < MBW; ++i) pn[i] = prenorm1_load(a, (w * MBW + i) * 16 + m, a.c_src);
   fetch(0);
   for (int p0 = 0; p0 < cnt; p0 += kWgStage) {
     __syncthreads();
@@ -1611,7 +1774,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_pairs(WgradPairArgs a, float* 
         const int pr = sl * 4 + g;
         float av[MBW], bv[NB];
 #pragma unroll
-        for (int i = 0; i < MBW; ++i) av[i] = F[pr * LDF + (w * MBW + i) * 16 + m];
+        for (int i = 0; i < MBW; ++i) { av[i] = F[pr * LDF + (w * MBW + i) * 16 + m]; if (pre) av[i] = prenorm1_apply(pn[i], av[i], a.pre_relu); }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) bv[nb] = G[pr * LDG + nb * 16 + m];
 #pragma unroll
@@ -1689,6 +1852,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_pairs_dma(WgradPairArgs a, flo
   for (int i = 0; i < AS; ++i)
 #pragma unroll
     for (int j = 0; j < BS * 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  PreNorm1 pn[AS];
+  const bool pre = a.pre_mean != nullptr;   // uniform
+#pragma unroll
+  for (int i = 0; i < AS; ++i) pn[i] = prenorm1_load(a, 4 * (m + 16 * i) + w, CS);
   issue(0, lds);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -1703,7 +1870,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_pairs_dma(WgradPairArgs a, flo
       float av[AS];
       float4 bv[BS];
 #pragma unroll
-      for (int i = 0; i < AS; ++i) av[i] = F[pr * ROWF + (m + 16 * i) * 4 + w];
+      for (int i = 0; i < AS; ++i) { av[i] = F[pr * ROWF + (m + 16 * i) * 4 + w]; if (pre) av[i] = prenorm1_apply(pn[i], av[i], a.pre_relu); }
 #pragma unroll
       for (int j = 0; j < BS; ++j) bv[j] = *reinterpret_cast<const float4*>(&G[pr * ROWG + (m + 16 * j) * 4]);
 #pragma unroll
@@ -1898,16 +2065,19 @@ static int ksplit_rows(const ConvArgs& a) {
   return (!WT && a.n_dst < 65536) ? 32 : 64;
 }
 
+// launch unless the call only asks which kernel would run (a.dry: fv2p_sparse_conv_prenorm_supported)
+#define FV2P_LAUNCH(kern, grid, block, lds, stream, ...) do { if (!a.dry) hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__); } while (0)
 template <int CINP, int NB, bool WT>
-static void launch_vec(const ConvArgs& a, hipStream_t s) {
+static int launch_vec(const ConvArgs& a, hipStream_t s) {   // 0: launched (or chosen, a.dry); 1: the chosen kernel cannot normalise its source rows (a.pre_mean)
   constexpr int TM = 128;
   constexpr size_t cmp_lds = (static_cast<size_t>(CINP) * NB * 16 + static_cast<size_t>(TM) * (NB * 16 + 16)) * sizeof(float) + 2 * TM * sizeof(int);
   const int impl = conv_impl();
   const bool use_cmp = impl == 2 && cmp_lds <= 64 * 1024;  // measured slower than the dense tile at KITTI sizes (profiles/r01_*): opt-in
   if (use_cmp) {
+    if (a.pre_mean) return 1;
     const unsigned blocks = static_cast<unsigned>(ceil_div(a.n_dst, TM));
-    hipLaunchKernelGGL((conv_rows_cmp<CINP, NB, WT, TM>), dim3(blocks), dim3(256), cmp_lds, s, a);
-    return;
+    FV2P_LAUNCH((conv_rows_cmp<CINP, NB, WT, TM>), dim3(blocks), dim3(256), cmp_lds, s, a);
+    return 0;
   }
   const unsigned blocks = static_cast<unsigned>(ceil_div(a.n_dst, 64));
   if constexpr ((CINP == 64 || CINP == 128) && NB % 4 == 0) {
@@ -1931,18 +2101,25 @@ static void launch_vec(const ConvArgs& a, hipStream_t s) {
         if constexpr (CINP == 128 && !WT) {
           if (abl) {   // timing-only ablations of the roofline layer's forward kernel (see the template's comment)
 #define FV2P_ABL(V) case V: { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_ksplit<CINP, WT, 64, 1, V>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-                              hipLaunchKernelGGL((conv_rows_ksplit<CINP, WT, 64, 1, V>), grid, dim3(256), lds64, s, b); return; }
+                              FV2P_LAUNCH((conv_rows_ksplit<CINP, WT, 64, 1, V>), grid, dim3(256), lds64, s, b); return 0; }
             switch (abl) { FV2P_ABL(1) FV2P_ABL(2) FV2P_ABL(3) FV2P_ABL(4) FV2P_ABL(5) FV2P_ABL(6) FV2P_ABL(7) FV2P_ABL(8) FV2P_ABL(9) FV2P_ABL(11) FV2P_ABL(15) default: break; }
 #undef FV2P_ABL
           }
         }
 #endif
+        if (a.pre_mean) {   // source rows normalised on the gather: forward convs only
+          if constexpr (!WT) {
+            static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_ksplit<CINP, WT, 64, 1, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
+            if (once) { FV2P_LAUNCH((conv_rows_ksplit<CINP, WT, 64, 1, 0, true>), grid, dim3(256), lds64, s, b); return 0; }
+          }
+          return 1;
+        }
         if (gps == 2) {
           static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_ksplit<CINP, WT, 64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
-          if (once) { hipLaunchKernelGGL((conv_rows_ksplit<CINP, WT, 64, 2>), grid, dim3(256), lds64, s, b); return; }
+          if (once) { FV2P_LAUNCH((conv_rows_ksplit<CINP, WT, 64, 2>), grid, dim3(256), lds64, s, b); return 0; }
         } else {
           static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_ksplit<CINP, WT, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
-          if (once) { hipLaunchKernelGGL((conv_rows_ksplit<CINP, WT, 64>), grid, dim3(256), lds64, s, b); return; }
+          if (once) { FV2P_LAUNCH((conv_rows_ksplit<CINP, WT, 64>), grid, dim3(256), lds64, s, b); return 0; }
         }
       }
       b.plan = nullptr;
@@ -1950,7 +2127,14 @@ static void launch_vec(const ConvArgs& a, hipStream_t s) {
         const size_t lds = ksplit_lds(32) + g_ksplit_pad;
         static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_ksplit<CINP, WT, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
         b.col_blocks = NB / 4;
-        if (once) { hipLaunchKernelGGL((conv_rows_ksplit<CINP, WT, 32>), dim3(static_cast<unsigned>(ceil_div(a.n_dst, 32)) * (NB / 4)), dim3(256), lds, s, b); return; }
+        if (a.pre_mean) {
+          if constexpr (!WT) {
+            static bool once_pre = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_ksplit<CINP, WT, 32, 1, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
+            if (once_pre) { FV2P_LAUNCH((conv_rows_ksplit<CINP, WT, 32, 1, 0, true>), dim3(static_cast<unsigned>(ceil_div(a.n_dst, 32)) * (NB / 4)), dim3(256), lds, s, b); return 0; }
+          }
+          return 1;
+        }
+        if (once) { FV2P_LAUNCH((conv_rows_ksplit<CINP, WT, 32>), dim3(static_cast<unsigned>(ceil_div(a.n_dst, 32)) * (NB / 4)), dim3(256), lds, s, b); return 0; }
       }
     }
   }
@@ -1967,8 +2151,15 @@ static void launch_vec(const ConvArgs& a, hipStream_t s) {
         const int groups = static_cast<int>(ceil_div(a.n_dst, 16));
         const int wgs = std::min(groups, conv_cu_count());
         const int per = static_cast<int>(ceil_div(groups, wgs));
-        hipLaunchKernelGGL((conv_rows_res<CINP, NB, WT, 27>), dim3(static_cast<unsigned>(ceil_div(groups, per))), dim3(1024), res_lds, s, a, per);
-        return;
+        if (a.pre_mean) {
+          if constexpr (!WT) {
+            static bool once_pre = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_res<CINP, NB, WT, 27, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
+            if (once_pre) { FV2P_LAUNCH((conv_rows_res<CINP, NB, WT, 27, true>), dim3(static_cast<unsigned>(ceil_div(groups, per))), dim3(1024), res_lds + 4 * CINP * sizeof(float), s, a, per); return 0; }
+          }
+          return 1;
+        }
+        FV2P_LAUNCH((conv_rows_res<CINP, NB, WT, 27>), dim3(static_cast<unsigned>(ceil_div(groups, per))), dim3(1024), res_lds, s, a, per);
+        return 0;
       }
     }
   }
@@ -1983,10 +2174,15 @@ static void launch_vec(const ConvArgs& a, hipStream_t s) {
                        (!WT || ((a.w_ld & 3) == 0 && (a.w_kstride & 3) == 0 && (reinterpret_cast<uintptr_t>(a.w) & 15) == 0));
     if (impl == 0 && thin_on && whole && a.kvol == 27 && !a.perm) {
       const unsigned groups = static_cast<unsigned>(ceil_div(a.n_dst, 16));
-      hipLaunchKernelGGL((conv_rows_thin<CINP, NB, WT, 27>), dim3(ceil_div(groups, 4u)), dim3(256), 0, s, a);
-      return;
+      if (a.pre_mean) {
+        if constexpr (!WT) { FV2P_LAUNCH((conv_rows_thin<CINP, NB, WT, 27, true>), dim3(ceil_div(groups, 4u)), dim3(256), kStatsDoneLds, s, a); return 0; }
+        return 1;
+      }
+      FV2P_LAUNCH((conv_rows_thin<CINP, NB, WT, 27>), dim3(ceil_div(groups, 4u)), dim3(256), kStatsDoneLds, s, a);
+      return 0;
     }
   }
+  if (a.pre_mean) return 1;   // the staged kernels below read their source rows as they are
   if constexpr (CINP * NB <= 512 && (WT || NB % 4 == 0)) {
     // LDS-DMA kernel: whole fragments only (every lane's 16-byte source must exist and be aligned)
     const bool whole = a.c_src == CINP && a.c_dst == NB * 16 && (a.w_ld & 3) == 0 && (a.w_kstride & 3) == 0 &&
@@ -1994,13 +2190,13 @@ static void launch_vec(const ConvArgs& a, hipStream_t s) {
                        (reinterpret_cast<uintptr_t>(a.dst) & 15) == 0 && (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0);
     constexpr size_t act_lds = 2 * CINP * NB * 16 * sizeof(float) + 32 * 64 * sizeof(int) + 16;
     if (a.perm && impl == 0 && whole && a.kvol > 1 && a.kvol <= 32 && act_lds <= 64 * 1024) {
-      hipLaunchKernelGGL((conv_rows_act<CINP, NB, WT>), dim3(blocks), dim3(256), act_lds, s, a);
-      return;
+      FV2P_LAUNCH((conv_rows_act<CINP, NB, WT>), dim3(blocks), dim3(256), act_lds, s, a);
+      return 0;
     }
     if (impl == 0 && whole && a.kvol > 1) {
       ConvArgs b = a; b.trace = g_conv_trace;
-      hipLaunchKernelGGL((conv_rows_dma<CINP, NB, WT>), dim3(blocks), dim3(256), 2 * CINP * NB * 16 * sizeof(float), s, b);
-      return;
+      FV2P_LAUNCH((conv_rows_dma<CINP, NB, WT>), dim3(blocks), dim3(256), std::max<size_t>(2 * CINP * NB * 16 * sizeof(float), kStatsDoneLds), s, b);
+      return 0;
     }
   }
   if constexpr (CINP * NB == 1024 && NB == 8) {
@@ -2011,23 +2207,26 @@ static void launch_vec(const ConvArgs& a, hipStream_t s) {
                        (reinterpret_cast<uintptr_t>(a.dst) & 15) == 0 && (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 15) == 0);
     if (impl == 0 && whole && a.kvol > 1) {
       ConvArgs b = a; b.trace = nullptr;
-      hipLaunchKernelGGL((conv_rows_dma<CINP, 4, WT>), dim3(blocks, 2), dim3(256), 2 * CINP * 4 * 16 * sizeof(float), s, b);
-      return;
+      FV2P_LAUNCH((conv_rows_dma<CINP, 4, WT>), dim3(blocks, 2), dim3(256), 2 * CINP * 4 * 16 * sizeof(float), s, b);
+      return 0;
     }
   }
   if constexpr (CINP * NB <= 256) {
     if (impl != 1 && a.kvol > 1) {  // FV2P_CONV_IMPL=dense keeps the unpipelined tile, =pipe the register-staged pipeline (parity tests run all)
       // KU = 2 (two offsets per barrier) measured slower than KU = 1 on MI355X (93.9 vs 89.6 us, 64->64 N=29k)
-      hipLaunchKernelGGL((conv_rows_pipe<CINP, NB, WT, 1>), dim3(blocks), dim3(256), 2 * CINP * NB * 16 * sizeof(float), s, a);
-      return;
+      FV2P_LAUNCH((conv_rows_pipe<CINP, NB, WT, 1>), dim3(blocks), dim3(256), std::max<size_t>(2 * CINP * NB * 16 * sizeof(float), kStatsDoneLds), s, a);
+      return 0;
     }
   }
-  hipLaunchKernelGGL((conv_rows_vec<CINP, NB, WT>), dim3(blocks), dim3(256), CINP * NB * 16 * sizeof(float), s, a);
+  FV2P_LAUNCH((conv_rows_vec<CINP, NB, WT>), dim3(blocks), dim3(256), std::max<size_t>(CINP * NB * 16 * sizeof(float), kStatsDoneLds), s, a);
+  return 0;
 }
 template <int STEPS, int NB, bool WT>
-static void launch_scalar(const ConvArgs& a, hipStream_t s) {
+static int launch_scalar(const ConvArgs& a, hipStream_t s) {
+  if (a.pre_mean) return 1;
   const unsigned blocks = static_cast<unsigned>(ceil_div(a.n_dst, 64));
-  hipLaunchKernelGGL((conv_rows_scalar<STEPS, NB, WT>), dim3(blocks), dim3(256), STEPS * 4 * NB * 16 * sizeof(float), s, a);
+  FV2P_LAUNCH((conv_rows_scalar<STEPS, NB, WT>), dim3(blocks), dim3(256), std::max<size_t>(STEPS * 4 * NB * 16 * sizeof(float), kStatsDoneLds), s, a);
+  return 0;
 }
 
 template <bool WT>
@@ -2036,19 +2235,20 @@ static int dispatch_conv(const ConvArgs& a, hipStream_t s) {
   const int nbp = nb <= 1 ? 1 : nb <= 2 ? 2 : nb <= 4 ? 4 : 8;
   const bool vec = (a.c_src % 4 == 0) && (a.ld_src % 4 == 0) && a.c_src >= 16 &&
                    (reinterpret_cast<uintptr_t>(a.src) % 16 == 0);
+  int unsupported = 0;   // 1: a.pre_mean with a kernel that cannot normalise its source rows (nothing was launched)
 #define FV2P_VEC_CASE(CINP)                                            \
   switch (nbp) {                                                       \
-    case 1: launch_vec<CINP, 1, WT>(a, s); break;                      \
-    case 2: launch_vec<CINP, 2, WT>(a, s); break;                      \
-    case 4: launch_vec<CINP, 4, WT>(a, s); break;                      \
-    default: launch_vec<CINP, 8, WT>(a, s); break;                     \
+    case 1: unsupported = launch_vec<CINP, 1, WT>(a, s); break;        \
+    case 2: unsupported = launch_vec<CINP, 2, WT>(a, s); break;        \
+    case 4: unsupported = launch_vec<CINP, 4, WT>(a, s); break;        \
+    default: unsupported = launch_vec<CINP, 8, WT>(a, s); break;       \
   }
 #define FV2P_SCALAR_CASE(STEPS)                                        \
   switch (nbp) {                                                       \
-    case 1: launch_scalar<STEPS, 1, WT>(a, s); break;                  \
-    case 2: launch_scalar<STEPS, 2, WT>(a, s); break;                  \
-    case 4: launch_scalar<STEPS, 4, WT>(a, s); break;                  \
-    default: launch_scalar<STEPS, 8, WT>(a, s); break;                 \
+    case 1: unsupported = launch_scalar<STEPS, 1, WT>(a, s); break;    \
+    case 2: unsupported = launch_scalar<STEPS, 2, WT>(a, s); break;    \
+    case 4: unsupported = launch_scalar<STEPS, 4, WT>(a, s); break;    \
+    default: unsupported = launch_scalar<STEPS, 8, WT>(a, s); break;   \
   }
   if (vec) {
     if (a.c_src <= 16) { FV2P_VEC_CASE(16) }
@@ -2064,7 +2264,7 @@ static int dispatch_conv(const ConvArgs& a, hipStream_t s) {
   }
 #undef FV2P_VEC_CASE
 #undef FV2P_SCALAR_CASE
-  return 0;
+  return unsupported;   // (> 0: not an error code; conv_rows_impl turns it into one or into the answer of the support query)
 }
 
 // ---- exact plan for tables of <= kPlanExactRows rows ------------------------------------------------------------------------------
@@ -2259,9 +2459,17 @@ extern "C" int fv2p_sparse_conv_set_paths(int thin_on, int res_on) {
   return 0;
 }
 
+// what a call adds to the plain conv: statistics finalised by the last workgroup, source rows normalised on the gather, a support query
+struct ConvExtra {
+  unsigned* fin_counter = nullptr;
+  BnFwdFin fwd = {nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f};   // forward statistics (all columns; moved per column block here)
+  BnBwdFin bwd = {nullptr, nullptr, nullptr, 1};                              // backward sums
+  const float* pre_mean = nullptr; const float* pre_invstd = nullptr; const float* pre_gamma = nullptr; const float* pre_beta = nullptr; int pre_relu = 0;
+  int dry = 0;
+};
 static int conv_rows_impl(const float* src, int64_t n_src, int c_src, const float* weight, int kvol, const int* tab, int64_t n_dst, int c_dst,
                           int flip_k, int transpose_w, const float* bias, float* dst, double* stats, hipStream_t stream,
-                          const ConvArgs* bn = nullptr, const int* perm = nullptr) {
+                          const ConvArgs* bn = nullptr, const int* perm = nullptr, const ConvExtra* ex = nullptr) {
   FV2P_REQUIRE(c_src >= 1 && c_dst >= 1 && kvol >= 1 && n_dst >= 0 && n_src >= 0, FV2P_EINVAL, "sparse_conv_rows: bad sizes");
   if (n_dst == 0) return 0;
   FV2P_REQUIRE(weight && tab && dst && (src || n_src == 0), FV2P_EINVAL, "sparse_conv_rows: null pointer");
@@ -2270,7 +2478,7 @@ static int conv_rows_impl(const float* src, int64_t n_src, int c_src, const floa
   // two channel axes are swapped: W_k^T is used, i.e. weight is [K][c_dst][c_src].
   const int w_rows = transpose_w ? c_dst : c_src, w_cols = transpose_w ? c_src : c_dst;
   int probe_slot = -1;
-  if (g_probe.armed) {   // (unlocked read of a flag: the probe is armed and read by the thread that measures)
+  if (g_probe.armed && !(ex && ex->dry)) {   // (unlocked read of a flag: the probe is armed and read by the thread that measures)
     std::lock_guard<std::mutex> lock(g_probe.mu);
     if (g_probe.armed && g_probe.used < kProbePairs && c_src == g_probe.c_src && c_dst == g_probe.c_dst && kvol == g_probe.kvol &&
         n_dst == g_probe.n_dst && (flip_k & 1) == g_probe.flip && !transpose_w && !bn) {
@@ -2288,6 +2496,25 @@ static int conv_rows_impl(const float* src, int64_t n_src, int c_src, const floa
       a.stats = stats ? stats + d0 : nullptr; a.stats_ld = c_dst;
       a.bn_x = nullptr; a.bn_mean = a.bn_invstd = a.bn_gamma = a.bn_beta = nullptr; a.bn_relu = 0;
       a.perm = perm;   // honoured by the LDS-DMA tile for permuted rows, ignored (plain row order, same result) by the others
+      a.fin_counter = nullptr; a.fin_stats = nullptr; a.fin_c = 0; a.fin_bump = 0; a.dry = ex ? ex->dry : 0;
+      a.fin_fwd = BnFwdFin{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f};
+      a.fin_bwd = BnBwdFin{nullptr, nullptr, nullptr, 1};
+      a.pre_mean = a.pre_invstd = a.pre_gamma = a.pre_beta = nullptr; a.pre_relu = 0;
+      if (ex && ex->pre_mean) {   // parameters of the SOURCE channels of this launch
+        a.pre_mean = ex->pre_mean + s0; a.pre_invstd = ex->pre_invstd + s0;
+        a.pre_gamma = ex->pre_gamma ? ex->pre_gamma + s0 : nullptr; a.pre_beta = ex->pre_beta ? ex->pre_beta + s0 : nullptr; a.pre_relu = ex->pre_relu;
+      }
+      if (ex && ex->fin_counter && stats && c_src <= 128) {   // one launch per column block holds the whole sum: its last workgroup finalises
+        a.fin_counter = ex->fin_counter; a.fin_stats = stats + d0; a.fin_c = cd;
+        if (bn) {
+          a.fin_bwd = BnBwdFin{ex->bwd.dgamma + d0, ex->bwd.dbeta + d0, ex->bwd.coef + d0, ex->bwd.batch_stats};
+        } else {
+          a.fin_fwd = ex->fwd;
+          a.fin_fwd.mean += d0; a.fin_fwd.invstd += d0;
+          if (a.fin_fwd.running_mean) { a.fin_fwd.running_mean += d0; a.fin_fwd.running_var += d0; }
+          a.fin_bump = d0 + 128 >= c_dst;
+        }
+      }
       if (bn && stats) {   // per-column pointers move with the column block, bn_x is addressed like dst (row * ld_dst + col)
         a.bn_x = bn->bn_x + d0; a.bn_mean = bn->bn_mean + d0; a.bn_invstd = bn->bn_invstd + d0;
         a.bn_gamma = bn->bn_gamma ? bn->bn_gamma + d0 : nullptr; a.bn_beta = bn->bn_beta ? bn->bn_beta + d0 : nullptr; a.bn_relu = bn->bn_relu;
@@ -2301,10 +2528,13 @@ static int conv_rows_impl(const float* src, int64_t n_src, int c_src, const floa
       a.bias = (bias && s0 == 0) ? bias + d0 : nullptr;
       a.dst = dst + d0; a.ld_dst = c_dst; a.c_dst = cd; a.accumulate = s0 > 0;
       int rc = transpose_w ? dispatch_conv<true>(a, stream) : dispatch_conv<false>(a, stream);
+      if (rc > 0) return a.dry ? 1 : set_error(FV2P_EINVAL, "sparse conv: the kernel for %d -> %d channels, %d offsets cannot normalise its source rows "
+                                                            "(ask fv2p_sparse_conv_prenorm_supported first)", c_src, c_dst, kvol);
       if (rc) return rc;
     }
   }
   if (probe_slot >= 0) FV2P_HIP(hipEventRecord(g_probe.ev[2 * probe_slot + 1], stream));
+  if (ex && ex->dry) return 0;   // nothing was launched
   FV2P_LAUNCH_CHECK();
   return 0;
 }
@@ -2395,6 +2625,71 @@ extern "C" int fv2p_sparse_conv_rows_stats(const float* src, int64_t n_src, int 
   return 0;
 }
 
+// conv whose statistics are finalised by its own last workgroup (mean / invstd / running statistics in memory when the launch ends, the
+// slots zero again), and / or whose source rows pass through a BatchNorm (+ReLU) on the gather.  stats == NULL: no statistics.
+extern "C" int fv2p_sparse_conv_rows_bnfin(const float* src, int64_t n_src, int c_src, const float* weight, int kvol, const int* tab,
+                                           int64_t n_dst, int c_dst, int flip_k, int transpose_w, const float* bias, float* dst,
+                                           double* stats, unsigned* counter, float eps, float momentum, float* running_mean, float* running_var,
+                                           int64_t* num_batches_tracked, float* mean, float* invstd, const float* pre_mean, const float* pre_invstd,
+                                           const float* pre_gamma, const float* pre_beta, int pre_relu, fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FV2P_REQUIRE(!stats || (counter && mean && invstd), FV2P_EINVAL, "sparse_conv_rows_bnfin: statistics need counter, mean and invstd");
+  FV2P_REQUIRE((running_mean == nullptr) == (running_var == nullptr), FV2P_EINVAL, "sparse_conv_rows_bnfin: running_mean and running_var come together");
+  FV2P_REQUIRE((pre_mean == nullptr) == (pre_invstd == nullptr), FV2P_EINVAL, "sparse_conv_rows_bnfin: pre_mean and pre_invstd come together");
+  FV2P_REQUIRE(!pre_mean || ((c_src & 3) == 0 && (reinterpret_cast<uintptr_t>(pre_mean) & 15) == 0 && (reinterpret_cast<uintptr_t>(pre_invstd) & 15) == 0 &&
+                            (reinterpret_cast<uintptr_t>(pre_gamma) & 15) == 0 && (reinterpret_cast<uintptr_t>(pre_beta) & 15) == 0),
+               FV2P_EINVAL, "sparse_conv_rows_bnfin: source BatchNorm parameters must be 16-byte aligned, channels a multiple of 4");
+  ConvExtra ex;
+  ex.pre_mean = pre_mean; ex.pre_invstd = pre_invstd; ex.pre_gamma = pre_gamma; ex.pre_beta = pre_beta; ex.pre_relu = pre_relu;
+  const bool fused = stats && c_src <= 128 && conv_impl() != 2 && n_dst > 0;
+  const BnFwdFin ff{mean, invstd, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), momentum, eps};
+  if (fused) { ex.fin_counter = counter; ex.fwd = ff; }
+  if (int rc = conv_rows_impl(src, n_src, c_src, weight, kvol, tab, n_dst, c_dst, flip_k, transpose_w, bias, dst, fused ? stats : nullptr, stream,
+                              nullptr, nullptr, &ex))
+    return rc;
+  if (stats && !fused && n_dst > 0) {   // sums by a pass over dst, finalised by one workgroup
+    if (int rc = bn_column_sums(dst, n_dst, c_dst, stats, stream)) return rc;
+    return bn_finalize_forward(stats, n_dst, c_dst, ff, stream);
+  }
+  return 0;
+}
+
+// 1 when fv2p_sparse_conv_rows_bnfin can normalise the source rows of a conv of this shape on the gather (the kernel the dispatcher would
+// choose has the PRE form: conv_rows_thin 16 -> 16, conv_rows_res 32 -> <= 32, conv_rows_ksplit 64 / 128 source channels), else 0.
+extern "C" int fv2p_sparse_conv_prenorm_supported(int c_src, int c_dst, int kvol, int64_t n_dst, int flip_k, int transpose_w) {
+  if (c_src < 1 || c_dst < 1 || kvol < 1 || n_dst < 1 || transpose_w || c_src > 128 || c_dst > 128 || (c_src & 3)) return 0;
+  ConvExtra ex;
+  ex.dry = 1;
+  float* fake = reinterpret_cast<float*>(static_cast<uintptr_t>(4096));   // never dereferenced: a dry run launches nothing
+  ex.pre_mean = ex.pre_invstd = fake;
+  const int rc = conv_rows_impl(fake, n_dst, c_src, fake, kvol, reinterpret_cast<const int*>(fake), n_dst, c_dst, flip_k, 0, nullptr, fake, nullptr, nullptr,
+                                nullptr, nullptr, &ex);
+  return rc == 0 ? 1 : 0;
+}
+
+extern "C" int fv2p_sparse_conv_rows_bnbwd_fin(const float* src, int64_t n_src, int c_src, const float* weight, int kvol, const int* tab,
+                                               int64_t n_dst, int c_dst, int flip_k, int transpose_w, float* dst, const float* bn_x,
+                                               const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_beta, int relu,
+                                               double* stats, unsigned* counter, int batch_stats, float* dgamma, float* dbeta, float* coef,
+                                               const int* perm, fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FV2P_REQUIRE(stats && counter && bn_x && bn_mean && bn_invstd && dgamma && dbeta && coef, FV2P_EINVAL, "sparse_conv_rows_bnbwd_fin: null pointer");
+  const bool fused = c_src <= 128 && conv_impl() != 2 && n_dst > 0;
+  ConvArgs bn;
+  bn.bn_x = bn_x; bn.bn_mean = bn_mean; bn.bn_invstd = bn_invstd; bn.bn_gamma = bn_gamma; bn.bn_beta = bn_beta; bn.bn_relu = relu;
+  ConvExtra ex;
+  const BnBwdFin bf{dgamma, dbeta, coef, batch_stats};
+  if (fused) { ex.fin_counter = counter; ex.bwd = bf; }
+  if (int rc = conv_rows_impl(src, n_src, c_src, weight, kvol, tab, n_dst, c_dst, flip_k, transpose_w, nullptr, dst, fused ? stats : nullptr, stream,
+                              fused ? &bn : nullptr, perm, &ex))
+    return rc;
+  if (!fused && n_dst > 0) {
+    if (int rc = bn_backward_sums(bn_x, dst, n_dst, c_dst, bn_mean, bn_invstd, bn_gamma, bn_beta, relu, stats, stream)) return rc;
+    return bn_finalize_backward(stats, n_dst, c_dst, bf, stream);
+  }
+  return 0;
+}
+
 extern "C" int fv2p_sparse_conv_rows_bnbwd(const float* src, int64_t n_src, int c_src, const float* weight, int kvol, const int* tab,
                                            int64_t n_dst, int c_dst, int flip_k, int transpose_w, float* dst, const float* bn_x,
                                            const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_beta, int relu,
@@ -2439,7 +2734,17 @@ static void wgrad_launch(const WgradArgs& a, float* partial, unsigned chunks, hi
 extern "C" int fv2p_sparse_conv_wgrad(const float* src, int64_t n_src, int c_src, const float* grad, const int* tab, int64_t n_dst,
                                       int c_dst, int kvol, int flip_k, int dense_k, float* dweight, void* ws, size_t ws_bytes,
                                       fv2p_stream_t stream_) {
+  return fv2p_sparse_conv_wgrad_pre(src, n_src, c_src, grad, tab, n_dst, c_dst, kvol, flip_k, dense_k, dweight, nullptr, nullptr, nullptr, nullptr, 0,
+                                    ws, ws_bytes, stream_);
+}
+
+// ... with the gathered operand passed through a BatchNorm (+ReLU) on its way into the MFMAs (the forward conv did the same on its gather)
+extern "C" int fv2p_sparse_conv_wgrad_pre(const float* src, int64_t n_src, int c_src, const float* grad, const int* tab, int64_t n_dst,
+                                          int c_dst, int kvol, int flip_k, int dense_k, float* dweight, const float* pre_mean,
+                                          const float* pre_invstd, const float* pre_gamma, const float* pre_beta, int pre_relu, void* ws,
+                                          size_t ws_bytes, fv2p_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FV2P_REQUIRE((pre_mean == nullptr) == (pre_invstd == nullptr), FV2P_EINVAL, "sparse_conv_wgrad: pre_mean and pre_invstd come together");
   FV2P_REQUIRE(c_src >= 1 && c_dst >= 1 && kvol >= 1 && n_dst >= 0 && dense_k < kvol, FV2P_EINVAL, "sparse_conv_wgrad: bad sizes");
   FV2P_REQUIRE(dweight, FV2P_EINVAL, "sparse_conv_wgrad: null dweight");
   if (n_dst == 0 || n_src == 0) {
@@ -2464,6 +2769,8 @@ extern "C" int fv2p_sparse_conv_wgrad(const float* src, int64_t n_src, int c_src
     a.grad = grad + d0; a.ld_grad = c_dst; a.c_grad = cd;
     a.tab = tab; a.n_dst = static_cast<int>(n_dst); a.kvol = kvol; a.flip = flip_k & 1;
     a.dw = dweight + static_cast<long long>(s0) * c_dst + d0; a.dw_kstride = static_cast<long long>(c_src) * c_dst; a.dw_ld = c_dst;
+    a.pre_mean = pre_mean ? pre_mean + s0 : nullptr; a.pre_invstd = pre_invstd ? pre_invstd + s0 : nullptr;
+    a.pre_gamma = pre_gamma ? pre_gamma + s0 : nullptr; a.pre_beta = pre_beta ? pre_beta + s0 : nullptr; a.pre_relu = pre_relu;
     const int mb = static_cast<int>(ceil_div(cs, 16));
     const int nb = static_cast<int>(ceil_div(cd, 16));
     const int nbp = nb <= 1 ? 1 : nb <= 2 ? 2 : nb <= 4 ? 4 : 8;
@@ -2513,7 +2820,16 @@ extern "C" size_t fv2p_sparse_conv_wgrad_pairs_ws_bytes(int64_t pair_len, int c_
 extern "C" int fv2p_sparse_conv_wgrad_pairs(const float* src, int64_t n_src, int c_src, const float* grad, int64_t n_grad, int c_dst,
                                             const int* pairs, const int* pair_num, int kvol, int64_t pair_len, int side_src,
                                             float* dweight, void* ws, size_t ws_bytes, fv2p_stream_t stream_) {
+  return fv2p_sparse_conv_wgrad_pairs_pre(src, n_src, c_src, grad, n_grad, c_dst, pairs, pair_num, kvol, pair_len, side_src, dweight, nullptr, nullptr,
+                                          nullptr, nullptr, 0, ws, ws_bytes, stream_);
+}
+
+extern "C" int fv2p_sparse_conv_wgrad_pairs_pre(const float* src, int64_t n_src, int c_src, const float* grad, int64_t n_grad, int c_dst,
+                                                const int* pairs, const int* pair_num, int kvol, int64_t pair_len, int side_src,
+                                                float* dweight, const float* pre_mean, const float* pre_invstd, const float* pre_gamma,
+                                                const float* pre_beta, int pre_relu, void* ws, size_t ws_bytes, fv2p_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FV2P_REQUIRE((pre_mean == nullptr) == (pre_invstd == nullptr), FV2P_EINVAL, "sparse_conv_wgrad_pairs: pre_mean and pre_invstd come together");
   FV2P_REQUIRE(c_src >= 1 && c_dst >= 1 && kvol >= 1 && pair_len >= 0 && (side_src == 0 || side_src == 1), FV2P_EINVAL,
                "sparse_conv_wgrad_pairs: bad sizes");
   FV2P_REQUIRE(dweight, FV2P_EINVAL, "sparse_conv_wgrad_pairs: null dweight");
@@ -2536,6 +2852,8 @@ extern "C" int fv2p_sparse_conv_wgrad_pairs(const float* src, int64_t n_src, int
       a.src = src + s0; a.ld_src = c_src; a.c_src = cs;
       a.grad = grad + d0; a.ld_grad = c_dst; a.c_grad = cd;
       a.pairs = pairs; a.pair_len = pair_len; a.pair_num = pair_num; a.side_src = side_src; a.kvol = kvol; a.chunk = chunk;
+      a.pre_mean = pre_mean ? pre_mean + s0 : nullptr; a.pre_invstd = pre_invstd ? pre_invstd + s0 : nullptr;
+      a.pre_gamma = pre_gamma ? pre_gamma + s0 : nullptr; a.pre_beta = pre_beta ? pre_beta + s0 : nullptr; a.pre_relu = pre_relu;
       const int mb = static_cast<int>(ceil_div(cs, 16)), nb = static_cast<int>(ceil_div(cd, 16));
       const int nbp = nb <= 1 ? 1 : nb <= 2 ? 2 : nb <= 4 ? 4 : 8;
       const int mbp = mb <= 1 ? 1 : mb <= 2 ? 2 : mb <= 4 ? 4 : 8;

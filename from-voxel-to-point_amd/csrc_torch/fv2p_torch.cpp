@@ -445,6 +445,334 @@ at::Tensor sparse_conv_bn_relu(const at::Tensor& features, const at::Tensor& wei
 }
 
 
+// ======================================================================================================================
+// Round 6: statistics finalised by the conv launch itself, BatchNorm (+ReLU) folded into the consumer conv's gather, the
+// residual tail in the normalisation's pass (include/fv2p_ops.h: fv2p_sparse_conv_rows_bnfin and friends).
+//
+//   conv_fin(features, W, ..., [bias], [BatchNorm that follows], [BatchNorm (+ReLU) the SOURCE rows pass through on the gather])
+//       -> (y, saved [2, Cout] = mean / invstd of y's BatchNorm, final when the conv launch ends)
+//   bn_apply(y, saved, gamma, beta, relu, [residual]) -> relu?((y - mean) * invstd * gamma + beta [+ residual])      ONE launch, no fold
+//
+// A post_act_block (conv -> BN -> ReLU, spconv_backbone.py:8-27) is conv_fin + bn_apply: 2 launches forward (as before, but the apply no
+// longer folds 64 slots in each of its workgroups) and, where the block's output feeds one conv only, 1 + 1 launches backward.
+// A SparseBasicBlock (spconv_backbone.py:32-68) is
+//       y1, s1 = conv_fin(x, W1, b1, bn1)            y2, s2 = conv_fin(y1, W2, b2, bn2, source = (s1, bn1, relu))
+//       out    = bn_apply(y2, s2, bn2, relu, residual = x)
+// 3 launches forward (was 8: two convs, two bias adds, two reduce + two apply passes, add, relu) - relu(bn1(y1)) is never written.
+// The conv bias: it feeds a train-mode BatchNorm, which removes every per-column constant - its gradient is identically zero in exact
+// arithmetic (torch returns the rounding noise of a column sum of dx).  The fused nodes add it in the conv epilogue and return zeros.
+struct FinState {
+  at::Tensor stats_f, stats_b, counter;   // slot buffers (zero between launches: the last workgroup clears what it folded), two counters
+};
+FinState& fin_state(const at::Tensor& like, void* stream) {
+  static std::mutex mu;
+  static std::map<std::pair<int, void*>, FinState> pool;
+  std::lock_guard<std::mutex> lock(mu);
+  auto key = std::make_pair(static_cast<int>(like.device().index()), stream);
+  auto it = pool.find(key);
+  if (it == pool.end()) {
+    FinState f;
+    const int64_t cap = static_cast<int64_t>(fv2p_sparse_conv_stat_slots()) * 2 * 1024;
+    f.stats_f = at::zeros({cap}, like.options().dtype(at::kDouble));
+    f.stats_b = at::zeros({cap}, like.options().dtype(at::kDouble));
+    f.counter = at::zeros({4}, like.options().dtype(at::kInt));
+    it = pool.emplace(key, std::move(f)).first;
+  }
+  return it->second;
+}
+static int g_bn_fold = -1;   // FV2P_BN_FOLD=0 / set_bn_fold(false): the Python layer keeps the round-5 arrangement (tests compare the two)
+bool bn_fold() {
+  if (g_bn_fold < 0) { const char* e = std::getenv("FV2P_BN_FOLD"); g_bn_fold = !(e && e[0] == '0'); }
+  return g_bn_fold != 0;
+}
+void set_bn_fold(bool on) { g_bn_fold = on ? 1 : 0; }
+
+const float* fptr(const at::Tensor& t) { return t.defined() ? t.data_ptr<float>() : nullptr; }
+at::Tensor opt(const c10::optional<at::Tensor>& t) { return (t.has_value() && t->defined()) ? *t : at::Tensor(); }
+
+// ---- bn_apply: y = relu?((x - mean) * invstd * gamma + beta [+ residual]) with finalised mean / invstd ------------------------------
+struct BnApplyFn : public torch::autograd::Function<BnApplyFn> {
+  static at::Tensor forward(AutogradContext* ctx, const at::Tensor& x_, const at::Tensor& saved_, const c10::optional<at::Tensor>& weight,
+                            const c10::optional<at::Tensor>& bias, bool relu, const c10::optional<at::Tensor>& residual_, bool batch_stats) {
+    require_f32_cuda(x_, "input");
+    const at::Tensor x = x_.contiguous(), saved = saved_.contiguous();
+    const at::Tensor residual = opt(residual_).defined() ? opt(residual_).contiguous() : at::Tensor();
+    const int64_t n = x.size(0), c = x.size(1);
+    TORCH_CHECK(saved.dim() == 2 && saved.size(0) == 2 && saved.size(1) == c, "bn_apply: saved statistics [2, C] expected");
+    TORCH_CHECK(!residual.defined() || residual.sizes() == x.sizes(), "bn_apply: residual must have the input's shape");
+    c10::DeviceGuard guard(x.device());
+    void* stream = cur_stream(x);
+    at::Tensor y = at::empty_like(x);
+    const at::Tensor w = opt(weight), b = opt(bias);
+    check(fv2p_batchnorm_apply_res(x.data_ptr<float>(), n, static_cast<int>(c), saved[0].data_ptr<float>(), saved[1].data_ptr<float>(), fptr(w), fptr(b),
+                                   relu ? 1 : 0, fptr(residual), y.data_ptr<float>(), stream),
+          "fv2p_batchnorm_apply_res");
+    ctx->save_for_backward({x, saved, w, b, residual.defined() ? y : at::Tensor()});
+    ctx->saved_data["relu"] = relu;
+    ctx->saved_data["batch_stats"] = batch_stats;
+    ctx->saved_data["residual"] = residual.defined();
+    return y;
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    const auto sv = ctx->get_saved_variables();
+    const at::Tensor &x = sv[0], &saved = sv[1], &weight = sv[2], &bias = sv[3], &out = sv[4];
+    const at::Tensor dy = grads[0].contiguous();
+    const int64_t n = x.size(0), c = x.size(1);
+    const bool relu = ctx->saved_data["relu"].toBool(), batch_stats = ctx->saved_data["batch_stats"].toBool();
+    c10::DeviceGuard guard(x.device());
+    void* stream = cur_stream(x);
+    at::Tensor dx = at::empty_like(x);
+    const float* mean = saved[0].data_ptr<float>();
+    const float* invstd = saved[1].data_ptr<float>();
+    if (ctx->saved_data["residual"].toBool()) {   // out = relu(bn(x) + identity): mask from out, dz is the identity branch's gradient
+      at::Tensor dz = at::empty_like(x), dpar = at::empty({2, c}, x.options());
+      at::Tensor ws = workspace(fv2p_batchnorm_ws_bytes(n, static_cast<int>(c)), x, stream);
+      if (relu) {
+        check(fv2p_batchnorm_backward_res(x.data_ptr<float>(), out.data_ptr<float>(), dy.data_ptr<float>(), n, static_cast<int>(c), mean, invstd, fptr(weight),
+                                          fptr(bias), batch_stats ? 1 : 0, dx.data_ptr<float>(), dz.data_ptr<float>(), dpar[0].data_ptr<float>(),
+                                          dpar[1].data_ptr<float>(), ws.data_ptr(), static_cast<size_t>(ws.numel()), stream),
+              "fv2p_batchnorm_backward_res");
+      } else {   // no ReLU after the sum: the identity branch receives dy itself
+        check(fv2p_batchnorm_backward(x.data_ptr<float>(), dy.data_ptr<float>(), n, static_cast<int>(c), mean, invstd, fptr(weight), fptr(bias), 0,
+                                      batch_stats ? 1 : 0, dx.data_ptr<float>(), dpar[0].data_ptr<float>(), dpar[1].data_ptr<float>(), ws.data_ptr(),
+                                      static_cast<size_t>(ws.numel()), stream),
+              "fv2p_batchnorm_backward");
+        dz = dy;
+      }
+      return {dx, at::Tensor(), weight.defined() ? dpar[0] : at::Tensor(), bias.defined() ? dpar[1] : at::Tensor(), at::Tensor(), dz, at::Tensor()};
+    }
+    // sums finalised by the backward-data conv that produced exactly this dy (ConvFinFn::backward): one launch, nothing folded
+    auto it = ctx->saved_data.find("fin_coef");
+    if (it != ctx->saved_data.end()) {
+      const at::Tensor coef = it->second.toTensor();   // [4, c]: dgamma, dbeta, c1, c2
+      const bool mine = ctx->saved_data["fin_dy"].toInt() == reinterpret_cast<int64_t>(dy.data_ptr()) &&
+                        ctx->saved_data["fin_ver"].toInt() == static_cast<int64_t>(dy._version());
+      ctx->saved_data.erase("fin_coef");
+      if (mine) {
+        check(fv2p_batchnorm_backward_fin(x.data_ptr<float>(), dy.data_ptr<float>(), n, static_cast<int>(c), mean, invstd, fptr(weight), fptr(bias),
+                                          relu ? 1 : 0, coef[2].data_ptr<float>(), dx.data_ptr<float>(), stream),
+              "fv2p_batchnorm_backward_fin");
+        return {dx, at::Tensor(), weight.defined() ? coef[0] : at::Tensor(), bias.defined() ? coef[1] : at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+      }
+    }
+    at::Tensor dpar = at::empty({2, c}, x.options());
+    at::Tensor ws = workspace(fv2p_batchnorm_ws_bytes(n, static_cast<int>(c)), x, stream);
+    check(fv2p_batchnorm_backward(x.data_ptr<float>(), dy.data_ptr<float>(), n, static_cast<int>(c), mean, invstd, fptr(weight), fptr(bias), relu ? 1 : 0,
+                                  batch_stats ? 1 : 0, dx.data_ptr<float>(), dpar[0].data_ptr<float>(), dpar[1].data_ptr<float>(), ws.data_ptr(),
+                                  static_cast<size_t>(ws.numel()), stream),
+          "fv2p_batchnorm_backward");
+    return {dx, at::Tensor(), weight.defined() ? dpar[0] : at::Tensor(), bias.defined() ? dpar[1] : at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+  }
+};
+
+// ---- conv_fin ----------------------------------------------------------------------------------------------------------------------
+struct ConvFinFn : public torch::autograd::Function<ConvFinFn> {
+  static variable_list forward(AutogradContext* ctx, const at::Tensor& features_, const at::Tensor& weight_, const at::Tensor& tab_f, int64_t flip_f,
+                               const at::Tensor& tab_b, int64_t flip_b, int64_t n_out, int64_t centre, const c10::optional<at::Tensor>& pairs,
+                               const c10::optional<at::Tensor>& pair_num, int64_t side_src, const c10::optional<at::Tensor>& perm_b,
+                               const c10::optional<at::Tensor>& conv_bias,
+                               // the BatchNorm that follows (its statistics): none of the three tensors defined + !training = no statistics
+                               bool want_stats, const c10::optional<at::Tensor>& running_mean, const c10::optional<at::Tensor>& running_var,
+                               const c10::optional<at::Tensor>& num_batches_tracked, bool training, double momentum, double eps,
+                               // the BatchNorm (+ReLU) the source rows pass through on the gather
+                               const c10::optional<at::Tensor>& pre_saved_, const c10::optional<at::Tensor>& pre_gamma_,
+                               const c10::optional<at::Tensor>& pre_beta_, bool pre_relu, bool pre_batch_stats) {
+    require_f32_cuda(features_, "features");
+    require_f32_cuda(weight_, "weight");
+    const at::Tensor features = features_.contiguous(), weight = weight_.contiguous();
+    const int64_t cin = weight.size(-2), cout = weight.size(-1);
+    const int64_t kvol = weight.numel() / (cin * cout);
+    TORCH_CHECK(features.dim() == 2 && features.size(1) == cin, "features [N, Cin] expected");
+    c10::DeviceGuard guard(features.device());
+    void* stream = cur_stream(features);
+    const at::Tensor cb = opt(conv_bias), rm = opt(running_mean), rv = opt(running_var), nbt = opt(num_batches_tracked);
+    const at::Tensor pre_saved = opt(pre_saved_).defined() ? opt(pre_saved_).contiguous() : at::Tensor();
+    const at::Tensor pre_gamma = opt(pre_gamma_), pre_beta = opt(pre_beta_);
+    const bool batch_stats = want_stats && (training || !rm.defined());
+    at::Tensor out = at::empty({n_out, cout}, features.options());
+    at::Tensor saved;
+    FinState& fs = fin_state(features, stream);
+    if (batch_stats) saved = at::empty({2, cout}, features.options());
+    else if (want_stats) saved = at::stack({rm, at::rsqrt(rv + eps)});
+    const bool track = batch_stats && training && rm.defined();
+    check(fv2p_sparse_conv_rows_bnfin(features.data_ptr<float>(), features.size(0), static_cast<int>(cin), weight.data_ptr<float>(), static_cast<int>(kvol),
+                                      tab_f.data_ptr<int>(), n_out, static_cast<int>(cout), static_cast<int>(flip_f), 0, fptr(cb), out.data_ptr<float>(),
+                                      batch_stats ? fs.stats_f.data_ptr<double>() : nullptr, reinterpret_cast<unsigned*>(fs.counter.data_ptr<int>()),
+                                      static_cast<float>(eps), static_cast<float>(momentum), track ? rm.data_ptr<float>() : nullptr,
+                                      track ? rv.data_ptr<float>() : nullptr, (track && nbt.defined()) ? nbt.data_ptr<int64_t>() : nullptr,
+                                      batch_stats ? saved[0].data_ptr<float>() : nullptr, batch_stats ? saved[1].data_ptr<float>() : nullptr,
+                                      pre_saved.defined() ? pre_saved[0].data_ptr<float>() : nullptr, pre_saved.defined() ? pre_saved[1].data_ptr<float>() : nullptr,
+                                      pre_saved.defined() ? fptr(pre_gamma) : nullptr, pre_saved.defined() ? fptr(pre_beta) : nullptr, pre_relu ? 1 : 0, stream),
+          "fv2p_sparse_conv_rows_bnfin");
+    const bool have_pairs = pairs.has_value() && pairs->defined() && pair_num.has_value() && pair_num->defined();
+    ctx->save_for_backward({features, weight, tab_f, tab_b, have_pairs ? *pairs : at::Tensor(), have_pairs ? *pair_num : at::Tensor(), opt(perm_b),
+                            pre_saved, pre_gamma, pre_beta});
+    ctx->saved_data["side_src"] = side_src;
+    ctx->saved_data["flip_f"] = flip_f;
+    ctx->saved_data["flip_b"] = flip_b;
+    ctx->saved_data["centre"] = centre;
+    ctx->saved_data["gated"] = is_gated(weight_);
+    ctx->saved_data["has_bias"] = cb.defined();
+    ctx->saved_data["pre_relu"] = pre_relu;
+    ctx->saved_data["pre_batch_stats"] = pre_batch_stats;
+    // features straight out of a bn_apply (no residual): the backward-data conv can take that layer's backward sums and finalise them
+    auto* bn_node = (!pre_saved.defined() && features_.grad_fn()) ? dynamic_cast<torch::autograd::CppNode<BnApplyFn>*>(features_.grad_fn().get()) : nullptr;
+    ctx->saved_data["bn_node"] = reinterpret_cast<int64_t>(bn_node);   // kept alive by this node's edge to it
+    if (!saved.defined()) saved = at::empty({0}, features.options());
+    ctx->mark_non_differentiable({saved});
+    return {out, saved};
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    const auto sv = ctx->get_saved_variables();
+    const at::Tensor &features = sv[0], &weight = sv[1], &tab_f = sv[2], &tab_b = sv[3], &pairs = sv[4], &pair_num = sv[5];
+    const at::Tensor &pre_saved = sv[7], &pre_gamma = sv[8], &pre_beta = sv[9];
+    const int* perm_b = (sv[6].defined() && sv[6].numel() == features.size(0)) ? sv[6].data_ptr<int>() : nullptr;
+    const at::Tensor g = grads[0].contiguous();
+    const int64_t cin = weight.size(-2), cout = weight.size(-1);
+    const int64_t kvol = weight.numel() / (cin * cout);
+    const int flip_f = static_cast<int>(ctx->saved_data["flip_f"].toInt()), flip_b = static_cast<int>(ctx->saved_data["flip_b"].toInt());
+    const int centre = static_cast<int>(ctx->saved_data["centre"].toInt());
+    const bool pre = pre_saved.defined(), pre_relu = ctx->saved_data["pre_relu"].toBool(), pre_bs = ctx->saved_data["pre_batch_stats"].toBool();
+    c10::DeviceGuard guard(features.device());
+    void* stream = cur_stream(features);
+    FinState& fs = fin_state(features, stream);
+    at::Tensor din, dw, dgamma_src, dbeta_src;
+    const bool need_in = ctx->needs_input_grad(0) || pre;   // (needs_input_grad counts tensor arguments that were defined: only 0 and 1 are stable)
+    const bool both = need_in && ctx->needs_input_grad(1);
+    const bool overlap = both && wgrad_overlap();
+    void* wstream = stream;
+    SideStream* side = nullptr;
+    if (ctx->needs_input_grad(1)) dw = at::empty_like(weight);
+    if (overlap) {
+      side = &side_stream(features.device().index());
+      TORCH_CHECK(hipEventRecord(side->fork, static_cast<hipStream_t>(stream)) == hipSuccess, "hipEventRecord failed");
+      TORCH_CHECK(hipStreamWaitEvent(side->stream.stream(), side->fork, 0) == hipSuccess, "hipStreamWaitEvent failed");
+      wstream = static_cast<void*>(side->stream.stream());
+    }
+    if (need_in) {
+      din = at::empty_like(features);
+      at::Tensor wt;
+      int transpose_w = 1;
+      if ((cout == 64 || cout == 128) && cin % 64 == 0 && cin <= 128 && kvol > 1) {   // W_k^T materialised for the K-split tile (SparseConvFn::backward)
+        wt = weight.view({kvol, cin, cout}).transpose(1, 2).contiguous();
+        transpose_w = 0;
+      }
+      const float* w_bwd = wt.defined() ? wt.data_ptr<float>() : weight.data_ptr<float>();
+      unsigned* counter = reinterpret_cast<unsigned*>(fs.counter.data_ptr<int>()) + 1;
+      if (pre) {
+        // d(relu(bn(y_src))) by the backward-data conv, the BatchNorm's backward sums from its epilogue, finalised by its last workgroup;
+        // then the BatchNorm's own backward pass in place: din becomes d(y_src)
+        at::Tensor coef = at::empty({4, cin}, features.options());
+        check(fv2p_sparse_conv_rows_bnbwd_fin(g.data_ptr<float>(), g.size(0), static_cast<int>(cout), w_bwd, static_cast<int>(kvol), tab_b.data_ptr<int>(),
+                                              features.size(0), static_cast<int>(cin), flip_b, transpose_w, din.data_ptr<float>(), features.data_ptr<float>(),
+                                              pre_saved[0].data_ptr<float>(), pre_saved[1].data_ptr<float>(), fptr(pre_gamma), fptr(pre_beta), pre_relu ? 1 : 0,
+                                              fs.stats_b.data_ptr<double>(), counter, pre_bs ? 1 : 0, coef[0].data_ptr<float>(), coef[1].data_ptr<float>(),
+                                              coef[2].data_ptr<float>(), perm_b, stream),
+              "fv2p_sparse_conv_rows_bnbwd_fin");
+        check(fv2p_batchnorm_backward_fin(features.data_ptr<float>(), din.data_ptr<float>(), features.size(0), static_cast<int>(cin),
+                                          pre_saved[0].data_ptr<float>(), pre_saved[1].data_ptr<float>(), fptr(pre_gamma), fptr(pre_beta), pre_relu ? 1 : 0,
+                                          coef[2].data_ptr<float>(), din.data_ptr<float>(), stream),
+              "fv2p_batchnorm_backward_fin");
+        dgamma_src = coef[0];
+        dbeta_src = coef[1];
+      } else {
+        auto* bn_node = reinterpret_cast<torch::autograd::CppNode<BnApplyFn>*>(ctx->saved_data["bn_node"].toInt());
+        bool fused = false;
+        if (bn_node && fuse_bn_stats() && cout <= 128 && cin <= 1024) {
+          AutogradContext& bctx = bn_node->ctx_;
+          if (!bctx.saved_data["residual"].toBool() && bctx.saved_data.find("fin_coef") == bctx.saved_data.end()) {
+            const auto bsaved = bctx.get_saved_variables();   // x, saved, weight, bias, out
+            const at::Tensor &bx = bsaved[0], &bstat = bsaved[1], &bw = bsaved[2], &bb = bsaved[3];
+            if (bx.defined() && bx.sizes() == din.sizes() && bx.is_contiguous()) {
+              at::Tensor coef = at::empty({4, cin}, features.options());
+              check(fv2p_sparse_conv_rows_bnbwd_fin(g.data_ptr<float>(), g.size(0), static_cast<int>(cout), w_bwd, static_cast<int>(kvol), tab_b.data_ptr<int>(),
+                                                    features.size(0), static_cast<int>(cin), flip_b, transpose_w, din.data_ptr<float>(), bx.data_ptr<float>(),
+                                                    bstat[0].data_ptr<float>(), bstat[1].data_ptr<float>(), fptr(bw), fptr(bb),
+                                                    bctx.saved_data["relu"].toBool() ? 1 : 0, fs.stats_b.data_ptr<double>(), counter,
+                                                    bctx.saved_data["batch_stats"].toBool() ? 1 : 0, coef[0].data_ptr<float>(), coef[1].data_ptr<float>(),
+                                                    coef[2].data_ptr<float>(), perm_b, stream),
+                    "fv2p_sparse_conv_rows_bnbwd_fin");
+              bctx.saved_data["fin_coef"] = coef;
+              bctx.saved_data["fin_dy"] = reinterpret_cast<int64_t>(din.data_ptr());
+              bctx.saved_data["fin_ver"] = static_cast<int64_t>(din._version());
+              fused = true;
+            }
+          }
+        }
+        if (!fused)
+          check(fv2p_sparse_conv_rows_perm(g.data_ptr<float>(), g.size(0), static_cast<int>(cout), w_bwd, static_cast<int>(kvol), tab_b.data_ptr<int>(),
+                                           features.size(0), static_cast<int>(cin), flip_b, transpose_w, nullptr, din.data_ptr<float>(), perm_b, stream),
+                "fv2p_sparse_conv_rows (backward data)");
+      }
+    }
+    if (ctx->needs_input_grad(1)) {
+      c10::optional<c10::hip::HIPStreamGuard> sg;
+      if (overlap) sg.emplace(side->stream);
+      const float* pm = pre ? pre_saved[0].data_ptr<float>() : nullptr;
+      const float* pi = pre ? pre_saved[1].data_ptr<float>() : nullptr;
+      if (pairs.defined()) {
+        const int64_t plen = pairs.size(2);
+        const size_t wsb = fv2p_sparse_conv_wgrad_pairs_ws_bytes(plen, static_cast<int>(cin), static_cast<int>(cout), static_cast<int>(kvol));
+        at::Tensor ws = workspace(wsb, features, wstream);
+        check(fv2p_sparse_conv_wgrad_pairs_pre(features.data_ptr<float>(), features.size(0), static_cast<int>(cin), g.data_ptr<float>(), g.size(0),
+                                               static_cast<int>(cout), pairs.data_ptr<int>(), pair_num.data_ptr<int>(), static_cast<int>(kvol), plen,
+                                               static_cast<int>(ctx->saved_data["side_src"].toInt()), dw.data_ptr<float>(), pm, pi, pre ? fptr(pre_gamma) : nullptr,
+                                               pre ? fptr(pre_beta) : nullptr, pre_relu ? 1 : 0, ws.data_ptr(), static_cast<size_t>(ws.numel()), wstream),
+              "fv2p_sparse_conv_wgrad_pairs_pre");
+      } else {
+        const size_t wsb = fv2p_sparse_conv_wgrad_ws_bytes(g.size(0), static_cast<int>(cin), static_cast<int>(cout), static_cast<int>(kvol));
+        at::Tensor ws = workspace(wsb, features, wstream);
+        check(fv2p_sparse_conv_wgrad_pre(features.data_ptr<float>(), features.size(0), static_cast<int>(cin), g.data_ptr<float>(), tab_f.data_ptr<int>(), g.size(0),
+                                         static_cast<int>(cout), static_cast<int>(kvol), flip_f, centre, dw.data_ptr<float>(), pm, pi, pre ? fptr(pre_gamma) : nullptr,
+                                         pre ? fptr(pre_beta) : nullptr, pre_relu ? 1 : 0, ws.data_ptr(), static_cast<size_t>(ws.numel()), wstream),
+              "fv2p_sparse_conv_wgrad_pre");
+      }
+    }
+    if (overlap && ctx->saved_data["gated"].toBool()) {
+      std::lock_guard<std::mutex> lock(g_pending_mu);
+      auto& parked = g_pending[features.device().index()];
+      for (const at::Tensor& t : {features, g, tab_f, pairs, pair_num, dw, pre_saved, pre_gamma, pre_beta})
+        if (t.defined()) parked.push_back(t);
+    } else if (overlap) {
+      TORCH_CHECK(hipEventRecord(side->join, side->stream.stream()) == hipSuccess, "hipEventRecord failed");
+      TORCH_CHECK(hipStreamWaitEvent(static_cast<hipStream_t>(stream), side->join, 0) == hipSuccess, "hipStreamWaitEvent failed");
+    }
+    variable_list out(25);   // one per forward argument: 0 features, 1 weight, 12 conv_bias, 21 pre_gamma, 22 pre_beta
+    out[0] = din;
+    out[1] = dw;
+    if (ctx->saved_data["has_bias"].toBool()) out[12] = at::zeros({cout}, features.options());   // see the section comment
+    if (pre) { out[21] = dgamma_src; out[22] = dbeta_src; }
+    return out;
+  }
+};
+
+// -> [y, saved]; see the section comment.  Returns an empty list when the arrangement is not the plain one (the caller then runs the modules).
+std::vector<at::Tensor> conv_fin(const at::Tensor& features, const at::Tensor& weight, const at::Tensor& tab_f, int64_t flip_f, const at::Tensor& tab_b,
+                                 int64_t flip_b, int64_t n_out, int64_t centre, const c10::optional<at::Tensor>& pairs,
+                                 const c10::optional<at::Tensor>& pair_num, int64_t side_src, const c10::optional<at::Tensor>& perm_b,
+                                 const c10::optional<at::Tensor>& conv_bias, bool want_stats, const c10::optional<at::Tensor>& running_mean,
+                                 const c10::optional<at::Tensor>& running_var, const c10::optional<at::Tensor>& num_batches_tracked, bool training,
+                                 double momentum, double eps, const c10::optional<at::Tensor>& pre_saved, const c10::optional<at::Tensor>& pre_gamma,
+                                 const c10::optional<at::Tensor>& pre_beta, bool pre_relu, bool pre_batch_stats) {
+  const bool has_bias = conv_bias.has_value() && conv_bias->defined();
+  const bool batch_stats = want_stats && (training || !(running_mean.has_value() && running_mean->defined()));
+  if (!features.is_cuda() || !fuse_bn_stats() || weight.size(-1) > 1024) return {};
+  if (n_out < 2 && training) return {};      // torch raises for one value per channel: let the caller run the module
+  if (has_bias && !batch_stats) return {};   // a bias whose gradient is NOT identically zero (no train-mode BatchNorm behind it): the modules run
+  return ConvFinFn::apply(features, weight, tab_f, flip_f, tab_b, flip_b, n_out, centre, pairs, pair_num, side_src, perm_b, conv_bias, want_stats,
+                          running_mean, running_var, num_batches_tracked, training, momentum, eps, pre_saved, pre_gamma, pre_beta, pre_relu, pre_batch_stats);
+}
+at::Tensor bn_apply(const at::Tensor& x, const at::Tensor& saved, const c10::optional<at::Tensor>& weight, const c10::optional<at::Tensor>& bias, bool relu,
+                    const c10::optional<at::Tensor>& residual, bool batch_stats) {
+  return BnApplyFn::apply(x, saved, weight, bias, relu, residual, batch_stats);
+}
+bool prenorm_supported(int64_t c_src, int64_t c_dst, int64_t kvol, int64_t n_dst, int64_t flip_k) {
+  return fv2p_sparse_conv_prenorm_supported(static_cast<int>(c_src), static_cast<int>(c_dst), static_cast<int>(kvol), n_dst, static_cast<int>(flip_k), 0) == 1;
+}
+
+
 // ---- input-pipeline entry points: one GIL-free call each ----------------------------------------------------------------
 // A pipeline thread that prepares the next batch shares the interpreter lock with the training thread.  Issued from
 // Python, a batch's voxelisation and rulebook chain is ~120 small calls, i.e. ~120 lock hand-offs per step with the
@@ -627,5 +955,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
         "voxelise a batch of clouds + MeanVFE + collate, without the GIL");
   m.def("build_rulebook_chain", &build_rulebook_chain, py::call_guard<py::gil_scoped_release>(),
         "build a chain of rulebooks (and pair lists) from root coordinates, without the GIL");
+  m.def("conv_fin", &conv_fin, "sparse conv with its BatchNorm statistics finalised by the launch (and optionally the source rows' BatchNorm + ReLU on the gather) -> [y, saved]");
+  m.def("bn_apply", &bn_apply, "relu?((x - mean) * invstd * gamma + beta [+ residual]) with finalised statistics, one launch");
+  m.def("prenorm_supported", &prenorm_supported, "the conv kernel of this shape can normalise its source rows on the gather");
+  m.def("set_bn_fold", &set_bn_fold, "round-6 arrangement of conv / BatchNorm / residual blocks on (default) or off (the round-5 one)");
+  m.def("bn_fold", &bn_fold);
   m.def("sparse_conv_bn_relu", &sparse_conv_bn_relu, "sparse conv -> BatchNorm1d (-> ReLU) with autograd, one call per backbone block");
 }

@@ -36,8 +36,19 @@ class _BasicBlock(spconv.SparseModule):
 
     def forward(self, x):
         identity = x.features
-        out = _conv_bn(self.conv1, self.bn1, self.relu, x)
-        out = _conv_bn(self.conv2, self.bn2, None, out)
+        # round 6: conv1 finalises bn1's statistics, conv2 normalises + rectifies its gathered rows (relu(bn1(y1)) is never written),
+        # bn2 + the identity + the ReLU are one launch (pcdet.ops.spconv.conv.conv_bn_fold); otherwise module by module as before
+        from pcdet.ops.spconv.conv import conv_bn_fold, materialise_pending
+        mid = conv_bn_fold(self.conv1, x, self.bn1, self.relu, defer=True)
+        if mid is not None:
+            out = conv_bn_fold(self.conv2, mid, self.bn2, self.relu, residual=identity)
+            if out is not None:
+                return out
+            materialise_pending(mid)
+            out = _conv_bn(self.conv2, self.bn2, None, mid)
+        else:
+            out = _conv_bn(self.conv1, self.bn1, self.relu, x)
+            out = _conv_bn(self.conv2, self.bn2, None, out)
         out.features = self.relu(out.features + identity)
         return out
 

@@ -15,7 +15,7 @@ _REFERENCE_NAMES = {
     _structure: ("SparseConvTensor", "scatter_nd"),
     _group: ("SparseGroup3d", "SubMGroup3d"),
 }
-_OWN_NAMES = {_prefetch: ("rulebook_recipe", "build_rulebooks", "attach_rulebooks"), _conv: ("defer_weight_gradients",)}
+_OWN_NAMES = {_prefetch: ("rulebook_recipe", "build_rulebooks", "attach_rulebooks"), _conv: ("defer_weight_gradients", "conv_bn_fold", "materialise_pending", "set_bn_fold", "fold_enabled")}
 
 __all__ = []
 for _table in (_REFERENCE_NAMES, _OWN_NAMES):

@@ -80,6 +80,12 @@ class SparseConvolution(SparseModule):
         """`_post` (internal, set by SparseSequential): the (BatchNorm1d, ReLU-or-None) pair that follows this conv; when
         the compiled binding can run conv -> BN -> ReLU in one call the returned tensor carries `_fv2p_post_done`."""
         assert isinstance(input, SparseConvTensor)
+        if _post is not None and not self.fused_bn:
+            folded = conv_bn_fold(self, input, _post[0], _post[1])
+            if folded is not None:
+                folded._fv2p_post_done = True
+                return folded
+        materialise_pending(input)   # (a BatchNorm left pending by conv_bn_fold(defer=True): this path reads materialised rows)
         # alias of self.weight made by defer_weight_gradients() for this pass (its dW is joined at the end of backward)
         weight = self.__dict__.pop("_fv2p_gated_weight", None)
         if weight is None or not torch.is_grad_enabled():
@@ -171,6 +177,111 @@ def _conv_bn_relu(self, features, rb, n_out, post, weight=None):
 
 
 SparseConvolution._conv_bn_relu = _conv_bn_relu
+
+
+def fold_enabled():
+    """Round-6 arrangement of conv / BatchNorm / residual blocks (csrc_torch/fv2p_torch.cpp: conv_fin, bn_apply): on unless FV2P_BN_FOLD=0
+    or `set_bn_fold(False)`; needs the compiled binding."""
+    import fv2p_native as _nat
+    ext = _nat.torch_ext()
+    return ext is not None and ext.bn_fold()
+
+
+def set_bn_fold(on):
+    import fv2p_native as _nat
+    ext = _nat.torch_ext()
+    if ext is not None:
+        ext.set_bn_fold(bool(on))
+
+
+def materialise_pending(x):
+    """A SparseConvTensor whose features are still the raw conv output with a BatchNorm (+ReLU) pending (conv_bn_fold(defer=True)):
+    apply it now (one launch, statistics already final) - for consumers that cannot normalise on their gather."""
+    pend = x.__dict__.pop("_fv2p_pending", None)
+    if pend is not None:
+        import fv2p_native as _nat
+        saved, bn, relu, batch_stats = pend
+        x.features = _nat.torch_ext().bn_apply(x.features, saved, bn.weight, bn.bias, relu, None, batch_stats)
+    return x
+
+
+def conv_bn_fold(conv, x, bn, relu_module, defer=False, residual=None):
+    """conv -> BatchNorm1d (-> ReLU) of the reference's blocks (spconv_backbone.py:8-27, 32-68) on the round-6 kernels:
+
+      * the conv's last workgroup finalises the BatchNorm statistics (mean / invstd / running statistics), so the normalisation is ONE
+        launch that folds nothing - or none at all:
+      * defer=True returns the RAW conv output with the BatchNorm (+ReLU) pending on the tensor; a following conv_bn_fold call on a
+        conv whose kernel can normalise its gathered source rows (conv_fin's `pre_*`; ext.prenorm_supported) never materialises
+        relu(bn(y)) - the bn1 -> relu -> conv2 of a residual block.  Any other consumer calls materialise_pending();
+      * residual: out = relu?(bn(conv(x)) + residual) in the normalisation's launch (the `out.features += identity; relu` tail).
+
+    Returns the output SparseConvTensor, or None when the situation is not the plain one (hooks, CPU, autocast, a conv bias without a
+    train-mode BatchNorm behind it ...): the caller then runs the modules one by one, with torch's own behaviour."""
+    import fv2p_native as _nat
+    from .norm import fusable
+    ext = _nat.torch_ext()
+    if ext is None or not ext.bn_fold() or conv.conv1x1 or conv.fused_bn or conv.inverse:
+        return None
+    if conv._forward_hooks or conv._forward_pre_hooks or conv._backward_hooks:
+        return None
+    features = x.features
+    if not (torch.is_tensor(features) and features.is_cuda and features.dtype == torch.float32 and features.dim() == 2
+            and conv.weight.dtype == torch.float32 and x.indices.shape[0] != 0):
+        return None
+    if not fusable(bn, relu_module, features, conv.out_channels):
+        return None
+    weight = conv.__dict__.get("_fv2p_gated_weight")   # alias made by defer_weight_gradients() for this pass (popped once it is used)
+    if weight is None or not torch.is_grad_enabled():
+        weight = conv.weight
+    indices, spatial_shape, batch_size = x.indices, x.spatial_shape, x.batch_size
+    if conv.subm:
+        out_spatial_shape = spatial_shape
+    elif conv.transposed:
+        out_spatial_shape = ops.get_deconv_output_size(spatial_shape, conv.kernel_size, conv.stride, conv.padding, conv.dilation, conv.output_padding)
+    else:
+        out_spatial_shape = ops.get_conv_output_size(spatial_shape, conv.kernel_size, conv.stride, conv.padding, conv.dilation)
+    datas = x.find_indice_pair(conv.indice_key)
+    if conv.indice_key is not None and datas is not None and geometry_matches(datas, conv, indices):
+        rb = datas
+    else:
+        rb = ops.build_rulebook(indices, batch_size, spatial_shape, conv.kernel_size, conv.stride, conv.padding, conv.dilation,
+                                conv.output_padding, conv.subm, conv.transposed)
+        x.indice_dict[conv.indice_key] = rb
+    outids = rb.outids
+    n_out = outids.shape[0]
+    if n_out < 2:
+        return None
+    cin, cout = conv.in_channels, conv.out_channels
+    (tab_f, flip_f), (tab_b, flip_b) = rb.out_table(cin), rb.in_table(cout)
+    centre = (rb.kvol // 2) if (rb.subm and rb.tab_out is None) else -1
+    have = rb._wpairs is not None and rb._num is not None
+    pend = x.__dict__.get("_fv2p_pending")
+    pre = (None, None, None, False, False)
+    if pend is not None:
+        if ext.prenorm_supported(cin, cout, rb.kvol, n_out, int(flip_f)):
+            saved_src, bn_src, relu_src, bs_src = pend
+            pre = (saved_src, bn_src.weight, bn_src.bias, relu_src, bs_src)
+        else:
+            features = materialise_pending(x).features
+    momentum = -1.0 if bn.momentum is None else float(bn.momentum)
+    res = ext.conv_fin(features, weight, tab_f, flip_f, tab_b, flip_b, n_out, centre, rb._wpairs if have else None, rb._num if have else None, 0,
+                       getattr(rb, "_perm_in", None), conv.bias, True, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.training,
+                       momentum, float(bn.eps), *pre)
+    if not res:
+        if pend is not None:
+            materialise_pending(x)
+        return None
+    conv.__dict__.pop("_fv2p_gated_weight", None)
+    y, saved = res
+    batch_stats = bool(bn.training or bn.running_mean is None)
+    out = SparseConvTensor(y, outids, out_spatial_shape, batch_size)
+    out.indice_dict = x.indice_dict
+    out.grid = x.grid
+    if defer and residual is None:
+        out._fv2p_pending = (saved, bn, relu_module is not None, batch_stats)
+    else:
+        out.features = ext.bn_apply(y, saved, bn.weight, bn.bias, relu_module is not None, residual, batch_stats)
+    return out
 
 
 def defer_weight_gradients(module):

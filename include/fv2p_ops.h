@@ -187,6 +187,42 @@ int fv2p_sparse_conv_rows_bnbwd(const float* src, int64_t n_src, int c_src, cons
                                 const int* tab, int64_t n_dst, int c_dst, int flip_k, int transpose_w, float* dst,
                                 const float* bn_x, const float* bn_mean, const float* bn_invstd, const float* bn_gamma,
                                 const float* bn_beta, int relu, double* stats, const int* perm, fv2p_stream_t stream);
+/* ---- round 6: BatchNorm statistics finalised by the conv launch, BatchNorm (+ReLU) of the source rows on the gather ------------
+ * The reference runs conv -> nn.BatchNorm1d -> nn.ReLU as three modules (spconv_backbone.py:8-27, modules.py:86-100) and, inside a
+ * residual block, conv1 -> bn1 -> relu -> conv2 (spconv_backbone.py:47-68).  Here
+ *   fv2p_sparse_conv_rows_bnfin     = fv2p_sparse_conv_rows_stats whose LAST workgroup folds the slots itself: when the launch ends mean /
+ *                                     invstd [c_dst] (and the running statistics, num_batches_tracked) are final, the slots zero again and
+ *                                     *counter (a zeroed device word the caller keeps per stream) zero again - BatchNorm apply kernels
+ *                                     (fv2p_batchnorm_apply_res) and consumer convs read 2 - 4 floats per column instead of folding
+ *                                     64 slots in every workgroup.  stats == NULL: no statistics.
+ *                                     pre_mean / pre_invstd / pre_gamma / pre_beta [c_src] (NULL = off): every gathered source row passes
+ *                                     through relu?((v - mean) * invstd * gamma + beta) on its way into the MFMAs - the producer's
+ *                                     BatchNorm(+ReLU) output is never materialised.  Same operations in the same order as
+ *                                     fv2p_batchnorm_apply: results are bit-identical to the conv over materialised rows.
+ *                                     Kernels with that form: ask fv2p_sparse_conv_prenorm_supported (else FV2P_EINVAL, nothing launched).
+ *   fv2p_sparse_conv_rows_bnbwd_fin = fv2p_sparse_conv_rows_bnbwd whose last workgroup leaves dgamma, dbeta [c_dst] and
+ *                                     coef [2][c_dst] = (mean dz, mean dz * xhat; zeros when batch_stats == 0) for fv2p_batchnorm_backward_fin.
+ *   fv2p_sparse_conv_wgrad(_pairs)_pre = the weight gradient with the same normalisation of the gathered operand. */
+int fv2p_sparse_conv_rows_bnfin(const float* src, int64_t n_src, int c_src, const float* weight, int kvol, const int* tab,
+                                int64_t n_dst, int c_dst, int flip_k, int transpose_w, const float* bias, float* dst,
+                                double* stats, unsigned* counter, float eps, float momentum, float* running_mean,
+                                float* running_var, int64_t* num_batches_tracked, float* mean, float* invstd,
+                                const float* pre_mean, const float* pre_invstd, const float* pre_gamma, const float* pre_beta,
+                                int pre_relu, fv2p_stream_t stream);
+int fv2p_sparse_conv_prenorm_supported(int c_src, int c_dst, int kvol, int64_t n_dst, int flip_k, int transpose_w);
+int fv2p_sparse_conv_rows_bnbwd_fin(const float* src, int64_t n_src, int c_src, const float* weight, int kvol, const int* tab,
+                                    int64_t n_dst, int c_dst, int flip_k, int transpose_w, float* dst, const float* bn_x,
+                                    const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_beta,
+                                    int relu, double* stats, unsigned* counter, int batch_stats, float* dgamma, float* dbeta,
+                                    float* coef, const int* perm, fv2p_stream_t stream);
+int fv2p_sparse_conv_wgrad_pre(const float* src, int64_t n_src, int c_src, const float* grad, const int* tab, int64_t n_dst,
+                               int c_dst, int kvol, int flip_k, int dense_k, float* dweight, const float* pre_mean,
+                               const float* pre_invstd, const float* pre_gamma, const float* pre_beta, int pre_relu, void* ws,
+                               size_t ws_bytes, fv2p_stream_t stream);
+int fv2p_sparse_conv_wgrad_pairs_pre(const float* src, int64_t n_src, int c_src, const float* grad, int64_t n_grad, int c_dst,
+                                     const int* pairs, const int* pair_num, int kvol, int64_t pair_len, int side_src,
+                                     float* dweight, const float* pre_mean, const float* pre_invstd, const float* pre_gamma,
+                                     const float* pre_beta, int pre_relu, void* ws, size_t ws_bytes, fv2p_stream_t stream);
 /* fv2p_sparse_conv_rows with a row order: perm [n_dst] (NULL = identity) says which destination rows share a 64-row
  * tile; every row's sum is unchanged (bit-identical results), only the work per tile changes — a tile visits just the
  * kernel offsets its rows use.  Meant for the backward-data conv of strided layers with fv2p_rulebook_class_perm's
@@ -549,6 +585,19 @@ int fv2p_batchnorm_backward_stats(const float* x, const float* dy, int64_t n, in
                                   const float* invstd, const float* gamma, const float* beta, int relu,
                                   int batch_stats, float* dx, float* dgamma, float* dbeta, const double* stats,
                                   double* zero_next, int64_t zero_count, fv2p_stream_t stream);
+/* round 6: fv2p_batchnorm_apply with an optional residual term, y = relu?(bn(x) + residual) - the tail of a residual block
+ * (spconv_backbone.py:63-66: out.features += identity; relu) in the normalisation's own pass; fv2p_batchnorm_backward_fin = the apply
+ * half of the backward with c1 / c2 (coef) already finalised by fv2p_sparse_conv_rows_bnbwd_fin; fv2p_batchnorm_backward_res = backward
+ * of out = relu(bn(x) + identity): the ReLU mask is read from `out`, dz = dout * [out > 0] (the identity branch's gradient) is written
+ * beside dx. */
+int fv2p_batchnorm_apply_res(const float* x, int64_t n, int c, const float* mean, const float* invstd, const float* gamma,
+                             const float* beta, int relu, const float* residual, float* y, fv2p_stream_t stream);
+int fv2p_batchnorm_backward_fin(const float* x, const float* dy, int64_t n, int c, const float* mean, const float* invstd,
+                                const float* gamma, const float* beta, int relu, const float* coef, float* dx,
+                                fv2p_stream_t stream);
+int fv2p_batchnorm_backward_res(const float* x, const float* out, const float* dout, int64_t n, int c, const float* mean,
+                                const float* invstd, const float* gamma, const float* beta, int batch_stats, float* dx,
+                                float* dz, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, fv2p_stream_t stream);
 int fv2p_batchnorm_apply(const float* x, int64_t n, int c, const float* mean, const float* invstd,
                          const float* gamma, const float* beta, int relu, float* y, fv2p_stream_t stream);
 int fv2p_batchnorm_backward(const float* x, const float* dy, int64_t n, int c, const float* mean,

@@ -191,7 +191,7 @@ def test_backward_ragged_tail_chunk_on_a_large_map(gpu):
         assert torch.equal(a, c)
     cx, co, cm = (t.clone().double().requires_grad_(True) for t in (x, offset, mask))
     w = m.weight.detach().cpu().double().requires_grad_(True)
-    ref = dcn_oracle.modulated_deform_conv(cx, co, cm, w, torch.zeros(cout, dtype=torch.float64), (1, 1), (1, 1), (1, 1), dg)
+    ref = dcn_oracle.modulated_deform_conv(cx, co, cm, w, m.bias.detach().cpu().double(), (1, 1), (1, 1), (1, 1), dg)   # (bias=False freezes the bias, it does not remove it)
     ref.backward(g.double())
     assert rel(parts[0], ref) < 1e-4 and rel(parts[4], w.grad) < 1e-4 and rel(parts[1], cx.grad) < 1e-4
 
