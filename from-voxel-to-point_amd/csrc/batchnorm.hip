@@ -516,3 +516,261 @@ extern "C" int fv2p_batchnorm_backward_res(const float* x, const float* out, con
   FV2P_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- one launch per BatchNorm pass: reduce, grid barrier, apply ----------------------------------------------------------------------
+// The BatchNorms that do not sit behind one of this library's convs (the decoder's Linear -> BatchNorm1d -> ReLU rows, the residual
+// tails, every layer whose incoming gradient is a sum of several) took two launches forward and two backward: a reduce pass on <= 64
+// workgroups and the apply pass, with the launch gap of two dependent kernels between them (bn_reduce_k<BWD> alone: 25 us x 29 per FV2P
+// step).  Here both phases are one kernel of G <= kOneGrid workgroups that are all resident at once (256 threads, 20 KB of LDS: a CU
+// holds eight, the chip 2 048 - several such launches from different streams still fit side by side, and kernels that do not wait for
+// anybody finish in between).  Phase 1: workgroup b reduces its rows and publishes partial[b] with agent-scope stores (write-through:
+// the eight XCD L2s are not coherent with each other), waits for their acknowledgement and counts itself in.  Barrier: one thread per
+// workgroup polls the counter with agent-scope loads.  Phase 2: every workgroup folds the G partials (fold_chunk: the same fixed order
+// as the two-launch form, so the statistics are bit-identical to it) and applies its share of the rows.  The last workgroup to leave
+// resets the two counters.  No fence: nothing but the partials and the counters crosses workgroups.
+constexpr int kOneGrid = 128;
+// Every workgroup folds ALL partials with loads that bypass its L2: G^2 x 2 c doubles cross the fabric per launch (33 MB at G = 128,
+// c = 128: 46 against 33 us for the two-launch forward at 10 000 x 128).  Wide layers therefore run on 32 workgroups (2 MB); what that
+// leaves of the chip is enough up to ~2 M elements (tools/bn_time.py), above that the caller keeps reduce + apply.
+static int one_grid(int c) { return c >= 64 ? 32 : kOneGrid; }
+extern "C" int fv2p_batchnorm_one_pays(int64_t n, int c, int backward) {
+  const int64_t elems = n * c;
+  if (elems > (2ll << 20)) return 0;
+  return backward ? 1 : (c <= 32 ? 1 : 0);   // forward: the reduce pass is short (12 - 18 us), one launch only wins on narrow layers
+}
+
+__device__ __forceinline__ void grid_arrive_and_wait(unsigned* counters, unsigned total) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this workgroup's partials have been acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(counters, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(counters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total) __builtin_amdgcn_s_sleep(2);
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void grid_leave(unsigned* counters, unsigned total) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (__hip_atomic_fetch_add(counters + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1u) {
+      __hip_atomic_store(counters, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(counters + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// phase 1 of both directions: per-channel (a, b) sums of this workgroup's rows -> partial[blockIdx][2][c], published agent-wide
+template <int V, bool BWD>
+__device__ __forceinline__ void one_reduce(const float* __restrict__ x, const float* __restrict__ dy, const BnGeom& g, const float* mean,
+                                           const float* invstd, const float* gamma, const float* beta, int relu, const float* mask_y,
+                                           double* partial, double (*red)[256 * V]) {
+  const int tid = threadIdx.x;
+  const int rl = tid / g.tcols, cq = tid % g.tcols;
+  const int col = cq * V;
+  const bool live = rl < g.rpp && col < g.c;
+  double s1[V], s2[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) s1[i] = s2[i] = 0.0;
+  if (live) {
+    float m[V] = {}, is[V] = {}, ga[V] = {}, be[V] = {};
+    if (BWD) {
+#pragma unroll
+      for (int i = 0; i < V; ++i) { m[i] = mean[col + i]; is[i] = invstd[col + i]; ga[i] = gamma ? gamma[col + i] : 1.f; be[i] = beta ? beta[col + i] : 0.f; }
+    }
+    const long long r0 = static_cast<long long>(blockIdx.x) * g.rows_per_block;
+    const long long r1 = min(r0 + g.rows_per_block, g.n);
+    constexpr int U = 8;
+    auto accumulate = [&](const Vec<V>& xv, const Vec<V>& gv, const Vec<V>& mv) {
+      if (!BWD) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) { const double d = xv.v[i]; s1[i] += d; s2[i] += d * d; }
+      } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          const float xhat = (xv.v[i] - m[i]) * is[i];
+          const float y = mask_y ? mv.v[i] : xhat * ga[i] + be[i];
+          const float dz = (relu && !(y > 0.f)) ? 0.f : gv.v[i];
+          s1[i] += dz; s2[i] += static_cast<double>(dz) * xhat;
+        }
+      }
+    };
+    long long r = r0 + rl;
+    for (; r + static_cast<long long>(U - 1) * g.rpp < r1; r += static_cast<long long>(U) * g.rpp) {
+      Vec<V> xv[U], gv[U], mv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        xv[u].load(x + (r + static_cast<long long>(u) * g.rpp) * g.c + col, 0, 0);
+        if (BWD) gv[u].load(dy + (r + static_cast<long long>(u) * g.rpp) * g.c + col, 0, 0);
+        if (BWD && mask_y) mv[u].load(mask_y + (r + static_cast<long long>(u) * g.rpp) * g.c + col, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) accumulate(xv[u], gv[u], mv[u]);
+    }
+    for (; r < r1; r += g.rpp) {
+      Vec<V> xv, gv, mv;
+      xv.load(x + r * g.c + col, 0, 0);
+      if (BWD) gv.load(dy + r * g.c + col, 0, 0);
+      if (BWD && mask_y) mv.load(mask_y + r * g.c + col, 0, 0);
+      accumulate(xv, gv, mv);
+    }
+  }
+  if (rl < g.rpp) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) { red[0][(rl * g.tcols + cq) * V + i] = s1[i]; red[1][(rl * g.tcols + cq) * V + i] = s2[i]; }
+  }
+  __syncthreads();
+  const int cpad = g.tcols * V;
+  for (int e = tid; e < cpad; e += 256) {
+    double a = 0.0, b = 0.0;
+    for (int q = 0; q < g.rpp; ++q) { a += red[0][q * cpad + e]; b += red[1][q * cpad + e]; }
+    if (e < g.c) {
+      __hip_atomic_store(partial + (static_cast<long long>(blockIdx.x) * 2 + 0) * g.c + e, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(partial + (static_cast<long long>(blockIdx.x) * 2 + 1) * g.c + e, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void bn_one_fwd_k(const float* __restrict__ x, long long units, BnGeom g, double* __restrict__ partial,
+                                                    unsigned* __restrict__ counters, BnFwdFin ff, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, int relu, float* __restrict__ y, const float* __restrict__ residual) {
+  __shared__ double red1[2][256 * V];
+  __shared__ float sh_is[kBnMaxC], sh_beta[kBnMaxC], sh_mean[kBnMaxC], sh_gamma[kBnMaxC];
+  one_reduce<V, false>(x, nullptr, g, nullptr, nullptr, nullptr, nullptr, 0, nullptr, partial, red1);
+  grid_arrive_and_wait(counters, gridDim.x);
+  double (*red)[256] = reinterpret_cast<double (*)[256]>(&red1[0][0]);
+  const int tid = threadIdx.x, c = g.c;
+  const int cfold = c < 256 ? c : 256;
+  for (int e0 = 0; e0 < c; e0 += cfold) {
+    const int e = e0 + tid;
+    double a, b;
+    fold_chunk<true>(g.nblk, c, partial, e0, cfold, red, &a, &b);
+    if (tid < cfold && e < c) {
+      float mu_f, is_f;
+      bn_fwd_channel(a, b, g.n, ff, e, blockIdx.x == 0, &mu_f, &is_f);
+      sh_mean[e] = mu_f; sh_is[e] = is_f;
+      sh_gamma[e] = gamma ? gamma[e] : 1.f;
+      sh_beta[e] = beta ? beta[e] : 0.f;
+    }
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && tid == 0 && ff.running_mean && ff.num_batches_tracked) *ff.num_batches_tracked += 1;
+  const int cv = c / V;
+  for (long long u = static_cast<long long>(blockIdx.x) * 256 + tid; u < units; u += static_cast<long long>(gridDim.x) * 256) {
+    const int col = static_cast<int>(u % cv) * V;
+    Vec<V> xv, rv, o;
+    xv.load(x + u * V, 0, 0);
+    if (residual) rv.load(residual + u * V, 0, 0);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const float xhat = (xv.v[i] - sh_mean[col + i]) * sh_is[col + i];
+      float t = xhat * sh_gamma[col + i] + sh_beta[col + i];
+      if (residual) t = t + rv.v[i];
+      o.v[i] = (relu && t <= 0.f) ? 0.f : t;
+    }
+    o.store(y + u * V);
+  }
+  grid_leave(counters, gridDim.x);
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void bn_one_bwd_k(const float* __restrict__ x, const float* __restrict__ dy, long long units, BnGeom g,
+                                                    double* __restrict__ partial, unsigned* __restrict__ counters, const float* __restrict__ mean,
+                                                    const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    int relu, BnBwdFin bf, float* __restrict__ dx, const float* __restrict__ mask_y,
+                                                    float* __restrict__ dz_out) {
+  __shared__ double red1[2][256 * V];
+  __shared__ float sh_mean[kBnMaxC], sh_is[kBnMaxC], sh_gamma[kBnMaxC], sh_beta[kBnMaxC], sh_c1[kBnMaxC], sh_c2[kBnMaxC];
+  one_reduce<V, true>(x, dy, g, mean, invstd, gamma, beta, relu, mask_y, partial, red1);
+  grid_arrive_and_wait(counters, gridDim.x);
+  double (*red)[256] = reinterpret_cast<double (*)[256]>(&red1[0][0]);
+  const int tid = threadIdx.x, c = g.c;
+  const int cfold = c < 256 ? c : 256;
+  for (int e0 = 0; e0 < c; e0 += cfold) {
+    const int e = e0 + tid;
+    double a, b;
+    fold_chunk<true>(g.nblk, c, partial, e0, cfold, red, &a, &b);
+    if (tid < cfold && e < c) {
+      const double n = static_cast<double>(g.n);
+      if (blockIdx.x == 0) { bf.dbeta[e] = static_cast<float>(a); bf.dgamma[e] = static_cast<float>(b); }
+      sh_c1[e] = bf.batch_stats ? static_cast<float>(a / n) : 0.f;
+      sh_c2[e] = bf.batch_stats ? static_cast<float>(b / n) : 0.f;
+      sh_mean[e] = mean[e]; sh_is[e] = invstd[e];
+      sh_gamma[e] = gamma ? gamma[e] : 1.f;
+      sh_beta[e] = beta ? beta[e] : 0.f;
+    }
+  }
+  __syncthreads();
+  const int cv = c / V;
+  for (long long u = static_cast<long long>(blockIdx.x) * 256 + tid; u < units; u += static_cast<long long>(gridDim.x) * 256) {
+    const int col = static_cast<int>(u % cv) * V;
+    Vec<V> xv, gv, mv, o, z;
+    xv.load(x + u * V, 0, 0);
+    gv.load(dy + u * V, 0, 0);
+    if (mask_y) mv.load(mask_y + u * V, 0, 0);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const float is = sh_is[col + i], ga = sh_gamma[col + i];
+      const float xhat = (xv.v[i] - sh_mean[col + i]) * is;
+      const float t = mask_y ? mv.v[i] : xhat * ga + sh_beta[col + i];
+      const float dz = (relu && !(t > 0.f)) ? 0.f : gv.v[i];
+      z.v[i] = dz;
+      o.v[i] = ga * is * (dz - sh_c1[col + i] - xhat * sh_c2[col + i]);
+    }
+    o.store(dx + u * V);
+    if (dz_out) z.store(dz_out + u * V);
+  }
+  grid_leave(counters, gridDim.x);
+}
+
+extern "C" size_t fv2p_batchnorm_one_ws_bytes(int c) {
+  Sizer s;
+  s.take<double>(static_cast<size_t>(kOneGrid) * 2 * (c > 0 ? c : 1));
+  return s.bytes();
+}
+
+// fv2p_batchnorm_forward (+ optional residual) in ONE launch.  counters: two zeroed device words the caller keeps per stream (zero again
+// when the launch ends).  Same statistics, bit for bit, as the two-launch form on the same number of partials.
+extern "C" int fv2p_batchnorm_forward_one(const float* x, int64_t n, int c, float eps, float momentum, const float* gamma, const float* beta,
+                                          int relu, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean,
+                                          float* invstd, const float* residual, float* y, void* ws, size_t ws_bytes, unsigned* counters,
+                                          fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FV2P_REQUIRE(n >= 1 && c >= 1, FV2P_EINVAL, "batchnorm_forward_one: n=%lld c=%d", static_cast<long long>(n), c);
+  FV2P_REQUIRE(x && y && mean && invstd && ws && counters, FV2P_EINVAL, "batchnorm_forward_one: null pointer");
+  FV2P_REQUIRE((running_mean == nullptr) == (running_var == nullptr), FV2P_EINVAL, "batchnorm_forward_one: running_mean and running_var come together");
+  FV2P_REQUIRE(ws_bytes >= fv2p_batchnorm_one_ws_bytes(c), FV2P_EWORKSPACE, "batchnorm_forward_one: workspace too small");
+  const bool vec = (c % 4 == 0) && aligned16(x) && aligned16(y) && (!residual || aligned16(residual));
+  BnGeom g;
+  FV2P_REQUIRE(bn_geom(n, c, vec, &g, one_grid(c)) == 0, FV2P_ELIMIT, "batchnorm: c=%d exceeds %d", c, vec ? kBnMaxC : 256);
+  Carver cv(ws, ws_bytes);
+  double* partial = cv.take<double>(static_cast<size_t>(kOneGrid) * 2 * c);
+  BnFwdFin ff{mean, invstd, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), momentum, eps};
+  const long long units = n * c / (vec ? 4 : 1);
+  if (vec) hipLaunchKernelGGL((bn_one_fwd_k<4>), dim3(g.nblk), dim3(256), 0, stream, x, units, g, partial, counters, ff, gamma, beta, relu, y, residual);
+  else hipLaunchKernelGGL((bn_one_fwd_k<1>), dim3(g.nblk), dim3(256), 0, stream, x, units, g, partial, counters, ff, gamma, beta, relu, y, residual);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
+// fv2p_batchnorm_backward / _backward_res in ONE launch: mask_y (NULL = recompute the ReLU mask from x) and dz_out (NULL = not wanted) as
+// in fv2p_batchnorm_backward_res.
+extern "C" int fv2p_batchnorm_backward_one(const float* x, const float* dy, int64_t n, int c, const float* mean, const float* invstd,
+                                           const float* gamma, const float* beta, int relu, int batch_stats, const float* mask_y, float* dx,
+                                           float* dz_out, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, unsigned* counters,
+                                           fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FV2P_REQUIRE(n >= 1 && c >= 1, FV2P_EINVAL, "batchnorm_backward_one: n=%lld c=%d", static_cast<long long>(n), c);
+  FV2P_REQUIRE(x && dy && mean && invstd && dx && dgamma && dbeta && ws && counters, FV2P_EINVAL, "batchnorm_backward_one: null pointer");
+  FV2P_REQUIRE(ws_bytes >= fv2p_batchnorm_one_ws_bytes(c), FV2P_EWORKSPACE, "batchnorm_backward_one: workspace too small");
+  const bool vec = (c % 4 == 0) && aligned16(x) && aligned16(dy) && aligned16(dx) && (!mask_y || aligned16(mask_y)) && (!dz_out || aligned16(dz_out));
+  BnGeom g;
+  FV2P_REQUIRE(bn_geom(n, c, vec, &g, one_grid(c)) == 0, FV2P_ELIMIT, "batchnorm: c=%d exceeds %d", c, vec ? kBnMaxC : 256);
+  Carver cv(ws, ws_bytes);
+  double* partial = cv.take<double>(static_cast<size_t>(kOneGrid) * 2 * c);
+  BnBwdFin bf{dgamma, dbeta, nullptr, batch_stats};
+  const long long units = n * c / (vec ? 4 : 1);
+  if (vec) hipLaunchKernelGGL((bn_one_bwd_k<4>), dim3(g.nblk), dim3(256), 0, stream, x, dy, units, g, partial, counters, mean, invstd, gamma, beta, relu, bf, dx, mask_y, dz_out);
+  else hipLaunchKernelGGL((bn_one_bwd_k<1>), dim3(g.nblk), dim3(256), 0, stream, x, dy, units, g, partial, counters, mean, invstd, gamma, beta, relu, bf, dx, mask_y, dz_out);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}

@@ -140,7 +140,10 @@ __device__ __forceinline__ int block_excl_scan_256(int v, int* lds_wave /*[4]*/,
   return base + incl - v;
 }
 
-constexpr int kStatSlots = 64;   // accumulator rows of the conv-epilogue BatchNorm statistics = partials the BatchNorm apply kernels fold
+// accumulator rows of the conv-epilogue BatchNorm statistics = partials that are folded afterwards.  64 until round 5; 16 since the conv
+// launch's last workgroup folds and clears them in its own tail (conv_stats_done): every slot it reads and zeroes lengthens the launch
+// (64 slots: +7 us per conv at 64 / 128 columns), while 4 x more fp64 atomics per address (~60 of ~10 ns) cost nothing measurable.
+constexpr int kStatSlots = 16;
 
 int bn_column_sums(const float* x, int64_t n, int c, double* stats, hipStream_t stream);   // batchnorm.hip
 int bn_backward_sums(const float* x, const float* dy, int64_t n, int c, const float* mean, const float* invstd, const float* gamma,

@@ -127,6 +127,7 @@ __device__ __forceinline__ void tile_stats(const ConvArgs& a, const float (&vals
 // scratch: kStatsDoneLds bytes of the kernel's DYNAMIC LDS that nothing else uses any more (no static LDS here: the K-split tile fills a
 // CU's 160 KB with two workgroups to within 768 bytes).
 constexpr size_t kStatsDoneLds = 2 * 256 * sizeof(double) + 16;
+constexpr unsigned kFinSubs = 64, kFinStride = 32;   // fin_counter: [0] the top word, [(1 + s) * kFinStride] word s; fv2p_sparse_conv_fin_counter_words() of them
 __device__ __forceinline__ void conv_stats_done(const ConvArgs& a, void* scratch) {
   if (!a.fin_counter) return;   // uniform
   double (*s_red)[256] = reinterpret_cast<double (*)[256]>(scratch);
@@ -134,8 +135,18 @@ __device__ __forceinline__ void conv_stats_done(const ConvArgs& a, void* scratch
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();   // (also: every wave is done with whatever the scratch region held)
   if (threadIdx.x == 0) {
-    const unsigned total = gridDim.x * gridDim.y;
-    s_last = __hip_atomic_fetch_add(a.fin_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == total - 1u ? 1u : 0u;
+    // Two levels: 488 workgroups of a K-split launch finish within a microsecond of each other, and 488 atomics on ONE word take 5 us
+    // (10 ns each at the memory side, tools/ubench/atomic_rate.hip); on 64 words 128 bytes apart 0.1 us.  Workgroup b counts itself in on
+    // word b % 64; whoever completes a word counts that word in on the top word; whoever completes the top word is last.
+    const unsigned total = gridDim.x * gridDim.y, bid = blockIdx.x + gridDim.x * blockIdx.y;
+    const unsigned sub = bid % kFinSubs, expect = (total - sub + kFinSubs - 1) / kFinSubs, subs = total < kFinSubs ? total : kFinSubs;
+    unsigned* word = a.fin_counter + (1 + sub) * kFinStride;
+    unsigned last = 0u;
+    if (__hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expect - 1u) {
+      __hip_atomic_store(word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = __hip_atomic_fetch_add(a.fin_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == subs - 1u ? 1u : 0u;
+    }
+    s_last = last;
   }
   __syncthreads();
   if (!s_last || threadIdx.x >= 256) return;   // (a 1024-thread workgroup folds with its first four waves)
@@ -144,7 +155,32 @@ __device__ __forceinline__ void conv_stats_done(const ConvArgs& a, void* scratch
   for (int e0 = 0; e0 < c; e0 += cfold) {
     const int e = e0 + tid;
     double sa, sb;
-    fold_chunk<true>(kStatSlots, c, a.fin_stats, e0, cfold, s_red, &sa, &sb, ld);
+    {
+      // fold_chunk's sums in fold_chunk's order, but with all of a thread's loads in flight at once: an agent-scope load goes past the L2
+      // to the fabric (~2 us), and eight-deep batches of dependent adds (fold_chunk's loop) made this tail 25 us at 128 columns
+      const int L = 256 / cfold, ee = e0 + tid % cfold, lane_q = tid / cfold;
+      constexpr int DEPTH = 16;
+      double pa = 0.0, pb = 0.0;
+      const bool live = lane_q < L && ee < c;
+      for (int q0 = lane_q; q0 < kStatSlots; q0 += L * DEPTH) {   // uniform trip count
+        double va[DEPTH], vb[DEPTH];
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) {
+          const int q = q0 + L * i;
+          const bool on = live && q < kStatSlots;
+          va[i] = on ? stat_load<true>(a.fin_stats + (static_cast<long long>(q) * 2 + 0) * ld + ee) : 0.0;
+          vb[i] = on ? stat_load<true>(a.fin_stats + (static_cast<long long>(q) * 2 + 1) * ld + ee) : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) { pa += va[i]; pb += vb[i]; }   // (x + 0.0 == x: past-the-end slots change nothing)
+      }
+      __syncthreads();
+      s_red[0][tid] = pa; s_red[1][tid] = pb;
+      __syncthreads();
+      sa = 0.0; sb = 0.0;
+      if (tid < cfold)
+        for (int q = 0; q < L; ++q) { sa += s_red[0][q * cfold + tid]; sb += s_red[1][q * cfold + tid]; }
+    }
     if (tid < cfold && e < c) {
       if (a.bn_x == nullptr) {
         float mu, is;
@@ -981,11 +1017,10 @@ __global__ __launch_bounds__(256) void conv_rows_thin(ConvArgs a) {
 // fragment order, and the 16 waves then walk 16-row groups on their own (conv_rows_thin's loop with the weight fragment read from LDS:
 // table entries up front, rows two offsets ahead, MFMAs skipped where no row has a neighbour, no barrier after the prologue).  Workgroup
 // b takes the b-th of gridDim.x contiguous ranges of groups, XCD-major.
-// PRE: BatchNorm (+ReLU) of the source rows applied on the gather (ConvArgs::pre_*).
-template <int CINP, int NB, bool WT, int KVOL, bool PRE = false>
+template <int CINP, int NB, bool WT, int KVOL>
 __global__ __launch_bounds__(1024) void conv_rows_res(ConvArgs a, int groups_per_wg) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [k][j][nb][lane][4]: B fragment of lane (n, g), k-step (j, t), tile nb at t
-  constexpr int J = CINP / 16, D = (PRE && NB > 1) ? 1 : 2, NST = D + 1, WSZ = CINP * NB * 16;   // (PRE at 32 -> 32: rows one offset ahead instead of two, or the 128 registers of a 16-wave workgroup spill)
+  constexpr int J = CINP / 16, D = 2, NST = D + 1, WSZ = CINP * NB * 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
   for (int e = threadIdx.x; e < KVOL * WSZ; e += 1024) {
     const int k = e / WSZ, q = e % WSZ;
@@ -995,24 +1030,6 @@ __global__ __launch_bounds__(1024) void conv_rows_res(ConvArgs a, int groups_per
     lds[k * WSZ + ((((c >> 4) * NB + (col >> 4)) * 64) + ((c >> 2) & 3) * 16 + (col & 15)) * 4 + (c & 3)] = v;
   }
   __syncthreads();
-  // PRE: the four parameter vectors of the 32 source channels sit behind the weights in LDS ([4][CINP] floats) and are read where a row
-  // piece is normalised (volatile: held in registers across the 27 offsets they push this 128-register kernel into scratch)
-  float* pre_lds = lds + KVOL * WSZ;
-  if constexpr (PRE) {
-    for (int e = threadIdx.x; e < 4 * CINP; e += 1024) {
-      const int which = e / CINP, ch = e % CINP;
-      const float* src = which == 0 ? a.pre_mean : which == 1 ? a.pre_invstd : which == 2 ? a.pre_gamma : a.pre_beta;
-      pre_lds[e] = src ? src[ch] : (which == 2 ? 1.f : 0.f);
-    }
-    __syncthreads();
-  }
-  auto pre_piece = [&](int j, float4 xv, bool valid) -> float4 {
-    PreNorm4 p;
-    const volatile f32x4* q = reinterpret_cast<const volatile f32x4*>(pre_lds + 16 * j + 4 * g);
-    p.mean = q[0]; p.is = q[CINP / 4]; p.ga = q[2 * CINP / 4]; p.be = q[3 * CINP / 4];
-    const f32x4 v = prenorm_apply(p, f32x4{xv.x, xv.y, xv.z, xv.w}, valid, a.pre_relu);
-    return make_float4(v[0], v[1], v[2], v[3]);
-  };
   const int groups = (a.n_dst + 15) / 16;
   const int first = xcd_major_tile(blockIdx.x, gridDim.x) * groups_per_wg;
   const int last = min(first + groups_per_wg, groups);
@@ -1022,9 +1039,9 @@ __global__ __launch_bounds__(1024) void conv_rows_res(ConvArgs a, int groups_per
     int tv[KVOL];
 #pragma unroll
     for (int k = 0; k < KVOL; ++k) tv[k] = row_ok ? a.tab[static_cast<long long>(a.flip ? (KVOL - 1 - k) : k) * a.n_dst + my_row] : -1;
-    unsigned live = 0, mine = 0;   // bit k: some row of the group / this lane's row has a neighbour at offset k
+    unsigned live = 0;   // bit k: some row of the group has a neighbour at offset k
 #pragma unroll
-    for (int k = 0; k < KVOL; ++k) { live |= (__ballot(tv[k] >= 0) != 0ull ? 1u : 0u) << k; mine |= (tv[k] >= 0 ? 1u : 0u) << k; }
+    for (int k = 0; k < KVOL; ++k) live |= (__ballot(tv[k] >= 0) != 0ull ? 1u : 0u) << k;
     float4 x[NST][J];
     auto request = [&](auto k_, float4 (&dst)[J]) {
       constexpr int k = decltype(k_)::value;
@@ -1054,8 +1071,7 @@ __global__ __launch_bounds__(1024) void conv_rows_res(ConvArgs a, int groups_per
       if ((live >> k) & 1u) {
 #pragma unroll
         for (int j = 0; j < J; ++j) {
-          float4 xv = x[k % NST][j];
-          if constexpr (PRE) xv = pre_piece(j, xv, (mine >> k) & 1u);
+          const float4 xv = x[k % NST][j];
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.x, bv[k & 1][j][nb].x, acc[nb], 0, 0, 0);
 #pragma unroll
@@ -2151,13 +2167,9 @@ static int launch_vec(const ConvArgs& a, hipStream_t s) {   // 0: launched (or c
         const int groups = static_cast<int>(ceil_div(a.n_dst, 16));
         const int wgs = std::min(groups, conv_cu_count());
         const int per = static_cast<int>(ceil_div(groups, wgs));
-        if (a.pre_mean) {
-          if constexpr (!WT) {
-            static bool once_pre = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_res<CINP, NB, WT, 27, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
-            if (once_pre) { FV2P_LAUNCH((conv_rows_res<CINP, NB, WT, 27, true>), dim3(static_cast<unsigned>(ceil_div(groups, per))), dim3(1024), res_lds + 4 * CINP * sizeof(float), s, a, per); return 0; }
-          }
-          return 1;
-        }
+        // (no PRE form here: normalising the gathered rows pushed this 128-register, 16-wave kernel into scratch - 66.8 against 47.1 us
+        //  at 39 k rows, more than the 5.6 us apply launch it saves; 32-channel consumers read materialised rows)
+        if (a.pre_mean) return 1;
         FV2P_LAUNCH((conv_rows_res<CINP, NB, WT, 27>), dim3(static_cast<unsigned>(ceil_div(groups, per))), dim3(1024), res_lds, s, a, per);
         return 0;
       }
@@ -2554,6 +2566,7 @@ extern "C" int fv2p_sparse_conv_rows_perm(const float* src, int64_t n_src, int c
 }
 
 extern "C" int fv2p_sparse_conv_stat_slots(void) { return kStatSlots; }
+extern "C" int fv2p_sparse_conv_fin_counter_words(void) { return static_cast<int>((1 + kFinSubs) * kFinStride); }
 extern "C" int64_t fv2p_conv_plan_ints(int64_t n_dst) {
   if (n_dst <= 0) return 0;
   return plan_level_offset(plan_levels(n_dst));
@@ -2655,7 +2668,7 @@ extern "C" int fv2p_sparse_conv_rows_bnfin(const float* src, int64_t n_src, int 
 }
 
 // 1 when fv2p_sparse_conv_rows_bnfin can normalise the source rows of a conv of this shape on the gather (the kernel the dispatcher would
-// choose has the PRE form: conv_rows_thin 16 -> 16, conv_rows_res 32 -> <= 32, conv_rows_ksplit 64 / 128 source channels), else 0.
+// choose has the PRE form: conv_rows_thin 16 -> 16, conv_rows_ksplit 64 / 128 source channels), else 0.
 extern "C" int fv2p_sparse_conv_prenorm_supported(int c_src, int c_dst, int kvol, int64_t n_dst, int flip_k, int transpose_w) {
   if (c_src < 1 || c_dst < 1 || kvol < 1 || n_dst < 1 || transpose_w || c_src > 128 || c_dst > 128 || (c_src & 3)) return 0;
   ConvExtra ex;

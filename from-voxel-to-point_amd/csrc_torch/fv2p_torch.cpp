@@ -113,6 +113,16 @@ static bool fuse_bn_stats() {
 void set_bn_epilogue(bool on) { g_bn_epilogue = on ? 1 : 0; }
 
 
+// two zeroed device words per (device, stream) for the one-launch BatchNorm passes (fv2p_batchnorm_forward_one / _backward_one);
+// defined with the round-6 state further down
+unsigned* one_counters(const at::Tensor& like, void* stream);
+static int g_bn_one = -1;   // FV2P_BN_ONE=0 / set_bn_one(false): the two-launch passes (tests compare the two)
+bool bn_one() {
+  if (g_bn_one < 0) { const char* e = std::getenv("FV2P_BN_ONE"); g_bn_one = !(e && e[0] == '0'); }
+  return g_bn_one != 0;
+}
+void set_bn_one(bool on) { g_bn_one = on ? 1 : 0; }
+
 // ---- BatchNorm1d (+ReLU) on [N, C] ---------------------------------------------------------------------------------------
 struct BnReluFn : public torch::autograd::Function<BnReluFn> {
   static at::Tensor forward(AutogradContext* ctx, const at::Tensor& x_, const c10::optional<at::Tensor>& weight, const c10::optional<at::Tensor>& bias,
@@ -143,6 +153,13 @@ struct BnReluFn : public torch::autograd::Function<BnReluFn> {
                                            y.data_ptr<float>(), stats->data_ptr<double>(),
                                            (zero_next.has_value() && zero_next->defined()) ? zero_next->data_ptr<double>() : nullptr, zero_count, stream),
               "fv2p_batchnorm_forward_stats");
+      } else if (bn_one() && fv2p_batchnorm_one_pays(n, static_cast<int>(c), 0)) {   // reduce, grid barrier, apply: one launch
+        at::Tensor ws = workspace(fv2p_batchnorm_one_ws_bytes(static_cast<int>(c)), x, stream);
+        check(fv2p_batchnorm_forward_one(x.data_ptr<float>(), n, static_cast<int>(c), static_cast<float>(eps), static_cast<float>(momentum), gamma, beta,
+                                         relu ? 1 : 0, track ? running_mean->data_ptr<float>() : nullptr, track ? running_var->data_ptr<float>() : nullptr,
+                                         nbt, mean.data_ptr<float>(), invstd.data_ptr<float>(), nullptr, y.data_ptr<float>(), ws.data_ptr(),
+                                         static_cast<size_t>(ws.numel()), one_counters(x, stream), stream),
+              "fv2p_batchnorm_forward_one");
       } else {
       at::Tensor ws = workspace(fv2p_batchnorm_ws_bytes(n, static_cast<int>(c)), x, stream);
       check(fv2p_batchnorm_forward(x.data_ptr<float>(), n, static_cast<int>(c), static_cast<float>(eps), static_cast<float>(momentum), gamma, beta,
@@ -199,12 +216,22 @@ struct BnReluFn : public torch::autograd::Function<BnReluFn> {
                 at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
       }
     }
+    if (bn_one() && fv2p_batchnorm_one_pays(n, static_cast<int>(c), 1)) {
+      at::Tensor ws = workspace(fv2p_batchnorm_one_ws_bytes(static_cast<int>(c)), x, stream);
+      check(fv2p_batchnorm_backward_one(x.data_ptr<float>(), dy.data_ptr<float>(), n, static_cast<int>(c), mean.data_ptr<float>(), invstd.data_ptr<float>(),
+                                        weight.defined() ? weight.data_ptr<float>() : nullptr, bias.defined() ? bias.data_ptr<float>() : nullptr,
+                                        ctx->saved_data["relu"].toBool() ? 1 : 0, ctx->saved_data["batch_stats"].toBool() ? 1 : 0, nullptr, dx.data_ptr<float>(),
+                                        nullptr, dpar[0].data_ptr<float>(), dpar[1].data_ptr<float>(), ws.data_ptr(), static_cast<size_t>(ws.numel()),
+                                        one_counters(x, stream), stream),
+            "fv2p_batchnorm_backward_one");
+    } else {
     at::Tensor ws = workspace(fv2p_batchnorm_ws_bytes(n, static_cast<int>(c)), x, stream);
     check(fv2p_batchnorm_backward(x.data_ptr<float>(), dy.data_ptr<float>(), n, static_cast<int>(c), mean.data_ptr<float>(), invstd.data_ptr<float>(),
                                   weight.defined() ? weight.data_ptr<float>() : nullptr, bias.defined() ? bias.data_ptr<float>() : nullptr,
                                   ctx->saved_data["relu"].toBool() ? 1 : 0, ctx->saved_data["batch_stats"].toBool() ? 1 : 0, dx.data_ptr<float>(),
                                   dpar[0].data_ptr<float>(), dpar[1].data_ptr<float>(), ws.data_ptr(), static_cast<size_t>(ws.numel()), stream),
           "fv2p_batchnorm_backward");
+    }
     return {dx, weight.defined() ? dpar[0] : at::Tensor(), bias.defined() ? dpar[1] : at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
             at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
   }
@@ -475,10 +502,13 @@ FinState& fin_state(const at::Tensor& like, void* stream) {
     const int64_t cap = static_cast<int64_t>(fv2p_sparse_conv_stat_slots()) * 2 * 1024;
     f.stats_f = at::zeros({cap}, like.options().dtype(at::kDouble));
     f.stats_b = at::zeros({cap}, like.options().dtype(at::kDouble));
-    f.counter = at::zeros({4}, like.options().dtype(at::kInt));
+    f.counter = at::zeros({2 * static_cast<int64_t>(fv2p_sparse_conv_fin_counter_words()) + 4}, like.options().dtype(at::kInt));   // forward | backward | 4 words of the one-launch BatchNorms
     it = pool.emplace(key, std::move(f)).first;
   }
   return it->second;
+}
+unsigned* one_counters(const at::Tensor& like, void* stream) {
+  return reinterpret_cast<unsigned*>(fin_state(like, stream).counter.data_ptr<int>()) + 2 * fv2p_sparse_conv_fin_counter_words();
 }
 static int g_bn_fold = -1;   // FV2P_BN_FOLD=0 / set_bn_fold(false): the Python layer keeps the round-5 arrangement (tests compare the two)
 bool bn_fold() {
@@ -528,7 +558,13 @@ struct BnApplyFn : public torch::autograd::Function<BnApplyFn> {
     if (ctx->saved_data["residual"].toBool()) {   // out = relu(bn(x) + identity): mask from out, dz is the identity branch's gradient
       at::Tensor dz = at::empty_like(x), dpar = at::empty({2, c}, x.options());
       at::Tensor ws = workspace(fv2p_batchnorm_ws_bytes(n, static_cast<int>(c)), x, stream);
-      if (relu) {
+      if (relu && bn_one() && fv2p_batchnorm_one_pays(n, static_cast<int>(c), 1)) {
+        at::Tensor ws1 = workspace(fv2p_batchnorm_one_ws_bytes(static_cast<int>(c)), x, stream);
+        check(fv2p_batchnorm_backward_one(x.data_ptr<float>(), dy.data_ptr<float>(), n, static_cast<int>(c), mean, invstd, fptr(weight), fptr(bias), 1,
+                                          batch_stats ? 1 : 0, out.data_ptr<float>(), dx.data_ptr<float>(), dz.data_ptr<float>(), dpar[0].data_ptr<float>(),
+                                          dpar[1].data_ptr<float>(), ws1.data_ptr(), static_cast<size_t>(ws1.numel()), one_counters(x, stream), stream),
+              "fv2p_batchnorm_backward_one");
+      } else if (relu) {
         check(fv2p_batchnorm_backward_res(x.data_ptr<float>(), out.data_ptr<float>(), dy.data_ptr<float>(), n, static_cast<int>(c), mean, invstd, fptr(weight),
                                           fptr(bias), batch_stats ? 1 : 0, dx.data_ptr<float>(), dz.data_ptr<float>(), dpar[0].data_ptr<float>(),
                                           dpar[1].data_ptr<float>(), ws.data_ptr(), static_cast<size_t>(ws.numel()), stream),
@@ -557,11 +593,19 @@ struct BnApplyFn : public torch::autograd::Function<BnApplyFn> {
       }
     }
     at::Tensor dpar = at::empty({2, c}, x.options());
-    at::Tensor ws = workspace(fv2p_batchnorm_ws_bytes(n, static_cast<int>(c)), x, stream);
-    check(fv2p_batchnorm_backward(x.data_ptr<float>(), dy.data_ptr<float>(), n, static_cast<int>(c), mean, invstd, fptr(weight), fptr(bias), relu ? 1 : 0,
-                                  batch_stats ? 1 : 0, dx.data_ptr<float>(), dpar[0].data_ptr<float>(), dpar[1].data_ptr<float>(), ws.data_ptr(),
-                                  static_cast<size_t>(ws.numel()), stream),
-          "fv2p_batchnorm_backward");
+    if (bn_one() && fv2p_batchnorm_one_pays(n, static_cast<int>(c), 1)) {
+      at::Tensor ws1 = workspace(fv2p_batchnorm_one_ws_bytes(static_cast<int>(c)), x, stream);
+      check(fv2p_batchnorm_backward_one(x.data_ptr<float>(), dy.data_ptr<float>(), n, static_cast<int>(c), mean, invstd, fptr(weight), fptr(bias), relu ? 1 : 0,
+                                        batch_stats ? 1 : 0, nullptr, dx.data_ptr<float>(), nullptr, dpar[0].data_ptr<float>(), dpar[1].data_ptr<float>(),
+                                        ws1.data_ptr(), static_cast<size_t>(ws1.numel()), one_counters(x, stream), stream),
+            "fv2p_batchnorm_backward_one");
+    } else {
+      at::Tensor ws = workspace(fv2p_batchnorm_ws_bytes(n, static_cast<int>(c)), x, stream);
+      check(fv2p_batchnorm_backward(x.data_ptr<float>(), dy.data_ptr<float>(), n, static_cast<int>(c), mean, invstd, fptr(weight), fptr(bias), relu ? 1 : 0,
+                                    batch_stats ? 1 : 0, dx.data_ptr<float>(), dpar[0].data_ptr<float>(), dpar[1].data_ptr<float>(), ws.data_ptr(),
+                                    static_cast<size_t>(ws.numel()), stream),
+            "fv2p_batchnorm_backward");
+    }
     return {dx, at::Tensor(), weight.defined() ? dpar[0] : at::Tensor(), bias.defined() ? dpar[1] : at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
   }
 };
@@ -660,7 +704,7 @@ struct ConvFinFn : public torch::autograd::Function<ConvFinFn> {
         transpose_w = 0;
       }
       const float* w_bwd = wt.defined() ? wt.data_ptr<float>() : weight.data_ptr<float>();
-      unsigned* counter = reinterpret_cast<unsigned*>(fs.counter.data_ptr<int>()) + 1;
+      unsigned* counter = reinterpret_cast<unsigned*>(fs.counter.data_ptr<int>()) + fv2p_sparse_conv_fin_counter_words();
       if (pre) {
         // d(relu(bn(y_src))) by the backward-data conv, the BatchNorm's backward sums from its epilogue, finalised by its last workgroup;
         // then the BatchNorm's own backward pass in place: din becomes d(y_src)
@@ -960,5 +1004,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("prenorm_supported", &prenorm_supported, "the conv kernel of this shape can normalise its source rows on the gather");
   m.def("set_bn_fold", &set_bn_fold, "round-6 arrangement of conv / BatchNorm / residual blocks on (default) or off (the round-5 one)");
   m.def("bn_fold", &bn_fold);
+  m.def("set_bn_one", &set_bn_one, "BatchNorm passes without conv-epilogue sums as one launch each (default) or as reduce + apply");
+  m.def("bn_one", &bn_one);
   m.def("sparse_conv_bn_relu", &sparse_conv_bn_relu, "sparse conv -> BatchNorm1d (-> ReLU) with autograd, one call per backbone block");
 }

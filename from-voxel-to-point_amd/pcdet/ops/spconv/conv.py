@@ -80,7 +80,7 @@ class SparseConvolution(SparseModule):
         """`_post` (internal, set by SparseSequential): the (BatchNorm1d, ReLU-or-None) pair that follows this conv; when
         the compiled binding can run conv -> BN -> ReLU in one call the returned tensor carries `_fv2p_post_done`."""
         assert isinstance(input, SparseConvTensor)
-        if _post is not None and not self.fused_bn:
+        if _post is not None and not self.fused_bn and FOLD_SEQUENTIAL:
             folded = conv_bn_fold(self, input, _post[0], _post[1])
             if folded is not None:
                 folded._fv2p_post_done = True
@@ -177,6 +177,15 @@ def _conv_bn_relu(self, features, rb, n_out, post, weight=None):
 
 
 SparseConvolution._conv_bn_relu = _conv_bn_relu
+
+
+# conv -> BatchNorm1d -> ReLU inside a SparseSequential (post_act_block) through conv_bn_fold as well?  Measured (plain VoxelBackBone8x,
+# batch 4, profiles/r06_*): NO - a conv that finalises its statistics itself ends 4.6 us later (its waves wait for their fp64 atomics,
+# the last workgroup folds and clears the slots), the apply launch it feeds is only 2.2 us shorter (5.4 against 7.6 us): 1.79 against
+# 1.68 ms per step.  The residual blocks are where the arrangement pays (no bias add, no separate reduce pass, no add / ReLU launches, no
+# relu(bn1(y1)) tensor: VoxelResBackBone8x 4.01 against 4.47 ms per step), so only they use it (fv2p_harness/backbone.py); the flag keeps
+# the path testable (tests/test_bn_fold_gpu.py).
+FOLD_SEQUENTIAL = False
 
 
 def fold_enabled():

@@ -192,7 +192,8 @@ int fv2p_sparse_conv_rows_bnbwd(const float* src, int64_t n_src, int c_src, cons
  * residual block, conv1 -> bn1 -> relu -> conv2 (spconv_backbone.py:47-68).  Here
  *   fv2p_sparse_conv_rows_bnfin     = fv2p_sparse_conv_rows_stats whose LAST workgroup folds the slots itself: when the launch ends mean /
  *                                     invstd [c_dst] (and the running statistics, num_batches_tracked) are final, the slots zero again and
- *                                     *counter (a zeroed device word the caller keeps per stream) zero again - BatchNorm apply kernels
+ *                                     counter[] (fv2p_sparse_conv_fin_counter_words() zeroed device words the caller keeps per stream
+ *                                     and direction) zero again - BatchNorm apply kernels
  *                                     (fv2p_batchnorm_apply_res) and consumer convs read 2 - 4 floats per column instead of folding
  *                                     64 slots in every workgroup.  stats == NULL: no statistics.
  *                                     pre_mean / pre_invstd / pre_gamma / pre_beta [c_src] (NULL = off): every gathered source row passes
@@ -210,6 +211,7 @@ int fv2p_sparse_conv_rows_bnfin(const float* src, int64_t n_src, int c_src, cons
                                 const float* pre_mean, const float* pre_invstd, const float* pre_gamma, const float* pre_beta,
                                 int pre_relu, fv2p_stream_t stream);
 int fv2p_sparse_conv_prenorm_supported(int c_src, int c_dst, int kvol, int64_t n_dst, int flip_k, int transpose_w);
+int fv2p_sparse_conv_fin_counter_words(void);
 int fv2p_sparse_conv_rows_bnbwd_fin(const float* src, int64_t n_src, int c_src, const float* weight, int kvol, const int* tab,
                                     int64_t n_dst, int c_dst, int flip_k, int transpose_w, float* dst, const float* bn_x,
                                     const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_beta,
@@ -598,6 +600,19 @@ int fv2p_batchnorm_backward_fin(const float* x, const float* dy, int64_t n, int 
 int fv2p_batchnorm_backward_res(const float* x, const float* out, const float* dout, int64_t n, int c, const float* mean,
                                 const float* invstd, const float* gamma, const float* beta, int batch_stats, float* dx,
                                 float* dz, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, fv2p_stream_t stream);
+/* round 6: both passes of a BatchNorm whose sums no conv epilogue takes, as ONE launch each (reduce, grid barrier over <= 128 resident
+ * workgroups, apply).  counters: two zeroed device words kept by the caller per stream (zero again when the launch ends); ws as
+ * fv2p_batchnorm_one_ws_bytes(c).  residual / mask_y / dz_out as in fv2p_batchnorm_apply_res / _backward_res (NULL = plain layer). */
+size_t fv2p_batchnorm_one_ws_bytes(int c);
+int fv2p_batchnorm_one_pays(int64_t n, int c, int backward);   /* 1: the one-launch pass is the faster one at this size (measured: tools/bn_time.py) */
+int fv2p_batchnorm_forward_one(const float* x, int64_t n, int c, float eps, float momentum, const float* gamma, const float* beta,
+                               int relu, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean,
+                               float* invstd, const float* residual, float* y, void* ws, size_t ws_bytes, unsigned* counters,
+                               fv2p_stream_t stream);
+int fv2p_batchnorm_backward_one(const float* x, const float* dy, int64_t n, int c, const float* mean, const float* invstd,
+                                const float* gamma, const float* beta, int relu, int batch_stats, const float* mask_y, float* dx,
+                                float* dz_out, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, unsigned* counters,
+                                fv2p_stream_t stream);
 int fv2p_batchnorm_apply(const float* x, int64_t n, int c, const float* mean, const float* invstd,
                          const float* gamma, const float* beta, int relu, float* y, fv2p_stream_t stream);
 int fv2p_batchnorm_backward(const float* x, const float* dy, int64_t n, int c, const float* mean,

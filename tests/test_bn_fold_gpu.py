@@ -111,6 +111,9 @@ def test_source_batchnorm_on_the_gather(gpu, cin, cout, n, relu):
     e = ext()
     batch, shape = 2, [9, 24, 22] if n < 10000 else [9, 60, 60]
     ind, feats, x = make_input(cin * 5 + cout + n, batch, shape, n, cin, gpu)
+    if cin == 32:   # conv_rows_res has no such form (it spilled: 66.8 against 47.1 us): 32-channel consumers read materialised rows
+        assert not e.prenorm_supported(cin, cout, 27, ind.shape[0], 1)
+        return
     assert e.prenorm_supported(cin, cout, 27, ind.shape[0], 1), "this shape is one the residual blocks of the backbones use"
     conv = spconv.SubMConv3d(cin, cout, 3, padding=1, bias=False, indice_key="k").to(gpu)
     rb, tab_f, flip_f, tab_b, flip_b = subm_tables(x, conv)
@@ -234,8 +237,11 @@ def test_post_act_block_and_eval_mode(gpu):
                                   spconv.SubMConv3d(64, 64, 3, padding=1, bias=False, indice_key="c"), nn.BatchNorm1d(64, eps=1e-3, momentum=0.01), nn.ReLU()).to(gpu)
     state = {k: v.clone() for k, v in net.state_dict().items()}
 
+    from pcdet.ops.spconv import conv as conv_mod
+
     def run(fold, train):
         spconv.set_bn_fold(fold)
+        conv_mod.FOLD_SEQUENTIAL = fold      # (off by default: only the residual blocks use the arrangement, pcdet/ops/spconv/conv.py)
         net.load_state_dict(state)
         net.zero_grad(set_to_none=True)
         net.train(train)
@@ -251,6 +257,7 @@ def test_post_act_block_and_eval_mode(gpu):
                 assert rel(on[2][k], off[2][k]) < 2e-5, (train, k)
     finally:
         spconv.set_bn_fold(True)
+        conv_mod.FOLD_SEQUENTIAL = False
 
 
 @pytest.mark.parametrize("c,n", [(16, 3000), (64, 777), (128, 5000), (20, 100)])
@@ -276,3 +283,49 @@ def test_residual_tail_forward_backward(gpu, c, n):
         assert rel(out, o) < 1e-5
         for a, b in ((xs, xh), (rs, rh), (gs, gh), (bs, bh)):
             assert rel(a.grad, b.grad) < 1e-5, relu
+
+
+@pytest.mark.parametrize("n,c", [(49152, 128), (49152, 64), (35000, 16), (777, 32), (2, 5), (100000, 20), (300, 256)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_one_launch_batchnorm_passes(gpu, n, c, relu):
+    """BatchNorm1d (+ReLU) whose sums no conv epilogue takes (the decoder's Linear -> BatchNorm1d -> ReLU rows): reduce, grid barrier and
+    apply in ONE launch per direction (fv2p_batchnorm_forward_one / _backward_one) against the two-launch passes (1e-6 forward, 1e-5
+    gradients: the same arithmetic per element, the sums taken over <= 128 instead of <= 64 partials) and against torch in float64
+    (1e-5); running statistics alike; twenty back-to-back calls give the same bits (the barrier's counters are reset by the launch)."""
+    e = ext()
+    from pcdet.ops.spconv.norm import batch_norm_relu
+    torch.manual_seed(n + c)
+    x0 = torch.randn(n, c, device=gpu) * 1.5 + 0.3
+    g = torch.randn(n, c, device=gpu)
+
+    def run(one):
+        e.set_bn_one(one)
+        torch.manual_seed(1)
+        bn = nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(gpu)
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.normal_(0, 0.2)
+        x = x0.clone().requires_grad_(True)
+        y = batch_norm_relu(bn, x, nn.ReLU() if relu else None)
+        assert y is not None
+        y.backward(g)
+        return y.detach(), x.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(), bn.running_var.clone(), bn.weight.detach().clone(), bn.bias.detach().clone()
+    try:
+        one, two = run(True), run(False)
+        for _ in range(20):
+            again = run(True)
+        assert all(torch.equal(a, b) for a, b in zip(one, again))
+    finally:
+        e.set_bn_one(True)
+    assert rel(one[0], two[0]) < 1e-6 and rel(one[4], two[4]) < 1e-6 and rel(one[5], two[5]) < 1e-6
+    for a, b in zip(one[1:4], two[1:4]):
+        assert rel(a, b) < 1e-5
+    xh = x0.cpu().double().requires_grad_(True)
+    bnh = nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).double()
+    with torch.no_grad():
+        bnh.weight.copy_(one[6].cpu().double())
+        bnh.bias.copy_(one[7].cpu().double())
+    yh = bnh(xh)
+    yh = torch.relu(yh) if relu else yh
+    yh.backward(g.cpu().double())
+    assert rel(one[0], yh) < 1e-5 and rel(one[1], xh.grad) < 1e-5 and rel(one[2], bnh.weight.grad) < 1e-5 and rel(one[3], bnh.bias.grad) < 1e-5

@@ -135,8 +135,18 @@ def test_sparse_sequential_uses_fused_pair_and_falls_back(gpu, front_end, monkey
             calls.append(post[1] is not None)
         return out
 
+    from pcdet.ops.spconv import conv as conv_mod
+    orig_fold = conv_mod.conv_bn_fold
+
+    def counting_fold(conv, x, bn, relu_module, defer=False, residual=None):   # round 6: conv (statistics finalised by its launch) + one apply launch
+        out = orig_fold(conv, x, bn, relu_module, defer, residual)
+        if out is not None:
+            calls.append(relu_module is not None)
+        return out
+
     monkeypatch.setattr(modules, "batch_norm_relu", counting)
     monkeypatch.setattr(SparseConvolution, "_conv_bn_relu", counting_block)
+    monkeypatch.setattr(conv_mod, "conv_bn_fold", counting_fold)
     y1, g1, rv1 = run(build())
     assert calls == [True]                       # the BN+ReLU pair went through the fused op
     net = build()
