@@ -167,9 +167,9 @@ def _conv_bn_relu(self, features, rb, n_out, post, weight=None):
     cin, cout = self.in_channels, self.out_channels   # forward gathers cin-channel rows, backward-data cout-channel rows
     (tab_f, flip_f), (tab_b, flip_b) = (rb.in_table(cin), rb.out_table(cout)) if self.inverse else (rb.out_table(cin), rb.in_table(cout))
     centre = (rb.kvol // 2) if (rb.subm and rb.tab_out is None and not self.inverse) else -1
-    have = rb._wpairs is not None and rb._num is not None
-    out = ext.sparse_conv_bn_relu(features, weight, tab_f, flip_f, tab_b, flip_b, n_out, centre, rb._wpairs if have else None,
-                                  rb._num if have else None, 1 if self.inverse else 0, self.bias, bn.weight, bn.bias, bn.running_mean,
+    wpairs, wnum = rb.pairs_for_wgrad(cin, cout)
+    out = ext.sparse_conv_bn_relu(features, weight, tab_f, flip_f, tab_b, flip_b, n_out, centre, wpairs,
+                                  wnum, 1 if self.inverse else 0, self.bias, bn.weight, bn.bias, bn.running_mean,
                                   bn.running_var, bn.num_batches_tracked, bn.training,
                                   -1.0 if bn.momentum is None else float(bn.momentum), float(bn.eps), relu is not None,
                                   None if self.inverse else getattr(rb, "_perm_in", None))
@@ -263,7 +263,7 @@ def conv_bn_fold(conv, x, bn, relu_module, defer=False, residual=None):
     cin, cout = conv.in_channels, conv.out_channels
     (tab_f, flip_f), (tab_b, flip_b) = rb.out_table(cin), rb.in_table(cout)
     centre = (rb.kvol // 2) if (rb.subm and rb.tab_out is None) else -1
-    have = rb._wpairs is not None and rb._num is not None
+    wpairs, wnum = rb.pairs_for_wgrad(cin, cout)
     pend = x.__dict__.get("_fv2p_pending")
     pre = (None, None, None, False, False)
     if pend is not None:
@@ -273,7 +273,7 @@ def conv_bn_fold(conv, x, bn, relu_module, defer=False, residual=None):
         else:
             features = materialise_pending(x).features
     momentum = -1.0 if bn.momentum is None else float(bn.momentum)
-    res = ext.conv_fin(features, weight, tab_f, flip_f, tab_b, flip_b, n_out, centre, rb._wpairs if have else None, rb._num if have else None, 0,
+    res = ext.conv_fin(features, weight, tab_f, flip_f, tab_b, flip_b, n_out, centre, wpairs, wnum, 0,
                        getattr(rb, "_perm_in", None), conv.bias, True, bn.running_mean, bn.running_var, bn.num_batches_tracked, bn.training,
                        momentum, float(bn.eps), *pre)
     if not res:

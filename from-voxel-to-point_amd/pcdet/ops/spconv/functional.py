@@ -124,9 +124,9 @@ def _dispatch(fn_cls):
             cin, cout = filters.shape[-2], filters.shape[-1]   # forward gathers cin-channel rows, backward-data cout-channel rows
             (tab_f, flip_f), (tab_b, flip_b) = (rb.in_table(cin), rb.out_table(cout)) if fn_cls.INVERSE else (rb.out_table(cin), rb.in_table(cout))
             centre = (rb.kvol // 2) if (rb.subm and rb.tab_out is None and not fn_cls.INVERSE) else -1
-            have = rb._wpairs is not None and rb._num is not None   # pair lists already materialised (prefetch): pair-split wgrad
+            wpairs, wnum = rb.pairs_for_wgrad(cin, cout)   # pair lists (prefetched, or built here for wide submanifold layers): pair-split wgrad
             return ext.sparse_conv(features, filters, tab_f, flip_f, tab_b, flip_b, num_activate_out, centre,
-                                   rb._wpairs if have else None, rb._num if have else None, 1 if fn_cls.INVERSE else 0,
+                                   wpairs, wnum, 1 if fn_cls.INVERSE else 0,
                                    None if fn_cls.INVERSE else getattr(rb, "_perm_in", None))
         return fn_cls.apply(features, filters, indice_pairs, indice_pair_num, num_activate_out)
 

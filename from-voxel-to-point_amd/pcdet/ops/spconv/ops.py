@@ -154,6 +154,17 @@ class Rulebook(object):
             self._num, self._wpairs = num, pairs
         return self._wpairs
 
+    def pairs_for_wgrad(self, cin, cout):
+        """(pairs, pair_num) for a conv's weight gradient, or (None, None): the table-driven weight gradient then runs.  Lists that exist
+        (an input pipeline built them with the rulebook) are used; a submanifold rulebook serving 64 / 128-channel convs in training builds
+        them on first use - two launches, ~20 us, against 131 -> 66 us per 128 -> 128 weight gradient and 4 such convs per table in the
+        residual backbone (profiles/r05_microbench_conv_kitti.txt); above 65 536 rows the table-driven form is not slower."""
+        if self._wpairs is None and self.subm and min(cin, cout) >= 64 and 0 < self.n_in <= 65536 and torch.is_grad_enabled():
+            self.wgrad_pairs()
+        if self._wpairs is not None and self._num is not None:
+            return self._wpairs, self._num
+        return None, None
+
     def _tuple(self):
         return (self.outids, self.indices, self.indice_pairs, self.indice_pair_num, self.spatial_shape)
 
