@@ -621,6 +621,7 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 __device__ __forceinline__ float lane_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 
 constexpr int kFpsWaves = 8;
+constexpr int kFpsTreeDefault = 0;
 // compile-time loop: f(integral_constant<int, Q>) for Q in [A, B) — register arrays are only ever indexed by constants
 template <int A, int B, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -629,7 +630,19 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for<A + 1, B>(f);
   }
 }
-template <int S, bool TRACE>
+// binary decision tree over a compile-time range: f(integral_constant<int, q>) for the run-time q in [LO, HI) (uniform q: scalar branches)
+template <int LO, int HI, class F>
+__device__ __forceinline__ void tree_dispatch(int q, F&& f) {
+  if constexpr (HI - LO == 1) f(std::integral_constant<int, LO>{});
+  else {
+    constexpr int MID = (LO + HI) / 2;
+    if (q < MID) tree_dispatch<LO, MID>(q, f);
+    else tree_dispatch<MID, HI>(q, f);
+  }
+}
+// TREE: the touched buckets are found by find-first-set + a binary tree of uniform branches (log2 S tests per touched bucket) instead of
+// the straight-line scan of groups of eight (S / 8 + 8 tests per round with one touched bucket)
+template <int S, bool TRACE, bool TREE = false>
 __global__ __launch_bounds__(kFpsWaves * 64) void fps_wave_k(int n, int m, int bs, const float* __restrict__ dataset,
                                                              const uint64_t* __restrict__ keys, float* __restrict__ temp, int* __restrict__ idxs,
                                                              unsigned long long* __restrict__ trace_) {
@@ -723,6 +736,20 @@ __global__ __launch_bounds__(kFpsWaves * 64) void fps_wave_k(int n, int m, int b
     if (touch) {
       // straight-line, wave-uniform tests (groups of eight first): every slot's update is a plain diamond, so the register
       // arrays are updated in place (a switch over the slot made hipcc keep two copies of pt[] and hoist the distance passes)
+      if constexpr (TREE) {
+        uint64_t rest = touch;
+        while (rest) {   // uniform
+          const int q = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(rest)) - 1);
+          rest &= rest - 1;
+          tree_dispatch<0, S>(q, [&](auto qc) __attribute__((always_inline)) {
+            constexpr int qq = decltype(qc)::value;
+            float ax = x1, ay = y1, az = z1;
+            asm volatile("" : "+v"(ax), "+v"(ay), "+v"(az));
+            pt[qq] = fminf(sqdist(px[qq], py[qq], pz[qq], ax, ay, az), pt[qq]);
+            refresh(qc);
+          });
+        }
+      } else
       static_for<0, (S + 7) / 8>([&](auto gc) __attribute__((always_inline)) {
         constexpr int g = decltype(gc)::value * 8;
         if ((touch >> g) & 0xffull)
@@ -1738,6 +1765,8 @@ extern "C" int fv2p_furthest_point_sampling(int b, int n, int m, const float* da
     if (form < 0) { const char* e = FV2P_DEV_ENV("FV2P_FPS_FORM"); form = (e && e[0] == 't') ? 0 : 1; }
     const int slots = static_cast<int>(ceil_div(n, kFpsWaves * 64));
     const int ppt = static_cast<int>(ceil_div(n, 1024));
+    static int tree = -1;   // development: FV2P_FPS_TREE=0/1 selects the scan of the touched buckets (see fps_wave_k)
+    if (tree < 0) { const char* e = FV2P_DEV_ENV("FV2P_FPS_TREE"); tree = e ? atoi(e) : kFpsTreeDefault; }
     if (form == 1 || ppt > 16) {
 #define FV2P_FPS(SS)                                                                                                       \
   do {                                                                                                                     \
@@ -1748,9 +1777,12 @@ extern "C" int fv2p_furthest_point_sampling(int b, int n, int m, const float* da
                                    static_cast<int>(lds)));                                                                \
       FV2P_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_wave_k<SS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                    static_cast<int>(lds)));                                                                \
+      FV2P_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_wave_k<SS, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                   static_cast<int>(lds)));                                                                \
       big = true;                                                                                                          \
     }                                                                                                                      \
     if (g_fps_trace) hipLaunchKernelGGL((fps_wave_k<SS, true>), dim3(b), dim3(kFpsWaves * 64), lds, st, n, m, bs, dataset, keys, temp, idxs, g_fps_trace); \
+    else if (tree) hipLaunchKernelGGL((fps_wave_k<SS, false, true>), dim3(b), dim3(kFpsWaves * 64), lds, st, n, m, bs, dataset, keys, temp, idxs, nullptr); \
     else hipLaunchKernelGGL((fps_wave_k<SS, false>), dim3(b), dim3(kFpsWaves * 64), lds, st, n, m, bs, dataset, keys, temp, idxs, nullptr); \
   } while (0)
       if (slots <= 8) FV2P_FPS(8);

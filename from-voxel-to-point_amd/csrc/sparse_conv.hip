@@ -53,7 +53,8 @@ struct ConvArgs {
   const float* bn_x; const float* bn_mean; const float* bn_invstd; const float* bn_gamma; const float* bn_beta; int bn_relu;
   // statistics finalised by the launch's LAST workgroup (conv_stats_done; bn_fold.hpp): on when fin_counter != nullptr
   unsigned* fin_counter;                             // zero before the launch, zero again after it
-  double* fin_stats; int fin_c;                      // this launch's columns of the slot buffer (unshifted by the kernels' column split), their number
+  double* fin_rows; double* fin_gslots; int fin_c;   // [tiles][2][stats_ld] rows, [groups][2][stats_ld] group slots (this launch's columns, unshifted by the kernels' column split), their number
+  int fin_groups, fin_col0;                          // groups the tiles fall into (tile % groups, <= kFinSubs); first column of the block a column-split kernel computes (set by the kernel)
   BnFwdFin fin_fwd;                                  // forward statistics (bn_x == nullptr): mean / invstd / running statistics of these columns
   BnBwdFin fin_bwd;                                  // backward sums (bn_x != nullptr): dgamma / dbeta / coef of these columns; coef rows are stats_ld apart
   int fin_bump;                                      // forward: this launch also advances num_batches_tracked (the last column block of a layer)
@@ -68,12 +69,23 @@ struct ConvArgs {
 
 // ---- BatchNorm statistics in the epilogue --------------------------------------------------------
 // Every conv of the reference's backbones feeds BatchNorm1d (spconv_backbone.py:8-27); its per-channel sum and sum of
-// squares are taken here from the accumulators instead of by a separate pass over dst.  A wave reduces its 16 rows
-// (fp64 from the first add on: E[x^2] - E[x]^2 cancels), then adds to one of kStatSlots accumulator rows with fp64
-// atomics — fire and forget, the kernel boundary orders them before the consumer (bn_apply_fwd_k folds the slots like
-// the partials of bn_reduce_k).  vals[i][reg]: value stored to row row0 + 4 * (lane / 16) + reg, column col[i].
+// squares are taken here from the accumulators instead of by a separate pass over dst (fp64 from the first add on:
+// E[x^2] - E[x]^2 cancels).  vals[i][reg]: value stored to row rows[reg] (-1: past the end), column col[i].  Two forms:
+//   * fv2p_sparse_conv_rows_stats (rounds 2 - 5): a wave reduces its 16 rows and adds to one of kStatSlots accumulator rows with fp64
+//     atomics - fire and forget, the kernel boundary orders them before the consumer (bn_apply_fwd_k folds the slots);
+//   * fv2p_sparse_conv_rows_bnfin (round 6, acc != nullptr): the lane only ACCUMULATES here; conv_stats_done combines the workgroup's
+//     sums, publishes them as the tile's row of a [tiles][2][C] buffer and the launch's last workgroups fold the rows in a fixed order:
+//     no float atomics, no slot clearing, statistics bit-identical from run to run.
 template <int NV>
-__device__ __forceinline__ void tile_stats_rows(const ConvArgs& a, const float (&vals)[NV][4], const int (&col)[NV], const int (&rows)[4]) {
+struct StatAcc {
+  double s1[NV], s2[NV];
+  __device__ __forceinline__ StatAcc() {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s1[i] = s2[i] = 0.0;
+  }
+};
+template <int NV>
+__device__ __forceinline__ void tile_stats_rows(const ConvArgs& a, const float (&vals)[NV][4], const int (&col)[NV], const int (&rows)[4], StatAcc<NV>* acc) {
   const int lane = threadIdx.x & 63, q = lane >> 4;   // rows[reg]: destination row of value reg, -1 past the end
   const int slot = (blockIdx.x * 4 + (threadIdx.x >> 6)) % kStatSlots;
   double* base = a.stats + static_cast<long long>(slot) * 2 * a.stats_ld;
@@ -100,6 +112,10 @@ __device__ __forceinline__ void tile_stats_rows(const ConvArgs& a, const float (
         }
       }
     }
+    if (a.fin_counter) {   // uniform: summed up by conv_stats_done
+      acc->s1[i] += s1; acc->s2[i] += s2;
+      continue;
+    }
     s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
     s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
     if (q == 0 && live) {
@@ -109,95 +125,123 @@ __device__ __forceinline__ void tile_stats_rows(const ConvArgs& a, const float (
   }
 }
 template <int NV>
-__device__ __forceinline__ void tile_stats(const ConvArgs& a, const float (&vals)[NV][4], const int (&col)[NV], int row0) {
+__device__ __forceinline__ void tile_stats(const ConvArgs& a, const float (&vals)[NV][4], const int (&col)[NV], int row0, StatAcc<NV>* acc) {
   const int q = (threadIdx.x & 63) >> 4;
   int rows[4];
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) rows[reg] = (row0 + q * 4 + reg < a.n_dst) ? row0 + q * 4 + reg : -1;
-  tile_stats_rows<NV>(a, vals, col, rows);
+  tile_stats_rows<NV>(a, vals, col, rows, acc);
 }
 
-// ---- finalisation by the last workgroup of the launch ------------------------------------------------------------------------------
-// Every workgroup calls this once, at its very end, after its tile_stats atomics.  The atomics are agent-scope (performed at the
-// coherence point of the eight XCDs, not in one XCD's L2), s_waitcnt vmcnt(0) returns when they have been acknowledged, and only then
-// does the workgroup count itself in with one more agent-scope atomic: the workgroup that finds all others counted reads complete
-// sums - with agent-scope loads, a plain load could hit a stale line of its own L2.  No fence anywhere (a release fence writes the
-// whole L2 back on gfx950: 20 us).  It folds the slots in fold_chunk's order, stores mean / invstd (running statistics
-// too) or dgamma / dbeta / c1 / c2, clears the slots for the next launch and resets the counter.
-// scratch: kStatsDoneLds bytes of the kernel's DYNAMIC LDS that nothing else uses any more (no static LDS here: the K-split tile fills a
+// ---- finalisation by the last workgroups of the launch ------------------------------------------------------------------------------
+// Every workgroup calls this once, at its very end (fv2p_sparse_conv_rows_bnfin / _bnbwd_fin only: a.fin_counter).
+//   1. the lanes' sums (StatAcc) are reduced over the wave's four row quads (shuffles) and over the workgroup's waves (LDS, wave
+//      order), and stored as row `tile` of fin_rows [tiles][2][stats_ld] - plain agent-scope stores, one row per tile whichever
+//      column block the workgroup computed;
+//   2. s_waitcnt vmcnt(0) returns when those stores have been acknowledged at the coherence point of the eight XCDs; only then the
+//      workgroup counts itself in on the word of its GROUP (tile % groups).  Whoever completes a group folds the group's rows, in row
+//      order, into the group's slot and counts the group in on the top word; whoever completes the top word folds the group slots, in
+//      group order, and writes mean / invstd / running statistics (forward) or dgamma / dbeta / c1 / c2 (backward sums).
+// Loads of other workgroups' rows are agent-scope loads (a plain load could hit a stale line of this XCD's L2).  No fence (a release
+// fence writes the whole L2 back on gfx950: 20 us), no float atomics, nothing to clear: rows and slots are overwritten by the next
+// launch.  Measured against the first form of this round (fp64 atomics into 16 slots, one last workgroup folding and clearing them:
+// + 8 - 13 us per launch, the waves waiting for ~250 k memory-side atomics): see profiles/README.md.
+// scratch: kStatsDoneLds bytes of the kernel's DYNAMIC LDS that nothing else uses any more (no static LDS: the K-split tile fills a
 // CU's 160 KB with two workgroups to within 768 bytes).
-constexpr size_t kStatsDoneLds = 2 * 256 * sizeof(double) + 16;
-constexpr unsigned kFinSubs = 64, kFinStride = 32;   // fin_counter: [0] the top word, [(1 + s) * kFinStride] word s; fv2p_sparse_conv_fin_counter_words() of them
-__device__ __forceinline__ void conv_stats_done(const ConvArgs& a, void* scratch) {
+constexpr size_t kStatsDoneLds = 9 * 1024;   // the largest [waves][2][columns] in use + the fold's buffer
+constexpr unsigned kFinSubs = 64, kFinStride = 32;   // fin_counter: [0] the top word, [(1 + g) * kFinStride] group g; fv2p_sparse_conv_fin_counter_words() of them
+// one thread: the sum over `count` doubles p[0], p[stride], ... in that order, with the loads batched sixteen deep (an agent-scope
+// load is a ~0.4 us round trip past the L2)
+__device__ __forceinline__ double fin_sum(const double* p, int count, long long stride) {
+  double acc = 0.0;
+  for (int r0 = 0; r0 < count; r0 += 16) {
+    double v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = (r0 + i < count) ? stat_load<true>(p + (r0 + i) * stride) : 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc += v[i];   // (x + 0.0 == x)
+  }
+  return acc;
+}
+template <int NV>
+__device__ __forceinline__ void conv_stats_done(const ConvArgs& a, void* scratch, const StatAcc<NV>& acc, const int (&cols)[NV], int tile, int n_tiles, int ncb) {
   if (!a.fin_counter) return;   // uniform
-  double (*s_red)[256] = reinterpret_cast<double (*)[256]>(scratch);
-  unsigned& s_last = *reinterpret_cast<unsigned*>(static_cast<char*>(scratch) + 2 * 256 * sizeof(double));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, n = lane & 15, q = lane >> 4;
+  constexpr int LC = NV * 16;   // columns this workgroup computed (local index i * 16 + n)
+  double* part = reinterpret_cast<double*>(scratch);                    // [nw][2][LC]
+  int* colmap = reinterpret_cast<int*>(part + nw * 2 * LC);             // [LC] launch column of a local column (-1: past the end)
+  unsigned* flag = reinterpret_cast<unsigned*>(colmap + LC);
+  double s1[NV], s2[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    s1[i] = acc.s1[i]; s2[i] = acc.s2[i];
+    s1[i] += __shfl_xor(s1[i], 16, 64); s2[i] += __shfl_xor(s2[i], 16, 64);
+    s1[i] += __shfl_xor(s1[i], 32, 64); s2[i] += __shfl_xor(s2[i], 32, 64);
+  }
+  __syncthreads();   // every wave is done with whatever the scratch region held
+  if (q == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      part[(wave * 2 + 0) * LC + i * 16 + n] = s1[i];
+      part[(wave * 2 + 1) * LC + i * 16 + n] = s2[i];
+      if (wave == 0) colmap[i * 16 + n] = cols[i] < a.c_dst ? a.fin_col0 + cols[i] : -1;
+    }
+  }
+  __syncthreads();
+  const int ld = a.stats_ld;
+  if (tid < 2 * LC) {
+    const int which = tid / LC, lc = tid % LC, gc = colmap[lc];
+    if (gc >= 0) {
+      double t = 0.0;
+      for (int w = 0; w < nw; ++w) t += part[(w * 2 + which) * LC + lc];
+      __hip_atomic_store(a.fin_rows + (static_cast<long long>(tile) * 2 + which) * ld + gc, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();   // (also: every wave is done with whatever the scratch region held)
-  if (threadIdx.x == 0) {
-    // Two levels: 488 workgroups of a K-split launch finish within a microsecond of each other, and 488 atomics on ONE word take 5 us
-    // (10 ns each at the memory side, tools/ubench/atomic_rate.hip); on 64 words 128 bytes apart 0.1 us.  Workgroup b counts itself in on
-    // word b % 64; whoever completes a word counts that word in on the top word; whoever completes the top word is last.
-    const unsigned total = gridDim.x * gridDim.y, bid = blockIdx.x + gridDim.x * blockIdx.y;
-    const unsigned sub = bid % kFinSubs, expect = (total - sub + kFinSubs - 1) / kFinSubs, subs = total < kFinSubs ? total : kFinSubs;
-    unsigned* word = a.fin_counter + (1 + sub) * kFinStride;
-    unsigned last = 0u;
+  __syncthreads();
+  const int G = a.fin_groups, grp = tile % G;
+  if (tid == 0) {
+    const unsigned expect = static_cast<unsigned>((n_tiles - grp + G - 1) / G) * static_cast<unsigned>(ncb);
+    unsigned* word = a.fin_counter + (1 + grp) * kFinStride;
+    unsigned role = 0u;
     if (__hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expect - 1u) {
       __hip_atomic_store(word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      last = __hip_atomic_fetch_add(a.fin_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == subs - 1u ? 1u : 0u;
+      role = 1u;
     }
-    s_last = last;
+    *flag = role;
   }
   __syncthreads();
-  if (!s_last || threadIdx.x >= 256) return;   // (a 1024-thread workgroup folds with its first four waves)
-  const int tid = threadIdx.x, c = a.fin_c, ld = a.stats_ld;
-  const int cfold = c < 256 ? c : 256;
-  for (int e0 = 0; e0 < c; e0 += cfold) {
-    const int e = e0 + tid;
-    double sa, sb;
-    {
-      // fold_chunk's sums in fold_chunk's order, but with all of a thread's loads in flight at once: an agent-scope load goes past the L2
-      // to the fabric (~2 us), and eight-deep batches of dependent adds (fold_chunk's loop) made this tail 25 us at 128 columns
-      const int L = 256 / cfold, ee = e0 + tid % cfold, lane_q = tid / cfold;
-      constexpr int DEPTH = 16;
-      double pa = 0.0, pb = 0.0;
-      const bool live = lane_q < L && ee < c;
-      for (int q0 = lane_q; q0 < kStatSlots; q0 += L * DEPTH) {   // uniform trip count
-        double va[DEPTH], vb[DEPTH];
-#pragma unroll
-        for (int i = 0; i < DEPTH; ++i) {
-          const int q = q0 + L * i;
-          const bool on = live && q < kStatSlots;
-          va[i] = on ? stat_load<true>(a.fin_stats + (static_cast<long long>(q) * 2 + 0) * ld + ee) : 0.0;
-          vb[i] = on ? stat_load<true>(a.fin_stats + (static_cast<long long>(q) * 2 + 1) * ld + ee) : 0.0;
-        }
-#pragma unroll
-        for (int i = 0; i < DEPTH; ++i) { pa += va[i]; pb += vb[i]; }   // (x + 0.0 == x: past-the-end slots change nothing)
-      }
-      __syncthreads();
-      s_red[0][tid] = pa; s_red[1][tid] = pb;
-      __syncthreads();
-      sa = 0.0; sb = 0.0;
-      if (tid < cfold)
-        for (int q = 0; q < L; ++q) { sa += s_red[0][q * cfold + tid]; sb += s_red[1][q * cfold + tid]; }
-    }
-    if (tid < cfold && e < c) {
-      if (a.bn_x == nullptr) {
-        float mu, is;
-        bn_fwd_channel(sa, sb, a.n_dst, a.fin_fwd, e, true, &mu, &is);
-      } else {
-        const double n = static_cast<double>(a.n_dst);
-        a.fin_bwd.dbeta[e] = static_cast<float>(sa);
-        a.fin_bwd.dgamma[e] = static_cast<float>(sb);
-        a.fin_bwd.coef[e] = a.fin_bwd.batch_stats ? static_cast<float>(sa / n) : 0.f;
-        a.fin_bwd.coef[ld + e] = a.fin_bwd.batch_stats ? static_cast<float>(sb / n) : 0.f;
-      }
-    }
+  if (*flag == 0u || tid >= 256) return;   // (a 1024-thread workgroup folds with its first four waves)
+  const int c = a.fin_c;                   // <= 128 columns per launch: one (column, which) pair per thread
+  const int which = tid / c, e = tid % c;
+  const bool mine = tid < 2 * c;
+  double* gslot = a.fin_gslots + static_cast<long long>(grp) * 2 * ld;
+  if (mine) {
+    const int count = (n_tiles - grp + G - 1) / G;
+    const double t = fin_sum(a.fin_rows + (static_cast<long long>(grp) * 2 + which) * ld + e, count, static_cast<long long>(G) * 2 * ld);
+    __hip_atomic_store(gslot + static_cast<long long>(which) * ld + e, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  for (int i = tid; i < kStatSlots * 2 * c; i += 256) {
-    const int row = i / c, e = i % c;
-    __hip_atomic_store(a.fin_stats + static_cast<long long>(row) * ld + e, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int groups = n_tiles < G ? n_tiles : G;
+  if (tid == 0) *flag = __hip_atomic_fetch_add(a.fin_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == static_cast<unsigned>(groups) - 1u ? 2u : 0u;
+  __syncthreads();
+  if (*flag != 2u) return;
+  double (*red)[256] = reinterpret_cast<double (*)[256]>(part);   // [2][c] totals
+  if (mine) red[which][e] = fin_sum(a.fin_gslots + static_cast<long long>(which) * ld + e, groups, 2ll * ld);
+  __syncthreads();
+  if (tid < c) {
+    const double sa = red[0][tid], sb = red[1][tid];
+    if (a.bn_x == nullptr) {
+      float mu, is;
+      bn_fwd_channel(sa, sb, a.n_dst, a.fin_fwd, tid, true, &mu, &is);
+    } else {
+      const double nn = static_cast<double>(a.n_dst);
+      a.fin_bwd.dbeta[tid] = static_cast<float>(sa);
+      a.fin_bwd.dgamma[tid] = static_cast<float>(sb);
+      a.fin_bwd.coef[tid] = a.fin_bwd.batch_stats ? static_cast<float>(sa / nn) : 0.f;
+      a.fin_bwd.coef[ld + tid] = a.fin_bwd.batch_stats ? static_cast<float>(sb / nn) : 0.f;
+    }
   }
   if (tid == 0) {
     if (a.bn_x == nullptr && a.fin_bump && a.fin_fwd.running_mean && a.fin_fwd.num_batches_tracked) *a.fin_fwd.num_batches_tracked += 1;
@@ -288,7 +332,7 @@ __device__ __forceinline__ void stage_w_scalar(const ConvArgs& a, const float* _
 }
 
 template <int NB>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x4 (&acc)[NB], int row0) {
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x4 (&acc)[NB], int row0, StatAcc<NB>* sacc) {
   const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
@@ -315,8 +359,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x4 (&a
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) vals[nb][reg] = acc[nb][reg] + b;
     }
-    tile_stats<NB>(a, vals, cols, row0);
+    tile_stats<NB>(a, vals, cols, row0, sacc);
   }
+}
+// the columns conv_epilogue's lane holds (accumulator nb of lane n: column 16 nb + n), for conv_stats_done
+template <int NB>
+__device__ __forceinline__ void epilogue_cols(int (&cols)[NB]) {
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) cols[nb] = nb * 16 + (threadIdx.x & 15);
 }
 
 // CINP: source channels padded to a multiple of 16 (c_src % 4 == 0 required, 16-byte row loads)
@@ -361,8 +411,11 @@ __global__ __launch_bounds__(256) void conv_rows_vec(ConvArgs a) {
       }
     }
   }
-  conv_epilogue<NB>(a, acc, row0);
-  conv_stats_done(a, lds);
+  StatAcc<NB> sacc;
+  conv_epilogue<NB>(a, acc, row0, &sacc);
+  int scols[NB];
+  epilogue_cols<NB>(scols);
+  conv_stats_done<NB>(a, lds, sacc, scols, blockIdx.x, gridDim.x, 1);
 }
 
 // ---- software-pipelined variant (CINP*NB <= 256) ---------------------------------------------------
@@ -519,8 +572,11 @@ __global__ __launch_bounds__(256) void conv_rows_pipe(ConvArgs a) {
       idx_nxt[u] = idx_nn[u];
     }
   }
-  conv_epilogue<NB>(a, acc, row0);
-  conv_stats_done(a, lds);
+  StatAcc<NB> sacc;
+  conv_epilogue<NB>(a, acc, row0, &sacc);
+  int scols[NB];
+  epilogue_cols<NB>(scols);
+  conv_stats_done<NB>(a, lds, sacc, scols, blockIdx.x, gridDim.x, 1);
 }
 
 // ---- LDS-DMA variant (the default for full 16-channel multiples) --------------------------------------
@@ -600,6 +656,7 @@ __global__ __launch_bounds__(256) void conv_rows_dma(ConvArgs a) {
     const int off = blockIdx.y * NB * 16;
     a.w += WT ? static_cast<long long>(off) * a.w_ld : off;
     a.dst += off;
+    a.fin_col0 = off;
     a.c_dst = NB * 16;
     if (a.bias) a.bias += off;
     if (a.stats) a.stats += off;
@@ -611,6 +668,7 @@ __global__ __launch_bounds__(256) void conv_rows_dma(ConvArgs a) {
   }
   unsigned long long t_begin = 0;
   if (a.trace) t_begin = __builtin_readcyclecounter();
+  StatAcc<NB> sacc;
   // rows past the end compute on the last row's neighbours and are never stored (no masks in the loop)
   const int my_row = min(row0 + r, a.n_dst - 1);
   f32x4 acc[NB];
@@ -746,9 +804,14 @@ __global__ __launch_bounds__(256) void conv_rows_dma(ConvArgs a) {
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) vals[i][reg] = acc[i][reg] + b;
     }
-    tile_stats<NB>(a, vals, cols, row0);
+    tile_stats<NB>(a, vals, cols, row0, &sacc);
   }
-  conv_stats_done(a, lds);
+  {
+    int scols[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) scols[i] = (NB % 4 == 0) ? (WT ? (NB * n + i) : (64 * (i / 4) + 4 * n + (i % 4))) : (NB * n + i);
+    conv_stats_done<NB>(a, lds, sacc, scols, blockIdx.x, gridDim.x, gridDim.y);
+  }
 }
 
 // ---- LDS-DMA variant for permuted rows: visits only the offsets its tile uses ----------------------------------------
@@ -885,6 +948,7 @@ __global__ __launch_bounds__(256) void conv_rows_act(ConvArgs a) {
   }
   // epilogue: accumulator i of lane (q, n) is output column  WT ? NB*n + i : 64*(i/4) + 4*n + i%4; rows through perm
   const int q = lane >> 4, n = lane & 15;
+  StatAcc<NB> sacc;
   int rows[4];
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg) {
@@ -924,9 +988,14 @@ __global__ __launch_bounds__(256) void conv_rows_act(ConvArgs a) {
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) vals[i][reg] = acc[i][reg] + b;
     }
-    tile_stats_rows<NB>(a, vals, cols, rows);
+    tile_stats_rows<NB>(a, vals, cols, rows, &sacc);
   }
-  conv_stats_done(a, lds);
+  {
+    int scols[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) scols[i] = (NB % 4 == 0) ? (WT ? (NB * n + i) : (64 * (i / 4) + 4 * n + (i % 4))) : (NB * n + i);
+    conv_stats_done<NB>(a, lds, sacc, scols, blockIdx.x, gridDim.x, 1);
+  }
 }
 
 // ---- thin layers (16 / 32 channels, 27 offsets): a wave, 16 destination rows, nothing staged, nothing shared -------------------------
@@ -945,6 +1014,7 @@ __global__ __launch_bounds__(256) void conv_rows_thin(ConvArgs a) {
   constexpr int J = CINP / 16, D = 2, NST = D + 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
   const int row0 = (xcd_major_tile(blockIdx.x, gridDim.x) * 4 + wave) * 16;
+  StatAcc<NB> sacc;
   if (row0 < a.n_dst) {   // (no barrier in the conv itself; waves past the end only take part in conv_stats_done)
   const int my_row = row0 + r;
   PreNorm4 pn[PRE ? J : 1];
@@ -1005,9 +1075,11 @@ __global__ __launch_bounds__(256) void conv_rows_thin(ConvArgs a) {
     }
     __builtin_amdgcn_sched_barrier(0);
   });
-  conv_epilogue<NB>(a, acc, row0);
+  conv_epilogue<NB>(a, acc, row0, &sacc);
   }
-  conv_stats_done(a, lds);
+  int scols[NB];
+  epilogue_cols<NB>(scols);
+  conv_stats_done<NB>(a, lds, sacc, scols, blockIdx.x, gridDim.x, 1);
 }
 
 // ---- thin layers with ALL 27 weight matrices resident in LDS (32 channels: 108 KB, one workgroup of 16 waves per CU) -------------------
@@ -1030,6 +1102,7 @@ __global__ __launch_bounds__(1024) void conv_rows_res(ConvArgs a, int groups_per
     lds[k * WSZ + ((((c >> 4) * NB + (col >> 4)) * 64) + ((c >> 2) & 3) * 16 + (col & 15)) * 4 + (c & 3)] = v;
   }
   __syncthreads();
+  StatAcc<NB> sacc;
   const int groups = (a.n_dst + 15) / 16;
   const int first = xcd_major_tile(blockIdx.x, gridDim.x) * groups_per_wg;
   const int last = min(first + groups_per_wg, groups);
@@ -1084,9 +1157,11 @@ __global__ __launch_bounds__(1024) void conv_rows_res(ConvArgs a, int groups_per
       }
       __builtin_amdgcn_sched_barrier(0);
     });
-    conv_epilogue<NB>(a, acc, row0);
+    conv_epilogue<NB>(a, acc, row0, &sacc);
   }
-  conv_stats_done(a, lds);
+  int scols[NB];
+  epilogue_cols<NB>(scols);
+  conv_stats_done<NB>(a, lds, sacc, scols, blockIdx.x, gridDim.x, 1);
 }
 
 // ---- pair-compacted tile with the reduction dimension split over the waves ---------------------------------------------------
@@ -1141,10 +1216,12 @@ __global__ __launch_bounds__(256) void conv_rows_ksplit(ConvArgs a) {
   if (a.plan) { r_begin = a.plan[tile]; r_end = a.plan[tile + 1]; }
   const int n_sub = (r_end - r_begin + TM - 1) / TM;
   const int sub_rows = n_sub > 0 ? (r_end - r_begin + n_sub - 1) / n_sub : 0;
+  StatAcc<4> sacc;
   if (ncb > 1) {   // column split as in conv_rows_dma
     const int off = cblk * 64;
     a.w += WT ? static_cast<long long>(off) * a.w_ld : off;
     a.dst += off;
+    a.fin_col0 = off;
     if (a.bias) a.bias += off;
     if (a.stats) a.stats += off;
     if (a.bn_x) {
@@ -1389,12 +1466,17 @@ __global__ __launch_bounds__(256) void conv_rows_ksplit(ConvArgs a) {
     }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) rows[reg] = (wrow0 + q * 4 + reg < row_end) ? wrow0 + q * 4 + reg : -1;
-    tile_stats_rows<4>(a, vals, cols, rows);
+    tile_stats_rows<4>(a, vals, cols, rows, &sacc);
   }
   }
   if (row0 + sub_rows < r_end) __syncthreads();   // the next sub-tile clears the accumulators the epilogue above reads
   }
-  conv_stats_done(a, lds);
+  {
+    int scols[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) scols[i] = 4 * (lane & 15) + i;
+    conv_stats_done<4>(a, lds, sacc, scols, tile, static_cast<int>(gridDim.x) / ncb, ncb);
+  }
 }
 
 // Compacted variant: the workgroup owns TM destination rows whose accumulators live in LDS.  For every kernel
@@ -1527,8 +1609,11 @@ __global__ __launch_bounds__(256) void conv_rows_scalar(ConvArgs a) {
           acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], lds[(s * NB + nb) * 64 + lane], acc[nb], 0, 0, 0);
     }
   }
-  conv_epilogue<NB>(a, acc, row0);
-  conv_stats_done(a, lds);
+  StatAcc<NB> sacc;
+  conv_epilogue<NB>(a, acc, row0, &sacc);
+  int scols[NB];
+  epilogue_cols<NB>(scols);
+  conv_stats_done<NB>(a, lds, sacc, scols, blockIdx.x, gridDim.x, 1);
 }
 
 // ---- weight gradient ----------------------------------------------------------------------------
@@ -2471,6 +2556,11 @@ extern "C" int fv2p_sparse_conv_set_paths(int thin_on, int res_on) {
   return 0;
 }
 
+// tiles any kernel of this file cuts n_dst rows into, at most (16-row groups; plan levels stay below n_dst / 16 tiles)
+static int64_t fin_tile_cap(int64_t n_dst) { return ceil_div(n_dst > 0 ? n_dst : 1, 16) + 64; }
+extern "C" size_t fv2p_sparse_conv_fin_ws_bytes(int64_t n_dst, int c_dst) {
+  return align_up(static_cast<size_t>(fin_tile_cap(n_dst) + kFinSubs) * 2 * static_cast<size_t>(c_dst > 0 ? c_dst : 1) * sizeof(double));
+}
 // what a call adds to the plain conv: statistics finalised by the last workgroup, source rows normalised on the gather, a support query
 struct ConvExtra {
   unsigned* fin_counter = nullptr;
@@ -2508,7 +2598,7 @@ static int conv_rows_impl(const float* src, int64_t n_src, int c_src, const floa
       a.stats = stats ? stats + d0 : nullptr; a.stats_ld = c_dst;
       a.bn_x = nullptr; a.bn_mean = a.bn_invstd = a.bn_gamma = a.bn_beta = nullptr; a.bn_relu = 0;
       a.perm = perm;   // honoured by the LDS-DMA tile for permuted rows, ignored (plain row order, same result) by the others
-      a.fin_counter = nullptr; a.fin_stats = nullptr; a.fin_c = 0; a.fin_bump = 0; a.dry = ex ? ex->dry : 0;
+      a.fin_counter = nullptr; a.fin_rows = a.fin_gslots = nullptr; a.fin_c = 0; a.fin_groups = 1; a.fin_col0 = 0; a.fin_bump = 0; a.dry = ex ? ex->dry : 0;
       a.fin_fwd = BnFwdFin{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f};
       a.fin_bwd = BnBwdFin{nullptr, nullptr, nullptr, 1};
       a.pre_mean = a.pre_invstd = a.pre_gamma = a.pre_beta = nullptr; a.pre_relu = 0;
@@ -2517,7 +2607,10 @@ static int conv_rows_impl(const float* src, int64_t n_src, int c_src, const floa
         a.pre_gamma = ex->pre_gamma ? ex->pre_gamma + s0 : nullptr; a.pre_beta = ex->pre_beta ? ex->pre_beta + s0 : nullptr; a.pre_relu = ex->pre_relu;
       }
       if (ex && ex->fin_counter && stats && c_src <= 128) {   // one launch per column block holds the whole sum: its last workgroup finalises
-        a.fin_counter = ex->fin_counter; a.fin_stats = stats + d0; a.fin_c = cd;
+        // stats: the workspace of fv2p_sparse_conv_fin_ws_bytes - [tile cap][2][c_dst] rows, then kFinSubs group slots
+        a.fin_counter = ex->fin_counter; a.fin_rows = stats + d0; a.fin_c = cd;
+        a.fin_gslots = stats + static_cast<long long>(fin_tile_cap(n_dst)) * 2 * c_dst + d0;
+        a.fin_groups = n_dst > 32768 ? static_cast<int>(kFinSubs) : 16;   // ~15 - 35 rows per group fold either way
         if (bn) {
           a.fin_bwd = BnBwdFin{ex->bwd.dgamma + d0, ex->bwd.dbeta + d0, ex->bwd.coef + d0, ex->bwd.batch_stats};
         } else {
@@ -2660,7 +2753,8 @@ extern "C" int fv2p_sparse_conv_rows_bnfin(const float* src, int64_t n_src, int 
   if (int rc = conv_rows_impl(src, n_src, c_src, weight, kvol, tab, n_dst, c_dst, flip_k, transpose_w, bias, dst, fused ? stats : nullptr, stream,
                               nullptr, nullptr, &ex))
     return rc;
-  if (stats && !fused && n_dst > 0) {   // sums by a pass over dst, finalised by one workgroup
+  if (stats && !fused && n_dst > 0) {   // sums by a pass over dst, finalised by one workgroup (the workspace's head serves as its slots)
+    FV2P_HIP(hipMemsetAsync(stats, 0, sizeof(double) * kStatSlots * 2 * static_cast<size_t>(c_dst), stream));
     if (int rc = bn_column_sums(dst, n_dst, c_dst, stats, stream)) return rc;
     return bn_finalize_forward(stats, n_dst, c_dst, ff, stream);
   }
@@ -2697,6 +2791,7 @@ extern "C" int fv2p_sparse_conv_rows_bnbwd_fin(const float* src, int64_t n_src, 
                               fused ? &bn : nullptr, perm, &ex))
     return rc;
   if (!fused && n_dst > 0) {
+    FV2P_HIP(hipMemsetAsync(stats, 0, sizeof(double) * kStatSlots * 2 * static_cast<size_t>(c_dst), stream));
     if (int rc = bn_backward_sums(bn_x, dst, n_dst, c_dst, bn_mean, bn_invstd, bn_gamma, bn_beta, relu, stats, stream)) return rc;
     return bn_finalize_backward(stats, n_dst, c_dst, bf, stream);
   }

@@ -489,7 +489,7 @@ at::Tensor sparse_conv_bn_relu(const at::Tensor& features, const at::Tensor& wei
 // The conv bias: it feeds a train-mode BatchNorm, which removes every per-column constant - its gradient is identically zero in exact
 // arithmetic (torch returns the rounding noise of a column sum of dx).  The fused nodes add it in the conv epilogue and return zeros.
 struct FinState {
-  at::Tensor stats_f, stats_b, counter;   // slot buffers (zero between launches: the last workgroup clears what it folded), two counters
+  at::Tensor counter;   // the completion counters of the finalising launches: forward | backward | the one-launch BatchNorms (zero between launches)
 };
 FinState& fin_state(const at::Tensor& like, void* stream) {
   static std::mutex mu;
@@ -499,9 +499,6 @@ FinState& fin_state(const at::Tensor& like, void* stream) {
   auto it = pool.find(key);
   if (it == pool.end()) {
     FinState f;
-    const int64_t cap = static_cast<int64_t>(fv2p_sparse_conv_stat_slots()) * 2 * 1024;
-    f.stats_f = at::zeros({cap}, like.options().dtype(at::kDouble));
-    f.stats_b = at::zeros({cap}, like.options().dtype(at::kDouble));
     f.counter = at::zeros({2 * static_cast<int64_t>(fv2p_sparse_conv_fin_counter_words()) + 4}, like.options().dtype(at::kInt));   // forward | backward | 4 words of the one-launch BatchNorms
     it = pool.emplace(key, std::move(f)).first;
   }
@@ -640,9 +637,11 @@ struct ConvFinFn : public torch::autograd::Function<ConvFinFn> {
     if (batch_stats) saved = at::empty({2, cout}, features.options());
     else if (want_stats) saved = at::stack({rm, at::rsqrt(rv + eps)});
     const bool track = batch_stats && training && rm.defined();
+    at::Tensor fin_ws;   // the tiles' rows of column sums + the group slots (written and read inside the launch)
+    if (batch_stats) fin_ws = workspace(fv2p_sparse_conv_fin_ws_bytes(n_out, static_cast<int>(cout)), features, stream);
     check(fv2p_sparse_conv_rows_bnfin(features.data_ptr<float>(), features.size(0), static_cast<int>(cin), weight.data_ptr<float>(), static_cast<int>(kvol),
                                       tab_f.data_ptr<int>(), n_out, static_cast<int>(cout), static_cast<int>(flip_f), 0, fptr(cb), out.data_ptr<float>(),
-                                      batch_stats ? fs.stats_f.data_ptr<double>() : nullptr, reinterpret_cast<unsigned*>(fs.counter.data_ptr<int>()),
+                                      batch_stats ? reinterpret_cast<double*>(fin_ws.data_ptr()) : nullptr, reinterpret_cast<unsigned*>(fs.counter.data_ptr<int>()),
                                       static_cast<float>(eps), static_cast<float>(momentum), track ? rm.data_ptr<float>() : nullptr,
                                       track ? rv.data_ptr<float>() : nullptr, (track && nbt.defined()) ? nbt.data_ptr<int64_t>() : nullptr,
                                       batch_stats ? saved[0].data_ptr<float>() : nullptr, batch_stats ? saved[1].data_ptr<float>() : nullptr,
@@ -705,6 +704,7 @@ struct ConvFinFn : public torch::autograd::Function<ConvFinFn> {
       }
       const float* w_bwd = wt.defined() ? wt.data_ptr<float>() : weight.data_ptr<float>();
       unsigned* counter = reinterpret_cast<unsigned*>(fs.counter.data_ptr<int>()) + fv2p_sparse_conv_fin_counter_words();
+      at::Tensor fin_ws = workspace(fv2p_sparse_conv_fin_ws_bytes(features.size(0), static_cast<int>(cin)), features, stream);
       if (pre) {
         // d(relu(bn(y_src))) by the backward-data conv, the BatchNorm's backward sums from its epilogue, finalised by its last workgroup;
         // then the BatchNorm's own backward pass in place: din becomes d(y_src)
@@ -712,7 +712,7 @@ struct ConvFinFn : public torch::autograd::Function<ConvFinFn> {
         check(fv2p_sparse_conv_rows_bnbwd_fin(g.data_ptr<float>(), g.size(0), static_cast<int>(cout), w_bwd, static_cast<int>(kvol), tab_b.data_ptr<int>(),
                                               features.size(0), static_cast<int>(cin), flip_b, transpose_w, din.data_ptr<float>(), features.data_ptr<float>(),
                                               pre_saved[0].data_ptr<float>(), pre_saved[1].data_ptr<float>(), fptr(pre_gamma), fptr(pre_beta), pre_relu ? 1 : 0,
-                                              fs.stats_b.data_ptr<double>(), counter, pre_bs ? 1 : 0, coef[0].data_ptr<float>(), coef[1].data_ptr<float>(),
+                                              reinterpret_cast<double*>(fin_ws.data_ptr()), counter, pre_bs ? 1 : 0, coef[0].data_ptr<float>(), coef[1].data_ptr<float>(),
                                               coef[2].data_ptr<float>(), perm_b, stream),
               "fv2p_sparse_conv_rows_bnbwd_fin");
         check(fv2p_batchnorm_backward_fin(features.data_ptr<float>(), din.data_ptr<float>(), features.size(0), static_cast<int>(cin),
@@ -734,7 +734,7 @@ struct ConvFinFn : public torch::autograd::Function<ConvFinFn> {
               check(fv2p_sparse_conv_rows_bnbwd_fin(g.data_ptr<float>(), g.size(0), static_cast<int>(cout), w_bwd, static_cast<int>(kvol), tab_b.data_ptr<int>(),
                                                     features.size(0), static_cast<int>(cin), flip_b, transpose_w, din.data_ptr<float>(), bx.data_ptr<float>(),
                                                     bstat[0].data_ptr<float>(), bstat[1].data_ptr<float>(), fptr(bw), fptr(bb),
-                                                    bctx.saved_data["relu"].toBool() ? 1 : 0, fs.stats_b.data_ptr<double>(), counter,
+                                                    bctx.saved_data["relu"].toBool() ? 1 : 0, reinterpret_cast<double*>(fin_ws.data_ptr()), counter,
                                                     bctx.saved_data["batch_stats"].toBool() ? 1 : 0, coef[0].data_ptr<float>(), coef[1].data_ptr<float>(),
                                                     coef[2].data_ptr<float>(), perm_b, stream),
                     "fv2p_sparse_conv_rows_bnbwd_fin");

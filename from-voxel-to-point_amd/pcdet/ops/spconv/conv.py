@@ -229,8 +229,8 @@ def conv_bn_fold(conv, x, bn, relu_module, defer=False, residual=None):
     import fv2p_native as _nat
     from .norm import fusable
     ext = _nat.torch_ext()
-    if ext is None or not ext.bn_fold() or conv.conv1x1 or conv.fused_bn or conv.inverse:
-        return None
+    if ext is None or not ext.bn_fold() or not isinstance(conv, SparseConvolution) or conv.conv1x1 or conv.fused_bn or conv.inverse:
+        return None   # (not a SparseConvolution: e.g. the host mirror the parity tests put in a block's place)
     if conv._forward_hooks or conv._forward_pre_hooks or conv._backward_hooks:
         return None
     features = x.features

@@ -190,8 +190,11 @@ int fv2p_sparse_conv_rows_bnbwd(const float* src, int64_t n_src, int c_src, cons
 /* ---- round 6: BatchNorm statistics finalised by the conv launch, BatchNorm (+ReLU) of the source rows on the gather ------------
  * The reference runs conv -> nn.BatchNorm1d -> nn.ReLU as three modules (spconv_backbone.py:8-27, modules.py:86-100) and, inside a
  * residual block, conv1 -> bn1 -> relu -> conv2 (spconv_backbone.py:47-68).  Here
- *   fv2p_sparse_conv_rows_bnfin     = fv2p_sparse_conv_rows_stats whose LAST workgroup folds the slots itself: when the launch ends mean /
- *                                     invstd [c_dst] (and the running statistics, num_batches_tracked) are final, the slots zero again and
+ *   fv2p_sparse_conv_rows_bnfin     = the conv that finalises the BatchNorm statistics of its own output: every workgroup stores its
+ *                                     tile's column sums as one row of `stats` (a workspace of fv2p_sparse_conv_fin_ws_bytes(n_dst, c_dst)
+ *                                     bytes, no initialisation needed), the launch's last workgroups fold the rows in a fixed order
+ *                                     (no float atomics: the statistics are bit-identical from run to run) and when the launch ends
+ *                                     mean / invstd [c_dst] (and the running statistics, num_batches_tracked) are final and
  *                                     counter[] (fv2p_sparse_conv_fin_counter_words() zeroed device words the caller keeps per stream
  *                                     and direction) zero again - BatchNorm apply kernels
  *                                     (fv2p_batchnorm_apply_res) and consumer convs read 2 - 4 floats per column instead of folding
@@ -212,6 +215,7 @@ int fv2p_sparse_conv_rows_bnfin(const float* src, int64_t n_src, int c_src, cons
                                 int pre_relu, fv2p_stream_t stream);
 int fv2p_sparse_conv_prenorm_supported(int c_src, int c_dst, int kvol, int64_t n_dst, int flip_k, int transpose_w);
 int fv2p_sparse_conv_fin_counter_words(void);
+size_t fv2p_sparse_conv_fin_ws_bytes(int64_t n_dst, int c_dst);
 int fv2p_sparse_conv_rows_bnbwd_fin(const float* src, int64_t n_src, int c_src, const float* weight, int kvol, const int* tab,
                                     int64_t n_dst, int c_dst, int flip_k, int transpose_w, float* dst, const float* bn_x,
                                     const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_beta,
