@@ -958,7 +958,7 @@ def roofline_probe(model, voxelize, pool, args, device, rec=None, in_step=None):
     layer = f"{'subm' if mod.subm else 'conv'} {cin}->{cout} key={mod.indice_key} n_in={rec['n_in']} n_out={rec['n_out']} pairs={rec['pairs']}"
     try:   # reported only for the very layer the counters were collected on (same channels, rows and pairs)
         prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-        with open(next(p for p in (os.path.join(prof, n) for n in ("r05_pmc_roofline.json", "r04_pmc_roofline.json", "r03_pmc_roofline.json")) if os.path.exists(p))) as f:
+        with open(next(p for p in (os.path.join(prof, n) for n in ("r06_pmc_roofline.json", "r05_pmc_roofline.json", "r04_pmc_roofline.json", "r03_pmc_roofline.json")) if os.path.exists(p))) as f:
             pmc = json.load(f)
         import re
         mt = re.search(r"(\d+)->(\d+) key=(\S+) n=(\d+) pairs=(\d+)", pmc.get("layer_line", ""))
@@ -976,8 +976,10 @@ def roofline_probe(model, voxelize, pool, args, device, rec=None, in_step=None):
         a = (flops / t / 1e12) if bound == "mfma" else (bytes_alg / t / 1e9)
         out.update(in_step)
         out["in_step_achieved"], out["in_step_frac"] = round(a, 3), round(a / peak, 4)
-        out["how"] += ("; in_step_*: the same layer's forward launches inside ordinary training steps of this run, each bracketed by an event pair on its "
-                       "launch stream (event-to-event time: the kernel plus one inter-packet gap); agrees with the rocprofv3 kernel table of the step (profiles/)")
+        out["how"] += ("; in_step_*: the same layer's forward launches inside ordinary training steps of this run (the launches that gather their rows as they "
+                       "are - the kernel instance of the isolated probe; in the step they also take the BatchNorm sums of their output and the launch's last "
+                       "workgroups finalise them, round 6), each bracketed by an event pair on its launch stream (event-to-event time: the kernel plus one "
+                       "inter-packet gap); agrees with the rocprofv3 kernel table of the step (profiles/)")
     return out
 
 

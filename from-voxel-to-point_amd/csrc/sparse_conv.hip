@@ -2583,7 +2583,7 @@ static int conv_rows_impl(const float* src, int64_t n_src, int c_src, const floa
   if (g_probe.armed && !(ex && ex->dry)) {   // (unlocked read of a flag: the probe is armed and read by the thread that measures)
     std::lock_guard<std::mutex> lock(g_probe.mu);
     if (g_probe.armed && g_probe.used < kProbePairs && c_src == g_probe.c_src && c_dst == g_probe.c_dst && kvol == g_probe.kvol &&
-        n_dst == g_probe.n_dst && (flip_k & 1) == g_probe.flip && !transpose_w && !bn) {
+        n_dst == g_probe.n_dst && (flip_k & 1) == g_probe.flip && !transpose_w && !bn && !(ex && ex->pre_mean)) {   // the plain-gather launches: the kernel instance the isolated probe times
       probe_slot = g_probe.used++;
       FV2P_HIP(hipEventRecord(g_probe.ev[2 * probe_slot], stream));
     }

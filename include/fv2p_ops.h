@@ -161,7 +161,8 @@ int fv2p_sparse_conv_set_paths(int thin_on, int res_on);
  * trace[8*blockIdx .. +7] (device memory, >= 8*ceil(n_dst/64) entries).  NULL switches it off. */
 int fv2p_sparse_conv_set_trace(unsigned long long* trace);
 /* Measurement hook (bench.py's roofline.in_step_us): while armed, every conv launch of fv2p_sparse_conv_rows* with exactly these
- * channel counts, kernel volume, destination rows and table direction (flip_k & 1) is bracketed by a pair of HIP events on the
+ * channel counts, kernel volume, destination rows and table direction (flip_k & 1) - forward convs that gather their source rows as
+ * they are (not the PRE form of fv2p_sparse_conv_rows_bnfin: another kernel instance) - is bracketed by a pair of HIP events on the
  * launch stream (at most 512 pairs; further launches run unbracketed).  fv2p_sparse_conv_probe_read waits for the recorded pairs,
  * returns their number and the sum of their elapsed times in microseconds, and disarms.  No reference counterpart (its timers are
  * commented out: spconv_ops.h:305-360). */

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Every profiles/<tag>_* file of a round from ONE tree in ONE call (run on the GPU box; copy gpurun_out/<tag>_* into profiles/ afterwards).
-#   bash tools/round_profiles.sh r05 [quick]
+#   bash tools/round_profiles.sh r06 [quick]
 # Sections: bench lines (4 workloads), kernel stats of the FV2P step / its boundary leg / MGAF (rocprofv3 --kernel-trace --stats), the per-op
 # tables of tools/microbench.py, the roofline kernel's counters (separate --pmc passes, counters only with --kernel-trace), the in-situ
 # launch times of the roofline kernel, the one-rank DDP stream-budget runs, the step-noise calibration.  profiles/README.md quotes only
 # numbers found in these files.
-TAG=${1:-r05}; QUICK=$2
+TAG=${1:-r06}; QUICK=$2
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 O=gpurun_out
@@ -53,6 +53,13 @@ if [ -z "$QUICK" ]; then
   python3 tools/microbench.py nn > $O/${TAG}_microbench_nn.txt 2>&1
   python3 tools/microbench.py sa > $O/${TAG}_microbench_sa.txt 2>&1
 fi
+
+echo "== round 6: what the BatchNorm statistics cost a conv launch, one-launch BatchNorm passes, the completion counter, the sampler's scan"
+python3 tools/fin_time.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_fin_time.txt; cat $O/${TAG}_fin_time.txt
+python3 tools/bn_time.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_bn_time.txt; tail -8 $O/${TAG}_bn_time.txt
+tools/ubench/atomic_rate > $O/${TAG}_atomic_rate.txt 2>&1; tail -17 $O/${TAG}_atomic_rate.txt
+{ for t in 0 1; do echo "== development library, FV2P_FPS_TREE=$t (0: straight-line scan of the touched buckets, the default; 1: find-first-set + binary tree)"; FV2P_LIB_DIR=$PWD/from-voxel-to-point_amd/lib/dev FV2P_FPS_TREE=$t python3 tools/microbench.py fps 2>&1 | grep "^FPS" | head -5; done; } > $O/${TAG}_fps_tree.txt; cat $O/${TAG}_fps_tree.txt
+for f in 1 0; do echo "FV2P_BN_FOLD=$f (1: residual blocks on conv_fin / bn_apply, 0: the round-5 arrangement): $(FV2P_BN_FOLD=$f python3 bench.py --workload backbone --backbone res8x --cpu-clouds 0 --no-roofline 2>/dev/null | grep -o '"ms_per_step": [0-9.]*')"; done > $O/${TAG}_res8x_fold.txt; cat $O/${TAG}_res8x_fold.txt
 
 echo "== counters of the roofline kernel"
 bash tools/pmc_roofline.sh $TAG > $O/pmc_roofline.log 2>&1; tail -2 $O/pmc_roofline.log
