@@ -623,8 +623,8 @@ __device__ __forceinline__ void one_reduce(const float* __restrict__ x, const fl
     double a = 0.0, b = 0.0;
     for (int q = 0; q < g.rpp; ++q) { a += red[0][q * cpad + e]; b += red[1][q * cpad + e]; }
     if (e < g.c) {
-      __hip_atomic_store(partial + (static_cast<long long>(blockIdx.x) * 2 + 0) * g.c + e, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(partial + (static_cast<long long>(blockIdx.x) * 2 + 1) * g.c + e, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      stat_publish(partial + (static_cast<long long>(blockIdx.x) * 2 + 0) * g.c + e, a);   // (not a store: see bn_fold.hpp)
+      stat_publish(partial + (static_cast<long long>(blockIdx.x) * 2 + 1) * g.c + e, b);
     }
   }
 }

@@ -37,6 +37,16 @@ __device__ __forceinline__ double stat_load(const double* p) {
   else return *p;
 }
 
+// Publishing a value other workgroups of the SAME launch will read after a counter says so.  A plain or agent-scope STORE is
+// acknowledged to the wave when this XCD's L2 has taken it (write-through, but the acknowledgement does not wait for the fabric): the
+// counter atomic issued after `s_waitcnt vmcnt(0)` can then be performed at the memory side BEFORE the data lands there, and a reader on
+// another XCD gets the old contents - seen as garbage statistics once two processes shared the GPU (tests/test_ddp_gpu.py, round 6).
+// A read-modify-write atomic is executed by the memory-side atomic unit itself and acknowledged after it was performed, exactly like the
+// counter: same-path ordering.  Hence an exchange instead of a store.
+__device__ __forceinline__ void stat_publish(double* p, double v) {
+  (void)__hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Folds the [nblk][2][c] partials of channels [e0, e0 + cfold) in a fixed order: L = 256 / cfold lanes per channel take
 // interleaved slices, then an ordered LDS fold.  Returns the two sums of channel e0 + tid (valid for tid < cfold).  256 threads.
 template <bool COHERENT>

@@ -50,18 +50,26 @@ def make_input(seed, batch, shape, n, cin, gpu):
     return ind, feats, spconv.SparseConvTensor(torch.from_numpy(feats).to(gpu), torch.from_numpy(ind).to(gpu), shape, batch)
 
 
-def subm_tables(x, conv):
-    """(rulebook, forward table, flip, backward table, flip) of a submanifold conv on x, as the Python layer passes them."""
+def subm_tables(x, conv, planned=False):
+    """(rulebook, forward table, flip, backward table, flip) of a submanifold conv on x, as the Python layer passes them.  planned: the
+    table carries a tiling plan, as from the third conv of a residual stage on (ops.Rulebook._plan) - a K-split launch then runs on the
+    plan's tile count (>= 256 whatever the row count)."""
     from pcdet.ops.spconv import ops
     rb = ops.build_rulebook(x.indices, x.batch_size, x.spatial_shape, conv.kernel_size, conv.stride, conv.padding, conv.dilation,
                             conv.output_padding, conv.subm, conv.transposed)
+    for _ in range(3 if planned else 0):
+        rb.out_table(conv.in_channels)
     (tab_f, flip_f), (tab_b, flip_b) = rb.out_table(conv.in_channels), rb.in_table(conv.out_channels)
+    if planned and conv.in_channels >= 64 and x.indices.shape[0] >= 1024:
+        assert flip_f & 2, "the table should carry its plan by now (FV2P_TAB_PLANNED)"
     return rb, tab_f, flip_f, tab_b, flip_b
 
 
-@pytest.mark.parametrize("c,n", [(16, 1500), (32, 1500), (64, 1500), (128, 1500), (64, 5000), (128, 70)])
-def test_statistics_finalised_by_the_conv_launch(gpu, c, n):
-    """conv_fin leaves mean / invstd of ITS output and the running statistics as BatchNorm1d would compute them: against float64 sums of the
+@pytest.mark.parametrize("c,n,planned", [(16, 1500, False), (32, 1500, False), (64, 1500, False), (128, 1500, False), (64, 5000, False), (128, 70, False),
+                                         (64, 1100, True), (128, 1500, True), (128, 2600, True), (64, 9000, True)])
+def test_statistics_finalised_by_the_conv_launch(gpu, c, n, planned):
+    """(planned: a small table with a tiling plan - 256 tiles for ~1 500 rows - once overran the row buffer of the finalisation.)
+    conv_fin leaves mean / invstd of ITS output and the running statistics as BatchNorm1d would compute them: against float64 sums of the
     conv's own output at 1e-6, running statistics like torch's (momentum 0.01, unbiased variance), num_batches_tracked + 1; a second call
     (the slots were cleared by the last workgroup, the counter reset) gives the same statistics again, and so does a third on another layer
     size in between (one slot buffer per stream serves every layer)."""
@@ -70,7 +78,7 @@ def test_statistics_finalised_by_the_conv_launch(gpu, c, n):
     ind, feats, x = make_input(c * 3 + n, batch, shape, n, c, gpu)
     conv = spconv.SubMConv3d(c, c, 3, padding=1, bias=True, indice_key="k").to(gpu)
     bn = nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(gpu)
-    rb, tab_f, flip_f, tab_b, flip_b = subm_tables(x, conv)
+    rb, tab_f, flip_f, tab_b, flip_b = subm_tables(x, conv, planned)
     rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
 
     def run():
