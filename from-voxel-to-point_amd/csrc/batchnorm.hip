@@ -534,9 +534,12 @@ constexpr int kOneGrid = 128;
 // leaves of the chip is enough up to ~2 M elements (tools/bn_time.py), above that the caller keeps reduce + apply.
 static int one_grid(int c) { return c >= 64 ? 32 : kOneGrid; }
 extern "C" int fv2p_batchnorm_one_pays(int64_t n, int c, int backward) {
+  // measured against the wide reduce + apply (tools/bn_time.py, profiles/r06_bn_time.txt): backward 64 against 73 us at 35 000 x 16 and
+  // 59 against 70 at 39 000 x 32, but 81 against 72 at 22 000 x 64 and 82 against 69 at 10 000 x 128 (32 workgroups are too few for
+  // the two passes over the tensor); forward equal at 16 columns, behind from 32 on
   const int64_t elems = n * c;
   if (elems > (2ll << 20)) return 0;
-  return backward ? 1 : (c <= 32 ? 1 : 0);   // forward: the reduce pass is short (12 - 18 us), one launch only wins on narrow layers
+  return backward ? (c <= 32 ? 1 : 0) : (c <= 16 ? 1 : 0);
 }
 
 __device__ __forceinline__ void grid_arrive_and_wait(unsigned* counters, unsigned total) {
@@ -771,6 +774,112 @@ extern "C" int fv2p_batchnorm_backward_one(const float* x, const float* dy, int6
   const long long units = n * c / (vec ? 4 : 1);
   if (vec) hipLaunchKernelGGL((bn_one_bwd_k<4>), dim3(g.nblk), dim3(256), 0, stream, x, dy, units, g, partial, counters, mean, invstd, gamma, beta, relu, bf, dx, mask_y, dz_out);
   else hipLaunchKernelGGL((bn_one_bwd_k<1>), dim3(g.nblk), dim3(256), 0, stream, x, dy, units, g, partial, counters, mean, invstd, gamma, beta, relu, bf, dx, mask_y, dz_out);
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- two launches, the first one wide: reduce on up to 512 workgroups with the sums finalised by its last workgroups, then apply -------
+// The decoder's Linear -> BatchNorm1d -> ReLU rows are 49 152 x 64 / 128 (12 - 25 MB): too large for the one-launch form, and their
+// reduce pass ran on <= 64 workgroups because EVERY apply workgroup folded all the partials (36.5 us backward, 18.5 us forward:
+// ~1.4 TB/s).  With the finalisation of bn_fold.hpp the partials are folded once, by the reduce launch's own last workgroups, so the
+// reduce can be as wide as the tensor wants and the apply pass reads finished numbers (mean / invstd, or c1 / c2).
+constexpr int kWideGrid = 512;
+template <int V, bool BWD>
+__global__ __launch_bounds__(256) void bn_reduce_fin_k(const float* __restrict__ x, const float* __restrict__ dy, BnGeom g, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       int relu, const float* __restrict__ mask_y, double* __restrict__ rows, double* __restrict__ gslots,
+                                                       unsigned* __restrict__ counter, int groups, FinOut fo) {
+  __shared__ double red1[2][256 * V];
+  __shared__ unsigned flag;
+  one_reduce<V, BWD>(x, dy, g, mean, invstd, gamma, beta, relu, mask_y, rows, red1);   // publishes row blockIdx.x of rows [nblk][2][c]
+  __syncthreads();
+  for (int e0 = 0; e0 < g.c; e0 += 128) {   // the protocol handles <= 128 columns a pass; every pass sees all workgroups (counters reset in between)
+    FinOut f = fo;
+    const int cc = min(128, g.c - e0);
+    f.ff.mean = fo.ff.mean ? fo.ff.mean + e0 : nullptr; f.ff.invstd = fo.ff.invstd ? fo.ff.invstd + e0 : nullptr;
+    f.ff.running_mean = fo.ff.running_mean ? fo.ff.running_mean + e0 : nullptr; f.ff.running_var = fo.ff.running_var ? fo.ff.running_var + e0 : nullptr;
+    f.bf.dgamma = fo.bf.dgamma ? fo.bf.dgamma + e0 : nullptr; f.bf.dbeta = fo.bf.dbeta ? fo.bf.dbeta + e0 : nullptr; f.bf.coef = fo.bf.coef ? fo.bf.coef + e0 : nullptr;
+    f.bump = fo.bump && (e0 + 128 >= g.c);
+    fin_rows_done(rows + e0, gslots + e0, counter + (e0 / 128) * ((1 + kFinSubs) * kFinStride), static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x), 1, groups,
+                  cc, g.c, &flag, reinterpret_cast<double (*)[256]>(&red1[0][0]), f);
+    __syncthreads();
+  }
+}
+
+extern "C" size_t fv2p_batchnorm_wide_ws_bytes(int c) {
+  Sizer s;
+  s.take<double>(static_cast<size_t>(kWideGrid + kFinSubs) * 2 * (c > 0 ? c : 1));
+  s.take<float>(2 * static_cast<size_t>(c > 0 ? c : 1));   // c1, c2 of the backward pass
+  return s.bytes();
+}
+extern "C" int fv2p_batchnorm_wide_counter_words(int c) { return static_cast<int>(((c > 0 ? c : 1) + 127) / 128 * (1 + kFinSubs) * kFinStride); }
+
+// fv2p_batchnorm_forward (+ optional residual) with the wide reduce: two launches, nothing folded in the apply pass.  counters:
+// fv2p_batchnorm_wide_counter_words(c) zeroed device words the caller keeps per stream (zero again when the reduce launch ends).
+extern "C" int fv2p_batchnorm_forward_wide(const float* x, int64_t n, int c, float eps, float momentum, const float* gamma, const float* beta,
+                                           int relu, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean,
+                                           float* invstd, const float* residual, float* y, void* ws, size_t ws_bytes, unsigned* counters,
+                                           fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FV2P_REQUIRE(n >= 1 && c >= 1, FV2P_EINVAL, "batchnorm_forward_wide: n=%lld c=%d", static_cast<long long>(n), c);
+  FV2P_REQUIRE(x && y && mean && invstd && ws && counters, FV2P_EINVAL, "batchnorm_forward_wide: null pointer");
+  FV2P_REQUIRE((running_mean == nullptr) == (running_var == nullptr), FV2P_EINVAL, "batchnorm_forward_wide: running_mean and running_var come together");
+  FV2P_REQUIRE(ws_bytes >= fv2p_batchnorm_wide_ws_bytes(c), FV2P_EWORKSPACE, "batchnorm_forward_wide: workspace too small");
+  const bool vec = (c % 4 == 0) && aligned16(x) && aligned16(y) && (!residual || aligned16(residual));
+  BnGeom g;
+  FV2P_REQUIRE(bn_geom(n, c, vec, &g, kWideGrid) == 0, FV2P_ELIMIT, "batchnorm: c=%d exceeds %d", c, vec ? kBnMaxC : 256);
+  Carver cv(ws, ws_bytes);
+  double* rows = cv.take<double>(static_cast<size_t>(kWideGrid + kFinSubs) * 2 * c);
+  double* gslots = rows + static_cast<size_t>(kWideGrid) * 2 * c;
+  FinOut fo;
+  fo.bwd = 0; fo.n = n; fo.bump = 1; fo.coef_ld = c;
+  fo.ff = BnFwdFin{mean, invstd, running_mean, running_var, reinterpret_cast<long long*>(num_batches_tracked), momentum, eps};
+  fo.bf = BnBwdFin{nullptr, nullptr, nullptr, 1};
+  const int groups = g.nblk > 256 ? 32 : 16;
+  const long long units = n * c / (vec ? 4 : 1);
+  const unsigned blocks = apply_blocks(units);
+  BnFwdFin ffa{mean, invstd, nullptr, nullptr, nullptr, 0.f, 0.f};
+  if (vec) {
+    hipLaunchKernelGGL((bn_reduce_fin_k<4, false>), dim3(g.nblk), dim3(256), 0, stream, x, nullptr, g, nullptr, nullptr, nullptr, nullptr, 0, nullptr, rows, gslots, counters, groups, fo);
+    hipLaunchKernelGGL((bn_apply_fwd_k<4, false>), dim3(blocks), dim3(256), 0, stream, x, units, g, nullptr, ffa, gamma, beta, relu, y, nullptr, 0, residual);
+  } else {
+    hipLaunchKernelGGL((bn_reduce_fin_k<1, false>), dim3(g.nblk), dim3(256), 0, stream, x, nullptr, g, nullptr, nullptr, nullptr, nullptr, 0, nullptr, rows, gslots, counters, groups, fo);
+    hipLaunchKernelGGL((bn_apply_fwd_k<1, false>), dim3(blocks), dim3(256), 0, stream, x, units, g, nullptr, ffa, gamma, beta, relu, y, nullptr, 0, residual);
+  }
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int fv2p_batchnorm_backward_wide(const float* x, const float* dy, int64_t n, int c, const float* mean, const float* invstd,
+                                            const float* gamma, const float* beta, int relu, int batch_stats, const float* mask_y, float* dx,
+                                            float* dz_out, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, unsigned* counters,
+                                            fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  FV2P_REQUIRE(n >= 1 && c >= 1, FV2P_EINVAL, "batchnorm_backward_wide: n=%lld c=%d", static_cast<long long>(n), c);
+  FV2P_REQUIRE(x && dy && mean && invstd && dx && dgamma && dbeta && ws && counters, FV2P_EINVAL, "batchnorm_backward_wide: null pointer");
+  FV2P_REQUIRE(ws_bytes >= fv2p_batchnorm_wide_ws_bytes(c), FV2P_EWORKSPACE, "batchnorm_backward_wide: workspace too small");
+  const bool vec = (c % 4 == 0) && aligned16(x) && aligned16(dy) && aligned16(dx) && (!mask_y || aligned16(mask_y)) && (!dz_out || aligned16(dz_out));
+  BnGeom g;
+  FV2P_REQUIRE(bn_geom(n, c, vec, &g, kWideGrid) == 0, FV2P_ELIMIT, "batchnorm: c=%d exceeds %d", c, vec ? kBnMaxC : 256);
+  Carver cv(ws, ws_bytes);
+  double* rows = cv.take<double>(static_cast<size_t>(kWideGrid + kFinSubs) * 2 * c);
+  double* gslots = rows + static_cast<size_t>(kWideGrid) * 2 * c;
+  float* coef = cv.take<float>(2 * static_cast<size_t>(c));
+  FinOut fo;
+  fo.bwd = 1; fo.n = n; fo.bump = 0; fo.coef_ld = c;
+  fo.ff = BnFwdFin{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f};
+  fo.bf = BnBwdFin{dgamma, dbeta, coef, batch_stats};
+  const int groups = g.nblk > 256 ? 32 : 16;
+  const long long units = n * c / (vec ? 4 : 1);
+  const unsigned blocks = apply_blocks(units);
+  BnBwdFin bfa{nullptr, nullptr, coef, batch_stats};
+  if (vec) {
+    hipLaunchKernelGGL((bn_reduce_fin_k<4, true>), dim3(g.nblk), dim3(256), 0, stream, x, dy, g, mean, invstd, gamma, beta, relu, mask_y, rows, gslots, counters, groups, fo);
+    hipLaunchKernelGGL((bn_apply_bwd_k<4, false>), dim3(blocks), dim3(256), 0, stream, x, dy, units, g, nullptr, mean, invstd, gamma, beta, relu, bfa, dx, nullptr, 0, mask_y, dz_out);
+  } else {
+    hipLaunchKernelGGL((bn_reduce_fin_k<1, true>), dim3(g.nblk), dim3(256), 0, stream, x, dy, g, mean, invstd, gamma, beta, relu, mask_y, rows, gslots, counters, groups, fo);
+    hipLaunchKernelGGL((bn_apply_bwd_k<1, false>), dim3(blocks), dim3(256), 0, stream, x, dy, units, g, nullptr, mean, invstd, gamma, beta, relu, bfa, dx, nullptr, 0, mask_y, dz_out);
+  }
   FV2P_LAUNCH_CHECK();
   return 0;
 }

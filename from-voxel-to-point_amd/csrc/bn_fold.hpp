@@ -94,6 +94,89 @@ __device__ __forceinline__ void bn_fwd_channel(double a, double b, long long n_r
   }
 }
 
+// ---- finalisation of per-tile rows by the launch's last workgroups (conv_stats_done in sparse_conv.hip, bn_reduce_fin_k in batchnorm.hip) ------
+// Protocol (every workgroup of the launch calls fin_rows_done once, after it PUBLISHED its row with stat_publish):
+//   s_waitcnt vmcnt(0): the row's atomics have been performed; the workgroup counts itself in on the word of its group (tile % G);
+//   whoever completes a group folds the group's rows, in row order, into the group's slot and counts the group in on the top word;
+//   whoever completes the top word folds the slots, in group order, and writes the results (FinOut).
+// Other workgroups' rows are read with agent-scope loads.  No fence, no float atomic add, nothing to clear; the sums are bit-identical
+// from run to run.  counter: fv2p_sparse_conv_fin_counter_words() zeroed words, zero again when the launch ends.
+constexpr unsigned kFinSubs = 64, kFinStride = 32;   // counter: [0] the top word, [(1 + g) * kFinStride] group g
+struct FinOut {
+  int bwd;          // 0: (sum x, sum x^2) -> mean / invstd / running statistics;  1: (sum dz, sum dz * xhat) -> dgamma / dbeta / coef
+  long long n;      // rows of the statistic
+  BnFwdFin ff;
+  BnBwdFin bf;
+  int bump;         // forward: advance num_batches_tracked
+  int coef_ld;      // backward: coef[0][c] at coef, coef[1][c] at coef + coef_ld
+};
+// one thread: the sum over `count` doubles p[0], p[stride], ... in that order, with the loads batched sixteen deep (an agent-scope
+// load is a ~0.4 us round trip past the L2)
+__device__ __forceinline__ double fin_sum(const double* p, int count, long long stride) {
+  double acc = 0.0;
+  for (int r0 = 0; r0 < count; r0 += 16) {
+    double v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = (r0 + i < count) ? stat_load<true>(p + (r0 + i) * stride) : 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc += v[i];   // (x + 0.0 == x)
+  }
+  return acc;
+}
+// c <= 128 columns (one (column, which) pair per thread of the first 256); ld: row stride of rows / slots in doubles;
+// flag, red: LDS scratch (one word, [2][256] doubles) nothing else uses any more
+__device__ __forceinline__ void fin_rows_done(double* rows, double* gslots, unsigned* counter, int tile, int n_tiles, int ncb, int G, int c, int ld,
+                                              unsigned* flag, double (*red)[256], const FinOut& fo) {
+  const int tid = threadIdx.x;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int grp = tile % G;
+  if (tid == 0) {
+    const unsigned expect = static_cast<unsigned>((n_tiles - grp + G - 1) / G) * static_cast<unsigned>(ncb);
+    unsigned* word = counter + (1 + grp) * kFinStride;
+    unsigned role = 0u;
+    if (__hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expect - 1u) {
+      __hip_atomic_store(word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      role = 1u;
+    }
+    *flag = role;
+  }
+  __syncthreads();
+  if (*flag == 0u || tid >= 256) return;   // (a 1024-thread workgroup folds with its first four waves)
+  const int which = tid / c, e = tid % c;
+  const bool mine = tid < 2 * c;
+  double* gslot = gslots + static_cast<long long>(grp) * 2 * ld;
+  if (mine) {
+    const int count = (n_tiles - grp + G - 1) / G;
+    stat_publish(gslot + static_cast<long long>(which) * ld + e, fin_sum(rows + (static_cast<long long>(grp) * 2 + which) * ld + e, count, static_cast<long long>(G) * 2 * ld));
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int groups = n_tiles < G ? n_tiles : G;
+  if (tid == 0) *flag = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == static_cast<unsigned>(groups) - 1u ? 2u : 0u;
+  __syncthreads();
+  if (*flag != 2u) return;
+  if (mine) red[which][e] = fin_sum(gslots + static_cast<long long>(which) * ld + e, groups, 2ll * ld);
+  __syncthreads();
+  if (tid < c) {
+    const double sa = red[0][tid], sb = red[1][tid];
+    if (!fo.bwd) {
+      float mu, is;
+      bn_fwd_channel(sa, sb, fo.n, fo.ff, tid, true, &mu, &is);
+    } else {
+      const double nn = static_cast<double>(fo.n);
+      fo.bf.dbeta[tid] = static_cast<float>(sa);
+      fo.bf.dgamma[tid] = static_cast<float>(sb);
+      fo.bf.coef[tid] = fo.bf.batch_stats ? static_cast<float>(sa / nn) : 0.f;
+      fo.bf.coef[fo.coef_ld + tid] = fo.bf.batch_stats ? static_cast<float>(sb / nn) : 0.f;
+    }
+  }
+  if (tid == 0) {
+    if (!fo.bwd && fo.bump && fo.ff.running_mean && fo.ff.num_batches_tracked) *fo.ff.num_batches_tracked += 1;
+    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // one-workgroup finalisation of sums a separate pass took (batchnorm.hip)
 int bn_finalize_forward(double* stats, int64_t n, int c, const BnFwdFin& ff, hipStream_t stream);
 int bn_finalize_backward(double* stats, int64_t n, int c, const BnBwdFin& bf, hipStream_t stream);

@@ -136,33 +136,16 @@ __device__ __forceinline__ void tile_stats(const ConvArgs& a, const float (&vals
 // ---- finalisation by the last workgroups of the launch ------------------------------------------------------------------------------
 // Every workgroup calls this once, at its very end (fv2p_sparse_conv_rows_bnfin / _bnbwd_fin only: a.fin_counter).
 //   1. the lanes' sums (StatAcc) are reduced over the wave's four row quads (shuffles) and over the workgroup's waves (LDS, wave
-//      order), and stored as row `tile` of fin_rows [tiles][2][stats_ld] - plain agent-scope stores, one row per tile whichever
-//      column block the workgroup computed;
-//   2. s_waitcnt vmcnt(0) returns when those stores have been acknowledged at the coherence point of the eight XCDs; only then the
-//      workgroup counts itself in on the word of its GROUP (tile % groups).  Whoever completes a group folds the group's rows, in row
-//      order, into the group's slot and counts the group in on the top word; whoever completes the top word folds the group slots, in
-//      group order, and writes mean / invstd / running statistics (forward) or dgamma / dbeta / c1 / c2 (backward sums).
-// Loads of other workgroups' rows are agent-scope loads (a plain load could hit a stale line of this XCD's L2).  No fence (a release
-// fence writes the whole L2 back on gfx950: 20 us), no float atomics, nothing to clear: rows and slots are overwritten by the next
-// launch.  Measured against the first form of this round (fp64 atomics into 16 slots, one last workgroup folding and clearing them:
-// + 8 - 13 us per launch, the waves waiting for ~250 k memory-side atomics): see profiles/README.md.
+//      order), and published as row `tile` of fin_rows [tiles][2][stats_ld] (stat_publish: exchange atomics), one row per tile
+//      whichever column block the workgroup computed;
+//   2. fin_rows_done (bn_fold.hpp): the group / top-word protocol that folds the rows in a fixed order and writes mean / invstd /
+//      running statistics (forward) or dgamma / dbeta / c1 / c2 (backward sums).
+// No fence (a release fence writes the whole L2 back on gfx950: 20 us), no float atomic adds, nothing to clear: rows and slots are
+// overwritten by the next launch.  Measured against the first form of this round (fp64 atomic adds into 16 slots, one last workgroup
+// folding and clearing them: + 8 - 13 us per launch, the waves waiting for ~250 k memory-side atomics): profiles/README.md.
 // scratch: kStatsDoneLds bytes of the kernel's DYNAMIC LDS that nothing else uses any more (no static LDS: the K-split tile fills a
 // CU's 160 KB with two workgroups to within 768 bytes).
 constexpr size_t kStatsDoneLds = 9 * 1024;   // the largest [waves][2][columns] in use + the fold's buffer
-constexpr unsigned kFinSubs = 64, kFinStride = 32;   // fin_counter: [0] the top word, [(1 + g) * kFinStride] group g; fv2p_sparse_conv_fin_counter_words() of them
-// one thread: the sum over `count` doubles p[0], p[stride], ... in that order, with the loads batched sixteen deep (an agent-scope
-// load is a ~0.4 us round trip past the L2)
-__device__ __forceinline__ double fin_sum(const double* p, int count, long long stride) {
-  double acc = 0.0;
-  for (int r0 = 0; r0 < count; r0 += 16) {
-    double v[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = (r0 + i < count) ? stat_load<true>(p + (r0 + i) * stride) : 0.0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc += v[i];   // (x + 0.0 == x)
-  }
-  return acc;
-}
 template <int NV>
 __device__ __forceinline__ void conv_stats_done(const ConvArgs& a, void* scratch, const StatAcc<NV>& acc, const int (&cols)[NV], int tile, int n_tiles, int ncb) {
   if (!a.fin_counter) return;   // uniform
@@ -170,7 +153,7 @@ __device__ __forceinline__ void conv_stats_done(const ConvArgs& a, void* scratch
   constexpr int LC = NV * 16;   // columns this workgroup computed (local index i * 16 + n)
   double* part = reinterpret_cast<double*>(scratch);                    // [nw][2][LC]
   int* colmap = reinterpret_cast<int*>(part + nw * 2 * LC);             // [LC] launch column of a local column (-1: past the end)
-  unsigned* flag = reinterpret_cast<unsigned*>(colmap + LC);
+  unsigned* flag = reinterpret_cast<unsigned*>(static_cast<char*>(scratch) + kStatsDoneLds - 16);   // behind everything the fold reuses
   double s1[NV], s2[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -197,56 +180,9 @@ __device__ __forceinline__ void conv_stats_done(const ConvArgs& a, void* scratch
       stat_publish(a.fin_rows + (static_cast<long long>(tile) * 2 + which) * ld + gc, t);
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  const int G = a.fin_groups, grp = tile % G;
-  if (tid == 0) {
-    const unsigned expect = static_cast<unsigned>((n_tiles - grp + G - 1) / G) * static_cast<unsigned>(ncb);
-    unsigned* word = a.fin_counter + (1 + grp) * kFinStride;
-    unsigned role = 0u;
-    if (__hip_atomic_fetch_add(word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expect - 1u) {
-      __hip_atomic_store(word, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      role = 1u;
-    }
-    *flag = role;
-  }
-  __syncthreads();
-  if (*flag == 0u || tid >= 256) return;   // (a 1024-thread workgroup folds with its first four waves)
-  const int c = a.fin_c;                   // <= 128 columns per launch: one (column, which) pair per thread
-  const int which = tid / c, e = tid % c;
-  const bool mine = tid < 2 * c;
-  double* gslot = a.fin_gslots + static_cast<long long>(grp) * 2 * ld;
-  if (mine) {
-    const int count = (n_tiles - grp + G - 1) / G;
-    const double t = fin_sum(a.fin_rows + (static_cast<long long>(grp) * 2 + which) * ld + e, count, static_cast<long long>(G) * 2 * ld);
-    stat_publish(gslot + static_cast<long long>(which) * ld + e, t);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  const int groups = n_tiles < G ? n_tiles : G;
-  if (tid == 0) *flag = __hip_atomic_fetch_add(a.fin_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == static_cast<unsigned>(groups) - 1u ? 2u : 0u;
-  __syncthreads();
-  if (*flag != 2u) return;
-  double (*red)[256] = reinterpret_cast<double (*)[256]>(part);   // [2][c] totals
-  if (mine) red[which][e] = fin_sum(a.fin_gslots + static_cast<long long>(which) * ld + e, groups, 2ll * ld);
-  __syncthreads();
-  if (tid < c) {
-    const double sa = red[0][tid], sb = red[1][tid];
-    if (a.bn_x == nullptr) {
-      float mu, is;
-      bn_fwd_channel(sa, sb, a.n_dst, a.fin_fwd, tid, true, &mu, &is);
-    } else {
-      const double nn = static_cast<double>(a.n_dst);
-      a.fin_bwd.dbeta[tid] = static_cast<float>(sa);
-      a.fin_bwd.dgamma[tid] = static_cast<float>(sb);
-      a.fin_bwd.coef[tid] = a.fin_bwd.batch_stats ? static_cast<float>(sa / nn) : 0.f;
-      a.fin_bwd.coef[ld + tid] = a.fin_bwd.batch_stats ? static_cast<float>(sb / nn) : 0.f;
-    }
-  }
-  if (tid == 0) {
-    if (a.bn_x == nullptr && a.fin_bump && a.fin_fwd.running_mean && a.fin_fwd.num_batches_tracked) *a.fin_fwd.num_batches_tracked += 1;
-    __hip_atomic_store(a.fin_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  FinOut fo;
+  fo.bwd = a.bn_x != nullptr; fo.n = a.n_dst; fo.ff = a.fin_fwd; fo.bf = a.fin_bwd; fo.bump = a.fin_bump; fo.coef_ld = ld;
+  fin_rows_done(a.fin_rows, a.fin_gslots, a.fin_counter, tile, n_tiles, ncb, a.fin_groups, a.fin_c, ld, flag, reinterpret_cast<double (*)[256]>(part), fo);
 }
 
 // source-row BatchNorm (+ReLU) on the gather: v holds source channels c0 .. c0 + 3 of a row that exists (`valid`; "no neighbour" stays 0).

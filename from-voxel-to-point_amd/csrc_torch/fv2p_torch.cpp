@@ -116,6 +116,13 @@ void set_bn_epilogue(bool on) { g_bn_epilogue = on ? 1 : 0; }
 // two zeroed device words per (device, stream) for the one-launch BatchNorm passes (fv2p_batchnorm_forward_one / _backward_one);
 // defined with the round-6 state further down
 unsigned* one_counters(const at::Tensor& like, void* stream);
+unsigned* wide_counters(const at::Tensor& like, void* stream);
+static int g_bn_wide = -1;   // FV2P_BN_WIDE=0 / set_bn_wide(false): reduce on <= 64 workgroups + apply that folds (rounds 2 - 5)
+bool bn_wide() {
+  if (g_bn_wide < 0) { const char* e = std::getenv("FV2P_BN_WIDE"); g_bn_wide = !(e && e[0] == '0'); }
+  return g_bn_wide != 0;
+}
+void set_bn_wide(bool on) { g_bn_wide = on ? 1 : 0; }
 static int g_bn_one = -1;   // FV2P_BN_ONE=0 / set_bn_one(false): the two-launch passes (tests compare the two)
 bool bn_one() {
   if (g_bn_one < 0) { const char* e = std::getenv("FV2P_BN_ONE"); g_bn_one = !(e && e[0] == '0'); }
@@ -160,6 +167,13 @@ struct BnReluFn : public torch::autograd::Function<BnReluFn> {
                                          nbt, mean.data_ptr<float>(), invstd.data_ptr<float>(), nullptr, y.data_ptr<float>(), ws.data_ptr(),
                                          static_cast<size_t>(ws.numel()), one_counters(x, stream), stream),
               "fv2p_batchnorm_forward_one");
+      } else if (bn_wide()) {   // large tensors: reduce on up to 512 workgroups, finalised by that launch; apply reads mean / invstd
+        at::Tensor ws = workspace(fv2p_batchnorm_wide_ws_bytes(static_cast<int>(c)), x, stream);
+        check(fv2p_batchnorm_forward_wide(x.data_ptr<float>(), n, static_cast<int>(c), static_cast<float>(eps), static_cast<float>(momentum), gamma, beta,
+                                          relu ? 1 : 0, track ? running_mean->data_ptr<float>() : nullptr, track ? running_var->data_ptr<float>() : nullptr,
+                                          nbt, mean.data_ptr<float>(), invstd.data_ptr<float>(), nullptr, y.data_ptr<float>(), ws.data_ptr(),
+                                          static_cast<size_t>(ws.numel()), wide_counters(x, stream), stream),
+              "fv2p_batchnorm_forward_wide");
       } else {
       at::Tensor ws = workspace(fv2p_batchnorm_ws_bytes(n, static_cast<int>(c)), x, stream);
       check(fv2p_batchnorm_forward(x.data_ptr<float>(), n, static_cast<int>(c), static_cast<float>(eps), static_cast<float>(momentum), gamma, beta,
@@ -224,6 +238,14 @@ struct BnReluFn : public torch::autograd::Function<BnReluFn> {
                                         nullptr, dpar[0].data_ptr<float>(), dpar[1].data_ptr<float>(), ws.data_ptr(), static_cast<size_t>(ws.numel()),
                                         one_counters(x, stream), stream),
             "fv2p_batchnorm_backward_one");
+    } else if (bn_wide()) {
+      at::Tensor ws = workspace(fv2p_batchnorm_wide_ws_bytes(static_cast<int>(c)), x, stream);
+      check(fv2p_batchnorm_backward_wide(x.data_ptr<float>(), dy.data_ptr<float>(), n, static_cast<int>(c), mean.data_ptr<float>(), invstd.data_ptr<float>(),
+                                         weight.defined() ? weight.data_ptr<float>() : nullptr, bias.defined() ? bias.data_ptr<float>() : nullptr,
+                                         ctx->saved_data["relu"].toBool() ? 1 : 0, ctx->saved_data["batch_stats"].toBool() ? 1 : 0, nullptr, dx.data_ptr<float>(),
+                                         nullptr, dpar[0].data_ptr<float>(), dpar[1].data_ptr<float>(), ws.data_ptr(), static_cast<size_t>(ws.numel()),
+                                         wide_counters(x, stream), stream),
+            "fv2p_batchnorm_backward_wide");
     } else {
     at::Tensor ws = workspace(fv2p_batchnorm_ws_bytes(n, static_cast<int>(c)), x, stream);
     check(fv2p_batchnorm_backward(x.data_ptr<float>(), dy.data_ptr<float>(), n, static_cast<int>(c), mean.data_ptr<float>(), invstd.data_ptr<float>(),
@@ -499,13 +521,17 @@ FinState& fin_state(const at::Tensor& like, void* stream) {
   auto it = pool.find(key);
   if (it == pool.end()) {
     FinState f;
-    f.counter = at::zeros({2 * static_cast<int64_t>(fv2p_sparse_conv_fin_counter_words()) + 4}, like.options().dtype(at::kInt));   // forward | backward | 4 words of the one-launch BatchNorms
+    f.counter = at::zeros({2 * static_cast<int64_t>(fv2p_sparse_conv_fin_counter_words()) + 4 + fv2p_batchnorm_wide_counter_words(1024)},
+                          like.options().dtype(at::kInt));   // conv forward | conv backward | 4 words of the one-launch BatchNorms | the wide BatchNorm reduce
     it = pool.emplace(key, std::move(f)).first;
   }
   return it->second;
 }
 unsigned* one_counters(const at::Tensor& like, void* stream) {
   return reinterpret_cast<unsigned*>(fin_state(like, stream).counter.data_ptr<int>()) + 2 * fv2p_sparse_conv_fin_counter_words();
+}
+unsigned* wide_counters(const at::Tensor& like, void* stream) {
+  return reinterpret_cast<unsigned*>(fin_state(like, stream).counter.data_ptr<int>()) + 2 * fv2p_sparse_conv_fin_counter_words() + 4;
 }
 static int g_bn_fold = -1;   // FV2P_BN_FOLD=0 / set_bn_fold(false): the Python layer keeps the round-5 arrangement (tests compare the two)
 bool bn_fold() {
@@ -561,6 +587,12 @@ struct BnApplyFn : public torch::autograd::Function<BnApplyFn> {
                                           batch_stats ? 1 : 0, out.data_ptr<float>(), dx.data_ptr<float>(), dz.data_ptr<float>(), dpar[0].data_ptr<float>(),
                                           dpar[1].data_ptr<float>(), ws1.data_ptr(), static_cast<size_t>(ws1.numel()), one_counters(x, stream), stream),
               "fv2p_batchnorm_backward_one");
+      } else if (relu && bn_wide()) {
+        at::Tensor ws2 = workspace(fv2p_batchnorm_wide_ws_bytes(static_cast<int>(c)), x, stream);
+        check(fv2p_batchnorm_backward_wide(x.data_ptr<float>(), dy.data_ptr<float>(), n, static_cast<int>(c), mean, invstd, fptr(weight), fptr(bias), 1,
+                                           batch_stats ? 1 : 0, out.data_ptr<float>(), dx.data_ptr<float>(), dz.data_ptr<float>(), dpar[0].data_ptr<float>(),
+                                           dpar[1].data_ptr<float>(), ws2.data_ptr(), static_cast<size_t>(ws2.numel()), wide_counters(x, stream), stream),
+              "fv2p_batchnorm_backward_wide");
       } else if (relu) {
         check(fv2p_batchnorm_backward_res(x.data_ptr<float>(), out.data_ptr<float>(), dy.data_ptr<float>(), n, static_cast<int>(c), mean, invstd, fptr(weight),
                                           fptr(bias), batch_stats ? 1 : 0, dx.data_ptr<float>(), dz.data_ptr<float>(), dpar[0].data_ptr<float>(),
@@ -596,6 +628,12 @@ struct BnApplyFn : public torch::autograd::Function<BnApplyFn> {
                                         batch_stats ? 1 : 0, nullptr, dx.data_ptr<float>(), nullptr, dpar[0].data_ptr<float>(), dpar[1].data_ptr<float>(),
                                         ws1.data_ptr(), static_cast<size_t>(ws1.numel()), one_counters(x, stream), stream),
             "fv2p_batchnorm_backward_one");
+    } else if (bn_wide()) {
+      at::Tensor ws2 = workspace(fv2p_batchnorm_wide_ws_bytes(static_cast<int>(c)), x, stream);
+      check(fv2p_batchnorm_backward_wide(x.data_ptr<float>(), dy.data_ptr<float>(), n, static_cast<int>(c), mean, invstd, fptr(weight), fptr(bias), relu ? 1 : 0,
+                                         batch_stats ? 1 : 0, nullptr, dx.data_ptr<float>(), nullptr, dpar[0].data_ptr<float>(), dpar[1].data_ptr<float>(),
+                                         ws2.data_ptr(), static_cast<size_t>(ws2.numel()), wide_counters(x, stream), stream),
+            "fv2p_batchnorm_backward_wide");
     } else {
       at::Tensor ws = workspace(fv2p_batchnorm_ws_bytes(n, static_cast<int>(c)), x, stream);
       check(fv2p_batchnorm_backward(x.data_ptr<float>(), dy.data_ptr<float>(), n, static_cast<int>(c), mean, invstd, fptr(weight), fptr(bias), relu ? 1 : 0,
@@ -1006,5 +1044,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("bn_fold", &bn_fold);
   m.def("set_bn_one", &set_bn_one, "BatchNorm passes without conv-epilogue sums as one launch each (default) or as reduce + apply");
   m.def("bn_one", &bn_one);
+  m.def("set_bn_wide", &set_bn_wide, "large BatchNorm passes with the wide reduce finalised by its own launch (default) or the <= 64-workgroup reduce + folding apply");
+  m.def("bn_wide", &bn_wide);
   m.def("sparse_conv_bn_relu", &sparse_conv_bn_relu, "sparse conv -> BatchNorm1d (-> ReLU) with autograd, one call per backbone block");
 }

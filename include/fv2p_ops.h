@@ -618,6 +618,20 @@ int fv2p_batchnorm_backward_one(const float* x, const float* dy, int64_t n, int 
                                 const float* gamma, const float* beta, int relu, int batch_stats, const float* mask_y, float* dx,
                                 float* dz_out, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, unsigned* counters,
                                 fv2p_stream_t stream);
+/* round 6: the two-launch passes for large tensors (the decoder's 49 152-row layers) with a WIDE reduce: up to 512 workgroups publish
+ * their partial sums as rows, the reduce launch's last workgroups fold them in a fixed order (the protocol of
+ * fv2p_sparse_conv_rows_bnfin) and the apply launch reads finished mean / invstd or c1 / c2.  counters:
+ * fv2p_batchnorm_wide_counter_words(c) zeroed device words kept by the caller per stream. */
+size_t fv2p_batchnorm_wide_ws_bytes(int c);
+int fv2p_batchnorm_wide_counter_words(int c);
+int fv2p_batchnorm_forward_wide(const float* x, int64_t n, int c, float eps, float momentum, const float* gamma, const float* beta,
+                                int relu, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean,
+                                float* invstd, const float* residual, float* y, void* ws, size_t ws_bytes, unsigned* counters,
+                                fv2p_stream_t stream);
+int fv2p_batchnorm_backward_wide(const float* x, const float* dy, int64_t n, int c, const float* mean, const float* invstd,
+                                 const float* gamma, const float* beta, int relu, int batch_stats, const float* mask_y, float* dx,
+                                 float* dz_out, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, unsigned* counters,
+                                 fv2p_stream_t stream);
 int fv2p_batchnorm_apply(const float* x, int64_t n, int c, const float* mean, const float* invstd,
                          const float* gamma, const float* beta, int relu, float* y, fv2p_stream_t stream);
 int fv2p_batchnorm_backward(const float* x, const float* dy, int64_t n, int c, const float* mean,

@@ -306,8 +306,9 @@ def test_one_launch_batchnorm_passes(gpu, n, c, relu):
     x0 = torch.randn(n, c, device=gpu) * 1.5 + 0.3
     g = torch.randn(n, c, device=gpu)
 
-    def run(one):
+    def run(one, wide=True):
         e.set_bn_one(one)
+        e.set_bn_wide(wide)
         torch.manual_seed(1)
         bn = nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(gpu)
         with torch.no_grad():
@@ -319,12 +320,21 @@ def test_one_launch_batchnorm_passes(gpu, n, c, relu):
         y.backward(g)
         return y.detach(), x.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(), bn.running_var.clone(), bn.weight.detach().clone(), bn.bias.detach().clone()
     try:
-        one, two = run(True), run(False)
+        one, two = run(True), run(False, False)
         for _ in range(20):
             again = run(True)
         assert all(torch.equal(a, b) for a, b in zip(one, again))
+        # the large-tensor form: reduce on up to 512 workgroups finalised by that launch + apply (what run(True) uses above ~2 M elements)
+        wide = run(False, True)
+        for _ in range(5):
+            wide_again = run(False, True)
+        assert all(torch.equal(a, b) for a, b in zip(wide, wide_again))
+        assert rel(wide[0], two[0]) < 1e-6 and rel(wide[4], two[4]) < 1e-6 and rel(wide[5], two[5]) < 1e-6
+        for a, b in zip(wide[1:4], two[1:4]):
+            assert rel(a, b) < 1e-5
     finally:
         e.set_bn_one(True)
+        e.set_bn_wide(True)
     assert rel(one[0], two[0]) < 1e-6 and rel(one[4], two[4]) < 1e-6 and rel(one[5], two[5]) < 1e-6
     for a, b in zip(one[1:4], two[1:4]):
         assert rel(a, b) < 1e-5
