@@ -185,7 +185,7 @@ SparseConvolution._conv_bn_relu = _conv_bn_relu
 # 1.68 ms per step.  The residual blocks are where the arrangement pays (no bias add, no separate reduce pass, no add / ReLU launches, no
 # relu(bn1(y1)) tensor: VoxelResBackBone8x 4.01 against 4.47 ms per step), so only they use it (fv2p_harness/backbone.py); the flag keeps
 # the path testable (tests/test_bn_fold_gpu.py).
-FOLD_SEQUENTIAL = False
+FOLD_SEQUENTIAL = os.environ.get("FV2P_FOLD_SEQUENTIAL", "0") == "1"
 
 
 def fold_enabled():
