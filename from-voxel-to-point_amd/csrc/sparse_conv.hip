@@ -944,10 +944,12 @@ __global__ __launch_bounds__(256) void conv_rows_act(ConvArgs a) {
 // Non-transposed product (rows as A, weights as B): the accumulators have the layout conv_epilogue expects.  B of lane (n, g), k-step
 // (j, t), column tile nb = W_k[16 j + 4 g + t][16 nb + n]: 16 bytes along k in the transposed layout (WT), four dwords otherwise.
 // PRE: BatchNorm (+ReLU) of the source rows applied on the gather (ConvArgs::pre_*: the lane's 4 J channels' parameters in registers).
-template <int CINP, int NB, bool WT, int KVOL, bool PRE = false>
+// DEPTH: offsets whose rows and weight fragment are in flight (8 registers per stage at 16 channels).  Two until round 6; at 35 k rows the
+// launch has two waves per SIMD and every wave walks 27 dependent-latency offsets - see the dispatcher for what deeper prefetch measured.
+template <int CINP, int NB, bool WT, int KVOL, bool PRE = false, int DEPTH = 2>
 __global__ __launch_bounds__(256) void conv_rows_thin(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // only conv_stats_done's scratch
-  constexpr int J = CINP / 16, D = 2, NST = D + 1;
+  constexpr int J = CINP / 16, D = DEPTH, NST = D + 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
   const int row0 = (xcd_major_tile(blockIdx.x, gridDim.x) * 4 + wave) * 16;
   StatAcc<NB> sacc;
@@ -1025,7 +1027,9 @@ __global__ __launch_bounds__(256) void conv_rows_thin(ConvArgs a) {
 // fragment order, and the 16 waves then walk 16-row groups on their own (conv_rows_thin's loop with the weight fragment read from LDS:
 // table entries up front, rows two offsets ahead, MFMAs skipped where no row has a neighbour, no barrier after the prologue).  Workgroup
 // b takes the b-th of gridDim.x contiguous ranges of groups, XCD-major.
-template <int CINP, int NB, bool WT, int KVOL>
+// PRE (16 source channels only): BatchNorm (+ReLU) of the source rows on the gather, parameters of the lane's four channels in registers
+// (at 32 channels the same pushed this 128-register kernel into scratch: 66.8 against 47.1 us)
+template <int CINP, int NB, bool WT, int KVOL, bool PRE = false>
 __global__ __launch_bounds__(1024) void conv_rows_res(ConvArgs a, int groups_per_wg) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [k][j][nb][lane][4]: B fragment of lane (n, g), k-step (j, t), tile nb at t
   constexpr int J = CINP / 16, D = 2, NST = D + 1, WSZ = CINP * NB * 16;
@@ -1039,6 +1043,11 @@ __global__ __launch_bounds__(1024) void conv_rows_res(ConvArgs a, int groups_per
   }
   __syncthreads();
   StatAcc<NB> sacc;
+  PreNorm4 pn[PRE ? J : 1];
+  if constexpr (PRE) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) prenorm_load(a, 16 * j + 4 * g, pn[j]);
+  }
   const int groups = (a.n_dst + 15) / 16;
   const int first = xcd_major_tile(blockIdx.x, gridDim.x) * groups_per_wg;
   const int last = min(first + groups_per_wg, groups);
@@ -1048,9 +1057,9 @@ __global__ __launch_bounds__(1024) void conv_rows_res(ConvArgs a, int groups_per
     int tv[KVOL];
 #pragma unroll
     for (int k = 0; k < KVOL; ++k) tv[k] = row_ok ? a.tab[static_cast<long long>(a.flip ? (KVOL - 1 - k) : k) * a.n_dst + my_row] : -1;
-    unsigned live = 0;   // bit k: some row of the group has a neighbour at offset k
+    unsigned live = 0, mine = 0;   // bit k: some row of the group / this lane's row has a neighbour at offset k
 #pragma unroll
-    for (int k = 0; k < KVOL; ++k) live |= (__ballot(tv[k] >= 0) != 0ull ? 1u : 0u) << k;
+    for (int k = 0; k < KVOL; ++k) { live |= (__ballot(tv[k] >= 0) != 0ull ? 1u : 0u) << k; if constexpr (PRE) mine |= (tv[k] >= 0 ? 1u : 0u) << k; }
     float4 x[NST][J];
     auto request = [&](auto k_, float4 (&dst)[J]) {
       constexpr int k = decltype(k_)::value;
@@ -1080,7 +1089,11 @@ __global__ __launch_bounds__(1024) void conv_rows_res(ConvArgs a, int groups_per
       if ((live >> k) & 1u) {
 #pragma unroll
         for (int j = 0; j < J; ++j) {
-          const float4 xv = x[k % NST][j];
+          float4 xv = x[k % NST][j];
+          if constexpr (PRE) {
+            const f32x4 v = prenorm_apply(pn[j], f32x4{xv.x, xv.y, xv.z, xv.w}, (mine >> k) & 1u, a.pre_relu);
+            xv = make_float4(v[0], v[1], v[2], v[3]);
+          }
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.x, bv[k & 1][j][nb].x, acc[nb], 0, 0, 0);
 #pragma unroll
@@ -1552,6 +1565,57 @@ __global__ __launch_bounds__(256) void conv_rows_scalar(ConvArgs a) {
   conv_stats_done<NB>(a, lds, sacc, scols, blockIdx.x, gridDim.x, 1);
 }
 
+// ---- the first layer of a backbone: 4 (or 5 .. 8) point features -> 16 / 32 channels, full 3 x 3 x 3 kernel ---------------------------
+// conv_rows_scalar stages every W_k (64 - 256 floats) through LDS with two barriers per offset: 27 x 2 barriers for 27 MFMAs per wave -
+// 26.6 - 35.6 us for the 35 k rows of `conv_input`, twice the 16 -> 16 layer that follows it with four times the work.  Here a wave works
+// alone, as in conv_rows_thin: its 27 table entries, then its 27 x STEPS feature dwords (lane (r, g): channel 4 s + g of row r's neighbour
+// at offset k: the four lanes of a row read one 16-byte row piece) and the 27 x STEPS x NB weight dwords of ITS fragment position are all
+// requested up front and stay in registers; then 27 x STEPS x NB MFMAs in conv_rows_scalar's order (same products, same sums: bit-identical
+// results), skipped where no row of the wave has a neighbour.  No LDS, no barrier.
+template <int STEPS, int NB, int KVOL>
+__global__ __launch_bounds__(256) void conv_rows_first(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // only conv_stats_done's scratch
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+  const int row0 = (blockIdx.x * 4 + wave) * 16;
+  StatAcc<NB> sacc;
+  if (row0 < a.n_dst) {
+    const int my_row = row0 + r;
+    const bool row_ok = my_row < a.n_dst;
+    int tv[KVOL];
+#pragma unroll
+    for (int k = 0; k < KVOL; ++k) tv[k] = row_ok ? a.tab[static_cast<long long>(a.flip ? (KVOL - 1 - k) : k) * a.n_dst + my_row] : -1;
+    float w[KVOL][STEPS][NB], f[KVOL][STEPS];
+#pragma unroll
+    for (int k = 0; k < KVOL; ++k)
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st) {
+        const int ch = 4 * st + g;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const int col = 16 * nb + r;
+          w[k][st][nb] = (ch < a.c_src && col < a.c_dst) ? a.w[static_cast<long long>(k) * a.w_kstride + static_cast<long long>(ch) * a.w_ld + col] : 0.f;
+        }
+        f[k][st] = (tv[k] >= 0 && ch < a.c_src) ? a.src[static_cast<long long>(tv[k]) * a.ld_src + ch] : 0.f;
+      }
+    f32x4 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < KVOL; ++k) {
+      if (__ballot(tv[k] >= 0) != 0ull) {
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(f[k][st], w[k][st][nb], acc[nb], 0, 0, 0);
+      }
+    }
+    conv_epilogue<NB>(a, acc, row0, &sacc);
+  }
+  int scols[NB];
+  epilogue_cols<NB>(scols);
+  conv_stats_done<NB>(a, lds, sacc, scols, blockIdx.x, gridDim.x, 1);
+}
+
 // ---- weight gradient ----------------------------------------------------------------------------
 struct WgradArgs {
   const float* src; int ld_src; int c_src;     // gathered operand (features), rows = tab values
@@ -2006,7 +2070,9 @@ static int conv_cu_count() {
 // thin-layer kernels of the auto mode: conv_rows_thin (16 -> 16) and conv_rows_res (32 -> 32 / 32 -> 16, weights resident in LDS).
 // -1 = not read yet (FV2P_CONV_THIN / FV2P_CONV_RES preset them, default on); fv2p_sparse_conv_set_paths() switches them at run time
 // so that the parity tests hold each kernel against the staged kernel it replaces in one process.
-static int g_thin_on = -1, g_res_on = -1;
+static int g_thin_on = -1, g_res_on = -1, g_first_on = -1;
+constexpr int kThinDepth = 2;      // offsets in flight per wave of conv_rows_thin (measured: see launch_vec)
+constexpr int kRes16Default = 3;   // conv_rows_res at 16 source channels: forward 16 -> 16, plain and PRE (see launch_vec)
 static bool path_on(int& flag, const char* e) {   // e: the development preset (FV2P_DEV_ENV), null in the release library
   if (flag < 0) flag = (!e || atoi(e) != 0) ? 1 : 0;
   return flag != 0;
@@ -2175,23 +2241,36 @@ static int launch_vec(const ConvArgs& a, hipStream_t s) {   // 0: launched (or c
       }
     }
   }
-  if constexpr (CINP == 32 && NB <= 2) {
+  if constexpr ((CINP == 32 || CINP == 16) && NB <= 2) {
     // 32 source channels, full 3 x 3 x 3 kernel: every W_k resident in LDS, one persistent workgroup of 16 waves per CU
-    const bool res_on = path_on(g_res_on, FV2P_DEV_ENV("FV2P_CONV_RES"));
+    // 16 source channels, FORWARD only: 11.7 against 14.0 us of conv_rows_thin at 35 k rows (whose non-transposed weight fragment is four
+    // dword loads per offset and wave); backward data (one 16-byte load) is equal on both, 11.7 / 11.8, and stays on conv_rows_thin.
+    // Development switch FV2P_CONV_RES16: bit 0 the plain 16 -> 16 forward, bit 1 its PRE form, bit 2 16 -> 32 as well.  Measured, residual
+    // backbone (batch 4) / plain backbone, ms per step: 0: 3.738 / 1.690, 1: 3.758 / 1.645, 3: 3.703 / -, 7: 3.835 / 1.669 -> 3.
+    static const int res16 = [] { const char* e = FV2P_DEV_ENV("FV2P_CONV_RES16"); return e ? atoi(e) : kRes16Default; }();
+    const bool pre = a.pre_mean != nullptr;
+    const bool res16_here = !WT && (res16 & 1) && (NB == 1 || (res16 & 4)) && (!pre || (res16 & 2));
+    const bool res_on = path_on(g_res_on, FV2P_DEV_ENV("FV2P_CONV_RES")) && (CINP == 32 || res16_here);
     const bool whole = a.c_src == CINP && a.c_dst == NB * 16 && (a.ld_src & 3) == 0 && (reinterpret_cast<uintptr_t>(a.src) & 15) == 0;
     constexpr size_t res_lds = static_cast<size_t>(27) * CINP * NB * 16 * sizeof(float);
     // measured (tools/microbench.py conv): subm 32 -> 32 at 39 k rows 29.4 us forward / 29.4 us backward data against 34.7 / 32.3 us of the
     // staged kernels; at 286 k rows (Waymo) 170 / 170 against 168 / 156 us - with several groups per wave the staged kernels' shared fragment wins back
     if (impl == 0 && res_on && whole && a.kvol == 27 && !a.perm && a.n_dst <= 65536) {
+      const int groups = static_cast<int>(ceil_div(a.n_dst, 16));
+      const int wgs = std::min(groups, conv_cu_count());
+      const int per = static_cast<int>(ceil_div(groups, wgs));
+      if (pre) {
+        // (no PRE form at 32 channels: normalising the gathered rows pushed this 128-register, 16-wave kernel into scratch - 66.8 against
+        //  47.1 us at 39 k rows, more than the 5.6 us apply launch it saves; 32-channel consumers read materialised rows)
+        if constexpr (CINP == 16 && !WT) {
+          static bool once_pre = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_res<CINP, NB, WT, 27, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
+          if (once_pre) { FV2P_LAUNCH((conv_rows_res<CINP, NB, WT, 27, true>), dim3(static_cast<unsigned>(ceil_div(groups, per))), dim3(1024), std::max(res_lds, kStatsDoneLds), s, a, per); return 0; }
+        }
+        return 1;
+      }
       static bool once = [] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_rows_res<CINP, NB, WT, 27>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }();
       if (once) {
-        const int groups = static_cast<int>(ceil_div(a.n_dst, 16));
-        const int wgs = std::min(groups, conv_cu_count());
-        const int per = static_cast<int>(ceil_div(groups, wgs));
-        // (no PRE form here: normalising the gathered rows pushed this 128-register, 16-wave kernel into scratch - 66.8 against 47.1 us
-        //  at 39 k rows, more than the 5.6 us apply launch it saves; 32-channel consumers read materialised rows)
-        if (a.pre_mean) return 1;
-        FV2P_LAUNCH((conv_rows_res<CINP, NB, WT, 27>), dim3(static_cast<unsigned>(ceil_div(groups, per))), dim3(1024), res_lds, s, a, per);
+        FV2P_LAUNCH((conv_rows_res<CINP, NB, WT, 27>), dim3(static_cast<unsigned>(ceil_div(groups, per))), dim3(1024), std::max(res_lds, kStatsDoneLds), s, a, per);
         return 0;
       }
     }
@@ -2207,11 +2286,19 @@ static int launch_vec(const ConvArgs& a, hipStream_t s) {   // 0: launched (or c
                        (!WT || ((a.w_ld & 3) == 0 && (a.w_kstride & 3) == 0 && (reinterpret_cast<uintptr_t>(a.w) & 15) == 0));
     if (impl == 0 && thin_on && whole && a.kvol == 27 && !a.perm) {
       const unsigned groups = static_cast<unsigned>(ceil_div(a.n_dst, 16));
+      static const int depth = [] { const char* e = FV2P_DEV_ENV("FV2P_THIN_DEPTH"); return e ? atoi(e) : kThinDepth; }();   // development: 2 / 4 / 6
       if (a.pre_mean) {
-        if constexpr (!WT) { FV2P_LAUNCH((conv_rows_thin<CINP, NB, WT, 27, true>), dim3(ceil_div(groups, 4u)), dim3(256), kStatsDoneLds, s, a); return 0; }
+        if constexpr (!WT) {
+          if (depth == 4) FV2P_LAUNCH((conv_rows_thin<CINP, NB, WT, 27, true, 4>), dim3(ceil_div(groups, 4u)), dim3(256), kStatsDoneLds, s, a);
+          else if (depth == 6) FV2P_LAUNCH((conv_rows_thin<CINP, NB, WT, 27, true, 6>), dim3(ceil_div(groups, 4u)), dim3(256), kStatsDoneLds, s, a);
+          else FV2P_LAUNCH((conv_rows_thin<CINP, NB, WT, 27, true>), dim3(ceil_div(groups, 4u)), dim3(256), kStatsDoneLds, s, a);
+          return 0;
+        }
         return 1;
       }
-      FV2P_LAUNCH((conv_rows_thin<CINP, NB, WT, 27>), dim3(ceil_div(groups, 4u)), dim3(256), kStatsDoneLds, s, a);
+      if (depth == 4) FV2P_LAUNCH((conv_rows_thin<CINP, NB, WT, 27, false, 4>), dim3(ceil_div(groups, 4u)), dim3(256), kStatsDoneLds, s, a);
+      else if (depth == 6) FV2P_LAUNCH((conv_rows_thin<CINP, NB, WT, 27, false, 6>), dim3(ceil_div(groups, 4u)), dim3(256), kStatsDoneLds, s, a);
+      else FV2P_LAUNCH((conv_rows_thin<CINP, NB, WT, 27>), dim3(ceil_div(groups, 4u)), dim3(256), kStatsDoneLds, s, a);
       return 0;
     }
   }
@@ -2258,6 +2345,14 @@ template <int STEPS, int NB, bool WT>
 static int launch_scalar(const ConvArgs& a, hipStream_t s) {
   if (a.pre_mean) return 1;
   const unsigned blocks = static_cast<unsigned>(ceil_div(a.n_dst, 64));
+  if constexpr (!WT && STEPS * NB <= 2) {
+    // the backbones' first layer (4 or 5 point features -> 16 / 32 channels, 27 offsets): everything in registers, no barrier.  Measured
+    // (FV2P_RES=1 tools/microbench.py conv, subm 4 -> 16 at 35 146 rows): see profiles/README.md, round 6
+    if (conv_impl() == 0 && path_on(g_first_on, FV2P_DEV_ENV("FV2P_CONV_FIRST")) && a.kvol == 27 && !a.perm) {
+      FV2P_LAUNCH((conv_rows_first<STEPS, NB, 27>), dim3(blocks), dim3(256), kStatsDoneLds, s, a);
+      return 0;
+    }
+  }
   FV2P_LAUNCH((conv_rows_scalar<STEPS, NB, WT>), dim3(blocks), dim3(256), std::max<size_t>(STEPS * 4 * NB * 16 * sizeof(float), kStatsDoneLds), s, a);
   return 0;
 }
@@ -2489,6 +2584,7 @@ extern "C" int fv2p_sparse_conv_set_paths(int thin_on, int res_on) {
   FV2P_REQUIRE(thin_on >= -1 && thin_on <= 1 && res_on >= -1 && res_on <= 1, FV2P_EINVAL, "set_paths: 1 = on, 0 = off, -1 = back to the environment's preset");
   fv2p::g_thin_on = thin_on;
   fv2p::g_res_on = res_on;
+  fv2p::g_first_on = thin_on;   // the first-layer kernel (conv_rows_first) is a thin-layer kernel too: one switch
   return 0;
 }
 

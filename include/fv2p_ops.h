@@ -153,7 +153,8 @@ int fv2p_conv_plan_build(int* tab, int kvol, int64_t n_dst, void* ws, size_t ws_
  * the same sum in the same k order. */
 int fv2p_sparse_conv_set_impl(int impl);
 /* Test / tuning hook for the two thin-layer kernels the heuristic (impl 0) adds for the full 3 x 3 x 3 kernel: conv_rows_thin
- * (16 -> 16, any row count) and conv_rows_res (32 source channels, <= 32 destination channels, <= 65 536 rows).  1 = on, 0 = off
+ * (16 -> 16, any row count; with it conv_rows_first: <= 8 source channels that are not a multiple of 4 or fewer than 16, <= 32 destination
+ * channels - the backbones' first layer) and conv_rows_res (32 source channels, <= 32 destination channels, <= 65 536 rows).  1 = on, 0 = off
  * (the staged kernels take those launches), -1 = back to the FV2P_CONV_THIN / FV2P_CONV_RES preset (default on).  Same sum, same k order. */
 int fv2p_sparse_conv_set_paths(int thin_on, int res_on);
 /* Profiling hook: when non-NULL, every workgroup of the LDS-DMA conv kernel writes {HW_ID, XCC_ID, start, end of the
