@@ -621,7 +621,7 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 __device__ __forceinline__ float lane_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 
 constexpr int kFpsWaves = 8;
-constexpr int kFpsTreeDefault = 0;
+constexpr int kFpsIdxDefault = 1;   // touched buckets through run-time register indices (fps_wave_k<S, TRACE, IDX>)
 // compile-time loop: f(integral_constant<int, Q>) for Q in [A, B) — register arrays are only ever indexed by constants
 template <int A, int B, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -630,19 +630,28 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for<A + 1, B>(f);
   }
 }
-// binary decision tree over a compile-time range: f(integral_constant<int, q>) for the run-time q in [LO, HI) (uniform q: scalar branches)
-template <int LO, int HI, class F>
-__device__ __forceinline__ void tree_dispatch(int q, F&& f) {
-  if constexpr (HI - LO == 1) f(std::integral_constant<int, LO>{});
-  else {
-    constexpr int MID = (LO + HI) / 2;
-    if (q < MID) tree_dispatch<LO, MID>(q, f);
-    else tree_dispatch<MID, HI>(q, f);
+// S register slots of a wave (one float per lane and slot), readable and writable by a RUN-TIME, wave-uniform slot number: hipcc lowers a
+// dynamic index into an 8 / 16 / 32-wide vector to s_set_gpr_idx_on + v_mov_b32 (no scratch, no branches); slots 32..47 are a second vector
+template <int S>
+struct SlotRegs {
+  static constexpr int LO = S <= 8 ? 8 : S <= 16 ? 16 : 32;
+  static constexpr int HI = S > 32 ? 16 : 2;
+  typedef float VLo __attribute__((ext_vector_type(LO)));
+  typedef float VHi __attribute__((ext_vector_type(HI)));
+  VLo lo;
+  VHi hi;
+  __device__ __forceinline__ float get(int q) const {
+    if constexpr (S > 32) { if (q >= 32) return hi[q - 32]; }
+    return lo[q];
   }
-}
-// TREE: the touched buckets are found by find-first-set + a binary tree of uniform branches (log2 S tests per touched bucket) instead of
-// the straight-line scan of groups of eight (S / 8 + 8 tests per round with one touched bucket)
-template <int S, bool TRACE, bool TREE = false>
+  __device__ __forceinline__ void set(int q, float v) {
+    if constexpr (S > 32) { if (q >= 32) { hi[q - 32] = v; return; } }
+    lo[q] = v;
+  }
+};
+// IDX: the touched buckets one after another through ONE copy of the update code, their registers addressed by the run-time slot number
+// (SlotRegs), instead of the straight-line scan of compile-time slots (S / 8 + 8 uniform tests per round and S copies of the update)
+template <int S, bool TRACE, bool IDX = false>
 __global__ __launch_bounds__(kFpsWaves * 64) void fps_wave_k(int n, int m, int bs, const float* __restrict__ dataset,
                                                              const uint64_t* __restrict__ keys, float* __restrict__ temp, int* __restrict__ idxs,
                                                              unsigned long long* __restrict__ trace_) {
@@ -650,7 +659,10 @@ __global__ __launch_bounds__(kFpsWaves * 64) void fps_wave_k(int n, int m, int b
   unsigned long long* const trace = TRACE ? trace_ : nullptr;   // compile-time off in the production instance (the runtime test cost 10 %)
   unsigned long long t_test = 0, t_touch = 0, t_best = 0, t_barrier = 0, t_pick = 0, t_mark = 0, n_touched = 0;   // test hook (fv2p_fps_set_trace)
   extern __shared__ uint32_t s_prio[];   // [S][kFpsWaves * 64]: reference priority of every point (read only when its bucket is touched)
-  __shared__ __attribute__((aligned(16))) uint32_t s_wave[2][kFpsWaves][8];   // candidate of every wave: max bits, priority, x, y, z, -
+  __shared__ __attribute__((aligned(16))) uint32_t s_wave[2][kFpsWaves][4];   // the point of every wave's candidate: x, y, z, -
+  // the round's winner: maximum over the waves' keys (distance bits, kPrioTop - priority, wave) by ONE LDS atomic per wave; three slots in
+  // rotation - round j fills slot j % 3 before the barrier, everybody reads it after, wave 0 clears slot (j + 1) % 3 (last read in round j - 2)
+  __shared__ unsigned long long s_key[3];
   int log2bs = 0;
   while ((1 << (log2bs + 1)) <= bs) ++log2bs;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -663,7 +675,7 @@ __global__ __launch_bounds__(kFpsWaves * 64) void fps_wave_k(int n, int m, int b
     return ((__brev(owner) >> (32 - log2bs)) << 16) | static_cast<uint32_t>(k >> log2bs);
   };
   auto index_of = [&](uint32_t pr) -> int { return static_cast<int>(((pr & 0xffffu) << log2bs) | (__brev(pr >> 16) >> (32 - log2bs))); };
-  float px[S], py[S], pz[S], pt[S];
+  SlotRegs<S> px, py, pz, pt;
   // lane s < S of this wave keeps the state of the wave's bucket s: box, running maximum, priority of the point holding it
   float lo0 = 0.f, lo1 = 0.f, lo2 = 0.f, hi0 = 0.f, hi1 = 0.f, hi2 = 0.f, bmax = -2.f, bcx = 0.f, bcy = 0.f, bcz = 0.f;
   uint32_t bprio = 0xffffffffu;
@@ -674,10 +686,10 @@ __global__ __launch_bounds__(kFpsWaves * 64) void fps_wave_k(int n, int m, int b
     const int k = static_cast<int>(keys[ok ? pos : n - 1] & 0xffffffull);   // clamped: no divergent load
     const float x = dataset[k * 3], y = dataset[k * 3 + 1], z = dataset[k * 3 + 2], t = temp[k];
     s_prio[s * (kFpsWaves * 64) + tid] = ok ? prio_of(k) : 0xffffffffu;   // only this thread ever reads it back
-    px[s] = ok ? x : 0.f;
-    py[s] = ok ? y : 0.f;
-    pz[s] = ok ? z : 0.f;
-    pt[s] = ok ? t : -2.f;   // an empty slot never holds a maximum (running distances are >= 0)
+    px.set(s, ok ? x : 0.f);
+    py.set(s, ok ? y : 0.f);
+    pz.set(s, ok ? z : 0.f);
+    pt.set(s, ok ? t : -2.f);   // an empty slot never holds a maximum (running distances are >= 0)
     // box of the bucket, kept by lane s
     const float bx0 = wave_min_f32(ok ? x : INFINITY), bx1 = wave_max_f32(ok ? x : -INFINITY);
     const float by0 = wave_min_f32(ok ? y : INFINITY), by1 = wave_max_f32(ok ? y : -INFINITY);
@@ -687,19 +699,22 @@ __global__ __launch_bounds__(kFpsWaves * 64) void fps_wave_k(int n, int m, int b
   }
   // bucket s: recompute (max, priority, candidate coordinates) from the registers; wave-uniform control flow.  The priority
   // reduction only runs when several points share the maximum.
-  auto refresh = [&](auto sc) __attribute__((always_inline)) {
-    constexpr int s = decltype(sc)::value;
+  auto refresh_slot = [&](int s, float x, float y, float z, float t) __attribute__((always_inline)) {   // s wave-uniform
     const uint32_t myp = s_prio[s * (kFpsWaves * 64) + tid];   // issued first: its latency hides behind the max reduction
-    const float mx = wave_max_f32(pt[s]);
-    const uint64_t holders = __ballot(pt[s] == mx);
-    int leader = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(holders)) - 1);
+    const float mx = wave_max_f32(t);
+    const uint64_t holders = __ballot(t == mx);
+    int leader = __builtin_amdgcn_readfirstlane(__builtin_ctzll(holders))   /* never empty: some lane holds the maximum */;
     uint32_t pm = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(myp), leader));
     if (holders & (holders - 1)) {
-      pm = wave_min_u32(pt[s] == mx ? myp : 0xffffffffu);
-      leader = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(__ballot(myp == pm && pt[s] == mx))) - 1);
+      pm = wave_min_u32(t == mx ? myp : 0xffffffffu);
+      leader = __builtin_amdgcn_readfirstlane(__builtin_ctzll(__ballot(myp == pm && t == mx)));
     }
-    const float cx = lane_f(px[s], leader), cy = lane_f(py[s], leader), cz = lane_f(pz[s], leader);
+    const float cx = lane_f(x, leader), cy = lane_f(y, leader), cz = lane_f(z, leader);
     if (lane == s) { bmax = mx; bprio = pm; bcx = cx; bcy = cy; bcz = cz; }   // the bucket's candidate point travels with its state
+  };
+  auto refresh = [&](auto sc) __attribute__((always_inline)) {
+    constexpr int s = decltype(sc)::value;
+    refresh_slot(s, px.get(s), py.get(s), pz.get(s), pt.get(s));
   };
   static_for<0, S>(refresh);
   // wave candidate from the S bucket states (every stored maximum is exact: a touched bucket is refreshed at once; keeping
@@ -723,7 +738,11 @@ __global__ __launch_bounds__(kFpsWaves * 64) void fps_wave_k(int n, int m, int b
   };
   wave_best();
   float x1 = dataset[0], y1 = dataset[1], z1 = dataset[2];
-  if (tid == 0) idxs[0] = 0;
+  if (tid == 0) { idxs[0] = 0; s_key[0] = 0ull; s_key[1] = 0ull; s_key[2] = 0ull; }
+  __syncthreads();
+  constexpr uint32_t kPrioTop = 0x03ffffffu;   // priorities are 26 bits (prio_of: 10 bits of owner order above 16 bits of slot)
+  const uint32_t key_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&s_key[0]));   // LDS byte address (low half of the flat one)
+  uint32_t ks = 8, ks_next = 16;                // byte offsets of slots j % 3 and (j + 1) % 3
   for (int j = 1; j < m; ++j) {
     if (trace) t_mark = __builtin_readcyclecounter();
     // which of my wave's buckets can the new point still lower?  (box bound in sqdist's operation order: exact skip)
@@ -736,19 +755,16 @@ __global__ __launch_bounds__(kFpsWaves * 64) void fps_wave_k(int n, int m, int b
     if (touch) {
       // straight-line, wave-uniform tests (groups of eight first): every slot's update is a plain diamond, so the register
       // arrays are updated in place (a switch over the slot made hipcc keep two copies of pt[] and hoist the distance passes)
-      if constexpr (TREE) {
+      if constexpr (IDX) {
         uint64_t rest = touch;
-        while (rest) {   // uniform
-          const int q = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(rest)) - 1);
+        do {   // uniform
+          const int q = __builtin_amdgcn_readfirstlane(__builtin_ctzll(rest));
           rest &= rest - 1;
-          tree_dispatch<0, S>(q, [&](auto qc) __attribute__((always_inline)) {
-            constexpr int qq = decltype(qc)::value;
-            float ax = x1, ay = y1, az = z1;
-            asm volatile("" : "+v"(ax), "+v"(ay), "+v"(az));
-            pt[qq] = fminf(sqdist(px[qq], py[qq], pz[qq], ax, ay, az), pt[qq]);
-            refresh(qc);
-          });
-        }
+          const float x = px.get(q), y = py.get(q), z = pz.get(q);
+          const float t = fminf(sqdist(x, y, z, x1, y1, z1), pt.get(q));
+          pt.set(q, t);
+          refresh_slot(q, x, y, z, t);
+        } while (rest);
       } else
       static_for<0, (S + 7) / 8>([&](auto gc) __attribute__((always_inline)) {
         constexpr int g = decltype(gc)::value * 8;
@@ -758,7 +774,7 @@ __global__ __launch_bounds__(kFpsWaves * 64) void fps_wave_k(int n, int m, int b
             if ((touch >> q) & 1ull) {
               float ax = x1, ay = y1, az = z1;
               asm volatile("" : "+v"(ax), "+v"(ay), "+v"(az));   // pins the distance pass inside its branch
-              pt[q] = fminf(sqdist(px[q], py[q], pz[q], ax, ay, az), pt[q]);
+              pt.set(q, fminf(sqdist(px.get(q), py.get(q), pz.get(q), ax, ay, az), pt.get(q)));
               refresh(qc);
             }
           });
@@ -772,26 +788,30 @@ __global__ __launch_bounds__(kFpsWaves * 64) void fps_wave_k(int n, int m, int b
     }
     const int buf = j & 1;
     if (lane == 0) {
-      *reinterpret_cast<uint4*>(&s_wave[buf][w][0]) = make_uint4(wbits, wprio, __float_as_uint(wcx), __float_as_uint(wcy));
-      s_wave[buf][w][4] = __float_as_uint(wcz);
+      *reinterpret_cast<uint4*>(&s_wave[buf][w][0]) = make_uint4(__float_as_uint(wcx), __float_as_uint(wcy), __float_as_uint(wcz), 0u);
+      // larger distance first (every real maximum is >= 0: unsigned order == float order), then the SMALLER reference priority; the wave
+      // number below the priority never decides (priorities are unique) and tells where the winner's point lies
+      const uint32_t low = ((kPrioTop - (wprio < kPrioTop ? wprio : kPrioTop)) << 3) | static_cast<uint32_t>(w);
+      // (written as the instruction: hipcc turns the builtin atomic into a loop over the active lanes with a cross-lane read each)
+      const unsigned long long key = (static_cast<unsigned long long>(wbits) << 32) | low;
+      asm volatile("ds_max_u64 %0, %1" :: "v"(key_base + ks), "v"(key) : "memory");
+      if (w == 0) asm volatile("ds_write_b64 %0, %1" :: "v"(key_base + ks_next), "v"(0ull) : "memory");
     }
     lds_barrier();
     if (trace) { const unsigned long long t = __builtin_readcyclecounter(); t_barrier += t - t_mark; t_mark = t; }
-    // 8 wave candidates (with their points), one per lane of the first row; every wave derives the same winner
-    const uint4 c = lane < kFpsWaves ? *reinterpret_cast<const uint4*>(&s_wave[buf][lane][0]) : make_uint4(0u, 0xffffffffu, 0u, 0u);
-    const uint32_t cz_bits = lane < kFpsWaves ? s_wave[buf][lane][4] : 0u;
-    const float gmax = lane_f(row_max_f32(__uint_as_float(c.x)), 0);
-    const uint64_t gtop = __ballot(lane < kFpsWaves && __uint_as_float(c.x) == gmax);
-    int gw = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(gtop)) - 1);
-    uint32_t gprio = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(c.y), gw));
-    if (gtop & (gtop - 1)) {
-      gprio = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(row_min_u32(__uint_as_float(c.x) == gmax ? c.y : 0xffffffffu)), 0));
-      gw = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(__ballot(lane < kFpsWaves && __uint_as_float(c.x) == gmax && c.y == gprio))) - 1);
-    }
-    x1 = __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(c.z), gw)));
-    y1 = __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(c.w), gw)));
-    z1 = __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cz_bits), gw)));
-    if (tid == 0) idxs[j] = index_of(gprio);
+    // every wave reads the same winner: two dependent LDS reads.  (Rounds 3 - 5: the eight candidates one per lane, a DPP row maximum, two
+    // ballots and five cross-lane reads - 533 clocks of the round's ~1 900.  Also tried: every lane reads the eight keys and folds them with
+    // seven 64-bit maxima - 810 clocks, 0.87 us per round.)
+    unsigned long long gkey;
+    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(gkey) : "v"(key_base + ks) : "memory");
+    const uint32_t glow = static_cast<uint32_t>(gkey);
+    const uint4 c = *reinterpret_cast<const uint4*>(&s_wave[buf][glow & 7u][0]);
+    x1 = __uint_as_float(c.x);
+    y1 = __uint_as_float(c.y);
+    z1 = __uint_as_float(c.z);
+    if (tid == 0) idxs[j] = index_of(kPrioTop - (glow >> 3));
+    ks = ks_next;
+    ks_next = ks_next == 16 ? 0 : ks_next + 8;
     if (trace) { asm volatile("" : "+v"(x1), "+v"(y1), "+v"(z1)); t_pick += __builtin_readcyclecounter() - t_mark; }
   }
   if (trace && lane == 0 && b == 0) {
@@ -801,7 +821,7 @@ __global__ __launch_bounds__(kFpsWaves * 64) void fps_wave_k(int n, int m, int b
 #pragma unroll
   for (int s = 0; s < S; ++s) {
     const uint32_t myp = s_prio[s * (kFpsWaves * 64) + tid];
-    if (myp != 0xffffffffu) temp[index_of(myp)] = pt[s];
+    if (myp != 0xffffffffu) temp[index_of(myp)] = pt.get(s);
   }
 }
 
@@ -858,7 +878,8 @@ __global__ __launch_bounds__(kStreamWaves * 64) void fps_stream_k(int n, int m, 
   if (m <= 0) return;
   unsigned long long t_test = 0, t_fetch = 0, t_first = 0, t_buckets = 0, t_best = 0, t_barrier = 0, t_pick = 0, t_mark = 0, n_touched = 0;   // test hook: clocks per phase (fv2p_fps_set_trace)
   asm volatile("v_mov_b32 v127, 0" ::: "v127");   // 128 VGPRs per wave x 4 waves per SIMD = the SIMD's register file: no other workgroup joins this CU
-  __shared__ __attribute__((aligned(16))) uint32_t s_wave[2][kStreamWaves][8];   // candidate of every wave: max bits, priority, x, y, z, -
+  __shared__ __attribute__((aligned(16))) uint32_t s_wave[2][kStreamWaves][4];   // the point of every wave's candidate: x, y, z, -
+  __shared__ unsigned long long s_key[3];   // the round's winner by one LDS atomic maximum per wave, three slots in rotation (see fps_wave_k)
   int log2bs = 0;
   while ((1 << (log2bs + 1)) <= bs) ++log2bs;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -944,7 +965,11 @@ __global__ __launch_bounds__(kStreamWaves * 64) void fps_stream_k(int n, int m, 
   };
   wave_best();
   float x1 = dataset[0], y1 = dataset[1], z1 = dataset[2];
-  if (tid == 0) idxs[0] = 0;
+  if (tid == 0) { idxs[0] = 0; s_key[0] = 0ull; s_key[1] = 0ull; s_key[2] = 0ull; }
+  __syncthreads();
+  constexpr uint32_t kPrioTop = 0x03ffffffu;   // priorities are 26 bits
+  const uint32_t key_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&s_key[0]));
+  uint32_t ks = 8, ks_next = 16;                // byte offsets of slots j % 3 and (j + 1) % 3
   for (int j = 1; j < m; ++j) {
     if (trace) t_mark = __builtin_readcyclecounter();
     const float gx = fmaxf(fmaxf(lo0 - x1, x1 - hi0), 0.f);
@@ -981,25 +1006,24 @@ __global__ __launch_bounds__(kStreamWaves * 64) void fps_stream_k(int n, int m, 
     }
     const int buf = j & 1;
     if (lane == 0) {
-      *reinterpret_cast<uint4*>(&s_wave[buf][w][0]) = make_uint4(wbits, wprio, __float_as_uint(wcx), __float_as_uint(wcy));
-      s_wave[buf][w][4] = __float_as_uint(wcz);
+      *reinterpret_cast<uint4*>(&s_wave[buf][w][0]) = make_uint4(__float_as_uint(wcx), __float_as_uint(wcy), __float_as_uint(wcz), 0u);
+      const uint32_t low = ((kPrioTop - (wprio < kPrioTop ? wprio : kPrioTop)) << 4) | static_cast<uint32_t>(w);
+      const unsigned long long key = (static_cast<unsigned long long>(wbits) << 32) | low;
+      asm volatile("ds_max_u64 %0, %1" :: "v"(key_base + ks), "v"(key) : "memory");
+      if (w == 0) asm volatile("ds_write_b64 %0, %1" :: "v"(key_base + ks_next), "v"(0ull) : "memory");
     }
     lds_barrier();   // the waves talk through LDS only; a bucket's distances are read and written by its own wave alone
     if (trace) { const unsigned long long t = __builtin_readcyclecounter(); t_barrier += t - t_mark; t_mark = t; }
-    const uint4 c = lane < kStreamWaves ? *reinterpret_cast<const uint4*>(&s_wave[buf][lane][0]) : make_uint4(0u, 0xffffffffu, 0u, 0u);
-    const uint32_t cz_bits = lane < kStreamWaves ? s_wave[buf][lane][4] : 0u;
-    const float gmax = lane_f(row_max_f32(__uint_as_float(c.x)), 0);
-    const uint64_t gtop = __ballot(lane < kStreamWaves && __uint_as_float(c.x) == gmax);
-    int gw = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(gtop)) - 1);
-    uint32_t gprio = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(c.y), gw));
-    if (gtop & (gtop - 1)) {
-      gprio = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(row_min_u32(__uint_as_float(c.x) == gmax ? c.y : 0xffffffffu)), 0));
-      gw = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(__ballot(lane < kStreamWaves && __uint_as_float(c.x) == gmax && c.y == gprio))) - 1);
-    }
-    x1 = __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(c.z), gw)));
-    y1 = __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(c.w), gw)));
-    z1 = __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cz_bits), gw)));
-    if (tid == 0) idxs[j] = index_of(gprio);
+    unsigned long long gkey;   // two dependent LDS reads (rounds 2 - 5: the sixteen candidates reduced again by every wave, 690 clocks)
+    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(gkey) : "v"(key_base + ks) : "memory");
+    const uint32_t glow = static_cast<uint32_t>(gkey);
+    const uint4 c = *reinterpret_cast<const uint4*>(&s_wave[buf][glow & 15u][0]);
+    x1 = __uint_as_float(c.x);
+    y1 = __uint_as_float(c.y);
+    z1 = __uint_as_float(c.z);
+    if (tid == 0) idxs[j] = index_of(kPrioTop - (glow >> 4));
+    ks = ks_next;
+    ks_next = ks_next == 16 ? 0 : ks_next + 8;
     if (trace) t_pick += __builtin_readcyclecounter() - t_mark;
   }
   if (trace && lane == 0 && b == 0) {
@@ -1765,8 +1789,11 @@ extern "C" int fv2p_furthest_point_sampling(int b, int n, int m, const float* da
     if (form < 0) { const char* e = FV2P_DEV_ENV("FV2P_FPS_FORM"); form = (e && e[0] == 't') ? 0 : 1; }
     const int slots = static_cast<int>(ceil_div(n, kFpsWaves * 64));
     const int ppt = static_cast<int>(ceil_div(n, 1024));
-    static int tree = -1;   // development: FV2P_FPS_TREE=0/1 selects the scan of the touched buckets (see fps_wave_k)
-    if (tree < 0) { const char* e = FV2P_DEV_ENV("FV2P_FPS_TREE"); tree = e ? atoi(e) : kFpsTreeDefault; }
+    static int tree = -1;   // development: FV2P_FPS_IDX=0/1 selects how the touched buckets are walked (see fps_wave_k)
+    if (tree < 0) { const char* e = FV2P_DEV_ENV("FV2P_FPS_IDX"); tree = e ? atoi(e) : kFpsIdxDefault; }
+    // measured (us per round, run-time index against compile-time scan): 16 384 points (32 slots) 0.601 / 0.714, 20 000 (40 slots: the
+    // second vector's branch, 237 registers) 0.830 / 0.757, 24 576 (48 slots) 0.956 / 0.801 -> run-time indices up to 32 slots (2 = always)
+    const bool idx_form = tree == 2 || (tree == 1 && slots <= 32);
     if (form == 1 || ppt > 16) {
 #define FV2P_FPS(SS)                                                                                                       \
   do {                                                                                                                     \
@@ -1779,10 +1806,13 @@ extern "C" int fv2p_furthest_point_sampling(int b, int n, int m, const float* da
                                    static_cast<int>(lds)));                                                                \
       FV2P_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_wave_k<SS, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                    static_cast<int>(lds)));                                                                \
+      FV2P_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fps_wave_k<SS, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                   static_cast<int>(lds)));                                                                \
       big = true;                                                                                                          \
     }                                                                                                                      \
-    if (g_fps_trace) hipLaunchKernelGGL((fps_wave_k<SS, true>), dim3(b), dim3(kFpsWaves * 64), lds, st, n, m, bs, dataset, keys, temp, idxs, g_fps_trace); \
-    else if (tree) hipLaunchKernelGGL((fps_wave_k<SS, false, true>), dim3(b), dim3(kFpsWaves * 64), lds, st, n, m, bs, dataset, keys, temp, idxs, nullptr); \
+    if (g_fps_trace && idx_form) hipLaunchKernelGGL((fps_wave_k<SS, true, true>), dim3(b), dim3(kFpsWaves * 64), lds, st, n, m, bs, dataset, keys, temp, idxs, g_fps_trace); \
+    else if (g_fps_trace) hipLaunchKernelGGL((fps_wave_k<SS, true>), dim3(b), dim3(kFpsWaves * 64), lds, st, n, m, bs, dataset, keys, temp, idxs, g_fps_trace); \
+    else if (idx_form) hipLaunchKernelGGL((fps_wave_k<SS, false, true>), dim3(b), dim3(kFpsWaves * 64), lds, st, n, m, bs, dataset, keys, temp, idxs, nullptr); \
     else hipLaunchKernelGGL((fps_wave_k<SS, false>), dim3(b), dim3(kFpsWaves * 64), lds, st, n, m, bs, dataset, keys, temp, idxs, nullptr); \
   } while (0)
       if (slots <= 8) FV2P_FPS(8);
