@@ -594,6 +594,9 @@ __global__ __launch_bounds__(1024) void fps_bucket_k(int n, int m, int bs, const
 // step; hipcc's update_dpp + fmaxf lowers to mov, mov_dpp, canonicalise, max).  quad_perm xor-1, xor-2, row_half_mirror and
 // row_mirror leave every lane of a 16-lane row with the row's result; row_bcast:15 / :31 carry it into lane 63.  The two wait
 // states a DPP read needs after the VALU write of its source are the s_nop 1 in front of every step.
+#ifndef FV2P_FPS_PICK_LANES
+#define FV2P_FPS_PICK_LANES 0
+#endif
 #define FV2P_ROW_CHAIN(op)                                                        \
   "s_nop 1\n\t" op " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t" \
   "s_nop 1\n\t" op " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t" \
@@ -621,6 +624,7 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 __device__ __forceinline__ float lane_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 
 constexpr int kFpsWaves = 8;
+constexpr bool kFpsPickLanes = FV2P_FPS_PICK_LANES;
 constexpr int kFpsIdxDefault = 1;   // touched buckets through run-time register indices (fps_wave_k<S, TRACE, IDX>)
 // compile-time loop: f(integral_constant<int, Q>) for Q in [A, B) — register arrays are only ever indexed by constants
 template <int A, int B, class F>
@@ -724,12 +728,12 @@ __global__ __launch_bounds__(kFpsWaves * 64) void fps_wave_k(int n, int m, int b
   auto wave_best = [&]() __attribute__((always_inline)) {
     const float v = lane < S ? bmax : -3.f;
     const float mx = wave_max_f32(v);
-    const uint64_t top = __ballot(lane < S && v == mx);
-    int slot = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(top)) - 1);
+    const uint64_t top = __builtin_amdgcn_ballot_w64(v == mx)   /* lanes >= S hold -3 < mx */;
+    int slot = __builtin_amdgcn_readfirstlane(__builtin_ctzll(top));
     uint32_t pm = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(bprio), slot));
     if (top & (top - 1)) {
       pm = wave_min_u32((lane < S && v == mx) ? bprio : 0xffffffffu);
-      slot = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(__ballot(lane < S && v == mx && bprio == pm))) - 1);
+      slot = __builtin_amdgcn_readfirstlane(__builtin_ctzll(__ballot(v == mx && bprio == pm)));
     }
     wslot = static_cast<uint32_t>(slot);
     wbits = __float_as_uint(fmaxf(mx, 0.f));   // every real maximum is >= 0: unsigned order == float order; empty wave -> 0 with priority ~0
@@ -750,7 +754,7 @@ __global__ __launch_bounds__(kFpsWaves * 64) void fps_wave_k(int n, int m, int b
     const float gy = fmaxf(fmaxf(lo1 - y1, y1 - hi1), 0.f);
     const float gz = fmaxf(fmaxf(lo2 - z1, z1 - hi2), 0.f);
     const float lb = gx * gx + gy * gy + gz * gz;
-    const uint64_t touch = __ballot(lane < S && lb < bmax);
+    const uint64_t touch = __builtin_amdgcn_ballot_w64(lb < bmax);   // lanes >= S hold bmax = -2 and lb >= 0: never set
     if (trace) { const unsigned long long t = __builtin_readcyclecounter(); t_test += t - t_mark; t_mark = t; n_touched += __popcll(touch); }
     if (touch) {
       // straight-line, wave-uniform tests (groups of eight first): every slot's update is a plain diamond, so the register
@@ -803,12 +807,26 @@ __global__ __launch_bounds__(kFpsWaves * 64) void fps_wave_k(int n, int m, int b
     // ballots and five cross-lane reads - 533 clocks of the round's ~1 900.  Also tried: every lane reads the eight keys and folds them with
     // seven 64-bit maxima - 810 clocks, 0.87 us per round.)
     unsigned long long gkey;
-    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(gkey) : "v"(key_base + ks) : "memory");
-    const uint32_t glow = static_cast<uint32_t>(gkey);
-    const uint4 c = *reinterpret_cast<const uint4*>(&s_wave[buf][glow & 7u][0]);
-    x1 = __uint_as_float(c.x);
-    y1 = __uint_as_float(c.y);
-    z1 = __uint_as_float(c.z);
+    uint32_t glow;
+    if constexpr (kFpsPickLanes) {
+      // the eight candidate points one per lane (lane & 7) beside the key: one LDS round trip, then three cross-lane reads
+      uint4 c;
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(c), "=&v"(gkey)
+                   : "v"(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&s_wave[buf][lane & 7][0]))), "v"(key_base + ks) : "memory");
+      glow = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(gkey))));
+      const int gw = static_cast<int>(glow & 7u);
+      x1 = __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(c.x), gw)));
+      y1 = __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(c.y), gw)));
+      z1 = __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(c.z), gw)));
+    } else {
+      asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(gkey) : "v"(key_base + ks) : "memory");
+      glow = static_cast<uint32_t>(gkey);
+      const uint4 c = *reinterpret_cast<const uint4*>(&s_wave[buf][glow & 7u][0]);
+      x1 = __uint_as_float(c.x);
+      y1 = __uint_as_float(c.y);
+      z1 = __uint_as_float(c.z);
+    }
     if (tid == 0) idxs[j] = index_of(kPrioTop - (glow >> 3));
     ks = ks_next;
     ks_next = ks_next == 16 ? 0 : ks_next + 8;
@@ -920,11 +938,11 @@ __global__ __launch_bounds__(kStreamWaves * 64) void fps_stream_k(int n, int m, 
     }
     const float mx = wave_max_f32(bv);
     const uint64_t holders = __ballot(bv == mx);
-    int leader = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(holders)) - 1);
+    int leader = __builtin_amdgcn_readfirstlane(__builtin_ctzll(holders));
     uint32_t pm = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(bp), leader));
     if (holders & (holders - 1)) {
       pm = wave_min_u32(bv == mx ? bp : 0xffffffffu);
-      leader = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(__ballot(bv == mx && bp == pm))) - 1);
+      leader = __builtin_amdgcn_readfirstlane(__builtin_ctzll(__ballot(bv == mx && bp == pm)));
     }
     const float cx = lane_f(bx, leader), cy = lane_f(by, leader), cz = lane_f(bz, leader);
     if (lane == l) { bmax = mx; bprio = pm; bcx = cx; bcy = cy; bcz = cz; }
@@ -952,11 +970,11 @@ __global__ __launch_bounds__(kStreamWaves * 64) void fps_stream_k(int n, int m, 
   auto wave_best = [&]() __attribute__((always_inline)) {
     const float mx = wave_max_f32(bmax);
     const uint64_t top = __ballot(bmax == mx);
-    int l = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(top)) - 1);
+    int l = __builtin_amdgcn_readfirstlane(__builtin_ctzll(top));
     uint32_t pm = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(bprio), l));
     if (top & (top - 1)) {
       pm = wave_min_u32(bmax == mx ? bprio : 0xffffffffu);
-      l = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<long long>(__ballot(bmax == mx && bprio == pm))) - 1);
+      l = __builtin_amdgcn_readfirstlane(__builtin_ctzll(__ballot(bmax == mx && bprio == pm)));
     }
     wlane = l;
     wbits = __float_as_uint(fmaxf(mx, 0.f));   // every real maximum is >= 0: unsigned order == float order; a wave without buckets -> 0 with priority ~0
