@@ -19,17 +19,21 @@
 
 namespace fv2p {
 
-struct RbGeom {
-  int in_shape[3], out_shape[3], k[3], s[3], p[3], d[3], E[3];
+template <int ND>
+struct RbGeomT {
+  int in_shape[ND], out_shape[ND], k[ND], s[ND], p[ND], d[ND], E[ND];
   int kvol, emax, transpose;
   long long out_vol;
 };
+using RbGeom = RbGeomT<3>;   // the 2-D / 3-D rulebooks (2-D: a leading dimension of size 1); RbGeomT<4>: SparseConv4d / SubMConv4d
 
-// Enumerated candidate e of input position `in` -> output position + kernel offset (geometry.h:24-142).
-__device__ __forceinline__ bool enum_out(const RbGeom& g, const int in[3], int e, int out[3], int* offset) {
-  int lower[3], upper[3], cs[3];
+// Enumerated candidate e of input position `in` -> output position + kernel offset (geometry.h:24-142), any number of dimensions
+template <int ND>
+__device__ __forceinline__ bool enum_out(const RbGeomT<ND>& g, const int* in, int e, int* out, int* offset) {
+  int lower[ND], upper[ND], cs[ND];
+  int total = 1;
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
+  for (int j = 0; j < ND; ++j) {
     if (g.transpose) {
       lower[j] = in[j] * g.s[j] - g.p[j];
       upper[j] = lower[j] + (g.k[j] - 1) * g.d[j];
@@ -39,16 +43,17 @@ __device__ __forceinline__ bool enum_out(const RbGeom& g, const int in[3], int e
     }
     cs[j] = (upper[j] - lower[j]) / g.d[j] + 1;
     if (cs[j] <= 0) return false;
+    total *= cs[j];
   }
-  if (e >= cs[0] * cs[1] * cs[2]) return false;
-  int c[3];
-  c[2] = e % cs[2]; e /= cs[2];
-  c[1] = e % cs[1];
-  c[0] = e / cs[1];
+  if (e >= total) return false;
+  int c[ND];
+#pragma unroll
+  for (int j = ND - 1; j > 0; --j) { c[j] = e % cs[j]; e /= cs[j]; }
+  c[0] = e;
   bool valid = true;
   int m = 1, off = 0;
 #pragma unroll
-  for (int j = 2; j >= 0; --j) {
+  for (int j = ND - 1; j >= 0; --j) {
     const int val = upper[j] - c[j] * g.d[j];
     out[j] = val;
     if (val < 0 || val > g.out_shape[j] - 1) valid = false;
@@ -60,17 +65,37 @@ __device__ __forceinline__ bool enum_out(const RbGeom& g, const int in[3], int e
   return valid;
 }
 
-__device__ __forceinline__ uint64_t flat_key(int b, const int pos[3], const int shape[3], long long vol) {
-  return static_cast<uint64_t>(b) * vol + (static_cast<uint64_t>(pos[0]) * shape[1] + pos[1]) * shape[2] + pos[2];
+template <int ND>
+__device__ __forceinline__ uint64_t flat_key_nd(int b, const int* pos, const int* shape, long long vol) {
+  uint64_t cell = static_cast<uint64_t>(pos[0]);
+#pragma unroll
+  for (int j = 1; j < ND; ++j) cell = cell * shape[j] + pos[j];
+  return static_cast<uint64_t>(b) * vol + cell;
+}
+__device__ __forceinline__ uint64_t flat_key(int b, const int pos[3], const int shape[3], long long vol) { return flat_key_nd<3>(b, pos, shape, vol); }
+// row i of the index tensor [n][1 + ND]: batch, position (3-D rows are one 16-byte load)
+template <int ND>
+__device__ __forceinline__ int load_row(const int* __restrict__ ind, int i, int* pos) {
+  if constexpr (ND == 3) {
+    const int4 c = reinterpret_cast<const int4*>(ind)[i];
+    pos[0] = c.y; pos[1] = c.z; pos[2] = c.w;
+    return c.x;
+  } else {
+    const int* r = ind + static_cast<int64_t>(i) * (ND + 1);
+#pragma unroll
+    for (int j = 0; j < ND; ++j) pos[j] = r[1 + j];
+    return r[0];
+  }
 }
 
 // subM: table key(position of row i) -> i ; duplicates: highest row wins (geometry.h:275-280).
-__global__ void rb_insert_rows(const int* __restrict__ ind, int n, RbGeom g, uint64_t* __restrict__ table, uint32_t mask) {
+template <int ND>
+__global__ void rb_insert_rows(const int* __restrict__ ind, int n, RbGeomT<ND> g, uint64_t* __restrict__ table, uint32_t mask) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const int4 c = reinterpret_cast<const int4*>(ind)[i];
-  const int pos[3] = {c.y, c.z, c.w};
-  const uint64_t key = flat_key(c.x, pos, g.out_shape, g.out_vol);
+  int pos[ND];
+  const int b = load_row<ND>(ind, i, pos);
+  const uint64_t key = flat_key_nd<ND>(b, pos, g.out_shape, g.out_vol);
   const uint64_t word = slot_pack(key, static_cast<uint32_t>(i));
   uint32_t h = hash_u64(key, mask);
   while (true) {
@@ -83,18 +108,19 @@ __global__ void rb_insert_rows(const int* __restrict__ ind, int n, RbGeom g, uin
 }
 
 // strided / transposed: hash-set of candidate output keys; the inserting thread appends the key to uniq[].
-__global__ void rb_insert_outputs(const int* __restrict__ ind, int n, RbGeom g, uint64_t* __restrict__ table, uint32_t mask,
+template <int ND>
+__global__ void rb_insert_outputs(const int* __restrict__ ind, int n, RbGeomT<ND> g, uint64_t* __restrict__ table, uint32_t mask,
                                   uint64_t* __restrict__ uniq, int* __restrict__ n_uniq) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int e = blockIdx.y;
   bool fresh = false;
   uint64_t key = 0;
   if (i < n) {
-    const int4 c = reinterpret_cast<const int4*>(ind)[i];
-    const int in[3] = {c.y, c.z, c.w};
-    int out[3], off;
-    if (enum_out(g, in, e, out, &off)) {
-      key = flat_key(c.x, out, g.out_shape, g.out_vol);
+    int in[ND];
+    const int b = load_row<ND>(ind, i, in);
+    int out[ND], off;
+    if (enum_out<ND>(g, in, e, out, &off)) {
+      key = flat_key_nd<ND>(b, out, g.out_shape, g.out_vol);
       const uint64_t word = slot_pack(key, static_cast<uint32_t>(kValMask));
       uint32_t h = hash_u64(key, mask);
       while (true) {
@@ -120,7 +146,8 @@ __global__ void rb_insert_outputs(const int* __restrict__ ind, int n, RbGeom g, 
 }
 
 // rank r -> table payload, decoded output coordinates
-__global__ void rb_assign_outputs(const uint64_t* __restrict__ uniq, int n_out, RbGeom g, uint64_t* __restrict__ table,
+template <int ND>
+__global__ void rb_assign_outputs(const uint64_t* __restrict__ uniq, int n_out, RbGeomT<ND> g, uint64_t* __restrict__ table,
                                   uint32_t mask, int* __restrict__ out_ind) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_out) return;
@@ -129,25 +156,30 @@ __global__ void rb_assign_outputs(const uint64_t* __restrict__ uniq, int n_out, 
   while (slot_key(table[h]) != key) h = (h + 1) & mask;
   table[h] = slot_pack(key, static_cast<uint32_t>(r));
   uint64_t rem = key % static_cast<uint64_t>(g.out_vol);
-  int4 o;
-  o.x = static_cast<int>(key / static_cast<uint64_t>(g.out_vol));
-  o.w = static_cast<int>(rem % g.out_shape[2]); rem /= g.out_shape[2];
-  o.z = static_cast<int>(rem % g.out_shape[1]);
-  o.y = static_cast<int>(rem / g.out_shape[1]);
-  reinterpret_cast<int4*>(out_ind)[r] = o;
+  int o[ND + 1];
+  o[0] = static_cast<int>(key / static_cast<uint64_t>(g.out_vol));
+#pragma unroll
+  for (int j = ND - 1; j > 0; --j) { o[1 + j] = static_cast<int>(rem % g.out_shape[j]); rem /= g.out_shape[j]; }
+  o[1] = static_cast<int>(rem);
+  if constexpr (ND == 3) reinterpret_cast<int4*>(out_ind)[r] = make_int4(o[0], o[1], o[2], o[3]);
+  else {
+#pragma unroll
+    for (int j = 0; j <= ND; ++j) out_ind[static_cast<int64_t>(r) * (ND + 1) + j] = o[j];
+  }
 }
 
 // one thread per (input row, candidate): probe and fill the neighbour tables
-__global__ void rb_fill_tables(const int* __restrict__ ind, int n_in, int n_out, RbGeom g, const uint64_t* __restrict__ table,
+template <int ND>
+__global__ void rb_fill_tables(const int* __restrict__ ind, int n_in, int n_out, RbGeomT<ND> g, const uint64_t* __restrict__ table,
                                uint32_t mask, int* __restrict__ tab_in, int* __restrict__ tab_out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int e = blockIdx.y;
   if (i >= n_in) return;
-  const int4 c = reinterpret_cast<const int4*>(ind)[i];
-  const int in[3] = {c.y, c.z, c.w};
-  int out[3], off;
-  if (!enum_out(g, in, e, out, &off)) return;
-  const int o = table_find(table, mask, flat_key(c.x, out, g.out_shape, g.out_vol));
+  int in[ND];
+  const int b = load_row<ND>(ind, i, in);
+  int out[ND], off;
+  if (!enum_out<ND>(g, in, e, out, &off)) return;
+  const int o = table_find(table, mask, flat_key_nd<ND>(b, out, g.out_shape, g.out_vol));
   if (o < 0) return;
   tab_in[static_cast<int64_t>(off) * n_in + i] = o;
   if (tab_out) tab_out[static_cast<int64_t>(off) * n_out + o] = i;
@@ -170,7 +202,7 @@ __global__ void rb_mark_outputs(const int* __restrict__ ind, int n, int batch, R
   if (static_cast<unsigned>(c.x) >= static_cast<unsigned>(batch)) return;   // a batch index outside the bitmap: the row takes no part
   const int in[3] = {c.y, c.z, c.w};
   int out[3], off;
-  if (!enum_out(g, in, e, out, &off)) return;
+  if (!enum_out<3>(g, in, e, out, &off)) return;
   const uint64_t key = flat_key(c.x, out, g.out_shape, g.out_vol);
   const uint32_t bit = 1u << (key & 31);
   uint32_t* wp = bitmap + (key >> 5);
@@ -227,7 +259,7 @@ __global__ void rb_fill_tables_bm(const int* __restrict__ ind, int n_in, int n_o
   if (static_cast<unsigned>(c.x) >= static_cast<unsigned>(batch)) return;
   const int in[3] = {c.y, c.z, c.w};
   int out[3], off;
-  if (!enum_out(g, in, e, out, &off)) return;
+  if (!enum_out<3>(g, in, e, out, &off)) return;
   const uint64_t key = flat_key(c.x, out, g.out_shape, g.out_vol);
   const uint32_t word = bitmap[key >> 5], bit = 1u << (key & 31);
   if (!(word & bit)) return;
@@ -317,10 +349,11 @@ struct RbWs {
   char* aux; size_t aux_bytes;
 };
 
-static int rb_geom(RbGeom* g, const int in_shape[3], const int out_shape[3], const int ksize[3], const int stride[3],
-                   const int padding[3], const int dilation[3], int subm, int transpose) {
+template <int ND>
+static int rb_geom(RbGeomT<ND>* g, const int* in_shape, const int* out_shape, const int* ksize, const int* stride,
+                   const int* padding, const int* dilation, int subm, int transpose) {
   g->kvol = 1; g->emax = 1; g->out_vol = 1; g->transpose = transpose && !subm;
-  for (int j = 0; j < 3; ++j) {
+  for (int j = 0; j < ND; ++j) {
     FV2P_REQUIRE(ksize[j] >= 1 && stride[j] >= 1 && dilation[j] >= 1 && in_shape[j] >= 1 && out_shape[j] >= 1, FV2P_EINVAL,
                  "rulebook: bad geometry in dim %d", j);
     g->in_shape[j] = in_shape[j]; g->out_shape[j] = out_shape[j]; g->k[j] = ksize[j]; g->d[j] = dilation[j];
@@ -365,6 +398,72 @@ static void bm_carve(C& c, long long cells, BmWs* w) {
   if (w) { w->bitmap = bitmap; w->prefix = prefix; w->sums = sums; w->words = words; w->tiles = tiles; w->aux = auxp; w->aux_bytes = aux; }
 }
 
+// The hash-set + sort rulebook of any dimension (the bitmap path above is 3-D only): begin = candidate outputs into the set (submanifold:
+// the rows themselves) and the host-side count, finish = sort, rank, tables.
+template <int ND>
+static int rulebook_begin_hashed(const int* indices, int64_t n_in, const RbGeomT<ND>& g, int subm, int64_t* n_out_host, void* ws, size_t ws_bytes,
+                                 hipStream_t stream) {
+  Carver c(ws, ws_bytes);
+  RbWs w;
+  rb_carve(c, n_in, g.emax, subm, &w);
+  FillJobs fill;
+  fill.add(w.table, sizeof(uint64_t) * w.cap, 0xFFFFFFFFu);
+  if (!subm) fill.add(w.n_uniq, sizeof(int) * 4, 0u);
+  if (int rc = multi_fill(fill, stream)) return rc;
+  const int T = 256;
+  const unsigned nb = static_cast<unsigned>(ceil_div(n_in, T));
+  if (subm) {
+    hipLaunchKernelGGL(rb_insert_rows<ND>, dim3(nb), dim3(T), 0, stream, indices, (int)n_in, g, w.table, w.cap - 1);
+    FV2P_LAUNCH_CHECK();
+    *n_out_host = n_in;
+    return 0;
+  }
+  FV2P_REQUIRE(static_cast<int64_t>(n_in) * g.emax <= kMaxRows, FV2P_ELIMIT, "rulebook: too many candidate outputs");
+  hipLaunchKernelGGL(rb_insert_outputs<ND>, dim3(nb, g.emax), dim3(T), 0, stream, indices, (int)n_in, g, w.table, w.cap - 1, w.uniq,
+                     w.n_uniq);
+  FV2P_LAUNCH_CHECK();
+  int n_out = 0;
+  FV2P_HIP(hipMemcpyAsync(&n_out, w.n_uniq, sizeof(int), hipMemcpyDeviceToHost, stream));
+  // Output row count = a host-side shape (the reference synchronises at the same place, spconv_ops.h:131-139).  Blocking
+  // wait on purpose: polling hipStreamQuery returns ~85 us sooner when nothing else runs, but its spinning contends with
+  // the training thread's launches inside the runtime and the whole step got 15 % slower (measured).
+  FV2P_HIP(hipStreamSynchronize(stream));
+  *n_out_host = n_out;
+  return 0;
+}
+
+template <int ND>
+static int rulebook_finish_hashed(const int* indices, int64_t n_in, int batch, const RbGeomT<ND>& g, int subm, int64_t n_out, int* out_indices,
+                                  int* tab_in, int* tab_out, int* indice_num, FillJobs& fill, void* ws, size_t ws_bytes, hipStream_t stream) {
+  Carver c(ws, ws_bytes);
+  RbWs w;
+  rb_carve(c, n_in, g.emax, subm, &w);
+  const int T = 256;
+  const unsigned nb = static_cast<unsigned>(ceil_div(n_in, T));
+  fill.add(tab_in, sizeof(int) * (size_t)g.kvol * n_in, 0xFFFFFFFFu);
+  if (tab_out && n_out > 0) fill.add(tab_out, sizeof(int) * (size_t)g.kvol * n_out, 0xFFFFFFFFu);
+  if (int rc = multi_fill(fill, stream)) return rc;
+  if (!subm) {
+    FV2P_REQUIRE(out_indices || n_out == 0, FV2P_EINVAL, "rulebook_finish: out_indices is null");
+    if (n_out > 0) {
+      const int bits = bits_for(static_cast<uint64_t>(batch) * g.out_vol);
+      if (int rc = radix_sort_u64(w.uniq, w.tmp, n_out, 0, bits, w.aux, w.aux_bytes, stream)) return rc;
+      hipLaunchKernelGGL(rb_assign_outputs<ND>, dim3((unsigned)ceil_div(n_out, T)), dim3(T), 0, stream, w.uniq, (int)n_out, g, w.table,
+                         w.cap - 1, out_indices);
+    }
+  } else {
+    FV2P_REQUIRE(n_out == n_in, FV2P_EINVAL, "rulebook_finish: subm needs n_out == n_in");
+  }
+  hipLaunchKernelGGL(rb_fill_tables<ND>, dim3(nb, g.emax), dim3(T), 0, stream, indices, (int)n_in, (int)n_out, g, w.table, w.cap - 1,
+                     tab_in, tab_out);
+  if (indice_num) {
+    const unsigned cb = static_cast<unsigned>(ceil_div(n_in, 1024) < 64 ? ceil_div(n_in, 1024) : 64);
+    hipLaunchKernelGGL(rb_count_rows, dim3(cb, g.kvol), dim3(T), 0, stream, tab_in, (int)n_in, indice_num);
+  }
+  FV2P_LAUNCH_CHECK();
+  return 0;
+}
+
 }  // namespace fv2p
 
 using namespace fv2p;
@@ -373,7 +472,7 @@ extern "C" size_t fv2p_rulebook_ws_bytes(int64_t n_in, const int ksize[3], const
                                          int transpose) {
   RbGeom g;
   const int one[3] = {1, 1, 1}, zero[3] = {0, 0, 0};
-  if (rb_geom(&g, one, one, ksize, stride, zero, dilation, subm, transpose)) return 0;
+  if (rb_geom<3>(&g, one, one, ksize, stride, zero, dilation, subm, transpose)) return 0;
   SizerC s;
   rb_carve(s, n_in > 0 ? n_in : 1, g.emax, subm, static_cast<RbWs*>(nullptr));
   return s.bytes();
@@ -408,7 +507,7 @@ extern "C" int fv2p_rulebook_begin(const int* indices, int64_t n_in, int batch, 
                                    int transpose, int64_t* n_out_host, void* ws, size_t ws_bytes, fv2p_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   RbGeom g;
-  if (int rc = rb_geom(&g, in_shape, out_shape, ksize, stride, padding, dilation, subm, transpose)) return rc;
+  if (int rc = rb_geom<3>(&g, in_shape, out_shape, ksize, stride, padding, dilation, subm, transpose)) return rc;
   FV2P_REQUIRE(n_out_host, FV2P_EINVAL, "rulebook_begin: n_out_host is null");
   FV2P_REQUIRE(n_in >= 0 && n_in <= kMaxRows, FV2P_ELIMIT, "rulebook: n_in=%lld outside [0, 2^24)", (long long)n_in);
   FV2P_REQUIRE(batch >= 1 && static_cast<double>(batch) * g.out_vol <= static_cast<double>(kMaxKey), FV2P_ELIMIT,
@@ -439,33 +538,7 @@ extern "C" int fv2p_rulebook_begin(const int* indices, int64_t n_in, int batch, 
     *n_out_host = n_out;
     return 0;
   }
-  Carver c(ws, ws_bytes);
-  RbWs w;
-  rb_carve(c, n_in, g.emax, subm, &w);
-  FillJobs fill;
-  fill.add(w.table, sizeof(uint64_t) * w.cap, 0xFFFFFFFFu);
-  if (!subm) fill.add(w.n_uniq, sizeof(int) * 4, 0u);
-  if (int rc = multi_fill(fill, stream)) return rc;
-  const int T = 256;
-  const unsigned nb = static_cast<unsigned>(ceil_div(n_in, T));
-  if (subm) {
-    hipLaunchKernelGGL(rb_insert_rows, dim3(nb), dim3(T), 0, stream, indices, (int)n_in, g, w.table, w.cap - 1);
-    FV2P_LAUNCH_CHECK();
-    *n_out_host = n_in;
-    return 0;
-  }
-  FV2P_REQUIRE(static_cast<int64_t>(n_in) * g.emax <= kMaxRows, FV2P_ELIMIT, "rulebook: too many candidate outputs");
-  hipLaunchKernelGGL(rb_insert_outputs, dim3(nb, g.emax), dim3(T), 0, stream, indices, (int)n_in, g, w.table, w.cap - 1, w.uniq,
-                     w.n_uniq);
-  FV2P_LAUNCH_CHECK();
-  int n_out = 0;
-  FV2P_HIP(hipMemcpyAsync(&n_out, w.n_uniq, sizeof(int), hipMemcpyDeviceToHost, stream));
-  // Output row count = a host-side shape (the reference synchronises at the same place, spconv_ops.h:131-139).  Blocking
-  // wait on purpose: polling hipStreamQuery returns ~85 us sooner when nothing else runs, but its spinning contends with
-  // the training thread's launches inside the runtime and the whole step got 15 % slower (measured).
-  FV2P_HIP(hipStreamSynchronize(stream));
-  *n_out_host = n_out;
-  return 0;
+  return rulebook_begin_hashed<3>(indices, n_in, g, subm, n_out_host, ws, ws_bytes, stream);
 }
 
 extern "C" int fv2p_rulebook_finish(const int* indices, int64_t n_in, int batch, const int in_shape[3], const int out_shape[3],
@@ -474,7 +547,7 @@ extern "C" int fv2p_rulebook_finish(const int* indices, int64_t n_in, int batch,
                                     void* ws, size_t ws_bytes, fv2p_stream_t stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   RbGeom g;
-  if (int rc = rb_geom(&g, in_shape, out_shape, ksize, stride, padding, dilation, subm, transpose)) return rc;
+  if (int rc = rb_geom<3>(&g, in_shape, out_shape, ksize, stride, padding, dilation, subm, transpose)) return rc;
   FillJobs fill;
   if (indice_num) fill.add(indice_num, sizeof(int) * g.kvol, 0u);
   if (n_in == 0) return multi_fill(fill, stream);
@@ -502,33 +575,55 @@ extern "C" int fv2p_rulebook_finish(const int* indices, int64_t n_in, int batch,
     FV2P_LAUNCH_CHECK();
     return 0;
   }
-  Carver c(ws, ws_bytes);
-  RbWs w;
-  rb_carve(c, n_in, g.emax, subm, &w);
-  const int T = 256;
-  const unsigned nb = static_cast<unsigned>(ceil_div(n_in, T));
-  fill.add(tab_in, sizeof(int) * (size_t)g.kvol * n_in, 0xFFFFFFFFu);
-  if (tab_out && n_out > 0) fill.add(tab_out, sizeof(int) * (size_t)g.kvol * n_out, 0xFFFFFFFFu);
-  if (int rc = multi_fill(fill, stream)) return rc;
-  if (!subm) {
-    FV2P_REQUIRE(out_indices || n_out == 0, FV2P_EINVAL, "rulebook_finish: out_indices is null");
-    if (n_out > 0) {
-      const int bits = bits_for(static_cast<uint64_t>(batch) * g.out_vol);
-      if (int rc = radix_sort_u64(w.uniq, w.tmp, n_out, 0, bits, w.aux, w.aux_bytes, stream)) return rc;
-      hipLaunchKernelGGL(rb_assign_outputs, dim3((unsigned)ceil_div(n_out, T)), dim3(T), 0, stream, w.uniq, (int)n_out, g, w.table,
-                         w.cap - 1, out_indices);
-    }
-  } else {
-    FV2P_REQUIRE(n_out == n_in, FV2P_EINVAL, "rulebook_finish: subm needs n_out == n_in");
-  }
-  hipLaunchKernelGGL(rb_fill_tables, dim3(nb, g.emax), dim3(T), 0, stream, indices, (int)n_in, (int)n_out, g, w.table, w.cap - 1,
-                     tab_in, tab_out);
-  if (indice_num) {
-    const unsigned cb = static_cast<unsigned>(ceil_div(n_in, 1024) < 64 ? ceil_div(n_in, 1024) : 64);
-    hipLaunchKernelGGL(rb_count_rows, dim3(cb, g.kvol), dim3(T), 0, stream, tab_in, (int)n_in, indice_num);
-  }
-  FV2P_LAUNCH_CHECK();
-  return 0;
+  return rulebook_finish_hashed<3>(indices, n_in, batch, g, subm, n_out, out_indices, tab_in, tab_out, indice_num, fill, ws, ws_bytes, stream);
+}
+
+// ---- 4-D rulebooks (SparseConv4d / SubMConv4d; spconv_ops.h:143-258 getIndicePair 4-D instantiations, all.cc:22-33) -------------------
+// The same hash set + sort on rows of five ints (batch, four coordinates); no bitmap path and no transposed form (the reference has no
+// SparseConvTranspose4d, conv.py:233-480).
+extern "C" size_t fv2p_rulebook4d_ws_bytes(int64_t n_in, const int ksize[4], const int stride[4], const int dilation[4], int subm) {
+  RbGeomT<4> g;
+  const int one[4] = {1, 1, 1, 1}, zero[4] = {0, 0, 0, 0};
+  if (rb_geom<4>(&g, one, one, ksize, stride, zero, dilation, subm, 0)) return 0;
+  SizerC s;
+  rb_carve(s, n_in > 0 ? n_in : 1, g.emax, subm, static_cast<RbWs*>(nullptr));
+  return s.bytes();
+}
+
+extern "C" int fv2p_rulebook4d_begin(const int* indices, int64_t n_in, int batch, const int in_shape[4], const int out_shape[4],
+                                     const int ksize[4], const int stride[4], const int padding[4], const int dilation[4], int subm,
+                                     int64_t* n_out_host, void* ws, size_t ws_bytes, fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  RbGeomT<4> g;
+  if (int rc = rb_geom<4>(&g, in_shape, out_shape, ksize, stride, padding, dilation, subm, 0)) return rc;
+  FV2P_REQUIRE(n_out_host, FV2P_EINVAL, "rulebook4d_begin: n_out_host is null");
+  FV2P_REQUIRE(n_in >= 0 && n_in <= kMaxRows, FV2P_ELIMIT, "rulebook4d: n_in=%lld outside [0, 2^24)", (long long)n_in);
+  double cells = static_cast<double>(batch);
+  for (int j = 0; j < 4; ++j) cells *= out_shape[j];
+  FV2P_REQUIRE(batch >= 1 && cells <= static_cast<double>(kMaxKey), FV2P_ELIMIT, "rulebook4d: batch*volume exceeds 2^40");
+  if (subm)
+    for (int j = 0; j < 4; ++j)
+      FV2P_REQUIRE(in_shape[j] == out_shape[j], FV2P_EINVAL, "rulebook4d: subm needs out_shape == in_shape");
+  if (n_in == 0) { *n_out_host = 0; return 0; }
+  FV2P_REQUIRE(indices && ws && ws_bytes >= fv2p_rulebook4d_ws_bytes(n_in, ksize, stride, dilation, subm), FV2P_EWORKSPACE,
+               "rulebook4d: workspace too small");
+  return rulebook_begin_hashed<4>(indices, n_in, g, subm, n_out_host, ws, ws_bytes, stream);
+}
+
+extern "C" int fv2p_rulebook4d_finish(const int* indices, int64_t n_in, int batch, const int in_shape[4], const int out_shape[4],
+                                      const int ksize[4], const int stride[4], const int padding[4], const int dilation[4], int subm,
+                                      int64_t n_out, int* out_indices, int* tab_in, int* tab_out, int* indice_num, void* ws, size_t ws_bytes,
+                                      fv2p_stream_t stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  RbGeomT<4> g;
+  if (int rc = rb_geom<4>(&g, in_shape, out_shape, ksize, stride, padding, dilation, subm, 0)) return rc;
+  FillJobs fill;
+  if (indice_num) fill.add(indice_num, sizeof(int) * g.kvol, 0u);
+  if (n_in == 0) return multi_fill(fill, stream);
+  FV2P_REQUIRE(tab_in, FV2P_EINVAL, "rulebook4d_finish: null tab_in");
+  FV2P_REQUIRE(ws && ws_bytes >= fv2p_rulebook4d_ws_bytes(n_in, ksize, stride, dilation, subm), FV2P_EWORKSPACE,
+               "rulebook4d: workspace too small");
+  return rulebook_finish_hashed<4>(indices, n_in, batch, g, subm, n_out, out_indices, tab_in, tab_out, indice_num, fill, ws, ws_bytes, stream);
 }
 
 // ---- row order for the backward-data conv of a strided layer -------------------------------------------------------------

@@ -251,8 +251,9 @@ def nd_tables(indices, batch_size, in_shape, out_shape, ksize, stride, padding, 
     conv are in ascending (batch, cell) order, the order the reference's GPU path gets from torch::_unique.
     -> (outids [M, 1 + N] i32, tab_in [K, n_in] i32: output row fed by input i through offset k or -1,
         tab_out [K, M] i32: input row feeding output o through offset k or -1).
-    Used for 4-D tensors only (SparseConv4d / SubMConv4d: API surface of the reference, no config builds one); the 2-D / 3-D
-    rulebooks are the hashed HIP build above."""
+    Since round 6 the 4-D rulebooks of device tensors come from the hashed HIP build as well (`_native_tables_4d`,
+    fv2p_rulebook4d_begin / _finish); this formulation stays as the definition the CPU tests pin against the restatement
+    (tests/test_rulebook_nd_oracle.py) and the GPU test holds the kernels to (tests/test_spconv4d_gpu.py), and serves host tensors."""
     dev = indices.device
     nd = len(in_shape)
     n = int(indices.shape[0])
@@ -290,6 +291,29 @@ def nd_tables(indices, batch_size, in_shape, out_shape, ksize, stride, padding, 
     return outids.contiguous(), tab_in.contiguous(), tab_out.contiguous()
 
 
+def _native_tables_4d(indices, batch_size, in_shape, out_shape, ksize, stride, padding, dilation, subm):
+    """The 4-D tables from the hashed builder (fv2p_rulebook4d_begin / _finish): same definition and row order as `nd_tables`."""
+    import ctypes
+    dev = indices.device
+    n_in = int(indices.shape[0])
+    kvol = int(np.prod(ksize))
+    ints = lambda v: [int(x) for x in v]
+    geom = (ints(in_shape), ints(out_shape), ints(ksize), ints(stride), ints(padding), ints(dilation), int(bool(subm)))
+    with _nat.device_guard(dev):
+        lib = _nat.lib()
+        arr = lambda v: (ctypes.c_int * 4)(*v)
+        ws = _nat.workspace(lib.fv2p_rulebook4d_ws_bytes(n_in, arr(geom[2]), arr(geom[3]), arr(geom[5]), geom[6]), dev)
+        n_out_host = ctypes.c_int64(0)
+        _nat.call("fv2p_rulebook4d_begin", indices, n_in, int(batch_size), *geom, ctypes.addressof(n_out_host), ws, ws.numel(), _nat.stream())
+        n_out = int(n_out_host.value)
+        tab_in = alloc_table(kvol, n_in, dev)
+        tab_out = alloc_table(kvol, n_out, dev)
+        outids = indices if subm else torch.empty((n_out, 5), dtype=torch.int32, device=dev)
+        _nat.call("fv2p_rulebook4d_finish", indices, n_in, int(batch_size), *geom, n_out, None if subm else outids, tab_in, tab_out, None,
+                  ws, ws.numel(), _nat.stream())
+    return outids, tab_in, tab_out
+
+
 def _build_rulebook_4d(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, out_padding, subm, transpose):
     if transpose:
         raise NotImplementedError("4-D transposed sparse convolution: the reference has no SparseConvTranspose4d either (conv.py:233-480)")
@@ -297,8 +321,11 @@ def _build_rulebook_4d(indices, batch_size, spatial_shape, ksize, stride, paddin
     if indices.dtype != torch.int32:
         indices = indices.int()
     indices = indices.contiguous()
-    outids, tab_in, tab_out = nd_tables(indices, batch_size, spatial_shape, out_shape, ksize, stride, padding, dilation, subm)
     kvol = int(np.prod(ksize))
+    if indices.is_cuda:
+        outids, tab_in, tab_out = _native_tables_4d(indices, batch_size, spatial_shape, out_shape, ksize, stride, padding, dilation, subm)
+    else:   # host tensors (the CPU tests of the table definition): the torch formulation
+        outids, tab_in, tab_out = nd_tables(indices, batch_size, spatial_shape, out_shape, ksize, stride, padding, dilation, subm)
     rb = Rulebook(outids, indices, tab_in, tab_out, None, spatial_shape, kvol, bool(subm))
     rb.out_spatial_shape = out_shape
     rb.geom = (tuple(ksize), tuple(stride), tuple(padding), tuple(dilation), tuple(out_padding), bool(subm), False)

@@ -104,6 +104,19 @@ int fv2p_rulebook_finish(const int* indices, int64_t n_in, int batch, const int 
                          const int dilation[3], int subm, int transpose, int64_t n_out, int* out_indices,
                          int* tab_in, int* tab_out, int* indice_num, void* ws, size_t ws_bytes,
                          fv2p_stream_t stream);
+/* 4-D rulebooks (SparseConv4d / SubMConv4d: spconv_ops.h:143-258 and the 4-D instantiations of getIndicePair, all.cc:22-33; Python
+ * entry point get_indice_pairs_4d, ops.py:96-150 of the reference).  indices [n_in, 5] = (batch, four coordinates), out_indices
+ * [n_out, 5]; the same two-phase hash set + radix sort as above (output rows in ascending (batch, cell) order), no bitmap path and
+ * no transposed form (the reference has no SparseConvTranspose4d).  Kernel offset index: row-major over ksize[0..3]. */
+size_t fv2p_rulebook4d_ws_bytes(int64_t n_in, const int ksize[4], const int stride[4], const int dilation[4], int subm);
+int fv2p_rulebook4d_begin(const int* indices, int64_t n_in, int batch, const int in_shape[4],
+                          const int out_shape[4], const int ksize[4], const int stride[4], const int padding[4],
+                          const int dilation[4], int subm, int64_t* n_out_host, void* ws, size_t ws_bytes,
+                          fv2p_stream_t stream);
+int fv2p_rulebook4d_finish(const int* indices, int64_t n_in, int batch, const int in_shape[4],
+                           const int out_shape[4], const int ksize[4], const int stride[4], const int padding[4],
+                           const int dilation[4], int subm, int64_t n_out, int* out_indices, int* tab_in,
+                           int* tab_out, int* indice_num, void* ws, size_t ws_bytes, fv2p_stream_t stream);
 /* Rows [n,4] (b,z,y,x) ordered by the residue class of (coordinate + padding) mod stride, stable inside a class:
  * input rows of one class of a strided conv reach the same few kernel offsets.  Strides 1 or 2. */
 size_t fv2p_rulebook_class_perm_ws_bytes(int64_t n);

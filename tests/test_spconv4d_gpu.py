@@ -96,3 +96,18 @@ def test_subm_conv4d_chain_matches_the_gather_mm_restatement(gpu):
     d0, dwa = oracle.indice_conv_backward(f0, wa, d1, ps, ns, subm=True)
     assert rel(c.weight.grad, dwc) < 1e-4 and rel(b.weight.grad, dwb) < 1e-4 and rel(a.weight.grad, dwa) < 1e-4
     assert rel(feats.grad, d0) < 1e-4 and rel(a.bias.grad, d1.sum(0)) < 1e-4
+
+
+@pytest.mark.parametrize("case", CASES4)
+def test_hashed_4d_builder_equals_the_sorted_key_formulation(gpu, case):
+    """fv2p_rulebook4d_begin / _finish (hash set + radix sort, rulebook.hip) against `ops.nd_tables` (torch sort / unique / searchsorted)
+    on the same rows: output rows, both neighbour tables, bit for bit; plus an empty tensor."""
+    batch, shape, n, k, s, p, d, subm = case
+    ind = torch.from_numpy(active(sum(shape) + n + 1, batch, shape, n)).to(gpu)
+    out_shape = shape if subm else ops.get_conv_output_size(shape, k, s, p, d)
+    want = ops.nd_tables(ind, batch, shape, out_shape, k, s, p, d, subm)
+    got = ops._native_tables_4d(ind, batch, shape, out_shape, k, s, p, d, subm)
+    for name, a, b in zip(("outids", "tab_in", "tab_out"), got, want):
+        assert a.dtype == torch.int32 and torch.equal(a, b), name
+    empty = ops._native_tables_4d(ind[:0], batch, shape, out_shape, k, s, p, d, subm)
+    assert empty[0].shape[0] == 0 and empty[1].shape == (int(np.prod(k)), 0)
