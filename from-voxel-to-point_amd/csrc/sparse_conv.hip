@@ -2072,7 +2072,7 @@ static int conv_cu_count() {
 // so that the parity tests hold each kernel against the staged kernel it replaces in one process.
 static int g_thin_on = -1, g_res_on = -1, g_first_on = -1;
 constexpr int kThinDepth = 2;      // offsets in flight per wave of conv_rows_thin (measured: see launch_vec)
-constexpr int kRes16Default = 3;   // conv_rows_res at 16 source channels: forward 16 -> 16, plain and PRE (see launch_vec)
+constexpr int kRes16Default = 1;   // conv_rows_res at 16 source channels: the plain forward 16 -> 16 (see launch_vec)
 static bool path_on(int& flag, const char* e) {   // e: the development preset (FV2P_DEV_ENV), null in the release library
   if (flag < 0) flag = (!e || atoi(e) != 0) ? 1 : 0;
   return flag != 0;
@@ -2246,7 +2246,9 @@ static int launch_vec(const ConvArgs& a, hipStream_t s) {   // 0: launched (or c
     // 16 source channels, FORWARD only: 11.7 against 14.0 us of conv_rows_thin at 35 k rows (whose non-transposed weight fragment is four
     // dword loads per offset and wave); backward data (one 16-byte load) is equal on both, 11.7 / 11.8, and stays on conv_rows_thin.
     // Development switch FV2P_CONV_RES16: bit 0 the plain 16 -> 16 forward, bit 1 its PRE form, bit 2 16 -> 32 as well.  Measured, residual
-    // backbone (batch 4) / plain backbone, ms per step: 0: 3.738 / 1.690, 1: 3.758 / 1.645, 3: 3.703 / -, 7: 3.835 / 1.669 -> 3.
+    // backbone (batch 4) / plain backbone, ms per step: 0: 3.738 / 1.690, 1: 3.758 / 1.645, 3: 3.703 / -, 7: 3.835 / 1.669 (all within the
+    // +- 0.03 of repeated runs).  Inside the FV2P step (rocprofv3, launches that also finalise their BatchNorm sums): plain forward 22.7 us
+    // on either kernel, the PRE form 26.1 here against 24.2 on conv_rows_thin -> 1: the plain forward only.
     static const int res16 = [] { const char* e = FV2P_DEV_ENV("FV2P_CONV_RES16"); return e ? atoi(e) : kRes16Default; }();
     const bool pre = a.pre_mean != nullptr;
     const bool res16_here = !WT && (res16 & 1) && (NB == 1 || (res16 & 4)) && (!pre || (res16 & 2));

@@ -269,6 +269,12 @@ def proposal_layer(batch_dict, nms_config):
     return out
 ref_cpu.roi_head.proposal_layer = proposal_layer
 close = lambda a, b, tol: float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max()))
+# The reference's RoI sampler draws from numpy's and torch's global generators (proposal_target_layer.py:97-147): seeded here, so that every
+# run of this test compares the same 64 RoIs.  (Unseeded, one run in ~8 drew RoIs whose corner loss sits at a tie of its two orientations
+# - torch.min over the flipped box, roi_withiou_head_template.py - where the reference's and the harness's roundings pick different branches:
+# same loss to 1e-5, regression-layer gradients 1e-2 apart, and the bound below failed.)
+np.random.seed(7)
+torch.manual_seed(7)
 with oracle_backend():
     bd = {"batch_size": 2, "points": points, "voxels": voxels, "voxel_num_points": nump, "voxel_coords": coords, "gt_boxes": gt}
     ret, tb, _ = ref_cpu(bd)

@@ -54,11 +54,12 @@ if [ -z "$QUICK" ]; then
   python3 tools/microbench.py sa > $O/${TAG}_microbench_sa.txt 2>&1
 fi
 
-echo "== round 6: what the BatchNorm statistics cost a conv launch, one-launch BatchNorm passes, the completion counter, the sampler's scan"
+echo "== round 6: what the BatchNorm statistics cost a conv launch, one-launch BatchNorm passes, the completion counter, the sampler's walk over its touched buckets"
 python3 tools/fin_time.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_fin_time.txt; cat $O/${TAG}_fin_time.txt
 python3 tools/bn_time.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_bn_time.txt; tail -8 $O/${TAG}_bn_time.txt
 tools/ubench/atomic_rate > $O/${TAG}_atomic_rate.txt 2>&1; tail -17 $O/${TAG}_atomic_rate.txt
-{ for t in 0 1; do echo "== development library, FV2P_FPS_TREE=$t (0: straight-line scan of the touched buckets, the default; 1: find-first-set + binary tree)"; FV2P_LIB_DIR=$PWD/from-voxel-to-point_amd/lib/dev FV2P_FPS_TREE=$t python3 tools/microbench.py fps 2>&1 | grep "^FPS" | head -5; done; } > $O/${TAG}_fps_tree.txt; cat $O/${TAG}_fps_tree.txt
+{ for t in 0 1 2; do echo "== development library, FV2P_FPS_IDX=$t (0: straight-line scan of compile-time slots, rounds 3-5; 1: run-time register indices up to 32 slots, the default; 2: at every slot count)"; FV2P_LIB_DIR=$PWD/from-voxel-to-point_amd/lib/dev FV2P_FPS_IDX=$t python3 tools/microbench.py fps 2>&1 | grep "^FPS" | head -5; done; } > $O/${TAG}_fps_idx.txt; cat $O/${TAG}_fps_idx.txt
+python3 tools/microbench.py fpstrace 2>&1 | grep -v amdgpu.ids > $O/${TAG}_fpstrace.txt; grep -A10 "n = 16384" $O/${TAG}_fpstrace.txt | tail -2
 for f in 1 0; do echo "FV2P_BN_FOLD=$f (1: residual blocks on conv_fin / bn_apply, 0: the round-5 arrangement): $(FV2P_BN_FOLD=$f python3 bench.py --workload backbone --backbone res8x --cpu-clouds 0 --no-roofline 2>/dev/null | grep -o '"ms_per_step": [0-9.]*')"; done > $O/${TAG}_res8x_fold.txt; cat $O/${TAG}_res8x_fold.txt
 
 echo "== counters of the roofline kernel"
