@@ -85,10 +85,11 @@ THIN_ROWS = [15, 16, 17, 4097, 65536, 65537]
 
 
 @pytest.mark.parametrize("n_rows", THIN_ROWS)
-@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 32), (32, 16), (16, 32)])
+@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 32), (32, 16), (16, 32), (4, 16), (5, 16), (4, 32)])
 def test_thin_layer_kernels_on_and_off_vs_oracle(gpu, cin, cout, n_rows):
-    """conv_rows_thin (16 -> 16: forward and backward data) and conv_rows_res (32 source channels, <= 65 536 rows: 32 -> 32 both
-    directions, 32 -> 16 forward, 16 -> 32 backward data) are what the heuristic launches for the backbones' first two levels; with
+    """conv_rows_thin (16 -> 16: backward data, and the forward with a source BatchNorm), conv_rows_res (32 source channels, <= 65 536
+    rows: 32 -> 32 both directions, 32 -> 16 forward, 16 -> 32 backward data; round 6: the plain 16 -> 16 forward) and conv_rows_first
+    (round 6: 4 / 5 point features -> 16 / 32 channels, forward) are what the heuristic launches for the backbones' first two levels; with
     fv2p_sparse_conv_set_paths(0, 0) the staged kernels take the same launches.  Both settings against the oracle's gather -> mm ->
     scatter loop (spconv_ops.h:260-457) at 1e-4, forward and input gradient, at row counts around the 16-row group, the 64-row tile
     and conv_rows_res's 65 536-row gate (65 537 rows: the staged kernel runs in both settings there); and against each other to
