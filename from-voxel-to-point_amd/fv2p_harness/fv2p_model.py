@@ -945,8 +945,12 @@ class FV2PDetector(nn.Module):
         b = len(clouds)
         # The first calls of every dense conv shape run MIOpen's solver search; with a branch of the step on a side stream that search
         # hung the device queue on one fresh box in three (never once the results were cached: DESIGN.md 1).  Whoever asks for a
-        # side-stream arrangement therefore gets the detector's first SAFE_FIRST_STEPS GPU steps on the calling stream only, then the
-        # arrangement asked for (FV2P_SAFE_FIRST=0 switches the guard off).
+        # side-stream arrangement therefore gets the detector's first SAFE_FIRST_STEPS GPU steps with both BRANCHES on the calling stream,
+        # then the arrangement asked for (FV2P_SAFE_FIRST=0 switches the guard off).  The guard covers the dense / point branch streams, whose
+        # kernels are MIOpen's; key-point sampling (this library's kernel only) keeps its own stream from the first step on.  Counted per
+        # detector, not per process: the search is per conv SHAPE, and a second detector may bring new shapes.  bench.py takes the guarded
+        # steps untimed when its warm-up is shorter (`guard_steps`); tests/test_fv2p_step_gpu.py::test_stream_arrangements_give_the_same_step
+        # holds the side-stream arrangement to the single-stream step that the oracle comparison runs.
         on_gpu = clouds[0].is_cuda
         branch_streams = on_gpu and self._gpu_steps >= (0 if os.environ.get("FV2P_SAFE_FIRST") == "0" else SAFE_FIRST_STEPS)
         if on_gpu:
