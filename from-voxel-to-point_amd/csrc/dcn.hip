@@ -93,7 +93,11 @@ __device__ __forceinline__ f32x4 ldx4(const char* base, unsigned off) { return *
 // x NHWC [B,H,W,Cin]; wt_oc [K][Cout][Cin]; y NHWC [npix][Cout].
 // Block = 4 waves, wave = MB*16 pixels x NB*16 output channels (grid.y = column blocks of NB*16).  Product formed transposed:
 // A = weights (rows = output channels, LDS), B = modulated bilinear samples (columns = pixels, registers of the lane that gathered them).
-template <int NB, int MB>
+// TAPIN (round 6): step order (group, 16-channel chunk, tap) instead of (tap, group, chunk).  The nine taps of one chunk gather from the same
+// 4 x 4-pixel neighbourhoods of 64-byte segments back to back (L1 / L2 hits), where the tap-outer order walks a pixel's whole channel
+// range per tap and comes back to it a tap later, after the concurrent tiles of the XCD have pushed it out of the L2.  The tap state of a
+// step (corner offsets, bilinear weights, mask) is then rebuilt every step from offsets fetched two steps ahead: ~40 VALU beside 4 NB MFMAs.
+template <int NB, int MB, bool TAPIN = false>
 __global__ __launch_bounds__(256, 2) void dcn_fwd_k(DcnGeom g, const float* __restrict__ x, const float* __restrict__ wt_oc,
                                                      const float* __restrict__ bias, const float* __restrict__ offset,
                                                      const float* __restrict__ mask, float* __restrict__ y, long long pix_base, int n_sub) {
@@ -186,10 +190,16 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_k(DcnGeom g, const float* __re
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) acc[nb][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // prologue: segment 0 taps, step 0 operands
+  // position of a step: tap k, group dgi, chunk c of the group
+  auto advance = [&](int& k_, int& dg_, int& c_) {
+    if constexpr (TAPIN) { if (++k_ == K) { k_ = 0; if (++c_ == cps) { c_ = 0; ++dg_; } } }
+    else { if (++c_ == cps) { c_ = 0; if (++dg_ == g.dg) { dg_ = 0; ++k_; } } }
+  };
+  // prologue: step 0 taps and operands; the offsets of the next tap state that will be needed
   load_offsets(0, 0);
   set_taps(0);
-  if (segs > 1) load_offsets(g.dg > 1 ? 0 : 1, g.dg > 1 ? 1 : 0);   // segment 1 = (tap, group) after (0, 0)
+  if constexpr (TAPIN) { if (steps > 1) { int k1 = 0, d1 = 0, c1 = 0; advance(k1, d1, c1); load_offsets(k1, d1); } }
+  else { if (segs > 1) load_offsets(g.dg > 1 ? 0 : 1, g.dg > 1 ? 1 : 0); }   // segment 1 = (tap, group) after (0, 0)
   dma(0, 0, lds);
   gather(0);
   f32x4 bs[MB];
@@ -200,14 +210,18 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_k(DcnGeom g, const float* __re
   for (int s = 0; s < steps; ++s) {
     float* cur = lds + (s & 1) * FRAG;
     // position of step s + 1
-    int c1 = c + 1, dg1 = dgi, k1 = k;
-    if (c1 == cps) { c1 = 0; ++dg1; if (dg1 == g.dg) { dg1 = 0; ++k1; } }
+    int c1 = c, dg1 = dgi, k1 = k;
+    advance(k1, dg1, c1);
     const bool more = s + 1 < steps;
     if (more) {
-      if (c1 == 0) set_taps(k1);                    // offsets were fetched at the first step of this segment
+      if (TAPIN || c1 == 0) set_taps(k1);           // its offsets were fetched a step (TAPIN) / a segment ago
       dma(k1, (dg1 * cps + c1) * 16, lds + ((s + 1) & 1) * FRAG);
       gather((dg1 * cps + c1) * 16);
-      if (c1 == 0) {                                // fetch the offsets of the segment after that
+      if constexpr (TAPIN) {                        // fetch the offsets of step s + 2
+        int c2 = c1, dg2 = dg1, k2 = k1;
+        advance(k2, dg2, c2);
+        if (s + 2 < steps) load_offsets(k2, dg2);
+      } else if (c1 == 0) {                         // fetch the offsets of the segment after that
         int dg2 = dg1 + 1, k2 = k1;
         if (dg2 == g.dg) { dg2 = 0; ++k2; }
         if (k2 < K) load_offsets(k2, dg2);
@@ -869,11 +883,24 @@ static int dcn_cu_count() {
   return cus;
 }
 
+// forward step order: -1 by shape, 0 (tap, group, chunk), 1 (group, chunk, tap) - fv2p_dcn_set_forward_order (tests, A/B runs)
+constexpr int kDcnTapInnerDefault = 0;   // forward step order when nobody chose one (measured: see DESIGN 3.6)
+static int g_dcn_fwd_order = -1;
+static bool dcn_forward_tap_inner(const DcnGeom& g) {
+  if (g_dcn_fwd_order >= 0) return g_dcn_fwd_order == 1;
+  static const int dev = [] { const char* e = FV2P_DEV_ENV("FV2P_DCN_FWD_ORDER"); return e ? atoi(e) : -1; }();
+  if (dev >= 0) return dev == 1;
+  return kDcnTapInnerDefault != 0;
+}
+
 template <int NB>
 static void dcn_fwd_launch(const DcnGeom& g, const float* x, const float* wt_oc, const float* bias, const float* offset, const float* mask,
                            float* y, long long npix, int col_blocks, hipStream_t stream) {
   const dim3 grid(static_cast<unsigned>(ceil_div(npix, 64) * col_blocks));   // one dimension: (tile, column block) decoded XCD-major in the kernel
-  hipLaunchKernelGGL((dcn_fwd_k<NB, 1>), grid, dim3(256), 2 * NB * 256 * sizeof(float), stream, g, x, wt_oc, bias, offset, mask, y, 0ll, col_blocks);
+  if (dcn_forward_tap_inner(g))
+    hipLaunchKernelGGL((dcn_fwd_k<NB, 1, true>), grid, dim3(256), 2 * NB * 256 * sizeof(float), stream, g, x, wt_oc, bias, offset, mask, y, 0ll, col_blocks);
+  else
+    hipLaunchKernelGGL((dcn_fwd_k<NB, 1>), grid, dim3(256), 2 * NB * 256 * sizeof(float), stream, g, x, wt_oc, bias, offset, mask, y, 0ll, col_blocks);
 }
 
 // Samples per launch sequence: the kernels address x, the column gradients and the sample lists with 32-bit offsets, so a call is
@@ -895,6 +922,12 @@ static int dcn_chunk_samples(const DcnGeom& g, bool backward) {
     bs = std::min(bs, ((1ll << 31) - 1) / std::max(pix * g.dg * K, 1ll));
   }
   return static_cast<int>(bs);   // 0: one sample alone is above a limit
+}
+
+extern "C" int fv2p_dcn_set_forward_order(int order) {
+  FV2P_REQUIRE(order >= -1 && order <= 1, FV2P_EINVAL, "dcn_set_forward_order: -1 (by shape), 0 (tap outer) or 1 (tap inner)");
+  g_dcn_fwd_order = order;
+  return 0;
 }
 
 extern "C" int fv2p_dcn_set_colg_cap(int64_t bytes) {

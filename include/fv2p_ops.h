@@ -535,6 +535,10 @@ int fv2p_dcn_forward(const float* x_nhwc, const float* wt_oc, const float* bias,
                      const float* mask, int batch, int height, int width, int c_in, int c_out, int h_out,
                      int w_out, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
                      int deformable_group, float* y_nhwc, fv2p_stream_t stream);
+/* Step order of the forward kernel: 0 = (tap, group, 16-channel chunk) - rounds 4 / 5 -, 1 = (group, chunk, tap): the nine taps of a chunk
+ * back to back (the chunk's 64-byte segments stay in L1 / L2 across the taps), -1 = the library's choice.  Results are identical
+ * term by term only within one order (the sum over (tap, channel) terms is taken in step order); both are within 1e-4 of the oracle. */
+int fv2p_dcn_set_forward_order(int order);
 /* Test hook: the cap on a chunk's column gradients in bytes (0 = back to the 1.5 GiB default). */
 int fv2p_dcn_set_colg_cap(int64_t bytes);
 size_t fv2p_dcn_backward_ws_bytes(int batch, int height, int width, int h_out, int w_out, int c_in, int c_out, int kh,

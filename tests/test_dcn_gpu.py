@@ -77,6 +77,39 @@ def test_random_offsets_forward_backward_vs_oracle(gpu, cin, cout, dg, stride, d
     assert rel(m.bias.grad, b.grad) < 1e-4
 
 
+@pytest.mark.parametrize("order", [0, 1], ids=["tap-outer", "tap-inner"])
+@pytest.mark.parametrize("cin,cout,dg,stride,dil,hw", [(32, 48, 2, 1, 1, (11, 13)), (64, 64, 4, 1, 2, (11, 13)), (16, 16, 1, 2, 1, (12, 9)), (256, 256, 4, 1, 1, (20, 18)),
+                                                       (128, 200, 1, 1, 1, (15, 17))])
+def test_forward_step_orders_vs_oracle(gpu, cin, cout, dg, stride, dil, hw, order):
+    """fv2p_dcn_set_forward_order: the forward kernel in (tap, group, chunk) and in (group, chunk, tap) step order, both against the float64
+    oracle at 1e-4 on offsets that leave the image, several groups / chunks per group, stride and dilation, ragged Cout; and against each
+    other to 1e-5 (same terms, another order of the sum)."""
+    import fv2p_native
+    torch.manual_seed(5)
+    B, (H, W) = 2, hw
+    pad = dil
+    Ho, Wo = (H + 2 * pad - (dil * 2 + 1)) // stride + 1, (W + 2 * pad - (dil * 2 + 1)) // stride + 1
+    x = torch.randn(B, cin, H, W)
+    offset = torch.randn(B, dg * 18, Ho, Wo) * 1.5
+    mask = torch.sigmoid(torch.randn(B, dg * 9, Ho, Wo))
+    m = ModulatedDeformConv(cin, cout, 3, stride=stride, padding=pad, dilation=dil, deformable_groups=dg, bias=True).to(gpu)
+    ref = dcn_oracle.modulated_deform_conv(x.double(), offset.double(), mask.double(), m.weight.detach().cpu().double(), m.bias.detach().cpu().double(),
+                                           (stride, stride), (pad, pad), (dil, dil), dg)
+    try:
+        fv2p_native.call("fv2p_dcn_set_forward_order", order)
+        with torch.no_grad():
+            y = m(x.to(gpu), offset.to(gpu), mask.to(gpu))
+        fv2p_native.call("fv2p_dcn_set_forward_order", 1 - order)
+        with torch.no_grad():
+            y_other = m(x.to(gpu), offset.to(gpu), mask.to(gpu))
+    finally:
+        fv2p_native.call("fv2p_dcn_set_forward_order", -1)
+    assert rel(y, ref) < 1e-4
+    assert rel(y, y_other) < 1e-5
+    with pytest.raises(fv2p_native.Fv2pError):
+        fv2p_native.call("fv2p_dcn_set_forward_order", 2)
+
+
 @pytest.mark.parametrize("cin,cout,dg,per_chunk", [(32, 48, 2, 2), (16, 16, 1, 1), (64, 64, 4, 3)])
 def test_backward_in_batch_chunks_vs_oracle(gpu, cin, cout, dg, per_chunk):
     """Both entry points cut a call into chunks of whole samples (32-bit addressing inside the kernels; at most 1.5 GiB of column
