@@ -95,8 +95,11 @@ __device__ __forceinline__ f32x4 ldx4(const char* base, unsigned off) { return *
 // A = weights (rows = output channels, LDS), B = modulated bilinear samples (columns = pixels, registers of the lane that gathered them).
 // TAPIN (round 6): step order (group, 16-channel chunk, tap) instead of (tap, group, chunk).  The nine taps of one chunk gather from the same
 // 4 x 4-pixel neighbourhoods of 64-byte segments back to back (L1 / L2 hits), where the tap-outer order walks a pixel's whole channel
-// range per tap and comes back to it a tap later, after the concurrent tiles of the XCD have pushed it out of the L2.  The tap state of a
-// step (corner offsets, bilinear weights, mask) is then rebuilt every step from offsets fetched two steps ahead: ~40 VALU beside 4 NB MFMAs.
+// range per tap and comes back to it a tap later, after the concurrent tiles of the XCD have pushed it out of the L2.  A step's tap state
+// (corner offsets, bilinear weights, mask) then changes at every step: the K states of the current group are built once per group by the
+// wave's own lanes (lane (n, gq): taps gq, gq + 4, ... of pixel n) into LDS, 32 bytes per (tap, pixel), and a step reads its state back
+// with two 16-byte reads.  (First form: rebuilt at every step from offsets fetched two steps ahead - ~45 VALU in front of every gather:
+// 2 080 against 1 730 us at the MGAF head.)
 template <int NB, int MB, bool TAPIN = false>
 __global__ __launch_bounds__(256, 2) void dcn_fwd_k(DcnGeom g, const float* __restrict__ x, const float* __restrict__ wt_oc,
                                                      const float* __restrict__ bias, const float* __restrict__ offset,
@@ -195,11 +198,46 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_k(DcnGeom g, const float* __re
     if constexpr (TAPIN) { if (++k_ == K) { k_ = 0; if (++c_ == cps) { c_ = 0; ++dg_; } } }
     else { if (++c_ == cps) { c_ = 0; if (++dg_ == g.dg) { dg_ = 0; ++k_; } } }
   };
+  // TAPIN: this wave's tap states of the current group, [K][16 pixels][8]: {offset of corner 0, + column, + row, mask} {four bilinear weights}
+  float* taps = lds + 2 * FRAG + wave * (K * 16 * 8);
+  auto build_group = [&](int dg_) {
+    static_assert(!TAPIN || MB == 1, "tap-inner order: one 16-pixel block per wave");
+    for (int kk = gq; kk < K; kk += 4) {
+      const float* ob = offset + (static_cast<long long>(pb[0]) * g.dg + dg_) * 2 * K * plane + ppos[0];
+      const float oh = ob[static_cast<long long>(2 * kk) * plane], ow = ob[static_cast<long long>(2 * kk + 1) * plane];
+      const float mm = mask[((static_cast<long long>(pb[0]) * g.dg + dg_) * K + kk) * plane + ppos[0]];
+      const int i = kk / g.kw, j = kk % g.kw;
+      Corner4 cn;
+      make_corners(g, live[0], pb[0], static_cast<float>(pho[0] * g.sh - g.ph + i * g.dh) + oh, static_cast<float>(pwo[0] * g.sw - g.pw + j * g.dw) + ow, mm, 0u, cn);
+      float* d = taps + (kk * 16 + n) * 8;
+      *reinterpret_cast<uint4*>(d) = make_uint4(cn.o[0], cn.o[1] - cn.o[0], cn.o[2] - cn.o[0], __float_as_uint(cn.m));
+      *reinterpret_cast<float4*>(d + 4) = make_float4(cn.w[0], cn.w[1], cn.w[2], cn.w[3]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // a wave's LDS operations complete in order: its own reads below see these writes
+  };
+  uint4 ta = make_uint4(0u, 0u, 0u, 0u);   // TAPIN: a step's tap state as it lies in LDS
+  float4 tw = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto fetch_taps = [&](int k_) {
+    const float* d = taps + (k_ * 16 + n) * 8;
+    ta = *reinterpret_cast<const uint4*>(d);
+    tw = *reinterpret_cast<const float4*>(d + 4);
+  };
+  auto expand_taps = [&]() {
+    const unsigned lb = 16u * gq;
+    t[0].o[0] = ta.x + lb; t[0].o[1] = ta.x + ta.y + lb; t[0].o[2] = ta.x + ta.z + lb; t[0].o[3] = ta.x + ta.y + ta.z + lb;
+    t[0].w[0] = tw.x; t[0].w[1] = tw.y; t[0].w[2] = tw.z; t[0].w[3] = tw.w;
+    t[0].m = __uint_as_float(ta.w);
+  };
   // prologue: step 0 taps and operands; the offsets of the next tap state that will be needed
-  load_offsets(0, 0);
-  set_taps(0);
-  if constexpr (TAPIN) { if (steps > 1) { int k1 = 0, d1 = 0, c1 = 0; advance(k1, d1, c1); load_offsets(k1, d1); } }
-  else { if (segs > 1) load_offsets(g.dg > 1 ? 0 : 1, g.dg > 1 ? 1 : 0); }   // segment 1 = (tap, group) after (0, 0)
+  if constexpr (TAPIN) {
+    build_group(0);
+    fetch_taps(0);
+    expand_taps();
+  } else {
+    load_offsets(0, 0);
+    set_taps(0);
+    if (segs > 1) load_offsets(g.dg > 1 ? 0 : 1, g.dg > 1 ? 1 : 0);   // segment 1 = (tap, group) after (0, 0)
+  }
   dma(0, 0, lds);
   gather(0);
   f32x4 bs[MB];
@@ -214,13 +252,14 @@ __global__ __launch_bounds__(256, 2) void dcn_fwd_k(DcnGeom g, const float* __re
     advance(k1, dg1, c1);
     const bool more = s + 1 < steps;
     if (more) {
-      if (TAPIN || c1 == 0) set_taps(k1);           // its offsets were fetched a step (TAPIN) / a segment ago
+      if constexpr (TAPIN) {
+        if (dg1 != dgi) build_group(dg1);           // (the state of step s is in registers already)
+        fetch_taps(k1);                             // (read two steps ahead into a second register set: 2 014 against 1 856 us at the head)
+        expand_taps();
+      } else if (c1 == 0) set_taps(k1);             // its offsets were fetched a segment ago
       dma(k1, (dg1 * cps + c1) * 16, lds + ((s + 1) & 1) * FRAG);
       gather((dg1 * cps + c1) * 16);
-      if constexpr (TAPIN) {                        // fetch the offsets of step s + 2
-        int c2 = c1, dg2 = dg1, k2 = k1;
-        advance(k2, dg2, c2);
-        if (s + 2 < steps) load_offsets(k2, dg2);
+      if constexpr (TAPIN) {
       } else if (c1 == 0) {                         // fetch the offsets of the segment after that
         int dg2 = dg1 + 1, k2 = k1;
         if (dg2 == g.dg) { dg2 = 0; ++k2; }
@@ -897,8 +936,10 @@ template <int NB>
 static void dcn_fwd_launch(const DcnGeom& g, const float* x, const float* wt_oc, const float* bias, const float* offset, const float* mask,
                            float* y, long long npix, int col_blocks, hipStream_t stream) {
   const dim3 grid(static_cast<unsigned>(ceil_div(npix, 64) * col_blocks));   // one dimension: (tile, column block) decoded XCD-major in the kernel
-  if (dcn_forward_tap_inner(g))
-    hipLaunchKernelGGL((dcn_fwd_k<NB, 1, true>), grid, dim3(256), 2 * NB * 256 * sizeof(float), stream, g, x, wt_oc, bias, offset, mask, y, 0ll, col_blocks);
+  const size_t lds_tapin = (2 * NB * 256 + 4 * static_cast<size_t>(g.kh) * g.kw * 16 * 8) * sizeof(float);
+  static const bool big_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&dcn_fwd_k<NB, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) == hipSuccess;
+  if (dcn_forward_tap_inner(g) && big_ok && lds_tapin <= 96 * 1024)
+    hipLaunchKernelGGL((dcn_fwd_k<NB, 1, true>), grid, dim3(256), lds_tapin, stream, g, x, wt_oc, bias, offset, mask, y, 0ll, col_blocks);
   else
     hipLaunchKernelGGL((dcn_fwd_k<NB, 1>), grid, dim3(256), 2 * NB * 256 * sizeof(float), stream, g, x, wt_oc, bias, offset, mask, y, 0ll, col_blocks);
 }
