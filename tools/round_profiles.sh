@@ -62,6 +62,14 @@ tools/ubench/atomic_rate > $O/${TAG}_atomic_rate.txt 2>&1; tail -17 $O/${TAG}_at
 python3 tools/microbench.py fpstrace 2>&1 | grep -v amdgpu.ids > $O/${TAG}_fpstrace.txt; grep -A10 "n = 16384" $O/${TAG}_fpstrace.txt | tail -2
 for f in 1 0; do echo "FV2P_BN_FOLD=$f (1: residual blocks on conv_fin / bn_apply, 0: the round-5 arrangement): $(FV2P_BN_FOLD=$f python3 bench.py --workload backbone --backbone res8x --cpu-clouds 0 --no-roofline 2>/dev/null | grep -o '"ms_per_step": [0-9.]*')"; done > $O/${TAG}_res8x_fold.txt; cat $O/${TAG}_res8x_fold.txt
 
+echo "== the isolated roofline probe inside the bench command, as the kernel trace has it"
+rm -rf $O/prof_probe
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_probe -o s -- python3 bench.py --watchdog 0 --steps 5 --warmup 5 --cpu-clouds 0 --inline-steps 0 --refstyle-steps 0 > $O/prof_probe.log 2>&1
+{ echo "rocprofv3 --kernel-trace --stats -- python3 bench.py --watchdog 0 --steps 5 --warmup 5 --cpu-clouds 0 --inline-steps 0 --refstyle-steps 0 (roofline probe ON)"
+  python3 tools/probe_from_trace.py "$(find $O/prof_probe -name '*kernel_trace.csv' | head -1)"
+  python3 -c "import json,sys; d=json.loads([l for l in open('$O/prof_probe.log') if l.startswith('{\"metric')][-1]); r=d['roofline']; print('bench line of the same run: ms_per_step', d['ms_per_step'], '(under the profiler), roofline.avg_kernel_us', r['avg_kernel_us'], 'roofline.frac', r['frac'], 'in_step_us', r.get('in_step_us'))"; } > $O/${TAG}_roofline_probe_trace.txt 2>&1
+cat $O/${TAG}_roofline_probe_trace.txt; rm -rf $O/prof_probe
+
 echo "== counters of the roofline kernel"
 bash tools/pmc_roofline.sh $TAG > $O/pmc_roofline.log 2>&1; tail -2 $O/pmc_roofline.log
 bash tools/pmc_mfma.sh $TAG > $O/pmc_mfma.log 2>&1; tail -2 $O/pmc_mfma.log
